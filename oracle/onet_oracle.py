@@ -1,0 +1,255 @@
+"""CPU ORACLE for the Onet twin-U-Net hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import this file.  The product path (``onet_amd``) never does:
+it fails loudly when the HIP extension is missing.
+
+What this is
+------------
+A table-driven, functional restatement (PyTorch *CPU* fp32 ops: ``F.conv2d``,
+``F.batch_norm`` ... i.e. the same ATen/oneDNN arithmetic the reference runs on
+CPU) of ``/root/reference/source_code/Onet_vanilla_20240606.py`` ("OV"):
+
+* ``unet_pass``        <- OV:39-58 (DoubleConv), OV:61-72 (Down), OV:75-101 (Up),
+                          OV:104-153 (UNet wiring; no ``outc`` head, returns (x1, y1))
+* ``onet_forward``     <- OV:174-191 (twin pass on X and clip(1-X+bias,0,1), head
+                          einsum, 2-channel softmax)
+* ``log1pexp_quirk``   <- OV:237-251 (the in-place, order-dependent piecewise
+                          function: x <= -37 maps to ln 2)
+* ``jsd`` / ``compute_loss`` <- OV:221-235, OV:253-267
+* ``predict_label``    <- OV:193-202
+
+Pinning
+-------
+The reference ships no tests or golden vectors for this path (SURVEY.md §4,
+§8c: "parity unpinned" by the reference itself).  This oracle is therefore
+pinned against OUTPUTS OF THE REFERENCE ITSELF, produced in the build
+container by ``tests/golden/make_golden.py`` (which imports OV with inert
+stubs for its unused imports) and committed as ``tests/golden/*.npz``;
+``tests/test_oracle_golden.py`` replays them.
+
+Weights are never stored: both sides regenerate them with ``det_state_dict``
+(NumPy PCG64 keyed by (seed, crc32(name)) -- independent of torch's RNG).
+"""
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5        # nn.BatchNorm2d default (OV:48,52)
+BN_MOMENTUM = 0.1    # nn.BatchNorm2d default
+
+ENC = [("inc", None, 64), ("down1", 64, 128), ("down2", 128, 256),
+       ("down3", 256, 512), ("down4", 512, 1024)]
+DEC = [("up1", 1024, 512), ("up2", 512, 256), ("up3", 256, 128), ("up4", 128, 64)]
+
+
+def _dc_prefix(block: str) -> str:
+    """state_dict prefix of the DoubleConv inside a UNet block (OV:111-120)."""
+    if block == "inc":
+        return "inc.double_conv"
+    if block.startswith("down"):
+        return f"{block}.maxpool_conv.1.double_conv"
+    return f"{block}.conv.double_conv"
+
+
+def param_table(in_chns: int = 1):
+    """Ordered (name, shape, kind) for one UNet, in nn.Module registration order.
+
+    kinds: conv | bn_w | bn_b | bn_rm | bn_rv | bn_nbt | convT_w | convT_b.
+    116 entries (SURVEY.md §5 checkpoint row)."""
+    rows = []
+
+    def dc(block, cin, cout):
+        p = _dc_prefix(block)
+        for idx, (ci, co) in ((0, (cin, cout)), (3, (cout, cout))):
+            rows.append((f"{p}.{idx}.weight", (co, ci, 3, 3), "conv"))
+            b = idx + 1
+            rows.append((f"{p}.{b}.weight", (co,), "bn_w"))
+            rows.append((f"{p}.{b}.bias", (co,), "bn_b"))
+            rows.append((f"{p}.{b}.running_mean", (co,), "bn_rm"))
+            rows.append((f"{p}.{b}.running_var", (co,), "bn_rv"))
+            rows.append((f"{p}.{b}.num_batches_tracked", (), "bn_nbt"))
+
+    for name, cin, cout in ENC:
+        dc(name, in_chns if cin is None else cin, cout)
+    for name, cin, cout in DEC:
+        rows.append((f"{name}.up.weight", (cin, cin // 2, 2, 2), "convT_w"))
+        rows.append((f"{name}.up.bias", (cin // 2,), "convT_b"))
+        dc(name, cin, cout)
+    return rows
+
+
+def det_state_dict(in_chns: int = 1, seed: int = 1981, randomize_running: bool = True):
+    """Deterministic UNet state (un-prefixed keys), independent of torch RNG."""
+    sd = OrderedDict()
+    for name, shape, kind in param_table(in_chns):
+        rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
+        if kind == "conv":
+            fan_in = shape[1] * 9
+            v = rng.standard_normal(shape) * np.sqrt(2.0 / fan_in)
+        elif kind == "convT_w":
+            v = rng.standard_normal(shape) * np.sqrt(1.0 / (shape[0] * 4)) * 2.0
+        elif kind == "convT_b":
+            v = 0.1 * rng.standard_normal(shape)
+        elif kind == "bn_w":
+            v = 1.0 + 0.1 * rng.standard_normal(shape)
+        elif kind == "bn_b":
+            v = 0.1 * rng.standard_normal(shape)
+        elif kind == "bn_rm":
+            v = 0.1 * rng.standard_normal(shape) if randomize_running else np.zeros(shape)
+        elif kind == "bn_rv":
+            v = 1.0 + 0.1 * np.abs(rng.standard_normal(shape)) if randomize_running else np.ones(shape)
+        elif kind == "bn_nbt":
+            sd[name] = torch.tensor(0, dtype=torch.long)
+            continue
+        sd[name] = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
+    return sd
+
+
+def onet_state_dict(in_chns=1, seed=1981, bshare=True, randomize_running=True):
+    """The 232-key Onet state_dict: topu.* + dwnu.* (aliases when shared, OV:163-164)."""
+    top = det_state_dict(in_chns, seed, randomize_running)
+    dwn = top if bshare else det_state_dict(in_chns, seed + 1, randomize_running)
+    sd = OrderedDict()
+    for k, v in top.items():
+        sd["topu." + k] = v
+    for k, v in dwn.items():
+        sd["dwnu." + k] = v
+    return sd
+
+
+def det_input(B, C, H, W, seed=7):
+    rng = np.random.Generator(np.random.PCG64([seed, B, C, H, W]))
+    return torch.from_numpy(rng.random((B, C, H, W), dtype=np.float32))
+
+
+# --------------------------------------------------------------------------
+# functional model
+# --------------------------------------------------------------------------
+def _conv_bn_relu(x, st, p, idx, training):
+    """conv3x3(pad 1, no bias) -> BN -> ReLU  (OV:47-49 / OV:51-53)."""
+    z = F.conv2d(x, st[f"{p}.{idx}.weight"], None, 1, 1)
+    b = idx + 1
+    y = F.batch_norm(z, st[f"{p}.{b}.running_mean"], st[f"{p}.{b}.running_var"],
+                     st[f"{p}.{b}.weight"], st[f"{p}.{b}.bias"],
+                     training, BN_MOMENTUM, BN_EPS)
+    if training:
+        st[f"{p}.{b}.num_batches_tracked"] += 1
+    return F.relu(y)
+
+
+def _double_conv(x, st, block, training):
+    p = _dc_prefix(block)
+    return _conv_bn_relu(_conv_bn_relu(x, st, p, 0, training), st, p, 3, training)
+
+
+def upsample_cat(x1, x2, st, block, bilinear=False):
+    """Up.forward up to (and including) the concat: OV:91-100."""
+    if bilinear:
+        u = F.interpolate(x1, scale_factor=2, mode="bilinear", align_corners=True)
+    else:
+        u = F.conv_transpose2d(x1, st[f"{block}.up.weight"], st[f"{block}.up.bias"], stride=2)
+    dy = x2.shape[2] - u.shape[2]
+    dx = x2.shape[3] - u.shape[3]
+    u = F.pad(u, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
+    return torch.cat([x2, u], dim=1)       # skip first, upsampled second (OV:100)
+
+
+def unet_pass(x, st, training=True):
+    """UNet.forward (OV:142-153): returns (x1, y1) = (first-block features, last-block features)."""
+    feats = [_double_conv(x, st, "inc", training)]
+    for name, _, _ in ENC[1:]:
+        feats.append(_double_conv(F.max_pool2d(feats[-1], 2), st, name, training))
+    y = feats[-1]
+    for lvl, (name, _, _) in enumerate(DEC):
+        skip = feats[3 - lvl]
+        y = _double_conv(upsample_cat(y, skip, st, name), st, name, training)
+    return feats[0], y
+
+
+def head(L, Hf):
+    """V = einsum('bpxy,bpxy->bxy', L, H).unsqueeze(1)  (OV:176-177)."""
+    return (L * Hf).sum(dim=1, keepdim=True)
+
+
+def onet_forward(X, top, dwn=None, training=True, bias=0.0):
+    """Onet.forward (OV:174-191).  ``top``/``dwn`` are un-prefixed UNet state
+    dicts of tensors (parameters may require grad); ``dwn is None`` == shared."""
+    dwn = top if dwn is None else dwn
+    Lt, Ht = unet_pass(X, top, training)
+    Vt = head(Lt, Ht)
+    Xd = torch.clip(1 - X + bias, 0, 1)
+    Ld, Hd = unet_pass(Xd, dwn, training)
+    Vd = head(Ld, Hd)
+    S = torch.softmax(torch.cat([Vt, Vd], dim=1), dim=1)     # Softmax2d
+    return Lt, Vt, Ld, Vd, S
+
+
+def log1pexp_quirk(x):
+    """Effective function of Onet.log1pexp (OV:237-251), autograd-equivalent.
+
+    The reference mutates x in place between range tests, so step-1 outputs
+    (exp(x) ~ 0 for x <= -37) are re-captured by step 2 and become
+    log(1+exp(exp(x))) = ln 2.  Piecewise on the ORIGINAL x:
+        x <= -37        : log(1 + exp(exp(x)))     (= ln 2;  d/dx ~ 0.5*exp(x))
+        -37 < x <= 18   : log(1 + exp(x))
+        18 < x < 33.3   : x + exp(-x)
+        otherwise       : x
+    (step-2 outputs never exceed 18 in fp32, so step 3 cannot re-capture them)."""
+    lo = x <= -37.0
+    mid = (x > -37.0) & (x <= 18.0)
+    hi = (x > 18.0) & (x < 33.3)
+    xs = torch.where(mid, x, torch.zeros_like(x))
+    f_lo = torch.log(1 + torch.exp(torch.exp(torch.where(lo, x, torch.full_like(x, -40.0)))))
+    f_mid = torch.log(1 + torch.exp(xs))
+    xh = torch.where(hi, x, torch.full_like(x, 20.0))
+    f_hi = xh + torch.exp(-xh)
+    return torch.where(lo, f_lo, torch.where(mid, f_mid, torch.where(hi, f_hi, x)))
+
+
+def jsd(Li, Si, Sp):
+    """Onet.jensen_shannon_divergence (OV:221-235); the p=64 x p=1 einsum
+    broadcast equals Si * sum_p Li (verified against the reference, §8c)."""
+    sL = Li.sum(dim=1)
+    LS = sL * Si[:, 0]
+    LSp = sL * Sp[:, 0]
+    return -log1pexp_quirk(-LS).mean() - log1pexp_quirk(LSp).mean()
+
+
+def compute_loss(Lt, St, Ld, Sd):
+    """Onet.compute_loss (OV:253-267)."""
+    return -(jsd(Lt, St, Sd) + jsd(Ld, Sd, St)) / 2
+
+
+def predict_label(S):
+    """Onet.predict_label (OV:193-202): argmax over the 2 channels, ties -> 0."""
+    return torch.argmax(S, dim=1)
+
+
+def clone_state(sd, requires_grad=True):
+    """Fresh leaf tensors from a (un-prefixed) UNet state dict."""
+    out = OrderedDict()
+    for k, v in sd.items():
+        t = v.detach().clone()
+        if requires_grad and t.is_floating_point() and "running" not in k:
+            t.requires_grad_(True)
+        out[k] = t
+    return out
+
+
+def train_mode_step(X, top, dwn=None):
+    """fwd + loss + backward; returns (outputs, loss, grads dict)."""
+    Lt, Vt, Ld, Vd, S = onet_forward(X, top, dwn, training=True)
+    loss = compute_loss(Lt, S[:, 0:1], Ld, S[:, 1:2])
+    loss.backward()
+    grads = OrderedDict((k, v.grad) for k, v in top.items() if v.requires_grad)
+    if dwn is not None:
+        for k, v in dwn.items():
+            if v.requires_grad:
+                grads["dwnu." + k] = v.grad
+    return (Lt, Vt, Ld, Vd, S), loss, grads

@@ -1,0 +1,125 @@
+"""Pin the CPU oracle (oracle/onet_oracle.py) to outputs of the REAL reference
+(tests/golden/*.npz, minted by tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import onet_oracle as orc
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+def test_param_table_matches_reference_key_list():
+    g = _load("onet_b2_c1_32.npz")
+    names = [str(n) for n in g["grad_names"]]
+    ours = ["topu." + n for n, _, k in orc.param_table(1) if k in ("conv", "bn_w", "bn_b", "convT_w", "convT_b")]
+    assert names == ours
+    assert len(orc.param_table(1)) == 116
+    assert len(orc.onet_state_dict(1)) == 232
+    n_train = sum(int(np.prod(s)) for _, s, k in orc.param_table(1) if k in ("conv", "bn_w", "bn_b", "convT_w", "convT_b"))
+    assert n_train == 31036416
+
+
+def test_log1pexp_table():
+    g = _load("log1pexp.npz")
+    x = torch.tensor(g["x"], requires_grad=True)
+    y = orc.log1pexp_quirk(x)
+    y.sum().backward()
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(x.grad.numpy(), g["dy"], rtol=1e-6, atol=1e-30)
+    # the quirk itself: x <= -37 -> ln 2
+    assert abs(float(orc.log1pexp_quirk(torch.tensor([-50.0]))[0]) - 0.6931472) < 1e-6
+
+
+def test_loss_extreme_branches():
+    g = _load("loss_extreme.npz")
+    Lt = torch.tensor(g["Lt"], requires_grad=True)
+    Ld = torch.tensor(g["Ld"], requires_grad=True)
+    Vt = torch.tensor(g["Vt"], requires_grad=True)
+    Vd = torch.tensor(g["Vd"], requires_grad=True)
+    S = torch.softmax(torch.cat([Vt, Vd], 1), 1)
+    loss = orc.compute_loss(Lt, S[:, 0:1], Ld, S[:, 1:2])
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    for a, b in ((Lt.grad, g["dLt"]), (Ld.grad, g["dLd"]), (Vt.grad, g["dVt"]), (Vd.grad, g["dVd"])):
+        np.testing.assert_allclose(a.numpy(), b, rtol=2e-5, atol=1e-8)
+
+
+def _run_oracle(meta):
+    B, C, H, W, bshare, train, steps = [int(v) for v in meta]
+    top = orc.clone_state(orc.det_state_dict(C, 1981))
+    dwn = None if bshare else orc.clone_state(orc.det_state_dict(C, 1982))
+    X = orc.det_input(B, C, H, W)
+    return B, C, H, W, bshare, train, steps, top, dwn, X
+
+
+def _sub(a, H):
+    a = a.detach().numpy()
+    return a if H <= 40 else (a[:, :, ::37, :] if a.ndim == 4 else a[:, ::37, :])
+
+
+CASES = ["b2_c1_16", "b2_c1_32", "b2_c3_32", "b2_c1_40", "b3_c1_32", "b2_c1_32_noshare", "b2_c1_256"]
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_train_step_matches_reference(tag):
+    g = _load(f"onet_{tag}.npz")
+    B, C, H, W, bshare, train, steps, top, dwn, X = _run_oracle(g["meta"])
+    (Lt, Vt, Ld, Vd, S), loss, grads = orc.train_mode_step(X, top, dwn)
+    assert abs(float(loss) - g["losses"][0]) <= 2e-6 * abs(g["losses"][0])
+    np.testing.assert_allclose(_sub(Vt, H), g["Vt"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(_sub(Vd, H), g["Vd"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(_sub(S, H), g["S"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(_sub(Lt.sum(1), H), g["Lt_chsum"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_array_equal(_sub(orc.predict_label(S), H).astype(np.uint8), g["label"])
+    names = [str(n) for n in g["grad_names"]]
+    for i, n in enumerate(names):
+        key = n[5:] if n.startswith("topu.") else "dwnu." + n[5:]
+        gr = grads[key].reshape(-1)
+        ref_norm = g["grad_norms"][i]
+        assert abs(float(gr.double().norm()) - ref_norm) <= 2e-4 * ref_norm + 1e-9, n
+        k = min(64, gr.numel())
+        np.testing.assert_allclose(gr[:k].numpy(), g["grad_heads"][i][:k], rtol=2e-3, atol=2e-4 * ref_norm / np.sqrt(gr.numel()) + 1e-9, err_msg=n)
+    # BN running stats: two momentum updates per forward when shared (X then 1-X)
+    rm = torch.cat([v for k, v in top.items() if k.endswith("running_mean")]).numpy()
+    rv = torch.cat([v for k, v in top.items() if k.endswith("running_var")]).numpy()
+    nref = rm.shape[0]
+    np.testing.assert_allclose(rm, g["bn_rm"][:nref], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rv, g["bn_rv"][:nref], rtol=1e-4, atol=1e-5)
+    nbt = [int(v) for k, v in top.items() if k.endswith("num_batches_tracked")]
+    assert nbt == [int(v) for v in g["bn_nbt"][:18]]
+    assert nbt[0] == (2 if bshare else 1)
+
+
+def test_eval_mode_matches_reference():
+    g = _load("onet_b2_c1_32_eval.npz")
+    B, C, H, W, bshare, train, steps, top, dwn, X = _run_oracle(g["meta"])
+    with torch.no_grad():
+        Lt, Vt, Ld, Vd, S = orc.onet_forward(X, top, dwn, training=False)
+        loss = orc.compute_loss(Lt, S[:, 0:1], Ld, S[:, 1:2])
+    assert abs(float(loss) - g["losses"][0]) <= 2e-6 * abs(g["losses"][0])
+    np.testing.assert_allclose(Vt.numpy(), g["Vt"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(S.numpy(), g["S"], rtol=1e-4, atol=1e-5)
+
+
+def test_adam_loss_sequence_matches_reference():
+    """Harness contract: zero_grad -> fwd -> loss -> bwd -> Adam, 4 steps."""
+    g = _load("onet_b2_c1_32_adam4.npz")
+    B, C, H, W, bshare, train, steps, top, dwn, X = _run_oracle(g["meta"])
+    params = [v for v in top.values() if v.requires_grad]
+    opt = torch.optim.Adam(params, lr=5e-6, betas=(0.9, 0.999), eps=1e-8)
+    losses = []
+    for _ in range(steps):
+        opt.zero_grad()
+        _, loss, _ = orc.train_mode_step(X, top, dwn)
+        losses.append(float(loss))
+        opt.step()
+    np.testing.assert_allclose(losses, g["losses"], rtol=5e-6)
+    nbt = [int(v) for k, v in top.items() if k.endswith("num_batches_tracked")]
+    assert nbt[0] == 2 * steps
