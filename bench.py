@@ -1,0 +1,140 @@
+"""Headline benchmark: training images/s of the Onet twin 256x256 pass on N MI355X
+(BASELINE.json metric), one process per GPU, weak scaling (per-GPU batch fixed).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = zero_grad + twin forward + JSD loss + backward + [RCCL all-reduce] + fused Adam on one
+synthetic K-distributed clutter batch already resident in HBM (TS:209-219 order).  Prints ONE JSON
+line on rank 0 with `roofline` (dominant MFMA kernel, HIP-event timed inside the timed region)
+and, at N=1, `cpu_baseline` (the CPU oracle timed on the host cores on a bounded sample)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
+
+
+def cpu_baseline(X_cpu, seconds_budget):
+    """fwd + loss + bwd + Adam of the CPU oracle (PyTorch CPU fp32, same ATen kernels the reference
+    runs) on a B=2 sample of the SAME synthetic batch."""
+    from oracle import onet_oracle as orc
+    xs = X_cpu[:2].contiguous()
+    top = orc.clone_state(orc.det_state_dict(xs.shape[1], 1981, randomize_running=False))
+    params = [v for v in top.values() if v.requires_grad]
+    opt = torch.optim.Adam(params, lr=5e-6, betas=(0.9, 0.999), eps=1e-8)
+    times = []
+    t_all = time.time()
+    for i in range(6):
+        t0 = time.time()
+        opt.zero_grad()
+        orc.train_mode_step(xs, top)
+        opt.step()
+        dt = time.time() - t0
+        if i > 0:
+            times.append(dt)
+        if time.time() - t_all > seconds_budget and len(times) >= 1:
+            break
+    mean = sum(times) / len(times)
+    return {"value": round(xs.shape[0] / mean, 4), "unit": "images/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": "B=2 of the same 1x%dx%d K-clutter batch, %d timed full training steps "
+            "(fwd+loss+bwd+Adam), 1 warm-up" % (xs.shape[2], xs.shape[3], len(times))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU (weak scaling)")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--chans", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam instead of the fused flat Adam")
+    args = ap.parse_args()
+
+    from onet_amd import Onet, _lib, ops
+    from onet_amd import data as odata
+    from onet_amd.trainer import FlatAdam, init_distributed, train_step
+    _lib.load()                      # fail loudly without the HIP library
+
+    rank, world, local = init_distributed("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    torch.manual_seed(1981)
+    onet = Onet(in_chns=args.chans, binit=True, bshare=True).to(dev)
+    opt = (torch.optim.Adam(onet.parameters(), lr=5e-6, betas=(0.9, 0.999), eps=1e-8) if args.torch_adam
+           else FlatAdam(onet, lr=5e-6, world_size=world))
+    if not args.torch_adam:
+        opt.broadcast_params(0)
+    onet.train()
+
+    X_cpu = torch.from_numpy(odata.make_clutter_batch(args.batch, args.size, args.size, seed=1981 + rank,
+                                                      channels=args.chans))
+    X = X_cpu.to(dev)                # inputs resident in HBM before the timed region
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        train_step(onet, opt, X)
+    barrier()
+    ops.PROFILE = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = train_step(onet, opt, X)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_val = float(loss.item())
+
+    if rank == 0:
+        kern = {}
+        for kind, recs in prof.items():
+            ms = sum(e0.elapsed_time(e1) for _, e0, e1 in recs)
+            fl = sum(f for f, _, _ in recs)
+            kern[kind] = {"launches": len(recs), "ms_total": round(ms, 3), "avg_ms": round(ms / len(recs), 4),
+                          "tflops": round(fl / (ms * 1e-3) / 1e12, 2)}
+        dom = max(kern, key=lambda k: kern[k]["ms_total"])
+        roofline = {"kernel": dom, "bound": "mfma", "achieved": kern[dom]["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "traffic": None, "launches_timed": kern[dom]["launches"], "avg_launch_ms": kern[dom]["avg_ms"],
+                    "all": kern}
+        imgs = args.batch * world * args.steps
+        out = {"metric": "training images/sec (twin 256x256 pass)", "value": round(imgs / elapsed, 3),
+               "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "configs[1]: batch=%d/GPU %dx%dx%d synthetic K-clutter, fp32, twin U-Net "
+                                      "fwd+JSD loss+bwd+Adam" % (args.batch, args.chans, args.size, args.size),
+                          "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                          "optimizer": "torch.optim.Adam" if args.torch_adam else "fused flat Adam (HIP)"},
+               "loss": loss_val, "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(X_cpu, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,192 @@
+/*
+ * onet_hip.h -- C ABI of libonet_hip.so: hand-written gfx950 (MI355X, CDNA4) HIP
+ * kernels for the Onet twin-U-Net hot path.
+ *
+ * This is the drop-in boundary.  The reference (joeyee/Onet) is pure Python on
+ * PyTorch; its "FFI" for this path is the set of ATen operators its model file
+ * calls.  Every entry point below cites the reference call site it replaces
+ * ("OV" = source_code/Onet_vanilla_20240606.py).  The Python mirror of the
+ * reference's nn.Module surface (onet_amd/modules.py) binds these with ctypes.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ *    stated; no torch types, no C++ types, no exceptions across the boundary;
+ *  - return 0 on success, a negative ONET_E* code otherwise; the message is
+ *    available from onet_last_error() (thread-local);
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); every
+ *    call only enqueues work -- no allocation, no host sync (graph-capturable);
+ *  - tensors are fp32 NCHW.  Activations carry an explicit BATCH STRIDE in
+ *    elements (`*_bs`): image b, channel c, pixel p lives at
+ *        base + b*bs + c*H*W + p
+ *    so a tensor may be a channel-slice of a wider concat buffer (OV:100 writes
+ *    skip and upsampled halves side by side; we never copy for it);
+ *  - "packed" weights are produced by onet_conv_pack_* once per optimizer step.
+ */
+#ifndef ONET_HIP_H
+#define ONET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ONET_OK 0
+#define ONET_EINVAL (-1)   /* bad argument / unsupported shape */
+#define ONET_EHIP (-2)     /* HIP runtime error (launch failure, ...) */
+
+const char* onet_last_error(void);
+int onet_abi_version(void);            /* bumps when a signature changes */
+int onet_device_info(int* cu_count, int* lds_bytes, int* wave_size, char* arch, int arch_len);
+
+/* ---- weight packing --------------------------------------------------- */
+/* nn.Conv2d weight [Cout][Cin][3][3] (OV:47,51) ->
+ *   wp_fwd   [Cin ][9][Cout]            (fwd  implicit-GEMM A operand)
+ *   wp_dgrad [Cout][9][Cin ] taps flipped (dgrad = conv of dZ with W^T rot180)
+ * either output may be NULL. */
+int onet_conv3x3_pack_weights(const float* w, float* wp_fwd, float* wp_dgrad,
+                              int Cout, int Cin, void* stream);
+/* nn.ConvTranspose2d weight [Cin][Cout][2][2] (OV:86) ->
+ *   wp_fwd   [Cin][4*Cout]   column m = (dy*2+dx)*Cout + co   (1x1 conv to 4*Cout "sub-pixel" channels)
+ *   wp_dgrad [4*Cout][Cin]   row    k = (dy*2+dx)*Cout + co */
+int onet_convT2x2_pack_weights(const float* w, float* wp_fwd, float* wp_dgrad,
+                               int Cin, int Cout, void* stream);
+
+/* ---- K1: 3x3 / 1x1 convolution, fp32 MFMA implicit GEMM ----------------- */
+/* z[b][co][y][x] = sum_{ci,ky,kx} wp[ci][ky*ks+kx][co] * x[b][ci][y+ky-p][x+kx-p]
+ * ks in {1,3}, p = ks/2, zero padding, stride 1, no bias (OV:47,51 via F.conv2d).
+ * dgrad is the same call with wp_dgrad and Cin/Cout swapped.
+ * bn_part (nullable): per-block partial sums for BatchNorm statistics,
+ *   layout [nparts][Cout][2] floats (sum, sum of squares), nparts from
+ *   onet_conv_fwd_nparts(); consumed by onet_bn_finalize. */
+int onet_conv_fwd(const float* x, int64_t x_bs, const float* wp, float* z, int64_t z_bs,
+                  float* bn_part, int B, int Cin, int Cout, int H, int W, int ks, void* stream);
+int onet_conv_fwd_nparts(int B, int Cout, int H, int W);
+
+/* wgrad: dw[co][ci][ky][kx] (+)= sum_{b,y,x} dz[b][co][y][x] * x[b][ci][y+ky-p][x+kx-p]
+ * (autograd of F.conv2d wrt weight; reference: implicit via loss.backward(), TS:217).
+ * Two launches: split-K partial slabs into `ws`, then a deterministic slab
+ * reduction.  ws must hold onet_conv_wgrad_ws_bytes() bytes.
+ * out_layout 0: dw is [Cout][Cin][ks][ks] (nn.Conv2d);
+ * out_layout 1: dw is nn.ConvTranspose2d [Cx][Cdz/4][2][2] where the dz operand has
+ *               4*Ct sub-pixel channels (q*Ct+co) and x operand is the convT input. */
+int onet_conv_wgrad(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs, float* dw,
+                    void* ws, int64_t ws_bytes, int B, int Cin, int Cout, int H, int W, int ks,
+                    int out_layout, int accumulate, void* stream);
+int64_t onet_conv_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W, int ks);
+
+/* ---- K2/K3: BatchNorm2d (+ReLU) ---------------------------------------- */
+/* partial per-channel (sum, sumsq) of z over B*HW: part [nparts][C][2].  (standalone
+ * statistics pass; the conv epilogue can emit the same partials instead) */
+int onet_bn_stats_partial(const float* z, int64_t z_bs, float* part, int nparts,
+                          int B, int C, int HW, void* stream);
+/* train-mode finalize (OV:48,52 -> F.batch_norm(training=True)):
+ *   mean = S/N, var = SS/N - mean^2 (accumulated in fp64), invstd = rsqrt(var+eps)
+ *   scale = gamma*invstd, shift = beta - mean*scale
+ *   running_mean = (1-m)*running_mean + m*mean
+ *   running_var  = (1-m)*running_var  + m*var*N/(N-1)     (unbiased, verified SURVEY §8c)
+ * save = [4][C]: mean, invstd, scale, shift.  running_* may be NULL. */
+int onet_bn_finalize(const float* part, int nparts, int64_t count, const float* gamma,
+                     const float* beta, float* running_mean, float* running_var,
+                     float momentum, float eps, float* save, int C, void* stream);
+/* eval-mode coefficients from running stats: same `save` layout. */
+int onet_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                        const float* running_var, float eps, float* save, int C, void* stream);
+/* a = max(0, z*scale + shift)   (BN + nn.ReLU, OV:48-49) */
+int onet_bn_relu_apply(const float* z, int64_t z_bs, float* a, int64_t a_bs, const float* save,
+                       int B, int C, int HW, void* stream);
+/* backward of BN(train)+ReLU.  dy = da * (z*scale+shift > 0);
+ * pass 1: part2 [nparts][C][2] = (sum dy, sum dy*xhat);
+ * finalize: dgamma (+)= sum dy*xhat, dbeta (+)= sum dy, coef [2][C] = (sum dy / N, sum dy*xhat / N);
+ * pass 2: dz = scale * (dy - c1 - xhat*c2)     [train]   or  dz = scale*dy [eval: coef NULL] */
+int onet_bn_relu_bwd_reduce(const float* da, int64_t da_bs, const float* z, int64_t z_bs,
+                            const float* save, float* part2, int nparts, int B, int C, int HW,
+                            void* stream);
+int onet_bn_bwd_finalize(const float* part2, int nparts, int64_t count, float* dgamma, float* dbeta,
+                         float* coef, int accumulate, int C, void* stream);
+int onet_bn_relu_bwd_apply(const float* da, int64_t da_bs, const float* z, int64_t z_bs,
+                           const float* save, const float* coef, float* dz, int64_t dz_bs,
+                           int B, int C, int HW, void* stream);
+
+/* ---- K4: MaxPool2d(2) (OV:67) ------------------------------------------- */
+int onet_maxpool2_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs,
+                      int B, int C, int H, int W, void* stream);
+/* dx = route dy to the first maximum of each 2x2 window (recomputed from x); rows/cols
+ * beyond 2*floor(H/2) get 0.  accumulate: dx += instead of dx =. */
+int onet_maxpool2_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs,
+                      float* dx, int64_t dx_bs, int B, int C, int H, int W, int accumulate,
+                      void* stream);
+
+/* ---- K5/K6: ConvTranspose2d(k=2,s=2) pixel shuffle + pad + concat (OV:86-100) ---- */
+/* sub [B][4*C][h][w] (1x1-conv output, channel q*C+co, q=dy*2+dx) + bias ->
+ * y[b][co][pt+2y+dy][pl+2x+dx]; the rest of the Ho x Wo plane is zero-filled (F.pad). */
+int onet_pixel_shuffle2_bias(const float* sub, const float* bias, float* y, int64_t y_bs,
+                             int B, int C, int h, int w, int Ho, int Wo, int pt, int pl, void* stream);
+/* inverse gather for backward: sub[b][q*C+co][y][x] = dy[b][co][pt+2y+dy][pl+2x+dx];
+ * dy planes are Ho x Wo; dbias (nullable) (+)= sum over b,y,x,q. */
+int onet_space_to_depth2(const float* dy, int64_t dy_bs, float* sub, float* dbias, int accumulate,
+                         int B, int C, int h, int w, int Ho, int Wo, int pt, int pl, void* stream);
+/* strided batch copy of a [B][n] block (torch.cat first half, OV:100) */
+int onet_copy_strided(const float* src, int64_t src_bs, float* dst, int64_t dst_bs,
+                      int B, int64_t n, void* stream);
+
+/* ---- K5': bilinear x2, align_corners=True (OV:83) ------------------------- */
+int onet_bilinear2x_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs, int B, int C,
+                        int h, int w, int Ho, int Wo, int pt, int pl, void* stream);
+/* dx must be zero-initialised (scatter-add of <= 9 contributions per element) */
+int onet_bilinear2x_bwd(const float* dy, int64_t dy_bs, float* dx, int64_t dx_bs, int B, int C,
+                        int h, int w, int Ho, int Wo, int pt, int pl, void* stream);
+
+/* ---- K7: Xd = clip(1 - X + bias, 0, 1) (OV:180) ---------------------------- */
+int onet_complement_clip(const float* x, float* y, float bias, int64_t n, void* stream);
+
+/* ---- K8/K9: head einsum + 2-way softmax (OV:176-189) ----------------------- */
+/* Vt = sum_c Lt*Ht, Vd = sum_c Ld*Hd, S = softmax([Vt,Vd]) -> S [B][2][HW] */
+int onet_head_softmax_fwd(const float* Lt, int64_t Lt_bs, const float* Ht, int64_t Ht_bs,
+                          const float* Ld, int64_t Ld_bs, const float* Hd, int64_t Hd_bs,
+                          float* Vt, float* Vd, float* S, int B, int C, int HW, void* stream);
+/* given dVt,dVd,dS (each nullable) and S: total dV, then dL = dV*H, dH = dV*L per branch */
+int onet_head_softmax_bwd(const float* dVt, const float* dVd, const float* dS, const float* S,
+                          const float* Lt, int64_t Lt_bs, const float* Ht, int64_t Ht_bs,
+                          const float* Ld, int64_t Ld_bs, const float* Hd, int64_t Hd_bs,
+                          float* dLt, float* dHt, float* dLd, float* dHd,
+                          int B, int C, int HW, void* stream);
+
+/* ---- K10: JSD loss with the reference's log1pexp quirk (OV:221-267) ---------- */
+/* One jsd term, Onet.jensen_shannon_divergence(Li, Si, Sprime) (OV:221-235):
+ *   jsd = -mean_{b,p} f(-Si*sL) - mean_{b,p} f(Sp*sL),   sL = sum_c L[c]   (the p=64 x p=1 einsum
+ *   broadcast of OV:231-232), f = the effective log1pexp of OV:237-251 (x <= -37 -> ln 2).
+ * Si/Sp: [B][HW] with batch stride (slices of S).  sums [B*HW] saves sL for backward;
+ * part: >= onet_jsd_nparts() doubles of scratch; jsd: 1 float.
+ * compute_loss (OV:253-267) = -(jsd(Lt,St,Sd) + jsd(Ld,Sd,St)) / 2 is composed by the caller. */
+int onet_jsd_fwd(const float* L, int64_t L_bs, const float* Si, int64_t Si_bs,
+                 const float* Sp, int64_t Sp_bs, float* sums, double* part, float* jsd,
+                 int B, int C, int HW, void* stream);
+int onet_jsd_nparts(void);
+/* gL [B][HW]: d jsd / dL (identical for every channel -- caller broadcasts); dSi,dSp [B][HW].
+ * gscale: device pointer to the upstream gradient of the jsd scalar (1 float). */
+int onet_jsd_bwd(const float* gscale, const float* sums, const float* Si, int64_t Si_bs,
+                 const float* Sp, int64_t Sp_bs, float* gL, float* dSi, float* dSp,
+                 int B, int HW, void* stream);
+/* elementwise quirk function, mutates x in place like OV:237-251; bwd: out = g * f'(x_original) */
+int onet_log1pexp_inplace(float* x, int64_t n, void* stream);
+int onet_log1pexp_bwd(const float* x, const float* g, float* out, int64_t n, void* stream);
+
+/* ---- K11: argmax over the 2 classes, ties -> 0 (OV:201) ---------------------- */
+int onet_argmax2(const float* S, int64_t* Y, int B, int HW, void* stream);
+
+/* ---- "next" row f-1: fused Adam over a flat buffer (TS:181-182) ---------------- */
+/* torch.optim.Adam semantics (no amsgrad, L2 weight_decay): step is 1-based. */
+int onet_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+/* ---- misc -------------------------------------------------------------------- */
+int onet_fill(float* p, float value, int64_t n, void* stream);
+/* y (+)= a*x, used for gradient accumulation of skip tensors */
+int onet_axpy(const float* x, int64_t x_bs, float* y, int64_t y_bs, float a, int B, int64_t n,
+              int accumulate, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ONET_HIP_H */

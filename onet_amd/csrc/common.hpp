@@ -1,0 +1,50 @@
+// Shared helpers for the gfx950 kernels of libonet_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/onet_hip.h"
+
+namespace onet {
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define ONET_REQUIRE(cond, ...)                    \
+    do {                                           \
+        if (!(cond)) {                             \
+            onet::set_error(__VA_ARGS__);          \
+            return ONET_EINVAL;                    \
+        }                                          \
+    } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// wave64 reductions via DPP/shuffles
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-wide sum of NV values for 256-thread blocks; result valid in thread 0
+template <typename T, int NV>
+__device__ __forceinline__ void block_sum_256(T (&v)[NV], T* smem /* >= 4*NV */) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) smem[wid * NV + i] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = smem[i] + smem[NV + i] + smem[2 * NV + i] + smem[3 * NV + i];
+    }
+}
+
+}  // namespace onet

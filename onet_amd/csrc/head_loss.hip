@@ -1,0 +1,247 @@
+// K8 head einsum('bpxy,bpxy->bxy') (OV:176,182), K9 cat + Softmax2d over 2 channels (OV:185-189),
+// K10 Jensen-Shannon MI loss with the reference's order-dependent log1pexp (OV:221-267),
+// K11 argmax over the 2 classes (OV:201).  HBM-bound: one thread per pixel, lanes along H*W
+// (coalesced), channel loop in registers; deterministic two-stage fp64 reduction for the loss.
+#include <algorithm>
+#include "common.hpp"
+
+using namespace onet;
+
+// Effective function of Onet.log1pexp (OV:237-251) on the ORIGINAL x:
+//   x <= -37 : log(1 + exp(exp(x)))  (= ln 2: step-1 outputs are re-captured by step 2)
+//   x <=  18 : log(1 + exp(x))       (literally, not log1p: underflows to 0 below ~-16.6 like torch)
+//   x < 33.3 : x + exp(-x)
+//   else     : x
+__device__ __forceinline__ float f_quirk(float x) {
+    if (x <= -37.f) return logf(1.f + expf(expf(x)));
+    if (x <= 18.f) return logf(1.f + expf(x));
+    if (x < 33.3f) return x + expf(-x);
+    return x;
+}
+// autograd derivative of the composed reference ops
+__device__ __forceinline__ float df_quirk(float x) {
+    if (x <= -37.f) {
+        const float e = expf(x), ee = expf(e);
+        return ee / (1.f + ee) * e;
+    }
+    if (x <= 18.f) {
+        const float e = expf(x);
+        return e / (1.f + e);
+    }
+    if (x < 33.3f) return 1.f - expf(-x);
+    return 1.f;
+}
+
+__global__ void log1pexp_kernel(float* x, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        x[i] = f_quirk(x[i]);
+}
+
+__global__ __launch_bounds__(256) void head_softmax_fwd_kernel(const float* __restrict__ Lt, int64_t Lt_bs,
+                                                               const float* __restrict__ Ht, int64_t Ht_bs,
+                                                               const float* __restrict__ Ld, int64_t Ld_bs,
+                                                               const float* __restrict__ Hd, int64_t Hd_bs,
+                                                               float* __restrict__ Vt, float* __restrict__ Vd,
+                                                               float* __restrict__ S, int B, int C, int HW) {
+    const int64_t n = (int64_t)B * HW;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / HW);
+        const int p = (int)(i % HW);
+        const float* lt = Lt + b * Lt_bs + p;
+        const float* ht = Ht + b * Ht_bs + p;
+        const float* ld = Ld + b * Ld_bs + p;
+        const float* hd = Hd + b * Hd_bs + p;
+        float vt = 0.f, vd = 0.f;
+        for (int c = 0; c < C; ++c) {
+            vt = fmaf(lt[(int64_t)c * HW], ht[(int64_t)c * HW], vt);
+            vd = fmaf(ld[(int64_t)c * HW], hd[(int64_t)c * HW], vd);
+        }
+        Vt[i] = vt;
+        Vd[i] = vd;
+        const float m = fmaxf(vt, vd);
+        const float et = expf(vt - m), ed = expf(vd - m);
+        const float inv = 1.f / (et + ed);
+        S[((int64_t)b * 2 + 0) * HW + p] = et * inv;
+        S[((int64_t)b * 2 + 1) * HW + p] = ed * inv;
+    }
+}
+
+__global__ __launch_bounds__(256) void head_softmax_bwd_kernel(
+    const float* __restrict__ dVt, const float* __restrict__ dVd, const float* __restrict__ dS,
+    const float* __restrict__ S, const float* __restrict__ Lt, int64_t Lt_bs, const float* __restrict__ Ht,
+    int64_t Ht_bs, const float* __restrict__ Ld, int64_t Ld_bs, const float* __restrict__ Hd, int64_t Hd_bs,
+    float* __restrict__ dLt, float* __restrict__ dHt, float* __restrict__ dLd, float* __restrict__ dHd, int B, int C,
+    int HW) {
+    const int64_t n = (int64_t)B * HW;
+    const int64_t CHW = (int64_t)C * HW;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / HW);
+        const int p = (int)(i % HW);
+        float gt = dVt ? dVt[i] : 0.f, gd = dVd ? dVd[i] : 0.f;
+        if (dS) {
+            const float st = S[((int64_t)b * 2 + 0) * HW + p], sd = S[((int64_t)b * 2 + 1) * HW + p];
+            const float a = dS[((int64_t)b * 2 + 0) * HW + p], d = dS[((int64_t)b * 2 + 1) * HW + p];
+            const float dot = a * st + d * sd;
+            gt += st * (a - dot);
+            gd += sd * (d - dot);
+        }
+        const float* lt = Lt + b * Lt_bs + p;
+        const float* ht = Ht + b * Ht_bs + p;
+        const float* ld = Ld + b * Ld_bs + p;
+        const float* hd = Hd + b * Hd_bs + p;
+        float* olt = dLt + b * CHW + p;
+        float* oht = dHt + b * CHW + p;
+        float* old_ = dLd + b * CHW + p;
+        float* ohd = dHd + b * CHW + p;
+        for (int c = 0; c < C; ++c) {
+            const int64_t o = (int64_t)c * HW;
+            olt[o] = gt * ht[o];
+            oht[o] = gt * lt[o];
+            old_[o] = gd * hd[o];
+            ohd[o] = gd * ld[o];
+        }
+    }
+}
+
+constexpr int JSD_BLOCKS = 2048;
+
+// one jsd term (OV:221-235):  jsd = -mean f(-Si*sL) - mean f(Sp*sL),  sL = sum_c L[c]
+__global__ __launch_bounds__(256) void jsd_fwd_kernel(const float* __restrict__ L, int64_t L_bs,
+                                                      const float* __restrict__ Si, int64_t Si_bs,
+                                                      const float* __restrict__ Sp, int64_t Sp_bs,
+                                                      float* __restrict__ sums, double* __restrict__ part, int B,
+                                                      int C, int HW) {
+    __shared__ double red[4];
+    const int64_t n = (int64_t)B * HW;
+    double acc[1] = {0.0};
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / HW);
+        const int p = (int)(i % HW);
+        const float* l = L + b * L_bs + p;
+        float sl = 0.f;
+        for (int c = 0; c < C; ++c) sl += l[(int64_t)c * HW];
+        sums[i] = sl;
+        const float si = Si[b * Si_bs + p], sp = Sp[b * Sp_bs + p];
+        acc[0] += (double)(f_quirk(-(sl * si)) + f_quirk(sl * sp));
+    }
+    block_sum_256<double, 1>(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc[0];
+}
+
+__global__ __launch_bounds__(256) void jsd_final_kernel(const double* __restrict__ part, int nparts, double scale,
+                                                        float* __restrict__ out) {
+    __shared__ double red[4];
+    double acc[1] = {0.0};
+    for (int i = threadIdx.x; i < nparts; i += 256) acc[0] += part[i];
+    block_sum_256<double, 1>(acc, red);
+    if (threadIdx.x == 0) out[0] = (float)(acc[0] * scale);
+}
+
+// gL = dJ/dL (same for every channel), dSi, dSp; g = upstream gradient of the jsd scalar
+__global__ __launch_bounds__(256) void jsd_bwd_kernel(const float* __restrict__ gscale,
+                                                      const float* __restrict__ sums,
+                                                      const float* __restrict__ Si, int64_t Si_bs,
+                                                      const float* __restrict__ Sp, int64_t Sp_bs,
+                                                      float* __restrict__ gL, float* __restrict__ dSi,
+                                                      float* __restrict__ dSp, int B, int HW) {
+    const int64_t n = (int64_t)B * HW;
+    const float g = -gscale[0] * (float)(1.0 / (double)n);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / HW);
+        const int p = (int)(i % HW);
+        const float sl = sums[i];
+        const float si = Si[b * Si_bs + p], sp = Sp[b * Sp_bs + p];
+        const float d1 = df_quirk(-(sl * si));
+        const float d2 = df_quirk(sl * sp);
+        gL[i] = g * (-si * d1 + sp * d2);
+        dSi[i] = g * (-sl * d1);
+        dSp[i] = g * (sl * d2);
+    }
+}
+
+__global__ void log1pexp_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ o,
+                                    int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        o[i] = g[i] * df_quirk(x[i]);
+}
+
+__global__ void argmax2_kernel(const float* __restrict__ S, int64_t* __restrict__ Y, int B, int HW) {
+    const int64_t n = (int64_t)B * HW;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / HW);
+        const int p = (int)(i % HW);
+        Y[i] = S[((int64_t)b * 2 + 1) * HW + p] > S[((int64_t)b * 2 + 0) * HW + p] ? 1 : 0;   // ties -> 0
+    }
+}
+
+static inline unsigned grid_px(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    if (b > 8192) b = 8192;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+
+extern "C" {
+
+int onet_head_softmax_fwd(const float* Lt, int64_t Lt_bs, const float* Ht, int64_t Ht_bs, const float* Ld,
+                          int64_t Ld_bs, const float* Hd, int64_t Hd_bs, float* Vt, float* Vd, float* S, int B,
+                          int C, int HW, void* stream) {
+    ONET_REQUIRE(Lt && Ht && Ld && Hd && Vt && Vd && S && B > 0 && C > 0 && HW > 0, "head_softmax_fwd: bad args");
+    hipLaunchKernelGGL(head_softmax_fwd_kernel, dim3(grid_px((int64_t)B * HW)), dim3(256), 0, as_stream(stream), Lt,
+                       Lt_bs, Ht, Ht_bs, Ld, Ld_bs, Hd, Hd_bs, Vt, Vd, S, B, C, HW);
+    return check_launch("head_softmax_fwd_kernel");
+}
+
+int onet_head_softmax_bwd(const float* dVt, const float* dVd, const float* dS, const float* S, const float* Lt,
+                          int64_t Lt_bs, const float* Ht, int64_t Ht_bs, const float* Ld, int64_t Ld_bs,
+                          const float* Hd, int64_t Hd_bs, float* dLt, float* dHt, float* dLd, float* dHd, int B,
+                          int C, int HW, void* stream) {
+    ONET_REQUIRE(S && Lt && Ht && Ld && Hd && dLt && dHt && dLd && dHd && B > 0 && C > 0 && HW > 0,
+                 "head_softmax_bwd: bad args");
+    hipLaunchKernelGGL(head_softmax_bwd_kernel, dim3(grid_px((int64_t)B * HW)), dim3(256), 0, as_stream(stream), dVt,
+                       dVd, dS, S, Lt, Lt_bs, Ht, Ht_bs, Ld, Ld_bs, Hd, Hd_bs, dLt, dHt, dLd, dHd, B, C, HW);
+    return check_launch("head_softmax_bwd_kernel");
+}
+
+int onet_jsd_nparts(void) { return JSD_BLOCKS; }
+
+int onet_jsd_fwd(const float* L, int64_t L_bs, const float* Si, int64_t Si_bs, const float* Sp, int64_t Sp_bs,
+                 float* sums, double* part, float* jsd, int B, int C, int HW, void* stream) {
+    ONET_REQUIRE(L && Si && Sp && sums && part && jsd && B > 0 && C > 0 && HW > 0, "jsd_fwd: bad args");
+    const int64_t n = (int64_t)B * HW;
+    int blocks = (int)std::min<int64_t>((n + 255) / 256, JSD_BLOCKS);
+    hipLaunchKernelGGL(jsd_fwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), L, L_bs, Si, Si_bs, Sp, Sp_bs,
+                       sums, part, B, C, HW);
+    int rc = check_launch("jsd_fwd_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(jsd_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), (const double*)part, blocks,
+                       -1.0 / (double)n, jsd);
+    return check_launch("jsd_final_kernel");
+}
+
+int onet_jsd_bwd(const float* gscale, const float* sums, const float* Si, int64_t Si_bs, const float* Sp,
+                 int64_t Sp_bs, float* gL, float* dSi, float* dSp, int B, int HW, void* stream) {
+    ONET_REQUIRE(gscale && sums && Si && Sp && gL && dSi && dSp && B > 0 && HW > 0, "jsd_bwd: bad args");
+    hipLaunchKernelGGL(jsd_bwd_kernel, dim3(grid_px((int64_t)B * HW)), dim3(256), 0, as_stream(stream), gscale, sums,
+                       Si, Si_bs, Sp, Sp_bs, gL, dSi, dSp, B, HW);
+    return check_launch("jsd_bwd_kernel");
+}
+
+int onet_log1pexp_bwd(const float* x, const float* g, float* out, int64_t n, void* stream) {
+    ONET_REQUIRE(x && g && out && n > 0, "log1pexp_bwd: bad args");
+    hipLaunchKernelGGL(log1pexp_bwd_kernel, dim3(grid_px(n)), dim3(256), 0, as_stream(stream), x, g, out, n);
+    return check_launch("log1pexp_bwd_kernel");
+}
+
+int onet_log1pexp_inplace(float* x, int64_t n, void* stream) {
+    ONET_REQUIRE(x && n > 0, "log1pexp: bad args");
+    hipLaunchKernelGGL(log1pexp_kernel, dim3(grid_px(n)), dim3(256), 0, as_stream(stream), x, n);
+    return check_launch("log1pexp_kernel");
+}
+
+int onet_argmax2(const float* S, int64_t* Y, int B, int HW, void* stream) {
+    ONET_REQUIRE(S && Y && B > 0 && HW > 0, "argmax2: bad args");
+    hipLaunchKernelGGL(argmax2_kernel, dim3(grid_px((int64_t)B * HW)), dim3(256), 0, as_stream(stream), S, Y, B, HW);
+    return check_launch("argmax2_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,335 @@
+// K4 MaxPool2d(2) (OV:67), K5/K6 ConvTranspose2d pixel shuffle + F.pad + cat placement (OV:86-100),
+// K5' bilinear x2 align_corners=True (OV:83), K7 clip(1-X+bias) (OV:180), plus fill/axpy/copy.
+// All HBM-bound streaming kernels: lanes run along W (coalesced), grid-stride, no LDS.
+#include "common.hpp"
+
+using namespace onet;
+
+static inline unsigned grid_for(int64_t n, int per_block = 256) {
+    int64_t b = (n + per_block - 1) / per_block;
+    if (b > 16384) b = 16384;   // grid-stride beyond this
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+// ---------------------------------------------------------------- maxpool
+__global__ void maxpool2_fwd_kernel(const float* __restrict__ x, int64_t x_bs, float* __restrict__ y,
+                                    int64_t y_bs, int B, int C, int H, int W, int Ho, int Wo) {
+    const int64_t n = (int64_t)B * C * Ho * Wo;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % Wo);
+        int64_t r = i / Wo;
+        const int oy = (int)(r % Ho);
+        r /= Ho;
+        const int c = (int)(r % C), b = (int)(r / C);
+        const float* p = x + (int64_t)b * x_bs + (int64_t)c * H * W + (int64_t)(2 * oy) * W + 2 * ox;
+        const float2 t = *reinterpret_cast<const float2*>(p);          // 2*ox even, W even or odd: see note
+        const float2 u = *reinterpret_cast<const float2*>(p + W);
+        y[(int64_t)b * y_bs + (int64_t)c * Ho * Wo + (int64_t)oy * Wo + ox] = fmaxf(fmaxf(t.x, t.y), fmaxf(u.x, u.y));
+    }
+}
+
+// scalar variant for odd W or unaligned strides (float2 loads need 8-B alignment)
+__global__ void maxpool2_fwd_kernel_s(const float* __restrict__ x, int64_t x_bs, float* __restrict__ y,
+                                      int64_t y_bs, int B, int C, int H, int W, int Ho, int Wo) {
+    const int64_t n = (int64_t)B * C * Ho * Wo;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % Wo);
+        int64_t r = i / Wo;
+        const int oy = (int)(r % Ho);
+        r /= Ho;
+        const int c = (int)(r % C), b = (int)(r / C);
+        const float* p = x + (int64_t)b * x_bs + (int64_t)c * H * W + (int64_t)(2 * oy) * W + 2 * ox;
+        y[(int64_t)b * y_bs + (int64_t)c * Ho * Wo + (int64_t)oy * Wo + ox] =
+            fmaxf(fmaxf(p[0], p[1]), fmaxf(p[W], p[W + 1]));
+    }
+}
+
+// one thread per INPUT pixel: dx = dy of its window if it is the window's first maximum, else 0
+__global__ void maxpool2_bwd_kernel(const float* __restrict__ x, int64_t x_bs, const float* __restrict__ dy,
+                                    int64_t dy_bs, float* __restrict__ dx, int64_t dx_bs, int B, int C, int H,
+                                    int W, int Ho, int Wo, int accumulate) {
+    const int64_t n = (int64_t)B * C * H * W;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ix = (int)(i % W);
+        int64_t r = i / W;
+        const int iy = (int)(r % H);
+        r /= H;
+        const int c = (int)(r % C), b = (int)(r / C);
+        const int oy = iy >> 1, ox = ix >> 1;
+        float g = 0.f;
+        if (oy < Ho && ox < Wo) {
+            const float* p = x + (int64_t)b * x_bs + (int64_t)c * H * W + (int64_t)(2 * oy) * W + 2 * ox;
+            const float v0 = p[0], v1 = p[1], v2 = p[W], v3 = p[W + 1];
+            // first maximum in scan order (dy-major), like ATen's max_pool2d
+            int am = 0;
+            float m = v0;
+            if (v1 > m) { m = v1; am = 1; }
+            if (v2 > m) { m = v2; am = 2; }
+            if (v3 > m) { m = v3; am = 3; }
+            const int me = ((iy & 1) << 1) | (ix & 1);
+            if (me == am) g = dy[(int64_t)b * dy_bs + (int64_t)c * Ho * Wo + (int64_t)oy * Wo + ox];
+        }
+        float* o = dx + (int64_t)b * dx_bs + (int64_t)c * H * W + (int64_t)iy * W + ix;
+        *o = accumulate ? *o + g : g;
+    }
+}
+
+// ---------------------------------------------------------------- convT pixel shuffle / space-to-depth
+__global__ void pixel_shuffle2_bias_kernel(const float* __restrict__ sub, const float* __restrict__ bias,
+                                           float* __restrict__ y, int64_t y_bs, int B, int C, int h, int w,
+                                           int Ho, int Wo, int pt, int pl) {
+    const int64_t n = (int64_t)B * C * Ho * Wo;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % Wo);
+        int64_t r = i / Wo;
+        const int oy = (int)(r % Ho);
+        r /= Ho;
+        const int co = (int)(r % C), b = (int)(r / C);
+        const int uy = oy - pt, ux = ox - pl;
+        float v = 0.f;   // F.pad border
+        if (uy >= 0 && uy < 2 * h && ux >= 0 && ux < 2 * w) {
+            const int q = ((uy & 1) << 1) | (ux & 1);
+            v = sub[(((int64_t)b * 4 * C + (int64_t)q * C + co) * h + (uy >> 1)) * w + (ux >> 1)] +
+                (bias ? bias[co] : 0.f);
+        }
+        y[(int64_t)b * y_bs + (int64_t)co * Ho * Wo + (int64_t)oy * Wo + ox] = v;
+    }
+}
+
+__global__ void space_to_depth2_kernel(const float* __restrict__ dy, int64_t dy_bs, float* __restrict__ sub,
+                                       int B, int C, int h, int w, int Ho, int Wo, int pt, int pl) {
+    const int64_t n = (int64_t)B * 4 * C * h * w;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % w);
+        int64_t r = i / w;
+        const int y = (int)(r % h);
+        r /= h;
+        const int k = (int)(r % (4 * C)), b = (int)(r / (4 * C));
+        const int q = k / C, co = k % C;
+        sub[i] = dy[(int64_t)b * dy_bs + (int64_t)co * Ho * Wo + (int64_t)(pt + 2 * y + (q >> 1)) * Wo + pl + 2 * x + (q & 1)];
+    }
+}
+
+// dbias[co] (+)= sum over b and the un-padded 2h x 2w window of dy; one block per channel
+__global__ __launch_bounds__(256) void convT_dbias_kernel(const float* __restrict__ dy, int64_t dy_bs,
+                                                          float* __restrict__ dbias, int accumulate, int B, int C,
+                                                          int h2, int w2, int Ho, int Wo, int pt, int pl) {
+    __shared__ double red[4];
+    const int co = blockIdx.x;
+    double v[1] = {0.0};
+    const int64_t n = (int64_t)B * h2 * w2;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const int x = (int)(i % w2);
+        const int64_t r = i / w2;
+        const int y = (int)(r % h2), b = (int)(r / h2);
+        v[0] += (double)dy[(int64_t)b * dy_bs + (int64_t)co * Ho * Wo + (int64_t)(pt + y) * Wo + pl + x];
+    }
+    block_sum_256<double, 1>(v, red);
+    if (threadIdx.x == 0) dbias[co] = accumulate ? dbias[co] + (float)v[0] : (float)v[0];
+}
+
+__global__ void copy_strided_kernel(const float* __restrict__ src, int64_t src_bs, float* __restrict__ dst,
+                                    int64_t dst_bs, int B, int64_t n4) {
+    const int64_t tot = (int64_t)B * n4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / n4);
+        const int64_t j = i % n4;
+        reinterpret_cast<float4*>(dst + (int64_t)b * dst_bs)[j] = reinterpret_cast<const float4*>(src + (int64_t)b * src_bs)[j];
+    }
+}
+
+__global__ void copy_strided_kernel_s(const float* __restrict__ src, int64_t src_bs, float* __restrict__ dst,
+                                      int64_t dst_bs, int B, int64_t n) {
+    const int64_t tot = (int64_t)B * n;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / n);
+        const int64_t j = i % n;
+        dst[(int64_t)b * dst_bs + j] = src[(int64_t)b * src_bs + j];
+    }
+}
+
+// ---------------------------------------------------------------- bilinear x2 (align_corners=True)
+__device__ __forceinline__ void bil_src(int o, int in, int out, int& i0, int& i1, float& l1) {
+    // ATen area_pixel_compute_source_index(align_corners=True): src = o * (in-1)/(out-1)
+    const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    const float s = scale * (float)o;
+    i0 = (int)s;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+}
+
+__global__ void bilinear2x_fwd_kernel(const float* __restrict__ x, int64_t x_bs, float* __restrict__ y,
+                                      int64_t y_bs, int B, int C, int h, int w, int Ho, int Wo, int pt, int pl) {
+    const int64_t n = (int64_t)B * C * Ho * Wo;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % Wo);
+        int64_t r = i / Wo;
+        const int oy = (int)(r % Ho);
+        r /= Ho;
+        const int c = (int)(r % C), b = (int)(r / C);
+        const int uy = oy - pt, ux = ox - pl;
+        float v = 0.f;
+        if (uy >= 0 && uy < 2 * h && ux >= 0 && ux < 2 * w) {
+            int y0, y1, x0, x1;
+            float ly, lx;
+            bil_src(uy, h, 2 * h, y0, y1, ly);
+            bil_src(ux, w, 2 * w, x0, x1, lx);
+            const float* p = x + (int64_t)b * x_bs + (int64_t)c * h * w;
+            const float hy = 1.f - ly, hx = 1.f - lx;
+            v = hy * (hx * p[y0 * w + x0] + lx * p[y0 * w + x1]) + ly * (hx * p[y1 * w + x0] + lx * p[y1 * w + x1]);
+        }
+        y[(int64_t)b * y_bs + (int64_t)c * Ho * Wo + (int64_t)oy * Wo + ox] = v;
+    }
+}
+
+// scatter-add into a zero-initialised dx (float atomics; <= 9 contributions per element)
+__global__ void bilinear2x_bwd_kernel(const float* __restrict__ dy, int64_t dy_bs, float* __restrict__ dx,
+                                      int64_t dx_bs, int B, int C, int h, int w, int Ho, int Wo, int pt, int pl) {
+    const int64_t n = (int64_t)B * C * 4 * h * w;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ux = (int)(i % (2 * w));
+        int64_t r = i / (2 * w);
+        const int uy = (int)(r % (2 * h));
+        r /= (2 * h);
+        const int c = (int)(r % C), b = (int)(r / C);
+        const float g = dy[(int64_t)b * dy_bs + (int64_t)c * Ho * Wo + (int64_t)(uy + pt) * Wo + ux + pl];
+        int y0, y1, x0, x1;
+        float ly, lx;
+        bil_src(uy, h, 2 * h, y0, y1, ly);
+        bil_src(ux, w, 2 * w, x0, x1, lx);
+        float* p = dx + (int64_t)b * dx_bs + (int64_t)c * h * w;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        atomicAdd(p + y0 * w + x0, hy * hx * g);
+        atomicAdd(p + y0 * w + x1, hy * lx * g);
+        atomicAdd(p + y1 * w + x0, ly * hx * g);
+        atomicAdd(p + y1 * w + x1, ly * lx * g);
+    }
+}
+
+// ---------------------------------------------------------------- elementwise
+__global__ void complement_clip_kernel(const float* __restrict__ x, float* __restrict__ y, float bias, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = fminf(fmaxf(1.f - x[i] + bias, 0.f), 1.f);
+}
+
+__global__ void fill_kernel(float* __restrict__ p, float v, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+__global__ void axpy_kernel(const float* __restrict__ x, int64_t x_bs, float* __restrict__ y, int64_t y_bs, float a,
+                            int B, int64_t n, int accumulate) {
+    const int64_t tot = (int64_t)B * n;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / n);
+        const int64_t j = i % n;
+        float* o = y + (int64_t)b * y_bs + j;
+        const float v = a * x[(int64_t)b * x_bs + j];
+        *o = accumulate ? *o + v : v;
+    }
+}
+
+extern "C" {
+
+int onet_maxpool2_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs, int B, int C, int H, int W,
+                      void* stream) {
+    ONET_REQUIRE(x && y && B > 0 && C > 0 && H >= 2 && W >= 2, "maxpool2_fwd: bad args (H=%d W=%d)", H, W);
+    const int Ho = H / 2, Wo = W / 2;
+    const int64_t n = (int64_t)B * C * Ho * Wo;
+    const bool aligned = ((W & 1) == 0) && ((x_bs & 1) == 0) && ((reinterpret_cast<uintptr_t>(x) & 7) == 0);
+    if (aligned)
+        hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), x, x_bs, y, y_bs, B, C, H, W, Ho, Wo);
+    else
+        hipLaunchKernelGGL(maxpool2_fwd_kernel_s, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), x, x_bs, y, y_bs, B, C, H, W, Ho, Wo);
+    return check_launch("maxpool2_fwd_kernel");
+}
+
+int onet_maxpool2_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, float* dx, int64_t dx_bs,
+                      int B, int C, int H, int W, int accumulate, void* stream) {
+    ONET_REQUIRE(x && dy && dx && B > 0 && C > 0 && H >= 2 && W >= 2, "maxpool2_bwd: bad args");
+    const int64_t n = (int64_t)B * C * H * W;
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), x, x_bs, dy, dy_bs, dx,
+                       dx_bs, B, C, H, W, H / 2, W / 2, accumulate);
+    return check_launch("maxpool2_bwd_kernel");
+}
+
+int onet_pixel_shuffle2_bias(const float* sub, const float* bias, float* y, int64_t y_bs, int B, int C, int h,
+                             int w, int Ho, int Wo, int pt, int pl, void* stream) {
+    ONET_REQUIRE(sub && y && B > 0 && C > 0 && h > 0 && w > 0, "pixel_shuffle2: bad args");
+    ONET_REQUIRE(pt >= 0 && pl >= 0 && pt + 2 * h <= Ho && pl + 2 * w <= Wo, "pixel_shuffle2: window outside plane");
+    const int64_t n = (int64_t)B * C * Ho * Wo;
+    hipLaunchKernelGGL(pixel_shuffle2_bias_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), sub, bias, y,
+                       y_bs, B, C, h, w, Ho, Wo, pt, pl);
+    return check_launch("pixel_shuffle2_bias_kernel");
+}
+
+int onet_copy_strided(const float* src, int64_t src_bs, float* dst, int64_t dst_bs, int B, int64_t n,
+                      void* stream) {
+    ONET_REQUIRE(src && dst && B > 0 && n > 0, "copy_strided: bad args");
+    const bool v4 = ((n & 3) == 0) && ((src_bs & 3) == 0) && ((dst_bs & 3) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+    if (v4)
+        hipLaunchKernelGGL(copy_strided_kernel, dim3(grid_for((int64_t)B * n / 4)), dim3(256), 0, as_stream(stream), src, src_bs, dst, dst_bs, B, n / 4);
+    else
+        hipLaunchKernelGGL(copy_strided_kernel_s, dim3(grid_for((int64_t)B * n)), dim3(256), 0, as_stream(stream), src, src_bs, dst, dst_bs, B, n);
+    return check_launch("copy_strided_kernel");
+}
+
+int onet_bilinear2x_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs, int B, int C, int h, int w, int Ho,
+                        int Wo, int pt, int pl, void* stream) {
+    ONET_REQUIRE(x && y && B > 0 && C > 0 && h > 0 && w > 0, "bilinear2x_fwd: bad args");
+    ONET_REQUIRE(pt >= 0 && pl >= 0 && pt + 2 * h <= Ho && pl + 2 * w <= Wo, "bilinear2x_fwd: window outside plane");
+    const int64_t n = (int64_t)B * C * Ho * Wo;
+    hipLaunchKernelGGL(bilinear2x_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), x, x_bs, y, y_bs, B, C,
+                       h, w, Ho, Wo, pt, pl);
+    return check_launch("bilinear2x_fwd_kernel");
+}
+
+int onet_complement_clip(const float* x, float* y, float bias, int64_t n, void* stream) {
+    ONET_REQUIRE(x && y && n > 0, "complement_clip: bad args");
+    hipLaunchKernelGGL(complement_clip_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), x, y, bias, n);
+    return check_launch("complement_clip_kernel");
+}
+
+int onet_fill(float* p, float value, int64_t n, void* stream) {
+    ONET_REQUIRE(p && n > 0, "fill: bad args");
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), p, value, n);
+    return check_launch("fill_kernel");
+}
+
+int onet_axpy(const float* x, int64_t x_bs, float* y, int64_t y_bs, float a, int B, int64_t n, int accumulate,
+              void* stream) {
+    ONET_REQUIRE(x && y && B > 0 && n > 0, "axpy: bad args");
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for((int64_t)B * n)), dim3(256), 0, as_stream(stream), x, x_bs, y, y_bs, a, B, n, accumulate);
+    return check_launch("axpy_kernel");
+}
+
+}  // extern "C"
+
+extern "C" int onet_space_to_depth2(const float* dy, int64_t dy_bs, float* sub, float* dbias, int accumulate, int B,
+                                    int C, int h, int w, int Ho, int Wo, int pt, int pl, void* stream) {
+    ONET_REQUIRE(dy && sub && B > 0 && C > 0 && h > 0 && w > 0, "space_to_depth2: bad args");
+    ONET_REQUIRE(pt >= 0 && pl >= 0 && pt + 2 * h <= Ho && pl + 2 * w <= Wo, "space_to_depth2: window outside plane");
+    const int64_t n = (int64_t)B * 4 * C * h * w;
+    hipLaunchKernelGGL(space_to_depth2_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), dy, dy_bs, sub, B, C, h,
+                       w, Ho, Wo, pt, pl);
+    int rc = check_launch("space_to_depth2_kernel");
+    if (rc) return rc;
+    if (dbias) {
+        hipLaunchKernelGGL(convT_dbias_kernel, dim3(C), dim3(256), 0, as_stream(stream), dy, dy_bs, dbias, accumulate, B,
+                           C, 2 * h, 2 * w, Ho, Wo, pt, pl);
+        rc = check_launch("convT_dbias_kernel");
+    }
+    return rc;
+}
+
+// dx must be zero-initialised by the caller (scatter-add)
+extern "C" int onet_bilinear2x_bwd(const float* dy, int64_t dy_bs, float* dx, int64_t dx_bs, int B, int C, int h,
+                                   int w, int Ho, int Wo, int pt, int pl, void* stream) {
+    ONET_REQUIRE(dy && dx && B > 0 && C > 0 && h > 0 && w > 0, "bilinear2x_bwd: bad args");
+    ONET_REQUIRE(pt >= 0 && pl >= 0 && pt + 2 * h <= Ho && pl + 2 * w <= Wo, "bilinear2x_bwd: window outside plane");
+    const int64_t n = (int64_t)B * C * 4 * h * w;
+    hipLaunchKernelGGL(bilinear2x_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), dy, dy_bs, dx, dx_bs, B,
+                       C, h, w, Ho, Wo, pt, pl);
+    return check_launch("bilinear2x_bwd_kernel");
+}

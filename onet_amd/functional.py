@@ -1,0 +1,239 @@
+"""torch.autograd glue: each Function is one fused unit of the Onet hot path whose forward
+and backward run hand-written HIP kernels through the C ABI (onet_amd.ops).  Autograd only
+orchestrates (graph walk, gradient accumulation of multiply-used tensors); it computes nothing
+of the model itself.  Reference call sites are cited per Function ("OV" =
+source_code/Onet_vanilla_20240606.py)."""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+class ConvBNReLUFn(torch.autograd.Function):
+    """Conv2d(3x3, pad 1, no bias) -> BatchNorm2d -> ReLU  (OV:47-49 / OV:51-53).
+
+    forward : conv_fwd (MFMA) -> BN statistics (+running-stat update) -> normalise+ReLU
+    backward: BN+ReLU backward (2 passes) -> wgrad (MFMA split-K) -> dgrad (MFMA)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, training, momentum, eps, packed, out):
+        ops.require_gpu(x, weight, gamma, beta)
+        wp_fwd, wp_dgrad = packed
+        Cout = weight.shape[0]
+        z = ops.conv_fwd(x, wp_fwd, Cout, 3)
+        if training:
+            save = ops.bn_train_coeffs(z, gamma, beta, running_mean, running_var, momentum, eps)
+        else:
+            save = ops.bn_eval_coeffs(gamma, beta, running_mean, running_var, eps)
+        # `out` is None or a 1-tuple holding a plane-contiguous destination view (kept out of autograd's sight)
+        a = ops.bn_relu_apply(z, save, out=None if out is None else out[0])
+        ctx.save_for_backward(x, z, save, wp_dgrad)
+        ctx.training = training
+        ctx.wshape = tuple(weight.shape)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        x, z, save, wp_dgrad = ctx.saved_tensors
+        need_x, need_w, need_g, need_b = ctx.needs_input_grad[:4]
+        dz, dgamma, dbeta = ops.bn_relu_bwd(da, z, save, ctx.training, need_affine_grads=(need_g or need_b))
+        dw = ops.conv_wgrad(x, dz, ctx.wshape, 3) if need_w else None
+        dx = ops.conv_fwd(dz, wp_dgrad, ctx.wshape[1], 3) if need_x else None
+        return dx, dw, (dgamma if need_g else None), (dbeta if need_b else None), None, None, None, None, None, None, None
+
+
+class Conv3x3Fn(torch.autograd.Function):
+    """Bare 3x3 convolution (standalone use of the conv parameter holder)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, packed):
+        ops.require_gpu(x, weight)
+        z = ops.conv_fwd(x, packed[0], weight.shape[0], 3)
+        ctx.save_for_backward(x, packed[1])
+        ctx.wshape = tuple(weight.shape)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, wp_dgrad = ctx.saved_tensors
+        dw = ops.conv_wgrad(x, dz, ctx.wshape, 3) if ctx.needs_input_grad[1] else None
+        dx = ops.conv_fwd(dz, wp_dgrad, ctx.wshape[1], 3) if ctx.needs_input_grad[0] else None
+        return dx, dw, None
+
+
+class BNReLUFn(torch.autograd.Function):
+    """BatchNorm2d -> ReLU on an existing pre-activation (standalone use)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, running_mean, running_var, training, momentum, eps):
+        ops.require_gpu(z, gamma, beta)
+        if training:
+            save = ops.bn_train_coeffs(z, gamma, beta, running_mean, running_var, momentum, eps)
+        else:
+            save = ops.bn_eval_coeffs(gamma, beta, running_mean, running_var, eps)
+        a = ops.bn_relu_apply(z, save)
+        ctx.save_for_backward(z, save)
+        ctx.training = training
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        z, save = ctx.saved_tensors
+        dz, dgamma, dbeta = ops.bn_relu_bwd(da, z, save, ctx.training, True)
+        return dz, dgamma, dbeta, None, None, None, None, None
+
+
+class MaxPool2Fn(torch.autograd.Function):
+    """nn.MaxPool2d(2)  (OV:67)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ops.require_gpu(x)
+        y = ops.maxpool2_fwd(x)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.maxpool2_bwd(x, dy)
+
+
+def _pad_offsets(x1_hw, x2_hw):
+    """F.pad amounts of OV:92-96: (top, left); right/bottom are implied by the skip size."""
+    dY = x2_hw[0] - 2 * x1_hw[0]
+    dX = x2_hw[1] - 2 * x1_hw[1]
+    if dY < 0 or dX < 0:
+        raise ValueError("Up: skip tensor smaller than the upsampled tensor (negative F.pad is not supported)")
+    return dY // 2, dX // 2
+
+
+class UpConvTCatFn(torch.autograd.Function):
+    """ConvTranspose2d(C, C/2, k=2, s=2) + F.pad + cat([skip, up], 1)  (OV:86, OV:91-100).
+
+    The transposed conv is a 1x1 MFMA convolution to 4*Ct sub-pixel channels followed by a
+    pixel-shuffle that writes straight into the second half of the concat buffer."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, weight, bias, packed):
+        ops.require_gpu(x1, x2, weight, bias)
+        wp_fwd, wp_dgrad = packed
+        B, Cin, h, w = x1.shape
+        Ct = weight.shape[1]
+        C2, Ho, Wo = x2.shape[1], x2.shape[2], x2.shape[3]
+        pt, pl = _pad_offsets((h, w), (Ho, Wo))
+        sub = ops.conv_fwd(x1, wp_fwd, 4 * Ct, 1)
+        cat = torch.empty((B, C2 + Ct, Ho, Wo), dtype=torch.float32, device=x1.device)
+        if C2 > 0:
+            ops.copy_strided(x2, cat[:, :C2])
+        ops.pixel_shuffle2_bias(sub, bias, cat[:, C2:], pt, pl)
+        ctx.save_for_backward(x1, wp_dgrad)
+        ctx.meta = (C2, Ct, h, w, pt, pl, tuple(weight.shape), bias is not None)
+        return cat
+
+    @staticmethod
+    def backward(ctx, dcat):
+        x1, wp_dgrad = ctx.saved_tensors
+        C2, Ct, h, w, pt, pl, wshape, has_bias = ctx.meta
+        need_x1, need_x2, need_w, need_b = ctx.needs_input_grad[:4]
+        dx2 = dcat[:, :C2] if need_x2 else None
+        dx1 = dw = db = None
+        if need_x1 or need_w or need_b:
+            dsub, db = ops.space_to_depth2(dcat[:, C2:], h, w, pt, pl, want_dbias=(need_b and has_bias))
+            if need_w:
+                dw = ops.conv_wgrad(x1, dsub, wshape, 1, out_layout=1)
+            if need_x1:
+                dx1 = ops.conv_fwd(dsub, wp_dgrad, wshape[0], 1)
+        return dx1, dx2, dw, db, None
+
+
+class UpBilinearCatFn(torch.autograd.Function):
+    """nn.Upsample(x2, bilinear, align_corners=True) + F.pad + cat  (OV:83, OV:91-100)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2):
+        ops.require_gpu(x1, x2)
+        B, C1, h, w = x1.shape
+        C2, Ho, Wo = x2.shape[1], x2.shape[2], x2.shape[3]
+        pt, pl = _pad_offsets((h, w), (Ho, Wo))
+        cat = torch.empty((B, C2 + C1, Ho, Wo), dtype=torch.float32, device=x1.device)
+        if C2 > 0:
+            ops.copy_strided(x2, cat[:, :C2])
+        ops.bilinear2x_fwd(x1, cat[:, C2:], pt, pl)
+        ctx.meta = (C2, h, w, pt, pl)
+        return cat
+
+    @staticmethod
+    def backward(ctx, dcat):
+        C2, h, w, pt, pl = ctx.meta
+        dx2 = dcat[:, :C2] if ctx.needs_input_grad[1] else None
+        dx1 = ops.bilinear2x_bwd(dcat[:, C2:], h, w, pt, pl) if ctx.needs_input_grad[0] else None
+        return dx1, dx2
+
+
+class HeadSoftmaxFn(torch.autograd.Function):
+    """V = einsum('bpxy,bpxy->bxy', L, H) for both branches + Softmax2d(cat[Vt,Vd])  (OV:176-189)."""
+
+    @staticmethod
+    def forward(ctx, Lt, Ht, Ld, Hd):
+        Vt, Vd, S = ops.head_softmax_fwd(Lt, Ht, Ld, Hd)
+        ctx.save_for_backward(Lt, Ht, Ld, Hd, S)
+        return Vt, Vd, S
+
+    @staticmethod
+    def backward(ctx, dVt, dVd, dS):
+        Lt, Ht, Ld, Hd, S = ctx.saved_tensors
+        dLt, dHt, dLd, dHd = ops.head_softmax_bwd(dVt, dVd, dS, S, Lt, Ht, Ld, Hd)
+        return dLt, dHt, dLd, dHd
+
+
+class JSDFn(torch.autograd.Function):
+    """Onet.jensen_shannon_divergence(Li, Si, Sprime)  (OV:221-235) incl. the log1pexp quirk."""
+
+    @staticmethod
+    def forward(ctx, Li, Si, Sp):
+        out, sums = ops.jsd_fwd(Li, Si, Sp)
+        ctx.save_for_backward(sums, Si, Sp)
+        ctx.shape = tuple(Li.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        sums, Si, Sp = ctx.saved_tensors
+        gL, dSi, dSp = ops.jsd_bwd(g, sums, Si, Sp, ctx.shape)
+        # d jsd / dL is identical for all 64 channels: hand autograd a stride-0 view, not a copy
+        return gL.expand(ctx.shape), dSi, dSp
+
+
+class Log1pExpFn(torch.autograd.Function):
+    """Onet.log1pexp: mutates its argument in place and returns it  (OV:237-251)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x0 = x.detach().clone()
+        ops.log1pexp_(x)
+        ctx.mark_dirty(x)
+        ctx.save_for_backward(x0)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        (x0,) = ctx.saved_tensors
+        return ops.log1pexp_bwd(x0, g)
+
+
+class ComplementClipFn(torch.autograd.Function):
+    """Xd = clip(1 - X + bias, 0, 1)  (OV:180)."""
+
+    @staticmethod
+    def forward(ctx, x, bias):
+        y = ops.complement_clip(x, bias)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        # only reached when the caller asks for d/dX (never on the training path): plumbing
+        (y,) = ctx.saved_tensors
+        return -g * ((y > 0) & (y < 1)).to(g.dtype), None

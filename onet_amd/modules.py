@@ -1,0 +1,306 @@
+"""Host-side mirror of the reference's model interface (source_code/Onet_vanilla_20240606.py,
+"OV"): same class names, constructor signatures, attribute tree, parameter names and
+state_dict keys (232 entries for Onet), same method names / argument meaning / error
+behaviour -- but every tensor operation runs a hand-written gfx950 HIP kernel through the
+C ABI (include/onet_hip.h).
+
+The leaf parameter holders subclass torch's own module types (``nn.Conv2d``,
+``nn.BatchNorm2d``, ``nn.ConvTranspose2d`` ...) ONLY to inherit parameter registration,
+default initialisation, ``state_dict`` layout and ``isinstance`` behaviour (the reference's
+``_initialize_weights`` and its model-summary hooks dispatch on those types).  Their
+``forward`` is overridden: ATen/MIOpen convolution, batch-norm, pooling, upsampling are never
+called.  There is no CPU fallback: a CPU tensor raises."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+from . import ops
+
+
+class _Packable:
+    """Caches GEMM-packed copies of ``self.weight``; re-packed when the parameter changes."""
+
+    _pack = None
+    _pack_key = None
+
+    def _pack_fn(self, w):
+        raise NotImplementedError
+
+    def packed(self):
+        w = self.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        if self._pack_key != key:
+            with torch.no_grad():
+                self._pack = self._pack_fn(w)
+            self._pack_key = key
+        return self._pack
+
+    def invalidate_packed(self):
+        self._pack_key = None
+
+
+def invalidate_packed(model: nn.Module):
+    """Call after parameters were updated behind autograd's back (fused Adam, NCCL broadcast)."""
+    for m in model.modules():
+        if isinstance(m, _Packable):
+            m.invalidate_packed()
+
+
+class Conv3x3(nn.Conv2d, _Packable):
+    """nn.Conv2d(cin, cout, kernel_size=3, padding=1, bias=False) parameter holder (OV:47,51)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__(in_channels, out_channels, kernel_size=3, padding=1, bias=False)
+
+    def _pack_fn(self, w):
+        return ops.pack3x3(w)
+
+    def forward(self, x):
+        return Fn.Conv3x3Fn.apply(x, self.weight, self.packed())
+
+
+class BatchNormReLU2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d parameter/buffer holder (OV:48,52).  In this network it is always followed
+    by ReLU (OV:49,53) and the HIP kernel fuses the two, so the ReLU entry of the Sequential is a
+    pass-through marker (see DoubleConv)."""
+
+    def forward(self, z):
+        if z.dim() != 4:
+            raise ValueError(f"expected 4D input (got {z.dim()}D input)")
+        training = self.training or (self.running_mean is None)
+        if training and self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+        return Fn.BNReLUFn.apply(z, self.weight, self.bias, self.running_mean, self.running_var, training,
+                                 self.momentum, self.eps)
+
+
+class FusedReLU(nn.ReLU):
+    """nn.ReLU(inplace=True) slot of the reference's Sequential (OV:49,53): the activation is applied
+    inside the BN kernel, so this module is the identity on already-rectified data."""
+
+    def __init__(self):
+        super().__init__(inplace=True)
+
+    def forward(self, x):
+        return x
+
+
+class DoubleConv(nn.Module):
+    """(convolution => [BN] => ReLU) * 2   -- OV:39-58."""
+
+    def __init__(self, in_channels, out_channels, mid_channels=None):
+        super().__init__()
+        if not mid_channels:
+            mid_channels = out_channels
+        self.double_conv = nn.Sequential(
+            Conv3x3(in_channels, mid_channels),
+            BatchNormReLU2d(mid_channels),
+            FusedReLU(),
+            Conv3x3(mid_channels, out_channels),
+            BatchNormReLU2d(out_channels),
+            FusedReLU(),
+        )
+
+    @staticmethod
+    def _unit(x, conv, bn, out=None):
+        training = bn.training or (bn.running_mean is None)
+        if x.dim() != 4:
+            raise ValueError(f"expected 4D input (got {x.dim()}D input)")
+        if x.shape[1] != conv.in_channels:
+            raise RuntimeError(f"Given groups=1, weight of size {list(conv.weight.shape)}, expected input"
+                               f"{list(x.shape)} to have {conv.in_channels} channels, but got {x.shape[1]} channels instead")
+        if training and x.shape[0] * x.shape[2] * x.shape[3] <= 1:
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size "
+                             f"{[x.shape[0], conv.out_channels, x.shape[2], x.shape[3]]}")
+        if training and bn.track_running_stats:
+            bn.num_batches_tracked.add_(1)
+        return Fn.ConvBNReLUFn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                     training, bn.momentum, bn.eps, conv.packed(), out)
+
+    def forward(self, x):
+        s = self.double_conv
+        return self._unit(self._unit(x, s[0], s[1]), s[3], s[4])
+
+
+class MaxPool2(nn.MaxPool2d):
+    """nn.MaxPool2d(2) (OV:67)."""
+
+    def __init__(self):
+        super().__init__(2)
+
+    def forward(self, x):
+        return Fn.MaxPool2Fn.apply(x)
+
+
+class Down(nn.Module):
+    """Downscaling with maxpool then double conv -- OV:61-72."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.maxpool_conv = nn.Sequential(MaxPool2(), DoubleConv(in_channels, out_channels))
+
+    def forward(self, x):
+        return self.maxpool_conv(x)
+
+
+class ConvT2x2(nn.ConvTranspose2d, _Packable):
+    """nn.ConvTranspose2d(cin, cin//2, kernel_size=2, stride=2) parameter holder (OV:86)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__(in_channels, out_channels, kernel_size=2, stride=2)
+
+    def _pack_fn(self, w):
+        return ops.packT2x2(w)
+
+    def forward(self, x, output_size=None):
+        # standalone use: up-sample only (no skip): concat with an empty skip
+        B, _, h, w = x.shape
+        empty = torch.empty((B, 0, 2 * h, 2 * w), dtype=x.dtype, device=x.device)
+        return Fn.UpConvTCatFn.apply(x, empty, self.weight, self.bias, self.packed())
+
+
+class BilinearUp2x(nn.Upsample):
+    """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (OV:83)."""
+
+    def __init__(self):
+        super().__init__(scale_factor=2, mode="bilinear", align_corners=True)
+
+    def forward(self, x):
+        B, _, h, w = x.shape
+        empty = torch.empty((B, 0, 2 * h, 2 * w), dtype=x.dtype, device=x.device)
+        return Fn.UpBilinearCatFn.apply(x, empty)
+
+
+class Up(nn.Module):
+    """Upscaling then double conv -- OV:75-101.  up -> F.pad to the skip size -> cat([x2, x1]) -> DoubleConv."""
+
+    def __init__(self, in_channels, out_channels, bilinear=True):
+        super().__init__()
+        if bilinear:
+            self.up = BilinearUp2x()
+            self.conv = DoubleConv(in_channels, out_channels, in_channels // 2)
+        else:
+            self.up = ConvT2x2(in_channels, in_channels // 2)
+            self.conv = DoubleConv(in_channels, out_channels)
+
+    def forward(self, x1, x2):
+        if isinstance(self.up, ConvT2x2):
+            x = Fn.UpConvTCatFn.apply(x1, x2, self.up.weight, self.up.bias, self.up.packed())
+        else:
+            x = Fn.UpBilinearCatFn.apply(x1, x2)
+        return self.conv(x)
+
+
+class UNet(nn.Module):
+    """OV:104-153: 5-level encoder (64..1024), 4-level decoder, no 1x1 head; returns (x1, y1)."""
+
+    def __init__(self, n_channels=1, n_classes=1, binit=False, bilinear=False):
+        super().__init__()
+        self.n_channels = n_channels
+        self.n_classes = n_classes
+        self.bilinear = bilinear
+
+        self.inc = DoubleConv(n_channels, 64)
+        self.down1 = Down(64, 128)
+        self.down2 = Down(128, 256)
+        self.down3 = Down(256, 512)
+        factor = 2 if bilinear else 1
+        self.down4 = Down(512, 1024 // factor)
+        self.up1 = Up(1024, 512 // factor, bilinear)
+        self.up2 = Up(512, 256 // factor, bilinear)
+        self.up3 = Up(256, 128 // factor, bilinear)
+        self.up4 = Up(128, 64, bilinear)
+        if binit:
+            self._initialize_weights()
+
+    def _initialize_weights(self, mode="fan_in"):
+        """OV:125-140: Kaiming-normal on every nn.Conv2d (ConvTranspose2d is NOT an nn.Conv2d, so it
+        keeps torch's default init and non-zero bias -- SURVEY.md §8a-4), BN weight 1 / bias 0."""
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode=mode, nonlinearity="relu")
+                if m.bias is not None:
+                    m.bias.data.zero_()
+            elif isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+            elif isinstance(m, nn.Linear):
+                m.weight.data.normal_(0, 0.01)
+                m.bias.data.zero_()
+
+    def forward(self, x):
+        x1 = self.inc(x)
+        x2 = self.down1(x1)
+        x3 = self.down2(x2)
+        x4 = self.down3(x3)
+        x5 = self.down4(x4)
+        y4 = self.up1(x5, x4)
+        y3 = self.up2(y4, x3)
+        y2 = self.up3(y3, x2)
+        y1 = self.up4(y2, x1)
+        return x1, y1
+
+
+class Softmax2(nn.Softmax2d):
+    """nn.Softmax2d slot (OV:171): 2-channel softmax; Onet.forward fuses it into the head kernel,
+    get_label() calls it directly on cat([Vt, Vd])."""
+
+    def forward(self, V):
+        if V.dim() != 4 or V.shape[1] != 2:
+            raise ValueError("Softmax2: expected a [B,2,H,W] logit tensor")
+        one = torch.ones((V.shape[0], 1, V.shape[2], V.shape[3]), dtype=V.dtype, device=V.device)
+        # softmax([Vt,Vd]) == head(L=V-channel, H=1): reuse the fused head kernel
+        _, _, S = Fn.HeadSoftmaxFn.apply(V[:, 0:1], one, V[:, 1:2], one)
+        return S
+
+
+class Onet(nn.Module):
+    """OV:156-267.  forward(X) -> (Lt, Vt, Ld, Vd, S); compute_loss(Lt, St, Ld, Sd) -> scalar."""
+
+    def __init__(self, in_chns=1, binit=False, bshare=True):
+        super().__init__()
+        self.topu = UNet(n_channels=in_chns, n_classes=1, bilinear=False, binit=binit)
+        if bshare:
+            self.dwnu = self.topu           # weight sharing: the SAME module object (OV:163-164)
+        else:
+            self.dwnu = UNet(n_channels=in_chns, n_classes=1, bilinear=False, binit=binit)
+        self.softmax = Softmax2()
+        self.bias = 0                       # background bias in [0,1], read every forward (OV:172,180)
+        self.check_finite = True            # OV:234 asserts the loss is not NaN (forces a device sync)
+
+    def forward(self, X):
+        Lt, Ht = self.topu(X)
+        Xd = Fn.ComplementClipFn.apply(X, float(self.bias))
+        Ld, Hd = self.dwnu(Xd)
+        Vt, Vd, S = Fn.HeadSoftmaxFn.apply(Lt, Ht, Ld, Hd)
+        return Lt, Vt, Ld, Vd, S
+
+    def predict_label(self, S):
+        with torch.no_grad():
+            assert (S.dim() == 4)
+            return ops.argmax2(S)
+
+    def get_label(self, Vt, Vd):
+        with torch.no_grad():
+            one = torch.ones_like(Vt)
+            _, _, V = Fn.HeadSoftmaxFn.apply(Vt, one, Vd, one)
+            return ops.argmax2(V), V
+
+    def jensen_shannon_divergence(self, Li, Si, Sprime):
+        assert (Li.dim() == 4 and Si.dim() == 4 and Sprime.dim() == 4)
+        jsd = Fn.JSDFn.apply(Li, Si, Sprime)
+        if self.check_finite:
+            assert (torch.isnan(jsd) == False)  # noqa: E712  (mirrors OV:234)
+        return jsd
+
+    def log1pexp(self, x):
+        return Fn.Log1pExpFn.apply(x)
+
+    def compute_loss(self, Lt, St, Ld, Sd):
+        jsd = getattr(self, "jensen_shannon_divergence", None)
+        if callable(jsd):
+            jsd_top = jsd(Lt, St, Sd)
+            jsd_dwn = jsd(Ld, Sd, St)
+            return -(jsd_top + jsd_dwn) / 2

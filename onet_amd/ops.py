@@ -1,0 +1,372 @@
+"""Tensor-level wrappers over the C ABI (include/onet_hip.h).
+
+PyTorch-ROCm tensors are used for STORAGE ONLY: every function here takes
+tensors, checks them, and hands raw device pointers + sizes + the current HIP
+stream to libonet_hip.so.  No torch compute op is called on the data path.
+There is no CPU fallback: CPU tensors raise."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+F32 = torch.float32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def require_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("onet_amd: the HIP path needs tensors on a ROCm GPU (got a CPU tensor); "
+                               "there is no CPU fallback -- move the module and inputs to 'cuda'")
+        if t is not None and t.dtype != F32 and t.is_floating_point():
+            raise TypeError(f"onet_amd: fp32 tensors expected, got {t.dtype}")
+
+
+def plane(t):
+    """-> (tensor, batch_stride) with the (C,H,W) block of every image contiguous.
+    Channel-slices of a concat buffer qualify as they are; anything else is copied."""
+    B, C, H, W = t.shape
+    ok = (W == 1 or t.stride(3) == 1) and (H == 1 or t.stride(2) == W) and (C == 1 or t.stride(1) == H * W)
+    if ok and B > 1 and t.stride(0) < C * H * W:
+        ok = False
+    if not ok:
+        t = t.contiguous()
+    return t, (t.stride(0) if B > 1 else C * H * W)
+
+
+# Optional in-process kernel timing (bench.py): PROFILE = {} enables HIP-event brackets around the
+# MFMA launches, on the stream they are launched on; entries: kind -> [(flops, ev_start, ev_end)].
+PROFILE = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return e0
+
+
+def _prof_end(kind, flops, e0):
+    if e0 is None:
+        return
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    PROFILE.setdefault(kind, []).append((flops, e0, e1))
+
+
+_WS = {}
+
+
+def workspace(nbytes, device):
+    """Grow-only scratch buffer per device (wgrad split-K slabs)."""
+    key = (device.type, device.index)
+    cur = _WS.get(key)
+    if cur is None or cur.numel() * 4 < nbytes:
+        cur = None
+        _WS.pop(key, None)
+        cur = torch.empty((int(nbytes) + 3) // 4, dtype=F32, device=device)
+        _WS[key] = cur
+    return cur
+
+
+# ----------------------------------------------------------------------------- conv
+def pack3x3(w):
+    require_gpu(w)
+    w = w.detach().contiguous()
+    Cout, Cin = w.shape[0], w.shape[1]
+    wf = torch.empty(Cin * 9 * Cout, dtype=F32, device=w.device)
+    wd = torch.empty(Cout * 9 * Cin, dtype=F32, device=w.device)
+    _lib.call("onet_conv3x3_pack_weights", _p(w), _p(wf), _p(wd), Cout, Cin, _stream())
+    return wf, wd
+
+
+def packT2x2(w):
+    require_gpu(w)
+    w = w.detach().contiguous()
+    Cin, Cout = w.shape[0], w.shape[1]
+    wf = torch.empty(Cin * 4 * Cout, dtype=F32, device=w.device)
+    wd = torch.empty(4 * Cout * Cin, dtype=F32, device=w.device)
+    _lib.call("onet_convT2x2_pack_weights", _p(w), _p(wf), _p(wd), Cin, Cout, _stream())
+    return wf, wd
+
+
+def conv_fwd(x, wp, Cout, ks, out=None):
+    """z = conv_ks(x) with packed weights wp ([Cin][ks*ks][Cout]); also used for dgrad."""
+    require_gpu(x, wp)
+    x, xbs = plane(x)
+    B, Cin, H, W = x.shape
+    if out is None:
+        out = torch.empty((B, Cout, H, W), dtype=F32, device=x.device)
+    zbs = out.stride(0) if B > 1 else Cout * H * W
+    e0 = _prof_begin()
+    _lib.call("onet_conv_fwd", _p(x), xbs, _p(wp), _p(out), zbs, None, B, Cin, Cout, H, W, ks, _stream())
+    _prof_end("conv_fwd_kernel", 2.0 * B * H * W * Cin * Cout * ks * ks, e0)
+    return out
+
+
+def conv_wgrad(x, dz, dw_shape, ks, out_layout=0):
+    require_gpu(x, dz)
+    x, xbs = plane(x)
+    dz, dzbs = plane(dz)
+    B, Cin, H, W = x.shape
+    Cout = dz.shape[1]
+    dw = torch.empty(dw_shape, dtype=F32, device=x.device)
+    need = _lib.load().onet_conv_wgrad_ws_bytes(B, Cin, Cout, H, W, ks)
+    ws = workspace(need, x.device)
+    e0 = _prof_begin()
+    _lib.call("onet_conv_wgrad", _p(x), xbs, _p(dz), dzbs, _p(dw), _p(ws), ws.numel() * 4, B, Cin, Cout, H, W, ks,
+              out_layout, 0, _stream())
+    _prof_end("conv_wgrad_kernel", 2.0 * B * H * W * Cin * Cout * ks * ks, e0)
+    return dw
+
+
+# ----------------------------------------------------------------------------- batch norm + relu
+def _bn_nparts(B, HW):
+    return B * max(1, (HW + 16383) // 16384)
+
+
+def bn_train_coeffs(z, gamma, beta, running_mean, running_var, momentum, eps):
+    """batch statistics -> save [4][C] = (mean, invstd, scale, shift); updates running stats in place."""
+    z, zbs = plane(z)
+    B, C, H, W = z.shape
+    if B * H * W <= 1:
+        raise ValueError(f"Expected more than 1 value per channel when training, got input size {list(z.shape)}")
+    nparts = _bn_nparts(B, H * W)
+    part = torch.empty((nparts, C, 2), dtype=F32, device=z.device)
+    _lib.call("onet_bn_stats_partial", _p(z), zbs, _p(part), nparts, B, C, H * W, _stream())
+    save = torch.empty((4, C), dtype=F32, device=z.device)
+    _lib.call("onet_bn_finalize", _p(part), nparts, B * H * W, _p(gamma), _p(beta), _p(running_mean),
+              _p(running_var), float(momentum), float(eps), _p(save), C, _stream())
+    return save
+
+
+def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
+    C = running_mean.numel()
+    save = torch.empty((4, C), dtype=F32, device=running_mean.device)
+    _lib.call("onet_bn_eval_coeffs", _p(gamma), _p(beta), _p(running_mean), _p(running_var), float(eps), _p(save),
+              C, _stream())
+    return save
+
+
+def bn_relu_apply(z, save, out=None):
+    z, zbs = plane(z)
+    B, C, H, W = z.shape
+    if out is None:
+        out = torch.empty((B, C, H, W), dtype=F32, device=z.device)
+    abs_ = out.stride(0) if B > 1 else C * H * W
+    _lib.call("onet_bn_relu_apply", _p(z), zbs, _p(out), abs_, _p(save), B, C, H * W, _stream())
+    return out
+
+
+def bn_relu_bwd(da, z, save, training, need_affine_grads=True):
+    """-> dz, dgamma, dbeta"""
+    da, dabs = plane(da)
+    z, zbs = plane(z)
+    B, C, H, W = z.shape
+    HW = H * W
+    nparts = _bn_nparts(B, HW)
+    dev = z.device
+    dgamma = dbeta = coef = None
+    if training or need_affine_grads:
+        part2 = torch.empty((nparts, C, 2), dtype=F32, device=dev)
+        _lib.call("onet_bn_relu_bwd_reduce", _p(da), dabs, _p(z), zbs, _p(save), _p(part2), nparts, B, C, HW, _stream())
+        dgamma = torch.empty(C, dtype=F32, device=dev)
+        dbeta = torch.empty(C, dtype=F32, device=dev)
+        coef = torch.empty((2, C), dtype=F32, device=dev) if training else None
+        _lib.call("onet_bn_bwd_finalize", _p(part2), nparts, B * HW, _p(dgamma), _p(dbeta), _p(coef), 0, C, _stream())
+    dz = torch.empty((B, C, H, W), dtype=F32, device=dev)
+    _lib.call("onet_bn_relu_bwd_apply", _p(da), dabs, _p(z), zbs, _p(save), _p(coef), _p(dz), C * HW, B, C, HW,
+              _stream())
+    return dz, dgamma, dbeta
+
+
+# ----------------------------------------------------------------------------- pool / up / cat
+def maxpool2_fwd(x):
+    x, xbs = plane(x)
+    B, C, H, W = x.shape
+    y = torch.empty((B, C, H // 2, W // 2), dtype=F32, device=x.device)
+    _lib.call("onet_maxpool2_fwd", _p(x), xbs, _p(y), C * (H // 2) * (W // 2), B, C, H, W, _stream())
+    return y
+
+
+def maxpool2_bwd(x, dy):
+    x, xbs = plane(x)
+    dy, dybs = plane(dy)
+    B, C, H, W = x.shape
+    dx = torch.empty((B, C, H, W), dtype=F32, device=x.device)
+    _lib.call("onet_maxpool2_bwd", _p(x), xbs, _p(dy), dybs, _p(dx), C * H * W, B, C, H, W, 0, _stream())
+    return dx
+
+
+def copy_strided(src, dst):
+    """dst[b] = src[b] for plane-contiguous [B,C,H,W] views."""
+    src, sbs = plane(src)
+    B, C, H, W = src.shape
+    dbs = dst.stride(0) if B > 1 else C * H * W
+    _lib.call("onet_copy_strided", _p(src), sbs, _p(dst), dbs, B, C * H * W, _stream())
+    return dst
+
+
+def pixel_shuffle2_bias(sub, bias, out, pt, pl):
+    """sub [B,4C,h,w] -> out [B,C,Ho,Wo] (a plane-contiguous view, e.g. the 2nd half of a cat buffer)."""
+    B, C4, h, w = sub.shape
+    C = C4 // 4
+    Ho, Wo = out.shape[2], out.shape[3]
+    obs = out.stride(0) if B > 1 else C * Ho * Wo
+    _lib.call("onet_pixel_shuffle2_bias", _p(sub), _p(bias), _p(out), obs, B, C, h, w, Ho, Wo, pt, pl, _stream())
+    return out
+
+
+def space_to_depth2(dy, h, w, pt, pl, want_dbias):
+    dy, dybs = plane(dy)
+    B, C, Ho, Wo = dy.shape
+    sub = torch.empty((B, 4 * C, h, w), dtype=F32, device=dy.device)
+    dbias = torch.empty(C, dtype=F32, device=dy.device) if want_dbias else None
+    _lib.call("onet_space_to_depth2", _p(dy), dybs, _p(sub), _p(dbias), 0, B, C, h, w, Ho, Wo, pt, pl, _stream())
+    return sub, dbias
+
+
+def bilinear2x_fwd(x, out, pt, pl):
+    x, xbs = plane(x)
+    B, C, h, w = x.shape
+    Ho, Wo = out.shape[2], out.shape[3]
+    obs = out.stride(0) if B > 1 else C * Ho * Wo
+    _lib.call("onet_bilinear2x_fwd", _p(x), xbs, _p(out), obs, B, C, h, w, Ho, Wo, pt, pl, _stream())
+    return out
+
+
+def bilinear2x_bwd(dy, h, w, pt, pl):
+    dy, dybs = plane(dy)
+    B, C, Ho, Wo = dy.shape
+    dx = torch.empty((B, C, h, w), dtype=F32, device=dy.device)
+    fill(dx, 0.0)
+    _lib.call("onet_bilinear2x_bwd", _p(dy), dybs, _p(dx), C * h * w, B, C, h, w, Ho, Wo, pt, pl, _stream())
+    return dx
+
+
+# ----------------------------------------------------------------------------- elementwise
+def complement_clip(x, bias):
+    require_gpu(x)
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    _lib.call("onet_complement_clip", _p(x), _p(y), float(bias), x.numel(), _stream())
+    return y
+
+
+def fill(t, value):
+    _lib.call("onet_fill", _p(t), float(value), t.numel(), _stream())
+    return t
+
+
+# ----------------------------------------------------------------------------- head / loss
+def head_softmax_fwd(Lt, Ht, Ld, Hd):
+    require_gpu(Lt, Ht, Ld, Hd)
+    Lt, a = plane(Lt)
+    Ht, b = plane(Ht)
+    Ld, c = plane(Ld)
+    Hd, d = plane(Hd)
+    B, C, H, W = Lt.shape
+    dev = Lt.device
+    Vt = torch.empty((B, 1, H, W), dtype=F32, device=dev)
+    Vd = torch.empty((B, 1, H, W), dtype=F32, device=dev)
+    S = torch.empty((B, 2, H, W), dtype=F32, device=dev)
+    _lib.call("onet_head_softmax_fwd", _p(Lt), a, _p(Ht), b, _p(Ld), c, _p(Hd), d, _p(Vt), _p(Vd), _p(S), B, C,
+              H * W, _stream())
+    return Vt, Vd, S
+
+
+def head_softmax_bwd(dVt, dVd, dS, S, Lt, Ht, Ld, Hd):
+    Lt, a = plane(Lt)
+    Ht, b = plane(Ht)
+    Ld, c = plane(Ld)
+    Hd, d = plane(Hd)
+    B, C, H, W = Lt.shape
+    dev = Lt.device
+    dVt = None if dVt is None else dVt.contiguous()
+    dVd = None if dVd is None else dVd.contiguous()
+    dS = None if dS is None else dS.contiguous()
+    outs = [torch.empty((B, C, H, W), dtype=F32, device=dev) for _ in range(4)]
+    _lib.call("onet_head_softmax_bwd", _p(dVt), _p(dVd), _p(dS), _p(S), _p(Lt), a, _p(Ht), b, _p(Ld), c, _p(Hd), d,
+              _p(outs[0]), _p(outs[1]), _p(outs[2]), _p(outs[3]), B, C, H * W, _stream())
+    return outs
+
+
+def _rows(t):
+    """[B,1,H,W] slice of S -> (tensor, batch stride) with the H*W block contiguous."""
+    B, C, H, W = t.shape
+    assert C == 1
+    ok = (W == 1 or t.stride(3) == 1) and (H == 1 or t.stride(2) == W)
+    if not ok:
+        t = t.contiguous()
+    return t, (t.stride(0) if B > 1 else H * W)
+
+
+def jsd_fwd(L, Si, Sp):
+    require_gpu(L, Si, Sp)
+    L, lbs = plane(L)
+    Si, ibs = _rows(Si)
+    Sp, pbs = _rows(Sp)
+    B, C, H, W = L.shape
+    dev = L.device
+    sums = torch.empty(B * H * W, dtype=F32, device=dev)
+    part = torch.empty(_lib.load().onet_jsd_nparts(), dtype=torch.float64, device=dev)
+    out = torch.empty((), dtype=F32, device=dev)
+    _lib.call("onet_jsd_fwd", _p(L), lbs, _p(Si), ibs, _p(Sp), pbs, _p(sums), _p(part), _p(out), B, C, H * W,
+              _stream())
+    return out, sums
+
+
+def jsd_bwd(g, sums, Si, Sp, shape):
+    B, C, H, W = shape
+    Si, ibs = _rows(Si)
+    Sp, pbs = _rows(Sp)
+    dev = sums.device
+    g = g.contiguous()
+    gL = torch.empty((B, 1, H, W), dtype=F32, device=dev)
+    dSi = torch.empty((B, 1, H, W), dtype=F32, device=dev)
+    dSp = torch.empty((B, 1, H, W), dtype=F32, device=dev)
+    _lib.call("onet_jsd_bwd", _p(g), _p(sums), _p(Si), ibs, _p(Sp), pbs, _p(gL), _p(dSi), _p(dSp), B, H * W,
+              _stream())
+    return gL, dSi, dSp
+
+
+def log1pexp_(x):
+    require_gpu(x)
+    if not x.is_contiguous():
+        raise ValueError("log1pexp_: contiguous tensor required (it is mutated in place)")
+    _lib.call("onet_log1pexp_inplace", _p(x), x.numel(), _stream())
+    return x
+
+
+def log1pexp_bwd(x_orig, g):
+    g = g.contiguous()
+    out = torch.empty_like(x_orig)
+    _lib.call("onet_log1pexp_bwd", _p(x_orig), _p(g), _p(out), x_orig.numel(), _stream())
+    return out
+
+
+def argmax2(S):
+    require_gpu(S)
+    S = S.contiguous()
+    B, C, H, W = S.shape
+    if C != 2:
+        raise ValueError("argmax2: S must have 2 channels")
+    Y = torch.empty((B, H, W), dtype=torch.int64, device=S.device)
+    _lib.call("onet_argmax2", _p(S), _p(Y), B, H * W, _stream())
+    return Y
+
+
+# ----------------------------------------------------------------------------- optimizer
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    require_gpu(p, g, m, v)
+    _lib.call("onet_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2),
+              float(eps), float(weight_decay), int(step), float(grad_scale), _stream())

@@ -1,0 +1,210 @@
+"""Training harness for the HIP Onet: the build's counterpart of the reference's training loops
+(harness contract) plus the data-parallel layer the reference does not have.
+
+* per step (TS:209-219, TZ:110-121):  zero_grad -> X.to(device) -> forward -> slice S ->
+  compute_loss -> backward -> [RCCL all-reduce of the flat gradient] -> Adam -> loss.item()
+* sim-clutter schedule (TS:181-182, TS:248-249): Adam(lr=5e-6), lr *= 0.5 at epochs 100, 200, ...
+* ZY-3 schedule (TZ:89-90, TZ:128): Adam(lr=1e-4) + CosineAnnealingWarmRestarts(T_0=300, T_mult=2,
+  eta_min=1e-6) stepped once per epoch
+* checkpoints (TS:255-266, TZ:145-149): {'net': state_dict (232 keys), 'epoch' | 'save_epoch': e}
+
+Data parallelism: one process per GPU, each rank takes B/N images of the batch,
+full weight replica; ONE all-reduce (sum) of the 31 036 416-element flat fp32 gradient buffer per
+step over RCCL/xGMI, folded into the fused Adam launch as grad_scale = 1/N.  BatchNorm statistics
+are local to the rank (PyTorch-DDP semantics)."""
+from __future__ import annotations
+
+import math
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .modules import invalidate_packed
+
+
+# ----------------------------------------------------------------------------- schedules
+def sim_lr(epoch: int, base_lr: float = 5e-6) -> float:
+    """learning rate in force DURING `epoch` of the sim-clutter loop (TS:248-249): halved after
+    epochs 100, 200, ... have finished."""
+    return base_lr * (0.5 ** max(0, (epoch - 1) // 100)) if epoch > 0 else base_lr
+
+
+def cosine_warm_restarts_lr(epoch: int, base_lr: float = 1e-4, T_0: int = 300, T_mult: int = 2,
+                            eta_min: float = 1e-6) -> float:
+    """torch.optim.lr_scheduler.CosineAnnealingWarmRestarts after `epoch` scheduler.step() calls (TZ:89-90,128)."""
+    t, Ti = epoch, T_0
+    while t >= Ti:
+        t -= Ti
+        Ti *= T_mult
+    return eta_min + (base_lr - eta_min) * (1 + math.cos(math.pi * t / Ti)) / 2
+
+
+# ----------------------------------------------------------------------------- flat Adam
+class FlatAdam:
+    """torch.optim.Adam semantics (TS:181-182) on ONE flat parameter buffer:
+    parameters and gradients of the model are re-pointed into flat fp32 buffers (so the RCCL
+    all-reduce is a single call and the update is a single fused HIP launch, onet_adam_step)."""
+
+    def __init__(self, model, lr=5e-6, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, process_group=None,
+                 world_size=1):
+        self.model = model
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatAdam: model has no trainable parameters")
+        dev = self.params[0].device
+        # 16-byte aligned slots so every parameter view stays float4-addressable
+        self.offsets, n = [], 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += (p.numel() + 3) // 4 * 4
+        self.numel = n
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.gflat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, off in zip(self.params, self.offsets):
+                view = self.flat[off:off + p.numel()].view_as(p)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.gflat[off:off + p.numel()].view_as(p)
+        invalidate_packed(model)
+        self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)]
+        self.step_count = 0
+        self.pg = process_group
+        self.world_size = world_size
+
+    def zero_grad(self, set_to_none: bool = False):
+        if self.gflat.is_cuda:
+            ops.fill(self.gflat, 0.0)
+        else:                       # host-side tests of the flat-buffer / all-reduce plumbing only
+            self.gflat.zero_()
+        for p, off in zip(self.params, self.offsets):   # re-attach if someone set .grad = None
+            if p.grad is None or p.grad.data_ptr() != self.gflat.data_ptr() + 4 * off:
+                p.grad = self.gflat[off:off + p.numel()].view_as(p)
+
+    def all_reduce_grads(self):
+        if self.world_size > 1:
+            dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def _gather_stray_grads(self):
+        """`model.zero_grad()` (set_to_none) detaches .grad from the flat buffer: copy such grads back."""
+        for p, off in zip(self.params, self.offsets):
+            if p.grad is not None and p.grad.data_ptr() != self.gflat.data_ptr() + 4 * off:
+                view = self.gflat[off:off + p.numel()].view_as(p)
+                view.copy_(p.grad)
+                p.grad = view
+
+    def step(self):
+        g = self.param_groups[0]
+        self._gather_stray_grads()
+        self.all_reduce_grads()
+        self.step_count += 1
+        ops.adam_step(self.flat, self.gflat, self.m, self.v, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                      g["weight_decay"], self.step_count, grad_scale=1.0 / self.world_size)
+        invalidate_packed(self.model)
+
+    def broadcast_params(self, src=0):
+        if self.world_size > 1:
+            dist.broadcast(self.flat, src=src, group=self.pg)
+            for b in self.model.buffers():
+                dist.broadcast(b, src=src, group=self.pg)
+            invalidate_packed(self.model)
+
+
+# ----------------------------------------------------------------------------- distributed
+def init_distributed(backend: str | None = None):
+    """-> (rank, world_size, local_rank).  Reads the torchrun environment; single process otherwise."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_batch(X, rank: int, world: int):
+    """rank r takes X[r*B/N:(r+1)*B/N] (equal shards; the mean of shard means is the global mean)."""
+    B = X.shape[0]
+    if B % world:
+        raise ValueError(f"batch {B} not divisible by world size {world}")
+    per = B // world
+    return X[rank * per:(rank + 1) * per]
+
+
+# ----------------------------------------------------------------------------- the step and the loops
+def train_step(onet, opt, X):
+    """One iteration exactly as TS:210-219 orders it.  Returns the loss tensor (0-dim, on device)."""
+    opt.zero_grad()
+    Lt, Vt, Ld, Vd, S = onet(X)
+    St = S[:, 0, :, :].unsqueeze(dim=1)
+    Sd = S[:, 1, :, :].unsqueeze(dim=1)
+    loss = onet.compute_loss(Lt, St, Ld, Sd)
+    loss.backward()
+    opt.step()
+    return loss
+
+
+def save_checkpoint(onet, path, epoch, key="epoch"):
+    """{'net': state_dict, 'epoch': e} (TS:264-266) or {'net', 'save_epoch'} (TZ:145-149)."""
+    torch.save({"net": onet.state_dict(), key: epoch}, path)
+
+
+def load_checkpoint(onet, path, map_location=None):
+    """resume = load_state_dict(torch.load(f)['net']) (TZ:77-82, TS:492-493)."""
+    ck = torch.load(path, map_location=map_location)
+    onet.load_state_dict(ck["net"])
+    invalidate_packed(onet)
+    return ck.get("epoch", ck.get("save_epoch"))
+
+
+def fit(onet, train_loader, device, epochs, schedule="sim", base_lr=None, eval_fn=None, eval_every=None,
+        out_root=None, model_name="Onet", fused_adam=True, rank=0, world=1, log=print):
+    """Epoch loop of TS:201-266 (schedule='sim') / TZ:99-153 (schedule='zy3').
+    `train_loader` yields (X, ...) with X a CPU or GPU float32 [B,C,H,W] tensor in [0,1]."""
+    if base_lr is None:
+        base_lr = 5e-6 if schedule == "sim" else 1e-4
+    if fused_adam:
+        opt = FlatAdam(onet, lr=base_lr, world_size=world)
+        opt.broadcast_params(0)
+    else:
+        opt = torch.optim.Adam(onet.parameters(), lr=base_lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0)
+    if eval_every is None:
+        eval_every = 50 if schedule == "sim" else 1
+    history = []
+    for epoch in range(epochs):
+        onet.train()
+        lr = sim_lr(epoch, base_lr) if schedule == "sim" else cosine_warm_restarts_lr(epoch, base_lr)
+        opt.param_groups[0]["lr"] = lr
+        losses, n_img, t0 = [], 0, time.time()
+        for batch in train_loader:
+            X = batch[0] if isinstance(batch, (tuple, list)) else batch
+            X = shard_batch(X, rank, world).to(device, non_blocking=True)
+            loss = train_step(onet, opt, X)
+            losses.append(loss.item())            # device->host sync every step, as TS:219
+            n_img += X.shape[0] * world
+        ep_loss = float(sum(losses) / max(1, len(losses)))
+        rec = {"epoch": epoch, "loss": ep_loss, "lr": lr, "images_per_s": n_img / max(1e-9, time.time() - t0)}
+        if eval_fn is not None and epoch % eval_every == 0:
+            onet.eval()
+            with torch.no_grad():
+                rec["eval"] = eval_fn(onet, epoch)
+        history.append(rec)
+        if rank == 0:
+            log("%s===Epoch: %04d loss: %.5f, lr: %.10f, %.1f img/s" % (model_name, epoch, ep_loss, lr, rec["images_per_s"]))
+        last = epoch == epochs - 1
+        if out_root and rank == 0 and (last or (schedule == "sim" and epoch == 300)):
+            save_checkpoint(onet, os.path.join(out_root, "%s_epoch_%d.pytorch" % (model_name, epoch)), epoch,
+                            key="epoch" if schedule == "sim" else "save_epoch")
+    return history

@@ -1,0 +1,230 @@
+"""GPU parity, end to end: the HIP-backed Onet (onet_amd / Onet_vanilla_20240606 shim) against
+ (a) golden vectors minted from the REAL reference (tests/golden/*.npz), and
+ (b) the CPU oracle re-run on the same seeded inputs,
+through the reference's own call sequence (TS:209-219): forward -> slice S -> compute_loss ->
+backward [-> Adam].  Tolerance 1e-3 relative fp32 (BASELINE.json north_star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import onet_oracle as orc
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+RTOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _model(C, bshare, dev, train=True):
+    import Onet_vanilla_20240606 as ov          # the drop-in module name the reference trainers import
+    m = ov.Onet(in_chns=C, binit=True, bshare=bshare)
+    m.load_state_dict(orc.onet_state_dict(C, 1981, bshare))
+    m = m.to(dev)
+    m.train(train)
+    return m
+
+
+def _sub(a, H):
+    a = a.detach().cpu().numpy()
+    return a if H <= 40 else (a[:, :, ::37, :] if a.ndim == 4 else a[:, ::37, :])
+
+
+def _close(a, b, what, rtol=RTOL):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    scale = np.abs(b).max() + 1e-30
+    err = np.abs(a - b).max()
+    assert err <= rtol * scale, f"{what}: max err {err:.3e}, scale {scale:.3e}"
+
+
+def _step(m, X):
+    m.zero_grad()
+    Lt, Vt, Ld, Vd, S = m(X)
+    St = S[:, 0].unsqueeze(1)
+    Sd = S[:, 1].unsqueeze(1)
+    loss = m.compute_loss(Lt, St, Ld, Sd)
+    loss.backward()
+    return (Lt, Vt, Ld, Vd, S), loss
+
+
+CASES = ["b2_c1_16", "b2_c1_32", "b2_c3_32", "b2_c1_40", "b3_c1_32", "b2_c1_32_noshare", "b2_c1_256"]
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_train_step_vs_reference_golden(dev, tag):
+    g = np.load(os.path.join(G, f"onet_{tag}.npz"))
+    B, C, H, W, bshare, train, steps = [int(v) for v in g["meta"]]
+    m = _model(C, bool(bshare), dev)
+    X = orc.det_input(B, C, H, W).to(dev)
+    (Lt, Vt, Ld, Vd, S), loss = _step(m, X)
+    assert Lt.shape == (B, 64, H, W) and Vt.shape == (B, 1, H, W) and S.shape == (B, 2, H, W)
+    assert abs(loss.item() - g["losses"][0]) <= RTOL * abs(g["losses"][0])
+    _close(_sub(Vt, H), g["Vt"], "Vt")
+    _close(_sub(Vd, H), g["Vd"], "Vd")
+    _close(_sub(S, H), g["S"], "S")
+    _close(_sub(Lt.sum(1), H), g["Lt_chsum"], "Lt channel sum")
+    _close(_sub(Ld.sum(1), H), g["Ld_chsum"], "Ld channel sum")
+    if "Lt" in g:
+        _close(Lt.detach().cpu().numpy(), g["Lt"], "Lt")
+        _close(Ld.detach().cpu().numpy(), g["Ld"], "Ld")
+    # labels: identical except where the two class probabilities are numerically tied
+    lab = _sub(m.predict_label(S), H).astype(np.uint8)
+    tie = np.abs(g["S"][:, 0] - g["S"][:, 1]) < 1e-3
+    assert np.array_equal(lab[~tie], g["label"][~tie])
+    # all 62 (124 unshared) parameter gradients
+    named = dict(m.named_parameters())
+    for i, n in enumerate(str(s) for s in g["grad_names"]):
+        gr = named[n].grad.detach().reshape(-1).double().cpu()
+        ref_norm = float(g["grad_norms"][i])
+        assert abs(float(gr.norm()) - ref_norm) <= RTOL * ref_norm + 1e-12, (n, float(gr.norm()), ref_norm)
+        k = min(64, gr.numel())
+        tol = RTOL * max(np.abs(g["grad_heads"][i][:k]).max(), ref_norm / np.sqrt(gr.numel()))
+        assert np.abs(gr[:k].numpy() - g["grad_heads"][i][:k]).max() <= tol + 1e-12, n
+    # BN running statistics: two momentum updates per forward when shared (X first, then 1-X)
+    rm = torch.cat([b.reshape(-1) for n, b in m.topu.named_buffers() if n.endswith("running_mean")]).cpu().numpy()
+    rv = torch.cat([b.reshape(-1) for n, b in m.topu.named_buffers() if n.endswith("running_var")]).cpu().numpy()
+    _close(rm, g["bn_rm"][:rm.size], "running_mean")
+    _close(rv, g["bn_rv"][:rv.size], "running_var")
+    nbt = [int(b) for n, b in m.topu.named_buffers() if n.endswith("num_batches_tracked")]
+    assert nbt == [int(v) for v in g["bn_nbt"][:18]]
+
+
+def test_eval_mode_vs_reference_golden(dev):
+    g = np.load(os.path.join(G, "onet_b2_c1_32_eval.npz"))
+    B, C, H, W, bshare, train, steps = [int(v) for v in g["meta"]]
+    m = _model(C, True, dev, train=False)
+    X = orc.det_input(B, C, H, W).to(dev)
+    with torch.no_grad():
+        Lt, Vt, Ld, Vd, S = m(X)
+        loss = m.compute_loss(Lt, S[:, 0].unsqueeze(1), Ld, S[:, 1].unsqueeze(1))
+    assert abs(loss.item() - g["losses"][0]) <= RTOL * abs(g["losses"][0])
+    _close(Vt.cpu().numpy(), g["Vt"], "Vt eval")
+    _close(S.cpu().numpy(), g["S"], "S eval")
+    assert all(int(b) == 0 for n, b in m.named_buffers() if n.endswith("num_batches_tracked"))
+
+
+@pytest.mark.parametrize("fused_adam", [False, True])
+def test_adam_loss_sequence_vs_reference_golden(dev, fused_adam):
+    """Harness contract: 4 x (zero_grad, fwd, loss, bwd, Adam lr 5e-6)."""
+    g = np.load(os.path.join(G, "onet_b2_c1_32_adam4.npz"))
+    B, C, H, W, bshare, train, steps = [int(v) for v in g["meta"]]
+    m = _model(C, True, dev)
+    X = orc.det_input(B, C, H, W).to(dev)
+    if fused_adam:
+        from onet_amd.trainer import FlatAdam
+        opt = FlatAdam(m, lr=5e-6, betas=(0.9, 0.999), eps=1e-8)
+    else:
+        opt = torch.optim.Adam(m.parameters(), lr=5e-6, betas=(0.9, 0.999), eps=1e-8)
+    losses = []
+    for _ in range(steps):
+        opt.zero_grad()
+        _, loss = _step_nozero(m, X)
+        losses.append(loss.item())
+        opt.step()
+    np.testing.assert_allclose(losses, g["losses"], rtol=RTOL)
+    named = dict(m.named_parameters())
+    for i, n in enumerate(str(s) for s in g["param_names"]):
+        p = named[n].detach().reshape(-1).double().cpu()
+        assert abs(float(p.norm()) - g["param_norms"][i]) <= 1e-5 * g["param_norms"][i] + 1e-12, n
+    nbt = [int(b) for n, b in m.topu.named_buffers() if n.endswith("num_batches_tracked")]
+    assert nbt[0] == 2 * steps
+
+
+def _step_nozero(m, X):
+    Lt, Vt, Ld, Vd, S = m(X)
+    loss = m.compute_loss(Lt, S[:, 0].unsqueeze(1), Ld, S[:, 1].unsqueeze(1))
+    loss.backward()
+    return (Lt, Vt, Ld, Vd, S), loss
+
+
+@pytest.mark.parametrize("tag,bilinear", [("convT_pad", False), ("bilinear_pad", True)])
+def test_up_block_vs_reference_golden(dev, tag, bilinear):
+    """Up block alone incl. the F.pad path (12 -> 24 vs skip 25: the NAU-rain shape, OV:92-96)."""
+    import zlib
+    import Onet_vanilla_20240606 as ov
+    g = np.load(os.path.join(G, f"up_{tag}.npz"))
+    h, w, H, W, _ = [int(v) for v in g["meta"]]
+    up = ov.Up(128, 64, bilinear=bilinear)
+    new = {}
+    for k, v in up.state_dict().items():
+        rng = np.random.Generator(np.random.PCG64([3, zlib.crc32(k.encode())]))
+        if v.dtype == torch.long:
+            new[k] = torch.tensor(0)
+        elif k.endswith("running_var"):
+            new[k] = torch.from_numpy((1 + 0.1 * np.abs(rng.standard_normal(tuple(v.shape)))).astype(np.float32))
+        elif v.dim() == 4:
+            fan = v.shape[1] * v.shape[2] * v.shape[3]
+            new[k] = torch.from_numpy((rng.standard_normal(tuple(v.shape)) * np.sqrt(2.0 / fan)).astype(np.float32))
+        elif k.endswith(".weight"):
+            new[k] = torch.from_numpy((1 + 0.1 * rng.standard_normal(tuple(v.shape))).astype(np.float32))
+        else:
+            new[k] = torch.from_numpy((0.1 * rng.standard_normal(tuple(v.shape))).astype(np.float32))
+    up.load_state_dict(new)
+    up = up.to(dev).train()
+    x1 = orc.det_input(2, 64 if bilinear else 128, h, w, seed=21).to(dev).requires_grad_(True)
+    x2 = orc.det_input(2, 64, H, W, seed=22).to(dev).requires_grad_(True)
+    y = up(x1, x2)
+    gy = (orc.det_input(*y.shape, seed=23) - 0.5).to(dev)
+    y.backward(gy)
+    _close(y.detach().cpu().numpy(), g["y"], "Up y")
+    _close(x1.grad.cpu().numpy(), g["dx1"], "Up dx1")
+    _close(x2.grad.cpu().numpy(), g["dx2"], "Up dx2")
+    named = dict(up.named_parameters())
+    for i, n in enumerate(str(s) for s in g["grad_names"]):
+        gr = named[n].grad.detach().reshape(-1).double().cpu()
+        assert abs(float(gr.norm()) - g["grad_norms"][i]) <= RTOL * g["grad_norms"][i] + 1e-12, n
+
+
+def test_vs_oracle_fresh_seed(dev):
+    """Same seeded inputs through the CPU oracle and the HIP path (not a stored fixture)."""
+    B, C, H, W = 4, 1, 64, 48
+    top = orc.clone_state(orc.det_state_dict(C, 77))
+    X = orc.det_input(B, C, H, W, seed=99)
+    (Lt, Vt, Ld, Vd, S), loss, grads = orc.train_mode_step(X, top)
+    import Onet_vanilla_20240606 as ov
+    m = ov.Onet(in_chns=C, binit=True, bshare=True)
+    sd = {}
+    for k, v in orc.det_state_dict(C, 77).items():
+        sd["topu." + k] = v
+        sd["dwnu." + k] = v
+    m.load_state_dict(sd)
+    m = m.to(dev).train()
+    (lt, vt, ld, vd, s), l2 = _step(m, X.to(dev))
+    assert abs(l2.item() - float(loss)) <= RTOL * abs(float(loss))
+    _close(lt.detach().cpu().numpy(), Lt.detach().numpy(), "Lt")
+    _close(vt.detach().cpu().numpy(), Vt.detach().numpy(), "Vt")
+    _close(s.detach().cpu().numpy(), S.detach().numpy(), "S")
+    named = dict(m.topu.named_parameters())
+    for k, gr in grads.items():
+        a = named[k].grad.detach().cpu().double()
+        b = gr.double()
+        assert float((a - b).norm()) <= RTOL * float(b.norm()) + 1e-12, k
+
+
+def test_state_dict_roundtrip_and_sharing(dev):
+    import Onet_vanilla_20240606 as ov
+    m = ov.Onet(1, True, True).to(dev)
+    sd = m.state_dict()
+    assert len(sd) == 232
+    assert m.dwnu is m.topu
+    assert sd["topu.inc.double_conv.0.weight"].data_ptr() == sd["dwnu.inc.double_conv.0.weight"].data_ptr()
+    m2 = ov.Onet(1, False, True)
+    m2.load_state_dict({k: v.cpu() for k, v in sd.items()})
+    for (n1, p1), (n2, p2) in zip(m.named_parameters(), m2.named_parameters()):
+        assert n1 == n2 and torch.equal(p1.detach().cpu(), p2.detach())
+
+
+def test_batch1_16x16_train_raises(dev):
+    """BN needs more than one value per channel in train mode (bottleneck is 1x1 at 16^2, B=1)."""
+    import Onet_vanilla_20240606 as ov
+    m = ov.Onet(1, True, True).to(dev).train()
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel"):
+        m(torch.rand(1, 1, 16, 16, device=dev))

@@ -1,0 +1,267 @@
+"""GPU parity, op by op: every HIP kernel (through the C ABI via onet_amd.ops / autograd
+Functions) against the same op of the CPU oracle's arithmetic (PyTorch CPU fp32) on identical
+seeded inputs.  Tolerance: BASELINE north_star says 1e-3 relative in fp32; single ops are held
+to 2e-4 of the output scale (summation order is the only difference)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from onet_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = np.random.Generator(np.random.PCG64([seed, *shape]))
+    return torch.from_numpy((g.standard_normal(shape) * scale).astype(np.float32))
+
+
+def close(a, b, tol=2e-4, what=""):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = float(b.abs().max()) + 1e-30
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (tol {tol})"
+
+
+CONV_SHAPES = [
+    # B, Cin, Cout, H, W, ks
+    (2, 64, 64, 40, 48, 3),      # pixel-heavy tile, ragged edges
+    (2, 16, 64, 16, 16, 3),      # 16-wide tile
+    (1, 32, 128, 64, 64, 3),     # channel-heavy tile
+    (2, 64, 256, 32, 32, 3),     # deep tile, 32 wide
+    (2, 128, 256, 16, 16, 3),    # deep tile, 16 wide
+    (64, 8, 2048, 16, 16, 3),    # 128-channel tile on 16-wide images
+    (2, 3, 10, 17, 23, 3),       # odd everything (masked channels, scalar weight path)
+    (2, 1, 64, 32, 32, 3),       # stem, Cin = 1
+    (3, 20, 36, 9, 7, 3),        # tiny image
+    (2, 128, 256, 12, 12, 1),    # 1x1 (convT sub-pixel GEMM)
+    (2, 64, 64, 40, 40, 1),
+    (2, 1024, 512, 4, 4, 3),     # very deep, tiny
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,ks", CONV_SHAPES)
+def test_conv_fwd_dgrad_wgrad(dev, B, Cin, Cout, H, W, ks):
+    from onet_amd import ops
+    x = rnd(B, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, ks, ks, seed=2, scale=(2.0 / (Cin * ks * ks)) ** 0.5)
+    g = rnd(B, Cout, H, W, seed=3)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    zr = F.conv2d(xr, wr, None, 1, ks // 2)
+    zr.backward(g)
+
+    xd, wd_, gd = x.to(dev), w.to(dev), g.to(dev)
+    if ks == 3:
+        wf, wdg = ops.pack3x3(wd_)
+    else:
+        # 1x1: packed layouts are plain transposes
+        wf = wd_.reshape(Cout, Cin).t().contiguous().reshape(-1)
+        wdg = wd_.reshape(Cout, Cin).contiguous().reshape(-1)
+    z = ops.conv_fwd(xd, wf, Cout, ks)
+    close(z, zr, what="fwd")
+    dx = ops.conv_fwd(gd, wdg, Cin, ks)
+    close(dx, xr.grad, what="dgrad")
+    dw = ops.conv_wgrad(xd, gd, (Cout, Cin, ks, ks), ks)
+    close(dw, wr.grad, tol=3e-4, what="wgrad")
+
+
+def test_conv_on_channel_slices(dev):
+    """inputs/outputs that are channel-slices of wider (concat) buffers: batch stride != C*H*W"""
+    from onet_amd import ops
+    B, Cin, Cout, H, W = 2, 32, 64, 24, 40
+    big = rnd(B, Cin + 16, H, W, seed=5)
+    w = rnd(Cout, Cin, 3, 3, seed=6, scale=0.1)
+    ref = F.conv2d(big[:, 16:], w, None, 1, 1)
+    bigd = big.to(dev)
+    wf, _ = ops.pack3x3(w.to(dev))
+    outbuf = torch.zeros((B, Cout + 8, H, W), device=dev)
+    ops.conv_fwd(bigd[:, 16:], wf, Cout, 3, out=outbuf[:, 8:])
+    close(outbuf[:, 8:], ref, what="sliced fwd")
+    assert float(outbuf[:, :8].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("B,C,H,W", [(2, 64, 32, 32), (3, 10, 7, 9), (2, 128, 130, 130)])
+def test_bn_relu(dev, training, B, C, H, W):
+    from onet_amd import functional as Fn
+    z = rnd(B, C, H, W, seed=7) * 2 + 0.7
+    gamma = 1 + 0.1 * rnd(C, seed=8)
+    beta = 0.1 * rnd(C, seed=9)
+    rm = 0.1 * rnd(C, seed=10)
+    rv = 1 + 0.1 * rnd(C, seed=11).abs()
+    g = rnd(B, C, H, W, seed=12)
+
+    zr, gr, br = z.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rmr, rvr = rm.clone(), rv.clone()
+    yr = F.relu(F.batch_norm(zr, rmr, rvr, gr, br, training, 0.1, 1e-5))
+    yr.backward(g)
+
+    zd, gd_, bd = z.to(dev).requires_grad_(True), gamma.to(dev).requires_grad_(True), beta.to(dev).requires_grad_(True)
+    rmd, rvd = rm.to(dev), rv.to(dev)
+    y = Fn.BNReLUFn.apply(zd, gd_, bd, rmd, rvd, training, 0.1, 1e-5)
+    y.backward(g.to(dev))
+    close(y, yr, what="bn fwd")
+    close(rmd, rmr, tol=1e-5, what="running_mean")
+    close(rvd, rvr, tol=1e-5, what="running_var")
+    close(zd.grad, zr.grad, tol=5e-4, what="dz")
+    close(gd_.grad, gr.grad, tol=5e-4, what="dgamma")
+    close(bd.grad, br.grad, tol=5e-4, what="dbeta")
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 8, 16, 16), (2, 3, 9, 11), (1, 64, 130, 34)])
+def test_maxpool(dev, B, C, H, W):
+    from onet_amd import functional as Fn
+    x = rnd(B, C, H, W, seed=13)
+    x[:, :, :4, :4] = 0.0          # ties: first maximum must win
+    x = torch.relu(x)
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 2)
+    g = rnd(*yr.shape, seed=14)
+    yr.backward(g)
+    xd = x.to(dev).requires_grad_(True)
+    y = Fn.MaxPool2Fn.apply(xd)
+    y.backward(g.to(dev))
+    assert torch.equal(y.cpu(), yr.detach())
+    assert torch.equal(xd.grad.cpu(), xr.grad)
+
+
+@pytest.mark.parametrize("h,w,Ho,Wo", [(8, 8, 16, 16), (12, 12, 25, 25), (5, 7, 11, 16)])
+def test_up_convT_cat(dev, h, w, Ho, Wo):
+    from onet_amd import functional as Fn
+    from onet_amd import ops
+    B, Cin, Ct, C2 = 2, 64, 32, 32
+    x1, x2 = rnd(B, Cin, h, w, seed=15), rnd(B, C2, Ho, Wo, seed=16)
+    wt, bt = rnd(Cin, Ct, 2, 2, seed=17, scale=0.1), rnd(Ct, seed=18, scale=0.1)
+    a, b_, c, d = [t.clone().requires_grad_(True) for t in (x1, x2, wt, bt)]
+    u = F.conv_transpose2d(a, c, d, stride=2)
+    dy, dx = Ho - u.shape[2], Wo - u.shape[3]
+    u = F.pad(u, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
+    ref = torch.cat([b_, u], 1)
+    g = rnd(*ref.shape, seed=19)
+    ref.backward(g)
+    A, Bt, Cw, Db = [t.to(dev).requires_grad_(True) for t in (x1, x2, wt, bt)]
+    out = Fn.UpConvTCatFn.apply(A, Bt, Cw, Db, ops.packT2x2(Cw))
+    out.backward(g.to(dev))
+    close(out, ref, what="up fwd")
+    close(A.grad, a.grad, what="dx1")
+    close(Bt.grad, b_.grad, tol=1e-6, what="dx2")
+    close(Cw.grad, c.grad, tol=3e-4, what="dW")
+    close(Db.grad, d.grad, tol=3e-4, what="dbias")
+
+
+@pytest.mark.parametrize("h,w,Ho,Wo", [(8, 8, 16, 16), (12, 12, 25, 25), (1, 1, 2, 2)])
+def test_up_bilinear_cat(dev, h, w, Ho, Wo):
+    from onet_amd import functional as Fn
+    B, C1, C2 = 2, 16, 8
+    x1, x2 = rnd(B, C1, h, w, seed=20), rnd(B, C2, Ho, Wo, seed=21)
+    a, b_ = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    u = F.interpolate(a, scale_factor=2, mode="bilinear", align_corners=True)
+    dy, dx = Ho - u.shape[2], Wo - u.shape[3]
+    ref = torch.cat([b_, F.pad(u, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])], 1)
+    g = rnd(*ref.shape, seed=22)
+    ref.backward(g)
+    A, Bt = x1.to(dev).requires_grad_(True), x2.to(dev).requires_grad_(True)
+    out = Fn.UpBilinearCatFn.apply(A, Bt)
+    out.backward(g.to(dev))
+    close(out, ref, tol=1e-5, what="bilinear fwd")
+    close(A.grad, a.grad, tol=1e-5, what="bilinear dx1")
+    close(Bt.grad, b_.grad, tol=1e-6, what="bilinear dx2")
+
+
+def test_head_softmax(dev):
+    from onet_amd import functional as Fn
+    B, C, H, W = 2, 64, 20, 24
+    ts = [rnd(B, C, H, W, seed=30 + i).abs() * 0.5 for i in range(4)]
+    r = [t.clone().requires_grad_(True) for t in ts]
+    Vt = (r[0] * r[1]).sum(1, keepdim=True)
+    Vd = (r[2] * r[3]).sum(1, keepdim=True)
+    S = torch.softmax(torch.cat([Vt, Vd], 1), 1)
+    gV, gS = rnd(B, 1, H, W, seed=40), rnd(B, 2, H, W, seed=41)
+    (Vt * gV).sum().add((Vd * gV * 0.5).sum()).add((S * gS).sum()).backward()
+    d = [t.to(dev).requires_grad_(True) for t in ts]
+    vt, vd, s = Fn.HeadSoftmaxFn.apply(*d)
+    ((vt * gV.to(dev)).sum() + (vd * gV.to(dev) * 0.5).sum() + (s * gS.to(dev)).sum()).backward()
+    close(vt, Vt, what="Vt")
+    close(vd, Vd, what="Vd")
+    close(s, S, tol=1e-5, what="S")
+    for i in range(4):
+        close(d[i].grad, r[i].grad, what=f"head grad {i}")
+
+
+def test_log1pexp_table_and_inplace(dev):
+    from onet_amd import Onet
+    g = np.load(os.path.join(G, "log1pexp.npz"))
+    m = Onet(1)
+    x = torch.tensor(g["x"], device=dev, requires_grad=True)
+    xin = x * 1.0
+    y = m.log1pexp(xin)
+    assert y.data_ptr() == xin.data_ptr()          # mutates and returns its argument (OV:237-251)
+    y.sum().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["y"], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["dy"], rtol=2e-5, atol=1e-30)
+
+
+def test_jsd_loss_extreme_golden(dev):
+    """compute_loss + all four gradients against the REAL reference on inputs that hit every
+    log1pexp branch (x<=-37 -> ln2, softplus, x+exp(-x), identity)."""
+    from onet_amd import Onet
+    g = np.load(os.path.join(G, "loss_extreme.npz"))
+    m = Onet(1)
+    Lt, Ld, Vt, Vd = [torch.tensor(g[k], device=dev, requires_grad=True) for k in ("Lt", "Ld", "Vt", "Vd")]
+    S = m.softmax(torch.cat([Vt, Vd], 1))
+    loss = m.compute_loss(Lt, S[:, 0].unsqueeze(1), Ld, S[:, 1].unsqueeze(1))
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    for t, k in ((Lt, "dLt"), (Ld, "dLd"), (Vt, "dVt"), (Vd, "dVd")):
+        close(t.grad, torch.tensor(g[k]), tol=1e-4, what=k)
+
+
+def test_argmax_ties(dev):
+    from onet_amd import Onet
+    S = torch.tensor([[[[0.5, 0.2, 0.8]], [[0.5, 0.8, 0.2]]]], device=dev)
+    Y = Onet(1).predict_label(S)
+    assert Y.dtype == torch.int64 and Y.tolist() == [[[0, 1, 0]]]
+
+
+def test_adam_matches_torch(dev):
+    from onet_amd import ops
+    n = 10007
+    p0, g0 = rnd(n, seed=50), rnd(n, seed=51)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    p = torch.zeros(n + 1, device=dev)[:n]
+    p.copy_(p0)
+    m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    for step in range(1, 4):
+        gk = g0 * step
+        pr.grad = gk.clone()
+        opt.step()
+        ops.adam_step(p, gk.to(dev), m, v, 1e-3, 0.9, 0.999, 1e-8, 0.0, step)
+    close(p, pr, tol=1e-6, what="adam params")
+
+
+def test_complement_clip(dev):
+    from onet_amd import ops
+    x = rnd(2, 1, 16, 16, seed=60) * 0.8 + 0.5
+    close(ops.complement_clip(x.to(dev), 0.1), torch.clip(1 - x + 0.1, 0, 1), tol=1e-7, what="clip")
+
+
+def test_cpu_tensor_is_refused():
+    from onet_amd import Onet
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Onet(1)(torch.zeros(2, 1, 16, 16))

@@ -1,0 +1,212 @@
+"""CPU-side tests: the C-ABI library loads and exports every symbol the header declares, the
+Python mirror has the reference's surface (names, signatures, state_dict keys, init behaviour),
+the host logic (schedules, sharding, flat buffers) is right, and the product path refuses to
+compute without a GPU (no CPU fallback)."""
+import ctypes
+import inspect
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import onet_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from onet_amd import _lib
+    protos = _lib.parse_header()
+    assert len(protos) >= 30
+    lib = ctypes.CDLL(_lib.LIBPATH) if os.path.exists(_lib.LIBPATH) else _lib.load()
+    for name in protos:
+        assert hasattr(lib, name), name
+    lib2 = _lib.load()
+    assert lib2.onet_abi_version() == 1
+    assert lib2.onet_jsd_nparts() > 0
+    assert lib2.onet_conv_wgrad_ws_bytes(32, 64, 64, 256, 256, 3) > 0
+
+
+def test_bad_arguments_return_error_codes_not_crashes():
+    from onet_amd import _lib
+    lib = _lib.load()
+    rc = lib.onet_conv_fwd(None, 0, None, None, 0, None, 1, 1, 1, 1, 1, 3, None)
+    assert rc == -1 and b"null" in lib.onet_last_error()
+    with pytest.raises(_lib.OnetHipError, match="ks must be 1 or 3"):
+        _lib.call("onet_conv_fwd", 8, 64, 8, 8, 64, None, 1, 1, 1, 8, 8, 5, None)
+
+
+def test_module_surface_matches_reference_signatures():
+    import Onet_vanilla_20240606 as ov
+    assert list(inspect.signature(ov.DoubleConv.__init__).parameters)[1:] == ["in_channels", "out_channels", "mid_channels"]
+    assert list(inspect.signature(ov.Down.__init__).parameters)[1:] == ["in_channels", "out_channels"]
+    sig = inspect.signature(ov.Up.__init__).parameters
+    assert list(sig)[1:] == ["in_channels", "out_channels", "bilinear"] and sig["bilinear"].default is True
+    sig = inspect.signature(ov.UNet.__init__).parameters
+    assert [(k, v.default) for k, v in list(sig.items())[1:]] == [("n_channels", 1), ("n_classes", 1), ("binit", False), ("bilinear", False)]
+    sig = inspect.signature(ov.Onet.__init__).parameters
+    assert [(k, v.default) for k, v in list(sig.items())[1:]] == [("in_chns", 1), ("binit", False), ("bshare", True)]
+    for meth in ("forward", "predict_label", "get_label", "jensen_shannon_divergence", "log1pexp", "compute_loss"):
+        assert callable(getattr(ov.Onet, meth))
+    assert list(inspect.signature(ov.Onet.compute_loss).parameters)[1:] == ["Lt", "St", "Ld", "Sd"]
+    assert list(inspect.signature(ov.Onet.jensen_shannon_divergence).parameters)[1:] == ["Li", "Si", "Sprime"]
+
+
+@pytest.mark.parametrize("in_chns,bshare", [(1, True), (3, True), (1, False)])
+def test_state_dict_keys_and_shapes_match_reference_layout(in_chns, bshare):
+    from onet_amd import Onet
+    m = Onet(in_chns=in_chns, binit=True, bshare=bshare)
+    sd = m.state_dict()
+    ref = orc.onet_state_dict(in_chns, 1981, bshare)
+    assert list(sd.keys()) == list(ref.keys())
+    assert len(sd) == 232
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(ref[k].shape), k
+        assert sd[k].dtype == ref[k].dtype, k
+    assert (m.dwnu is m.topu) == bshare
+    n = sum(p.numel() for p in m.parameters())
+    assert n == (31036416 if in_chns == 1 else 31036416 + 2 * 64 * 9) * (1 if bshare else 2)
+    assert len(list(m.parameters())) == (62 if bshare else 124)
+    m.load_state_dict(ref)      # reference-format checkpoints load
+    assert m.bias == 0 and isinstance(m.softmax, torch.nn.Softmax2d)
+
+
+def test_init_follows_reference_rules():
+    """binit: Kaiming-normal(fan_in, relu) on every nn.Conv2d, BN weight 1 / bias 0; ConvTranspose2d keeps
+    torch's default init with a NON-zero bias."""
+    from onet_amd import Onet
+    torch.manual_seed(0)
+    m = Onet(1, binit=True)
+    w = m.topu.down2.maxpool_conv[1].double_conv[3].weight
+    assert abs(float(w.std()) - math.sqrt(2.0 / (256 * 9))) < 0.02 * math.sqrt(2.0 / (256 * 9))
+    bn = m.topu.inc.double_conv[1]
+    assert float(bn.weight.min()) == 1.0 and float(bn.bias.abs().max()) == 0.0
+    up = m.topu.up1.up
+    assert isinstance(up, torch.nn.ConvTranspose2d) and not isinstance(up, torch.nn.Conv2d)
+    bound = 1.0 / math.sqrt(512 * 4)
+    assert float(up.weight.abs().max()) <= bound + 1e-6 and float(up.bias.abs().max()) > 0
+
+
+def test_cpu_tensor_is_refused_loudly():
+    from onet_amd import Onet
+    m = Onet(1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(2, 1, 16, 16))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.compute_loss(torch.zeros(1, 64, 4, 4), torch.zeros(1, 1, 4, 4), torch.zeros(1, 64, 4, 4), torch.zeros(1, 1, 4, 4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.predict_label(torch.zeros(1, 2, 4, 4))
+
+
+def test_product_does_not_import_the_oracle():
+    import re
+    pkg = os.path.join(ROOT, "onet_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn
+    assert not re.search(r"^\s*(from|import)\s+oracle", open(os.path.join(ROOT, "Onet_vanilla_20240606.py")).read(), flags=re.M)
+
+
+def test_sim_lr_schedule_matches_reference_loop():
+    from onet_amd.trainer import sim_lr
+    lr, seen = 5e-6, []
+    for epoch in range(301):
+        seen.append(lr)
+        if epoch % 100 == 0 and epoch > 0:     # TS:248-249
+            lr *= 0.5
+    assert [sim_lr(e) for e in range(301)] == pytest.approx(seen, rel=1e-12)
+
+
+def test_cosine_schedule_matches_torch_scheduler():
+    from onet_amd.trainer import cosine_warm_restarts_lr
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=1e-4)
+    sch = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt, T_0=300, T_mult=2, eta_min=1e-6)
+    for epoch in range(1000):
+        assert cosine_warm_restarts_lr(epoch) == pytest.approx(opt.param_groups[0]["lr"], rel=1e-9), epoch
+        opt.step()
+        sch.step()
+
+
+def test_shard_batch_and_flat_buffers():
+    from onet_amd.trainer import FlatAdam, shard_batch
+    X = torch.arange(8 * 3).reshape(8, 3)
+    assert torch.equal(torch.cat([shard_batch(X, r, 4) for r in range(4)]), X)
+    with pytest.raises(ValueError):
+        shard_batch(X, 0, 3)
+    lin = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    ref = [p.detach().clone() for p in lin.parameters()]
+    opt = FlatAdam(lin, lr=1e-3)
+    assert opt.numel % 4 == 0 and all(o % 4 == 0 for o in opt.offsets)
+    for p, r, off in zip(lin.parameters(), ref, opt.offsets):
+        assert torch.equal(p.detach(), r)
+        assert p.data_ptr() == opt.flat.data_ptr() + 4 * off
+        assert p.grad.data_ptr() == opt.gflat.data_ptr() + 4 * off
+    lin(torch.ones(4, 5)).sum().backward()
+    assert float(opt.gflat.abs().sum()) > 0            # autograd accumulated INTO the flat buffer
+    lin.zero_grad()                                     # set_to_none: grads detach from the flat buffer
+    lin(torch.ones(4, 5)).sum().backward()
+    opt.zero_grad()
+    assert float(opt.gflat.abs().sum()) == 0
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        opt.step()                                      # the fused Adam kernel has no CPU path
+
+
+def test_synthetic_clutter_generator():
+    from onet_amd import data
+    X, lab = data.make_clutter_batch(2, 64, 64, seed=3, with_labels=True)
+    assert X.shape == (2, 1, 64, 64) and X.dtype == np.float32 and lab.shape == (2, 64, 64)
+    assert float(X.min()) == 0.0 and float(X.max()) == 1.0
+    X2 = data.make_clutter_batch(2, 64, 64, seed=3)
+    assert np.array_equal(X, X2)
+    # K-distributed amplitude is heavier-tailed than Rayleigh: scale-free moment ratio E[a^4]/E[a^2]^2 > 2
+    a = data.k_clutter_frame(np.random.Generator(np.random.PCG64(1)), 256)
+    assert np.mean(a ** 4) / np.mean(a ** 2) ** 2 > 2.1
+
+
+def test_up_block_oracle_vs_reference_golden():
+    """oracle.upsample_cat (convT and bilinear, F.pad path) pinned to the real reference's Up block."""
+    import zlib
+    for tag, bilinear in (("convT_pad", False), ("bilinear_pad", True)):
+        g = np.load(os.path.join(ROOT, "tests", "golden", f"up_{tag}.npz"))
+        h, w, H, W, _ = [int(v) for v in g["meta"]]
+        names = (["up.weight", "up.bias"] if not bilinear else [])
+        mid = 64
+        shapes = {"up.weight": (128, 64, 2, 2), "up.bias": (64,)}
+        st = {}
+        for k in names:
+            rng = np.random.Generator(np.random.PCG64([3, zlib.crc32(k.encode())]))
+            shp = shapes[k]
+            if len(shp) == 4:
+                st["blk." + k] = torch.from_numpy((rng.standard_normal(shp) * np.sqrt(2.0 / (shp[1] * 4))).astype(np.float32))
+            else:
+                st["blk." + k] = torch.from_numpy((0.1 * rng.standard_normal(shp)).astype(np.float32))
+        x1 = orc.det_input(2, 64 if bilinear else 128, h, w, seed=21)
+        x2 = orc.det_input(2, 64, H, W, seed=22)
+        cat = orc.upsample_cat(x1, x2, st, "blk", bilinear=bilinear)
+        assert cat.shape == (2, 128, H, W)
+        # first conv of the block (in -> mid) on the concat must reproduce the reference's y after BN/ReLU x2:
+        for idx, (ci, co) in ((0, (128, mid)), (3, (mid, 64))):
+            for suffix, shp in ((f"conv.double_conv.{idx}.weight", (co, ci, 3, 3)),):
+                rng = np.random.Generator(np.random.PCG64([3, zlib.crc32(suffix.encode())]))
+                st["w%d" % idx] = torch.from_numpy((rng.standard_normal(shp) * np.sqrt(2.0 / (ci * 9))).astype(np.float32))
+            b = idx + 1
+            for nm in ("weight", "bias", "running_mean", "running_var"):
+                key = f"conv.double_conv.{b}.{nm}"
+                rng = np.random.Generator(np.random.PCG64([3, zlib.crc32(key.encode())]))
+                if nm == "running_var":
+                    v = 1 + 0.1 * np.abs(rng.standard_normal((co,)))
+                elif nm == "weight":
+                    v = 1 + 0.1 * rng.standard_normal((co,))
+                else:
+                    v = 0.1 * rng.standard_normal((co,))
+                st[f"bn{idx}.{nm}"] = torch.from_numpy(v.astype(np.float32))
+        y = cat
+        for idx in (0, 3):
+            y = torch.nn.functional.conv2d(y, st["w%d" % idx], None, 1, 1)
+            y = torch.relu(torch.nn.functional.batch_norm(y, st[f"bn{idx}.running_mean"].clone(), st[f"bn{idx}.running_var"].clone(),
+                                                          st[f"bn{idx}.weight"], st[f"bn{idx}.bias"], True, 0.1, 1e-5))
+        np.testing.assert_allclose(y.numpy(), g["y"], rtol=1e-4, atol=1e-5)
