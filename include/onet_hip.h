@@ -57,7 +57,7 @@ int onet_convT2x2_pack_weights(const float* w, float* wp_fwd, float* wp_dgrad,
  * ks in {1,3}, p = ks/2, zero padding, stride 1, no bias (OV:47,51 via F.conv2d).
  * dgrad is the same call with wp_dgrad and Cin/Cout swapped.
  * bn_part (nullable): per-block partial sums for BatchNorm statistics,
- *   layout [nparts][Cout][2] floats (sum, sum of squares), nparts from
+ *   layout [nparts][Cout][3] floats (n, mean, M2), nparts from
  *   onet_conv_fwd_nparts(); consumed by onet_bn_finalize. */
 int onet_conv_fwd(const float* x, int64_t x_bs, const float* wp, float* z, int64_t z_bs,
                   float* bn_part, int B, int Cin, int Cout, int H, int W, int ks, void* stream);
@@ -76,29 +76,32 @@ int onet_conv_wgrad(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs
 int64_t onet_conv_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W, int ks);
 
 /* ---- K2/K3: BatchNorm2d (+ReLU) ---------------------------------------- */
-/* partial per-channel (sum, sumsq) of z over B*HW: part [nparts][C][2].  (standalone
- * statistics pass; the conv epilogue can emit the same partials instead) */
+/* Welford partials of z per channel: part [nparts][C][3] = (n_k, mean_k, M2_k = sum (z-mean_k)^2)
+ * over nparts = B*chunks slices of the B*HW values (standalone statistics pass; the conv epilogue
+ * can emit the same records instead).  Robust where E[z^2]-mean^2 is not (tiny counts, |mean|>>std). */
 int onet_bn_stats_partial(const float* z, int64_t z_bs, float* part, int nparts,
                           int B, int C, int HW, void* stream);
 /* train-mode finalize (OV:48,52 -> F.batch_norm(training=True)):
- *   mean = S/N, var = SS/N - mean^2 (accumulated in fp64), invstd = rsqrt(var+eps)
- *   scale = gamma*invstd, shift = beta - mean*scale
+ *   Chan merge of the partials in fp64: mean, var = M2/N (biased), invstd = rsqrt(var+eps)
+ *   scale = gamma*invstd
  *   running_mean = (1-m)*running_mean + m*mean
  *   running_var  = (1-m)*running_var  + m*var*N/(N-1)     (unbiased, verified SURVEY §8c)
- * save = [4][C]: mean, invstd, scale, shift.  running_* may be NULL. */
+ * save = [4][C]: mean, invstd, scale, beta.  running_* may be NULL. */
 int onet_bn_finalize(const float* part, int nparts, int64_t count, const float* gamma,
                      const float* beta, float* running_mean, float* running_var,
                      float momentum, float eps, float* save, int C, void* stream);
 /* eval-mode coefficients from running stats: same `save` layout. */
 int onet_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, float* save, int C, void* stream);
-/* a = max(0, z*scale + shift)   (BN + nn.ReLU, OV:48-49) */
+/* a = max(0, (z-mean)*scale + beta)   (BN + nn.ReLU, OV:48-49) */
 int onet_bn_relu_apply(const float* z, int64_t z_bs, float* a, int64_t a_bs, const float* save,
                        int B, int C, int HW, void* stream);
-/* backward of BN(train)+ReLU.  dy = da * (z*scale+shift > 0);
- * pass 1: part2 [nparts][C][2] = (sum dy, sum dy*xhat);
- * finalize: dgamma (+)= sum dy*xhat, dbeta (+)= sum dy, coef [2][C] = (sum dy / N, sum dy*xhat / N);
- * pass 2: dz = scale * (dy - c1 - xhat*c2)     [train]   or  dz = scale*dy [eval: coef NULL] */
+/* backward of BN(train)+ReLU.  dy = da * ((z-mean)*scale+beta > 0);
+ * pass 1: part2 [nparts][C][4] = (sum dy, sum dy*xhat) as (hi, lo) float pairs of fp64 sums;
+ * finalize: dgamma (+)= sum dy*xhat, dbeta (+)= sum dy, coef [4][C] = (hi, lo) pairs of
+ *           c1 = sum dy / N and c2 = sum dy*xhat / N;
+ * pass 2: dz = scale * (dy - c1 - xhat*c2)     [train]   or  dz = scale*dy [eval: coef NULL],
+ *         evaluated in fp64 per element like ATen's CPU kernel (accscalar_t = double). */
 int onet_bn_relu_bwd_reduce(const float* da, int64_t da_bs, const float* z, int64_t z_bs,
                             const float* save, float* part2, int nparts, int B, int C, int HW,
                             void* stream);
@@ -123,9 +126,10 @@ int onet_maxpool2_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_
 int onet_pixel_shuffle2_bias(const float* sub, const float* bias, float* y, int64_t y_bs,
                              int B, int C, int h, int w, int Ho, int Wo, int pt, int pl, void* stream);
 /* inverse gather for backward: sub[b][q*C+co][y][x] = dy[b][co][pt+2y+dy][pl+2x+dx];
- * dy planes are Ho x Wo; dbias (nullable) (+)= sum over b,y,x,q. */
-int onet_space_to_depth2(const float* dy, int64_t dy_bs, float* sub, float* dbias, int accumulate,
-                         int B, int C, int h, int w, int Ho, int Wo, int pt, int pl, void* stream);
+ * dy planes are Ho x Wo; dbias (nullable) (+)= sum over b,y,x,q (needs scratch: B*C doubles). */
+int onet_space_to_depth2(const float* dy, int64_t dy_bs, float* sub, float* dbias, double* scratch,
+                         int accumulate, int B, int C, int h, int w, int Ho, int Wo, int pt, int pl,
+                         void* stream);
 /* strided batch copy of a [B][n] block (torch.cat first half, OV:100) */
 int onet_copy_strided(const float* src, int64_t src_bs, float* dst, int64_t dst_bs,
                       int B, int64_t n, void* stream);

@@ -6,66 +6,94 @@
 
 using namespace onet;
 
-// partial (sum, sumsq) over one image plane chunk: part[p][c][2], p = b*chunks + chunk
+// Welford-style partial over one image plane chunk: part[p][c][3] = (n_k, mean_k, M2_k) with
+// M2_k = sum (z - mean_k)^2 taken in a second pass over the (L2-resident) chunk.  E[z^2]-mean^2
+// in fp32 loses the variance when |mean| >> std or when B*H*W is tiny (1x1 bottleneck at 16^2).
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ z, int64_t z_bs,
                                                                float* __restrict__ part, int C, int HW,
                                                                int chunks, int chunk_len) {
-    __shared__ float red[8];
+    __shared__ double red[8];
+    __shared__ double bcast;
     const int c = blockIdx.x % C;
     const int p = blockIdx.x / C;
     const int b = p / chunks, ch = p % chunks;
     const float* src = z + (int64_t)b * z_bs + (int64_t)c * HW;
     const int beg = ch * chunk_len;
     const int end = min(beg + chunk_len, HW);
-    float v[2] = {0.f, 0.f};
-    if (((HW & 3) == 0) && ((z_bs & 3) == 0) && ((chunk_len & 3) == 0)) {
+    const bool vec = ((HW & 3) == 0) && ((z_bs & 3) == 0) && ((chunk_len & 3) == 0);
+    // fp64 accumulation like ATen's CPU batch norm (acc_type<float> = double); free in an HBM-bound pass
+    double v[1] = {0.0};
+    if (vec) {
         for (int i = beg + threadIdx.x * 4; i < end; i += 1024) {
             const float4 q = *reinterpret_cast<const float4*>(src + i);
-            v[0] += (q.x + q.y) + (q.z + q.w);
-            v[1] += (q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w);
+            v[0] += ((double)q.x + (double)q.y) + ((double)q.z + (double)q.w);
+        }
+    } else {
+        for (int i = beg + threadIdx.x; i < end; i += 256) v[0] += (double)src[i];
+    }
+    block_sum_256<double, 1>(v, red);
+    const double n = (double)(end - beg);
+    if (threadIdx.x == 0) bcast = v[0] / n;
+    __syncthreads();
+    const double mean = bcast;
+    double m2[1] = {0.0};
+    if (vec) {
+        for (int i = beg + threadIdx.x * 4; i < end; i += 1024) {
+            const float4 q = *reinterpret_cast<const float4*>(src + i);
+            const double d0 = q.x - mean, d1 = q.y - mean, d2 = q.z - mean, d3 = q.w - mean;
+            m2[0] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         }
     } else {
         for (int i = beg + threadIdx.x; i < end; i += 256) {
-            const float q = src[i];
-            v[0] += q;
-            v[1] += q * q;
+            const double d = src[i] - mean;
+            m2[0] += d * d;
         }
     }
-    block_sum_256<float, 2>(v, red);
+    __syncthreads();   // red[] is reused
+    block_sum_256<double, 1>(m2, red);
     if (threadIdx.x == 0) {
-        part[((int64_t)p * C + c) * 2 + 0] = v[0];
-        part[((int64_t)p * C + c) * 2 + 1] = v[1];
+        float* o = part + ((int64_t)p * C + c) * 3;
+        o[0] = (float)n;
+        o[1] = (float)mean;
+        o[2] = (float)(m2[0] + n * (mean - (double)(float)mean) * (mean - (double)(float)mean));  // M2 about the ROUNDED mean
     }
 }
 
-// one wave per channel: fp64 reduction of the partials, then the BN coefficients
-__global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict__ part, int nparts, double count,
+// one wave per channel: Chan's parallel merge of the (n, mean, M2) partials in fp64, then the BN coefficients
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict__ part, int nparts,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* running_mean,
                                                          float* running_var, float momentum, float eps,
                                                          float* __restrict__ save, int C) {
     const int c = blockIdx.x;
-    double s = 0.0, ss = 0.0;
+    double n = 0.0, s = 0.0;
     for (int p = threadIdx.x; p < nparts; p += 64) {
-        s += (double)part[((int64_t)p * C + c) * 2 + 0];
-        ss += (double)part[((int64_t)p * C + c) * 2 + 1];
+        const float* o = part + ((int64_t)p * C + c) * 3;
+        n += (double)o[0];
+        s += (double)o[0] * (double)o[1];
     }
+    n = wave_sum(n);
     s = wave_sum(s);
-    ss = wave_sum(ss);
+    const double mean = s / n;
+    double m2 = 0.0;
+    for (int p = threadIdx.x; p < nparts; p += 64) {
+        const float* o = part + ((int64_t)p * C + c) * 3;
+        const double d = (double)o[1] - mean;
+        m2 += (double)o[2] + (double)o[0] * d * d;
+    }
+    m2 = wave_sum(m2);
     if (threadIdx.x == 0) {
-        const double mean = s / count;
-        double var = ss / count - mean * mean;
-        if (var < 0.0) var = 0.0;
+        const double var = m2 / n;
         const float invstd = (float)(1.0 / sqrt(var + (double)eps));
         const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
         const float scale = g * invstd;
         save[c] = (float)mean;
         save[C + c] = invstd;
         save[2 * C + c] = scale;
-        save[3 * C + c] = bt - (float)mean * scale;
+        save[3 * C + c] = bt;
         if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
         if (running_var) {
-            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            const double unb = n > 1.0 ? m2 / (n - 1.0) : var;
             running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
         }
     }
@@ -81,49 +109,52 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
     save[c] = rm[c];
     save[C + c] = invstd;
     save[2 * C + c] = scale;
-    save[3 * C + c] = bt - rm[c] * scale;
+    save[3 * C + c] = bt;
 }
 
-// a = max(0, z*scale + shift); one block per 4096-element chunk of a (b, c) plane
+// a = max(0, (z-mean)*scale + beta)  (the centred form: z*scale+shift cancels badly when |mean| >> std); one block per 4096-element chunk of a (b, c) plane
 __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restrict__ z, int64_t z_bs,
                                                             float* __restrict__ a, int64_t a_bs,
                                                             const float* __restrict__ save, int C, int HW,
                                                             int chunks) {
     const int plane = blockIdx.x / chunks, ch = blockIdx.x % chunks;
     const int b = plane / C, c = plane % C;
-    const float sc = save[2 * C + c], sh = save[3 * C + c];
+    const float mean = save[c], sc = save[2 * C + c], sh = save[3 * C + c];
     const float* src = z + (int64_t)b * z_bs + (int64_t)c * HW;
     float* dst = a + (int64_t)b * a_bs + (int64_t)c * HW;
     const int beg = ch * 4096, end = min(beg + 4096, HW);
     if (((HW & 3) == 0) && ((z_bs & 3) == 0) && ((a_bs & 3) == 0)) {
         for (int i = beg + threadIdx.x * 4; i < end; i += 1024) {
             float4 q = *reinterpret_cast<const float4*>(src + i);
-            q.x = fmaxf(fmaf(q.x, sc, sh), 0.f);
-            q.y = fmaxf(fmaf(q.y, sc, sh), 0.f);
-            q.z = fmaxf(fmaf(q.z, sc, sh), 0.f);
-            q.w = fmaxf(fmaf(q.w, sc, sh), 0.f);
+            q.x = fmaxf(fmaf(q.x - mean, sc, sh), 0.f);
+            q.y = fmaxf(fmaf(q.y - mean, sc, sh), 0.f);
+            q.z = fmaxf(fmaf(q.z - mean, sc, sh), 0.f);
+            q.w = fmaxf(fmaf(q.w - mean, sc, sh), 0.f);
             *reinterpret_cast<float4*>(dst + i) = q;
         }
     } else {
-        for (int i = beg + threadIdx.x; i < end; i += 256) dst[i] = fmaxf(fmaf(src[i], sc, sh), 0.f);
+        for (int i = beg + threadIdx.x; i < end; i += 256) dst[i] = fmaxf(fmaf(src[i] - mean, sc, sh), 0.f);
     }
 }
 
-// backward pass 1: part2[p][c] = (sum dy, sum dy*xhat), dy = da * [z*scale+shift > 0]
+// backward pass 1: part2[p][c] = (sum dy, sum dy*xhat), dy = da * [(z-mean)*scale+beta > 0].
+// Sums are taken in fp64 (ATen's CPU kernel accumulates in double): both sums cancel heavily
+// (BN outputs are zero-mean), so fp32 accumulation would cost orders of magnitude of accuracy.
 __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const float* __restrict__ da, int64_t da_bs,
                                                                  const float* __restrict__ z, int64_t z_bs,
                                                                  const float* __restrict__ save,
                                                                  float* __restrict__ part2, int C, int HW,
                                                                  int chunks, int chunk_len) {
-    __shared__ float red[8];
+    __shared__ double red[8];
     const int c = blockIdx.x % C;
     const int p = blockIdx.x / C;
     const int b = p / chunks, ch = p % chunks;
     const float mean = save[c], invstd = save[C + c], sc = save[2 * C + c], sh = save[3 * C + c];
+    const double meand = mean, invd = invstd;
     const float* zs = z + (int64_t)b * z_bs + (int64_t)c * HW;
     const float* ds = da + (int64_t)b * da_bs + (int64_t)c * HW;
     const int beg = ch * chunk_len, end = min(beg + chunk_len, HW);
-    float v[2] = {0.f, 0.f};
+    double v[2] = {0.0, 0.0};
     if (((HW & 3) == 0) && ((z_bs & 3) == 0) && ((da_bs & 3) == 0) && ((chunk_len & 3) == 0)) {
         for (int i = beg + threadIdx.x * 4; i < end; i += 1024) {
             const float4 q = *reinterpret_cast<const float4*>(zs + i);
@@ -131,22 +162,26 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const float* __
             const float zz[4] = {q.x, q.y, q.z, q.w}, gg[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float dy = fmaf(zz[k], sc, sh) > 0.f ? gg[k] : 0.f;
+                const double dy = fmaf(zz[k] - mean, sc, sh) > 0.f ? (double)gg[k] : 0.0;
                 v[0] += dy;
-                v[1] += dy * ((zz[k] - mean) * invstd);
+                v[1] += dy * (((double)zz[k] - meand) * invd);
             }
         }
     } else {
         for (int i = beg + threadIdx.x; i < end; i += 256) {
-            const float dy = fmaf(zs[i], sc, sh) > 0.f ? ds[i] : 0.f;
+            const double dy = fmaf(zs[i] - mean, sc, sh) > 0.f ? (double)ds[i] : 0.0;
             v[0] += dy;
-            v[1] += dy * ((zs[i] - mean) * invstd);
+            v[1] += dy * (((double)zs[i] - meand) * invd);
         }
     }
-    block_sum_256<float, 2>(v, red);
+    block_sum_256<double, 2>(v, red);
     if (threadIdx.x == 0) {
-        part2[((int64_t)p * C + c) * 2 + 0] = v[0];
-        part2[((int64_t)p * C + c) * 2 + 1] = v[1];
+        // two floats per sum (hi + lo) keep ~48 bits through the float partial buffer
+        float* o = part2 + ((int64_t)p * C + c) * 4;
+        o[0] = (float)v[0];
+        o[1] = (float)(v[0] - (double)o[0]);
+        o[2] = (float)v[1];
+        o[3] = (float)(v[1] - (double)o[2]);
     }
 }
 
@@ -156,22 +191,29 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __rest
     const int c = blockIdx.x;
     double s = 0.0, sx = 0.0;
     for (int p = threadIdx.x; p < nparts; p += 64) {
-        s += (double)part2[((int64_t)p * C + c) * 2 + 0];
-        sx += (double)part2[((int64_t)p * C + c) * 2 + 1];
+        const float* o = part2 + ((int64_t)p * C + c) * 4;
+        s += (double)o[0] + (double)o[1];
+        sx += (double)o[2] + (double)o[3];
     }
     s = wave_sum(s);
     sx = wave_sum(sx);
     if (threadIdx.x == 0) {
         if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s : (float)s;
         if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)sx : (float)sx;
-        if (coef) {
-            coef[c] = (float)(s / count);
-            coef[C + c] = (float)(sx / count);
+        if (coef) {   // (hi, lo) float pairs of c1 = sum dy / N and c2 = sum dy*xhat / N
+            const double c1 = s / count, c2 = sx / count;
+            coef[c] = (float)c1;
+            coef[C + c] = (float)(c1 - (double)(float)c1);
+            coef[2 * C + c] = (float)c2;
+            coef[3 * C + c] = (float)(c2 - (double)(float)c2);
         }
     }
 }
 
-// backward pass 2: dz = scale * (dy - c1 - xhat*c2)  (train)  |  dz = scale*dy (eval, coef == NULL)
+// backward pass 2: dz = scale * (dy - c1 - xhat*c2)  (train)  |  dz = scale*dy (eval, coef == NULL).
+// Evaluated per element in fp64 and rounded once, as ATen's CPU kernel does (accscalar_t = double):
+// the three terms cancel (strongly when B*H*W per channel is small), so fp32 arithmetic here
+// is what limits end-to-end gradient parity, and fp64 VALU is free in this HBM-bound pass.
 __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __restrict__ da, int64_t da_bs,
                                                                 const float* __restrict__ z, int64_t z_bs,
                                                                 const float* __restrict__ save,
@@ -181,7 +223,9 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
     const int plane = blockIdx.x / chunks, ch = blockIdx.x % chunks;
     const int b = plane / C, c = plane % C;
     const float mean = save[c], invstd = save[C + c], sc = save[2 * C + c], sh = save[3 * C + c];
-    const float c1 = coef ? coef[c] : 0.f, c2 = coef ? coef[C + c] : 0.f;
+    const double meand = mean, invd = invstd, scd = sc;
+    const double c1 = coef ? (double)coef[c] + (double)coef[C + c] : 0.0;
+    const double c2 = coef ? (double)coef[2 * C + c] + (double)coef[3 * C + c] : 0.0;
     const float* zs = z + (int64_t)b * z_bs + (int64_t)c * HW;
     const float* ds = da + (int64_t)b * da_bs + (int64_t)c * HW;
     float* out = dz + (int64_t)b * dz_bs + (int64_t)c * HW;
@@ -194,15 +238,15 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
             float o[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float dy = fmaf(zz[k], sc, sh) > 0.f ? gg[k] : 0.f;
-                o[k] = sc * (dy - c1 - ((zz[k] - mean) * invstd) * c2);
+                const double dy = fmaf(zz[k] - mean, sc, sh) > 0.f ? (double)gg[k] : 0.0;
+                o[k] = (float)(scd * (dy - c1 - (((double)zz[k] - meand) * invd) * c2));
             }
             *reinterpret_cast<float4*>(out + i) = make_float4(o[0], o[1], o[2], o[3]);
         }
     } else {
         for (int i = beg + threadIdx.x; i < end; i += 256) {
-            const float dy = fmaf(zs[i], sc, sh) > 0.f ? ds[i] : 0.f;
-            out[i] = sc * (dy - c1 - ((zs[i] - mean) * invstd) * c2);
+            const double dy = fmaf(zs[i] - mean, sc, sh) > 0.f ? (double)ds[i] : 0.0;
+            out[i] = (float)(scd * (dy - c1 - (((double)zs[i] - meand) * invd) * c2));
         }
     }
 }
@@ -232,8 +276,9 @@ int onet_bn_finalize(const float* part, int nparts, int64_t count, const float* 
                      float* running_mean, float* running_var, float momentum, float eps, float* save, int C,
                      void* stream) {
     ONET_REQUIRE(part && save && nparts > 0 && count > 0 && C > 0, "bn_finalize: bad args");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, as_stream(stream), part, nparts, (double)count,
-                       gamma, beta, running_mean, running_var, momentum, eps, save, C);
+    (void)count;   // the partials carry their own counts
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, as_stream(stream), part, nparts, gamma, beta,
+                       running_mean, running_var, momentum, eps, save, C);
     return check_launch("bn_finalize_kernel");
 }
 

@@ -12,6 +12,7 @@
 // MFMA operand maps (cdna_hip_programming.md §3): A lane l -> A[i=l&31][k=l>>5],
 //   B lane l -> B[k=l>>5][j=l&31], D reg r lane l -> D[(r&3)+8*(r>>2)+4*(l>>5)][l&31].
 #include <algorithm>
+#include <cstdlib>
 #include "common.hpp"
 
 using namespace onet;
@@ -74,17 +75,42 @@ struct ConvCfg {
     static constexpr int LDS_BYTES = (W_FLOATS + IN_FLOATS) * 4;
 };
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Buffer loads with a 32-bit byte offset: the hardware range check returns 0 for any offset >=
+// num_records, so zero padding (image border, channel tails) costs no branch: out-of-image
+// elements simply get the offset OOB_OFF.
+constexpr unsigned OOB_OFF = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int64_t bytes) {
+    const int n = bytes > 0x7fffffffll ? 0x7fffffff : (int)bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000);
+}
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ __forceinline__ u32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+}
+
+// Software pipeline per K-chunk of CI_T input channels:
+//   regs(chunk c+1) <- buffer loads issued BEFORE the MFMA block of chunk c (latency hidden under
+//   288 MFMAs/wave), LDS <- regs after it; 2 blocks/CU cover the commit + barrier bubbles.
 template <int KS, int MT, int NT, int WM, int WN, int TW>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
     using C = ConvCfg<KS, MT, NT, WM, WN, TW>;
     static_assert(WM * WN == 4, "4 waves per block");
     constexpr int TAPS = C::TAPS, PAD = C::PAD, RPT = C::RPT, ROWS = C::ROWS;
-    constexpr int IN_ROWS = C::IN_ROWS, IN_COLS = C::IN_COLS, ROW_STRIDE = C::ROW_STRIDE;
+    constexpr int ROW_STRIDE = C::ROW_STRIDE;
     constexpr int CH_STRIDE = C::CH_STRIDE, CO_T = C::CO_T;
+    constexpr int IN_FLOATS = C::IN_FLOATS, W_FLOATS = C::W_FLOATS;
+    constexpr int NIN = (IN_FLOATS + 255) / 256;        // input dwords staged per thread per chunk
+    constexpr int NW4 = (W_FLOATS / 4 + 255) / 256;     // weight float4s per thread per chunk
+    constexpr int NW1 = (W_FLOATS + 255) / 256;         // scalar fallback (Cout % 4 != 0)
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* w_lds = smem;                  // [CI_T][TAPS][CO_T]
-    float* in_lds = smem + C::W_FLOATS;   // [CI_T][IN_ROWS][ROW_STRIDE]
+    float* in_lds = smem + W_FLOATS;      // [CI_T][IN_ROWS][ROW_STRIDE]
 
     int bid = blockIdx.x;
     const int coT = bid % a.coTiles;
@@ -101,63 +127,97 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     const int px = l31 % TW, py = l31 / TW;
     const int HW = a.H * a.W;
 
+    // Two-level accumulation (small register tiles only, i.e. the deep layers where K = 9*Cin reaches
+    // 9216): an MFMA accumulator is a strictly sequential fp32 fmaf chain, whose rounding error grows
+    // ~sqrt(K); every FLUSH chunks (288 terms) the chain is folded into a second accumulator set.
+    constexpr bool TWO_LEVEL = (MT * NT <= 4);
+    constexpr int FLUSH = 4;
     f32x16 acc[MT][NT];
+    f32x16 tot[TWO_LEVEL ? MT : 1][TWO_LEVEL ? NT : 1];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                acc[m][n][r] = 0.f;
+                if constexpr (TWO_LEVEL) tot[m][n][r] = 0.f;
+            }
 
     const float* a_ptr = w_lds + kh * TAPS * CO_T + wm * 32 * MT + l31;
     const float* b_ptr = in_lds + kh * CH_STRIDE + (wn * NT * RPT + py) * ROW_STRIDE + px;
 
-    const float* xb = a.x + (int64_t)b * a.x_bs;
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x + (int64_t)b * a.x_bs, (int64_t)a.Cin * HW * 4);
+    const __amdgpu_buffer_rsrc_t wr = make_rsrc(a.wp, (int64_t)a.Cin * TAPS * a.Cout * 4);
     const bool vec4 = (a.Cout & 3) == 0;
 
-    for (int c0 = 0; c0 < a.Cin; c0 += CI_T) {
-        __syncthreads();  // everyone is done reading the previous chunk
-        // ---- stage packed weights [CI_T][TAPS][CO_T] (rows of CO_T contiguous floats)
+    // chunk-invariant byte offsets of this thread's staged elements (OOB_OFF = zero padding)
+    unsigned in_off[NIN];
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) {
+        const int i = tid + 256 * k;
+        const int ci = i / CH_STRIDE, rem = i % CH_STRIDE;
+        const int r = rem / ROW_STRIDE, c = rem % ROW_STRIDE;
+        const int yy = y0 - PAD + r, xx = x0 - PAD + c;
+        const bool ok = (i < IN_FLOATS) && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+        in_off[k] = ok ? (unsigned)((ci * HW + yy * a.W + xx) * 4) : OOB_OFF;
+    }
+    unsigned w_off[NW4];
+#pragma unroll
+    for (int k = 0; k < NW4; ++k) {
+        const int i = (tid + 256 * k) * 4;
+        const int ci = i / (TAPS * CO_T), rem = i % (TAPS * CO_T);
+        const int t = rem / CO_T, co = rem % CO_T;
+        const bool ok = (i < W_FLOATS) && (co0 + co < a.Cout);
+        w_off[k] = ok ? (unsigned)(((ci * TAPS + t) * a.Cout + co0 + co) * 4) : OOB_OFF;
+    }
+    const unsigned in_step = (unsigned)(CI_T * HW * 4), w_step = (unsigned)(CI_T * TAPS * a.Cout * 4);
+
+    float xin[NIN];
+    u32x4 wv[NW4];
+    auto issue = [&](unsigned cin_bytes, unsigned cw_bytes) {
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) xin[k] = bload(xr, in_off[k] + cin_bytes);
         if (vec4) {
-            for (int i = tid * 4; i < C::W_FLOATS; i += 1024) {
-                const int ci = i / (TAPS * CO_T);
-                const int rem = i % (TAPS * CO_T);
-                const int t = rem / CO_T, co = rem % CO_T;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (c0 + ci < a.Cin && co0 + co < a.Cout)
-                    v = *reinterpret_cast<const float4*>(a.wp + ((int64_t)(c0 + ci) * TAPS + t) * a.Cout + co0 + co);
-                *reinterpret_cast<float4*>(w_lds + i) = v;
+#pragma unroll
+            for (int k = 0; k < NW4; ++k) wv[k] = bload4(wr, w_off[k] + cw_bytes);
+        }
+    };
+    auto commit = [&](int c0) {
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) {
+            const int i = tid + 256 * k;
+            if (i < IN_FLOATS) in_lds[i] = xin[k];
+        }
+        if (vec4) {
+#pragma unroll
+            for (int k = 0; k < NW4; ++k) {
+                const int i = (tid + 256 * k) * 4;
+                if (i < W_FLOATS) *reinterpret_cast<u32x4*>(w_lds + i) = wv[k];
             }
-        } else {
-            for (int i = tid; i < C::W_FLOATS; i += 256) {
-                const int ci = i / (TAPS * CO_T);
-                const int rem = i % (TAPS * CO_T);
+        } else {   // rare: Cout not a multiple of 4 -> unpipelined scalar weight staging
+#pragma unroll 1
+            for (int k = 0; k < NW1; ++k) {
+                const int i = tid + 256 * k;
+                const int ci = i / (TAPS * CO_T), rem = i % (TAPS * CO_T);
                 const int t = rem / CO_T, co = rem % CO_T;
                 float v = 0.f;
-                if (c0 + ci < a.Cin && co0 + co < a.Cout)
-                    v = a.wp[((int64_t)(c0 + ci) * TAPS + t) * a.Cout + co0 + co];
-                w_lds[i] = v;
+                if (i < W_FLOATS && co0 + co < a.Cout)
+                    v = bload(wr, (unsigned)((((c0 + ci) * TAPS + t) * a.Cout + co0 + co) * 4));
+                if (i < W_FLOATS) w_lds[i] = v;
             }
         }
-        // ---- stage the zero-padded input halo tile [CI_T][IN_ROWS][IN_COLS]
-        {
-            constexpr int LPR = (IN_COLS <= 32) ? 32 : 64;  // lanes per tile row
-            constexpr int RPI = 256 / LPR;                  // tile rows per iteration
-            const int col = tid % LPR, rsub = tid / LPR;
-            const int xx = x0 - PAD + col;
-            const bool colok = (col < IN_COLS);
-            const bool xok = colok && xx >= 0 && xx < a.W;
-            for (int rr = rsub; rr < CI_T * IN_ROWS; rr += RPI) {
-                const int ci = rr / IN_ROWS, r = rr % IN_ROWS;
-                const int yy = y0 - PAD + r;
-                float v = 0.f;
-                if (xok && (c0 + ci) < a.Cin && yy >= 0 && yy < a.H)
-                    v = xb[(int64_t)(c0 + ci) * HW + (int64_t)yy * a.W + xx];
-                if (colok) in_lds[ci * CH_STRIDE + r * ROW_STRIDE + col] = v;
-            }
-        }
+    };
+
+    unsigned cin_bytes = 0, cw_bytes = 0;
+    issue(0, 0);
+    for (int c0 = 0; c0 < a.Cin; c0 += CI_T) {
+        commit(c0);
         __syncthreads();
-        // ---- MFMA over (tap, channel pair)
+        cin_bytes += in_step;
+        cw_bytes += w_step;
+        issue(cin_bytes, cw_bytes);                 // next chunk (past the end: range check -> zeros, no traffic)
+        __builtin_amdgcn_sched_barrier(0);          // keep the loads ahead of the MFMA block
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
             const int ky = t / KS, kx = t % KS;
@@ -176,6 +236,25 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
             }
         }
+        if constexpr (TWO_LEVEL) {
+            if (((c0 / CI_T) % FLUSH) == FLUSH - 1) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        tot[m][n] += acc[m][n];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+                    }
+            }
+        }
+        __syncthreads();                            // everyone is done reading this chunk's LDS
+    }
+    if constexpr (TWO_LEVEL) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] += tot[m][n];
     }
 
     // ---- epilogue: D[co][pix] -> z (lanes run along x: coalesced 128-B rows)
@@ -216,20 +295,37 @@ static int launch_fwd(ConvArgs a, hipStream_t st) {
     return check_launch("conv_fwd_kernel");
 }
 
+// Tile configurations <MT, NT, WM, WN, TW> (per-wave register tile MT x NT of 32x32 MFMA tiles,
+// 4 waves as WM x WN, TW-pixel-wide column tiles):
+//   P  <2,4,1,4,32>   64 co x (16 rows x 32 px)   pixel-heavy, single-level accumulation
+//   C  <2,4,2,2,32>  128 co x ( 8 rows x 32 px)   channel-heavy, single-level accumulation
+//   D  <2,2,1,4,TW>   64 co x ( 8 rows x 32 px | 16 rows x 16 px)   two-level accumulation
+//   E  <2,2,2,2,32>  128 co x ( 4 rows x 32 px)   two-level accumulation
+// ONET_CONV_CFG=P|C|D|E forces one (tuning / A-B runs); default: heuristic below.
+static int conv_cfg_override() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ONET_CONV_CFG");
+        v = (e && e[0]) ? e[0] : 0;
+    }
+    return v;
+}
+
 template <int KS>
 static int dispatch_fwd(const ConvArgs& a, hipStream_t st) {
-    // tile configuration: P = pixel-heavy (64 co x 16 column tiles), C = channel-heavy
-    // (128 co x 8 column tiles), D = deep/small images (64 co x 8 column tiles)
     const bool wide = a.W > 16;
-    const int64_t pix = (int64_t)a.B * a.H * a.W;
-    if (a.Cout <= 64 || (wide && a.H >= 64)) {
-        if (a.Cout >= 128 && wide) return launch_fwd<KS, 2, 4, 2, 2, 32>(a, st);
-        return wide ? launch_fwd<KS, 2, 4, 1, 4, 32>(a, st) : launch_fwd<KS, 2, 2, 1, 4, 16>(a, st);
+    if (!wide) return launch_fwd<KS, 2, 2, 1, 4, 16>(a, st);
+    switch (conv_cfg_override()) {
+        case 'P': return launch_fwd<KS, 2, 4, 1, 4, 32>(a, st);
+        case 'C': return launch_fwd<KS, 2, 4, 2, 2, 32>(a, st);
+        case 'D': return launch_fwd<KS, 2, 2, 1, 4, 32>(a, st);
+        case 'E': return launch_fwd<KS, 2, 2, 2, 2, 32>(a, st);
+        default: break;
     }
-    // deep layers: few pixels, many channels
-    const int64_t blocksC = (pix / 256) * (a.Cout / 128);
-    if (blocksC >= 1024) return wide ? launch_fwd<KS, 2, 4, 2, 2, 32>(a, st) : launch_fwd<KS, 2, 4, 2, 2, 16>(a, st);
-    return wide ? launch_fwd<KS, 2, 2, 1, 4, 32>(a, st) : launch_fwd<KS, 2, 2, 1, 4, 16>(a, st);
+    // Measured on MI355X (tools/bench_conv.py, B=32, 256^2 U-Net layer shapes, fwd+dgrad): P 138.6, D 134.6,
+    // C 115-124, E 109-118 TFLOP/s.  D is the default: within 3 % of P and it carries the two-level
+    // accumulation that keeps |z - exact| ~2e-7 (fewer ReLU-kink sign flips against the reference).
+    return launch_fwd<KS, 2, 2, 1, 4, 32>(a, st);
 }
 
 // ------------------------------------------------------------------ wgrad
@@ -253,11 +349,19 @@ struct WgCfg {
 };
 
 // slab[ks][tap][co][ci] = sum over this block's pixel strips of dz[co][p] * x[ci][p + tap]
+// Staging is software-pipelined like the forward kernel: the buffer loads of strip u+splitK are
+// issued before the 288-MFMA block of strip u and committed to LDS after it.  All staged elements
+// of a thread sit at a constant channel stride, so one base offset per operand suffices.
 template <int KS, int PW>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
+__global__ __launch_bounds__(256, KS == 3 ? 1 : 2) void conv_wgrad_kernel(WgArgs a) {
     using C = WgCfg<KS, PW>;
     constexpr int TAPS = C::TAPS, PAD = C::PAD, PR = C::PR, XR = C::XR, XC = C::XC;
     constexpr int DZ_STRIDE = C::DZ_STRIDE, X_STRIDE = C::X_STRIDE;
+    constexpr int NDZ = 16;                                  // 64 ch * 64 px / 256 threads
+    constexpr int ROWS_PER_K = 256 / PW;                     // x rows covered by the block per step
+    constexpr int CH_PER_K = ROWS_PER_K / XR;                // whole channels per step
+    constexpr int NXM = 64 / CH_PER_K;                       // steps for the 64 channels (main columns)
+    constexpr int NXH = (KS == 3) ? (64 * XR * 2 + 255) / 256 : 0;   // halo-column dwords per thread
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dz_lds = smem;                    // [64 co][DZ_STRIDE]
@@ -275,6 +379,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
     const int l31 = lane & 31, kh = lane >> 5;
     const int HW = a.H * a.W;
 
+    // (split-K already bounds every fp32 accumulation chain to nunits/splitK strips of 64 pixels)
     f32x16 acc[TAPS];
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
@@ -284,44 +389,71 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
     const float* a_ptr = dz_lds + (wm * 32 + l31) * DZ_STRIDE + kh;
     const float* b_ptr = x_lds + (wn * 32 + l31) * X_STRIDE + kh;
 
+    // per-thread staging coordinates (unit-invariant parts)
+    const int dz_c = tid >> 6, dz_p = tid & 63, dz_r = dz_p / PW, dz_col = dz_p % PW;
+    const int xm_col = tid % PW, xm_rowid = tid / PW, xm_cp = xm_rowid / XR, xm_r = xm_rowid % XR;
+    const bool xm_thread = xm_rowid < CH_PER_K * XR;
+    const unsigned dz_kstep = (unsigned)(4 * HW * 4), xm_kstep = (unsigned)(CH_PER_K * HW * 4);
+
+    float dzv[NDZ], xmv[NXM], xhv[NXH > 0 ? NXH : 1];
     const int nunits = a.B * a.stripsY * a.stripsX;
-    for (int u = ks; u < nunits; u += a.splitK) {
-        const int sx = u % a.stripsX;
-        const int sy = (u / a.stripsX) % a.stripsY;
-        const int b = u / (a.stripsX * a.stripsY);
+
+    auto issue = [&](int u) {
+        // past the last unit every offset is out of range: the loads return 0 without traffic
+        const bool live = u < nunits;
+        const int uu = live ? u : 0;
+        const int sx = uu % a.stripsX;
+        const int sy = (uu / a.stripsX) % a.stripsY;
+        const int b = uu / (a.stripsX * a.stripsY);
         const int y0 = sy * PR, x0 = sx * PW;
-        __syncthreads();
-        {   // dz strip: [64][PR][PW]
-            const int col = tid % PW, rsub = tid / PW;
-            const int xx = x0 + col;
-            const float* dzb = a.dz + (int64_t)b * a.dz_bs;
-            for (int rr = rsub; rr < 64 * PR; rr += 256 / PW) {
-                const int c = rr / PR, r = rr % PR;
-                const int yy = y0 + r;
-                float v = 0.f;
-                if (co0 + c < a.Cout && yy < a.H && xx < a.W)
-                    v = dzb[(int64_t)(co0 + c) * HW + (int64_t)yy * a.W + xx];
-                dz_lds[c * DZ_STRIDE + r * PW + col] = v;
-            }
+        const __amdgpu_buffer_rsrc_t dr = make_rsrc(a.dz + (int64_t)b * a.dz_bs, (int64_t)a.Cout * HW * 4);
+        const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x + (int64_t)b * a.x_bs, (int64_t)a.Cin * HW * 4);
+        {
+            const int yy = y0 + dz_r, xx = x0 + dz_col;
+            const bool ok = live && yy < a.H && xx < a.W;
+            const unsigned base = ok ? (unsigned)(((co0 + dz_c) * HW + yy * a.W + xx) * 4) : OOB_OFF;
+#pragma unroll
+            for (int k = 0; k < NDZ; ++k) dzv[k] = bload(dr, base + k * dz_kstep);
         }
-        {   // x halo strip: [64][XR][XC]
-            constexpr int LPR = (XC <= 32) ? 32 : 64;
-            constexpr int RPI = 256 / LPR;
-            const int col = tid % LPR, rsub = tid / LPR;
-            const int xx = x0 - PAD + col;
-            const bool colok = col < XC;
-            const bool xok = colok && xx >= 0 && xx < a.W;
-            const float* xb = a.x + (int64_t)b * a.x_bs;
-            for (int rr = rsub; rr < 64 * XR; rr += RPI) {
-                const int c = rr / XR, r = rr % XR;
-                const int yy = y0 - PAD + r;
-                float v = 0.f;
-                if (xok && ci0 + c < a.Cin && yy >= 0 && yy < a.H)
-                    v = xb[(int64_t)(ci0 + c) * HW + (int64_t)yy * a.W + xx];
-                if (colok) x_lds[c * X_STRIDE + r * XC + col] = v;
-            }
+        {
+            const int yy = y0 - PAD + xm_r, xx = x0 + xm_col;
+            const bool ok = live && xm_thread && yy >= 0 && yy < a.H && xx < a.W;
+            const unsigned base = ok ? (unsigned)(((ci0 + xm_cp) * HW + yy * a.W + xx) * 4) : OOB_OFF;
+#pragma unroll
+            for (int k = 0; k < NXM; ++k) xmv[k] = bload(xr, base + k * xm_kstep);
         }
+#pragma unroll
+        for (int j = 0; j < NXH; ++j) {
+            const int e = tid + 256 * j;
+            const int c = e / (2 * XR), q = e % (2 * XR);
+            const int r = q >> 1, side = q & 1;
+            const int yy = y0 - PAD + r, xx = side ? x0 + PW : x0 - 1;
+            const bool ok = live && e < 64 * XR * 2 && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+            xhv[j] = bload(xr, ok ? (unsigned)(((ci0 + c) * HW + yy * a.W + xx) * 4) : OOB_OFF);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int k = 0; k < NDZ; ++k) dz_lds[(dz_c + 4 * k) * DZ_STRIDE + dz_p] = dzv[k];
+        if (xm_thread) {
+#pragma unroll
+            for (int k = 0; k < NXM; ++k)
+                x_lds[(xm_cp + CH_PER_K * k) * X_STRIDE + xm_r * XC + xm_col + PAD] = xmv[k];
+        }
+#pragma unroll
+        for (int j = 0; j < NXH; ++j) {
+            const int e = tid + 256 * j;
+            const int c = e / (2 * XR), q = e % (2 * XR);
+            if (e < 64 * XR * 2) x_lds[c * X_STRIDE + (q >> 1) * XC + ((q & 1) ? XC - 1 : 0)] = xhv[j];
+        }
+    };
+
+    issue(ks);
+    for (int u = ks; u < nunits; u += a.splitK) {
+        commit();
         __syncthreads();
+        issue(u + a.splitK);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < PR; ++r) {
 #pragma unroll
@@ -335,6 +467,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
                 }
             }
         }
+        __syncthreads();
     }
     // slab[ks][t][co][ci]; lanes run along ci (coalesced)
     float* sl = a.slab + (int64_t)ks * TAPS * a.Cout * a.Cin;
@@ -351,16 +484,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
     }
 }
 
-// dw (+)= sum_ks slab[ks][t][co][ci], written in the nn.Module parameter layout
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splitK,
-                                    int taps, int Cout, int Cin, int out_layout, int accumulate) {
+// dw (+)= sum_ks slab[ks][t][co][ci], written in the nn.Module parameter layout.
+// block = 64 consecutive (co,ci) x 4 split-K groups for one tap; LDS combine of the 4 groups.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                           int splitK, int taps, int Cout, int Cin, int out_layout,
+                                                           int accumulate) {
+    __shared__ float red[256];
     const int64_t n = (int64_t)Cout * Cin;
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int ci = (int)(i % Cin), co = (int)(i / Cin);
-    for (int t = 0; t < taps; ++t) {
-        float s = 0.f;
-        for (int k = 0; k < splitK; ++k) s += slab[((int64_t)k * taps + t) * n + i];
+    const int t = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int g = threadIdx.x >> 6;
+    float s = 0.f;
+    if (i < n)
+        for (int k = g; k < splitK; k += 4) s += slab[((int64_t)k * taps + t) * n + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        s = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+        const int ci = (int)(i % Cin), co = (int)(i / Cin);
         int64_t o;
         if (out_layout == 0) {
             o = i * taps + t;                               // [co][ci][ky][kx]
@@ -468,8 +609,8 @@ int onet_conv_wgrad(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs
     int rc = check_launch("conv_wgrad_kernel");
     if (rc) return rc;
     const int64_t n = (int64_t)Cout * Cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (const float*)ws, dw,
-                       a.splitK, ks * ks, Cout, Cin, out_layout, accumulate);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv(n, 64), (unsigned)(ks * ks)), dim3(256), 0, st,
+                       (const float*)ws, dw, a.splitK, ks * ks, Cout, Cin, out_layout, accumulate);
     return check_launch("wgrad_reduce_kernel");
 }
 

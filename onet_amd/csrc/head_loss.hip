@@ -60,9 +60,9 @@ __global__ __launch_bounds__(256) void head_softmax_fwd_kernel(const float* __re
         Vd[i] = vd;
         const float m = fmaxf(vt, vd);
         const float et = expf(vt - m), ed = expf(vd - m);
-        const float inv = 1.f / (et + ed);
-        S[((int64_t)b * 2 + 0) * HW + p] = et * inv;
-        S[((int64_t)b * 2 + 1) * HW + p] = ed * inv;
+        const float den = et + ed;
+        S[((int64_t)b * 2 + 0) * HW + p] = et / den;
+        S[((int64_t)b * 2 + 1) * HW + p] = ed / den;
     }
 }
 
@@ -81,9 +81,12 @@ __global__ __launch_bounds__(256) void head_softmax_bwd_kernel(
         if (dS) {
             const float st = S[((int64_t)b * 2 + 0) * HW + p], sd = S[((int64_t)b * 2 + 1) * HW + p];
             const float a = dS[((int64_t)b * 2 + 0) * HW + p], d = dS[((int64_t)b * 2 + 1) * HW + p];
-            const float dot = a * st + d * sd;
-            gt += st * (a - dot);
-            gd += sd * (d - dot);
+            // 2-class softmax backward in its cancellation-free form: with St + Sd = 1,
+            // St*(a - (a*St + d*Sd)) == St*Sd*(a - d) and the Vd component is its negative.
+            // (the textbook form loses everything once St rounds to 1, which it does at init: |V| ~ 47)
+            const float t = st * sd * (a - d);
+            gt += t;
+            gd -= t;
         }
         const float* lt = Lt + b * Lt_bs + p;
         const float* ht = Ht + b * Ht_bs + p;

@@ -111,22 +111,31 @@ __global__ void space_to_depth2_kernel(const float* __restrict__ dy, int64_t dy_
     }
 }
 
-// dbias[co] (+)= sum over b and the un-padded 2h x 2w window of dy; one block per channel
-__global__ __launch_bounds__(256) void convT_dbias_kernel(const float* __restrict__ dy, int64_t dy_bs,
-                                                          float* __restrict__ dbias, int accumulate, int B, int C,
-                                                          int h2, int w2, int Ho, int Wo, int pt, int pl) {
+// dbias[co] (+)= sum over b and the un-padded 2h x 2w window of dy.  Two deterministic stages:
+// (channel, image) partials in fp64, then one wave per channel folds the B partials.
+__global__ __launch_bounds__(256) void convT_dbias_partial_kernel(const float* __restrict__ dy, int64_t dy_bs,
+                                                                  double* __restrict__ scratch, int B, int C, int h2,
+                                                                  int w2, int Ho, int Wo, int pt, int pl) {
     __shared__ double red[4];
-    const int co = blockIdx.x;
+    const int co = blockIdx.x % C, b = blockIdx.x / C;
     double v[1] = {0.0};
-    const int64_t n = (int64_t)B * h2 * w2;
-    for (int64_t i = threadIdx.x; i < n; i += 256) {
-        const int x = (int)(i % w2);
-        const int64_t r = i / w2;
-        const int y = (int)(r % h2), b = (int)(r / h2);
-        v[0] += (double)dy[(int64_t)b * dy_bs + (int64_t)co * Ho * Wo + (int64_t)(pt + y) * Wo + pl + x];
+    const float* src = dy + (int64_t)b * dy_bs + (int64_t)co * Ho * Wo;
+    const int n = h2 * w2;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int x = i % w2, y = i / w2;
+        v[0] += (double)src[(int64_t)(pt + y) * Wo + pl + x];
     }
     block_sum_256<double, 1>(v, red);
-    if (threadIdx.x == 0) dbias[co] = accumulate ? dbias[co] + (float)v[0] : (float)v[0];
+    if (threadIdx.x == 0) scratch[(int64_t)b * C + co] = v[0];
+}
+
+__global__ __launch_bounds__(64) void convT_dbias_final_kernel(const double* __restrict__ scratch,
+                                                               float* __restrict__ dbias, int accumulate, int B, int C) {
+    const int co = blockIdx.x;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < B; b += 64) s += scratch[(int64_t)b * C + co];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) dbias[co] = accumulate ? dbias[co] + (float)s : (float)s;
 }
 
 __global__ void copy_strided_kernel(const float* __restrict__ src, int64_t src_bs, float* __restrict__ dst,
@@ -306,8 +315,9 @@ int onet_axpy(const float* x, int64_t x_bs, float* y, int64_t y_bs, float a, int
 
 }  // extern "C"
 
-extern "C" int onet_space_to_depth2(const float* dy, int64_t dy_bs, float* sub, float* dbias, int accumulate, int B,
-                                    int C, int h, int w, int Ho, int Wo, int pt, int pl, void* stream) {
+extern "C" int onet_space_to_depth2(const float* dy, int64_t dy_bs, float* sub, float* dbias, double* scratch,
+                                    int accumulate, int B, int C, int h, int w, int Ho, int Wo, int pt, int pl,
+                                    void* stream) {
     ONET_REQUIRE(dy && sub && B > 0 && C > 0 && h > 0 && w > 0, "space_to_depth2: bad args");
     ONET_REQUIRE(pt >= 0 && pl >= 0 && pt + 2 * h <= Ho && pl + 2 * w <= Wo, "space_to_depth2: window outside plane");
     const int64_t n = (int64_t)B * 4 * C * h * w;
@@ -316,9 +326,14 @@ extern "C" int onet_space_to_depth2(const float* dy, int64_t dy_bs, float* sub, 
     int rc = check_launch("space_to_depth2_kernel");
     if (rc) return rc;
     if (dbias) {
-        hipLaunchKernelGGL(convT_dbias_kernel, dim3(C), dim3(256), 0, as_stream(stream), dy, dy_bs, dbias, accumulate, B,
-                           C, 2 * h, 2 * w, Ho, Wo, pt, pl);
-        rc = check_launch("convT_dbias_kernel");
+        ONET_REQUIRE(scratch, "space_to_depth2: dbias needs a scratch buffer of B*C doubles");
+        hipLaunchKernelGGL(convT_dbias_partial_kernel, dim3((unsigned)((int64_t)B * C)), dim3(256), 0, as_stream(stream),
+                           dy, dy_bs, scratch, B, C, 2 * h, 2 * w, Ho, Wo, pt, pl);
+        rc = check_launch("convT_dbias_partial_kernel");
+        if (rc) return rc;
+        hipLaunchKernelGGL(convT_dbias_final_kernel, dim3(C), dim3(64), 0, as_stream(stream), (const double*)scratch,
+                           dbias, accumulate, B, C);
+        rc = check_launch("convT_dbias_final_kernel");
     }
     return rc;
 }

@@ -141,7 +141,7 @@ def bn_train_coeffs(z, gamma, beta, running_mean, running_var, momentum, eps):
     if B * H * W <= 1:
         raise ValueError(f"Expected more than 1 value per channel when training, got input size {list(z.shape)}")
     nparts = _bn_nparts(B, H * W)
-    part = torch.empty((nparts, C, 2), dtype=F32, device=z.device)
+    part = torch.empty((nparts, C, 3), dtype=F32, device=z.device)
     _lib.call("onet_bn_stats_partial", _p(z), zbs, _p(part), nparts, B, C, H * W, _stream())
     save = torch.empty((4, C), dtype=F32, device=z.device)
     _lib.call("onet_bn_finalize", _p(part), nparts, B * H * W, _p(gamma), _p(beta), _p(running_mean),
@@ -177,11 +177,11 @@ def bn_relu_bwd(da, z, save, training, need_affine_grads=True):
     dev = z.device
     dgamma = dbeta = coef = None
     if training or need_affine_grads:
-        part2 = torch.empty((nparts, C, 2), dtype=F32, device=dev)
+        part2 = torch.empty((nparts, C, 4), dtype=F32, device=dev)
         _lib.call("onet_bn_relu_bwd_reduce", _p(da), dabs, _p(z), zbs, _p(save), _p(part2), nparts, B, C, HW, _stream())
         dgamma = torch.empty(C, dtype=F32, device=dev)
         dbeta = torch.empty(C, dtype=F32, device=dev)
-        coef = torch.empty((2, C), dtype=F32, device=dev) if training else None
+        coef = torch.empty((4, C), dtype=F32, device=dev) if training else None
         _lib.call("onet_bn_bwd_finalize", _p(part2), nparts, B * HW, _p(dgamma), _p(dbeta), _p(coef), 0, C, _stream())
     dz = torch.empty((B, C, H, W), dtype=F32, device=dev)
     _lib.call("onet_bn_relu_bwd_apply", _p(da), dabs, _p(z), zbs, _p(save), _p(coef), _p(dz), C * HW, B, C, HW,
@@ -231,7 +231,9 @@ def space_to_depth2(dy, h, w, pt, pl, want_dbias):
     B, C, Ho, Wo = dy.shape
     sub = torch.empty((B, 4 * C, h, w), dtype=F32, device=dy.device)
     dbias = torch.empty(C, dtype=F32, device=dy.device) if want_dbias else None
-    _lib.call("onet_space_to_depth2", _p(dy), dybs, _p(sub), _p(dbias), 0, B, C, h, w, Ho, Wo, pt, pl, _stream())
+    scratch = torch.empty(B * C, dtype=torch.float64, device=dy.device) if want_dbias else None
+    _lib.call("onet_space_to_depth2", _p(dy), dybs, _p(sub), _p(dbias), _p(scratch), 0, B, C, h, w, Ho, Wo, pt, pl,
+              _stream())
     return sub, dbias
 
 

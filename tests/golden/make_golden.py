@@ -115,6 +115,29 @@ def run_case(ov, tag, B, C, H, W, bshare=True, train=True, full=False, steps=1):
         if train and steps > 1:
             opt.step()
     out["losses"] = np.array(losses, dtype=np.float64)
+    if train and steps == 1:
+        # fp64 evaluation of the SAME reference graph ("truth"): tells how well-conditioned each
+        # quantity is, i.e. how far the reference's own fp32 result is from exact arithmetic.
+        torch.manual_seed(0)
+        m64 = ov.Onet(in_chns=C, binit=True, bshare=bshare)
+        m64.load_state_dict(orc.onet_state_dict(C, 1981, bshare))
+        m64 = m64.double().train()
+        Lt, Vt, Ld, Vd, S = m64(X.double())
+        l64 = m64.compute_loss(Lt, S[:, 0].unsqueeze(1), Ld, S[:, 1].unsqueeze(1))
+        l64.backward()
+        out["loss64"] = np.float64(l64.item())
+        names, norms, heads = [], [], []
+        for n, p_ in m64.named_parameters():
+            g = p_.grad.detach().reshape(-1)
+            norms.append(float(g.norm()))
+            h = np.zeros(64, dtype=np.float64)
+            k = min(64, g.numel())
+            h[:k] = g[:k].numpy()
+            heads.append(h)
+        out["grad_norms64"] = np.array(norms, dtype=np.float64)
+        out["grad_heads64"] = np.stack(heads)
+        out["Vt64"] = Vt.detach().numpy() if H <= 40 else Vt.detach().numpy()[:, :, ::37, :]
+        out["S64"] = S.detach().numpy() if H <= 40 else S.detach().numpy()[:, :, ::37, :]
     if steps > 1:
         out["bn_rm_end"], out["bn_rv_end"], out["bn_nbt_end"] = bn_digest(model)
         pn = [(n, p.detach()) for n, p in model.named_parameters()]
