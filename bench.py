@@ -21,6 +21,25 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
+PMC_JSON = os.path.join(ROOT, "profiles", "pmc_bench_latest.json")   # written by tools/pmc_parse.py
+
+
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of THIS
+    command (FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950
+    correction).  PMC counters cannot be collected inside the timed run, so the number comes from
+    profiles/; None if the file is absent."""
+    try:
+        d = json.load(open(PMC_JSON))
+    except Exception:
+        return None
+    tot_b = tot_n = 0
+    for k, v in d.items():
+        if k.startswith(kernel_prefix) and "hbm_bytes_per_launch" in v:
+            n = v["FETCH_SIZE"]["launches"]
+            tot_b += v["hbm_bytes_per_launch"] * n
+            tot_n += n
+    return (tot_b / tot_n) if tot_n else None
 
 
 def cpu_baseline(X_cpu, seconds_budget):
@@ -116,7 +135,8 @@ def main():
         dom = max(kern, key=lambda k: kern[k]["ms_total"])
         roofline = {"kernel": dom, "bound": "mfma", "achieved": kern[dom]["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4),
-                    "traffic": None, "launches_timed": kern[dom]["launches"], "avg_launch_ms": kern[dom]["avg_ms"],
+                    "traffic": pmc_traffic(dom), "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc, profiles/)",
+                    "launches_timed": kern[dom]["launches"], "avg_launch_ms": kern[dom]["avg_ms"],
                     "all": kern}
         imgs = args.batch * world * args.steps
         out = {"metric": "training images/sec (twin 256x256 pass)", "value": round(imgs / elapsed, 3),

@@ -112,7 +112,15 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
     float* w_lds = smem;                  // [CI_T][TAPS][CO_T]
     float* in_lds = smem + W_FLOATS;      // [CI_T][IN_ROWS][ROW_STRIDE]
 
-    int bid = blockIdx.x;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with a private
+    // L2), so give every XCD a CONTIGUOUS range of logical tiles -- horizontally adjacent tiles share
+    // halo columns / 128-B lines and the co-tiles of one pixel tile share the whole input tile.
+    // (bijective for any grid size; placement only affects speed, never results)
+    int bid;
+    {
+        const int n = gridDim.x, q = n >> 3, r = n & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
     const int coT = bid % a.coTiles;
     bid /= a.coTiles;
     const int tx = bid % a.tilesX;
@@ -367,11 +375,19 @@ __global__ __launch_bounds__(256, KS == 3 ? 1 : 2) void conv_wgrad_kernel(WgArgs
     float* dz_lds = smem;                    // [64 co][DZ_STRIDE]
     float* x_lds = smem + 64 * DZ_STRIDE;    // [64 ci][X_STRIDE]
 
-    int bid = blockIdx.x;
-    const int ks = bid % a.splitK;
-    bid /= a.splitK;
-    const int ciT = bid % a.ciTiles;
-    const int coT = bid / a.ciTiles;
+    // XCD-aware order (see conv_fwd_kernel): every XCD gets a contiguous range of logical blocks,
+    // ordered split-K slice major / (ci,co) tile minor, so the blocks that stream the SAME pixel strips
+    // (all tiles of one slice) run back to back on one XCD and share them through its L2.
+    int bid;
+    {
+        const int n = gridDim.x, q = n >> 3, r = n & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int tiles = a.ciTiles * a.coTiles;
+    const int ks = bid / tiles;
+    const int tile = bid % tiles;
+    const int ciT = tile % a.ciTiles;
+    const int coT = tile / a.ciTiles;
     const int co0 = coT * 64, ci0 = ciT * 64;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
