@@ -104,8 +104,10 @@ def main():
                                                       channels=args.chans))
     X = X_cpu.to(dev)                # inputs resident in HBM before the timed region
 
+    distributed = dist.is_available() and dist.is_initialized()
+
     def barrier():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -119,7 +121,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -151,7 +153,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(X_cpu, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -357,19 +357,26 @@ struct WgCfg {
 };
 
 // slab[ks][tap][co][ci] = sum over this block's pixel strips of dz[co][p] * x[ci][p + tap]
-// Staging is software-pipelined like the forward kernel: the buffer loads of strip u+splitK are
-// issued before the 288-MFMA block of strip u and committed to LDS after it.  All staged elements
-// of a thread sit at a constant channel stride, so one base offset per operand suffices.
+// Block = 4*TG waves: a 2 x 2 grid of 32co x 32ci sub-tiles times TG tap groups (3x3: one kernel ROW
+// per group, 3 accumulators = 48 VGPRs per wave -> 12 waves = 3 per SIMD hide LDS latency and the
+// commit/barrier bubbles; 1x1: TG = 1).  Staging is software-pipelined like the forward kernel: the
+// buffer loads of strip u+splitK are issued before the MFMA block of strip u and committed to LDS
+// after it.  All staged elements of a thread sit at a constant channel stride, so one base offset
+// per operand suffices.
 template <int KS, int PW>
-__global__ __launch_bounds__(256, KS == 3 ? 1 : 2) void conv_wgrad_kernel(WgArgs a) {
+__global__ __launch_bounds__(256 * KS, KS == 3 ? 3 : 2) void conv_wgrad_kernel(WgArgs a) {
     using C = WgCfg<KS, PW>;
     constexpr int TAPS = C::TAPS, PAD = C::PAD, PR = C::PR, XR = C::XR, XC = C::XC;
     constexpr int DZ_STRIDE = C::DZ_STRIDE, X_STRIDE = C::X_STRIDE;
-    constexpr int NDZ = 16;                                  // 64 ch * 64 px / 256 threads
-    constexpr int ROWS_PER_K = 256 / PW;                     // x rows covered by the block per step
+    constexpr int TG = KS;                                   // tap groups = kernel rows
+    constexpr int NTAP = TAPS / TG;                          // taps per wave (one kernel row)
+    constexpr int NTHR = 256 * TG;
+    constexpr int DZ_CSTEP = NTHR / 64;                      // dz channels covered per step
+    constexpr int NDZ = (64 + DZ_CSTEP - 1) / DZ_CSTEP;
+    constexpr int ROWS_PER_K = NTHR / PW;                    // x rows covered by the block per step
     constexpr int CH_PER_K = ROWS_PER_K / XR;                // whole channels per step
-    constexpr int NXM = 64 / CH_PER_K;                       // steps for the 64 channels (main columns)
-    constexpr int NXH = (KS == 3) ? (64 * XR * 2 + 255) / 256 : 0;   // halo-column dwords per thread
+    constexpr int NXM = (64 + CH_PER_K - 1) / CH_PER_K;      // steps for the 64 channels (main columns)
+    constexpr int NXH = (KS == 3) ? (64 * XR * 2 + NTHR - 1) / NTHR : 0;   // halo-column dwords per thread
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dz_lds = smem;                    // [64 co][DZ_STRIDE]
@@ -391,25 +398,25 @@ __global__ __launch_bounds__(256, KS == 3 ? 1 : 2) void conv_wgrad_kernel(WgArgs
     const int co0 = coT * 64, ci0 = ciT * 64;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
+    const int tg = wid >> 2, wm = (wid >> 1) & 1, wn = wid & 1;
     const int l31 = lane & 31, kh = lane >> 5;
     const int HW = a.H * a.W;
 
     // (split-K already bounds every fp32 accumulation chain to nunits/splitK strips of 64 pixels)
-    f32x16 acc[TAPS];
+    f32x16 acc[NTAP];
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t)
+    for (int t = 0; t < NTAP; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     const float* a_ptr = dz_lds + (wm * 32 + l31) * DZ_STRIDE + kh;
-    const float* b_ptr = x_lds + (wn * 32 + l31) * X_STRIDE + kh;
+    const float* b_ptr = x_lds + (wn * 32 + l31) * X_STRIDE + kh + tg * XC;   // this wave's kernel row
 
     // per-thread staging coordinates (unit-invariant parts)
     const int dz_c = tid >> 6, dz_p = tid & 63, dz_r = dz_p / PW, dz_col = dz_p % PW;
     const int xm_col = tid % PW, xm_rowid = tid / PW, xm_cp = xm_rowid / XR, xm_r = xm_rowid % XR;
     const bool xm_thread = xm_rowid < CH_PER_K * XR;
-    const unsigned dz_kstep = (unsigned)(4 * HW * 4), xm_kstep = (unsigned)(CH_PER_K * HW * 4);
+    const unsigned dz_kstep = (unsigned)(DZ_CSTEP * HW * 4), xm_kstep = (unsigned)(CH_PER_K * HW * 4);
 
     float dzv[NDZ], xmv[NXM], xhv[NXH > 0 ? NXH : 1];
     const int nunits = a.B * a.stripsY * a.stripsX;
@@ -429,18 +436,20 @@ __global__ __launch_bounds__(256, KS == 3 ? 1 : 2) void conv_wgrad_kernel(WgArgs
             const bool ok = live && yy < a.H && xx < a.W;
             const unsigned base = ok ? (unsigned)(((co0 + dz_c) * HW + yy * a.W + xx) * 4) : OOB_OFF;
 #pragma unroll
-            for (int k = 0; k < NDZ; ++k) dzv[k] = bload(dr, base + k * dz_kstep);
+            for (int k = 0; k < NDZ; ++k)
+                dzv[k] = bload(dr, (dz_c + DZ_CSTEP * k < 64) ? base + k * dz_kstep : OOB_OFF);
         }
         {
             const int yy = y0 - PAD + xm_r, xx = x0 + xm_col;
             const bool ok = live && xm_thread && yy >= 0 && yy < a.H && xx < a.W;
             const unsigned base = ok ? (unsigned)(((ci0 + xm_cp) * HW + yy * a.W + xx) * 4) : OOB_OFF;
 #pragma unroll
-            for (int k = 0; k < NXM; ++k) xmv[k] = bload(xr, base + k * xm_kstep);
+            for (int k = 0; k < NXM; ++k)
+                xmv[k] = bload(xr, (xm_cp + CH_PER_K * k < 64) ? base + k * xm_kstep : OOB_OFF);
         }
 #pragma unroll
         for (int j = 0; j < NXH; ++j) {
-            const int e = tid + 256 * j;
+            const int e = tid + NTHR * j;
             const int c = e / (2 * XR), q = e % (2 * XR);
             const int r = q >> 1, side = q & 1;
             const int yy = y0 - PAD + r, xx = side ? x0 + PW : x0 - 1;
@@ -450,15 +459,17 @@ __global__ __launch_bounds__(256, KS == 3 ? 1 : 2) void conv_wgrad_kernel(WgArgs
     };
     auto commit = [&]() {
 #pragma unroll
-        for (int k = 0; k < NDZ; ++k) dz_lds[(dz_c + 4 * k) * DZ_STRIDE + dz_p] = dzv[k];
+        for (int k = 0; k < NDZ; ++k)
+            if (dz_c + DZ_CSTEP * k < 64) dz_lds[(dz_c + DZ_CSTEP * k) * DZ_STRIDE + dz_p] = dzv[k];
         if (xm_thread) {
 #pragma unroll
             for (int k = 0; k < NXM; ++k)
-                x_lds[(xm_cp + CH_PER_K * k) * X_STRIDE + xm_r * XC + xm_col + PAD] = xmv[k];
+                if (xm_cp + CH_PER_K * k < 64)
+                    x_lds[(xm_cp + CH_PER_K * k) * X_STRIDE + xm_r * XC + xm_col + PAD] = xmv[k];
         }
 #pragma unroll
         for (int j = 0; j < NXH; ++j) {
-            const int e = tid + 256 * j;
+            const int e = tid + NTHR * j;
             const int c = e / (2 * XR), q = e % (2 * XR);
             if (e < 64 * XR * 2) x_lds[c * X_STRIDE + (q >> 1) * XC + ((q & 1) ? XC - 1 : 0)] = xhv[j];
         }
@@ -476,9 +487,8 @@ __global__ __launch_bounds__(256, KS == 3 ? 1 : 2) void conv_wgrad_kernel(WgArgs
             for (int j = 0; j < PW / 2; ++j) {
                 const float av = a_ptr[r * PW + 2 * j];
 #pragma unroll
-                for (int t = 0; t < TAPS; ++t) {
-                    const int ky = t / KS, kx = t % KS;
-                    const float bv = b_ptr[(r + ky) * XC + 2 * j + kx];
+                for (int t = 0; t < NTAP; ++t) {
+                    const float bv = b_ptr[r * XC + 2 * j + t];     // kx = t within this wave's kernel row
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
                 }
             }
@@ -490,11 +500,11 @@ __global__ __launch_bounds__(256, KS == 3 ? 1 : 2) void conv_wgrad_kernel(WgArgs
     const int ci = ci0 + wn * 32 + l31;
     if (ci < a.Cin) {
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t) {
+        for (int t = 0; t < NTAP; ++t) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (co < a.Cout) sl[((int64_t)t * a.Cout + co) * a.Cin + ci] = acc[t][r];
+                if (co < a.Cout) sl[((int64_t)(tg * NTAP + t) * a.Cout + co) * a.Cin + ci] = acc[t][r];
             }
         }
     }
@@ -529,6 +539,83 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// Stem wgrad (Cin <= 4: the 1- or 3-channel input image, OV:111): dW[co][ci][tap] has only 64*Cin*9
+// entries but reduces over every pixel, so it is an HBM-bound streaming reduction over dz, not a GEMM
+// (the MFMA tile would be 63/64 padding).  One block per (image, 32-row band, group of COG output
+// channels): a thread owns pixel columns and walks down the band with a 3x3 sliding window of the
+// input in registers (3 new loads per row), COG*CIN*9 accumulators, then wave-shuffle + LDS
+// reduction; partial slab [image*band][tap][co][ci] for wgrad_reduce_kernel (deterministic).
+constexpr int STEM_ROWS = 32;
+template <int CIN, int COG>
+__global__ __launch_bounds__(256) void conv3x3_stem_wgrad_kernel(WgArgs a) {
+    constexpr int NV = COG * CIN * 9;
+    __shared__ float red[4][NV];
+    const int cogs = (a.Cout + COG - 1) / COG;
+    const int bandsY = (a.H + STEM_ROWS - 1) / STEM_ROWS;
+    const int cg = blockIdx.x % cogs, bb = blockIdx.x / cogs;
+    const int b = bb / bandsY, y0 = (bb % bandsY) * STEM_ROWS;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int HW = a.H * a.W, W = a.W, H = a.H;
+    const float* xb = a.x + (int64_t)b * a.x_bs;
+    const float* dzb = a.dz + (int64_t)b * a.dz_bs + (int64_t)cg * COG * HW;
+    const int y1 = min(y0 + STEM_ROWS, H);
+    float acc[COG][CIN][9];
+#pragma unroll
+    for (int g = 0; g < COG; ++g)
+#pragma unroll
+        for (int c = 0; c < CIN; ++c)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[g][c][t] = 0.f;
+    for (int x = tid; x < W; x += 256) {
+        float win[CIN][3][3];   // rows y-1, y, y+1 ; cols x-1, x, x+1
+#pragma unroll
+        for (int c = 0; c < CIN; ++c)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int yy = y0 - 1 + r, xx = x - 1 + k;
+                    win[c][r + 1][k] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? xb[(int64_t)c * HW + (int64_t)yy * W + xx] : 0.f;
+                }
+        for (int y = y0; y < y1; ++y) {
+#pragma unroll
+            for (int c = 0; c < CIN; ++c)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    win[c][0][k] = win[c][1][k];
+                    win[c][1][k] = win[c][2][k];
+                    const int yy = y + 1, xx = x - 1 + k;
+                    win[c][2][k] = (yy < H && xx >= 0 && xx < W) ? xb[(int64_t)c * HW + (int64_t)yy * W + xx] : 0.f;
+                }
+#pragma unroll
+            for (int g = 0; g < COG; ++g) {
+                const float gz = (cg * COG + g < a.Cout) ? dzb[(int64_t)g * HW + (int64_t)y * W + x] : 0.f;
+#pragma unroll
+                for (int c = 0; c < CIN; ++c)
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) acc[g][c][t] = fmaf(gz, win[c][t / 3][t % 3], acc[g][c][t]);
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < COG; ++g)
+#pragma unroll
+        for (int c = 0; c < CIN; ++c)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float s = wave_sum(acc[g][c][t]);
+                if (lane == 0) red[wid][(g * CIN + c) * 9 + t] = s;
+            }
+    __syncthreads();
+    float* sl = a.slab + (int64_t)bb * 9 * a.Cout * CIN;
+    for (int i = tid; i < NV; i += 256) {
+        const int g = i / (CIN * 9), c = (i / 9) % CIN, t = i % 9;
+        const int co = cg * COG + g;
+        if (co < a.Cout)
+            sl[((int64_t)t * a.Cout + co) * CIN + c] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+    }
+}
+
 template <int KS, int PW>
 static void launch_wgrad(const WgArgs& a, int64_t blocks, hipStream_t st) {
     using C = WgCfg<KS, PW>;
@@ -539,7 +626,7 @@ static void launch_wgrad(const WgArgs& a, int64_t blocks, hipStream_t st) {
                                   C::LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256 * KS), C::LDS_BYTES, st, a);
 }
 
 static void wgrad_plan(int B, int Cin, int Cout, int H, int W, int ks, int& pw, int& splitK,
@@ -597,7 +684,11 @@ int onet_conv_fwd(const float* x, int64_t x_bs, const float* wp, float* z, int64
     return ks == 3 ? dispatch_fwd<3>(a, as_stream(stream)) : dispatch_fwd<1>(a, as_stream(stream));
 }
 
+static inline bool use_stem_wgrad(int Cin, int ks) { return ks == 3 && Cin <= 4; }
+static inline int stem_blocks(int B, int H) { return B * ((H + STEM_ROWS - 1) / STEM_ROWS); }
+
 int64_t onet_conv_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W, int ks) {
+    if (use_stem_wgrad(Cin, ks)) return (int64_t)stem_blocks(B, H) * 9 * Cout * Cin * 4;
     int pw, splitK, sx, sy;
     wgrad_plan(B, Cin, Cout, H, W, ks, pw, splitK, sx, sy);
     return (int64_t)splitK * ks * ks * Cout * Cin * 4;
@@ -611,6 +702,24 @@ int onet_conv_wgrad(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs
     ONET_REQUIRE(ks == 1 || ks == 3, "conv_wgrad: ks must be 1 or 3 (got %d)", ks);
     ONET_REQUIRE(out_layout == 0 || (out_layout == 1 && ks == 1 && Cout % 4 == 0), "conv_wgrad: bad out_layout");
     WgArgs a{x, x_bs, dz, dz_bs, (float*)ws, B, Cin, Cout, H, W, cdiv(Cin, 64), cdiv(Cout, 64), 1, 1, 1};
+    if (use_stem_wgrad(Cin, ks) && out_layout == 0) {
+        const int nb = stem_blocks(B, H);
+        const int64_t need = (int64_t)nb * 9 * Cout * Cin * 4;
+        ONET_REQUIRE(ws_bytes >= need, "conv_wgrad(stem): workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
+        hipStream_t st = as_stream(stream);
+        switch (Cin) {
+            case 1: hipLaunchKernelGGL((conv3x3_stem_wgrad_kernel<1, 8>), dim3(nb * cdiv(Cout, 8)), dim3(256), 0, st, a); break;
+            case 2: hipLaunchKernelGGL((conv3x3_stem_wgrad_kernel<2, 4>), dim3(nb * cdiv(Cout, 4)), dim3(256), 0, st, a); break;
+            case 3: hipLaunchKernelGGL((conv3x3_stem_wgrad_kernel<3, 2>), dim3(nb * cdiv(Cout, 2)), dim3(256), 0, st, a); break;
+            default: hipLaunchKernelGGL((conv3x3_stem_wgrad_kernel<4, 2>), dim3(nb * cdiv(Cout, 2)), dim3(256), 0, st, a); break;
+        }
+        int rc = check_launch("conv3x3_stem_wgrad_kernel");
+        if (rc) return rc;
+        const int64_t n = (int64_t)Cout * Cin;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv(n, 64), 9u), dim3(256), 0, st,
+                           (const float*)ws, dw, nb, 9, Cout, Cin, 0, accumulate);
+        return check_launch("wgrad_reduce_kernel");
+    }
     int pw;
     wgrad_plan(B, Cin, Cout, H, W, ks, pw, a.splitK, a.stripsX, a.stripsY);
     const int64_t need = (int64_t)a.splitK * ks * ks * Cout * Cin * 4;

@@ -87,7 +87,7 @@ class FlatAdam:
                 p.grad = self.gflat[off:off + p.numel()].view_as(p)
 
     def all_reduce_grads(self):
-        if self.world_size > 1:
+        if self.world_size > 1 or (dist.is_available() and dist.is_initialized()):
             dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM, group=self.pg)
 
     def _gather_stray_grads(self):
@@ -108,7 +108,7 @@ class FlatAdam:
         invalidate_packed(self.model)
 
     def broadcast_params(self, src=0):
-        if self.world_size > 1:
+        if self.world_size > 1 or (dist.is_available() and dist.is_initialized()):
             dist.broadcast(self.flat, src=src, group=self.pg)
             for b in self.model.buffers():
                 dist.broadcast(b, src=src, group=self.pg)
@@ -121,7 +121,8 @@ def init_distributed(backend: str | None = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # initialise whenever a launcher set RANK (also for world == 1: it exercises the RCCL path on one GPU)
+    if "RANK" in os.environ and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
