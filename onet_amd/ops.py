@@ -130,6 +130,28 @@ def conv_wgrad(x, dz, dw_shape, ks, out_layout=0):
 
 
 # ----------------------------------------------------------------------------- batch norm + relu
+# SyncBN (SURVEY.md §8e-ii, opt-in): the per-rank Welford partials (forward) and (sum dy, sum dy*xhat)
+# partials (backward) are all-gathered over the data-parallel group before the finalize kernels, so
+# every rank normalises with the statistics of the GLOBAL batch and running stats stay identical.
+SYNC_BN = False
+
+
+def set_sync_bn(flag: bool):
+    global SYNC_BN
+    SYNC_BN = bool(flag)
+
+
+def _gather_partials(part):
+    """[nparts, C, k] -> [world*nparts, C, k] over the default process group (RCCL)."""
+    import torch.distributed as dist
+    if not (SYNC_BN and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return part, 1
+    world = dist.get_world_size()
+    out = torch.empty((world * part.shape[0],) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device)
+    dist.all_gather_into_tensor(out, part.contiguous())
+    return out, world
+
+
 def _bn_nparts(B, HW):
     return B * max(1, (HW + 16383) // 16384)
 
@@ -143,8 +165,10 @@ def bn_train_coeffs(z, gamma, beta, running_mean, running_var, momentum, eps):
     nparts = _bn_nparts(B, H * W)
     part = torch.empty((nparts, C, 3), dtype=F32, device=z.device)
     _lib.call("onet_bn_stats_partial", _p(z), zbs, _p(part), nparts, B, C, H * W, _stream())
+    part, world = _gather_partials(part)
+    nparts *= world
     save = torch.empty((4, C), dtype=F32, device=z.device)
-    _lib.call("onet_bn_finalize", _p(part), nparts, B * H * W, _p(gamma), _p(beta), _p(running_mean),
+    _lib.call("onet_bn_finalize", _p(part), nparts, B * H * W * world, _p(gamma), _p(beta), _p(running_mean),
               _p(running_var), float(momentum), float(eps), _p(save), C, _stream())
     return save
 
@@ -182,7 +206,15 @@ def bn_relu_bwd(da, z, save, training, need_affine_grads=True):
         dgamma = torch.empty(C, dtype=F32, device=dev)
         dbeta = torch.empty(C, dtype=F32, device=dev)
         coef = torch.empty((4, C), dtype=F32, device=dev) if training else None
-        _lib.call("onet_bn_bwd_finalize", _p(part2), nparts, B * HW, _p(dgamma), _p(dbeta), _p(coef), 0, C, _stream())
+        gathered, world = _gather_partials(part2) if training else (part2, 1)
+        if world == 1:
+            _lib.call("onet_bn_bwd_finalize", _p(part2), nparts, B * HW, _p(dgamma), _p(dbeta), _p(coef), 0, C, _stream())
+        else:
+            # SyncBN: dgamma/dbeta are the LOCAL sums (the gradient all-reduce adds the ranks, as in
+            # torch.nn.SyncBatchNorm); c1/c2 in `coef` are means over the GLOBAL batch.
+            _lib.call("onet_bn_bwd_finalize", _p(part2), nparts, B * HW, _p(dgamma), _p(dbeta), None, 0, C, _stream())
+            _lib.call("onet_bn_bwd_finalize", _p(gathered), nparts * world, B * HW * world, None, None, _p(coef), 0, C,
+                      _stream())
     dz = torch.empty((B, C, H, W), dtype=F32, device=dev)
     _lib.call("onet_bn_relu_bwd_apply", _p(da), dabs, _p(z), zbs, _p(save), _p(coef), _p(dz), C * HW, B, C, HW,
               _stream())

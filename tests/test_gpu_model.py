@@ -253,3 +253,41 @@ def test_batch1_16x16_train_raises(dev):
     m = ov.Onet(1, True, True).to(dev).train()
     with pytest.raises(ValueError, match="Expected more than 1 value per channel"):
         m(torch.rand(1, 1, 16, 16, device=dev))
+
+
+def test_config5_shape_3x512x512(dev):
+    """BASELINE config 5 shape (3-channel 512x512 ZY-3 tile): loss and head logits vs the CPU oracle."""
+    B, C, H, W = 2, 3, 512, 512
+    X = orc.det_input(B, C, H, W, seed=5)
+    with torch.no_grad():
+        top = orc.clone_state(orc.det_state_dict(C, 1981), requires_grad=False)
+        Lt, Vt, Ld, Vd, S = orc.onet_forward(X, top, None, training=True)
+        rloss = orc.compute_loss(Lt, S[:, 0:1], Ld, S[:, 1:2])
+    m = _model(C, True, dev)
+    (lt, vt, ld, vd, s), loss = _step(m, X.to(dev))
+    assert lt.shape == (B, 64, H, W) and s.shape == (B, 2, H, W)
+    assert abs(loss.item() - float(rloss)) <= RTOL * abs(float(rloss))
+    _close(vt.detach().cpu().numpy()[:, :, ::61, :], Vt.numpy()[:, :, ::61, :], "Vt 512")
+    g = m.topu.inc.double_conv[0].weight.grad
+    assert g.shape == (64, 3, 3, 3) and bool(torch.isfinite(g).all())
+
+
+def test_sync_bn_plumbing_with_duplicated_shard(dev, monkeypatch):
+    """SyncBN all-gathers the per-rank BN partials.  Faking a 2-rank gather that returns the SAME shard
+    twice must reproduce the single-rank result (statistics of a duplicated batch are unchanged;
+    dgamma/dbeta stay the local sums)."""
+    from onet_amd import ops
+    B, C, H, W = 2, 1, 32, 32
+    X = orc.det_input(B, C, H, W).to(dev)
+    m = _model(C, True, dev)
+    _, loss0 = _step(m, X)
+    g0 = {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+    rm0 = m.topu.inc.double_conv[1].running_mean.detach().clone()
+    m2 = _model(C, True, dev)
+    monkeypatch.setattr(ops, "_gather_partials", lambda part: (torch.cat([part, part]), 2))
+    _, loss1 = _step(m2, X)
+    assert abs(loss1.item() - loss0.item()) <= 1e-6 * abs(loss0.item())
+    assert torch.allclose(m2.topu.inc.double_conv[1].running_mean, rm0, rtol=1e-5, atol=1e-7)
+    for n, p in m2.named_parameters():
+        a, b = p.grad.double(), g0[n].double()
+        assert float((a - b).norm()) <= 1e-4 * float(b.norm()) + 1e-12, n
