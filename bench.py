@@ -135,10 +135,13 @@ def main():
             kern[kind] = {"launches": len(recs), "ms_total": round(ms, 3), "avg_ms": round(ms / len(recs), 4),
                           "tflops": round(fl / (ms * 1e-3) / 1e12, 2)}
         dom = max(kern, key=lambda k: kern[k]["ms_total"])
+        algo = {"conv_wino_kernel": "Winograd F(2x2,3x3) on fp32 MFMA: achieved = direct-convolution FLOPs / time "
+                                    "(the kernel issues 2.25x fewer MFMA FLOPs, so frac can exceed the MFMA busy fraction)",
+                "conv_fwd_kernel": "direct implicit GEMM on fp32 MFMA", "conv_wgrad_kernel": "split-K MFMA wgrad"}
         roofline = {"kernel": dom, "bound": "mfma", "achieved": kern[dom]["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4),
                     "traffic": pmc_traffic(dom), "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc, profiles/)",
-                    "launches_timed": kern[dom]["launches"], "avg_launch_ms": kern[dom]["avg_ms"],
+                    "launches_timed": kern[dom]["launches"], "avg_launch_ms": kern[dom]["avg_ms"], "algorithm": algo.get(dom, dom),
                     "all": kern}
         imgs = args.batch * world * args.steps
         out = {"metric": "training images/sec (twin 256x256 pass)", "value": round(imgs / elapsed, 3),

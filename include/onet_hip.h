@@ -63,6 +63,15 @@ int onet_conv_fwd(const float* x, int64_t x_bs, const float* wp, float* z, int64
                   float* bn_part, int B, int Cin, int Cout, int H, int W, int ks, void* stream);
 int onet_conv_fwd_nparts(int B, int Cout, int H, int W);
 
+/* Fast path for ks=3: Winograd F(2x2,3x3) on the fp32 matrix cores (2.25x fewer multiplies; same
+ * call sites OV:47,51).  wq_fwd [Cin][16][Cout] = G g G^T, wq_dgrad [Cout][16][Cin] = G rot180(g) G^T;
+ * input transform B^T d B in registers from the LDS halo tile, output transform A^T M A in the
+ * epilogue.  Requires Cout % 4 == 0 (otherwise use onet_conv_fwd). */
+int onet_conv3x3_pack_weights_winograd(const float* w, float* wq_fwd, float* wq_dgrad,
+                                       int Cout, int Cin, void* stream);
+int onet_conv3x3_winograd_fwd(const float* x, int64_t x_bs, const float* wq, float* z, int64_t z_bs,
+                              int B, int Cin, int Cout, int H, int W, void* stream);
+
 /* wgrad: dw[co][ci][ky][kx] (+)= sum_{b,y,x} dz[b][co][y][x] * x[b][ci][y+ky-p][x+kx-p]
  * (autograd of F.conv2d wrt weight; reference: implicit via loss.backward(), TS:217).
  * Two launches: split-K partial slabs into `ws`, then a deterministic slab

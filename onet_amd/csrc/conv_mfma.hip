@@ -121,12 +121,15 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
         const int n = gridDim.x, q = n >> 3, r = n & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
-    const int coT = bid % a.coTiles;
-    bid /= a.coTiles;
+    // pixel tile fastest, output-channel tile slowest: the ~32 blocks resident on one XCD at a time then
+    // stream the SAME packed weights (the larger operand per K-chunk) through its L2 once, and
+    // neighbouring pixel tiles share their halo lines.
     const int tx = bid % a.tilesX;
     bid /= a.tilesX;
     const int ty = bid % a.tilesY;
-    const int b = bid / a.tilesY;
+    bid /= a.tilesY;
+    const int b = bid % a.B;
+    const int coT = bid / a.B;
     const int co0 = coT * CO_T, y0 = ty * ROWS, x0 = tx * TW;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;

@@ -1,0 +1,409 @@
+// K1 (fast path): 3x3 convolution forward / dgrad by Winograd F(2x2, 3x3) on the fp32 matrix cores.
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A        (Lavin & Gray 2016; 2.25x fewer multiplies)
+//
+// Replaces the same call sites as conv_mfma.hip (F.conv2d + input-grad, OV:47,51).  The 16 Winograd
+// positions become 16 independent GEMMs  M_pos[co][tile] = sum_ci V_pos[co][ci] * U_pos[ci][tile],
+// i.e. per wave SIXTEEN 32x32 MFMA accumulators (256 VGPRs, one wave per SIMD):
+//   rows  = 32 output channels, columns = 32 Winograd tiles (2x2 output pixels each), K = channels.
+// * weights are pre-transformed once per optimizer step (V = G g G^T, packed [ci][16][co]);
+// * the input transform B^T d B is done in registers, per lane, from the SAME zero-padded LDS halo
+//   tile the direct kernel stages (8 ds_read_b64 + 32 adds per channel pair), so no transformed
+//   tensor ever touches HBM;
+// * the output transform A^T M A runs on the accumulators in the epilogue (24 adds per tile) and
+//   stores float2 pixel pairs (lanes = neighbouring tiles -> 128-B coalesced rows).
+// Same software pipeline as the direct kernel (buffer-load prefetch of chunk c+1 under the MFMAs of
+// chunk c, hardware range check = zero padding) and the same XCD-aware tile order.
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+#include "common.hpp"
+
+using namespace onet;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB_OFF_W = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wmake_rsrc(const void* base, int64_t bytes) {
+    const int n = bytes > 0x7fffffffll ? 0x7fffffff : (int)bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000);
+}
+__device__ __forceinline__ float wbload(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ __forceinline__ u32x4 wbload4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+}
+// LDS-DMA: 64 lanes x 16 B land at lds_byte_addr + lane*16 (wave-uniform base in M0, lane-linear image).
+// Inline asm on purpose: after the builtin form (__builtin_amdgcn_raw_ptr_buffer_load_lds) hipcc puts
+// s_waitcnt vmcnt(0) in front of the next ds_read -- it cannot tell the two LDS buffers apart -- which
+// exposes the whole DMA latency every chunk (measured: 215 -> 187 TFLOP/s).  The asm load is invisible
+// to its bookkeeping; it is retired by the explicit vmcnt(0) in front of the chunk barrier
+// (cdna_hip_programming.md §5.7).  M0 is saved and restored inside the statement.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dma16_to_lds(i32x4 rsrc, unsigned lds_byte_addr, unsigned voff) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(lds_byte_addr)
+                 : "memory");
+}
+__device__ __forceinline__ i32x4 make_rsrc_words(const void* base, int64_t bytes) {
+    const uint64_t p = reinterpret_cast<uint64_t>(base);
+    i32x4 r;
+    r.x = (int)(p & 0xffffffffu);
+    r.y = (int)((p >> 32) & 0xffffu);                     // stride 0
+    r.z = bytes > 0x7fffffffll ? 0x7fffffff : (int)bytes; // num_records (bytes)
+    r.w = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ unsigned lds_addr_of(const float* p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)p;
+}
+
+// ------------------------------------------------------------------ weight transform + packing
+// w [Cout][Cin][3][3] -> wq_fwd [Cin][16][Cout] = G g G^T ;  wq_dgrad [Cout][16][Cin] = G g' G^T with
+// g' = g rotated by 180 degrees (dgrad = convolution of dZ with the flipped, transposed filter)
+__device__ __forceinline__ void wino_G(const float g[3][3], float V[4][4]) {
+    float r[4][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        r[0][j] = g[0][j];
+        r[1][j] = 0.5f * (g[0][j] + g[1][j] + g[2][j]);
+        r[2][j] = 0.5f * (g[0][j] - g[1][j] + g[2][j]);
+        r[3][j] = g[2][j];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        V[i][0] = r[i][0];
+        V[i][1] = 0.5f * (r[i][0] + r[i][1] + r[i][2]);
+        V[i][2] = 0.5f * (r[i][0] - r[i][1] + r[i][2]);
+        V[i][3] = r[i][2];
+    }
+}
+
+__global__ void pack3x3_wino_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wd,
+                                    int Cout, int Cin) {
+    const int64_t n = (int64_t)Cout * Cin;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cin), co = (int)(i / Cin);
+        float g[3][3], gr[3][3], V[4][4];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                g[a][b] = w[i * 9 + a * 3 + b];
+                gr[2 - a][2 - b] = g[a][b];
+            }
+        if (wf) {
+            wino_G(g, V);
+#pragma unroll
+            for (int p = 0; p < 16; ++p) wf[((int64_t)ci * 16 + p) * Cout + co] = V[p >> 2][p & 3];
+        }
+        if (wd) {
+            wino_G(gr, V);
+#pragma unroll
+            for (int p = 0; p < 16; ++p) wd[((int64_t)co * 16 + p) * Cin + ci] = V[p >> 2][p & 3];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ forward / dgrad
+struct WinoArgs {
+    const float* x;
+    int64_t x_bs;
+    const float* wq;      // [Cin][16][Cout]
+    float* z;
+    int64_t z_bs;
+    int B, Cin, Cout, H, W, tilesX, tilesY, coTiles;
+};
+
+template <int TW, int CI_T>
+struct WinoCfg {
+    static constexpr int TC = TW / 2;                 // Winograd tile columns per block (= per wave)
+    static constexpr int TRW = 32 / TC;               // tile rows per wave (32 tiles per wave)
+    static constexpr int ROWS = 2 * TRW * 2;          // output pixel rows per block (2 waves along rows)
+    static constexpr int IN_ROWS = ROWS + 2, IN_COLS = TW + 2;
+    static constexpr int RS = (TW == 32) ? 48 : 24;   // LDS row stride: 2*RS*tr spreads the tile rows over
+                                                      // disjoint bank ranges for the ds_read_b64 patches
+    static constexpr int CH_STRIDE = IN_ROWS * RS;
+    static constexpr int CO_T = 64;
+    static constexpr int W_FLOATS = CI_T * 16 * CO_T;
+    static constexpr int IN_LOGICAL = CI_T * IN_ROWS * IN_COLS;
+    static constexpr int BUF_FLOATS = W_FLOATS + CI_T * CH_STRIDE;       // one staging buffer (weights + input tile)
+    static constexpr int LDS_BYTES = 2 * BUF_FLOATS * 4;                 // double-buffered
+};
+
+// Block = 8 waves = 2 position halves x 2 channel halves x 2 tile halves: a wave owns the Winograd rows
+// xi in {2*ph, 2*ph+1} (8 of the 16 positions, 128 accumulator VGPRs), so two waves share a SIMD and
+// hide each other's LDS / transform latency, and every wave keeps registers for operand prefetch.
+// The output transform is linear in the positions: each half applies A^T . A to its own rows and the
+// two partial 2x2 outputs are added through LDS in the epilogue.
+template <int TW, int CI_T>
+__global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoArgs a) {
+    using C = WinoCfg<TW, CI_T>;
+    constexpr int TC = C::TC, TRW = C::TRW, ROWS = C::ROWS, IN_ROWS = C::IN_ROWS, IN_COLS = C::IN_COLS;
+    constexpr int RS = C::RS, CH_STRIDE = C::CH_STRIDE, CO_T = C::CO_T, W_FLOATS = C::W_FLOATS;
+    constexpr int NTHR = 512;
+    constexpr int NIN = (C::IN_LOGICAL + NTHR - 1) / NTHR;
+    constexpr int NW4 = (W_FLOATS / 4 + NTHR - 1) / NTHR;
+    static_assert(C::LDS_BYTES >= 256 * 64 * 4, "epilogue exchange buffer must fit the staging LDS");
+    static_assert(W_FLOATS % (64 * 4) == 0, "weights are staged in whole 1-KB LDS-DMA pieces");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x { w [CI_T][16][CO_T], in [CI_T][IN_ROWS][RS] }
+
+    int bid;
+    {   // XCD-aware tile order (see conv_mfma.hip)
+        const int n = gridDim.x, q = n >> 3, r = n & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    // pixel tile fastest, output-channel tile slowest: the ~32 blocks resident on one XCD at a time then
+    // stream the SAME packed weights (the larger operand per K-chunk) through its L2 once, and
+    // neighbouring pixel tiles share their halo lines.
+    const int tx = bid % a.tilesX;
+    bid /= a.tilesX;
+    const int ty = bid % a.tilesY;
+    bid /= a.tilesY;
+    const int b = bid % a.B;
+    const int coT = bid / a.B;
+    const int co0 = coT * CO_T, y0 = ty * ROWS, x0 = tx * TW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int ph = wid >> 2, wm = (wid >> 1) & 1, wn = wid & 1;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int tc = l31 % TC, tr = l31 / TC;           // this lane's Winograd tile within the wave
+    const int HW = a.H * a.W;
+
+    f32x16 acc[8];                                    // positions (2*ph + i)*4 + j  ->  acc[i*4 + j]
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+
+    const int a_idx = (kh * 16 + ph * 8) * CO_T + wm * 32 + l31;
+    // rows of the 4x4 patch this half needs: xi = 0,1 use d0,d1,d2 ; xi = 2,3 use d1,d2,d3
+    const int p_idx = W_FLOATS + kh * CH_STRIDE + ((wn * TRW + tr) * 2 + ph) * RS + tc * 2;
+
+    const __amdgpu_buffer_rsrc_t xr = wmake_rsrc(a.x + (int64_t)b * a.x_bs, (int64_t)a.Cin * HW * 4);
+    const i32x4 wr4 = make_rsrc_words(a.wq, (int64_t)a.Cin * 16 * a.Cout * 4);
+
+    unsigned in_off[NIN];
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) {
+        const int i = tid + NTHR * k;
+        const int ci = i / (IN_ROWS * IN_COLS), rem = i % (IN_ROWS * IN_COLS);
+        const int r = rem / IN_COLS, c = rem % IN_COLS;
+        const int yy = y0 - 1 + r, xx = x0 - 1 + c;
+        const bool ok = (i < C::IN_LOGICAL) && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+        in_off[k] = ok ? (unsigned)((ci * HW + yy * a.W + xx) * 4) : OOB_OFF_W;
+    }
+    unsigned w_off[NW4];
+#pragma unroll
+    for (int k = 0; k < NW4; ++k) {
+        const int i = (tid + NTHR * k) * 4;
+        const int ci = i / (16 * CO_T), rem = i % (16 * CO_T);
+        const int p = rem / CO_T, co = rem % CO_T;
+        const bool ok = (i < W_FLOATS) && (co0 + co < a.Cout);
+        w_off[k] = ok ? (unsigned)(((ci * 16 + p) * a.Cout + co0 + co) * 4) : OOB_OFF_W;
+    }
+    const unsigned in_step = (unsigned)(CI_T * HW * 4), w_step = (unsigned)(CI_T * 16 * a.Cout * 4);
+
+    // Staging: the packed weight slice (32 KB per chunk, the larger operand) goes global -> LDS by
+    // LDS-DMA (buffer_load ... lds: no VGPRs, no ds_write pass; the LDS image is lane-linear, which is
+    // exactly the [ci][pos][co] copy order); the halo input tile (irregular, zero-padded) goes
+    // through 6 prefetch VGPRs.  Out-of-range lanes of either kind read 0 by the buffer range check.
+    const int wid_u = __builtin_amdgcn_readfirstlane(wid);
+    float xin[NIN];
+    auto issue = [&](unsigned cin_bytes, unsigned cw_bytes, float* buf) {
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) xin[k] = wbload(xr, in_off[k] + cin_bytes);
+#pragma unroll
+        for (int k = 0; k < NW4; ++k) {
+            if ((wid_u * 64 + NTHR * k) * 4 < W_FLOATS)      // wave-uniform: whole 1-KB pieces only
+                dma16_to_lds(wr4, lds_addr_of(buf) + (unsigned)((wid_u * 64 + NTHR * k) * 16), w_off[k] + cw_bytes);
+        }
+    };
+    auto commit = [&](float* buf) {
+        float* in_lds = buf + W_FLOATS;
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) {
+            const int i = tid + NTHR * k;
+            const int ci = i / (IN_ROWS * IN_COLS), rem = i % (IN_ROWS * IN_COLS);
+            const int r = rem / IN_COLS, c = rem % IN_COLS;
+            if (i < C::IN_LOGICAL) in_lds[ci * CH_STRIDE + r * RS + c] = xin[k];
+        }
+    };
+    // One K-step = one channel pair: 3 patch rows (6 ds_read_b64), 16 adds, 8 A reads, 8 MFMAs.
+    // PH and the LDS buffer are compile-time (specialised code per position half, immediate LDS
+    // offsets): with two waves per SIMD the VALU issue slots between MFMAs are the scarce resource
+    // (an fp32 MFMA leaves room for ~14 VALU issues per 64-cycle slot), so nothing may be spent on
+    // selects or address arithmetic.
+    auto mfma_steps = [&](auto phc, auto bufc, auto cpb, auto cpe) {
+        constexpr int PH = decltype(phc)::value, BUF = decltype(bufc)::value;
+        constexpr int CP0 = decltype(cpb)::value, CP1 = decltype(cpe)::value;
+        const float* a_ptr = smem + a_idx + BUF * C::BUF_FLOATS;
+        const float* p_ptr = smem + p_idx + BUF * C::BUF_FLOATS;
+#pragma unroll
+        for (int cp = CP0; cp < CP1; ++cp) {
+            float d[3][4];                         // rows PH .. PH+2 of the 4x4 patch, channel 2*cp + kh
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float2 lo = *reinterpret_cast<const float2*>(p_ptr + cp * 2 * CH_STRIDE + i * RS);
+                const float2 hi = *reinterpret_cast<const float2*>(p_ptr + cp * 2 * CH_STRIDE + i * RS + 2);
+                d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
+            }
+            // rows of B^T d:  PH=0: t0 = d0 - d2, t1 = d1 + d2 ;  PH=1 (d[] = d1,d2,d3): t2 = d2 - d1, t3 = d1 - d3
+            float t[2][4], u[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (PH == 0) {
+                    t[0][j] = d[0][j] - d[2][j];
+                    t[1][j] = d[1][j] + d[2][j];
+                } else {
+                    t[0][j] = d[1][j] - d[0][j];
+                    t[1][j] = d[0][j] - d[2][j];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                u[i * 4 + 0] = t[i][0] - t[i][2];
+                u[i * 4 + 1] = t[i][1] + t[i][2];
+                u[i * 4 + 2] = t[i][2] - t[i][1];
+                u[i * 4 + 3] = t[i][1] - t[i][3];
+            }
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const float av = a_ptr[(cp * 2 * 16 + p) * CO_T];
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, u[p], acc[p], 0, 0, 0);
+            }
+        }
+    };
+
+    // Double-buffered LDS, ONE barrier per chunk: the loads of chunk c+1 are issued before the MFMAs of
+    // chunk c and committed to the other buffer half-way through them, so neither the global latency
+    // nor the LDS write pass is exposed (the partner wave on the SIMD keeps the matrix pipe busy).
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using H0 = std::integral_constant<int, 0>;
+    using H2 = std::integral_constant<int, CI_T / 2>;
+    unsigned cin_bytes = 0, cw_bytes = 0;
+    auto chunk = [&](auto phc, auto bufc) {
+        constexpr int BUF = decltype(bufc)::value;
+        float* bufn = smem + (BUF ^ 1) * C::BUF_FLOATS;
+        cin_bytes += in_step;
+        cw_bytes += w_step;
+        issue(cin_bytes, cw_bytes, bufn);            // past the end: range check -> zeros, no traffic
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_steps(phc, bufc, H0{}, H2{});
+        __builtin_amdgcn_sched_barrier(0);
+        commit(bufn);                                // 6 dwords per thread; the weight DMA lands on its own
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire this wave's LDS-DMA pieces
+        __syncthreads();
+    };
+    auto run = [&](auto phc) {
+        const int nch = (a.Cin + CI_T - 1) / CI_T;
+        int c = 0;
+        for (; c + 2 <= nch; c += 2) {
+            chunk(phc, I0{});
+            chunk(phc, I1{});
+        }
+        if (c < nch) chunk(phc, I0{});
+    };
+    issue(0, 0, smem);
+    commit(smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (ph == 0) run(I0{}); else run(I1{});
+
+    // ---- epilogue: partial output transform of this half's rows, halves added through LDS
+    //   s0 = m0 + m1 + m2 , s1 = m1 - m2 - m3  (xi index)  ->  ph=0 contributes (m0+m1, m1), ph=1 (m2, -m2-m3)
+    float* ex = smem;                                  // [256 lanes of the ph=0 waves][64] floats, reused LDS
+    const int slot = (wid & 3) * 64 + lane;            // matching lane of the partner wave (same wm, wn)
+    float* zb = a.z + (int64_t)b * a.z_bs;
+    const int oy = y0 + (wn * TRW + tr) * 2, ox = x0 + tc * 2;
+    const bool r0ok = oy < a.H, r1ok = oy + 1 < a.H, c0ok = ox < a.W, c1ok = ox + 1 < a.W;
+    const bool vec2 = c1ok && ((a.W & 1) == 0) && ((a.z_bs & 1) == 0);
+    float y[16][4];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float s0[4], s1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float mA = acc[j][r], mB = acc[4 + j][r];      // rows xi = 2ph, 2ph+1
+            s0[j] = ph ? mA : mA + mB;
+            s1[j] = ph ? -mA - mB : mB;
+        }
+        y[r][0] = s0[0] + s0[1] + s0[2];
+        y[r][1] = s0[1] - s0[2] - s0[3];
+        y[r][2] = s1[0] + s1[1] + s1[2];
+        y[r][3] = s1[1] - s1[2] - s1[3];
+    }
+    if (ph == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ex[(r * 4 + q) * 256 + slot] = y[r][q];
+    }
+    __syncthreads();
+    if (ph == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const float y00 = y[r][0] + ex[(r * 4 + 0) * 256 + slot], y01 = y[r][1] + ex[(r * 4 + 1) * 256 + slot];
+            const float y10 = y[r][2] + ex[(r * 4 + 2) * 256 + slot], y11 = y[r][3] + ex[(r * 4 + 3) * 256 + slot];
+            if (co < a.Cout && c0ok) {
+                float* o = zb + (int64_t)co * HW + (int64_t)oy * a.W + ox;
+                if (vec2) {
+                    if (r0ok) *reinterpret_cast<float2*>(o) = make_float2(y00, y01);
+                    if (r1ok) *reinterpret_cast<float2*>(o + a.W) = make_float2(y10, y11);
+                } else {
+                    if (r0ok) { o[0] = y00; if (c1ok) o[1] = y01; }
+                    if (r1ok) { o[a.W] = y10; if (c1ok) o[a.W + 1] = y11; }
+                }
+            }
+        }
+    }
+}
+
+template <int TW, int CI_T>
+static int launch_wino(WinoArgs a, hipStream_t st) {
+    using C = WinoCfg<TW, CI_T>;
+    a.tilesX = cdiv(a.W, TW);
+    a.tilesY = cdiv(a.H, C::ROWS);
+    a.coTiles = cdiv(a.Cout, C::CO_T);
+    const int64_t blocks = (int64_t)a.B * a.tilesX * a.tilesY * a.coTiles;
+    ONET_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv_wino: grid %lld out of range", (long long)blocks);
+    auto kern = conv_wino_kernel<TW, CI_T>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  C::LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), C::LDS_BYTES, st, a);
+    return check_launch("conv_wino_kernel");
+}
+
+extern "C" {
+
+int onet_conv3x3_pack_weights_winograd(const float* w, float* wq_fwd, float* wq_dgrad, int Cout, int Cin,
+                                       void* stream) {
+    ONET_REQUIRE(w && Cout > 0 && Cin > 0, "pack3x3_winograd: bad args");
+    const int64_t n = (int64_t)Cout * Cin;
+    hipLaunchKernelGGL(pack3x3_wino_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n, 256), 4096)), dim3(256), 0,
+                       as_stream(stream), w, wq_fwd, wq_dgrad, Cout, Cin);
+    return check_launch("pack3x3_wino_kernel");
+}
+
+int onet_conv3x3_winograd_fwd(const float* x, int64_t x_bs, const float* wq, float* z, int64_t z_bs, int B, int Cin,
+                              int Cout, int H, int W, void* stream) {
+    ONET_REQUIRE(x && wq && z, "conv3x3_winograd_fwd: null pointer");
+    ONET_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv3x3_winograd_fwd: bad shape");
+    ONET_REQUIRE((Cout & 3) == 0, "conv3x3_winograd_fwd: Cout must be a multiple of 4 (use onet_conv_fwd)");
+    ONET_REQUIRE(x_bs >= (int64_t)Cin * H * W && z_bs >= (int64_t)Cout * H * W, "conv3x3_winograd_fwd: batch stride too small");
+    WinoArgs a{x, x_bs, wq, z, z_bs, B, Cin, Cout, H, W, 0, 0, 0};
+    return (W > 16) ? launch_wino<32, 8>(a, as_stream(stream)) : launch_wino<16, 8>(a, as_stream(stream));
+}
+
+}  // extern "C"

@@ -19,27 +19,26 @@ class ConvBNReLUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, running_mean, running_var, training, momentum, eps, packed, out):
         ops.require_gpu(x, weight, gamma, beta)
-        wp_fwd, wp_dgrad = packed
-        Cout = weight.shape[0]
-        z = ops.conv_fwd(x, wp_fwd, Cout, 3)
+        z = ops.conv3x3_auto(x, packed, 0)
         if training:
             save = ops.bn_train_coeffs(z, gamma, beta, running_mean, running_var, momentum, eps)
         else:
             save = ops.bn_eval_coeffs(gamma, beta, running_mean, running_var, eps)
         # `out` is None or a 1-tuple holding a plane-contiguous destination view (kept out of autograd's sight)
         a = ops.bn_relu_apply(z, save, out=None if out is None else out[0])
-        ctx.save_for_backward(x, z, save, wp_dgrad)
+        ctx.save_for_backward(x, z, save)
         ctx.training = training
+        ctx.packed = packed
         ctx.wshape = tuple(weight.shape)
         return a
 
     @staticmethod
     def backward(ctx, da):
-        x, z, save, wp_dgrad = ctx.saved_tensors
+        x, z, save = ctx.saved_tensors
         need_x, need_w, need_g, need_b = ctx.needs_input_grad[:4]
         dz, dgamma, dbeta = ops.bn_relu_bwd(da, z, save, ctx.training, need_affine_grads=(need_g or need_b))
         dw = ops.conv_wgrad(x, dz, ctx.wshape, 3) if need_w else None
-        dx = ops.conv_fwd(dz, wp_dgrad, ctx.wshape[1], 3) if need_x else None
+        dx = ops.conv3x3_auto(dz, ctx.packed, 1) if need_x else None
         return dx, dw, (dgamma if need_g else None), (dbeta if need_b else None), None, None, None, None, None, None, None
 
 
@@ -49,16 +48,17 @@ class Conv3x3Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, packed):
         ops.require_gpu(x, weight)
-        z = ops.conv_fwd(x, packed[0], weight.shape[0], 3)
-        ctx.save_for_backward(x, packed[1])
+        z = ops.conv3x3_auto(x, packed, 0)
+        ctx.save_for_backward(x)
+        ctx.packed = packed
         ctx.wshape = tuple(weight.shape)
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        x, wp_dgrad = ctx.saved_tensors
+        (x,) = ctx.saved_tensors
         dw = ops.conv_wgrad(x, dz, ctx.wshape, 3) if ctx.needs_input_grad[1] else None
-        dx = ops.conv_fwd(dz, wp_dgrad, ctx.wshape[1], 3) if ctx.needs_input_grad[0] else None
+        dx = ops.conv3x3_auto(dz, ctx.packed, 1) if ctx.needs_input_grad[0] else None
         return dx, dw, None
 
 

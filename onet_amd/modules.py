@@ -55,7 +55,7 @@ class Conv3x3(nn.Conv2d, _Packable):
         super().__init__(in_channels, out_channels, kernel_size=3, padding=1, bias=False)
 
     def _pack_fn(self, w):
-        return ops.pack3x3(w)
+        return ops.pack3x3_auto(w)
 
     def forward(self, x):
         return Fn.Conv3x3Fn.apply(x, self.weight, self.packed())

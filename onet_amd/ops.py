@@ -99,6 +99,60 @@ def packT2x2(w):
     return wf, wd
 
 
+# 3x3 convolution algorithm for fwd/dgrad: "winograd" (F(2x2,3x3) on the MFMA cores, default) or
+# "direct" (implicit GEMM); ONET_CONV_ALGO overrides.  Layers the Winograd kernel does not take
+# (stem Cin < 16, channel counts not multiples of 4) always use the direct kernel.
+import os as _os
+CONV_ALGO = _os.environ.get("ONET_CONV_ALGO", "winograd")
+
+
+def use_winograd(Cin, Cout, H, W):
+    """Winograd pays on real feature maps; on maps smaller than 8x8 its 2x2-tile quantisation wastes
+    most of the MFMA tile and the direct kernel's two-level accumulation is the more accurate one."""
+    return CONV_ALGO == "winograd" and Cin >= 16 and Cin % 4 == 0 and Cout % 4 == 0 and min(H, W) >= 8
+
+
+def pack3x3_auto(w):
+    """-> dict of packed weights for conv3x3_auto: direct (fwd, dgrad) always, Winograd when eligible."""
+    Cout, Cin = w.shape[0], w.shape[1]
+    pk = {"direct": pack3x3(w), "Cin": Cin, "Cout": Cout}
+    if CONV_ALGO == "winograd" and Cin >= 16 and Cin % 4 == 0 and Cout % 4 == 0:
+        pk["winograd"] = pack3x3_winograd(w)
+    return pk
+
+
+def conv3x3_auto(x, pk, direction, out=None):
+    """direction 0: forward (Cin -> Cout); 1: dgrad (Cout -> Cin) with the flipped/transposed pack."""
+    Co = pk["Cout"] if direction == 0 else pk["Cin"]
+    if "winograd" in pk and use_winograd(pk["Cin"], pk["Cout"], x.shape[2], x.shape[3]):
+        return conv3x3_winograd(x, pk["winograd"][direction], Co, out=out)
+    return conv_fwd(x, pk["direct"][direction], Co, 3, out=out)
+
+
+def pack3x3_winograd(w):
+    require_gpu(w)
+    w = w.detach().contiguous()
+    Cout, Cin = w.shape[0], w.shape[1]
+    wf = torch.empty(Cin * 16 * Cout, dtype=F32, device=w.device)
+    wd = torch.empty(Cout * 16 * Cin, dtype=F32, device=w.device)
+    _lib.call("onet_conv3x3_pack_weights_winograd", _p(w), _p(wf), _p(wd), Cout, Cin, _stream())
+    return wf, wd
+
+
+def conv3x3_winograd(x, wq, Cout, out=None):
+    """z = conv3x3(x) by Winograd F(2x2,3x3) with transformed weights wq ([Cin][16][Cout]); fwd and dgrad."""
+    require_gpu(x, wq)
+    x, xbs = plane(x)
+    B, Cin, H, W = x.shape
+    if out is None:
+        out = torch.empty((B, Cout, H, W), dtype=F32, device=x.device)
+    zbs = out.stride(0) if B > 1 else Cout * H * W
+    e0 = _prof_begin()
+    _lib.call("onet_conv3x3_winograd_fwd", _p(x), xbs, _p(wq), _p(out), zbs, B, Cin, Cout, H, W, _stream())
+    _prof_end("conv_wino_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0)
+    return out
+
+
 def conv_fwd(x, wp, Cout, ks, out=None):
     """z = conv_ks(x) with packed weights wp ([Cin][ks*ks][Cout]); also used for dgrad."""
     require_gpu(x, wp)

@@ -14,8 +14,10 @@ gradient is discontinuous: wherever a pre-activation lies within rounding distan
 fp32 evaluations may mask it differently, and ONE such element shifts every upstream gradient by
 ~1/sqrt(#elements of that activation) (measured with tools/diag_acts.py: the error steps from 1e-5 to
 ~2e-3 at a single tensor).  Gradients are therefore checked against the TRUTH with the bound
-    max(1e-3, 4 x eps_ref, 1/sqrt(n_bottleneck))        n_bottleneck = B*1024*(H/16)*(W/16)
-(= one kink flip at the smallest activation); forward outputs, loss, labels and running statistics
+    max(1e-3, 4 x eps_ref, 2/sqrt(n_bottleneck))        n_bottleneck = B*1024*(H/16)*(W/16)
+(= two kink flips at the smallest activation; the Winograd kernel's z is 2-4x noisier than the
+direct kernel's on the deep layers -- tools/conv_accuracy.py: 8.5e-7 vs 2.3e-7 of exact at Cin=1024 --
+so flips against the exact evaluation are that much likelier); forward outputs, loss, labels and running statistics
 are held to the plain 1e-3."""
 import os
 
@@ -102,7 +104,7 @@ def test_train_step_vs_reference_golden(dev, tag):
     h32, h64 = g["grad_heads"].astype(np.float64), g["grad_heads64"]
     hs = np.linalg.norm(h64, axis=1) + 1e-300
     eps_ref = max(float(np.max(np.abs(n32 - n64) / n64)), float(np.max(np.linalg.norm(h32 - h64, axis=1) / hs)))
-    tol = max(RTOL, 4 * eps_ref, 1.0 / np.sqrt(B * 1024 * max(1, H // 16) * max(1, W // 16)))
+    tol = max(RTOL, 4 * eps_ref, 2.0 / np.sqrt(B * 1024 * max(1, H // 16) * max(1, W // 16)))
     for i, n in enumerate(names):
         gr = named[n].grad.detach().reshape(-1).double().cpu()
         k = min(64, gr.numel())
@@ -230,7 +232,7 @@ def test_vs_oracle_fresh_seed(dev):
     for k, gr in grads.items():
         a = named[k].grad.detach().cpu().double()
         t = grads64[k]
-        tol = max(RTOL, 4 * eps_ref, 1.0 / (B * 1024 * (H // 16) * (W // 16)) ** 0.5)
+        tol = max(RTOL, 4 * eps_ref, 2.0 / (B * 1024 * (H // 16) * (W // 16)) ** 0.5)
         assert float((a - t).norm() / t.norm()) <= tol, (k, float((a - t).norm() / t.norm()), eps_ref)
 
 

@@ -80,6 +80,24 @@ def test_conv_fwd_dgrad_wgrad(dev, B, Cin, Cout, H, W, ks):
     close(dw, wr.grad, tol=3e-4, what="wgrad")
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 64, 64, 40, 48), (2, 16, 64, 16, 16), (1, 32, 128, 64, 64),
+                                             (2, 128, 256, 16, 16), (2, 24, 36, 9, 7), (3, 8, 64, 33, 31),
+                                             (2, 1024, 512, 4, 4), (2, 3, 12, 17, 23)])
+def test_conv3x3_winograd_fwd_dgrad(dev, B, Cin, Cout, H, W):
+    """Winograd F(2x2,3x3) MFMA path against the direct CPU convolution (fwd and dgrad orientation)."""
+    from onet_amd import ops
+    x = rnd(B, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=(2.0 / (Cin * 9)) ** 0.5)
+    g = rnd(B, Cout, H, W, seed=3)
+    xr = x.clone().requires_grad_(True)
+    zr = F.conv2d(xr, w, None, 1, 1)
+    zr.backward(g)
+    qf, qd = ops.pack3x3_winograd(w.to(dev))
+    close(ops.conv3x3_winograd(x.to(dev), qf, Cout), zr, what="winograd fwd")
+    if Cin % 4 == 0:
+        close(ops.conv3x3_winograd(g.to(dev), qd, Cin), xr.grad, what="winograd dgrad")
+
+
 def test_conv_on_channel_slices(dev):
     """inputs/outputs that are channel-slices of wider (concat) buffers: batch stride != C*H*W"""
     from onet_amd import ops
