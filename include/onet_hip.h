@@ -71,6 +71,12 @@ int onet_conv3x3_pack_weights_winograd(const float* w, float* wq_fwd, float* wq_
                                        int Cout, int Cin, void* stream);
 int onet_conv3x3_winograd_fwd(const float* x, int64_t x_bs, const float* wq, float* z, int64_t z_bs,
                               int B, int Cin, int Cout, int H, int W, void* stream);
+/* Winograd weight gradient: dW = G^T [ sum_tiles (A dY A^T) (.) (B^T d B) ] G, split-K over pixel strips,
+ * deterministic slab reduction; dw is [Cout][Cin][3][3]. */
+int onet_conv3x3_winograd_wgrad(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs, float* dw,
+                                void* ws, int64_t ws_bytes, int B, int Cin, int Cout, int H, int W,
+                                int accumulate, void* stream);
+int64_t onet_conv3x3_winograd_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W);
 
 /* wgrad: dw[co][ci][ky][kx] (+)= sum_{b,y,x} dz[b][co][y][x] * x[b][ci][y+ky-p][x+kx-p]
  * (autograd of F.conv2d wrt weight; reference: implicit via loss.backward(), TS:217).

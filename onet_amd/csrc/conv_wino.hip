@@ -215,7 +215,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoArgs a) {
     // through 6 prefetch VGPRs.  Out-of-range lanes of either kind read 0 by the buffer range check.
     const int wid_u = __builtin_amdgcn_readfirstlane(wid);
     float xin[NIN];
-    auto issue = [&](unsigned cin_bytes, unsigned cw_bytes, float* buf) {
+    auto issue = [&](unsigned cin_bytes, unsigned cw_bytes, float* buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < NIN; ++k) xin[k] = wbload(xr, in_off[k] + cin_bytes);
 #pragma unroll
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoArgs a) {
                 dma16_to_lds(wr4, lds_addr_of(buf) + (unsigned)((wid_u * 64 + NTHR * k) * 16), w_off[k] + cw_bytes);
         }
     };
-    auto commit = [&](float* buf) {
+    auto commit = [&](float* buf) __attribute__((always_inline)) {
         float* in_lds = buf + W_FLOATS;
 #pragma unroll
         for (int k = 0; k < NIN; ++k) {
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoArgs a) {
     // offsets): with two waves per SIMD the VALU issue slots between MFMAs are the scarce resource
     // (an fp32 MFMA leaves room for ~14 VALU issues per 64-cycle slot), so nothing may be spent on
     // selects or address arithmetic.
-    auto mfma_steps = [&](auto phc, auto bufc, auto cpb, auto cpe) {
+    auto mfma_steps = [&](auto phc, auto bufc, auto cpb, auto cpe) __attribute__((always_inline)) {
         constexpr int PH = decltype(phc)::value, BUF = decltype(bufc)::value;
         constexpr int CP0 = decltype(cpb)::value, CP1 = decltype(cpe)::value;
         const float* a_ptr = smem + a_idx + BUF * C::BUF_FLOATS;
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoArgs a) {
     using H0 = std::integral_constant<int, 0>;
     using H2 = std::integral_constant<int, CI_T / 2>;
     unsigned cin_bytes = 0, cw_bytes = 0;
-    auto chunk = [&](auto phc, auto bufc) {
+    auto chunk = [&](auto phc, auto bufc) __attribute__((always_inline)) {
         constexpr int BUF = decltype(bufc)::value;
         float* bufn = smem + (BUF ^ 1) * C::BUF_FLOATS;
         cin_bytes += in_step;
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire this wave's LDS-DMA pieces
         __syncthreads();
     };
-    auto run = [&](auto phc) {
+    auto run = [&](auto phc) __attribute__((always_inline)) {
         const int nch = (a.Cin + CI_T - 1) / CI_T;
         int c = 0;
         for (; c + 2 <= nch; c += 2) {
@@ -385,6 +385,304 @@ static int launch_wino(WinoArgs a, hipStream_t st) {
     return check_launch("conv_wino_kernel");
 }
 
+// ------------------------------------------------------------------ wgrad
+//   dW = G^T [ sum_tiles (A dY A^T) (.) (B^T d B) ] G          (Winograd F(2x2,3x3) weight gradient)
+// 16 GEMMs  M_pos[co][ci] = sum_tile Z_pos[co][tile] * U_pos[ci][tile]: M = co, N = ci, K = tiles.
+// Block = 8 waves = 2 position halves x 2 co halves x 2 ci halves (64 co x 64 ci x 16 positions),
+// 8 accumulators per wave; both transforms run in registers from channel-major LDS strips whose
+// channel stride is == 2 (mod 64) floats, so the 32 lanes (= 32 channels) of a ds_read_b64 hit 64
+// distinct banks.  Split-K over (image, strip) units; raw per-position slabs are reduced
+// deterministically and then folded by G^T . G into the nn.Conv2d layout.
+struct WwArgs {
+    const float* x;
+    int64_t x_bs;
+    const float* dz;
+    int64_t dz_bs;
+    float* slab;
+    int B, Cin, Cout, H, W, ciTiles, coTiles, splitK, stripsY, stripsX;
+};
+
+template <int PW>
+struct WwCfg {
+    static constexpr int PR = 64 / PW;                      // pixel rows per strip (64 px = 16 tiles)
+    static constexpr int XR = PR + 2, XC = PW + 2;
+    static constexpr int TCS = PW / 2;                      // tiles per tile row
+    static constexpr int DZS = 66;                          // 64 px + 2   (== 2 mod 64)
+    static constexpr int XS = (XR * XC <= 130) ? 130 : 194; // >= XR*XC and == 2 mod 64
+    static constexpr int BUF_FLOATS = 64 * (DZS + XS);
+    static constexpr int LDS_BYTES = 2 * BUF_FLOATS * 4;
+};
+
+template <int PW>
+__global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(WwArgs a) {
+    using C = WwCfg<PW>;
+    constexpr int PR = C::PR, XR = C::XR, XC = C::XC, TCS = C::TCS, DZS = C::DZS, XS = C::XS;
+    constexpr int NTHR = 512;
+    constexpr int NDZ = 8;                                   // 64 ch * 64 px / 512
+    constexpr int ROWS_PER_K = NTHR / PW, CH_PER_K = ROWS_PER_K / XR;
+    constexpr int NXM = (64 + CH_PER_K - 1) / CH_PER_K;
+    constexpr int NXH = (64 * XR * 2 + NTHR - 1) / NTHR;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x { dz [64][DZS], x [64][XS] }
+
+    int bid;
+    {
+        const int n = gridDim.x, q = n >> 3, r = n & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int tiles = a.ciTiles * a.coTiles;
+    const int ks = bid / tiles, tile = bid % tiles;
+    const int ciT = tile % a.ciTiles, coT = tile / a.ciTiles;
+    const int co0 = coT * 64, ci0 = ciT * 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int ph = wid >> 2, wm = (wid >> 1) & 1, wn = wid & 1;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int HW = a.H * a.W;
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+
+    const int a_idx = (wm * 32 + l31) * DZS + kh * 2;                        // dz tile of lane parity kh
+    const int b_idx = 64 * DZS + (wn * 32 + l31) * XS + ph * XC + kh * 2;    // patch rows ph..ph+2
+
+    const int dz_c = tid >> 6, dz_p = tid & 63, dz_r = dz_p / PW, dz_col = dz_p % PW;
+    const int xm_col = tid % PW, xm_rowid = tid / PW, xm_cp = xm_rowid / XR, xm_r = xm_rowid % XR;
+    const bool xm_thread = xm_rowid < CH_PER_K * XR;
+    const unsigned dz_kstep = (unsigned)(8 * HW * 4), xm_kstep = (unsigned)(CH_PER_K * HW * 4);
+
+    float dzv[NDZ], xmv[NXM], xhv[NXH];
+    const int nunits = a.B * a.stripsY * a.stripsX;
+
+    auto issue = [&](int u) __attribute__((always_inline)) {
+        const bool live = u < nunits;
+        const int uu = live ? u : 0;
+        const int sx = uu % a.stripsX;
+        const int sy = (uu / a.stripsX) % a.stripsY;
+        const int b = uu / (a.stripsX * a.stripsY);
+        const int y0 = sy * PR, x0 = sx * PW;
+        const __amdgpu_buffer_rsrc_t dr = wmake_rsrc(a.dz + (int64_t)b * a.dz_bs, (int64_t)a.Cout * HW * 4);
+        const __amdgpu_buffer_rsrc_t xr = wmake_rsrc(a.x + (int64_t)b * a.x_bs, (int64_t)a.Cin * HW * 4);
+        {
+            const int yy = y0 + dz_r, xx = x0 + dz_col;
+            const bool ok = live && yy < a.H && xx < a.W;
+            const unsigned base = ok ? (unsigned)(((co0 + dz_c) * HW + yy * a.W + xx) * 4) : OOB_OFF_W;
+#pragma unroll
+            for (int k = 0; k < NDZ; ++k) dzv[k] = wbload(dr, base + k * dz_kstep);
+        }
+        {
+            const int yy = y0 - 1 + xm_r, xx = x0 + xm_col;
+            const bool ok = live && xm_thread && yy >= 0 && yy < a.H && xx < a.W;
+            const unsigned base = ok ? (unsigned)(((ci0 + xm_cp) * HW + yy * a.W + xx) * 4) : OOB_OFF_W;
+#pragma unroll
+            for (int k = 0; k < NXM; ++k)
+                xmv[k] = wbload(xr, (xm_cp + CH_PER_K * k < 64) ? base + k * xm_kstep : OOB_OFF_W);
+        }
+#pragma unroll
+        for (int j = 0; j < NXH; ++j) {
+            const int e = tid + NTHR * j;
+            const int c = e / (2 * XR), q = e % (2 * XR);
+            const int r = q >> 1, side = q & 1;
+            const int yy = y0 - 1 + r, xx = side ? x0 + PW : x0 - 1;
+            const bool ok = live && e < 64 * XR * 2 && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+            xhv[j] = wbload(xr, ok ? (unsigned)(((ci0 + c) * HW + yy * a.W + xx) * 4) : OOB_OFF_W);
+        }
+    };
+    auto commit = [&](float* buf) __attribute__((always_inline)) {
+        float* dz_lds = buf;
+        float* x_lds = buf + 64 * DZS;
+#pragma unroll
+        for (int k = 0; k < NDZ; ++k) dz_lds[(dz_c + 8 * k) * DZS + dz_p] = dzv[k];
+        if (xm_thread) {
+#pragma unroll
+            for (int k = 0; k < NXM; ++k)
+                if (xm_cp + CH_PER_K * k < 64) x_lds[(xm_cp + CH_PER_K * k) * XS + xm_r * XC + xm_col + 1] = xmv[k];
+        }
+#pragma unroll
+        for (int j = 0; j < NXH; ++j) {
+            const int e = tid + NTHR * j;
+            const int c = e / (2 * XR), q = e % (2 * XR);
+            if (e < 64 * XR * 2) x_lds[c * XS + (q >> 1) * XC + ((q & 1) ? XC - 1 : 0)] = xhv[j];
+        }
+    };
+    // one K-step = one pair of tiles (lane parity kh picks the tile): 2+3 LDS reads, 22 adds, 8 MFMAs
+    auto steps = [&](auto phc, auto bufc, auto sb, auto se) __attribute__((always_inline)) {
+        constexpr int PH = decltype(phc)::value, BUF = decltype(bufc)::value;
+        constexpr int S0 = decltype(sb)::value, S1 = decltype(se)::value;
+        const float* zp = smem + BUF * C::BUF_FLOATS + a_idx;
+        const float* xp = smem + BUF * C::BUF_FLOATS + b_idx;
+#pragma unroll
+        for (int st = S0; st < S1; ++st) {
+            const int trow = (2 * st) / TCS, tcol2 = ((2 * st) % TCS) * 2;   // tile 2*st (+kh via the lane base)
+            const float2 y0v = *reinterpret_cast<const float2*>(zp + (2 * trow) * PW + tcol2);
+            const float2 y1v = *reinterpret_cast<const float2*>(zp + (2 * trow + 1) * PW + tcol2);
+            float d[3][4];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float2 lo = *reinterpret_cast<const float2*>(xp + (2 * trow + i) * XC + tcol2);
+                const float2 hi = *reinterpret_cast<const float2*>(xp + (2 * trow + i) * XC + tcol2 + 2);
+                d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
+            }
+            // Z rows xi = 2PH, 2PH+1 of A dY A^T
+            float zr[2][2], z[8];
+            if constexpr (PH == 0) {
+                zr[0][0] = y0v.x; zr[0][1] = y0v.y;
+                zr[1][0] = y0v.x + y1v.x; zr[1][1] = y0v.y + y1v.y;
+            } else {
+                zr[0][0] = y0v.x - y1v.x; zr[0][1] = y0v.y - y1v.y;
+                zr[1][0] = -y1v.x; zr[1][1] = -y1v.y;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                z[i * 4 + 0] = zr[i][0];
+                z[i * 4 + 1] = zr[i][0] + zr[i][1];
+                z[i * 4 + 2] = zr[i][0] - zr[i][1];
+                z[i * 4 + 3] = -zr[i][1];
+            }
+            // U rows xi = 2PH, 2PH+1 of B^T d B (d[] holds patch rows PH..PH+2)
+            float t[2][4], u[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (PH == 0) {
+                    t[0][j] = d[0][j] - d[2][j];
+                    t[1][j] = d[1][j] + d[2][j];
+                } else {
+                    t[0][j] = d[1][j] - d[0][j];
+                    t[1][j] = d[0][j] - d[2][j];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                u[i * 4 + 0] = t[i][0] - t[i][2];
+                u[i * 4 + 1] = t[i][1] + t[i][2];
+                u[i * 4 + 2] = t[i][2] - t[i][1];
+                u[i * 4 + 3] = t[i][1] - t[i][3];
+            }
+#pragma unroll
+            for (int p = 0; p < 8; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(z[p], u[p], acc[p], 0, 0, 0);
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using S0 = std::integral_constant<int, 0>;
+    using S4 = std::integral_constant<int, 4>;
+    using S8 = std::integral_constant<int, 8>;
+    int unext = ks;
+    auto stage = [&](auto phc, auto bufc) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(bufc)::value;
+        unext += a.splitK;
+        issue(unext);
+        __builtin_amdgcn_sched_barrier(0);
+        steps(phc, bufc, S0{}, S4{});
+        __builtin_amdgcn_sched_barrier(0);
+        commit(smem + (BUF ^ 1) * C::BUF_FLOATS);
+        __builtin_amdgcn_sched_barrier(0);
+        steps(phc, bufc, S4{}, S8{});
+        __syncthreads();
+    };
+    auto run = [&](auto phc) __attribute__((always_inline)) {
+        const int nst = (nunits - ks + a.splitK - 1) / a.splitK;
+        int c = 0;
+        for (; c + 2 <= nst; c += 2) {
+            stage(phc, I0{});
+            stage(phc, I1{});
+        }
+        if (c < nst) stage(phc, I0{});
+    };
+    issue(ks);
+    commit(smem);
+    __syncthreads();
+    if (ph == 0) run(I0{}); else run(I1{});
+
+    // raw slab[ks][pos][co][ci]; lanes run along ci (coalesced)
+    float* sl = a.slab + (int64_t)ks * 16 * a.Cout * a.Cin;
+    const int ci = ci0 + wn * 32 + l31;
+    if (ci < a.Cin) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (co < a.Cout) sl[((int64_t)(ph * 8 + p) * a.Cout + co) * a.Cin + ci] = acc[p][r];
+            }
+        }
+    }
+}
+
+// raw[pos][i] = sum_ks slab[ks][pos][i]   (i = co*Cin + ci); block = 64 i x 4 split-K groups
+__global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ raw,
+                                                                int splitK, int64_t n) {
+    __shared__ float red[256];
+    const int p = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int g = threadIdx.x >> 6;
+    float s = 0.f;
+    if (i < n)
+        for (int k = g; k < splitK; k += 4) s += slab[((int64_t)k * 16 + p) * n + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (g == 0 && i < n)
+        raw[(int64_t)p * n + i] = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+}
+
+// dw[co][ci][3][3] (+)= G^T M G,  G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]
+__global__ void wino_wgrad_transform_kernel(const float* __restrict__ raw, float* __restrict__ dw, int64_t n,
+                                            int accumulate) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float m[4][4], r[3][4];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) m[p >> 2][p & 3] = raw[(int64_t)p * n + i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r[0][j] = m[0][j] + 0.5f * (m[1][j] + m[2][j]);
+        r[1][j] = 0.5f * (m[1][j] - m[2][j]);
+        r[2][j] = 0.5f * (m[1][j] + m[2][j]) + m[3][j];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float g0 = r[k][0] + 0.5f * (r[k][1] + r[k][2]);
+        const float g1 = 0.5f * (r[k][1] - r[k][2]);
+        const float g2 = 0.5f * (r[k][1] + r[k][2]) + r[k][3];
+        float* o = dw + i * 9 + k * 3;
+        o[0] = accumulate ? o[0] + g0 : g0;
+        o[1] = accumulate ? o[1] + g1 : g1;
+        o[2] = accumulate ? o[2] + g2 : g2;
+    }
+}
+
+static void wino_wgrad_plan(int B, int Cin, int Cout, int H, int W, int& pw, int& splitK, int& sx, int& sy) {
+    pw = (W > 16) ? 32 : 16;
+    const int pr = 64 / pw;
+    sx = cdiv(W, pw);
+    sy = cdiv(H, pr);
+    const int64_t nunits = (int64_t)B * sx * sy;
+    const int64_t tiles = (int64_t)cdiv(Cout, 64) * cdiv(Cin, 64);
+    int64_t s = (512 + tiles - 1) / tiles;                       // one 8-wave block per CU, ~2 rounds
+    const int64_t per = (int64_t)16 * Cout * Cin * 4;
+    const int64_t cap = (160ll << 20) / (per > 0 ? per : 1);
+    if (s > cap) s = cap;
+    if (s > nunits) s = nunits;
+    if (s < 1) s = 1;
+    splitK = (int)s;
+}
+
+template <int PW>
+static void launch_wino_wgrad(const WwArgs& a, int64_t blocks, hipStream_t st) {
+    using C = WwCfg<PW>;
+    auto kern = conv_wino_wgrad_kernel<PW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  C::LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), C::LDS_BYTES, st, a);
+}
+
 extern "C" {
 
 int onet_conv3x3_pack_weights_winograd(const float* w, float* wq_fwd, float* wq_dgrad, int Cout, int Cin,
@@ -404,6 +702,38 @@ int onet_conv3x3_winograd_fwd(const float* x, int64_t x_bs, const float* wq, flo
     ONET_REQUIRE(x_bs >= (int64_t)Cin * H * W && z_bs >= (int64_t)Cout * H * W, "conv3x3_winograd_fwd: batch stride too small");
     WinoArgs a{x, x_bs, wq, z, z_bs, B, Cin, Cout, H, W, 0, 0, 0};
     return (W > 16) ? launch_wino<32, 8>(a, as_stream(stream)) : launch_wino<16, 8>(a, as_stream(stream));
+}
+
+int64_t onet_conv3x3_winograd_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W) {
+    int pw, splitK, sx, sy;
+    wino_wgrad_plan(B, Cin, Cout, H, W, pw, splitK, sx, sy);
+    return ((int64_t)splitK + 1) * 16 * Cout * Cin * 4;
+}
+
+int onet_conv3x3_winograd_wgrad(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs, float* dw, void* ws,
+                                int64_t ws_bytes, int B, int Cin, int Cout, int H, int W, int accumulate,
+                                void* stream) {
+    ONET_REQUIRE(x && dz && dw && ws, "conv3x3_winograd_wgrad: null pointer");
+    ONET_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv3x3_winograd_wgrad: bad shape");
+    WwArgs a{x, x_bs, dz, dz_bs, (float*)ws, B, Cin, Cout, H, W, cdiv(Cin, 64), cdiv(Cout, 64), 1, 1, 1};
+    int pw;
+    wino_wgrad_plan(B, Cin, Cout, H, W, pw, a.splitK, a.stripsX, a.stripsY);
+    const int64_t n = (int64_t)Cout * Cin;
+    const int64_t need = ((int64_t)a.splitK + 1) * 16 * n * 4;
+    ONET_REQUIRE(ws_bytes >= need, "conv3x3_winograd_wgrad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
+    const int64_t blocks = (int64_t)a.splitK * a.ciTiles * a.coTiles;
+    hipStream_t st = as_stream(stream);
+    if (pw == 32) launch_wino_wgrad<32>(a, blocks, st); else launch_wino_wgrad<16>(a, blocks, st);
+    int rc = check_launch("conv_wino_wgrad_kernel");
+    if (rc) return rc;
+    float* raw = (float*)ws + (int64_t)a.splitK * 16 * n;
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((unsigned)cdiv(n, 64), 16u), dim3(256), 0, st, (const float*)ws, raw,
+                       a.splitK, n);
+    rc = check_launch("wino_wgrad_reduce_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(wino_wgrad_transform_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (const float*)raw, dw,
+                       n, accumulate);
+    return check_launch("wino_wgrad_transform_kernel");
 }
 
 }  // extern "C"

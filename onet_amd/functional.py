@@ -37,7 +37,7 @@ class ConvBNReLUFn(torch.autograd.Function):
         x, z, save = ctx.saved_tensors
         need_x, need_w, need_g, need_b = ctx.needs_input_grad[:4]
         dz, dgamma, dbeta = ops.bn_relu_bwd(da, z, save, ctx.training, need_affine_grads=(need_g or need_b))
-        dw = ops.conv_wgrad(x, dz, ctx.wshape, 3) if need_w else None
+        dw = ops.conv3x3_wgrad_auto(x, dz, ctx.wshape) if need_w else None
         dx = ops.conv3x3_auto(dz, ctx.packed, 1) if need_x else None
         return dx, dw, (dgamma if need_g else None), (dbeta if need_b else None), None, None, None, None, None, None, None
 
@@ -57,7 +57,7 @@ class Conv3x3Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz):
         (x,) = ctx.saved_tensors
-        dw = ops.conv_wgrad(x, dz, ctx.wshape, 3) if ctx.needs_input_grad[1] else None
+        dw = ops.conv3x3_wgrad_auto(x, dz, ctx.wshape) if ctx.needs_input_grad[1] else None
         dx = ops.conv3x3_auto(dz, ctx.packed, 1) if ctx.needs_input_grad[0] else None
         return dx, dw, None
 

@@ -153,6 +153,29 @@ def conv3x3_winograd(x, wq, Cout, out=None):
     return out
 
 
+def conv3x3_winograd_wgrad(x, dz, dw_shape):
+    require_gpu(x, dz)
+    x, xbs = plane(x)
+    dz, dzbs = plane(dz)
+    B, Cin, H, W = x.shape
+    Cout = dz.shape[1]
+    dw = torch.empty(dw_shape, dtype=F32, device=x.device)
+    need = _lib.load().onet_conv3x3_winograd_wgrad_ws_bytes(B, Cin, Cout, H, W)
+    ws = workspace(need, x.device)
+    e0 = _prof_begin()
+    _lib.call("onet_conv3x3_winograd_wgrad", _p(x), xbs, _p(dz), dzbs, _p(dw), _p(ws), ws.numel() * 4, B, Cin, Cout,
+              H, W, 0, _stream())
+    _prof_end("conv_wino_wgrad_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0)
+    return dw
+
+
+def conv3x3_wgrad_auto(x, dz, dw_shape):
+    Cout, Cin = dw_shape[0], dw_shape[1]
+    if use_winograd(Cin, Cout, x.shape[2], x.shape[3]):
+        return conv3x3_winograd_wgrad(x, dz, dw_shape)
+    return conv_wgrad(x, dz, dw_shape, 3)
+
+
 def conv_fwd(x, wp, Cout, ks, out=None):
     """z = conv_ks(x) with packed weights wp ([Cin][ks*ks][Cout]); also used for dgrad."""
     require_gpu(x, wp)

@@ -98,6 +98,19 @@ def test_conv3x3_winograd_fwd_dgrad(dev, B, Cin, Cout, H, W):
         close(ops.conv3x3_winograd(g.to(dev), qd, Cin), xr.grad, what="winograd dgrad")
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 64, 64, 40, 48), (2, 16, 64, 16, 16), (1, 32, 128, 64, 64),
+                                             (2, 128, 256, 16, 16), (2, 24, 36, 9, 7), (3, 16, 64, 33, 31),
+                                             (2, 1024, 512, 4, 4), (4, 64, 64, 128, 128)])
+def test_conv3x3_winograd_wgrad(dev, B, Cin, Cout, H, W):
+    from onet_amd import ops
+    x = torch.relu(rnd(B, Cin, H, W, seed=1))
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=0.1).requires_grad_(True)
+    g = rnd(B, Cout, H, W, seed=3)
+    F.conv2d(x, w, None, 1, 1).backward(g)
+    dw = ops.conv3x3_winograd_wgrad(x.to(dev), g.to(dev), (Cout, Cin, 3, 3))
+    close(dw, w.grad, tol=3e-4, what="winograd wgrad")
+
+
 def test_conv_on_channel_slices(dev):
     """inputs/outputs that are channel-slices of wider (concat) buffers: batch stride != C*H*W"""
     from onet_amd import ops

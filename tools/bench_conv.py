@@ -22,7 +22,7 @@ def timeit(fn, n=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 
-tot = {"fwd": [0, 0], "dgrad": [0, 0], "wgrad": [0, 0], "wino": [0, 0], "winod": [0, 0]}
+tot = {"fwd": [0, 0], "dgrad": [0, 0], "wgrad": [0, 0], "wino": [0, 0], "winod": [0, 0], "winow": [0, 0]}
 which = os.environ.get("WHICH", "fwd,dgrad,wgrad").split(",")
 for name, ci, co, d in L:
     H = S // d
@@ -43,6 +43,9 @@ for name, ci, co, d in L:
         out.append(f"wino {t:7.3f} ms {fl/t/1e9:6.1f} TF")
         t = timeit(lambda: ops.conv3x3_winograd(dz, qd, ci)); tot["winod"][0] += fl; tot["winod"][1] += t
         out.append(f"wino-dgrad {t:7.3f} ms {fl/t/1e9:6.1f} TF")
+    if "winow" in which and ci >= 16:
+        t = timeit(lambda: ops.conv3x3_winograd_wgrad(x, dz, (co, ci, 3, 3))); tot["winow"][0] += fl; tot["winow"][1] += t
+        out.append(f"wino-wgrad {t:7.3f} ms {fl/t/1e9:6.1f} TF")
     if "wgrad" in which:
         t = timeit(lambda: ops.conv_wgrad(x, dz, (co, ci, 3, 3), 3)); tot["wgrad"][0] += fl; tot["wgrad"][1] += t
         out.append(f"wgrad {t:7.3f} ms {fl/t/1e9:6.1f} TF")
