@@ -119,7 +119,7 @@ struct WinoArgs {
     int B, Cin, Cout, H, W, tilesX, tilesY, coTiles;
 };
 
-template <int TW, int CI_T>
+template <int TW, int CI_T, int WM>
 struct WinoCfg {
     static constexpr int TC = TW / 2;                 // Winograd tile columns per block (= per wave)
     static constexpr int TRW = 32 / TC;               // tile rows per wave (32 tiles per wave)
@@ -128,7 +128,8 @@ struct WinoCfg {
     static constexpr int RS = (TW == 32) ? 48 : 24;   // LDS row stride: 2*RS*tr spreads the tile rows over
                                                       // disjoint bank ranges for the ds_read_b64 patches
     static constexpr int CH_STRIDE = IN_ROWS * RS;
-    static constexpr int CO_T = 64;
+    static constexpr int CO_T = 32 * WM;              // WM = 2: 8-wave block, 1 per CU;  WM = 1: 4-wave block, 2 per CU
+    static constexpr int NTHR = 256 * WM;
     static constexpr int W_FLOATS = CI_T * 16 * CO_T;
     static constexpr int IN_LOGICAL = CI_T * IN_ROWS * IN_COLS;
     static constexpr int BUF_FLOATS = W_FLOATS + CI_T * CH_STRIDE;       // one staging buffer (weights + input tile)
@@ -140,15 +141,17 @@ struct WinoCfg {
 // hide each other's LDS / transform latency, and every wave keeps registers for operand prefetch.
 // The output transform is linear in the positions: each half applies A^T . A to its own rows and the
 // two partial 2x2 outputs are added through LDS in the epilogue.
-template <int TW, int CI_T>
-__global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoArgs a) {
-    using C = WinoCfg<TW, CI_T>;
+// DBG != 0: timing-only ablation builds (tools/ablate_wino.py); outputs are garbage.
+//   bit0: no global staging   bit1: no input transform   bit2: no A-operand LDS reads   bit3: no patch LDS reads
+template <int TW, int CI_T, int WM, int DBG = 0>
+__global__ __launch_bounds__(256 * WM, 2) void conv_wino_kernel(WinoArgs a) {
+    using C = WinoCfg<TW, CI_T, WM>;
     constexpr int TC = C::TC, TRW = C::TRW, ROWS = C::ROWS, IN_ROWS = C::IN_ROWS, IN_COLS = C::IN_COLS;
     constexpr int RS = C::RS, CH_STRIDE = C::CH_STRIDE, CO_T = C::CO_T, W_FLOATS = C::W_FLOATS;
-    constexpr int NTHR = 512;
+    constexpr int NTHR = C::NTHR;
     constexpr int NIN = (C::IN_LOGICAL + NTHR - 1) / NTHR;
     constexpr int NW4 = (W_FLOATS / 4 + NTHR - 1) / NTHR;
-    static_assert(C::LDS_BYTES >= 256 * 64 * 4, "epilogue exchange buffer must fit the staging LDS");
+    static_assert(C::LDS_BYTES >= 2 * WM * 64 * 64 * 4, "epilogue exchange buffer must fit the staging LDS");
     static_assert(W_FLOATS % (64 * 4) == 0, "weights are staged in whole 1-KB LDS-DMA pieces");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x { w [CI_T][16][CO_T], in [CI_T][IN_ROWS][RS] }
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoArgs a) {
     const int co0 = coT * CO_T, y0 = ty * ROWS, x0 = tx * TW;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int ph = wid >> 2, wm = (wid >> 1) & 1, wn = wid & 1;
+    const int ph = wid / (2 * WM), wm = (wid >> 1) & (WM - 1), wn = wid & 1;
     const int l31 = lane & 31, kh = lane >> 5;
     const int tc = l31 % TC, tr = l31 / TC;           // this lane's Winograd tile within the wave
     const int HW = a.H * a.W;
@@ -249,9 +252,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoArgs a) {
             float d[3][4];                         // rows PH .. PH+2 of the 4x4 patch, channel 2*cp + kh
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const float2 lo = *reinterpret_cast<const float2*>(p_ptr + cp * 2 * CH_STRIDE + i * RS);
-                const float2 hi = *reinterpret_cast<const float2*>(p_ptr + cp * 2 * CH_STRIDE + i * RS + 2);
-                d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
+                if constexpr (DBG & 8) {
+                    d[i][0] = d[i][1] = d[i][2] = d[i][3] = __builtin_bit_cast(float, (unsigned)(lane + i + cp) | 0x3f000000u);
+                    asm volatile("" : "+v"(d[i][0]), "+v"(d[i][1]), "+v"(d[i][2]), "+v"(d[i][3]));
+                } else {
+                    const float2 lo = *reinterpret_cast<const float2*>(p_ptr + cp * 2 * CH_STRIDE + i * RS);
+                    const float2 hi = *reinterpret_cast<const float2*>(p_ptr + cp * 2 * CH_STRIDE + i * RS + 2);
+                    d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
+                }
             }
             // rows of B^T d:  PH=0: t0 = d0 - d2, t1 = d1 + d2 ;  PH=1 (d[] = d1,d2,d3): t2 = d2 - d1, t3 = d1 - d3
             float t[2][4], u[8];
@@ -272,9 +280,18 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoArgs a) {
                 u[i * 4 + 2] = t[i][2] - t[i][1];
                 u[i * 4 + 3] = t[i][1] - t[i][3];
             }
+            if constexpr (DBG & 2) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) u[p] = d[p % 3][p & 3];
+            }
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
-                const float av = a_ptr[(cp * 2 * 16 + p) * CO_T];
+                float av;
+                if constexpr (DBG & 4) {
+                    av = d[0][p & 3];
+                } else {
+                    av = a_ptr[(cp * 2 * 16 + p) * CO_T];
+                }
                 acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, u[p], acc[p], 0, 0, 0);
             }
         }
@@ -293,11 +310,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoArgs a) {
         float* bufn = smem + (BUF ^ 1) * C::BUF_FLOATS;
         cin_bytes += in_step;
         cw_bytes += w_step;
-        issue(cin_bytes, cw_bytes, bufn);            // past the end: range check -> zeros, no traffic
+        if constexpr (!(DBG & 1)) issue(cin_bytes, cw_bytes, bufn);   // past the end: range check -> zeros, no traffic
         __builtin_amdgcn_sched_barrier(0);
         mfma_steps(phc, bufc, H0{}, H2{});
         __builtin_amdgcn_sched_barrier(0);
-        commit(bufn);                                // 6 dwords per thread; the weight DMA lands on its own
+        if constexpr (!(DBG & 1)) commit(bufn);      // 6 dwords per thread; the weight DMA lands on its own
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire this wave's LDS-DMA pieces
         __syncthreads();
     };
@@ -318,8 +335,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoArgs a) {
 
     // ---- epilogue: partial output transform of this half's rows, halves added through LDS
     //   s0 = m0 + m1 + m2 , s1 = m1 - m2 - m3  (xi index)  ->  ph=0 contributes (m0+m1, m1), ph=1 (m2, -m2-m3)
-    float* ex = smem;                                  // [256 lanes of the ph=0 waves][64] floats, reused LDS
-    const int slot = (wid & 3) * 64 + lane;            // matching lane of the partner wave (same wm, wn)
+    constexpr int EXL = 2 * WM * 64;                   // lanes of the ph=0 waves
+    float* ex = smem;                                  // [64 values][EXL lanes], reused LDS
+    const int slot = (wid % (2 * WM)) * 64 + lane;     // matching lane of the partner wave (same wm, wn)
     float* zb = a.z + (int64_t)b * a.z_bs;
     const int oy = y0 + (wn * TRW + tr) * 2, ox = x0 + tc * 2;
     const bool r0ok = oy < a.H, r1ok = oy + 1 < a.H, c0ok = ox < a.W, c1ok = ox + 1 < a.W;
@@ -343,15 +361,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) ex[(r * 4 + q) * 256 + slot] = y[r][q];
+            for (int q = 0; q < 4; ++q) ex[(r * 4 + q) * EXL + slot] = y[r][q];
     }
     __syncthreads();
     if (ph == 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            const float y00 = y[r][0] + ex[(r * 4 + 0) * 256 + slot], y01 = y[r][1] + ex[(r * 4 + 1) * 256 + slot];
-            const float y10 = y[r][2] + ex[(r * 4 + 2) * 256 + slot], y11 = y[r][3] + ex[(r * 4 + 3) * 256 + slot];
+            const float y00 = y[r][0] + ex[(r * 4 + 0) * EXL + slot], y01 = y[r][1] + ex[(r * 4 + 1) * EXL + slot];
+            const float y10 = y[r][2] + ex[(r * 4 + 2) * EXL + slot], y11 = y[r][3] + ex[(r * 4 + 3) * EXL + slot];
             if (co < a.Cout && c0ok) {
                 float* o = zb + (int64_t)co * HW + (int64_t)oy * a.W + ox;
                 if (vec2) {
@@ -366,22 +384,22 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(WinoArgs a) {
     }
 }
 
-template <int TW, int CI_T>
+template <int TW, int CI_T, int WM, int DBG = 0>
 static int launch_wino(WinoArgs a, hipStream_t st) {
-    using C = WinoCfg<TW, CI_T>;
+    using C = WinoCfg<TW, CI_T, WM>;
     a.tilesX = cdiv(a.W, TW);
     a.tilesY = cdiv(a.H, C::ROWS);
     a.coTiles = cdiv(a.Cout, C::CO_T);
     const int64_t blocks = (int64_t)a.B * a.tilesX * a.tilesY * a.coTiles;
     ONET_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv_wino: grid %lld out of range", (long long)blocks);
-    auto kern = conv_wino_kernel<TW, CI_T>;
+    auto kern = conv_wino_kernel<TW, CI_T, WM, DBG>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   C::LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), C::LDS_BYTES, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::NTHR), C::LDS_BYTES, st, a);
     return check_launch("conv_wino_kernel");
 }
 
@@ -701,7 +719,29 @@ int onet_conv3x3_winograd_fwd(const float* x, int64_t x_bs, const float* wq, flo
     ONET_REQUIRE((Cout & 3) == 0, "conv3x3_winograd_fwd: Cout must be a multiple of 4 (use onet_conv_fwd)");
     ONET_REQUIRE(x_bs >= (int64_t)Cin * H * W && z_bs >= (int64_t)Cout * H * W, "conv3x3_winograd_fwd: batch stride too small");
     WinoArgs a{x, x_bs, wq, z, z_bs, B, Cin, Cout, H, W, 0, 0, 0};
-    return (W > 16) ? launch_wino<32, 8>(a, as_stream(stream)) : launch_wino<16, 8>(a, as_stream(stream));
+    static int wm = -1;
+    if (wm < 0) {
+        const char* e = getenv("ONET_WINO_WM");      // tuning override: 1 = 4-wave blocks x 2/CU, 2 = 8-wave blocks
+        wm = (e && e[0] == '2') ? 2 : 1;
+    }
+    static int dbg = -1;
+    if (dbg < 0) {
+        const char* e = getenv("ONET_WINO_DBG");     // timing-only ablations, W > 16 only
+        dbg = e ? atoi(e) : 0;
+    }
+    if (dbg && W > 16) {
+        switch (dbg) {
+            case 1: return launch_wino<32, 8, 2, 1>(a, as_stream(stream));
+            case 2: return launch_wino<32, 8, 2, 2>(a, as_stream(stream));
+            case 4: return launch_wino<32, 8, 2, 4>(a, as_stream(stream));
+            case 8: return launch_wino<32, 8, 2, 8>(a, as_stream(stream));
+            case 14: return launch_wino<32, 8, 2, 14>(a, as_stream(stream));
+            case 15: return launch_wino<32, 8, 2, 15>(a, as_stream(stream));
+            default: break;
+        }
+    }
+    if (wm == 2) return (W > 16) ? launch_wino<32, 8, 2>(a, as_stream(stream)) : launch_wino<16, 8, 2>(a, as_stream(stream));
+    return (W > 16) ? launch_wino<32, 8, 1>(a, as_stream(stream)) : launch_wino<16, 8, 1>(a, as_stream(stream));
 }
 
 int64_t onet_conv3x3_winograd_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W) {
