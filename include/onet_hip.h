@@ -194,6 +194,16 @@ int onet_log1pexp_bwd(const float* x, const float* g, float* out, int64_t n, voi
 /* ---- K11: argmax over the 2 classes, ties -> 0 (OV:201) ---------------------- */
 int onet_argmax2(const float* S, int64_t* Y, int B, int HW, void* stream);
 
+/* ---- "next" row f-3: the evaluation step either side of the path (UT = utils_20231218.py) ------- */
+/* tensor_normal_per_frame (UT:673-689): y = (x - min) / (max - min + np.spacing(1)) per (b, c) plane */
+int onet_normalise_per_frame(const float* x, float* y, int planes, int HW, void* stream);
+/* per-image 2-class confusion counts [B][4] = (TP, FP, FN, TN), positive class = 1: the inputs of
+ * _acc/_miou/_target_iou/_detection_rate/_false_alarm_rate (UT:100-192) */
+int onet_confusion2(const int64_t* pred, const int64_t* target, int64_t* counts, int B, int HW,
+                    void* stream);
+/* out = 1 - pred (hard label re-assignment, UT:429) */
+int onet_flip_labels(const int64_t* pred, int64_t* out, int64_t n, void* stream);
+
 /* ---- "next" row f-1: fused Adam over a flat buffer (TS:181-182) ---------------- */
 /* torch.optim.Adam semantics (no amsgrad, L2 weight_decay): step is 1-based. */
 int onet_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,

@@ -293,3 +293,40 @@ def test_sync_bn_plumbing_with_duplicated_shard(dev, monkeypatch):
     for n, p in m2.named_parameters():
         a, b = p.grad.double(), g0[n].double()
         assert float((a - b).norm()) <= 1e-4 * float(b.norm()) + 1e-12, n
+
+
+def test_eval_side_kernels_vs_reference_formulas(dev):
+    """tensor_normal_per_frame + confusion-count metrics + re_assign_label against the reference's formulas
+    (utils_20231218.py:100-192, 410-453, 673-689) restated with torch on the CPU."""
+    from onet_amd import metrics as M
+    g = np.random.Generator(np.random.PCG64(3))
+    X = torch.from_numpy(g.standard_normal((3, 2, 37, 41)).astype(np.float32) * 5 + 2)
+    X[1, 0] = 0.75                                             # constant frame: max == min
+    v = X.reshape(3, 2, -1)
+    ref = ((v - v.min(-1, keepdim=True)[0]) / (v.max(-1, keepdim=True)[0] - v.min(-1, keepdim=True)[0] + np.spacing(1))).reshape(X.shape)
+    np.testing.assert_allclose(M.tensor_normal_per_frame(X.to(dev)).cpu().numpy(), ref.numpy(), rtol=1e-6, atol=1e-7)
+
+    pred = torch.from_numpy((g.random((4, 32, 32)) > 0.7).astype(np.int64))
+    gt = torch.from_numpy((g.random((4, 32, 32)) > 0.8).astype(np.float32))
+    pred[3] = 0; gt[3] = 0                                      # empty class case of _miou
+    c = M.confusion_counts(pred.to(dev), gt.to(dev))
+    p, t = pred, gt.to(torch.int64)
+    assert c.cpu().tolist() == [[int(((p[i] == 1) & (t[i] == 1)).sum()), int(((p[i] == 1) & (t[i] == 0)).sum()),
+                                 int(((p[i] == 0) & (t[i] == 1)).sum()), int(((p[i] == 0) & (t[i] == 0)).sum())] for i in range(4)]
+    acc_ref = (p == t).sum().item() / float(p.numel())
+    assert abs(M._acc(c) - acc_ref) < 1e-12
+    miou_ref = 0.0
+    for k in range(2):
+        ge, pe = (t == k), (p == k)
+        miou_ref += float(torch.sum(ge & pe) / torch.sum(ge | pe))
+    assert abs(M._miou(c) - miou_ref / 2) < 1e-6
+    c3 = M.confusion_counts(pred[3:4].to(dev), gt[3:4].to(dev))
+    assert M._miou(c3) == 1.0                                   # class 1 absent from both -> 1 (UT:127-129), class 0 perfect -> 1
+    tp = float(torch.sum((t == 1) * (p == 1))); gtp = float(torch.sum(t == 1)); fp = float(torch.sum((t == 0) * (p == 1))); gtf = float(torch.sum(t == 0))
+    assert abs(M._detection_rate(c) - tp / (gtp + np.spacing(1))) < 1e-12
+    assert abs(M._false_alarm_rate(c) - fp / (gtf + np.spacing(1))) < 1e-12
+    assert abs(M._target_iou(c) - float(torch.sum(t.bool() & p.bool())) / (float(torch.sum(t.bool() | p.bool())) + np.spacing(1))) < 1e-12
+    inv = 1 - t                                                  # a prediction that is the complement of gt must be flipped
+    out = M.re_assign_label(inv.to(dev), t.to(dev))
+    assert torch.equal(out.cpu(), t)
+    assert torch.equal(M.re_assign_label(t.to(dev), t.to(dev)).cpu(), t)

@@ -210,3 +210,27 @@ def test_up_block_oracle_vs_reference_golden():
             y = torch.relu(torch.nn.functional.batch_norm(y, st[f"bn{idx}.running_mean"].clone(), st[f"bn{idx}.running_var"].clone(),
                                                           st[f"bn{idx}.weight"], st[f"bn{idx}.bias"], True, 0.1, 1e-5))
         np.testing.assert_allclose(y.numpy(), g["y"], rtol=1e-4, atol=1e-5)
+
+
+def test_reference_wire_formats(tmp_path):
+    """checkpoint {'net','epoch'|'save_epoch'} and the sim-clutter .pt dict schema."""
+    from onet_amd import Onet, io
+    from onet_amd import data
+    m = Onet(1, binit=True)
+    io.save_checkpoint(m, tmp_path / "a.pytorch", 7)
+    io.save_checkpoint(m, tmp_path / "b.pytorch", 9, zy3=True)
+    ck = torch.load(tmp_path / "a.pytorch")
+    assert sorted(ck.keys()) == ["epoch", "net"] and len(ck["net"]) == 232
+    assert sorted(torch.load(tmp_path / "b.pytorch").keys()) == ["net", "save_epoch"]
+    m2 = Onet(1)
+    assert io.load_checkpoint(m2, tmp_path / "a.pytorch") == 7
+    assert io.load_checkpoint(m2, tmp_path / "b.pytorch") == 9
+    assert torch.equal(m2.topu.up1.up.bias, m.topu.up1.up.bias)
+    X, lab = data.make_clutter_batch(3, 32, 32, seed=5, with_labels=True)
+    io.save_simclutter_pt(tmp_path / "r.pt", X, lab, [0, 1, 2])
+    d = torch.load(tmp_path / "r.pt")
+    assert sorted(d.keys()) == ["psnr", "rayleigh_imgs", "rayleigh_labels"] and d["rayleigh_imgs"].shape == (3, 1, 32, 32)
+    imgs, labels, snrs = io.load_simclutter_pt(tmp_path / "r.pt")
+    assert imgs.dtype == torch.float32 and labels.shape == (3, 32, 32) and snrs.tolist() == [0, 1, 2]
+    tr, te = io.split_train_test(10)
+    assert len(tr) == 9 and len(te) == 1 and sorted(np.concatenate([tr, te]).tolist()) == list(range(10))
