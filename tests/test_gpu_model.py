@@ -330,3 +330,28 @@ def test_eval_side_kernels_vs_reference_formulas(dev):
     out = M.re_assign_label(inv.to(dev), t.to(dev))
     assert torch.equal(out.cpu(), t)
     assert torch.equal(M.re_assign_label(t.to(dev), t.to(dev)).cpu(), t)
+
+
+def test_fit_loop_eval_and_checkpoint(dev, tmp_path):
+    """The harness counterpart (trainer.fit): 2 epochs on synthetic clutter, eval metrics, checkpoint reload."""
+    from onet_amd import data, io, metrics
+    from onet_amd.trainer import fit, sim_lr
+    import Onet_vanilla_20240606 as ov
+    X, lab = data.make_clutter_batch(8, 32, 32, seed=11, with_labels=True)
+    imgs = metrics.tensor_normal_per_frame(torch.from_numpy(X).to(dev))
+    labels = torch.from_numpy(lab).to(dev)
+    torch.manual_seed(3)
+    m = ov.Onet(1, True, True).to(dev)
+    batches = [(imgs[0:4],), (imgs[4:8],)]
+    hist = fit(m, batches, dev, epochs=2, schedule="sim", eval_fn=lambda net, e: metrics.evaluate(net, imgs, labels),
+               eval_every=1, out_root=str(tmp_path), log=lambda *a: None)
+    assert len(hist) == 2 and all(np.isfinite(h["loss"]) for h in hist)
+    assert hist[0]["lr"] == sim_lr(0) and 0.0 <= hist[1]["eval"]["acc"] <= 1.0 and 0.0 <= hist[1]["eval"]["miou"] <= 1.0
+    assert int(m.topu.inc.double_conv[1].num_batches_tracked) == 2 * 2 * 2      # epochs x batches x twin passes
+    ck = tmp_path / "Onet_epoch_1.pytorch"
+    assert ck.exists()
+    m2 = ov.Onet(1, False, True).to(dev)
+    assert io.load_checkpoint(m2, ck, map_location=dev) == 1
+    m.eval(); m2.eval()
+    with torch.no_grad():
+        assert torch.equal(m(imgs[:2])[4], m2(imgs[:2])[4])
