@@ -355,3 +355,48 @@ def test_fit_loop_eval_and_checkpoint(dev, tmp_path):
     m.eval(); m2.eval()
     with torch.no_grad():
         assert torch.equal(m(imgs[:2])[4], m2(imgs[:2])[4])
+
+
+def test_training_step_is_bitwise_deterministic(dev):
+    """No atomics on the default path: split-K slabs and BN partials are reduced in a fixed order, so two runs
+    of the same step give bit-identical loss, outputs and gradients."""
+    B, C, H, W = 4, 1, 64, 64
+    X = orc.det_input(B, C, H, W, seed=3).to(dev)
+    res = []
+    for _ in range(2):
+        m = _model(C, True, dev)
+        (Lt, Vt, Ld, Vd, S), loss = _step(m, X)
+        res.append((loss.detach().clone(), S.detach().clone(), [p.grad.detach().clone() for p in m.parameters()]))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for a, b in zip(res[0][2], res[1][2]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,C,H,W", [(1, 1, 96, 64), (2, 3, 80, 112), (5, 1, 48, 48)])
+def test_rectangular_and_odd_batch_shapes_vs_oracle(dev, B, C, H, W):
+    """H != W, batch 1 and 5, 3-channel input: forward + loss against the CPU oracle."""
+    X = orc.det_input(B, C, H, W, seed=17)
+    with torch.no_grad():
+        top = orc.clone_state(orc.det_state_dict(C, 1981), requires_grad=False)
+        Lt, Vt, Ld, Vd, S = orc.onet_forward(X, top, None, training=True)
+        rloss = orc.compute_loss(Lt, S[:, 0:1], Ld, S[:, 1:2])
+    m = _model(C, True, dev)
+    (lt, vt, ld, vd, s), loss = _step(m, X.to(dev))
+    assert abs(loss.item() - float(rloss)) <= RTOL * abs(float(rloss))
+    _close(vt.detach().cpu().numpy(), Vt.numpy(), "Vt")
+    _close(s.detach().cpu().numpy(), S.numpy(), "S")
+    _close(lt.detach().cpu().numpy(), Lt.numpy(), "Lt")
+    assert all(bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+
+
+def test_non_contiguous_and_strided_inputs(dev):
+    """channels-last / sliced / expanded inputs are accepted (copied to the plane-contiguous layout)."""
+    B, C, H, W = 2, 1, 32, 32
+    X = orc.det_input(B, C, H, W, seed=4).to(dev)
+    m = _model(C, True, dev, train=False)
+    with torch.no_grad():
+        ref = m(X)[4]
+        big = torch.zeros(B, C, H, 2 * W, device=dev)
+        big[..., ::2] = X
+        assert torch.equal(m(big[..., ::2])[4], ref)
+        assert torch.equal(m(X.to(memory_format=torch.channels_last))[4], ref)
