@@ -143,7 +143,7 @@ struct WinoCfg {
 // two partial 2x2 outputs are added through LDS in the epilogue.
 // DBG != 0: timing-only ablation builds (tools/ablate_wino.py); outputs are garbage.
 //   bit0: no global staging   bit1: no input transform   bit2: no A-operand LDS reads   bit3: no patch LDS reads
-template <int TW, int CI_T, int WM, int DBG = 0>
+template <int TW, int CI_T, int WM, int DBG = 0, bool PIPE = true>
 __global__ __launch_bounds__(256 * WM, 2) void conv_wino_kernel(WinoArgs a) {
     using C = WinoCfg<TW, CI_T, WM>;
     constexpr int TC = C::TC, TRW = C::TRW, ROWS = C::ROWS, IN_ROWS = C::IN_ROWS, IN_COLS = C::IN_COLS;
@@ -332,7 +332,169 @@ __global__ __launch_bounds__(256 * WM, 2) void conv_wino_kernel(WinoArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // (tried: a static s_setprio for waves 4-7 to break SIMD-partner lockstep -- 205 vs 210 TFLOP/s, not kept)
-    if (ph == 0) run(I0{}); else run(I1{});
+    if constexpr (!PIPE) {
+        if (ph == 0) run(I0{}); else run(I1{});
+    } else {
+        // Register-level software pipeline across K-steps AND chunks.  During the 8 MFMAs of K-step s the
+        // wave (1) issues the 7 LDS reads of step s+1 up front, (2) transforms them (16 adds) in the issue
+        // shadow of MFMAs 4..7, so every MFMA finds its operands in registers and a single wave can keep
+        // the matrix pipe busy.  The chunk barrier sits in the MIDDLE of the second-to-last K-step: by
+        // then every wave has pulled the last step's operands of chunk c into registers, so the barrier
+        // both publishes chunk c+1 (committed just before it) and frees buffer c&1 for the staging of
+        // chunk c+2, which is issued right after it -- the prefetch of step 0 of chunk c+1 then runs
+        // under the last K-step of chunk c and no pipeline fill is exposed per chunk.
+        constexpr int STEPS = CI_T / 2;
+        float uC[8], avC[8];
+        auto lds_patch = [&](auto bufc, auto cpc, float (&d)[3][4]) __attribute__((always_inline)) {
+            constexpr int BUF = decltype(bufc)::value, CP = decltype(cpc)::value;
+            const float* p_ptr = smem + p_idx + BUF * C::BUF_FLOATS + CP * 2 * CH_STRIDE;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if constexpr (DBG & 8) {
+                    d[i][0] = d[i][1] = d[i][2] = d[i][3] = __builtin_bit_cast(float, (unsigned)(lane + i + CP) | 0x3f000000u);
+                    asm volatile("" : "+v"(d[i][0]), "+v"(d[i][1]), "+v"(d[i][2]), "+v"(d[i][3]));
+                } else {
+                    const float2 lo = *reinterpret_cast<const float2*>(p_ptr + i * RS);
+                    const float2 hi = *reinterpret_cast<const float2*>(p_ptr + i * RS + 2);
+                    d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
+                }
+            }
+        };
+        auto lds_a = [&](auto bufc, auto cpc, float (&av)[8]) __attribute__((always_inline)) {
+            constexpr int BUF = decltype(bufc)::value, CP = decltype(cpc)::value;
+            const float* a_ptr = smem + a_idx + BUF * C::BUF_FLOATS + CP * 2 * 16 * CO_T;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                if constexpr (DBG & 4) av[p] = __builtin_bit_cast(float, (unsigned)(lane + p) | 0x3f000000u);
+                else av[p] = a_ptr[p * CO_T];
+            }
+        };
+        auto rows = [&](auto phc, const float (&d)[3][4], float (&t)[2][4], int i) __attribute__((always_inline)) {
+            constexpr int PH = decltype(phc)::value;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (PH == 0) t[i][j] = i == 0 ? d[0][j] - d[2][j] : d[1][j] + d[2][j];
+                else t[i][j] = i == 0 ? d[1][j] - d[0][j] : d[0][j] - d[2][j];
+            }
+        };
+        auto cols = [&](const float (&t)[2][4], float (&u)[8], int i) __attribute__((always_inline)) {
+            u[i * 4 + 0] = t[i][0] - t[i][2];
+            u[i * 4 + 1] = t[i][1] + t[i][2];
+            u[i * 4 + 2] = t[i][2] - t[i][1];
+            u[i * 4 + 3] = t[i][1] - t[i][3];
+        };
+        auto mfma4 = [&](int p0) __attribute__((always_inline)) {
+#pragma unroll
+            for (int p = p0; p < p0 + 4; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(avC[p], uC[p], acc[p], 0, 0, 0);
+        };
+        // one K-step: MFMAs on (avC, uC); fetch + transform the operands that live at (nbuf, ncp)
+        // staging of chunk c+2 in two slices (half of the input dwords, then half of the weight DMA pieces
+        // each), spread over the two K-steps after the barrier so that the eight waves do not queue their
+        // ten VMEM instructions on the texture-address path in front of the next MFMA
+        auto issue_in = [&](int part) __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = 0; k < NIN; ++k)
+                if (k * 2 / NIN == part) xin[k] = wbload(xr, in_off[k] + cin_bytes);
+        };
+        auto issue_w = [&](int part, float* buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = 0; k < NW4; ++k)
+                if (k * 2 / NW4 == part && (wid_u * 64 + NTHR * k) * 4 < W_FLOATS)
+                    dma16_to_lds(wr4, lds_addr_of(buf) + (unsigned)((wid_u * 64 + NTHR * k) * 16), w_off[k] + cw_bytes);
+        };
+        // one K-step: MFMAs on (avC, uC); fetch + transform the operands that live at (nbuf, ncp).
+        // MODE 0: plain   1: chunk barrier (commit the staged chunk, publish)   2 / 3: staging slice 0 / 1 into buffer TB
+        auto kstep = [&](auto phc, auto nbufc, auto ncpc, auto modec, auto tbc) __attribute__((always_inline)) {
+            constexpr int MODE = decltype(modec)::value, TB = decltype(tbc)::value;
+            float d[3][4], avn[8], t[2][4], un[8];
+            constexpr bool LD = !(DBG & 8), LA = !(DBG & 4);
+            __builtin_amdgcn_sched_barrier(0);
+            // R1: the three patch reads of step s+1, one per MFMA (a burst of 7 reads from all eight waves
+            // would queue on the LDS and hold the MFMAs behind it)
+            lds_patch(nbufc, ncpc, d);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(avC[0], uC[0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(avC[1], uC[1], acc[1], 0, 0, 0);
+            if constexpr (LD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if constexpr (LD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if constexpr (LD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            // R2: the A operands of step s+1
+            lds_a(nbufc, ncpc, avn);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(avC[2], uC[2], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(avC[3], uC[3], acc[3], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if constexpr (LA) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if constexpr (LA) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            if constexpr (MODE >= 2) {
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!(DBG & 1)) issue_w(MODE - 2, smem + TB * C::BUF_FLOATS);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (MODE == 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!(DBG & 1)) commit(smem + TB * C::BUF_FLOATS);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                // the input dwords of chunk c+2 (HBM latency, six loads) go out at once; its weight DMA
+                // (L2 hits, 4 KB per wave) follows in two slices over the next two K-steps
+                cin_bytes += in_step;
+                cw_bytes += w_step;
+                if constexpr (!(DBG & 1)) { issue_in(0); issue_in(1); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // R3: the transform adds of step s+1, four at a time in the shadow of MFMAs 4..7
+            mfma4(4);
+            rows(phc, d, t, 0); rows(phc, d, t, 1);
+            cols(t, un, 0); cols(t, un, 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            }
+            if constexpr (DBG & 2) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) un[p] = d[p % 3][p & 3];
+            }
+#pragma unroll
+            for (int p = 0; p < 8; ++p) { uC[p] = un[p]; avC[p] = avn[p]; }
+        };
+        auto pchunk = [&](auto phc, auto bufc) __attribute__((always_inline)) {
+            constexpr int BUF = decltype(bufc)::value;
+            using BC = std::integral_constant<int, BUF>;
+            using BN = std::integral_constant<int, BUF ^ 1>;
+            using K = std::integral_constant<int, 0>;
+            static_assert(STEPS == 4, "pipelined chunk is written for 4 K-steps");
+            // buffer BUF holds chunk c, BUF^1 receives chunk c+1 (slice 0 went out in the previous chunk's last step)
+            kstep(phc, BC{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 3>{}, BN{});   // slice 1 of c+1
+            kstep(phc, BC{}, std::integral_constant<int, 2>{}, K{}, BC{});
+            kstep(phc, BC{}, std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, BN{});   // commit c+1, barrier
+            kstep(phc, BN{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, BC{});   // slice 0 of c+2
+        };
+        auto prun = [&](auto phc) __attribute__((always_inline)) {
+            {   // prologue: slice 0 of chunk 1 in flight, operands of (chunk 0, step 0) in registers
+                cin_bytes += in_step;
+                cw_bytes += w_step;
+                if constexpr (!(DBG & 1)) { issue_in(0); issue_in(1); issue_w(0, smem + C::BUF_FLOATS); }
+                float d[3][4], t[2][4];
+                lds_patch(I0{}, I0{}, d);
+                lds_a(I0{}, I0{}, avC);
+                rows(phc, d, t, 0); rows(phc, d, t, 1);
+                cols(t, uC, 0); cols(t, uC, 1);
+            }
+            const int nch = (a.Cin + CI_T - 1) / CI_T;
+            int c = 0;
+            for (; c + 2 <= nch; c += 2) {
+                pchunk(phc, I0{});
+                pchunk(phc, I1{});
+            }
+            if (c < nch) pchunk(phc, I0{});
+        };
+        if (ph == 0) prun(I0{}); else prun(I1{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (all-zero) staging of a non-existent
+        __syncthreads();                                   // chunk must land before the epilogue reuses the LDS
+    }
 
     // ---- epilogue: partial output transform of this half's rows, halves added through LDS
     //   s0 = m0 + m1 + m2 , s1 = m1 - m2 - m3  (xi index)  ->  ph=0 contributes (m0+m1, m1), ph=1 (m2, -m2-m3)
@@ -385,7 +547,7 @@ __global__ __launch_bounds__(256 * WM, 2) void conv_wino_kernel(WinoArgs a) {
     }
 }
 
-template <int TW, int CI_T, int WM, int DBG = 0>
+template <int TW, int CI_T, int WM, int DBG = 0, bool PIPE = true>
 static int launch_wino(WinoArgs a, hipStream_t st) {
     using C = WinoCfg<TW, CI_T, WM>;
     a.tilesX = cdiv(a.W, TW);
@@ -393,7 +555,7 @@ static int launch_wino(WinoArgs a, hipStream_t st) {
     a.coTiles = cdiv(a.Cout, C::CO_T);
     const int64_t blocks = (int64_t)a.B * a.tilesX * a.tilesY * a.coTiles;
     ONET_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv_wino: grid %lld out of range", (long long)blocks);
-    auto kern = conv_wino_kernel<TW, CI_T, WM, DBG>;
+    auto kern = conv_wino_kernel<TW, CI_T, WM, DBG, PIPE>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -741,6 +903,13 @@ int onet_conv3x3_winograd_fwd(const float* x, int64_t x_bs, const float* wq, flo
             default: break;
         }
     }
+    static int pipe = -1;
+    if (pipe < 0) {
+        const char* e = getenv("ONET_WINO_PIPE");    // 0 = the pre-pipelining main loop (A/B timing)
+        pipe = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (wm == 2 && !pipe)
+        return (W > 16) ? launch_wino<32, 8, 2, 0, false>(a, as_stream(stream)) : launch_wino<16, 8, 2, 0, false>(a, as_stream(stream));
     if (wm == 2) return (W > 16) ? launch_wino<32, 8, 2>(a, as_stream(stream)) : launch_wino<16, 8, 2>(a, as_stream(stream));
     return (W > 16) ? launch_wino<32, 8, 1>(a, as_stream(stream)) : launch_wino<16, 8, 1>(a, as_stream(stream));
 }
