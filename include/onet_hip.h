@@ -71,6 +71,13 @@ int onet_conv3x3_pack_weights_winograd(const float* w, float* wq_fwd, float* wq_
                                        int Cout, int Cin, void* stream);
 int onet_conv3x3_winograd_fwd(const float* x, int64_t x_bs, const float* wq, float* z, int64_t z_bs,
                               int B, int Cin, int Cout, int H, int W, void* stream);
+/* Larger-tile variant for fwd / dgrad: Winograd F(4x4,3x3) (4x fewer multiplies; 6x6 input tiles, interpolation
+ * points 0, +-1, +-2; fp32 error ~3e-6 rms per layer).  wq_fwd [Cin][36][Cout], wq_dgrad [Cout][36][Cin].
+ * Requires Cin % 4 == 0 and Cout % 4 == 0.  Same call sites as onet_conv3x3_winograd_fwd. */
+int onet_conv3x3_pack_weights_winograd4(const float* w, float* wq_fwd, float* wq_dgrad,
+                                        int Cout, int Cin, void* stream);
+int onet_conv3x3_winograd4_fwd(const float* x, int64_t x_bs, const float* wq, float* z, int64_t z_bs,
+                               int B, int Cin, int Cout, int H, int W, void* stream);
 /* Winograd weight gradient: dW = G^T [ sum_tiles (A dY A^T) (.) (B^T d B) ] G, split-K over pixel strips,
  * deterministic slab reduction; dw is [Cout][Cin][3][3]. */
 int onet_conv3x3_winograd_wgrad(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs, float* dw,

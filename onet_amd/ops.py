@@ -153,6 +153,31 @@ def conv3x3_winograd(x, wq, Cout, out=None):
     return out
 
 
+def pack3x3_winograd4(w):
+    """F(4x4,3x3) transformed weights: (fwd [Cin][36][Cout], dgrad [Cout][36][Cin])."""
+    require_gpu(w)
+    w = w.detach().contiguous()
+    Cout, Cin = w.shape[0], w.shape[1]
+    wf = torch.empty(Cin * 36 * Cout, dtype=F32, device=w.device)
+    wd = torch.empty(Cout * 36 * Cin, dtype=F32, device=w.device)
+    _lib.call("onet_conv3x3_pack_weights_winograd4", _p(w), _p(wf), _p(wd), Cout, Cin, _stream())
+    return wf, wd
+
+
+def conv3x3_winograd4(x, wq, Cout, out=None):
+    """z = conv3x3(x) by Winograd F(4x4,3x3) with transformed weights wq ([Cin][36][Cout]); fwd and dgrad."""
+    require_gpu(x, wq)
+    x, xbs = plane(x)
+    B, Cin, H, W = x.shape
+    if out is None:
+        out = torch.empty((B, Cout, H, W), dtype=F32, device=x.device)
+    zbs = out.stride(0) if B > 1 else Cout * H * W
+    e0 = _prof_begin()
+    _lib.call("onet_conv3x3_winograd4_fwd", _p(x), xbs, _p(wq), _p(out), zbs, B, Cin, Cout, H, W, _stream())
+    _prof_end("conv_wino4_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0)
+    return out
+
+
 def conv3x3_winograd_wgrad(x, dz, dw_shape):
     require_gpu(x, dz)
     x, xbs = plane(x)

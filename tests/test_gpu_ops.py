@@ -99,6 +99,24 @@ def test_conv3x3_winograd_fwd_dgrad(dev, B, Cin, Cout, H, W):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 64, 64, 40, 48), (2, 16, 64, 16, 16), (1, 32, 128, 64, 64),
+                                             (3, 128, 256, 16, 16), (2, 24, 36, 9, 7), (3, 8, 64, 33, 31),
+                                             (2, 1024, 512, 4, 4), (2, 4, 12, 17, 23), (1, 64, 128, 32, 96)])
+def test_conv3x3_winograd4_fwd_dgrad(dev, B, Cin, Cout, H, W):
+    """Winograd F(4x4,3x3) MFMA path against the direct CPU convolution (fwd and dgrad orientation);
+    ragged edges, odd batch with the two-images-per-block layout (W <= 16), channel tails."""
+    from onet_amd import ops
+    x = rnd(B, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=(2.0 / (Cin * 9)) ** 0.5)
+    g = rnd(B, Cout, H, W, seed=3)
+    xr = x.clone().requires_grad_(True)
+    zr = F.conv2d(xr, w, None, 1, 1)
+    zr.backward(g)
+    qf, qd = ops.pack3x3_winograd4(w.to(dev))
+    close(ops.conv3x3_winograd4(x.to(dev), qf, Cout), zr, tol=2e-4, what="winograd4 fwd")
+    close(ops.conv3x3_winograd4(g.to(dev), qd, Cin), xr.grad, tol=2e-4, what="winograd4 dgrad")
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 64, 64, 40, 48), (2, 16, 64, 16, 16), (1, 32, 128, 64, 64),
                                              (2, 128, 256, 16, 16), (2, 24, 36, 9, 7), (3, 16, 64, 33, 31),
                                              (2, 1024, 512, 4, 4), (4, 64, 64, 128, 128)])
 def test_conv3x3_winograd_wgrad(dev, B, Cin, Cout, H, W):

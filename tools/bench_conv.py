@@ -22,7 +22,7 @@ def timeit(fn, n=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 
-tot = {"fwd": [0, 0], "dgrad": [0, 0], "wgrad": [0, 0], "wino": [0, 0], "winod": [0, 0], "winow": [0, 0]}
+tot = {"fwd": [0, 0], "dgrad": [0, 0], "wgrad": [0, 0], "wino": [0, 0], "winod": [0, 0], "winow": [0, 0], "wino4": [0, 0], "wino4d": [0, 0]}
 which = os.environ.get("WHICH", "fwd,dgrad,wgrad").split(",")
 for name, ci, co, d in L:
     H = S // d
@@ -43,6 +43,12 @@ for name, ci, co, d in L:
         out.append(f"wino {t:7.3f} ms {fl/t/1e9:6.1f} TF")
         t = timeit(lambda: ops.conv3x3_winograd(dz, qd, ci)); tot["winod"][0] += fl; tot["winod"][1] += t
         out.append(f"wino-dgrad {t:7.3f} ms {fl/t/1e9:6.1f} TF")
+    if "wino4" in which and ci >= 8:
+        q4f, q4d = ops.pack3x3_winograd4(w)
+        t = timeit(lambda: ops.conv3x3_winograd4(x, q4f, co)); tot["wino4"][0] += fl; tot["wino4"][1] += t
+        out.append(f"wino4 {t:7.3f} ms {fl/t/1e9:6.1f} TF")
+        t = timeit(lambda: ops.conv3x3_winograd4(dz, q4d, ci)); tot["wino4d"][0] += fl; tot["wino4d"][1] += t
+        out.append(f"wino4-dgrad {t:7.3f} ms {fl/t/1e9:6.1f} TF")
     if "winow" in which and ci >= 16:
         t = timeit(lambda: ops.conv3x3_winograd_wgrad(x, dz, (co, ci, 3, 3))); tot["winow"][0] += fl; tot["winow"][1] += t
         out.append(f"wino-wgrad {t:7.3f} ms {fl/t/1e9:6.1f} TF")
