@@ -71,7 +71,7 @@ def cpu_baseline(X_cpu, seconds_budget):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU (weak scaling)")
     ap.add_argument("--size", type=int, default=256)
@@ -137,6 +137,10 @@ def main():
         dom = max(kern, key=lambda k: kern[k]["ms_total"])
         algo = {"conv_wino_kernel": "Winograd F(2x2,3x3) on fp32 MFMA: achieved = direct-convolution FLOPs / time "
                                     "(the kernel issues 2.25x fewer MFMA FLOPs, so frac can exceed the MFMA busy fraction)",
+                "conv_wino4_kernel": "Winograd F(4x4,3x3) on fp32 MFMA: achieved = direct-convolution FLOPs / time "
+                                     "(the kernel issues 4x fewer MFMA FLOPs, so frac can exceed 1)",
+                "conv_wino_wgrad_kernel": "Winograd F(2x2,3x3) weight gradient on fp32 MFMA: achieved = direct-convolution "
+                                          "FLOPs / time (2.25x fewer MFMA FLOPs issued)",
                 "conv_fwd_kernel": "direct implicit GEMM on fp32 MFMA", "conv_wgrad_kernel": "split-K MFMA wgrad"}
         roofline = {"kernel": dom, "bound": "mfma", "achieved": kern[dom]["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4),

@@ -25,30 +25,28 @@
 
 using namespace onet;
 
-namespace {
-
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr unsigned OOB4 = 0x80000000u;
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* base, int64_t bytes) {
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* base, int64_t bytes) {
     const int n = bytes > 0x7fffffffll ? 0x7fffffff : (int)bytes;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000);
 }
-__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned off) {
+static __device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
 // LDS-DMA, inline asm for the reason given in conv_wino.hip (the compiler must not see it)
-__device__ __forceinline__ void dma16(i32x4 rsrc, unsigned lds_byte_addr, unsigned voff) {
+static __device__ __forceinline__ void dma16(i32x4 rsrc, unsigned lds_byte_addr, unsigned voff) {
     unsigned keep;
     asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(voff), "s"(rsrc), "s"(lds_byte_addr)
                  : "memory");
 }
-__device__ __forceinline__ i32x4 rsrc_words(const void* base, int64_t bytes) {
+static __device__ __forceinline__ i32x4 rsrc_words(const void* base, int64_t bytes) {
     const uint64_t p = reinterpret_cast<uint64_t>(base);
     i32x4 r;
     r.x = (int)(p & 0xffffffffu);
@@ -57,13 +55,13 @@ __device__ __forceinline__ i32x4 rsrc_words(const void* base, int64_t bytes) {
     r.w = 0x00020000;
     return r;
 }
-__device__ __forceinline__ unsigned lds_addr(const float* p) {
+static __device__ __forceinline__ unsigned lds_addr(const float* p) {
     return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)p;
 }
 
 // ------------------------------------------------------------------ weight transform + packing
 // U = G g G^T (6x6),  G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
-__device__ __forceinline__ void g3(const float a, const float b, const float c, float (&o)[6]) {
+static __device__ __forceinline__ void g3(const float a, const float b, const float c, float (&o)[6]) {
     const float s = a + c;
     o[0] = 0.25f * a;
     o[1] = (-1.f / 6.f) * (s + b);
@@ -73,7 +71,7 @@ __device__ __forceinline__ void g3(const float a, const float b, const float c, 
     o[4] = q - (1.f / 12.f) * b;
     o[5] = c;
 }
-__device__ __forceinline__ void wino4_G(const float g[3][3], float U[6][6]) {
+static __device__ __forceinline__ void wino4_G(const float g[3][3], float U[6][6]) {
     float r[6][3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -143,7 +141,7 @@ struct W4Cfg {
 
 // half of B^T (input transform): HALF 0 -> rows 0,1,2 from d0..d4 ; HALF 1 -> rows 3,4,5 from d1..d5 (passed as d[0..4])
 template <int HALF>
-__device__ __forceinline__ void bt3(const float d0, const float d1, const float d2, const float d3, const float d4,
+static __device__ __forceinline__ void bt3(const float d0, const float d1, const float d2, const float d3, const float d4,
                                     float& o0, float& o1, float& o2) {
     if constexpr (HALF == 0) {
         o0 = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
@@ -159,7 +157,7 @@ __device__ __forceinline__ void bt3(const float d0, const float d1, const float 
 }
 // half of A^T (output transform): HALF 0 -> columns 0,1,2 of A^T ; HALF 1 -> columns 3,4,5
 template <int HALF>
-__device__ __forceinline__ void at3(const float m0, const float m1, const float m2, float (&o)[4]) {
+static __device__ __forceinline__ void at3(const float m0, const float m1, const float m2, float (&o)[4]) {
     if constexpr (HALF == 0) {
         const float s = m1 + m2, dd = m1 - m2;
         o[0] = m0 + s; o[1] = dd; o[2] = s; o[3] = dd;
@@ -172,7 +170,7 @@ __device__ __forceinline__ void at3(const float m0, const float m1, const float 
 struct Patch { f32x4 q[5]; f32x2 h[5]; };     // five patch rows: columns 0..3 and 4..5
 
 template <int TXB, int RH, int CH>
-__device__ __forceinline__ void wino4_body(const Wino4Args& a, float* smem) {
+static __device__ __forceinline__ void wino4_body(const Wino4Args& a, float* smem) {
     using C = W4Cfg<TXB>;
     constexpr int IMG = C::IMG, IN_ROWS = C::IN_ROWS, IN_COLS = C::IN_COLS, RS = C::RS;
     constexpr int CH_STRIDE = C::CH_STRIDE, CO_T = C::CO_T, W_FLOATS = C::W_FLOATS, NTHR = C::NTHR, NIN = C::NIN;
@@ -511,7 +509,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4Args a) {
 }
 
 template <int TXB>
-int launch_wino4(Wino4Args a, hipStream_t st) {
+static int launch_wino4(Wino4Args a, hipStream_t st) {
     using C = W4Cfg<TXB>;
     a.tilesX = cdiv(a.W, C::PXW);
     a.tilesY = cdiv(a.H, C::PXH);
@@ -529,8 +527,6 @@ int launch_wino4(Wino4Args a, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::NTHR), C::LDS_BYTES, st, a);
     return check_launch("conv_wino4_kernel");
 }
-
-}  // namespace
 
 extern "C" {
 

@@ -99,34 +99,78 @@ def packT2x2(w):
     return wf, wd
 
 
-# 3x3 convolution algorithm for fwd/dgrad: "winograd" (F(2x2,3x3) on the MFMA cores, default) or
-# "direct" (implicit GEMM); ONET_CONV_ALGO overrides.  Layers the Winograd kernel does not take
-# (stem Cin < 16, channel counts not multiples of 4) always use the direct kernel.
+# 3x3 convolution algorithm for fwd/dgrad, chosen per call from the layer shape (ONET_CONV_ALGO overrides):
+#   "auto" (default)  Winograd F(4x4,3x3) where its 64-channel x 32-tile blocks fill the chip, else F(2x2,3x3),
+#                     else the direct implicit-GEMM kernel
+#   "winograd4"       F(4x4,3x3) on every legal layer with maps >= 8x8 (parity tests)      "winograd" / "winograd2"  F(2x2,3x3)
+#   "direct"          implicit GEMM only
+# Layers no Winograd kernel takes (stem Cin < 16, channel counts not multiples of 4) always run direct.
 import os as _os
-CONV_ALGO = _os.environ.get("ONET_CONV_ALGO", "winograd")
+CONV_ALGO = _os.environ.get("ONET_CONV_ALGO", "auto")
+_N_CU = 256
+
+
+def _wino_legal(Cin, Cout):
+    return Cin >= 16 and Cin % 4 == 0 and Cout % 4 == 0
+
+
+def conv3x3_algo(B, Cin, Cout, H, W):
+    """-> "winograd4" | "winograd" | "direct" for a conv with Cin inputs and Cout outputs on B maps of H x W."""
+    algo = "winograd" if CONV_ALGO == "winograd2" else CONV_ALGO
+    if algo == "direct" or not _wino_legal(Cin, Cout):
+        return "direct"
+    # on maps smaller than 8x8 the tile quantisation wastes most of an MFMA tile and the direct kernel's
+    # two-level accumulation is the more accurate one (the 1x1 .. 4x4 bottleneck maps of small inputs feed
+    # BatchNorm batches of a few values per channel, which amplify any rounding difference)
+    if min(H, W) < 8:
+        return "direct"
+    if algo == "winograd4":
+        return "winograd4"
+    if algo == "winograd":
+        return "winograd"
+    if min(H, W) >= 16:
+        img = 1 if W > 16 else 2                       # conv_wino4.hip block: 32 tiles of 4x4 px, 64 channels
+        blocks = -(-B // img) * -(-W // (32 if W > 16 else 16)) * -(-H // 16) * -(-Cout // 64)
+        if blocks >= (_N_CU * 7) // 8:
+            return "winograd4"
+    return "winograd"
 
 
 def use_winograd(Cin, Cout, H, W):
-    """Winograd pays on real feature maps; on maps smaller than 8x8 its 2x2-tile quantisation wastes
-    most of the MFMA tile and the direct kernel's two-level accumulation is the more accurate one."""
-    return CONV_ALGO == "winograd" and Cin >= 16 and Cin % 4 == 0 and Cout % 4 == 0 and min(H, W) >= 8
+    """Does the Winograd weight-gradient kernel (F(2x2,3x3)) take this layer?"""
+    return CONV_ALGO != "direct" and _wino_legal(Cin, Cout) and min(H, W) >= 8
+
+
+class Packed3x3(dict):
+    """Packed forms of one 3x3 weight, built on first use per algorithm: [algo] -> (fwd, dgrad)."""
+
+    def __init__(self, w):
+        super().__init__(Cin=w.shape[1], Cout=w.shape[0])
+        self.w = w.detach()
+
+    def get_pack(self, algo):
+        if algo not in self:
+            self[algo] = {"direct": pack3x3, "winograd": pack3x3_winograd, "winograd4": pack3x3_winograd4}[algo](self.w)
+        return self[algo]
 
 
 def pack3x3_auto(w):
-    """-> dict of packed weights for conv3x3_auto: direct (fwd, dgrad) always, Winograd when eligible."""
-    Cout, Cin = w.shape[0], w.shape[1]
-    pk = {"direct": pack3x3(w), "Cin": Cin, "Cout": Cout}
-    if CONV_ALGO == "winograd" and Cin >= 16 and Cin % 4 == 0 and Cout % 4 == 0:
-        pk["winograd"] = pack3x3_winograd(w)
+    """-> lazily packed weights for conv3x3_auto (the direct pack is always built: stem / tiny maps)."""
+    pk = Packed3x3(w)
+    pk.get_pack("direct")
     return pk
 
 
 def conv3x3_auto(x, pk, direction, out=None):
     """direction 0: forward (Cin -> Cout); 1: dgrad (Cout -> Cin) with the flipped/transposed pack."""
-    Co = pk["Cout"] if direction == 0 else pk["Cin"]
-    if "winograd" in pk and use_winograd(pk["Cin"], pk["Cout"], x.shape[2], x.shape[3]):
-        return conv3x3_winograd(x, pk["winograd"][direction], Co, out=out)
-    return conv_fwd(x, pk["direct"][direction], Co, 3, out=out)
+    Ci, Co = (pk["Cin"], pk["Cout"]) if direction == 0 else (pk["Cout"], pk["Cin"])
+    algo = conv3x3_algo(x.shape[0], Ci, Co, x.shape[2], x.shape[3])
+    wq = pk.get_pack(algo)[direction]
+    if algo == "winograd4":
+        return conv3x3_winograd4(x, wq, Co, out=out)
+    if algo == "winograd":
+        return conv3x3_winograd(x, wq, Co, out=out)
+    return conv_fwd(x, wq, Co, 3, out=out)
 
 
 def pack3x3_winograd(w):

@@ -74,8 +74,20 @@ def _step(m, X):
 CASES = ["b2_c1_16", "b2_c1_32", "b2_c3_32", "b2_c1_40", "b3_c1_32", "b2_c1_32_noshare", "b2_c1_256"]
 
 
+@pytest.mark.parametrize("algo", ["auto", "winograd4"])
 @pytest.mark.parametrize("tag", CASES)
-def test_train_step_vs_reference_golden(dev, tag):
+def test_train_step_vs_reference_golden(dev, tag, algo, monkeypatch):
+    """algo "auto": the shape heuristic of ops.conv3x3_algo (small batches mostly land on F(2x2,3x3) and direct);
+    "winograd4": F(4x4,3x3) forced on every legal layer, the kernel the B=32 benchmark spends most time in."""
+    from onet_amd import ops
+    if algo == "winograd4" and tag not in ("b2_c1_40", "b2_c1_32_noshare", "b2_c1_256"):
+        # F(4x4,3x3) rounds ~6x coarser than F(2x2,3x3) (2.7e-6 vs 4e-7 of the output scale per layer).  The
+        # 16- and 32-pixel goldens are conditioned at 1e-2 already (BatchNorm over 2..8 values per channel);
+        # there the extra noise flips more ReLU kinks than the two the bound allows (measured 0.030 vs 0.022).
+        # ops.conv3x3_algo never selects F(4x4) for such grids (it needs >= 224 blocks of 32 tiles), so only
+        # the well-conditioned cases are forced through it.
+        pytest.skip("F(4x4,3x3) is not dispatched on tiny, ill-conditioned grids")
+    monkeypatch.setattr(ops, "CONV_ALGO", algo)
     g = np.load(os.path.join(G, f"onet_{tag}.npz"))
     B, C, H, W, bshare, train, steps = [int(v) for v in g["meta"]]
     m = _model(C, bool(bshare), dev)
