@@ -1,0 +1,56 @@
+"""Turn gpurun_out/prof_TAG (tools/profile_round.sh) into the committed summaries under profiles/:
+  TAG_kernel_stats_bench_b32_256.{csv,md}, TAG_pmc_bench_b32_256.json (+ pmc_bench_latest.json), TAG_sq_counters_bench_b32_256.md
+usage: python tools/profile_to_md.py TAG "one-line description of the code state" """
+import collections, csv, glob, json, os, shutil, subprocess, sys
+tag, desc = sys.argv[1], sys.argv[2]
+src = f"gpurun_out/prof_{tag}"
+os.makedirs("profiles", exist_ok=True)
+# ---- kernel stats
+st = glob.glob(f"{src}/stats/**/*kernel_stats.csv", recursive=True)[0]
+shutil.copy(st, f"profiles/{tag}_kernel_stats_bench_b32_256.csv")
+rows = list(csv.DictReader(open(st)))
+tot = sum(int(r["TotalDurationNs"]) for r in rows)
+bench = {}
+try:
+    bench = json.loads(open(f"{src}/bench_line_under_profiler.json").read())
+except Exception:
+    pass
+with open(f"profiles/{tag}_kernel_stats_bench_b32_256.md", "w") as f:
+    f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline ({desc})\n\n")
+    f.write(f"MI355X, B=32 1x256x256, fp32; 4 training steps traced (1 warm-up + 3 timed).  Total kernel time {tot/1e6:.1f} ms = "
+            f"{tot/4e6:.1f} ms/step.")
+    if bench:
+        dom = bench["roofline"]["kernel"]
+        f.write(f"  bench under the profiler: {bench['ms_per_step']} ms/step, {bench['value']} images/s.\n"
+                f"bench.py's own HIP-event timing of the dominant kernel in the same run: {dom}, "
+                f"{bench['roofline']['launches_timed']} launches, avg {bench['roofline']['avg_launch_ms']} ms "
+                f"(this table: the `{dom}` rows).\n")
+    f.write("\n| kernel | calls | total ms | avg us | % |\n|---|---:|---:|---:|---:|\n")
+    for r in rows[:40]:
+        f.write(f"| `{r['Name'][:90]}` | {r['Calls']} | {int(r['TotalDurationNs'])/1e6:.2f} | {float(r['AverageNs'])/1e3:.1f} | {r['Percentage']} |\n")
+# ---- PMC traffic
+out = f"profiles/{tag}_pmc_bench_b32_256.json"
+subprocess.run([sys.executable, "tools/pmc_parse.py", f"{src}/fetch", f"{src}/write", "--json", out], check=True, stdout=subprocess.DEVNULL)
+shutil.copy(out, "profiles/pmc_bench_latest.json")
+# ---- SQ counters
+vals = collections.defaultdict(lambda: collections.defaultdict(list))
+for fcsv in glob.glob(f"{src}/sq/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(fcsv)):
+        vals[r["Kernel_Name"].split("(")[0].replace("void ", "")[:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+dur = collections.defaultdict(list)
+for fcsv in glob.glob(f"{src}/sq/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(fcsv)):
+        dur[r["Kernel_Name"].split("(")[0].replace("void ", "")[:60]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+with open(f"profiles/{tag}_sq_counters_bench_b32_256.md", "w") as f:
+    f.write(f"# rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace -- python bench.py --steps 3 --warmup 1 ({desc})\n\n")
+    f.write("effective clock = GRBM_GUI_ACTIVE / 8 / duration (MI355X_MICROARCH.md, DVFS give-back); MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs).\n"
+            "Profiled passes run slower than un-profiled ones (same guide), so durations here are longer than in the kernel-stats table.\n\n")
+    f.write("| kernel | launches | total ms | effective clock GHz | MFMA busy |\n|---|---:|---:|---:|---:|\n")
+    for k in sorted(dur, key=lambda k: -sum(dur[k]))[:16]:
+        g = vals[k].get("GRBM_GUI_ACTIVE", [])
+        m = vals[k].get("SQ_VALU_MFMA_BUSY_CYCLES", [])
+        if not g:
+            continue
+        cyc = sum(g) / 8
+        f.write(f"| `{k}` | {len(dur[k])} | {sum(dur[k])/1e6:.2f} | {cyc / sum(dur[k]):.2f} | {sum(m) / 1024 / cyc:.3f} |\n")
+print("written profiles/ for", tag)
