@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam instead of the fused flat Adam")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="one gradient all-reduce after backward instead of bucketed all-reduces overlapped with it")
+    ap.add_argument("--bucket-mb", type=float, default=32.0)
     args = ap.parse_args()
 
     from onet_amd import Onet, _lib, ops
@@ -98,13 +101,15 @@ def main():
            else FlatAdam(onet, lr=5e-6, world_size=world))
     if not args.torch_adam:
         opt.broadcast_params(0)
+    distributed = dist.is_available() and dist.is_initialized()
+    overlap = distributed and not args.torch_adam and not args.no_overlap
+    if overlap:
+        opt.enable_overlap(args.bucket_mb)
     onet.train()
 
     X_cpu = torch.from_numpy(odata.make_clutter_batch(args.batch, args.size, args.size, seed=1981 + rank,
                                                       channels=args.chans))
     X = X_cpu.to(dev)                # inputs resident in HBM before the timed region
-
-    distributed = dist.is_available() and dist.is_initialized()
 
     def barrier():
         if distributed:
@@ -155,7 +160,10 @@ def main():
                "config": {"workload": "configs[1]: batch=%d/GPU %dx%dx%d synthetic K-clutter, fp32, twin U-Net "
                                       "fwd+JSD loss+bwd+Adam" % (args.batch, args.chans, args.size, args.size),
                           "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                          "optimizer": "torch.optim.Adam" if args.torch_adam else "fused flat Adam (HIP)"},
+                          "optimizer": "torch.optim.Adam" if args.torch_adam else "fused flat Adam (HIP)",
+                          "grad_allreduce": ("none (1 process)" if not distributed else
+                                             "%g MB buckets overlapped with backward" % args.bucket_mb if overlap
+                                             else "single all-reduce after backward")},
                "loss": loss_val, "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(X_cpu, args.cpu_seconds)

@@ -76,6 +76,55 @@ class FlatAdam:
         self.step_count = 0
         self.pg = process_group
         self.world_size = world_size
+        self._buckets = None          # set by enable_overlap()
+
+    # ------------------------------------------------------------------ bucketed all-reduce overlapped with backward
+    def enable_overlap(self, bucket_mb: float = 32.0):
+        """instead of ONE all-reduce after backward, reduce contiguous slices of the flat gradient
+        buffer as soon as backward has produced them.  Buckets are cut from the END of the parameter list
+        (autograd reaches the last layers first), each at least `bucket_mb` MB; a bucket's all-reduce is issued
+        asynchronously from the post-accumulate-grad hook of its last missing parameter -- with shared weights
+        (`dwnu is topu`) autograd sums both passes' contributions before that hook fires once -- and runs on the
+        collective library's own stream while backward continues.  `step()` waits for all of them.  The reduced
+        values are identical to the single all-reduce (same elementwise sums), so is the update."""
+        if self._buckets is not None:
+            return
+        cap = max(1, int(bucket_mb * 2 ** 20 / 4))
+        self._buckets, end, members = [], self.numel, []
+        for i in reversed(range(len(self.params))):
+            members.append(i)
+            start = self.offsets[i]
+            if end - start >= cap or i == 0:
+                self._buckets.append({"start": start, "end": end, "params": members, "pending": len(members),
+                                      "work": None, "launched": False})
+                end, members = start, []
+        self._bucket_of = {i: b for b, bk in enumerate(self._buckets) for i in bk["params"]}
+        self._hooks = [p.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_grad(i))
+                       for i, p in enumerate(self.params)]
+
+    def _launch_bucket(self, bk, async_op=True):
+        view = self.gflat[bk["start"]:bk["end"]]
+        bk["work"] = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op)
+        bk["launched"] = True
+
+    def _on_grad(self, i):
+        p, off = self.params[i], self.offsets[i]
+        if p.grad is not None and p.grad.data_ptr() != self.gflat.data_ptr() + 4 * off:
+            view = self.gflat[off:off + p.numel()].view_as(p)      # someone detached .grad: put it back first
+            view.copy_(p.grad)
+            p.grad = view
+        bk = self._buckets[self._bucket_of[i]]
+        bk["pending"] -= 1
+        if bk["pending"] == 0 and not bk["launched"] and dist.is_available() and dist.is_initialized():
+            self._launch_bucket(bk)
+
+    def _finish_overlap(self):
+        for bk in self._buckets:
+            if not bk["launched"]:                  # a parameter that got no gradient this step kept it open
+                self._launch_bucket(bk, async_op=False)
+            elif bk["work"] is not None:
+                bk["work"].wait()
+            bk.update(pending=len(bk["params"]), work=None, launched=False)
 
     def zero_grad(self, set_to_none: bool = False):
         if self.gflat.is_cuda:
@@ -85,10 +134,16 @@ class FlatAdam:
         for p, off in zip(self.params, self.offsets):   # re-attach if someone set .grad = None
             if p.grad is None or p.grad.data_ptr() != self.gflat.data_ptr() + 4 * off:
                 p.grad = self.gflat[off:off + p.numel()].view_as(p)
+        if self._buckets is not None:
+            for bk in self._buckets:
+                bk.update(pending=len(bk["params"]), work=None, launched=False)
 
     def all_reduce_grads(self):
         if self.world_size > 1 or (dist.is_available() and dist.is_initialized()):
-            dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM, group=self.pg)
+            if self._buckets is not None:
+                self._finish_overlap()
+            else:
+                dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM, group=self.pg)
 
     def _gather_stray_grads(self):
         """`model.zero_grad()` (set_to_none) detaches .grad from the flat buffer: copy such grads back."""
@@ -179,6 +234,8 @@ def fit(onet, train_loader, device, epochs, schedule="sim", base_lr=None, eval_f
     if fused_adam:
         opt = FlatAdam(onet, lr=base_lr, world_size=world)
         opt.broadcast_params(0)
+        if world > 1:
+            opt.enable_overlap()
     else:
         opt = torch.optim.Adam(onet.parameters(), lr=base_lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0)
     if eval_every is None:

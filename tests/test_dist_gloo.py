@@ -47,6 +47,28 @@ def _worker(rank, world, port, q):
         dist.all_gather(both, mine)
         assert torch.allclose(opt.gflat, sum(both), rtol=1e-6, atol=1e-7)
 
+        # (1b) bucketed all-reduce issued from the backward hooks (overlap path) == the single all-reduce, bit for bit;
+        #      tiny buckets so that several are in flight, one parameter left without a gradient on purpose
+        net2 = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+        unused = torch.nn.Parameter(torch.ones(7))
+        net2.register_parameter("unused", unused)
+        opt2 = FlatAdam(net2, lr=1e-3, world_size=world)
+        opt2.broadcast_params(0)
+        opt2.zero_grad()
+        net2(shard_batch(X, rank, world)).pow(2).sum().backward()
+        local = opt2.gflat.clone()
+        opt2.all_reduce_grads()
+        want = opt2.gflat.clone()
+        opt2.enable_overlap(bucket_mb=1e-4)
+        assert len(opt2._buckets) >= 3
+        for _ in range(2):                                   # twice: the bucket state must reset between steps
+            opt2.zero_grad()
+            net2(shard_batch(X, rank, world)).pow(2).sum().backward()
+            assert any(bk["launched"] for bk in opt2._buckets), "no bucket was reduced during backward"
+            opt2.all_reduce_grads()
+            assert torch.equal(opt2.gflat, want), (opt2.gflat - want).abs().max()
+        assert not torch.equal(local, want)
+
         # (2) DP semantics on the real model (CPU oracle): averaged shard gradients == the mean of the
         #     per-shard reference runs (local-BN / DDP semantics)
         B, C, H, W = 4, 1, 16, 16
