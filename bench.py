@@ -164,7 +164,8 @@ def main():
                           "grad_allreduce": ("none (1 process)" if not distributed else
                                              "%g MB buckets overlapped with backward" % args.bucket_mb if overlap
                                              else "single all-reduce after backward")},
-               "loss": loss_val, "roofline": roofline}
+               "loss": loss_val, "hbm_peak_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
+               "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(X_cpu, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -412,3 +412,22 @@ def test_non_contiguous_and_strided_inputs(dev):
         big[..., ::2] = X
         assert torch.equal(m(big[..., ::2])[4], ref)
         assert torch.equal(m(X.to(memory_format=torch.channels_last))[4], ref)
+
+
+def test_config3_batch256_single_gpu_fits_and_steps(dev):
+    """BASELINE config 3's shape (B=256, 1x256x256 on ONE MI355X) in fp32: the step must fit the 288 GB of HBM
+    (measured peak 175 GB) and give a finite loss and finite gradients; the loss of the B=256 batch built by
+    tiling the B=2 golden input 128 times equals the golden loss (BatchNorm statistics of a tiled batch are those
+    of the tile; the JSD means are over B*H*W)."""
+    free, _total = torch.cuda.mem_get_info(dev)
+    if free < 200 * 2 ** 30:
+        pytest.skip("needs ~175 GB of free HBM")
+    g = np.load(os.path.join(G, "onet_b2_c1_256.npz"))
+    X = orc.det_input(2, 1, 256, 256).to(dev).repeat(128, 1, 1, 1)
+    m = _model(1, True, dev)
+    (_, _, _, _, S), loss = _step(m, X)
+    assert S.shape == (256, 2, 256, 256)
+    assert abs(loss.item() - g["losses"][0]) <= RTOL * abs(g["losses"][0])
+    assert all(bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+    del m, X, S, loss
+    torch.cuda.empty_cache()
