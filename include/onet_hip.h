@@ -51,6 +51,27 @@ int onet_conv3x3_pack_weights(const float* w, float* wp_fwd, float* wp_dgrad,
  *   wp_dgrad [4*Cout][Cin]   row    k = (dy*2+dx)*Cout + co */
 int onet_convT2x2_pack_weights(const float* w, float* wp_fwd, float* wp_dgrad,
                                int Cin, int Cout, void* stream);
+/* Fused forward of nn.ConvTranspose2d(Cin, Ct, kernel_size=2, stride=2) (OV:86) + F.pad offsets + the write into
+ * the second half of the concat buffer (OV:91-100): one 1x1 MFMA GEMM whose epilogue does the pixel shuffle and
+ * the bias.  wq [Cin][4*Ct] with column c*4 + (2*di + dj); y is the [Ct][Ho][Wo] window (batch stride y_bs) and
+ * receives rows pt .. pt+2h-1, columns pl .. pl+2w-1 (the caller zeroes a non-empty F.pad border). */
+int onet_convT2x2_pack_weights_fused(const float* w, float* wq, int Cin, int Cout, void* stream);
+int onet_convT2x2_fwd(const float* x, int64_t x_bs, const float* wq, const float* bias, float* y, int64_t y_bs,
+                      int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, void* stream);
+/* Backward of the same module without materialising the space-to-depth tensor: the 1x1 GEMM kernels gather their
+ * dy operand straight from the [Ct][Ho][Wo] window of the concat gradient (dy_bs = its batch stride).
+ *   dgrad: dx[b][ci][i][j] = sum_{c,di,dj} dy[b][c][pt+2i+di][pl+2j+dj] * W[ci][c][di][dj]   (wp_dgrad of
+ *          onet_convT2x2_pack_weights; Ct % 8 == 0)
+ *   wgrad: dw[ci][c][di][dj] = sum_{b,i,j} x[b][ci][i][j] * dy[b][c][pt+2i+di][pl+2j+dj]     (Ct % 64 == 0; workspace
+ *          of onet_conv_wgrad_ws_bytes(B, Cin, 4*Ct, h, w, 1))
+ *   dbias: db[c] = sum dy[:, c, window]  (scratch: B*C doubles) */
+int onet_convT2x2_dgrad(const float* dy, int64_t dy_bs, const float* wp_dgrad, float* dx, int64_t dx_bs, int B,
+                        int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, void* stream);
+int onet_convT2x2_wgrad(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, float* dw, void* ws,
+                        int64_t ws_bytes, int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl,
+                        void* stream);
+int onet_convT2x2_dbias(const float* dy, int64_t dy_bs, float* dbias, double* scratch, int accumulate, int B,
+                        int C, int h, int w, int Ho, int Wo, int pt, int pl, void* stream);
 
 /* ---- K1: 3x3 / 1x1 convolution, fp32 MFMA implicit GEMM ----------------- */
 /* z[b][co][y][x] = sum_{ci,ky,kx} wp[ci][ky*ks+kx][co] * x[b][ci][y+ky-p][x+kx-p]

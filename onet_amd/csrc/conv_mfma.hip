@@ -34,8 +34,10 @@ __global__ void pack3x3_kernel(const float* __restrict__ w, float* __restrict__ 
     }
 }
 
+// wq: sub-pixel index fastest (column c*4 + q) -- the layout of the fused convT forward, whose epilogue finds
+// the four sub-pixels of one output channel in four consecutive accumulator rows of one lane
 __global__ void packT2x2_kernel(const float* __restrict__ w, float* __restrict__ wf,
-                                float* __restrict__ wd, int Cin, int Cout) {
+                                float* __restrict__ wd, float* __restrict__ wq, int Cin, int Cout) {
     int64_t n = (int64_t)Cin * Cout * 4;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -45,6 +47,7 @@ __global__ void packT2x2_kernel(const float* __restrict__ w, float* __restrict__
         float v = w[i];
         if (wf) wf[(int64_t)ci * (4 * Cout) + q * Cout + co] = v;
         if (wd) wd[((int64_t)q * Cout + co) * Cin + ci] = v;
+        if (wq) wq[(int64_t)ci * (4 * Cout) + co * 4 + q] = v;
     }
 }
 
@@ -57,6 +60,10 @@ struct ConvArgs {
     int64_t z_bs;
     float* bn_part;
     int B, Cin, Cout, H, W, tilesX, tilesY, coTiles;
+    // fused ConvTranspose2d(k=2, s=2) epilogue (SHUF kernels only): z is the [Cout/4][Ho][Wo] window of the concat
+    // buffer, GEMM row n = c*4 + q holds sub-pixel q = 2*di + dj of output channel c
+    const float* bias = nullptr;
+    int Ho = 0, Wo = 0, pt = 0, pl = 0;
 };
 
 constexpr int CI_T = 8;  // input channels staged per K-chunk
@@ -96,8 +103,11 @@ __device__ __forceinline__ u32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off) 
 // Software pipeline per K-chunk of CI_T input channels:
 //   regs(chunk c+1) <- buffer loads issued BEFORE the MFMA block of chunk c (latency hidden under
 //   288 MFMAs/wave), LDS <- regs after it; 2 blocks/CU cover the commit + barrier bubbles.
-template <int KS, int MT, int NT, int WM, int WN, int TW>
+// MODE 0: plain   1: ConvTranspose2d forward (pixel-shuffle + bias epilogue)   2: ConvTranspose2d input-grad (the
+// GEMM input channel q*Ct + c at pixel (i, j) is gathered from dy[c][pt + 2i + di][pl + 2j + dj], q = 2*di + dj)
+template <int KS, int MT, int NT, int WM, int WN, int TW, int MODE = 0>
 __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
+    constexpr bool SHUF = (MODE == 1), S2D = (MODE == 2);
     using C = ConvCfg<KS, MT, NT, WM, WN, TW>;
     static_assert(WM * WN == 4, "4 waves per block");
     constexpr int TAPS = C::TAPS, PAD = C::PAD, RPT = C::RPT, ROWS = C::ROWS;
@@ -158,7 +168,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
     const float* a_ptr = w_lds + kh * TAPS * CO_T + wm * 32 * MT + l31;
     const float* b_ptr = in_lds + kh * CH_STRIDE + (wn * NT * RPT + py) * ROW_STRIDE + px;
 
-    const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x + (int64_t)b * a.x_bs, (int64_t)a.Cin * HW * 4);
+    const int HWo = a.Ho * a.Wo, s2d_Ct = a.Cin >> 2;     // S2D only
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x + (int64_t)b * a.x_bs, S2D ? (int64_t)s2d_Ct * HWo * 4 : (int64_t)a.Cin * HW * 4);
     const __amdgpu_buffer_rsrc_t wr = make_rsrc(a.wp, (int64_t)a.Cin * TAPS * a.Cout * 4);
     const bool vec4 = (a.Cout & 3) == 0;
 
@@ -171,8 +182,15 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
         const int r = rem / ROW_STRIDE, c = rem % ROW_STRIDE;
         const int yy = y0 - PAD + r, xx = x0 - PAD + c;
         const bool ok = (i < IN_FLOATS) && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-        in_off[k] = ok ? (unsigned)((ci * HW + yy * a.W + xx) * 4) : OOB_OFF;
+        if constexpr (S2D) in_off[k] = ok ? (unsigned)((ci * HWo + (a.pt + 2 * yy) * a.Wo + a.pl + 2 * xx) * 4) : OOB_OFF;
+        else in_off[k] = ok ? (unsigned)((ci * HW + yy * a.W + xx) * 4) : OOB_OFF;
     }
+    // S2D: byte offset of GEMM input channel c0 (a multiple of CI_T; Ct % CI_T == 0 keeps a chunk inside one sub-pixel)
+    auto s2d_bytes = [&](int c0) -> unsigned {
+        if (c0 >= a.Cin) return OOB_OFF;
+        const int q = c0 / s2d_Ct, cc = c0 % s2d_Ct;
+        return (unsigned)((cc * HWo + (q >> 1) * a.Wo + (q & 1)) * 4);
+    };
     unsigned w_off[NW4];
 #pragma unroll
     for (int k = 0; k < NW4; ++k) {
@@ -225,7 +243,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
     for (int c0 = 0; c0 < a.Cin; c0 += CI_T) {
         commit(c0);
         __syncthreads();
-        cin_bytes += in_step;
+        if constexpr (S2D) cin_bytes = s2d_bytes(c0 + CI_T);
+        else cin_bytes += in_step;
         cw_bytes += w_step;
         issue(cin_bytes, cw_bytes);                 // next chunk (past the end: range check -> zeros, no traffic)
         __builtin_amdgcn_sched_barrier(0);          // keep the loads ahead of the MFMA block
@@ -271,6 +290,40 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
     // ---- epilogue: D[co][pix] -> z (lanes run along x: coalesced 128-B rows)
     float* zb = a.z + (int64_t)b * a.z_bs;
     const int xo = x0 + px;
+    if constexpr (SHUF) {
+        // pixel shuffle + bias + F.pad offsets fused (OV:86, 91-100): accumulator rows 4g .. 4g+3 of a lane are the
+        // 2x2 sub-pixels of ONE output channel at low-res pixel (yo, xo) -> two float2 row stores (lanes along x:
+        // 512 contiguous bytes per wave row)
+        const int64_t HWo = (int64_t)a.Ho * a.Wo;
+        const bool vec2 = ((a.pl & 1) == 0) && ((a.Wo & 1) == 0) && ((a.z_bs & 1) == 0) &&
+                          ((reinterpret_cast<uintptr_t>(a.z) & 7) == 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int yo = y0 + (wn * NT + n) * RPT + py;
+                if (yo < a.H && xo < a.W) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int c = ((co0 + (wm * MT + m) * 32) >> 2) + 2 * g + kh;
+                        if (c < (a.Cout >> 2)) {
+                            const float bv = a.bias ? a.bias[c] : 0.f;
+                            float* o = zb + (int64_t)c * HWo + (int64_t)(a.pt + 2 * yo) * a.Wo + a.pl + 2 * xo;
+                            const float v0 = acc[m][n][4 * g] + bv, v1 = acc[m][n][4 * g + 1] + bv;
+                            const float v2 = acc[m][n][4 * g + 2] + bv, v3 = acc[m][n][4 * g + 3] + bv;
+                            if (vec2) {
+                                *reinterpret_cast<float2*>(o) = make_float2(v0, v1);
+                                *reinterpret_cast<float2*>(o + a.Wo) = make_float2(v2, v3);
+                            } else {
+                                o[0] = v0; o[1] = v1; o[a.Wo] = v2; o[a.Wo + 1] = v3;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -287,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs a) {
     }
 }
 
-template <int KS, int MT, int NT, int WM, int WN, int TW>
+template <int KS, int MT, int NT, int WM, int WN, int TW, int MODE = 0>
 static int launch_fwd(ConvArgs a, hipStream_t st) {
     using C = ConvCfg<KS, MT, NT, WM, WN, TW>;
     a.tilesX = cdiv(a.W, TW);
@@ -295,7 +348,7 @@ static int launch_fwd(ConvArgs a, hipStream_t st) {
     a.coTiles = cdiv(a.Cout, C::CO_T);
     const int64_t blocks = (int64_t)a.B * a.tilesX * a.tilesY * a.coTiles;
     ONET_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv_fwd: grid %lld out of range", (long long)blocks);
-    auto kern = conv_fwd_kernel<KS, MT, NT, WM, WN, TW>;
+    auto kern = conv_fwd_kernel<KS, MT, NT, WM, WN, TW, MODE>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -347,6 +400,9 @@ struct WgArgs {
     int64_t dz_bs;
     float* slab;
     int B, Cin, Cout, H, W, ciTiles, coTiles, splitK, stripsY, stripsX;
+    // ConvTranspose2d weight-grad (S2D kernels): dz is the [Ct][Ho][Wo] window of dcat, GEMM row q*Ct + c at pixel
+    // (i, j) is dy[c][pt + 2i + di][pl + 2j + dj]
+    int s2d_Ct = 0, Ho = 0, Wo = 0, pt = 0, pl = 0;
 };
 
 template <int KS, int PW>
@@ -366,7 +422,7 @@ struct WgCfg {
 // buffer loads of strip u+splitK are issued before the MFMA block of strip u and committed to LDS
 // after it.  All staged elements of a thread sit at a constant channel stride, so one base offset
 // per operand suffices.
-template <int KS, int PW>
+template <int KS, int PW, bool S2D = false>
 __global__ __launch_bounds__(256 * KS, KS == 3 ? 3 : 2) void conv_wgrad_kernel(WgArgs a) {
     using C = WgCfg<KS, PW>;
     constexpr int TAPS = C::TAPS, PAD = C::PAD, PR = C::PR, XR = C::XR, XC = C::XC;
@@ -432,15 +488,24 @@ __global__ __launch_bounds__(256 * KS, KS == 3 ? 3 : 2) void conv_wgrad_kernel(W
         const int sy = (uu / a.stripsX) % a.stripsY;
         const int b = uu / (a.stripsX * a.stripsY);
         const int y0 = sy * PR, x0 = sx * PW;
-        const __amdgpu_buffer_rsrc_t dr = make_rsrc(a.dz + (int64_t)b * a.dz_bs, (int64_t)a.Cout * HW * 4);
+        const int HWo = a.Ho * a.Wo;
+        const __amdgpu_buffer_rsrc_t dr = make_rsrc(a.dz + (int64_t)b * a.dz_bs, S2D ? (int64_t)a.s2d_Ct * HWo * 4 : (int64_t)a.Cout * HW * 4);
         const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x + (int64_t)b * a.x_bs, (int64_t)a.Cin * HW * 4);
         {
             const int yy = y0 + dz_r, xx = x0 + dz_col;
             const bool ok = live && yy < a.H && xx < a.W;
-            const unsigned base = ok ? (unsigned)(((co0 + dz_c) * HW + yy * a.W + xx) * 4) : OOB_OFF;
+            unsigned base, kstep;
+            if constexpr (S2D) {          // Ct % 64 == 0: the block's 64 GEMM rows share one sub-pixel q
+                const int q = co0 / a.s2d_Ct, cc = co0 % a.s2d_Ct + dz_c;
+                base = ok ? (unsigned)((cc * HWo + (a.pt + 2 * yy + (q >> 1)) * a.Wo + a.pl + 2 * xx + (q & 1)) * 4) : OOB_OFF;
+                kstep = (unsigned)(DZ_CSTEP * HWo * 4);
+            } else {
+                base = ok ? (unsigned)(((co0 + dz_c) * HW + yy * a.W + xx) * 4) : OOB_OFF;
+                kstep = dz_kstep;
+            }
 #pragma unroll
             for (int k = 0; k < NDZ; ++k)
-                dzv[k] = bload(dr, (dz_c + DZ_CSTEP * k < 64) ? base + k * dz_kstep : OOB_OFF);
+                dzv[k] = bload(dr, (ok && dz_c + DZ_CSTEP * k < 64) ? base + k * kstep : OOB_OFF);
         }
         {
             const int yy = y0 - PAD + xm_r, xx = x0 + xm_col;
@@ -619,10 +684,10 @@ __global__ __launch_bounds__(256) void conv3x3_stem_wgrad_kernel(WgArgs a) {
     }
 }
 
-template <int KS, int PW>
+template <int KS, int PW, bool S2D = false>
 static void launch_wgrad(const WgArgs& a, int64_t blocks, hipStream_t st) {
     using C = WgCfg<KS, PW>;
-    auto kern = conv_wgrad_kernel<KS, PW>;
+    auto kern = conv_wgrad_kernel<KS, PW, S2D>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -666,8 +731,39 @@ int onet_convT2x2_pack_weights(const float* w, float* wp_fwd, float* wp_dgrad, i
     ONET_REQUIRE(w && Cout > 0 && Cin > 0, "packT2x2: bad args");
     const int64_t n = (int64_t)Cout * Cin * 4;
     hipLaunchKernelGGL(packT2x2_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n, 256), 4096)), dim3(256), 0,
-                       as_stream(stream), w, wp_fwd, wp_dgrad, Cin, Cout);
+                       as_stream(stream), w, wp_fwd, wp_dgrad, (float*)nullptr, Cin, Cout);
     return check_launch("packT2x2_kernel");
+}
+
+int onet_convT2x2_pack_weights_fused(const float* w, float* wq, int Cin, int Cout, void* stream) {
+    ONET_REQUIRE(w && wq && Cout > 0 && Cin > 0, "packT2x2_fused: bad args");
+    const int64_t n = (int64_t)Cout * Cin * 4;
+    hipLaunchKernelGGL(packT2x2_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n, 256), 4096)), dim3(256), 0,
+                       as_stream(stream), w, (float*)nullptr, (float*)nullptr, wq, Cin, Cout);
+    return check_launch("packT2x2_kernel");
+}
+
+int onet_convT2x2_fwd(const float* x, int64_t x_bs, const float* wq, const float* bias, float* y, int64_t y_bs,
+                      int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, void* stream) {
+    ONET_REQUIRE(x && wq && y, "convT2x2_fwd: null pointer");
+    ONET_REQUIRE(B > 0 && Cin > 0 && Ct > 0 && h > 0 && w > 0, "convT2x2_fwd: bad shape");
+    ONET_REQUIRE(pt >= 0 && pl >= 0 && pt + 2 * h <= Ho && pl + 2 * w <= Wo, "convT2x2_fwd: window outside plane");
+    ONET_REQUIRE(x_bs >= (int64_t)Cin * h * w && y_bs >= (int64_t)Ct * Ho * Wo, "convT2x2_fwd: batch stride too small");
+    ConvArgs a{x, x_bs, wq, y, y_bs, nullptr, B, Cin, 4 * Ct, h, w, 0, 0, 0, bias, Ho, Wo, pt, pl};
+    return (w > 16) ? launch_fwd<1, 2, 2, 1, 4, 32, 1>(a, as_stream(stream))
+                    : launch_fwd<1, 2, 2, 1, 4, 16, 1>(a, as_stream(stream));
+}
+
+int onet_convT2x2_dgrad(const float* dy, int64_t dy_bs, const float* wp_dgrad, float* dx, int64_t dx_bs, int B,
+                        int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, void* stream) {
+    ONET_REQUIRE(dy && wp_dgrad && dx, "convT2x2_dgrad: null pointer");
+    ONET_REQUIRE(B > 0 && Cin > 0 && Ct > 0 && h > 0 && w > 0, "convT2x2_dgrad: bad shape");
+    ONET_REQUIRE(Ct % CI_T == 0, "convT2x2_dgrad: Ct must be a multiple of %d (use onet_space_to_depth2 + onet_conv_fwd)", CI_T);
+    ONET_REQUIRE(pt >= 0 && pl >= 0 && pt + 2 * h <= Ho && pl + 2 * w <= Wo, "convT2x2_dgrad: window outside plane");
+    ONET_REQUIRE(dy_bs >= (int64_t)Ct * Ho * Wo && dx_bs >= (int64_t)Cin * h * w, "convT2x2_dgrad: batch stride too small");
+    ConvArgs a{dy, dy_bs, wp_dgrad, dx, dx_bs, nullptr, B, 4 * Ct, Cin, h, w, 0, 0, 0, nullptr, Ho, Wo, pt, pl};
+    return (w > 16) ? launch_fwd<1, 2, 2, 1, 4, 32, 2>(a, as_stream(stream))
+                    : launch_fwd<1, 2, 2, 1, 4, 16, 2>(a, as_stream(stream));
 }
 
 int onet_conv_fwd_nparts(int B, int Cout, int H, int W) {
@@ -739,6 +835,31 @@ int onet_conv_wgrad(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs
     const int64_t n = (int64_t)Cout * Cin;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv(n, 64), (unsigned)(ks * ks)), dim3(256), 0, st,
                        (const float*)ws, dw, a.splitK, ks * ks, Cout, Cin, out_layout, accumulate);
+    return check_launch("wgrad_reduce_kernel");
+}
+
+int onet_convT2x2_wgrad(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, float* dw, void* ws,
+                        int64_t ws_bytes, int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl,
+                        void* stream) {
+    ONET_REQUIRE(x && dy && dw && ws, "convT2x2_wgrad: null pointer");
+    ONET_REQUIRE(B > 0 && Cin > 0 && Ct > 0 && h > 0 && w > 0, "convT2x2_wgrad: bad shape");
+    ONET_REQUIRE(Ct % 64 == 0, "convT2x2_wgrad: Ct must be a multiple of 64 (use onet_space_to_depth2 + onet_conv_wgrad)");
+    ONET_REQUIRE(pt >= 0 && pl >= 0 && pt + 2 * h <= Ho && pl + 2 * w <= Wo, "convT2x2_wgrad: window outside plane");
+    ONET_REQUIRE(dy_bs >= (int64_t)Ct * Ho * Wo && x_bs >= (int64_t)Cin * h * w, "convT2x2_wgrad: batch stride too small");
+    const int Cout = 4 * Ct;
+    WgArgs a{x, x_bs, dy, dy_bs, (float*)ws, B, Cin, Cout, h, w, cdiv(Cin, 64), cdiv(Cout, 64), 1, 1, 1, Ct, Ho, Wo, pt, pl};
+    int pw;
+    wgrad_plan(B, Cin, Cout, h, w, 1, pw, a.splitK, a.stripsX, a.stripsY);
+    const int64_t need = (int64_t)a.splitK * Cout * Cin * 4;
+    ONET_REQUIRE(ws_bytes >= need, "convT2x2_wgrad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
+    const int64_t blocks = (int64_t)a.splitK * a.ciTiles * a.coTiles;
+    hipStream_t st = as_stream(stream);
+    if (pw == 32) launch_wgrad<1, 32, true>(a, blocks, st); else launch_wgrad<1, 16, true>(a, blocks, st);
+    int rc = check_launch("conv_wgrad_kernel");
+    if (rc) return rc;
+    const int64_t n = (int64_t)Cout * Cin;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv(n, 64), 1u), dim3(256), 0, st, (const float*)ws, dw,
+                       a.splitK, 1, Cout, Cin, 1, 0);
     return check_launch("wgrad_reduce_kernel");
 }
 

@@ -338,6 +338,19 @@ extern "C" int onet_space_to_depth2(const float* dy, int64_t dy_bs, float* sub, 
     return rc;
 }
 
+extern "C" int onet_convT2x2_dbias(const float* dy, int64_t dy_bs, float* dbias, double* scratch, int accumulate, int B,
+                                   int C, int h, int w, int Ho, int Wo, int pt, int pl, void* stream) {
+    ONET_REQUIRE(dy && dbias && scratch && B > 0 && C > 0 && h > 0 && w > 0, "convT2x2_dbias: bad args");
+    ONET_REQUIRE(pt >= 0 && pl >= 0 && pt + 2 * h <= Ho && pl + 2 * w <= Wo, "convT2x2_dbias: window outside plane");
+    hipLaunchKernelGGL(convT_dbias_partial_kernel, dim3((unsigned)((int64_t)B * C)), dim3(256), 0, as_stream(stream), dy,
+                       dy_bs, scratch, B, C, 2 * h, 2 * w, Ho, Wo, pt, pl);
+    int rc = check_launch("convT_dbias_partial_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(convT_dbias_final_kernel, dim3(C), dim3(64), 0, as_stream(stream), (const double*)scratch, dbias,
+                       accumulate, B, C);
+    return check_launch("convT_dbias_final_kernel");
+}
+
 // dx must be zero-initialised by the caller (scatter-add)
 extern "C" int onet_bilinear2x_bwd(const float* dy, int64_t dy_bs, float* dx, int64_t dx_bs, int B, int C, int h,
                                    int w, int Ho, int Wo, int pt, int pl, void* stream) {

@@ -118,16 +118,17 @@ class UpConvTCatFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x1, x2, weight, bias, packed):
         ops.require_gpu(x1, x2, weight, bias)
-        wp_fwd, wp_dgrad = packed
+        wp_fused, wp_dgrad = packed
         B, Cin, h, w = x1.shape
         Ct = weight.shape[1]
         C2, Ho, Wo = x2.shape[1], x2.shape[2], x2.shape[3]
         pt, pl = _pad_offsets((h, w), (Ho, Wo))
-        sub = ops.conv_fwd(x1, wp_fwd, 4 * Ct, 1)
         cat = torch.empty((B, C2 + Ct, Ho, Wo), dtype=torch.float32, device=x1.device)
         if C2 > 0:
             ops.copy_strided(x2, cat[:, :C2])
-        ops.pixel_shuffle2_bias(sub, bias, cat[:, C2:], pt, pl)
+        if (Ho, Wo) != (2 * h, 2 * w):
+            cat[:, C2:].zero_()                      # F.pad border (only when H or W is not a multiple of 16)
+        ops.convT2x2_fwd(x1, wp_fused, bias, cat[:, C2:], Ct, pt, pl)
         ctx.save_for_backward(x1, wp_dgrad)
         ctx.meta = (C2, Ct, h, w, pt, pl, tuple(weight.shape), bias is not None)
         return cat
@@ -139,7 +140,14 @@ class UpConvTCatFn(torch.autograd.Function):
         need_x1, need_x2, need_w, need_b = ctx.needs_input_grad[:4]
         dx2 = dcat[:, :C2] if need_x2 else None
         dx1 = dw = db = None
-        if need_x1 or need_w or need_b:
+        if (need_x1 or need_w or need_b) and ops.convT2x2_bwd_fusable(Ct):
+            # the GEMM kernels gather dy from the concat gradient themselves: no space-to-depth tensor
+            dup = dcat[:, C2:]
+            if need_w or need_b:
+                dw, db = ops.convT2x2_wgrad(x1, dup, wshape, pt, pl, want_dbias=(need_b and has_bias))
+            if need_x1:
+                dx1 = ops.convT2x2_dgrad(dup, wp_dgrad, wshape[0], h, w, pt, pl)
+        elif need_x1 or need_w or need_b:
             dsub, db = ops.space_to_depth2(dcat[:, C2:], h, w, pt, pl, want_dbias=(need_b and has_bias))
             if need_w:
                 dw = ops.conv_wgrad(x1, dsub, wshape, 1, out_layout=1)

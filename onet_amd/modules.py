@@ -152,7 +152,7 @@ class ConvT2x2(nn.ConvTranspose2d, _Packable):
         super().__init__(in_channels, out_channels, kernel_size=2, stride=2)
 
     def _pack_fn(self, w):
-        return ops.packT2x2(w)
+        return ops.packT2x2_fused(w), ops.packT2x2(w)[1]
 
     def forward(self, x, output_size=None):
         # standalone use: up-sample only (no skip): concat with an empty skip

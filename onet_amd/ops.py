@@ -99,6 +99,30 @@ def packT2x2(w):
     return wf, wd
 
 
+def packT2x2_fused(w):
+    """[Cin][4*Ct] with column c*4 + sub-pixel: the layout of convT2x2_fwd's shuffle epilogue."""
+    require_gpu(w)
+    w = w.detach().contiguous()
+    Cin, Cout = w.shape[0], w.shape[1]
+    wq = torch.empty(Cin * 4 * Cout, dtype=F32, device=w.device)
+    _lib.call("onet_convT2x2_pack_weights_fused", _p(w), _p(wq), Cin, Cout, _stream())
+    return wq
+
+
+def convT2x2_fwd(x, wq, bias, out, Ct, pt, pl):
+    """out[:, c, pt + 2i + di, pl + 2j + dj] = sum_ci x[:, ci, i, j] * W[ci, c, di, dj] + bias[c]: ConvTranspose2d(k=2, s=2)
+    written straight into `out`, a plane-contiguous [B, Ct, Ho, Wo] view (e.g. the second half of a concat buffer)."""
+    require_gpu(x, wq, out)
+    x, xbs = plane(x)
+    B, Cin, h, w = x.shape
+    Ho, Wo = out.shape[2], out.shape[3]
+    obs = out.stride(0) if B > 1 else Ct * Ho * Wo
+    e0 = _prof_begin()
+    _lib.call("onet_convT2x2_fwd", _p(x), xbs, _p(wq), _p(bias), _p(out), obs, B, Cin, Ct, h, w, Ho, Wo, pt, pl, _stream())
+    _prof_end("conv_fwd_kernel", 2.0 * B * h * w * Cin * 4 * Ct, e0)
+    return out
+
+
 # 3x3 convolution algorithm for fwd/dgrad, chosen per call from the layer shape (ONET_CONV_ALGO overrides):
 #   "auto" (default)  Winograd F(4x4,3x3) where its 64-channel x 32-tile blocks fill the chip, else F(2x2,3x3),
 #                     else the direct implicit-GEMM kernel
@@ -155,10 +179,9 @@ class Packed3x3(dict):
 
 
 def pack3x3_auto(w):
-    """-> lazily packed weights for conv3x3_auto (the direct pack is always built: stem / tiny maps)."""
-    pk = Packed3x3(w)
-    pk.get_pack("direct")
-    return pk
+    """-> lazily packed weights for conv3x3_auto: each algorithm's transform runs on first use after a weight
+    update, so a layer only pays for the packs its shapes actually select."""
+    return Packed3x3(w)
 
 
 def conv3x3_auto(x, pk, direction, out=None):
@@ -413,6 +436,46 @@ def space_to_depth2(dy, h, w, pt, pl, want_dbias):
     _lib.call("onet_space_to_depth2", _p(dy), dybs, _p(sub), _p(dbias), _p(scratch), 0, B, C, h, w, Ho, Wo, pt, pl,
               _stream())
     return sub, dbias
+
+
+def convT2x2_bwd_fusable(Ct):
+    """The gather-fused ConvTranspose2d backward needs a block's 64 GEMM rows inside one sub-pixel plane."""
+    return Ct % 64 == 0
+
+
+def convT2x2_dgrad(dy, wp_dgrad, Cin, h, w, pt, pl):
+    """dx1 of ConvTranspose2d(k=2, s=2) straight from the [B, Ct, Ho, Wo] window `dy` of the concat gradient."""
+    require_gpu(dy, wp_dgrad)
+    dy, dybs = plane(dy)
+    B, Ct, Ho, Wo = dy.shape
+    dx = torch.empty((B, Cin, h, w), dtype=F32, device=dy.device)
+    e0 = _prof_begin()
+    _lib.call("onet_convT2x2_dgrad", _p(dy), dybs, _p(wp_dgrad), _p(dx), Cin * h * w, B, Cin, Ct, h, w, Ho, Wo, pt, pl,
+              _stream())
+    _prof_end("conv_fwd_kernel", 2.0 * B * h * w * Cin * 4 * Ct, e0)
+    return dx
+
+
+def convT2x2_wgrad(x, dy, dw_shape, pt, pl, want_dbias):
+    """(dW [Cin, Ct, 2, 2], dbias | None) of ConvTranspose2d(k=2, s=2) from x1 and the concat-gradient window."""
+    require_gpu(x, dy)
+    x, xbs = plane(x)
+    dy, dybs = plane(dy)
+    B, Cin, h, w = x.shape
+    Ct, Ho, Wo = dy.shape[1], dy.shape[2], dy.shape[3]
+    dw = torch.empty(dw_shape, dtype=F32, device=x.device)
+    need = _lib.load().onet_conv_wgrad_ws_bytes(B, Cin, 4 * Ct, h, w, 1)
+    ws = workspace(need, x.device)
+    e0 = _prof_begin()
+    _lib.call("onet_convT2x2_wgrad", _p(x), xbs, _p(dy), dybs, _p(dw), _p(ws), ws.numel() * 4, B, Cin, Ct, h, w, Ho, Wo,
+              pt, pl, _stream())
+    _prof_end("conv_wgrad_kernel", 2.0 * B * h * w * Cin * 4 * Ct, e0)
+    db = None
+    if want_dbias:
+        db = torch.empty(Ct, dtype=F32, device=x.device)
+        scratch = torch.empty(B * Ct, dtype=torch.float64, device=x.device)
+        _lib.call("onet_convT2x2_dbias", _p(dy), dybs, _p(db), _p(scratch), 0, B, Ct, h, w, Ho, Wo, pt, pl, _stream())
+    return dw, db
 
 
 def bilinear2x_fwd(x, out, pt, pl):

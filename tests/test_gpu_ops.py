@@ -189,11 +189,16 @@ def test_maxpool(dev, B, C, H, W):
     assert torch.equal(xd.grad.cpu(), xr.grad)
 
 
-@pytest.mark.parametrize("h,w,Ho,Wo", [(8, 8, 16, 16), (12, 12, 25, 25), (5, 7, 11, 16)])
-def test_up_convT_cat(dev, h, w, Ho, Wo):
+@pytest.mark.parametrize("h,w,Ho,Wo,Cin,Ct", [(8, 8, 16, 16, 64, 32), (12, 12, 25, 25, 64, 32), (5, 7, 11, 16, 64, 32),
+                                              (32, 32, 64, 64, 128, 64), (17, 40, 35, 80, 24, 12),
+                                              (9, 20, 19, 41, 256, 128), (16, 16, 32, 32, 128, 64)])
+def test_up_convT_cat(dev, h, w, Ho, Wo, Cin, Ct):
+    """ConvTranspose2d(k=2, s=2) + F.pad + cat through the fused shuffle-epilogue GEMM (odd pad offsets, a wide map,
+    channel counts that do not fill the 64-row GEMM tile) and its backward (Ct % 64 == 0: the gather-fused dgrad / wgrad;
+    otherwise space-to-depth + plain 1x1 GEMMs)."""
     from onet_amd import functional as Fn
     from onet_amd import ops
-    B, Cin, Ct, C2 = 2, 64, 32, 32
+    B, C2 = 2, Ct
     x1, x2 = rnd(B, Cin, h, w, seed=15), rnd(B, C2, Ho, Wo, seed=16)
     wt, bt = rnd(Cin, Ct, 2, 2, seed=17, scale=0.1), rnd(Ct, seed=18, scale=0.1)
     a, b_, c, d = [t.clone().requires_grad_(True) for t in (x1, x2, wt, bt)]
@@ -204,7 +209,7 @@ def test_up_convT_cat(dev, h, w, Ho, Wo):
     g = rnd(*ref.shape, seed=19)
     ref.backward(g)
     A, Bt, Cw, Db = [t.to(dev).requires_grad_(True) for t in (x1, x2, wt, bt)]
-    out = Fn.UpConvTCatFn.apply(A, Bt, Cw, Db, ops.packT2x2(Cw))
+    out = Fn.UpConvTCatFn.apply(A, Bt, Cw, Db, (ops.packT2x2_fused(Cw), ops.packT2x2(Cw)[1]))
     out.backward(g.to(dev))
     close(out, ref, what="up fwd")
     close(A.grad, a.grad, what="dx1")
