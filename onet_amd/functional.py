@@ -116,18 +116,23 @@ class UpConvTCatFn(torch.autograd.Function):
     pixel-shuffle that writes straight into the second half of the concat buffer."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, packed):
+    def forward(ctx, x1, x2, weight, bias, packed, cat_holder=None):
         ops.require_gpu(x1, x2, weight, bias)
         wp_fused, wp_dgrad = packed
         B, Cin, h, w = x1.shape
         Ct = weight.shape[1]
         C2, Ho, Wo = x2.shape[1], x2.shape[2], x2.shape[3]
         pt, pl = _pad_offsets((h, w), (Ho, Wo))
-        cat = torch.empty((B, C2 + Ct, Ho, Wo), dtype=torch.float32, device=x1.device)
-        if C2 > 0:
-            ops.copy_strided(x2, cat[:, :C2])
+        cat = None if cat_holder is None else cat_holder[0]
+        in_place = (cat is not None and tuple(cat.shape) == (B, C2 + Ct, Ho, Wo) and C2 > 0
+                    and x2.data_ptr() == cat.data_ptr() and x2.stride() == cat[:, :C2].stride())
+        if not in_place:       # x2 is an ordinary tensor: torch.cat's copy of the skip half
+            cat = torch.empty((B, C2 + Ct, Ho, Wo), dtype=torch.float32, device=x1.device)
+            if C2 > 0:
+                ops.copy_strided(x2, cat[:, :C2])
         if (Ho, Wo) != (2 * h, 2 * w):
-            cat[:, C2:].zero_()                      # F.pad border (only when H or W is not a multiple of 16)
+            for bi in range(B):                      # F.pad border (only when H or W is not a multiple of 16); raw
+                ops.fill(cat[bi, C2:], 0.0)          # fills: a torch in-place op on the base of the skip view is forbidden
         ops.convT2x2_fwd(x1, wp_fused, bias, cat[:, C2:], Ct, pt, pl)
         ctx.save_for_backward(x1, wp_dgrad)
         ctx.meta = (C2, Ct, h, w, pt, pl, tuple(weight.shape), bias is not None)
@@ -153,7 +158,7 @@ class UpConvTCatFn(torch.autograd.Function):
                 dw = ops.conv_wgrad(x1, dsub, wshape, 1, out_layout=1)
             if need_x1:
                 dx1 = ops.conv_fwd(dsub, wp_dgrad, wshape[0], 1)
-        return dx1, dx2, dw, db, None
+        return dx1, dx2, dw, db, None, None
 
 
 class UpBilinearCatFn(torch.autograd.Function):

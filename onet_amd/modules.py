@@ -119,9 +119,10 @@ class DoubleConv(nn.Module):
         return Fn.ConvBNReLUFn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                      training, bn.momentum, bn.eps, conv.packed(), out)
 
-    def forward(self, x):
+    def forward(self, x, out=None):
+        """`out`: optional plane-contiguous [B, Cout, H, W] destination view (the skip half of a concat buffer)."""
         s = self.double_conv
-        return self._unit(self._unit(x, s[0], s[1]), s[3], s[4])
+        return self._unit(self._unit(x, s[0], s[1]), s[3], s[4], None if out is None else (out,))
 
 
 class MaxPool2(nn.MaxPool2d):
@@ -141,8 +142,8 @@ class Down(nn.Module):
         super().__init__()
         self.maxpool_conv = nn.Sequential(MaxPool2(), DoubleConv(in_channels, out_channels))
 
-    def forward(self, x):
-        return self.maxpool_conv(x)
+    def forward(self, x, out=None):
+        return self.maxpool_conv[1](self.maxpool_conv[0](x), out=out)
 
 
 class ConvT2x2(nn.ConvTranspose2d, _Packable):
@@ -185,9 +186,12 @@ class Up(nn.Module):
             self.up = ConvT2x2(in_channels, in_channels // 2)
             self.conv = DoubleConv(in_channels, out_channels)
 
-    def forward(self, x1, x2):
+    def forward(self, x1, x2, cat=None):
+        """`cat`: optional concat buffer whose first channels already ARE x2 (UNet.forward lets the encoder write its
+        skip outputs there, so torch.cat's copy of the skip tensor, OV:100, never happens)."""
         if isinstance(self.up, ConvT2x2):
-            x = Fn.UpConvTCatFn.apply(x1, x2, self.up.weight, self.up.bias, self.up.packed())
+            x = Fn.UpConvTCatFn.apply(x1, x2, self.up.weight, self.up.bias, self.up.packed(),
+                                      None if cat is None else (cat,))
         else:
             x = Fn.UpBilinearCatFn.apply(x1, x2)
         return self.conv(x)
@@ -231,15 +235,30 @@ class UNet(nn.Module):
                 m.bias.data.zero_()
 
     def forward(self, x):
-        x1 = self.inc(x)
-        x2 = self.down1(x1)
-        x3 = self.down2(x2)
-        x4 = self.down3(x3)
+        # ConvTranspose path: the four skip tensors are produced directly inside the first half of their concat
+        # buffers (allocated here, before the encoder runs), the decoder fills the second half
+        cats = [None] * 4
+        if not self.bilinear and x.dim() == 4 and x.is_cuda:
+            B, h, w = x.shape[0], x.shape[2], x.shape[3]
+            for k, enc in enumerate((self.inc, self.down1.maxpool_conv[1], self.down2.maxpool_conv[1],
+                                     self.down3.maxpool_conv[1])):
+                C = enc.double_conv[3].out_channels
+                if h > 0 and w > 0:
+                    cats[k] = torch.empty((B, 2 * C, h, w), dtype=torch.float32, device=x.device)
+                h, w = h // 2, w // 2
+
+        def skip(k, C):
+            return None if cats[k] is None else cats[k][:, :C]
+
+        x1 = self.inc(x, out=skip(0, self.inc.double_conv[3].out_channels))
+        x2 = self.down1(x1, out=skip(1, self.down1.maxpool_conv[1].double_conv[3].out_channels))
+        x3 = self.down2(x2, out=skip(2, self.down2.maxpool_conv[1].double_conv[3].out_channels))
+        x4 = self.down3(x3, out=skip(3, self.down3.maxpool_conv[1].double_conv[3].out_channels))
         x5 = self.down4(x4)
-        y4 = self.up1(x5, x4)
-        y3 = self.up2(y4, x3)
-        y2 = self.up3(y3, x2)
-        y1 = self.up4(y2, x1)
+        y4 = self.up1(x5, x4, cat=cats[3])
+        y3 = self.up2(y4, x3, cat=cats[2])
+        y2 = self.up3(y3, x2, cat=cats[1])
+        y1 = self.up4(y2, x1, cat=cats[0])
         return x1, y1
 
 
