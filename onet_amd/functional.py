@@ -17,16 +17,32 @@ class ConvBNReLUFn(torch.autograd.Function):
     backward: BN+ReLU backward (2 passes) -> wgrad (MFMA split-K) -> dgrad (MFMA)"""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, training, momentum, eps, packed, out):
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, training, momentum, eps, packed, out, groups=1):
         ops.require_gpu(x, weight, gamma, beta)
         z = ops.conv3x3_auto(x, packed, 0)
-        if training:
-            save = ops.bn_train_coeffs(z, gamma, beta, running_mean, running_var, momentum, eps)
-        else:
-            save = ops.bn_eval_coeffs(gamma, beta, running_mean, running_var, eps)
         # `out` is None or a 1-tuple holding a plane-contiguous destination view (kept out of autograd's sight)
-        a = ops.bn_relu_apply(z, save, out=None if out is None else out[0])
-        ctx.save_for_backward(x, z, save)
+        dst = None if out is None else out[0]
+        G = groups if (training and groups > 1) else 1
+        if G == 1:
+            if training:
+                save = ops.bn_train_coeffs(z, gamma, beta, running_mean, running_var, momentum, eps)
+            else:
+                save = ops.bn_eval_coeffs(gamma, beta, running_mean, running_var, eps)
+            a = ops.bn_relu_apply(z, save, out=dst)
+            saves = (save,)
+        else:
+            # twin batch: the G batch slices are separate BatchNorm batches (own statistics, running stats updated
+            # slice after slice, exactly as G consecutive forward passes would)
+            B = z.shape[0]
+            Bg = B // G
+            a = dst if dst is not None else torch.empty_like(z)
+            saves = []
+            for g in range(G):
+                zg = z[g * Bg:(g + 1) * Bg]
+                sv = ops.bn_train_coeffs(zg, gamma, beta, running_mean, running_var, momentum, eps)
+                ops.bn_relu_apply(zg, sv, out=a[g * Bg:(g + 1) * Bg])
+                saves.append(sv)
+        ctx.save_for_backward(x, z, *saves)
         ctx.training = training
         ctx.packed = packed
         ctx.wshape = tuple(weight.shape)
@@ -34,12 +50,24 @@ class ConvBNReLUFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, da):
-        x, z, save = ctx.saved_tensors
+        x, z = ctx.saved_tensors[:2]
+        saves = ctx.saved_tensors[2:]
         need_x, need_w, need_g, need_b = ctx.needs_input_grad[:4]
-        dz, dgamma, dbeta = ops.bn_relu_bwd(da, z, save, ctx.training, need_affine_grads=(need_g or need_b))
+        G = len(saves)
+        if G == 1:
+            dz, dgamma, dbeta = ops.bn_relu_bwd(da, z, saves[0], ctx.training, need_affine_grads=(need_g or need_b))
+        else:
+            Bg = z.shape[0] // G
+            dz = torch.empty_like(z)
+            dgamma = dbeta = None
+            for g in range(G):
+                sl = slice(g * Bg, (g + 1) * Bg)
+                _, dgamma, dbeta = ops.bn_relu_bwd(da[sl], z[sl], saves[g], ctx.training, need_affine_grads=True,
+                                                   out=dz[sl], acc=None if g == 0 else (dgamma, dbeta))
         dw = ops.conv3x3_wgrad_auto(x, dz, ctx.wshape) if need_w else None
         dx = ops.conv3x3_auto(dz, ctx.packed, 1) if need_x else None
-        return dx, dw, (dgamma if need_g else None), (dbeta if need_b else None), None, None, None, None, None, None, None
+        return (dx, dw, (dgamma if need_g else None), (dbeta if need_b else None), None, None, None, None, None, None,
+                None, None)
 
 
 class Conv3x3Fn(torch.autograd.Function):
@@ -199,6 +227,95 @@ class HeadSoftmaxFn(torch.autograd.Function):
         Lt, Ht, Ld, Hd, S = ctx.saved_tensors
         dLt, dHt, dLd, dHd = ops.head_softmax_bwd(dVt, dVd, dS, S, Lt, Ht, Ld, Hd)
         return dLt, dHt, dLd, dHd
+
+
+class TwinInputFn(torch.autograd.Function):
+    """[X ; clip(1 - X + bias, 0, 1)] as one batch of 2B (OV:180 for the second half)."""
+
+    @staticmethod
+    def forward(ctx, x, bias):
+        ops.require_gpu(x)
+        x = x.contiguous()
+        B = x.shape[0]
+        xx = torch.empty((2 * B,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+        xx[:B].copy_(x)
+        ops.complement_clip(x, bias, out=xx[B:])
+        ctx.save_for_backward(xx)
+        return xx
+
+    @staticmethod
+    def backward(ctx, g):
+        # only reached when the caller asks for d/dX (never on the training path): plumbing
+        (xx,) = ctx.saved_tensors
+        B = xx.shape[0] // 2
+        y = xx[B:]
+        return g[:B] - g[B:] * ((y > 0) & (y < 1)).to(g.dtype), None
+
+
+class TwinSplitFn(torch.autograd.Function):
+    """full [2B, ...] -> (top half, down half) as views.  The module's own head and loss differentiate the FULL
+    tensor directly; this node only carries gradient when a caller uses Lt / Ld in a graph of their own."""
+
+    @staticmethod
+    def forward(ctx, full):
+        B = full.shape[0] // 2
+        ctx.shape = tuple(full.shape)
+        return full[:B], full[B:]
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        B = ctx.shape[0] // 2
+        ref = g0 if g0 is not None else g1
+        out = torch.zeros(ctx.shape, dtype=ref.dtype, device=ref.device) if (g0 is None or g1 is None) else \
+            torch.empty(ctx.shape, dtype=ref.dtype, device=ref.device)
+        if g0 is not None:
+            out[:B].copy_(g0)
+        if g1 is not None:
+            out[B:].copy_(g1)
+        return out
+
+
+class HeadSoftmaxTwinFn(torch.autograd.Function):
+    """HeadSoftmaxFn on the twin batch: L = [Lt ; Ld], H = [Ht ; Hd] (each [2B, 64, H, W])."""
+
+    @staticmethod
+    def forward(ctx, L, H):
+        B = L.shape[0] // 2
+        Vt, Vd, S = ops.head_softmax_fwd(L[:B], H[:B], L[B:], H[B:])
+        ctx.save_for_backward(L, H, S)
+        return Vt, Vd, S
+
+    @staticmethod
+    def backward(ctx, dVt, dVd, dS):
+        L, H, S = ctx.saved_tensors
+        B = L.shape[0] // 2
+        dL, dH = ops.head_softmax_bwd(dVt, dVd, dS, S, L[:B], H[:B], L[B:], H[B:], twin=True)
+        return dL, dH
+
+
+class JSDTwinFn(torch.autograd.Function):
+    """(jsd(Lt, St, Sd), jsd(Ld, Sd, St)) of Onet.compute_loss (OV:253-267) with L = [Lt ; Ld] the twin batch: the two
+    channel-constant gradients come back as ONE stride-0 view over the full tensor."""
+
+    @staticmethod
+    def forward(ctx, L, St, Sd):
+        B = L.shape[0] // 2
+        top, s_top = ops.jsd_fwd(L[:B], St, Sd)
+        dwn, s_dwn = ops.jsd_fwd(L[B:], Sd, St)
+        ctx.save_for_backward(s_top, s_dwn, St, Sd)
+        ctx.shape = tuple(L.shape)
+        return top, dwn
+
+    @staticmethod
+    def backward(ctx, g_top, g_dwn):
+        s_top, s_dwn, St, Sd = ctx.saved_tensors
+        B2, C, H, W = ctx.shape
+        half = (B2 // 2, C, H, W)
+        zero = torch.zeros((), dtype=torch.float32, device=St.device)
+        gLt, dSt_a, dSd_a = ops.jsd_bwd(zero if g_top is None else g_top, s_top, St, Sd, half)
+        gLd, dSd_b, dSt_b = ops.jsd_bwd(zero if g_dwn is None else g_dwn, s_dwn, Sd, St, half)
+        gL = torch.cat([gLt, gLd], 0)                     # [2B, 1, H, W]
+        return gL.expand(ctx.shape), dSt_a + dSt_b, dSd_a + dSd_b
 
 
 class JSDFn(torch.autograd.Function):

@@ -104,25 +104,26 @@ class DoubleConv(nn.Module):
         )
 
     @staticmethod
-    def _unit(x, conv, bn, out=None):
+    def _unit(x, conv, bn, out=None, groups=1):
         training = bn.training or (bn.running_mean is None)
         if x.dim() != 4:
             raise ValueError(f"expected 4D input (got {x.dim()}D input)")
         if x.shape[1] != conv.in_channels:
             raise RuntimeError(f"Given groups=1, weight of size {list(conv.weight.shape)}, expected input"
                                f"{list(x.shape)} to have {conv.in_channels} channels, but got {x.shape[1]} channels instead")
-        if training and x.shape[0] * x.shape[2] * x.shape[3] <= 1:
+        if training and (x.shape[0] // groups) * x.shape[2] * x.shape[3] <= 1:
             raise ValueError(f"Expected more than 1 value per channel when training, got input size "
-                             f"{[x.shape[0], conv.out_channels, x.shape[2], x.shape[3]]}")
+                             f"{[x.shape[0] // groups, conv.out_channels, x.shape[2], x.shape[3]]}")
         if training and bn.track_running_stats:
-            bn.num_batches_tracked.add_(1)
+            bn.num_batches_tracked.add_(groups)
         return Fn.ConvBNReLUFn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                     training, bn.momentum, bn.eps, conv.packed(), out)
+                                     training, bn.momentum, bn.eps, conv.packed(), out, groups)
 
-    def forward(self, x, out=None):
-        """`out`: optional plane-contiguous [B, Cout, H, W] destination view (the skip half of a concat buffer)."""
+    def forward(self, x, out=None, groups=1):
+        """`out`: optional plane-contiguous [B, Cout, H, W] destination view (the skip half of a concat buffer);
+        `groups`: the batch holds that many independent BatchNorm batches (twin pass)."""
         s = self.double_conv
-        return self._unit(self._unit(x, s[0], s[1]), s[3], s[4], None if out is None else (out,))
+        return self._unit(self._unit(x, s[0], s[1], None, groups), s[3], s[4], None if out is None else (out,), groups)
 
 
 class MaxPool2(nn.MaxPool2d):
@@ -142,8 +143,8 @@ class Down(nn.Module):
         super().__init__()
         self.maxpool_conv = nn.Sequential(MaxPool2(), DoubleConv(in_channels, out_channels))
 
-    def forward(self, x, out=None):
-        return self.maxpool_conv[1](self.maxpool_conv[0](x), out=out)
+    def forward(self, x, out=None, groups=1):
+        return self.maxpool_conv[1](self.maxpool_conv[0](x), out=out, groups=groups)
 
 
 class ConvT2x2(nn.ConvTranspose2d, _Packable):
@@ -186,7 +187,7 @@ class Up(nn.Module):
             self.up = ConvT2x2(in_channels, in_channels // 2)
             self.conv = DoubleConv(in_channels, out_channels)
 
-    def forward(self, x1, x2, cat=None):
+    def forward(self, x1, x2, cat=None, groups=1):
         """`cat`: optional concat buffer whose first channels already ARE x2 (UNet.forward lets the encoder write its
         skip outputs there, so torch.cat's copy of the skip tensor, OV:100, never happens)."""
         if isinstance(self.up, ConvT2x2):
@@ -194,7 +195,7 @@ class Up(nn.Module):
                                       None if cat is None else (cat,))
         else:
             x = Fn.UpBilinearCatFn.apply(x1, x2)
-        return self.conv(x)
+        return self.conv(x, groups=groups)
 
 
 class UNet(nn.Module):
@@ -234,7 +235,7 @@ class UNet(nn.Module):
                 m.weight.data.normal_(0, 0.01)
                 m.bias.data.zero_()
 
-    def forward(self, x):
+    def forward(self, x, groups=1):
         # ConvTranspose path: the four skip tensors are produced directly inside the first half of their concat
         # buffers (allocated here, before the encoder runs), the decoder fills the second half
         cats = [None] * 4
@@ -250,15 +251,16 @@ class UNet(nn.Module):
         def skip(k, C):
             return None if cats[k] is None else cats[k][:, :C]
 
-        x1 = self.inc(x, out=skip(0, self.inc.double_conv[3].out_channels))
-        x2 = self.down1(x1, out=skip(1, self.down1.maxpool_conv[1].double_conv[3].out_channels))
-        x3 = self.down2(x2, out=skip(2, self.down2.maxpool_conv[1].double_conv[3].out_channels))
-        x4 = self.down3(x3, out=skip(3, self.down3.maxpool_conv[1].double_conv[3].out_channels))
-        x5 = self.down4(x4)
-        y4 = self.up1(x5, x4, cat=cats[3])
-        y3 = self.up2(y4, x3, cat=cats[2])
-        y2 = self.up3(y3, x2, cat=cats[1])
-        y1 = self.up4(y2, x1, cat=cats[0])
+        g = groups
+        x1 = self.inc(x, out=skip(0, self.inc.double_conv[3].out_channels), groups=g)
+        x2 = self.down1(x1, out=skip(1, self.down1.maxpool_conv[1].double_conv[3].out_channels), groups=g)
+        x3 = self.down2(x2, out=skip(2, self.down2.maxpool_conv[1].double_conv[3].out_channels), groups=g)
+        x4 = self.down3(x3, out=skip(3, self.down3.maxpool_conv[1].double_conv[3].out_channels), groups=g)
+        x5 = self.down4(x4, groups=g)
+        y4 = self.up1(x5, x4, cat=cats[3], groups=g)
+        y3 = self.up2(y4, x3, cat=cats[2], groups=g)
+        y2 = self.up3(y3, x2, cat=cats[1], groups=g)
+        y1 = self.up4(y2, x1, cat=cats[0], groups=g)
         return x1, y1
 
 
@@ -290,6 +292,17 @@ class Onet(nn.Module):
         self.check_finite = True            # OV:234 asserts the loss is not NaN (forces a device sync)
 
     def forward(self, X):
+        if self.dwnu is self.topu and ops.TWIN and X.dim() == 4 and X.is_cuda:
+            # shared weights: X and 1-X go through every convolution as ONE batch of 2B (twice the blocks per launch,
+            # weights packed / weight gradients reduced once); BatchNorm treats the halves as two batches, in the
+            # reference's order (X first).  Results: identical activations, weight gradients summed in one
+            # split-K reduction instead of two plus autograd's add.
+            XX = Fn.TwinInputFn.apply(X, float(self.bias))
+            L, H = self.topu(XX, groups=2)
+            Vt, Vd, S = Fn.HeadSoftmaxTwinFn.apply(L, H)
+            Lt, Ld = Fn.TwinSplitFn.apply(L)
+            Lt._onet_twin = Ld._onet_twin = L          # compute_loss differentiates the full tensor directly
+            return Lt, Vt, Ld, Vd, S
         Lt, Ht = self.topu(X)
         Xd = Fn.ComplementClipFn.apply(X, float(self.bias))
         Ld, Hd = self.dwnu(Xd)
@@ -318,6 +331,18 @@ class Onet(nn.Module):
         return Fn.Log1pExpFn.apply(x)
 
     def compute_loss(self, Lt, St, Ld, Sd):
+        full = getattr(Lt, "_onet_twin", None)
+        if (full is not None and full is getattr(Ld, "_onet_twin", None) and full.shape[0] == 2 * Lt.shape[0]
+                and type(self).jensen_shannon_divergence is Onet.jensen_shannon_divergence
+                and "jensen_shannon_divergence" not in self.__dict__):
+            # Lt / Ld are the halves of this module's own twin batch: both JSD terms on the full tensor, so that
+            # its gradient is ONE add (head + loss) instead of two half-tensor adds and a re-assembly copy
+            assert (Lt.dim() == 4 and St.dim() == 4 and Sd.dim() == 4)
+            jsd_top, jsd_dwn = Fn.JSDTwinFn.apply(full, St, Sd)
+            if self.check_finite:
+                assert (torch.isnan(jsd_top) == False)  # noqa: E712  (mirrors OV:234)
+                assert (torch.isnan(jsd_dwn) == False)  # noqa: E712
+            return -(jsd_top + jsd_dwn) / 2
         jsd = getattr(self, "jensen_shannon_divergence", None)
         if callable(jsd):
             jsd_top = jsd(Lt, St, Sd)

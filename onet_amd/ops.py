@@ -131,6 +131,10 @@ def convT2x2_fwd(x, wq, bias, out, Ct, pt, pl):
 # Layers no Winograd kernel takes (stem Cin < 16, channel counts not multiples of 4) always run direct.
 import os as _os
 CONV_ALGO = _os.environ.get("ONET_CONV_ALGO", "auto")
+# Weight-shared Onet (dwnu is topu): run the X and the 1-X pass as ONE batch of 2B through every convolution
+# (BatchNorm keeps the two halves as separate statistics groups).  ONET_TWIN=0 runs the two passes one after the
+# other, as the reference does.
+TWIN = _os.environ.get("ONET_TWIN", "1") != "0"
 _N_CU = 256
 
 
@@ -360,8 +364,9 @@ def bn_relu_apply(z, save, out=None):
     return out
 
 
-def bn_relu_bwd(da, z, save, training, need_affine_grads=True):
-    """-> dz, dgamma, dbeta"""
+def bn_relu_bwd(da, z, save, training, need_affine_grads=True, out=None, acc=None):
+    """-> dz, dgamma, dbeta.  `out`: plane-contiguous destination for dz (a batch slice of a larger buffer);
+    `acc` = (dgamma, dbeta) of another statistics group of the same layer to accumulate into."""
     da, dabs = plane(da)
     z, zbs = plane(z)
     B, C, H, W = z.shape
@@ -372,20 +377,25 @@ def bn_relu_bwd(da, z, save, training, need_affine_grads=True):
     if training or need_affine_grads:
         part2 = torch.empty((nparts, C, 4), dtype=F32, device=dev)
         _lib.call("onet_bn_relu_bwd_reduce", _p(da), dabs, _p(z), zbs, _p(save), _p(part2), nparts, B, C, HW, _stream())
-        dgamma = torch.empty(C, dtype=F32, device=dev)
-        dbeta = torch.empty(C, dtype=F32, device=dev)
+        if acc is None:
+            dgamma = torch.empty(C, dtype=F32, device=dev)
+            dbeta = torch.empty(C, dtype=F32, device=dev)
+        else:
+            dgamma, dbeta = acc
+        accf = 0 if acc is None else 1
         coef = torch.empty((4, C), dtype=F32, device=dev) if training else None
         gathered, world = _gather_partials(part2) if training else (part2, 1)
         if world == 1:
-            _lib.call("onet_bn_bwd_finalize", _p(part2), nparts, B * HW, _p(dgamma), _p(dbeta), _p(coef), 0, C, _stream())
+            _lib.call("onet_bn_bwd_finalize", _p(part2), nparts, B * HW, _p(dgamma), _p(dbeta), _p(coef), accf, C, _stream())
         else:
             # SyncBN: dgamma/dbeta are the LOCAL sums (the gradient all-reduce adds the ranks, as in
             # torch.nn.SyncBatchNorm); c1/c2 in `coef` are means over the GLOBAL batch.
-            _lib.call("onet_bn_bwd_finalize", _p(part2), nparts, B * HW, _p(dgamma), _p(dbeta), None, 0, C, _stream())
+            _lib.call("onet_bn_bwd_finalize", _p(part2), nparts, B * HW, _p(dgamma), _p(dbeta), None, accf, C, _stream())
             _lib.call("onet_bn_bwd_finalize", _p(gathered), nparts * world, B * HW * world, None, None, _p(coef), 0, C,
                       _stream())
-    dz = torch.empty((B, C, H, W), dtype=F32, device=dev)
-    _lib.call("onet_bn_relu_bwd_apply", _p(da), dabs, _p(z), zbs, _p(save), _p(coef), _p(dz), C * HW, B, C, HW,
+    dz = torch.empty((B, C, H, W), dtype=F32, device=dev) if out is None else out
+    dzbs = dz.stride(0) if B > 1 else C * HW
+    _lib.call("onet_bn_relu_bwd_apply", _p(da), dabs, _p(z), zbs, _p(save), _p(coef), _p(dz), dzbs, B, C, HW,
               _stream())
     return dz, dgamma, dbeta
 
@@ -497,10 +507,10 @@ def bilinear2x_bwd(dy, h, w, pt, pl):
 
 
 # ----------------------------------------------------------------------------- elementwise
-def complement_clip(x, bias):
+def complement_clip(x, bias, out=None):
     require_gpu(x)
     x = x.contiguous()
-    y = torch.empty_like(x)
+    y = torch.empty_like(x) if out is None else out          # `out`: a contiguous tensor of x's size
     _lib.call("onet_complement_clip", _p(x), _p(y), float(bias), x.numel(), _stream())
     return y
 
@@ -527,7 +537,8 @@ def head_softmax_fwd(Lt, Ht, Ld, Hd):
     return Vt, Vd, S
 
 
-def head_softmax_bwd(dVt, dVd, dS, S, Lt, Ht, Ld, Hd):
+def head_softmax_bwd(dVt, dVd, dS, S, Lt, Ht, Ld, Hd, twin=False):
+    """-> dLt, dHt, dLd, dHd; twin=True: -> (dL, dH) of shape [2B, C, H, W], the top and down halves adjacent."""
     Lt, a = plane(Lt)
     Ht, b = plane(Ht)
     Ld, c = plane(Ld)
@@ -537,10 +548,15 @@ def head_softmax_bwd(dVt, dVd, dS, S, Lt, Ht, Ld, Hd):
     dVt = None if dVt is None else dVt.contiguous()
     dVd = None if dVd is None else dVd.contiguous()
     dS = None if dS is None else dS.contiguous()
-    outs = [torch.empty((B, C, H, W), dtype=F32, device=dev) for _ in range(4)]
+    if twin:
+        dL = torch.empty((2 * B, C, H, W), dtype=F32, device=dev)
+        dH = torch.empty((2 * B, C, H, W), dtype=F32, device=dev)
+        outs = [dL[:B], dH[:B], dL[B:], dH[B:]]
+    else:
+        outs = [torch.empty((B, C, H, W), dtype=F32, device=dev) for _ in range(4)]
     _lib.call("onet_head_softmax_bwd", _p(dVt), _p(dVd), _p(dS), _p(S), _p(Lt), a, _p(Ht), b, _p(Ld), c, _p(Hd), d,
               _p(outs[0]), _p(outs[1]), _p(outs[2]), _p(outs[3]), B, C, H * W, _stream())
-    return outs
+    return (dL, dH) if twin else outs
 
 
 def _rows(t):
