@@ -10,21 +10,45 @@ st = glob.glob(f"{src}/stats/**/*kernel_stats.csv", recursive=True)[0]
 shutil.copy(st, f"profiles/{tag}_kernel_stats_bench_b32_256.csv")
 rows = list(csv.DictReader(open(st)))
 tot = sum(int(r["TotalDurationNs"]) for r in rows)
+# steady-state view from the kernel trace: only the last three adam_kernel-delimited steps (the warm-up steps carry
+# one-time costs such as the first touch of a freshly grown split-K workspace: single 20 ms wgrad launches)
+tr = glob.glob(f"{src}/stats/**/*kernel_trace.csv", recursive=True)
+steady = None
+if tr:
+    ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(tr[0])))
+    adam = [i for i, e in enumerate(ev) if e[2].startswith("adam_kernel")]
+    if len(adam) >= 4:
+        adam = adam[-4:]                     # the last three optimizer-delimited steps
+        ev = ev[adam[0] + 1:adam[-1] + 1]
+        agg = collections.defaultdict(lambda: [0, 0])
+        for s0, e0, n in ev:
+            agg[n][0] += 1
+            agg[n][1] += e0 - s0
+        steady = (len(adam) - 1, agg)
 bench = {}
 try:
     bench = json.loads(open(f"{src}/bench_line_under_profiler.json").read())
 except Exception:
     pass
 with open(f"profiles/{tag}_kernel_stats_bench_b32_256.md", "w") as f:
-    f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline ({desc})\n\n")
-    f.write(f"MI355X, B=32 1x256x256, fp32; 4 training steps traced (1 warm-up + 3 timed).  Total kernel time {tot/1e6:.1f} ms = "
-            f"{tot/4e6:.1f} ms/step.")
+    f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 3 --no-cpu-baseline ({desc})\n\n")
+    f.write(f"MI355X, B=32 1x256x256, fp32; 6 training steps traced (3 warm-up + 3 timed).  Total kernel time {tot/1e6:.1f} ms = "
+            f"{tot/6e6:.1f} ms/step over all six.")
     if bench:
         dom = bench["roofline"]["kernel"]
         f.write(f"  bench under the profiler: {bench['ms_per_step']} ms/step, {bench['value']} images/s.\n"
                 f"bench.py's own HIP-event timing of the dominant kernel in the same run: {dom}, "
                 f"{bench['roofline']['launches_timed']} launches, avg {bench['roofline']['avg_launch_ms']} ms "
                 f"(this table: the `{dom}` rows).\n")
+    if steady:
+        nst, agg = steady
+        stot = sum(v[1] for v in agg.values())
+        f.write(f"\nSteady state (the {nst} timed steps only, from the kernel trace of the same run; the warm-up step carries one-time "
+                f"costs): {stot/1e6/nst:.1f} ms of kernel time per step.\n")
+        f.write("\n| kernel (steady state) | calls | total ms | avg us | % |\n|---|---:|---:|---:|---:|\n")
+        for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+            f.write(f"| `{n[:90]}` | {c} | {t/1e6:.2f} | {t/c/1e3:.1f} | {100*t/stot:.2f} |\n")
+    f.write("\nAll traced launches (rocprofv3's own `--stats` table, warm-up step included):\n")
     f.write("\n| kernel | calls | total ms | avg us | % |\n|---|---:|---:|---:|---:|\n")
     for r in rows[:40]:
         f.write(f"| `{r['Name'][:90]}` | {r['Calls']} | {int(r['TotalDurationNs'])/1e6:.2f} | {float(r['AverageNs'])/1e3:.1f} | {r['Percentage']} |\n")
@@ -42,7 +66,7 @@ for fcsv in glob.glob(f"{src}/sq/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(fcsv)):
         dur[r["Kernel_Name"].split("(")[0].replace("void ", "")[:60]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 with open(f"profiles/{tag}_sq_counters_bench_b32_256.md", "w") as f:
-    f.write(f"# rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace -- python bench.py --steps 3 --warmup 1 ({desc})\n\n")
+    f.write(f"# rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace -- python bench.py --steps 3 --warmup 3 ({desc})\n\n")
     f.write("effective clock = GRBM_GUI_ACTIVE / 8 / duration (MI355X_MICROARCH.md, DVFS give-back); MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs).\n"
             "Profiled passes run slower than un-profiled ones (same guide), so durations here are longer than in the kernel-stats table.\n\n")
     f.write("| kernel | launches | total ms | effective clock GHz | MFMA busy |\n|---|---:|---:|---:|---:|\n")
