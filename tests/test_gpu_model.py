@@ -480,3 +480,19 @@ def test_twin_halves_used_in_a_callers_own_graph(dev, monkeypatch):
         grads[twin] = [p.grad.detach().clone() for p in m.parameters()]
     for ga, gb in zip(grads[False], grads[True]):
         assert float((ga - gb).norm()) <= 2e-5 * float(ga.norm()) + 1e-12
+
+
+def test_twin_batch_input_gradient(dev, monkeypatch):
+    """d loss / d X through the twin batch ([X ; clip(1 - X + bias)]) equals the two-pass graph's."""
+    from onet_amd import ops
+    B, C, H, W = 2, 1, 32, 32
+    X0 = orc.det_input(B, C, H, W, seed=8).to(dev)
+    g = {}
+    for twin in (False, True):
+        monkeypatch.setattr(ops, "TWIN", twin)
+        m = _model(C, True, dev)
+        X = X0.clone().requires_grad_(True)
+        Lt, Vt, Ld, Vd, S = m(X)
+        m.compute_loss(Lt, S[:, 0:1], Ld, S[:, 1:2]).backward()
+        g[twin] = X.grad.detach().clone()
+    assert float((g[False] - g[True]).norm()) <= 2e-5 * float(g[False].norm()) + 1e-12
