@@ -134,7 +134,8 @@ struct W4Cfg {
     static constexpr int IN_LOGICAL = CI_T * IMG * IN_ROWS * IN_COLS;
     static constexpr int NIN = (IN_LOGICAL + NTHR - 1) / NTHR;
     static constexpr int BUF_FLOATS = W_FLOATS + CI_T * CH_STRIDE;
-    static constexpr int EX_FLOATS = 6 * 32 * 64;          // epilogue exchange: 6 writer waves x 32 values x 64 lanes
+    static constexpr int EX_LANE = 36;                     // exchange: 32 values per lane, lane stride 36 floats (144 B): 16-B
+    static constexpr int EX_FLOATS = 6 * 64 * EX_LANE;     // aligned and the 16 lanes of a b128 group land on 16 distinct 4-bank sets
     static constexpr int LDS_FLOATS = (2 * BUF_FLOATS > 2 * EX_FLOATS) ? 2 * BUF_FLOATS : 2 * EX_FLOATS;
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
 };
@@ -458,8 +459,8 @@ static __device__ __forceinline__ void wino4_body(const Wino4Args& a, float* sme
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int y = 0; y < 4; ++y)
-#pragma unroll
-                    for (int x = 0; x < 4; ++x) ex[(((PG - 1) * 2 + wm) * 32 + h * 16 + y * 4 + x) * 64 + lane] = yv[h][y][x];
+                    *reinterpret_cast<float4*>(ex + (((PG - 1) * 2 + wm) * 64 + lane) * C::EX_LANE + h * 16 + y * 4) =
+                        make_float4(yv[h][y][0], yv[h][y][1], yv[h][y][2], yv[h][y][3]);
         }
         __syncthreads();
         if constexpr (PG == 0) {
@@ -470,11 +471,9 @@ static __device__ __forceinline__ void wino4_body(const Wino4Args& a, float* sme
 #pragma unroll
                 for (int y = 0; y < 4; ++y)
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) {
-                        float s = yv[h][y][x];
-#pragma unroll
-                        for (int g = 0; g < 3; ++g) s += ex[((g * 2 + wm) * 32 + h * 16 + y * 4 + x) * 64 + lane];
-                        yv[h][y][x] = s;
+                    for (int g = 0; g < 3; ++g) {
+                        const float4 v = *reinterpret_cast<const float4*>(ex + ((g * 2 + wm) * 64 + lane) * C::EX_LANE + h * 16 + y * 4);
+                        yv[h][y][0] += v.x; yv[h][y][1] += v.y; yv[h][y][2] += v.z; yv[h][y][3] += v.w;
                     }
                 if (co < a.Cout && img_ok && ox < a.W) {
                     float* o = (IMG == 1 ? zb[0] : (img ? zb[IMG - 1] : zb[0])) + (int64_t)co * HW + (int64_t)oy * a.W + ox;
