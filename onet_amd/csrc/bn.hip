@@ -6,14 +6,16 @@
 
 using namespace onet;
 
-// Welford-style partial over one image plane chunk: part[p][c][3] = (n_k, mean_k, M2_k) with
-// M2_k = sum (z - mean_k)^2 taken in a second pass over the (L2-resident) chunk.  E[z^2]-mean^2
-// in fp32 loses the variance when |mean| >> std or when B*H*W is tiny (1x1 bottleneck at 16^2).
+// Partial over one image plane chunk: part[p][c][3] = (n_k, mean_k, M2_k), M2_k = sum (z - mean_k)^2.
+// ONE pass in fp64 over sums shifted by a pivot (the chunk's first element, within a few standard deviations of
+// its mean): s1 = sum (z - pivot), s2 = sum (z - pivot)^2, mean = pivot + s1/n, M2 = s2 - s1^2/n.  With the shift
+// the subtraction in M2 cancels at most a few bits of a 53-bit accumulator; the plain fp32 E[z^2]-mean^2 loses the
+// variance when |mean| >> std or when B*H*W is tiny (1x1 bottleneck at 16^2), and the earlier two-pass form read
+// every chunk twice (2.9 TB/s effective against 4.9 for the apply pass).
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ z, int64_t z_bs,
                                                                float* __restrict__ part, int C, int HW,
                                                                int chunks, int chunk_len) {
-    __shared__ double red[8];
-    __shared__ double bcast;
+    __shared__ double red[16];
     const int c = blockIdx.x % C;
     const int p = blockIdx.x / C;
     const int b = p / chunks, ch = p % chunks;
@@ -21,41 +23,33 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     const int beg = ch * chunk_len;
     const int end = min(beg + chunk_len, HW);
     const bool vec = ((HW & 3) == 0) && ((z_bs & 3) == 0) && ((chunk_len & 3) == 0);
+    const double pivot = (double)src[beg];
     // fp64 accumulation like ATen's CPU batch norm (acc_type<float> = double); free in an HBM-bound pass
-    double v[1] = {0.0};
+    double v[2] = {0.0, 0.0};
     if (vec) {
         for (int i = beg + threadIdx.x * 4; i < end; i += 1024) {
             const float4 q = *reinterpret_cast<const float4*>(src + i);
-            v[0] += ((double)q.x + (double)q.y) + ((double)q.z + (double)q.w);
-        }
-    } else {
-        for (int i = beg + threadIdx.x; i < end; i += 256) v[0] += (double)src[i];
-    }
-    block_sum_256<double, 1>(v, red);
-    const double n = (double)(end - beg);
-    if (threadIdx.x == 0) bcast = v[0] / n;
-    __syncthreads();
-    const double mean = bcast;
-    double m2[1] = {0.0};
-    if (vec) {
-        for (int i = beg + threadIdx.x * 4; i < end; i += 1024) {
-            const float4 q = *reinterpret_cast<const float4*>(src + i);
-            const double d0 = q.x - mean, d1 = q.y - mean, d2 = q.z - mean, d3 = q.w - mean;
-            m2[0] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            const double d0 = q.x - pivot, d1 = q.y - pivot, d2 = q.z - pivot, d3 = q.w - pivot;
+            v[0] += (d0 + d1) + (d2 + d3);
+            v[1] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         }
     } else {
         for (int i = beg + threadIdx.x; i < end; i += 256) {
-            const double d = src[i] - mean;
-            m2[0] += d * d;
+            const double d = src[i] - pivot;
+            v[0] += d;
+            v[1] += d * d;
         }
     }
-    __syncthreads();   // red[] is reused
-    block_sum_256<double, 1>(m2, red);
+    block_sum_256<double, 2>(v, red);
     if (threadIdx.x == 0) {
+        const double n = (double)(end - beg);
+        const double mean = pivot + v[0] / n;
+        double m2 = v[1] - v[0] * v[0] / n;
+        if (m2 < 0.0) m2 = 0.0;
         float* o = part + ((int64_t)p * C + c) * 3;
         o[0] = (float)n;
         o[1] = (float)mean;
-        o[2] = (float)(m2[0] + n * (mean - (double)(float)mean) * (mean - (double)(float)mean));  // M2 about the ROUNDED mean
+        o[2] = (float)(m2 + n * (mean - (double)(float)mean) * (mean - (double)(float)mean));  // M2 about the ROUNDED mean
     }
 }
 
