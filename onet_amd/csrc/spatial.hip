@@ -75,6 +75,47 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, int64_t x_bs, c
     }
 }
 
+// fast path (W % 4 == 0, H even, 16-B aligned planes): one thread per 2 x 4 input patch = two pooling windows;
+// float4 row loads / stores, one index decomposition per 8 pixels (the per-pixel kernel above spends its time on
+// four redundant window loads and three runtime divisions per element: 2.3 TB/s effective)
+__global__ __launch_bounds__(256) void maxpool2_bwd_v4_kernel(const float* __restrict__ x, int64_t x_bs,
+                                                              const float* __restrict__ dy, int64_t dy_bs,
+                                                              float* __restrict__ dx, int64_t dx_bs, int B, int C, int H,
+                                                              int W, int accumulate) {
+    const int Ho = H >> 1, Wo = W >> 1, W4 = W >> 2;
+    const int64_t n = (int64_t)B * C * Ho * W4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % W4);
+        int64_t r = i / W4;
+        const int oy = (int)(r % Ho);
+        r /= Ho;
+        const int c = (int)(r % C), b = (int)(r / C);
+        const int64_t in_off = (int64_t)c * H * W + (int64_t)(2 * oy) * W + 4 * q;
+        const float4 r0 = *reinterpret_cast<const float4*>(x + (int64_t)b * x_bs + in_off);
+        const float4 r1 = *reinterpret_cast<const float4*>(x + (int64_t)b * x_bs + in_off + W);
+        const float2 g = *reinterpret_cast<const float2*>(dy + (int64_t)b * dy_bs + (int64_t)c * Ho * Wo + (int64_t)oy * Wo + 2 * q);
+        // first maximum in scan order (dy-major), like ATen's max_pool2d
+        int a0 = 0, a1 = 0;
+        float m0 = r0.x, m1 = r0.z;
+        if (r0.y > m0) { m0 = r0.y; a0 = 1; }
+        if (r1.x > m0) { m0 = r1.x; a0 = 2; }
+        if (r1.y > m0) { m0 = r1.y; a0 = 3; }
+        if (r0.w > m1) { m1 = r0.w; a1 = 1; }
+        if (r1.z > m1) { m1 = r1.z; a1 = 2; }
+        if (r1.w > m1) { m1 = r1.w; a1 = 3; }
+        float4 o0 = make_float4(a0 == 0 ? g.x : 0.f, a0 == 1 ? g.x : 0.f, a1 == 0 ? g.y : 0.f, a1 == 1 ? g.y : 0.f);
+        float4 o1 = make_float4(a0 == 2 ? g.x : 0.f, a0 == 3 ? g.x : 0.f, a1 == 2 ? g.y : 0.f, a1 == 3 ? g.y : 0.f);
+        float* o = dx + (int64_t)b * dx_bs + in_off;
+        if (accumulate) {
+            const float4 p0 = *reinterpret_cast<const float4*>(o), p1 = *reinterpret_cast<const float4*>(o + W);
+            o0.x += p0.x; o0.y += p0.y; o0.z += p0.z; o0.w += p0.w;
+            o1.x += p1.x; o1.y += p1.y; o1.z += p1.z; o1.w += p1.w;
+        }
+        *reinterpret_cast<float4*>(o) = o0;
+        *reinterpret_cast<float4*>(o + W) = o1;
+    }
+}
+
 // ---------------------------------------------------------------- convT pixel shuffle / space-to-depth
 __global__ void pixel_shuffle2_bias_kernel(const float* __restrict__ sub, const float* __restrict__ bias,
                                            float* __restrict__ y, int64_t y_bs, int B, int C, int h, int w,
@@ -257,6 +298,14 @@ int onet_maxpool2_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_
                       int B, int C, int H, int W, int accumulate, void* stream) {
     ONET_REQUIRE(x && dy && dx && B > 0 && C > 0 && H >= 2 && W >= 2, "maxpool2_bwd: bad args");
     const int64_t n = (int64_t)B * C * H * W;
+    const bool v4 = ((W & 3) == 0) && ((H & 1) == 0) && ((x_bs & 3) == 0) && ((dx_bs & 3) == 0) && ((dy_bs & 1) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dx) & 15) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(dy) & 7) == 0);
+    if (v4) {
+        hipLaunchKernelGGL(maxpool2_bwd_v4_kernel, dim3(grid_for(n / 8)), dim3(256), 0, as_stream(stream), x, x_bs, dy, dy_bs,
+                           dx, dx_bs, B, C, H, W, accumulate);
+        return check_launch("maxpool2_bwd_v4_kernel");
+    }
     hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), x, x_bs, dy, dy_bs, dx,
                        dx_bs, B, C, H, W, H / 2, W / 2, accumulate);
     return check_launch("maxpool2_bwd_kernel");
