@@ -46,6 +46,7 @@ class ConvBNReLUFn(torch.autograd.Function):
         ctx.training = training
         ctx.packed = packed
         ctx.wshape = tuple(weight.shape)
+        ctx.params = (weight, gamma, beta)          # for ops.grad_slot_if_free in backward
         return a
 
     @staticmethod
@@ -53,9 +54,12 @@ class ConvBNReLUFn(torch.autograd.Function):
         x, z = ctx.saved_tensors[:2]
         saves = ctx.saved_tensors[2:]
         need_x, need_w, need_g, need_b = ctx.needs_input_grad[:4]
+        pw, pg, pb = ctx.params
+        aff = (ops.grad_slot_if_free(pg) if need_g else None, ops.grad_slot_if_free(pb) if need_b else None)
         G = len(saves)
         if G == 1:
-            dz, dgamma, dbeta = ops.bn_relu_bwd(da, z, saves[0], ctx.training, need_affine_grads=(need_g or need_b))
+            dz, dgamma, dbeta = ops.bn_relu_bwd(da, z, saves[0], ctx.training, need_affine_grads=(need_g or need_b),
+                                                affine_out=aff)
         else:
             Bg = z.shape[0] // G
             dz = torch.empty_like(z)
@@ -63,8 +67,9 @@ class ConvBNReLUFn(torch.autograd.Function):
             for g in range(G):
                 sl = slice(g * Bg, (g + 1) * Bg)
                 _, dgamma, dbeta = ops.bn_relu_bwd(da[sl], z[sl], saves[g], ctx.training, need_affine_grads=True,
-                                                   out=dz[sl], acc=None if g == 0 else (dgamma, dbeta))
-        dw = ops.conv3x3_wgrad_auto(x, dz, ctx.wshape) if need_w else None
+                                                   out=dz[sl], acc=None if g == 0 else (dgamma, dbeta),
+                                                   affine_out=aff if g == 0 else None)
+        dw = ops.conv3x3_wgrad_auto(x, dz, ctx.wshape, out=ops.grad_slot_if_free(pw)) if need_w else None
         dx = ops.conv3x3_auto(dz, ctx.packed, 1) if need_x else None
         return (dx, dw, (dgamma if need_g else None), (dbeta if need_b else None), None, None, None, None, None, None,
                 None, None)
@@ -164,6 +169,7 @@ class UpConvTCatFn(torch.autograd.Function):
         ops.convT2x2_fwd(x1, wp_fused, bias, cat[:, C2:], Ct, pt, pl)
         ctx.save_for_backward(x1, wp_dgrad)
         ctx.meta = (C2, Ct, h, w, pt, pl, tuple(weight.shape), bias is not None)
+        ctx.params = (weight, bias)
         return cat
 
     @staticmethod
@@ -177,7 +183,9 @@ class UpConvTCatFn(torch.autograd.Function):
             # the GEMM kernels gather dy from the concat gradient themselves: no space-to-depth tensor
             dup = dcat[:, C2:]
             if need_w or need_b:
-                dw, db = ops.convT2x2_wgrad(x1, dup, wshape, pt, pl, want_dbias=(need_b and has_bias))
+                dw, db = ops.convT2x2_wgrad(x1, dup, wshape, pt, pl, want_dbias=(need_b and has_bias),
+                                            out=ops.grad_slot_if_free(ctx.params[0]),
+                                            db_out=ops.grad_slot_if_free(ctx.params[1]) if has_bias else None)
             if need_x1:
                 dx1 = ops.convT2x2_dgrad(dup, wp_dgrad, wshape[0], h, w, pt, pl)
         elif need_x1 or need_w or need_b:

@@ -249,13 +249,25 @@ def conv3x3_winograd4(x, wq, Cout, out=None):
     return out
 
 
-def conv3x3_winograd_wgrad(x, dz, dw_shape):
+def grad_slot_if_free(param):
+    """FlatAdam registers, per parameter, its slice of the flat gradient buffer.  When the parameter has no .grad yet
+    (FlatAdam.zero_grad sets it to None) a backward kernel may write its result straight into that slice and hand the
+    view to autograd, which then adopts it as .grad without an accumulation kernel (62 + 72 tiny adds per step
+    otherwise).  -> a fresh contiguous view, or None (no slot, or a gradient is already there: regular path)."""
+    slot = getattr(param, "_onet_gslot", None)
+    if slot is None or param.grad is not None:
+        return None
+    flat, off, n, shape = slot
+    return flat[off:off + n].view(shape)
+
+
+def conv3x3_winograd_wgrad(x, dz, dw_shape, out=None):
     require_gpu(x, dz)
     x, xbs = plane(x)
     dz, dzbs = plane(dz)
     B, Cin, H, W = x.shape
     Cout = dz.shape[1]
-    dw = torch.empty(dw_shape, dtype=F32, device=x.device)
+    dw = torch.empty(dw_shape, dtype=F32, device=x.device) if out is None else out
     need = _lib.load().onet_conv3x3_winograd_wgrad_ws_bytes(B, Cin, Cout, H, W)
     ws = workspace(need, x.device)
     e0 = _prof_begin()
@@ -265,11 +277,11 @@ def conv3x3_winograd_wgrad(x, dz, dw_shape):
     return dw
 
 
-def conv3x3_wgrad_auto(x, dz, dw_shape):
+def conv3x3_wgrad_auto(x, dz, dw_shape, out=None):
     Cout, Cin = dw_shape[0], dw_shape[1]
     if use_winograd(Cin, Cout, x.shape[2], x.shape[3]):
-        return conv3x3_winograd_wgrad(x, dz, dw_shape)
-    return conv_wgrad(x, dz, dw_shape, 3)
+        return conv3x3_winograd_wgrad(x, dz, dw_shape, out=out)
+    return conv_wgrad(x, dz, dw_shape, 3, out=out)
 
 
 def conv_fwd(x, wp, Cout, ks, out=None):
@@ -286,13 +298,13 @@ def conv_fwd(x, wp, Cout, ks, out=None):
     return out
 
 
-def conv_wgrad(x, dz, dw_shape, ks, out_layout=0):
+def conv_wgrad(x, dz, dw_shape, ks, out_layout=0, out=None):
     require_gpu(x, dz)
     x, xbs = plane(x)
     dz, dzbs = plane(dz)
     B, Cin, H, W = x.shape
     Cout = dz.shape[1]
-    dw = torch.empty(dw_shape, dtype=F32, device=x.device)
+    dw = torch.empty(dw_shape, dtype=F32, device=x.device) if out is None else out
     need = _lib.load().onet_conv_wgrad_ws_bytes(B, Cin, Cout, H, W, ks)
     ws = workspace(need, x.device)
     e0 = _prof_begin()
@@ -364,9 +376,10 @@ def bn_relu_apply(z, save, out=None):
     return out
 
 
-def bn_relu_bwd(da, z, save, training, need_affine_grads=True, out=None, acc=None):
+def bn_relu_bwd(da, z, save, training, need_affine_grads=True, out=None, acc=None, affine_out=None):
     """-> dz, dgamma, dbeta.  `out`: plane-contiguous destination for dz (a batch slice of a larger buffer);
-    `acc` = (dgamma, dbeta) of another statistics group of the same layer to accumulate into."""
+    `acc` = (dgamma, dbeta) of another statistics group of the same layer to accumulate into; `affine_out` =
+    (dgamma, dbeta) destinations to overwrite (None entries are allocated)."""
     da, dabs = plane(da)
     z, zbs = plane(z)
     B, C, H, W = z.shape
@@ -378,8 +391,9 @@ def bn_relu_bwd(da, z, save, training, need_affine_grads=True, out=None, acc=Non
         part2 = torch.empty((nparts, C, 4), dtype=F32, device=dev)
         _lib.call("onet_bn_relu_bwd_reduce", _p(da), dabs, _p(z), zbs, _p(save), _p(part2), nparts, B, C, HW, _stream())
         if acc is None:
-            dgamma = torch.empty(C, dtype=F32, device=dev)
-            dbeta = torch.empty(C, dtype=F32, device=dev)
+            og, ob = affine_out if affine_out is not None else (None, None)
+            dgamma = torch.empty(C, dtype=F32, device=dev) if og is None else og
+            dbeta = torch.empty(C, dtype=F32, device=dev) if ob is None else ob
         else:
             dgamma, dbeta = acc
         accf = 0 if acc is None else 1
@@ -466,14 +480,14 @@ def convT2x2_dgrad(dy, wp_dgrad, Cin, h, w, pt, pl):
     return dx
 
 
-def convT2x2_wgrad(x, dy, dw_shape, pt, pl, want_dbias):
+def convT2x2_wgrad(x, dy, dw_shape, pt, pl, want_dbias, out=None, db_out=None):
     """(dW [Cin, Ct, 2, 2], dbias | None) of ConvTranspose2d(k=2, s=2) from x1 and the concat-gradient window."""
     require_gpu(x, dy)
     x, xbs = plane(x)
     dy, dybs = plane(dy)
     B, Cin, h, w = x.shape
     Ct, Ho, Wo = dy.shape[1], dy.shape[2], dy.shape[3]
-    dw = torch.empty(dw_shape, dtype=F32, device=x.device)
+    dw = torch.empty(dw_shape, dtype=F32, device=x.device) if out is None else out
     need = _lib.load().onet_conv_wgrad_ws_bytes(B, Cin, 4 * Ct, h, w, 1)
     ws = workspace(need, x.device)
     e0 = _prof_begin()
@@ -482,7 +496,7 @@ def convT2x2_wgrad(x, dy, dw_shape, pt, pl, want_dbias):
     _prof_end("conv_wgrad_kernel", 2.0 * B * h * w * Cin * 4 * Ct, e0)
     db = None
     if want_dbias:
-        db = torch.empty(Ct, dtype=F32, device=x.device)
+        db = torch.empty(Ct, dtype=F32, device=x.device) if db_out is None else db_out
         scratch = torch.empty(B * Ct, dtype=torch.float64, device=x.device)
         _lib.call("onet_convT2x2_dbias", _p(dy), dybs, _p(db), _p(scratch), 0, B, Ct, h, w, Ho, Wo, pt, pl, _stream())
     return dw, db

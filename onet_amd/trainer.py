@@ -71,6 +71,9 @@ class FlatAdam:
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.gflat[off:off + p.numel()].view_as(p)
+                # backward kernels may write this slice directly (ops.grad_slot_if_free) when .grad is None
+                p._onet_gslot = (self.gflat, off, p.numel(), tuple(p.shape))
+        self.direct_grads = bool(self.gflat.is_cuda)
         invalidate_packed(model)
         self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)]
         self.step_count = 0
@@ -131,9 +134,15 @@ class FlatAdam:
             ops.fill(self.gflat, 0.0)
         else:                       # host-side tests of the flat-buffer / all-reduce plumbing only
             self.gflat.zero_()
-        for p, off in zip(self.params, self.offsets):   # re-attach if someone set .grad = None
-            if p.grad is None or p.grad.data_ptr() != self.gflat.data_ptr() + 4 * off:
-                p.grad = self.gflat[off:off + p.numel()].view_as(p)
+        if self.direct_grads:
+            # .grad = None: the first gradient of a parameter is WRITTEN into its slice of the (zeroed) flat buffer by
+            # the producing kernel and adopted by autograd as-is; a second one (two-pass mode) is added by autograd
+            for p in self.params:
+                p.grad = None
+        else:
+            for p, off in zip(self.params, self.offsets):   # re-attach if someone set .grad = None
+                if p.grad is None or p.grad.data_ptr() != self.gflat.data_ptr() + 4 * off:
+                    p.grad = self.gflat[off:off + p.numel()].view_as(p)
         if self._buckets is not None:
             for bk in self._buckets:
                 bk.update(pending=len(bk["params"]), work=None, launched=False)
