@@ -198,6 +198,16 @@ int onet_head_softmax_bwd(const float* dVt, const float* dVd, const float* dS, c
                           const float* Ld, int64_t Ld_bs, const float* Hd, int64_t Hd_bs,
                           float* dLt, float* dHt, float* dLd, float* dHd,
                           int B, int C, int HW, void* stream);
+/* The same head with the per-pixel channel sums sL = sum_c L[c] as a by-product (sLt, sLd: [B][HW]) -- the only thing
+ * jensen_shannon_divergence (OV:221-235) needs of L -- and, in backward, with their gradients gsLt / gsLd (NULL = 0)
+ * folded into dLt / dLd, so that the loss neither re-reads L nor costs a full-tensor gradient add. */
+int onet_head_softmax_sums_fwd(const float* Lt, int64_t Lt_bs, const float* Ht, int64_t Ht_bs, const float* Ld,
+                               int64_t Ld_bs, const float* Hd, int64_t Hd_bs, float* Vt, float* Vd, float* S,
+                               float* sLt, float* sLd, int B, int C, int HW, void* stream);
+int onet_head_softmax_sums_bwd(const float* dVt, const float* dVd, const float* dS, const float* gsLt, const float* gsLd,
+                               const float* S, const float* Lt, int64_t Lt_bs, const float* Ht, int64_t Ht_bs,
+                               const float* Ld, int64_t Ld_bs, const float* Hd, int64_t Hd_bs, float* dLt, float* dHt,
+                               float* dLd, float* dHd, int B, int C, int HW, void* stream);
 
 /* ---- K10: JSD loss with the reference's log1pexp quirk (OV:221-267) ---------- */
 /* One jsd term, Onet.jensen_shannon_divergence(Li, Si, Sprime) (OV:221-235):
@@ -206,6 +216,7 @@ int onet_head_softmax_bwd(const float* dVt, const float* dVd, const float* dS, c
  * Si/Sp: [B][HW] with batch stride (slices of S).  sums [B*HW] saves sL for backward;
  * part: >= onet_jsd_nparts() doubles of scratch; jsd: 1 float.
  * compute_loss (OV:253-267) = -(jsd(Lt,St,Sd) + jsd(Ld,Sd,St)) / 2 is composed by the caller. */
+/* (L may be NULL: `sums` is then an INPUT, the channel sums from onet_head_softmax_sums_fwd) */
 int onet_jsd_fwd(const float* L, int64_t L_bs, const float* Si, int64_t Si_bs,
                  const float* Sp, int64_t Sp_bs, float* sums, double* part, float* jsd,
                  int B, int C, int HW, void* stream);

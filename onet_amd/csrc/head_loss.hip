@@ -42,7 +42,8 @@ __global__ __launch_bounds__(256) void head_softmax_fwd_kernel(const float* __re
                                                                const float* __restrict__ Ld, int64_t Ld_bs,
                                                                const float* __restrict__ Hd, int64_t Hd_bs,
                                                                float* __restrict__ Vt, float* __restrict__ Vd,
-                                                               float* __restrict__ S, int B, int C, int HW) {
+                                                               float* __restrict__ S, float* __restrict__ sLt,
+                                                               float* __restrict__ sLd, int B, int C, int HW) {
     const int64_t n = (int64_t)B * HW;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int b = (int)(i / HW);
@@ -51,13 +52,18 @@ __global__ __launch_bounds__(256) void head_softmax_fwd_kernel(const float* __re
         const float* ht = Ht + b * Ht_bs + p;
         const float* ld = Ld + b * Ld_bs + p;
         const float* hd = Hd + b * Hd_bs + p;
-        float vt = 0.f, vd = 0.f;
+        float vt = 0.f, vd = 0.f, st_ = 0.f, sd_ = 0.f;   // st_/sd_: sum_c L[c] in jsd_fwd_kernel's order (bit-identical)
         for (int c = 0; c < C; ++c) {
-            vt = fmaf(lt[(int64_t)c * HW], ht[(int64_t)c * HW], vt);
-            vd = fmaf(ld[(int64_t)c * HW], hd[(int64_t)c * HW], vd);
+            const float a = lt[(int64_t)c * HW], d = ld[(int64_t)c * HW];
+            vt = fmaf(a, ht[(int64_t)c * HW], vt);
+            vd = fmaf(d, hd[(int64_t)c * HW], vd);
+            st_ += a;
+            sd_ += d;
         }
         Vt[i] = vt;
         Vd[i] = vd;
+        if (sLt) sLt[i] = st_;
+        if (sLd) sLd[i] = sd_;
         const float m = fmaxf(vt, vd);
         const float et = expf(vt - m), ed = expf(vd - m);
         const float den = et + ed;
@@ -70,8 +76,8 @@ __global__ __launch_bounds__(256) void head_softmax_bwd_kernel(
     const float* __restrict__ dVt, const float* __restrict__ dVd, const float* __restrict__ dS,
     const float* __restrict__ S, const float* __restrict__ Lt, int64_t Lt_bs, const float* __restrict__ Ht,
     int64_t Ht_bs, const float* __restrict__ Ld, int64_t Ld_bs, const float* __restrict__ Hd, int64_t Hd_bs,
-    float* __restrict__ dLt, float* __restrict__ dHt, float* __restrict__ dLd, float* __restrict__ dHd, int B, int C,
-    int HW) {
+    float* __restrict__ dLt, float* __restrict__ dHt, float* __restrict__ dLd, float* __restrict__ dHd,
+    const float* __restrict__ gsLt, const float* __restrict__ gsLd, int B, int C, int HW) {
     const int64_t n = (int64_t)B * HW;
     const int64_t CHW = (int64_t)C * HW;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -96,11 +102,12 @@ __global__ __launch_bounds__(256) void head_softmax_bwd_kernel(
         float* oht = dHt + b * CHW + p;
         float* old_ = dLd + b * CHW + p;
         float* ohd = dHd + b * CHW + p;
+        const float at = gsLt ? gsLt[i] : 0.f, ad = gsLd ? gsLd[i] : 0.f;   // d loss / d (sum_c L[c]): same for every channel
         for (int c = 0; c < C; ++c) {
             const int64_t o = (int64_t)c * HW;
-            olt[o] = gt * ht[o];
+            olt[o] = fmaf(gt, ht[o], at);
             oht[o] = gt * lt[o];
-            old_[o] = gd * hd[o];
+            old_[o] = fmaf(gd, hd[o], ad);
             ohd[o] = gd * ld[o];
         }
     }
@@ -120,10 +127,15 @@ __global__ __launch_bounds__(256) void jsd_fwd_kernel(const float* __restrict__ 
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int b = (int)(i / HW);
         const int p = (int)(i % HW);
-        const float* l = L + b * L_bs + p;
-        float sl = 0.f;
-        for (int c = 0; c < C; ++c) sl += l[(int64_t)c * HW];
-        sums[i] = sl;
+        float sl;
+        if (L) {
+            const float* l = L + b * L_bs + p;
+            sl = 0.f;
+            for (int c = 0; c < C; ++c) sl += l[(int64_t)c * HW];
+            sums[i] = sl;
+        } else {
+            sl = sums[i];                  // channel sums handed over by onet_head_softmax_sums_fwd
+        }
         const float si = Si[b * Si_bs + p], sp = Sp[b * Sp_bs + p];
         acc[0] += (double)(f_quirk(-(sl * si)) + f_quirk(sl * sp));
     }
@@ -190,7 +202,16 @@ int onet_head_softmax_fwd(const float* Lt, int64_t Lt_bs, const float* Ht, int64
                           int C, int HW, void* stream) {
     ONET_REQUIRE(Lt && Ht && Ld && Hd && Vt && Vd && S && B > 0 && C > 0 && HW > 0, "head_softmax_fwd: bad args");
     hipLaunchKernelGGL(head_softmax_fwd_kernel, dim3(grid_px((int64_t)B * HW)), dim3(256), 0, as_stream(stream), Lt,
-                       Lt_bs, Ht, Ht_bs, Ld, Ld_bs, Hd, Hd_bs, Vt, Vd, S, B, C, HW);
+                       Lt_bs, Ht, Ht_bs, Ld, Ld_bs, Hd, Hd_bs, Vt, Vd, S, (float*)nullptr, (float*)nullptr, B, C, HW);
+    return check_launch("head_softmax_fwd_kernel");
+}
+
+int onet_head_softmax_sums_fwd(const float* Lt, int64_t Lt_bs, const float* Ht, int64_t Ht_bs, const float* Ld,
+                               int64_t Ld_bs, const float* Hd, int64_t Hd_bs, float* Vt, float* Vd, float* S,
+                               float* sLt, float* sLd, int B, int C, int HW, void* stream) {
+    ONET_REQUIRE(Lt && Ht && Ld && Hd && Vt && Vd && S && sLt && sLd && B > 0 && C > 0 && HW > 0, "head_softmax_sums_fwd: bad args");
+    hipLaunchKernelGGL(head_softmax_fwd_kernel, dim3(grid_px((int64_t)B * HW)), dim3(256), 0, as_stream(stream), Lt,
+                       Lt_bs, Ht, Ht_bs, Ld, Ld_bs, Hd, Hd_bs, Vt, Vd, S, sLt, sLd, B, C, HW);
     return check_launch("head_softmax_fwd_kernel");
 }
 
@@ -201,7 +222,19 @@ int onet_head_softmax_bwd(const float* dVt, const float* dVd, const float* dS, c
     ONET_REQUIRE(S && Lt && Ht && Ld && Hd && dLt && dHt && dLd && dHd && B > 0 && C > 0 && HW > 0,
                  "head_softmax_bwd: bad args");
     hipLaunchKernelGGL(head_softmax_bwd_kernel, dim3(grid_px((int64_t)B * HW)), dim3(256), 0, as_stream(stream), dVt,
-                       dVd, dS, S, Lt, Lt_bs, Ht, Ht_bs, Ld, Ld_bs, Hd, Hd_bs, dLt, dHt, dLd, dHd, B, C, HW);
+                       dVd, dS, S, Lt, Lt_bs, Ht, Ht_bs, Ld, Ld_bs, Hd, Hd_bs, dLt, dHt, dLd, dHd, (const float*)nullptr,
+                       (const float*)nullptr, B, C, HW);
+    return check_launch("head_softmax_bwd_kernel");
+}
+
+int onet_head_softmax_sums_bwd(const float* dVt, const float* dVd, const float* dS, const float* gsLt, const float* gsLd,
+                               const float* S, const float* Lt, int64_t Lt_bs, const float* Ht, int64_t Ht_bs,
+                               const float* Ld, int64_t Ld_bs, const float* Hd, int64_t Hd_bs, float* dLt, float* dHt,
+                               float* dLd, float* dHd, int B, int C, int HW, void* stream) {
+    ONET_REQUIRE(S && Lt && Ht && Ld && Hd && dLt && dHt && dLd && dHd && B > 0 && C > 0 && HW > 0,
+                 "head_softmax_sums_bwd: bad args");
+    hipLaunchKernelGGL(head_softmax_bwd_kernel, dim3(grid_px((int64_t)B * HW)), dim3(256), 0, as_stream(stream), dVt,
+                       dVd, dS, S, Lt, Lt_bs, Ht, Ht_bs, Ld, Ld_bs, Hd, Hd_bs, dLt, dHt, dLd, dHd, gsLt, gsLd, B, C, HW);
     return check_launch("head_softmax_bwd_kernel");
 }
 
@@ -209,7 +242,7 @@ int onet_jsd_nparts(void) { return JSD_BLOCKS; }
 
 int onet_jsd_fwd(const float* L, int64_t L_bs, const float* Si, int64_t Si_bs, const float* Sp, int64_t Sp_bs,
                  float* sums, double* part, float* jsd, int B, int C, int HW, void* stream) {
-    ONET_REQUIRE(L && Si && Sp && sums && part && jsd && B > 0 && C > 0 && HW > 0, "jsd_fwd: bad args");
+    ONET_REQUIRE(Si && Sp && sums && part && jsd && B > 0 && C > 0 && HW > 0, "jsd_fwd: bad args");
     const int64_t n = (int64_t)B * HW;
     int blocks = (int)std::min<int64_t>((n + 255) / 256, JSD_BLOCKS);
     hipLaunchKernelGGL(jsd_fwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), L, L_bs, Si, Si_bs, Sp, Sp_bs,

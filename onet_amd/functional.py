@@ -284,46 +284,44 @@ class TwinSplitFn(torch.autograd.Function):
 
 
 class HeadSoftmaxTwinFn(torch.autograd.Function):
-    """HeadSoftmaxFn on the twin batch: L = [Lt ; Ld], H = [Ht ; Hd] (each [2B, 64, H, W])."""
+    """HeadSoftmaxFn on the twin batch: L = [Lt ; Ld], H = [Ht ; Hd] (each [2B, 64, H, W]).  Also returns the per-pixel
+    channel sums of Lt and Ld -- all the loss needs of L (OV:231-232: the einsum with a 1-channel S is S * sum_c L) --
+    so that compute_loss works on [B,1,H,W] tensors and its gradient re-enters here as two small maps."""
 
     @staticmethod
     def forward(ctx, L, H):
         B = L.shape[0] // 2
-        Vt, Vd, S = ops.head_softmax_fwd(L[:B], H[:B], L[B:], H[B:])
+        Vt, Vd, S, sLt, sLd = ops.head_softmax_fwd(L[:B], H[:B], L[B:], H[B:], want_sums=True)
         ctx.save_for_backward(L, H, S)
-        return Vt, Vd, S
+        return Vt, Vd, S, sLt, sLd
 
     @staticmethod
-    def backward(ctx, dVt, dVd, dS):
+    def backward(ctx, dVt, dVd, dS, gsLt, gsLd):
         L, H, S = ctx.saved_tensors
         B = L.shape[0] // 2
-        dL, dH = ops.head_softmax_bwd(dVt, dVd, dS, S, L[:B], H[:B], L[B:], H[B:], twin=True)
+        dL, dH = ops.head_softmax_bwd(dVt, dVd, dS, S, L[:B], H[:B], L[B:], H[B:], twin=True, gsums=(gsLt, gsLd))
         return dL, dH
 
 
-class JSDTwinFn(torch.autograd.Function):
-    """(jsd(Lt, St, Sd), jsd(Ld, Sd, St)) of Onet.compute_loss (OV:253-267) with L = [Lt ; Ld] the twin batch: the two
-    channel-constant gradients come back as ONE stride-0 view over the full tensor."""
+class JSDSumsFn(torch.autograd.Function):
+    """(jsd(Lt, St, Sd), jsd(Ld, Sd, St)) of Onet.compute_loss (OV:253-267) from the channel sums sLt, sLd."""
 
     @staticmethod
-    def forward(ctx, L, St, Sd):
-        B = L.shape[0] // 2
-        top, s_top = ops.jsd_fwd(L[:B], St, Sd)
-        dwn, s_dwn = ops.jsd_fwd(L[B:], Sd, St)
-        ctx.save_for_backward(s_top, s_dwn, St, Sd)
-        ctx.shape = tuple(L.shape)
+    def forward(ctx, sLt, sLd, St, Sd):
+        top, _ = ops.jsd_fwd(None, St, Sd, sums=sLt)
+        dwn, _ = ops.jsd_fwd(None, Sd, St, sums=sLd)
+        ctx.save_for_backward(sLt, sLd, St, Sd)
         return top, dwn
 
     @staticmethod
     def backward(ctx, g_top, g_dwn):
-        s_top, s_dwn, St, Sd = ctx.saved_tensors
-        B2, C, H, W = ctx.shape
-        half = (B2 // 2, C, H, W)
+        sLt, sLd, St, Sd = ctx.saved_tensors
+        B, _, H, W = sLt.shape
+        half = (B, 1, H, W)
         zero = torch.zeros((), dtype=torch.float32, device=St.device)
-        gLt, dSt_a, dSd_a = ops.jsd_bwd(zero if g_top is None else g_top, s_top, St, Sd, half)
-        gLd, dSd_b, dSt_b = ops.jsd_bwd(zero if g_dwn is None else g_dwn, s_dwn, Sd, St, half)
-        gL = torch.cat([gLt, gLd], 0)                     # [2B, 1, H, W]
-        return gL.expand(ctx.shape), dSt_a + dSt_b, dSd_a + dSd_b
+        gLt, dSt_a, dSd_a = ops.jsd_bwd(zero if g_top is None else g_top, sLt.contiguous().view(-1), St, Sd, half)
+        gLd, dSd_b, dSt_b = ops.jsd_bwd(zero if g_dwn is None else g_dwn, sLd.contiguous().view(-1), Sd, St, half)
+        return gLt, gLd, dSt_a + dSt_b, dSd_a + dSd_b
 
 
 class JSDFn(torch.autograd.Function):

@@ -299,9 +299,9 @@ class Onet(nn.Module):
             # split-K reduction instead of two plus autograd's add.
             XX = Fn.TwinInputFn.apply(X, float(self.bias))
             L, H = self.topu(XX, groups=2)
-            Vt, Vd, S = Fn.HeadSoftmaxTwinFn.apply(L, H)
+            Vt, Vd, S, sLt, sLd = Fn.HeadSoftmaxTwinFn.apply(L, H)
             Lt, Ld = Fn.TwinSplitFn.apply(L)
-            Lt._onet_twin = Ld._onet_twin = L          # compute_loss differentiates the full tensor directly
+            Lt._onet_twin = Ld._onet_twin = (L, sLt, sLd)     # compute_loss works on the channel sums of L
             return Lt, Vt, Ld, Vd, S
         Lt, Ht = self.topu(X)
         Xd = Fn.ComplementClipFn.apply(X, float(self.bias))
@@ -331,14 +331,15 @@ class Onet(nn.Module):
         return Fn.Log1pExpFn.apply(x)
 
     def compute_loss(self, Lt, St, Ld, Sd):
-        full = getattr(Lt, "_onet_twin", None)
-        if (full is not None and full is getattr(Ld, "_onet_twin", None) and full.shape[0] == 2 * Lt.shape[0]
+        twin = getattr(Lt, "_onet_twin", None)
+        if (twin is not None and twin is getattr(Ld, "_onet_twin", None) and twin[0].shape[0] == 2 * Lt.shape[0]
                 and type(self).jensen_shannon_divergence is Onet.jensen_shannon_divergence
                 and "jensen_shannon_divergence" not in self.__dict__):
-            # Lt / Ld are the halves of this module's own twin batch: both JSD terms on the full tensor, so that
-            # its gradient is ONE add (head + loss) instead of two half-tensor adds and a re-assembly copy
+            # Lt / Ld are the halves of this module's own twin batch: the JSD terms only need sum_c L, which the head
+            # kernel already produced; their gradient flows back INTO the head's backward kernel as two [B,1,H,W]
+            # maps (no second read of L, no full-tensor gradient add)
             assert (Lt.dim() == 4 and St.dim() == 4 and Sd.dim() == 4)
-            jsd_top, jsd_dwn = Fn.JSDTwinFn.apply(full, St, Sd)
+            jsd_top, jsd_dwn = Fn.JSDSumsFn.apply(twin[1], twin[2], St, Sd)
             if self.check_finite:
                 assert (torch.isnan(jsd_top) == False)  # noqa: E712  (mirrors OV:234)
                 assert (torch.isnan(jsd_dwn) == False)  # noqa: E712

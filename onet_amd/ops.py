@@ -535,7 +535,8 @@ def fill(t, value):
 
 
 # ----------------------------------------------------------------------------- head / loss
-def head_softmax_fwd(Lt, Ht, Ld, Hd):
+def head_softmax_fwd(Lt, Ht, Ld, Hd, want_sums=False):
+    """-> Vt, Vd, S  (+ sLt, sLd = per-pixel channel sums of Lt / Ld, [B,1,H,W], when want_sums)."""
     require_gpu(Lt, Ht, Ld, Hd)
     Lt, a = plane(Lt)
     Ht, b = plane(Ht)
@@ -546,13 +547,20 @@ def head_softmax_fwd(Lt, Ht, Ld, Hd):
     Vt = torch.empty((B, 1, H, W), dtype=F32, device=dev)
     Vd = torch.empty((B, 1, H, W), dtype=F32, device=dev)
     S = torch.empty((B, 2, H, W), dtype=F32, device=dev)
+    if want_sums:
+        sLt = torch.empty((B, 1, H, W), dtype=F32, device=dev)
+        sLd = torch.empty((B, 1, H, W), dtype=F32, device=dev)
+        _lib.call("onet_head_softmax_sums_fwd", _p(Lt), a, _p(Ht), b, _p(Ld), c, _p(Hd), d, _p(Vt), _p(Vd), _p(S),
+                  _p(sLt), _p(sLd), B, C, H * W, _stream())
+        return Vt, Vd, S, sLt, sLd
     _lib.call("onet_head_softmax_fwd", _p(Lt), a, _p(Ht), b, _p(Ld), c, _p(Hd), d, _p(Vt), _p(Vd), _p(S), B, C,
               H * W, _stream())
     return Vt, Vd, S
 
 
-def head_softmax_bwd(dVt, dVd, dS, S, Lt, Ht, Ld, Hd, twin=False):
-    """-> dLt, dHt, dLd, dHd; twin=True: -> (dL, dH) of shape [2B, C, H, W], the top and down halves adjacent."""
+def head_softmax_bwd(dVt, dVd, dS, S, Lt, Ht, Ld, Hd, twin=False, gsums=(None, None)):
+    """-> dLt, dHt, dLd, dHd; twin=True: -> (dL, dH) of shape [2B, C, H, W], the top and down halves adjacent.
+    gsums = (d loss / d sLt, d loss / d sLd), [B,1,H,W] each or None: added to every channel of dLt / dLd."""
     Lt, a = plane(Lt)
     Ht, b = plane(Ht)
     Ld, c = plane(Ld)
@@ -568,8 +576,10 @@ def head_softmax_bwd(dVt, dVd, dS, S, Lt, Ht, Ld, Hd, twin=False):
         outs = [dL[:B], dH[:B], dL[B:], dH[B:]]
     else:
         outs = [torch.empty((B, C, H, W), dtype=F32, device=dev) for _ in range(4)]
-    _lib.call("onet_head_softmax_bwd", _p(dVt), _p(dVd), _p(dS), _p(S), _p(Lt), a, _p(Ht), b, _p(Ld), c, _p(Hd), d,
-              _p(outs[0]), _p(outs[1]), _p(outs[2]), _p(outs[3]), B, C, H * W, _stream())
+    gst = None if gsums[0] is None else gsums[0].contiguous()
+    gsd = None if gsums[1] is None else gsums[1].contiguous()
+    _lib.call("onet_head_softmax_sums_bwd", _p(dVt), _p(dVd), _p(dS), _p(gst), _p(gsd), _p(S), _p(Lt), a, _p(Ht), b,
+              _p(Ld), c, _p(Hd), d, _p(outs[0]), _p(outs[1]), _p(outs[2]), _p(outs[3]), B, C, H * W, _stream())
     return (dL, dH) if twin else outs
 
 
@@ -583,14 +593,22 @@ def _rows(t):
     return t, (t.stride(0) if B > 1 else H * W)
 
 
-def jsd_fwd(L, Si, Sp):
-    require_gpu(L, Si, Sp)
-    L, lbs = plane(L)
+def jsd_fwd(L, Si, Sp, sums=None):
+    """one jsd term; `sums` given ([B,1,H,W] contiguous channel sums from the head kernel): L is not read (may be None)."""
+    require_gpu(Si, Sp)
     Si, ibs = _rows(Si)
     Sp, pbs = _rows(Sp)
-    B, C, H, W = L.shape
-    dev = L.device
-    sums = torch.empty(B * H * W, dtype=F32, device=dev)
+    if sums is not None:
+        B, _, H, W = sums.shape
+        C, lbs, L = 1, 0, None
+        dev = sums.device
+        sums = sums.contiguous()
+    else:
+        require_gpu(L)
+        L, lbs = plane(L)
+        B, C, H, W = L.shape
+        dev = L.device
+        sums = torch.empty(B * H * W, dtype=F32, device=dev)
     part = torch.empty(_lib.load().onet_jsd_nparts(), dtype=torch.float64, device=dev)
     out = torch.empty((), dtype=F32, device=dev)
     _lib.call("onet_jsd_fwd", _p(L), lbs, _p(Si), ibs, _p(Sp), pbs, _p(sums), _p(part), _p(out), B, C, H * W,
