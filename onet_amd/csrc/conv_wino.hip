@@ -689,82 +689,101 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(WwArgs a) {
             if (e < 64 * XR * 2) x_lds[c * XS + (q >> 1) * XC + ((q & 1) ? XC - 1 : 0)] = xhv[j];
         }
     };
-    // one K-step = one pair of tiles (lane parity kh picks the tile): 2+3 LDS reads, 22 adds, 8 MFMAs
-    auto steps = [&](auto phc, auto bufc, auto sb, auto se) __attribute__((always_inline)) {
-        constexpr int PH = decltype(phc)::value, BUF = decltype(bufc)::value;
-        constexpr int S0 = decltype(sb)::value, S1 = decltype(se)::value;
-        const float* zp = smem + BUF * C::BUF_FLOATS + a_idx;
-        const float* xp = smem + BUF * C::BUF_FLOATS + b_idx;
-#pragma unroll
-        for (int st = S0; st < S1; ++st) {
-            const int trow = (2 * st) / TCS, tcol2 = ((2 * st) % TCS) * 2;   // tile 2*st (+kh via the lane base)
-            const float2 y0v = *reinterpret_cast<const float2*>(zp + (2 * trow) * PW + tcol2);
-            const float2 y1v = *reinterpret_cast<const float2*>(zp + (2 * trow + 1) * PW + tcol2);
-            float d[3][4];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const float2 lo = *reinterpret_cast<const float2*>(xp + (2 * trow + i) * XC + tcol2);
-                const float2 hi = *reinterpret_cast<const float2*>(xp + (2 * trow + i) * XC + tcol2 + 2);
-                d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
-            }
-            // Z rows xi = 2PH, 2PH+1 of A dY A^T
-            float zr[2][2], z[8];
-            if constexpr (PH == 0) {
-                zr[0][0] = y0v.x; zr[0][1] = y0v.y;
-                zr[1][0] = y0v.x + y1v.x; zr[1][1] = y0v.y + y1v.y;
-            } else {
-                zr[0][0] = y0v.x - y1v.x; zr[0][1] = y0v.y - y1v.y;
-                zr[1][0] = -y1v.x; zr[1][1] = -y1v.y;
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                z[i * 4 + 0] = zr[i][0];
-                z[i * 4 + 1] = zr[i][0] + zr[i][1];
-                z[i * 4 + 2] = zr[i][0] - zr[i][1];
-                z[i * 4 + 3] = -zr[i][1];
-            }
-            // U rows xi = 2PH, 2PH+1 of B^T d B (d[] holds patch rows PH..PH+2)
-            float t[2][4], u[8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if constexpr (PH == 0) {
-                    t[0][j] = d[0][j] - d[2][j];
-                    t[1][j] = d[1][j] + d[2][j];
-                } else {
-                    t[0][j] = d[1][j] - d[0][j];
-                    t[1][j] = d[0][j] - d[2][j];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                u[i * 4 + 0] = t[i][0] - t[i][2];
-                u[i * 4 + 1] = t[i][1] + t[i][2];
-                u[i * 4 + 2] = t[i][2] - t[i][1];
-                u[i * 4 + 3] = t[i][1] - t[i][3];
-            }
-#pragma unroll
-            for (int p = 0; p < 8; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(z[p], u[p], acc[p], 0, 0, 0);
-        }
-    };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    using S0 = std::integral_constant<int, 0>;
-    using S4 = std::integral_constant<int, 4>;
-    using S8 = std::integral_constant<int, 8>;
+    // Register-level software pipeline across K-steps AND units (same idea as conv_wino_kernel): the operands of
+    // step s+1 are read from LDS and transformed under the MFMAs of step s; the unit barrier sits in the
+    // second-to-last step (by then every wave holds the unit's last operands in registers), so the first step of
+    // the next unit never waits for LDS behind a barrier.  Timing-only ablation without the barrier: +6.6 %.
+    float zC[8], uC[8];
+    auto operands = [&](auto phc, auto bufc, auto stc, float (&z)[8], float (&u)[8]) __attribute__((always_inline)) {
+        constexpr int PH = decltype(phc)::value, BUF = decltype(bufc)::value, st = decltype(stc)::value;
+        const float* zp = smem + BUF * C::BUF_FLOATS + a_idx;
+        const float* xp = smem + BUF * C::BUF_FLOATS + b_idx;
+        constexpr int trow = (2 * st) / TCS, tcol2 = ((2 * st) % TCS) * 2;   // tile 2*st (+kh via the lane base)
+        const float2 y0v = *reinterpret_cast<const float2*>(zp + (2 * trow) * PW + tcol2);
+        const float2 y1v = *reinterpret_cast<const float2*>(zp + (2 * trow + 1) * PW + tcol2);
+        float d[3][4];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float2 lo = *reinterpret_cast<const float2*>(xp + (2 * trow + i) * XC + tcol2);
+            const float2 hi = *reinterpret_cast<const float2*>(xp + (2 * trow + i) * XC + tcol2 + 2);
+            d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
+        }
+        float zr[2][2];
+        if constexpr (PH == 0) {
+            zr[0][0] = y0v.x; zr[0][1] = y0v.y;
+            zr[1][0] = y0v.x + y1v.x; zr[1][1] = y0v.y + y1v.y;
+        } else {
+            zr[0][0] = y0v.x - y1v.x; zr[0][1] = y0v.y - y1v.y;
+            zr[1][0] = -y1v.x; zr[1][1] = -y1v.y;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            z[i * 4 + 0] = zr[i][0];
+            z[i * 4 + 1] = zr[i][0] + zr[i][1];
+            z[i * 4 + 2] = zr[i][0] - zr[i][1];
+            z[i * 4 + 3] = -zr[i][1];
+        }
+        float t[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (PH == 0) {
+                t[0][j] = d[0][j] - d[2][j];
+                t[1][j] = d[1][j] + d[2][j];
+            } else {
+                t[0][j] = d[1][j] - d[0][j];
+                t[1][j] = d[0][j] - d[2][j];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            u[i * 4 + 0] = t[i][0] - t[i][2];
+            u[i * 4 + 1] = t[i][1] + t[i][2];
+            u[i * 4 + 2] = t[i][2] - t[i][1];
+            u[i * 4 + 3] = t[i][1] - t[i][3];
+        }
+    };
     int unext = ks;
+    // MODE 0 plain; 1: commit the staged unit after the MFMAs (mid-unit); 2: barrier after the next operands are in
+    auto wstep = [&](auto phc, auto nbufc, auto nstc, auto modec, auto curbufc) __attribute__((always_inline)) {
+        constexpr int MODE = decltype(modec)::value, CUR = decltype(curbufc)::value;
+        float zN[8], uN[8];
+        __builtin_amdgcn_sched_barrier(0);
+        operands(phc, nbufc, nstc, zN, uN);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(zC[p], uC[p], acc[p], 0, 0, 0);
+        // pin the order: the five LDS reads first, then the 22 transform adds spread under the MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MODE == 1) commit(smem + (CUR ^ 1) * C::BUF_FLOATS);
+        if constexpr (MODE == 2) __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 8; ++p) { zC[p] = zN[p]; uC[p] = uN[p]; }
+    };
     auto stage = [&](auto phc, auto bufc) __attribute__((always_inline)) {
         constexpr int BUF = decltype(bufc)::value;
+        using BC = std::integral_constant<int, BUF>;
+        using BN = std::integral_constant<int, BUF ^ 1>;
+        using P = std::integral_constant<int, 0>;
         unext += a.splitK;
         issue(unext);
-        __builtin_amdgcn_sched_barrier(0);
-        steps(phc, bufc, S0{}, S4{});
-        __builtin_amdgcn_sched_barrier(0);
-        commit(smem + (BUF ^ 1) * C::BUF_FLOATS);
-        __builtin_amdgcn_sched_barrier(0);
-        steps(phc, bufc, S4{}, S8{});
-        __syncthreads();
+        wstep(phc, BC{}, std::integral_constant<int, 1>{}, P{}, BC{});
+        wstep(phc, BC{}, std::integral_constant<int, 2>{}, P{}, BC{});
+        wstep(phc, BC{}, std::integral_constant<int, 3>{}, P{}, BC{});
+        wstep(phc, BC{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{}, BC{});   // commit unit u+1
+        wstep(phc, BC{}, std::integral_constant<int, 5>{}, P{}, BC{});
+        wstep(phc, BC{}, std::integral_constant<int, 6>{}, P{}, BC{});
+        wstep(phc, BC{}, std::integral_constant<int, 7>{}, std::integral_constant<int, 2>{}, BC{});   // barrier
+        wstep(phc, BN{}, std::integral_constant<int, 0>{}, P{}, BC{});
     };
     auto run = [&](auto phc) __attribute__((always_inline)) {
+        operands(phc, I0{}, I0{}, zC, uC);
         const int nst = (nunits - ks + a.splitK - 1) / a.splitK;
         int c = 0;
         for (; c + 2 <= nst; c += 2) {
