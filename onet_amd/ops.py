@@ -255,8 +255,11 @@ def grad_slot_if_free(param):
     view to autograd, which then adopts it as .grad without an accumulation kernel (62 + 72 tiny adds per step
     otherwise).  -> a fresh contiguous view, or None (no slot, or a gradient is already there: regular path)."""
     slot = getattr(param, "_onet_gslot", None)
-    if slot is None or param.grad is not None:
+    if slot is None or param.grad is not None or getattr(param, "_onet_gslot_taken", False):
         return None
+    # one taker per zero_grad: with shared weights used twice in a graph (two-pass mode) autograd sums the two
+    # contributions in its input buffer BEFORE .grad is set, so ".grad is None" alone would hand the slice out twice
+    param._onet_gslot_taken = True
     flat, off, n, shape = slot
     return flat[off:off + n].view(shape)
 

@@ -139,6 +139,7 @@ class FlatAdam:
             # the producing kernel and adopted by autograd as-is; a second one (two-pass mode) is added by autograd
             for p in self.params:
                 p.grad = None
+                p._onet_gslot_taken = False
         else:
             for p, off in zip(self.params, self.offsets):   # re-attach if someone set .grad = None
                 if p.grad is None or p.grad.data_ptr() != self.gflat.data_ptr() + 4 * off:

@@ -74,7 +74,7 @@ def _step(m, X):
 CASES = ["b2_c1_16", "b2_c1_32", "b2_c3_32", "b2_c1_40", "b3_c1_32", "b2_c1_32_noshare", "b2_c1_256"]
 
 
-@pytest.mark.parametrize("algo", ["auto", "winograd4", "auto-two-pass"])
+@pytest.mark.parametrize("algo", ["auto", "winograd4", "auto-two-pass", "winograd", "direct"])
 @pytest.mark.parametrize("tag", CASES)
 def test_train_step_vs_reference_golden(dev, tag, algo, monkeypatch):
     """algo "auto": the shape heuristic of ops.conv3x3_algo (small batches mostly land on F(2x2,3x3) and direct);
@@ -85,6 +85,8 @@ def test_train_step_vs_reference_golden(dev, tag, algo, monkeypatch):
             pytest.skip("two-pass mode is covered on three cases")
         monkeypatch.setattr(ops, "TWIN", False)
         algo = "auto"
+    if algo in ("winograd", "direct") and tag not in ("b2_c1_40", "b2_c1_256"):
+        pytest.skip("forced F(2x2,3x3) / direct kernels are covered on two cases")
     if algo == "winograd4" and tag not in ("b2_c1_40", "b2_c1_32_noshare", "b2_c1_256"):
         # F(4x4,3x3) rounds ~6x coarser than F(2x2,3x3) (2.7e-6 vs 4e-7 of the output scale per layer).  The
         # 16- and 32-pixel goldens are conditioned at 1e-2 already (BatchNorm over 2..8 values per channel);
@@ -151,9 +153,14 @@ def test_eval_mode_vs_reference_golden(dev):
     assert all(int(b) == 0 for n, b in m.named_buffers() if n.endswith("num_batches_tracked"))
 
 
-@pytest.mark.parametrize("fused_adam", [False, True])
-def test_adam_loss_sequence_vs_reference_golden(dev, fused_adam):
-    """Harness contract: 4 x (zero_grad, fwd, loss, bwd, Adam lr 5e-6)."""
+@pytest.mark.parametrize("fused_adam", [False, True, "two-pass"])
+def test_adam_loss_sequence_vs_reference_golden(dev, fused_adam, monkeypatch):
+    """Harness contract: 4 x (zero_grad, fwd, loss, bwd, Adam lr 5e-6).  "two-pass": the fused flat
+    Adam with ONET_TWIN=0 -- the first pass's gradients are written into the flat buffer by the kernels, the second
+    pass's are added by autograd."""
+    if fused_adam == "two-pass":
+        from onet_amd import ops
+        monkeypatch.setattr(ops, "TWIN", False)
     g = np.load(os.path.join(G, "onet_b2_c1_32_adam4.npz"))
     B, C, H, W, bshare, train, steps = [int(v) for v in g["meta"]]
     m = _model(C, True, dev)
