@@ -143,13 +143,19 @@ def main():
         algo = {"conv_wino_kernel": "Winograd F(2x2,3x3) on fp32 MFMA: achieved = direct-convolution FLOPs / time "
                                     "(the kernel issues 2.25x fewer MFMA FLOPs, so frac can exceed the MFMA busy fraction)",
                 "conv_wino4_kernel": "Winograd F(4x4,3x3) on fp32 MFMA: achieved = direct-convolution FLOPs / time "
-                                     "(the kernel issues 4x fewer MFMA FLOPs, so frac can exceed 1)",
+                                     "(the kernel issues 4x fewer MFMA FLOPs, so frac can exceed 1; hardware_frac = issued MFMA FLOPs / time / "
+                                     "peak, which the SQ_VALU_MFMA_BUSY_CYCLES profile under profiles/ confirms)",
                 "conv_wino_wgrad_kernel": "Winograd F(2x2,3x3) weight gradient on fp32 MFMA: achieved = direct-convolution "
                                           "FLOPs / time (2.25x fewer MFMA FLOPs issued)",
                 "conv_fwd_kernel": "direct implicit GEMM on fp32 MFMA", "conv_wgrad_kernel": "split-K MFMA wgrad"}
+        # multiplies the algorithm issues relative to direct convolution: F(4x4,3x3) 36 per 16 outputs x 9 taps -> 1/4,
+        # F(2x2,3x3) 16 per 4 x 9 -> 1/2.25
+        reduction = {"conv_wino4_kernel": 4.0, "conv_wino_kernel": 2.25, "conv_wino_wgrad_kernel": 2.25}.get(dom, 1.0)
         roofline = {"kernel": dom, "bound": "mfma", "achieved": kern[dom]["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4),
                     "traffic": pmc_traffic(dom), "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc, profiles/)",
+                    "mfma_flop_reduction": reduction,
+                    "hardware_frac": round(kern[dom]["tflops"] / reduction / FP32_MFMA_PEAK_TFLOPS, 4),
                     "launches_timed": kern[dom]["launches"], "avg_launch_ms": kern[dom]["avg_ms"], "algorithm": algo.get(dom, dom),
                     "all": kern}
         imgs = args.batch * world * args.steps
