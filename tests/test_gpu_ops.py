@@ -319,3 +319,36 @@ def test_cpu_tensor_is_refused():
     from onet_amd import Onet
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         Onet(1)(torch.zeros(2, 1, 16, 16))
+
+
+def test_conv_kernels_random_shapes_fuzz(dev):
+    """40 random layer shapes (ragged maps down to 1x1, odd batches, channel counts off the 32/64 tile grid) through all
+    four 3x3 kernels -- direct, F(2x2,3x3), F(4x4,3x3), and both weight-gradient kernels -- against the CPU convolution."""
+    from onet_amd import ops
+    rng = np.random.default_rng(20240606)
+    for it in range(40):
+        B = int(rng.integers(1, 6))
+        Cin = 4 * int(rng.integers(1, 41))
+        Cout = 4 * int(rng.integers(1, 41))
+        H = int(rng.integers(1, 71))
+        W = int(rng.integers(1, 71))
+        x = rnd(B, Cin, H, W, seed=1000 + it)
+        w = rnd(Cout, Cin, 3, 3, seed=2000 + it, scale=(2.0 / (Cin * 9)) ** 0.5)
+        g = rnd(B, Cout, H, W, seed=3000 + it)
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        zr = F.conv2d(xr, wr, None, 1, 1)
+        zr.backward(g)
+        xd, wd_, gd = x.to(dev), w.to(dev), g.to(dev)
+        tag = f"#{it} B{B} {Cin}->{Cout} {H}x{W}"
+        pf, pd = ops.pack3x3(wd_)
+        close(ops.conv_fwd(xd, pf, Cout, 3), zr, what="direct fwd " + tag)
+        close(ops.conv_fwd(gd, pd, Cin, 3), xr.grad, what="direct dgrad " + tag)
+        q2f, q2d = ops.pack3x3_winograd(wd_)
+        close(ops.conv3x3_winograd(xd, q2f, Cout), zr, what="F(2x2) fwd " + tag)
+        close(ops.conv3x3_winograd(gd, q2d, Cin), xr.grad, what="F(2x2) dgrad " + tag)
+        q4f, q4d = ops.pack3x3_winograd4(wd_)
+        close(ops.conv3x3_winograd4(xd, q4f, Cout), zr, what="F(4x4) fwd " + tag)
+        close(ops.conv3x3_winograd4(gd, q4d, Cin), xr.grad, what="F(4x4) dgrad " + tag)
+        close(ops.conv_wgrad(xd, gd, (Cout, Cin, 3, 3), 3), wr.grad, tol=3e-4, what="direct wgrad " + tag)
+        if Cin >= 16:
+            close(ops.conv3x3_winograd_wgrad(xd, gd, (Cout, Cin, 3, 3)), wr.grad, tol=3e-4, what="Winograd wgrad " + tag)
