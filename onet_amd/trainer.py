@@ -185,11 +185,12 @@ def init_distributed(backend: str | None = None):
     """-> (rank, world_size, local_rank).  Reads the torchrun environment; single process otherwise."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("ONET_FORCE_LOCAL_RANK", os.environ.get("LOCAL_RANK", "0")))
     # initialise whenever a launcher set RANK (also for world == 1: it exercises the RCCL path on one GPU)
     if "RANK" in os.environ and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        backend = os.environ.get("ONET_DIST_BACKEND", backend)     # rehearsal: N ranks sharing ONE GPU over gloo
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
