@@ -248,6 +248,12 @@ static __device__ __forceinline__ void wino4_body(const Wino4Args& a, float* sme
         for (int k = 0; k < NIN; ++k) xin[S][k] = bload(xr, in_off[k] + cin_bytes);
         cin_bytes += in_step;
     };
+    auto issue_in_range = [&](auto setc, int k0, int k1) __attribute__((always_inline)) {
+        constexpr int S = decltype(setc)::value;
+#pragma unroll
+        for (int k = 0; k < NIN; ++k)
+            if (k >= k0 && k < k1) xin[S][k] = bload(xr, in_off[k] + cin_bytes);
+    };
     // weight pieces k in [K0, K1) of the chunk at cw_bytes
     auto issue_w = [&](float* buf, int K0, int K1) __attribute__((always_inline)) {
 #pragma unroll
@@ -351,42 +357,62 @@ static __device__ __forceinline__ void wino4_body(const Wino4Args& a, float* sme
         __builtin_amdgcn_sched_barrier(0);
         lds_patch_wait(pt, d);
         __builtin_amdgcn_sched_barrier(0);
-        // R2: row pass of B^T (30 VALU) under MFMAs 3..5
+        // R2: row pass of B^T (30 VALU) under MFMAs 3..5 (step B: plus the input dwords of chunk c+3, spread likewise)
         xform_rows(d, t);
         mfma_range(3, 6);
+        if constexpr (MODE == 2) {
+            static_assert(NIN <= 6, "input dwords are spread over MFMAs 3..5, two each");
+            issue_in_range(std::integral_constant<int, CUR ^ 1>{}, 0, NIN);
+            cin_bytes += in_step;
+        }
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+            if constexpr (MODE == 2) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+        using SETN = std::integral_constant<int, CUR ^ 1>;   // MODE 1: inputs of chunk c+1; MODE 2: set (c+3)&1, freed in MODE 1
+        float* cur_buf = smem + CUR * C::BUF_FLOATS;
         if constexpr (MODE == 1) {
             lds_a(nbufc, ncpc, avn);      // MUST precede the barrier: the DMA issued after it overwrites these weights
             // chunk c lives in CUR; its last operands are in registers once the LDS counter drains (the
             // compiler's lgkmcnt(0) in front of s_barrier), so after the barrier CUR may be overwritten
-            using SETN = std::integral_constant<int, CUR ^ 1>;               // inputs of chunk c+1 sit in set (c+1)&1
             commit(SETN{}, smem + (CUR ^ 1) * C::BUF_FLOATS);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIN) : "memory");        // all but the youngest input set: the DMA of c+1 landed
             __syncthreads();
-            issue_w(smem + CUR * C::BUF_FLOATS, 0, 2);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (MODE == 2) {
-            issue_w(smem + CUR * C::BUF_FLOATS, 2, NWK);
-            cw_bytes += w_step;
-            using SETN = std::integral_constant<int, CUR ^ 1>;               // set (c+3)&1 == (c+1)&1, freed by the commit above
-            issue_in(SETN{});
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // R3: the A operands of step s+1 (nine b32 reads, issued first), column pass (18 VALU) under MFMAs 6..8
+        // R3: column pass (18 VALU) under MFMAs 6..8.  The staging VMEM instructions of chunk c+2 / c+3 go out ONE per
+        // MFMA (step A: the first two weight pieces; step B: the other three and the five input dwords): the eight
+        // waves of the block share one texture-address path, and a burst of 8 VMEM per wave parks every wave's next
+        // MFMA behind it.
         if constexpr (MODE != 1) lds_a(nbufc, ncpc, avn);
         xform_cols(t, un);
-        mfma_range(6, 9);
-        if constexpr (MODE != 1) __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+        if constexpr (MODE == 0) {
+            mfma_range(6, 9);
+            __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+            for (int q = 0; q < 3; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+            }
+        } else {
+            if constexpr (MODE == 2) __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                mfma_range(6 + q, 7 + q);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (MODE == 1) {
+                    if (q < 2) issue_w(cur_buf, q, q + 1);
+                } else {
+                    issue_w(cur_buf, 2 + q, 3 + q);          // NWK == 5: pieces 2, 3, 4
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (MODE == 2) cw_bytes += w_step;
         }
 #pragma unroll
         for (int p = 0; p < 9; ++p) { uC[p] = un[p]; avC[p] = avn[p]; }
