@@ -750,6 +750,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(WwArgs a) {
         constexpr int MODE = decltype(modec)::value, CUR = decltype(curbufc)::value;
         float zN[8], uN[8];
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MODE == 3) {              // first step of a unit: the ~25 staging loads of the next unit, spread
+            unext += a.splitK;                  // over this step's MFMAs instead of issued in one burst in front of them
+            issue(unext);
+        }
         operands(phc, nbufc, nstc, zN, uN);
 #pragma unroll
         for (int p = 0; p < 8; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(zC[p], uC[p], acc[p], 0, 0, 0);
@@ -758,7 +762,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(WwArgs a) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, MODE == 3 ? 12 : 3, 0);
+            if constexpr (MODE == 3) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (MODE == 1) commit(smem + (CUR ^ 1) * C::BUF_FLOATS);
@@ -771,9 +776,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(WwArgs a) {
         using BC = std::integral_constant<int, BUF>;
         using BN = std::integral_constant<int, BUF ^ 1>;
         using P = std::integral_constant<int, 0>;
-        unext += a.splitK;
-        issue(unext);
-        wstep(phc, BC{}, std::integral_constant<int, 1>{}, P{}, BC{});
+        wstep(phc, BC{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 3>{}, BC{});
         wstep(phc, BC{}, std::integral_constant<int, 2>{}, P{}, BC{});
         wstep(phc, BC{}, std::integral_constant<int, 3>{}, P{}, BC{});
         wstep(phc, BC{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{}, BC{});   // commit unit u+1
