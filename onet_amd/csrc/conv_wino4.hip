@@ -357,23 +357,32 @@ static __device__ __forceinline__ void wino4_body(const Wino4Args& a, float* sme
         __builtin_amdgcn_sched_barrier(0);
         lds_patch_wait(pt, d);
         __builtin_amdgcn_sched_barrier(0);
-        // R2: row pass of B^T (30 VALU) under MFMAs 3..5 (step B: plus the input dwords of chunk c+3, spread likewise)
+        // R2: row pass of B^T (30 VALU) under MFMAs 3..5.  Step B also issues the remaining three weight pieces of chunk
+        // c+2 here, one per MFMA -- BEFORE the input dwords of chunk c+3 (R3): the vmcnt(NIN) in front of the next
+        // barrier relies on those NIN loads being the youngest in the queue.
+        float* cur_buf = smem + CUR * C::BUF_FLOATS;
         xform_rows(d, t);
-        mfma_range(3, 6);
-        if constexpr (MODE == 2) {
-            static_assert(NIN <= 6, "input dwords are spread over MFMAs 3..5, two each");
-            issue_in_range(std::integral_constant<int, CUR ^ 1>{}, 0, NIN);
-            cin_bytes += in_step;
-        }
+        if constexpr (MODE != 2) {
+            mfma_range(3, 6);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
-            if constexpr (MODE == 2) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+            for (int q = 0; q < 3; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                mfma_range(3 + q, 4 + q);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                issue_w(cur_buf, 2 + q, 3 + q);              // NWK == 5: pieces 2, 3, 4
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            cw_bytes += w_step;
         }
         __builtin_amdgcn_sched_barrier(0);
         using SETN = std::integral_constant<int, CUR ^ 1>;   // MODE 1: inputs of chunk c+1; MODE 2: set (c+3)&1, freed in MODE 1
-        float* cur_buf = smem + CUR * C::BUF_FLOATS;
         if constexpr (MODE == 1) {
             lds_a(nbufc, ncpc, avn);      // MUST precede the barrier: the DMA issued after it overwrites these weights
             // chunk c lives in CUR; its last operands are in registers once the LDS counter drains (the
@@ -383,36 +392,35 @@ static __device__ __forceinline__ void wino4_body(const Wino4Args& a, float* sme
             __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
         }
-        // R3: column pass (18 VALU) under MFMAs 6..8.  The staging VMEM instructions of chunk c+2 / c+3 go out ONE per
-        // MFMA (step A: the first two weight pieces; step B: the other three and the five input dwords): the eight
+        // R3: column pass (18 VALU) under MFMAs 6..8.  The staging VMEM instructions go out ONE OR TWO per MFMA (step A:
+        // the first two weight pieces of chunk c+2 after the barrier; step B: the input dwords of chunk c+3): the eight
         // waves of the block share one texture-address path, and a burst of 8 VMEM per wave parks every wave's next
         // MFMA behind it.
         if constexpr (MODE != 1) lds_a(nbufc, ncpc, avn);
         xform_cols(t, un);
-        if constexpr (MODE == 0) {
-            mfma_range(6, 9);
-            __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-            }
-        } else {
-            if constexpr (MODE == 2) __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+        if constexpr (MODE == 1) {
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 mfma_range(6 + q, 7 + q);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (MODE == 1) {
-                    if (q < 2) issue_w(cur_buf, q, q + 1);
-                } else {
-                    issue_w(cur_buf, 2 + q, 3 + q);          // NWK == 5: pieces 2, 3, 4
-                }
+                if (q < 2) issue_w(cur_buf, q, q + 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (MODE == 2) cw_bytes += w_step;
+        } else {
+            mfma_range(6, 9);
+            if constexpr (MODE == 2) {
+                issue_in_range(SETN{}, 0, NIN);
+                cin_bytes += in_step;
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                if constexpr (MODE == 2) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+            }
         }
 #pragma unroll
         for (int p = 0; p < 9; ++p) { uC[p] = un[p]; avC[p] = avn[p]; }

@@ -381,19 +381,24 @@ def test_fit_loop_eval_and_checkpoint(dev, tmp_path):
         assert torch.equal(m(imgs[:2])[4], m2(imgs[:2])[4])
 
 
-def test_training_step_is_bitwise_deterministic(dev):
-    """No atomics on the default path: split-K slabs and BN partials are reduced in a fixed order, so two runs
-    of the same step give bit-identical loss, outputs and gradients."""
-    B, C, H, W = 4, 1, 64, 64
+@pytest.mark.parametrize("algo", ["auto", "winograd4"])
+def test_training_step_is_bitwise_deterministic(dev, algo, monkeypatch):
+    """No atomics on the default path: split-K slabs and BN partials are reduced in a fixed order, so repeated runs
+    of the same step give bit-identical loss, outputs and gradients (also a tripwire for staging races in the
+    software-pipelined kernels: "winograd4" forces the F(4x4,3x3) kernel onto every legal layer)."""
+    from onet_amd import ops
+    monkeypatch.setattr(ops, "CONV_ALGO", algo)
+    B, C, H, W = (4, 1, 64, 64) if algo == "auto" else (3, 1, 128, 128)
     X = orc.det_input(B, C, H, W, seed=3).to(dev)
     res = []
-    for _ in range(2):
+    for _ in range(2 if algo == "auto" else 4):
         m = _model(C, True, dev)
         (Lt, Vt, Ld, Vd, S), loss = _step(m, X)
         res.append((loss.detach().clone(), S.detach().clone(), [p.grad.detach().clone() for p in m.parameters()]))
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
-    for a, b in zip(res[0][2], res[1][2]):
-        assert torch.equal(a, b)
+    for other in res[1:]:
+        assert torch.equal(res[0][0], other[0]) and torch.equal(res[0][1], other[1])
+        for a, b in zip(res[0][2], other[2]):
+            assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("B,C,H,W", [(1, 1, 96, 64), (2, 3, 80, 112), (5, 1, 48, 48)])
