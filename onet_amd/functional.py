@@ -133,6 +133,26 @@ class MaxPool2Fn(torch.autograd.Function):
         return ops.maxpool2_bwd(x, dy)
 
 
+class SkipPoolFn(torch.autograd.Function):
+    """x -> (x, maxpool2(x)) for an encoder output that feeds both the next Down (OV:67) and an Up's skip concat
+    (OV:100): backward sums the two gradients inside the pooling-backward kernel (one pass instead of pool backward +
+    autograd's full-tensor add)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ops.require_gpu(x)
+        y = ops.maxpool2_fwd(x)
+        ctx.save_for_backward(x)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, g_skip, g_pool):
+        (x,) = ctx.saved_tensors
+        if g_pool is None:
+            return g_skip
+        return ops.maxpool2_bwd(x, g_pool, add=None if g_skip is None else g_skip)
+
+
 def _pad_offsets(x1_hw, x2_hw):
     """F.pad amounts of OV:92-96: (top, left); right/bottom are implied by the skip size."""
     dY = x2_hw[0] - 2 * x1_hw[0]

@@ -12,6 +12,8 @@ default initialisation, ``state_dict`` layout and ``isinstance`` behaviour (the 
 called.  There is no CPU fallback: a CPU tensor raises."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -126,6 +128,9 @@ class DoubleConv(nn.Module):
         return self._unit(self._unit(x, s[0], s[1], None, groups), s[3], s[4], None if out is None else (out,), groups)
 
 
+_SKIPPOOL = os.environ.get("ONET_SKIPPOOL", "1") != "0"
+
+
 class MaxPool2(nn.MaxPool2d):
     """nn.MaxPool2d(2) (OV:67)."""
 
@@ -143,8 +148,10 @@ class Down(nn.Module):
         super().__init__()
         self.maxpool_conv = nn.Sequential(MaxPool2(), DoubleConv(in_channels, out_channels))
 
-    def forward(self, x, out=None, groups=1):
-        return self.maxpool_conv[1](self.maxpool_conv[0](x), out=out, groups=groups)
+    def forward(self, x, out=None, groups=1, pooled=None):
+        """`pooled`: maxpool2(x) when the caller already has it (UNet.forward pools skip tensors with SkipPoolFn)."""
+        p = self.maxpool_conv[0](x) if pooled is None else pooled
+        return self.maxpool_conv[1](p, out=out, groups=groups)
 
 
 class ConvT2x2(nn.ConvTranspose2d, _Packable):
@@ -252,11 +259,21 @@ class UNet(nn.Module):
             return None if cats[k] is None else cats[k][:, :C]
 
         g = groups
+
+        def fork(t):
+            # skip tensors feed the next Down's pooling AND an Up's concat: one node, so that their two gradients are
+            # summed inside the pooling-backward kernel
+            return Fn.SkipPoolFn.apply(t) if (t.is_cuda and _SKIPPOOL) else (t, None)
+
         x1 = self.inc(x, out=skip(0, self.inc.double_conv[3].out_channels), groups=g)
-        x2 = self.down1(x1, out=skip(1, self.down1.maxpool_conv[1].double_conv[3].out_channels), groups=g)
-        x3 = self.down2(x2, out=skip(2, self.down2.maxpool_conv[1].double_conv[3].out_channels), groups=g)
-        x4 = self.down3(x3, out=skip(3, self.down3.maxpool_conv[1].double_conv[3].out_channels), groups=g)
-        x5 = self.down4(x4, groups=g)
+        x1, p1 = fork(x1)
+        x2 = self.down1(x1, out=skip(1, self.down1.maxpool_conv[1].double_conv[3].out_channels), groups=g, pooled=p1)
+        x2, p2 = fork(x2)
+        x3 = self.down2(x2, out=skip(2, self.down2.maxpool_conv[1].double_conv[3].out_channels), groups=g, pooled=p2)
+        x3, p3 = fork(x3)
+        x4 = self.down3(x3, out=skip(3, self.down3.maxpool_conv[1].double_conv[3].out_channels), groups=g, pooled=p3)
+        x4, p4 = fork(x4)
+        x5 = self.down4(x4, groups=g, pooled=p4)
         y4 = self.up1(x5, x4, cat=cats[3], groups=g)
         y3 = self.up2(y4, x3, cat=cats[2], groups=g)
         y2 = self.up3(y3, x2, cat=cats[1], groups=g)

@@ -189,6 +189,30 @@ def test_maxpool(dev, B, C, H, W):
     assert torch.equal(xd.grad.cpu(), xr.grad)
 
 
+@pytest.mark.parametrize("B,C,H,W", [(2, 3, 8, 8), (3, 5, 7, 9), (2, 4, 16, 12), (1, 2, 6, 10)])
+def test_skip_pool(dev, B, C, H, W):
+    """A skip tensor feeds both the pooling (OV:67) and the concat (OV:100): SkipPoolFn sums the two gradients inside
+    the pooling backward; the skip gradient arrives as a channel slice of a wider (concat) gradient."""
+    from onet_amd import functional as Fn
+    x = torch.relu(rnd(B, C, H, W, seed=15))
+    x[:, :, :4, :4] = 0.0
+    gp = rnd(B, C, H // 2, W // 2, seed=16)
+    gcat = rnd(B, 2 * C, H, W, seed=17)
+    xr = x.clone().requires_grad_(True)
+    (F.max_pool2d(xr, 2) * gp).sum().backward()
+    want = xr.grad + gcat[:, :C]
+    xd = x.to(dev).requires_grad_(True)
+    s, p = Fn.SkipPoolFn.apply(xd)
+    assert torch.equal(p.cpu(), F.max_pool2d(x, 2)) and torch.equal(s.cpu(), x)
+    torch.autograd.backward([s, p], [gcat.to(dev)[:, :C], gp.to(dev)])
+    assert torch.equal(xd.grad.cpu(), want)
+    # only one consumer
+    xd.grad = None
+    s, p = Fn.SkipPoolFn.apply(xd)
+    p.backward(gp.to(dev))
+    assert torch.equal(xd.grad.cpu(), xr.grad)
+
+
 @pytest.mark.parametrize("h,w,Ho,Wo,Cin,Ct", [(8, 8, 16, 16, 64, 32), (12, 12, 25, 25, 64, 32), (5, 7, 11, 16, 64, 32),
                                               (32, 32, 64, 64, 128, 64), (17, 40, 35, 80, 24, 12),
                                               (9, 20, 19, 41, 256, 128), (16, 16, 32, 32, 128, 64)])
