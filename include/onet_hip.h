@@ -99,6 +99,14 @@ int onet_conv3x3_pack_weights_winograd4(const float* w, float* wq_fwd, float* wq
                                         int Cout, int Cin, void* stream);
 int onet_conv3x3_winograd4_fwd(const float* x, int64_t x_bs, const float* wq, float* z, int64_t z_bs,
                                int B, int Cin, int Cout, int H, int W, void* stream);
+/* The same convolution with the BatchNorm statistics pass of OV:48,52 folded into its epilogue: every block also
+ * writes the (n, mean, M2) record of its 16 x 32 output pixels per channel, CHANNEL-MAJOR:
+ * part [Cout][nparts][3], nparts = onet_conv3x3_winograd4_nparts(B, H, W) = B * blocks per image (image-major, so a
+ * batch slice is a contiguous range of records); consumed by onet_bn_finalize_cm.  W > 16 only (nparts() returns 0
+ * where the statistics are not emitted: use onet_bn_stats_partial there). */
+int onet_conv3x3_winograd4_nparts(int B, int H, int W);
+int onet_conv3x3_winograd4_fwd_stats(const float* x, int64_t x_bs, const float* wq, float* z, int64_t z_bs,
+                                     float* part, int B, int Cin, int Cout, int H, int W, void* stream);
 /* Winograd weight gradient: dW = G^T [ sum_tiles (A dY A^T) (.) (B^T d B) ] G, split-K over pixel strips,
  * deterministic slab reduction; dw is [Cout][Cin][3][3]. */
 int onet_conv3x3_winograd_wgrad(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs, float* dw,
@@ -133,6 +141,10 @@ int onet_bn_stats_partial(const float* z, int64_t z_bs, float* part, int nparts,
 int onet_bn_finalize(const float* part, int nparts, int64_t count, const float* gamma,
                      const float* beta, float* running_mean, float* running_var,
                      float momentum, float eps, float* save, int C, void* stream);
+/* onet_bn_finalize for channel-major partials: channel c's records are part[c * c_stride + 3 * p], p < nparts. */
+int onet_bn_finalize_cm(const float* part, int nparts, int64_t c_stride, const float* gamma,
+                        const float* beta, float* running_mean, float* running_var,
+                        float momentum, float eps, float* save, int C, void* stream);
 /* eval-mode coefficients from running stats: same `save` layout. */
 int onet_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, float* save, int C, void* stream);

@@ -93,6 +93,55 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict
     }
 }
 
+// The same merge for partials laid out channel-major, `part[c * c_stride + p * 3]` (written by the F(4x4) convolution's
+// epilogue, one per 16 x 32-pixel block: thousands per channel), one 256-thread block per channel.
+__global__ __launch_bounds__(256) void bn_finalize_cm_kernel(const float* __restrict__ part, int nparts, int64_t c_stride,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* running_mean,
+                                                            float* running_var, float momentum, float eps,
+                                                            float* __restrict__ save, int C) {
+    __shared__ double red[16];
+    __shared__ double bc[2];
+    const int c = blockIdx.x;
+    const float* src = part + (int64_t)c * c_stride;
+    double v[2] = {0.0, 0.0};
+    for (int p = threadIdx.x; p < nparts; p += 256) {
+        const float* o = src + (int64_t)p * 3;
+        v[0] += (double)o[0];
+        v[1] += (double)o[0] * (double)o[1];
+    }
+    block_sum_256<double, 2>(v, red);
+    if (threadIdx.x == 0) {
+        bc[0] = v[0];
+        bc[1] = v[1] / v[0];
+    }
+    __syncthreads();
+    const double n = bc[0], mean = bc[1];
+    double w[1] = {0.0};
+    for (int p = threadIdx.x; p < nparts; p += 256) {
+        const float* o = src + (int64_t)p * 3;
+        const double d = (double)o[1] - mean;
+        w[0] += (double)o[2] + (double)o[0] * d * d;
+    }
+    __syncthreads();
+    block_sum_256<double, 1>(w, red);
+    if (threadIdx.x == 0) {
+        const double m2 = w[0];
+        const double var = m2 / n;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+        save[c] = (float)mean;
+        save[C + c] = invstd;
+        save[2 * C + c] = g * invstd;
+        save[3 * C + c] = bt;
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        if (running_var) {
+            const double unb = n > 1.0 ? m2 / (n - 1.0) : var;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+        }
+    }
+}
+
 __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
                                       float eps, float* save, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -274,6 +323,15 @@ int onet_bn_finalize(const float* part, int nparts, int64_t count, const float* 
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, as_stream(stream), part, nparts, gamma, beta,
                        running_mean, running_var, momentum, eps, save, C);
     return check_launch("bn_finalize_kernel");
+}
+
+int onet_bn_finalize_cm(const float* part, int nparts, int64_t c_stride, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, float momentum, float eps, float* save, int C,
+                        void* stream) {
+    ONET_REQUIRE(part && save && nparts > 0 && C > 0 && c_stride >= (int64_t)nparts * 3, "bn_finalize_cm: bad args");
+    hipLaunchKernelGGL(bn_finalize_cm_kernel, dim3(C), dim3(256), 0, as_stream(stream), part, nparts, c_stride, gamma,
+                       beta, running_mean, running_var, momentum, eps, save, C);
+    return check_launch("bn_finalize_cm_kernel");
 }
 
 int onet_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,

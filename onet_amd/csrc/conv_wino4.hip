@@ -124,6 +124,7 @@ struct Wino4Args {
     float* z;
     int64_t z_bs;
     int B, Cin, Cout, H, W, tilesX, tilesY, imgGroups, coTiles;
+    float* stats;         // ST kernels: BatchNorm partials [Cout][B * tilesX * tilesY][3] = (n, mean, M2) per block
 };
 
 template <int TXB>
@@ -176,7 +177,21 @@ static __device__ __forceinline__ void at3(const float m0, const float m1, const
 
 struct Patch { f32x4 q[5]; f32x2 h[5]; };     // five patch rows: columns 0..3 and 4..5
 
-template <int TXB, int RH, int CH>
+// sum over the 32 lanes of a wave half, valid in lanes 16..31 / 48..63: four cyclic rotations inside the rows of 16
+// (DPP row_ror), then lane 15 of the even rows added into the odd rows (DPP row_bcast:15)
+#define ONET_DPP_ADD(v, ctrl, rmask) \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
+static __device__ __forceinline__ float half_sum_hi(float v) {
+    ONET_DPP_ADD(v, 0x128, 0xf);   // row_ror:8
+    ONET_DPP_ADD(v, 0x124, 0xf);   // row_ror:4
+    ONET_DPP_ADD(v, 0x122, 0xf);   // row_ror:2
+    ONET_DPP_ADD(v, 0x121, 0xf);   // row_ror:1
+    ONET_DPP_ADD(v, 0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+    return v;
+}
+#undef ONET_DPP_ADD
+
+template <int TXB, int RH, int CH, bool ST = false>
 static __device__ __forceinline__ void wino4_body(const Wino4Args& a, float* smem) {
     using C = W4Cfg<TXB>;
     constexpr int IMG = C::IMG, IN_ROWS = C::IN_ROWS, IN_COLS = C::IN_COLS, RS = C::RS;
@@ -476,6 +491,11 @@ static __device__ __forceinline__ void wino4_body(const Wino4Args& a, float* sme
     const bool img_ok = (b0 + img) < a.B;
     const bool vec4 = ((a.W & 3) == 0) && ((a.z_bs & 3) == 0) && (ox + 3 < a.W);
     constexpr int PG = RH * 2 + CH;
+    // ST: BatchNorm statistics of this block's 64 channels x (16 x 32) pixels from the final sums, shifted by a
+    // pivot (the block's first output of the channel) so that fp32 is enough; merged in fp64 by bn_finalize
+    constexpr float st_n = (float)(C::PXW * C::PXH), st_inv = 1.f / st_n;   // full blocks only (host-checked)
+    const int64_t st_nblk = (int64_t)a.B * a.tilesX * a.tilesY;
+    const int64_t st_blk = ((int64_t)bg * a.tilesY + ty) * a.tilesX + tx;
 #pragma unroll
     for (int ps = 0; ps < 8; ++ps) {
         float* ex = smem + (ps & 1) * C::EX_FLOATS;
@@ -494,18 +514,21 @@ static __device__ __forceinline__ void wino4_body(const Wino4Args& a, float* sme
 #pragma unroll
             for (int y = 0; y < 4; ++y) at3<CH>(rowp[y][0], rowp[y][1], rowp[y][2], yv[h][y]);
         }
-        if constexpr (PG != 0) {
+        // summing role: group 0 finishes register h = 0 of the pass, group 1 register h = 1; exchange slot 0 holds
+        // group 1's h = 0 partial and group 0's h = 1 partial, slots 1 and 2 both partials of groups 2 and 3
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < 2; ++h) {
+            if (PG == h) continue;
+            constexpr int SLOT = (PG < 2) ? 0 : PG - 1;
 #pragma unroll
-                for (int y = 0; y < 4; ++y)
-                    *reinterpret_cast<float4*>(ex + (((PG - 1) * 2 + wm) * 64 + lane) * C::EX_LANE + h * 16 + y * 4) =
-                        make_float4(yv[h][y][0], yv[h][y][1], yv[h][y][2], yv[h][y][3]);
+            for (int y = 0; y < 4; ++y)
+                *reinterpret_cast<float4*>(ex + ((SLOT * 2 + wm) * 64 + lane) * C::EX_LANE + h * 16 + y * 4) =
+                    make_float4(yv[h][y][0], yv[h][y][1], yv[h][y][2], yv[h][y][3]);
         }
         __syncthreads();
-        if constexpr (PG == 0) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
+        if constexpr (PG < 2) {
+            {
+                constexpr int h = PG;
                 const int r = 2 * ps + h;
                 const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
 #pragma unroll
@@ -515,6 +538,34 @@ static __device__ __forceinline__ void wino4_body(const Wino4Args& a, float* sme
                         const float4 v = *reinterpret_cast<const float4*>(ex + ((g * 2 + wm) * 64 + lane) * C::EX_LANE + h * 16 + y * 4);
                         yv[h][y][0] += v.x; yv[h][y][1] += v.y; yv[h][y][2] += v.z; yv[h][y][3] += v.w;
                     }
+                if constexpr (ST) {
+                    static_assert(!ST || IMG == 1, "fused statistics: one image per block");
+                    const int piv = __builtin_bit_cast(int, yv[h][0][0]);
+                    const float p0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(piv, 0));
+                    const float p1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(piv, 32));
+                    const float pv = kh ? p1 : p0;
+                    // packed fp32 (v_pk_add_f32 / v_pk_fma_f32): two pixels per VALU op
+                    f32x2 q1 = {0.f, 0.f}, q2 = {0.f, 0.f};
+                    const f32x2 pv2 = {pv, pv};
+#pragma unroll
+                    for (int y = 0; y < 4; ++y)
+#pragma unroll
+                        for (int x = 0; x < 4; x += 2) {
+                            const f32x2 v2 = {yv[h][y][x], yv[h][y][x + 1]};
+                            const f32x2 d = v2 - pv2;
+                            q1 += d;
+                            q2 = __builtin_elementwise_fma(d, d, q2);
+                        }
+                    float s1 = q1.x + q1.y, s2 = q2.x + q2.y;
+                    s1 = half_sum_hi(s1);
+                    s2 = half_sum_hi(s2);
+                    if (l31 == 31 && co < a.Cout) {
+                        float* sp = a.stats + ((int64_t)co * st_nblk + st_blk) * 3;
+                        sp[0] = st_n;
+                        sp[1] = fmaf(s1, st_inv, pv);
+                        sp[2] = fmaxf(fmaf(-s1 * st_inv, s1, s2), 0.f);
+                    }
+                }
                 if (co < a.Cout && img_ok && ox < a.W) {
                     float* o = (IMG == 1 ? zb[0] : (img ? zb[IMG - 1] : zb[0])) + (int64_t)co * HW + (int64_t)oy * a.W + ox;
 #pragma unroll
@@ -535,19 +586,19 @@ static __device__ __forceinline__ void wino4_body(const Wino4Args& a, float* sme
     }
 }
 
-template <int TXB>
+template <int TXB, bool ST = false>
 __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4Args a) {
     extern __shared__ __attribute__((aligned(16))) float smem4[];
     const int pg = (threadIdx.x >> 6) >> 1;           // wave-uniform
     switch (__builtin_amdgcn_readfirstlane(pg)) {
-        case 0: wino4_body<TXB, 0, 0>(a, smem4); break;
-        case 1: wino4_body<TXB, 0, 1>(a, smem4); break;
-        case 2: wino4_body<TXB, 1, 0>(a, smem4); break;
-        default: wino4_body<TXB, 1, 1>(a, smem4); break;
+        case 0: wino4_body<TXB, 0, 0, ST>(a, smem4); break;
+        case 1: wino4_body<TXB, 0, 1, ST>(a, smem4); break;
+        case 2: wino4_body<TXB, 1, 0, ST>(a, smem4); break;
+        default: wino4_body<TXB, 1, 1, ST>(a, smem4); break;
     }
 }
 
-template <int TXB>
+template <int TXB, bool ST = false>
 static int launch_wino4(Wino4Args a, hipStream_t st) {
     using C = W4Cfg<TXB>;
     a.tilesX = cdiv(a.W, C::PXW);
@@ -556,7 +607,7 @@ static int launch_wino4(Wino4Args a, hipStream_t st) {
     a.coTiles = cdiv(a.Cout, C::CO_T);
     const int64_t blocks = (int64_t)a.imgGroups * a.tilesX * a.tilesY * a.coTiles;
     ONET_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv_wino4: grid %lld out of range", (long long)blocks);
-    auto kern = conv_wino4_kernel<TXB>;
+    auto kern = conv_wino4_kernel<TXB, ST>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -592,8 +643,29 @@ int onet_conv3x3_winograd4_fwd(const float* x, int64_t x_bs, const float* wq, fl
     ONET_REQUIRE(x_bs >= (int64_t)Cin * H * W && z_bs >= (int64_t)Cout * H * W, "conv3x3_winograd4_fwd: batch stride too small");
     ONET_REQUIRE((x_bs + (int64_t)(Cin + 16) * H * W) * 4 < (1ll << 31) && (int64_t)(Cin + 16) * 36 * Cout * 4 < (1ll << 31),
                  "conv3x3_winograd4_fwd: operand exceeds the 2 GiB buffer-resource range");
-    Wino4Args a{x, x_bs, wq, z, z_bs, B, Cin, Cout, H, W, 0, 0, 0, 0};
+    Wino4Args a{x, x_bs, wq, z, z_bs, B, Cin, Cout, H, W, 0, 0, 0, 0, nullptr};
     return (W > 16) ? launch_wino4<8>(a, as_stream(stream)) : launch_wino4<4>(a, as_stream(stream));
+}
+
+int onet_conv3x3_winograd4_nparts(int B, int H, int W) {
+    // statistics are emitted by full 16 x 32-pixel blocks only (every U-Net level of a 2^k-sized input down to 32 px)
+    if (B <= 0 || H <= 0 || W <= 0 || (W % W4Cfg<8>::PXW) != 0 || (H % W4Cfg<8>::PXH) != 0) return 0;
+    const int64_t n = (int64_t)B * cdiv(W, W4Cfg<8>::PXW) * cdiv(H, W4Cfg<8>::PXH);
+    return n < (1ll << 31) ? (int)n : 0;
+}
+
+int onet_conv3x3_winograd4_fwd_stats(const float* x, int64_t x_bs, const float* wq, float* z, int64_t z_bs, float* part,
+                                     int B, int Cin, int Cout, int H, int W, void* stream) {
+    ONET_REQUIRE(x && wq && z && part, "conv3x3_winograd4_fwd_stats: null pointer");
+    ONET_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv3x3_winograd4_fwd_stats: bad shape");
+    ONET_REQUIRE((W % W4Cfg<8>::PXW) == 0 && (H % W4Cfg<8>::PXH) == 0,
+                 "conv3x3_winograd4_fwd_stats: W %% 32 == 0 and H %% 16 == 0 required (onet_conv3x3_winograd4_nparts() == 0 elsewhere)");
+    ONET_REQUIRE((Cout & 3) == 0 && (Cin & 3) == 0, "conv3x3_winograd4_fwd_stats: Cin and Cout must be multiples of 4");
+    ONET_REQUIRE(x_bs >= (int64_t)Cin * H * W && z_bs >= (int64_t)Cout * H * W, "conv3x3_winograd4_fwd_stats: batch stride too small");
+    ONET_REQUIRE((x_bs + (int64_t)(Cin + 16) * H * W) * 4 < (1ll << 31) && (int64_t)(Cin + 16) * 36 * Cout * 4 < (1ll << 31),
+                 "conv3x3_winograd4_fwd_stats: operand exceeds the 2 GiB buffer-resource range");
+    Wino4Args a{x, x_bs, wq, z, z_bs, B, Cin, Cout, H, W, 0, 0, 0, 0, part};
+    return launch_wino4<8, true>(a, as_stream(stream));
 }
 
 }  // extern "C"

@@ -19,13 +19,15 @@ class ConvBNReLUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, running_mean, running_var, training, momentum, eps, packed, out, groups=1):
         ops.require_gpu(x, weight, gamma, beta)
-        z = ops.conv3x3_auto(x, packed, 0)
+        # training: the F(4x4) kernel emits the BatchNorm statistics records from its epilogue (cm), where it can
+        z, cm = ops.conv3x3_fwd_bn_partials(x, packed) if training else (ops.conv3x3_auto(x, packed, 0), None)
         # `out` is None or a 1-tuple holding a plane-contiguous destination view (kept out of autograd's sight)
         dst = None if out is None else out[0]
         G = groups if (training and groups > 1) else 1
         if G == 1:
             if training:
-                save = ops.bn_train_coeffs(z, gamma, beta, running_mean, running_var, momentum, eps)
+                save = ops.bn_train_coeffs(z, gamma, beta, running_mean, running_var, momentum, eps,
+                                           cm=None if cm is None else (cm, 0, cm.shape[1]))
             else:
                 save = ops.bn_eval_coeffs(gamma, beta, running_mean, running_var, eps)
             a = ops.bn_relu_apply(z, save, out=dst)
@@ -39,7 +41,9 @@ class ConvBNReLUFn(torch.autograd.Function):
             saves = []
             for g in range(G):
                 zg = z[g * Bg:(g + 1) * Bg]
-                sv = ops.bn_train_coeffs(zg, gamma, beta, running_mean, running_var, momentum, eps)
+                npg = 0 if cm is None else cm.shape[1] // G
+                sv = ops.bn_train_coeffs(zg, gamma, beta, running_mean, running_var, momentum, eps,
+                                         cm=None if cm is None else (cm, g * npg, npg))
                 ops.bn_relu_apply(zg, sv, out=a[g * Bg:(g + 1) * Bg])
                 saves.append(sv)
         ctx.save_for_backward(x, z, *saves)

@@ -200,6 +200,33 @@ def conv3x3_auto(x, pk, direction, out=None):
     return conv_fwd(x, wq, Co, 3, out=out)
 
 
+FUSE_BN_STATS = _os.environ.get("ONET_FUSE_BN_STATS", "1") != "0"
+
+
+def conv3x3_fwd_bn_partials(x, pk):
+    """Forward 3x3 convolution of a Conv-BatchNorm pair (OV:47-48, 51-52): -> (z, cm).  cm = the channel-major
+    BatchNorm records [Cout, nparts, 3] the F(4x4) kernel's epilogue emits (image-major: nparts / B per image), or None
+    where the selected kernel does not emit them (then `bn_train_coeffs` runs its own statistics pass)."""
+    Ci, Co = pk["Cin"], pk["Cout"]
+    B, _, H, W = x.shape
+    algo = conv3x3_algo(B, Ci, Co, H, W)
+    nparts = 0
+    if algo == "winograd4" and FUSE_BN_STATS and not SYNC_BN:
+        nparts = int(_lib.load().onet_conv3x3_winograd4_nparts(B, H, W))
+    if nparts <= 0:
+        return conv3x3_auto(x, pk, 0), None
+    wq = pk.get_pack(algo)[0]
+    require_gpu(x, wq)
+    x, xbs = plane(x)
+    out = torch.empty((B, Co, H, W), dtype=F32, device=x.device)
+    cm = torch.empty((Co, nparts, 3), dtype=F32, device=x.device)
+    e0 = _prof_begin()
+    _lib.call("onet_conv3x3_winograd4_fwd_stats", _p(x), xbs, _p(wq), _p(out), Co * H * W, _p(cm), B, Ci, Co, H, W,
+              _stream())
+    _prof_end("conv_wino4_kernel", 2.0 * B * H * W * Ci * Co * 9, e0)
+    return out, cm
+
+
 def pack3x3_winograd(w):
     require_gpu(w)
     w = w.detach().contiguous()
@@ -344,12 +371,21 @@ def _bn_nparts(B, HW):
     return B * max(1, (HW + 16383) // 16384)
 
 
-def bn_train_coeffs(z, gamma, beta, running_mean, running_var, momentum, eps):
-    """batch statistics -> save [4][C] = (mean, invstd, scale, shift); updates running stats in place."""
+def bn_train_coeffs(z, gamma, beta, running_mean, running_var, momentum, eps, cm=None):
+    """batch statistics -> save [4][C] = (mean, invstd, scale, shift); updates running stats in place.
+    `cm` = (records [C, NP, 3], first, count): the convolution already produced this batch's statistics records
+    (`conv3x3_fwd_bn_partials`), records first .. first+count-1 of every channel belong to `z`."""
     z, zbs = plane(z)
     B, C, H, W = z.shape
     if B * H * W <= 1:
         raise ValueError(f"Expected more than 1 value per channel when training, got input size {list(z.shape)}")
+    if cm is not None:
+        rec, first, count = cm
+        assert rec.shape[0] == C and rec.shape[2] == 3 and 0 <= first and first + count <= rec.shape[1]
+        save = torch.empty((4, C), dtype=F32, device=z.device)
+        _lib.call("onet_bn_finalize_cm", rec.data_ptr() + first * 12, count, rec.shape[1] * 3, _p(gamma), _p(beta),
+                  _p(running_mean), _p(running_var), float(momentum), float(eps), _p(save), C, _stream())
+        return save
     nparts = _bn_nparts(B, H * W)
     part = torch.empty((nparts, C, 3), dtype=F32, device=z.device)
     _lib.call("onet_bn_stats_partial", _p(z), zbs, _p(part), nparts, B, C, H * W, _stream())

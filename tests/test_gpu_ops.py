@@ -189,6 +189,50 @@ def test_maxpool(dev, B, C, H, W):
     assert torch.equal(xd.grad.cpu(), xr.grad)
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 8, 64, 32, 32), (3, 16, 72, 16, 64), (2, 4, 12, 48, 32),
+                                             (4, 64, 128, 64, 64), (2, 8, 8, 32, 96)])
+def test_winograd4_fused_bn_statistics(dev, B, Cin, Cout, H, W):
+    """F(4x4) forward with the BatchNorm statistics records written by its epilogue (maps made of full 16 x 32-pixel
+    blocks; channel tails): z bit-identical to the plain kernel, and finalize(records) == finalize(separate statistics
+    pass) for the whole batch and for a batch slice (the twin batch's statistics groups).  Ragged maps report
+    nparts == 0 and keep the separate statistics pass."""
+    from onet_amd import _lib, ops
+    for h, w in [(40, 40), (16, 16), (20, 64), (32, 48)]:
+        assert int(_lib.load().onet_conv3x3_winograd4_nparts(B, h, w)) == 0
+    x = rnd(B, Cin, H, W, seed=31) + 0.7
+    w = rnd(Cout, Cin, 3, 3, seed=32) / (3.0 * Cin ** 0.5)
+    xd = x.to(dev)
+    qf, _ = ops.pack3x3_winograd4(w.to(dev))
+    z0 = ops.conv3x3_winograd4(xd, qf, Cout)
+    nparts = int(_lib.load().onet_conv3x3_winograd4_nparts(B, H, W))
+    assert nparts == B * (W // 32) * (H // 16)
+    z1 = torch.empty_like(z0)
+    cm = torch.full((Cout, nparts, 3), float("nan"), device=dev)
+    _lib.call("onet_conv3x3_winograd4_fwd_stats", xd.data_ptr(), Cin * H * W, qf.data_ptr(), z1.data_ptr(),
+              Cout * H * W, cm.data_ptr(), B, Cin, Cout, H, W, torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(z0, z1)
+    assert torch.isfinite(cm).all()
+    assert float(cm[:, :, 0].sum(1).min()) == float(cm[:, :, 0].sum(1).max()) == B * H * W
+    gamma = (1 + 0.1 * rnd(Cout, seed=33)).to(dev)
+    beta = (0.1 * rnd(Cout, seed=34)).to(dev)
+    for lo, hi in [(0, B), (B // 2, B)]:
+        zs = z0[lo:hi]
+        rm0, rv0 = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
+        rm1, rv1 = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
+        s0 = ops.bn_train_coeffs(zs, gamma, beta, rm0, rv0, 0.1, 1e-5)
+        npi = nparts // B
+        s1 = ops.bn_train_coeffs(zs, gamma, beta, rm1, rv1, 0.1, 1e-5, cm=(cm, lo * npi, (hi - lo) * npi))
+        sd = float(zs.std())
+        assert float((s0[0] - s1[0]).abs().max()) <= 2e-6 * sd, "mean"
+        assert float(((s0[1] - s1[1]) / s0[1]).abs().max()) <= 1e-5, "invstd"
+        assert float((rm0 - rm1).abs().max()) <= 1e-6 * sd and float(((rv0 - rv1) / rv0).abs().max()) <= 1e-5
+        # and against torch in fp64
+        zr = zs.double().cpu()
+        assert float((s1[0].cpu().double() - zr.mean((0, 2, 3))).abs().max()) <= 2e-6 * sd
+        ir = 1.0 / torch.sqrt(zr.var((0, 2, 3), unbiased=False) + 1e-5)
+        assert float(((s1[1].cpu().double() - ir) / ir).abs().max()) <= 1e-5
+
+
 @pytest.mark.parametrize("B,C,H,W", [(2, 3, 8, 8), (3, 5, 7, 9), (2, 4, 16, 12), (1, 2, 6, 10)])
 def test_skip_pool(dev, B, C, H, W):
     """A skip tensor feeds both the pooling (OV:67) and the concat (OV:100): SkipPoolFn sums the two gradients inside
