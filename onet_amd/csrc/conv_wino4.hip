@@ -496,13 +496,19 @@ static __device__ __forceinline__ void wino4_body(const Wino4Args& a, float* sme
     constexpr float st_n = (float)(C::PXW * C::PXH), st_inv = 1.f / st_n;   // full blocks only (host-checked)
     const int64_t st_nblk = (int64_t)a.B * a.tilesX * a.tilesY;
     const int64_t st_blk = ((int64_t)bg * a.tilesY + ty) * a.tilesX + tx;
+    // The eight passes run as two rolled halves of four (accumulator registers 8..15 are moved down to 0..7 between
+    // them): half the straight-line code.  The kernel's four position-group bodies were 68 KB against a 64 KB
+    // instruction cache shared by two CUs, most of it this epilogue.
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
 #pragma unroll
-    for (int ps = 0; ps < 8; ++ps) {
-        float* ex = smem + (ps & 1) * C::EX_FLOATS;
+    for (int ps4 = 0; ps4 < 4; ++ps4) {
+        const int ps = half * 4 + ps4;
+        float* ex = smem + (ps4 & 1) * C::EX_FLOATS;
         float yv[2][4][4];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int r = 2 * ps + h;
+            const int r = 2 * ps4 + h;
             float rowp[4][3];                         // A^T (row half) applied to the 3 position rows, per column j
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
@@ -582,6 +588,13 @@ static __device__ __forceinline__ void wino4_body(const Wino4Args& a, float* sme
                     }
                 }
             }
+        }
+    }
+        if (half == 0) {
+#pragma unroll
+            for (int p = 0; p < 9; ++p)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) acc[p][r] = acc[p][r + 8];
         }
     }
 }
