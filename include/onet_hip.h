@@ -174,10 +174,12 @@ int onet_maxpool2_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs,
 int onet_maxpool2_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs,
                       float* dx, int64_t dx_bs, int B, int C, int H, int W, int accumulate,
                       void* stream);
-/* dx = maxpool2 backward + add: the gradient of a tensor that feeds BOTH the pooling and a skip connection
- * (OV:141-149: x1..x4 go to the next Down and to an Up's torch.cat) in one pass instead of autograd's separate add. */
+/* dx = maxpool2 backward + add [+ add2]: the gradient of a tensor that feeds BOTH the pooling and a skip connection
+ * (OV:141-149: x1..x4 go to the next Down and to an Up's torch.cat; x1 is also returned, OV:152, and enters the
+ * head: add2, nullable) in one pass instead of autograd's separate full-tensor adds. */
 int onet_maxpool2_bwd_add(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, const float* add,
-                          int64_t add_bs, float* dx, int64_t dx_bs, int B, int C, int H, int W, void* stream);
+                          int64_t add_bs, const float* add2, int64_t add2_bs, float* dx, int64_t dx_bs,
+                          int B, int C, int H, int W, void* stream);
 
 /* ---- K5/K6: ConvTranspose2d(k=2,s=2) pixel shuffle + pad + concat (OV:86-100) ---- */
 /* sub [B][4*C][h][w] (1x1-conv output, channel q*C+co, q=dy*2+dx) + bias ->

@@ -49,7 +49,7 @@ __global__ void maxpool2_fwd_kernel_s(const float* __restrict__ x, int64_t x_bs,
 __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, int64_t x_bs, const float* __restrict__ dy,
                                     int64_t dy_bs, float* __restrict__ dx, int64_t dx_bs, int B, int C, int H,
                                     int W, int Ho, int Wo, int accumulate, const float* __restrict__ add,
-                                    int64_t add_bs) {
+                                    int64_t add_bs, const float* __restrict__ add2, int64_t add2_bs) {
     const int64_t n = (int64_t)B * C * H * W;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int ix = (int)(i % W);
@@ -73,6 +73,7 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, int64_t x_bs, c
         }
         float* o = dx + (int64_t)b * dx_bs + (int64_t)c * H * W + (int64_t)iy * W + ix;
         if (add) g += add[(int64_t)b * add_bs + (int64_t)c * H * W + (int64_t)iy * W + ix];
+        if (add2) g += add2[(int64_t)b * add2_bs + (int64_t)c * H * W + (int64_t)iy * W + ix];
         *o = accumulate ? *o + g : g;
     }
 }
@@ -84,7 +85,8 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_v4_kernel(const float* __res
                                                               const float* __restrict__ dy, int64_t dy_bs,
                                                               float* __restrict__ dx, int64_t dx_bs, int B, int C, int H,
                                                               int W, int accumulate, const float* __restrict__ add,
-                                                              int64_t add_bs) {
+                                                              int64_t add_bs, const float* __restrict__ add2,
+                                                              int64_t add2_bs) {
     const int Ho = H >> 1, Wo = W >> 1, W4 = W >> 2;
     const int64_t n = (int64_t)B * C * Ho * W4;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -112,6 +114,12 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_v4_kernel(const float* __res
         if (add) {           // the other gradient of a tensor that also feeds a skip connection: dx = pool grad + add
             const float4 p0 = *reinterpret_cast<const float4*>(add + (int64_t)b * add_bs + in_off);
             const float4 p1 = *reinterpret_cast<const float4*>(add + (int64_t)b * add_bs + in_off + W);
+            o0.x += p0.x; o0.y += p0.y; o0.z += p0.z; o0.w += p0.w;
+            o1.x += p1.x; o1.y += p1.y; o1.z += p1.z; o1.w += p1.w;
+        }
+        if (add2) {          // and a third one (the U-Net's first output is pooled, concatenated AND returned to the head)
+            const float4 p0 = *reinterpret_cast<const float4*>(add2 + (int64_t)b * add2_bs + in_off);
+            const float4 p1 = *reinterpret_cast<const float4*>(add2 + (int64_t)b * add2_bs + in_off + W);
             o0.x += p0.x; o0.y += p0.y; o0.z += p0.z; o0.w += p0.w;
             o1.x += p1.x; o1.y += p1.y; o1.z += p1.z; o1.w += p1.w;
         }
@@ -289,19 +297,21 @@ __global__ void axpy_kernel(const float* __restrict__ x, int64_t x_bs, float* __
 }
 
 static int maxpool2_bwd_impl(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, float* dx, int64_t dx_bs, int B,
-                             int C, int H, int W, int accumulate, const float* add, int64_t add_bs, void* stream) {
+                             int C, int H, int W, int accumulate, const float* add, int64_t add_bs, const float* add2,
+                             int64_t add2_bs, void* stream) {
     const int64_t n = (int64_t)B * C * H * W;
     const bool v4 = ((W & 3) == 0) && ((H & 1) == 0) && ((x_bs & 3) == 0) && ((dx_bs & 3) == 0) && ((dy_bs & 1) == 0) &&
                     ((add_bs & 3) == 0) && ((reinterpret_cast<uintptr_t>(add) & 15) == 0) &&
+                    ((add2_bs & 3) == 0) && ((reinterpret_cast<uintptr_t>(add2) & 15) == 0) &&
                     ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dx) & 15) == 0) &&
                     ((reinterpret_cast<uintptr_t>(dy) & 7) == 0);
     if (v4) {
         hipLaunchKernelGGL(maxpool2_bwd_v4_kernel, dim3(grid_for(n / 8)), dim3(256), 0, as_stream(stream), x, x_bs, dy, dy_bs,
-                           dx, dx_bs, B, C, H, W, accumulate, add, add_bs);
+                           dx, dx_bs, B, C, H, W, accumulate, add, add_bs, add2, add2_bs);
         return check_launch("maxpool2_bwd_v4_kernel");
     }
     hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), x, x_bs, dy, dy_bs, dx,
-                       dx_bs, B, C, H, W, H / 2, W / 2, accumulate, add, add_bs);
+                       dx_bs, B, C, H, W, H / 2, W / 2, accumulate, add, add_bs, add2, add2_bs);
     return check_launch("maxpool2_bwd_kernel");
 }
 
@@ -323,13 +333,14 @@ int onet_maxpool2_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs, int 
 int onet_maxpool2_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, float* dx, int64_t dx_bs,
                       int B, int C, int H, int W, int accumulate, void* stream) {
     ONET_REQUIRE(x && dy && dx && B > 0 && C > 0 && H >= 2 && W >= 2, "maxpool2_bwd: bad args");
-    return maxpool2_bwd_impl(x, x_bs, dy, dy_bs, dx, dx_bs, B, C, H, W, accumulate, nullptr, 0, stream);
+    return maxpool2_bwd_impl(x, x_bs, dy, dy_bs, dx, dx_bs, B, C, H, W, accumulate, nullptr, 0, nullptr, 0, stream);
 }
 
 int onet_maxpool2_bwd_add(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, const float* add, int64_t add_bs,
-                          float* dx, int64_t dx_bs, int B, int C, int H, int W, void* stream) {
+                          const float* add2, int64_t add2_bs, float* dx, int64_t dx_bs, int B, int C, int H, int W,
+                          void* stream) {
     ONET_REQUIRE(x && dy && add && dx && B > 0 && C > 0 && H >= 2 && W >= 2, "maxpool2_bwd_add: bad args");
-    return maxpool2_bwd_impl(x, x_bs, dy, dy_bs, dx, dx_bs, B, C, H, W, 0, add, add_bs, stream);
+    return maxpool2_bwd_impl(x, x_bs, dy, dy_bs, dx, dx_bs, B, C, H, W, 0, add, add_bs, add2, add2_bs, stream);
 }
 
 int onet_pixel_shuffle2_bias(const float* sub, const float* bias, float* y, int64_t y_bs, int B, int C, int h,

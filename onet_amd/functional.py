@@ -138,23 +138,25 @@ class MaxPool2Fn(torch.autograd.Function):
 
 
 class SkipPoolFn(torch.autograd.Function):
-    """x -> (x, maxpool2(x)) for an encoder output that feeds both the next Down (OV:67) and an Up's skip concat
-    (OV:100): backward sums the two gradients inside the pooling-backward kernel (one pass instead of pool backward +
-    autograd's full-tensor add)."""
+    """x -> (x, maxpool2(x)[, x]) for an encoder output that feeds both the next Down (OV:67) and an Up's skip concat
+    (OV:100) -- and, for the first one, also leaves the U-Net as its first output (OV:152): backward sums the two or
+    three gradients inside the pooling-backward kernel (one pass instead of pool backward + autograd's full-tensor
+    adds)."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, returned=False):
         ops.require_gpu(x)
         y = ops.maxpool2_fwd(x)
         ctx.save_for_backward(x)
-        return x.view_as(x), y
+        return (x.view_as(x), y, x.view_as(x)) if returned else (x.view_as(x), y)
 
     @staticmethod
-    def backward(ctx, g_skip, g_pool):
+    def backward(ctx, g_skip, g_pool, g_ret=None):
         (x,) = ctx.saved_tensors
         if g_pool is None:
-            return g_skip
-        return ops.maxpool2_bwd(x, g_pool, add=None if g_skip is None else g_skip)
+            gs = [g for g in (g_skip, g_ret) if g is not None]
+            return (sum(gs[1:], gs[0]) if gs else None), None
+        return ops.maxpool2_bwd(x, g_pool, add=g_skip, add2=g_ret), None
 
 
 def _pad_offsets(x1_hw, x2_hw):

@@ -260,13 +260,15 @@ class UNet(nn.Module):
 
         g = groups
 
-        def fork(t):
-            # skip tensors feed the next Down's pooling AND an Up's concat: one node, so that their two gradients are
-            # summed inside the pooling-backward kernel
-            return Fn.SkipPoolFn.apply(t) if (t.is_cuda and _SKIPPOOL) else (t, None)
+        def fork(t, returned=False):
+            # skip tensors feed the next Down's pooling AND an Up's concat (x1 also leaves as the first output): one
+            # node, so that their gradients are summed inside the pooling-backward kernel
+            if t.is_cuda and _SKIPPOOL:
+                return Fn.SkipPoolFn.apply(t, returned)
+            return (t, None, t) if returned else (t, None)
 
         x1 = self.inc(x, out=skip(0, self.inc.double_conv[3].out_channels), groups=g)
-        x1, p1 = fork(x1)
+        x1, p1, x1_out = fork(x1, True)
         x2 = self.down1(x1, out=skip(1, self.down1.maxpool_conv[1].double_conv[3].out_channels), groups=g, pooled=p1)
         x2, p2 = fork(x2)
         x3 = self.down2(x2, out=skip(2, self.down2.maxpool_conv[1].double_conv[3].out_channels), groups=g, pooled=p2)
@@ -278,7 +280,7 @@ class UNet(nn.Module):
         y3 = self.up2(y4, x3, cat=cats[2], groups=g)
         y2 = self.up3(y3, x2, cat=cats[1], groups=g)
         y1 = self.up4(y2, x1, cat=cats[0], groups=g)
-        return x1, y1
+        return x1_out, y1
 
 
 class Softmax2(nn.Softmax2d):

@@ -462,19 +462,22 @@ def maxpool2_fwd(x):
     return y
 
 
-def maxpool2_bwd(x, dy, add=None):
-    """dx of MaxPool2d(2); `add`: another gradient of x (plane-contiguous, e.g. a slice of a concat gradient) summed in
-    the same pass."""
+def maxpool2_bwd(x, dy, add=None, add2=None):
+    """dx of MaxPool2d(2); `add`, `add2`: other gradients of x (plane-contiguous, e.g. a slice of a concat gradient)
+    summed in the same pass."""
     x, xbs = plane(x)
     dy, dybs = plane(dy)
     B, C, H, W = x.shape
     dx = torch.empty((B, C, H, W), dtype=F32, device=x.device)
+    if add is None and add2 is not None:
+        add, add2 = add2, None
     if add is None:
         _lib.call("onet_maxpool2_bwd", _p(x), xbs, _p(dy), dybs, _p(dx), C * H * W, B, C, H, W, 0, _stream())
     else:
         add, abs_ = plane(add)
-        _lib.call("onet_maxpool2_bwd_add", _p(x), xbs, _p(dy), dybs, _p(add), abs_, _p(dx), C * H * W, B, C, H, W,
-                  _stream())
+        a2, a2bs = plane(add2) if add2 is not None else (None, 0)
+        _lib.call("onet_maxpool2_bwd_add", _p(x), xbs, _p(dy), dybs, _p(add), abs_, _p(a2), a2bs, _p(dx), C * H * W,
+                  B, C, H, W, _stream())
     return dx
 
 

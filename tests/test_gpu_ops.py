@@ -250,6 +250,16 @@ def test_skip_pool(dev, B, C, H, W):
     assert torch.equal(p.cpu(), F.max_pool2d(x, 2)) and torch.equal(s.cpu(), x)
     torch.autograd.backward([s, p], [gcat.to(dev)[:, :C], gp.to(dev)])
     assert torch.equal(xd.grad.cpu(), want)
+    # three consumers (the first encoder output is pooled, concatenated and returned)
+    gret = rnd(B, C, H, W, seed=18)
+    xd.grad = None
+    s, p, r = Fn.SkipPoolFn.apply(xd, True)
+    torch.autograd.backward([s, p, r], [gcat.to(dev)[:, :C], gp.to(dev), gret.to(dev)])
+    close(xd.grad, want + gret, tol=1e-6, what="skip + pool + returned")
+    xd.grad = None
+    s, p, r = Fn.SkipPoolFn.apply(xd, True)
+    torch.autograd.backward([p, r], [gp.to(dev), gret.to(dev)])
+    assert torch.equal(xd.grad.cpu(), xr.grad + gret)
     # only one consumer
     xd.grad = None
     s, p = Fn.SkipPoolFn.apply(xd)
