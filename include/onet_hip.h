@@ -107,6 +107,16 @@ int onet_conv3x3_winograd4_fwd(const float* x, int64_t x_bs, const float* wq, fl
 int onet_conv3x3_winograd4_nparts(int B, int H, int W);
 int onet_conv3x3_winograd4_fwd_stats(const float* x, int64_t x_bs, const float* wq, float* z, int64_t z_bs,
                                      float* part, int B, int Cin, int Cout, int H, int W, void* stream);
+/* The F(4x4) input-gradient launch of a Conv-BN-ReLU-Conv chain (OV:47-53: da = dgrad(dz) is the gradient of the
+ * ACTIVATION a = relu(bn(z_prev)) of the convolution below) with the first BatchNorm-backward pass folded into its
+ * epilogue: part2 [Cda][nparts][2] = (sum dy, sum dy * xhat) per 16 x 32-pixel block, dy = da * [a > 0], xhat from
+ * save_prev [B / group_images][4][Cda] (onet_bn_finalize's `save`, one per statistics group of group_images
+ * consecutive images); nparts = onet_conv3x3_winograd4_nparts(B, H, W) (image-major), consumed by
+ * onet_bn_bwd_finalize_cm instead of onet_bn_relu_bwd_reduce + onet_bn_bwd_finalize.  Full blocks only. */
+int onet_conv3x3_winograd4_dgrad_bnreduce(const float* dz, int64_t dz_bs, const float* wq_dgrad, float* da,
+                                          int64_t da_bs, const float* z_prev, int64_t z_prev_bs,
+                                          const float* save_prev, int group_images, float* part2,
+                                          int B, int Cdz, int Cda, int H, int W, void* stream);
 /* Winograd weight gradient: dW = G^T [ sum_tiles (A dY A^T) (.) (B^T d B) ] G, split-K over pixel strips,
  * deterministic slab reduction; dw is [Cout][Cin][3][3]. */
 int onet_conv3x3_winograd_wgrad(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs, float* dw,
@@ -162,6 +172,10 @@ int onet_bn_relu_bwd_reduce(const float* da, int64_t da_bs, const float* z, int6
                             void* stream);
 int onet_bn_bwd_finalize(const float* part2, int nparts, int64_t count, float* dgamma, float* dbeta,
                          float* coef, int accumulate, int C, void* stream);
+/* onet_bn_bwd_finalize for the channel-major two-float records of onet_conv3x3_winograd4_dgrad_bnreduce:
+ * channel c's records are part2[c * c_stride + 2 * p], p < nparts. */
+int onet_bn_bwd_finalize_cm(const float* part2, int nparts, int64_t c_stride, int64_t count, float* dgamma,
+                            float* dbeta, float* coef, int accumulate, int C, void* stream);
 int onet_bn_relu_bwd_apply(const float* da, int64_t da_bs, const float* z, int64_t z_bs,
                            const float* save, const float* coef, float* dz, int64_t dz_bs,
                            int B, int C, int HW, void* stream);

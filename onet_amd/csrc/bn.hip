@@ -253,6 +253,35 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __rest
     }
 }
 
+// the same finalize for the (sum dy, sum dy*xhat) records the F(4x4) dgrad epilogue writes per 16 x 32-pixel block,
+// channel-major: part2[c * c_stride + 2 * p] (fp32 sums over 512 pixels each, merged here in fp64)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_cm_kernel(const float* __restrict__ part2, int nparts,
+                                                                int64_t c_stride, double count, float* dgamma,
+                                                                float* dbeta, float* coef, int accumulate, int C) {
+    __shared__ double red[16];
+    const int c = blockIdx.x;
+    const float2* src = reinterpret_cast<const float2*>(part2 + (int64_t)c * c_stride);
+    double v[2] = {0.0, 0.0};
+    for (int p = threadIdx.x; p < nparts; p += 256) {
+        const float2 o = src[p];
+        v[0] += (double)o.x;
+        v[1] += (double)o.y;
+    }
+    block_sum_256<double, 2>(v, red);
+    if (threadIdx.x == 0) {
+        const double s = v[0], sx = v[1];
+        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s : (float)s;
+        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)sx : (float)sx;
+        if (coef) {
+            const double c1 = s / count, c2 = sx / count;
+            coef[c] = (float)c1;
+            coef[C + c] = (float)(c1 - (double)(float)c1);
+            coef[2 * C + c] = (float)c2;
+            coef[3 * C + c] = (float)(c2 - (double)(float)c2);
+        }
+    }
+}
+
 // backward pass 2: dz = scale * (dy - c1 - xhat*c2)  (train)  |  dz = scale*dy (eval, coef == NULL).
 // Evaluated per element in fp64 and rounded once, as ATen's CPU kernel does (accscalar_t = double):
 // the three terms cancel (strongly when B*H*W per channel is small), so fp32 arithmetic here
@@ -361,6 +390,14 @@ int onet_bn_relu_bwd_reduce(const float* da, int64_t da_bs, const float* z, int6
     hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3((unsigned)((int64_t)nparts * C)), dim3(256), 0,
                        as_stream(stream), da, da_bs, z, z_bs, save, part2, C, HW, chunks, chunk_len);
     return check_launch("bn_relu_bwd_reduce_kernel");
+}
+
+int onet_bn_bwd_finalize_cm(const float* part2, int nparts, int64_t c_stride, int64_t count, float* dgamma, float* dbeta,
+                            float* coef, int accumulate, int C, void* stream) {
+    ONET_REQUIRE(part2 && nparts > 0 && count > 0 && C > 0 && c_stride >= (int64_t)nparts * 2, "bn_bwd_finalize_cm: bad args");
+    hipLaunchKernelGGL(bn_bwd_finalize_cm_kernel, dim3(C), dim3(256), 0, as_stream(stream), part2, nparts, c_stride,
+                       (double)count, dgamma, dbeta, coef, accumulate, C);
+    return check_launch("bn_bwd_finalize_cm_kernel");
 }
 
 int onet_bn_bwd_finalize(const float* part2, int nparts, int64_t count, float* dgamma, float* dbeta, float* coef,

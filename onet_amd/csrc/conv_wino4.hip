@@ -124,7 +124,12 @@ struct Wino4Args {
     float* z;
     int64_t z_bs;
     int B, Cin, Cout, H, W, tilesX, tilesY, imgGroups, coTiles;
-    float* stats;         // ST kernels: BatchNorm partials [Cout][B * tilesX * tilesY][3] = (n, mean, M2) per block
+    float* stats;         // EP 1: BatchNorm partials [Cout][B * tilesX * tilesY][3] = (n, mean, M2) per block
+                          // EP 2: BatchNorm-backward partials [Cout][B * tilesX * tilesY][2] = (sum dy, sum dy * xhat)
+    const float* br_z;    // EP 2: pre-activation of the layer whose activation gradient this launch produces
+    int64_t br_z_bs;
+    const float* br_save; // EP 2: [groups][4][Cout] = (mean, invstd, scale, shift) per statistics group
+    int br_group;         // EP 2: images per statistics group
 };
 
 template <int TXB>
@@ -191,7 +196,7 @@ static __device__ __forceinline__ float half_sum_hi(float v) {
 }
 #undef ONET_DPP_ADD
 
-template <int TXB, int RH, int CH, bool ST = false>
+template <int TXB, int RH, int CH, int EP = 0>
 static __device__ __forceinline__ void wino4_body(const Wino4Args& a, float* smem) {
     using C = W4Cfg<TXB>;
     constexpr int IMG = C::IMG, IN_ROWS = C::IN_ROWS, IN_COLS = C::IN_COLS, RS = C::RS;
@@ -496,6 +501,25 @@ static __device__ __forceinline__ void wino4_body(const Wino4Args& a, float* sme
     constexpr float st_n = (float)(C::PXW * C::PXH), st_inv = 1.f / st_n;   // full blocks only (host-checked)
     const int64_t st_nblk = (int64_t)a.B * a.tilesX * a.tilesY;
     const int64_t st_blk = ((int64_t)bg * a.tilesY + ty) * a.tilesX + tx;
+    // EP 2: this launch is a dgrad whose output is the gradient of the ACTIVATION a = relu(bn(z)) of the layer below
+    // (OV:47-49 -> 51): the first BatchNorm-backward pass (sum dy, sum dy * xhat with dy = da * [a > 0]) is taken here
+    // from the final sums.  The summing waves fetch the z rows and the channel's coefficients ONE PASS AHEAD (the
+    // loads of a pass would otherwise sit on its critical path: +8 % on the launch, measured).
+    float4 zn[4];
+    float cn[4];
+    auto br_issue = [&](int ps_) __attribute__((always_inline)) {
+        if constexpr (EP == 2 && PG < 2) {
+            const int r_ = 2 * ps_ + PG;
+            const int co_ = co0 + wm * 32 + (r_ & 3) + 8 * (r_ >> 2) + 4 * kh;
+            const int cc = co_ < a.Cout ? co_ : 0;
+            const float* sv = a.br_save + (int64_t)(bg / a.br_group) * 4 * a.Cout;
+            cn[0] = sv[cc]; cn[1] = sv[a.Cout + cc]; cn[2] = sv[2 * a.Cout + cc]; cn[3] = sv[3 * a.Cout + cc];
+            const float* zp = a.br_z + (int64_t)bg * a.br_z_bs + (int64_t)cc * HW + (int64_t)oy * a.W + ox;
+#pragma unroll
+            for (int y = 0; y < 4; ++y) zn[y] = *reinterpret_cast<const float4*>(zp + y * a.W);
+        }
+    };
+    br_issue(0);
     // The eight passes run as two rolled halves of four (accumulator registers 8..15 are moved down to 0..7 between
     // them): half the straight-line code.  The kernel's four position-group bodies were 68 KB against a 64 KB
     // instruction cache shared by two CUs, most of it this epilogue.
@@ -537,6 +561,15 @@ static __device__ __forceinline__ void wino4_body(const Wino4Args& a, float* sme
                 constexpr int h = PG;
                 const int r = 2 * ps + h;
                 const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                // EP 2: the z rows and coefficients of this pass were requested one pass ahead (br_issue)
+                float4 zr[4];
+                float br_mean = 0.f, br_inv = 0.f, br_sc = 0.f, br_sh = 0.f;
+                if constexpr (EP == 2) {
+#pragma unroll
+                    for (int y = 0; y < 4; ++y) zr[y] = zn[y];
+                    br_mean = cn[0]; br_inv = cn[1]; br_sc = cn[2]; br_sh = cn[3];
+                    if (ps + 1 < 8) br_issue(ps + 1);
+                }
 #pragma unroll
                 for (int y = 0; y < 4; ++y)
 #pragma unroll
@@ -544,8 +577,8 @@ static __device__ __forceinline__ void wino4_body(const Wino4Args& a, float* sme
                         const float4 v = *reinterpret_cast<const float4*>(ex + ((g * 2 + wm) * 64 + lane) * C::EX_LANE + h * 16 + y * 4);
                         yv[h][y][0] += v.x; yv[h][y][1] += v.y; yv[h][y][2] += v.z; yv[h][y][3] += v.w;
                     }
-                if constexpr (ST) {
-                    static_assert(!ST || IMG == 1, "fused statistics: one image per block");
+                if constexpr (EP == 1) {
+                    static_assert(EP == 0 || IMG == 1, "fused statistics: one image per block");
                     const int piv = __builtin_bit_cast(int, yv[h][0][0]);
                     const float p0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(piv, 0));
                     const float p1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(piv, 32));
@@ -570,6 +603,27 @@ static __device__ __forceinline__ void wino4_body(const Wino4Args& a, float* sme
                         sp[0] = st_n;
                         sp[1] = fmaf(s1, st_inv, pv);
                         sp[2] = fmaxf(fmaf(-s1 * st_inv, s1, s2), 0.f);
+                    }
+                }
+                if constexpr (EP == 2) {
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int y = 0; y < 4; ++y) {
+                        const float zz[4] = {zr[y].x, zr[y].y, zr[y].z, zr[y].w};
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) {
+                            const float zc = zz[x] - br_mean;
+                            const float g = fmaf(zc, br_sc, br_sh) > 0.f ? yv[h][y][x] : 0.f;   // same mask expression as bn_relu_bwd_*
+                            s1 += g;
+                            s2 = fmaf(g, zc, s2);
+                        }
+                    }
+                    s1 = half_sum_hi(s1);
+                    s2 = half_sum_hi(s2) * br_inv;          // xhat = (z - mean) * invstd
+                    if (l31 == 31 && co < a.Cout) {
+                        float* sp = a.stats + ((int64_t)co * st_nblk + st_blk) * 2;
+                        sp[0] = s1;
+                        sp[1] = s2;
                     }
                 }
                 if (co < a.Cout && img_ok && ox < a.W) {
@@ -599,19 +653,19 @@ static __device__ __forceinline__ void wino4_body(const Wino4Args& a, float* sme
     }
 }
 
-template <int TXB, bool ST = false>
+template <int TXB, int EP = 0>
 __global__ __launch_bounds__(512, 2) void conv_wino4_kernel(Wino4Args a) {
     extern __shared__ __attribute__((aligned(16))) float smem4[];
     const int pg = (threadIdx.x >> 6) >> 1;           // wave-uniform
     switch (__builtin_amdgcn_readfirstlane(pg)) {
-        case 0: wino4_body<TXB, 0, 0, ST>(a, smem4); break;
-        case 1: wino4_body<TXB, 0, 1, ST>(a, smem4); break;
-        case 2: wino4_body<TXB, 1, 0, ST>(a, smem4); break;
-        default: wino4_body<TXB, 1, 1, ST>(a, smem4); break;
+        case 0: wino4_body<TXB, 0, 0, EP>(a, smem4); break;
+        case 1: wino4_body<TXB, 0, 1, EP>(a, smem4); break;
+        case 2: wino4_body<TXB, 1, 0, EP>(a, smem4); break;
+        default: wino4_body<TXB, 1, 1, EP>(a, smem4); break;
     }
 }
 
-template <int TXB, bool ST = false>
+template <int TXB, int EP = 0>
 static int launch_wino4(Wino4Args a, hipStream_t st) {
     using C = W4Cfg<TXB>;
     a.tilesX = cdiv(a.W, C::PXW);
@@ -620,7 +674,7 @@ static int launch_wino4(Wino4Args a, hipStream_t st) {
     a.coTiles = cdiv(a.Cout, C::CO_T);
     const int64_t blocks = (int64_t)a.imgGroups * a.tilesX * a.tilesY * a.coTiles;
     ONET_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv_wino4: grid %lld out of range", (long long)blocks);
-    auto kern = conv_wino4_kernel<TXB, ST>;
+    auto kern = conv_wino4_kernel<TXB, EP>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -656,7 +710,7 @@ int onet_conv3x3_winograd4_fwd(const float* x, int64_t x_bs, const float* wq, fl
     ONET_REQUIRE(x_bs >= (int64_t)Cin * H * W && z_bs >= (int64_t)Cout * H * W, "conv3x3_winograd4_fwd: batch stride too small");
     ONET_REQUIRE((x_bs + (int64_t)(Cin + 16) * H * W) * 4 < (1ll << 31) && (int64_t)(Cin + 16) * 36 * Cout * 4 < (1ll << 31),
                  "conv3x3_winograd4_fwd: operand exceeds the 2 GiB buffer-resource range");
-    Wino4Args a{x, x_bs, wq, z, z_bs, B, Cin, Cout, H, W, 0, 0, 0, 0, nullptr};
+    Wino4Args a{x, x_bs, wq, z, z_bs, B, Cin, Cout, H, W, 0, 0, 0, 0, nullptr, nullptr, 0, nullptr, 1};
     return (W > 16) ? launch_wino4<8>(a, as_stream(stream)) : launch_wino4<4>(a, as_stream(stream));
 }
 
@@ -677,8 +731,26 @@ int onet_conv3x3_winograd4_fwd_stats(const float* x, int64_t x_bs, const float* 
     ONET_REQUIRE(x_bs >= (int64_t)Cin * H * W && z_bs >= (int64_t)Cout * H * W, "conv3x3_winograd4_fwd_stats: batch stride too small");
     ONET_REQUIRE((x_bs + (int64_t)(Cin + 16) * H * W) * 4 < (1ll << 31) && (int64_t)(Cin + 16) * 36 * Cout * 4 < (1ll << 31),
                  "conv3x3_winograd4_fwd_stats: operand exceeds the 2 GiB buffer-resource range");
-    Wino4Args a{x, x_bs, wq, z, z_bs, B, Cin, Cout, H, W, 0, 0, 0, 0, part};
-    return launch_wino4<8, true>(a, as_stream(stream));
+    Wino4Args a{x, x_bs, wq, z, z_bs, B, Cin, Cout, H, W, 0, 0, 0, 0, part, nullptr, 0, nullptr, 1};
+    return launch_wino4<8, 1>(a, as_stream(stream));
+}
+
+int onet_conv3x3_winograd4_dgrad_bnreduce(const float* dz, int64_t dz_bs, const float* wq_dgrad, float* da, int64_t da_bs,
+                                          const float* z_prev, int64_t z_prev_bs, const float* save_prev, int group_images,
+                                          float* part2, int B, int Cdz, int Cda, int H, int W, void* stream) {
+    ONET_REQUIRE(dz && wq_dgrad && da && z_prev && save_prev && part2, "conv3x3_winograd4_dgrad_bnreduce: null pointer");
+    ONET_REQUIRE(B > 0 && Cdz > 0 && Cda > 0 && H > 0 && W > 0 && group_images > 0 && (B % group_images) == 0,
+                 "conv3x3_winograd4_dgrad_bnreduce: bad shape");
+    ONET_REQUIRE((W % W4Cfg<8>::PXW) == 0 && (H % W4Cfg<8>::PXH) == 0,
+                 "conv3x3_winograd4_dgrad_bnreduce: W %% 32 == 0 and H %% 16 == 0 required (onet_conv3x3_winograd4_nparts() == 0 elsewhere)");
+    ONET_REQUIRE((Cda & 3) == 0 && (Cdz & 3) == 0, "conv3x3_winograd4_dgrad_bnreduce: channel counts must be multiples of 4");
+    ONET_REQUIRE(dz_bs >= (int64_t)Cdz * H * W && da_bs >= (int64_t)Cda * H * W && z_prev_bs >= (int64_t)Cda * H * W &&
+                     (z_prev_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(z_prev) & 15) == 0,
+                 "conv3x3_winograd4_dgrad_bnreduce: batch stride too small or z_prev not 16-byte aligned");
+    ONET_REQUIRE((dz_bs + (int64_t)(Cdz + 16) * H * W) * 4 < (1ll << 31) && (int64_t)(Cdz + 16) * 36 * Cda * 4 < (1ll << 31),
+                 "conv3x3_winograd4_dgrad_bnreduce: operand exceeds the 2 GiB buffer-resource range");
+    Wino4Args a{dz, dz_bs, wq_dgrad, da, da_bs, B, Cdz, Cda, H, W, 0, 0, 0, 0, part2, z_prev, z_prev_bs, save_prev, group_images};
+    return launch_wino4<8, 2>(a, as_stream(stream));
 }
 
 }  // extern "C"

@@ -13,70 +13,97 @@ from . import ops
 class ConvBNReLUFn(torch.autograd.Function):
     """Conv2d(3x3, pad 1, no bias) -> BatchNorm2d -> ReLU  (OV:47-49 / OV:51-53).
 
-    forward : conv_fwd (MFMA) -> BN statistics (+running-stat update) -> normalise+ReLU
-    backward: BN+ReLU backward (2 passes) -> wgrad (MFMA split-K) -> dgrad (MFMA)"""
+    forward : conv (MFMA; the F(4x4) kernel also emits the BN statistics records) -> finalize -> normalise+ReLU
+    backward: BN+ReLU backward (reduce + apply) -> wgrad (MFMA split-K) -> dgrad (MFMA)
+
+    `link_out` / `link_in`: the dict DoubleConv shares between its two units.  The first unit publishes its
+    pre-activation and BN coefficients in it; the second unit's backward then folds the first unit's BN-backward reduce
+    pass into its own dgrad launch (whose output IS the first unit's `da`) and leaves the records in the dict."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, training, momentum, eps, packed, out, groups=1):
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, training, momentum, eps, packed, out, groups=1,
+                link_out=None, link_in=None):
         ops.require_gpu(x, weight, gamma, beta)
         # training: the F(4x4) kernel emits the BatchNorm statistics records from its epilogue (cm), where it can
         z, cm = ops.conv3x3_fwd_bn_partials(x, packed) if training else (ops.conv3x3_auto(x, packed, 0), None)
         # `out` is None or a 1-tuple holding a plane-contiguous destination view (kept out of autograd's sight)
         dst = None if out is None else out[0]
         G = groups if (training and groups > 1) else 1
+        C = z.shape[1]
+        save_all = torch.empty((G, 4, C), dtype=torch.float32, device=z.device)
         if G == 1:
             if training:
-                save = ops.bn_train_coeffs(z, gamma, beta, running_mean, running_var, momentum, eps,
-                                           cm=None if cm is None else (cm, 0, cm.shape[1]))
+                ops.bn_train_coeffs(z, gamma, beta, running_mean, running_var, momentum, eps,
+                                    cm=None if cm is None else (cm, 0, cm.shape[1]), save=save_all[0])
             else:
-                save = ops.bn_eval_coeffs(gamma, beta, running_mean, running_var, eps)
-            a = ops.bn_relu_apply(z, save, out=dst)
-            saves = (save,)
+                ops.bn_eval_coeffs(gamma, beta, running_mean, running_var, eps, save=save_all[0])
+            a = ops.bn_relu_apply(z, save_all[0], out=dst)
         else:
             # twin batch: the G batch slices are separate BatchNorm batches (own statistics, running stats updated
             # slice after slice, exactly as G consecutive forward passes would)
             B = z.shape[0]
             Bg = B // G
             a = dst if dst is not None else torch.empty_like(z)
-            saves = []
             for g in range(G):
                 zg = z[g * Bg:(g + 1) * Bg]
                 npg = 0 if cm is None else cm.shape[1] // G
-                sv = ops.bn_train_coeffs(zg, gamma, beta, running_mean, running_var, momentum, eps,
-                                         cm=None if cm is None else (cm, g * npg, npg))
-                ops.bn_relu_apply(zg, sv, out=a[g * Bg:(g + 1) * Bg])
-                saves.append(sv)
-        ctx.save_for_backward(x, z, *saves)
+                ops.bn_train_coeffs(zg, gamma, beta, running_mean, running_var, momentum, eps,
+                                    cm=None if cm is None else (cm, g * npg, npg), save=save_all[g])
+                ops.bn_relu_apply(zg, save_all[g], out=a[g * Bg:(g + 1) * Bg])
+        ctx.save_for_backward(x, z, save_all)
         ctx.training = training
         ctx.packed = packed
         ctx.wshape = tuple(weight.shape)
         ctx.params = (weight, gamma, beta)          # for ops.grad_slot_if_free in backward
+        ctx.link_out = ctx.link_in = None
+        if training and link_out is not None:
+            link_out.clear()
+            link_out.update(z=z, save=save_all)
+            ctx.link_out = link_out
+        if training and link_in is not None and "z" in link_in:
+            ctx.link_in = link_in
         return a
 
     @staticmethod
     def backward(ctx, da):
-        x, z = ctx.saved_tensors[:2]
-        saves = ctx.saved_tensors[2:]
+        x, z, save_all = ctx.saved_tensors
         need_x, need_w, need_g, need_b = ctx.needs_input_grad[:4]
         pw, pg, pb = ctx.params
         aff = (ops.grad_slot_if_free(pg) if need_g else None, ops.grad_slot_if_free(pb) if need_b else None)
-        G = len(saves)
+        G = save_all.shape[0]
+        # the reduce records of THIS layer, if the unit above wrote them while producing exactly this `da`
+        rec = None
+        lk = ctx.link_out
+        if lk is not None and "rec" in lk:
+            rda, rec = lk.pop("da"), lk.pop("rec")
+            if rda.data_ptr() != da.data_ptr() or rda.shape != da.shape or rda.stride() != da.stride():
+                rec = None                          # autograd handed over something else (another consumer, a hook)
         if G == 1:
-            dz, dgamma, dbeta = ops.bn_relu_bwd(da, z, saves[0], ctx.training, need_affine_grads=(need_g or need_b),
-                                                affine_out=aff)
+            dz, dgamma, dbeta = ops.bn_relu_bwd(da, z, save_all[0], ctx.training, need_affine_grads=(need_g or need_b),
+                                                affine_out=aff, red=None if rec is None else (rec, 0, rec.shape[1]))
         else:
             Bg = z.shape[0] // G
             dz = torch.empty_like(z)
             dgamma = dbeta = None
             for g in range(G):
                 sl = slice(g * Bg, (g + 1) * Bg)
-                _, dgamma, dbeta = ops.bn_relu_bwd(da[sl], z[sl], saves[g], ctx.training, need_affine_grads=True,
+                npg = 0 if rec is None else rec.shape[1] // G
+                _, dgamma, dbeta = ops.bn_relu_bwd(da[sl], z[sl], save_all[g], ctx.training, need_affine_grads=True,
                                                    out=dz[sl], acc=None if g == 0 else (dgamma, dbeta),
-                                                   affine_out=aff if g == 0 else None)
+                                                   affine_out=aff if g == 0 else None,
+                                                   red=None if rec is None else (rec, g * npg, npg))
         dw = ops.conv3x3_wgrad_auto(x, dz, ctx.wshape, out=ops.grad_slot_if_free(pw)) if need_w else None
-        dx = ops.conv3x3_auto(dz, ctx.packed, 1) if need_x else None
+        dx = None
+        if need_x:
+            lk = ctx.link_in
+            fused = ops.conv3x3_dgrad_bnreduce(dz, ctx.packed, lk["z"], lk["save"]) if lk is not None else None
+            if fused is not None:
+                dx, r = fused
+                lk["da"], lk["rec"] = dx, r
+            else:
+                dx = ops.conv3x3_auto(dz, ctx.packed, 1)
         return (dx, dw, (dgamma if need_g else None), (dbeta if need_b else None), None, None, None, None, None, None,
-                None, None)
+                None, None, None, None)
 
 
 class Conv3x3Fn(torch.autograd.Function):

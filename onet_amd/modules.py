@@ -106,7 +106,7 @@ class DoubleConv(nn.Module):
         )
 
     @staticmethod
-    def _unit(x, conv, bn, out=None, groups=1):
+    def _unit(x, conv, bn, out=None, groups=1, link_out=None, link_in=None):
         training = bn.training or (bn.running_mean is None)
         if x.dim() != 4:
             raise ValueError(f"expected 4D input (got {x.dim()}D input)")
@@ -119,13 +119,15 @@ class DoubleConv(nn.Module):
         if training and bn.track_running_stats:
             bn.num_batches_tracked.add_(groups)
         return Fn.ConvBNReLUFn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                     training, bn.momentum, bn.eps, conv.packed(), out, groups)
+                                     training, bn.momentum, bn.eps, conv.packed(), out, groups, link_out, link_in)
 
     def forward(self, x, out=None, groups=1):
         """`out`: optional plane-contiguous [B, Cout, H, W] destination view (the skip half of a concat buffer);
         `groups`: the batch holds that many independent BatchNorm batches (twin pass)."""
         s = self.double_conv
-        return self._unit(self._unit(x, s[0], s[1], None, groups), s[3], s[4], None if out is None else (out,), groups)
+        link = {}       # unit 1 -> unit 2: lets unit 2's dgrad launch take unit 1's BatchNorm-backward reduce pass with it
+        a1 = self._unit(x, s[0], s[1], None, groups, link_out=link)
+        return self._unit(a1, s[3], s[4], None if out is None else (out,), groups, link_in=link)
 
 
 _SKIPPOOL = os.environ.get("ONET_SKIPPOOL", "1") != "0"

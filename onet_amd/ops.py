@@ -227,6 +227,39 @@ def conv3x3_fwd_bn_partials(x, pk):
     return out, cm
 
 
+FUSE_BN_REDUCE = _os.environ.get("ONET_FUSE_BN_REDUCE", "1") != "0"
+
+
+def conv3x3_dgrad_bnreduce(dz, pk, z_prev, save_prev):
+    """Input gradient of the second convolution of a Conv-BN-ReLU-Conv chain (OV:47-53) with the first BatchNorm-backward
+    pass of the layer BELOW folded into the epilogue: -> (da, records [Cin, nparts, 2]) or None where the F(4x4) kernel
+    is not the one selected / the map is not made of full blocks.  save_prev: [G, 4, Cin] coefficients of the G
+    statistics groups (consecutive batch slices) of the layer below; z_prev its pre-activation."""
+    if not FUSE_BN_REDUCE or SYNC_BN:
+        return None
+    Ci, Co = pk["Cout"], pk["Cin"]                       # dgrad: Cout -> Cin
+    B, _, H, W = dz.shape
+    if conv3x3_algo(B, Ci, Co, H, W) != "winograd4":
+        return None
+    nparts = int(_lib.load().onet_conv3x3_winograd4_nparts(B, H, W))
+    G = save_prev.shape[0]
+    if nparts <= 0 or B % G or tuple(z_prev.shape) != (B, Co, H, W) or not save_prev.is_contiguous():
+        return None
+    z_prev, zbs = plane(z_prev)
+    if (zbs & 3) or (z_prev.data_ptr() & 15):
+        return None
+    wq = pk.get_pack("winograd4")[1]
+    require_gpu(dz, wq, z_prev, save_prev)
+    dz, dbs = plane(dz)
+    da = torch.empty((B, Co, H, W), dtype=F32, device=dz.device)
+    rec = torch.empty((Co, nparts, 2), dtype=F32, device=dz.device)
+    e0 = _prof_begin()
+    _lib.call("onet_conv3x3_winograd4_dgrad_bnreduce", _p(dz), dbs, _p(wq), _p(da), Co * H * W, _p(z_prev), zbs,
+              _p(save_prev), B // G, _p(rec), B, Ci, Co, H, W, _stream())
+    _prof_end("conv_wino4_kernel", 2.0 * B * H * W * Ci * Co * 9, e0)
+    return da, rec
+
+
 def pack3x3_winograd(w):
     require_gpu(w)
     w = w.detach().contiguous()
@@ -371,7 +404,7 @@ def _bn_nparts(B, HW):
     return B * max(1, (HW + 16383) // 16384)
 
 
-def bn_train_coeffs(z, gamma, beta, running_mean, running_var, momentum, eps, cm=None):
+def bn_train_coeffs(z, gamma, beta, running_mean, running_var, momentum, eps, cm=None, save=None):
     """batch statistics -> save [4][C] = (mean, invstd, scale, shift); updates running stats in place.
     `cm` = (records [C, NP, 3], first, count): the convolution already produced this batch's statistics records
     (`conv3x3_fwd_bn_partials`), records first .. first+count-1 of every channel belong to `z`."""
@@ -382,7 +415,8 @@ def bn_train_coeffs(z, gamma, beta, running_mean, running_var, momentum, eps, cm
     if cm is not None:
         rec, first, count = cm
         assert rec.shape[0] == C and rec.shape[2] == 3 and 0 <= first and first + count <= rec.shape[1]
-        save = torch.empty((4, C), dtype=F32, device=z.device)
+        if save is None:
+            save = torch.empty((4, C), dtype=F32, device=z.device)
         _lib.call("onet_bn_finalize_cm", rec.data_ptr() + first * 12, count, rec.shape[1] * 3, _p(gamma), _p(beta),
                   _p(running_mean), _p(running_var), float(momentum), float(eps), _p(save), C, _stream())
         return save
@@ -391,15 +425,17 @@ def bn_train_coeffs(z, gamma, beta, running_mean, running_var, momentum, eps, cm
     _lib.call("onet_bn_stats_partial", _p(z), zbs, _p(part), nparts, B, C, H * W, _stream())
     part, world = _gather_partials(part)
     nparts *= world
-    save = torch.empty((4, C), dtype=F32, device=z.device)
+    if save is None:
+        save = torch.empty((4, C), dtype=F32, device=z.device)
     _lib.call("onet_bn_finalize", _p(part), nparts, B * H * W * world, _p(gamma), _p(beta), _p(running_mean),
               _p(running_var), float(momentum), float(eps), _p(save), C, _stream())
     return save
 
 
-def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
+def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps, save=None):
     C = running_mean.numel()
-    save = torch.empty((4, C), dtype=F32, device=running_mean.device)
+    if save is None:
+        save = torch.empty((4, C), dtype=F32, device=running_mean.device)
     _lib.call("onet_bn_eval_coeffs", _p(gamma), _p(beta), _p(running_mean), _p(running_var), float(eps), _p(save),
               C, _stream())
     return save
@@ -415,10 +451,12 @@ def bn_relu_apply(z, save, out=None):
     return out
 
 
-def bn_relu_bwd(da, z, save, training, need_affine_grads=True, out=None, acc=None, affine_out=None):
+def bn_relu_bwd(da, z, save, training, need_affine_grads=True, out=None, acc=None, affine_out=None, red=None):
     """-> dz, dgamma, dbeta.  `out`: plane-contiguous destination for dz (a batch slice of a larger buffer);
     `acc` = (dgamma, dbeta) of another statistics group of the same layer to accumulate into; `affine_out` =
-    (dgamma, dbeta) destinations to overwrite (None entries are allocated)."""
+    (dgamma, dbeta) destinations to overwrite (None entries are allocated); `red` = (records [C, NP, 2], first, count):
+    the (sum dy, sum dy*xhat) records of this batch slice were already written by the dgrad launch that produced
+    `da` (`conv3x3_dgrad_bnreduce`), so the reduce pass over (da, z) is skipped."""
     da, dabs = plane(da)
     z, zbs = plane(z)
     B, C, H, W = z.shape
@@ -426,7 +464,19 @@ def bn_relu_bwd(da, z, save, training, need_affine_grads=True, out=None, acc=Non
     nparts = _bn_nparts(B, HW)
     dev = z.device
     dgamma = dbeta = coef = None
-    if training or need_affine_grads:
+    if red is not None and (training or need_affine_grads):
+        rec, first, count = red
+        assert rec.shape[0] == C and rec.shape[2] == 2 and 0 <= first and first + count <= rec.shape[1]
+        if acc is None:
+            og, ob = affine_out if affine_out is not None else (None, None)
+            dgamma = torch.empty(C, dtype=F32, device=dev) if og is None else og
+            dbeta = torch.empty(C, dtype=F32, device=dev) if ob is None else ob
+        else:
+            dgamma, dbeta = acc
+        coef = torch.empty((4, C), dtype=F32, device=dev) if training else None
+        _lib.call("onet_bn_bwd_finalize_cm", rec.data_ptr() + first * 8, count, rec.shape[1] * 2, B * HW, _p(dgamma),
+                  _p(dbeta), _p(coef), 0 if acc is None else 1, C, _stream())
+    elif training or need_affine_grads:
         part2 = torch.empty((nparts, C, 4), dtype=F32, device=dev)
         _lib.call("onet_bn_relu_bwd_reduce", _p(da), dabs, _p(z), zbs, _p(save), _p(part2), nparts, B, C, HW, _stream())
         if acc is None:

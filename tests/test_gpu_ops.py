@@ -233,6 +233,59 @@ def test_winograd4_fused_bn_statistics(dev, B, Cin, Cout, H, W):
         assert float(((s1[1].cpu().double() - ir) / ir).abs().max()) <= 1e-5
 
 
+@pytest.mark.parametrize("B,Cin,Cmid,Cout,H,W,G", [(4, 8, 64, 32, 32, 32, 1), (4, 16, 72, 64, 32, 64, 2),
+                                                    (2, 16, 24, 16, 48, 32, 1)])
+def test_double_conv_fused_bn_backward_reduce(dev, B, Cin, Cmid, Cout, H, W, G, monkeypatch):
+    """DoubleConv (OV:39-58) under forced F(4x4): unit 2's dgrad launch also writes unit 1's BatchNorm-backward reduce
+    records (sum dy, sum dy*xhat per 16 x 32 block).  (a) the records against fp64 sums of the same quantities;
+    (b) every gradient of the block against the unfused path (separate reduce kernel), one and two statistics groups."""
+    from onet_amd import ops, modules
+    monkeypatch.setattr(ops, "CONV_ALGO", "winograd4")
+    torch.manual_seed(5)
+    m = modules.DoubleConv(Cin, Cout, Cmid).to(dev)
+    with torch.no_grad():
+        for bn in (m.double_conv[1], m.double_conv[4]):
+            bn.weight.copy_(1 + 0.2 * rnd(bn.weight.numel(), seed=41))
+            bn.bias.copy_(0.2 * rnd(bn.bias.numel(), seed=42))
+    x = rnd(B, Cin, H, W, seed=43).to(dev)
+    gy = rnd(B, Cout, H, W, seed=44).to(dev)
+
+    def run(fuse):
+        monkeypatch.setattr(ops, "FUSE_BN_REDUCE", fuse)
+        m.zero_grad()
+        xd = x.clone().requires_grad_(True)
+        y = m(xd, groups=G)
+        y.backward(gy)
+        return [xd.grad.clone()] + [p.grad.clone() for p in m.parameters()]
+
+    seen = []
+    real = ops.conv3x3_dgrad_bnreduce
+    monkeypatch.setattr(ops, "conv3x3_dgrad_bnreduce", lambda *a: seen.append(real(*a)) or seen[-1])
+    fused, plain = run(True), run(False)
+    assert seen and seen[0] is not None, "the fused dgrad launch was not taken"
+    for i, (a, b) in enumerate(zip(fused, plain)):
+        close(a, b, tol=2e-5, what=f"fused vs separate reduce, tensor {i}")
+    # (a) records vs fp64
+    da, rec = seen[0]
+    link_z = {}
+    monkeypatch.setattr(ops, "FUSE_BN_REDUCE", False)
+    s = m.double_conv
+    with torch.no_grad():
+        z1 = ops.conv3x3_auto(x, s[0].packed(), 0)
+    Bg = B // G
+    tot = rec.double().cpu().reshape(Cmid, G, -1, 2).sum(2)              # [C, G, 2]
+    for g in range(G):
+        zg = z1[g * Bg:(g + 1) * Bg].double().cpu()
+        mean = zg.mean((0, 2, 3), keepdim=True)
+        inv = 1.0 / torch.sqrt(zg.var((0, 2, 3), unbiased=False, keepdim=True) + s[1].eps)
+        xh = (zg - mean) * inv
+        act = xh * s[1].weight.double().cpu().view(1, -1, 1, 1) + s[1].bias.double().cpu().view(1, -1, 1, 1)
+        dy = da[g * Bg:(g + 1) * Bg].double().cpu() * (act > 0)
+        scale = float(dy.abs().sum((0, 2, 3)).max())
+        assert float((tot[:, g, 0] - dy.sum((0, 2, 3))).abs().max()) <= 2e-5 * scale
+        assert float((tot[:, g, 1] - (dy * xh).sum((0, 2, 3))).abs().max()) <= 2e-5 * scale * float(xh.abs().max())
+
+
 @pytest.mark.parametrize("B,C,H,W", [(2, 3, 8, 8), (3, 5, 7, 9), (2, 4, 16, 12), (1, 2, 6, 10)])
 def test_skip_pool(dev, B, C, H, W):
     """A skip tensor feeds both the pooling (OV:67) and the concat (OV:100): SkipPoolFn sums the two gradients inside
