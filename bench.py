@@ -21,6 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (no sparsity)
 PMC_JSON = os.path.join(ROOT, "profiles", "pmc_bench_latest.json")   # written by tools/pmc_parse.py
 
 
@@ -76,6 +77,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU (weak scaling)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--chans", type=int, default=1)
+    ap.add_argument("--conv", default=None, choices=["auto", "bf16", "winograd4", "winograd", "direct"],
+                    help="ops.CONV_ALGO for this run (default: ONET_CONV_ALGO or auto = the fp32 kernels); bf16 = BASELINE "
+                         "config 3's bf16-operand MFMA path for forward / input gradient")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam instead of the fused flat Adam")
@@ -88,6 +92,9 @@ def main():
     from onet_amd import data as odata
     from onet_amd.trainer import FlatAdam, init_distributed, train_step
     _lib.load()                      # fail loudly without the HIP library
+    if args.conv:
+        ops.CONV_ALGO = args.conv
+    bf16 = ops.CONV_ALGO == "bf16"
 
     rank, world, local = init_distributed("nccl")
     if world != args.gpus:
@@ -120,6 +127,7 @@ def main():
         train_step(onet, opt, X)
     barrier()
     ops.PROFILE = {}
+    dev_allocs0 = int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = train_step(onet, opt, X)
@@ -147,30 +155,38 @@ def main():
                                      "peak, which the SQ_VALU_MFMA_BUSY_CYCLES profile under profiles/ confirms)",
                 "conv_wino_wgrad_kernel": "Winograd F(2x2,3x3) weight gradient on fp32 MFMA: achieved = direct-convolution "
                                           "FLOPs / time (2.25x fewer MFMA FLOPs issued)",
+                "conv3x3_bf16_kernel": "direct implicit GEMM, bf16 operands (rounded on the way into LDS) on "
+                                       "v_mfma_f32_32x32x16_bf16, fp32 accumulation; peak = dense bf16 MFMA",
                 "conv_fwd_kernel": "direct implicit GEMM on fp32 MFMA", "conv_wgrad_kernel": "split-K MFMA wgrad"}
         # multiplies the algorithm issues relative to direct convolution: F(4x4,3x3) 36 per 16 outputs x 9 taps -> 1/4,
         # F(2x2,3x3) 16 per 4 x 9 -> 1/2.25
         reduction = {"conv_wino4_kernel": 4.0, "conv_wino_kernel": 2.25, "conv_wino_wgrad_kernel": 2.25}.get(dom, 1.0)
-        roofline = {"kernel": dom, "bound": "mfma", "achieved": kern[dom]["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4),
+        peak = BF16_MFMA_PEAK_TFLOPS if dom == "conv3x3_bf16_kernel" else FP32_MFMA_PEAK_TFLOPS
+        roofline = {"kernel": dom, "bound": "mfma", "achieved": kern[dom]["tflops"], "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / peak, 4),
                     "traffic": pmc_traffic(dom), "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc, profiles/)",
                     "mfma_flop_reduction": reduction,
-                    "hardware_frac": round(kern[dom]["tflops"] / reduction / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "hardware_frac": round(kern[dom]["tflops"] / reduction / peak, 4),
                     "launches_timed": kern[dom]["launches"], "avg_launch_ms": kern[dom]["avg_ms"], "algorithm": algo.get(dom, dom),
                     "all": kern}
         imgs = args.batch * world * args.steps
         out = {"metric": "training images/sec (twin 256x256 pass)", "value": round(imgs / elapsed, 3),
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "configs[1]: batch=%d/GPU %dx%dx%d synthetic K-clutter, fp32, twin U-Net "
-                                      "fwd+JSD loss+bwd+Adam" % (args.batch, args.chans, args.size, args.size),
+               "vs_baseline": None, "dtype": "bf16 conv operands (fwd/dgrad), f32 accumulate/storage/wgrad" if bf16 else "f32",
+               "data": "synthetic",
+               "config": {"workload": "%s: batch=%d/GPU %dx%dx%d synthetic K-clutter, %s, twin U-Net "
+                                      "fwd+JSD loss+bwd+Adam" % ("configs[2]" if bf16 else "configs[1]", args.batch, args.chans,
+                                                                 args.size, args.size, "bf16 MFMA conv path" if bf16 else "fp32"),
                           "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                           "optimizer": "torch.optim.Adam" if args.torch_adam else "fused flat Adam (HIP)",
                           "grad_allreduce": ("none (1 process)" if not distributed else
                                              "%g MB buckets overlapped with backward" % args.bucket_mb if overlap
                                              else "single all-reduce after backward")},
                "loss": loss_val, "hbm_peak_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
+               "hbm_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 2),
+               "alloc_retries": int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0)),
+               "device_allocs_in_timed_steps": int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0)) - dev_allocs0,
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(X_cpu, args.cpu_seconds)

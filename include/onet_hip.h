@@ -117,6 +117,19 @@ int onet_conv3x3_winograd4_dgrad_bnreduce(const float* dz, int64_t dz_bs, const 
                                           int64_t da_bs, const float* z_prev, int64_t z_prev_bs,
                                           const float* save_prev, int group_images, float* part2,
                                           int B, int Cdz, int Cda, int H, int W, void* stream);
+/* BASELINE config 3's "bf16 MFMA conv path" for the same call sites (OV:47,51; forward and input gradient): bf16
+ * OPERANDS on v_mfma_f32_32x32x16_bf16, fp32 tensors in HBM, fp32 accumulation.  The activations are rounded to bf16
+ * (nearest-even) on their way into LDS, the weights once per optimizer step by the pack: wq_fwd [Cin/16][9][Cout][16],
+ * wq_dgrad [Cout/16][9][Cin][16] (taps rotated), both bf16.  Requires Cin % 16 == 0 and Cout % 4 == 0 in the
+ * orientation of the call.  Result == an fp32 convolution of the bf16-rounded operands up to summation order. */
+int onet_conv3x3_pack_weights_bf16(const float* w, void* wq_fwd, void* wq_dgrad, int Cout, int Cin, void* stream);
+int onet_conv3x3_bf16_fwd(const float* x, int64_t x_bs, const void* wq, float* z, int64_t z_bs,
+                          int B, int Cin, int Cout, int H, int W, void* stream);
+/* ... and the weight gradient of the same layers with bf16 operands (x and dz rounded on the way into LDS, fp32
+ * accumulation, deterministic split-K): dw [Cout][Cin][3][3] fp32.  W % 4 == 0. */
+int64_t onet_conv3x3_wgrad_bf16_ws_bytes(int B, int Cin, int Cout, int H, int W);
+int onet_conv3x3_wgrad_bf16(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs, float* dw, void* ws,
+                            int64_t ws_bytes, int B, int Cin, int Cout, int H, int W, int accumulate, void* stream);
 /* Winograd weight gradient: dW = G^T [ sum_tiles (A dY A^T) (.) (B^T d B) ] G, split-K over pixel strips,
  * deterministic slab reduction; dw is [Cout][Cin][3][3]. */
 int onet_conv3x3_winograd_wgrad(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs, float* dw,

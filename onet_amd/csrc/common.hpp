@@ -47,4 +47,8 @@ __device__ __forceinline__ void block_sum_256(T (&v)[NV], T* smem /* >= 4*NV */)
     }
 }
 
+// conv_mfma.hip: dw (+)= sum_k slab[k][tap][co][ci] in the nn.Module layout (deterministic split-K reduction)
+int launch_wgrad_reduce(const float* slab, float* dw, int splitK, int taps, int Cout, int Cin, int out_layout, int accumulate,
+                        hipStream_t st);
+
 }  // namespace onet

@@ -1,0 +1,452 @@
+// 3x3 convolution forward + dgrad with bf16 operands on the gfx950 matrix cores (v_mfma_f32_32x32x16_bf16),
+// fp32 tensors in HBM, fp32 accumulation: BASELINE config 3's "bf16 MFMA conv path" for F.conv2d / its input
+// gradient at OV:47,51.  Selected only by ONET_CONV_ALGO=bf16 (the fp32 kernels stay the default: the headline metric
+// is an fp32 one).
+//
+// GEMM view as in conv_mfma.hip: D[co][pix] = sum_{tap, ci} W[ci][tap][co] * X[ci][pix + tap], M = output channels,
+// N = 32 consecutive pixels of an image row, K = 16 input channels per MFMA.  What bf16 changes:
+//  * an MFMA operand is 8 bf16 = 16 bytes per lane (A lane l -> A[i = l&31][k = 8*(l>>5) .. +7], B likewise), i.e. the
+//    8 K-values of a lane are 8 CHANNELS of one pixel / one output channel.  The LDS tiles are therefore
+//    channel-innermost: input halo tile [row][col][16 ch] bf16 (32 B per pixel), weights [tap][co][16 ch]; a fragment
+//    is ONE ds_read_b128 per lane, the 64 lanes of a wave covering 2 KB contiguously (conflict-free);
+//  * the fp32 -> bf16 conversion (v_cvt_pk_bf16_f32, round-to-nearest-even) happens on the way into LDS: a staging
+//    thread gathers the 8 channel planes of ONE pixel (8 dword loads, each coalesced along x across the wave), packs
+//    them and stores 16 bytes; weights are packed to bf16 once per optimizer step (onet_conv3x3_pack_weights_bf16);
+//  * per 16-channel chunk a wave issues 9 taps x (2 A + NT B) ds_read_b128 for 9 x 2 x NT MFMAs of 32 cycles
+//    (NT = 2 image rows per wave: 64 accumulator registers, two 4-wave blocks per CU).
+// Requires Cin % 16 == 0 (K never straddles a chunk) and W > 16; everything else takes the fp32 kernels.
+#include <algorithm>
+#include <cstdlib>
+#include "common.hpp"
+
+using namespace onet;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4b __attribute__((ext_vector_type(4)));
+typedef float f32x4b __attribute__((ext_vector_type(4)));
+
+constexpr unsigned OOB_B = 0x80000000u;
+
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t b_rsrc(const void* base, int64_t bytes) {
+    const int n = bytes > 0x7fffffffll ? 0x7fffffff : (int)bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000);
+}
+static __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+
+// w [Cout][Cin][3][3] fp32 -> wf [Cin/16][9][Cout][16] bf16 (forward), wd [Cout16/16][9][Cin][16] bf16 with the taps
+// rotated by 180 degrees (input gradient = the same kernel with the roles of Cin and Cout swapped); the channel tail
+// of wd (Cout % 16 != 0) is zero-filled
+__global__ void pack3x3_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wf, __bf16* __restrict__ wd,
+                                    int Cout, int Cin, int which) {
+    const int K = which == 0 ? Cin : ((Cout + 15) / 16) * 16, N = which == 0 ? Cout : Cin;
+    const int64_t n = (int64_t)K * 9 * N;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int kc = (int)(i & 15);
+        int64_t r = i >> 4;
+        const int nn = (int)(r % N);
+        r /= N;
+        const int t = (int)(r % 9), kg = (int)(r / 9);
+        const int k = kg * 16 + kc;
+        float v = 0.f;
+        if (which == 0) v = w[((int64_t)nn * Cin + k) * 9 + t];
+        else if (k < Cout) v = w[((int64_t)k * Cin + nn) * 9 + (8 - t)];
+        (which == 0 ? wf : wd)[i] = (__bf16)v;
+    }
+}
+
+struct BfArgs {
+    const float* x;
+    int64_t x_bs;
+    const __bf16* wq;     // [Cin/16][9][Cout][16]
+    float* z;
+    int64_t z_bs;
+    int B, Cin, Cout, H, W, tilesX, tilesY, coTiles;
+};
+
+template <int NT>
+struct BfCfg {
+    static constexpr int CO_T = 64, ROWS = 4 * NT, TW = 32;            // 4 waves x NT image rows of 32 pixels
+    static constexpr int IN_ROWS = ROWS + 2, IN_COLS = TW + 2;
+    static constexpr int IN_ITEMS = IN_ROWS * IN_COLS * 2;            // (pixel, 8-channel half) = one 16-byte LDS slot
+    static constexpr int NIT = (IN_ITEMS + 255) / 256;
+    static constexpr int W_ITEMS = 9 * CO_T * 2;                       // 16-byte slots of the weight slice
+    static constexpr int NWI = (W_ITEMS + 255) / 256;
+    static constexpr int LDS_BYTES = (IN_ITEMS + W_ITEMS) * 16;
+};
+
+template <int NT, int WPS>
+__global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
+    using C = BfCfg<NT>;
+    constexpr int ROWS = C::ROWS, IN_COLS = C::IN_COLS, NIT = C::NIT, NWI = C::NWI, CO_T = C::CO_T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    u32x4b* w_lds = reinterpret_cast<u32x4b*>(smem_b);                 // [9][64 co][2 halves]
+    u32x4b* in_lds = w_lds + C::W_ITEMS;                               // [IN_ROWS][IN_COLS][2 halves]
+
+    int bid;
+    {   // XCD-aware tile order (see conv_mfma.hip)
+        const int n = gridDim.x, q = n >> 3, r = n & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int tx = bid % a.tilesX;
+    bid /= a.tilesX;
+    const int ty = bid % a.tilesY;
+    bid /= a.tilesY;
+    const int b = bid % a.B;
+    const int coT = bid / a.B;
+    const int co0 = coT * CO_T, y0 = ty * ROWS, x0 = tx * 32;
+
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int HW = a.H * a.W;
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const __amdgpu_buffer_rsrc_t xr = b_rsrc(a.x + (int64_t)b * a.x_bs, (int64_t)a.Cin * HW * 4);
+    const __amdgpu_buffer_rsrc_t wr = b_rsrc(a.wq, (int64_t)a.Cin * 9 * a.Cout * 2);
+
+    // staging slots of this thread: (pixel, half) -> 8 channel planes; byte offset of channel 0 of the half
+    unsigned in_off[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int i = tid + 256 * k;
+        const int half = i & 1, p = i >> 1;
+        const int r = p / IN_COLS, c = p % IN_COLS;
+        const int yy = y0 - 1 + r, xx = x0 - 1 + c;
+        const bool ok = (i < C::IN_ITEMS) && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+        in_off[k] = ok ? (unsigned)(((half * 8) * HW + yy * a.W + xx) * 4) : OOB_B;
+    }
+    // weight slots: (tap, co, half) -> 16 bytes of the packed slice [chunk][tap][co][16]
+    unsigned w_off[NWI];
+#pragma unroll
+    for (int k = 0; k < NWI; ++k) {
+        const int i = tid + 256 * k;
+        const int half = i & 1, co = (i >> 1) % CO_T, t = (i >> 1) / CO_T;
+        const bool ok = (i < C::W_ITEMS) && (co0 + co < a.Cout);
+        w_off[k] = ok ? (unsigned)(((t * a.Cout + co0 + co) * 16 + half * 8) * 2) : OOB_B;
+    }
+    const unsigned in_step = (unsigned)(16 * HW * 4), w_step = (unsigned)(9 * a.Cout * 16 * 2);
+    const unsigned plane = (unsigned)(HW * 4);
+
+    float xin[NIT][8];
+    u32x4b wv[NWI];
+    auto issue = [&](unsigned cin_bytes, unsigned cw_bytes) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k)
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                xin[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                          xr, in_off[k] + cin_bytes + c * plane, 0, 0));   // OOB_B + anything stays out of range -> 0
+#pragma unroll
+        for (int k = 0; k < NWI; ++k)
+            wv[k] = __builtin_amdgcn_raw_buffer_load_b128(wr, w_off[k] + cw_bytes, 0, 0);
+    };
+    auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int i = tid + 256 * k;
+            if (i < C::IN_ITEMS) {
+                u32x4b v = {pack_bf16(xin[k][0], xin[k][1]), pack_bf16(xin[k][2], xin[k][3]),
+                            pack_bf16(xin[k][4], xin[k][5]), pack_bf16(xin[k][6], xin[k][7])};
+                in_lds[i] = v;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NWI; ++k) {
+            const int i = tid + 256 * k;
+            if (i < C::W_ITEMS) w_lds[i] = wv[k];
+        }
+    };
+
+    const u32x4b* a_ptr = w_lds + l31 * 2 + kh;                                   // + (tap * 64 + m * 32) * 2
+    const u32x4b* b_ptr = in_lds + ((wn * NT) * IN_COLS + l31) * 2 + kh;          // + ((n + ky) * IN_COLS + kx) * 2
+
+    unsigned cin_bytes = 0, cw_bytes = 0;
+    issue(0, 0);
+    for (int c0 = 0; c0 < a.Cin; c0 += 16) {
+        commit();
+        __syncthreads();
+        cin_bytes += in_step;
+        cw_bytes += w_step;
+        issue(cin_bytes, cw_bytes);                  // next chunk (past the end: range check -> zeros, no traffic)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ky = t / 3, kx = t % 3;
+            bf16x8 av[2], bv[NT];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) av[m] = __builtin_bit_cast(bf16x8, a_ptr[(t * CO_T + m * 32) * 2]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bv[n] = __builtin_bit_cast(bf16x8, b_ptr[((n + ky) * IN_COLS + kx) * 2]);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m], bv[n], acc[m][n], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    float* zb = a.z + (int64_t)b * a.z_bs;
+    const int xo = x0 + l31;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int yo = y0 + wn * NT + n;
+            if (yo < a.H && xo < a.W) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    if (co < a.Cout) zb[(int64_t)co * HW + (int64_t)yo * a.W + xo] = acc[m][n][r];
+                }
+            }
+        }
+}
+
+template <int NT, int WPS>
+static int launch_bf16(BfArgs a, hipStream_t st) {
+    using C = BfCfg<NT>;
+    a.tilesX = cdiv(a.W, 32);
+    a.tilesY = cdiv(a.H, C::ROWS);
+    a.coTiles = cdiv(a.Cout, C::CO_T);
+    const int64_t blocks = (int64_t)a.B * a.tilesX * a.tilesY * a.coTiles;
+    ONET_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv3x3_bf16: grid %lld out of range", (long long)blocks);
+    auto kern = conv3x3_bf16_kernel<NT, WPS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, st, a);
+    return check_launch("conv3x3_bf16_kernel");
+}
+
+
+// ------------------------------------------------------------------ weight gradient, bf16 operands
+//   dW[co][ci][ky][kx] = sum_{b,y,x} dz[b][co][y][x] * X[b][ci][y+ky-1][x+kx-1]:  M = co, N = ci, K = pixels, one
+//   accumulator per tap (9 x 16 registers per wave), v_mfma_f32_32x32x16_bf16 with the 8 K-values of a lane = 8
+//   CONSECUTIVE PIXELS of one channel row -- the natural NCHW order, so the tiles stay pixel-innermost: a unit is a
+//   4-row x 16-pixel patch of one image (4 K-steps = its 4 rows), dz [64 co][4][16] and the halo patch of x
+//   [64 ci][6][18] rounded to bf16 on the way into LDS.  The A fragment is one ds_read_b128 per K-step; the three
+//   horizontally shifted B fragments of a patch row come from ONE ds_read_b128 + ds_read_b32 (10 bf16): shift 0 and 2
+//   are dword-aligned, shift 1 is four v_alignbit_b32.  Channel strides 36 / 76 dwords (4 x odd) keep the 16-lane
+//   groups of a b128 read on 64 distinct banks.  Split-K over (image, patch) units, raw slabs [split][tap][co][ci]
+//   reduced deterministically by wgrad_reduce_kernel (conv_mfma.hip).
+struct BwArgs {
+    const float* x;
+    int64_t x_bs;
+    const float* dz;
+    int64_t dz_bs;
+    float* slab;
+    int B, Cin, Cout, H, W, ciTiles, coTiles, splitK, tilesY, tilesX;
+};
+
+constexpr int BW_SDZ = 36, BW_SX = 76, BW_XROW = 12;        // dword strides: per co, per ci, per patch row
+
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_bf16_kernel(BwArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned dz_lds[64 * BW_SDZ];
+    __shared__ __attribute__((aligned(16))) unsigned x_lds[64 * BW_SX];
+
+    int bid;
+    {
+        const int n = gridDim.x, q = n >> 3, r = n & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int tiles = a.ciTiles * a.coTiles;
+    const int ks = bid / tiles, tile = bid % tiles;
+    const int ci0 = (tile % a.ciTiles) * 64, co0 = (tile / a.ciTiles) * 64;
+    const int nunits = a.B * a.tilesY * a.tilesX;
+    const int per = (nunits + a.splitK - 1) / a.splitK;
+    const int u0 = ks * per, u1 = min(u0 + per, nunits);
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int HW = a.H * a.W;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // staging roles: dz -- thread = (co, patch row): 16 floats as 4 b128 loads; x -- thread = one or two (ci, patch row)
+    // rows of 18 floats: the 16 interior columns as 4 b128 loads (x0 % 16 == 0, W % 4 == 0: aligned, and a float4 is
+    // entirely inside or outside the image) + the two halo columns
+    const int dz_c = tid >> 2, dz_r = tid & 3;
+    u32x4b dzv[4];
+    u32x4b xq[2][4];
+    float xh[2][2];
+    auto issue = [&](int u) __attribute__((always_inline)) {
+        const bool live = u < u1;
+        const int uu = live ? u : 0;
+        const int tx = uu % a.tilesX, ty = (uu / a.tilesX) % a.tilesY, b = uu / (a.tilesX * a.tilesY);
+        const int y0 = ty * 4, x0 = tx * 16;
+        const __amdgpu_buffer_rsrc_t dr = b_rsrc(a.dz + (int64_t)b * a.dz_bs, (int64_t)a.Cout * HW * 4);
+        const __amdgpu_buffer_rsrc_t xr = b_rsrc(a.x + (int64_t)b * a.x_bs, (int64_t)a.Cin * HW * 4);
+        {
+            const int yy = y0 + dz_r;
+            const bool ok = live && yy < a.H && co0 + dz_c < a.Cout;
+            const unsigned base = (unsigned)(((co0 + dz_c) * HW + yy * a.W + x0) * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                dzv[k] = __builtin_amdgcn_raw_buffer_load_b128(dr, (ok && x0 + 4 * k < a.W) ? base + 16 * k : OOB_B, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int e = tid + 256 * j;                 // row item: ci = e / 6, patch row = e % 6
+            const int c = e / 6, r = e % 6;
+            const int yy = y0 - 1 + r;
+            const bool rok = live && e < 64 * 6 && yy >= 0 && yy < a.H && ci0 + c < a.Cin;
+            const unsigned base = (unsigned)(((ci0 + c) * HW + yy * a.W + x0) * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                xq[j][k] = __builtin_amdgcn_raw_buffer_load_b128(xr, (rok && x0 + 4 * k < a.W) ? base + 16 * k : OOB_B, 0, 0);
+            xh[j][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (rok && x0 > 0) ? base - 4 : OOB_B, 0, 0));
+            xh[j][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (rok && x0 + 16 < a.W) ? base + 64 : OOB_B, 0, 0));
+        }
+    };
+    auto commit = [&]() __attribute__((always_inline)) {
+        u32x4b* d = reinterpret_cast<u32x4b*>(dz_lds + dz_c * BW_SDZ + dz_r * 8);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // (bit-cast the whole vector: __builtin_bit_cast(float, vec[i]) on an element of an ext-vector reads element 0)
+            const f32x4b lo = __builtin_bit_cast(f32x4b, dzv[2 * h]), hi = __builtin_bit_cast(f32x4b, dzv[2 * h + 1]);
+            u32x4b v = {pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(hi[0], hi[1]), pack_bf16(hi[2], hi[3])};
+            d[h] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int e = tid + 256 * j;
+            if (e < 64 * 6) {
+                // patch element 0 = column x0 - 1: dword p = (element 2p, 2p + 1) = (f[2p - 1], f[2p]) of the interior row f
+                const f32x4b f0 = __builtin_bit_cast(f32x4b, xq[j][0]), f1 = __builtin_bit_cast(f32x4b, xq[j][1]);
+                const f32x4b f2 = __builtin_bit_cast(f32x4b, xq[j][2]), f3 = __builtin_bit_cast(f32x4b, xq[j][3]);
+                unsigned* row = x_lds + (e / 6) * BW_SX + (e % 6) * BW_XROW;
+                const u32x4b w0 = {pack_bf16(xh[j][0], f0[0]), pack_bf16(f0[1], f0[2]), pack_bf16(f0[3], f1[0]), pack_bf16(f1[1], f1[2])};
+                const u32x4b w1 = {pack_bf16(f1[3], f2[0]), pack_bf16(f2[1], f2[2]), pack_bf16(f2[3], f3[0]), pack_bf16(f3[1], f3[2])};
+                *reinterpret_cast<u32x4b*>(row) = w0;
+                *reinterpret_cast<u32x4b*>(row + 4) = w1;
+                row[8] = pack_bf16(f3[3], xh[j][1]);
+            }
+        }
+    };
+
+    const unsigned* a_ptr = dz_lds + (wm * 32 + l31) * BW_SDZ + kh * 4;
+    const unsigned* b_ptr = x_lds + (wn * 32 + l31) * BW_SX + kh * 4;
+
+    issue(u0);
+    for (int u = u0; u < u1; ++u) {
+        commit();
+        __syncthreads();
+        issue(u + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 av = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4b*>(a_ptr + s * 8));
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const u32x4b q = *reinterpret_cast<const u32x4b*>(b_ptr + (s + ky) * BW_XROW);
+                const unsigned d4 = b_ptr[(s + ky) * BW_XROW + 4];
+                const u32x4b s1 = {__builtin_amdgcn_alignbit(q[1], q[0], 16), __builtin_amdgcn_alignbit(q[2], q[1], 16),
+                                   __builtin_amdgcn_alignbit(q[3], q[2], 16), __builtin_amdgcn_alignbit(d4, q[3], 16)};
+                const u32x4b s2 = {q[1], q[2], q[3], d4};
+                acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, q), acc[ky * 3 + 0], 0, 0, 0);
+                acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, s1), acc[ky * 3 + 1], 0, 0, 0);
+                acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, s2), acc[ky * 3 + 2], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    const int64_t n = (int64_t)a.Cout * a.Cin;
+    const int ci = ci0 + wn * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float* o = a.slab + ((int64_t)ks * 9 + t) * n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (co < a.Cout && ci < a.Cin) o[(int64_t)co * a.Cin + ci] = acc[t][r];
+        }
+    }
+}
+
+static void wgrad_bf16_plan(int B, int Cin, int Cout, int H, int W, int& splitK, int& tilesY, int& tilesX) {
+    tilesY = cdiv(H, 4);
+    tilesX = cdiv(W, 16);
+    const int64_t units = (int64_t)B * tilesY * tilesX;
+    const int tiles = cdiv(Cin, 64) * cdiv(Cout, 64);
+    int64_t k = std::max<int64_t>(1, 1024 / tiles);          // ~4 blocks per CU in flight over the launch
+    k = std::min<int64_t>(k, std::max<int64_t>(1, units / 16)); // at least 16 units (64 K-steps) per block
+    splitK = (int)k;
+}
+
+extern "C" {
+
+int onet_conv3x3_pack_weights_bf16(const float* w, void* wq_fwd, void* wq_dgrad, int Cout, int Cin, void* stream) {
+    ONET_REQUIRE(w && (wq_fwd || wq_dgrad) && Cout > 0 && Cin > 0, "conv3x3_pack_weights_bf16: bad args");
+    ONET_REQUIRE(!wq_fwd || (Cin % 16) == 0, "conv3x3_pack_weights_bf16: Cin must be a multiple of 16 for the forward pack");
+    const int64_t n = (int64_t)std::max(Cin, ((Cout + 15) / 16) * 16) * 9 * std::max(Cout, Cin);
+    const int blocks = (int)std::min<int64_t>((n + 255) / 256, 8192);
+    if (wq_fwd) {
+        hipLaunchKernelGGL(pack3x3_bf16_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, (__bf16*)wq_fwd, (__bf16*)nullptr, Cout, Cin, 0);
+        int rc = check_launch("pack3x3_bf16_kernel");
+        if (rc) return rc;
+    }
+    if (wq_dgrad)
+        hipLaunchKernelGGL(pack3x3_bf16_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, (__bf16*)nullptr, (__bf16*)wq_dgrad, Cout, Cin, 1);
+    return check_launch("pack3x3_bf16_kernel");
+}
+
+int onet_conv3x3_bf16_fwd(const float* x, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin, int Cout,
+                          int H, int W, void* stream) {
+    ONET_REQUIRE(x && wq && z, "conv3x3_bf16_fwd: null pointer");
+    ONET_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv3x3_bf16_fwd: bad shape");
+    ONET_REQUIRE((Cin % 16) == 0 && (Cout % 4) == 0, "conv3x3_bf16_fwd: Cin must be a multiple of 16, Cout of 4 (use onet_conv_fwd)");
+    ONET_REQUIRE(x_bs >= (int64_t)Cin * H * W && z_bs >= (int64_t)Cout * H * W, "conv3x3_bf16_fwd: batch stride too small");
+    ONET_REQUIRE((int64_t)(Cin + 32) * H * W * 4 < (1ll << 31) && (int64_t)(Cin + 32) * 9 * Cout * 2 < (1ll << 31),
+                 "conv3x3_bf16_fwd: operand exceeds the 2 GiB buffer-resource range");
+    BfArgs a{x, x_bs, (const __bf16*)wq, z, z_bs, B, Cin, Cout, H, W, 0, 0, 0};
+    // 4 waves x 2 rows x 32 px, two blocks (8 waves) per CU: 373-851 TF on the U-Net's layers against 278-527 for
+    // 4-row waves at one wave per SIMD and ~100 for 4-row waves squeezed into 256 VGPRs (700 B/lane of scratch)
+    return launch_bf16<2, 2>(a, as_stream(stream));
+}
+
+int64_t onet_conv3x3_wgrad_bf16_ws_bytes(int B, int Cin, int Cout, int H, int W) {
+    int splitK, ty, tx;
+    wgrad_bf16_plan(B, Cin, Cout, H, W, splitK, ty, tx);
+    return (int64_t)splitK * 9 * Cout * Cin * 4;
+}
+
+int onet_conv3x3_wgrad_bf16(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs, float* dw, void* ws, int64_t ws_bytes,
+                            int B, int Cin, int Cout, int H, int W, int accumulate, void* stream) {
+    ONET_REQUIRE(x && dz && dw && ws, "conv3x3_wgrad_bf16: null pointer");
+    ONET_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv3x3_wgrad_bf16: bad shape");
+    ONET_REQUIRE((W & 3) == 0 && (dz_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(dz) & 15) == 0,
+                 "conv3x3_wgrad_bf16: W %% 4 == 0 and 16-byte aligned dz rows required (use onet_conv_wgrad)");
+    ONET_REQUIRE(x_bs >= (int64_t)Cin * H * W && dz_bs >= (int64_t)Cout * H * W, "conv3x3_wgrad_bf16: batch stride too small");
+    ONET_REQUIRE((int64_t)std::max(Cin, Cout) * H * W * 4 < (1ll << 31), "conv3x3_wgrad_bf16: image exceeds the 2 GiB buffer-resource range");
+    BwArgs a{x, x_bs, dz, dz_bs, (float*)ws, B, Cin, Cout, H, W, cdiv(Cin, 64), cdiv(Cout, 64), 1, 1, 1};
+    wgrad_bf16_plan(B, Cin, Cout, H, W, a.splitK, a.tilesY, a.tilesX);
+    const int64_t need = (int64_t)a.splitK * 9 * Cout * Cin * 4;
+    ONET_REQUIRE(ws_bytes >= need, "conv3x3_wgrad_bf16: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
+    const int64_t blocks = (int64_t)a.splitK * a.ciTiles * a.coTiles;
+    hipLaunchKernelGGL(conv3x3_wgrad_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
+    int rc = check_launch("conv3x3_wgrad_bf16_kernel");
+    if (rc) return rc;
+    return launch_wgrad_reduce((const float*)ws, dw, a.splitK, 9, Cout, Cin, 0, accumulate, as_stream(stream));
+}
+
+}  // extern "C"

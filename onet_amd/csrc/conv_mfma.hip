@@ -607,6 +607,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+namespace onet {
+int launch_wgrad_reduce(const float* slab, float* dw, int splitK, int taps, int Cout, int Cin, int out_layout, int accumulate,
+                        hipStream_t st) {
+    const int64_t n = (int64_t)Cout * Cin;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv(n, 64), (unsigned)taps), dim3(256), 0, st, slab, dw, splitK,
+                       taps, Cout, Cin, out_layout, accumulate);
+    return check_launch("wgrad_reduce_kernel");
+}
+}  // namespace onet
+
 // Stem wgrad (Cin <= 4: the 1- or 3-channel input image, OV:111): dW[co][ci][tap] has only 64*Cin*9
 // entries but reduces over every pixel, so it is an HBM-bound streaming reduction over dz, not a GEMM
 // (the MFMA tile would be 63/64 padding).  One block per (image, 32-row band, group of COG output

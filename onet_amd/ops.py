@@ -128,6 +128,9 @@ def convT2x2_fwd(x, wq, bias, out, Ct, pt, pl):
 #                     else the direct implicit-GEMM kernel
 #   "winograd4"       F(4x4,3x3) on every legal layer with maps >= 8x8 (parity tests)      "winograd" / "winograd2"  F(2x2,3x3)
 #   "direct"          implicit GEMM only
+#   "bf16"            BASELINE config 3: bf16-operand MFMA kernel (conv_bf16.hip) for forward / input gradient on every
+#                     layer with Cin % 16 == 0 and maps >= 32 px wide, weight gradients of every layer with Cin >= 16 on
+#                     maps >= 16 px wide; "auto" (fp32) elsewhere
 # Layers no Winograd kernel takes (stem Cin < 16, channel counts not multiples of 4) always run direct.
 import os as _os
 CONV_ALGO = _os.environ.get("ONET_CONV_ALGO", "auto")
@@ -145,6 +148,10 @@ def _wino_legal(Cin, Cout):
 def conv3x3_algo(B, Cin, Cout, H, W):
     """-> "winograd4" | "winograd" | "direct" for a conv with Cin inputs and Cout outputs on B maps of H x W."""
     algo = "winograd" if CONV_ALGO == "winograd2" else CONV_ALGO
+    if algo == "bf16":
+        if Cin % 16 == 0 and Cout % 4 == 0 and W >= 32 and H >= 8:
+            return "bf16"
+        algo = "auto"
     if algo == "direct" or not _wino_legal(Cin, Cout):
         return "direct"
     # on maps smaller than 8x8 the tile quantisation wastes most of an MFMA tile and the direct kernel's
@@ -178,7 +185,8 @@ class Packed3x3(dict):
 
     def get_pack(self, algo):
         if algo not in self:
-            self[algo] = {"direct": pack3x3, "winograd": pack3x3_winograd, "winograd4": pack3x3_winograd4}[algo](self.w)
+            self[algo] = {"direct": pack3x3, "winograd": pack3x3_winograd, "winograd4": pack3x3_winograd4,
+                          "bf16": pack3x3_bf16}[algo](self.w)
         return self[algo]
 
 
@@ -195,6 +203,8 @@ def conv3x3_auto(x, pk, direction, out=None):
     wq = pk.get_pack(algo)[direction]
     if algo == "winograd4":
         return conv3x3_winograd4(x, wq, Co, out=out)
+    if algo == "bf16":
+        return conv3x3_bf16(x, wq, Co, out=out)
     if algo == "winograd":
         return conv3x3_winograd(x, wq, Co, out=out)
     return conv_fwd(x, wq, Co, 3, out=out)
@@ -309,6 +319,36 @@ def conv3x3_winograd4(x, wq, Cout, out=None):
     return out
 
 
+def pack3x3_bf16(w):
+    """bf16 packs of a 3x3 weight for conv_bf16.hip: (fwd [Cin/16][9][Cout][16], dgrad [Cout/16][9][Cin][16]); a pack
+    whose K dimension is not a multiple of 16 is None (that orientation takes the fp32 kernels)."""
+    require_gpu(w)
+    w = w.detach().contiguous()
+    Cout, Cin = w.shape[0], w.shape[1]
+    BF = torch.bfloat16
+    wf = torch.empty(Cin * 9 * Cout, dtype=BF, device=w.device) if Cin % 16 == 0 else None
+    wd = torch.empty(-(-Cout // 16) * 16 * 9 * Cin, dtype=BF, device=w.device) if Cout % 16 == 0 else None
+    if wf is not None or wd is not None:
+        _lib.call("onet_conv3x3_pack_weights_bf16", _p(w), _p(wf), _p(wd), Cout, Cin, _stream())
+    return wf, wd
+
+
+def conv3x3_bf16(x, wq, Cout, out=None):
+    """z = conv3x3(x) with bf16 operands (x rounded on load, wq packed bf16), fp32 accumulation and output."""
+    require_gpu(x)
+    if wq is None or not wq.is_cuda or wq.dtype != torch.bfloat16:
+        raise TypeError("conv3x3_bf16: wq must be a bf16 pack on the GPU (pack3x3_bf16)")
+    x, xbs = plane(x)
+    B, Cin, H, W = x.shape
+    if out is None:
+        out = torch.empty((B, Cout, H, W), dtype=F32, device=x.device)
+    zbs = out.stride(0) if B > 1 else Cout * H * W
+    e0 = _prof_begin()
+    _lib.call("onet_conv3x3_bf16_fwd", _p(x), xbs, _p(wq), _p(out), zbs, B, Cin, Cout, H, W, _stream())
+    _prof_end("conv3x3_bf16_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0)
+    return out
+
+
 def grad_slot_if_free(param):
     """FlatAdam registers, per parameter, its slice of the flat gradient buffer.  When the parameter has no .grad yet
     (FlatAdam.zero_grad sets it to None) a backward kernel may write its result straight into that slice and hand the
@@ -340,8 +380,28 @@ def conv3x3_winograd_wgrad(x, dz, dw_shape, out=None):
     return dw
 
 
+def conv3x3_wgrad_bf16(x, dz, dw_shape, out=None):
+    """dW of a 3x3 convolution with bf16 operands (x, dz rounded on the way into LDS), fp32 accumulation."""
+    require_gpu(x, dz)
+    x, xbs = plane(x)
+    dz, dzbs = plane(dz)
+    B, Cin, H, W = x.shape
+    Cout = dz.shape[1]
+    dw = torch.empty(dw_shape, dtype=F32, device=x.device) if out is None else out
+    need = _lib.load().onet_conv3x3_wgrad_bf16_ws_bytes(B, Cin, Cout, H, W)
+    ws = workspace(need, x.device)
+    e0 = _prof_begin()
+    _lib.call("onet_conv3x3_wgrad_bf16", _p(x), xbs, _p(dz), dzbs, _p(dw), _p(ws), ws.numel() * 4, B, Cin, Cout, H, W, 0,
+              _stream())
+    _prof_end("conv3x3_wgrad_bf16_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0)
+    return dw
+
+
 def conv3x3_wgrad_auto(x, dz, dw_shape, out=None):
     Cout, Cin = dw_shape[0], dw_shape[1]
+    if (CONV_ALGO == "bf16" and Cin >= 16 and x.shape[3] >= 16 and x.shape[3] % 4 == 0 and x.shape[2] >= 8
+            and dz.is_contiguous()):
+        return conv3x3_wgrad_bf16(x, dz, dw_shape, out=out)
     if use_winograd(Cin, Cout, x.shape[2], x.shape[3]):
         return conv3x3_winograd_wgrad(x, dz, dw_shape, out=out)
     return conv_wgrad(x, dz, dw_shape, 3, out=out)

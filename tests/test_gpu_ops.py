@@ -233,6 +233,51 @@ def test_winograd4_fused_bn_statistics(dev, B, Cin, Cout, H, W):
         assert float(((s1[1].cpu().double() - ir) / ir).abs().max()) <= 1e-5
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 16, 64, 32, 32), (1, 32, 48, 20, 44), (2, 64, 128, 64, 64),
+                                             (3, 48, 32, 17, 33), (2, 128, 64, 16, 96)])
+def test_conv3x3_bf16_operands(dev, B, Cin, Cout, H, W):
+    """BASELINE config 3's bf16 MFMA conv path (conv_bf16.hip), forward and input-gradient orientation: the kernel
+    rounds activations and weights to bf16 (nearest-even) and accumulates in fp32, so it must equal an fp64 convolution
+    of the bf16-ROUNDED operands to fp32 summation accuracy (1e-5 of the output scale) -- and the full-precision
+    convolution to bf16 accuracy (2^-8 relative per operand: 2e-2 of the output scale at these depths)."""
+    from onet_amd import ops
+    x = rnd(B, Cin, H, W, seed=51)
+    w = rnd(Cout, Cin, 3, 3, seed=52, scale=(2.0 / (Cin * 9)) ** 0.5)
+    g = rnd(B, Cout, H, W, seed=53)
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float64)
+    qf, qd = ops.pack3x3_bf16(w.to(dev))
+    z = ops.conv3x3_bf16(x.to(dev), qf, Cout).cpu().double()
+    z_ref = F.conv2d(rb(x), rb(w), None, 1, 1)
+    z_full = F.conv2d(x.double(), w.double(), None, 1, 1)
+    sc = float(z_full.abs().max())
+    assert float((z - z_ref).abs().max()) <= 1e-5 * sc, "fwd vs bf16-rounded operands"
+    assert float((z - z_full).abs().max()) <= 2e-2 * sc, "fwd vs full precision"
+    if Cout % 16 == 0:
+        dx = ops.conv3x3_bf16(g.to(dev), qd, Cin).cpu().double()
+        dx_ref = F.conv_transpose2d(rb(g), rb(w), None, 1, 1)
+        sc = float(dx_ref.abs().max())
+        assert float((dx - dx_ref).abs().max()) <= 1e-5 * sc, "dgrad vs bf16-rounded operands"
+    else:
+        assert qd is None
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 64, 64, 32, 32), (3, 16, 48, 20, 44), (2, 128, 64, 16, 16),
+                                             (1, 72, 40, 9, 28), (4, 64, 128, 64, 64)])
+def test_conv3x3_wgrad_bf16_operands(dev, B, Cin, Cout, H, W):
+    """bf16-operand weight gradient (conv_bf16.hip): equal to the fp64 weight gradient of the bf16-ROUNDED x and dz to
+    fp32 summation accuracy; ragged patches (H % 4, W % 16), channel tails, several split-K plans."""
+    from onet_amd import ops
+    x = rnd(B, Cin, H, W, seed=61)
+    g = rnd(B, Cout, H, W, seed=62)
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float64)
+    dw = ops.conv3x3_wgrad_bf16(x.to(dev), g.to(dev), (Cout, Cin, 3, 3)).cpu().double()
+    ref = torch.nn.grad.conv2d_weight(rb(x), (Cout, Cin, 3, 3), rb(g), stride=1, padding=1)
+    full = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), g.double(), stride=1, padding=1)
+    sc = float(full.abs().max())
+    assert float((dw - ref).abs().max()) <= 2e-5 * sc, "vs bf16-rounded operands"
+    assert float((dw - full).abs().max()) <= 2e-2 * sc, "vs full precision"
+
+
 @pytest.mark.parametrize("B,Cin,Cmid,Cout,H,W,G", [(4, 8, 64, 32, 32, 32, 1), (4, 16, 72, 64, 32, 64, 2),
                                                     (2, 16, 24, 16, 48, 32, 1)])
 def test_double_conv_fused_bn_backward_reduce(dev, B, Cin, Cmid, Cout, H, W, G, monkeypatch):
