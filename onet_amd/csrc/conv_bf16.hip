@@ -388,7 +388,9 @@ static void wgrad_bf16_plan(int B, int Cin, int Cout, int H, int W, int& splitK,
     tilesX = cdiv(W, 16);
     const int64_t units = (int64_t)B * tilesY * tilesX;
     const int tiles = cdiv(Cin, 64) * cdiv(Cout, 64);
-    int64_t k = std::max<int64_t>(1, 1024 / tiles);          // ~4 blocks per CU in flight over the launch
+    static int target = -1;
+    if (target < 0) { const char* e = getenv("ONET_BF16_WG_BLOCKS"); target = (e && atoi(e) > 0) ? atoi(e) : 512; }
+    int64_t k = std::max<int64_t>(1, target / tiles);        // blocks over the launch (2 resident per CU)
     k = std::min<int64_t>(k, std::max<int64_t>(1, units / 16)); // at least 16 units (64 K-steps) per block
     splitK = (int)k;
 }

@@ -3,6 +3,8 @@
 usage: python tools/profile_to_md.py TAG "one-line description of the code state" """
 import collections, csv, glob, json, os, shutil, subprocess, sys
 tag, desc = sys.argv[1], sys.argv[2]
+extra = os.environ.get("BENCH_ARGS", "")                 # the BENCH_ARGS the set was collected with, e.g. "--conv bf16"
+what = "B=32 1x256x256, " + ("bf16 MFMA conv path (fp32 storage / accumulation)" if "bf16" in extra else "fp32")
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 # ---- kernel stats
@@ -31,8 +33,8 @@ try:
 except Exception:
     pass
 with open(f"profiles/{tag}_kernel_stats_bench_b32_256.md", "w") as f:
-    f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 3 --no-cpu-baseline ({desc})\n\n")
-    f.write(f"MI355X, B=32 1x256x256, fp32; 6 training steps traced (3 warm-up + 3 timed).  Total kernel time {tot/1e6:.1f} ms = "
+    f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 3 --no-cpu-baseline {extra} ({desc})\n\n")
+    f.write(f"MI355X, {what}; 6 training steps traced (3 warm-up + 3 timed).  Total kernel time {tot/1e6:.1f} ms = "
             f"{tot/6e6:.1f} ms/step over all six.")
     if bench:
         dom = bench["roofline"]["kernel"]
@@ -55,7 +57,8 @@ with open(f"profiles/{tag}_kernel_stats_bench_b32_256.md", "w") as f:
 # ---- PMC traffic
 out = f"profiles/{tag}_pmc_bench_b32_256.json"
 subprocess.run([sys.executable, "tools/pmc_parse.py", f"{src}/fetch", f"{src}/write", "--json", out], check=True, stdout=subprocess.DEVNULL)
-shutil.copy(out, "profiles/pmc_bench_latest.json")
+if not extra:
+    shutil.copy(out, "profiles/pmc_bench_latest.json")       # the default (fp32) run is what bench.py's `traffic` quotes
 # ---- SQ counters
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for fcsv in glob.glob(f"{src}/sq/**/*counter_collection.csv", recursive=True):
@@ -66,7 +69,7 @@ for fcsv in glob.glob(f"{src}/sq/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(fcsv)):
         dur[r["Kernel_Name"].split("(")[0].replace("void ", "")[:60]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 with open(f"profiles/{tag}_sq_counters_bench_b32_256.md", "w") as f:
-    f.write(f"# rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace -- python bench.py --steps 3 --warmup 3 ({desc})\n\n")
+    f.write(f"# rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace -- python bench.py --steps 3 --warmup 3 {extra} ({desc})\n\n")
     f.write("effective clock = GRBM_GUI_ACTIVE / 8 / duration (MI355X_MICROARCH.md, DVFS give-back); MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs).\n"
             "Profiled passes run slower than un-profiled ones (same guide), so durations here are longer than in the kernel-stats table.\n\n")
     f.write("| kernel | launches | total ms | effective clock GHz | MFMA busy |\n|---|---:|---:|---:|---:|\n")
