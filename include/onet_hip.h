@@ -207,6 +207,15 @@ int onet_maxpool2_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_
 int onet_maxpool2_bwd_add(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, const float* add,
                           int64_t add_bs, const float* add2, int64_t add2_bs, float* dx, int64_t dx_bs,
                           int B, int C, int H, int W, void* stream);
+/* onet_maxpool2_bwd_add for an x that is the OUTPUT a = relu(bn(z)) of a Conv-BN-ReLU unit (OV:58 -> 67): the sum it
+ * writes is that unit's activation gradient, so the unit's first BatchNorm-backward pass rides along: part2
+ * [B * bands][C][4] = onet_bn_relu_bwd_reduce's records (bands = onet_maxpool2_bwd_bn_bands(H, W), 0 = fused form not
+ * available), save [B / group_images][4][C].  add / add2 nullable. */
+int onet_maxpool2_bwd_bn_bands(int H, int W);
+int onet_maxpool2_bwd_add_bnreduce(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, const float* add,
+                                   int64_t add_bs, const float* add2, int64_t add2_bs, float* dx, int64_t dx_bs,
+                                   const float* z, int64_t z_bs, const float* save, int group_images,
+                                   float* part2, int B, int C, int H, int W, void* stream);
 
 /* ---- K5/K6: ConvTranspose2d(k=2,s=2) pixel shuffle + pad + concat (OV:86-100) ---- */
 /* sub [B][4*C][h][w] (1x1-conv output, channel q*C+co, q=dy*2+dx) + bias ->

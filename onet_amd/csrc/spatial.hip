@@ -296,6 +296,85 @@ __global__ void axpy_kernel(const float* __restrict__ x, int64_t x_bs, float* __
     }
 }
 
+
+// maxpool2_bwd_v4_kernel + the first BatchNorm-backward pass of the layer that PRODUCED x: x = a = relu(bn(z)) is an
+// encoder output (OV:58 -> 67, 100, 152), so the sum written to dx IS that layer's activation gradient and the
+// (sum dy, sum dy * xhat) records of bn_relu_bwd_reduce_kernel (bn.hip; same mask expression, fp64 sums, hi/lo float
+// pairs, [image * bands + band][C][4]) can be taken on the way out instead of re-reading dx.  One block per (image,
+// channel, band of rows).
+__global__ __launch_bounds__(256) void maxpool2_bwd_bn_kernel(const float* __restrict__ x, int64_t x_bs,
+                                                              const float* __restrict__ dy, int64_t dy_bs,
+                                                              const float* __restrict__ add, int64_t add_bs,
+                                                              const float* __restrict__ add2, int64_t add2_bs,
+                                                              float* __restrict__ dx, int64_t dx_bs,
+                                                              const float* __restrict__ z, int64_t z_bs,
+                                                              const float* __restrict__ save, int group_images,
+                                                              float* __restrict__ part2, int C, int H, int W, int bands,
+                                                              int band_rows) {
+    __shared__ double red[8];
+    const int c = blockIdx.x % C, p = blockIdx.x / C;
+    const int b = p / bands, band = p % bands;
+    const int Ho = H >> 1, Wo = W >> 1, W4 = W >> 2;
+    const float* sv = save + (int64_t)(b / group_images) * 4 * C;
+    const float mean = sv[c], invstd = sv[C + c], sc = sv[2 * C + c], sh = sv[3 * C + c];
+    const double meand = mean, invd = invstd;
+    const int oy0 = band * (band_rows >> 1), oy1 = min(oy0 + (band_rows >> 1), Ho);
+    const int npatch = (oy1 - oy0) * W4;
+    double v[2] = {0.0, 0.0};
+    for (int i = threadIdx.x; i < npatch; i += 256) {
+        const int q = i % W4, oy = oy0 + i / W4;
+        const int64_t in_off = (int64_t)c * H * W + (int64_t)(2 * oy) * W + 4 * q;
+        const float4 r0 = *reinterpret_cast<const float4*>(x + (int64_t)b * x_bs + in_off);
+        const float4 r1 = *reinterpret_cast<const float4*>(x + (int64_t)b * x_bs + in_off + W);
+        const float4 z0 = *reinterpret_cast<const float4*>(z + (int64_t)b * z_bs + in_off);
+        const float4 z1 = *reinterpret_cast<const float4*>(z + (int64_t)b * z_bs + in_off + W);
+        const float2 g = *reinterpret_cast<const float2*>(dy + (int64_t)b * dy_bs + (int64_t)c * Ho * Wo + (int64_t)oy * Wo + 2 * q);
+        int a0 = 0, a1 = 0;
+        float m0 = r0.x, m1 = r0.z;
+        if (r0.y > m0) { m0 = r0.y; a0 = 1; }
+        if (r1.x > m0) { m0 = r1.x; a0 = 2; }
+        if (r1.y > m0) { m0 = r1.y; a0 = 3; }
+        if (r0.w > m1) { m1 = r0.w; a1 = 1; }
+        if (r1.z > m1) { m1 = r1.z; a1 = 2; }
+        if (r1.w > m1) { m1 = r1.w; a1 = 3; }
+        float o[8] = {a0 == 0 ? g.x : 0.f, a0 == 1 ? g.x : 0.f, a1 == 0 ? g.y : 0.f, a1 == 1 ? g.y : 0.f,
+                      a0 == 2 ? g.x : 0.f, a0 == 3 ? g.x : 0.f, a1 == 2 ? g.y : 0.f, a1 == 3 ? g.y : 0.f};
+        if (add) {
+            const float4 p0 = *reinterpret_cast<const float4*>(add + (int64_t)b * add_bs + in_off);
+            const float4 p1 = *reinterpret_cast<const float4*>(add + (int64_t)b * add_bs + in_off + W);
+            o[0] += p0.x; o[1] += p0.y; o[2] += p0.z; o[3] += p0.w; o[4] += p1.x; o[5] += p1.y; o[6] += p1.z; o[7] += p1.w;
+        }
+        if (add2) {
+            const float4 p0 = *reinterpret_cast<const float4*>(add2 + (int64_t)b * add2_bs + in_off);
+            const float4 p1 = *reinterpret_cast<const float4*>(add2 + (int64_t)b * add2_bs + in_off + W);
+            o[0] += p0.x; o[1] += p0.y; o[2] += p0.z; o[3] += p0.w; o[4] += p1.x; o[5] += p1.y; o[6] += p1.z; o[7] += p1.w;
+        }
+        float* dst = dx + (int64_t)b * dx_bs + in_off;
+        *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(dst + W) = make_float4(o[4], o[5], o[6], o[7]);
+        const float zz[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const double dyk = fmaf(zz[k] - mean, sc, sh) > 0.f ? (double)o[k] : 0.0;
+            v[0] += dyk;
+            v[1] += dyk * (((double)zz[k] - meand) * invd);
+        }
+    }
+    block_sum_256<double, 2>(v, red);
+    if (threadIdx.x == 0) {
+        float* o = part2 + ((int64_t)p * C + c) * 4;
+        o[0] = (float)v[0];
+        o[1] = (float)(v[0] - (double)o[0]);
+        o[2] = (float)v[1];
+        o[3] = (float)(v[1] - (double)o[2]);
+    }
+}
+
+static void pool_bn_plan(int H, int W, int& bands, int& band_rows) {
+    band_rows = std::max(2, (16384 / std::max(W, 1)) & ~1);
+    bands = cdiv(H, band_rows);
+}
+
 static int maxpool2_bwd_impl(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, float* dx, int64_t dx_bs, int B,
                              int C, int H, int W, int accumulate, const float* add, int64_t add_bs, const float* add2,
                              int64_t add2_bs, void* stream) {
@@ -341,6 +420,33 @@ int onet_maxpool2_bwd_add(const float* x, int64_t x_bs, const float* dy, int64_t
                           void* stream) {
     ONET_REQUIRE(x && dy && add && dx && B > 0 && C > 0 && H >= 2 && W >= 2, "maxpool2_bwd_add: bad args");
     return maxpool2_bwd_impl(x, x_bs, dy, dy_bs, dx, dx_bs, B, C, H, W, 0, add, add_bs, add2, add2_bs, stream);
+}
+
+int onet_maxpool2_bwd_bn_bands(int H, int W) {
+    if (H < 2 || W < 4 || (W & 3) || (H & 1)) return 0;       // the fused form needs the 2 x 4 patch layout
+    int bands, rows;
+    pool_bn_plan(H, W, bands, rows);
+    return bands;
+}
+
+int onet_maxpool2_bwd_add_bnreduce(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, const float* add, int64_t add_bs,
+                                   const float* add2, int64_t add2_bs, float* dx, int64_t dx_bs, const float* z, int64_t z_bs,
+                                   const float* save, int group_images, float* part2, int B, int C, int H, int W, void* stream) {
+    ONET_REQUIRE(x && dy && dx && z && save && part2 && B > 0 && C > 0, "maxpool2_bwd_add_bnreduce: bad args");
+    ONET_REQUIRE(group_images > 0 && (B % group_images) == 0, "maxpool2_bwd_add_bnreduce: bad statistics groups");
+    const bool ok = H >= 2 && W >= 4 && ((W & 3) == 0) && ((H & 1) == 0) && ((x_bs & 3) == 0) && ((dx_bs & 3) == 0) &&
+                    ((z_bs & 3) == 0) && ((dy_bs & 1) == 0) && ((add_bs & 3) == 0) && ((add2_bs & 3) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dx) & 15) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(z) & 15) == 0) && ((reinterpret_cast<uintptr_t>(add) & 15) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(add2) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dy) & 7) == 0);
+    ONET_REQUIRE(ok, "maxpool2_bwd_add_bnreduce: W %% 4 == 0, even H and 16-byte aligned planes required (onet_maxpool2_bwd_bn_bands() == 0 elsewhere)");
+    int bands, rows;
+    pool_bn_plan(H, W, bands, rows);
+    const int64_t blocks = (int64_t)B * bands * C;
+    ONET_REQUIRE(blocks < (1ll << 31), "maxpool2_bwd_add_bnreduce: grid too large");
+    hipLaunchKernelGGL(maxpool2_bwd_bn_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, x_bs, dy, dy_bs, add,
+                       add_bs, add2, add2_bs, dx, dx_bs, z, z_bs, save, group_images, part2, C, H, W, bands, rows);
+    return check_launch("maxpool2_bwd_bn_kernel");
 }
 
 int onet_pixel_shuffle2_bias(const float* sub, const float* bias, float* y, int64_t y_bs, int B, int C, int h,

@@ -72,15 +72,16 @@ class ConvBNReLUFn(torch.autograd.Function):
         aff = (ops.grad_slot_if_free(pg) if need_g else None, ops.grad_slot_if_free(pb) if need_b else None)
         G = save_all.shape[0]
         # the reduce records of THIS layer, if the unit above wrote them while producing exactly this `da`
-        rec = None
+        rec = rec4 = None
         lk = ctx.link_out
-        if lk is not None and "rec" in lk:
-            rda, rec = lk.pop("da"), lk.pop("rec")
+        if lk is not None and ("rec" in lk or "rec4" in lk):
+            rda, rec, rec4 = lk.pop("da"), lk.pop("rec", None), lk.pop("rec4", None)
             if rda.data_ptr() != da.data_ptr() or rda.shape != da.shape or rda.stride() != da.stride():
-                rec = None                          # autograd handed over something else (another consumer, a hook)
+                rec = rec4 = None                   # autograd handed over something else (another consumer, a hook)
         if G == 1:
             dz, dgamma, dbeta = ops.bn_relu_bwd(da, z, save_all[0], ctx.training, need_affine_grads=(need_g or need_b),
-                                                affine_out=aff, red=None if rec is None else (rec, 0, rec.shape[1]))
+                                                affine_out=aff, red=None if rec is None else (rec, 0, rec.shape[1]),
+                                                red4=None if rec4 is None else (rec4, 0, rec4.shape[0]))
         else:
             Bg = z.shape[0] // G
             dz = torch.empty_like(z)
@@ -88,10 +89,12 @@ class ConvBNReLUFn(torch.autograd.Function):
             for g in range(G):
                 sl = slice(g * Bg, (g + 1) * Bg)
                 npg = 0 if rec is None else rec.shape[1] // G
+                np4 = 0 if rec4 is None else rec4.shape[0] // G
                 _, dgamma, dbeta = ops.bn_relu_bwd(da[sl], z[sl], save_all[g], ctx.training, need_affine_grads=True,
                                                    out=dz[sl], acc=None if g == 0 else (dgamma, dbeta),
                                                    affine_out=aff if g == 0 else None,
-                                                   red=None if rec is None else (rec, g * npg, npg))
+                                                   red=None if rec is None else (rec, g * npg, npg),
+                                                   red4=None if rec4 is None else (rec4, g * np4, np4))
         dw = ops.conv3x3_wgrad_auto(x, dz, ctx.wshape, out=ops.grad_slot_if_free(pw)) if need_w else None
         dx = None
         if need_x:
@@ -168,13 +171,16 @@ class SkipPoolFn(torch.autograd.Function):
     """x -> (x, maxpool2(x)[, x]) for an encoder output that feeds both the next Down (OV:67) and an Up's skip concat
     (OV:100) -- and, for the first one, also leaves the U-Net as its first output (OV:152): backward sums the two or
     three gradients inside the pooling-backward kernel (one pass instead of pool backward + autograd's full-tensor
-    adds)."""
+    adds).  `link`: the dict the producing Conv-BN-ReLU unit published its (z, save) in; the sum written here IS that
+    unit's activation gradient, so its BatchNorm-backward reduce records are taken in the same kernel and left in the
+    dict for the unit's backward."""
 
     @staticmethod
-    def forward(ctx, x, returned=False):
+    def forward(ctx, x, returned=False, link=None):
         ops.require_gpu(x)
         y = ops.maxpool2_fwd(x)
         ctx.save_for_backward(x)
+        ctx.link = link if (link is not None and "z" in link) else None
         return (x.view_as(x), y, x.view_as(x)) if returned else (x.view_as(x), y)
 
     @staticmethod
@@ -182,8 +188,14 @@ class SkipPoolFn(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         if g_pool is None:
             gs = [g for g in (g_skip, g_ret) if g is not None]
-            return (sum(gs[1:], gs[0]) if gs else None), None
-        return ops.maxpool2_bwd(x, g_pool, add=g_skip, add2=g_ret), None
+            return (sum(gs[1:], gs[0]) if gs else None), None, None
+        lk = ctx.link
+        if lk is not None:
+            dx, part2 = ops.maxpool2_bwd(x, g_pool, add=g_skip, add2=g_ret, bn=(lk["z"], lk["save"]))
+            if part2 is not None:
+                lk["da"], lk["rec4"] = dx, part2
+            return dx, None, None
+        return ops.maxpool2_bwd(x, g_pool, add=g_skip, add2=g_ret), None, None
 
 
 def _pad_offsets(x1_hw, x2_hw):

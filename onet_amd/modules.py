@@ -121,13 +121,14 @@ class DoubleConv(nn.Module):
         return Fn.ConvBNReLUFn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                      training, bn.momentum, bn.eps, conv.packed(), out, groups, link_out, link_in)
 
-    def forward(self, x, out=None, groups=1):
+    def forward(self, x, out=None, groups=1, pool_link=None):
         """`out`: optional plane-contiguous [B, Cout, H, W] destination view (the skip half of a concat buffer);
-        `groups`: the batch holds that many independent BatchNorm batches (twin pass)."""
+        `groups`: the batch holds that many independent BatchNorm batches (twin pass); `pool_link`: dict the second
+        unit publishes its (z, save) in for the SkipPoolFn that consumes the block's output."""
         s = self.double_conv
         link = {}       # unit 1 -> unit 2: lets unit 2's dgrad launch take unit 1's BatchNorm-backward reduce pass with it
         a1 = self._unit(x, s[0], s[1], None, groups, link_out=link)
-        return self._unit(a1, s[3], s[4], None if out is None else (out,), groups, link_in=link)
+        return self._unit(a1, s[3], s[4], None if out is None else (out,), groups, link_out=pool_link, link_in=link)
 
 
 _SKIPPOOL = os.environ.get("ONET_SKIPPOOL", "1") != "0"
@@ -150,10 +151,11 @@ class Down(nn.Module):
         super().__init__()
         self.maxpool_conv = nn.Sequential(MaxPool2(), DoubleConv(in_channels, out_channels))
 
-    def forward(self, x, out=None, groups=1, pooled=None):
-        """`pooled`: maxpool2(x) when the caller already has it (UNet.forward pools skip tensors with SkipPoolFn)."""
+    def forward(self, x, out=None, groups=1, pooled=None, pool_link=None):
+        """`pooled`: maxpool2(x) when the caller already has it (UNet.forward pools skip tensors with SkipPoolFn);
+        `pool_link`: see DoubleConv.forward."""
         p = self.maxpool_conv[0](x) if pooled is None else pooled
-        return self.maxpool_conv[1](p, out=out, groups=groups)
+        return self.maxpool_conv[1](p, out=out, groups=groups, pool_link=pool_link)
 
 
 class ConvT2x2(nn.ConvTranspose2d, _Packable):
@@ -262,21 +264,26 @@ class UNet(nn.Module):
 
         g = groups
 
-        def fork(t, returned=False):
+        def fork(t, returned=False, link=None):
             # skip tensors feed the next Down's pooling AND an Up's concat (x1 also leaves as the first output): one
             # node, so that their gradients are summed inside the pooling-backward kernel
             if t.is_cuda and _SKIPPOOL:
-                return Fn.SkipPoolFn.apply(t, returned)
+                return Fn.SkipPoolFn.apply(t, returned, link)
             return (t, None, t) if returned else (t, None)
 
-        x1 = self.inc(x, out=skip(0, self.inc.double_conv[3].out_channels), groups=g)
-        x1, p1, x1_out = fork(x1, True)
-        x2 = self.down1(x1, out=skip(1, self.down1.maxpool_conv[1].double_conv[3].out_channels), groups=g, pooled=p1)
-        x2, p2 = fork(x2)
-        x3 = self.down2(x2, out=skip(2, self.down2.maxpool_conv[1].double_conv[3].out_channels), groups=g, pooled=p2)
-        x3, p3 = fork(x3)
-        x4 = self.down3(x3, out=skip(3, self.down3.maxpool_conv[1].double_conv[3].out_channels), groups=g, pooled=p3)
-        x4, p4 = fork(x4)
+        # pl[i]: the producing block's second unit -> the SkipPoolFn of its output (BatchNorm-backward reduce records)
+        pl = [{} for _ in range(4)]
+        x1 = self.inc(x, out=skip(0, self.inc.double_conv[3].out_channels), groups=g, pool_link=pl[0])
+        x1, p1, x1_out = fork(x1, True, pl[0])
+        x2 = self.down1(x1, out=skip(1, self.down1.maxpool_conv[1].double_conv[3].out_channels), groups=g, pooled=p1,
+                        pool_link=pl[1])
+        x2, p2 = fork(x2, False, pl[1])
+        x3 = self.down2(x2, out=skip(2, self.down2.maxpool_conv[1].double_conv[3].out_channels), groups=g, pooled=p2,
+                        pool_link=pl[2])
+        x3, p3 = fork(x3, False, pl[2])
+        x4 = self.down3(x3, out=skip(3, self.down3.maxpool_conv[1].double_conv[3].out_channels), groups=g, pooled=p3,
+                        pool_link=pl[3])
+        x4, p4 = fork(x4, False, pl[3])
         x5 = self.down4(x4, groups=g, pooled=p4)
         y4 = self.up1(x5, x4, cat=cats[3], groups=g)
         y3 = self.up2(y4, x3, cat=cats[2], groups=g)

@@ -511,12 +511,13 @@ def bn_relu_apply(z, save, out=None):
     return out
 
 
-def bn_relu_bwd(da, z, save, training, need_affine_grads=True, out=None, acc=None, affine_out=None, red=None):
+def bn_relu_bwd(da, z, save, training, need_affine_grads=True, out=None, acc=None, affine_out=None, red=None, red4=None):
     """-> dz, dgamma, dbeta.  `out`: plane-contiguous destination for dz (a batch slice of a larger buffer);
     `acc` = (dgamma, dbeta) of another statistics group of the same layer to accumulate into; `affine_out` =
     (dgamma, dbeta) destinations to overwrite (None entries are allocated); `red` = (records [C, NP, 2], first, count):
     the (sum dy, sum dy*xhat) records of this batch slice were already written by the dgrad launch that produced
-    `da` (`conv3x3_dgrad_bnreduce`), so the reduce pass over (da, z) is skipped."""
+    `da` (`conv3x3_dgrad_bnreduce`), so the reduce pass over (da, z) is skipped; `red4` = (records [NP, C, 4], first,
+    count): the same in the reduce kernel's own record format (written by the pooling-backward kernel)."""
     da, dabs = plane(da)
     z, zbs = plane(z)
     B, C, H, W = z.shape
@@ -537,8 +538,13 @@ def bn_relu_bwd(da, z, save, training, need_affine_grads=True, out=None, acc=Non
         _lib.call("onet_bn_bwd_finalize_cm", rec.data_ptr() + first * 8, count, rec.shape[1] * 2, B * HW, _p(dgamma),
                   _p(dbeta), _p(coef), 0 if acc is None else 1, C, _stream())
     elif training or need_affine_grads:
-        part2 = torch.empty((nparts, C, 4), dtype=F32, device=dev)
-        _lib.call("onet_bn_relu_bwd_reduce", _p(da), dabs, _p(z), zbs, _p(save), _p(part2), nparts, B, C, HW, _stream())
+        if red4 is not None:
+            rec4, first, count = red4
+            assert rec4.shape[1] == C and rec4.shape[2] == 4 and 0 <= first and first + count <= rec4.shape[0]
+            part2, nparts = rec4[first:first + count], count
+        else:
+            part2 = torch.empty((nparts, C, 4), dtype=F32, device=dev)
+            _lib.call("onet_bn_relu_bwd_reduce", _p(da), dabs, _p(z), zbs, _p(save), _p(part2), nparts, B, C, HW, _stream())
         if acc is None:
             og, ob = affine_out if affine_out is not None else (None, None)
             dgamma = torch.empty(C, dtype=F32, device=dev) if og is None else og
@@ -572,23 +578,37 @@ def maxpool2_fwd(x):
     return y
 
 
-def maxpool2_bwd(x, dy, add=None, add2=None):
+def maxpool2_bwd(x, dy, add=None, add2=None, bn=None):
     """dx of MaxPool2d(2); `add`, `add2`: other gradients of x (plane-contiguous, e.g. a slice of a concat gradient)
-    summed in the same pass."""
+    summed in the same pass.  `bn` = (z, save_all [G, 4, C]): x is the output relu(bn(z)) of a Conv-BN-ReLU unit with G
+    statistics groups -- the unit's BatchNorm-backward reduce records are taken on the way: -> (dx, part2 [B * bands, C, 4])
+    (or (dx, None) where the fused form is not available)."""
     x, xbs = plane(x)
     dy, dybs = plane(dy)
     B, C, H, W = x.shape
     dx = torch.empty((B, C, H, W), dtype=F32, device=x.device)
     if add is None and add2 is not None:
         add, add2 = add2, None
+    a1, a1bs = plane(add) if add is not None else (None, 0)
+    a2, a2bs = plane(add2) if add2 is not None else (None, 0)
+    if bn is not None:
+        z, save_all = bn
+        bands = int(_lib.load().onet_maxpool2_bwd_bn_bands(H, W)) if (FUSE_BN_REDUCE and not SYNC_BN) else 0
+        z, zbs = plane(z)
+        G = save_all.shape[0]
+        aligned = all(t is None or (t.data_ptr() & 15) == 0 for t in (x, z, a1, a2)) and (dy.data_ptr() & 7) == 0 and \
+            all((v & 3) == 0 for v in (xbs, zbs, a1bs, a2bs)) and (dybs & 1) == 0
+        if bands > 0 and aligned and B % G == 0 and tuple(z.shape) == (B, C, H, W) and save_all.is_contiguous():
+            part2 = torch.empty((B * bands, C, 4), dtype=F32, device=x.device)
+            _lib.call("onet_maxpool2_bwd_add_bnreduce", _p(x), xbs, _p(dy), dybs, _p(a1), a1bs, _p(a2), a2bs, _p(dx),
+                      C * H * W, _p(z), zbs, _p(save_all), B // G, _p(part2), B, C, H, W, _stream())
+            return dx, part2
     if add is None:
         _lib.call("onet_maxpool2_bwd", _p(x), xbs, _p(dy), dybs, _p(dx), C * H * W, B, C, H, W, 0, _stream())
     else:
-        add, abs_ = plane(add)
-        a2, a2bs = plane(add2) if add2 is not None else (None, 0)
-        _lib.call("onet_maxpool2_bwd_add", _p(x), xbs, _p(dy), dybs, _p(add), abs_, _p(a2), a2bs, _p(dx), C * H * W,
+        _lib.call("onet_maxpool2_bwd_add", _p(x), xbs, _p(dy), dybs, _p(a1), a1bs, _p(a2), a2bs, _p(dx), C * H * W,
                   B, C, H, W, _stream())
-    return dx
+    return dx if bn is None else (dx, None)
 
 
 def copy_strided(src, dst):

@@ -365,6 +365,35 @@ def test_skip_pool(dev, B, C, H, W):
     assert torch.equal(xd.grad.cpu(), xr.grad)
 
 
+@pytest.mark.parametrize("B,C,H,W,G", [(4, 6, 16, 16, 1), (4, 5, 12, 40, 2), (2, 3, 64, 256, 1)])
+def test_pool_backward_with_bn_reduce(dev, B, C, H, W, G):
+    """onet_maxpool2_bwd_add_bnreduce: dx identical to the plain pooling backward (+ adds), and the BatchNorm-backward
+    records it takes on the way equal to those of the reduce kernel run on that dx (same fp64 sums), per group."""
+    from onet_amd import ops
+    z = rnd(B, C, H, W, seed=71).to(dev)
+    gamma = (1 + 0.3 * rnd(C, seed=72)).to(dev)
+    beta = (0.2 * rnd(C, seed=73)).to(dev)
+    Bg = B // G
+    save = torch.empty(G, 4, C, device=dev)
+    a = torch.empty_like(z)
+    for g in range(G):
+        ops.bn_train_coeffs(z[g * Bg:(g + 1) * Bg], gamma, beta, None, None, 0.1, 1e-5, save=save[g])
+        ops.bn_relu_apply(z[g * Bg:(g + 1) * Bg], save[g], out=a[g * Bg:(g + 1) * Bg])
+    gp = rnd(B, C, H // 2, W // 2, seed=74).to(dev)
+    gs = rnd(B, 2 * C, H, W, seed=75).to(dev)[:, :C]
+    gr = rnd(B, C, H, W, seed=76).to(dev)
+    want = ops.maxpool2_bwd(a, gp, add=gs, add2=gr)
+    dx, part2 = ops.maxpool2_bwd(a, gp, add=gs, add2=gr, bn=(z, save))
+    assert part2 is not None and torch.equal(dx, want)
+    npg = part2.shape[0] // G
+    for g in range(G):
+        sl = slice(g * Bg, (g + 1) * Bg)
+        _, dg0, db0 = ops.bn_relu_bwd(want[sl], z[sl], save[g], True)
+        _, dg1, db1 = ops.bn_relu_bwd(want[sl], z[sl], save[g], True, red4=(part2, g * npg, npg))
+        close(dg1, dg0, tol=1e-6, what="dgamma")
+        close(db1, db0, tol=1e-6, what="dbeta")
+
+
 @pytest.mark.parametrize("h,w,Ho,Wo,Cin,Ct", [(8, 8, 16, 16, 64, 32), (12, 12, 25, 25, 64, 32), (5, 7, 11, 16, 64, 32),
                                               (32, 32, 64, 64, 128, 64), (17, 40, 35, 80, 24, 12),
                                               (9, 20, 19, 41, 256, 128), (16, 16, 32, 32, 128, 64)])
