@@ -95,6 +95,9 @@ def main():
     if args.conv:
         ops.CONV_ALGO = args.conv
     bf16 = ops.CONV_ALGO == "bf16"
+    # the loop owns the optimizer step: the loss's NaN assertion (OV:234) is evaluated by FlatAdam.step() before the update
+    # instead of by a device synchronisation between forward and backward (ops.LAZY_NAN_CHECK)
+    ops.LAZY_NAN_CHECK = not args.torch_adam
 
     rank, world, local = init_distributed("nccl")
     if world != args.gpus:

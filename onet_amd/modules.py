@@ -370,8 +370,14 @@ class Onet(nn.Module):
             jsd_top, jsd_dwn = Fn.JSDSumsFn.apply(twin[1], twin[2], St, Sd)
             if self.check_finite:
                 # OV:234 asserts each term right after computing it (two device syncs); both terms exist here
-                # already, so one sync answers for the pair
-                assert not bool(torch.isnan(jsd_top + jsd_dwn)), "jsd is NaN"
+                # already, so one check answers for the pair -- in place, or (ops.LAZY_NAN_CHECK, set by training
+                # loops that own the optimizer step) deferred to FlatAdam.step() / the next compute_loss
+                ops.check_deferred_nan()
+                flag = torch.isnan(jsd_top + jsd_dwn)
+                if ops.LAZY_NAN_CHECK:
+                    ops.defer_nan_check(flag)
+                else:
+                    assert not bool(flag), "jsd is NaN"
             return -(jsd_top + jsd_dwn) / 2
         jsd = getattr(self, "jensen_shannon_divergence", None)
         if callable(jsd):

@@ -164,6 +164,7 @@ class FlatAdam:
                 p.grad = view
 
     def step(self):
+        ops.check_deferred_nan()          # the loss's OV:234 verdict (ops.LAZY_NAN_CHECK), BEFORE the update is applied
         g = self.param_groups[0]
         self._gather_stray_grads()
         self.all_reduce_grads()
@@ -240,6 +241,8 @@ def fit(onet, train_loader, device, epochs, schedule="sim", base_lr=None, eval_f
         out_root=None, model_name="Onet", fused_adam=True, rank=0, world=1, log=print):
     """Epoch loop of TS:201-266 (schedule='sim') / TZ:99-153 (schedule='zy3').
     `train_loader` yields (X, ...) with X a CPU or GPU float32 [B,C,H,W] tensor in [0,1]."""
+    if fused_adam:
+        ops.LAZY_NAN_CHECK = True     # OV:234's assertion is raised by FlatAdam.step(), before the update, without a mid-step sync
     if base_lr is None:
         base_lr = 5e-6 if schedule == "sim" else 1e-4
     if fused_adam:

@@ -172,6 +172,45 @@ def test_bf16_conv_path_vs_reference_golden(dev, monkeypatch):
     print(f"bf16 path: loss rel {rel:.2e}, worst gradient-norm error {worst:.2e}")
 
 
+def test_deferred_nan_assertion(dev, monkeypatch):
+    """OV:234's "jsd is not NaN" assertion: in place by default (AssertionError out of compute_loss); with
+    ops.LAZY_NAN_CHECK (training loops that own the optimizer step) the same AssertionError comes out of
+    FlatAdam.step() BEFORE the update is applied -- no device synchronisation between forward and backward.
+    (A NaN is injected into the JSD terms: NaN inputs do not survive the ReLUs, fmaxf(NaN, 0) = 0.)"""
+    from onet_amd import functional as Fn
+    from onet_amd import ops
+    from onet_amd.trainer import FlatAdam
+    X = orc.det_input(2, 1, 32, 32).to(dev)
+    real = Fn.JSDSumsFn.apply
+    poison = {"on": False}
+
+    def jsd_sums(*a):
+        top, dwn = real(*a)
+        return (top * float("nan") if poison["on"] else top), dwn
+
+    monkeypatch.setattr(Fn.JSDSumsFn, "apply", staticmethod(jsd_sums))
+    m = _model(1, True, dev)
+    _step(m, X)
+    poison["on"] = True
+    with pytest.raises(AssertionError):
+        _step(m, X)
+    monkeypatch.setattr(ops, "LAZY_NAN_CHECK", True)
+    poison["on"] = False
+    m = _model(1, True, dev)
+    opt = FlatAdam(m, lr=1e-4, world_size=1)
+    opt.zero_grad()
+    _step_nozero(m, X)
+    opt.step()                                   # clean step: nothing raised
+    before = opt.flat.clone()
+    poison["on"] = True
+    opt.zero_grad()
+    _step_nozero(m, X)                           # NaN loss: not raised here ...
+    with pytest.raises(AssertionError):
+        opt.step()                               # ... but here, and the parameters are untouched
+    assert torch.equal(opt.flat, before)
+    assert not ops._NAN_PENDING
+
+
 def test_eval_mode_vs_reference_golden(dev):
     g = np.load(os.path.join(G, "onet_b2_c1_32_eval.npz"))
     B, C, H, W, bshare, train, steps = [int(v) for v in g["meta"]]
