@@ -68,9 +68,10 @@ struct BfArgs {
     int B, Cin, Cout, H, W, tilesX, tilesY, coTiles;
 };
 
-template <int NT>
+template <int NT, int TW_ = 32>
 struct BfCfg {
-    static constexpr int CO_T = 64, ROWS = 4 * NT, TW = 32;            // 4 waves x NT image rows of 32 pixels
+    static constexpr int TW = TW_, RPT = 32 / TW;                      // image rows per 32-pixel MFMA column tile
+    static constexpr int CO_T = 64, ROWS = 4 * NT * RPT;               // 4 waves x NT column tiles (TW = 16: 2 rows each)
     static constexpr int IN_ROWS = ROWS + 2, IN_COLS = TW + 2;
     static constexpr int IN_ITEMS = IN_ROWS * IN_COLS * 2;            // (pixel, 8-channel half) = one 16-byte LDS slot
     static constexpr int NIT = (IN_ITEMS + 255) / 256;
@@ -79,10 +80,10 @@ struct BfCfg {
     static constexpr int LDS_BYTES = (IN_ITEMS + W_ITEMS) * 16;
 };
 
-template <int NT, int WPS>
+template <int NT, int WPS, int TW = 32>
 __global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
-    using C = BfCfg<NT>;
-    constexpr int ROWS = C::ROWS, IN_COLS = C::IN_COLS, NIT = C::NIT, NWI = C::NWI, CO_T = C::CO_T;
+    using C = BfCfg<NT, TW>;
+    constexpr int ROWS = C::ROWS, IN_COLS = C::IN_COLS, NIT = C::NIT, NWI = C::NWI, CO_T = C::CO_T, RPT = C::RPT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     u32x4b* w_lds = reinterpret_cast<u32x4b*>(smem_b);                 // [9][64 co][2 halves]
     u32x4b* in_lds = w_lds + C::W_ITEMS;                               // [IN_ROWS][IN_COLS][2 halves]
@@ -98,10 +99,11 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
     bid /= a.tilesY;
     const int b = bid % a.B;
     const int coT = bid / a.B;
-    const int co0 = coT * CO_T, y0 = ty * ROWS, x0 = tx * 32;
+    const int co0 = coT * CO_T, y0 = ty * ROWS, x0 = tx * TW;
 
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
+    const int px = l31 % TW, py = l31 / TW;
     const int HW = a.H * a.W;
 
     f32x16 acc[2][NT];
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
     };
 
     const u32x4b* a_ptr = w_lds + l31 * 2 + kh;                                   // + (tap * 64 + m * 32) * 2
-    const u32x4b* b_ptr = in_lds + ((wn * NT) * IN_COLS + l31) * 2 + kh;          // + ((n + ky) * IN_COLS + kx) * 2
+    const u32x4b* b_ptr = in_lds + ((wn * NT * RPT + py) * IN_COLS + px) * 2 + kh;   // + ((n * RPT + ky) * IN_COLS + kx) * 2
 
     unsigned cin_bytes = 0, cw_bytes = 0;
     issue(0, 0);
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
 #pragma unroll
             for (int m = 0; m < 2; ++m) av[m] = __builtin_bit_cast(bf16x8, a_ptr[(t * CO_T + m * 32) * 2]);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) bv[n] = __builtin_bit_cast(bf16x8, b_ptr[((n + ky) * IN_COLS + kx) * 2]);
+            for (int n = 0; n < NT; ++n) bv[n] = __builtin_bit_cast(bf16x8, b_ptr[((n * RPT + ky) * IN_COLS + kx) * 2]);
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -198,12 +200,12 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
     }
 
     float* zb = a.z + (int64_t)b * a.z_bs;
-    const int xo = x0 + l31;
+    const int xo = x0 + px;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            const int yo = y0 + wn * NT + n;
+            const int yo = y0 + (wn * NT + n) * RPT + py;
             if (yo < a.H && xo < a.W) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -214,15 +216,15 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
         }
 }
 
-template <int NT, int WPS>
+template <int NT, int WPS, int TW = 32>
 static int launch_bf16(BfArgs a, hipStream_t st) {
-    using C = BfCfg<NT>;
-    a.tilesX = cdiv(a.W, 32);
+    using C = BfCfg<NT, TW>;
+    a.tilesX = cdiv(a.W, TW);
     a.tilesY = cdiv(a.H, C::ROWS);
     a.coTiles = cdiv(a.Cout, C::CO_T);
     const int64_t blocks = (int64_t)a.B * a.tilesX * a.tilesY * a.coTiles;
     ONET_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv3x3_bf16: grid %lld out of range", (long long)blocks);
-    auto kern = conv3x3_bf16_kernel<NT, WPS>;
+    auto kern = conv3x3_bf16_kernel<NT, WPS, TW>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -423,7 +425,7 @@ int onet_conv3x3_bf16_fwd(const float* x, int64_t x_bs, const void* wq, float* z
     BfArgs a{x, x_bs, (const __bf16*)wq, z, z_bs, B, Cin, Cout, H, W, 0, 0, 0};
     // 4 waves x 2 rows x 32 px, two blocks (8 waves) per CU: 373-851 TF on the U-Net's layers against 278-527 for
     // 4-row waves at one wave per SIMD and ~100 for 4-row waves squeezed into 256 VGPRs (700 B/lane of scratch)
-    return launch_bf16<2, 2>(a, as_stream(stream));
+    return (W > 16) ? launch_bf16<2, 2>(a, as_stream(stream)) : launch_bf16<2, 2, 16>(a, as_stream(stream));
 }
 
 int64_t onet_conv3x3_wgrad_bf16_ws_bytes(int B, int Cin, int Cout, int H, int W) {

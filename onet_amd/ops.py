@@ -157,8 +157,7 @@ def convT2x2_fwd(x, wq, bias, out, Ct, pt, pl):
 #   "winograd4"       F(4x4,3x3) on every legal layer with maps >= 8x8 (parity tests)      "winograd" / "winograd2"  F(2x2,3x3)
 #   "direct"          implicit GEMM only
 #   "bf16"            BASELINE config 3: bf16-operand MFMA kernel (conv_bf16.hip) for forward / input gradient on every
-#                     layer with Cin % 16 == 0 and maps >= 32 px wide, weight gradients of every layer with Cin >= 16 on
-#                     maps >= 16 px wide; "auto" (fp32) elsewhere
+#                     layer with Cin % 16 == 0 and the weight gradient of every layer with Cin >= 16, on maps >= 16 px wide; "auto" (fp32) elsewhere
 # Layers no Winograd kernel takes (stem Cin < 16, channel counts not multiples of 4) always run direct.
 import os as _os
 CONV_ALGO = _os.environ.get("ONET_CONV_ALGO", "auto")
@@ -177,7 +176,7 @@ def conv3x3_algo(B, Cin, Cout, H, W):
     """-> "winograd4" | "winograd" | "direct" for a conv with Cin inputs and Cout outputs on B maps of H x W."""
     algo = "winograd" if CONV_ALGO == "winograd2" else CONV_ALGO
     if algo == "bf16":
-        if Cin % 16 == 0 and Cout % 4 == 0 and W >= 32 and H >= 8:
+        if Cin % 16 == 0 and Cout % 4 == 0 and W >= 16 and H >= 8:
             return "bf16"
         algo = "auto"
     if algo == "direct" or not _wino_legal(Cin, Cout):

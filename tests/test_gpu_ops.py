@@ -234,7 +234,8 @@ def test_winograd4_fused_bn_statistics(dev, B, Cin, Cout, H, W):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 16, 64, 32, 32), (1, 32, 48, 20, 44), (2, 64, 128, 64, 64),
-                                             (3, 48, 32, 17, 33), (2, 128, 64, 16, 96)])
+                                             (3, 48, 32, 17, 33), (2, 128, 64, 16, 96), (3, 64, 128, 16, 16),
+                                             (2, 32, 80, 21, 13)])
 def test_conv3x3_bf16_operands(dev, B, Cin, Cout, H, W):
     """BASELINE config 3's bf16 MFMA conv path (conv_bf16.hip), forward and input-gradient orientation: the kernel
     rounds activations and weights to bf16 (nearest-even) and accumulates in fp32, so it must equal an fp64 convolution
