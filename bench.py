@@ -176,7 +176,7 @@ def main():
         out = {"metric": "training images/sec (twin 256x256 pass)", "value": round(imgs / elapsed, 3),
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "bf16 conv operands (fwd/dgrad), f32 accumulate/storage/wgrad" if bf16 else "f32",
+               "vs_baseline": None, "dtype": "bf16 conv operands (fwd/dgrad/wgrad), f32 accumulate/storage" if bf16 else "f32",
                "data": "synthetic",
                "config": {"workload": "%s: batch=%d/GPU %dx%dx%d synthetic K-clutter, %s, twin U-Net "
                                       "fwd+JSD loss+bwd+Adam" % ("configs[2]" if bf16 else "configs[1]", args.batch, args.chans,
