@@ -99,7 +99,11 @@ class ConvBNReLUFn(torch.autograd.Function):
         dx = None
         if need_x:
             lk = ctx.link_in
-            fused = ops.conv3x3_dgrad_bnreduce(dz, ctx.packed, lk["z"], lk["save"]) if lk is not None else None
+            fused = None
+            if lk is not None and "z" in lk:
+                # (z, save) leave the dict here: the graph -- and with it this ctx and the dict -- lives as long as the
+                # caller holds the loss tensor, i.e. into the next step; a whole set of pre-activations must not
+                fused = ops.conv3x3_dgrad_bnreduce(dz, ctx.packed, lk.pop("z"), lk.pop("save"))
             if fused is not None:
                 dx, r = fused
                 lk["da"], lk["rec"] = dx, r
@@ -190,8 +194,8 @@ class SkipPoolFn(torch.autograd.Function):
             gs = [g for g in (g_skip, g_ret) if g is not None]
             return (sum(gs[1:], gs[0]) if gs else None), None, None
         lk = ctx.link
-        if lk is not None:
-            dx, part2 = ops.maxpool2_bwd(x, g_pool, add=g_skip, add2=g_ret, bn=(lk["z"], lk["save"]))
+        if lk is not None and "z" in lk:
+            dx, part2 = ops.maxpool2_bwd(x, g_pool, add=g_skip, add2=g_ret, bn=(lk.pop("z"), lk.pop("save")))
             if part2 is not None:
                 lk["da"], lk["rec4"] = dx, part2
             return dx, None, None
