@@ -211,6 +211,30 @@ def test_deferred_nan_assertion(dev, monkeypatch):
     assert not ops._NAN_PENDING
 
 
+def test_held_loss_does_not_pin_activations(dev):
+    """A training loop holds the loss tensor (and with it the autograd graph objects) until the next step overwrites it.
+    Saved tensors are released by backward; whatever the Functions keep on ctx besides must be small: the dicts that
+    hand BatchNorm records between units once kept every pre-activation alive into the next step (+30 GB at B=256)."""
+    import gc
+    m = _model(1, True, dev)
+    X = orc.det_input(2, 1, 64, 64).to(dev)
+    _, loss = _step(m, X)                      # warm the allocator / packs
+    del loss
+    m.zero_grad(set_to_none=True)
+    gc.collect()
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated(dev)
+    outs, loss = _step(m, X)
+    del outs
+    m.zero_grad(set_to_none=True)
+    gc.collect()
+    torch.cuda.synchronize()
+    held = torch.cuda.memory_allocated(dev) - base
+    act = 2 * 2 * 64 * 64 * 64 * 4             # ONE 64-channel full-resolution activation of the twin batch
+    assert held < act // 2, f"{held} bytes stay allocated while the loss is held (one activation = {act})"
+    del loss
+
+
 def test_eval_mode_vs_reference_golden(dev):
     g = np.load(os.path.join(G, "onet_b2_c1_32_eval.npz"))
     B, C, H, W, bshare, train, steps = [int(v) for v in g["meta"]]
