@@ -130,6 +130,14 @@ int onet_conv3x3_bf16_fwd(const float* x, int64_t x_bs, const void* wq, float* z
 int64_t onet_conv3x3_wgrad_bf16_ws_bytes(int B, int Cin, int Cout, int H, int W);
 int onet_conv3x3_wgrad_bf16(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs, float* dw, void* ws,
                             int64_t ws_bytes, int B, int Cin, int Cout, int H, int W, int accumulate, void* stream);
+/* Larger-tile weight gradient: Winograd F(3x3,4x4) (4x fewer multiplies than direct, 1.78x fewer than the F(2x2,3x3)
+ * kernel below; 6x6 input tiles, 4x4 tiles of dz in the filter's role, the points of onet_conv3x3_winograd4_fwd; split-K
+ * 36-position slabs folded by A'^T . A').  Where onet_conv3x3_winograd4_wgrad_ok() returns 1 (W % 32 == 0, H % 4 == 0,
+ * Cin % 32 == 0); same result contract as onet_conv3x3_winograd_wgrad. */
+int onet_conv3x3_winograd4_wgrad_ok(int B, int Cin, int Cout, int H, int W);
+int64_t onet_conv3x3_winograd4_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W);
+int onet_conv3x3_winograd4_wgrad(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs, float* dw, void* ws,
+                                 int64_t ws_bytes, int B, int Cin, int Cout, int H, int W, int accumulate, void* stream);
 /* Winograd weight gradient: dW = G^T [ sum_tiles (A dY A^T) (.) (B^T d B) ] G, split-K over pixel strips,
  * deterministic slab reduction; dw is [Cout][Cin][3][3]. */
 int onet_conv3x3_winograd_wgrad(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs, float* dw,

@@ -407,6 +407,32 @@ def conv3x3_winograd_wgrad(x, dz, dw_shape, out=None):
     return dw
 
 
+def conv3x3_winograd4_wgrad(x, dz, dw_shape, out=None):
+    """dW of a 3x3 convolution by Winograd F(3x3,4x4) (conv_wino4w.hip); see `winograd4_wgrad_ok` for its shapes."""
+    require_gpu(x, dz)
+    x, xbs = plane(x)
+    dz, dzbs = plane(dz)
+    B, Cin, H, W = x.shape
+    Cout = dz.shape[1]
+    dw = torch.empty(dw_shape, dtype=F32, device=x.device) if out is None else out
+    need = _lib.load().onet_conv3x3_winograd4_wgrad_ws_bytes(B, Cin, Cout, H, W)
+    ws = workspace(need, x.device)
+    e0 = _prof_begin()
+    _lib.call("onet_conv3x3_winograd4_wgrad", _p(x), xbs, _p(dz), dzbs, _p(dw), _p(ws), ws.numel() * 4, B, Cin, Cout, H, W,
+              0, _stream())
+    _prof_end("conv_wino4_wgrad_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0)
+    return dw
+
+
+WGRAD4 = _os.environ.get("ONET_WGRAD4", "0") != "0"
+
+
+def winograd4_wgrad_ok(x, dz):
+    B, Cin, H, W = x.shape
+    return bool(_lib.load().onet_conv3x3_winograd4_wgrad_ok(B, Cin, dz.shape[1], H, W)) and \
+        x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and dz.is_contiguous()
+
+
 def conv3x3_wgrad_bf16(x, dz, dw_shape, out=None):
     """dW of a 3x3 convolution with bf16 operands (x, dz rounded on the way into LDS), fp32 accumulation."""
     require_gpu(x, dz)
@@ -430,6 +456,8 @@ def conv3x3_wgrad_auto(x, dz, dw_shape, out=None):
             and dz.is_contiguous()):
         return conv3x3_wgrad_bf16(x, dz, dw_shape, out=out)
     if use_winograd(Cin, Cout, x.shape[2], x.shape[3]):
+        if WGRAD4 and winograd4_wgrad_ok(x, dz):
+            return conv3x3_winograd4_wgrad(x, dz, dw_shape, out=out)
         return conv3x3_winograd_wgrad(x, dz, dw_shape, out=out)
     return conv_wgrad(x, dz, dw_shape, 3, out=out)
 

@@ -262,6 +262,22 @@ def test_conv3x3_bf16_operands(dev, B, Cin, Cout, H, W):
         assert qd is None
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(1, 32, 64, 4, 32), (2, 64, 64, 32, 32), (3, 32, 72, 20, 64), (2, 128, 256, 64, 64),
+                                             (4, 64, 128, 16, 96)])
+def test_conv3x3_winograd4_wgrad(dev, B, Cin, Cout, H, W):
+    """Winograd F(3x3,4x4) weight gradient (conv_wino4w.hip) against the fp64 weight gradient: single unit, several
+    units and split-K plans, channel tails in Cout, borders (zero padding on all four sides)."""
+    from onet_amd import ops
+    x = rnd(B, Cin, H, W, seed=91)
+    g = rnd(B, Cout, H, W, seed=92)
+    assert ops.winograd4_wgrad_ok(x.to(dev), g.to(dev))
+    dw = ops.conv3x3_winograd4_wgrad(x.to(dev), g.to(dev), (Cout, Cin, 3, 3)).cpu().double()
+    ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), g.double(), stride=1, padding=1)
+    sc = float(ref.abs().max())
+    err = float((dw - ref).abs().max())
+    assert err <= 2e-4 * sc, (err, sc)
+
+
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 64, 64, 32, 32), (3, 16, 48, 20, 44), (2, 128, 64, 16, 16),
                                              (1, 72, 40, 9, 28), (4, 64, 128, 64, 64)])
 def test_conv3x3_wgrad_bf16_operands(dev, B, Cin, Cout, H, W):

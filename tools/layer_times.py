@@ -28,6 +28,7 @@ for name, ci, co, div in layers:
     tf = timeit(lambda: ops.conv3x3_auto(x, pk, 0))
     td = timeit(lambda: ops.conv3x3_auto(g, pk, 1))
     tw = timeit(lambda: ops.conv3x3_wgrad_auto(x, g, (co, ci, 3, 3)))
+    tw4 = timeit(lambda: ops.conv3x3_winograd4_wgrad(x, g, (co, ci, 3, 3))) if ops.winograd4_wgrad_ok(x, g) else float("nan")
     tot[0] += tf; tot[1] += td; tot[2] += tw
-    print(f"{name:8s} {ci:5d} {co:5d} {h:5d} | {tf:6.3f} {fl/tf:5.0f} | {td:6.3f} {fl/td:5.0f} | {tw:6.3f} {fl/tw:5.0f}   algo {ops.conv3x3_algo(B, ci, co, h, h)}/{ops.conv3x3_algo(B, co, ci, h, h)}")
+    print(f"{name:8s} {ci:5d} {co:5d} {h:5d} | {tf:6.3f} {fl/tf:5.0f} | {td:6.3f} {fl/td:5.0f} | {tw:6.3f} {fl/tw:5.0f} | F(4x4)-wgrad {tw4:6.3f} {fl/tw4:5.0f}   algo {ops.conv3x3_algo(B, ci, co, h, h)}/{ops.conv3x3_algo(B, co, ci, h, h)}")
 print("totals ms: fwd %.2f dgrad %.2f wgrad %.2f" % tuple(tot))
