@@ -60,7 +60,8 @@ struct W4wArgs {
 };
 
 constexpr int W4_SX = 220, W4_SDZ = 132, W4_XROW = 36;     // floats: per ci (6 rows x 36), per co (4 rows x 32), per patch row
-constexpr int W4_LDS_FLOATS = 32 * W4_SX + 64 * W4_SDZ;
+constexpr int W4_BUF_FLOATS = 32 * W4_SX + 64 * W4_SDZ;   // one unit: 62 KB
+constexpr int W4_LDS_FLOATS = 2 * W4_BUF_FLOATS;          // double-buffered: one barrier per unit
 
 template <int RH, int CH>
 static __device__ __forceinline__ void wino4w_body(const W4wArgs& a, float* lds) {
@@ -79,8 +80,6 @@ static __device__ __forceinline__ void wino4w_body(const W4wArgs& a, float* lds)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid & 1;
     const int l31 = lane & 31, kh = lane >> 5;
     const int HW = a.H * a.W;
-    float* x_lds = lds;
-    float* dz_lds = lds + 32 * W4_SX;
 
     f32x16 acc[9];
 #pragma unroll
@@ -117,7 +116,9 @@ static __device__ __forceinline__ void wino4w_body(const W4wArgs& a, float* lds)
             for (int k = 0; k < 8; ++k) q[k] = __builtin_amdgcn_raw_buffer_load_b128(dr, ok ? base + 16 * k : OOB_W4, 0, 0);
         }
     };
-    auto commit = [&]() __attribute__((always_inline)) {
+    auto commit = [&](float* buf) __attribute__((always_inline)) {
+        float* x_lds = buf;
+        float* dz_lds = buf + 32 * W4_SX;
         if (x_role) {
             // LDS row: element 0 = column x0 - 1, 1..32 the interior, 33 = column x0 + 32: the interior sits one float off
             // the 16-byte grid, so the b128 stores are re-cut from neighbouring loads (register selection, no VALU)
@@ -141,16 +142,15 @@ static __device__ __forceinline__ void wino4w_body(const W4wArgs& a, float* lds)
         }
     };
 
-    const float* xb = x_lds + l31 * W4_SX + RH * W4_XROW + kh * 4;             // patch rows RH .. RH+4 of tile 2s + kh
-    const float* zb = dz_lds + (wm * 32 + l31) * W4_SDZ + kh * 4;              // dY rows 0..3 of tile 2s + kh
+    const int xb_off = l31 * W4_SX + RH * W4_XROW + kh * 4;                   // patch rows RH .. RH+4 of tile 2s + kh
+    const int zb_off = 32 * W4_SX + (wm * 32 + l31) * W4_SDZ + kh * 4;         // dY rows 0..3 of tile 2s + kh
 
-    issue(u0);
-    for (int u = u0; u < u1; ++u) {
-        commit();
-        __syncthreads();
-        issue(u + 1);
+    auto ksteps = [&](const float* buf, int s0, int s1) __attribute__((always_inline)) {
+        const float* xb = buf + xb_off;
+        const float* zb = buf + zb_off;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
+            if (s < s0 || s >= s1) continue;
             float d[5][6];
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
@@ -176,6 +176,22 @@ static __device__ __forceinline__ void wino4w_body(const W4wArgs& a, float* lds)
 #pragma unroll
             for (int p = 0; p < 9; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[p], uu[p], acc[p], 0, 0, 0);
         }
+    };
+
+    // unit u lives in buffer (u - u0) & 1; the registers hold unit u+1 during the first half of unit u's K-steps and are
+    // committed to the other buffer between K-steps 1 and 2 (every wave left that buffer at the barrier that ended unit
+    // u-1), then take unit u+2: ONE barrier per unit
+    issue(u0);
+    commit(lds);
+    __syncthreads();
+    issue(u0 + 1);
+    for (int u = u0; u < u1; ++u) {
+        float* cur = lds + ((u - u0) & 1) * W4_BUF_FLOATS;
+        float* nxt = lds + (((u - u0) & 1) ^ 1) * W4_BUF_FLOATS;
+        ksteps(cur, 0, 2);
+        commit(nxt);
+        issue(u + 2);
+        ksteps(cur, 2, 4);
         __syncthreads();
     }
 
