@@ -38,15 +38,16 @@ static __device__ __forceinline__ void w_bt3(float d0, float d1, float d2, float
         o0 = fmaf(2.f, e, c); o1 = fmaf(-2.f, e, c); o2 = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
     }
 }
-// half of G' (6x4: rows p^j / N_p for p = 0, 1, -1, 2, -2 with N = 4, -6, -6, 24, 24; row inf = (0,0,0,1))
+// half of G' (6x4: rows p^j / N_p for p = 0, 1, -1, 2, -2 with N = 4, -6, -6, 24, 24; row inf = (0,0,0,1)) WITHOUT the
+// 1/N_p factors: they are applied once per position by the fold kernel (W4_SCALE), not per tile here
 template <int HALF>
 static __device__ __forceinline__ void w_g3(float d0, float d1, float d2, float d3, float& o0, float& o1, float& o2) {
     if constexpr (HALF == 0) {
         const float e = d0 + d2, o = d1 + d3;
-        o0 = 0.25f * d0; o1 = (-1.f / 6.f) * (e + o); o2 = (-1.f / 6.f) * (e - o);
+        o0 = d0; o1 = e + o; o2 = e - o;
     } else {
         const float e = fmaf(4.f, d2, d0), o = fmaf(8.f, d3, 2.f * d1);
-        o0 = (1.f / 24.f) * (e + o); o1 = (1.f / 24.f) * (e - o); o2 = d3;
+        o0 = e + o; o1 = e - o; o2 = d3;
     }
 }
 
@@ -227,12 +228,13 @@ __global__ __launch_bounds__(256) void wino4w_fold_kernel(const float* __restric
                                                           int64_t n, int accumulate) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
+    constexpr float W4_SCALE[6] = {0.25f, -1.f / 6.f, -1.f / 6.f, 1.f / 24.f, 1.f / 24.f, 1.f};   // 1 / N_p of G'
     float m[6][6];
 #pragma unroll
     for (int p = 0; p < 36; ++p) {
         float s = 0.f;
         for (int k = 0; k < splitK; ++k) s += slab[((int64_t)k * 36 + p) * n + i];
-        m[p / 6][p % 6] = s;
+        m[p / 6][p % 6] = s * (W4_SCALE[p / 6] * W4_SCALE[p % 6]);
     }
     float t[3][6];
 #pragma unroll

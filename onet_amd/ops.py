@@ -425,9 +425,9 @@ def conv3x3_winograd4_wgrad(x, dz, dw_shape, out=None):
 
 
 # ONET_WGRAD4: "auto" (default) = the F(3x3,4x4) weight gradient where it is the faster one today: layers with at least
-# 32 (64 co x 32 ci) tiles, whose operands are re-read from L2 (d2.c2, d3.*, up1.*, up2.* of the 256x256 U-Net: 237-285
-# TF against 224-236); with fewer tiles its one-unit prefetch does not cover HBM latency (70-164 TF).  "1": wherever
-# legal; "0": never.
+# 256 input channels, whose strips are re-read from L2 by many tiles (d2.c2, d3.*, up1.*, up2.*, up3.c1 of the 256x256
+# U-Net: 244-290 TF against 227-237); below that its one-unit prefetch does not cover HBM latency (72-166 TF).
+# "1": wherever legal; "0": never.
 WGRAD4 = _os.environ.get("ONET_WGRAD4", "auto")
 
 
@@ -460,7 +460,7 @@ def conv3x3_wgrad_auto(x, dz, dw_shape, out=None):
             and dz.is_contiguous()):
         return conv3x3_wgrad_bf16(x, dz, dw_shape, out=out)
     if use_winograd(Cin, Cout, x.shape[2], x.shape[3]):
-        if WGRAD4 != "0" and (WGRAD4 == "1" or (Cin // 32) * (-(-Cout // 64)) >= 32) and winograd4_wgrad_ok(x, dz):
+        if WGRAD4 != "0" and (WGRAD4 == "1" or Cin >= 256) and winograd4_wgrad_ok(x, dz):
             return conv3x3_winograd4_wgrad(x, dz, dw_shape, out=out)
         return conv3x3_winograd_wgrad(x, dz, dw_shape, out=out)
     return conv_wgrad(x, dz, dw_shape, 3, out=out)
