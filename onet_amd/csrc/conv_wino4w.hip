@@ -60,12 +60,21 @@ struct W4wArgs {
     int B, Cin, Cout, H, W, ciTiles, coTiles, splitK, tilesY, tilesX;
 };
 
-constexpr int W4_SX = 220, W4_SDZ = 132, W4_XROW = 36;     // floats: per ci (6 rows x 36), per co (4 rows x 32), per patch row
-constexpr int W4_BUF_FLOATS = 32 * W4_SX + 64 * W4_SDZ;   // one unit: 62 KB
-constexpr int W4_LDS_FLOATS = 2 * W4_BUF_FLOATS;          // double-buffered: one barrier per unit
+constexpr int W4_SDZ = 132;                               // floats per co: 4 rows x 32 px (+4: stride 4 x odd)
+// input strip per ci: 6 patch rows of W4C<W16>::XROW floats.  W16 = 0: one image row segment, element 0 = column x0 - 1,
+// 1..32 the interior, 33 = column x0 + 32.  W16 = 1 (16-px-wide maps: two IMAGES side by side, their tile rows are the
+// unit's 8 tiles): 0 | 16 px of image 0 | 0 | 2 pad | 0 | 16 px of image 1 | 0 -- image 1 starts at element 20 so that its
+// patches stay 16-byte aligned; every halo column is the zero padding
+template <int W16>
+struct W4C {
+    static constexpr int XROW = W16 ? 40 : 36, SX = W16 ? 244 : 220;          // SX = 6 * XROW + 4 (4 x odd)
+    static constexpr int BUF_FLOATS = 32 * SX + 64 * W4_SDZ;                   // one unit: 62 / 65 KB
+    static constexpr int LDS_FLOATS = 2 * BUF_FLOATS;                          // double-buffered: one barrier per unit
+};
 
-template <int RH, int CH>
-static __device__ __forceinline__ void wino4w_body(const W4wArgs& a, float* lds) {
+template <int RH, int CH, int W16>
+static __device__ __forceinline__ void wino4w_body(const W4wArgs a, float* lds) {
+    constexpr int W4_XROW = W4C<W16>::XROW, W4_SX = W4C<W16>::SX, W4_BUF_FLOATS = W4C<W16>::BUF_FLOATS;
     int bid;
     {
         const int n = gridDim.x, q = n >> 3, r = n & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -74,7 +83,7 @@ static __device__ __forceinline__ void wino4w_body(const W4wArgs& a, float* lds)
     const int tiles = a.ciTiles * a.coTiles;
     const int ks = bid / tiles, tile = bid % tiles;
     const int ci0 = (tile % a.ciTiles) * 32, co0 = (tile / a.ciTiles) * 64;
-    const int nunits = a.B * a.tilesY * a.tilesX;
+    const int nunits = W16 ? (a.B / 2) * a.tilesY : a.B * a.tilesY * a.tilesX;
     const int per = (nunits + a.splitK - 1) / a.splitK;
     const int u0 = ks * per, u1 = min(u0 + per, nunits);
 
@@ -97,24 +106,35 @@ static __device__ __forceinline__ void wino4w_body(const W4wArgs& a, float* lds)
     auto issue = [&](int u) __attribute__((always_inline)) {
         const bool live = u < u1;
         const int uu = live ? u : 0;
-        const int tx = uu % a.tilesX, ty = (uu / a.tilesX) % a.tilesY, b = uu / (a.tilesX * a.tilesY);
+        const int tx = W16 ? 0 : uu % a.tilesX, ty = W16 ? uu % a.tilesY : (uu / a.tilesX) % a.tilesY;
+        const int b = W16 ? 2 * (uu / a.tilesY) : uu / (a.tilesX * a.tilesY);          // W16: images b, b + 1
         const int y0 = ty * 4, x0 = tx * 32;
         if (x_role) {
-            const __amdgpu_buffer_rsrc_t xr = w4_rsrc(a.x + (int64_t)b * a.x_bs, (int64_t)a.Cin * HW * 4);
+            const __amdgpu_buffer_rsrc_t xr = w4_rsrc(a.x + (int64_t)b * a.x_bs, ((W16 ? a.x_bs : 0) + (int64_t)a.Cin * HW) * 4);
             const int yy = y0 - 1 + xr_r;
             const bool rok = live && yy >= 0 && yy < a.H && ci0 + xr_c < a.Cin;
             const unsigned base = (unsigned)(((ci0 + xr_c) * HW + yy * a.W + x0) * 4);
+            const unsigned img1 = (unsigned)(a.x_bs * 4);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) q[k] = __builtin_amdgcn_raw_buffer_load_b128(xr, rok ? base + 16 * k : OOB_W4, 0, 0);
-            hl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (rok && x0 > 0) ? base - 4 : OOB_W4, 0, 0));
-            hr = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (rok && x0 + 32 < a.W) ? base + 128 : OOB_W4, 0, 0));
+            for (int k = 0; k < 8; ++k)
+                q[k] = __builtin_amdgcn_raw_buffer_load_b128(xr, rok ? (W16 ? base + (k >> 2) * img1 + 16 * (k & 3) : base + 16 * k) : OOB_W4, 0, 0);
+            if constexpr (!W16) {
+                hl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (rok && x0 > 0) ? base - 4 : OOB_W4, 0, 0));
+                hr = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (rok && x0 + 32 < a.W) ? base + 128 : OOB_W4, 0, 0));
+            } else {
+                // (never left unassigned: with hl / hr captured but untouched on this path hipcc keeps the whole closure
+                // in scratch -- 368 B/lane and 2.5x the run time)
+                hl = hr = 0.f;
+            }
         } else if (z_role) {
-            const __amdgpu_buffer_rsrc_t dr = w4_rsrc(a.dz + (int64_t)b * a.dz_bs, (int64_t)a.Cout * HW * 4);
+            const __amdgpu_buffer_rsrc_t dr = w4_rsrc(a.dz + (int64_t)b * a.dz_bs, ((W16 ? a.dz_bs : 0) + (int64_t)a.Cout * HW) * 4);
             const int yy = y0 + zr_r;
             const bool ok = live && yy < a.H && co0 + zr_c < a.Cout;
             const unsigned base = (unsigned)(((co0 + zr_c) * HW + yy * a.W + x0) * 4);
+            const unsigned img1 = (unsigned)(a.dz_bs * 4);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) q[k] = __builtin_amdgcn_raw_buffer_load_b128(dr, ok ? base + 16 * k : OOB_W4, 0, 0);
+            for (int k = 0; k < 8; ++k)
+                q[k] = __builtin_amdgcn_raw_buffer_load_b128(dr, ok ? (W16 ? base + (k >> 2) * img1 + 16 * (k & 3) : base + 16 * k) : OOB_W4, 0, 0);
         }
     };
     auto commit = [&](float* buf) __attribute__((always_inline)) {
@@ -127,15 +147,35 @@ static __device__ __forceinline__ void wino4w_body(const W4wArgs& a, float* lds)
             f32x4w f[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) f[k] = __builtin_bit_cast(f32x4w, q[k]);
-            f32x4w w0 = {hl, f[0][0], f[0][1], f[0][2]};
-            *reinterpret_cast<f32x4w*>(row) = w0;
+            if constexpr (!W16) {
+                f32x4w w0 = {hl, f[0][0], f[0][1], f[0][2]};
+                *reinterpret_cast<f32x4w*>(row) = w0;
 #pragma unroll
-            for (int k = 1; k < 8; ++k) {
-                f32x4w wk = {f[k - 1][3], f[k][0], f[k][1], f[k][2]};
-                *reinterpret_cast<f32x4w*>(row + 4 * k) = wk;
+                for (int k = 1; k < 8; ++k) {
+                    f32x4w wk = {f[k - 1][3], f[k][0], f[k][1], f[k][2]};
+                    *reinterpret_cast<f32x4w*>(row + 4 * k) = wk;
+                }
+                f32x2w w8 = {f[7][3], hr};
+                *reinterpret_cast<f32x2w*>(row + 32) = w8;
+            } else {
+                // image m at elements 20 m .. 20 m + 17
+                const f32x4w a0 = {0.f, f[0][0], f[0][1], f[0][2]}, a1 = {f[0][3], f[1][0], f[1][1], f[1][2]};
+                const f32x4w a2 = {f[1][3], f[2][0], f[2][1], f[2][2]}, a3 = {f[2][3], f[3][0], f[3][1], f[3][2]};
+                const f32x2w a4 = {f[3][3], 0.f};
+                const f32x4w b0 = {0.f, f[4][0], f[4][1], f[4][2]}, b1 = {f[4][3], f[5][0], f[5][1], f[5][2]};
+                const f32x4w b2 = {f[5][3], f[6][0], f[6][1], f[6][2]}, b3 = {f[6][3], f[7][0], f[7][1], f[7][2]};
+                const f32x2w b4 = {f[7][3], 0.f};
+                *reinterpret_cast<f32x4w*>(row) = a0;
+                *reinterpret_cast<f32x4w*>(row + 4) = a1;
+                *reinterpret_cast<f32x4w*>(row + 8) = a2;
+                *reinterpret_cast<f32x4w*>(row + 12) = a3;
+                *reinterpret_cast<f32x2w*>(row + 16) = a4;
+                *reinterpret_cast<f32x4w*>(row + 20) = b0;
+                *reinterpret_cast<f32x4w*>(row + 24) = b1;
+                *reinterpret_cast<f32x4w*>(row + 28) = b2;
+                *reinterpret_cast<f32x4w*>(row + 32) = b3;
+                *reinterpret_cast<f32x2w*>(row + 36) = b4;
             }
-            f32x2w w8 = {f[7][3], hr};
-            *reinterpret_cast<f32x2w*>(row + 32) = w8;
         } else if (z_role) {
             u32x4w* row = reinterpret_cast<u32x4w*>(dz_lds + zr_c * W4_SDZ + zr_r * 32);
 #pragma unroll
@@ -155,8 +195,9 @@ static __device__ __forceinline__ void wino4w_body(const W4wArgs& a, float* lds)
             float d[5][6];
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
-                const f32x4w v = *reinterpret_cast<const f32x4w*>(xb + r * W4_XROW + s * 8);
-                const f32x2w h = *reinterpret_cast<const f32x2w*>(xb + r * W4_XROW + s * 8 + 4);
+                const int so = s * 8 + ((W16 && s >= 2) ? 4 : 0);               // W16: tiles 4..7 are image 1, 4 floats on
+                const f32x4w v = *reinterpret_cast<const f32x4w*>(xb + r * W4_XROW + so);
+                const f32x2w h = *reinterpret_cast<const f32x2w*>(xb + r * W4_XROW + so + 4);
                 d[r][0] = v[0]; d[r][1] = v[1]; d[r][2] = v[2]; d[r][3] = v[3]; d[r][4] = h[0]; d[r][5] = h[1];
             }
             float y[4][4];
@@ -212,14 +253,15 @@ static __device__ __forceinline__ void wino4w_body(const W4wArgs& a, float* lds)
         }
 }
 
+template <int W16>
 __global__ __launch_bounds__(512, 2) void conv_wino4_wgrad_kernel(W4wArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem_w4[];
     const int pg = (threadIdx.x >> 6) >> 1;
     switch (__builtin_amdgcn_readfirstlane(pg)) {
-        case 0: wino4w_body<0, 0>(a, smem_w4); break;
-        case 1: wino4w_body<0, 1>(a, smem_w4); break;
-        case 2: wino4w_body<1, 0>(a, smem_w4); break;
-        default: wino4w_body<1, 1>(a, smem_w4); break;
+        case 0: wino4w_body<0, 0, W16>(a, smem_w4); break;
+        case 1: wino4w_body<0, 1, W16>(a, smem_w4); break;
+        case 2: wino4w_body<1, 0, W16>(a, smem_w4); break;
+        default: wino4w_body<1, 1, W16>(a, smem_w4); break;
     }
 }
 
@@ -257,7 +299,7 @@ __global__ __launch_bounds__(256) void wino4w_fold_kernel(const float* __restric
 static void wino4w_plan(int B, int Cin, int Cout, int H, int W, int& splitK, int& tilesY, int& tilesX) {
     tilesY = cdiv(H, 4);
     tilesX = cdiv(W, 32);
-    const int64_t units = (int64_t)B * tilesY * tilesX;
+    const int64_t units = (W == 16) ? (int64_t)(B / 2) * tilesY : (int64_t)B * tilesY * tilesX;
     const int64_t tiles = (int64_t)cdiv(Cin, 32) * cdiv(Cout, 64);
     int64_t k = std::max<int64_t>(1, (512 + tiles - 1) / tiles);                 // one 8-wave block per CU, ~2 rounds
     const int64_t per = (int64_t)36 * Cout * Cin * 4;
@@ -269,7 +311,8 @@ static void wino4w_plan(int B, int Cin, int Cout, int H, int W, int& splitK, int
 extern "C" {
 
 int onet_conv3x3_winograd4_wgrad_ok(int B, int Cin, int Cout, int H, int W) {
-    return (B > 0 && Cin >= 32 && (Cin % 32) == 0 && Cout > 0 && (Cout % 4) == 0 && (W % 32) == 0 && (H % 4) == 0) ? 1 : 0;
+    const bool wide = (W % 32) == 0, two = (W == 16) && (B % 2) == 0;       // two: a pair of 16-px-wide images per unit
+    return (B > 0 && Cin >= 32 && (Cin % 32) == 0 && Cout > 0 && (Cout % 4) == 0 && (wide || two) && (H % 4) == 0) ? 1 : 0;
 }
 
 int64_t onet_conv3x3_winograd4_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W) {
@@ -282,7 +325,7 @@ int onet_conv3x3_winograd4_wgrad(const float* x, int64_t x_bs, const float* dz, 
                                  int B, int Cin, int Cout, int H, int W, int accumulate, void* stream) {
     ONET_REQUIRE(x && dz && dw && ws, "conv3x3_winograd4_wgrad: null pointer");
     ONET_REQUIRE(onet_conv3x3_winograd4_wgrad_ok(B, Cin, Cout, H, W),
-                 "conv3x3_winograd4_wgrad: needs W %% 32 == 0, H %% 4 == 0, Cin %% 32 == 0 (use onet_conv3x3_winograd_wgrad)");
+                 "conv3x3_winograd4_wgrad: needs W %% 32 == 0 (or W == 16 with even B), H %% 4 == 0, Cin %% 32 == 0 (use onet_conv3x3_winograd_wgrad)");
     ONET_REQUIRE((x_bs & 3) == 0 && (dz_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dz) & 15) == 0,
                  "conv3x3_winograd4_wgrad: 16-byte aligned image planes required");
     ONET_REQUIRE(x_bs >= (int64_t)Cin * H * W && dz_bs >= (int64_t)Cout * H * W, "conv3x3_winograd4_wgrad: batch stride too small");
@@ -292,13 +335,25 @@ int onet_conv3x3_winograd4_wgrad(const float* x, int64_t x_bs, const float* dz, 
     const int64_t n = (int64_t)Cout * Cin;
     ONET_REQUIRE(ws_bytes >= (int64_t)a.splitK * 36 * n * 4, "conv3x3_winograd4_wgrad: workspace too small");
     const int64_t blocks = (int64_t)a.splitK * a.ciTiles * a.coTiles;
-    auto kern = conv_wino4_wgrad_kernel;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_FLOATS * 4);
-        attr_set = true;
+    if (W == 16) {
+        ONET_REQUIRE(((x_bs + (int64_t)Cin * H * W) * 4 < (1ll << 31)) && ((dz_bs + (int64_t)Cout * H * W) * 4 < (1ll << 31)),
+                     "conv3x3_winograd4_wgrad: image pair exceeds the 2 GiB buffer-resource range");
+        auto kern = conv_wino4_wgrad_kernel<1>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, W4C<1>::LDS_FLOATS * 4);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), W4C<1>::LDS_FLOATS * 4, as_stream(stream), a);
+    } else {
+        auto kern = conv_wino4_wgrad_kernel<0>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, W4C<0>::LDS_FLOATS * 4);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), W4C<0>::LDS_FLOATS * 4, as_stream(stream), a);
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), W4_LDS_FLOATS * 4, as_stream(stream), a);
     int rc = check_launch("conv_wino4_wgrad_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(wino4w_fold_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream), (const float*)ws, dw, a.splitK, n,

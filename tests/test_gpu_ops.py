@@ -263,7 +263,7 @@ def test_conv3x3_bf16_operands(dev, B, Cin, Cout, H, W):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(1, 32, 64, 4, 32), (2, 64, 64, 32, 32), (3, 32, 72, 20, 64), (2, 128, 256, 64, 64),
-                                             (4, 64, 128, 16, 96)])
+                                             (4, 64, 128, 16, 96), (2, 32, 64, 4, 16), (6, 64, 96, 16, 16), (4, 256, 128, 8, 16)])
 def test_conv3x3_winograd4_wgrad(dev, B, Cin, Cout, H, W):
     """Winograd F(3x3,4x4) weight gradient (conv_wino4w.hip) against the fp64 weight gradient: single unit, several
     units and split-K plans, channel tails in Cout, borders (zero padding on all four sides)."""
