@@ -425,8 +425,9 @@ def conv3x3_winograd4_wgrad(x, dz, dw_shape, out=None):
 
 
 # ONET_WGRAD4: "auto" (default) = the F(3x3,4x4) weight gradient where it is the faster one today: layers with at least
-# 256 input channels, whose strips are re-read from L2 by many tiles (d2.c2, d3.*, up1.*, up2.*, up3.c1 of the 256x256
-# U-Net: 244-290 TF against 227-237); below that its one-unit prefetch does not cover HBM latency (72-166 TF).
+# 256 input channels (or 128 -> >= 256), whose strips are re-read from L2 by many tiles (d2.*, d3.*, d4.*, up1.*, up2.*,
+# up3.c1 of the 256x256 U-Net: 224-298 TF against 205-238); below that its one-unit prefetch does not cover HBM latency
+# (64-channel layers: 130 TF against 200) or it only ties (128 -> 128).
 # "1": wherever legal; "0": never.
 WGRAD4 = _os.environ.get("ONET_WGRAD4", "auto")
 
@@ -460,7 +461,7 @@ def conv3x3_wgrad_auto(x, dz, dw_shape, out=None):
             and dz.is_contiguous()):
         return conv3x3_wgrad_bf16(x, dz, dw_shape, out=out)
     if use_winograd(Cin, Cout, x.shape[2], x.shape[3]):
-        if WGRAD4 != "0" and (WGRAD4 == "1" or Cin >= 256) and winograd4_wgrad_ok(x, dz):
+        if WGRAD4 != "0" and (WGRAD4 == "1" or Cin >= 256 or (Cin >= 128 and Cout >= 256)) and winograd4_wgrad_ok(x, dz):
             return conv3x3_winograd4_wgrad(x, dz, dw_shape, out=out)
         return conv3x3_winograd_wgrad(x, dz, dw_shape, out=out)
     return conv_wgrad(x, dz, dw_shape, 3, out=out)
