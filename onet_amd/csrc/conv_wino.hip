@@ -864,7 +864,9 @@ static void wino_wgrad_plan(int B, int Cin, int Cout, int H, int W, int& pw, int
     sy = cdiv(H, pr);
     const int64_t nunits = (int64_t)B * sx * sy;
     const int64_t tiles = (int64_t)cdiv(Cout, 64) * cdiv(Cin, 64);
-    int64_t s = (512 + tiles - 1) / tiles;                       // one 8-wave block per CU, ~2 rounds
+    static int target = -1;
+    if (target < 0) { const char* e = getenv("ONET_W2W_BLOCKS"); target = (e && atoi(e) > 0) ? atoi(e) : 256; }
+    int64_t s = (target + tiles - 1) / tiles;                    // one 8-wave block per CU, ONE round (256 vs 512: +2-6 %; 384 / 768: -20 %)
     const int64_t per = (int64_t)16 * Cout * Cin * 4;
     const int64_t cap = (160ll << 20) / (per > 0 ? per : 1);
     if (s > cap) s = cap;
