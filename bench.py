@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (no sparsity)
+HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 PMC_JSON = os.path.join(ROOT, "profiles", "pmc_bench_latest.json")   # written by tools/pmc_parse.py
 
 
@@ -43,30 +44,55 @@ def pmc_traffic(kernel_prefix):
     return (tot_b / tot_n) if tot_n else None
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(X_cpu, seconds_budget):
-    """fwd + loss + bwd + Adam of the CPU oracle (PyTorch CPU fp32, same ATen kernels the reference
-    runs) on a B=2 sample of the SAME synthetic batch."""
+    """fwd + loss + bwd + Adam of the CPU oracle (PyTorch CPU fp32: the same ATen / oneDNN kernels the reference runs
+    on CPU) on the host cores of this box, for n = all cores and n = 8 threads.  The sample is the first
+    B_s images of the SAME synthetic batch, B_s = the largest power of two <= the benchmark batch whose 3 timed steps fit
+    the budget of a thread setting (half of --cpu-seconds), estimated from a B=2 warm-up step."""
     from oracle import onet_oracle as orc
-    xs = X_cpu[:2].contiguous()
-    top = orc.clone_state(orc.det_state_dict(xs.shape[1], 1981, randomize_running=False))
-    params = [v for v in top.values() if v.requires_grad]
-    opt = torch.optim.Adam(params, lr=5e-6, betas=(0.9, 0.999), eps=1e-8)
-    times = []
-    t_all = time.time()
-    for i in range(6):
-        t0 = time.time()
-        opt.zero_grad()
-        orc.train_mode_step(xs, top)
-        opt.step()
-        dt = time.time() - t0
-        if i > 0:
-            times.append(dt)
-        if time.time() - t_all > seconds_budget and len(times) >= 1:
-            break
-    mean = sum(times) / len(times)
-    return {"value": round(xs.shape[0] / mean, 4), "unit": "images/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": "B=2 of the same 1x%dx%d K-clutter batch, %d timed full training steps "
-            "(fwd+loss+bwd+Adam), 1 warm-up" % (xs.shape[2], xs.shape[3], len(times))}
+    ncores = os.cpu_count() or 1
+    settings = [ncores] + ([8] if ncores > 8 else [])
+    per_setting = seconds_budget / len(settings)
+    by_threads, sample = {}, {}
+    for n in settings:
+        torch.set_num_threads(n)
+        top = orc.clone_state(orc.det_state_dict(X_cpu.shape[1], 1981, randomize_running=False))
+        params = [v for v in top.values() if v.requires_grad]
+        opt = torch.optim.Adam(params, lr=5e-6, betas=(0.9, 0.999), eps=1e-8)
+
+        def step(xs):
+            t0 = time.perf_counter()
+            opt.zero_grad()
+            orc.train_mode_step(xs, top)
+            opt.step()
+            return time.perf_counter() - t0
+
+        t_warm = step(X_cpu[:2].contiguous())                 # warm-up (allocator, oneDNN primitive cache) + estimate
+        bs = 2
+        while bs * 2 <= X_cpu.shape[0] and 3 * t_warm * (bs * 2) / 2 <= per_setting - t_warm:
+            bs *= 2
+        xs = X_cpu[:bs].contiguous()
+        times = [step(xs) for _ in range(3)]
+        by_threads[str(n)] = round(bs / (sum(times) / len(times)), 4)
+        sample[str(n)] = bs
+    torch.set_num_threads(ncores)
+    n0 = str(settings[0])
+    return {"value": by_threads[n0], "unit": "images/s", "cores": settings[0], "kind": "port",
+            "cpu_model": _cpu_model(), "by_threads": by_threads,
+            "sample": "first %s images (n=%s threads) of the same %dx%dx%d K-clutter batch; per thread setting 1 warm-up "
+                      "step at B=2 + 3 timed full training steps (zero_grad+fwd+loss+bwd+Adam) of the CPU oracle"
+                      % ("/".join(str(sample[k]) for k in by_threads), "/".join(by_threads), X_cpu.shape[1],
+                         X_cpu.shape[2], X_cpu.shape[3])}
 
 
 def main():
@@ -81,7 +107,11 @@ def main():
                     help="ops.CONV_ALGO for this run (default: ONET_CONV_ALGO or auto = the fp32 kernels); bf16 = BASELINE "
                          "config 3's bf16-operand MFMA path for forward / input gradient")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--mfma-events-only", action="store_true",
+                    help="HIP-event brackets around the MFMA launches only (default: around every launch of the library, "
+                         "which the whole-step breakdown and the streaming-kernel roofline need)")
+    ap.add_argument("--cpu-seconds", type=float, default=60.0,
+                    help="budget of the CPU-oracle baseline (split over the thread settings n = all cores and n = 8)")
     ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam instead of the fused flat Adam")
     ap.add_argument("--no-overlap", action="store_true",
                     help="one gradient all-reduce after backward instead of bucketed all-reduces overlapped with it")
@@ -129,14 +159,14 @@ def main():
     for _ in range(args.warmup):
         train_step(onet, opt, X)
     barrier()
-    ops.PROFILE = {}
+    ops.profile_start(everything=not args.mfma_events_only)
     dev_allocs0 = int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = train_step(onet, opt, X)
     barrier()
     elapsed = time.perf_counter() - t0
-    prof, ops.PROFILE = ops.PROFILE, None
+    prof, prof_all = ops.profile_stop()
     if distributed:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -144,34 +174,74 @@ def main():
     loss_val = float(loss.item())
 
     if rank == 0:
+        # multiplies the algorithm issues relative to direct convolution: F(4x4,3x3) 36 per 16 outputs x 9 taps -> 1/4,
+        # F(2x2,3x3) 16 per 4 x 9 -> 1/2.25 (the weight-gradient kernels F(3x3,4x4) / F(3x3,2x2) likewise)
+        REDUCTION = {"conv_wino4_kernel": 4.0, "conv_wino_kernel": 2.25, "conv_wino_wgrad_kernel": 2.25,
+                     "conv_wino4_wgrad_kernel": 4.0}
+        BF16 = ("conv3x3_bf16_kernel", "conv3x3_wgrad_bf16_kernel")
+        ALGO = {"conv_wino_kernel": "Winograd F(2x2,3x3) on fp32 MFMA (fwd + dgrad)",
+                "conv_wino4_kernel": "Winograd F(4x4,3x3) on fp32 MFMA (fwd + dgrad; BatchNorm statistics / backward-reduce "
+                                     "epilogues)",
+                "conv_wino_wgrad_kernel": "Winograd F(2x2,3x3) weight gradient on fp32 MFMA, deterministic split-K",
+                "conv_wino4_wgrad_kernel": "Winograd F(3x3,4x4) weight gradient on fp32 MFMA, deterministic split-K",
+                "conv3x3_bf16_kernel": "direct implicit GEMM on v_mfma_f32_32x32x16_bf16 (bf16 operands, fp32 accumulate)",
+                "conv3x3_wgrad_bf16_kernel": "split-K weight gradient on v_mfma_f32_32x32x16_bf16",
+                "conv_fwd_kernel": "direct implicit GEMM on fp32 MFMA (stem, tiny maps, ConvTranspose2d GEMMs)",
+                "conv_wgrad_kernel": "direct split-K weight gradient on fp32 MFMA (stem, tiny maps, ConvTranspose2d)"}
         kern = {}
         for kind, recs in prof.items():
-            ms = sum(e0.elapsed_time(e1) for _, e0, e1 in recs)
-            fl = sum(f for f, _, _ in recs)
+            ms = sum(r[1].elapsed_time(r[2]) for r in recs)
+            fl = sum(r[0] for r in recs)
+            by = sum(r[3] for r in recs)
+            peak = BF16_MFMA_PEAK_TFLOPS if kind in BF16 else FP32_MFMA_PEAK_TFLOPS
+            issued = fl / REDUCTION.get(kind, 1.0)
             kern[kind] = {"launches": len(recs), "ms_total": round(ms, 3), "avg_ms": round(ms / len(recs), 4),
-                          "tflops": round(fl / (ms * 1e-3) / 1e12, 2)}
+                          "direct_equivalent_tflops": round(fl / (ms * 1e-3) / 1e12, 2),
+                          "issued_mfma_tflops": round(issued / (ms * 1e-3) / 1e12, 2),
+                          "mfma_frac": round(issued / (ms * 1e-3) / 1e12 / peak, 4),
+                          "compulsory_gbps": round(by / (ms * 1e-3) / 1e9, 1),
+                          "hbm_frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
         dom = max(kern, key=lambda k: kern[k]["ms_total"])
-        algo = {"conv_wino_kernel": "Winograd F(2x2,3x3) on fp32 MFMA: achieved = direct-convolution FLOPs / time "
-                                    "(the kernel issues 2.25x fewer MFMA FLOPs, so frac can exceed the MFMA busy fraction)",
-                "conv_wino4_kernel": "Winograd F(4x4,3x3) on fp32 MFMA: achieved = direct-convolution FLOPs / time "
-                                     "(the kernel issues 4x fewer MFMA FLOPs, so frac can exceed 1; hardware_frac = issued MFMA FLOPs / time / "
-                                     "peak, which the SQ_VALU_MFMA_BUSY_CYCLES profile under profiles/ confirms)",
-                "conv_wino_wgrad_kernel": "Winograd F(2x2,3x3) weight gradient on fp32 MFMA: achieved = direct-convolution "
-                                          "FLOPs / time (2.25x fewer MFMA FLOPs issued)",
-                "conv3x3_bf16_kernel": "direct implicit GEMM, bf16 operands (rounded on the way into LDS) on "
-                                       "v_mfma_f32_32x32x16_bf16, fp32 accumulation; peak = dense bf16 MFMA",
-                "conv_fwd_kernel": "direct implicit GEMM on fp32 MFMA", "conv_wgrad_kernel": "split-K MFMA wgrad"}
-        # multiplies the algorithm issues relative to direct convolution: F(4x4,3x3) 36 per 16 outputs x 9 taps -> 1/4,
-        # F(2x2,3x3) 16 per 4 x 9 -> 1/2.25
-        reduction = {"conv_wino4_kernel": 4.0, "conv_wino_kernel": 2.25, "conv_wino_wgrad_kernel": 2.25}.get(dom, 1.0)
-        peak = BF16_MFMA_PEAK_TFLOPS if dom == "conv3x3_bf16_kernel" else FP32_MFMA_PEAK_TFLOPS
-        roofline = {"kernel": dom, "bound": "mfma", "achieved": kern[dom]["tflops"], "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(kern[dom]["tflops"] / peak, 4),
-                    "traffic": pmc_traffic(dom), "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc, profiles/)",
-                    "mfma_flop_reduction": reduction,
-                    "hardware_frac": round(kern[dom]["tflops"] / reduction / peak, 4),
-                    "launches_timed": kern[dom]["launches"], "avg_launch_ms": kern[dom]["avg_ms"], "algorithm": algo.get(dom, dom),
-                    "all": kern}
+        d = kern[dom]
+        traffic = pmc_traffic(dom)
+        if dom in BF16:
+            # in bf16 the 64- and 128-channel layers sit below the ridge (312 FLOP/B): the launch is priced
+            # against HBM; `achieved` = compulsory bytes (operands once + result once, fp32 storage) / time
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": d["compulsory_gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": d["hbm_frac"], "mfma_frac": d["mfma_frac"]}
+        else:
+            # fp32: every dense layer is far above the ridge (19.7 FLOP/B): priced against the fp32 MFMA peak with the MFMA
+            # FLOPs the kernel ISSUES (Winograd issues 4x / 2.25x fewer than the direct algorithm performs)
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": d["issued_mfma_tflops"], "peak": FP32_MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": d["mfma_frac"], "hbm_frac": d["hbm_frac"]}
+        roofline.update({"traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc, profiles/)",
+                         "compulsory_bytes_per_launch": round(d["compulsory_gbps"] * 1e9 * d["avg_ms"] * 1e-3),
+                         "direct_equivalent_tflops": d["direct_equivalent_tflops"],
+                         "mfma_flop_reduction": REDUCTION.get(dom, 1.0), "launches_timed": d["launches"],
+                         "avg_launch_ms": d["avg_ms"], "algorithm": ALGO.get(dom, dom), "kernels": kern})
+        if prof_all:
+            stream = {}
+            for name, recs in prof_all.items():
+                ms = sum(r[1].elapsed_time(r[2]) for r in recs)
+                by = sum(r[0] for r in recs if r[0])
+                stream[name] = {"launches": len(recs), "ms_total": round(ms, 3), "avg_ms": round(ms / len(recs), 4),
+                                "gbps": round(by / (ms * 1e-3) / 1e9, 1) if by else None}
+            priced = {k: v for k, v in stream.items() if v["gbps"]}
+            sdom = max(priced, key=lambda k: priced[k]["ms_total"])
+            roofline["streaming"] = {"kernel": sdom, "bound": "hbm", "achieved": priced[sdom]["gbps"], "peak": HBM_PEAK_GBPS,
+                                     "unit": "GB/s", "frac": round(priced[sdom]["gbps"] / HBM_PEAK_GBPS, 4),
+                                     "launches_timed": priced[sdom]["launches"], "avg_launch_ms": priced[sdom]["avg_ms"],
+                                     "kernels": dict(sorted(stream.items(), key=lambda kv: -kv[1]["ms_total"])[:12])}
+            mfma_ms = sum(v["ms_total"] for v in kern.values()) / args.steps
+            hbm_ms = sum(v["ms_total"] for v in priced.values()) / args.steps
+            small_ms = sum(v["ms_total"] for k, v in stream.items() if k not in priced) / args.steps
+            wall = elapsed / args.steps * 1e3
+            roofline["step"] = {"wall_ms": round(wall, 3), "mfma_kernels_ms": round(mfma_ms, 3),
+                                "hbm_kernels_ms": round(hbm_ms, 3), "small_kernels_ms": round(small_ms, 3),
+                                "unattributed_ms": round(wall - mfma_ms - hbm_ms - small_ms, 3),
+                                "mfma_share": round(mfma_ms / wall, 4), "hbm_share": round(hbm_ms / wall, 4),
+                                "note": "per-launch HIP-event brackets on the launch stream, inside the timed region; "
+                                        "unattributed = torch glue kernels, event overhead and launch gaps"}
         imgs = args.batch * world * args.steps
         out = {"metric": "training images/sec (twin 256x256 pass)", "value": round(imgs / elapsed, 3),
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -200,4 +270,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException as e:      # noqa: BLE001 -- any failure (RCCL included) ends THIS rank at once with a non-zero code:
+        if isinstance(e, SystemExit) and e.code in (0, None):      # no in-process retry, no waiting in a collective's
+            raise                                                  # destructor; the launcher then stops the other ranks
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)

@@ -83,10 +83,20 @@ def last_error() -> str:
     return load().onet_last_error().decode()
 
 
-def call(name: str, *args):
-    """Call an int-returning entry point; raise OnetHipError on a negative code."""
+# Optional per-launch timing hook (bench.py): an object with begin() -> token and end(name, nbytes, token), installed by
+# onet_amd.ops while a profile is being taken.  None (default): no overhead.
+PROFILE_HOOK = None
+
+
+def call(name: str, *args, nbytes=None):
+    """Call an int-returning entry point; raise OnetHipError on a negative code.  `nbytes`: the algorithmic HBM bytes of
+    this launch (streaming kernels), recorded with its duration when a profile hook is installed."""
     lib = load()
+    hook = PROFILE_HOOK
+    tok = hook.begin() if hook is not None else None
     rc = getattr(lib, name)(*args)
+    if tok is not None:
+        hook.end(name, nbytes, tok)
     if rc != 0:
         raise OnetHipError(f"{name} failed ({rc}): {lib.onet_last_error().decode()}")
     return rc

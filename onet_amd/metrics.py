@@ -50,37 +50,77 @@ def _acc(counts) -> float:
 
 def _miou(counts) -> float:
     """mean IoU over the 2 classes with the reference's empty-class rules (UT:119-155): a class absent from
-    both prediction and ground truth scores 1, absent from exactly one scores 0."""
+    both prediction and ground truth scores 1, absent from exactly one scores 0.  The reference accumulates
+    `torch.sum(inter) / torch.sum(union)` (a float32 tensor) and ends with `miou.item() / nums`: when NEITHER class
+    takes the tensor branch -- prediction and ground truth each a single, different class -- `miou` is still a python
+    float there and UT:152 raises AttributeError; mirrored, since "same error behaviour" is the drop-in rule."""
     tp, fp, fn, tn = _tot(counts)
-    miou = 0.0
+    miou, is_tensor = np.float32(0.0), False
     for inter, gt, pd in ((tn, tn + fp, tn + fn), (tp, tp + fn, tp + fp)):      # class 0, class 1
         if gt == 0 and pd == 0:
-            miou += 1.0
+            miou = np.float32(miou + np.float32(1.0))
         elif gt == 0 or pd == 0:
-            miou += 0.0
+            pass
         else:
-            miou += float(np.float32(inter) / np.float32(gt + pd - inter))      # torch.sum/torch.sum in fp32
-    return miou / 2
+            miou = np.float32(miou + np.float32(inter) / np.float32(gt + pd - inter))   # int64 / int64 -> float32 tensor
+            is_tensor = True
+    if not is_tensor:
+        raise AttributeError("'float' object has no attribute 'item'")
+    return float(miou) / 2
+
+
+def _ratio32(num: int, den: int) -> float:
+    """`torch.sum(a) / (torch.sum(b) + np.spacing(1))` as the reference evaluates it: int64 tensor + python float ->
+    float32 tensor, int64 / float32 -> float32."""
+    return float(np.float32(num) / (np.float32(den) + np.float32(_EPS)))
 
 
 def _target_iou(counts) -> float:
     tp, fp, fn, tn = _tot(counts)
-    return tp / (tp + fp + fn + _EPS)                                            # UT:157-173
+    return _ratio32(tp, tp + fp + fn)                                            # UT:157-173
 
 
 def _detection_rate(counts) -> float:
     tp, fp, fn, tn = _tot(counts)
-    return tp / (tp + fn + _EPS)                                                 # UT:175-186
+    return _ratio32(tp, tp + fn)                                                 # UT:175-186
 
 
 def _false_alarm_rate(counts) -> float:
     tp, fp, fn, tn = _tot(counts)
-    return fp / (fp + tn + _EPS)                                                 # UT:188-192
+    return _ratio32(fp, fp + tn)                                                 # UT:188-192
 
 
 def flipped(counts):
     """confusion counts of 1 - pred: TP<->FN, FP<->TN."""
     return counts[..., [2, 3, 0, 1]]
+
+
+def _hungarian_match(counts, num_k: int = 2):
+    """UT:258-285 on the confusion counts: votes[c1][c2] = #(pred == c1 and gt == c2), assignment minimising
+    N - votes (scipy's linear_sum_assignment, the reference's own dependency, so ties resolve identically).
+    -> [(pred class, gt class), ...]."""
+    assert num_k == 2
+    from scipy.optimize import linear_sum_assignment
+    tp, fp, fn, tn = _tot(counts)
+    votes = np.array([[tn, fn], [fp, tp]], dtype=np.float64)
+    rows, cols = linear_sum_assignment(float(tp + fp + fn + tn) - votes)
+    return [(int(r), int(c)) for r, c in zip(rows, cols)]
+
+
+def reorder_segmentation(predict_label: torch.Tensor, gt_label: torch.Tensor) -> torch.Tensor:
+    """UT:360-375: relabel the prediction by the Hungarian match between predicted and ground-truth classes (2 classes:
+    keep, or swap 0 <-> 1); returns a new tensor of gt_label's shape."""
+    require_gpu(predict_label, gt_label)
+    assert predict_label.numel() == gt_label.numel()
+    c = confusion_counts(predict_label.reshape(1, -1), gt_label.reshape(1, -1))
+    match = dict(_hungarian_match(c, 2))
+    p = predict_label.reshape(gt_label.shape).to(torch.int64).contiguous()
+    if match.get(0, 0) == 1:                                                     # swap
+        out = torch.empty_like(p)
+        _lib.call("onet_flip_labels", _p(p), _p(out), p.numel(), _stream())
+    else:
+        out = p.clone()
+    return out.to(predict_label.dtype)
 
 
 def re_assign_label(predict_label: torch.Tensor, gt_label: torch.Tensor, gt_k: int = 2) -> torch.Tensor:

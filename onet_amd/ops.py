@@ -45,22 +45,66 @@ def plane(t):
 # Optional in-process kernel timing (bench.py): PROFILE = {} enables HIP-event brackets around the
 # MFMA launches, on the stream they are launched on; entries: kind -> [(flops, ev_start, ev_end)].
 PROFILE = None
+# PROFILE_ALL = {} additionally brackets EVERY other launch of the library (streaming kernels: BatchNorm, pooling, head,
+# loss, Adam, packs): entry point -> [(algorithmic HBM bytes | None, ev_start, ev_end)].
+PROFILE_ALL = None
+_IN_MFMA_BRACKET = False
+
+
+class _AllHook:
+    """_lib.PROFILE_HOOK while PROFILE_ALL is collected; launches inside an MFMA bracket are already timed."""
+
+    @staticmethod
+    def begin():
+        if PROFILE_ALL is None or _IN_MFMA_BRACKET:
+            return None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return e0
+
+    @staticmethod
+    def end(name, nbytes, e0):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        PROFILE_ALL.setdefault(name, []).append((nbytes, e0, e1))
+
+
+def profile_start(everything=True):
+    global PROFILE, PROFILE_ALL
+    PROFILE = {}
+    PROFILE_ALL = {} if everything else None
+    _lib.PROFILE_HOOK = _AllHook if everything else None
+
+
+def profile_stop():
+    """-> (mfma records, all-other records); timing is off afterwards."""
+    global PROFILE, PROFILE_ALL
+    out = (PROFILE, PROFILE_ALL or {})
+    PROFILE = PROFILE_ALL = None
+    _lib.PROFILE_HOOK = None
+    return out
 
 
 def _prof_begin():
+    global _IN_MFMA_BRACKET
     if PROFILE is None:
         return None
     e0 = torch.cuda.Event(enable_timing=True)
     e0.record()
+    _IN_MFMA_BRACKET = True
     return e0
 
 
-def _prof_end(kind, flops, e0):
+def _prof_end(kind, flops, e0, nbytes=0.0):
+    """flops: direct-algorithm FLOPs of the launch; nbytes: its compulsory HBM bytes (operands read once + result written
+    once, fp32)."""
+    global _IN_MFMA_BRACKET
     if e0 is None:
         return
+    _IN_MFMA_BRACKET = False
     e1 = torch.cuda.Event(enable_timing=True)
     e1.record()
-    PROFILE.setdefault(kind, []).append((flops, e0, e1))
+    PROFILE.setdefault(kind, []).append((flops, e0, e1, nbytes))
 
 
 # OV:234 asserts "jsd is not NaN" inside the loss, which costs a device synchronisation in the MIDDLE of a step (forward
@@ -147,7 +191,7 @@ def convT2x2_fwd(x, wq, bias, out, Ct, pt, pl):
     obs = out.stride(0) if B > 1 else Ct * Ho * Wo
     e0 = _prof_begin()
     _lib.call("onet_convT2x2_fwd", _p(x), xbs, _p(wq), _p(bias), _p(out), obs, B, Cin, Ct, h, w, Ho, Wo, pt, pl, _stream())
-    _prof_end("conv_fwd_kernel", 2.0 * B * h * w * Cin * 4 * Ct, e0)
+    _prof_end("conv_fwd_kernel", 2.0 * B * h * w * Cin * 4 * Ct, e0, 4.0 * (B * h * w * (Cin + 4 * Ct) + 4 * Cin * Ct))
     return out
 
 
@@ -260,7 +304,7 @@ def conv3x3_fwd_bn_partials(x, pk):
     e0 = _prof_begin()
     _lib.call("onet_conv3x3_winograd4_fwd_stats", _p(x), xbs, _p(wq), _p(out), Co * H * W, _p(cm), B, Ci, Co, H, W,
               _stream())
-    _prof_end("conv_wino4_kernel", 2.0 * B * H * W * Ci * Co * 9, e0)
+    _prof_end("conv_wino4_kernel", 2.0 * B * H * W * Ci * Co * 9, e0, 4.0 * (B * H * W * (Ci + Co) + 9 * Ci * Co))
     return out, cm
 
 
@@ -293,7 +337,7 @@ def conv3x3_dgrad_bnreduce(dz, pk, z_prev, save_prev):
     e0 = _prof_begin()
     _lib.call("onet_conv3x3_winograd4_dgrad_bnreduce", _p(dz), dbs, _p(wq), _p(da), Co * H * W, _p(z_prev), zbs,
               _p(save_prev), B // G, _p(rec), B, Ci, Co, H, W, _stream())
-    _prof_end("conv_wino4_kernel", 2.0 * B * H * W * Ci * Co * 9, e0)
+    _prof_end("conv_wino4_kernel", 2.0 * B * H * W * Ci * Co * 9, e0, 4.0 * (B * H * W * (Ci + Co) + 9 * Ci * Co))
     return da, rec
 
 
@@ -317,7 +361,7 @@ def conv3x3_winograd(x, wq, Cout, out=None):
     zbs = out.stride(0) if B > 1 else Cout * H * W
     e0 = _prof_begin()
     _lib.call("onet_conv3x3_winograd_fwd", _p(x), xbs, _p(wq), _p(out), zbs, B, Cin, Cout, H, W, _stream())
-    _prof_end("conv_wino_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0)
+    _prof_end("conv_wino_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
     return out
 
 
@@ -342,7 +386,7 @@ def conv3x3_winograd4(x, wq, Cout, out=None):
     zbs = out.stride(0) if B > 1 else Cout * H * W
     e0 = _prof_begin()
     _lib.call("onet_conv3x3_winograd4_fwd", _p(x), xbs, _p(wq), _p(out), zbs, B, Cin, Cout, H, W, _stream())
-    _prof_end("conv_wino4_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0)
+    _prof_end("conv_wino4_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
     return out
 
 
@@ -372,7 +416,7 @@ def conv3x3_bf16(x, wq, Cout, out=None):
     zbs = out.stride(0) if B > 1 else Cout * H * W
     e0 = _prof_begin()
     _lib.call("onet_conv3x3_bf16_fwd", _p(x), xbs, _p(wq), _p(out), zbs, B, Cin, Cout, H, W, _stream())
-    _prof_end("conv3x3_bf16_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0)
+    _prof_end("conv3x3_bf16_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
     return out
 
 
@@ -403,7 +447,7 @@ def conv3x3_winograd_wgrad(x, dz, dw_shape, out=None):
     e0 = _prof_begin()
     _lib.call("onet_conv3x3_winograd_wgrad", _p(x), xbs, _p(dz), dzbs, _p(dw), _p(ws), ws.numel() * 4, B, Cin, Cout,
               H, W, 0, _stream())
-    _prof_end("conv_wino_wgrad_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0)
+    _prof_end("conv_wino_wgrad_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
     return dw
 
 
@@ -420,7 +464,7 @@ def conv3x3_winograd4_wgrad(x, dz, dw_shape, out=None):
     e0 = _prof_begin()
     _lib.call("onet_conv3x3_winograd4_wgrad", _p(x), xbs, _p(dz), dzbs, _p(dw), _p(ws), ws.numel() * 4, B, Cin, Cout, H, W,
               0, _stream())
-    _prof_end("conv_wino4_wgrad_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0)
+    _prof_end("conv_wino4_wgrad_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
     return dw
 
 
@@ -451,7 +495,7 @@ def conv3x3_wgrad_bf16(x, dz, dw_shape, out=None):
     e0 = _prof_begin()
     _lib.call("onet_conv3x3_wgrad_bf16", _p(x), xbs, _p(dz), dzbs, _p(dw), _p(ws), ws.numel() * 4, B, Cin, Cout, H, W, 0,
               _stream())
-    _prof_end("conv3x3_wgrad_bf16_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0)
+    _prof_end("conv3x3_wgrad_bf16_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
     return dw
 
 
@@ -477,7 +521,8 @@ def conv_fwd(x, wp, Cout, ks, out=None):
     zbs = out.stride(0) if B > 1 else Cout * H * W
     e0 = _prof_begin()
     _lib.call("onet_conv_fwd", _p(x), xbs, _p(wp), _p(out), zbs, None, B, Cin, Cout, H, W, ks, _stream())
-    _prof_end("conv_fwd_kernel", 2.0 * B * H * W * Cin * Cout * ks * ks, e0)
+    _prof_end("conv_fwd_kernel", 2.0 * B * H * W * Cin * Cout * ks * ks, e0,
+              4.0 * (B * H * W * (Cin + Cout) + ks * ks * Cin * Cout))
     return out
 
 
@@ -493,7 +538,8 @@ def conv_wgrad(x, dz, dw_shape, ks, out_layout=0, out=None):
     e0 = _prof_begin()
     _lib.call("onet_conv_wgrad", _p(x), xbs, _p(dz), dzbs, _p(dw), _p(ws), ws.numel() * 4, B, Cin, Cout, H, W, ks,
               out_layout, 0, _stream())
-    _prof_end("conv_wgrad_kernel", 2.0 * B * H * W * Cin * Cout * ks * ks, e0)
+    _prof_end("conv_wgrad_kernel", 2.0 * B * H * W * Cin * Cout * ks * ks, e0,
+              4.0 * (B * H * W * (Cin + Cout) + ks * ks * Cin * Cout))
     return dw
 
 
@@ -542,7 +588,7 @@ def bn_train_coeffs(z, gamma, beta, running_mean, running_var, momentum, eps, cm
         return save
     nparts = _bn_nparts(B, H * W)
     part = torch.empty((nparts, C, 3), dtype=F32, device=z.device)
-    _lib.call("onet_bn_stats_partial", _p(z), zbs, _p(part), nparts, B, C, H * W, _stream())
+    _lib.call("onet_bn_stats_partial", _p(z), zbs, _p(part), nparts, B, C, H * W, _stream(), nbytes=4 * z.numel())
     part, world = _gather_partials(part)
     nparts *= world
     if save is None:
@@ -567,7 +613,7 @@ def bn_relu_apply(z, save, out=None):
     if out is None:
         out = torch.empty((B, C, H, W), dtype=F32, device=z.device)
     abs_ = out.stride(0) if B > 1 else C * H * W
-    _lib.call("onet_bn_relu_apply", _p(z), zbs, _p(out), abs_, _p(save), B, C, H * W, _stream())
+    _lib.call("onet_bn_relu_apply", _p(z), zbs, _p(out), abs_, _p(save), B, C, H * W, _stream(), nbytes=8 * z.numel())
     return out
 
 
@@ -604,7 +650,8 @@ def bn_relu_bwd(da, z, save, training, need_affine_grads=True, out=None, acc=Non
             part2, nparts = rec4[first:first + count], count
         else:
             part2 = torch.empty((nparts, C, 4), dtype=F32, device=dev)
-            _lib.call("onet_bn_relu_bwd_reduce", _p(da), dabs, _p(z), zbs, _p(save), _p(part2), nparts, B, C, HW, _stream())
+            _lib.call("onet_bn_relu_bwd_reduce", _p(da), dabs, _p(z), zbs, _p(save), _p(part2), nparts, B, C, HW, _stream(),
+                      nbytes=8 * z.numel())
         if acc is None:
             og, ob = affine_out if affine_out is not None else (None, None)
             dgamma = torch.empty(C, dtype=F32, device=dev) if og is None else og
@@ -625,7 +672,7 @@ def bn_relu_bwd(da, z, save, training, need_affine_grads=True, out=None, acc=Non
     dz = torch.empty((B, C, H, W), dtype=F32, device=dev) if out is None else out
     dzbs = dz.stride(0) if B > 1 else C * HW
     _lib.call("onet_bn_relu_bwd_apply", _p(da), dabs, _p(z), zbs, _p(save), _p(coef), _p(dz), dzbs, B, C, HW,
-              _stream())
+              _stream(), nbytes=12 * z.numel())
     return dz, dgamma, dbeta
 
 
@@ -634,7 +681,7 @@ def maxpool2_fwd(x):
     x, xbs = plane(x)
     B, C, H, W = x.shape
     y = torch.empty((B, C, H // 2, W // 2), dtype=F32, device=x.device)
-    _lib.call("onet_maxpool2_fwd", _p(x), xbs, _p(y), C * (H // 2) * (W // 2), B, C, H, W, _stream())
+    _lib.call("onet_maxpool2_fwd", _p(x), xbs, _p(y), C * (H // 2) * (W // 2), B, C, H, W, _stream(), nbytes=5 * x.numel())
     return y
 
 
@@ -661,13 +708,15 @@ def maxpool2_bwd(x, dy, add=None, add2=None, bn=None):
         if bands > 0 and aligned and B % G == 0 and tuple(z.shape) == (B, C, H, W) and save_all.is_contiguous():
             part2 = torch.empty((B * bands, C, 4), dtype=F32, device=x.device)
             _lib.call("onet_maxpool2_bwd_add_bnreduce", _p(x), xbs, _p(dy), dybs, _p(a1), a1bs, _p(a2), a2bs, _p(dx),
-                      C * H * W, _p(z), zbs, _p(save_all), B // G, _p(part2), B, C, H, W, _stream())
+                      C * H * W, _p(z), zbs, _p(save_all), B // G, _p(part2), B, C, H, W, _stream(),
+                      nbytes=(13 + 4 * (a1 is not None) + 4 * (a2 is not None)) * x.numel())
             return dx, part2
     if add is None:
-        _lib.call("onet_maxpool2_bwd", _p(x), xbs, _p(dy), dybs, _p(dx), C * H * W, B, C, H, W, 0, _stream())
+        _lib.call("onet_maxpool2_bwd", _p(x), xbs, _p(dy), dybs, _p(dx), C * H * W, B, C, H, W, 0, _stream(),
+                  nbytes=9 * x.numel())
     else:
         _lib.call("onet_maxpool2_bwd_add", _p(x), xbs, _p(dy), dybs, _p(a1), a1bs, _p(a2), a2bs, _p(dx), C * H * W,
-                  B, C, H, W, _stream())
+                  B, C, H, W, _stream(), nbytes=(9 + 4 * (a1 is not None) + 4 * (a2 is not None)) * x.numel())
     return dx if bn is None else (dx, None)
 
 
@@ -715,7 +764,7 @@ def convT2x2_dgrad(dy, wp_dgrad, Cin, h, w, pt, pl):
     e0 = _prof_begin()
     _lib.call("onet_convT2x2_dgrad", _p(dy), dybs, _p(wp_dgrad), _p(dx), Cin * h * w, B, Cin, Ct, h, w, Ho, Wo, pt, pl,
               _stream())
-    _prof_end("conv_fwd_kernel", 2.0 * B * h * w * Cin * 4 * Ct, e0)
+    _prof_end("conv_fwd_kernel", 2.0 * B * h * w * Cin * 4 * Ct, e0, 4.0 * (B * h * w * (Cin + 4 * Ct) + 4 * Cin * Ct))
     return dx
 
 
@@ -732,7 +781,7 @@ def convT2x2_wgrad(x, dy, dw_shape, pt, pl, want_dbias, out=None, db_out=None):
     e0 = _prof_begin()
     _lib.call("onet_convT2x2_wgrad", _p(x), xbs, _p(dy), dybs, _p(dw), _p(ws), ws.numel() * 4, B, Cin, Ct, h, w, Ho, Wo,
               pt, pl, _stream())
-    _prof_end("conv_wgrad_kernel", 2.0 * B * h * w * Cin * 4 * Ct, e0)
+    _prof_end("conv_wgrad_kernel", 2.0 * B * h * w * Cin * 4 * Ct, e0, 4.0 * (B * h * w * (Cin + 4 * Ct) + 4 * Cin * Ct))
     db = None
     if want_dbias:
         db = torch.empty(Ct, dtype=F32, device=x.device) if db_out is None else db_out
@@ -790,7 +839,7 @@ def head_softmax_fwd(Lt, Ht, Ld, Hd, want_sums=False):
         sLt = torch.empty((B, 1, H, W), dtype=F32, device=dev)
         sLd = torch.empty((B, 1, H, W), dtype=F32, device=dev)
         _lib.call("onet_head_softmax_sums_fwd", _p(Lt), a, _p(Ht), b, _p(Ld), c, _p(Hd), d, _p(Vt), _p(Vd), _p(S),
-                  _p(sLt), _p(sLd), B, C, H * W, _stream())
+                  _p(sLt), _p(sLd), B, C, H * W, _stream(), nbytes=16 * Lt.numel())
         return Vt, Vd, S, sLt, sLd
     _lib.call("onet_head_softmax_fwd", _p(Lt), a, _p(Ht), b, _p(Ld), c, _p(Hd), d, _p(Vt), _p(Vd), _p(S), B, C,
               H * W, _stream())
@@ -818,7 +867,8 @@ def head_softmax_bwd(dVt, dVd, dS, S, Lt, Ht, Ld, Hd, twin=False, gsums=(None, N
     gst = None if gsums[0] is None else gsums[0].contiguous()
     gsd = None if gsums[1] is None else gsums[1].contiguous()
     _lib.call("onet_head_softmax_sums_bwd", _p(dVt), _p(dVd), _p(dS), _p(gst), _p(gsd), _p(S), _p(Lt), a, _p(Ht), b,
-              _p(Ld), c, _p(Hd), d, _p(outs[0]), _p(outs[1]), _p(outs[2]), _p(outs[3]), B, C, H * W, _stream())
+              _p(Ld), c, _p(Hd), d, _p(outs[0]), _p(outs[1]), _p(outs[2]), _p(outs[3]), B, C, H * W, _stream(),
+              nbytes=32 * Lt.numel())
     return (dL, dH) if twin else outs
 
 
@@ -899,4 +949,4 @@ def argmax2(S):
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     require_gpu(p, g, m, v)
     _lib.call("onet_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2),
-              float(eps), float(weight_decay), int(step), float(grad_scale), _stream())
+              float(eps), float(weight_decay), int(step), float(grad_scale), _stream(), nbytes=28 * p.numel())

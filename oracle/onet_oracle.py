@@ -30,6 +30,20 @@ stubs for its unused imports) and committed as ``tests/golden/*.npz``;
 
 Weights are never stored: both sides regenerate them with ``det_state_dict``
 (NumPy PCG64 keyed by (seed, crc32(name)) -- independent of torch's RNG).
+
+Routing-controlled evaluation (``Routing``)
+-------------------------------------------
+The network is piecewise linear in its activations: every ReLU (OV:49,53) and every
+MaxPool2d window (OV:67) takes a discrete decision, and the GRADIENT is discontinuous in
+those decisions.  Two correct fp32 evaluations whose pre-activations differ in the last
+bits decide a handful of elements differently, and a single decision at the last layer
+moves every upstream gradient by ~1/sqrt(#elements) -- measured here on the reference's
+own ATen kernels: fp32 vs fp64 gradients differ by 3e-3 .. 5e-3 (relative L2, EVERY
+parameter, every input size from 16^2 to 256^2, saturated head or not), and by 4e-6 once
+the fp64 evaluation is made to take the fp32 run's decisions (tests/test_oracle_routing.py).
+``Routing`` records those decisions (ReLU masks + pooling indices) from one evaluation and
+replays them in another, which turns gradient parity into a continuous -- hence tightly
+testable -- statement, plus an audit of the decisions themselves.
 """
 from __future__ import annotations
 
@@ -84,8 +98,15 @@ def param_table(in_chns: int = 1):
     return rows
 
 
-def det_state_dict(in_chns: int = 1, seed: int = 1981, randomize_running: bool = True):
-    """Deterministic UNet state (un-prefixed keys), independent of torch RNG."""
+HEAD_BN = ("inc.double_conv.4", "up4.conv.double_conv.4")     # the BatchNorms whose outputs are L and H of the head
+
+
+def det_state_dict(in_chns: int = 1, seed: int = 1981, randomize_running: bool = True, head_gain: float = 1.0):
+    """Deterministic UNet state (un-prefixed keys), independent of torch RNG.
+
+    head_gain < 1 scales gamma and beta of the two BatchNorms that feed the head (OV:176-177), i.e. L and H and with
+    them |V| ~ head_gain^2: at head_gain = 1 the initial logits reach |V| ~ 47 and the 2-way softmax is saturated on
+    a fifth of the pixels; 0.3 gives |V| <= 5 (no pixel beyond S = 0.95)."""
     sd = OrderedDict()
     for name, shape, kind in param_table(in_chns):
         rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
@@ -107,14 +128,16 @@ def det_state_dict(in_chns: int = 1, seed: int = 1981, randomize_running: bool =
         elif kind == "bn_nbt":
             sd[name] = torch.tensor(0, dtype=torch.long)
             continue
+        if head_gain != 1.0 and kind in ("bn_w", "bn_b") and name.rsplit(".", 1)[0] in HEAD_BN:
+            v = v * head_gain
         sd[name] = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
     return sd
 
 
-def onet_state_dict(in_chns=1, seed=1981, bshare=True, randomize_running=True):
+def onet_state_dict(in_chns=1, seed=1981, bshare=True, randomize_running=True, head_gain=1.0):
     """The 232-key Onet state_dict: topu.* + dwnu.* (aliases when shared, OV:163-164)."""
-    top = det_state_dict(in_chns, seed, randomize_running)
-    dwn = top if bshare else det_state_dict(in_chns, seed + 1, randomize_running)
+    top = det_state_dict(in_chns, seed, randomize_running, head_gain)
+    dwn = top if bshare else det_state_dict(in_chns, seed + 1, randomize_running, head_gain)
     sd = OrderedDict()
     for k, v in top.items():
         sd["topu." + k] = v
@@ -131,7 +154,68 @@ def det_input(B, C, H, W, seed=7):
 # --------------------------------------------------------------------------
 # functional model
 # --------------------------------------------------------------------------
-def _conv_bn_relu(x, st, p, idx, training):
+class Routing:
+    """The discrete decisions of one twin forward, in call order: 36 ReLU masks (18 Conv-BN-ReLU units per
+    U-Net pass, X pass first) and 8 max-pool index maps (4 per pass).
+
+    mode "record": the evaluation decides freely and its decisions are stored.
+    mode "replay": the evaluation TAKES the stored decisions (relu(y) -> y * mask, max-pool -> gather at the stored
+    indices) and `audit` lists, per decision site, how many elements the free decision would have taken differently
+    and how far from the switching point the worst of them lies (|y| at a flipped ReLU / the gap between the window
+    maximum and the routed element at a re-routed pool window), in units of the tensor's largest magnitude."""
+
+    def __init__(self):
+        self.mode = "record"
+        self.masks, self.pools = [], []
+        self.audit = []
+        self._i = self._j = 0
+
+    def replay(self):
+        self.mode, self._i, self._j, self.audit = "replay", 0, 0, []
+        return self
+
+    @classmethod
+    def from_activations(cls, acts, pooled_units=(1, 3, 5, 7), units_per_pass=18):
+        """Decisions of ANOTHER implementation from its post-ReLU activations `acts` (list of [B,C,H,W] tensors in
+        call order, 18 per pass): mask = a > 0; pooling indices = first maximum of each 2x2 window of the outputs
+        of inc / down1 / down2 / down3 (units 1, 3, 5, 7 of a pass), as nn.MaxPool2d takes it."""
+        r = cls()
+        for n, a in enumerate(acts):
+            r.masks.append(a > 0)
+            if n % units_per_pass in pooled_units:
+                r.pools.append(F.max_pool2d(a.float(), 2, return_indices=True)[1])
+        return r.replay()
+
+    def relu(self, y):
+        if self.mode == "record":
+            self.masks.append((y > 0).detach())
+            return F.relu(y)
+        m = self.masks[self._i]
+        self._i += 1
+        yd = y.detach()
+        flip = (yd > 0) != m
+        n = int(flip.sum())
+        self.audit.append(("relu", n, m.numel(), float(yd[flip].abs().max() / yd.abs().max()) if n else 0.0))
+        return y * m.to(y.dtype)
+
+    def maxpool2(self, a):
+        if self.mode == "record":
+            out, idx = F.max_pool2d(a, 2, return_indices=True)
+            self.pools.append(idx)
+            return out
+        idx = self.pools[self._j]
+        self._j += 1
+        B, C = a.shape[0], a.shape[1]
+        out = a.reshape(B, C, -1).gather(2, idx.reshape(B, C, -1)).view(idx.shape)
+        free, fidx = F.max_pool2d(a.detach(), 2, return_indices=True)
+        moved = fidx != idx
+        n = int(moved.sum())
+        gap = float((free - out.detach())[moved].max() / a.detach().abs().max()) if n else 0.0
+        self.audit.append(("pool", n, idx.numel(), gap))
+        return out
+
+
+def _conv_bn_relu(x, st, p, idx, training, routing=None):
     """conv3x3(pad 1, no bias) -> BN -> ReLU  (OV:47-49 / OV:51-53)."""
     z = F.conv2d(x, st[f"{p}.{idx}.weight"], None, 1, 1)
     b = idx + 1
@@ -140,12 +224,12 @@ def _conv_bn_relu(x, st, p, idx, training):
                      training, BN_MOMENTUM, BN_EPS)
     if training:
         st[f"{p}.{b}.num_batches_tracked"] += 1
-    return F.relu(y)
+    return F.relu(y) if routing is None else routing.relu(y)
 
 
-def _double_conv(x, st, block, training):
+def _double_conv(x, st, block, training, routing=None):
     p = _dc_prefix(block)
-    return _conv_bn_relu(_conv_bn_relu(x, st, p, 0, training), st, p, 3, training)
+    return _conv_bn_relu(_conv_bn_relu(x, st, p, 0, training, routing), st, p, 3, training, routing)
 
 
 def upsample_cat(x1, x2, st, block, bilinear=False):
@@ -160,15 +244,16 @@ def upsample_cat(x1, x2, st, block, bilinear=False):
     return torch.cat([x2, u], dim=1)       # skip first, upsampled second (OV:100)
 
 
-def unet_pass(x, st, training=True):
+def unet_pass(x, st, training=True, routing=None):
     """UNet.forward (OV:142-153): returns (x1, y1) = (first-block features, last-block features)."""
-    feats = [_double_conv(x, st, "inc", training)]
+    feats = [_double_conv(x, st, "inc", training, routing)]
     for name, _, _ in ENC[1:]:
-        feats.append(_double_conv(F.max_pool2d(feats[-1], 2), st, name, training))
+        pooled = F.max_pool2d(feats[-1], 2) if routing is None else routing.maxpool2(feats[-1])
+        feats.append(_double_conv(pooled, st, name, training, routing))
     y = feats[-1]
     for lvl, (name, _, _) in enumerate(DEC):
         skip = feats[3 - lvl]
-        y = _double_conv(upsample_cat(y, skip, st, name), st, name, training)
+        y = _double_conv(upsample_cat(y, skip, st, name), st, name, training, routing)
     return feats[0], y
 
 
@@ -177,14 +262,14 @@ def head(L, Hf):
     return (L * Hf).sum(dim=1, keepdim=True)
 
 
-def onet_forward(X, top, dwn=None, training=True, bias=0.0):
+def onet_forward(X, top, dwn=None, training=True, bias=0.0, routing=None):
     """Onet.forward (OV:174-191).  ``top``/``dwn`` are un-prefixed UNet state
     dicts of tensors (parameters may require grad); ``dwn is None`` == shared."""
     dwn = top if dwn is None else dwn
-    Lt, Ht = unet_pass(X, top, training)
+    Lt, Ht = unet_pass(X, top, training, routing)
     Vt = head(Lt, Ht)
     Xd = torch.clip(1 - X + bias, 0, 1)
-    Ld, Hd = unet_pass(Xd, dwn, training)
+    Ld, Hd = unet_pass(Xd, dwn, training, routing)
     Vd = head(Ld, Hd)
     S = torch.softmax(torch.cat([Vt, Vd], dim=1), dim=1)     # Softmax2d
     return Lt, Vt, Ld, Vd, S
@@ -242,9 +327,9 @@ def clone_state(sd, requires_grad=True):
     return out
 
 
-def train_mode_step(X, top, dwn=None):
+def train_mode_step(X, top, dwn=None, routing=None):
     """fwd + loss + backward; returns (outputs, loss, grads dict)."""
-    Lt, Vt, Ld, Vd, S = onet_forward(X, top, dwn, training=True)
+    Lt, Vt, Ld, Vd, S = onet_forward(X, top, dwn, training=True, routing=routing)
     loss = compute_loss(Lt, S[:, 0:1], Ld, S[:, 1:2])
     loss.backward()
     grads = OrderedDict((k, v.grad) for k, v in top.items() if v.requires_grad)

@@ -146,6 +146,95 @@ def run_case(ov, tag, B, C, H, W, bshare=True, train=True, full=False, steps=1):
     print(tag, "losses", losses)
 
 
+def grad_samples(named_grads, n_big=1024):
+    """Per parameter: L2 norm, and the gradient itself where it has <= 4096 elements (every BatchNorm gamma / beta,
+    ConvTranspose2d bias, the stem convolution) or a strided sample of n_big elements spread over the whole tensor."""
+    norms, vals, offs = [], [], [0]
+    for _, g in named_grads:
+        g = g.detach().reshape(-1).double()
+        norms.append(float(g.norm()))
+        v = g if g.numel() <= 4096 else g[:: g.numel() // n_big][:n_big]
+        vals.append(v.numpy())
+        offs.append(offs[-1] + v.numel())
+    return np.array(norms), np.concatenate(vals), np.array(offs, dtype=np.int64)
+
+
+def install_routing(model, routing):
+    """Swap every nn.ReLU / nn.MaxPool2d of a reference model INSTANCE (OV:49,53,67) for a module that records or
+    replays its decisions through `routing` (oracle.Routing): the reference's own graph, its own conv / BN / convT /
+    cat / head / loss code, with only the discrete decisions taken from outside."""
+    import torch.nn as nn
+
+    class RoutedReLU(nn.Module):
+        def forward(self, y):
+            return routing.relu(y)
+
+    class RoutedPool(nn.Module):
+        def forward(self, a):
+            return routing.maxpool2(a)
+
+    for mod in list(model.modules()):
+        if isinstance(mod, nn.Sequential):
+            for i, child in enumerate(mod):
+                if isinstance(child, nn.ReLU):
+                    mod[i] = RoutedReLU()
+                elif isinstance(child, nn.MaxPool2d):
+                    mod[i] = RoutedPool()
+
+
+def run_routed_case(ov, tag, B, C, H, W, head_gain=0.3):
+    """Well-conditioned head (|V| <= 5), larger batch.  Three evaluations of the REAL reference graph:
+    fp32 (decisions recorded), fp64 deciding freely ("truth"), fp64 taking the fp32 run's decisions ("routed").
+    fp32 vs truth differ by 3e-3..5e-3 on every parameter (ReLU / pooling decisions flip at rounding level), fp32 vs
+    routed by ~1e-5: that is what tests/test_oracle_routing.py and the routing-controlled GPU tests build on."""
+    X = orc.det_input(B, C, H, W)
+    sd = orc.onet_state_dict(C, 1981, True, head_gain=head_gain)
+
+    def build(dtype, routing=None):
+        torch.manual_seed(0)
+        m = ov.Onet(in_chns=C, binit=True, bshare=True)
+        m.load_state_dict(sd)
+        m = m.to(dtype).train()
+        if routing is not None:
+            install_routing(m, routing)
+        Lt, Vt, Ld, Vd, S = m(X.to(dtype))
+        loss = m.compute_loss(Lt, S[:, 0].unsqueeze(1), Ld, S[:, 1].unsqueeze(1))
+        loss.backward()
+        return m, (Lt, Vt, Ld, Vd, S), loss
+
+    r = orc.Routing()
+    m32, o32, l32 = build(torch.float32, r)
+    out = {"meta": np.array([B, C, H, W, 1, 1, 1]), "head_gain": np.float64(head_gain),
+           "losses": np.array([float(l32)]), "Vt": o32[1].detach().numpy()[:, :, ::37, :],
+           "Vd": o32[3].detach().numpy()[:, :, ::37, :], "S": o32[4].detach().numpy()[:, :, ::37, :],
+           "Lt_chsum": o32[0].detach().sum(1).numpy()[:, ::37, :], "Ld_chsum": o32[2].detach().sum(1).numpy()[:, ::37, :],
+           "label": m32.predict_label(o32[4]).numpy().astype(np.uint8)[:, ::37, :]}
+    named = [(n, p.grad) for n, p in m32.named_parameters()]
+    out["grad_names"] = np.array([n for n, _ in named])
+    out["grad_norms"], out["grad_vals"], out["grad_offs"] = grad_samples(named)
+    out["bn_rm"], out["bn_rv"], out["bn_nbt"] = bn_digest(m32)
+    del m32, o32
+    m64, o64, l64 = build(torch.float64)
+    out["loss64"] = np.float64(l64.item())
+    out["grad_norms64"], out["grad_vals64"], _ = grad_samples([(n, p.grad) for n, p in m64.named_parameters()])
+    out["Vt64"] = o64[1].detach().numpy()[:, :, ::37, :]
+    del m64, o64
+    m64r, o64r, l64r = build(torch.float64, r.replay())
+    out["loss64r"] = np.float64(l64r.item())
+    out["grad_norms64r"], out["grad_vals64r"], _ = grad_samples([(n, p.grad) for n, p in m64r.named_parameters()])
+    out["routing_audit"] = np.array([[a[1], a[2], a[3]] for a in r.audit], dtype=np.float64)
+    out["grad_vals"] = out["grad_vals"].astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, f"onet_{tag}.npz"), **out)
+
+    def worst(a, b):
+        o = out["grad_offs"]
+        return max(np.linalg.norm(a[o[i]:o[i + 1]] - b[o[i]:o[i + 1]]) / np.linalg.norm(b[o[i]:o[i + 1]])
+                   for i in range(len(o) - 1))
+    print(tag, "loss", float(l32), float(l64), float(l64r), "| fp32 vs truth %.2e, fp32 vs routed %.2e, flips %d" % (
+        worst(out["grad_vals"].astype(np.float64), out["grad_vals64"]),
+        worst(out["grad_vals"].astype(np.float64), out["grad_vals64r"]), int(out["routing_audit"][:, 0].sum())))
+
+
 def run_log1pexp(ov):
     model = ov.Onet(in_chns=1)
     xs = np.array([-100, -50, -37.0001, -37, -36.9999, -20, -10, -1, 0, 1, 10, 17.9999, 18, 18.0001,
@@ -213,11 +302,117 @@ def run_up_block(ov, bilinear, tag, h=12, w=12, H=25, W=25):
     print("up", tag, float(y.abs().mean()))
 
 
+def eval_side_cases():
+    """Label maps for the eval-side fixtures (stored in the fixture next to the outputs): random, complement of the ground
+    truth, all-background prediction, empty ground truth, both empty, tie between the two assignments."""
+    rng = np.random.Generator(np.random.PCG64(2024))
+    H, W = 24, 40
+    gt = (rng.random((H, W)) > 0.8).astype(np.int64)
+    cases = [("random", (rng.random((H, W)) > 0.7).astype(np.int64), gt),
+             ("complement", 1 - gt, gt),
+             ("mostly_right", np.where(rng.random((H, W)) > 0.1, gt, 1 - gt), gt),
+             ("pred_all_bg", np.zeros((H, W), np.int64), gt),
+             ("gt_all_bg", (rng.random((H, W)) > 0.5).astype(np.int64), np.zeros((H, W), np.int64)),
+             ("both_all_bg", np.zeros((H, W), np.int64), np.zeros((H, W), np.int64)),
+             ("both_all_fg", np.ones((H, W), np.int64), np.ones((H, W), np.int64))]
+    cases.append(("disjoint", np.zeros((H, W), np.int64), np.ones((H, W), np.int64)))   # UT:152 raises AttributeError
+    tie_p = np.zeros((H, W), np.int64)
+    tie_p[:, : W // 2] = 1
+    tie_g = np.zeros((H, W), np.int64)
+    tie_g[: H // 2] = 1
+    cases.append(("tie", tie_p, tie_g))
+    return cases
+
+
+def run_eval_side():
+    """Eval-side helpers of the reference (utils_20231218.py, "UT") on fixed label maps / frames:
+    _acc, _miou, _target_iou, _detection_rate, _false_alarm_rate (UT:100-192), re_assign_label (UT:410-453),
+    reorder_segmentation / _hungarian_match (UT:258-285, 360-375), tensor_normal_per_frame (UT:673-689)."""
+    import utils_20231218 as ut
+    out = {}
+    names = []
+    for name, p, g in eval_side_cases():
+        names.append(name)
+        out[f"{name}_pred"], out[f"{name}_gt"] = p.astype(np.uint8), g.astype(np.uint8)
+        P, Gt = torch.from_numpy(p), torch.from_numpy(g)
+        Gf = Gt.to(torch.float32)                      # the reference's label tensors are float32 (RG:283)
+        vals = []
+        for fn in (lambda: ut._acc(P, Gt, 2), lambda: ut._miou(P, Gt, 2), lambda: ut._target_iou(P, Gt),
+                   lambda: ut._detection_rate(P, Gt), lambda: ut._false_alarm_rate(P, Gt)):
+            try:
+                vals.append(float(fn()))
+            except AttributeError:                     # UT:152: `.item()` on a python float when no class is mixed
+                vals.append(np.nan)
+        out[f"{name}_metrics"] = np.array(vals, dtype=np.float64)
+        out[f"{name}_reassign"] = ut.re_assign_label(P, Gf).numpy().astype(np.int64)
+        out[f"{name}_reorder"] = ut.reorder_segmentation(P.clone(), Gt.clone()).numpy().astype(np.int64)
+    out["names"] = np.array(names)
+    rng = np.random.Generator(np.random.PCG64(77))
+    X = (rng.standard_normal((3, 2, 19, 23)) * 5 + 2).astype(np.float32)
+    X[1, 0] = 0.75                                     # constant frame: max == min
+    out["norm_in"] = X
+    out["norm_out"] = ut.tensor_normal_per_frame(torch.from_numpy(X)).numpy()
+    np.savez_compressed(os.path.join(HERE, "eval_side.npz"), **out)
+    print("eval_side", {n: out[f"{n}_metrics"].round(4).tolist() for n in names})
+
+
+def run_wire_formats(ov):
+    """(1) key list of the REAL Onet state_dict (names, shapes, dtypes; 232 entries, TS:264) and of a checkpoint dict as
+    the trainers write it; (2) a small data file written by the reference's own writer `prepare_data` (RG:300-324) --
+    with the frame count per PSNR cut from 150 to 2 and a 48x48 centre crop so that the fixture stays small (the
+    writer's hard-coded `psnrs.extend([psnr] * 150)` is left as it is: 1650 PSNR entries for 22 frames)."""
+    import json
+    sd = ov.Onet(in_chns=1, binit=True, bshare=True).state_dict()
+    sd3 = ov.Onet(in_chns=3, binit=True, bshare=False).state_dict()
+    spec = {"onet_c1_share": [[k, list(v.shape), str(v.dtype)] for k, v in sd.items()],
+            "onet_c3_noshare": [[k, list(v.shape), str(v.dtype)] for k, v in sd3.items()],
+            "checkpoint_keys_sim": ["net", "epoch"], "checkpoint_keys_zy3": ["net", "save_epoch"]}
+    json.dump(spec, open(os.path.join(HERE, "state_dict_keys.json"), "w"))
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+
+    class CenterCrop:                                   # torchvision is not installed: the one transform RG:302 uses
+        def __init__(self, size):
+            self.size = size
+
+        def __call__(self, t):
+            h, w = self.size
+            H, W = t.shape[-2:]
+            return t[..., (H - h) // 2:(H - h) // 2 + h, (W - w) // 2:(W - w) // 2 + w]
+
+    tvt.CenterCrop = CenterCrop
+    tv.transforms = tvt
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.transforms", tvt)
+    cwd = os.getcwd()
+    try:
+        os.chdir("/tmp")
+        import Rayleigh_bg_Gaussian_EOT_generator_20230208 as rg
+    finally:
+        os.chdir(cwd)
+    real = rg.prepare_frames
+    rg.prepare_frames = lambda type="rayleigh", fnums=4, snr=10: real(type=type, fnums=2, snr=snr)
+    np.random.seed(1981)
+    path = os.path.join(HERE, "rayleigh_writer_sample.pt")
+    rg.prepare_data(img_sz=(48, 48), bg_type="rayleigh", file_name=path)
+    d = torch.load(path)
+    print("wire formats:", len(spec["onet_c1_share"]), "keys;", {k: (tuple(v.shape) if hasattr(v, "shape") else len(v))
+                                                                  for k, v in d.items()})
+
+
 if __name__ == "__main__":
     ov = import_reference()
+    if os.environ.get("GOLDEN_ONLY") == "evalside":
+        run_eval_side()
+        run_wire_formats(ov)
+        sys.exit(0)
     if os.environ.get("GOLDEN_ONLY") == "up":
         run_up_block(ov, False, "convT_pad")
         run_up_block(ov, True, "bilinear_pad")
+        sys.exit(0)
+    if os.environ.get("GOLDEN_ONLY") == "routed":
+        run_routed_case(ov, "routed_b8_c1_128", 8, 1, 128, 128)
+        run_routed_case(ov, "routed_b4_c1_256", 4, 1, 256, 256)
         sys.exit(0)
     run_log1pexp(ov)
     run_loss_extreme(ov)
@@ -232,3 +427,7 @@ if __name__ == "__main__":
     run_case(ov, "b2_c1_256", 2, 1, 256, 256)         # BASELINE config C1 shape
     run_up_block(ov, False, "convT_pad")
     run_up_block(ov, True, "bilinear_pad")
+    run_routed_case(ov, "routed_b8_c1_128", 8, 1, 128, 128)   # unsaturated head, large N, full / strided gradients
+    run_routed_case(ov, "routed_b4_c1_256", 4, 1, 256, 256)
+    run_eval_side()
+    run_wire_formats(ov)

@@ -1,0 +1,202 @@
+"""Gradient parity of the HIP path at 1e-4 -- ten times tighter than the north-star's 1e-3 -- on EVERY element of EVERY
+parameter gradient, including the B=32 256x256 benchmark dispatch (F(4x4,3x3) with both fused epilogues, F(3x3,4x4)
+and F(2x2,3x3) weight gradients, fused ConvTranspose2d GEMMs, pooling backward with the BatchNorm reduce).
+
+Why "routing-controlled": the Onet gradient is discontinuous in every ReLU / max-pool decision.  The reference's own fp32
+gradients are 3e-3..7e-3 from its fp64 gradients on every parameter at every size (goldens `routed_*`, minted from the real
+reference; tests/test_oracle_routing.py), so no fp32 implementation can be held to 1e-3 against a FREE fp64 evaluation --
+and a bound loose enough to pass would also pass a 1 % systematic kernel error.  Here the fp64 oracle takes the discrete
+decisions of the HIP run (oracle.Routing.from_activations: ReLU masks and pooling indices rebuilt from the HIP
+activations); what remains is a smooth function, and the HIP gradients must match it to fp32 rounding.  The decisions
+themselves are audited: wherever the free fp64 evaluation would decide differently, the pre-activation (or the window
+gap) must lie within rounding distance of the switching point, and such elements must be rare.
+
+Forward outputs / loss / labels / running statistics stay on the plain 1e-3 against the reference goldens."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import onet_oracle as orc
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+GRAD_TOL = 1e-4          # relative L2 per parameter tensor, HIP fp32 vs routed fp64 oracle
+FLIP_DIST = 2e-4         # a decision may differ from the free fp64 one only this close to its switch (of the tensor's max)
+FLIP_FRAC = 2e-4         # ... and on at most this fraction of a tensor's elements
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _to64(sd):
+    return {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+
+
+def _hip_step_recording(m, X, monkeypatch, keep):
+    """One HIP training step (TS:210-217 order) with the output of every Conv-BN-ReLU unit captured for the images
+    `keep` (indices into the batch) -> (outputs, loss, acts in the oracle's call order: 18 units of the X pass, then
+    18 of the 1-X pass)."""
+    from onet_amd import functional as Fn
+    from onet_amd import ops
+    assert ops.TWIN and m.dwnu is m.topu
+    B = X.shape[0]
+    idx = torch.tensor(list(keep), device=X.device)
+    rec = []
+    real = Fn.ConvBNReLUFn.apply
+
+    def apply(*a, **k):
+        out = real(*a, **k)
+        o = out.detach()
+        assert o.shape[0] == 2 * B
+        rec.append((o[idx].cpu(), o[idx + B].cpu()))
+        return out
+
+    monkeypatch.setattr(Fn.ConvBNReLUFn, "apply", staticmethod(apply))
+    m.zero_grad()
+    Lt, Vt, Ld, Vd, S = m(X)
+    loss = m.compute_loss(Lt, S[:, 0].unsqueeze(1), Ld, S[:, 1].unsqueeze(1))
+    loss.backward()
+    monkeypatch.setattr(Fn.ConvBNReLUFn, "apply", real)
+    assert len(rec) == 18
+    return (Lt, Vt, Ld, Vd, S), loss, [r[0] for r in rec] + [r[1] for r in rec]
+
+
+def _routed_oracle(Xcpu, C, seed, gain, acts):
+    r = orc.Routing.from_activations(acts)
+    top = orc.clone_state(_to64(orc.det_state_dict(C, seed, head_gain=gain)))
+    outs, loss, grads = orc.train_mode_step(Xcpu.double(), top, routing=r)
+    return outs, loss, grads, r
+
+
+def _check(m, grads64, routing, what):
+    named = dict(m.topu.named_parameters())
+    worst = (0.0, "")
+    for k, t in grads64.items():
+        a = named[k].grad.detach().cpu().double()
+        e = float((a - t).norm() / t.norm())
+        worst = max(worst, (e, k))
+        assert e <= GRAD_TOL, (what, k, e)
+        # element-wise too: no single element further off than GRAD_TOL of the tensor's largest magnitude x sqrt(n) share
+        assert float((a - t).abs().max()) <= 20 * GRAD_TOL * float(t.abs().max()), (what, k)
+    flips = sum(a[1] for a in routing.audit)
+    dist = max(a[3] for a in routing.audit)
+    frac = max(a[1] / a[2] for a in routing.audit)
+    assert dist <= FLIP_DIST, (what, "a decision differs from the exact one far from its switching point", dist)
+    assert frac <= FLIP_FRAC, (what, "too many decisions differ from the exact ones", frac)
+    print(f"{what}: worst gradient error {worst[0]:.2e} ({worst[1]}); {flips} of "
+          f"{sum(a[2] for a in routing.audit)} decisions differ from the exact ones, farthest {dist:.1e} from the switch")
+
+
+def _model(C, gain, dev, seed=1981):
+    import Onet_vanilla_20240606 as ov
+    m = ov.Onet(in_chns=C, binit=True, bshare=True)
+    m.load_state_dict(orc.onet_state_dict(C, seed, True, head_gain=gain))
+    return m.to(dev).train()
+
+
+CASES = {
+    # tag: (B, C, H, W, head_gain, algorithms)
+    "b8_c1_128": (8, 1, 128, 128, 0.3, ("auto", "winograd4", "winograd", "direct")),
+    "b4_c1_256": (4, 1, 256, 256, 0.3, ("auto", "winograd4")),
+    "b2_c3_64_saturated": (2, 3, 64, 64, 1.0, ("auto", "winograd4")),
+    "b3_c1_40_padpath": (3, 1, 40, 40, 1.0, ("auto",)),
+}
+
+
+@pytest.mark.parametrize("algo", ["auto", "winograd4", "winograd", "direct"])
+@pytest.mark.parametrize("tag", list(CASES))
+def test_every_gradient_element_vs_routed_fp64_oracle(dev, tag, algo, monkeypatch):
+    from onet_amd import ops
+    B, C, H, W, gain, algos = CASES[tag]
+    if algo not in algos:
+        pytest.skip("algorithm not forced on this case")
+    monkeypatch.setattr(ops, "CONV_ALGO", algo)
+    X = orc.det_input(B, C, H, W)
+    m = _model(C, gain, dev)
+    (Lt, Vt, Ld, Vd, S), loss, acts = _hip_step_recording(m, X.to(dev), monkeypatch, range(B))
+    (oLt, oVt, oLd, oVd, oS), oloss, g64, r = _routed_oracle(X, C, 1981, gain, acts)
+    assert abs(loss.item() - float(oloss)) <= 1e-5 * abs(float(oloss))
+    assert float((Vt.detach().cpu().double() - oVt.detach()).abs().max()) <= 1e-4 * float(oVt.detach().abs().max())
+    # S = softmax([Vt, Vd]): |dS| <= |dV| / 4, and |V| reaches 35 in the saturated cases
+    assert float((S.detach().cpu().double() - oS.detach()).abs().max()) <= 1e-4 * max(1.0, float(oVt.detach().abs().max()) / 4)
+    _check(m, g64, r, f"{tag}/{algo}")
+    g = os.path.join(G, f"onet_routed_{tag}.npz")
+    if os.path.exists(g):                       # the same case as recorded from the REAL reference (fp32): forward at 1e-3
+        g = np.load(g)
+        assert abs(loss.item() - g["losses"][0]) <= 1e-3 * abs(g["losses"][0])
+        for name, t in (("Vt", Vt), ("Vd", Vd), ("S", S)):
+            ref = g[name]
+            assert np.abs(t.detach().cpu().numpy()[:, :, ::37, :] - ref).max() <= 1e-3 * np.abs(ref).max(), name
+        lab = m.predict_label(S).cpu().numpy().astype(np.uint8)[:, ::37, :]
+        tie = np.abs(g["S"][:, 0] - g["S"][:, 1]) < 1e-3
+        assert np.array_equal(lab[~tie], g["label"][~tie])
+        rm = torch.cat([b.reshape(-1) for n, b in m.topu.named_buffers() if n.endswith("running_mean")]).cpu().numpy()
+        rv = torch.cat([b.reshape(-1) for n, b in m.topu.named_buffers() if n.endswith("running_var")]).cpu().numpy()
+        assert np.abs(rm - g["bn_rm"][:rm.size]).max() <= 1e-3 * np.abs(g["bn_rm"]).max()
+        assert np.abs(rv - g["bn_rv"][:rv.size]).max() <= 1e-3 * np.abs(g["bn_rv"]).max()
+        # gradients of the reference's fp32 run: its decisions differ from ours at a few dozen elements, so this
+        # comparison carries the decision noise the reference has against ITSELF in fp64 (measured in the golden)
+        offs = g["grad_offs"]
+        v32, v64 = g["grad_vals"].astype(np.float64), g["grad_vals64"]
+        named = dict(m.named_parameters())
+        eps_ref = max(np.linalg.norm(v32[offs[i]:offs[i + 1]] - v64[offs[i]:offs[i + 1]]) /
+                      np.linalg.norm(v64[offs[i]:offs[i + 1]]) for i in range(len(offs) - 1))
+        for i, n in enumerate(str(s) for s in g["grad_names"]):
+            gr = named[n].grad.detach().reshape(-1).double().cpu()
+            v = (gr if gr.numel() <= 4096 else gr[:: gr.numel() // 1024][:1024]).numpy()
+            e = np.linalg.norm(v - v32[offs[i]:offs[i + 1]]) / np.linalg.norm(v32[offs[i]:offs[i + 1]])
+            assert e <= 3 * eps_ref, (n, e, eps_ref)
+
+
+def test_benchmark_dispatch_b32_256_every_gradient_element(dev, monkeypatch):
+    """BASELINE configs[1] as benchmarked: B=32, 1x256x256, default dispatch.  The batch is the B=2 golden input tiled
+    16 times: BatchNorm statistics, loss and every parameter gradient of a tiled batch equal those of the tile (means
+    over B*H*W), so the fp64 oracle runs at B=2 under the decisions the HIP run took on the first two images of each
+    half -- after checking that all 16 copies decided identically."""
+    from onet_amd import ops
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 40 * 2 ** 30:
+        pytest.skip("needs ~25 GB of free HBM")
+    g = np.load(os.path.join(G, "onet_b2_c1_256.npz"))
+    x2 = orc.det_input(2, 1, 256, 256)
+    X = x2.to(dev).repeat(16, 1, 1, 1)
+    m = _model(1, 1.0, dev)
+    used = {}
+    for name in ("conv3x3_fwd_bn_partials", "conv3x3_dgrad_bnreduce", "conv3x3_winograd4_wgrad", "conv3x3_winograd_wgrad",
+                 "convT2x2_wgrad", "convT2x2_dgrad"):
+        real = getattr(ops, name)
+
+        def spy(*a, _real=real, _name=name, **k):
+            out = _real(*a, **k)
+            if out is not None and not (isinstance(out, tuple) and out[-1] is None and _name == "conv3x3_fwd_bn_partials"):
+                used[_name] = used.get(_name, 0) + 1
+            return out
+
+        monkeypatch.setattr(ops, name, spy)
+    copies = []
+    from onet_amd import functional as Fn
+    real_apply = Fn.ConvBNReLUFn.apply
+
+    def apply(*a, **k):
+        out = real_apply(*a, **k)
+        o = out.detach()
+        copies.append(bool(torch.equal(o[0:2] > 0, o[30:32] > 0)) and bool(torch.equal(o[32:34] > 0, o[46:48] > 0)))
+        return out
+
+    monkeypatch.setattr(Fn.ConvBNReLUFn, "apply", staticmethod(apply))
+    (Lt, Vt, Ld, Vd, S), loss, acts = _hip_step_recording(m, X, monkeypatch, range(2))
+    assert all(copies) and len(copies) == 18, "tile copies took different ReLU decisions"
+    # the benchmark's kernels really ran: fused-statistics forward, fused-reduce dgrad, both Winograd weight gradients
+    assert used.get("conv3x3_fwd_bn_partials", 0) >= 14 and used.get("conv3x3_dgrad_bnreduce", 0) >= 6, used
+    assert used.get("conv3x3_winograd4_wgrad", 0) >= 8 and used.get("convT2x2_wgrad", 0) == 4, used
+    assert abs(loss.item() - g["losses"][0]) <= 1e-3 * abs(g["losses"][0])
+    assert np.abs(Vt.detach().cpu().numpy()[:2, :, ::37, :] - g["Vt"]).max() <= 1e-3 * np.abs(g["Vt"]).max()
+    _, oloss, g64, r = _routed_oracle(x2, 1, 1981, 1.0, acts)
+    assert abs(loss.item() - float(oloss)) <= 1e-5 * abs(float(oloss))
+    _check(m, g64, r, "B=32 256x256 benchmark dispatch")

@@ -1,0 +1,102 @@
+"""Routing-controlled evaluation of the CPU oracle, pinned to the REAL reference (CPU only).
+
+The Onet gradient is discontinuous in every ReLU / max-pool decision, so "fp32 gradient within 1e-3 of the exact
+one" is not a property ANY fp32 evaluation has -- the reference's own ATen kernels sit 3e-3..7e-3 from their fp64
+selves on every parameter (golden `routed_*`: recorded from the reference, reproduced here).  With the decisions
+of the fp32 run replayed in the fp64 evaluation (oracle.Routing) the same comparison gives ~2e-5.  The GPU parity
+tests use exactly this: fp64 oracle under the HIP path's own decisions, every gradient element, tolerance 1e-4,
+plus an audit that the decisions differ from the free fp64 ones only at rounding distance from the switch."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import onet_oracle as orc
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _to64(sd):
+    return {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+
+
+def _samples(grads, names, offs, n_big=1024):
+    out = []
+    for n in names:
+        g = grads[n[5:]].detach().reshape(-1).double()
+        out.append((g if g.numel() <= 4096 else g[:: g.numel() // n_big][:n_big]).numpy())
+    v = np.concatenate(out)
+    assert v.size == offs[-1]
+    return v
+
+
+def _worst(a, b, offs):
+    return max(np.linalg.norm(a[offs[i]:offs[i + 1]] - b[offs[i]:offs[i + 1]]) /
+               (np.linalg.norm(b[offs[i]:offs[i + 1]]) + 1e-300) for i in range(len(offs) - 1))
+
+
+@pytest.mark.parametrize("tag", ["routed_b8_c1_128", "routed_b4_c1_256"])
+def test_routed_oracle_matches_routed_reference(tag):
+    g = np.load(os.path.join(G, f"onet_{tag}.npz"))
+    B, C, H, W = [int(v) for v in g["meta"][:4]]
+    gain = float(g["head_gain"])
+    names = [str(n) for n in g["grad_names"]]
+    offs = g["grad_offs"]
+    X = orc.det_input(B, C, H, W)
+    torch.set_num_threads(min(8, torch.get_num_threads()))
+    r = orc.Routing()
+    top = orc.clone_state(orc.det_state_dict(C, 1981, head_gain=gain))
+    (Lt, Vt, Ld, Vd, S), loss, g32 = orc.train_mode_step(X, top, routing=r)
+    # fp32: same ATen ops as the reference -> same numbers, same decisions
+    assert abs(float(loss) - g["losses"][0]) <= 2e-6 * abs(g["losses"][0])
+    np.testing.assert_allclose(Vt.detach().numpy()[:, :, ::37, :], g["Vt"], rtol=1e-4, atol=1e-4)
+    assert float(Vt.detach().abs().max()) < 6.0                      # the head is NOT saturated in these cases
+    v32 = _samples(g32, names, offs)
+    assert _worst(v32, g["grad_vals"].astype(np.float64), offs) <= 2e-4
+    # fp64 under the fp32 run's decisions: the reference's routed evaluation, to fp64 accuracy
+    top64 = orc.clone_state(_to64(orc.det_state_dict(C, 1981, head_gain=gain)))
+    _, loss64r, g64r = orc.train_mode_step(X.double(), top64, routing=r.replay())
+    assert abs(float(loss64r) - float(g["loss64r"])) <= 1e-10 * abs(float(g["loss64r"]))
+    v64r = _samples(g64r, names, offs)
+    assert _worst(v64r, g["grad_vals64r"], offs) <= 1e-7
+    for i, n in enumerate(names):
+        assert abs(float(g64r[n[5:]].norm()) - g["grad_norms64r"][i]) <= 1e-7 * g["grad_norms64r"][i], n
+    # the statement itself, on the reference's numbers: routed 1e-4 or better, free 1e-3 or worse
+    e_routed = _worst(g["grad_vals"].astype(np.float64), g["grad_vals64r"], offs)
+    e_free = _worst(g["grad_vals"].astype(np.float64), g["grad_vals64"], offs)
+    assert e_routed <= 1e-4 and e_free >= 1e-3, (e_routed, e_free)
+    # and every decision the fp64 run would have taken differently sits at rounding distance from its switch
+    audit = g["routing_audit"]
+    assert audit[:, 0].sum() > 0 and audit[:, 2].max() <= 1e-5
+    assert (audit[:, 0] / audit[:, 1]).max() <= 1e-4
+
+
+def test_routing_from_activations_equals_recorded_routing():
+    """Routing.from_activations (how the GPU tests obtain the HIP path's decisions) rebuilds the recorded decisions
+    from the post-ReLU activations alone."""
+    B, C, H, W = 2, 1, 32, 32
+    X = orc.det_input(B, C, H, W)
+    acts = []
+    real = orc.Routing.relu
+
+    class Rec(orc.Routing):
+        def relu(self, y):
+            out = real(self, y)
+            acts.append(out.detach().clone())
+            return out
+
+    r = Rec()
+    top = orc.clone_state(orc.det_state_dict(C, 1981))
+    _, _, g_rec = orc.train_mode_step(X, top, routing=r)
+    r2 = orc.Routing.from_activations(acts)
+    assert len(r2.masks) == 36 and len(r2.pools) == 8
+    for a, b in zip(r.masks, r2.masks):
+        assert torch.equal(a, b)
+    for a, b in zip(r.pools, r2.pools):
+        assert torch.equal(a, b)
+    top2 = orc.clone_state(orc.det_state_dict(C, 1981))
+    _, _, g_rep = orc.train_mode_step(X, top2, routing=r2)
+    assert all(a[1] == 0 for a in r2.audit)
+    for k in g_rec:
+        assert torch.allclose(g_rec[k], g_rep[k], rtol=1e-6, atol=1e-9), k
