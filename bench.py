@@ -54,13 +54,29 @@ def _cpu_model():
     return "unknown"
 
 
+def _host_cores():
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU box hands each job a
+    share of the host; os.cpu_count() reports the whole machine and 128 threads on a 16-core share run 3x slower than 16)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(X_cpu, seconds_budget):
     """fwd + loss + bwd + Adam of the CPU oracle (PyTorch CPU fp32: the same ATen / oneDNN kernels the reference runs
     on CPU) on the host cores of this box, for n = all cores and n = 8 threads.  The sample is the first
     B_s images of the SAME synthetic batch, B_s = the largest power of two <= the benchmark batch whose 3 timed steps fit
     the budget of a thread setting (half of --cpu-seconds), estimated from a B=2 warm-up step."""
     from oracle import onet_oracle as orc
-    ncores = os.cpu_count() or 1
+    ncores = _host_cores()
     settings = [ncores] + ([8] if ncores > 8 else [])
     per_setting = seconds_budget / len(settings)
     by_threads, sample = {}, {}
@@ -82,15 +98,21 @@ def cpu_baseline(X_cpu, seconds_budget):
         while bs * 2 <= X_cpu.shape[0] and 3 * t_warm * (bs * 2) / 2 <= per_setting - t_warm:
             bs *= 2
         xs = X_cpu[:bs].contiguous()
-        times = [step(xs) for _ in range(3)]
+        times = []
+        for _ in range(3):
+            times.append(step(xs))
+            sys.stderr.write("[cpu_baseline] n=%d B=%d step %.2f s\n" % (n, bs, times[-1]))
+            sys.stderr.flush()
+            if sum(times) > 2.0 * per_setting:                # the estimate was off: stop at what we have
+                break
         by_threads[str(n)] = round(bs / (sum(times) / len(times)), 4)
         sample[str(n)] = bs
     torch.set_num_threads(ncores)
     n0 = str(settings[0])
     return {"value": by_threads[n0], "unit": "images/s", "cores": settings[0], "kind": "port",
-            "cpu_model": _cpu_model(), "by_threads": by_threads,
+            "cpu_model": _cpu_model(), "host_cpus": os.cpu_count(), "by_threads": by_threads,
             "sample": "first %s images (n=%s threads) of the same %dx%dx%d K-clutter batch; per thread setting 1 warm-up "
-                      "step at B=2 + 3 timed full training steps (zero_grad+fwd+loss+bwd+Adam) of the CPU oracle"
+                      "step at B=2 + up to 3 timed full training steps (zero_grad+fwd+loss+bwd+Adam) of the CPU oracle"
                       % ("/".join(str(sample[k]) for k in by_threads), "/".join(by_threads), X_cpu.shape[1],
                          X_cpu.shape[2], X_cpu.shape[3])}
 

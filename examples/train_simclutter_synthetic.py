@@ -30,8 +30,11 @@ def main():
     torch.cuda.set_device(dev)
     os.makedirs(args.out, exist_ok=True)
 
-    X, lab = data.make_clutter_batch(args.frames, args.size, args.size, seed=1981, with_labels=True)
-    io.save_simclutter_pt(os.path.join(args.out, "synthetic_kdist.pt"), X, lab, [0] * args.frames)
+    if rank == 0:                 # one writer; the other ranks read the finished file
+        X, lab = data.make_clutter_batch(args.frames, args.size, args.size, seed=1981, with_labels=True)
+        io.save_simclutter_pt(os.path.join(args.out, "synthetic_kdist.pt"), X, lab, [0] * args.frames)
+    if world > 1:
+        torch.distributed.barrier()
     imgs, labels, snrs = io.load_simclutter_pt(os.path.join(args.out, "synthetic_kdist.pt"))
     tr, te = io.split_train_test(args.frames)
     imgs = metrics.tensor_normal_per_frame(imgs.to(dev))            # DS:110, on the GPU

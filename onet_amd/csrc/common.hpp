@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <stdio.h>
 #include "../../include/onet_hip.h"
 
@@ -21,6 +22,18 @@ int check_launch(const char* what);
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// "first launch on THIS device" flag for per-function attributes (hipFuncSetAttribute is per device): one process may
+// drive several GPUs, and two host threads may launch at once.
+struct PerDeviceOnce {
+    std::atomic<uint64_t> seen{0};
+    bool first() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        const uint64_t bit = 1ull << (d & 63);
+        return !(seen.fetch_or(bit, std::memory_order_relaxed) & bit);
+    }
+};
 
 // wave64 reductions via DPP/shuffles
 template <typename T>

@@ -225,10 +225,9 @@ static int launch_bf16(BfArgs a, hipStream_t st) {
     const int64_t blocks = (int64_t)a.B * a.tilesX * a.tilesY * a.coTiles;
     ONET_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv3x3_bf16: grid %lld out of range", (long long)blocks);
     auto kern = conv3x3_bf16_kernel<NT, WPS, TW>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, st, a);
     return check_launch("conv3x3_bf16_kernel");

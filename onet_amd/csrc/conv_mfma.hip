@@ -349,11 +349,10 @@ static int launch_fwd(ConvArgs a, hipStream_t st) {
     const int64_t blocks = (int64_t)a.B * a.tilesX * a.tilesY * a.coTiles;
     ONET_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv_fwd: grid %lld out of range", (long long)blocks);
     auto kern = conv_fwd_kernel<KS, MT, NT, WM, WN, TW, MODE>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   C::LDS_BYTES);
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, st, a);
     return check_launch("conv_fwd_kernel");
@@ -698,11 +697,10 @@ template <int KS, int PW, bool S2D = false>
 static void launch_wgrad(const WgArgs& a, int64_t blocks, hipStream_t st) {
     using C = WgCfg<KS, PW>;
     auto kern = conv_wgrad_kernel<KS, PW, S2D>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   C::LDS_BYTES);
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256 * KS), C::LDS_BYTES, st, a);
 }

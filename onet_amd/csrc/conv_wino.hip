@@ -556,11 +556,10 @@ static int launch_wino(WinoArgs a, hipStream_t st) {
     const int64_t blocks = (int64_t)a.B * a.tilesX * a.tilesY * a.coTiles;
     ONET_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv_wino: grid %lld out of range", (long long)blocks);
     auto kern = conv_wino_kernel<TW, CI_T, WM, DBG, PIPE>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   C::LDS_BYTES);
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::NTHR), C::LDS_BYTES, st, a);
     return check_launch("conv_wino_kernel");
@@ -879,11 +878,10 @@ template <int PW>
 static void launch_wino_wgrad(const WwArgs& a, int64_t blocks, hipStream_t st) {
     using C = WwCfg<PW>;
     auto kern = conv_wino_wgrad_kernel<PW>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   C::LDS_BYTES);
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), C::LDS_BYTES, st, a);
 }

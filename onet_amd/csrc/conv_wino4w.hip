@@ -341,18 +341,16 @@ int onet_conv3x3_winograd4_wgrad(const float* x, int64_t x_bs, const float* dz, 
         ONET_REQUIRE(((x_bs + (int64_t)Cin * H * W) * 4 < (1ll << 31)) && ((dz_bs + (int64_t)Cout * H * W) * 4 < (1ll << 31)),
                      "conv3x3_winograd4_wgrad: image pair exceeds the 2 GiB buffer-resource range");
         auto kern = conv_wino4_wgrad_kernel<1>;
-        static bool attr_set = false;
-        if (!attr_set) {
+        static PerDeviceOnce attr_once;
+        if (attr_once.first()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, W4C<1>::LDS_FLOATS * 4);
-            attr_set = true;
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), W4C<1>::LDS_FLOATS * 4, as_stream(stream), a);
     } else {
         auto kern = conv_wino4_wgrad_kernel<0>;
-        static bool attr_set = false;
-        if (!attr_set) {
+        static PerDeviceOnce attr_once;
+        if (attr_once.first()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, W4C<0>::LDS_FLOATS * 4);
-            attr_set = true;
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), W4C<0>::LDS_FLOATS * 4, as_stream(stream), a);
     }

@@ -329,7 +329,10 @@ class Onet(nn.Module):
             L, H = self.topu(XX, groups=2)
             Vt, Vd, S, sLt, sLd = Fn.HeadSoftmaxTwinFn.apply(L, H)
             Lt, Ld = Fn.TwinSplitFn.apply(L)
-            Lt._onet_twin = Ld._onet_twin = (L, sLt, sLd)     # compute_loss works on the channel sums of L
+            # compute_loss may work on the channel sums of L -- if it is handed exactly these halves, in this order and
+            # unmodified (role and tensor version are checked there)
+            tw = (L, sLt, sLd)
+            Lt._onet_twin, Ld._onet_twin = (tw, 0, Lt._version), (tw, 1, Ld._version)
             return Lt, Vt, Ld, Vd, S
         Lt, Ht = self.topu(X)
         Xd = Fn.ComplementClipFn.apply(X, float(self.bias))
@@ -359,8 +362,12 @@ class Onet(nn.Module):
         return Fn.Log1pExpFn.apply(x)
 
     def compute_loss(self, Lt, St, Ld, Sd):
-        twin = getattr(Lt, "_onet_twin", None)
-        if (twin is not None and twin is getattr(Ld, "_onet_twin", None) and twin[0].shape[0] == 2 * Lt.shape[0]
+        tag_t, tag_d = getattr(Lt, "_onet_twin", None), getattr(Ld, "_onet_twin", None)
+        twin = None
+        if (tag_t is not None and tag_d is not None and tag_t[0] is tag_d[0] and tag_t[1] == 0 and tag_d[1] == 1
+                and tag_t[2] == Lt._version and tag_d[2] == Ld._version):
+            twin = tag_t[0]       # Lt is the top half, Ld the down half of ONE forward, neither modified in place since
+        if (twin is not None and twin[0].shape[0] == 2 * Lt.shape[0]
                 and type(self).jensen_shannon_divergence is Onet.jensen_shannon_divergence
                 and "jensen_shannon_divergence" not in self.__dict__):
             # Lt / Ld are the halves of this module's own twin batch: the JSD terms only need sum_c L, which the head

@@ -216,9 +216,17 @@ def _wino_legal(Cin, Cout):
     return Cin >= 16 and Cin % 4 == 0 and Cout % 4 == 0
 
 
+def _in_buffer_range(Cin, Cout, H, W):
+    """The F(4x4) and bf16 kernels address ONE image (inside a concat buffer of up to twice its channels) through a
+    32-bit buffer resource: their entry points reject operands beyond 2 GiB, so the dispatch does not select them there."""
+    return (2 * max(Cin, Cout) + 16) * H * W * 4 < 2 ** 31 and (max(Cin, Cout) + 16) * 36 * min(Cin, Cout) * 4 < 2 ** 31
+
+
 def conv3x3_algo(B, Cin, Cout, H, W):
     """-> "winograd4" | "winograd" | "direct" for a conv with Cin inputs and Cout outputs on B maps of H x W."""
     algo = "winograd" if CONV_ALGO == "winograd2" else CONV_ALGO
+    if algo in ("bf16", "winograd4", "auto") and not _in_buffer_range(Cin, Cout, H, W):
+        algo = "winograd"
     if algo == "bf16":
         if Cin % 16 == 0 and Cout % 4 == 0 and W >= 16 and H >= 8:
             return "bf16"
@@ -562,7 +570,10 @@ def _gather_partials(part):
         return part, 1
     world = dist.get_world_size()
     out = torch.empty((world * part.shape[0],) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device)
-    dist.all_gather_into_tensor(out, part.contiguous())
+    if dist.get_backend() == "nccl":
+        dist.all_gather_into_tensor(out, part.contiguous())
+    else:       # gloo (CPU tests, the two-ranks-on-one-GPU rehearsal) has no flat all-gather: per-rank views of `out`
+        dist.all_gather(list(out.chunk(world, dim=0)), part.contiguous())
     return out, world
 
 

@@ -80,6 +80,10 @@ class FlatAdam:
         self.pg = process_group
         self.world_size = world_size
         self._buckets = None          # set by enable_overlap()
+        # host-side group for the per-step NaN verdict (see _check_nan_all_ranks); created collectively, here
+        self._flag_pg = None
+        if world_size > 1 and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            self._flag_pg = dist.new_group(backend="gloo")
 
     # ------------------------------------------------------------------ bucketed all-reduce overlapped with backward
     def enable_overlap(self, bucket_mb: float = 32.0):
@@ -163,14 +167,56 @@ class FlatAdam:
                 view.copy_(p.grad)
                 p.grad = view
 
+    def _check_nan_all_ranks(self):
+        """The loss's OV:234 verdict (ops.LAZY_NAN_CHECK), BEFORE the update is applied.  With several ranks the verdict
+        is shared first (one byte over a host-side gloo group: no GPU work, the host runs ahead of the device anyway), so
+        that every rank raises in the same step instead of one rank leaving its peers waiting in the all-reduce."""
+        try:
+            ops.check_deferred_nan()
+            bad = None
+        except AssertionError as e:
+            bad = e
+        if self._flag_pg is not None:
+            flag = torch.tensor([0 if bad is None else 1], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self._flag_pg)
+            if bad is None and int(flag.item()):
+                bad = AssertionError("jsd is NaN (on another rank)")
+        if bad is not None:
+            if self._buckets is not None:            # leave no asynchronous all-reduce behind
+                for bk in self._buckets:
+                    if bk["work"] is not None:
+                        bk["work"].wait()
+                    bk.update(pending=len(bk["params"]), work=None, launched=False)
+            raise bad
+
+    def _segments_with_grads(self):
+        """torch.optim.Adam skips parameters whose .grad is None (frozen or unused branches keep p, m and v untouched).
+        -> None when every parameter has a gradient (one launch over the whole buffer), else the [start, end) element
+        ranges of the maximal runs of parameters that do."""
+        have = [p.grad is not None for p in self.params]
+        if all(have):
+            return None
+        segs, start = [], None
+        for i, h in enumerate(have):
+            if h and start is None:
+                start = self.offsets[i]
+            if not h and start is not None:
+                segs.append((start, self.offsets[i]))
+                start = None
+        if start is not None:
+            segs.append((start, self.numel))
+        return segs
+
     def step(self):
-        ops.check_deferred_nan()          # the loss's OV:234 verdict (ops.LAZY_NAN_CHECK), BEFORE the update is applied
+        self._check_nan_all_ranks()
         g = self.param_groups[0]
+        segs = self._segments_with_grads() if self.direct_grads else None
         self._gather_stray_grads()
         self.all_reduce_grads()
         self.step_count += 1
-        ops.adam_step(self.flat, self.gflat, self.m, self.v, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
-                      g["weight_decay"], self.step_count, grad_scale=1.0 / self.world_size)
+        for a, b in ([(0, self.numel)] if segs is None else segs):
+            ops.adam_step(self.flat[a:b], self.gflat[a:b], self.m[a:b], self.v[a:b], g["lr"], g["betas"][0], g["betas"][1],
+                          g["eps"], g["weight_decay"], self.step_count, grad_scale=1.0 / self.world_size)
         invalidate_packed(self.model)
 
     def broadcast_params(self, src=0):
@@ -202,11 +248,15 @@ def init_distributed(backend: str | None = None):
     return rank, world, local
 
 
-def shard_batch(X, rank: int, world: int):
-    """rank r takes X[r*B/N:(r+1)*B/N] (equal shards; the mean of shard means is the global mean)."""
+def shard_batch(X, rank: int, world: int, drop_remainder: bool = False):
+    """rank r takes X[r*B/N:(r+1)*B/N] (equal shards; the mean of shard means is the global mean).
+    drop_remainder: the reference's DataLoaders keep the last, smaller batch of an epoch (no drop_last, DS:144); equal
+    shards need B % N == 0, so the loop drops the B % N trailing images of such a batch instead of aborting."""
     B = X.shape[0]
     if B % world:
-        raise ValueError(f"batch {B} not divisible by world size {world}")
+        if not drop_remainder or B < world:
+            raise ValueError(f"batch {B} not divisible by world size {world}")
+        B -= B % world
     per = B // world
     return X[rank * per:(rank + 1) * per]
 
@@ -225,24 +275,33 @@ def train_step(onet, opt, X):
 
 
 def save_checkpoint(onet, path, epoch, key="epoch"):
-    """{'net': state_dict, 'epoch': e} (TS:264-266) or {'net', 'save_epoch'} (TZ:145-149)."""
-    torch.save({"net": onet.state_dict(), key: epoch}, path)
+    """{'net': state_dict, 'epoch': e} (TS:264-266) or {'net', 'save_epoch'} (TZ:145-149): onet_amd.io."""
+    from . import io
+    io.save_checkpoint(onet, path, epoch, zy3=(key == "save_epoch"))
 
 
 def load_checkpoint(onet, path, map_location=None):
-    """resume = load_state_dict(torch.load(f)['net']) (TZ:77-82, TS:492-493)."""
-    ck = torch.load(path, map_location=map_location)
-    onet.load_state_dict(ck["net"])
-    invalidate_packed(onet)
-    return ck.get("epoch", ck.get("save_epoch"))
+    """resume = load_state_dict(torch.load(f)['net']) (TZ:77-82, TS:492-493): onet_amd.io."""
+    from . import io
+    return io.load_checkpoint(onet, path, map_location=map_location)
 
 
 def fit(onet, train_loader, device, epochs, schedule="sim", base_lr=None, eval_fn=None, eval_every=None,
         out_root=None, model_name="Onet", fused_adam=True, rank=0, world=1, log=print):
     """Epoch loop of TS:201-266 (schedule='sim') / TZ:99-153 (schedule='zy3').
     `train_loader` yields (X, ...) with X a CPU or GPU float32 [B,C,H,W] tensor in [0,1]."""
+    lazy_before = ops.LAZY_NAN_CHECK
     if fused_adam:
         ops.LAZY_NAN_CHECK = True     # OV:234's assertion is raised by FlatAdam.step(), before the update, without a mid-step sync
+    try:
+        return _fit(onet, train_loader, device, epochs, schedule, base_lr, eval_fn, eval_every, out_root, model_name,
+                    fused_adam, rank, world, log)
+    finally:
+        ops.LAZY_NAN_CHECK = lazy_before
+
+
+def _fit(onet, train_loader, device, epochs, schedule, base_lr, eval_fn, eval_every, out_root, model_name, fused_adam,
+         rank, world, log):
     if base_lr is None:
         base_lr = 5e-6 if schedule == "sim" else 1e-4
     if fused_adam:
@@ -262,7 +321,7 @@ def fit(onet, train_loader, device, epochs, schedule="sim", base_lr=None, eval_f
         losses, n_img, t0 = [], 0, time.time()
         for batch in train_loader:
             X = batch[0] if isinstance(batch, (tuple, list)) else batch
-            X = shard_batch(X, rank, world).to(device, non_blocking=True)
+            X = shard_batch(X, rank, world, drop_remainder=True).to(device, non_blocking=True)
             loss = train_step(onet, opt, X)
             losses.append(loss.item())            # device->host sync every step, as TS:219
             n_img += X.shape[0] * world
@@ -276,7 +335,7 @@ def fit(onet, train_loader, device, epochs, schedule="sim", base_lr=None, eval_f
         if rank == 0:
             log("%s===Epoch: %04d loss: %.5f, lr: %.10f, %.1f img/s" % (model_name, epoch, ep_loss, lr, rec["images_per_s"]))
         last = epoch == epochs - 1
-        if out_root and rank == 0 and (last or (schedule == "sim" and epoch == 300)):
+        if out_root and rank == 0 and (last or epoch == 300):          # TS:255 and TZ:141: the final epoch and epoch 300
             save_checkpoint(onet, os.path.join(out_root, "%s_epoch_%d.pytorch" % (model_name, epoch)), epoch,
                             key="epoch" if schedule == "sim" else "save_epoch")
     return history

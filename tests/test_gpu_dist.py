@@ -23,15 +23,23 @@ def _free_port():
     return p
 
 
-@pytest.mark.timeout(600)
-def test_bench_two_ranks_sharing_one_gpu_over_gloo():
-    if not torch.cuda.is_available():
-        pytest.skip("no GPU")
+def _torchrun(script, *args):
     env = dict(os.environ, ONET_DIST_BACKEND="gloo", ONET_FORCE_LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1", "--batch", "4", "--size", "64", "--no-cpu-baseline", "--bucket-mb", "8"]
-    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
+           "127.0.0.1", "--master-port", str(_free_port()), script] + list(args)
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("shape", ["c2_small", "c5_3x512x512"])
+def test_bench_two_ranks_sharing_one_gpu_over_gloo(shape):
+    """c2_small: the benchmark program at a small size; c5_3x512x512: BASELINE configs[4]'s tile shape (3-channel
+    512x512, 4 images per rank) through the same two-rank path."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    extra = ["--batch", "4", "--size", "64"] if shape == "c2_small" else ["--batch", "4", "--size", "512", "--chans", "3"]
+    out = _torchrun(os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                    "--bucket-mb", "8", *extra)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]                     # rank 0 only
@@ -39,3 +47,25 @@ def test_bench_two_ranks_sharing_one_gpu_over_gloo():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["scaling"] == "weak"
     assert "overlapped with backward" in d["config"]["grad_allreduce"]
     assert d["value"] > 0 and d["loss"] == d["loss"]               # finite
+    assert 0 < d["roofline"]["frac"] <= 1.0
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_syncbn_equals_one_rank():
+    """tests/dist_worker.py: replicas bit-identical after 2 steps; 2-rank SyncBN == 1 rank on the concatenated batch
+    (ops._gather_partials over a real process group)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    out = _torchrun(os.path.join(ROOT, "tests", "dist_worker.py"))
+    if out.returncode != 0:
+        print(out.stdout[-3000:])
+        print(out.stderr[-6000:])
+    assert out.returncode == 0
+    assert "DIST_OK" in out.stdout, out.stdout[-1500:]
+
+
+def test_bench_exits_nonzero_on_a_failure_inside_main():
+    """No in-process restart: any exception in a rank's main() (an RCCL error included) ends the process with code 1."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3"], cwd=ROOT, capture_output=True,
+                         text=True, timeout=300, env=dict(os.environ, WORLD_SIZE="1"))
+    assert out.returncode != 0
