@@ -63,10 +63,14 @@ int onet_convT2x2_fwd(const float* x, int64_t x_bs, const float* wq, const float
  *   dgrad: dx[b][ci][i][j] = sum_{c,di,dj} dy[b][c][pt+2i+di][pl+2j+dj] * W[ci][c][di][dj]   (wp_dgrad of
  *          onet_convT2x2_pack_weights; Ct % 8 == 0)
  *   wgrad: dw[ci][c][di][dj] = sum_{b,i,j} x[b][ci][i][j] * dy[b][c][pt+2i+di][pl+2j+dj]     (Ct % 64 == 0; workspace
- *          of onet_conv_wgrad_ws_bytes(B, Cin, 4*Ct, h, w, 1))
+ *          of onet_convT2x2_wgrad_ws_bytes(B, Cin, Ct, h, w))
+ * Maps whose pixel count is a multiple of 128 (32 for wgrad) with Cin % 128 == 0, Ct % 32 == 0 and no F.pad offsets -- every
+ * Up block of a 2^k-sized input -- run as DMA-fed 128 x 128 MFMA GEMMs (convt_gemm.hip), anything else on the 64-row
+ * direct kernels.
  *   dbias: db[c] = sum dy[:, c, window]  (scratch: B*C doubles) */
 int onet_convT2x2_dgrad(const float* dy, int64_t dy_bs, const float* wp_dgrad, float* dx, int64_t dx_bs, int B,
                         int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, void* stream);
+int64_t onet_convT2x2_wgrad_ws_bytes(int B, int Cin, int Ct, int h, int w);   /* workspace of onet_convT2x2_wgrad */
 int onet_convT2x2_wgrad(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, float* dw, void* ws,
                         int64_t ws_bytes, int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl,
                         void* stream);
@@ -298,6 +302,19 @@ int onet_argmax2(const float* S, int64_t* Y, int B, int HW, void* stream);
 /* ---- "next" row f-3: the evaluation step either side of the path (UT = utils_20231218.py) ------- */
 /* tensor_normal_per_frame (UT:673-689): y = (x - min) / (max - min + np.spacing(1)) per (b, c) plane */
 int onet_normalise_per_frame(const float* x, float* y, int planes, int HW, void* stream);
+
+/* ---- f-4: synthetic K-distributed sea clutter on the GPU (reference generators KD:469-526, RG:63-216; the recipe of
+ * onet_amd/data.py).  `frames` frames of 512 x 512 are synthesised (white Philox fields -> FFT colouring -> MNLT to a
+ * Gamma(5) texture x coloured complex speckle), `n_targets` rotated 2-D Gaussian extended targets per frame are added
+ * (targets [frames][n_targets][6] = centre x, centre y, sigma x, sigma y, cos theta, sin theta in frame pixels; peak
+ * amplitude sqrt(10^(snr_db[f] / 10) * mean clutter power)), and the centred H x W crop is written to out [frames][H][W]
+ * (label [frames][H][W] = 1 inside a target's e^-2 contour; may be NULL).  Per-frame normalisation to [0,1] is
+ * onet_normalise_per_frame (UT:673-689).  Deterministic in (seed, frame index): ranks generate disjoint frame ranges
+ * by passing different seeds. */
+int onet_clutter_frame_size(void);
+int64_t onet_clutter_ws_bytes(int frames);
+int onet_clutter_generate(float* out, float* label, const float* targets, const float* snr_db, int n_targets, int frames,
+                          int H, int W, uint64_t seed, float corr_len, void* ws, int64_t ws_bytes, void* stream);
 /* per-image 2-class confusion counts [B][4] = (TP, FP, FN, TN), positive class = 1: the inputs of
  * _acc/_miou/_target_iou/_detection_rate/_false_alarm_rate (UT:100-192) */
 int onet_confusion2(const int64_t* pred, const int64_t* target, int64_t* counts, int B, int HW,

@@ -11,11 +11,13 @@ import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), "include", "onet_hip.h")
-LIBPATH = os.path.join(HERE, "libonet_hip.so")
+# ONET_HIP_LIB: another build of the same library (onet_amd.build --variant ...) for same-box A/B runs
+LIBPATH = os.environ.get("ONET_HIP_LIB") or os.path.join(HERE, "libonet_hip.so")
 
 _CT = {
     "int": ctypes.c_int,
     "int64_t": ctypes.c_int64,
+    "uint64_t": ctypes.c_uint64,
     "float": ctypes.c_float,
     "double": ctypes.c_double,
 }

@@ -751,12 +751,27 @@ int onet_convT2x2_pack_weights_fused(const float* w, float* wq, int Cin, int Cou
     return check_launch("packT2x2_kernel");
 }
 
+// ONET_CONVT_GEMM=0 keeps the 64-row direct kernels for the ConvTranspose2d GEMMs (A/B runs)
+static bool convt_gemm_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("ONET_CONVT_GEMM"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on != 0;
+}
+
+int64_t onet_convT2x2_wgrad_ws_bytes(int B, int Cin, int Ct, int h, int w) {
+    return std::max<int64_t>(onet_conv_wgrad_ws_bytes(B, Cin, 4 * Ct, h, w, 1), convt_gemm_wgrad_ws_bytes(B, Cin, Ct, h, w));
+}
+
 int onet_convT2x2_fwd(const float* x, int64_t x_bs, const float* wq, const float* bias, float* y, int64_t y_bs,
                       int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, void* stream) {
     ONET_REQUIRE(x && wq && y, "convT2x2_fwd: null pointer");
     ONET_REQUIRE(B > 0 && Cin > 0 && Ct > 0 && h > 0 && w > 0, "convT2x2_fwd: bad shape");
     ONET_REQUIRE(pt >= 0 && pl >= 0 && pt + 2 * h <= Ho && pl + 2 * w <= Wo, "convT2x2_fwd: window outside plane");
     ONET_REQUIRE(x_bs >= (int64_t)Cin * h * w && y_bs >= (int64_t)Ct * Ho * Wo, "convT2x2_fwd: batch stride too small");
+    if (convt_gemm_enabled()) {
+        const int rc = convt_gemm_fwd(x, x_bs, wq, bias, y, y_bs, B, Cin, Ct, h, w, Ho, Wo, pt, pl, as_stream(stream));
+        if (rc <= 0) return rc;          // 1: shape outside the 128 x 128 GEMM's fast path
+    }
     ConvArgs a{x, x_bs, wq, y, y_bs, nullptr, B, Cin, 4 * Ct, h, w, 0, 0, 0, bias, Ho, Wo, pt, pl};
     return (w > 16) ? launch_fwd<1, 2, 2, 1, 4, 32, 1>(a, as_stream(stream))
                     : launch_fwd<1, 2, 2, 1, 4, 16, 1>(a, as_stream(stream));
@@ -769,6 +784,10 @@ int onet_convT2x2_dgrad(const float* dy, int64_t dy_bs, const float* wp_dgrad, f
     ONET_REQUIRE(Ct % CI_T == 0, "convT2x2_dgrad: Ct must be a multiple of %d (use onet_space_to_depth2 + onet_conv_fwd)", CI_T);
     ONET_REQUIRE(pt >= 0 && pl >= 0 && pt + 2 * h <= Ho && pl + 2 * w <= Wo, "convT2x2_dgrad: window outside plane");
     ONET_REQUIRE(dy_bs >= (int64_t)Ct * Ho * Wo && dx_bs >= (int64_t)Cin * h * w, "convT2x2_dgrad: batch stride too small");
+    if (convt_gemm_enabled()) {
+        const int rc = convt_gemm_dgrad(dy, dy_bs, wp_dgrad, dx, dx_bs, B, Cin, Ct, h, w, Ho, Wo, pt, pl, as_stream(stream));
+        if (rc <= 0) return rc;
+    }
     ConvArgs a{dy, dy_bs, wp_dgrad, dx, dx_bs, nullptr, B, 4 * Ct, Cin, h, w, 0, 0, 0, nullptr, Ho, Wo, pt, pl};
     return (w > 16) ? launch_fwd<1, 2, 2, 1, 4, 32, 2>(a, as_stream(stream))
                     : launch_fwd<1, 2, 2, 1, 4, 16, 2>(a, as_stream(stream));
@@ -854,6 +873,10 @@ int onet_convT2x2_wgrad(const float* x, int64_t x_bs, const float* dy, int64_t d
     ONET_REQUIRE(Ct % 64 == 0, "convT2x2_wgrad: Ct must be a multiple of 64 (use onet_space_to_depth2 + onet_conv_wgrad)");
     ONET_REQUIRE(pt >= 0 && pl >= 0 && pt + 2 * h <= Ho && pl + 2 * w <= Wo, "convT2x2_wgrad: window outside plane");
     ONET_REQUIRE(dy_bs >= (int64_t)Ct * Ho * Wo && x_bs >= (int64_t)Cin * h * w, "convT2x2_wgrad: batch stride too small");
+    if (convt_gemm_enabled()) {
+        const int rc = convt_gemm_wgrad(x, x_bs, dy, dy_bs, dw, ws, ws_bytes, B, Cin, Ct, h, w, Ho, Wo, pt, pl, as_stream(stream));
+        if (rc <= 0) return rc;
+    }
     const int Cout = 4 * Ct;
     WgArgs a{x, x_bs, dy, dy_bs, (float*)ws, B, Cin, Cout, h, w, cdiv(Cin, 64), cdiv(Cout, 64), 1, 1, 1, Ct, Ho, Wo, pt, pl};
     int pw;

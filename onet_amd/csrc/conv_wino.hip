@@ -21,6 +21,10 @@
 
 using namespace onet;
 
+#ifndef ONET_WW_ASYM
+#define ONET_WW_ASYM 0
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned OOB_OFF_W = 0x80000000u;
@@ -775,12 +779,18 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(WwArgs a) {
         using BC = std::integral_constant<int, BUF>;
         using BN = std::integral_constant<int, BUF ^ 1>;
         using P = std::integral_constant<int, 0>;
-        wstep(phc, BC{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 3>{}, BC{});
+        // SIMD partners are the waves (w, w + 4), i.e. ph = 0 / 1, and run this program in lockstep: staging bursts that
+        // hit both at once idle the matrix pipe.  ONET_WW_ASYM: the ph = 1 waves issue the next unit's loads and commit
+        // the staged unit two K-steps later than the ph = 0 waves (both before the unit barrier in step 6).
+        constexpr int SH = (ONET_WW_ASYM && decltype(phc)::value == 1) ? 2 : 0;
+        using MI = std::integral_constant<int, 3>;    // issue
+        using MC = std::integral_constant<int, 1>;    // commit
+        wstep(phc, BC{}, std::integral_constant<int, 1>{}, std::conditional_t<SH == 0, MI, P>{}, BC{});
         wstep(phc, BC{}, std::integral_constant<int, 2>{}, P{}, BC{});
-        wstep(phc, BC{}, std::integral_constant<int, 3>{}, P{}, BC{});
-        wstep(phc, BC{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{}, BC{});   // commit unit u+1
+        wstep(phc, BC{}, std::integral_constant<int, 3>{}, std::conditional_t<SH == 2, MI, P>{}, BC{});
+        wstep(phc, BC{}, std::integral_constant<int, 4>{}, std::conditional_t<SH == 0, MC, P>{}, BC{});   // commit unit u+1
         wstep(phc, BC{}, std::integral_constant<int, 5>{}, P{}, BC{});
-        wstep(phc, BC{}, std::integral_constant<int, 6>{}, P{}, BC{});
+        wstep(phc, BC{}, std::integral_constant<int, 6>{}, std::conditional_t<SH == 2, MC, P>{}, BC{});
         wstep(phc, BC{}, std::integral_constant<int, 7>{}, std::integral_constant<int, 2>{}, BC{});   // barrier
         wstep(phc, BN{}, std::integral_constant<int, 0>{}, P{}, BC{});
     };

@@ -25,6 +25,14 @@
 
 using namespace onet;
 
+// ONET_W4_ASYM: the two waves of a SIMD (position groups pg and pg + 2: RH = 0 / 1) run the same program in lockstep,
+// so whatever stalls one stalls both and the matrix pipe idles.  1: weight DMA pieces of a chunk issued by the RH = 0 waves in
+// step A and by the RH = 1 waves in step B (same-box +2 % on the kernel).  (Moving the RH = 1 waves' input dwords to step A as
+// well -- one VMEM burst per wave and step -- was slower: 1.109 vs 1.066 ms per launch.)
+#ifndef ONET_W4_ASYM
+#define ONET_W4_ASYM 1
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -396,10 +404,22 @@ static __device__ __forceinline__ void wino4_body(const Wino4Args& a, float* sme
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
                 __builtin_amdgcn_sched_barrier(0);
+#if ONET_W4_ASYM
+                // the two waves of a SIMD (position groups pg and pg + 2, i.e. RH = 0 / 1) run this program in lockstep: a
+                // weight piece issued by both at once stalls both and the matrix pipe idles; with the RH = 0 waves issuing
+                // ALL their pieces of the chunk in step A and the RH = 1 waves theirs in step B, one of the pair keeps
+                // issuing MFMAs while the other sits in the DMA issue
+                if constexpr (RH == 1) issue_w(cur_buf, 2 * q, 2 * q + 2);   // pieces (0,1), (2,3), (4)
+#else
                 issue_w(cur_buf, 2 + q, 3 + q);              // NWK == 5: pieces 2, 3, 4
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
+#if ONET_W4_ASYM
+            if constexpr (RH == 1) cw_bytes += w_step;
+#else
             cw_bytes += w_step;
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
         using SETN = std::integral_constant<int, CUR ^ 1>;   // MODE 1: inputs of chunk c+1; MODE 2: set (c+3)&1, freed in MODE 1
@@ -425,9 +445,16 @@ static __device__ __forceinline__ void wino4_body(const Wino4Args& a, float* sme
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
                 __builtin_amdgcn_sched_barrier(0);
+#if ONET_W4_ASYM
+                if constexpr (RH == 0) issue_w(cur_buf, 2 * q, 2 * q + 2);
+#else
                 if (q < 2) issue_w(cur_buf, q, q + 1);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
+#if ONET_W4_ASYM
+            if constexpr (RH == 0) cw_bytes += w_step;
+#endif
         } else {
             mfma_range(6, 9);
             if constexpr (MODE == 2) {

@@ -15,6 +15,10 @@
 
 using namespace onet;
 
+#ifndef ONET_W4W_ASYM
+#define ONET_W4W_ASYM 1
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4w __attribute__((ext_vector_type(4)));
 typedef float f32x2w __attribute__((ext_vector_type(2)));
@@ -230,10 +234,21 @@ static __device__ __forceinline__ void wino4w_body(const W4wArgs a, float* lds) 
     for (int u = u0; u < u1; ++u) {
         float* cur = lds + ((u - u0) & 1) * W4_BUF_FLOATS;
         float* nxt = lds + (((u - u0) & 1) ^ 1) * W4_BUF_FLOATS;
+#if ONET_W4W_ASYM
+        // the x rows are staged by waves 0..2, the dz rows by waves 4..7: SIMD partners (w, w + 4), i.e. position groups with
+        // RH = 0 / 1.  In lockstep both partners sit in their staging burst (8 b128 loads + 9 b128 LDS stores) at once
+        // and the matrix pipe idles: the RH = 1 waves stage one K-step earlier
+        ksteps(cur, 0, 1);
+        if constexpr (RH == 1) { commit(nxt); issue(u + 2); }
+        ksteps(cur, 1, 2);
+        if constexpr (RH == 0) { commit(nxt); issue(u + 2); }
+        ksteps(cur, 2, 4);
+#else
         ksteps(cur, 0, 2);
         commit(nxt);
         issue(u + 2);
         ksteps(cur, 2, 4);
+#endif
         __syncthreads();
     }
 

@@ -1,0 +1,401 @@
+// The three GEMMs of nn.ConvTranspose2d(Cin, Ct, kernel_size=2, stride=2) (OV:86) on the fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32), as DMA-fed 128 x 128 block tiles:
+//
+//   forward  y[b][c][2i+di][2j+dj] = bias[c] + sum_ci  x[b][ci][i][j] * W[ci][c][di][dj]        M = 4 Ct, N = pixels, K = Cin
+//   dgrad    dx[b][ci][i][j]       = sum_{c,di,dj} dy[b][c][2i+di][2j+dj] * W[ci][c][di][dj]     M = Cin,  N = pixels, K = 4 Ct
+//   wgrad    dW[ci][c][di][dj]     = sum_{b,i,j}   x[b][ci][i][j] * dy[b][c][2i+di][2j+dj]       M = Cin,  N = 4 Ct,   K = pixels
+//
+// These are plain dense contractions (arithmetic intensity 42-128 FLOP/B per layer, SURVEY 8d: MFMA-bound in fp32); with one
+// tap per staged operand the 64-row direct kernel of conv_mfma.hip spent 3x the staging instructions per MFMA of its 3x3
+// form and ran at 61-63 % of the fp32 MFMA peak.  Here:
+// * block = 256 threads = 4 waves (2 x 2), wave tile 64 x 64 = four 32x32 accumulators (64 VGPRs): ONE LDS fragment read
+//   per MFMA instead of two, two to four blocks per CU;
+// * both operands arrive by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KB per wave-instruction, no staging registers), double
+//   buffered, ONE barrier per K-chunk of 32 (forward, dgrad: 16) K-steps;
+// * the pixel shuffle (forward) / its inverse (dgrad, wgrad) costs nothing: the forward epilogue finds the four sub-pixels
+//   of a channel in four consecutive accumulator rows of one lane (float2 row stores straight into the concat buffer); the
+//   backward kernels DMA the dy rows as they lie in the concat gradient and pick the sub-pixel at fragment-read time;
+// * wgrad operands are pixel-major in memory (K contiguous): fragments are ds_read_b128 with lanes 0-31 / 32-63 taking the
+//   two halves of an 8-pixel group (K-step t contracts pixels 8g + t and 8g + 4 + t), bank conflicts removed by an XOR
+//   swizzle of the 16-byte chunks that the DMA applies on the SOURCE side (its LDS destination is lane-linear).
+// Shapes outside the fast path (maps whose pixel count is not a multiple of 128, odd F.pad offsets, channel tails) keep the
+// kernels of conv_mfma.hip: onet_convT2x2_{fwd,dgrad,wgrad} dispatch.
+#include <algorithm>
+#include <cstdlib>
+#include "common.hpp"
+
+using namespace onet;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4g __attribute__((ext_vector_type(4)));
+typedef int i32x4g __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ i32x4g g_rsrc(const void* base, int64_t bytes) {
+    const uint64_t p = reinterpret_cast<uint64_t>(base);
+    i32x4g r;
+    r.x = (int)(p & 0xffffffffu);
+    r.y = (int)((p >> 32) & 0xffffu);
+    r.z = bytes > 0x7fffffffll ? 0x7fffffff : (int)bytes;
+    r.w = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ unsigned g_lds(const float* p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)p;
+}
+// LDS-DMA of 64 x 16 bytes: lane l's 16 bytes at (rsrc base + voff) land at LDS byte address lds_base + 16 l.
+// Inline asm: the compiler must not see a load (it would order every later ds_read behind a vmcnt(0)).
+__device__ __forceinline__ void g_dma16(i32x4g rsrc, unsigned lds_base, unsigned voff) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(lds_base)
+                 : "memory");
+}
+
+struct GArgs {
+    const float* a;       // forward: wq [Cin][4Ct];  dgrad: wd [4Ct][Cin] (row q*Ct + c);  wgrad: x
+    const float* b;       // forward: x;              dgrad: dy window;                       wgrad: dy window
+    float* out;           // forward: y window;       dgrad: dx;                              wgrad: slab [splitK][Cin][4Ct]
+    const float* bias;
+    int64_t a_bs, b_bs, out_bs;
+    int B, Cin, Ct, h, w, Wo, HoWo;   // y / dy plane: Ho x Wo with Ho = 2h, Wo = 2w (fast path: no F.pad offsets)
+    int mTiles, nTiles, splitK, chunksPerSplit;
+};
+
+__device__ __forceinline__ int xcd_order(int n) {
+    const int q = n >> 3, r = n & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+
+constexpr int KC = 16;                 // forward / dgrad: K per chunk (8 K-steps)
+constexpr int TILE_F = KC * 128;       // floats of one operand tile
+
+// ------------------------------------------------------------------------------------------------ forward and dgrad
+// MODE 0: forward (A rows = wq[k][m], B rows = x[b][k][pixels]);  MODE 1: dgrad (A rows = wd[q*Ct + c][ci], B rows =
+// dy[b][c][2y + di][...] as they lie: 256 floats per (c, di) for the tile's 128 pixels)
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void convt_gemm_kernel(GArgs g) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * TILE_F];      // [buf][A | B]
+    int bid = xcd_order(gridDim.x);
+    const int mt = bid % g.mTiles;                 // m tile fastest: the blocks of one pixel tile share its B rows in L2
+    const int nt = bid / g.mTiles;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR)
+    const int wr = wid >> 1, wc = wid & 1, l31 = lane & 31, kh = lane >> 5;
+    const int hw = g.h * g.w;
+    const int M = MODE == 0 ? 4 * g.Ct : g.Cin, K = MODE == 0 ? g.Cin : 4 * g.Ct;
+    const int m0 = mt * 128;
+    const int n0 = nt * 128;                       // global pixel index (b * hw + p); hw % 128 == 0: one image per tile
+    const int b = n0 / hw, p0 = n0 % hw;
+
+    const i32x4g ra = g_rsrc(g.a, (int64_t)K * M * 4);
+    const i32x4g rb = MODE == 0 ? g_rsrc(g.b + (int64_t)b * g.b_bs, (int64_t)g.Cin * hw * 4)
+                                : g_rsrc(g.b + (int64_t)b * g.b_bs, (int64_t)g.Ct * g.HoWo * 4);
+    // DMA roles: wave w issues A pieces 2w, 2w+1 and B pieces 2w, 2w+1 of every chunk (piece = 1 KB)
+    unsigned a_off[2], b_off[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = 2 * wid + j;
+        const int kk = 2 * p + (lane >> 5);                                   // A row of the chunk held by this lane
+        if (MODE == 0) {
+            a_off[j] = (unsigned)(((int64_t)kk * M + m0 + (lane & 31) * 4) * 4);
+            b_off[j] = (unsigned)(((int64_t)kk * hw + p0 + (lane & 31) * 4) * 4);
+        } else {
+            const int cl = kk >> 2, q = kk & 3;                               // chunk row kk = cl * 4 + q  <-  wd row q * Ct + c
+            a_off[j] = (unsigned)((((int64_t)q * g.Ct + cl) * M + m0 + (lane & 31) * 4) * 4);
+            // B piece p = row (cl, di) = (p >> 1, p & 1): 256 floats = the tile's 128 pixels x dj, 2 pixels per lane
+            const int px = p0 + 2 * lane, y = px / g.w, x = px % g.w;
+            b_off[j] = (unsigned)((((int64_t)(p >> 1)) * g.HoWo + (int64_t)(2 * y + (p & 1)) * g.Wo + 2 * x) * 4);
+        }
+    }
+    const unsigned a_step = MODE == 0 ? (unsigned)((int64_t)KC * M * 4) : (unsigned)(4 * M * 4);       // dgrad: 4 channels on
+    const unsigned b_step = MODE == 0 ? (unsigned)((int64_t)KC * hw * 4) : (unsigned)((int64_t)4 * g.HoWo * 4);
+    // piece q of the wave's four per chunk: 0, 1 = its two A pieces, 2, 3 = its two B pieces
+    auto issue1 = [&](int chunk, int buf, int q) __attribute__((always_inline)) {
+        const unsigned la = g_lds(lds) + (unsigned)(buf * 2 * TILE_F * 4), lb = la + TILE_F * 4;
+        const int j = q & 1;
+        if (q < 2) g_dma16(ra, la + (2 * wid + j) * 1024, a_off[j] + chunk * a_step);
+        else g_dma16(rb, lb + (2 * wid + j) * 1024, b_off[j] + chunk * b_step);
+    };
+    auto issue = [&](int chunk, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) issue1(chunk, buf, q);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+    const int nch = K / KC;
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+        const int buf = c & 1;
+        const bool more = c + 1 < nch;
+        const float* A = lds + buf * 2 * TILE_F + wr * 64 + l31;
+        const float* Bt = lds + buf * 2 * TILE_F + TILE_F;
+#pragma unroll
+        for (int s = 0; s < KC / 2; ++s) {
+            // the next chunk's four DMA pieces go out one per two K-steps, not as a burst in front of the MFMAs (a piece
+            // holds the issuing wave for 60-180 cycles)
+            if ((s & 1) == 0 && more) issue1(c + 1, buf ^ 1, s >> 1);
+            float av[2], bv[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) av[t] = A[(2 * s + kh) * 128 + t * 32];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (MODE == 0) bv[u] = Bt[(2 * s + kh) * 128 + wc * 64 + u * 32 + l31];
+                else bv[u] = Bt[((s >> 1) * 2 + (s & 1)) * 256 + 2 * (wc * 64 + u * 32 + l31) + kh];   // row (cl, di), dj = kh
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[u], acc[t][u], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // chunk c+1 landed (issued a whole chunk of MFMAs ago)
+        __syncthreads();                                        // ... and every wave is done with this buffer
+    }
+
+    // ---- epilogue
+    if (MODE == 0) {
+        float* yb = g.out + (int64_t)b * g.out_bs;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int p = p0 + wc * 64 + u * 32 + l31, y = p / g.w, x = p % g.w;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int c = (m0 + wr * 64 + t * 32 + 8 * gq + 4 * kh) >> 2;      // rows 4 gq .. 4 gq + 3 = sub-pixels of c
+                    const float bs = g.bias ? g.bias[c] : 0.f;
+                    float* o = yb + (int64_t)c * g.HoWo + (int64_t)(2 * y) * g.Wo + 2 * x;
+                    *reinterpret_cast<float2*>(o) = make_float2(acc[t][u][4 * gq] + bs, acc[t][u][4 * gq + 1] + bs);
+                    *reinterpret_cast<float2*>(o + g.Wo) = make_float2(acc[t][u][4 * gq + 2] + bs, acc[t][u][4 * gq + 3] + bs);
+                }
+            }
+    } else {
+        float* xb = g.out + (int64_t)b * g.out_bs;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int p = p0 + wc * 64 + u * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ci = m0 + wr * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    xb[(int64_t)ci * hw + p] = acc[t][u][r];
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ wgrad
+constexpr int KP = 32;                          // pixels per chunk (16 K-steps)
+constexpr int WA_F = 128 * KP;                  // A tile: 128 ci rows x 32 px
+constexpr int WB_F = 64 * 2 * KP;               // B tile: 64 (c, di) rows x (32 px x dj)
+
+__global__ __launch_bounds__(256, 2) void convt_wgrad_gemm_kernel(GArgs g) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * (WA_F + WB_F)];
+    int bid = xcd_order(gridDim.x);
+    const int tiles = g.mTiles * g.nTiles;
+    const int ks = bid / tiles, tile = bid % tiles;
+    const int mt = tile % g.mTiles, nt = tile / g.mTiles;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR)
+    const int wr = wid >> 1, wc = wid & 1, l31 = lane & 31, kh = lane >> 5;
+    const int hw = g.h * g.w;
+    const int ci0 = mt * 128, c0 = nt * 32;                      // N tile = 32 channels x 4 sub-pixels
+    const int ch0 = ks * g.chunksPerSplit;
+    const int nchunks_all = (int)(((int64_t)g.B * hw) / KP);
+    const int ch1 = min(ch0 + g.chunksPerSplit, nchunks_all);
+
+    // DMA roles per chunk: 16 A pieces (8 rows x 128 B each) + 16 B pieces (4 rows x 256 B each), 8 per wave
+    // A: lane -> row = 8 p + (l >> 3), physical 16-B chunk l & 7 holds source chunk (l & 7) ^ ((row >> 1) & 7)
+    // B: lane -> row = 4 p + (l >> 4), physical chunk l & 15 holds source chunk (l & 15) ^ (row & 7)
+    auto issue = [&](int chunk, int buf, int j0, int j1) __attribute__((always_inline)) {
+        const int64_t pix = (int64_t)chunk * KP;
+        const int b = (int)(pix / hw), p0 = (int)(pix % hw);
+        const i32x4g rx = g_rsrc(g.a + (int64_t)b * g.a_bs, (int64_t)g.Cin * hw * 4);
+        const i32x4g rd = g_rsrc(g.b + (int64_t)b * g.b_bs, (int64_t)g.Ct * g.HoWo * 4);
+        const unsigned la = g_lds(lds) + (unsigned)(buf * (WA_F + WB_F) * 4), lb = la + WA_F * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < j0 || j >= j1) continue;
+            const int p = 4 * wid + j;
+            {
+                const int row = 8 * p + (lane >> 3), src = (lane & 7) ^ ((row >> 1) & 7);
+                g_dma16(rx, la + p * 1024, (unsigned)((((int64_t)(ci0 + row)) * hw + p0 + src * 4) * 4));
+            }
+            {
+                const int row = 4 * p + (lane >> 4), src = (lane & 15) ^ (row & 7);      // row = cl * 2 + di
+                const int px = p0 + 2 * src, y = px / g.w, x = px % g.w;                 // 16 B = 2 pixels x dj
+                g_dma16(rd, lb + p * 1024,
+                        (unsigned)((((int64_t)(c0 + (row >> 1))) * g.HoWo + (int64_t)(2 * y + (row & 1)) * g.Wo + 2 * x) * 4));
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+    // fragment addresses (floats).  A: row = wr*64 + t*32 + l31, chunk 2 gg + kh.  B: lane j = l31 -> m = wc*64 + u*32 + j =
+    // (cl, di, dj): row = m >> 1, dj = m & 1 = l31 & 1; chunks 4 gg + 2 kh, + 1
+    int a_row[2], b_row[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) a_row[t] = wr * 64 + t * 32 + l31;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) b_row[u] = (wc * 64 + u * 32 + l31) >> 1;
+    const bool dj = (l31 & 1) != 0;
+
+    if (ch0 < ch1) {
+        issue(ch0, 0, 0, 4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    for (int c = ch0; c < ch1; ++c) {
+        const int buf = (c - ch0) & 1;
+        const bool more = c + 1 < ch1;
+        const float* A = lds + buf * (WA_F + WB_F);
+        const float* Bt = A + WA_F;
+#pragma unroll
+        for (int gg = 0; gg < KP / 8; ++gg) {
+            if (more) issue(c + 1, buf ^ 1, gg, gg + 1);        // one A and one B piece of the next chunk per 16 MFMAs
+            f32x4g a4[2], b4[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                a4[t] = *reinterpret_cast<const f32x4g*>(A + a_row[t] * KP + (((2 * gg + kh) ^ ((a_row[t] >> 1) & 7)) << 2));
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    b4[u][e] = *reinterpret_cast<const f32x4g*>(Bt + b_row[u] * (2 * KP) + (((4 * gg + 2 * kh + e) ^ (b_row[u] & 7)) << 2));
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                float bv[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const f32x4g v = b4[u][tt >> 1];
+                    bv[u] = dj ? v[(tt & 1) * 2 + 1] : v[(tt & 1) * 2];
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t][tt], bv[u], acc[t][u], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    float* slab = g.out + (int64_t)ks * g.Cin * 4 * g.Ct;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int m = 4 * c0 + wc * 64 + u * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci0 + wr * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                slab[(int64_t)ci * 4 * g.Ct + m] = acc[t][u][r];
+            }
+        }
+}
+
+// dw[i] (+)= sum_k slab[k][i], fixed order: bit-reproducible
+__global__ __launch_bounds__(256) void convt_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splitK,
+                                                                 int64_t n4, int accumulate) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 s = reinterpret_cast<const float4*>(slab)[i];
+    for (int k = 1; k < splitK; ++k) {
+        const float4 v = reinterpret_cast<const float4*>(slab)[(int64_t)k * n4 + i];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (accumulate) {
+        const float4 o = reinterpret_cast<float4*>(dw)[i];
+        s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+    }
+    reinterpret_cast<float4*>(dw)[i] = s;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+void wgrad_plan(int B, int Cin, int Ct, int h, int w, int& splitK, int& per) {
+    const int64_t chunks = (int64_t)B * h * w / KP;
+    const int64_t tiles = (int64_t)(Cin / 128) * (Ct / 32);
+    int64_t k = std::max<int64_t>(1, (512 + tiles - 1) / tiles);                  // ~2 blocks per CU
+    k = std::min<int64_t>(k, std::max<int64_t>(1, chunks / 16));                  // at least 16 chunks (256 K-steps) per block
+    k = std::min<int64_t>(k, std::max<int64_t>(1, (256ll << 20) / ((int64_t)Cin * 4 * Ct * 4)));
+    per = (int)((chunks + k - 1) / k);
+    splitK = (int)((chunks + per - 1) / per);
+}
+
+}  // namespace
+
+namespace onet {
+
+// Fast-path predicates + launches; return ONET_NOT_TAKEN (1) when the shape is not taken (caller falls back to conv_mfma.hip)
+int convt_gemm_fwd(const float* x, int64_t x_bs, const float* wq, const float* bias, float* y, int64_t y_bs, int B, int Cin,
+                   int Ct, int h, int w, int Ho, int Wo, int pt, int pl, hipStream_t st) {
+    const int64_t hw = (int64_t)h * w;
+    if (pt || pl || Ho != 2 * h || Wo != 2 * w || (Cin % KC) || (Ct % 32) || (hw % 128) || (w & 1) || !aligned16(x) || !aligned16(wq) ||
+        (x_bs & 3) || (reinterpret_cast<uintptr_t>(y) & 7) || (y_bs & 1) || (int64_t)Cin * hw * 4 >= (1ll << 31) ||
+        (int64_t)Cin * 4 * Ct * 4 >= (1ll << 31))
+        return 1;
+    GArgs g{wq, x, y, bias, 0, x_bs, y_bs, B, Cin, Ct, h, w, Wo, Ho * Wo, (4 * Ct) / 128, (int)(B * hw / 128), 1, 0};
+    const int64_t blocks = (int64_t)g.mTiles * g.nTiles;
+    if (blocks <= 0 || blocks >= (1ll << 31)) return 1;
+    hipLaunchKernelGGL(convt_gemm_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, g);
+    return check_launch("convt_gemm_kernel<0>");
+}
+
+int convt_gemm_dgrad(const float* dy, int64_t dy_bs, const float* wd, float* dx, int64_t dx_bs, int B, int Cin, int Ct, int h,
+                     int w, int Ho, int Wo, int pt, int pl, hipStream_t st) {
+    const int64_t hw = (int64_t)h * w;
+    if (pt || pl || Ho != 2 * h || Wo != 2 * w || (Cin % 128) || (Ct % 4) || (hw % 128) || (w & 1) || !aligned16(dy) || !aligned16(wd) ||
+        (dy_bs & 3) || (int64_t)Ct * Ho * Wo * 4 >= (1ll << 31) || (int64_t)Cin * 4 * Ct * 4 >= (1ll << 31))
+        return 1;
+    GArgs g{wd, dy, dx, nullptr, 0, dy_bs, dx_bs, B, Cin, Ct, h, w, Wo, Ho * Wo, Cin / 128, (int)(B * hw / 128), 1, 0};
+    const int64_t blocks = (int64_t)g.mTiles * g.nTiles;
+    if (blocks <= 0 || blocks >= (1ll << 31)) return 1;
+    hipLaunchKernelGGL(convt_gemm_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, g);
+    return check_launch("convt_gemm_kernel<1>");
+}
+
+int64_t convt_gemm_wgrad_ws_bytes(int B, int Cin, int Ct, int h, int w) {
+    if ((Cin % 128) || (Ct % 32) || (((int64_t)h * w) % KP)) return 0;
+    int k, per;
+    wgrad_plan(B, Cin, Ct, h, w, k, per);
+    return (int64_t)k * Cin * 4 * Ct * 4;
+}
+
+int convt_gemm_wgrad(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, float* dw, void* ws, int64_t ws_bytes, int B,
+                     int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, hipStream_t st) {
+    const int64_t hw = (int64_t)h * w;
+    if (pt || pl || Ho != 2 * h || Wo != 2 * w || (Cin % 128) || (Ct % 32) || (hw % KP) || (w & 1) || !aligned16(x) || !aligned16(dy) ||
+        !aligned16(dw) || (x_bs & 3) || (dy_bs & 3) || (int64_t)Cin * hw * 4 >= (1ll << 31) || (int64_t)Ct * Ho * Wo * 4 >= (1ll << 31))
+        return 1;
+    GArgs g{x, dy, (float*)ws, nullptr, x_bs, dy_bs, 0, B, Cin, Ct, h, w, Wo, Ho * Wo, Cin / 128, Ct / 32, 1, 0};
+    wgrad_plan(B, Cin, Ct, h, w, g.splitK, g.chunksPerSplit);
+    const int64_t n = (int64_t)Cin * 4 * Ct;
+    if (ws_bytes < (int64_t)g.splitK * n * 4) return 1;
+    const int64_t blocks = (int64_t)g.splitK * g.mTiles * g.nTiles;
+    hipLaunchKernelGGL(convt_wgrad_gemm_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g);
+    int rc = check_launch("convt_wgrad_gemm_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(convt_wgrad_reduce_kernel, dim3((unsigned)cdiv(n / 4, 256)), dim3(256), 0, st, (const float*)ws, dw, g.splitK,
+                       n / 4, 0);
+    return check_launch("convt_wgrad_reduce_kernel");
+}
+
+}  // namespace onet

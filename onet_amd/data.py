@@ -94,3 +94,44 @@ def make_clutter_batch(B, H=256, W=256, seed=1981, snr_choices=(0, 1, 2), channe
     if with_labels:
         return X, np.stack(labels)
     return X
+
+
+# ----------------------------------------------------------------------------- on the GPU (csrc/clutter.hip)
+def target_params(rng, frames, n, n_targets=20):
+    """Host-side draw of the extended targets' geometry, as `add_targets` draws it (RG:198-209 scaled to an n-pixel
+    frame): -> float32 [frames, n_targets, 6] = (cx, cy, sigma_x, sigma_y, cos theta, sin theta)."""
+    t = np.empty((frames, n_targets, 6), dtype=np.float32)
+    for f in range(frames):
+        for k in range(n_targets):
+            cx, cy = rng.normal(n / 2, 30 * n / 400 * 3), rng.normal(n / 2, 24 * n / 400 * 3)
+            sx, sy = np.abs(rng.normal(10, 2)) / 2.5 + 1.0, np.abs(rng.normal(18, 2)) / 2.5 + 1.0
+            th = rng.uniform(0, np.pi)
+            t[f, k] = (cx, cy, sx, sy, np.cos(th), np.sin(th))
+    return t
+
+
+def make_clutter_batch_gpu(B, H=256, W=256, seed=1981, snr_choices=(0, 1, 2), device="cuda", with_labels=False,
+                           n_targets=20, corr_len=10.0, normalise=True):
+    """The recipe of `make_clutter_batch` synthesised ON the GPU (white Philox fields, FFT colouring, MNLT, speckle,
+    targets, crop, per-frame normalisation): -> float32 [B, 1, H, W] device tensor in [0,1] (and labels [B,H,W]).
+    Frames depend on (seed, frame index) only, so each data-parallel rank can make its own shard with its own seed;
+    the random streams differ from the NumPy generator's (statistics agree: tests/test_gpu_ops.py)."""
+    import torch
+    from . import _lib
+    from .ops import _p, _stream
+    dev = torch.device(device)
+    n = int(_lib.load().onet_clutter_frame_size())
+    if H > n or W > n:
+        raise ValueError(f"make_clutter_batch_gpu: H, W <= {n}")
+    rng = np.random.Generator(np.random.PCG64(seed))
+    tg = torch.from_numpy(target_params(rng, B, n, n_targets)).to(dev)
+    snr = torch.from_numpy(rng.choice(np.asarray(snr_choices, dtype=np.float32), size=B).astype(np.float32)).to(dev)
+    ws = torch.empty(int(_lib.load().onet_clutter_ws_bytes(B)) // 4 + 4, dtype=torch.float32, device=dev)
+    out = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+    lab = torch.empty((B, H, W), dtype=torch.float32, device=dev) if with_labels else None
+    _lib.call("onet_clutter_generate", _p(out), _p(lab), _p(tg), _p(snr), n_targets, B, H, W, int(seed) & (2 ** 64 - 1),
+              float(corr_len), _p(ws), ws.numel() * 4, _stream())
+    if normalise:
+        from .metrics import tensor_normal_per_frame
+        out = tensor_normal_per_frame(out)
+    return (out, lab) if with_labels else out

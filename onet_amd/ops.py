@@ -787,7 +787,7 @@ def convT2x2_wgrad(x, dy, dw_shape, pt, pl, want_dbias, out=None, db_out=None):
     B, Cin, h, w = x.shape
     Ct, Ho, Wo = dy.shape[1], dy.shape[2], dy.shape[3]
     dw = torch.empty(dw_shape, dtype=F32, device=x.device) if out is None else out
-    need = _lib.load().onet_conv_wgrad_ws_bytes(B, Cin, 4 * Ct, h, w, 1)
+    need = _lib.load().onet_convT2x2_wgrad_ws_bytes(B, Cin, Ct, h, w)
     ws = workspace(need, x.device)
     e0 = _prof_begin()
     _lib.call("onet_convT2x2_wgrad", _p(x), xbs, _p(dy), dybs, _p(dw), _p(ws), ws.numel() * 4, B, Cin, Ct, h, w, Ho, Wo,

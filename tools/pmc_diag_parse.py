@@ -21,7 +21,7 @@ for key in sorted(per):
         print(f"   {c:32s} {d[c]:16.1f}{extra}")
     if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "GRBM_GUI_ACTIVE" in d:
         print(f"   MFMA busy = {d['SQ_VALU_MFMA_BUSY_CYCLES'] / (d['GRBM_GUI_ACTIVE'] / 8 * 1024):.3f}")
-    if "SQ_INSTS_MFMA" in d:
+    if d.get("SQ_INSTS_MFMA", 0) > 0:
         m = d["SQ_INSTS_MFMA"]
         print("   per MFMA: VALU %.2f  LDS %.2f  VMEM_RD %.3f  SALU %.2f  SMEM %.3f" % (
             (d.get("SQ_INSTS_VALU", 0) - m) / m, d.get("SQ_INSTS_LDS", 0) / m, d.get("SQ_INSTS_VMEM_RD", 0) / m,
