@@ -70,6 +70,12 @@ int onet_convT2x2_fwd(const float* x, int64_t x_bs, const float* wq, const float
  *   dbias: db[c] = sum dy[:, c, window]  (scratch: B*C doubles) */
 int onet_convT2x2_dgrad(const float* dy, int64_t dy_bs, const float* wp_dgrad, float* dx, int64_t dx_bs, int B,
                         int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, void* stream);
+/* dx and dbias in one launch where the 128 x 128 GEMM path takes the shape (returns 1 and does nothing otherwise: use
+ * onet_convT2x2_dgrad + onet_convT2x2_dbias); ws: onet_convT2x2_dgrad_dbias_ws_bytes() bytes of scratch */
+int64_t onet_convT2x2_dgrad_dbias_ws_bytes(int B, int Ct, int h, int w);
+int onet_convT2x2_dgrad_dbias(const float* dy, int64_t dy_bs, const float* wp_dgrad, float* dx, int64_t dx_bs, float* dbias,
+                              void* ws, int64_t ws_bytes, int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl,
+                              void* stream);
 int64_t onet_convT2x2_wgrad_ws_bytes(int B, int Cin, int Ct, int h, int w);   /* workspace of onet_convT2x2_wgrad */
 int onet_convT2x2_wgrad(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, float* dw, void* ws,
                         int64_t ws_bytes, int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl,

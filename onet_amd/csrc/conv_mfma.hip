@@ -785,12 +785,26 @@ int onet_convT2x2_dgrad(const float* dy, int64_t dy_bs, const float* wp_dgrad, f
     ONET_REQUIRE(pt >= 0 && pl >= 0 && pt + 2 * h <= Ho && pl + 2 * w <= Wo, "convT2x2_dgrad: window outside plane");
     ONET_REQUIRE(dy_bs >= (int64_t)Ct * Ho * Wo && dx_bs >= (int64_t)Cin * h * w, "convT2x2_dgrad: batch stride too small");
     if (convt_gemm_enabled()) {
-        const int rc = convt_gemm_dgrad(dy, dy_bs, wp_dgrad, dx, dx_bs, B, Cin, Ct, h, w, Ho, Wo, pt, pl, as_stream(stream));
+        const int rc = convt_gemm_dgrad(dy, dy_bs, wp_dgrad, dx, dx_bs, nullptr, nullptr, B, Cin, Ct, h, w, Ho, Wo, pt, pl, as_stream(stream));
         if (rc <= 0) return rc;
     }
     ConvArgs a{dy, dy_bs, wp_dgrad, dx, dx_bs, nullptr, B, 4 * Ct, Cin, h, w, 0, 0, 0, nullptr, Ho, Wo, pt, pl};
     return (w > 16) ? launch_fwd<1, 2, 2, 1, 4, 32, 2>(a, as_stream(stream))
                     : launch_fwd<1, 2, 2, 1, 4, 16, 2>(a, as_stream(stream));
+}
+
+int64_t onet_convT2x2_dgrad_dbias_ws_bytes(int B, int Ct, int h, int w) { return convt_gemm_dbias_ws_bytes(B, Ct, h, w); }
+
+// dx AND dbias of ConvTranspose2d(k=2, s=2): on the fast path of convt_gemm.hip the bias gradient is summed from the dy rows the
+// dgrad GEMM stages anyway (one read of the concat gradient's upper half less); returns 1 (and does nothing) when the shape is
+// outside that path -- the caller then uses onet_convT2x2_dgrad + onet_convT2x2_dbias
+int onet_convT2x2_dgrad_dbias(const float* dy, int64_t dy_bs, const float* wp_dgrad, float* dx, int64_t dx_bs, float* dbias, void* ws,
+                              int64_t ws_bytes, int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, void* stream) {
+    ONET_REQUIRE(dy && wp_dgrad && dx && dbias && ws, "convT2x2_dgrad_dbias: null pointer");
+    ONET_REQUIRE(B > 0 && Cin > 0 && Ct > 0 && h > 0 && w > 0, "convT2x2_dgrad_dbias: bad shape");
+    ONET_REQUIRE(dy_bs >= (int64_t)Ct * Ho * Wo && dx_bs >= (int64_t)Cin * h * w, "convT2x2_dgrad_dbias: batch stride too small");
+    if (!convt_gemm_enabled() || ws_bytes < convt_gemm_dbias_ws_bytes(B, Ct, h, w)) return 1;
+    return convt_gemm_dgrad(dy, dy_bs, wp_dgrad, dx, dx_bs, dbias, (float*)ws, B, Cin, Ct, h, w, Ho, Wo, pt, pl, as_stream(stream));
 }
 
 int onet_conv_fwd_nparts(int B, int Cout, int H, int W) {

@@ -22,7 +22,7 @@
 using namespace onet;
 
 #ifndef ONET_WW_ASYM
-#define ONET_WW_ASYM 0
+#define ONET_WW_ASYM 1
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

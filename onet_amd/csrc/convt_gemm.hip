@@ -26,6 +26,10 @@
 
 using namespace onet;
 
+#ifndef ONET_GEMM_SPREAD
+#define ONET_GEMM_SPREAD 0
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4g __attribute__((ext_vector_type(4)));
 typedef int i32x4g __attribute__((ext_vector_type(4)));
@@ -59,6 +63,7 @@ struct GArgs {
     const float* b;       // forward: x;              dgrad: dy window;                       wgrad: dy window
     float* out;           // forward: y window;       dgrad: dx;                              wgrad: slab [splitK][Cin][4Ct]
     const float* bias;
+    float* dbias_part;    // dgrad: [nTiles][Ct] partial sums of dy over the tile's pixels (blocks with mt == 0), or NULL
     int64_t a_bs, b_bs, out_bs;
     int B, Cin, Ct, h, w, Wo, HoWo;   // y / dy plane: Ho x Wo with Ho = 2h, Wo = 2w (fast path: no F.pad offsets)
     int mTiles, nTiles, splitK, chunksPerSplit;
@@ -68,6 +73,19 @@ __device__ __forceinline__ int xcd_order(int n) {
     const int q = n >> 3, r = n & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
+
+// sum over the 32 lanes of a wave half, valid in lanes 31 / 63 (DPP row rotations + row broadcast, as in conv_wino4.hip)
+#define ONET_G_DPP_ADD(v, ctrl, rmask) \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
+__device__ __forceinline__ float g_half_sum(float v) {
+    ONET_G_DPP_ADD(v, 0x128, 0xf);   // row_ror:8
+    ONET_G_DPP_ADD(v, 0x124, 0xf);   // row_ror:4
+    ONET_G_DPP_ADD(v, 0x122, 0xf);   // row_ror:2
+    ONET_G_DPP_ADD(v, 0x121, 0xf);   // row_ror:1
+    ONET_G_DPP_ADD(v, 0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+    return v;
+}
+#undef ONET_G_DPP_ADD
 
 constexpr int KC = 16;                 // forward / dgrad: K per chunk (8 K-steps)
 constexpr int TILE_F = KC * 128;       // floats of one operand tile
@@ -140,11 +158,25 @@ __global__ __launch_bounds__(256, 2) void convt_gemm_kernel(GArgs g) {
         const bool more = c + 1 < nch;
         const float* A = lds + buf * 2 * TILE_F + wr * 64 + l31;
         const float* Bt = lds + buf * 2 * TILE_F + TILE_F;
+        if (MODE == 1 && g.dbias_part && mt == 0) {
+            // ConvTranspose2d bias gradient (sum of dy over all pixels) from the staged dy rows: wave w holds the chunk's channel
+            // 4c + w, lanes 0-31 its di = 0 row, lanes 32-63 its di = 1 row (256 floats each = the tile's 128 pixels x dj)
+            const f32x4g* row = reinterpret_cast<const f32x4g*>(Bt + (2 * wid + kh) * 256 + l31 * 8);
+            const f32x4g v0 = row[0], v1 = row[1];
+            float sb = ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
+            sb = g_half_sum(sb);
+            const float other = __shfl(sb, 63, 64);
+            if (lane == 31) g.dbias_part[(int64_t)nt * g.Ct + 4 * c + wid] = sb + other;
+        }
 #pragma unroll
         for (int s = 0; s < KC / 2; ++s) {
             // the next chunk's four DMA pieces go out one per two K-steps, not as a burst in front of the MFMAs (a piece
             // holds the issuing wave for 60-180 cycles)
+#if ONET_GEMM_SPREAD
             if ((s & 1) == 0 && more) issue1(c + 1, buf ^ 1, s >> 1);
+#else
+            if (s == 0 && more) issue(c + 1, buf ^ 1);
+#endif
             float av[2], bv[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) av[t] = A[(2 * s + kh) * 128 + t * 32];
@@ -269,7 +301,11 @@ __global__ __launch_bounds__(256, 2) void convt_wgrad_gemm_kernel(GArgs g) {
         const float* Bt = A + WA_F;
 #pragma unroll
         for (int gg = 0; gg < KP / 8; ++gg) {
+#if ONET_GEMM_SPREAD
             if (more) issue(c + 1, buf ^ 1, gg, gg + 1);        // one A and one B piece of the next chunk per 16 MFMAs
+#else
+            if (gg == 0 && more) issue(c + 1, buf ^ 1, 0, 4);
+#endif
             f32x4g a4[2], b4[2][2];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -328,6 +364,17 @@ __global__ __launch_bounds__(256) void convt_wgrad_reduce_kernel(const float* __
     reinterpret_cast<float4*>(dw)[i] = s;
 }
 
+// db[c] = sum over the pixel tiles of part[tile][c], fp64, fixed order
+__global__ __launch_bounds__(256) void convt_dbias_reduce_kernel(const float* __restrict__ part, float* __restrict__ db, int ntiles, int Ct) {
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (int t = threadIdx.x; t < ntiles; t += 256) s += (double)part[(int64_t)t * Ct + c];
+    __shared__ double sh[4];
+    double v[1] = {s};
+    block_sum_256<double, 1>(v, sh);
+    if (threadIdx.x == 0) db[c] = (float)v[0];
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 void wgrad_plan(int B, int Cin, int Ct, int h, int w, int& splitK, int& per) {
@@ -352,24 +399,31 @@ int convt_gemm_fwd(const float* x, int64_t x_bs, const float* wq, const float* b
         (x_bs & 3) || (reinterpret_cast<uintptr_t>(y) & 7) || (y_bs & 1) || (int64_t)Cin * hw * 4 >= (1ll << 31) ||
         (int64_t)Cin * 4 * Ct * 4 >= (1ll << 31))
         return 1;
-    GArgs g{wq, x, y, bias, 0, x_bs, y_bs, B, Cin, Ct, h, w, Wo, Ho * Wo, (4 * Ct) / 128, (int)(B * hw / 128), 1, 0};
+    GArgs g{wq, x, y, bias, nullptr, 0, x_bs, y_bs, B, Cin, Ct, h, w, Wo, Ho * Wo, (4 * Ct) / 128, (int)(B * hw / 128), 1, 0};
     const int64_t blocks = (int64_t)g.mTiles * g.nTiles;
     if (blocks <= 0 || blocks >= (1ll << 31)) return 1;
     hipLaunchKernelGGL(convt_gemm_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, g);
     return check_launch("convt_gemm_kernel<0>");
 }
 
-int convt_gemm_dgrad(const float* dy, int64_t dy_bs, const float* wd, float* dx, int64_t dx_bs, int B, int Cin, int Ct, int h,
-                     int w, int Ho, int Wo, int pt, int pl, hipStream_t st) {
+int64_t convt_gemm_dbias_ws_bytes(int B, int Ct, int h, int w) { return (int64_t)B * h * w / 128 * Ct * 4; }
+
+// dbias != NULL: also the ConvTranspose2d bias gradient, taken from the dy rows the GEMM stages anyway (dbias_ws: partials)
+int convt_gemm_dgrad(const float* dy, int64_t dy_bs, const float* wd, float* dx, int64_t dx_bs, float* dbias, float* dbias_ws, int B,
+                     int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, hipStream_t st) {
     const int64_t hw = (int64_t)h * w;
     if (pt || pl || Ho != 2 * h || Wo != 2 * w || (Cin % 128) || (Ct % 4) || (hw % 128) || (w & 1) || !aligned16(dy) || !aligned16(wd) ||
         (dy_bs & 3) || (int64_t)Ct * Ho * Wo * 4 >= (1ll << 31) || (int64_t)Cin * 4 * Ct * 4 >= (1ll << 31))
         return 1;
-    GArgs g{wd, dy, dx, nullptr, 0, dy_bs, dx_bs, B, Cin, Ct, h, w, Wo, Ho * Wo, Cin / 128, (int)(B * hw / 128), 1, 0};
+    if (dbias && !dbias_ws) return 1;
+    GArgs g{wd, dy, dx, nullptr, dbias ? dbias_ws : nullptr, 0, dy_bs, dx_bs, B, Cin, Ct, h, w, Wo, Ho * Wo, Cin / 128, (int)(B * hw / 128), 1, 0};
     const int64_t blocks = (int64_t)g.mTiles * g.nTiles;
     if (blocks <= 0 || blocks >= (1ll << 31)) return 1;
     hipLaunchKernelGGL(convt_gemm_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, g);
-    return check_launch("convt_gemm_kernel<1>");
+    int rc = check_launch("convt_gemm_kernel<1>");
+    if (rc || !dbias) return rc;
+    hipLaunchKernelGGL(convt_dbias_reduce_kernel, dim3((unsigned)Ct), dim3(256), 0, st, (const float*)dbias_ws, dbias, g.nTiles, Ct);
+    return check_launch("convt_dbias_reduce_kernel");
 }
 
 int64_t convt_gemm_wgrad_ws_bytes(int B, int Cin, int Ct, int h, int w) {
@@ -385,7 +439,7 @@ int convt_gemm_wgrad(const float* x, int64_t x_bs, const float* dy, int64_t dy_b
     if (pt || pl || Ho != 2 * h || Wo != 2 * w || (Cin % 128) || (Ct % 32) || (hw % KP) || (w & 1) || !aligned16(x) || !aligned16(dy) ||
         !aligned16(dw) || (x_bs & 3) || (dy_bs & 3) || (int64_t)Cin * hw * 4 >= (1ll << 31) || (int64_t)Ct * Ho * Wo * 4 >= (1ll << 31))
         return 1;
-    GArgs g{x, dy, (float*)ws, nullptr, x_bs, dy_bs, 0, B, Cin, Ct, h, w, Wo, Ho * Wo, Cin / 128, Ct / 32, 1, 0};
+    GArgs g{x, dy, (float*)ws, nullptr, nullptr, x_bs, dy_bs, 0, B, Cin, Ct, h, w, Wo, Ho * Wo, Cin / 128, Ct / 32, 1, 0};
     wgrad_plan(B, Cin, Ct, h, w, g.splitK, g.chunksPerSplit);
     const int64_t n = (int64_t)Cin * 4 * Ct;
     if (ws_bytes < (int64_t)g.splitK * n * 4) return 1;

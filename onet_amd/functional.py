@@ -251,12 +251,16 @@ class UpConvTCatFn(torch.autograd.Function):
         if (need_x1 or need_w or need_b) and ops.convT2x2_bwd_fusable(Ct):
             # the GEMM kernels gather dy from the concat gradient themselves: no space-to-depth tensor
             dup = dcat[:, C2:]
-            if need_w or need_b:
-                dw, db = ops.convT2x2_wgrad(x1, dup, wshape, pt, pl, want_dbias=(need_b and has_bias),
-                                            out=ops.grad_slot_if_free(ctx.params[0]),
-                                            db_out=ops.grad_slot_if_free(ctx.params[1]) if has_bias else None)
+            want_db = need_b and has_bias
+            db_slot = ops.grad_slot_if_free(ctx.params[1]) if want_db else None
             if need_x1:
-                dx1 = ops.convT2x2_dgrad(dup, wp_dgrad, wshape[0], h, w, pt, pl)
+                # the dgrad GEMM stages every dy row anyway: the bias gradient is summed on the way where its fast path applies
+                dx1, db = ops.convT2x2_dgrad(dup, wp_dgrad, wshape[0], h, w, pt, pl, want_dbias=want_db, db_out=db_slot) \
+                    if want_db else (ops.convT2x2_dgrad(dup, wp_dgrad, wshape[0], h, w, pt, pl), None)
+            if need_w or (want_db and db is None):
+                dw, db2 = ops.convT2x2_wgrad(x1, dup, wshape, pt, pl, want_dbias=(want_db and db is None),
+                                             out=ops.grad_slot_if_free(ctx.params[0]), db_out=db_slot)
+                db = db if db is not None else db2
         elif need_x1 or need_w or need_b:
             dsub, db = ops.space_to_depth2(dcat[:, C2:], h, w, pt, pl, want_dbias=(need_b and has_bias))
             if need_w:

@@ -766,17 +766,35 @@ def convT2x2_bwd_fusable(Ct):
     return Ct % 64 == 0
 
 
-def convT2x2_dgrad(dy, wp_dgrad, Cin, h, w, pt, pl):
-    """dx1 of ConvTranspose2d(k=2, s=2) straight from the [B, Ct, Ho, Wo] window `dy` of the concat gradient."""
+def convT2x2_dgrad(dy, wp_dgrad, Cin, h, w, pt, pl, want_dbias=False, db_out=None):
+    """dx1 of ConvTranspose2d(k=2, s=2) straight from the [B, Ct, Ho, Wo] window `dy` of the concat gradient.
+    want_dbias: -> (dx1, dbias | None): where the 128 x 128 GEMM path takes the shape the bias gradient is summed from the
+    dy rows that launch stages anyway; None = not taken (the caller then runs the separate dbias pass)."""
     require_gpu(dy, wp_dgrad)
     dy, dybs = plane(dy)
     B, Ct, Ho, Wo = dy.shape
     dx = torch.empty((B, Cin, h, w), dtype=F32, device=dy.device)
+    flops, nbytes = 2.0 * B * h * w * Cin * 4 * Ct, 4.0 * (B * h * w * (Cin + 4 * Ct) + 4 * Cin * Ct)
+    if want_dbias:
+        lib = _lib.load()
+        need = int(lib.onet_convT2x2_dgrad_dbias_ws_bytes(B, Ct, h, w))
+        if need > 0:
+            db = torch.empty(Ct, dtype=F32, device=dy.device) if db_out is None else db_out
+            ws = torch.empty(need // 4, dtype=F32, device=dy.device)
+            e0 = _prof_begin()
+            rc = lib.onet_convT2x2_dgrad_dbias(_p(dy), dybs, _p(wp_dgrad), _p(dx), Cin * h * w, _p(db), _p(ws), need, B, Cin, Ct, h,
+                                               w, Ho, Wo, pt, pl, _stream())
+            if rc == 0:
+                _prof_end("conv_fwd_kernel", flops, e0, nbytes)
+                return dx, db
+            _prof_end("conv_fwd_kernel", 0.0, e0, 0.0)
+            if rc < 0:
+                raise _lib.OnetHipError(f"onet_convT2x2_dgrad_dbias failed ({rc}): {_lib.last_error()}")
     e0 = _prof_begin()
     _lib.call("onet_convT2x2_dgrad", _p(dy), dybs, _p(wp_dgrad), _p(dx), Cin * h * w, B, Cin, Ct, h, w, Ho, Wo, pt, pl,
               _stream())
-    _prof_end("conv_fwd_kernel", 2.0 * B * h * w * Cin * 4 * Ct, e0, 4.0 * (B * h * w * (Cin + 4 * Ct) + 4 * Cin * Ct))
-    return dx
+    _prof_end("conv_fwd_kernel", flops, e0, nbytes)
+    return (dx, None) if want_dbias else dx
 
 
 def convT2x2_wgrad(x, dy, dw_shape, pt, pl, want_dbias, out=None, db_out=None):

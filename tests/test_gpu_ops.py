@@ -581,9 +581,8 @@ def test_conv_kernels_random_shapes_fuzz(dev):
 def test_gpu_clutter_generator_statistics_vs_numpy_recipe(dev):
     """csrc/clutter.hip against the NumPy statement of the same recipe (onet_amd/data.py, itself the reference's
     generators KD:469-526 / RG:63-216): different random streams, so the comparison is statistical --
-    (1) the line FFT against numpy.fft on the white field's spectrum (through the colouring identity: with a flat filter
-        the output must equal the input), (2) K-distribution moments of the raw amplitude: E[a^2] = E[|s|^2] E[tau],
-        normalised intensity moment E[a^4] / E[a^2]^2 = 2 (nu + 1) / nu for nu = 5 within sampling error,
+    (1) frames are bit-reproducible from (seed, frame) and differ across seeds, (2) moments of the raw amplitude: overall
+        power and the normalised intensity moment E[a^4] / E[a^2]^2 equal the NumPy recipe's within sampling error,
     (3) texture correlation: the ACF of the amplitude at lag 5 is clearly positive and decays by lag 60,
     (4) labels cover the same area fraction as the NumPy generator's, frames are in [0,1] and reproducible."""
     from onet_amd import data
@@ -598,16 +597,18 @@ def test_gpu_clutter_generator_statistics_vs_numpy_recipe(dev):
     ref = np.stack([data.k_clutter_frame(np.random.Generator(np.random.PCG64(100 + i)), 512)[128:384, 128:384] for i in range(3)])
     m2, m4 = (raw ** 2).mean(), (raw ** 4).mean()
     r2, r4 = (ref ** 2).mean(), (ref ** 4).mean()
-    assert abs(m4 / m2 ** 2 - 2.4) < 0.25 and abs(r4 / r2 ** 2 - 2.4) < 0.3, (m4 / m2 ** 2, r4 / r2 ** 2)   # 2 (nu + 1) / nu
+    # normalised intensity moment E[a^4] / E[a^2]^2: 2 (nu + 1) / nu = 2.4 for white speckle, ~3.5 with this recipe's coloured
+    # speckle (|f|^-0.6 from f = 0.1: most of its power sits in the lowest frequencies); the two implementations must agree
+    assert abs(m4 / m2 ** 2 - r4 / r2 ** 2) < 0.1 * r4 / r2 ** 2 and 2.4 < m4 / m2 ** 2 < 5.0, (m4 / m2 ** 2, r4 / r2 ** 2)
     assert 0.5 < m2 / r2 < 2.0, (m2, r2)                        # same overall scale as the NumPy recipe
 
     def acf(a, lag):
         a = a - a.mean(axis=(1, 2), keepdims=True)
         return float((a[:, :, :-lag] * a[:, :, lag:]).mean() / (a * a).mean())
 
-    for lag, lo, hi in ((5, 0.05, 0.9), (60, -0.1, 0.1)):
+    for lag, lo, hi in ((5, 0.02, 0.9), (60, -0.1, 0.1)):        # measured: 0.050 (GPU) / 0.049 (NumPy) at lag 5
         g, r = acf(raw ** 2, lag), acf(ref ** 2, lag)
-        assert lo < g < hi and lo < r < hi and abs(g - r) < 0.12, (lag, g, r)
+        assert lo < g < hi and lo < r < hi and abs(g - r) < 0.03, (lag, g, r)
     _, lab_ref = data.make_clutter_batch(3, H, W, seed=5, with_labels=True)
     fg, fr = float(lab.mean()), float(lab_ref.mean())
     assert 0.3 * fr < fg < 3.0 * fr and set(lab.unique().tolist()) <= {0.0, 1.0}, (fg, fr)
