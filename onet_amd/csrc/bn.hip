@@ -6,6 +6,10 @@
 
 using namespace onet;
 
+#ifndef ONET_BN_BATCH
+#define ONET_BN_BATCH 1
+#endif
+
 // Partial over one image plane chunk: part[p][c][3] = (n_k, mean_k, M2_k), M2_k = sum (z - mean_k)^2.
 // ONE pass in fp64 over sums shifted by a pivot (the chunk's first element, within a few standard deviations of
 // its mean): s1 = sum (z - pivot), s2 = sum (z - pivot)^2, mean = pivot + s1/n, M2 = s2 - s1^2/n.  With the shift
@@ -27,7 +31,21 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     // fp64 accumulation like ATen's CPU batch norm (acc_type<float> = double); free in an HBM-bound pass
     double v[2] = {0.0, 0.0};
     if (vec) {
-        for (int i = beg + threadIdx.x * 4; i < end; i += 1024) {
+        int i = beg + threadIdx.x * 4;
+#if ONET_BN_BATCH
+        for (; i + 3072 < end; i += 4096) {       // four 16-byte loads in flight per thread; same summation order as below
+            float4 q[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = *reinterpret_cast<const float4*>(src + i + 1024 * k);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double d0 = q[k].x - pivot, d1 = q[k].y - pivot, d2 = q[k].z - pivot, d3 = q[k].w - pivot;
+                v[0] += (d0 + d1) + (d2 + d3);
+                v[1] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+        }
+#endif
+        for (; i < end; i += 1024) {
             const float4 q = *reinterpret_cast<const float4*>(src + i);
             const double d0 = q.x - pivot, d1 = q.y - pivot, d2 = q.z - pivot, d3 = q.w - pivot;
             v[0] += (d0 + d1) + (d2 + d3);
@@ -167,6 +185,23 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restr
     float* dst = a + (int64_t)b * a_bs + (int64_t)c * HW;
     const int beg = ch * 4096, end = min(beg + 4096, HW);
     if (((HW & 3) == 0) && ((z_bs & 3) == 0) && ((a_bs & 3) == 0)) {
+#if ONET_BN_BATCH
+        if (end - beg == 4096) {          // full chunk: all four 16-byte loads of the thread in flight before the first use
+            const int i0 = beg + threadIdx.x * 4;
+            float4 q[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = *reinterpret_cast<const float4*>(src + i0 + 1024 * k);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                q[k].x = fmaxf(fmaf(q[k].x - mean, sc, sh), 0.f);
+                q[k].y = fmaxf(fmaf(q[k].y - mean, sc, sh), 0.f);
+                q[k].z = fmaxf(fmaf(q[k].z - mean, sc, sh), 0.f);
+                q[k].w = fmaxf(fmaf(q[k].w - mean, sc, sh), 0.f);
+                *reinterpret_cast<float4*>(dst + i0 + 1024 * k) = q[k];
+            }
+            return;
+        }
+#endif
         for (int i = beg + threadIdx.x * 4; i < end; i += 1024) {
             float4 q = *reinterpret_cast<const float4*>(src + i);
             q.x = fmaxf(fmaf(q.x - mean, sc, sh), 0.f);
@@ -199,7 +234,28 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const float* __
     const int beg = ch * chunk_len, end = min(beg + chunk_len, HW);
     double v[2] = {0.0, 0.0};
     if (((HW & 3) == 0) && ((z_bs & 3) == 0) && ((da_bs & 3) == 0) && ((chunk_len & 3) == 0)) {
-        for (int i = beg + threadIdx.x * 4; i < end; i += 1024) {
+        int i = beg + threadIdx.x * 4;
+#if ONET_BN_BATCH
+        for (; i + 3072 < end; i += 4096) {       // eight 16-byte loads in flight per thread; same summation order as below
+            float4 q[4], g[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                q[k] = *reinterpret_cast<const float4*>(zs + i + 1024 * k);
+                g[k] = *reinterpret_cast<const float4*>(ds + i + 1024 * k);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float zz[4] = {q[k].x, q[k].y, q[k].z, q[k].w}, gg[4] = {g[k].x, g[k].y, g[k].z, g[k].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const double dy = fmaf(zz[e] - mean, sc, sh) > 0.f ? (double)gg[e] : 0.0;
+                    v[0] += dy;
+                    v[1] += dy * (((double)zz[e] - meand) * invd);
+                }
+            }
+        }
+#endif
+        for (; i < end; i += 1024) {
             const float4 q = *reinterpret_cast<const float4*>(zs + i);
             const float4 g = *reinterpret_cast<const float4*>(ds + i);
             const float zz[4] = {q.x, q.y, q.z, q.w}, gg[4] = {g.x, g.y, g.z, g.w};
@@ -303,6 +359,29 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
     float* out = dz + (int64_t)b * dz_bs + (int64_t)c * HW;
     const int beg = ch * 4096, end = min(beg + 4096, HW);
     if (((HW & 3) == 0) && ((z_bs & 3) == 0) && ((da_bs & 3) == 0) && ((dz_bs & 3) == 0)) {
+#if ONET_BN_BATCH
+        if (end - beg == 4096) {          // full chunk: the thread's eight 16-byte loads in flight before the first use
+            const int i0 = beg + threadIdx.x * 4;
+            float4 q[4], g[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                q[k] = *reinterpret_cast<const float4*>(zs + i0 + 1024 * k);
+                g[k] = *reinterpret_cast<const float4*>(ds + i0 + 1024 * k);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float zz[4] = {q[k].x, q[k].y, q[k].z, q[k].w}, gg[4] = {g[k].x, g[k].y, g[k].z, g[k].w};
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const double dy = fmaf(zz[e] - mean, sc, sh) > 0.f ? (double)gg[e] : 0.0;
+                    o[e] = (float)(scd * (dy - c1 - (((double)zz[e] - meand) * invd) * c2));
+                }
+                *reinterpret_cast<float4*>(out + i0 + 1024 * k) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+            return;
+        }
+#endif
         for (int i = beg + threadIdx.x * 4; i < end; i += 1024) {
             const float4 q = *reinterpret_cast<const float4*>(zs + i);
             const float4 g = *reinterpret_cast<const float4*>(ds + i);

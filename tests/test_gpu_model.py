@@ -144,8 +144,8 @@ def test_bf16_conv_path_vs_reference_golden(dev, monkeypatch):
     """BASELINE config 3: the bf16-operand MFMA conv path (`ONET_CONV_ALGO=bf16`: forward and input gradient of every
     3x3 layer with >= 16 input channels on maps >= 32 px wide; weight gradients and everything else fp32) on the
     256x256 golden of the reference.  bf16 operands carry 2^-9 relative rounding each, so this is NOT the 1e-3 fp32
-    bar: the loss must agree to 2e-2, the head logits to 5e-2 of their scale, every parameter gradient's norm to 15 %,
-    and the label map on all but 3 % of the pixels."""
+    bar: the loss must agree to 1e-3 (measured 3e-5), the head logits to 5e-2 of their scale, every parameter gradient's norm
+    to 8 % (measured 6 %), and the label map on all but 2.5 % of the pixels (measured 1.6 %)."""
     from onet_amd import ops
     monkeypatch.setattr(ops, "CONV_ALGO", "bf16")
     used = []
@@ -158,17 +158,17 @@ def test_bf16_conv_path_vs_reference_golden(dev, monkeypatch):
     (Lt, Vt, Ld, Vd, S), loss = _step(m, X)
     assert len(used) >= 2 * 12, f"bf16 kernel launches: {len(used)}"
     rel = abs(loss.item() - g["losses"][0]) / abs(g["losses"][0])
-    assert rel <= 2e-2, ("loss", loss.item(), g["losses"][0], rel)
+    assert rel <= 1e-3, ("loss", loss.item(), g["losses"][0], rel)          # measured 3e-5
     for name, t in (("Vt", Vt), ("Vd", Vd)):
         ref = g[name]
         e = float(np.max(np.abs(_sub(t, H) - ref))) / float(np.max(np.abs(ref)))
         assert e <= 5e-2, (name, e)
     lab = _sub(m.predict_label(S), H).astype(np.uint8)
-    assert float(np.mean(lab != g["label"])) <= 3e-2      # measured 1.6 %: pixels whose two class scores are within bf16 noise
+    assert float(np.mean(lab != g["label"])) <= 2.5e-2    # measured 1.6 %: pixels whose two class scores are within bf16 noise
     named = dict(m.named_parameters())
     n64 = g["grad_norms64"]
     worst = max(abs(float(named[str(n)].grad.double().norm()) - n64[i]) / n64[i] for i, n in enumerate(g["grad_names"]))
-    assert worst <= 0.15, ("gradient norm", worst)
+    assert worst <= 0.08, ("gradient norm", worst)                          # measured 6 %
     print(f"bf16 path: loss rel {rel:.2e}, worst gradient-norm error {worst:.2e}")
 
 
