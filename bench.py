@@ -26,13 +26,16 @@ HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6
 PMC_JSON = os.path.join(ROOT, "profiles", "pmc_bench_latest.json")   # written by tools/pmc_parse.py
 
 
-def pmc_traffic(kernel_prefix):
+def pmc_traffic(kernel_prefix, bf16=False, batch=32):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of THIS
     command (FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950
     correction).  PMC counters cannot be collected inside the timed run, so the number comes from
-    profiles/; None if the file is absent."""
+    profiles/ (the default fp32 B=32 run: pmc_bench_latest.json; other configurations:
+    pmc_bench_<f32|bf16>_b<batch>_latest.json); None if the file is absent."""
+    path = PMC_JSON if (not bf16 and batch == 32) else os.path.join(
+        ROOT, "profiles", "pmc_bench_%s_b%d_latest.json" % ("bf16" if bf16 else "f32", batch))
     try:
-        d = json.load(open(PMC_JSON))
+        d = json.load(open(path))
     except Exception:
         return None
     tot_b = tot_n = 0
@@ -225,7 +228,7 @@ def main():
                           "hbm_frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
         dom = max(kern, key=lambda k: kern[k]["ms_total"])
         d = kern[dom]
-        traffic = pmc_traffic(dom)
+        traffic = pmc_traffic(dom, bf16, args.batch)
         if dom in BF16:
             # in bf16 the 64- and 128-channel layers sit below the ridge (312 FLOP/B): the launch is priced
             # against HBM; `achieved` = compulsory bytes (operands once + result once, fp32 storage) / time

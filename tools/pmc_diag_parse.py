@@ -3,7 +3,7 @@ import collections, csv, glob, sys
 vals = collections.defaultdict(list)
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        name = r["Kernel_Name"].split("(")[0].replace("void ", "")[:48]
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")[:48]
         key = (name, r.get("Grid_Size", "?"))
         vals[(key, r["Counter_Name"])].append(float(r["Counter_Value"]))
 per = collections.defaultdict(dict)

@@ -18,7 +18,7 @@ vals = collections.defaultdict(list)
 for d in args:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            name = r["Kernel_Name"].split("(")[0].replace("void ", "")[:64]
+            name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")[:64]
             vals[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
 res = collections.defaultdict(dict)
 for (k, c), v in sorted(vals.items()):

@@ -63,15 +63,17 @@ out = f"profiles/{tag}_pmc_{sfx}.json"
 subprocess.run([sys.executable, "tools/pmc_parse.py", f"{src}/fetch", f"{src}/write", "--json", out], check=True, stdout=subprocess.DEVNULL)
 if not extra:
     shutil.copy(out, "profiles/pmc_bench_latest.json")       # the default (fp32) run is what bench.py's `traffic` quotes
+else:                                                        # other configurations: looked up by conv path and batch
+    shutil.copy(out, f"profiles/pmc_bench_{'bf16' if 'bf16' in extra else 'f32'}_b{batch}_latest.json")
 # ---- SQ counters
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for fcsv in glob.glob(f"{src}/sq/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(fcsv)):
-        vals[r["Kernel_Name"].split("(")[0].replace("void ", "")[:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        vals[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")[:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 dur = collections.defaultdict(list)
 for fcsv in glob.glob(f"{src}/sq/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(fcsv)):
-        dur[r["Kernel_Name"].split("(")[0].replace("void ", "")[:60]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        dur[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")[:60]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 with open(f"profiles/{tag}_sq_counters_{sfx}.md", "w") as f:
     f.write(f"# rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace -- python bench.py --steps 3 --warmup 3 {extra} ({desc})\n\n")
     f.write("effective clock = GRBM_GUI_ACTIVE / 8 / duration (MI355X_MICROARCH.md, DVFS give-back); MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs).\n"
