@@ -140,6 +140,25 @@ int onet_conv3x3_bf16_fwd(const float* x, int64_t x_bs, const void* wq, float* z
 int64_t onet_conv3x3_wgrad_bf16_ws_bytes(int B, int Cin, int Cout, int H, int W);
 int onet_conv3x3_wgrad_bf16(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs, float* dw, void* ws,
                             int64_t ws_bytes, int B, int Cin, int Cout, int H, int W, int accumulate, void* stream);
+/* bf16 STORAGE of the conv operands (BASELINE config 3): the same kernels reading bf16 NCHW tensors (strides in elements)
+ * that the producing kernels wrote next to their fp32 outputs (onet_bn_relu_apply_b, onet_bn_relu_bwd_apply_b,
+ * onet_maxpool2_fwd_b, onet_convT2x2_fwd_b).  The fp32-input forms round to bf16 (nearest even) on the way into LDS, the
+ * producers round the same way, so the results are bit-identical; the operand bytes halve.  x_is_bf16 / dz_is_bf16 select
+ * per operand.  W % 8 == 0 and 16-byte aligned rows for the weight gradient. */
+int onet_bn_relu_apply_b(const float* z, int64_t z_bs, float* a, int64_t a_bs, void* a_bf16, int64_t a16_bs, const float* save,
+                         int B, int C, int HW, void* stream);                  /* a and / or its bf16 copy (either may be NULL) */
+int onet_bn_relu_bwd_apply_b(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save, const float* coef,
+                             float* dz, int64_t dz_bs, void* dz_bf16, int64_t dz16_bs, int B, int C, int HW, void* stream);
+int onet_maxpool2_fwd_b(const float* x, int64_t x_bs, float* y, int64_t y_bs, void* y_bf16, int64_t y16_bs, int B, int C, int H,
+                        int W, void* stream);                                   /* 1: y written, no bf16 copy (odd / unaligned map) */
+int onet_convT2x2_fwd_b(const float* x, int64_t x_bs, const float* wq, const float* bias, float* y, int64_t y_bs, void* y_bf16,
+                        int64_t y16_bs, int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, void* stream);
+                                                                                /* 1: shape outside the GEMM path, nothing done */
+int onet_conv3x3_bf16_fwd_b(const void* x_bf16, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin,
+                            int Cout, int H, int W, void* stream);
+int onet_conv3x3_wgrad_bf16_b(const void* x, int x_is_bf16, int64_t x_bs, const void* dz, int dz_is_bf16, int64_t dz_bs,
+                              float* dw, void* ws, int64_t ws_bytes, int B, int Cin, int Cout, int H, int W, int accumulate,
+                              void* stream);
 /* Larger-tile weight gradient: Winograd F(3x3,4x4) (4x fewer multiplies than direct, 1.78x fewer than the F(2x2,3x3)
  * kernel below; 6x6 input tiles, 4x4 tiles of dz in the filter's role, the points of onet_conv3x3_winograd4_fwd; split-K
  * 36-position slabs folded by A'^T . A').  Where onet_conv3x3_winograd4_wgrad_ok() returns 1 (W % 32 == 0, H % 4 == 0,

@@ -174,17 +174,27 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
 }
 
 // a = max(0, (z-mean)*scale + beta)  (the centred form: z*scale+shift cancels badly when |mean| >> std); one block per 4096-element chunk of a (b, c) plane
+typedef __bf16 bn_bf16x4 __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ void store_bf16x4(__bf16* p, float4 q) {     // round to nearest even, as the conv kernels' staging
+    bn_bf16x4 v = {(__bf16)q.x, (__bf16)q.y, (__bf16)q.z, (__bf16)q.w};
+    *reinterpret_cast<bn_bf16x4*>(p) = v;
+}
+
+// a16 (optional): a bf16 copy of the activation for the bf16 conv kernels (bf16 STORAGE of their operands); a may be NULL
+// when only the bf16 copy is wanted
 __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restrict__ z, int64_t z_bs,
                                                             float* __restrict__ a, int64_t a_bs,
                                                             const float* __restrict__ save, int C, int HW,
-                                                            int chunks) {
+                                                            int chunks, __bf16* __restrict__ a16 = nullptr,
+                                                            int64_t a16_bs = 0) {
     const int plane = blockIdx.x / chunks, ch = blockIdx.x % chunks;
     const int b = plane / C, c = plane % C;
     const float mean = save[c], sc = save[2 * C + c], sh = save[3 * C + c];
     const float* src = z + (int64_t)b * z_bs + (int64_t)c * HW;
-    float* dst = a + (int64_t)b * a_bs + (int64_t)c * HW;
+    float* dst = a ? a + (int64_t)b * a_bs + (int64_t)c * HW : nullptr;
+    __bf16* d16 = a16 ? a16 + (int64_t)b * a16_bs + (int64_t)c * HW : nullptr;
     const int beg = ch * 4096, end = min(beg + 4096, HW);
-    if (((HW & 3) == 0) && ((z_bs & 3) == 0) && ((a_bs & 3) == 0)) {
+    if (((HW & 3) == 0) && ((z_bs & 3) == 0) && ((a_bs & 3) == 0) && ((a16_bs & 3) == 0)) {
 #if ONET_BN_BATCH
         if (end - beg == 4096) {          // full chunk: all four 16-byte loads of the thread in flight before the first use
             const int i0 = beg + threadIdx.x * 4;
@@ -197,7 +207,8 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restr
                 q[k].y = fmaxf(fmaf(q[k].y - mean, sc, sh), 0.f);
                 q[k].z = fmaxf(fmaf(q[k].z - mean, sc, sh), 0.f);
                 q[k].w = fmaxf(fmaf(q[k].w - mean, sc, sh), 0.f);
-                *reinterpret_cast<float4*>(dst + i0 + 1024 * k) = q[k];
+                if (dst) *reinterpret_cast<float4*>(dst + i0 + 1024 * k) = q[k];
+                if (d16) store_bf16x4(d16 + i0 + 1024 * k, q[k]);
             }
             return;
         }
@@ -208,10 +219,15 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restr
             q.y = fmaxf(fmaf(q.y - mean, sc, sh), 0.f);
             q.z = fmaxf(fmaf(q.z - mean, sc, sh), 0.f);
             q.w = fmaxf(fmaf(q.w - mean, sc, sh), 0.f);
-            *reinterpret_cast<float4*>(dst + i) = q;
+            if (dst) *reinterpret_cast<float4*>(dst + i) = q;
+            if (d16) store_bf16x4(d16 + i, q);
         }
     } else {
-        for (int i = beg + threadIdx.x; i < end; i += 256) dst[i] = fmaxf(fmaf(src[i] - mean, sc, sh), 0.f);
+        for (int i = beg + threadIdx.x; i < end; i += 256) {
+            const float v = fmaxf(fmaf(src[i] - mean, sc, sh), 0.f);
+            if (dst) dst[i] = v;
+            if (d16) d16[i] = (__bf16)v;
+        }
     }
 }
 
@@ -347,7 +363,8 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
                                                                 const float* __restrict__ save,
                                                                 const float* __restrict__ coef,
                                                                 float* __restrict__ dz, int64_t dz_bs, int C,
-                                                                int HW, int chunks) {
+                                                                int HW, int chunks, __bf16* __restrict__ dz16 = nullptr,
+                                                                int64_t dz16_bs = 0) {
     const int plane = blockIdx.x / chunks, ch = blockIdx.x % chunks;
     const int b = plane / C, c = plane % C;
     const float mean = save[c], invstd = save[C + c], sc = save[2 * C + c], sh = save[3 * C + c];
@@ -356,9 +373,10 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
     const double c2 = coef ? (double)coef[2 * C + c] + (double)coef[3 * C + c] : 0.0;
     const float* zs = z + (int64_t)b * z_bs + (int64_t)c * HW;
     const float* ds = da + (int64_t)b * da_bs + (int64_t)c * HW;
-    float* out = dz + (int64_t)b * dz_bs + (int64_t)c * HW;
+    float* out = dz ? dz + (int64_t)b * dz_bs + (int64_t)c * HW : nullptr;
+    __bf16* o16 = dz16 ? dz16 + (int64_t)b * dz16_bs + (int64_t)c * HW : nullptr;
     const int beg = ch * 4096, end = min(beg + 4096, HW);
-    if (((HW & 3) == 0) && ((z_bs & 3) == 0) && ((da_bs & 3) == 0) && ((dz_bs & 3) == 0)) {
+    if (((HW & 3) == 0) && ((z_bs & 3) == 0) && ((da_bs & 3) == 0) && ((dz_bs & 3) == 0) && ((dz16_bs & 3) == 0)) {
 #if ONET_BN_BATCH
         if (end - beg == 4096) {          // full chunk: the thread's eight 16-byte loads in flight before the first use
             const int i0 = beg + threadIdx.x * 4;
@@ -377,7 +395,8 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
                     const double dy = fmaf(zz[e] - mean, sc, sh) > 0.f ? (double)gg[e] : 0.0;
                     o[e] = (float)(scd * (dy - c1 - (((double)zz[e] - meand) * invd) * c2));
                 }
-                *reinterpret_cast<float4*>(out + i0 + 1024 * k) = make_float4(o[0], o[1], o[2], o[3]);
+                if (out) *reinterpret_cast<float4*>(out + i0 + 1024 * k) = make_float4(o[0], o[1], o[2], o[3]);
+                if (o16) store_bf16x4(o16 + i0 + 1024 * k, make_float4(o[0], o[1], o[2], o[3]));
             }
             return;
         }
@@ -392,12 +411,15 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
                 const double dy = fmaf(zz[k] - mean, sc, sh) > 0.f ? (double)gg[k] : 0.0;
                 o[k] = (float)(scd * (dy - c1 - (((double)zz[k] - meand) * invd) * c2));
             }
-            *reinterpret_cast<float4*>(out + i) = make_float4(o[0], o[1], o[2], o[3]);
+            if (out) *reinterpret_cast<float4*>(out + i) = make_float4(o[0], o[1], o[2], o[3]);
+            if (o16) store_bf16x4(o16 + i, make_float4(o[0], o[1], o[2], o[3]));
         }
     } else {
         for (int i = beg + threadIdx.x; i < end; i += 256) {
             const double dy = fmaf(zs[i] - mean, sc, sh) > 0.f ? (double)ds[i] : 0.0;
-            out[i] = (float)(scd * (dy - c1 - (((double)zs[i] - meand) * invd) * c2));
+            const float v = (float)(scd * (dy - c1 - (((double)zs[i] - meand) * invd) * c2));
+            if (out) out[i] = v;
+            if (o16) o16[i] = (__bf16)v;
         }
     }
 }
@@ -461,6 +483,17 @@ int onet_bn_relu_apply(const float* z, int64_t z_bs, float* a, int64_t a_bs, con
     return check_launch("bn_relu_apply_kernel");
 }
 
+int onet_bn_relu_apply_b(const float* z, int64_t z_bs, float* a, int64_t a_bs, void* a_bf16, int64_t a16_bs, const float* save, int B,
+                         int C, int HW, void* stream) {
+    ONET_REQUIRE(z && (a || a_bf16) && save && B > 0 && C > 0 && HW > 0, "bn_relu_apply_b: bad args");
+    const int chunks = cdiv(HW, 4096);
+    const int64_t blocks = (int64_t)B * C * chunks;
+    ONET_REQUIRE(blocks < (1ll << 31), "bn_relu_apply_b: grid too large");
+    hipLaunchKernelGGL(bn_relu_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), z, z_bs, a, a_bs, save, C, HW,
+                       chunks, (__bf16*)a_bf16, a16_bs);
+    return check_launch("bn_relu_apply_kernel");
+}
+
 int onet_bn_relu_bwd_reduce(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save,
                             float* part2, int nparts, int B, int C, int HW, void* stream) {
     ONET_REQUIRE(da && z && save && part2 && B > 0 && C > 0 && HW > 0, "bn_relu_bwd_reduce: bad args");
@@ -495,6 +528,17 @@ int onet_bn_relu_bwd_apply(const float* da, int64_t da_bs, const float* z, int64
     ONET_REQUIRE(blocks < (1ll << 31), "bn_relu_bwd_apply: grid too large");
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), da, da_bs,
                        z, z_bs, save, coef, dz, dz_bs, C, HW, chunks);
+    return check_launch("bn_relu_bwd_apply_kernel");
+}
+
+int onet_bn_relu_bwd_apply_b(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save, const float* coef,
+                             float* dz, int64_t dz_bs, void* dz_bf16, int64_t dz16_bs, int B, int C, int HW, void* stream) {
+    ONET_REQUIRE(da && z && save && (dz || dz_bf16) && B > 0 && C > 0 && HW > 0, "bn_relu_bwd_apply_b: bad args");
+    const int chunks = cdiv(HW, 4096);
+    const int64_t blocks = (int64_t)B * C * chunks;
+    ONET_REQUIRE(blocks < (1ll << 31), "bn_relu_bwd_apply_b: grid too large");
+    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), da, da_bs, z, z_bs, save, coef,
+                       dz, dz_bs, C, HW, chunks, (__bf16*)dz_bf16, dz16_bs);
     return check_launch("bn_relu_bwd_apply_kernel");
 }
 

@@ -60,8 +60,8 @@ __global__ void pack3x3_bf16_kernel(const float* __restrict__ w, __bf16* __restr
 }
 
 struct BfArgs {
-    const float* x;
-    int64_t x_bs;
+    const void* x;        // fp32 NCHW, or bf16 NCHW (XB kernels: bf16 STORAGE of the operand, written by the BatchNorm / pooling /
+    int64_t x_bs;         // ConvTranspose2d kernels next to their fp32 outputs; strides in elements)
     const __bf16* wq;     // [Cin/16][9][Cout][16]
     float* z;
     int64_t z_bs;
@@ -80,7 +80,7 @@ struct BfCfg {
     static constexpr int LDS_BYTES = (IN_ITEMS + W_ITEMS) * 16;
 };
 
-template <int NT, int WPS, int TW = 32>
+template <int NT, int WPS, int TW = 32, bool XB = false>
 __global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
     using C = BfCfg<NT, TW>;
     constexpr int ROWS = C::ROWS, IN_COLS = C::IN_COLS, NIT = C::NIT, NWI = C::NWI, CO_T = C::CO_T, RPT = C::RPT;
@@ -114,7 +114,8 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    const __amdgpu_buffer_rsrc_t xr = b_rsrc(a.x + (int64_t)b * a.x_bs, (int64_t)a.Cin * HW * 4);
+    constexpr int XE = XB ? 2 : 4;                                     // bytes per element of x
+    const __amdgpu_buffer_rsrc_t xr = b_rsrc(static_cast<const char*>(a.x) + (int64_t)b * a.x_bs * XE, (int64_t)a.Cin * HW * XE);
     const __amdgpu_buffer_rsrc_t wr = b_rsrc(a.wq, (int64_t)a.Cin * 9 * a.Cout * 2);
 
     // staging slots of this thread: (pixel, half) -> 8 channel planes; byte offset of channel 0 of the half
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
         const int r = p / IN_COLS, c = p % IN_COLS;
         const int yy = y0 - 1 + r, xx = x0 - 1 + c;
         const bool ok = (i < C::IN_ITEMS) && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-        in_off[k] = ok ? (unsigned)(((half * 8) * HW + yy * a.W + xx) * 4) : OOB_B;
+        in_off[k] = ok ? (unsigned)(((half * 8) * HW + yy * a.W + xx) * XE) : OOB_B;
     }
     // weight slots: (tap, co, half) -> 16 bytes of the packed slice [chunk][tap][co][16]
     unsigned w_off[NWI];
@@ -137,18 +138,23 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
         const bool ok = (i < C::W_ITEMS) && (co0 + co < a.Cout);
         w_off[k] = ok ? (unsigned)(((t * a.Cout + co0 + co) * 16 + half * 8) * 2) : OOB_B;
     }
-    const unsigned in_step = (unsigned)(16 * HW * 4), w_step = (unsigned)(9 * a.Cout * 16 * 2);
-    const unsigned plane = (unsigned)(HW * 4);
+    const unsigned in_step = (unsigned)(16 * HW * XE), w_step = (unsigned)(9 * a.Cout * 16 * 2);
+    const unsigned plane = (unsigned)(HW * XE);
 
-    float xin[NIT][8];
+    float xin[NIT][8];                               // XB: the low 16 bits hold the bf16 value
     u32x4b wv[NWI];
     auto issue = [&](unsigned cin_bytes, unsigned cw_bytes) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < NIT; ++k)
 #pragma unroll
-            for (int c = 0; c < 8; ++c)
-                xin[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                          xr, in_off[k] + cin_bytes + c * plane, 0, 0));   // OOB_B + anything stays out of range -> 0
+            for (int c = 0; c < 8; ++c) {
+                if constexpr (XB)
+                    xin[k][c] = __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(
+                                                              xr, in_off[k] + cin_bytes + c * plane, 0, 0));
+                else
+                    xin[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                              xr, in_off[k] + cin_bytes + c * plane, 0, 0));   // OOB_B + anything stays out of range -> 0
+            }
 #pragma unroll
         for (int k = 0; k < NWI; ++k)
             wv[k] = __builtin_amdgcn_raw_buffer_load_b128(wr, w_off[k] + cw_bytes, 0, 0);
@@ -158,8 +164,14 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
         for (int k = 0; k < NIT; ++k) {
             const int i = tid + 256 * k;
             if (i < C::IN_ITEMS) {
-                u32x4b v = {pack_bf16(xin[k][0], xin[k][1]), pack_bf16(xin[k][2], xin[k][3]),
-                            pack_bf16(xin[k][4], xin[k][5]), pack_bf16(xin[k][6], xin[k][7])};
+                u32x4b v;
+                if constexpr (XB) {
+                    auto pk = [](float lo, float hi) { return __builtin_bit_cast(unsigned, lo) | (__builtin_bit_cast(unsigned, hi) << 16); };
+                    v = u32x4b{pk(xin[k][0], xin[k][1]), pk(xin[k][2], xin[k][3]), pk(xin[k][4], xin[k][5]), pk(xin[k][6], xin[k][7])};
+                } else {
+                    v = u32x4b{pack_bf16(xin[k][0], xin[k][1]), pack_bf16(xin[k][2], xin[k][3]),
+                               pack_bf16(xin[k][4], xin[k][5]), pack_bf16(xin[k][6], xin[k][7])};
+                }
                 in_lds[i] = v;
             }
         }
@@ -216,7 +228,7 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
         }
 }
 
-template <int NT, int WPS, int TW = 32>
+template <int NT, int WPS, int TW = 32, bool XB = false>
 static int launch_bf16(BfArgs a, hipStream_t st) {
     using C = BfCfg<NT, TW>;
     a.tilesX = cdiv(a.W, TW);
@@ -224,7 +236,7 @@ static int launch_bf16(BfArgs a, hipStream_t st) {
     a.coTiles = cdiv(a.Cout, C::CO_T);
     const int64_t blocks = (int64_t)a.B * a.tilesX * a.tilesY * a.coTiles;
     ONET_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv3x3_bf16: grid %lld out of range", (long long)blocks);
-    auto kern = conv3x3_bf16_kernel<NT, WPS, TW>;
+    auto kern = conv3x3_bf16_kernel<NT, WPS, TW, XB>;
     static PerDeviceOnce attr_once;
     if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -245,9 +257,9 @@ static int launch_bf16(BfArgs a, hipStream_t st) {
 //   groups of a b128 read on 64 distinct banks.  Split-K over (image, patch) units, raw slabs [split][tap][co][ci]
 //   reduced deterministically by wgrad_reduce_kernel (conv_mfma.hip).
 struct BwArgs {
-    const float* x;
+    const void* x;        // fp32 or bf16 (XB) NCHW, strides in elements
     int64_t x_bs;
-    const float* dz;
+    const void* dz;       // fp32 or bf16 (ZB)
     int64_t dz_bs;
     float* slab;
     int B, Cin, Cout, H, W, ciTiles, coTiles, splitK, tilesY, tilesX;
@@ -255,6 +267,7 @@ struct BwArgs {
 
 constexpr int BW_SDZ = 36, BW_SX = 76, BW_XROW = 12;        // dword strides: per co, per ci, per patch row
 
+template <bool XB = false, bool ZB = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_bf16_kernel(BwArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned dz_lds[64 * BW_SDZ];
     __shared__ __attribute__((aligned(16))) unsigned x_lds[64 * BW_SX];
@@ -294,15 +307,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_bf16_kernel(BwArgs a) {
         const int uu = live ? u : 0;
         const int tx = uu % a.tilesX, ty = (uu / a.tilesX) % a.tilesY, b = uu / (a.tilesX * a.tilesY);
         const int y0 = ty * 4, x0 = tx * 16;
-        const __amdgpu_buffer_rsrc_t dr = b_rsrc(a.dz + (int64_t)b * a.dz_bs, (int64_t)a.Cout * HW * 4);
-        const __amdgpu_buffer_rsrc_t xr = b_rsrc(a.x + (int64_t)b * a.x_bs, (int64_t)a.Cin * HW * 4);
+        constexpr int XE = XB ? 2 : 4, ZE = ZB ? 2 : 4;
+        const __amdgpu_buffer_rsrc_t dr = b_rsrc(static_cast<const char*>(a.dz) + (int64_t)b * a.dz_bs * ZE, (int64_t)a.Cout * HW * ZE);
+        const __amdgpu_buffer_rsrc_t xr = b_rsrc(static_cast<const char*>(a.x) + (int64_t)b * a.x_bs * XE, (int64_t)a.Cin * HW * XE);
         {
             const int yy = y0 + dz_r;
             const bool ok = live && yy < a.H && co0 + dz_c < a.Cout;
-            const unsigned base = (unsigned)(((co0 + dz_c) * HW + yy * a.W + x0) * 4);
+            const unsigned base = (unsigned)(((co0 + dz_c) * HW + yy * a.W + x0) * ZE);
+            if constexpr (ZB) {       // 16 bf16 = two b128 loads, already in the LDS format
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                dzv[k] = __builtin_amdgcn_raw_buffer_load_b128(dr, (ok && x0 + 4 * k < a.W) ? base + 16 * k : OOB_B, 0, 0);
+                for (int k = 0; k < 2; ++k)
+                    dzv[k] = __builtin_amdgcn_raw_buffer_load_b128(dr, (ok && x0 + 8 * k < a.W) ? base + 16 * k : OOB_B, 0, 0);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    dzv[k] = __builtin_amdgcn_raw_buffer_load_b128(dr, (ok && x0 + 4 * k < a.W) ? base + 16 * k : OOB_B, 0, 0);
+            }
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -310,27 +330,53 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_bf16_kernel(BwArgs a) {
             const int c = e / 6, r = e % 6;
             const int yy = y0 - 1 + r;
             const bool rok = live && e < 64 * 6 && yy >= 0 && yy < a.H && ci0 + c < a.Cin;
-            const unsigned base = (unsigned)(((ci0 + c) * HW + yy * a.W + x0) * 4);
+            const unsigned base = (unsigned)(((ci0 + c) * HW + yy * a.W + x0) * XE);
+            if constexpr (XB) {       // 16 interior bf16 = two b128 loads (W % 8 == 0: a load is entirely inside or outside the row)
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                xq[j][k] = __builtin_amdgcn_raw_buffer_load_b128(xr, (rok && x0 + 4 * k < a.W) ? base + 16 * k : OOB_B, 0, 0);
-            xh[j][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (rok && x0 > 0) ? base - 4 : OOB_B, 0, 0));
-            xh[j][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (rok && x0 + 16 < a.W) ? base + 64 : OOB_B, 0, 0));
+                for (int k = 0; k < 2; ++k)
+                    xq[j][k] = __builtin_amdgcn_raw_buffer_load_b128(xr, (rok && x0 + 8 * k < a.W) ? base + 16 * k : OOB_B, 0, 0);
+                xh[j][0] = __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(xr, (rok && x0 > 0) ? base - 2 : OOB_B, 0, 0));
+                xh[j][1] = __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(xr, (rok && x0 + 16 < a.W) ? base + 32 : OOB_B, 0, 0));
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    xq[j][k] = __builtin_amdgcn_raw_buffer_load_b128(xr, (rok && x0 + 4 * k < a.W) ? base + 16 * k : OOB_B, 0, 0);
+                xh[j][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (rok && x0 > 0) ? base - 4 : OOB_B, 0, 0));
+                xh[j][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (rok && x0 + 16 < a.W) ? base + 64 : OOB_B, 0, 0));
+            }
         }
     };
     auto commit = [&]() __attribute__((always_inline)) {
         u32x4b* d = reinterpret_cast<u32x4b*>(dz_lds + dz_c * BW_SDZ + dz_r * 8);
+        if constexpr (ZB) {
+            d[0] = dzv[0];
+            d[1] = dzv[1];
+        } else {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            // (bit-cast the whole vector: __builtin_bit_cast(float, vec[i]) on an element of an ext-vector reads element 0)
-            const f32x4b lo = __builtin_bit_cast(f32x4b, dzv[2 * h]), hi = __builtin_bit_cast(f32x4b, dzv[2 * h + 1]);
-            u32x4b v = {pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(hi[0], hi[1]), pack_bf16(hi[2], hi[3])};
-            d[h] = v;
+            for (int h = 0; h < 2; ++h) {
+                // (bit-cast the whole vector: __builtin_bit_cast(float, vec[i]) on an element of an ext-vector reads element 0)
+                const f32x4b lo = __builtin_bit_cast(f32x4b, dzv[2 * h]), hi = __builtin_bit_cast(f32x4b, dzv[2 * h + 1]);
+                u32x4b v = {pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(hi[0], hi[1]), pack_bf16(hi[2], hi[3])};
+                d[h] = v;
+            }
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int e = tid + 256 * j;
-            if (e < 64 * 6) {
+            if (e < 64 * 6 && XB) {
+                // bf16 source: interior dwords q[p] = (f[2p], f[2p+1]); patch dword p = (f[2p-1], f[2p]) = the upper half of q[p-1]
+                // and the lower half of q[p] (v_alignbit), dword 0 = (left halo, f[0]), dword 8 = (f[15], right halo)
+                unsigned* row = x_lds + (e / 6) * BW_SX + (e % 6) * BW_XROW;
+                const u32x4b q0 = xq[j][0], q1 = xq[j][1];
+                const unsigned hl = __builtin_bit_cast(unsigned, xh[j][0]), hr = __builtin_bit_cast(unsigned, xh[j][1]);
+                const u32x4b w0 = {hl | (q0[0] << 16), __builtin_amdgcn_alignbit(q0[1], q0[0], 16), __builtin_amdgcn_alignbit(q0[2], q0[1], 16),
+                                   __builtin_amdgcn_alignbit(q0[3], q0[2], 16)};
+                const u32x4b w1 = {__builtin_amdgcn_alignbit(q1[0], q0[3], 16), __builtin_amdgcn_alignbit(q1[1], q1[0], 16),
+                                   __builtin_amdgcn_alignbit(q1[2], q1[1], 16), __builtin_amdgcn_alignbit(q1[3], q1[2], 16)};
+                *reinterpret_cast<u32x4b*>(row) = w0;
+                *reinterpret_cast<u32x4b*>(row + 4) = w1;
+                row[8] = (q1[3] >> 16) | (hr << 16);
+            } else if (e < 64 * 6) {
                 // patch element 0 = column x0 - 1: dword p = (element 2p, 2p + 1) = (f[2p - 1], f[2p]) of the interior row f
                 const f32x4b f0 = __builtin_bit_cast(f32x4b, xq[j][0]), f1 = __builtin_bit_cast(f32x4b, xq[j][1]);
                 const f32x4b f2 = __builtin_bit_cast(f32x4b, xq[j][2]), f3 = __builtin_bit_cast(f32x4b, xq[j][3]);
@@ -413,8 +459,8 @@ int onet_conv3x3_pack_weights_bf16(const float* w, void* wq_fwd, void* wq_dgrad,
     return check_launch("pack3x3_bf16_kernel");
 }
 
-int onet_conv3x3_bf16_fwd(const float* x, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin, int Cout,
-                          int H, int W, void* stream) {
+static int bf16_fwd(const void* x, bool x_bf16, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin, int Cout,
+                    int H, int W, void* stream) {
     ONET_REQUIRE(x && wq && z, "conv3x3_bf16_fwd: null pointer");
     ONET_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv3x3_bf16_fwd: bad shape");
     ONET_REQUIRE((Cin % 16) == 0 && (Cout % 4) == 0, "conv3x3_bf16_fwd: Cin must be a multiple of 16, Cout of 4 (use onet_conv_fwd)");
@@ -424,7 +470,19 @@ int onet_conv3x3_bf16_fwd(const float* x, int64_t x_bs, const void* wq, float* z
     BfArgs a{x, x_bs, (const __bf16*)wq, z, z_bs, B, Cin, Cout, H, W, 0, 0, 0};
     // 4 waves x 2 rows x 32 px, two blocks (8 waves) per CU: 373-851 TF on the U-Net's layers against 278-527 for
     // 4-row waves at one wave per SIMD and ~100 for 4-row waves squeezed into 256 VGPRs (700 B/lane of scratch)
+    // (three blocks per CU for the bf16-input kernel -- 168 VGPRs -- changed nothing: 0.412 vs 0.410 ms per launch)
+    if (x_bf16) return (W > 16) ? launch_bf16<2, 2, 32, true>(a, as_stream(stream)) : launch_bf16<2, 2, 16, true>(a, as_stream(stream));
     return (W > 16) ? launch_bf16<2, 2>(a, as_stream(stream)) : launch_bf16<2, 2, 16>(a, as_stream(stream));
+}
+
+int onet_conv3x3_bf16_fwd(const float* x, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin, int Cout,
+                          int H, int W, void* stream) {
+    return bf16_fwd(x, false, x_bs, wq, z, z_bs, B, Cin, Cout, H, W, stream);
+}
+
+int onet_conv3x3_bf16_fwd_b(const void* x_bf16, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin, int Cout,
+                            int H, int W, void* stream) {
+    return bf16_fwd(x_bf16, true, x_bs, wq, z, z_bs, B, Cin, Cout, H, W, stream);
 }
 
 int64_t onet_conv3x3_wgrad_bf16_ws_bytes(int B, int Cin, int Cout, int H, int W) {
@@ -433,12 +491,14 @@ int64_t onet_conv3x3_wgrad_bf16_ws_bytes(int B, int Cin, int Cout, int H, int W)
     return (int64_t)splitK * 9 * Cout * Cin * 4;
 }
 
-int onet_conv3x3_wgrad_bf16(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs, float* dw, void* ws, int64_t ws_bytes,
-                            int B, int Cin, int Cout, int H, int W, int accumulate, void* stream) {
+static int bf16_wgrad(const void* x, bool xb, int64_t x_bs, const void* dz, bool zb, int64_t dz_bs, float* dw, void* ws, int64_t ws_bytes,
+                      int B, int Cin, int Cout, int H, int W, int accumulate, void* stream) {
     ONET_REQUIRE(x && dz && dw && ws, "conv3x3_wgrad_bf16: null pointer");
     ONET_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv3x3_wgrad_bf16: bad shape");
     ONET_REQUIRE((W & 3) == 0 && (dz_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(dz) & 15) == 0,
                  "conv3x3_wgrad_bf16: W %% 4 == 0 and 16-byte aligned dz rows required (use onet_conv_wgrad)");
+    ONET_REQUIRE(!(xb || zb) || ((W & 7) == 0 && (x_bs & 7) == 0 && (dz_bs & 7) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0),
+                 "conv3x3_wgrad_bf16: bf16 operands need W %% 8 == 0 and 16-byte aligned rows");
     ONET_REQUIRE(x_bs >= (int64_t)Cin * H * W && dz_bs >= (int64_t)Cout * H * W, "conv3x3_wgrad_bf16: batch stride too small");
     ONET_REQUIRE((int64_t)std::max(Cin, Cout) * H * W * 4 < (1ll << 31), "conv3x3_wgrad_bf16: image exceeds the 2 GiB buffer-resource range");
     BwArgs a{x, x_bs, dz, dz_bs, (float*)ws, B, Cin, Cout, H, W, cdiv(Cin, 64), cdiv(Cout, 64), 1, 1, 1};
@@ -446,10 +506,24 @@ int onet_conv3x3_wgrad_bf16(const float* x, int64_t x_bs, const float* dz, int64
     const int64_t need = (int64_t)a.splitK * 9 * Cout * Cin * 4;
     ONET_REQUIRE(ws_bytes >= need, "conv3x3_wgrad_bf16: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
     const int64_t blocks = (int64_t)a.splitK * a.ciTiles * a.coTiles;
-    hipLaunchKernelGGL(conv3x3_wgrad_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
+    const dim3 g((unsigned)blocks), t(256);
+    if (xb && zb) hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<true, true>), g, t, 0, as_stream(stream), a);
+    else if (xb) hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<true, false>), g, t, 0, as_stream(stream), a);
+    else if (zb) hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<false, true>), g, t, 0, as_stream(stream), a);
+    else hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<false, false>), g, t, 0, as_stream(stream), a);
     int rc = check_launch("conv3x3_wgrad_bf16_kernel");
     if (rc) return rc;
     return launch_wgrad_reduce((const float*)ws, dw, a.splitK, 9, Cout, Cin, 0, accumulate, as_stream(stream));
+}
+
+int onet_conv3x3_wgrad_bf16(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs, float* dw, void* ws, int64_t ws_bytes,
+                            int B, int Cin, int Cout, int H, int W, int accumulate, void* stream) {
+    return bf16_wgrad(x, false, x_bs, dz, false, dz_bs, dw, ws, ws_bytes, B, Cin, Cout, H, W, accumulate, stream);
+}
+
+int onet_conv3x3_wgrad_bf16_b(const void* x, int x_is_bf16, int64_t x_bs, const void* dz, int dz_is_bf16, int64_t dz_bs, float* dw,
+                              void* ws, int64_t ws_bytes, int B, int Cin, int Cout, int H, int W, int accumulate, void* stream) {
+    return bf16_wgrad(x, x_is_bf16 != 0, x_bs, dz, dz_is_bf16 != 0, dz_bs, dw, ws, ws_bytes, B, Cin, Cout, H, W, accumulate, stream);
 }
 
 }  // extern "C"

@@ -769,12 +769,24 @@ int onet_convT2x2_fwd(const float* x, int64_t x_bs, const float* wq, const float
     ONET_REQUIRE(pt >= 0 && pl >= 0 && pt + 2 * h <= Ho && pl + 2 * w <= Wo, "convT2x2_fwd: window outside plane");
     ONET_REQUIRE(x_bs >= (int64_t)Cin * h * w && y_bs >= (int64_t)Ct * Ho * Wo, "convT2x2_fwd: batch stride too small");
     if (convt_gemm_enabled()) {
-        const int rc = convt_gemm_fwd(x, x_bs, wq, bias, y, y_bs, B, Cin, Ct, h, w, Ho, Wo, pt, pl, as_stream(stream));
+        const int rc = convt_gemm_fwd(x, x_bs, wq, bias, y, y_bs, nullptr, 0, B, Cin, Ct, h, w, Ho, Wo, pt, pl, as_stream(stream));
         if (rc <= 0) return rc;          // 1: shape outside the 128 x 128 GEMM's fast path
     }
     ConvArgs a{x, x_bs, wq, y, y_bs, nullptr, B, Cin, 4 * Ct, h, w, 0, 0, 0, bias, Ho, Wo, pt, pl};
     return (w > 16) ? launch_fwd<1, 2, 2, 1, 4, 32, 1>(a, as_stream(stream))
                     : launch_fwd<1, 2, 2, 1, 4, 16, 1>(a, as_stream(stream));
+}
+
+// forward + a bf16 copy of the up-sampled tensor (operand storage for the bf16 conv kernels): only on the 128 x 128 GEMM path;
+// returns 1 (and does nothing) elsewhere -- the caller then runs onet_convT2x2_fwd and the consumer reads fp32
+int onet_convT2x2_fwd_b(const float* x, int64_t x_bs, const float* wq, const float* bias, float* y, int64_t y_bs, void* y_bf16,
+                        int64_t y16_bs, int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, void* stream) {
+    ONET_REQUIRE(x && wq && y_bf16, "convT2x2_fwd_b: null pointer");       // y may be NULL: bf16 output only
+    ONET_REQUIRE(B > 0 && Cin > 0 && Ct > 0 && h > 0 && w > 0, "convT2x2_fwd_b: bad shape");
+    ONET_REQUIRE(x_bs >= (int64_t)Cin * h * w && (!y || y_bs >= (int64_t)Ct * Ho * Wo) && y16_bs >= (int64_t)Ct * Ho * Wo,
+                 "convT2x2_fwd_b: batch stride too small");
+    if (!convt_gemm_enabled()) return 1;
+    return convt_gemm_fwd(x, x_bs, wq, bias, y, y_bs, y_bf16, y16_bs, B, Cin, Ct, h, w, Ho, Wo, pt, pl, as_stream(stream));
 }
 
 int onet_convT2x2_dgrad(const float* dy, int64_t dy_bs, const float* wp_dgrad, float* dx, int64_t dx_bs, int B,

@@ -64,6 +64,8 @@ struct GArgs {
     float* out;           // forward: y window;       dgrad: dx;                              wgrad: slab [splitK][Cin][4Ct]
     const float* bias;
     float* dbias_part;    // dgrad: [nTiles][Ct] partial sums of dy over the tile's pixels (blocks with mt == 0), or NULL
+    __bf16* out16;        // forward: optional bf16 copy of y (operand storage for the bf16 conv kernels), batch stride out16_bs
+    int64_t out16_bs;
     int64_t a_bs, b_bs, out_bs;
     int B, Cin, Ct, h, w, Wo, HoWo;   // y / dy plane: Ho x Wo with Ho = 2h, Wo = 2w (fast path: no F.pad offsets)
     int mTiles, nTiles, splitK, chunksPerSplit;
@@ -206,9 +208,20 @@ __global__ __launch_bounds__(256, 2) void convt_gemm_kernel(GArgs g) {
                 for (int gq = 0; gq < 4; ++gq) {
                     const int c = (m0 + wr * 64 + t * 32 + 8 * gq + 4 * kh) >> 2;      // rows 4 gq .. 4 gq + 3 = sub-pixels of c
                     const float bs = g.bias ? g.bias[c] : 0.f;
-                    float* o = yb + (int64_t)c * g.HoWo + (int64_t)(2 * y) * g.Wo + 2 * x;
-                    *reinterpret_cast<float2*>(o) = make_float2(acc[t][u][4 * gq] + bs, acc[t][u][4 * gq + 1] + bs);
-                    *reinterpret_cast<float2*>(o + g.Wo) = make_float2(acc[t][u][4 * gq + 2] + bs, acc[t][u][4 * gq + 3] + bs);
+                    const int64_t oo = (int64_t)c * g.HoWo + (int64_t)(2 * y) * g.Wo + 2 * x;
+                    float* o = yb + oo;
+                    const float v0 = acc[t][u][4 * gq] + bs, v1 = acc[t][u][4 * gq + 1] + bs, v2 = acc[t][u][4 * gq + 2] + bs,
+                                v3 = acc[t][u][4 * gq + 3] + bs;
+                    if (g.out) {
+                        *reinterpret_cast<float2*>(o) = make_float2(v0, v1);
+                        *reinterpret_cast<float2*>(o + g.Wo) = make_float2(v2, v3);
+                    }
+                    if (g.out16) {
+                        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+                        __bf16* o16 = g.out16 + (int64_t)b * g.out16_bs + oo;
+                        *reinterpret_cast<bf2*>(o16) = bf2{(__bf16)v0, (__bf16)v1};
+                        *reinterpret_cast<bf2*>(o16 + g.Wo) = bf2{(__bf16)v2, (__bf16)v3};
+                    }
                 }
             }
     } else {
@@ -392,14 +405,16 @@ void wgrad_plan(int B, int Cin, int Ct, int h, int w, int& splitK, int& per) {
 namespace onet {
 
 // Fast-path predicates + launches; return ONET_NOT_TAKEN (1) when the shape is not taken (caller falls back to conv_mfma.hip)
-int convt_gemm_fwd(const float* x, int64_t x_bs, const float* wq, const float* bias, float* y, int64_t y_bs, int B, int Cin,
-                   int Ct, int h, int w, int Ho, int Wo, int pt, int pl, hipStream_t st) {
+int convt_gemm_fwd(const float* x, int64_t x_bs, const float* wq, const float* bias, float* y, int64_t y_bs, void* y16, int64_t y16_bs,
+                   int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, hipStream_t st) {
     const int64_t hw = (int64_t)h * w;
     if (pt || pl || Ho != 2 * h || Wo != 2 * w || (Cin % KC) || (Ct % 32) || (hw % 128) || (w & 1) || !aligned16(x) || !aligned16(wq) ||
         (x_bs & 3) || (reinterpret_cast<uintptr_t>(y) & 7) || (y_bs & 1) || (int64_t)Cin * hw * 4 >= (1ll << 31) ||
         (int64_t)Cin * 4 * Ct * 4 >= (1ll << 31))
         return 1;
-    GArgs g{wq, x, y, bias, nullptr, 0, x_bs, y_bs, B, Cin, Ct, h, w, Wo, Ho * Wo, (4 * Ct) / 128, (int)(B * hw / 128), 1, 0};
+    if (y16 && ((reinterpret_cast<uintptr_t>(y16) & 3) || (y16_bs & 1))) return 1;
+    if (!y && !y16) return 1;
+    GArgs g{wq, x, y, bias, nullptr, (__bf16*)y16, y16_bs, 0, x_bs, y_bs, B, Cin, Ct, h, w, Wo, Ho * Wo, (4 * Ct) / 128, (int)(B * hw / 128), 1, 0};
     const int64_t blocks = (int64_t)g.mTiles * g.nTiles;
     if (blocks <= 0 || blocks >= (1ll << 31)) return 1;
     hipLaunchKernelGGL(convt_gemm_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, g);
@@ -416,7 +431,7 @@ int convt_gemm_dgrad(const float* dy, int64_t dy_bs, const float* wd, float* dx,
         (dy_bs & 3) || (int64_t)Ct * Ho * Wo * 4 >= (1ll << 31) || (int64_t)Cin * 4 * Ct * 4 >= (1ll << 31))
         return 1;
     if (dbias && !dbias_ws) return 1;
-    GArgs g{wd, dy, dx, nullptr, dbias ? dbias_ws : nullptr, 0, dy_bs, dx_bs, B, Cin, Ct, h, w, Wo, Ho * Wo, Cin / 128, (int)(B * hw / 128), 1, 0};
+    GArgs g{wd, dy, dx, nullptr, dbias ? dbias_ws : nullptr, nullptr, 0, 0, dy_bs, dx_bs, B, Cin, Ct, h, w, Wo, Ho * Wo, Cin / 128, (int)(B * hw / 128), 1, 0};
     const int64_t blocks = (int64_t)g.mTiles * g.nTiles;
     if (blocks <= 0 || blocks >= (1ll << 31)) return 1;
     hipLaunchKernelGGL(convt_gemm_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, g);
@@ -439,7 +454,7 @@ int convt_gemm_wgrad(const float* x, int64_t x_bs, const float* dy, int64_t dy_b
     if (pt || pl || Ho != 2 * h || Wo != 2 * w || (Cin % 128) || (Ct % 32) || (hw % KP) || (w & 1) || !aligned16(x) || !aligned16(dy) ||
         !aligned16(dw) || (x_bs & 3) || (dy_bs & 3) || (int64_t)Cin * hw * 4 >= (1ll << 31) || (int64_t)Ct * Ho * Wo * 4 >= (1ll << 31))
         return 1;
-    GArgs g{x, dy, (float*)ws, nullptr, nullptr, x_bs, dy_bs, 0, B, Cin, Ct, h, w, Wo, Ho * Wo, Cin / 128, Ct / 32, 1, 0};
+    GArgs g{x, dy, (float*)ws, nullptr, nullptr, nullptr, 0, x_bs, dy_bs, 0, B, Cin, Ct, h, w, Wo, Ho * Wo, Cin / 128, Ct / 32, 1, 0};
     wgrad_plan(B, Cin, Ct, h, w, g.splitK, g.chunksPerSplit);
     const int64_t n = (int64_t)Cin * 4 * Ct;
     if (ws_bytes < (int64_t)g.splitK * n * 4) return 1;

@@ -22,14 +22,26 @@ class ConvBNReLUFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, running_mean, running_var, training, momentum, eps, packed, out, groups=1,
-                link_out=None, link_in=None):
+                link_out=None, link_in=None, b16=None):
+        """b16 (bf16 storage, BASELINE config 3 only): dict with "x16" = the bf16 copy of x written by its producer (or None),
+        "out16" = a plane-contiguous bf16 destination for the copy of the output (or None: allocated); forward leaves the
+        output's copy in b16["a16"] for the caller to attach to the returned tensor."""
         ops.require_gpu(x, weight, gamma, beta)
+        x16 = None if b16 is None else b16.get("x16")
         # training: the F(4x4) kernel emits the BatchNorm statistics records from its epilogue (cm), where it can
-        z, cm = ops.conv3x3_fwd_bn_partials(x, packed) if training else (ops.conv3x3_auto(x, packed, 0), None)
+        z, cm = ops.conv3x3_fwd_bn_partials(x, packed, x16=x16) if training else (ops.conv3x3_auto(x, packed, 0, x16=x16), None)
         # `out` is None or a 1-tuple holding a plane-contiguous destination view (kept out of autograd's sight)
         dst = None if out is None else out[0]
         G = groups if (training and groups > 1) else 1
         C = z.shape[1]
+        a16 = None
+        if b16 is not None:
+            a16 = b16.get("out16")
+            if a16 is None:
+                a16 = torch.empty(z.shape, dtype=torch.bfloat16, device=z.device)
+        # bf16 storage: every consumer of this activation reads the bf16 copy -> no fp32 tensor is written, a placeholder
+        # goes through autograd
+        drop = a16 is not None and bool(b16.get("drop_fp32")) and dst is None
         save_all = torch.empty((G, 4, C), dtype=torch.float32, device=z.device)
         if G == 1:
             if training:
@@ -37,20 +49,27 @@ class ConvBNReLUFn(torch.autograd.Function):
                                     cm=None if cm is None else (cm, 0, cm.shape[1]), save=save_all[0])
             else:
                 ops.bn_eval_coeffs(gamma, beta, running_mean, running_var, eps, save=save_all[0])
-            a = ops.bn_relu_apply(z, save_all[0], out=dst)
+            a = ops.bn_relu_apply(z, save_all[0], out=dst, out16=a16, no_fp32=drop)
+            if drop:
+                a = ops.fp32_placeholder(z.shape, z.device)
         else:
             # twin batch: the G batch slices are separate BatchNorm batches (own statistics, running stats updated
             # slice after slice, exactly as G consecutive forward passes would)
             B = z.shape[0]
             Bg = B // G
-            a = dst if dst is not None else torch.empty_like(z)
+            a = dst if dst is not None else (ops.fp32_placeholder(z.shape, z.device) if drop else torch.empty_like(z))
             for g in range(G):
                 zg = z[g * Bg:(g + 1) * Bg]
                 npg = 0 if cm is None else cm.shape[1] // G
                 ops.bn_train_coeffs(zg, gamma, beta, running_mean, running_var, momentum, eps,
                                     cm=None if cm is None else (cm, g * npg, npg), save=save_all[g])
-                ops.bn_relu_apply(zg, save_all[g], out=a[g * Bg:(g + 1) * Bg])
-        ctx.save_for_backward(x, z, save_all)
+                ops.bn_relu_apply(zg, save_all[g], out=None if drop else a[g * Bg:(g + 1) * Bg],
+                                  out16=None if a16 is None else a16[g * Bg:(g + 1) * Bg], no_fp32=drop)
+        if b16 is not None:
+            b16["a16"] = a16
+        # (the weight gradient reads the bf16 copy too; saved WITH the tensors so that backward releases it -- a ctx attribute
+        # would live as long as the caller holds the loss)
+        ctx.save_for_backward(x, z, save_all, x16)
         ctx.training = training
         ctx.packed = packed
         ctx.wshape = tuple(weight.shape)
@@ -66,7 +85,7 @@ class ConvBNReLUFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, da):
-        x, z, save_all = ctx.saved_tensors
+        x, z, save_all, x16 = ctx.saved_tensors
         need_x, need_w, need_g, need_b = ctx.needs_input_grad[:4]
         pw, pg, pb = ctx.params
         aff = (ops.grad_slot_if_free(pg) if need_g else None, ops.grad_slot_if_free(pb) if need_b else None)
@@ -78,26 +97,36 @@ class ConvBNReLUFn(torch.autograd.Function):
             rda, rec, rec4 = lk.pop("da"), lk.pop("rec", None), lk.pop("rec4", None)
             if rda.data_ptr() != da.data_ptr() or rda.shape != da.shape or rda.stride() != da.stride():
                 rec = rec4 = None                   # autograd handed over something else (another consumer, a hook)
+        # bf16 storage: when both consumers of dz (weight gradient, input gradient) are the bf16 kernels, the BatchNorm
+        # backward writes dz in bf16 ONLY
+        Bz, Cz, Hz, Wz = z.shape
+        dz16 = None
+        if (ops.bf16_storage() and ops.wgrad_takes_bf16(ctx.wshape[1], Hz, Wz) and Wz % 8 == 0 and
+                (not need_x or ops.conv3x3_algo(Bz, Cz, ctx.wshape[1], Hz, Wz) == "bf16")):
+            dz16 = torch.empty(z.shape, dtype=torch.bfloat16, device=z.device)
         if G == 1:
             dz, dgamma, dbeta = ops.bn_relu_bwd(da, z, save_all[0], ctx.training, need_affine_grads=(need_g or need_b),
                                                 affine_out=aff, red=None if rec is None else (rec, 0, rec.shape[1]),
-                                                red4=None if rec4 is None else (rec4, 0, rec4.shape[0]))
+                                                red4=None if rec4 is None else (rec4, 0, rec4.shape[0]), out16=dz16)
         else:
             Bg = z.shape[0] // G
-            dz = torch.empty_like(z)
+            dz = torch.empty_like(z) if dz16 is None else None
             dgamma = dbeta = None
             for g in range(G):
                 sl = slice(g * Bg, (g + 1) * Bg)
                 npg = 0 if rec is None else rec.shape[1] // G
                 np4 = 0 if rec4 is None else rec4.shape[0] // G
                 _, dgamma, dbeta = ops.bn_relu_bwd(da[sl], z[sl], save_all[g], ctx.training, need_affine_grads=True,
-                                                   out=dz[sl], acc=None if g == 0 else (dgamma, dbeta),
+                                                   out=None if dz is None else dz[sl], acc=None if g == 0 else (dgamma, dbeta),
                                                    affine_out=aff if g == 0 else None,
                                                    red=None if rec is None else (rec, g * npg, npg),
-                                                   red4=None if rec4 is None else (rec4, g * np4, np4))
-        dw = ops.conv3x3_wgrad_auto(x, dz, ctx.wshape, out=ops.grad_slot_if_free(pw)) if need_w else None
+                                                   red4=None if rec4 is None else (rec4, g * np4, np4),
+                                                   out16=None if dz16 is None else dz16[sl])
+        dw = ops.conv3x3_wgrad_auto(x, dz, ctx.wshape, out=ops.grad_slot_if_free(pw), x16=x16, dz16=dz16) if need_w else None
         dx = None
-        if need_x:
+        if need_x and dz16 is not None:
+            dx = ops.conv3x3_auto(None, ctx.packed, 1, x16=dz16)
+        elif need_x:
             lk = ctx.link_in
             fused = None
             if lk is not None and "z" in lk:
@@ -109,8 +138,11 @@ class ConvBNReLUFn(torch.autograd.Function):
                 lk["da"], lk["rec"] = dx, r
             else:
                 dx = ops.conv3x3_auto(dz, ctx.packed, 1)
+        if ctx.link_in is not None:                 # whatever path ran: the unit below's (z, save) must not outlive this backward
+            ctx.link_in.pop("z", None)
+            ctx.link_in.pop("save", None)
         return (dx, dw, (dgamma if need_g else None), (dbeta if need_b else None), None, None, None, None, None, None,
-                None, None, None, None)
+                None, None, None, None, None)
 
 
 class Conv3x3Fn(torch.autograd.Function):
@@ -180,9 +212,11 @@ class SkipPoolFn(torch.autograd.Function):
     dict for the unit's backward."""
 
     @staticmethod
-    def forward(ctx, x, returned=False, link=None):
+    def forward(ctx, x, returned=False, link=None, b16=None):
         ops.require_gpu(x)
-        y = ops.maxpool2_fwd(x)
+        y = ops.maxpool2_fwd(x, bf16_only=bool(b16 and b16.get("bf16_only")))
+        if b16 is not None:                                   # bf16 storage: the pooled tensor's bf16 copy, for the caller to re-attach
+            b16["y16"] = ops.b16_of(y)
         ctx.save_for_backward(x)
         ctx.link = link if (link is not None and "z" in link) else None
         return (x.view_as(x), y, x.view_as(x)) if returned else (x.view_as(x), y)
@@ -192,14 +226,14 @@ class SkipPoolFn(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         if g_pool is None:
             gs = [g for g in (g_skip, g_ret) if g is not None]
-            return (sum(gs[1:], gs[0]) if gs else None), None, None
+            return (sum(gs[1:], gs[0]) if gs else None), None, None, None
         lk = ctx.link
         if lk is not None and "z" in lk:
             dx, part2 = ops.maxpool2_bwd(x, g_pool, add=g_skip, add2=g_ret, bn=(lk.pop("z"), lk.pop("save")))
             if part2 is not None:
                 lk["da"], lk["rec4"] = dx, part2
-            return dx, None, None
-        return ops.maxpool2_bwd(x, g_pool, add=g_skip, add2=g_ret), None, None
+            return dx, None, None, None
+        return ops.maxpool2_bwd(x, g_pool, add=g_skip, add2=g_ret), None, None, None
 
 
 def _pad_offsets(x1_hw, x2_hw):
@@ -218,7 +252,9 @@ class UpConvTCatFn(torch.autograd.Function):
     pixel-shuffle that writes straight into the second half of the concat buffer."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, packed, cat_holder=None):
+    def forward(ctx, x1, x2, weight, bias, packed, cat_holder=None, b16=None):
+        """b16 (bf16 storage): dict with "cat16" = the bf16 twin of the concat buffer whose skip half the encoder already
+        wrote; the up-sampled half is written here and b16["ok"] tells the caller whether the twin is complete."""
         ops.require_gpu(x1, x2, weight, bias)
         wp_fused, wp_dgrad = packed
         B, Cin, h, w = x1.shape
@@ -226,6 +262,17 @@ class UpConvTCatFn(torch.autograd.Function):
         C2, Ho, Wo = x2.shape[1], x2.shape[2], x2.shape[3]
         pt, pl = _pad_offsets((h, w), (Ho, Wo))
         cat = None if cat_holder is None else cat_holder[0]
+        if b16 is not None and b16.get("bf16_only") and b16.get("cat16") is not None:
+            # bf16 storage, the consuming convolution reads only the bf16 twin of the concat buffer: the skip half is there
+            # already (the encoder's BatchNorm wrote it), the up-sampled half goes there in bf16, and NO fp32 concat exists
+            cat16 = b16["cat16"]
+            if tuple(cat16.shape) == (B, C2 + Ct, Ho, Wo) and (Ho, Wo) == (2 * h, 2 * w) and \
+                    ops.convT2x2_fwd(x1, wp_fused, bias, None, Ct, pt, pl, out16=cat16[:, C2:]):
+                b16["ok"] = True
+                ctx.save_for_backward(x1, wp_dgrad)
+                ctx.meta = (C2, Ct, h, w, pt, pl, tuple(weight.shape), bias is not None)
+                ctx.params = (weight, bias)
+                return ops.fp32_placeholder((B, C2 + Ct, Ho, Wo), x1.device)
         in_place = (cat is not None and tuple(cat.shape) == (B, C2 + Ct, Ho, Wo) and C2 > 0
                     and x2.data_ptr() == cat.data_ptr() and x2.stride() == cat[:, :C2].stride())
         if not in_place:       # x2 is an ordinary tensor: torch.cat's copy of the skip half
@@ -235,7 +282,10 @@ class UpConvTCatFn(torch.autograd.Function):
         if (Ho, Wo) != (2 * h, 2 * w):
             for bi in range(B):                      # F.pad border (only when H or W is not a multiple of 16); raw
                 ops.fill(cat[bi, C2:], 0.0)          # fills: a torch in-place op on the base of the skip view is forbidden
-        ops.convT2x2_fwd(x1, wp_fused, bias, cat[:, C2:], Ct, pt, pl)
+        cat16 = None if (b16 is None or not in_place) else b16.get("cat16")
+        wrote = ops.convT2x2_fwd(x1, wp_fused, bias, cat[:, C2:], Ct, pt, pl, out16=None if cat16 is None else cat16[:, C2:])
+        if b16 is not None:
+            b16["ok"] = bool(wrote)
         ctx.save_for_backward(x1, wp_dgrad)
         ctx.meta = (C2, Ct, h, w, pt, pl, tuple(weight.shape), bias is not None)
         ctx.params = (weight, bias)
@@ -267,7 +317,7 @@ class UpConvTCatFn(torch.autograd.Function):
                 dw = ops.conv_wgrad(x1, dsub, wshape, 1, out_layout=1)
             if need_x1:
                 dx1 = ops.conv_fwd(dsub, wp_dgrad, wshape[0], 1)
-        return dx1, dx2, dw, db, None, None
+        return dx1, dx2, dw, db, None, None, None
 
 
 class UpBilinearCatFn(torch.autograd.Function):

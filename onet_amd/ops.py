@@ -34,6 +34,8 @@ def plane(t):
     """-> (tensor, batch_stride) with the (C,H,W) block of every image contiguous.
     Channel-slices of a concat buffer qualify as they are; anything else is copied."""
     B, C, H, W = t.shape
+    if W > 1 and t.stride(3) == 0:
+        raise RuntimeError("onet_amd: an fp32 placeholder (bf16 storage: tensor kept in bf16 only) reached a kernel that reads fp32")
     ok = (W == 1 or t.stride(3) == 1) and (H == 1 or t.stride(2) == W) and (C == 1 or t.stride(1) == H * W)
     if ok and B > 1 and t.stride(0) < C * H * W:
         ok = False
@@ -181,18 +183,33 @@ def packT2x2_fused(w):
     return wq
 
 
-def convT2x2_fwd(x, wq, bias, out, Ct, pt, pl):
+def convT2x2_fwd(x, wq, bias, out, Ct, pt, pl, out16=None):
     """out[:, c, pt + 2i + di, pl + 2j + dj] = sum_ci x[:, ci, i, j] * W[ci, c, di, dj] + bias[c]: ConvTranspose2d(k=2, s=2)
-    written straight into `out`, a plane-contiguous [B, Ct, Ho, Wo] view (e.g. the second half of a concat buffer)."""
+    written straight into `out`, a plane-contiguous [B, Ct, Ho, Wo] view (e.g. the second half of a concat buffer).
+    out16: the matching bf16 view (bf16 storage) -> returns True if the copy was written (128 x 128 GEMM path only)."""
     require_gpu(x, wq, out)
     x, xbs = plane(x)
     B, Cin, h, w = x.shape
-    Ho, Wo = out.shape[2], out.shape[3]
-    obs = out.stride(0) if B > 1 else Ct * Ho * Wo
+    ref = out if out is not None else out16          # out None (with out16): bf16 output only -- returns False if not possible
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    obs = 0 if out is None else (out.stride(0) if B > 1 else Ct * Ho * Wo)
+    flops, nb = 2.0 * B * h * w * Cin * 4 * Ct, 4.0 * (B * h * w * (Cin + 4 * Ct) + 4 * Cin * Ct)
+    if out16 is not None:
+        o16bs = out16.stride(0) if B > 1 else Ct * Ho * Wo
+        e0 = _prof_begin()
+        rc = _lib.load().onet_convT2x2_fwd_b(_p(x), xbs, _p(wq), _p(bias), _p(out), obs, _p(out16), o16bs, B, Cin, Ct, h, w, Ho, Wo,
+                                             pt, pl, _stream())
+        _prof_end("conv_fwd_kernel", flops if rc == 0 else 0.0, e0, nb if rc == 0 else 0.0)
+        if rc == 0:
+            return True
+        if rc < 0:
+            raise _lib.OnetHipError(f"onet_convT2x2_fwd_b failed ({rc}): {_lib.last_error()}")
+    if out is None:
+        return False
     e0 = _prof_begin()
     _lib.call("onet_convT2x2_fwd", _p(x), xbs, _p(wq), _p(bias), _p(out), obs, B, Cin, Ct, h, w, Ho, Wo, pt, pl, _stream())
-    _prof_end("conv_fwd_kernel", 2.0 * B * h * w * Cin * 4 * Ct, e0, 4.0 * (B * h * w * (Cin + 4 * Ct) + 4 * Cin * Ct))
-    return out
+    _prof_end("conv_fwd_kernel", flops, e0, nb)
+    return False
 
 
 # 3x3 convolution algorithm for fwd/dgrad, chosen per call from the layer shape (ONET_CONV_ALGO overrides):
@@ -210,6 +227,58 @@ CONV_ALGO = _os.environ.get("ONET_CONV_ALGO", "auto")
 # other, as the reference does.
 TWIN = _os.environ.get("ONET_TWIN", "1") != "0"
 _N_CU = 256
+
+
+# bf16 STORAGE of the conv operands (only with CONV_ALGO == "bf16", BASELINE config 3): the kernels that produce an
+# activation or a pre-activation gradient also write a bf16 copy, and the bf16 conv kernels read that copy instead of rounding
+# the fp32 tensor on the way into LDS -- same rounding (nearest even), so bit-identical results at half the operand bytes.
+# A tensor carries its copy as `t._onet_b16 = (bf16 tensor, t._version)`.  ONET_BF16_STORAGE=0 keeps fp32 operands.
+BF16_STORAGE = _os.environ.get("ONET_BF16_STORAGE", "1") != "0"
+BF = torch.bfloat16
+
+
+def bf16_storage():
+    return BF16_STORAGE and CONV_ALGO == "bf16"
+
+
+def b16_of(t):
+    """The valid bf16 copy riding on fp32 tensor `t`, or None."""
+    tag = getattr(t, "_onet_b16", None)
+    if tag is None or not bf16_storage():
+        return None
+    t16, ver = tag
+    if ver != t._version or tuple(t16.shape) != tuple(t.shape) or t16.dtype != BF:
+        return None
+    return t16
+
+
+def tag_b16(t, t16):
+    if t16 is not None:
+        t._onet_b16 = (t16, t._version)
+    return t
+
+
+def consumer_reads_bf16(B, Cin, Cout, H, W):
+    """Will a 3x3 convolution (Cin -> Cout on B maps of H x W) read ONLY the bf16 copy of its input -- forward and weight
+    gradient both on the bf16 kernels?  Then the producer need not write the fp32 tensor at all."""
+    return bf16_storage() and conv3x3_algo(B, Cin, Cout, H, W) == "bf16" and wgrad_takes_bf16(Cin, H, W) and W % 8 == 0
+
+
+def fp32_placeholder(shape, device):
+    """A zero-stride fp32 tensor of the given shape (4 bytes of storage): what autograd passes around in place of an
+    activation whose only consumers read its bf16 copy (`_onet_b16`).  Never read by a kernel."""
+    return torch.empty(1, dtype=F32, device=device).as_strided(tuple(shape), (0,) * len(shape))
+
+
+def plane16(t):
+    """-> (bf16 tensor, batch stride in elements) if its (C,H,W) block is contiguous per image, else (None, 0)."""
+    if t is None:
+        return None, 0
+    B, C, H, W = t.shape
+    ok = (W == 1 or t.stride(3) == 1) and (H == 1 or t.stride(2) == W) and (C == 1 or t.stride(1) == H * W)
+    if not ok or (B > 1 and t.stride(0) < C * H * W):
+        return None, 0
+    return t, (t.stride(0) if B > 1 else C * H * W)
 
 
 def _wino_legal(Cin, Cout):
@@ -275,15 +344,17 @@ def pack3x3_auto(w):
     return Packed3x3(w)
 
 
-def conv3x3_auto(x, pk, direction, out=None):
-    """direction 0: forward (Cin -> Cout); 1: dgrad (Cout -> Cin) with the flipped/transposed pack."""
+def conv3x3_auto(x, pk, direction, out=None, x16=None):
+    """direction 0: forward (Cin -> Cout); 1: dgrad (Cout -> Cin) with the flipped/transposed pack.
+    x16: a bf16 copy of x (bf16 storage); x itself may then be None (shape taken from x16)."""
     Ci, Co = (pk["Cin"], pk["Cout"]) if direction == 0 else (pk["Cout"], pk["Cin"])
-    algo = conv3x3_algo(x.shape[0], Ci, Co, x.shape[2], x.shape[3])
+    shp = (x if x is not None else x16).shape
+    algo = conv3x3_algo(shp[0], Ci, Co, shp[2], shp[3])
     wq = pk.get_pack(algo)[direction]
     if algo == "winograd4":
         return conv3x3_winograd4(x, wq, Co, out=out)
     if algo == "bf16":
-        return conv3x3_bf16(x, wq, Co, out=out)
+        return conv3x3_bf16(x, wq, Co, out=out, x16=x16)
     if algo == "winograd":
         return conv3x3_winograd(x, wq, Co, out=out)
     return conv_fwd(x, wq, Co, 3, out=out)
@@ -292,7 +363,7 @@ def conv3x3_auto(x, pk, direction, out=None):
 FUSE_BN_STATS = _os.environ.get("ONET_FUSE_BN_STATS", "1") != "0"
 
 
-def conv3x3_fwd_bn_partials(x, pk):
+def conv3x3_fwd_bn_partials(x, pk, x16=None):
     """Forward 3x3 convolution of a Conv-BatchNorm pair (OV:47-48, 51-52): -> (z, cm).  cm = the channel-major
     BatchNorm records [Cout, nparts, 3] the F(4x4) kernel's epilogue emits (image-major: nparts / B per image), or None
     where the selected kernel does not emit them (then `bn_train_coeffs` runs its own statistics pass)."""
@@ -303,7 +374,7 @@ def conv3x3_fwd_bn_partials(x, pk):
     if algo == "winograd4" and FUSE_BN_STATS and not SYNC_BN:
         nparts = int(_lib.load().onet_conv3x3_winograd4_nparts(B, H, W))
     if nparts <= 0:
-        return conv3x3_auto(x, pk, 0), None
+        return conv3x3_auto(x, pk, 0, x16=x16), None
     wq = pk.get_pack(algo)[0]
     require_gpu(x, wq)
     x, xbs = plane(x)
@@ -412,19 +483,31 @@ def pack3x3_bf16(w):
     return wf, wd
 
 
-def conv3x3_bf16(x, wq, Cout, out=None):
-    """z = conv3x3(x) with bf16 operands (x rounded on load, wq packed bf16), fp32 accumulation and output."""
-    require_gpu(x)
+def conv3x3_bf16(x, wq, Cout, out=None, x16=None):
+    """z = conv3x3(x) with bf16 operands (x rounded on load, wq packed bf16), fp32 accumulation and output.
+    x16: a bf16 copy of x written by its producer (bf16 storage): read instead of x -- same rounding, half the bytes."""
     if wq is None or not wq.is_cuda or wq.dtype != torch.bfloat16:
         raise TypeError("conv3x3_bf16: wq must be a bf16 pack on the GPU (pack3x3_bf16)")
-    x, xbs = plane(x)
-    B, Cin, H, W = x.shape
+    x16, x16bs = plane16(x16)
+    if x16 is not None:
+        B, Cin, H, W = x16.shape
+        dev = x16.device
+    else:
+        require_gpu(x)
+        x, xbs = plane(x)
+        B, Cin, H, W = x.shape
+        dev = x.device
     if out is None:
-        out = torch.empty((B, Cout, H, W), dtype=F32, device=x.device)
+        out = torch.empty((B, Cout, H, W), dtype=F32, device=dev)
     zbs = out.stride(0) if B > 1 else Cout * H * W
     e0 = _prof_begin()
-    _lib.call("onet_conv3x3_bf16_fwd", _p(x), xbs, _p(wq), _p(out), zbs, B, Cin, Cout, H, W, _stream())
-    _prof_end("conv3x3_bf16_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
+    if x16 is not None:
+        _lib.call("onet_conv3x3_bf16_fwd_b", _p(x16), x16bs, _p(wq), _p(out), zbs, B, Cin, Cout, H, W, _stream())
+        nb = B * H * W * (2.0 * Cin + 4.0 * Cout) + 18.0 * Cin * Cout
+    else:
+        _lib.call("onet_conv3x3_bf16_fwd", _p(x), xbs, _p(wq), _p(out), zbs, B, Cin, Cout, H, W, _stream())
+        nb = 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout)
+    _prof_end("conv3x3_bf16_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, nb)
     return out
 
 
@@ -490,28 +573,53 @@ def winograd4_wgrad_ok(x, dz):
         x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and dz.is_contiguous()
 
 
-def conv3x3_wgrad_bf16(x, dz, dw_shape, out=None):
-    """dW of a 3x3 convolution with bf16 operands (x, dz rounded on the way into LDS), fp32 accumulation."""
-    require_gpu(x, dz)
-    x, xbs = plane(x)
-    dz, dzbs = plane(dz)
-    B, Cin, H, W = x.shape
-    Cout = dz.shape[1]
-    dw = torch.empty(dw_shape, dtype=F32, device=x.device) if out is None else out
+def conv3x3_wgrad_bf16(x, dz, dw_shape, out=None, x16=None, dz16=None):
+    """dW of a 3x3 convolution with bf16 operands (x, dz rounded on the way into LDS), fp32 accumulation.
+    x16 / dz16: bf16 copies written by the producers (bf16 storage), read instead of the fp32 tensors where given (the
+    fp32 argument may then be None)."""
+    x16, x16bs = plane16(x16)
+    dz16, dz16bs = plane16(dz16)
+    ref_x, ref_dz = (x16 if x16 is not None else x), (dz16 if dz16 is not None else dz)
+    B, Cin, H, W = ref_x.shape
+    Cout = ref_dz.shape[1]
+    if (x16 is not None or dz16 is not None) and (W % 8 or (x16 is not None and (x16bs % 8 or x16.data_ptr() % 16)) or
+                                                  (dz16 is not None and (dz16bs % 8 or dz16.data_ptr() % 16))):
+        if x is None or dz is None:
+            raise ValueError("conv3x3_wgrad_bf16: bf16 operands need W % 8 == 0 and 16-byte aligned rows")
+        x16 = dz16 = None
+    if x16 is None:
+        require_gpu(x)
+        x, xbs = plane(x)
+    if dz16 is None:
+        require_gpu(dz)
+        dz, dzbs = plane(dz)
+    dev = ref_x.device
+    dw = torch.empty(dw_shape, dtype=F32, device=dev) if out is None else out
     need = _lib.load().onet_conv3x3_wgrad_bf16_ws_bytes(B, Cin, Cout, H, W)
-    ws = workspace(need, x.device)
+    ws = workspace(need, dev)
     e0 = _prof_begin()
-    _lib.call("onet_conv3x3_wgrad_bf16", _p(x), xbs, _p(dz), dzbs, _p(dw), _p(ws), ws.numel() * 4, B, Cin, Cout, H, W, 0,
-              _stream())
-    _prof_end("conv3x3_wgrad_bf16_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
+    if x16 is None and dz16 is None:
+        _lib.call("onet_conv3x3_wgrad_bf16", _p(x), xbs, _p(dz), dzbs, _p(dw), _p(ws), ws.numel() * 4, B, Cin, Cout, H, W, 0,
+                  _stream())
+    else:
+        _lib.call("onet_conv3x3_wgrad_bf16_b", _p(x16 if x16 is not None else x), int(x16 is not None),
+                  x16bs if x16 is not None else xbs, _p(dz16 if dz16 is not None else dz), int(dz16 is not None),
+                  dz16bs if dz16 is not None else dzbs, _p(dw), _p(ws), ws.numel() * 4, B, Cin, Cout, H, W, 0, _stream())
+    nb = B * H * W * ((2.0 if x16 is not None else 4.0) * Cin + (2.0 if dz16 is not None else 4.0) * Cout) + 36.0 * Cin * Cout
+    _prof_end("conv3x3_wgrad_bf16_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, nb)
     return dw
 
 
-def conv3x3_wgrad_auto(x, dz, dw_shape, out=None):
+def wgrad_takes_bf16(Cin, H, W):
+    """Does conv3x3_wgrad_auto route this layer to the bf16 weight-gradient kernel (given contiguous dz)?"""
+    return CONV_ALGO == "bf16" and Cin >= 16 and W >= 16 and W % 4 == 0 and H >= 8
+
+
+def conv3x3_wgrad_auto(x, dz, dw_shape, out=None, x16=None, dz16=None):
     Cout, Cin = dw_shape[0], dw_shape[1]
-    if (CONV_ALGO == "bf16" and Cin >= 16 and x.shape[3] >= 16 and x.shape[3] % 4 == 0 and x.shape[2] >= 8
-            and dz.is_contiguous()):
-        return conv3x3_wgrad_bf16(x, dz, dw_shape, out=out)
+    shp = (x if x is not None else x16).shape
+    if wgrad_takes_bf16(Cin, shp[2], shp[3]) and (dz16 is not None or dz.is_contiguous()):
+        return conv3x3_wgrad_bf16(x, dz, dw_shape, out=out, x16=x16, dz16=dz16)
     if use_winograd(Cin, Cout, x.shape[2], x.shape[3]):
         if WGRAD4 != "0" and (WGRAD4 == "1" or Cin >= 256 or (Cin >= 128 and Cout >= 256)) and winograd4_wgrad_ok(x, dz):
             return conv3x3_winograd4_wgrad(x, dz, dw_shape, out=out)
@@ -618,23 +726,38 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps, save=None):
     return save
 
 
-def bn_relu_apply(z, save, out=None):
+def bn_relu_apply(z, save, out=None, out16=None, no_fp32=False):
+    """a = relu(bn(z)); out16: plane-contiguous bf16 destination for a copy of a (bf16 storage of the conv operands);
+    no_fp32 (with out16): write the bf16 copy ONLY and return None."""
     z, zbs = plane(z)
     B, C, H, W = z.shape
+    if out16 is not None and no_fp32:
+        o16bs = out16.stride(0) if B > 1 else C * H * W
+        _lib.call("onet_bn_relu_apply_b", _p(z), zbs, None, 0, _p(out16), o16bs, _p(save), B, C, H * W, _stream(),
+                  nbytes=6 * z.numel())
+        return None
     if out is None:
         out = torch.empty((B, C, H, W), dtype=F32, device=z.device)
     abs_ = out.stride(0) if B > 1 else C * H * W
+    if out16 is not None:
+        o16bs = out16.stride(0) if B > 1 else C * H * W
+        _lib.call("onet_bn_relu_apply_b", _p(z), zbs, _p(out), abs_, _p(out16), o16bs, _p(save), B, C, H * W, _stream(),
+                  nbytes=10 * z.numel())
+        return out
     _lib.call("onet_bn_relu_apply", _p(z), zbs, _p(out), abs_, _p(save), B, C, H * W, _stream(), nbytes=8 * z.numel())
     return out
 
 
-def bn_relu_bwd(da, z, save, training, need_affine_grads=True, out=None, acc=None, affine_out=None, red=None, red4=None):
+def bn_relu_bwd(da, z, save, training, need_affine_grads=True, out=None, acc=None, affine_out=None, red=None, red4=None,
+                out16=None):
     """-> dz, dgamma, dbeta.  `out`: plane-contiguous destination for dz (a batch slice of a larger buffer);
     `acc` = (dgamma, dbeta) of another statistics group of the same layer to accumulate into; `affine_out` =
     (dgamma, dbeta) destinations to overwrite (None entries are allocated); `red` = (records [C, NP, 2], first, count):
     the (sum dy, sum dy*xhat) records of this batch slice were already written by the dgrad launch that produced
     `da` (`conv3x3_dgrad_bnreduce`), so the reduce pass over (da, z) is skipped; `red4` = (records [NP, C, 4], first,
-    count): the same in the reduce kernel's own record format (written by the pooling-backward kernel)."""
+    count): the same in the reduce kernel's own record format (written by the pooling-backward kernel).
+    `out16`: plane-contiguous bf16 destination -- dz is then written in bf16 ONLY (its consumers are the bf16 dgrad and
+    weight-gradient kernels) and the returned dz is None."""
     da, dabs = plane(da)
     z, zbs = plane(z)
     B, C, H, W = z.shape
@@ -680,6 +803,11 @@ def bn_relu_bwd(da, z, save, training, need_affine_grads=True, out=None, acc=Non
             _lib.call("onet_bn_bwd_finalize", _p(part2), nparts, B * HW, _p(dgamma), _p(dbeta), None, accf, C, _stream())
             _lib.call("onet_bn_bwd_finalize", _p(gathered), nparts * world, B * HW * world, None, None, _p(coef), 0, C,
                       _stream())
+    if out16 is not None:
+        o16bs = out16.stride(0) if B > 1 else C * HW
+        _lib.call("onet_bn_relu_bwd_apply_b", _p(da), dabs, _p(z), zbs, _p(save), _p(coef), None, 0, _p(out16), o16bs, B, C, HW,
+                  _stream(), nbytes=10 * z.numel())
+        return None, dgamma, dbeta
     dz = torch.empty((B, C, H, W), dtype=F32, device=dev) if out is None else out
     dzbs = dz.stride(0) if B > 1 else C * HW
     _lib.call("onet_bn_relu_bwd_apply", _p(da), dabs, _p(z), zbs, _p(save), _p(coef), _p(dz), dzbs, B, C, HW,
@@ -688,9 +816,22 @@ def bn_relu_bwd(da, z, save, training, need_affine_grads=True, out=None, acc=Non
 
 
 # ----------------------------------------------------------------------------- pool / up / cat
-def maxpool2_fwd(x):
+def maxpool2_fwd(x, bf16_only=False):
+    """y = MaxPool2d(2)(x); under bf16 storage y carries a bf16 copy for the convolution that consumes it.  bf16_only: the
+    consumer reads nothing else -- y is a placeholder (even, 8-byte aligned maps; otherwise the flag is ignored)."""
     x, xbs = plane(x)
     B, C, H, W = x.shape
+    if bf16_storage() and B * C * (H // 2) * (W // 2) > 0:
+        bf16_only = bf16_only and W % 2 == 0 and xbs % 2 == 0 and x.data_ptr() % 8 == 0
+        y = fp32_placeholder((B, C, H // 2, W // 2), x.device) if bf16_only else \
+            torch.empty((B, C, H // 2, W // 2), dtype=F32, device=x.device)
+        y16 = torch.empty((B, C, H // 2, W // 2), dtype=BF, device=x.device)
+        lib = _lib.load()
+        rc = lib.onet_maxpool2_fwd_b(_p(x), xbs, None if bf16_only else _p(y), C * (H // 2) * (W // 2), _p(y16),
+                                     C * (H // 2) * (W // 2), B, C, H, W, _stream())
+        if rc < 0:
+            raise _lib.OnetHipError(f"onet_maxpool2_fwd_b failed ({rc}): {_lib.last_error()}")
+        return tag_b16(y, y16 if rc == 0 else None)
     y = torch.empty((B, C, H // 2, W // 2), dtype=F32, device=x.device)
     _lib.call("onet_maxpool2_fwd", _p(x), xbs, _p(y), C * (H // 2) * (W // 2), B, C, H, W, _stream(), nbytes=5 * x.numel())
     return y

@@ -172,6 +172,46 @@ def test_bf16_conv_path_vs_reference_golden(dev, monkeypatch):
     print(f"bf16 path: loss rel {rel:.2e}, worst gradient-norm error {worst:.2e}")
 
 
+@pytest.mark.parametrize("shape", [(2, 1, 256, 256), (3, 1, 64, 96)])
+def test_bf16_storage_is_bit_identical_to_rounding_on_load(dev, shape, monkeypatch):
+    """BASELINE config 3 with bf16 STORAGE of the conv operands (the BatchNorm / pooling / ConvTranspose2d kernels write bf16
+    copies next to their fp32 outputs, the BatchNorm backward writes dz in bf16 only; the bf16 conv kernels read those): the
+    producers round to nearest even exactly as the conv kernels do on the way into LDS, so loss, outputs and every gradient
+    must be BIT-IDENTICAL to the fp32-storage bf16 path -- and the copies must really be used."""
+    from onet_amd import ops
+    monkeypatch.setattr(ops, "CONV_ALGO", "bf16")
+    B, C, H, W = shape
+    X = orc.det_input(B, C, H, W, seed=12).to(dev)
+    res, used = {}, {}
+    for storage in (False, True):
+        monkeypatch.setattr(ops, "BF16_STORAGE", storage)
+        cnt = {"fwd16": 0, "wg16": 0}
+        rf, rw = ops.conv3x3_bf16, ops.conv3x3_wgrad_bf16
+
+        def f(*a, _r=rf, **k):
+            cnt["fwd16"] += k.get("x16") is not None
+            return _r(*a, **k)
+
+        def wg(*a, _r=rw, **k):
+            cnt["wg16"] += (k.get("x16") is not None) + (k.get("dz16") is not None)
+            return _r(*a, **k)
+
+        monkeypatch.setattr(ops, "conv3x3_bf16", f)
+        monkeypatch.setattr(ops, "conv3x3_wgrad_bf16", wg)
+        m = _model(C, True, dev)
+        (Lt, Vt, Ld, Vd, S), loss = _step(m, X)
+        res[storage] = (loss.detach().clone(), S.detach().clone(), Lt.detach().clone(), [p.grad.detach().clone() for p in m.parameters()])
+        used[storage] = dict(cnt)
+        monkeypatch.setattr(ops, "conv3x3_bf16", rf)
+        monkeypatch.setattr(ops, "conv3x3_wgrad_bf16", rw)
+    assert used[False] == {"fwd16": 0, "wg16": 0}
+    assert used[True]["fwd16"] >= 20 and used[True]["wg16"] >= 20, used     # forward + dgrad launches, weight-gradient operands
+    a, b = res[False], res[True]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for ga, gb in zip(a[3], b[3]):
+        assert torch.equal(ga, gb)
+
+
 def test_deferred_nan_assertion(dev, monkeypatch):
     """OV:234's "jsd is not NaN" assertion: in place by default (AssertionError out of compute_loss); with
     ops.LAZY_NAN_CHECK (training loops that own the optimizer step) the same AssertionError comes out of

@@ -253,11 +253,16 @@ def test_conv3x3_bf16_operands(dev, B, Cin, Cout, H, W):
     sc = float(z_full.abs().max())
     assert float((z - z_ref).abs().max()) <= 1e-5 * sc, "fwd vs bf16-rounded operands"
     assert float((z - z_full).abs().max()) <= 2e-2 * sc, "fwd vs full precision"
+    # bf16 STORAGE of the operand: the producer's bf16 copy (rounded to nearest even, as torch does) read instead of x
+    z16 = ops.conv3x3_bf16(None, qf, Cout, x16=x.to(dev).to(torch.bfloat16))
+    assert torch.equal(z16.cpu().double(), z), "bf16-storage forward must be bit-identical to rounding on load"
     if Cout % 16 == 0:
         dx = ops.conv3x3_bf16(g.to(dev), qd, Cin).cpu().double()
         dx_ref = F.conv_transpose2d(rb(g), rb(w), None, 1, 1)
         sc = float(dx_ref.abs().max())
         assert float((dx - dx_ref).abs().max()) <= 1e-5 * sc, "dgrad vs bf16-rounded operands"
+        dx16 = ops.conv3x3_bf16(None, qd, Cin, x16=g.to(dev).to(torch.bfloat16))
+        assert torch.equal(dx16.cpu().double(), dx)
     else:
         assert qd is None
 
@@ -292,6 +297,13 @@ def test_conv3x3_wgrad_bf16_operands(dev, B, Cin, Cout, H, W):
     full = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), g.double(), stride=1, padding=1)
     sc = float(full.abs().max())
     assert float((dw - ref).abs().max()) <= 2e-5 * sc, "vs bf16-rounded operands"
+    if W % 8 == 0:          # bf16 STORAGE of either or both operands: bit-identical to rounding on load
+        x16, g16 = x.to(dev).to(torch.bfloat16), g.to(dev).to(torch.bfloat16)
+        for kw in ({"x16": x16}, {"dz16": g16}, {"x16": x16, "dz16": g16}):
+            d2 = ops.conv3x3_wgrad_bf16(x.to(dev), g.to(dev), (Cout, Cin, 3, 3), **kw)
+            assert torch.equal(d2.cpu().double(), dw), sorted(kw)
+        d3 = ops.conv3x3_wgrad_bf16(None, None, (Cout, Cin, 3, 3), x16=x16, dz16=g16)
+        assert torch.equal(d3.cpu().double(), dw)
     assert float((dw - full).abs().max()) <= 2e-2 * sc, "vs full precision"
 
 
