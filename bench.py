@@ -187,8 +187,10 @@ def main():
     ops.profile_start(everything=not args.mfma_events_only)
     dev_allocs0 = int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0))
     t0 = time.perf_counter()
+    allocs_per_step = []
     for _ in range(args.steps):
         loss = train_step(onet, opt, X)
+        allocs_per_step.append(int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0)))     # host-side counter, no sync
     barrier()
     elapsed = time.perf_counter() - t0
     prof, prof_all = ops.profile_stop()
@@ -285,6 +287,7 @@ def main():
                "hbm_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 2),
                "alloc_retries": int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0)),
                "device_allocs_in_timed_steps": int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0)) - dev_allocs0,
+               "device_allocs_per_timed_step": [b - a for a, b in zip([dev_allocs0] + allocs_per_step, allocs_per_step)],
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(X_cpu, args.cpu_seconds)

@@ -35,6 +35,19 @@ struct PerDeviceOnce {
     }
 };
 
+// compute units of the current device (persistent-grid launches); cached per device
+inline int device_cu_count() {
+    static std::atomic<int> cached[64];
+    int d = 0;
+    (void)hipGetDevice(&d);
+    int n = cached[d & 63].load(std::memory_order_relaxed);
+    if (n <= 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256;
+        cached[d & 63].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
 // wave64 reductions via DPP/shuffles
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {

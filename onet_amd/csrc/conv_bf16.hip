@@ -6,14 +6,21 @@
 // GEMM view as in conv_mfma.hip: D[co][pix] = sum_{tap, ci} W[ci][tap][co] * X[ci][pix + tap], M = output channels,
 // N = 32 consecutive pixels of an image row, K = 16 input channels per MFMA.  What bf16 changes:
 //  * an MFMA operand is 8 bf16 = 16 bytes per lane (A lane l -> A[i = l&31][k = 8*(l>>5) .. +7], B likewise), i.e. the
-//    8 K-values of a lane are 8 CHANNELS of one pixel / one output channel.  The LDS tiles are therefore
-//    channel-innermost: input halo tile [row][col][16 ch] bf16 (32 B per pixel), weights [tap][co][16 ch]; a fragment
-//    is ONE ds_read_b128 per lane, the 64 lanes of a wave covering 2 KB contiguously (conflict-free);
+//    8 K-values of a lane are 8 CHANNELS of one pixel / one output channel.  The LDS tiles are therefore made of 16-byte
+//    slots of 8 channels, the two 8-channel halves of a 16-channel chunk kept apart: input halo tile [half][row][col],
+//    weights [tap][half][co]; a fragment is ONE ds_read_b128 per lane and every 16-lane group of it reads 256 contiguous
+//    bytes (no bank conflicts: SQ_LDS_BANK_CONFLICT = 0);
 //  * the fp32 -> bf16 conversion (v_cvt_pk_bf16_f32, round-to-nearest-even) happens on the way into LDS: a staging
-//    thread gathers the 8 channel planes of ONE pixel (8 dword loads, each coalesced along x across the wave), packs
-//    them and stores 16 bytes; weights are packed to bf16 once per optimizer step (onet_conv3x3_pack_weights_bf16);
-//  * per 16-channel chunk a wave issues 9 taps x (2 A + NT B) ds_read_b128 for 9 x 2 x NT MFMAs of 32 cycles
-//    (NT = 2 image rows per wave: 64 accumulator registers, two 4-wave blocks per CU).
+//    thread gathers the 8 channel planes of ONE pixel (8 loads, each coalesced along x across the wave), packs them and
+//    stores 16 bytes; with bf16 STORAGE of the operand (XB) the loads are 2-byte loads of the producer's bf16 copy --
+//    the same values; weights are packed to bf16 once per optimizer step (onet_conv3x3_pack_weights_bf16);
+//  * per 16-channel chunk a wave issues 18 A + 3 x (NT + 2) B ds_read_b128 for 9 x 2 x NT MFMAs of 32 cycles
+//    (NT = 2 image rows per wave: 64 accumulator registers, two 4-wave blocks per CU), the reads one tap ahead of the MFMAs;
+//  * blocks are persistent and the load -> LDS -> MFMA pipeline runs across tile boundaries (see the kernel).
+//  Measured limits (tools/time_bf16.py, ablation builds -DONET_BF_ABL=n, B = 64): removing the input loads saves 24-30 %, the
+//  stores 23 %, the MFMAs 19 % -- no single resource is saturated; the chunk period follows the global-load latency (loads are
+//  issued one chunk = 0.5-1 us of MFMA work ahead).  8-byte quad loads with an in-register transpose (a quarter of the load
+//  instructions) changed nothing (2.85 vs 2.80 ms over the six layer shapes) and were dropped.
 // Requires Cin % 16 == 0 (K never straddles a chunk) and W > 16; everything else takes the fp32 kernels.
 #include <algorithm>
 #include <cstdlib>
@@ -29,6 +36,12 @@ typedef float f32x4b __attribute__((ext_vector_type(4)));
 
 constexpr unsigned OOB_B = 0x80000000u;
 
+// experiments (tools/time_bf16.py, onet_amd.build --variant): 1 no global loads after the first chunk, 2 also no LDS commits,
+// 3 no MFMAs, 4 no epilogue stores.  Wrong results by construction; 0 in every shipped build.
+#ifndef ONET_BF_ABL
+#define ONET_BF_ABL 0
+#endif
+
 static __device__ __forceinline__ __amdgpu_buffer_rsrc_t b_rsrc(const void* base, int64_t bytes) {
     const int n = bytes > 0x7fffffffll ? 0x7fffffff : (int)bytes;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000);
@@ -38,20 +51,24 @@ static __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     return __builtin_bit_cast(unsigned, v);
 }
 
-// w [Cout][Cin][3][3] fp32 -> wf [Cin/16][9][Cout][16] bf16 (forward), wd [Cout16/16][9][Cin][16] bf16 with the taps
-// rotated by 180 degrees (input gradient = the same kernel with the roles of Cin and Cout swapped); the channel tail
-// of wd (Cout % 16 != 0) is zero-filled
+// w [Cout][Cin][3][3] fp32 -> wf [Cin/16][9][2][Cout][8] bf16 (forward: chunk of 16 input channels, tap, 8-channel half,
+// output channel, channel within the half), wd [Cout16/16][9][2][Cin][8] bf16 with the taps rotated by 180 degrees (input
+// gradient = the same kernel with the roles of Cin and Cout swapped); the channel tail of wd (Cout % 16 != 0) is zero-filled.
+// The 8-channel halves are the two K-halves of an MFMA operand (lanes 0-31 / 32-63): keeping each half contiguous over the
+// output channels makes both the global load and the LDS fragment read of a 16-lane group one contiguous 256-byte run.
 __global__ void pack3x3_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wf, __bf16* __restrict__ wd,
                                     int Cout, int Cin, int which) {
     const int K = which == 0 ? Cin : ((Cout + 15) / 16) * 16, N = which == 0 ? Cout : Cin;
     const int64_t n = (int64_t)K * 9 * N;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int kc = (int)(i & 15);
-        int64_t r = i >> 4;
+        const int kc = (int)(i & 7);
+        int64_t r = i >> 3;
         const int nn = (int)(r % N);
         r /= N;
+        const int half = (int)(r & 1);
+        r >>= 1;
         const int t = (int)(r % 9), kg = (int)(r / 9);
-        const int k = kg * 16 + kc;
+        const int k = kg * 16 + half * 8 + kc;
         float v = 0.f;
         if (which == 0) v = w[((int64_t)nn * Cin + k) * 9 + t];
         else if (k < Cout) v = w[((int64_t)k * Cin + nn) * 9 + (8 - t)];
@@ -62,88 +79,120 @@ __global__ void pack3x3_bf16_kernel(const float* __restrict__ w, __bf16* __restr
 struct BfArgs {
     const void* x;        // fp32 NCHW, or bf16 NCHW (XB kernels: bf16 STORAGE of the operand, written by the BatchNorm / pooling /
     int64_t x_bs;         // ConvTranspose2d kernels next to their fp32 outputs; strides in elements)
-    const __bf16* wq;     // [Cin/16][9][Cout][16]
+    const __bf16* wq;     // [Cin/16][9][2][Cout][8]
     float* z;
     int64_t z_bs;
     int B, Cin, Cout, H, W, tilesX, tilesY, coTiles;
 };
 
+// LDS, per 16-channel chunk (two such buffers: the next chunk is committed while the current one is read):
+//   weights [9 taps][2 halves][64 co] and the input halo tile [2 halves][NPIXP pixels], one 16-byte slot (8 bf16 channels) each.
+// A fragment read (ds_read_b128) of a 16-lane group is then 16 consecutive slots = 256 contiguous bytes = all 64 banks once;
+// the interleaved [pixel][half] order of the first version of this kernel put the 16 lanes 32 bytes apart (2-way conflict on
+// every read: SQ_LDS_BANK_CONFLICT = 40 % of SQ_LDS_IDX_ACTIVE).
 template <int NT, int TW_ = 32>
 struct BfCfg {
     static constexpr int TW = TW_, RPT = 32 / TW;                      // image rows per 32-pixel MFMA column tile
     static constexpr int CO_T = 64, ROWS = 4 * NT * RPT;               // 4 waves x NT column tiles (TW = 16: 2 rows each)
     static constexpr int IN_ROWS = ROWS + 2, IN_COLS = TW + 2;
-    static constexpr int IN_ITEMS = IN_ROWS * IN_COLS * 2;            // (pixel, 8-channel half) = one 16-byte LDS slot
-    static constexpr int NIT = (IN_ITEMS + 255) / 256;
-    static constexpr int W_ITEMS = 9 * CO_T * 2;                       // 16-byte slots of the weight slice
+    static constexpr int NPIX = IN_ROWS * IN_COLS;
+    static constexpr int NIT = (((NPIX + 31) / 32) * 64 + 255) / 256;  // staging rounds: 64 slots = 32 pixels x 2 halves per wave
+    static constexpr int NPIXP = NIT * 128;                            // pixel slots per half (padded: every staging slot exists)
+    static constexpr int W_ITEMS = 9 * 2 * CO_T;
     static constexpr int NWI = (W_ITEMS + 255) / 256;
-    static constexpr int LDS_BYTES = (IN_ITEMS + W_ITEMS) * 16;
+    static constexpr int W_SLOTS = NWI * 256;
+    static constexpr int BUF_SLOTS = W_SLOTS + 2 * NPIXP;
+    static constexpr int LDS_BYTES = 2 * BUF_SLOTS * 16;
+    static constexpr int NB = (NT - 1) * RPT + 3;                      // distinct B row-fragments per horizontal tap
 };
 
+// PERSISTENT blocks: a block walks over output tiles (tile = 64 output channels x ROWS x TW pixels of one image), and the chunk
+// pipeline -- global loads two 16-channel chunks ahead of the MFMAs, LDS commit one ahead -- runs ACROSS tile boundaries: while
+// a tile's accumulators are stored, the first two chunks of the next tile are already in LDS / in flight.  With one tile per
+// block (the first version) the 64- and 128-channel layers of the 256x256 level spent two thirds of their time in the
+// un-overlapped prologue (first loads) and epilogue (64 KB of stores per tile): 0.46 ms of 0.68 ms at 64 channels.
 template <int NT, int WPS, int TW = 32, bool XB = false>
 __global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
     using C = BfCfg<NT, TW>;
     constexpr int ROWS = C::ROWS, IN_COLS = C::IN_COLS, NIT = C::NIT, NWI = C::NWI, CO_T = C::CO_T, RPT = C::RPT;
+    constexpr int NPIXP = C::NPIXP, NB = C::NB, BUF = C::BUF_SLOTS;
+    constexpr int XE = XB ? 2 : 4;                                     // bytes per element of x
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    u32x4b* w_lds = reinterpret_cast<u32x4b*>(smem_b);                 // [9][64 co][2 halves]
-    u32x4b* in_lds = w_lds + C::W_ITEMS;                               // [IN_ROWS][IN_COLS][2 halves]
+    u32x4b* lds = reinterpret_cast<u32x4b*>(smem_b);                   // [2 buffers][weights W_SLOTS | input 2 x NPIXP]
 
-    int bid;
-    {   // XCD-aware tile order (see conv_mfma.hip)
-        const int n = gridDim.x, q = n >> 3, r = n & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    // tiles of this block: every XCD (blockIdx % 8) owns a contiguous range of the tile list (neighbouring tiles share halo
+    // rows and the weight slice in that XCD's L2); its blocks stride through the range
+    const int ntiles = a.tilesX * a.tilesY * a.B * a.coTiles;
+    int t_first, t_end, t_stride;
+    {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int q = ntiles >> 3, r = ntiles & 7;
+        const int start = xcd * q + min(xcd, r);
+        t_stride = (gridDim.x + 7 - xcd) >> 3;
+        t_first = start + j;
+        t_end = start + q + (xcd < r ? 1 : 0);
     }
-    const int tx = bid % a.tilesX;
-    bid /= a.tilesX;
-    const int ty = bid % a.tilesY;
-    bid /= a.tilesY;
-    const int b = bid % a.B;
-    const int coT = bid / a.B;
-    const int co0 = coT * CO_T, y0 = ty * ROWS, x0 = tx * TW;
+    if (t_first >= t_end) return;
 
-    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kh = lane >> 5;
     const int px = l31 % TW, py = l31 / TW;
     const int HW = a.H * a.W;
+    const int nchunks = a.Cin >> 4;
 
-    f32x16 acc[2][NT];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-
-    constexpr int XE = XB ? 2 : 4;                                     // bytes per element of x
-    const __amdgpu_buffer_rsrc_t xr = b_rsrc(static_cast<const char*>(a.x) + (int64_t)b * a.x_bs * XE, (int64_t)a.Cin * HW * XE);
     const __amdgpu_buffer_rsrc_t wr = b_rsrc(a.wq, (int64_t)a.Cin * 9 * a.Cout * 2);
-
-    // staging slots of this thread: (pixel, half) -> 8 channel planes; byte offset of channel 0 of the half
-    unsigned in_off[NIT];
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-        const int i = tid + 256 * k;
-        const int half = i & 1, p = i >> 1;
-        const int r = p / IN_COLS, c = p % IN_COLS;
-        const int yy = y0 - 1 + r, xx = x0 - 1 + c;
-        const bool ok = (i < C::IN_ITEMS) && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-        in_off[k] = ok ? (unsigned)(((half * 8) * HW + yy * a.W + xx) * XE) : OOB_B;
-    }
-    // weight slots: (tap, co, half) -> 16 bytes of the packed slice [chunk][tap][co][16]
-    unsigned w_off[NWI];
-#pragma unroll
-    for (int k = 0; k < NWI; ++k) {
-        const int i = tid + 256 * k;
-        const int half = i & 1, co = (i >> 1) % CO_T, t = (i >> 1) / CO_T;
-        const bool ok = (i < C::W_ITEMS) && (co0 + co < a.Cout);
-        w_off[k] = ok ? (unsigned)(((t * a.Cout + co0 + co) * 16 + half * 8) * 2) : OOB_B;
-    }
     const unsigned in_step = (unsigned)(16 * HW * XE), w_step = (unsigned)(9 * a.Cout * 16 * 2);
     const unsigned plane = (unsigned)(HW * XE);
 
+    // ---- staging side: runs two chunks ahead of the compute side, across tiles
+    // slots of this thread: round k, wave wn, lane -> (8-channel half = lane / 32, pixel = 32 * (wn + 4 k) + lane % 32): a wave
+    // loads 32 consecutive halo pixels of 8 channel planes (coalesced along x), and its ds_write_b128 puts every 16-lane group on
+    // 256 contiguous bytes; weight slots i = tid + 256 k = (tap, half, co) -> 16 bytes of the slice [chunk][tap][half][co][8]
+    unsigned in_off[NIT], w_off[NWI];
+    __amdgpu_buffer_rsrc_t xr;
+    int st_tile = t_first, st_chunk = 0;
+    unsigned cin_bytes = 0, cw_bytes = 0;
+    auto setup_stage = [&]() __attribute__((always_inline)) {
+        const bool live = st_tile < t_end;
+        int v = live ? st_tile : t_first;
+        const int tx = v % a.tilesX;
+        v /= a.tilesX;
+        const int ty = v % a.tilesY;
+        v /= a.tilesY;
+        const int b = v % a.B, co0 = (v / a.B) * CO_T;
+        const int y0 = ty * ROWS, x0 = tx * TW;
+        xr = b_rsrc(static_cast<const char*>(a.x) + (int64_t)b * a.x_bs * XE, (int64_t)a.Cin * HW * XE);
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int p = (wn + 4 * k) * 32 + l31;
+            const int r = p / IN_COLS, c = p % IN_COLS;
+            const int yy = y0 - 1 + r, xx = x0 - 1 + c;
+            const bool ok = live && p < C::NPIX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+            in_off[k] = ok ? (unsigned)(((kh * 8) * HW + yy * a.W + xx) * XE) : OOB_B;
+        }
+#pragma unroll
+        for (int k = 0; k < NWI; ++k) {
+            const int i = tid + 256 * k;
+            const int co = i & (CO_T - 1), th = i >> 6;                // th = tap * 2 + half
+            const bool ok = live && (i < C::W_ITEMS) && (co0 + co < a.Cout);
+            w_off[k] = ok ? (unsigned)((th * a.Cout + co0 + co) * 16) : OOB_B;
+        }
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
+        ++st_chunk;
+        cin_bytes += in_step;
+        cw_bytes += w_step;
+        if (st_chunk == nchunks) {
+            st_chunk = 0;
+            cin_bytes = cw_bytes = 0;
+            st_tile += t_stride;
+            setup_stage();                           // past the last tile: every slot out of range -> zeros, no traffic
+        }
+    };
+
     float xin[NIT][8];                               // XB: the low 16 bits hold the bf16 value
     u32x4b wv[NWI];
-    auto issue = [&](unsigned cin_bytes, unsigned cw_bytes) __attribute__((always_inline)) {
+    auto issue = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < NIT; ++k)
 #pragma unroll
@@ -159,73 +208,117 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
         for (int k = 0; k < NWI; ++k)
             wv[k] = __builtin_amdgcn_raw_buffer_load_b128(wr, w_off[k] + cw_bytes, 0, 0);
     };
-    auto commit = [&]() __attribute__((always_inline)) {
+    u32x4b* const w_st = lds + tid;                                    // + 256 k          (+ buffer * BUF)
+    u32x4b* const in_st = lds + C::W_SLOTS + kh * NPIXP + wn * 32 + l31;   // + 128 k
+    auto commit = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
-            const int i = tid + 256 * k;
-            if (i < C::IN_ITEMS) {
-                u32x4b v;
-                if constexpr (XB) {
-                    auto pk = [](float lo, float hi) { return __builtin_bit_cast(unsigned, lo) | (__builtin_bit_cast(unsigned, hi) << 16); };
-                    v = u32x4b{pk(xin[k][0], xin[k][1]), pk(xin[k][2], xin[k][3]), pk(xin[k][4], xin[k][5]), pk(xin[k][6], xin[k][7])};
-                } else {
-                    v = u32x4b{pack_bf16(xin[k][0], xin[k][1]), pack_bf16(xin[k][2], xin[k][3]),
-                               pack_bf16(xin[k][4], xin[k][5]), pack_bf16(xin[k][6], xin[k][7])};
-                }
-                in_lds[i] = v;
+            u32x4b v;
+            if constexpr (XB) {
+                auto pk = [](float lo, float hi) { return __builtin_bit_cast(unsigned, lo) | (__builtin_bit_cast(unsigned, hi) << 16); };
+                v = u32x4b{pk(xin[k][0], xin[k][1]), pk(xin[k][2], xin[k][3]), pk(xin[k][4], xin[k][5]), pk(xin[k][6], xin[k][7])};
+            } else {
+                v = u32x4b{pack_bf16(xin[k][0], xin[k][1]), pack_bf16(xin[k][2], xin[k][3]),
+                           pack_bf16(xin[k][4], xin[k][5]), pack_bf16(xin[k][6], xin[k][7])};
             }
+            in_st[buf * BUF + 128 * k] = v;          // padding slots (pixel >= NPIX) exist and receive zeros
         }
 #pragma unroll
-        for (int k = 0; k < NWI; ++k) {
-            const int i = tid + 256 * k;
-            if (i < C::W_ITEMS) w_lds[i] = wv[k];
-        }
+        for (int k = 0; k < NWI; ++k) w_st[buf * BUF + 256 * k] = wv[k];
     };
 
-    const u32x4b* a_ptr = w_lds + l31 * 2 + kh;                                   // + (tap * 64 + m * 32) * 2
-    const u32x4b* b_ptr = in_lds + ((wn * NT * RPT + py) * IN_COLS + px) * 2 + kh;   // + ((n * RPT + ky) * IN_COLS + kx) * 2
+    const u32x4b* const a_ptr = lds + kh * CO_T + l31;                                        // + (tap * 2) * 64 + m * 32
+    const u32x4b* const b_ptr = lds + C::W_SLOTS + kh * NPIXP + (wn * NT * RPT + py) * IN_COLS + px;   // + j * IN_COLS + kx
 
-    unsigned cin_bytes = 0, cw_bytes = 0;
-    issue(0, 0);
-    for (int c0 = 0; c0 < a.Cin; c0 += 16) {
-        commit();
-        __syncthreads();
-        cin_bytes += in_step;
-        cw_bytes += w_step;
-        issue(cin_bytes, cw_bytes);                  // next chunk (past the end: range check -> zeros, no traffic)
-        __builtin_amdgcn_sched_barrier(0);
+    setup_stage();
+    issue();
+    commit(0);
+    advance();
+    issue();                                         // second chunk (or the first of the next tile)
+    __syncthreads();
+    int buf = 0;
+    for (int tile = t_first; tile < t_end; tile += t_stride) {
+        f32x16 acc[2][NT];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int ky = t / 3, kx = t % 3;
-            bf16x8 av[2], bv[NT];
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int m = 0; m < 2; ++m) av[m] = __builtin_bit_cast(bf16x8, a_ptr[(t * CO_T + m * 32) * 2]);
+            for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int n = 0; n < NT; ++n) bv[n] = __builtin_bit_cast(bf16x8, b_ptr[((n * RPT + ky) * IN_COLS + kx) * 2]);
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+        for (int c = 0; c < nchunks; ++c) {
+            const u32x4b* const ab = a_ptr + buf * BUF;
+            const u32x4b* const bb = b_ptr + buf * BUF;
+            // Fragment reads run ONE tap ahead of the MFMAs that consume them (two register sets), the taps in kx-major order
+            // so that the NB row-fragments of a horizontal shift serve its three vertical taps; the row-fragments of the next
+            // shift are fetched during the three taps of the current one.
+            u32x4b Aq[2][2], Bq[2][NB];
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int j = 0; j < NB; ++j) Bq[0][j] = bb[j * IN_COLS];
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m], bv[n], acc[m][n], 0, 0, 0);
+            for (int m = 0; m < 2; ++m) Aq[0][m] = ab[m * 32];
+#pragma unroll
+            for (int idx = 0; idx < 9; ++idx) {
+                const int kx = idx / 3, ky = idx % 3;
+                if (idx < 8) {
+                    const int nt = ((idx + 1) % 3) * 3 + (idx + 1) / 3;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) Aq[(idx + 1) & 1][m] = ab[nt * 2 * CO_T + m * 32];
+                }
+                if (kx < 2) {
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+                        if (j % 3 == ky) Bq[(kx + 1) & 1][j] = bb[j * IN_COLS + kx + 1];
+                }
+                if (idx == 4) {
+                    // the other buffer was last read one chunk ago (barrier since): the chunk after this one goes in, and the
+                    // loads of the one after that take over the staging registers
+                    if (ONET_BF_ABL != 2) commit(buf ^ 1);
+                    advance();
+                    if (ONET_BF_ABL != 1 && ONET_BF_ABL != 2) issue();
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        if (ONET_BF_ABL == 3) {           // keep the fragment reads alive without the matrix pipe
+                            acc[m][n][0] += __builtin_bit_cast(float, Aq[idx & 1][m][0] ^ Bq[kx & 1][n * RPT + ky][0]);
+                            continue;
+                        }
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Aq[idx & 1][m]),
+                                                                            __builtin_bit_cast(bf16x8, Bq[kx & 1][n * RPT + ky]), acc[m][n], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+            buf ^= 1;
         }
-        __syncthreads();
-    }
 
-    float* zb = a.z + (int64_t)b * a.z_bs;
-    const int xo = x0 + px;
+        int v = tile;
+        const int tx = v % a.tilesX;
+        v /= a.tilesX;
+        const int ty = v % a.tilesY;
+        v /= a.tilesY;
+        const int b = v % a.B, co0 = (v / a.B) * CO_T;
+        const int y0 = ty * ROWS, x0 = tx * TW;
+        float* zb = a.z + (int64_t)b * a.z_bs;
+        const int xo = x0 + px;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int yo = y0 + (wn * NT + n) * RPT + py;
-            if (yo < a.H && xo < a.W) {
+            for (int n = 0; n < NT; ++n) {
+                const int yo = y0 + (wn * NT + n) * RPT + py;
+                if (yo < a.H && xo < a.W) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                    if (co < a.Cout) zb[(int64_t)co * HW + (int64_t)yo * a.W + xo] = acc[m][n][r];
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                        if (ONET_BF_ABL == 4 && (r || acc[m][n][r] != 12345.f)) continue;
+                        if (co < a.Cout) zb[(int64_t)co * HW + (int64_t)yo * a.W + xo] = acc[m][n][r];
+                    }
                 }
             }
-        }
+    }
 }
 
 template <int NT, int WPS, int TW = 32, bool XB = false>
@@ -234,13 +327,16 @@ static int launch_bf16(BfArgs a, hipStream_t st) {
     a.tilesX = cdiv(a.W, TW);
     a.tilesY = cdiv(a.H, C::ROWS);
     a.coTiles = cdiv(a.Cout, C::CO_T);
-    const int64_t blocks = (int64_t)a.B * a.tilesX * a.tilesY * a.coTiles;
-    ONET_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv3x3_bf16: grid %lld out of range", (long long)blocks);
+    const int64_t tiles = (int64_t)a.B * a.tilesX * a.tilesY * a.coTiles;
+    ONET_REQUIRE(tiles > 0 && tiles < (1ll << 31), "conv3x3_bf16: tile count %lld out of range", (long long)tiles);
     auto kern = conv3x3_bf16_kernel<NT, WPS, TW, XB>;
     static PerDeviceOnce attr_once;
     if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     }
+    // persistent grid: as many blocks as are resident at once (WPS per CU), a multiple of the 8 XCDs
+    const int64_t resident = (int64_t)device_cu_count() * WPS;
+    const int64_t blocks = std::min<int64_t>((tiles + 7) / 8 * 8, std::max<int64_t>(8, resident / 8 * 8));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, st, a);
     return check_launch("conv3x3_bf16_kernel");
 }

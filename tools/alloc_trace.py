@@ -19,6 +19,7 @@ ap.add_argument("--size", type=int, default=256)
 ap.add_argument("--conv", default=None)
 ap.add_argument("--steps", type=int, default=12)
 ap.add_argument("--profile-from", type=int, default=-1)
+ap.add_argument("--no-sync", action="store_true", help="let the host run ahead of the GPU between steps")
 ap.add_argument("--hold-loss", action="store_true", help="keep the previous step's loss alive, as a training loop does")
 a = ap.parse_args()
 if a.conv:
@@ -38,13 +39,15 @@ for i in range(a.steps):
     n0 = st("num_device_alloc")
     f0 = st("num_device_free")
     torch.cuda.reset_peak_memory_stats(dev)
-    torch.cuda.synchronize()
+    if not a.no_sync:
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     r = train_step(onet, opt, X)
     if a.hold_loss:
         loss = r
     del r
-    torch.cuda.synchronize()
+    if not a.no_sync:
+        torch.cuda.synchronize()
     print(f"step {i:2d}  {1e3 * (time.perf_counter() - t0):8.2f} ms  mallocs {st('num_device_alloc') - n0:3d}  frees "
           f"{st('num_device_free') - f0:3d}  reserved {torch.cuda.memory_reserved(dev) / 2**30:7.2f}  allocated "
           f"{torch.cuda.memory_allocated(dev) / 2**30:7.2f}  peak {torch.cuda.max_memory_allocated(dev) / 2**30:7.2f} GiB",

@@ -28,6 +28,11 @@ for ci, co, H in shapes:
         rep(lambda: ops.conv3x3_winograd4_wgrad(x, dz, (co, ci, 3, 3)))
     if "winow" in which:
         rep(lambda: ops.conv3x3_winograd_wgrad(x, dz, (co, ci, 3, 3)))
+    if "bf16" in which:                     # bf16 STORAGE variants (operands read as bf16 copies)
+        x16, dz16 = x.to(torch.bfloat16), dz.to(torch.bfloat16)
+        bf, bd = ops.pack3x3_bf16(w)
+        rep(lambda: ops.conv3x3_bf16(None, bf, co, x16=x16))
+        rep(lambda: ops.conv3x3_wgrad_bf16(None, None, (co, ci, 3, 3), x16=x16, dz16=dz16))
 if "convT" in which:
     for cin, h in ((128, 128), (512, 32)):
         ct = cin // 2
