@@ -156,6 +156,14 @@ int onet_convT2x2_fwd_b(const float* x, int64_t x_bs, const float* wq, const flo
                                                                                 /* 1: shape outside the GEMM path, nothing done */
 int onet_conv3x3_bf16_fwd_b(const void* x_bf16, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin,
                             int Cout, int H, int W, void* stream);
+
+/* Forward of a Conv-BatchNorm pair on the bf16 kernels with the BatchNorm batch statistics of z taken from the final
+ * accumulators (F.conv2d + the statistics half of nn.BatchNorm2d, OV:47-48 / 51-52): part [Cout][nparts][3] = (n, mean, M2) per
+ * tile, consumed by onet_bn_finalize_cm.  nparts = onet_conv3x3_bf16_nparts(B, H, W); 0 = the map is not made of full tiles
+ * (use onet_conv3x3_bf16_fwd[_b] + onet_bn_stats_partial).  x: fp32, or the bf16 copy when x_is_bf16. */
+int onet_conv3x3_bf16_nparts(int B, int H, int W);
+int onet_conv3x3_bf16_fwd_stats(const void* x, int x_is_bf16, int64_t x_bs, const void* wq, float* z, int64_t z_bs, float* part, int B,
+                                int Cin, int Cout, int H, int W, void* stream);
 int onet_conv3x3_wgrad_bf16_b(const void* x, int x_is_bf16, int64_t x_bs, const void* dz, int dz_is_bf16, int64_t dz_bs,
                               float* dw, void* ws, int64_t ws_bytes, int B, int Cin, int Cout, int H, int W, int accumulate,
                               void* stream);

@@ -83,7 +83,21 @@ struct BfArgs {
     float* z;
     int64_t z_bs;
     int B, Cin, Cout, H, W, tilesX, tilesY, coTiles;
+    float* stats;         // ST kernels: BatchNorm partials [Cout][B * tilesY * tilesX][3] = (n, mean, M2) per tile
 };
+
+// sum over the 32 lanes of a wave half, valid in lanes 31 / 63 (DPP row rotations + row broadcast, as in conv_wino4.hip)
+#define ONET_BF_DPP_ADD(v, ctrl, rmask) \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
+static __device__ __forceinline__ float bf_half_sum(float v) {
+    ONET_BF_DPP_ADD(v, 0x128, 0xf);   // row_ror:8
+    ONET_BF_DPP_ADD(v, 0x124, 0xf);   // row_ror:4
+    ONET_BF_DPP_ADD(v, 0x122, 0xf);   // row_ror:2
+    ONET_BF_DPP_ADD(v, 0x121, 0xf);   // row_ror:1
+    ONET_BF_DPP_ADD(v, 0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+    return v;
+}
+#undef ONET_BF_DPP_ADD
 
 // LDS, per 16-channel chunk (two such buffers: the next chunk is committed while the current one is read):
 //   weights [9 taps][2 halves][64 co] and the input halo tile [2 halves][NPIXP pixels], one 16-byte slot (8 bf16 channels) each.
@@ -111,7 +125,11 @@ struct BfCfg {
 // a tile's accumulators are stored, the first two chunks of the next tile are already in LDS / in flight.  With one tile per
 // block (the first version) the 64- and 128-channel layers of the 256x256 level spent two thirds of their time in the
 // un-overlapped prologue (first loads) and epilogue (64 KB of stores per tile): 0.46 ms of 0.68 ms at 64 channels.
-template <int NT, int WPS, int TW = 32, bool XB = false>
+// ST: the forward of a Conv-BatchNorm pair (OV:47-48, 51-52) also emits the BatchNorm statistics of its output, one (n, mean,
+// M2) record per tile and channel from the final accumulators (pivot-shifted sums per wave, the four waves of the tile merged
+// through LDS; full tiles only, host-checked) -- the separate statistics pass re-read every z once (12.8 ms of a 355 ms step
+// at B = 256).
+template <int NT, int WPS, int TW = 32, bool XB = false, bool ST = false>
 __global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
     using C = BfCfg<NT, TW>;
     constexpr int ROWS = C::ROWS, IN_COLS = C::IN_COLS, NIT = C::NIT, NWI = C::NWI, CO_T = C::CO_T, RPT = C::RPT;
@@ -302,6 +320,53 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
         v /= a.tilesY;
         const int b = v % a.B, co0 = (v / a.B) * CO_T;
         const int y0 = ty * ROWS, x0 = tx * TW;
+        if constexpr (ST) {
+            float* sc = reinterpret_cast<float*>(lds + 2 * BUF);       // [4 waves][64 channels][mean, M2]
+            constexpr float npw = (float)(NT * 32), inv_npw = 1.f / npw;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    // lanes 0-31 hold 32 pixels of channel c, lanes 32-63 of channel c + 4; pivot = the wave's first pixel
+                    const int piv = __builtin_bit_cast(int, acc[m][0][r]);
+                    const float p0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(piv, 0));
+                    const float p1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(piv, 32));
+                    const float pv = kh ? p1 : p0;
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const float d = acc[m][n][r] - pv;
+                        s1 += d;
+                        s2 = fmaf(d, d, s2);
+                    }
+                    s1 = bf_half_sum(s1);
+                    s2 = bf_half_sum(s2);
+                    if (l31 == 31) {
+                        const int cl = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                        sc[(wn * 64 + cl) * 2] = fmaf(s1, inv_npw, pv);
+                        sc[(wn * 64 + cl) * 2 + 1] = fmaxf(fmaf(-s1 * inv_npw, s1, s2), 0.f);
+                    }
+                }
+            __syncthreads();
+            if (tid < 64 && co0 + tid < a.Cout) {
+                float mw[4], qw[4];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    mw[w] = sc[(w * 64 + tid) * 2];
+                    qw[w] = sc[(w * 64 + tid) * 2 + 1];
+                }
+                const float mean = 0.25f * ((mw[0] + mw[1]) + (mw[2] + mw[3]));
+                float m2 = (qw[0] + qw[1]) + (qw[2] + qw[3]);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) m2 = fmaf(npw * (mw[w] - mean), mw[w] - mean, m2);
+                const int64_t nblk = (int64_t)a.B * a.tilesY * a.tilesX;
+                const int64_t blk = ((int64_t)b * a.tilesY + ty) * a.tilesX + tx;
+                float* sp = a.stats + ((int64_t)(co0 + tid) * nblk + blk) * 3;
+                sp[0] = 4.f * npw;
+                sp[1] = mean;
+                sp[2] = m2;
+            }
+        }
         float* zb = a.z + (int64_t)b * a.z_bs;
         const int xo = x0 + px;
 #pragma unroll
@@ -321,23 +386,24 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
     }
 }
 
-template <int NT, int WPS, int TW = 32, bool XB = false>
+template <int NT, int WPS, int TW = 32, bool XB = false, bool ST = false>
 static int launch_bf16(BfArgs a, hipStream_t st) {
     using C = BfCfg<NT, TW>;
+    constexpr int LDS_BYTES = C::LDS_BYTES + (ST ? 4 * 64 * 2 * 4 : 0);
     a.tilesX = cdiv(a.W, TW);
     a.tilesY = cdiv(a.H, C::ROWS);
     a.coTiles = cdiv(a.Cout, C::CO_T);
     const int64_t tiles = (int64_t)a.B * a.tilesX * a.tilesY * a.coTiles;
     ONET_REQUIRE(tiles > 0 && tiles < (1ll << 31), "conv3x3_bf16: tile count %lld out of range", (long long)tiles);
-    auto kern = conv3x3_bf16_kernel<NT, WPS, TW, XB>;
+    auto kern = conv3x3_bf16_kernel<NT, WPS, TW, XB, ST>;
     static PerDeviceOnce attr_once;
     if (attr_once.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     }
     // persistent grid: as many blocks as are resident at once (WPS per CU), a multiple of the 8 XCDs
     const int64_t resident = (int64_t)device_cu_count() * WPS;
     const int64_t blocks = std::min<int64_t>((tiles + 7) / 8 * 8, std::max<int64_t>(8, resident / 8 * 8));
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), LDS_BYTES, st, a);
     return check_launch("conv3x3_bf16_kernel");
 }
 
@@ -555,15 +621,29 @@ int onet_conv3x3_pack_weights_bf16(const float* w, void* wq_fwd, void* wq_dgrad,
     return check_launch("pack3x3_bf16_kernel");
 }
 
+// records per channel of the fused statistics (0: the map is not made of full tiles -- separate statistics pass)
+static int bf16_nparts(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    const int tw = W > 16 ? 32 : 16, rows = W > 16 ? 8 : 16;
+    if (W % tw || H % rows) return 0;
+    const int64_t n = (int64_t)B * (H / rows) * (W / tw);
+    return n < (1 << 30) ? (int)n : 0;
+}
+
 static int bf16_fwd(const void* x, bool x_bf16, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin, int Cout,
-                    int H, int W, void* stream) {
+                    int H, int W, void* stream, float* stats = nullptr) {
     ONET_REQUIRE(x && wq && z, "conv3x3_bf16_fwd: null pointer");
     ONET_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv3x3_bf16_fwd: bad shape");
     ONET_REQUIRE((Cin % 16) == 0 && (Cout % 4) == 0, "conv3x3_bf16_fwd: Cin must be a multiple of 16, Cout of 4 (use onet_conv_fwd)");
     ONET_REQUIRE(x_bs >= (int64_t)Cin * H * W && z_bs >= (int64_t)Cout * H * W, "conv3x3_bf16_fwd: batch stride too small");
     ONET_REQUIRE((int64_t)(Cin + 32) * H * W * 4 < (1ll << 31) && (int64_t)(Cin + 32) * 9 * Cout * 2 < (1ll << 31),
                  "conv3x3_bf16_fwd: operand exceeds the 2 GiB buffer-resource range");
-    BfArgs a{x, x_bs, (const __bf16*)wq, z, z_bs, B, Cin, Cout, H, W, 0, 0, 0};
+    BfArgs a{x, x_bs, (const __bf16*)wq, z, z_bs, B, Cin, Cout, H, W, 0, 0, 0, stats};
+    if (stats) {
+        ONET_REQUIRE(bf16_nparts(B, H, W) > 0, "conv3x3_bf16_fwd_stats: the map must be made of full tiles (onet_conv3x3_bf16_nparts() == 0 elsewhere)");
+        if (x_bf16) return (W > 16) ? launch_bf16<2, 2, 32, true, true>(a, as_stream(stream)) : launch_bf16<2, 2, 16, true, true>(a, as_stream(stream));
+        return (W > 16) ? launch_bf16<2, 2, 32, false, true>(a, as_stream(stream)) : launch_bf16<2, 2, 16, false, true>(a, as_stream(stream));
+    }
     // 4 waves x 2 rows x 32 px, two blocks (8 waves) per CU: 373-851 TF on the U-Net's layers against 278-527 for
     // 4-row waves at one wave per SIMD and ~100 for 4-row waves squeezed into 256 VGPRs (700 B/lane of scratch)
     // (three blocks per CU for the bf16-input kernel -- 168 VGPRs -- changed nothing: 0.412 vs 0.410 ms per launch)
@@ -579,6 +659,14 @@ int onet_conv3x3_bf16_fwd(const float* x, int64_t x_bs, const void* wq, float* z
 int onet_conv3x3_bf16_fwd_b(const void* x_bf16, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin, int Cout,
                             int H, int W, void* stream) {
     return bf16_fwd(x_bf16, true, x_bs, wq, z, z_bs, B, Cin, Cout, H, W, stream);
+}
+
+int onet_conv3x3_bf16_nparts(int B, int H, int W) { return bf16_nparts(B, H, W); }
+
+int onet_conv3x3_bf16_fwd_stats(const void* x, int x_is_bf16, int64_t x_bs, const void* wq, float* z, int64_t z_bs, float* part, int B,
+                                int Cin, int Cout, int H, int W, void* stream) {
+    ONET_REQUIRE(part, "conv3x3_bf16_fwd_stats: null pointer");
+    return bf16_fwd(x, x_is_bf16 != 0, x_bs, wq, z, z_bs, B, Cin, Cout, H, W, stream, part);
 }
 
 int64_t onet_conv3x3_wgrad_bf16_ws_bytes(int B, int Cin, int Cout, int H, int W) {

@@ -368,11 +368,29 @@ def conv3x3_fwd_bn_partials(x, pk, x16=None):
     BatchNorm records [Cout, nparts, 3] the F(4x4) kernel's epilogue emits (image-major: nparts / B per image), or None
     where the selected kernel does not emit them (then `bn_train_coeffs` runs its own statistics pass)."""
     Ci, Co = pk["Cin"], pk["Cout"]
-    B, _, H, W = x.shape
+    B, _, H, W = (x if x is not None else x16).shape
     algo = conv3x3_algo(B, Ci, Co, H, W)
     nparts = 0
     if algo == "winograd4" and FUSE_BN_STATS and not SYNC_BN:
         nparts = int(_lib.load().onet_conv3x3_winograd4_nparts(B, H, W))
+    if algo == "bf16" and FUSE_BN_STATS and not SYNC_BN:
+        nparts = int(_lib.load().onet_conv3x3_bf16_nparts(B, H, W))
+        x16p, x16bs = plane16(x16)
+        if nparts > 0 and (x16p is not None or x is not None):
+            wq = pk.get_pack(algo)[0]
+            if x16p is None:
+                require_gpu(x)
+                xs, xbs = plane(x)
+            dev = (x16p if x16p is not None else x).device
+            out = torch.empty((B, Co, H, W), dtype=F32, device=dev)
+            cm = torch.empty((Co, nparts, 3), dtype=F32, device=dev)
+            e0 = _prof_begin()
+            _lib.call("onet_conv3x3_bf16_fwd_stats", _p(x16p if x16p is not None else xs), int(x16p is not None),
+                      x16bs if x16p is not None else xbs, _p(wq), _p(out), Co * H * W, _p(cm), B, Ci, Co, H, W, _stream())
+            _prof_end("conv3x3_bf16_kernel", 2.0 * B * H * W * Ci * Co * 9, e0,
+                      B * H * W * ((2.0 if x16p is not None else 4.0) * Ci + 4.0 * Co) + 18.0 * Ci * Co)
+            return out, cm
+        nparts = 0
     if nparts <= 0:
         return conv3x3_auto(x, pk, 0, x16=x16), None
     wq = pk.get_pack(algo)[0]

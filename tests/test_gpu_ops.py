@@ -233,11 +233,58 @@ def test_winograd4_fused_bn_statistics(dev, B, Cin, Cout, H, W):
         assert float(((s1[1].cpu().double() - ir) / ir).abs().max()) <= 1e-5
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W,x_bf16", [(2, 16, 64, 32, 32, True), (3, 32, 72, 16, 64, False), (4, 64, 128, 64, 64, True),
+                                                    (2, 16, 40, 32, 16, True), (5, 48, 64, 16, 16, False), (2, 32, 64, 200, 96, True)])
+def test_bf16_fused_bn_statistics(dev, B, Cin, Cout, H, W, x_bf16):
+    """bf16 forward with the BatchNorm statistics records written by its epilogue (maps made of full tiles: 8 x 32 pixels, or
+    16 x 16 on maps up to 16 wide; channel tails; several tiles per persistent block): z bit-identical to the plain kernel, and
+    finalize(records) == finalize(separate statistics pass) for the whole batch and for a batch slice (the twin batch's
+    statistics groups).  Ragged maps report nparts == 0 and keep the separate statistics pass."""
+    from onet_amd import _lib, ops
+    for h, w in [(40, 40), (20, 64), (8, 16), (17, 32)]:
+        assert int(_lib.load().onet_conv3x3_bf16_nparts(B, h, w)) == 0
+    x = rnd(B, Cin, H, W, seed=31) + 0.7
+    w = rnd(Cout, Cin, 3, 3, seed=32) / (3.0 * Cin ** 0.5)
+    xd = x.to(dev)
+    x16 = xd.to(torch.bfloat16)
+    qf, _ = ops.pack3x3_bf16(w.to(dev))
+    z0 = ops.conv3x3_bf16(xd, qf, Cout)
+    nparts = int(_lib.load().onet_conv3x3_bf16_nparts(B, H, W))
+    assert nparts == (B * (W // 32) * (H // 8) if W > 16 else B * (W // 16) * (H // 16))
+    z1 = torch.empty_like(z0)
+    cm = torch.full((Cout, nparts, 3), float("nan"), device=dev)
+    src = x16 if x_bf16 else xd
+    _lib.call("onet_conv3x3_bf16_fwd_stats", src.data_ptr(), int(x_bf16), Cin * H * W, qf.data_ptr(), z1.data_ptr(),
+              Cout * H * W, cm.data_ptr(), B, Cin, Cout, H, W, torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(z0, z1)
+    assert torch.isfinite(cm).all()
+    assert float(cm[:, :, 0].sum(1).min()) == float(cm[:, :, 0].sum(1).max()) == B * H * W
+    gamma = (1 + 0.1 * rnd(Cout, seed=33)).to(dev)
+    beta = (0.1 * rnd(Cout, seed=34)).to(dev)
+    for lo, hi in [(0, B), (B // 2, B)]:
+        zs = z0[lo:hi]
+        rm0, rv0 = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
+        rm1, rv1 = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
+        s0 = ops.bn_train_coeffs(zs, gamma, beta, rm0, rv0, 0.1, 1e-5)
+        npi = nparts // B
+        s1 = ops.bn_train_coeffs(zs, gamma, beta, rm1, rv1, 0.1, 1e-5, cm=(cm, lo * npi, (hi - lo) * npi))
+        sd = float(zs.std())
+        assert float((s0[0] - s1[0]).abs().max()) <= 2e-6 * sd, "mean"
+        assert float(((s0[1] - s1[1]) / s0[1]).abs().max()) <= 1e-5, "invstd"
+        assert float((rm0 - rm1).abs().max()) <= 1e-6 * sd and float(((rv0 - rv1) / rv0).abs().max()) <= 1e-5
+        zr = zs.double().cpu()
+        assert float((s1[0].cpu().double() - zr.mean((0, 2, 3))).abs().max()) <= 2e-6 * sd
+        ir = 1.0 / torch.sqrt(zr.var((0, 2, 3), unbiased=False) + 1e-5)
+        assert float(((s1[1].cpu().double() - ir) / ir).abs().max()) <= 1e-5
+
+
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 16, 64, 32, 32), (1, 32, 48, 20, 44), (2, 64, 128, 64, 64),
                                              (3, 48, 32, 17, 33), (2, 128, 64, 16, 96), (3, 64, 128, 16, 16),
-                                             (2, 32, 80, 21, 13)])
+                                             (2, 32, 80, 21, 13), (2, 16, 96, 200, 288), (1, 48, 64, 512, 320)])
 def test_conv3x3_bf16_operands(dev, B, Cin, Cout, H, W):
-    """BASELINE config 3's bf16 MFMA conv path (conv_bf16.hip), forward and input-gradient orientation: the kernel
+    """(The last two shapes give the persistent blocks several tiles each: 900 and 640 tiles on 512 resident blocks, one and three
+    16-channel chunks per tile.)
+    BASELINE config 3's bf16 MFMA conv path (conv_bf16.hip), forward and input-gradient orientation: the kernel
     rounds activations and weights to bf16 (nearest-even) and accumulates in fp32, so it must equal an fp64 convolution
     of the bf16-ROUNDED operands to fp32 summation accuracy (1e-5 of the output scale) -- and the full-precision
     convolution to bf16 accuracy (2^-8 relative per operand: 2e-2 of the output scale at these depths)."""
