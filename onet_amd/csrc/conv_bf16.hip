@@ -41,6 +41,9 @@ constexpr unsigned OOB_B = 0x80000000u;
 #ifndef ONET_BF_ABL
 #define ONET_BF_ABL 0
 #endif
+#ifndef ONET_BW_ABL       // the same for the weight-gradient kernel: 1 no loads after the first unit, 2 also no commits, 3 no MFMAs
+#define ONET_BW_ABL 0
+#endif
 
 static __device__ __forceinline__ __amdgpu_buffer_rsrc_t b_rsrc(const void* base, int64_t bytes) {
     const int n = bytes > 0x7fffffffll ? 0x7fffffff : (int)bytes;
@@ -557,9 +560,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_bf16_kernel(BwArgs a) {
 
     issue(u0);
     for (int u = u0; u < u1; ++u) {
-        commit();
+        if (ONET_BW_ABL != 2 || u == u0) commit();
         __syncthreads();
-        issue(u + 1);
+        if (ONET_BW_ABL != 1 && ONET_BW_ABL != 2) issue(u + 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -571,6 +574,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_bf16_kernel(BwArgs a) {
                 const u32x4b s1 = {__builtin_amdgcn_alignbit(q[1], q[0], 16), __builtin_amdgcn_alignbit(q[2], q[1], 16),
                                    __builtin_amdgcn_alignbit(q[3], q[2], 16), __builtin_amdgcn_alignbit(d4, q[3], 16)};
                 const u32x4b s2 = {q[1], q[2], q[3], d4};
+                if (ONET_BW_ABL == 3) {     // fragment reads and shifts without the matrix pipe
+                    acc[ky * 3][0] += __builtin_bit_cast(float, q[0] ^ s1[1] ^ s2[2] ^ __builtin_bit_cast(u32x4b, av)[0]);
+                    continue;
+                }
                 acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, q), acc[ky * 3 + 0], 0, 0, 0);
                 acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, s1), acc[ky * 3 + 1], 0, 0, 0);
                 acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, s2), acc[ky * 3 + 2], 0, 0, 0);
@@ -592,9 +599,196 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_bf16_kernel(BwArgs a) {
     }
 }
 
+// ---- weight gradient on maps at least 64 pixels wide: ROW units.  The 4-row x 16-pixel patches above fetch 32-byte pieces of
+// 128-byte lines (a quarter of every line per unit, six halo rows for four): on the 256x256 and 128x128 levels the kernel was
+// bound by those requests, not by the matrix pipe (without the global loads 0.31 instead of 0.77 ms at 64 channels; without
+// the MFMAs 0.75).  Here a unit is ONE image row of a 64-pixel strip: dz [64 co][64 px] and x rows y-1, y, y+1 [64 ci][66 px];
+// a block walks down the strip, so the x rows live in a 4-slot ring in LDS and every unit loads exactly one new row of each
+// operand as whole 128-byte lines.  The four K-steps of a unit are its four 16-pixel segments; fragments, shifts and the MFMA
+// mapping are those of the patch kernel.
+constexpr int BR_SDZ = 36, BR_SX = 148, BR_SLOT = 36;      // dword strides: per co; per ci (4 x odd); per ring slot
+
+template <bool XB = false, bool ZB = false>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_bf16_row_kernel(BwArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned dz_lds[2 * 64 * BR_SDZ];
+    __shared__ __attribute__((aligned(16))) unsigned x_lds[64 * BR_SX];
+
+    int bid;
+    {
+        const int n = gridDim.x, q = n >> 3, r = n & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int tiles = a.ciTiles * a.coTiles;
+    const int ks = bid / tiles, tile = bid % tiles;
+    const int ci0 = (tile % a.ciTiles) * 64, co0 = (tile / a.ciTiles) * 64;
+    const int nunits = a.B * a.tilesX * a.H;                   // unit = (image, 64-pixel strip, row), rows fastest
+    const int per = (nunits + a.splitK - 1) / a.splitK;
+    const int u0 = ks * per, u1 = min(u0 + per, nunits);
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int HW = a.H * a.W;
+    constexpr int XE = XB ? 2 : 4, ZE = ZB ? 2 : 4;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // staging roles: thread = (channel = tid / 4, 16-pixel segment = tid % 4) of the dz row and of the x row.  NS register sets:
+    // with both operands in bf16 (18 registers a set) the loads run TWO units ahead of the MFMAs -- a unit is 36 MFMAs = 0.5 us
+    // of matrix time, a miss to HBM several times that
+    constexpr int NS = (XB && ZB) ? 2 : 1;
+    const int st_c = tid >> 2, st_s = tid & 3;
+    u32x4b dzv[NS][4], xq[NS][4];
+    float xh[NS][2];
+    // loads of one dz row and / or one x row of strip (b, x0): row < 0 or >= H -> zeros
+    auto issue_dz = [&](int set, int b, int x0, int y) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t dr = b_rsrc(static_cast<const char*>(a.dz) + (int64_t)b * a.dz_bs * ZE, (int64_t)a.Cout * HW * ZE);
+        const int xs = x0 + 16 * st_s;
+        const bool ok = y >= 0 && y < a.H && co0 + st_c < a.Cout;
+        const unsigned base = (unsigned)(((co0 + st_c) * HW + y * a.W + xs) * ZE);
+#pragma unroll
+        for (int k = 0; k < (ZB ? 2 : 4); ++k)
+            dzv[set][k] = __builtin_amdgcn_raw_buffer_load_b128(dr, (ok && xs + (ZB ? 8 : 4) * k < a.W) ? base + 16 * k : OOB_B, 0, 0);
+    };
+    auto issue_x = [&](int set, int b, int x0, int y) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t xr = b_rsrc(static_cast<const char*>(a.x) + (int64_t)b * a.x_bs * XE, (int64_t)a.Cin * HW * XE);
+        const int xs = x0 + 16 * st_s;
+        const bool ok = y >= 0 && y < a.H && ci0 + st_c < a.Cin;
+        const unsigned base = (unsigned)(((ci0 + st_c) * HW + y * a.W + xs) * XE);
+#pragma unroll
+        for (int k = 0; k < (XB ? 2 : 4); ++k)
+            xq[set][k] = __builtin_amdgcn_raw_buffer_load_b128(xr, (ok && xs + (XB ? 8 : 4) * k < a.W) ? base + 16 * k : OOB_B, 0, 0);
+        if constexpr (XB) {
+            xh[set][0] = __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(xr, (ok && xs > 0 && xs - 1 < a.W) ? base - 2 : OOB_B, 0, 0));
+            xh[set][1] = __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(xr, (ok && st_s == 3 && xs + 16 < a.W) ? base + 32 : OOB_B, 0, 0));
+        } else {
+            xh[set][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (ok && xs > 0 && xs - 1 < a.W) ? base - 4 : OOB_B, 0, 0));
+            xh[set][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (ok && st_s == 3 && xs + 16 < a.W) ? base + 64 : OOB_B, 0, 0));
+        }
+    };
+    auto commit_dz = [&](int set, int buf) __attribute__((always_inline)) {
+        u32x4b* d = reinterpret_cast<u32x4b*>(dz_lds + buf * 64 * BR_SDZ + st_c * BR_SDZ + st_s * 8);
+        if constexpr (ZB) {
+            d[0] = dzv[set][0];
+            d[1] = dzv[set][1];
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4b lo = __builtin_bit_cast(f32x4b, dzv[set][2 * h]), hi = __builtin_bit_cast(f32x4b, dzv[set][2 * h + 1]);
+                d[h] = u32x4b{pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(hi[0], hi[1]), pack_bf16(hi[2], hi[3])};
+            }
+        }
+    };
+    // row element e = column x0 - 1 + e; dword p = (e[2p], e[2p+1]) = (f[2p-1], f[2p]) of the interior row f: the segment's eight
+    // dwords start with (pixel left of the segment, its first pixel); the strip's last dword (f[63], right halo) is segment 3's
+    auto commit_x = [&](int set, int slot) __attribute__((always_inline)) {
+        unsigned* row = x_lds + st_c * BR_SX + slot * BR_SLOT + st_s * 8;
+        if constexpr (XB) {
+            const u32x4b q0 = xq[set][0], q1 = xq[set][1];
+            const unsigned hl = __builtin_bit_cast(unsigned, xh[set][0]), hr = __builtin_bit_cast(unsigned, xh[set][1]);
+            const u32x4b w0 = {hl | (q0[0] << 16), __builtin_amdgcn_alignbit(q0[1], q0[0], 16), __builtin_amdgcn_alignbit(q0[2], q0[1], 16),
+                               __builtin_amdgcn_alignbit(q0[3], q0[2], 16)};
+            const u32x4b w1 = {__builtin_amdgcn_alignbit(q1[0], q0[3], 16), __builtin_amdgcn_alignbit(q1[1], q1[0], 16),
+                               __builtin_amdgcn_alignbit(q1[2], q1[1], 16), __builtin_amdgcn_alignbit(q1[3], q1[2], 16)};
+            *reinterpret_cast<u32x4b*>(row) = w0;
+            *reinterpret_cast<u32x4b*>(row + 4) = w1;
+            if (st_s == 3) row[8] = (q1[3] >> 16) | (hr << 16);
+        } else {
+            const f32x4b f0 = __builtin_bit_cast(f32x4b, xq[set][0]), f1 = __builtin_bit_cast(f32x4b, xq[set][1]);
+            const f32x4b f2 = __builtin_bit_cast(f32x4b, xq[set][2]), f3 = __builtin_bit_cast(f32x4b, xq[set][3]);
+            const u32x4b w0 = {pack_bf16(xh[set][0], f0[0]), pack_bf16(f0[1], f0[2]), pack_bf16(f0[3], f1[0]), pack_bf16(f1[1], f1[2])};
+            const u32x4b w1 = {pack_bf16(f1[3], f2[0]), pack_bf16(f2[1], f2[2]), pack_bf16(f2[3], f3[0]), pack_bf16(f3[1], f3[2])};
+            *reinterpret_cast<u32x4b*>(row) = w0;
+            *reinterpret_cast<u32x4b*>(row + 4) = w1;
+            if (st_s == 3) row[8] = pack_bf16(f3[3], xh[set][1]);
+        }
+    };
+
+    const unsigned* a_ptr = dz_lds + (wm * 32 + l31) * BR_SDZ + kh * 4;
+    const unsigned* b_ptr = x_lds + (wn * 32 + l31) * BR_SX + kh * 4;
+
+    int u = u0;
+    while (u < u1) {
+        // a run of rows inside one strip: y = yb .. ye - 1
+        const int yb = u % a.H, sb = u / a.H;
+        const int tx = sb % a.tilesX, b = sb / a.tilesX;
+        const int x0 = tx * 64;
+        const int ye = min(a.H, yb + (u1 - u));
+        // run prologue: rows yb - 1 and yb of x into the ring (synchronously), then the dz row and the next x row of the first NS
+        // units in flight
+        __syncthreads();                              // every wave is done with the previous run's ring and dz buffers
+        issue_x(0, b, x0, yb - 1);
+        commit_x(0, (yb - 1) & 3);
+        issue_x(0, b, x0, yb);
+        commit_x(0, yb & 3);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            issue_dz(k, b, x0, yb + k);               // (rows past the run's end are loaded and never used)
+            issue_x(k, b, x0, yb + k + 1);
+        }
+        for (int yq = yb; yq < ye; yq += NS) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int y = yq + k;
+                if (y >= ye) break;
+                const int buf = y & 1;
+                commit_dz(k, buf);
+                commit_x(k, (y + 1) & 3);             // slot of row y - 3: last read two barriers ago
+                __syncthreads();
+                if (y + NS < ye) {
+                    issue_dz(k, b, x0, y + NS);
+                    issue_x(k, b, x0, y + NS + 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned* ab = a_ptr + buf * 64 * BR_SDZ;
+#pragma unroll
+                for (int sg = 0; sg < 4; ++sg) {
+                    const bf16x8 av = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4b*>(ab + sg * 8));
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const unsigned* br = b_ptr + ((y - 1 + ky) & 3) * BR_SLOT + sg * 8;
+                        const u32x4b q = *reinterpret_cast<const u32x4b*>(br);
+                        const unsigned d4 = br[4];
+                        const u32x4b s1 = {__builtin_amdgcn_alignbit(q[1], q[0], 16), __builtin_amdgcn_alignbit(q[2], q[1], 16),
+                                           __builtin_amdgcn_alignbit(q[3], q[2], 16), __builtin_amdgcn_alignbit(d4, q[3], 16)};
+                        const u32x4b s2 = {q[1], q[2], q[3], d4};
+                        acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, q), acc[ky * 3 + 0], 0, 0, 0);
+                        acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, s1), acc[ky * 3 + 1], 0, 0, 0);
+                        acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, s2), acc[ky * 3 + 2], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        u += ye - yb;
+    }
+
+    const int64_t n = (int64_t)a.Cout * a.Cin;
+    const int ci = ci0 + wn * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float* o = a.slab + ((int64_t)ks * 9 + t) * n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (co < a.Cout && ci < a.Cin) o[(int64_t)co * a.Cin + ci] = acc[t][r];
+        }
+    }
+}
+
+static bool wgrad_bf16_rows(int W) {
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("ONET_BF16_WG_ROWS"); mode = (e && e[0] == '0') ? 0 : 1; }
+    return mode == 1 && W >= 64;
+}
+
 static void wgrad_bf16_plan(int B, int Cin, int Cout, int H, int W, int& splitK, int& tilesY, int& tilesX) {
-    tilesY = cdiv(H, 4);
-    tilesX = cdiv(W, 16);
+    const bool rows = wgrad_bf16_rows(W);
+    tilesY = rows ? H : cdiv(H, 4);
+    tilesX = rows ? cdiv(W, 64) : cdiv(W, 16);
     const int64_t units = (int64_t)B * tilesY * tilesX;
     const int tiles = cdiv(Cin, 64) * cdiv(Cout, 64);
     static int target = -1;
@@ -691,6 +885,12 @@ static int bf16_wgrad(const void* x, bool xb, int64_t x_bs, const void* dz, bool
     ONET_REQUIRE(ws_bytes >= need, "conv3x3_wgrad_bf16: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
     const int64_t blocks = (int64_t)a.splitK * a.ciTiles * a.coTiles;
     const dim3 g((unsigned)blocks), t(256);
+    if (wgrad_bf16_rows(W)) {
+        if (xb && zb) hipLaunchKernelGGL((conv3x3_wgrad_bf16_row_kernel<true, true>), g, t, 0, as_stream(stream), a);
+        else if (xb) hipLaunchKernelGGL((conv3x3_wgrad_bf16_row_kernel<true, false>), g, t, 0, as_stream(stream), a);
+        else if (zb) hipLaunchKernelGGL((conv3x3_wgrad_bf16_row_kernel<false, true>), g, t, 0, as_stream(stream), a);
+        else hipLaunchKernelGGL((conv3x3_wgrad_bf16_row_kernel<false, false>), g, t, 0, as_stream(stream), a);
+    } else
     if (xb && zb) hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<true, true>), g, t, 0, as_stream(stream), a);
     else if (xb) hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<true, false>), g, t, 0, as_stream(stream), a);
     else if (zb) hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<false, true>), g, t, 0, as_stream(stream), a);

@@ -331,10 +331,13 @@ def test_conv3x3_winograd4_wgrad(dev, B, Cin, Cout, H, W):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 64, 64, 32, 32), (3, 16, 48, 20, 44), (2, 128, 64, 16, 16),
-                                             (1, 72, 40, 9, 28), (4, 64, 128, 64, 64)])
+                                             (1, 72, 40, 9, 28), (4, 64, 128, 64, 64), (2, 64, 64, 40, 72), (3, 32, 96, 24, 128),
+                                             (1, 80, 64, 256, 256), (2, 16, 16, 3, 68), (5, 48, 40, 7, 200)])
 def test_conv3x3_wgrad_bf16_operands(dev, B, Cin, Cout, H, W):
     """bf16-operand weight gradient (conv_bf16.hip): equal to the fp64 weight gradient of the bf16-ROUNDED x and dz to
-    fp32 summation accuracy; ragged patches (H % 4, W % 16), channel tails, several split-K plans."""
+    fp32 summation accuracy; ragged patches (H % 4, W % 16), channel tails, several split-K plans.  Maps from 64 pixels of
+    width take the row-streaming kernel: whole and partial 64-pixel strips (W = 72, 68, 200), runs of rows that cross strips and
+    images inside one block's split-K range, maps of three rows."""
     from onet_amd import ops
     x = rnd(B, Cin, H, W, seed=61)
     g = rnd(B, Cout, H, W, seed=62)
