@@ -7,7 +7,7 @@ extra = os.environ.get("BENCH_ARGS", "")                 # the BENCH_ARGS the se
 import re
 _m = re.search(r"--batch\s+(\d+)", extra)
 batch = int(_m.group(1)) if _m else 32
-what = f"B={batch} 1x256x256, " + ("bf16 MFMA conv path (fp32 storage / accumulation)" if "bf16" in extra else "fp32")
+what = f"B={batch} 1x256x256, " + ("bf16 MFMA conv path (bf16 copies of the conv operands, fp32 master tensors and accumulation)" if "bf16" in extra else "fp32")
 sfx = f"bench_b{batch}_256"
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
@@ -38,8 +38,10 @@ except Exception:
     pass
 with open(f"profiles/{tag}_kernel_stats_{sfx}.md", "w") as f:
     f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 3 --no-cpu-baseline {extra} ({desc})\n\n")
-    f.write(f"MI355X, {what}; 6 training steps traced (3 warm-up + 3 timed).  Total kernel time {tot/1e6:.1f} ms = "
-            f"{tot/6e6:.1f} ms/step over all six.")
+    _w = re.findall(r"--warmup\s+(\d+)", "--warmup 3 " + extra)
+    nwarm = int(_w[-1])
+    f.write(f"MI355X, {what}; {nwarm + 3} training steps traced ({nwarm} warm-up + 3 timed).  Total kernel time {tot/1e6:.1f} ms = "
+            f"{tot/1e6/(nwarm + 3):.1f} ms/step over all of them.")
     if bench:
         dom = bench["roofline"]["kernel"]
         f.write(f"  bench under the profiler: {bench['ms_per_step']} ms/step, {bench['value']} images/s.\n"
