@@ -76,6 +76,11 @@ int64_t onet_convT2x2_dgrad_dbias_ws_bytes(int B, int Ct, int h, int w);
 int onet_convT2x2_dgrad_dbias(const float* dy, int64_t dy_bs, const float* wp_dgrad, float* dx, int64_t dx_bs, float* dbias,
                               void* ws, int64_t ws_bytes, int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl,
                               void* stream);
+/* Operand precision of the three ConvTranspose2d GEMMs (OV:86) on their 128 x 128 fast path: on = 1 rounds the MFMA operands to
+ * bf16 (nearest-even) with fp32 accumulation and fp32 results -- nn.ConvTranspose2d under torch.autocast(bfloat16), BASELINE
+ * configs[2]; 0 (default) = fp32.  Process-wide; call before the launches it governs. */
+int onet_convT2x2_set_bf16(int on);
+
 int64_t onet_convT2x2_wgrad_ws_bytes(int B, int Cin, int Ct, int h, int w);   /* workspace of onet_convT2x2_wgrad */
 int onet_convT2x2_wgrad(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, float* dw, void* ws,
                         int64_t ws_bytes, int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl,

@@ -758,6 +758,13 @@ static bool convt_gemm_enabled() {
     return on != 0;
 }
 
+// operand precision of the ConvTranspose2d GEMMs (128 x 128 fast path only): 1 = bf16 operands, fp32 accumulation -- what
+// torch.autocast(bfloat16) does to nn.ConvTranspose2d; process-wide, set by the host before the calls it governs
+int onet_convT2x2_set_bf16(int on) {
+    convt_set_bf16(on);
+    return 0;
+}
+
 int64_t onet_convT2x2_wgrad_ws_bytes(int B, int Cin, int Ct, int h, int w) {
     return std::max<int64_t>(onet_conv_wgrad_ws_bytes(B, Cin, 4 * Ct, h, w, 1), convt_gemm_wgrad_ws_bytes(B, Cin, Ct, h, w));
 }

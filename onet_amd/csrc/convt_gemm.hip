@@ -29,10 +29,17 @@ using namespace onet;
 #ifndef ONET_GEMM_SPREAD
 #define ONET_GEMM_SPREAD 0
 #endif
+#ifndef ONET_GEMM_ABL       // experiments: 1 = no MFMAs (fragment reads kept alive): the data-movement floor of the structure
+#define ONET_GEMM_ABL 0
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4g __attribute__((ext_vector_type(4)));
+typedef float f32x2g __attribute__((ext_vector_type(2)));
 typedef int i32x4g __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8g __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2g __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -56,6 +63,20 @@ __device__ __forceinline__ void g_dma16(i32x4g rsrc, unsigned lds_base, unsigned
                  : "=&s"(keep)
                  : "v"(voff), "s"(rsrc), "s"(lds_base)
                  : "memory");
+}
+
+// BF (BASELINE configs[2], bf16 MFMA conv path): the same DMA-fed fp32 tiles, but a K-chunk of 16 is ONE
+// v_mfma_f32_32x32x16_bf16 per accumulator instead of eight v_mfma_f32_32x32x2_f32: a lane gathers its 8 K-values from LDS
+// (as many ds_read as before), rounds them to bf16 (v_cvt_pk_bf16_f32, nearest-even: the rounding the bf16 conv kernels apply
+// to their operands) and accumulates in fp32.  The fp32 kernels spend 2.6-2.8x their data-movement time in the matrix pipe
+// (timing-only build without the MFMAs: 0.90 vs 2.31 ms over the four decoder levels at B = 64).
+__device__ __forceinline__ unsigned g_pack(float lo, float hi) {
+    bf16x2g v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ bf16x8g g_pack8(const float (&v)[8]) {
+    const u32x4g q = {g_pack(v[0], v[1]), g_pack(v[2], v[3]), g_pack(v[4], v[5]), g_pack(v[6], v[7])};
+    return __builtin_bit_cast(bf16x8g, q);
 }
 
 struct GArgs {
@@ -95,7 +116,7 @@ constexpr int TILE_F = KC * 128;       // floats of one operand tile
 // ------------------------------------------------------------------------------------------------ forward and dgrad
 // MODE 0: forward (A rows = wq[k][m], B rows = x[b][k][pixels]);  MODE 1: dgrad (A rows = wd[q*Ct + c][ci], B rows =
 // dy[b][c][2y + di][...] as they lie: 256 floats per (c, di) for the tile's 128 pixels)
-template <int MODE>
+template <int MODE, bool BF = false>
 __global__ __launch_bounds__(256, 2) void convt_gemm_kernel(GArgs g) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * TILE_F];      // [buf][A | B]
     int bid = xcd_order(gridDim.x);
@@ -170,6 +191,39 @@ __global__ __launch_bounds__(256, 2) void convt_gemm_kernel(GArgs g) {
             const float other = __shfl(sb, 63, 64);
             if (lane == 31) g.dbias_part[(int64_t)nt * g.Ct + 4 * c + wid] = sb + other;
         }
+        if constexpr (BF) {
+            if (more) issue(c + 1, buf ^ 1);
+            // one K = 16 MFMA per accumulator: lane (i, kh) holds K-values 8 kh .. 8 kh + 7 of the chunk
+            float af[2][8], bf[2][8];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) af[t][i] = A[(8 * kh + i) * 128 + t * 32];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (MODE == 0) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) bf[u][i] = Bt[(8 * kh + i) * 128 + wc * 64 + u * 32 + l31];
+                } else {
+                    // chunk row kk = 8 kh + i = (channel cl = 2 kh + i / 4, di = (i / 2) % 2, dj = i % 2): the (dj = 0, 1) pair is adjacent
+#pragma unroll
+                    for (int ip = 0; ip < 4; ++ip) {
+                        const f32x2g v = *reinterpret_cast<const f32x2g*>(Bt + ((2 * kh + (ip >> 1)) * 2 + (ip & 1)) * 256 + 2 * (wc * 64 + u * 32 + l31));
+                        bf[u][2 * ip] = v[0];
+                        bf[u][2 * ip + 1] = v[1];
+                    }
+                }
+            }
+            bf16x8g a8[2], b8[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) a8[t] = g_pack8(af[t]);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) b8[u] = g_pack8(bf[u]);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[t], b8[u], acc[t][u], 0, 0, 0);
+        } else {
 #pragma unroll
         for (int s = 0; s < KC / 2; ++s) {
             // the next chunk's four DMA pieces go out one per two K-steps, not as a burst in front of the MFMAs (a piece
@@ -190,7 +244,11 @@ __global__ __launch_bounds__(256, 2) void convt_gemm_kernel(GArgs g) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[u], acc[t][u], 0, 0, 0);
+                for (int u = 0; u < 2; ++u) {
+                    if (ONET_GEMM_ABL == 1) { acc[t][u][0] += av[t] * bv[u]; continue; }
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[u], acc[t][u], 0, 0, 0);
+                }
+        }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // chunk c+1 landed (issued a whole chunk of MFMAs ago)
         __syncthreads();                                        // ... and every wave is done with this buffer
@@ -245,6 +303,7 @@ constexpr int KP = 32;                          // pixels per chunk (16 K-steps)
 constexpr int WA_F = 128 * KP;                  // A tile: 128 ci rows x 32 px
 constexpr int WB_F = 64 * 2 * KP;               // B tile: 64 (c, di) rows x (32 px x dj)
 
+template <bool BF = false>
 __global__ __launch_bounds__(256, 2) void convt_wgrad_gemm_kernel(GArgs g) {
     __shared__ __attribute__((aligned(16))) float lds[2 * (WA_F + WB_F)];
     int bid = xcd_order(gridDim.x);
@@ -312,6 +371,41 @@ __global__ __launch_bounds__(256, 2) void convt_wgrad_gemm_kernel(GArgs g) {
         const bool more = c + 1 < ch1;
         const float* A = lds + buf * (WA_F + WB_F);
         const float* Bt = A + WA_F;
+        if constexpr (BF) {
+            if (more) issue(c + 1, buf ^ 1, 0, 4);
+            // K = 16 pixels per MFMA: lane (i, kh) holds pixels 8 gg + 4 kh + 0..3 of two consecutive 8-pixel groups
+#pragma unroll
+            for (int g2 = 0; g2 < KP / 16; ++g2) {
+                float af[2][8], bf[2][8];
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int gg = 2 * g2 + h2;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const f32x4g v = *reinterpret_cast<const f32x4g*>(A + a_row[t] * KP + (((2 * gg + kh) ^ ((a_row[t] >> 1) & 7)) << 2));
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) af[t][4 * h2 + i] = v[i];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const f32x4g v = *reinterpret_cast<const f32x4g*>(Bt + b_row[u] * (2 * KP) + (((4 * gg + 2 * kh + e) ^ (b_row[u] & 7)) << 2));
+                            bf[u][4 * h2 + 2 * e] = dj ? v[1] : v[0];
+                            bf[u][4 * h2 + 2 * e + 1] = dj ? v[3] : v[2];
+                        }
+                }
+                bf16x8g a8[2], b8[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) a8[t] = g_pack8(af[t]);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) b8[u] = g_pack8(bf[u]);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[t], b8[u], acc[t][u], 0, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int gg = 0; gg < KP / 8; ++gg) {
 #if ONET_GEMM_SPREAD
@@ -341,6 +435,7 @@ __global__ __launch_bounds__(256, 2) void convt_wgrad_gemm_kernel(GArgs g) {
 #pragma unroll
                     for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t][tt], bv[u], acc[t][u], 0, 0, 0);
             }
+        }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -404,6 +499,12 @@ void wgrad_plan(int B, int Cin, int Ct, int h, int w, int& splitK, int& per) {
 
 namespace onet {
 
+// operand precision of the three GEMMs: 0 fp32 (default), 1 bf16 operands with fp32 accumulation (the bf16 conv path of BASELINE
+// configs[2]; set per call by the host side from its conv algorithm switch: onet_convT2x2_set_bf16)
+static std::atomic<int> g_convt_bf16{0};
+void convt_set_bf16(int on) { g_convt_bf16.store(on ? 1 : 0, std::memory_order_relaxed); }
+bool convt_bf16_operands() { return g_convt_bf16.load(std::memory_order_relaxed) != 0; }
+
 // Fast-path predicates + launches; return ONET_NOT_TAKEN (1) when the shape is not taken (caller falls back to conv_mfma.hip)
 int convt_gemm_fwd(const float* x, int64_t x_bs, const float* wq, const float* bias, float* y, int64_t y_bs, void* y16, int64_t y16_bs,
                    int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, hipStream_t st) {
@@ -417,7 +518,8 @@ int convt_gemm_fwd(const float* x, int64_t x_bs, const float* wq, const float* b
     GArgs g{wq, x, y, bias, nullptr, (__bf16*)y16, y16_bs, 0, x_bs, y_bs, B, Cin, Ct, h, w, Wo, Ho * Wo, (4 * Ct) / 128, (int)(B * hw / 128), 1, 0};
     const int64_t blocks = (int64_t)g.mTiles * g.nTiles;
     if (blocks <= 0 || blocks >= (1ll << 31)) return 1;
-    hipLaunchKernelGGL(convt_gemm_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, g);
+    if (convt_bf16_operands()) hipLaunchKernelGGL((convt_gemm_kernel<0, true>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((convt_gemm_kernel<0, false>), dim3((unsigned)blocks), dim3(256), 0, st, g);
     return check_launch("convt_gemm_kernel<0>");
 }
 
@@ -434,7 +536,8 @@ int convt_gemm_dgrad(const float* dy, int64_t dy_bs, const float* wd, float* dx,
     GArgs g{wd, dy, dx, nullptr, dbias ? dbias_ws : nullptr, nullptr, 0, 0, dy_bs, dx_bs, B, Cin, Ct, h, w, Wo, Ho * Wo, Cin / 128, (int)(B * hw / 128), 1, 0};
     const int64_t blocks = (int64_t)g.mTiles * g.nTiles;
     if (blocks <= 0 || blocks >= (1ll << 31)) return 1;
-    hipLaunchKernelGGL(convt_gemm_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, g);
+    if (convt_bf16_operands()) hipLaunchKernelGGL((convt_gemm_kernel<1, true>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((convt_gemm_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, st, g);
     int rc = check_launch("convt_gemm_kernel<1>");
     if (rc || !dbias) return rc;
     hipLaunchKernelGGL(convt_dbias_reduce_kernel, dim3((unsigned)Ct), dim3(256), 0, st, (const float*)dbias_ws, dbias, g.nTiles, Ct);
@@ -459,7 +562,8 @@ int convt_gemm_wgrad(const float* x, int64_t x_bs, const float* dy, int64_t dy_b
     const int64_t n = (int64_t)Cin * 4 * Ct;
     if (ws_bytes < (int64_t)g.splitK * n * 4) return 1;
     const int64_t blocks = (int64_t)g.splitK * g.mTiles * g.nTiles;
-    hipLaunchKernelGGL(convt_wgrad_gemm_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g);
+    if (convt_bf16_operands()) hipLaunchKernelGGL(convt_wgrad_gemm_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(convt_wgrad_gemm_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, g);
     int rc = check_launch("convt_wgrad_gemm_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(convt_wgrad_reduce_kernel, dim3((unsigned)cdiv(n / 4, 256)), dim3(256), 0, st, (const float*)ws, dw, g.splitK,

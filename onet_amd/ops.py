@@ -183,10 +183,20 @@ def packT2x2_fused(w):
     return wq
 
 
+# BASELINE configs[2]: under the bf16 conv path the ConvTranspose2d GEMMs take bf16 MFMA operands too (what torch.autocast does to
+# nn.ConvTranspose2d); ONET_CONVT_BF16=0 keeps them fp32.  The switch is process-wide in the library, so it is set per call.
+CONVT_BF16 = _os.environ.get("ONET_CONVT_BF16", "1") != "0"
+
+
+def _convt_precision():
+    _lib.load().onet_convT2x2_set_bf16(int(CONV_ALGO == "bf16" and CONVT_BF16))
+
+
 def convT2x2_fwd(x, wq, bias, out, Ct, pt, pl, out16=None):
     """out[:, c, pt + 2i + di, pl + 2j + dj] = sum_ci x[:, ci, i, j] * W[ci, c, di, dj] + bias[c]: ConvTranspose2d(k=2, s=2)
     written straight into `out`, a plane-contiguous [B, Ct, Ho, Wo] view (e.g. the second half of a concat buffer).
     out16: the matching bf16 view (bf16 storage) -> returns True if the copy was written (128 x 128 GEMM path only)."""
+    _convt_precision()
     require_gpu(x, wq, out)
     x, xbs = plane(x)
     B, Cin, h, w = x.shape
@@ -929,6 +939,7 @@ def convT2x2_dgrad(dy, wp_dgrad, Cin, h, w, pt, pl, want_dbias=False, db_out=Non
     """dx1 of ConvTranspose2d(k=2, s=2) straight from the [B, Ct, Ho, Wo] window `dy` of the concat gradient.
     want_dbias: -> (dx1, dbias | None): where the 128 x 128 GEMM path takes the shape the bias gradient is summed from the
     dy rows that launch stages anyway; None = not taken (the caller then runs the separate dbias pass)."""
+    _convt_precision()
     require_gpu(dy, wp_dgrad)
     dy, dybs = plane(dy)
     B, Ct, Ho, Wo = dy.shape
@@ -958,6 +969,7 @@ def convT2x2_dgrad(dy, wp_dgrad, Cin, h, w, pt, pl, want_dbias=False, db_out=Non
 
 def convT2x2_wgrad(x, dy, dw_shape, pt, pl, want_dbias, out=None, db_out=None):
     """(dW [Cin, Ct, 2, 2], dbias | None) of ConvTranspose2d(k=2, s=2) from x1 and the concat-gradient window."""
+    _convt_precision()
     require_gpu(x, dy)
     x, xbs = plane(x)
     dy, dybs = plane(dy)

@@ -504,6 +504,44 @@ def test_up_convT_cat(dev, h, w, Ho, Wo, Cin, Ct):
     close(Db.grad, d.grad, tol=3e-4, what="dbias")
 
 
+@pytest.mark.parametrize("h,w,Cin,Ct", [(32, 32, 128, 64), (16, 16, 128, 64), (16, 16, 256, 128), (64, 64, 128, 64), (8, 32, 384, 192)])
+def test_up_convT_cat_bf16_operands(dev, h, w, Cin, Ct, monkeypatch):
+    """BASELINE configs[2]: under the bf16 conv path the three ConvTranspose2d GEMMs (128 x 128 fast path) round their MFMA
+    operands to bf16 and accumulate in fp32 -- each must equal the fp64 result for the bf16-ROUNDED operands to fp32 summation
+    accuracy (1e-5 of scale; the bias gradient is summed from the unrounded fp32 rows), must differ from the fp32 kernels'
+    result (the bf16 kernels really ran), and the switch must not leak into fp32 calls made afterwards.  (Ct % 64 == 0: the
+    shapes whose forward AND backward take the GEMM path.)"""
+    from onet_amd import functional as Fn
+    from onet_amd import ops
+    B, C2, Ho, Wo = 2, Ct, 2 * h, 2 * w
+    x1, x2 = rnd(B, Cin, h, w, seed=15), rnd(B, C2, Ho, Wo, seed=16)
+    wt, bt = rnd(Cin, Ct, 2, 2, seed=17, scale=0.1), rnd(Ct, seed=18, scale=0.1)
+    g = rnd(B, C2 + Ct, Ho, Wo, seed=19)
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float64)
+    a, c = rb(x1).requires_grad_(True), rb(wt).requires_grad_(True)
+    u = F.conv_transpose2d(a, c, bt.double(), stride=2)
+    u.backward(rb(g[:, C2:]))
+    db_ref = g[:, C2:].double().sum((0, 2, 3))
+
+    def run():
+        A, Bt, Cw, Db = [t.to(dev).requires_grad_(True) for t in (x1, x2, wt, bt)]
+        out = Fn.UpConvTCatFn.apply(A, Bt, Cw, Db, (ops.packT2x2_fused(Cw), ops.packT2x2(Cw)[1]))
+        out.backward(g.to(dev))
+        return out.detach()[:, C2:].cpu().double(), A.grad.cpu().double(), Cw.grad.cpu().double(), Db.grad.cpu().double()
+
+    f32 = run()
+    monkeypatch.setattr(ops, "CONV_ALGO", "bf16")
+    b16 = run()
+    monkeypatch.setattr(ops, "CONV_ALGO", "auto")
+    again = run()
+    for got, ref, what in ((b16[0], u.detach(), "up fwd"), (b16[1], a.grad, "dx1"), (b16[2], c.grad, "dW"), (b16[3], db_ref, "dbias")):
+        sc = float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= (1e-5 if what != "dbias" else 1e-4) * sc, what
+    for i, what in enumerate(("up fwd", "dx1", "dW")):
+        assert float((b16[i] - f32[i]).abs().max()) > 1e-4 * float(f32[i].abs().max()), what + ": the bf16 kernels did not run"
+        assert torch.equal(again[i], f32[i]), what + ": bf16 switch leaked into an fp32 call"
+
+
 @pytest.mark.parametrize("h,w,Ho,Wo", [(8, 8, 16, 16), (12, 12, 25, 25), (1, 1, 2, 2)])
 def test_up_bilinear_cat(dev, h, w, Ho, Wo):
     from onet_amd import functional as Fn
