@@ -206,6 +206,8 @@ def main():
         REDUCTION = {"conv_wino4_kernel": 4.0, "conv_wino_kernel": 2.25, "conv_wino_wgrad_kernel": 2.25,
                      "conv_wino4_wgrad_kernel": 4.0}
         BF16 = ("conv3x3_bf16_kernel", "conv3x3_wgrad_bf16_kernel")
+        if bf16 and ops.CONVT_BF16:     # the ConvTranspose2d GEMMs take bf16 operands too (priced against the bf16 peak)
+            BF16 += ("convt_gemm_kernel", "convt_wgrad_gemm_kernel")
         ALGO = {"conv_wino_kernel": "Winograd F(2x2,3x3) on fp32 MFMA (fwd + dgrad)",
                 "conv_wino4_kernel": "Winograd F(4x4,3x3) on fp32 MFMA (fwd + dgrad; BatchNorm statistics / backward-reduce "
                                      "epilogues)",
@@ -213,8 +215,12 @@ def main():
                 "conv_wino4_wgrad_kernel": "Winograd F(3x3,4x4) weight gradient on fp32 MFMA, deterministic split-K",
                 "conv3x3_bf16_kernel": "direct implicit GEMM on v_mfma_f32_32x32x16_bf16 (bf16 operands, fp32 accumulate)",
                 "conv3x3_wgrad_bf16_kernel": "split-K weight gradient on v_mfma_f32_32x32x16_bf16",
-                "conv_fwd_kernel": "direct implicit GEMM on fp32 MFMA (stem, tiny maps, ConvTranspose2d GEMMs)",
-                "conv_wgrad_kernel": "direct split-K weight gradient on fp32 MFMA (stem, tiny maps, ConvTranspose2d)"}
+                "conv_fwd_kernel": "direct implicit GEMM on fp32 MFMA (stem, tiny maps)",
+                "conv_wgrad_kernel": "direct split-K weight gradient on fp32 MFMA (stem, tiny maps)",
+                "convt_gemm_kernel": "ConvTranspose2d forward / input-gradient GEMMs, 128x128 DMA-fed tiles (fp32 MFMA; bf16 "
+                                     "operands under --conv bf16)",
+                "convt_wgrad_gemm_kernel": "ConvTranspose2d weight-gradient GEMM, split-K (fp32 MFMA; bf16 operands under "
+                                           "--conv bf16)"}
         kern = {}
         for kind, recs in prof.items():
             ms = sum(r[1].elapsed_time(r[2]) for r in recs)

@@ -69,7 +69,9 @@ __device__ __forceinline__ void g_dma16(i32x4g rsrc, unsigned lds_base, unsigned
 // v_mfma_f32_32x32x16_bf16 per accumulator instead of eight v_mfma_f32_32x32x2_f32: a lane gathers its 8 K-values from LDS
 // (as many ds_read as before), rounds them to bf16 (v_cvt_pk_bf16_f32, nearest-even: the rounding the bf16 conv kernels apply
 // to their operands) and accumulates in fp32.  The fp32 kernels spend 2.6-2.8x their data-movement time in the matrix pipe
-// (timing-only build without the MFMAs: 0.90 vs 2.31 ms over the four decoder levels at B = 64).
+// (timing-only build without the MFMAs: 0.90 vs 2.31 ms over the four decoder levels at B = 64).  Measured with bf16 operands:
+// forward 0.97, dgrad 0.77, wgrad 0.92 ms (fp32: 2.32 / 2.13 / 2.51).  A ring of four chunk buffers with the DMA three chunks
+// ahead (the bf16 chunk is only 128 cycles of MFMAs) was NOT faster: forward 1.10, dgrad 0.78 -- dropped.
 __device__ __forceinline__ unsigned g_pack(float lo, float hi) {
     bf16x2g v = {(__bf16)lo, (__bf16)hi};
     return __builtin_bit_cast(unsigned, v);

@@ -209,7 +209,7 @@ def convT2x2_fwd(x, wq, bias, out, Ct, pt, pl, out16=None):
         e0 = _prof_begin()
         rc = _lib.load().onet_convT2x2_fwd_b(_p(x), xbs, _p(wq), _p(bias), _p(out), obs, _p(out16), o16bs, B, Cin, Ct, h, w, Ho, Wo,
                                              pt, pl, _stream())
-        _prof_end("conv_fwd_kernel", flops if rc == 0 else 0.0, e0, nb if rc == 0 else 0.0)
+        _prof_end("convt_gemm_kernel", flops if rc == 0 else 0.0, e0, nb if rc == 0 else 0.0)
         if rc == 0:
             return True
         if rc < 0:
@@ -218,7 +218,7 @@ def convT2x2_fwd(x, wq, bias, out, Ct, pt, pl, out16=None):
         return False
     e0 = _prof_begin()
     _lib.call("onet_convT2x2_fwd", _p(x), xbs, _p(wq), _p(bias), _p(out), obs, B, Cin, Ct, h, w, Ho, Wo, pt, pl, _stream())
-    _prof_end("conv_fwd_kernel", flops, e0, nb)
+    _prof_end("convt_gemm_kernel", flops, e0, nb)
     return False
 
 
@@ -955,15 +955,15 @@ def convT2x2_dgrad(dy, wp_dgrad, Cin, h, w, pt, pl, want_dbias=False, db_out=Non
             rc = lib.onet_convT2x2_dgrad_dbias(_p(dy), dybs, _p(wp_dgrad), _p(dx), Cin * h * w, _p(db), _p(ws), need, B, Cin, Ct, h,
                                                w, Ho, Wo, pt, pl, _stream())
             if rc == 0:
-                _prof_end("conv_fwd_kernel", flops, e0, nbytes)
+                _prof_end("convt_gemm_kernel", flops, e0, nbytes)
                 return dx, db
-            _prof_end("conv_fwd_kernel", 0.0, e0, 0.0)
+            _prof_end("convt_gemm_kernel", 0.0, e0, 0.0)
             if rc < 0:
                 raise _lib.OnetHipError(f"onet_convT2x2_dgrad_dbias failed ({rc}): {_lib.last_error()}")
     e0 = _prof_begin()
     _lib.call("onet_convT2x2_dgrad", _p(dy), dybs, _p(wp_dgrad), _p(dx), Cin * h * w, B, Cin, Ct, h, w, Ho, Wo, pt, pl,
               _stream())
-    _prof_end("conv_fwd_kernel", flops, e0, nbytes)
+    _prof_end("convt_gemm_kernel", flops, e0, nbytes)
     return (dx, None) if want_dbias else dx
 
 
@@ -981,7 +981,7 @@ def convT2x2_wgrad(x, dy, dw_shape, pt, pl, want_dbias, out=None, db_out=None):
     e0 = _prof_begin()
     _lib.call("onet_convT2x2_wgrad", _p(x), xbs, _p(dy), dybs, _p(dw), _p(ws), ws.numel() * 4, B, Cin, Ct, h, w, Ho, Wo,
               pt, pl, _stream())
-    _prof_end("conv_wgrad_kernel", 2.0 * B * h * w * Cin * 4 * Ct, e0, 4.0 * (B * h * w * (Cin + 4 * Ct) + 4 * Cin * Ct))
+    _prof_end("convt_wgrad_gemm_kernel", 2.0 * B * h * w * Cin * 4 * Ct, e0, 4.0 * (B * h * w * (Cin + 4 * Ct) + 4 * Cin * Ct))
     db = None
     if want_dbias:
         db = torch.empty(Ct, dtype=F32, device=x.device) if db_out is None else db_out
