@@ -20,7 +20,10 @@
 //  Measured limits (tools/time_bf16.py, ablation builds -DONET_BF_ABL=n, B = 64): removing the input loads saves 24-30 %, the
 //  stores 23 %, the MFMAs 19 % -- no single resource is saturated; the chunk period follows the global-load latency (loads are
 //  issued one chunk = 0.5-1 us of MFMA work ahead).  8-byte quad loads with an in-register transpose (a quarter of the load
-//  instructions) changed nothing (2.85 vs 2.80 ms over the six layer shapes) and were dropped.
+//  instructions) changed nothing (2.85 vs 2.80 ms over the six layer shapes) and were dropped.  Neither did a longer prefetch
+//  distance: input loads THREE chunks ahead in two register sets (244-256 VGPRs, no scratch) ran at 2.98 vs 2.77 ms -- so it
+//  is not the load latency as such; what is left is the in-order issue of ~130 non-MFMA instructions per chunk and wave with
+//  only two waves per SIMD to interleave (SQ: "waiting to issue" 0.58-0.63 of the wave cycles).
 // Requires Cin % 16 == 0 (K never straddles a chunk) and W > 16; everything else takes the fp32 kernels.
 #include <algorithm>
 #include <cstdlib>
