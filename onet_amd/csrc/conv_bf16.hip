@@ -17,13 +17,11 @@
 //  * per 16-channel chunk a wave issues 18 A + 3 x (NT + 2) B ds_read_b128 for 9 x 2 x NT MFMAs of 32 cycles
 //    (NT = 2 image rows per wave: 64 accumulator registers, two 4-wave blocks per CU), the reads one tap ahead of the MFMAs;
 //  * blocks are persistent and the load -> LDS -> MFMA pipeline runs across tile boundaries (see the kernel).
-//  Measured limits (tools/time_bf16.py, ablation builds -DONET_BF_ABL=n, B = 64): removing the input loads saves 24-30 %, the
-//  stores 23 %, the MFMAs 19 % -- no single resource is saturated; the chunk period follows the global-load latency (loads are
-//  issued one chunk = 0.5-1 us of MFMA work ahead).  8-byte quad loads with an in-register transpose (a quarter of the load
-//  instructions) changed nothing (2.85 vs 2.80 ms over the six layer shapes) and were dropped.  Neither did a longer prefetch
-//  distance: input loads THREE chunks ahead in two register sets (244-256 VGPRs, no scratch) ran at 2.98 vs 2.77 ms -- so it
-//  is not the load latency as such; what is left is the in-order issue of ~130 non-MFMA instructions per chunk and wave with
-//  only two waves per SIMD to interleave (SQ: "waiting to issue" 0.58-0.63 of the wave cycles).
+//  Measured limits (tools/time_bf16.py, ablation builds -DONET_BF_ABL=n, B = 64; table in DESIGN.md 4.2d): the cost that does not
+//  hide is the request rate of the NCHW input tile's cache lines (~240 half-used 128-byte lines per chunk): loading the input
+//  once saves 25 %, the weights once 5 %; a quarter of the planes is as good as none; a quarter of the load INSTRUCTIONS for the
+//  same lines (8-byte quad loads + in-register transpose) changes nothing, and neither does a longer prefetch distance (two
+//  register sets, loads three chunks ahead: slower) nor fewer VALU adds.  One block per CU keeps 80 % of the throughput.
 // Requires Cin % 16 == 0 (K never straddles a chunk) and W > 16; everything else takes the fp32 kernels.
 #include <algorithm>
 #include <cstdlib>
@@ -40,7 +38,7 @@ typedef float f32x4b __attribute__((ext_vector_type(4)));
 constexpr unsigned OOB_B = 0x80000000u;
 
 // experiments (tools/time_bf16.py, onet_amd.build --variant): 1 no global loads after the first chunk, 2 also no LDS commits,
-// 3 no MFMAs, 4 no epilogue stores.  Wrong results by construction; 0 in every shipped build.
+// 3 no MFMAs, 4 no epilogue stores, 7 weight slice loaded once per block, 8 input tile loaded once.  Wrong results by construction; 0 in every shipped build.
 #ifndef ONET_BF_ABL
 #define ONET_BF_ABL 0
 #endif
@@ -218,19 +216,29 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
     u32x4b wv[NWI];
     auto issue = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 0; k < NIT; ++k)
+        for (int k = 0; k < NIT; ++k) {
+            if (ONET_BF_ABL == 8 && (st_chunk | (st_tile - t_first)) != 0) break;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
+                // the chunk / plane part of the address is wave-uniform: it rides in the instruction's scalar offset (no VALU add
+                // per load); the per-lane part alone decides the range check (OOB_B -> 0)
                 if constexpr (XB)
                     xin[k][c] = __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(
-                                                              xr, in_off[k] + cin_bytes + c * plane, 0, 0));
+                                                              xr, in_off[k], (int)(cin_bytes + c * plane), 0));
                 else
                     xin[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                              xr, in_off[k] + cin_bytes + c * plane, 0, 0));   // OOB_B + anything stays out of range -> 0
+                                                              xr, in_off[k], (int)(cin_bytes + c * plane), 0));
             }
+        }
+        if (ONET_BF_ABL == 7 && (st_chunk | (st_tile - t_first)) != 0) return;     // experiment: weight slice loaded once per block
+        if (ONET_BF_ABL == 8) {                                                      // experiment: input loaded once, weights always
+#pragma unroll
+            for (int k = 0; k < NWI; ++k) wv[k] = __builtin_amdgcn_raw_buffer_load_b128(wr, w_off[k], (int)cw_bytes, 0);
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < NWI; ++k)
-            wv[k] = __builtin_amdgcn_raw_buffer_load_b128(wr, w_off[k] + cw_bytes, 0, 0);
+            wv[k] = __builtin_amdgcn_raw_buffer_load_b128(wr, w_off[k], (int)cw_bytes, 0);
     };
     u32x4b* const w_st = lds + tid;                                    // + 256 k          (+ buffer * BUF)
     u32x4b* const in_st = lds + C::W_SLOTS + kh * NPIXP + wn * 32 + l31;   // + 128 k
@@ -395,7 +403,9 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
 template <int NT, int WPS, int TW = 32, bool XB = false, bool ST = false>
 static int launch_bf16(BfArgs a, hipStream_t st) {
     using C = BfCfg<NT, TW>;
-    constexpr int LDS_BYTES = C::LDS_BYTES + (ST ? 4 * 64 * 2 * 4 : 0);
+    static int lds_pad = -1;      // experiment: ONET_BF16_LDS_PAD=bytes of unused dynamic LDS (forces fewer blocks per CU)
+    if (lds_pad < 0) { const char* e = getenv("ONET_BF16_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }
+    const int LDS_BYTES = C::LDS_BYTES + (ST ? 4 * 64 * 2 * 4 : 0) + lds_pad;
     a.tilesX = cdiv(a.W, TW);
     a.tilesY = cdiv(a.H, C::ROWS);
     a.coTiles = cdiv(a.Cout, C::CO_T);
@@ -407,7 +417,7 @@ static int launch_bf16(BfArgs a, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     }
     // persistent grid: as many blocks as are resident at once (WPS per CU), a multiple of the 8 XCDs
-    const int64_t resident = (int64_t)device_cu_count() * WPS;
+    const int64_t resident = (int64_t)device_cu_count() * (lds_pad > 30000 ? 1 : WPS);
     const int64_t blocks = std::min<int64_t>((tiles + 7) / 8 * 8, std::max<int64_t>(8, resident / 8 * 8));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), LDS_BYTES, st, a);
     return check_launch("conv3x3_bf16_kernel");
