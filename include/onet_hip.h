@@ -162,6 +162,11 @@ int onet_convT2x2_fwd_b(const float* x, int64_t x_bs, const float* wq, const flo
 int onet_conv3x3_bf16_fwd_b(const void* x_bf16, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin,
                             int Cout, int H, int W, void* stream);
 
+/* EXPERIMENT (groundwork for a channel-blocked bf16 operand layout): onet_conv3x3_bf16_fwd_b with the bf16 copy of x laid out as
+ * [C/8][H][W][8] per image (x_bs in elements, 16-byte aligned).  Not used by the module yet. */
+int onet_conv3x3_bf16_fwd_blk(const void* x_blk, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin, int Cout,
+                              int H, int W, void* stream);
+
 /* Forward of a Conv-BatchNorm pair on the bf16 kernels with the BatchNorm batch statistics of z taken from the final
  * accumulators (F.conv2d + the statistics half of nn.BatchNorm2d, OV:47-48 / 51-52): part [Cout][nparts][3] = (n, mean, M2) per
  * tile, consumed by onet_bn_finalize_cm.  nparts = onet_conv3x3_bf16_nparts(B, H, W); 0 = the map is not made of full tiles

@@ -133,7 +133,9 @@ struct BfCfg {
 // M2) record per tile and channel from the final accumulators (pivot-shifted sums per wave, the four waves of the tile merged
 // through LDS; full tiles only, host-checked) -- the separate statistics pass re-read every z once (12.8 ms of a 355 ms step
 // at B = 256).
-template <int NT, int WPS, int TW = 32, bool XB = false, bool ST = false>
+// XB: 0 fp32 NCHW input; 1 bf16 NCHW copy; 2 bf16 CHANNEL-BLOCKED copy [C/8][H][W][8] (a staging slot = 16 contiguous bytes: one
+// b128 load instead of eight 2-byte loads, and a halo row of a tile = 34 x 16 B of fully used cache lines)
+template <int NT, int WPS, int TW = 32, int XB = 0, bool ST = false>
 __global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
     using C = BfCfg<NT, TW>;
     constexpr int ROWS = C::ROWS, IN_COLS = C::IN_COLS, NIT = C::NIT, NWI = C::NWI, CO_T = C::CO_T, RPT = C::RPT;
@@ -190,7 +192,8 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
             const int r = p / IN_COLS, c = p % IN_COLS;
             const int yy = y0 - 1 + r, xx = x0 - 1 + c;
             const bool ok = live && p < C::NPIX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-            in_off[k] = ok ? (unsigned)(((kh * 8) * HW + yy * a.W + xx) * XE) : OOB_B;
+            if constexpr (XB == 2) in_off[k] = ok ? (unsigned)((kh * HW + yy * a.W + xx) * 16) : OOB_B;
+            else in_off[k] = ok ? (unsigned)(((kh * 8) * HW + yy * a.W + xx) * XE) : OOB_B;
         }
 #pragma unroll
         for (int k = 0; k < NWI; ++k) {
@@ -212,17 +215,23 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
         }
     };
 
-    float xin[NIT][8];                               // XB: the low 16 bits hold the bf16 value
+    float xin[XB == 2 ? 1 : NIT][8];                 // XB = 1: the low 16 bits hold the bf16 value
+    u32x4b xblk[XB == 2 ? NIT : 1];                  // XB = 2: the slot as it lies in memory
     u32x4b wv[NWI];
     auto issue = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
             if (ONET_BF_ABL == 8 && (st_chunk | (st_tile - t_first)) != 0) break;
+            if constexpr (XB == 2) {
+                xblk[k] = __builtin_amdgcn_raw_buffer_load_b128(xr, in_off[k], (int)cin_bytes, 0);
+                continue;
+            }
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 // the chunk / plane part of the address is wave-uniform: it rides in the instruction's scalar offset (no VALU add
                 // per load); the per-lane part alone decides the range check (OOB_B -> 0)
-                if constexpr (XB)
+                if constexpr (XB == 2) {
+                } else if constexpr (XB == 1)
                     xin[k][c] = __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(
                                                               xr, in_off[k], (int)(cin_bytes + c * plane), 0));
                 else
@@ -246,7 +255,9 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
             u32x4b v;
-            if constexpr (XB) {
+            if constexpr (XB == 2) {
+                v = xblk[k];
+            } else if constexpr (XB == 1) {
                 auto pk = [](float lo, float hi) { return __builtin_bit_cast(unsigned, lo) | (__builtin_bit_cast(unsigned, hi) << 16); };
                 v = u32x4b{pk(xin[k][0], xin[k][1]), pk(xin[k][2], xin[k][3]), pk(xin[k][4], xin[k][5]), pk(xin[k][6], xin[k][7])};
             } else {
@@ -400,7 +411,7 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
     }
 }
 
-template <int NT, int WPS, int TW = 32, bool XB = false, bool ST = false>
+template <int NT, int WPS, int TW = 32, int XB = 0, bool ST = false>
 static int launch_bf16(BfArgs a, hipStream_t st) {
     using C = BfCfg<NT, TW>;
     static int lds_pad = -1;      // experiment: ONET_BF16_LDS_PAD=bytes of unused dynamic LDS (forces fewer blocks per CU)
@@ -837,7 +848,7 @@ static int bf16_nparts(int B, int H, int W) {
     return n < (1 << 30) ? (int)n : 0;
 }
 
-static int bf16_fwd(const void* x, bool x_bf16, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin, int Cout,
+static int bf16_fwd(const void* x, int x_bf16, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin, int Cout,
                     int H, int W, void* stream, float* stats = nullptr) {
     ONET_REQUIRE(x && wq && z, "conv3x3_bf16_fwd: null pointer");
     ONET_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv3x3_bf16_fwd: bad shape");
@@ -848,24 +859,32 @@ static int bf16_fwd(const void* x, bool x_bf16, int64_t x_bs, const void* wq, fl
     BfArgs a{x, x_bs, (const __bf16*)wq, z, z_bs, B, Cin, Cout, H, W, 0, 0, 0, stats};
     if (stats) {
         ONET_REQUIRE(bf16_nparts(B, H, W) > 0, "conv3x3_bf16_fwd_stats: the map must be made of full tiles (onet_conv3x3_bf16_nparts() == 0 elsewhere)");
-        if (x_bf16) return (W > 16) ? launch_bf16<2, 2, 32, true, true>(a, as_stream(stream)) : launch_bf16<2, 2, 16, true, true>(a, as_stream(stream));
-        return (W > 16) ? launch_bf16<2, 2, 32, false, true>(a, as_stream(stream)) : launch_bf16<2, 2, 16, false, true>(a, as_stream(stream));
+        if (x_bf16) return (W > 16) ? launch_bf16<2, 2, 32, 1, true>(a, as_stream(stream)) : launch_bf16<2, 2, 16, 1, true>(a, as_stream(stream));
+        return (W > 16) ? launch_bf16<2, 2, 32, 0, true>(a, as_stream(stream)) : launch_bf16<2, 2, 16, 0, true>(a, as_stream(stream));
     }
     // 4 waves x 2 rows x 32 px, two blocks (8 waves) per CU: 373-851 TF on the U-Net's layers against 278-527 for
     // 4-row waves at one wave per SIMD and ~100 for 4-row waves squeezed into 256 VGPRs (700 B/lane of scratch)
     // (three blocks per CU for the bf16-input kernel -- 168 VGPRs -- changed nothing: 0.412 vs 0.410 ms per launch)
-    if (x_bf16) return (W > 16) ? launch_bf16<2, 2, 32, true>(a, as_stream(stream)) : launch_bf16<2, 2, 16, true>(a, as_stream(stream));
+    if (x_bf16 == 2) return (W > 16) ? launch_bf16<2, 2, 32, 2>(a, as_stream(stream)) : launch_bf16<2, 2, 16, 2>(a, as_stream(stream));
+    if (x_bf16) return (W > 16) ? launch_bf16<2, 2, 32, 1>(a, as_stream(stream)) : launch_bf16<2, 2, 16, 1>(a, as_stream(stream));
     return (W > 16) ? launch_bf16<2, 2>(a, as_stream(stream)) : launch_bf16<2, 2, 16>(a, as_stream(stream));
 }
 
 int onet_conv3x3_bf16_fwd(const float* x, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin, int Cout,
                           int H, int W, void* stream) {
-    return bf16_fwd(x, false, x_bs, wq, z, z_bs, B, Cin, Cout, H, W, stream);
+    return bf16_fwd(x, 0, x_bs, wq, z, z_bs, B, Cin, Cout, H, W, stream);
 }
 
 int onet_conv3x3_bf16_fwd_b(const void* x_bf16, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin, int Cout,
                             int H, int W, void* stream) {
-    return bf16_fwd(x_bf16, true, x_bs, wq, z, z_bs, B, Cin, Cout, H, W, stream);
+    return bf16_fwd(x_bf16, 1, x_bs, wq, z, z_bs, B, Cin, Cout, H, W, stream);
+}
+
+// EXPERIMENT (round 3 groundwork): the same forward with the bf16 copy in the channel-blocked layout [C/8][H][W][8]
+int onet_conv3x3_bf16_fwd_blk(const void* x_blk, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin, int Cout,
+                              int H, int W, void* stream) {
+    ONET_REQUIRE((reinterpret_cast<uintptr_t>(x_blk) & 15) == 0 && (x_bs & 7) == 0, "conv3x3_bf16_fwd_blk: 16-byte aligned slots required");
+    return bf16_fwd(x_blk, 2, x_bs, wq, z, z_bs, B, Cin, Cout, H, W, stream);
 }
 
 int onet_conv3x3_bf16_nparts(int B, int H, int W) { return bf16_nparts(B, H, W); }
@@ -873,7 +892,7 @@ int onet_conv3x3_bf16_nparts(int B, int H, int W) { return bf16_nparts(B, H, W);
 int onet_conv3x3_bf16_fwd_stats(const void* x, int x_is_bf16, int64_t x_bs, const void* wq, float* z, int64_t z_bs, float* part, int B,
                                 int Cin, int Cout, int H, int W, void* stream) {
     ONET_REQUIRE(part, "conv3x3_bf16_fwd_stats: null pointer");
-    return bf16_fwd(x, x_is_bf16 != 0, x_bs, wq, z, z_bs, B, Cin, Cout, H, W, stream, part);
+    return bf16_fwd(x, x_is_bf16 != 0 ? 1 : 0, x_bs, wq, z, z_bs, B, Cin, Cout, H, W, stream, part);
 }
 
 int64_t onet_conv3x3_wgrad_bf16_ws_bytes(int B, int Cin, int Cout, int H, int W) {

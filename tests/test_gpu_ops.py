@@ -330,6 +330,22 @@ def test_conv3x3_winograd4_wgrad(dev, B, Cin, Cout, H, W):
     assert err <= 2e-4 * sc, (err, sc)
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 16, 64, 32, 32), (3, 48, 32, 17, 33), (2, 64, 128, 16, 16), (2, 16, 96, 200, 288)])
+def test_conv3x3_bf16_channel_blocked_input(dev, B, Cin, Cout, H, W):
+    """Experimental entry point onet_conv3x3_bf16_fwd_blk: the bf16 forward reading its operand from a channel-blocked copy
+    [C/8][H][W][8] (one 16-byte load per staging slot) must be bit-identical to the NCHW bf16 copy path."""
+    from onet_amd import _lib, ops
+    x16 = rnd(B, Cin, H, W, seed=51).to(dev).to(torch.bfloat16)
+    w = rnd(Cout, Cin, 3, 3, seed=52, scale=(2.0 / (Cin * 9)) ** 0.5)
+    qf, _ = ops.pack3x3_bf16(w.to(dev))
+    z0 = ops.conv3x3_bf16(None, qf, Cout, x16=x16)
+    xb = x16.view(B, Cin // 8, 8, H, W).permute(0, 1, 3, 4, 2).contiguous()
+    z1 = torch.full_like(z0, float("nan"))
+    _lib.call("onet_conv3x3_bf16_fwd_blk", xb.data_ptr(), Cin * H * W, qf.data_ptr(), z1.data_ptr(), Cout * H * W, B, Cin, Cout, H, W,
+              torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(z0, z1)
+
+
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 64, 64, 32, 32), (3, 16, 48, 20, 44), (2, 128, 64, 16, 16),
                                              (1, 72, 40, 9, 28), (4, 64, 128, 64, 64), (2, 64, 64, 40, 72), (3, 32, 96, 24, 128),
                                              (1, 80, 64, 256, 256), (2, 16, 16, 3, 68), (5, 48, 40, 7, 200)])

@@ -15,8 +15,19 @@ for ci, co, H in shapes:
     dz16 = torch.randn(B, co, H, H, device="cuda").to(torch.bfloat16)
     w = torch.randn(co, ci, 3, 3, device="cuda") * 0.05
     bf, bd = ops.pack3x3_bf16(w)
+    if os.environ.get("BLOCKED"):      # channel-blocked copy [C/8][H][W][8] through the experimental entry point
+        from onet_amd import _lib
+        xb = x16.view(B, ci // 8, 8, H, H).permute(0, 1, 3, 4, 2).contiguous()
+        zb = torch.empty(B, co, H, H, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        z0 = ops.conv3x3_bf16(None, bf, co, x16=x16)
+        _lib.call("onet_conv3x3_bf16_fwd_blk", xb.data_ptr(), ci * H * H, bf.data_ptr(), zb.data_ptr(), co * H * H, B, ci, co, H, H, st)
+        assert torch.equal(z0, zb), "blocked-layout forward differs"
+        fwd = lambda: _lib.call("onet_conv3x3_bf16_fwd_blk", xb.data_ptr(), ci * H * H, bf.data_ptr(), zb.data_ptr(), co * H * H, B, ci, co, H, H, st)
+    else:
+        fwd = lambda: ops.conv3x3_bf16(None, bf, co, x16=x16)
     res = []
-    for fn in (lambda: ops.conv3x3_bf16(None, bf, co, x16=x16),
+    for fn in (fwd,
                lambda: ops.conv3x3_wgrad_bf16(None, None, (co, ci, 3, 3), x16=x16, dz16=dz16)):
         for _ in range(3):
             fn()
