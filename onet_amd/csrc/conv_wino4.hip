@@ -255,7 +255,10 @@ static __device__ __forceinline__ void wino4_body(const Wino4Args& a, float* sme
         const int ci = i / (IMG * IN_ROWS * IN_COLS), rem = i % (IMG * IN_ROWS * IN_COLS);
         const int m = rem / (IN_ROWS * IN_COLS), r = (rem % (IN_ROWS * IN_COLS)) / IN_COLS, c = rem % IN_COLS;
         const int yy = y0 - 1 + r, xx = x0 - 1 + c;
-        const bool ok = (i < C::IN_LOGICAL) && m < nimg && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+        bool ok = (i < C::IN_LOGICAL) && m < nimg && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+#if defined(ONET_W4_ABL) && ONET_W4_ABL == 1       // timing experiment: no halo COLUMNS (a row piece = one aligned 128-byte line instead of three)
+        ok = ok && c >= 1 && c <= IN_COLS - 2;
+#endif
         in_off[k] = ok ? (unsigned)(((int64_t)m * a.x_bs + ci * HW + yy * a.W + xx) * 4) : OOB4;
     }
     // weight DMA piece q = wid + 8k covers packed rows 4q .. 4q+3 of this block's 64-channel slice
