@@ -516,6 +516,15 @@ static __device__ __forceinline__ void wino4_body(const Wino4Args& a, float* sme
     if (c < nch) chunk(I0{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (all-zero) staging must land before the LDS is reused
     __syncthreads();
+#if defined(ONET_W4_ABL) && ONET_W4_ABL == 3           // timing experiment: no epilogue at all (accumulators kept alive)
+    {
+        float s = 0.f;
+#pragma unroll
+        for (int p = 0; p < 9; ++p) s += acc[p][0];
+        if (s == 12345.678f) a.z[tid] = s;
+        return;
+    }
+#endif
 
     // ---- epilogue: partial A^T M A of this position group; the four groups are summed through LDS by the
     // RH = CH = 0 wave of each channel half, two accumulator registers (= 2 channels x 32 tiles x 16 px) per pass

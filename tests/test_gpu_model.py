@@ -177,12 +177,14 @@ def test_bf16_conv_path_vs_reference_golden(dev, monkeypatch):
     print(f"bf16 path: loss rel {rel:.2e}, worst gradient-norm error {worst:.2e}")
 
 
-@pytest.mark.parametrize("shape", [(2, 1, 256, 256), (3, 1, 64, 96)])
+@pytest.mark.parametrize("shape", [(2, 1, 256, 256), (3, 1, 64, 96), (2, 1, 40, 40), (2, 3, 48, 80), (1, 1, 128, 128)])
 def test_bf16_storage_is_bit_identical_to_rounding_on_load(dev, shape, monkeypatch):
     """BASELINE config 3 with bf16 STORAGE of the conv operands (the BatchNorm / pooling / ConvTranspose2d kernels write bf16
     copies next to their fp32 outputs, the BatchNorm backward writes dz in bf16 only; the bf16 conv kernels read those): the
     producers round to nearest even exactly as the conv kernels do on the way into LDS, so loss, outputs and every gradient
-    must be BIT-IDENTICAL to the fp32-storage bf16 path -- and the copies must really be used."""
+    must be BIT-IDENTICAL to the fp32-storage bf16 path -- and the copies must really be used.  The small and ragged shapes
+    exercise the fall-backs: levels whose width is not a multiple of 8 keep fp32 operands (no placeholder may reach them), the
+    F.pad path builds an ordinary fp32 concat buffer."""
     from onet_amd import _lib, ops
     monkeypatch.setattr(ops, "CONV_ALGO", "bf16")
     B, C, H, W = shape
@@ -207,7 +209,10 @@ def test_bf16_storage_is_bit_identical_to_rounding_on_load(dev, shape, monkeypat
         used[storage] = dict(cnt)
         monkeypatch.setattr(_lib, "call", real_call)
     assert used[False] == {"fwd16": 0, "wg16": 0}
-    assert used[True]["fwd16"] >= 20 and used[True]["wg16"] >= 20, used     # forward + dgrad launches, weight-gradient operands
+    if H % 16 == 0 and W % 16 == 0 and min(H, W) >= 64:
+        assert used[True]["fwd16"] >= 20 and used[True]["wg16"] >= 20, used     # forward + dgrad launches, weight-gradient operands
+    else:       # ragged / small maps (F.pad path, W % 8 != 0 levels): fewer layers qualify, the fp32 fall-backs take the rest
+        assert used[True]["fwd16"] >= 1, used
     a, b = res[False], res[True]
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
     for ga, gb in zip(a[3], b[3]):
