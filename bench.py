@@ -217,6 +217,8 @@ def main():
                 "conv3x3_wgrad_bf16_kernel": "split-K weight gradient on v_mfma_f32_32x32x16_bf16",
                 "conv_fwd_kernel": "direct implicit GEMM on fp32 MFMA (stem, tiny maps)",
                 "conv_wgrad_kernel": "direct split-K weight gradient on fp32 MFMA (stem, tiny maps)",
+                "stem_conv_stats_kernel": "stem convolution (Cin = n_channels) + BatchNorm statistics, one streaming VALU pass "
+                                          "(bound by writing z: see hbm_frac)",
                 "convt_gemm_kernel": "ConvTranspose2d forward / input-gradient GEMMs, 128x128 DMA-fed tiles (fp32 MFMA; bf16 "
                                      "operands under --conv bf16)",
                 "convt_wgrad_gemm_kernel": "ConvTranspose2d weight-gradient GEMM, split-K (fp32 MFMA; bf16 operands under "

@@ -162,6 +162,15 @@ int onet_convT2x2_fwd_b(const float* x, int64_t x_bs, const float* wq, const flo
 int onet_conv3x3_bf16_fwd_b(const void* x_bf16, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin,
                             int Cout, int H, int W, void* stream);
 
+/* The stem: first 3x3 convolution of the U-Net (F.conv2d of `inc`, OV:47, Cin = n_channels in 1..4, no bias) and the batch
+ * statistics of its BatchNorm (OV:48) in one streaming pass.  w: the nn.Conv2d weight [Cout][Cin][3][3] as it is (no pack);
+ * part [Cout][nparts][3] = (n, mean, M2) per 16 x 64-pixel tile for onet_bn_finalize_cm, or NULL (convolution only).
+ * nparts = onet_conv3x3_stem_nparts(B, Cin, Cout, H, W); 0 = not applicable (Cin > 4, Cout > 128, H % 16 or W % 64): use
+ * onet_conv_fwd + onet_bn_stats_partial. */
+int onet_conv3x3_stem_nparts(int B, int Cin, int Cout, int H, int W);
+int onet_conv3x3_stem_fwd_stats(const float* x, int64_t x_bs, const float* w, float* z, int64_t z_bs, float* part, int B, int Cin,
+                                int Cout, int H, int W, void* stream);
+
 /* EXPERIMENT (groundwork for a channel-blocked bf16 operand layout): onet_conv3x3_bf16_fwd_b with the bf16 copy of x laid out as
  * [C/8][H][W][8] per image (x_bs in elements, 16-byte aligned).  Not used by the module yet. */
 int onet_conv3x3_bf16_fwd_blk(const void* x_blk, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin, int Cout,

@@ -371,6 +371,7 @@ def conv3x3_auto(x, pk, direction, out=None, x16=None):
 
 
 FUSE_BN_STATS = _os.environ.get("ONET_FUSE_BN_STATS", "1") != "0"
+STEM_FUSED = _os.environ.get("ONET_STEM_FUSED", "1") != "0"      # 0: the stem takes the direct MFMA kernel + a statistics pass
 
 
 def conv3x3_fwd_bn_partials(x, pk, x16=None):
@@ -379,6 +380,19 @@ def conv3x3_fwd_bn_partials(x, pk, x16=None):
     where the selected kernel does not emit them (then `bn_train_coeffs` runs its own statistics pass)."""
     Ci, Co = pk["Cin"], pk["Cout"]
     B, _, H, W = (x if x is not None else x16).shape
+    if Ci <= 4 and x is not None and STEM_FUSED and FUSE_BN_STATS and not SYNC_BN and hasattr(pk, "w"):
+        # the stem (Cin = n_channels): one streaming pass writes z and its statistics records (stem.hip)
+        nparts = int(_lib.load().onet_conv3x3_stem_nparts(B, Ci, Co, H, W))
+        if nparts > 0:
+            require_gpu(x)
+            xs, xbs = plane(x)
+            w = pk.w if pk.w.is_contiguous() else pk.w.contiguous()
+            out = torch.empty((B, Co, H, W), dtype=F32, device=x.device)
+            cm = torch.empty((Co, nparts, 3), dtype=F32, device=x.device)
+            e0 = _prof_begin()
+            _lib.call("onet_conv3x3_stem_fwd_stats", _p(xs), xbs, _p(w), _p(out), Co * H * W, _p(cm), B, Ci, Co, H, W, _stream())
+            _prof_end("stem_conv_stats_kernel", 2.0 * B * H * W * Ci * Co * 9, e0, 4.0 * (B * H * W * (Ci + Co) + 9 * Ci * Co))
+            return out, cm
     algo = conv3x3_algo(B, Ci, Co, H, W)
     nparts = 0
     if algo == "winograd4" and FUSE_BN_STATS and not SYNC_BN:

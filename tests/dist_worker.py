@@ -40,6 +40,10 @@ def main():
         return loss
 
     # ---- two ranks, SyncBN, overlapped buckets
+    # (SyncBN takes the stem through the direct kernel + all-gathered partials; the 1-rank comparison run below must take the same
+    # stem kernel: z differs by 1e-7 between the two, which flips the sign of rounding-level gradients of the 9-element stem filters,
+    # and Adam turns a sign flip into a full lr-sized step -- 1e-3 of the stem BatchNorm's running mean after two steps)
+    ops.STEM_FUSED = False
     ops.set_sync_bn(True)
     m = build(rank)
     opt = FlatAdam(m, lr=1e-4, world_size=world)

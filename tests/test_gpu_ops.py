@@ -233,6 +233,53 @@ def test_winograd4_fused_bn_statistics(dev, B, Cin, Cout, H, W):
         assert float(((s1[1].cpu().double() - ir) / ir).abs().max()) <= 1e-5
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 1, 64, 32, 64), (3, 3, 64, 48, 128), (2, 1, 64, 256, 256), (4, 2, 40, 16, 64),
+                                             (2, 4, 128, 32, 192)])
+def test_stem_conv_fused_bn_statistics(dev, B, Cin, Cout, H, W):
+    """stem.hip: the first convolution (Cin = n_channels in 1..4) with its BatchNorm statistics records in one streaming pass:
+    z against the fp64 convolution at fp32 accuracy (a 9 Cin-term FMA chain), finalize(records) == finalize(separate pass) for
+    the whole batch and a batch slice, and against fp64; maps not made of 16 x 64 tiles, Cin > 4 or Cout > 128 report 0."""
+    from onet_amd import _lib, ops
+    lib = _lib.load()
+    for args in [(B, 1, 64, 40, 64), (B, 1, 64, 32, 96), (B, 5, 64, 32, 64), (B, 1, 136, 32, 64)]:
+        assert int(lib.onet_conv3x3_stem_nparts(*args)) == 0
+    x = rnd(B, Cin, H, W, seed=71) + 0.3
+    w = rnd(Cout, Cin, 3, 3, seed=72) / (3.0 * Cin ** 0.5)
+    xd, wd = x.to(dev), w.to(dev)
+    nparts = int(lib.onet_conv3x3_stem_nparts(B, Cin, Cout, H, W))
+    assert nparts == B * (H // 16) * (W // 64)
+    z = torch.full((B, Cout, H, W), float("nan"), device=dev)
+    cm = torch.full((Cout, nparts, 3), float("nan"), device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.call("onet_conv3x3_stem_fwd_stats", xd.data_ptr(), Cin * H * W, wd.data_ptr(), z.data_ptr(), Cout * H * W, cm.data_ptr(),
+              B, Cin, Cout, H, W, st)
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    assert float((z.cpu().double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    z2 = torch.empty_like(z)                                  # convolution only
+    _lib.call("onet_conv3x3_stem_fwd_stats", xd.data_ptr(), Cin * H * W, wd.data_ptr(), z2.data_ptr(), Cout * H * W, None,
+              B, Cin, Cout, H, W, st)
+    assert torch.equal(z, z2)
+    assert torch.isfinite(cm).all()
+    assert float(cm[:, :, 0].sum(1).min()) == float(cm[:, :, 0].sum(1).max()) == B * H * W
+    gamma = (1 + 0.1 * rnd(Cout, seed=33)).to(dev)
+    beta = (0.1 * rnd(Cout, seed=34)).to(dev)
+    for lo, hi in [(0, B), (B // 2, B)]:
+        zs = z[lo:hi]
+        rm0, rv0 = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
+        rm1, rv1 = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
+        s0 = ops.bn_train_coeffs(zs, gamma, beta, rm0, rv0, 0.1, 1e-5)
+        npi = nparts // B
+        s1 = ops.bn_train_coeffs(zs, gamma, beta, rm1, rv1, 0.1, 1e-5, cm=(cm, lo * npi, (hi - lo) * npi))
+        sd = float(zs.std())
+        assert float((s0[0] - s1[0]).abs().max()) <= 2e-6 * sd, "mean"
+        assert float(((s0[1] - s1[1]) / s0[1]).abs().max()) <= 1e-5, "invstd"
+        assert float((rm0 - rm1).abs().max()) <= 1e-6 * sd and float(((rv0 - rv1) / rv0).abs().max()) <= 1e-5
+        zr = zs.double().cpu()
+        assert float((s1[0].cpu().double() - zr.mean((0, 2, 3))).abs().max()) <= 2e-6 * sd
+        ir = 1.0 / torch.sqrt(zr.var((0, 2, 3), unbiased=False) + 1e-5)
+        assert float(((s1[1].cpu().double() - ir) / ir).abs().max()) <= 1e-5
+
+
 @pytest.mark.parametrize("B,Cin,Cout,H,W,x_bf16", [(2, 16, 64, 32, 32, True), (3, 32, 72, 16, 64, False), (4, 64, 128, 64, 64, True),
                                                     (2, 16, 40, 32, 16, True), (5, 48, 64, 16, 16, False), (2, 32, 64, 200, 96, True)])
 def test_bf16_fused_bn_statistics(dev, B, Cin, Cout, H, W, x_bf16):
