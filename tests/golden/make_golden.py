@@ -182,7 +182,7 @@ def install_routing(model, routing):
                     mod[i] = RoutedPool()
 
 
-def run_routed_case(ov, tag, B, C, H, W, head_gain=0.3):
+def run_routed_case(ov, tag, B, C, H, W, head_gain=0.3, with_routed=True):
     """Well-conditioned head (|V| <= 5), larger batch.  Three evaluations of the REAL reference graph:
     fp32 (decisions recorded), fp64 deciding freely ("truth"), fp64 taking the fp32 run's decisions ("routed").
     fp32 vs truth differ by 3e-3..5e-3 on every parameter (ReLU / pooling decisions flip at rounding level), fp32 vs
@@ -219,10 +219,11 @@ def run_routed_case(ov, tag, B, C, H, W, head_gain=0.3):
     out["grad_norms64"], out["grad_vals64"], _ = grad_samples([(n, p.grad) for n, p in m64.named_parameters()])
     out["Vt64"] = o64[1].detach().numpy()[:, :, ::37, :]
     del m64, o64
-    m64r, o64r, l64r = build(torch.float64, r.replay())
-    out["loss64r"] = np.float64(l64r.item())
-    out["grad_norms64r"], out["grad_vals64r"], _ = grad_samples([(n, p.grad) for n, p in m64r.named_parameters()])
-    out["routing_audit"] = np.array([[a[1], a[2], a[3]] for a in r.audit], dtype=np.float64)
+    if with_routed:
+        m64r, o64r, l64r = build(torch.float64, r.replay())
+        out["loss64r"] = np.float64(l64r.item())
+        out["grad_norms64r"], out["grad_vals64r"], _ = grad_samples([(n, p.grad) for n, p in m64r.named_parameters()])
+        out["routing_audit"] = np.array([[a[1], a[2], a[3]] for a in r.audit], dtype=np.float64)
     out["grad_vals"] = out["grad_vals"].astype(np.float32)
     np.savez_compressed(os.path.join(HERE, f"onet_{tag}.npz"), **out)
 
@@ -230,6 +231,9 @@ def run_routed_case(ov, tag, B, C, H, W, head_gain=0.3):
         o = out["grad_offs"]
         return max(np.linalg.norm(a[o[i]:o[i + 1]] - b[o[i]:o[i + 1]]) / np.linalg.norm(b[o[i]:o[i + 1]])
                    for i in range(len(o) - 1))
+    if not with_routed:
+        print(tag, "loss", float(l32), float(l64), "| fp32 vs truth %.2e" % worst(out["grad_vals"].astype(np.float64), out["grad_vals64"]))
+        return
     print(tag, "loss", float(l32), float(l64), float(l64r), "| fp32 vs truth %.2e, fp32 vs routed %.2e, flips %d" % (
         worst(out["grad_vals"].astype(np.float64), out["grad_vals64"]),
         worst(out["grad_vals"].astype(np.float64), out["grad_vals64r"]), int(out["routing_audit"][:, 0].sum())))
@@ -409,6 +413,11 @@ if __name__ == "__main__":
     if os.environ.get("GOLDEN_ONLY") == "up":
         run_up_block(ov, False, "convT_pad")
         run_up_block(ov, True, "bilinear_pad")
+        sys.exit(0)
+    if os.environ.get("GOLDEN_ONLY") == "c5":            # BASELINE configs[4]'s tile shape: 3 x 512 x 512 (ZY-3 cloud tiles)
+        # (fp32 + free fp64 evaluations of the reference only: the module-swap replay of this script reproduces the loss but not
+        # the gradients at B = 1 -- the oracle's own routed evaluation agrees with the reference's fp32 gradients to 7e-5 here)
+        run_routed_case(ov, "routed_b1_c3_512", 1, 3, 512, 512, with_routed=False)
         sys.exit(0)
     if os.environ.get("GOLDEN_ONLY") == "routed":
         run_routed_case(ov, "routed_b8_c1_128", 8, 1, 128, 128)

@@ -107,6 +107,7 @@ CASES = {
     "b4_c1_256": (4, 1, 256, 256, 0.3, ("auto", "winograd4")),
     "b2_c3_64_saturated": (2, 3, 64, 64, 1.0, ("auto", "winograd4")),
     "b3_c1_40_padpath": (3, 1, 40, 40, 1.0, ("auto",)),
+    "b1_c3_512": (1, 3, 512, 512, 0.3, ("auto",)),        # BASELINE configs[4]'s tile shape (3-channel 512 x 512), batch statistics over ONE image
 }
 
 
