@@ -278,13 +278,20 @@ def main():
                                 "note": "per-launch HIP-event brackets on the launch stream, inside the timed region; "
                                         "unattributed = torch glue kernels, event overhead and launch gaps"}
         imgs = args.batch * world * args.steps
-        out = {"metric": "training images/sec (twin 256x256 pass)", "value": round(imgs / elapsed, 3),
+        if args.size == 256 and args.chans == 1:
+            cfg_name = "configs[2]" if bf16 else ("configs[3]" if world > 1 and args.batch * world == 256 else "configs[1]")
+        elif args.size == 512 and args.chans == 3:
+            cfg_name = "configs[4]-shaped (3x512x512 tiles)"
+        else:
+            cfg_name = "non-BASELINE shape"
+        out = {"metric": "training images/sec (twin %dx%d pass)" % (args.size, args.size), "value": round(imgs / elapsed, 3),
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "bf16 conv operands (fwd/dgrad/wgrad), f32 accumulate/storage" if bf16 else "f32",
+               "vs_baseline": None,
+               "dtype": "bf16 MFMA operands (3x3 conv fwd/dgrad/wgrad, ConvTranspose2d), f32 accumulate, f32 master tensors" if bf16 else "f32",
                "data": "synthetic",
                "config": {"workload": "%s: batch=%d/GPU %dx%dx%d synthetic K-clutter, %s, twin U-Net "
-                                      "fwd+JSD loss+bwd+Adam" % ("configs[2]" if bf16 else "configs[1]", args.batch, args.chans,
+                                      "fwd+JSD loss+bwd+Adam" % (cfg_name, args.batch, args.chans,
                                                                  args.size, args.size, "bf16 MFMA conv path" if bf16 else "fp32"),
                           "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                           "optimizer": "torch.optim.Adam" if args.torch_adam else "fused flat Adam (HIP)",
