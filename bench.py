@@ -288,7 +288,9 @@ def main():
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None,
-               "dtype": "bf16 MFMA operands (3x3 conv fwd/dgrad/wgrad, ConvTranspose2d), f32 accumulate, f32 master tensors" if bf16 else "f32",
+               "dtype": "bf16" if bf16 else "f32",
+               "precision": ("bf16 MFMA operands (3x3 conv fwd/dgrad/wgrad, ConvTranspose2d GEMMs), f32 accumulation, f32 conv outputs, "
+                             "BatchNorm, loss, master weights and optimizer") if bf16 else "f32 throughout",
                "data": "synthetic",
                "config": {"workload": "%s: batch=%d/GPU %dx%dx%d synthetic K-clutter, %s, twin U-Net "
                                       "fwd+JSD loss+bwd+Adam" % (cfg_name, args.batch, args.chans,
