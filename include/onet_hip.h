@@ -238,6 +238,13 @@ int onet_bn_eval_coeffs(const float* gamma, const float* beta, const float* runn
 /* a = max(0, (z-mean)*scale + beta)   (BN + nn.ReLU, OV:48-49) */
 int onet_bn_relu_apply(const float* z, int64_t z_bs, float* a, int64_t a_bs, const float* save,
                        int B, int C, int HW, void* stream);
+/* relu(bn(z)) AND its 2x2 max-pooling in one pass (nn.BatchNorm2d + nn.ReLU of an encoder block followed by nn.MaxPool2d(2),
+ * OV:48-49 / 52-53 -> OV:67): a [B,C,H,W] (and / or its bf16 copy a_bf16), y [B,C,H/2,W/2] (and / or y_bf16); any of the four may be
+ * NULL as long as one of each pair is given.  Bit-identical to onet_bn_relu_apply[_b] followed by onet_maxpool2_fwd[_b].
+ * Returns 1 (nothing done) unless H % 2 == 0, W % 4 == 0 and rows are 16-byte aligned. */
+int onet_bn_relu_apply_pool(const float* z, int64_t z_bs, float* a, int64_t a_bs, void* a_bf16, int64_t a16_bs, float* y, int64_t y_bs,
+                            void* y_bf16, int64_t y16_bs, const float* save, int B, int C, int H, int W, void* stream);
+
 /* backward of BN(train)+ReLU.  dy = da * ((z-mean)*scale+beta > 0);
  * pass 1: part2 [nparts][C][4] = (sum dy, sum dy*xhat) as (hi, lo) float pairs of fp64 sums;
  * finalize: dgamma (+)= sum dy*xhat, dbeta (+)= sum dy, coef [4][C] = (hi, lo) pairs of

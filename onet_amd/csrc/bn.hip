@@ -231,6 +231,46 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restr
     }
 }
 
+// The same pass for an encoder output that is max-pooled next (OV:49/53 -> nn.MaxPool2d(2), OV:67): a thread owns a 2 x 4 patch,
+// writes the activation (and / or its bf16 copy) and the two pooled values of the patch (and / or their bf16 copies) -- the
+// separate pooling pass re-read the whole activation.  Same arithmetic as bn_relu_apply_kernel + maxpool2_fwd_kernel: identical
+// bits.  Requires H % 2 == 0, W % 4 == 0 and 16-byte aligned rows (host-checked).
+typedef __bf16 bn_bf16x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void bn_relu_apply_pool_kernel(const float* __restrict__ z, int64_t z_bs, float* __restrict__ a,
+                                                                 int64_t a_bs, __bf16* __restrict__ a16, int64_t a16_bs,
+                                                                 float* __restrict__ y, int64_t y_bs, __bf16* __restrict__ y16,
+                                                                 int64_t y16_bs, const float* __restrict__ save, int C, int H, int W,
+                                                                 int blocks_per_plane) {
+    const int plane = blockIdx.x / blocks_per_plane, blk = blockIdx.x % blocks_per_plane;
+    const int b = plane / C, c = plane % C;
+    const float mean = save[c], sc = save[2 * C + c], sh = save[3 * C + c];
+    const int qw = W >> 2, npatch = (H >> 1) * qw;
+    const int i = blk * 256 + threadIdx.x;
+    if (i >= npatch) return;
+    const int pr = i / qw, q = i % qw;
+    const int64_t off = (int64_t)c * H * W + (int64_t)(2 * pr) * W + 4 * q;
+    const float* src = z + (int64_t)b * z_bs + off;
+    float4 r0 = *reinterpret_cast<const float4*>(src), r1 = *reinterpret_cast<const float4*>(src + W);
+    r0.x = fmaxf(fmaf(r0.x - mean, sc, sh), 0.f); r0.y = fmaxf(fmaf(r0.y - mean, sc, sh), 0.f);
+    r0.z = fmaxf(fmaf(r0.z - mean, sc, sh), 0.f); r0.w = fmaxf(fmaf(r0.w - mean, sc, sh), 0.f);
+    r1.x = fmaxf(fmaf(r1.x - mean, sc, sh), 0.f); r1.y = fmaxf(fmaf(r1.y - mean, sc, sh), 0.f);
+    r1.z = fmaxf(fmaf(r1.z - mean, sc, sh), 0.f); r1.w = fmaxf(fmaf(r1.w - mean, sc, sh), 0.f);
+    if (a) {
+        float* d = a + (int64_t)b * a_bs + off;
+        *reinterpret_cast<float4*>(d) = r0;
+        *reinterpret_cast<float4*>(d + W) = r1;
+    }
+    if (a16) {
+        __bf16* d = a16 + (int64_t)b * a16_bs + off;
+        store_bf16x4(d, r0);
+        store_bf16x4(d + W, r1);
+    }
+    const float m0 = fmaxf(fmaxf(r0.x, r0.y), fmaxf(r1.x, r1.y)), m1 = fmaxf(fmaxf(r0.z, r0.w), fmaxf(r1.z, r1.w));
+    const int64_t yo = (int64_t)c * (H >> 1) * (W >> 1) + (int64_t)pr * (W >> 1) + 2 * q;
+    if (y) *reinterpret_cast<float2*>(y + (int64_t)b * y_bs + yo) = make_float2(m0, m1);
+    if (y16) *reinterpret_cast<bn_bf16x2*>(y16 + (int64_t)b * y16_bs + yo) = bn_bf16x2{(__bf16)m0, (__bf16)m1};
+}
+
 // backward pass 1: part2[p][c] = (sum dy, sum dy*xhat), dy = da * [(z-mean)*scale+beta > 0].
 // Sums are taken in fp64 (ATen's CPU kernel accumulates in double): both sums cancel heavily
 // (BN outputs are zero-mean), so fp32 accumulation would cost orders of magnitude of accuracy.
@@ -492,6 +532,21 @@ int onet_bn_relu_apply_b(const float* z, int64_t z_bs, float* a, int64_t a_bs, v
     hipLaunchKernelGGL(bn_relu_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), z, z_bs, a, a_bs, save, C, HW,
                        chunks, (__bf16*)a_bf16, a16_bs);
     return check_launch("bn_relu_apply_kernel");
+}
+
+int onet_bn_relu_apply_pool(const float* z, int64_t z_bs, float* a, int64_t a_bs, void* a_bf16, int64_t a16_bs, float* y, int64_t y_bs,
+                            void* y_bf16, int64_t y16_bs, const float* save, int B, int C, int H, int W, void* stream) {
+    ONET_REQUIRE(z && (a || a_bf16) && (y || y_bf16) && save && B > 0 && C > 0 && H > 0 && W > 0, "bn_relu_apply_pool: bad args");
+    auto al = [](const void* p, uintptr_t m) { return (reinterpret_cast<uintptr_t>(p) & m) == 0; };
+    if ((H & 1) || (W & 3) || (z_bs & 3) || (a_bs & 3) || (a16_bs & 3) || (y_bs & 1) || (y16_bs & 1) || !al(z, 15) || !al(a, 15) ||
+        !al(a_bf16, 7) || !al(y, 7) || !al(y_bf16, 3))
+        return 1;                                  // not taken: run onet_bn_relu_apply[_b] and onet_maxpool2_fwd[_b]
+    const int npatch = (H / 2) * (W / 4), bpp = cdiv(npatch, 256);
+    const int64_t blocks = (int64_t)B * C * bpp;
+    ONET_REQUIRE(blocks < (1ll << 31), "bn_relu_apply_pool: grid too large");
+    hipLaunchKernelGGL(bn_relu_apply_pool_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), z, z_bs, a, a_bs,
+                       (__bf16*)a_bf16, a16_bs, y, y_bs, (__bf16*)y_bf16, y16_bs, save, C, H, W, bpp);
+    return check_launch("bn_relu_apply_pool_kernel");
 }
 
 int onet_bn_relu_bwd_reduce(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save,

@@ -27,6 +27,9 @@ class ConvBNReLUFn(torch.autograd.Function):
         "out16" = a plane-contiguous bf16 destination for the copy of the output (or None: allocated); forward leaves the
         output's copy in b16["a16"] for the caller to attach to the returned tensor."""
         ops.require_gpu(x, weight, gamma, beta)
+        # an encoder output that is max-pooled next: {"bf16_only": bool} left in the link dict by UNet.forward (read before the dict
+        # is refilled below); the pooled tensor goes back through the same dict for SkipPoolFn
+        want_pool = link_out.pop("want_pool", None) if link_out is not None else None
         x16 = None if b16 is None else b16.get("x16")
         # training: the F(4x4) kernel emits the BatchNorm statistics records from its epilogue (cm), where it can
         z, cm = ops.conv3x3_fwd_bn_partials(x, packed, x16=x16) if training else (ops.conv3x3_auto(x, packed, 0, x16=x16), None)
@@ -43,13 +46,33 @@ class ConvBNReLUFn(torch.autograd.Function):
         # goes through autograd
         drop = a16 is not None and bool(b16.get("drop_fp32")) and dst is None
         save_all = torch.empty((G, 4, C), dtype=torch.float32, device=z.device)
+        Bz, _, Hz, Wz = z.shape
+        pooled = None
+        if want_pool is not None and ops.FUSE_POOL and not drop and Hz % 2 == 0 and Wz % 4 == 0:
+            only16 = bool(want_pool.get("bf16_only")) and a16 is not None
+            py = None if only16 else torch.empty((Bz, C, Hz // 2, Wz // 2), dtype=torch.float32, device=z.device)
+            py16 = torch.empty((Bz, C, Hz // 2, Wz // 2), dtype=torch.bfloat16, device=z.device) if a16 is not None else None
+            pooled = (py, py16)
+
+        def apply(zg, sv, o, o16, sl):
+            """BatchNorm + ReLU of one statistics group (batch slice sl), with the pooled output where it was asked for"""
+            nonlocal pooled
+            if pooled is not None:
+                if o is None and not drop:
+                    o = torch.empty_like(zg)
+                if ops.bn_relu_apply_pool(zg, sv, o, o16, None if pooled[0] is None else pooled[0][sl],
+                                          None if pooled[1] is None else pooled[1][sl]):
+                    return o
+                pooled = None                       # shape not taken: the separate pooling pass runs as before
+            return ops.bn_relu_apply(zg, sv, out=o, out16=o16, no_fp32=drop)
+
         if G == 1:
             if training:
                 ops.bn_train_coeffs(z, gamma, beta, running_mean, running_var, momentum, eps,
                                     cm=None if cm is None else (cm, 0, cm.shape[1]), save=save_all[0])
             else:
                 ops.bn_eval_coeffs(gamma, beta, running_mean, running_var, eps, save=save_all[0])
-            a = ops.bn_relu_apply(z, save_all[0], out=dst, out16=a16, no_fp32=drop)
+            a = apply(z, save_all[0], dst, a16, slice(0, Bz))
             if drop:
                 a = ops.fp32_placeholder(z.shape, z.device)
         else:
@@ -63,8 +86,8 @@ class ConvBNReLUFn(torch.autograd.Function):
                 npg = 0 if cm is None else cm.shape[1] // G
                 ops.bn_train_coeffs(zg, gamma, beta, running_mean, running_var, momentum, eps,
                                     cm=None if cm is None else (cm, g * npg, npg), save=save_all[g])
-                ops.bn_relu_apply(zg, save_all[g], out=None if drop else a[g * Bg:(g + 1) * Bg],
-                                  out16=None if a16 is None else a16[g * Bg:(g + 1) * Bg], no_fp32=drop)
+                apply(zg, save_all[g], None if drop else a[g * Bg:(g + 1) * Bg],
+                      None if a16 is None else a16[g * Bg:(g + 1) * Bg], slice(g * Bg, (g + 1) * Bg))
         if b16 is not None:
             b16["a16"] = a16
         # (the weight gradient reads the bf16 copy too; saved WITH the tensors so that backward releases it -- a ctx attribute
@@ -81,6 +104,8 @@ class ConvBNReLUFn(torch.autograd.Function):
             ctx.link_out = link_out
         if training and link_in is not None and "z" in link_in:
             ctx.link_in = link_in
+        if pooled is not None and link_out is not None:
+            link_out["pooled"] = pooled
         return a
 
     @staticmethod
@@ -214,9 +239,17 @@ class SkipPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, returned=False, link=None, b16=None):
         ops.require_gpu(x)
-        y = ops.maxpool2_fwd(x, bf16_only=bool(b16 and b16.get("bf16_only")))
-        if b16 is not None:                                   # bf16 storage: the pooled tensor's bf16 copy, for the caller to re-attach
-            b16["y16"] = ops.b16_of(y)
+        pooled = link.pop("pooled", None) if link is not None else None
+        if pooled is not None and tuple((pooled[0] if pooled[0] is not None else pooled[1]).shape) == \
+                (x.shape[0], x.shape[1], x.shape[2] // 2, x.shape[3] // 2):
+            # the producing BatchNorm + ReLU pass already wrote the pooled tensor (onet_bn_relu_apply_pool)
+            y = pooled[0] if pooled[0] is not None else ops.fp32_placeholder(pooled[1].shape, x.device)
+            if b16 is not None:
+                b16["y16"] = pooled[1]
+        else:
+            y = ops.maxpool2_fwd(x, bf16_only=bool(b16 and b16.get("bf16_only")))
+            if b16 is not None:                               # bf16 storage: the pooled tensor's bf16 copy, for the caller to re-attach
+                b16["y16"] = ops.b16_of(y)
         ctx.save_for_backward(x)
         ctx.link = link if (link is not None and "z" in link) else None
         return (x.view_as(x), y, x.view_as(x)) if returned else (x.view_as(x), y)

@@ -313,6 +313,13 @@ class UNet(nn.Module):
         c1 = self.down1.maxpool_conv[1].double_conv[3].out_channels
         c2 = self.down2.maxpool_conv[1].double_conv[3].out_channels
         c3 = self.down3.maxpool_conv[1].double_conv[3].out_channels
+        if x.dim() == 4 and x.is_cuda and _SKIPPOOL and ops.FUSE_POOL:
+            # the four encoder outputs are max-pooled next: their BatchNorm + ReLU pass writes the pooled tensor too
+            hh, ww = x.shape[2], x.shape[3]
+            for i, nxt in enumerate((self.down1, self.down2, self.down3, self.down4)):
+                cv = nxt.maxpool_conv[1].double_conv[0]
+                pl[i]["want_pool"] = {"bf16_only": ops.consumer_reads_bf16(x.shape[0], cv.in_channels, cv.out_channels, hh // 2, ww // 2)}
+                hh, ww = hh // 2, ww // 2
         x1 = self.inc(x, out=skip(0, c0), groups=g, pool_link=pl[0], out16=skip16(0, c0))
         x1, p1, x1_out = fork(x1, True, pl[0], self.down1)
         x2 = self.down1(x1, out=skip(1, c1), groups=g, pooled=p1, pool_link=pl[1], out16=skip16(1, c1))

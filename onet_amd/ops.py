@@ -790,6 +790,28 @@ def bn_relu_apply(z, save, out=None, out16=None, no_fp32=False):
     return out
 
 
+FUSE_POOL = _os.environ.get("ONET_FUSE_POOL", "1") != "0"       # 0: separate max-pool pass after BatchNorm + ReLU
+
+
+def bn_relu_apply_pool(z, save, out, out16, y, y16):
+    """a = relu(bn(z)) and y = maxpool2(a) in one pass (an encoder block's output that is pooled next); out / out16 and y / y16:
+    fp32 destination and / or its bf16 copy (plane-contiguous; at least one of each pair).  -> False (nothing done) where the
+    fused kernel does not take the shape."""
+    z, zbs = plane(z)
+    B, C, H, W = z.shape
+    if H % 2 or W % 4:
+        return False
+
+    def bs(t, n):
+        return 0 if t is None else (t.stride(0) if B > 1 else n)
+    n, m = C * H * W, C * (H // 2) * (W // 2)
+    rc = _lib.load().onet_bn_relu_apply_pool(_p(z), zbs, _p(out), bs(out, n), _p(out16), bs(out16, n), _p(y), bs(y, m), _p(y16),
+                                            bs(y16, m), _p(save), B, C, H, W, _stream())
+    if rc < 0:
+        raise _lib.OnetHipError(f"onet_bn_relu_apply_pool failed ({rc}): {_lib.last_error()}")
+    return rc == 0
+
+
 def bn_relu_bwd(da, z, save, training, need_affine_grads=True, out=None, acc=None, affine_out=None, red=None, red4=None,
                 out16=None):
     """-> dz, dgamma, dbeta.  `out`: plane-contiguous destination for dz (a batch slice of a larger buffer);

@@ -219,6 +219,45 @@ def test_bf16_storage_is_bit_identical_to_rounding_on_load(dev, shape, monkeypat
         assert torch.equal(ga, gb)
 
 
+@pytest.mark.parametrize("algo", ["auto", "bf16"])
+def test_fused_pooling_is_bit_identical(dev, algo, monkeypatch):
+    """The encoder's BatchNorm + ReLU passes also write the pooled tensors (onet_bn_relu_apply_pool): loss, outputs and every
+    gradient bit-identical to the separate max-pool pass (ONET_FUSE_POOL=0), in fp32 and with bf16 storage of the operands --
+    and the separate pass must really be gone."""
+    from onet_amd import _lib, ops
+    monkeypatch.setattr(ops, "CONV_ALGO", algo)
+    X = orc.det_input(3, 1, 64, 96, seed=14).to(dev)
+    res, pools = {}, {}
+    for fused in (False, True):
+        monkeypatch.setattr(ops, "FUSE_POOL", fused)
+        cnt = {"pool": 0, "fused": 0}
+        real_call, real_pool, real_fp = _lib.call, ops.maxpool2_fwd, ops.bn_relu_apply_pool
+
+        def pool(*a, _r=real_pool, **k):
+            cnt["pool"] += 1
+            return _r(*a, **k)
+
+        def fp(*a, _r=real_fp, **k):
+            ok = _r(*a, **k)
+            cnt["fused"] += int(ok)
+            return ok
+
+        monkeypatch.setattr(ops, "maxpool2_fwd", pool)
+        monkeypatch.setattr(ops, "bn_relu_apply_pool", fp)
+        m = _model(1, True, dev)
+        (Lt, Vt, Ld, Vd, S), loss = _step(m, X)
+        res[fused] = (loss.detach().clone(), S.detach().clone(), [p.grad.detach().clone() for p in m.parameters()])
+        pools[fused] = dict(cnt)
+        monkeypatch.setattr(ops, "maxpool2_fwd", real_pool)
+        monkeypatch.setattr(ops, "bn_relu_apply_pool", real_fp)
+    assert pools[False] == {"pool": 4, "fused": 0}
+    assert pools[True] == {"pool": 0, "fused": 8}, pools        # four encoder outputs x two statistics groups of the twin batch
+    a, b = res[False], res[True]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for ga, gb in zip(a[2], b[2]):
+        assert torch.equal(ga, gb)
+
+
 def test_deferred_nan_assertion(dev, monkeypatch):
     """OV:234's "jsd is not NaN" assertion: in place by default (AssertionError out of compute_loss); with
     ops.LAZY_NAN_CHECK (training loops that own the optimizer step) the same AssertionError comes out of

@@ -233,6 +233,38 @@ def test_winograd4_fused_bn_statistics(dev, B, Cin, Cout, H, W):
         assert float(((s1[1].cpu().double() - ir) / ir).abs().max()) <= 1e-5
 
 
+@pytest.mark.parametrize("B,C,H,W", [(2, 8, 16, 32), (3, 5, 6, 12), (2, 64, 64, 64), (1, 3, 2, 4)])
+def test_bn_relu_apply_pool_fused(dev, B, C, H, W):
+    """onet_bn_relu_apply_pool: BatchNorm + ReLU and the 2x2 max-pooling of its output in one pass -- every output (activation,
+    its bf16 copy, pooled tensor, its bf16 copy, each optional) bit-identical to the two separate kernels; shapes it does not
+    take (odd H, W % 4) return False."""
+    from onet_amd import ops
+    z = (rnd(B, C, H, W, seed=81) * 2 + 0.3).to(dev)
+    gamma, beta = (1 + 0.2 * rnd(C, seed=82)).to(dev), (0.2 * rnd(C, seed=83)).to(dev)
+    save = ops.bn_train_coeffs(z, gamma, beta, torch.zeros(C, device=dev), torch.ones(C, device=dev), 0.1, 1e-5)
+    a_ref = ops.bn_relu_apply(z, save)
+    y_ref = ops.maxpool2_fwd(a_ref)
+    BF = torch.bfloat16
+    for want_a, want_a16, want_y, want_y16 in [(1, 0, 1, 0), (1, 1, 1, 1), (0, 1, 0, 1), (1, 1, 0, 1), (0, 1, 1, 0)]:
+        a = torch.full_like(z, float("nan")) if want_a else None
+        a16 = torch.zeros((B, C, H, W), dtype=BF, device=dev) if want_a16 else None
+        y = torch.full((B, C, H // 2, W // 2), float("nan"), device=dev) if want_y else None
+        y16 = torch.zeros((B, C, H // 2, W // 2), dtype=BF, device=dev) if want_y16 else None
+        assert ops.bn_relu_apply_pool(z, save, a, a16, y, y16)
+        if want_a:
+            assert torch.equal(a, a_ref)
+        if want_a16:
+            assert torch.equal(a16, a_ref.to(BF))
+        if want_y:
+            assert torch.equal(y, y_ref)
+        if want_y16:
+            assert torch.equal(y16, y_ref.to(BF))
+    zz = z[:, :, : H - 1 if H > 2 else H, :].contiguous() if H > 2 else z[..., : W - 2].contiguous()
+    o = torch.empty_like(zz)
+    yy = torch.empty((B, C, zz.shape[2] // 2, zz.shape[3] // 2), device=dev)
+    assert not ops.bn_relu_apply_pool(zz, save, o, None, yy, None)
+
+
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 1, 64, 32, 64), (3, 3, 64, 48, 128), (2, 1, 64, 256, 256), (4, 2, 40, 16, 64),
                                              (2, 4, 128, 32, 192)])
 def test_stem_conv_fused_bn_statistics(dev, B, Cin, Cout, H, W):
