@@ -83,7 +83,12 @@ class FlatAdam:
         # host-side group for the per-step NaN verdict (see _check_nan_all_ranks); created collectively, here
         self._flag_pg = None
         if world_size > 1 and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            self._flag_pg = dist.new_group(backend="gloo")
+            try:
+                self._flag_pg = dist.new_group(backend="gloo")
+            except Exception as e:      # no gloo in this build / rendezvous refused: every rank fails alike -> per-rank verdicts
+                import warnings
+                warnings.warn(f"onet_amd: no host-side group for the shared NaN verdict ({e}); a NaN loss raises on its own rank only")
+                self._flag_pg = None
 
     # ------------------------------------------------------------------ bucketed all-reduce overlapped with backward
     def enable_overlap(self, bucket_mb: float = 32.0):
