@@ -3,22 +3,27 @@
 
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N          # N > 1 without a launcher: starts the line above itself, as a CHILD process
 
 A step = zero_grad + twin forward + JSD loss + backward + [RCCL all-reduce] + fused Adam on one
 synthetic K-distributed clutter batch already resident in HBM (TS:209-219 order).  Prints ONE JSON
 line on rank 0 with `roofline` (dominant MFMA kernel, HIP-event timed inside the timed region)
-and, at N=1, `cpu_baseline` (the CPU oracle timed on the host cores on a bounded sample)."""
+and, at N=1, `cpu_baseline` (the CPU oracle timed on the host cores on the SAME batch) and `secondary`
+(BASELINE configs[2]: the bf16 MFMA conv path at B=256, run after the headline's timed region in a child
+process of its own so that it starts from a fresh allocator).
+
+Nothing in this file touches the GPU (no torch / onet_amd import) before `_self_launch` has had its chance:
+a process that has initialised HIP must not be replaced or forked into ranks."""
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+torch = dist = None          # imported by main(), after the launcher decision
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (no sparsity)
@@ -76,13 +81,14 @@ def _host_cores():
 def cpu_baseline(X_cpu, seconds_budget):
     """fwd + loss + bwd + Adam of the CPU oracle (PyTorch CPU fp32: the same ATen / oneDNN kernels the reference runs
     on CPU) on the host cores of this box, for n = all cores and n = 8 threads.  The sample is the first
-    B_s images of the SAME synthetic batch, B_s = the largest power of two <= the benchmark batch whose 3 timed steps fit
-    the budget of a thread setting (half of --cpu-seconds), estimated from a B=2 warm-up step."""
+    B_s images of the SAME synthetic batch, B_s = the largest power of two <= the benchmark batch of which two timed steps
+    fit a thread setting's share of the budget (estimated from a B=2 warm-up step); up to 3 steps are timed while they fit.
+    At the default budget that is the WHOLE configs[1] batch (32 / 32 images)."""
     from oracle import onet_oracle as orc
     ncores = _host_cores()
     settings = [ncores] + ([8] if ncores > 8 else [])
     per_setting = seconds_budget / len(settings)
-    by_threads, sample = {}, {}
+    by_threads, sample, nsteps = {}, {}, {}
     for n in settings:
         torch.set_num_threads(n)
         top = orc.clone_state(orc.det_state_dict(X_cpu.shape[1], 1981, randomize_running=False))
@@ -98,29 +104,99 @@ def cpu_baseline(X_cpu, seconds_budget):
 
         t_warm = step(X_cpu[:2].contiguous())                 # warm-up (allocator, oneDNN primitive cache) + estimate
         bs = 2
-        while bs * 2 <= X_cpu.shape[0] and 3 * t_warm * (bs * 2) / 2 <= per_setting - t_warm:
+        while bs * 2 <= X_cpu.shape[0] and 2 * t_warm * (bs * 2) / 2 <= per_setting - t_warm:
             bs *= 2
+        if bs * 2 > X_cpu.shape[0] and 2 * t_warm * X_cpu.shape[0] / 2 <= per_setting - t_warm:
+            bs = X_cpu.shape[0]                               # a batch that is not a power of two: all of it
         xs = X_cpu[:bs].contiguous()
-        times = []
+        times, t_begin = [], time.perf_counter()
         for _ in range(3):
+            if times and (time.perf_counter() - t_begin) + max(times) > per_setting:
+                break
             times.append(step(xs))
             sys.stderr.write("[cpu_baseline] n=%d B=%d step %.2f s\n" % (n, bs, times[-1]))
             sys.stderr.flush()
-            if sum(times) > 2.0 * per_setting:                # the estimate was off: stop at what we have
-                break
         by_threads[str(n)] = round(bs / (sum(times) / len(times)), 4)
-        sample[str(n)] = bs
+        sample[str(n)], nsteps[str(n)] = bs, len(times)
     torch.set_num_threads(ncores)
     n0 = str(settings[0])
+    B = X_cpu.shape[0]
     return {"value": by_threads[n0], "unit": "images/s", "cores": settings[0], "kind": "port",
             "cpu_model": _cpu_model(), "host_cpus": os.cpu_count(), "by_threads": by_threads,
-            "sample": "first %s images (n=%s threads) of the same %dx%dx%d K-clutter batch; per thread setting 1 warm-up "
-                      "step at B=2 + up to 3 timed full training steps (zero_grad+fwd+loss+bwd+Adam) of the CPU oracle"
-                      % ("/".join(str(sample[k]) for k in by_threads), "/".join(by_threads), X_cpu.shape[1],
-                         X_cpu.shape[2], X_cpu.shape[3])}
+            "sample": "%s of the %d images (n=%s threads) of the same %dx%dx%d K-clutter batch the GPU ran; per thread setting 1 "
+                      "warm-up step at B=2 + %s timed full training steps (zero_grad+fwd+loss+bwd+Adam) of the CPU oracle"
+                      % ("/".join(str(sample[k]) for k in by_threads), B, "/".join(by_threads), X_cpu.shape[1],
+                         X_cpu.shape[2], X_cpu.shape[3], "/".join(str(nsteps[k]) for k in by_threads))}
 
 
-def main():
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _relay_child(cmd, env=None):
+    """Run `cmd` as a child process; stderr is inherited (progress stays visible), stdout is returned.  -> (rc, stdout)."""
+    proc = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
+    out, _ = proc.communicate()
+    return proc.returncode, out or ""
+
+
+def _self_launch(args, argv):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: THIS process (which has not imported torch.cuda / onet_amd and
+    makes no GPU call) starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`
+    as a child, relays rank 0's JSON line and exits with the child's code.  No exec, no retry."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this image
+    env.setdefault("OMP_NUM_THREADS", "1")
+    sys.stderr.write("[bench] --gpus %d without a launcher: starting %s\n" % (args.gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    rc, out = _relay_child(cmd, env)
+    for ln in out.splitlines():
+        if ln.startswith("{"):
+            print(ln, flush=True)
+        elif ln.strip():
+            sys.stderr.write(ln + "\n")
+    return rc
+
+
+SECONDARY_ARGS = ["--gpus", "1", "--conv", "bf16", "--batch", "256", "--warmup", "8", "--steps", "5",
+                  "--no-cpu-baseline", "--no-secondary"]
+
+
+def secondary_config2():
+    """BASELINE configs[2] (B=256 1x256x256, bf16 MFMA conv path, one GPU) measured by the same program in a child process,
+    after the headline's timed region and with the parent's HBM released.  -> the object attached as
+    out["secondary"]["configs[2]"]; a failure is reported in the object, it does not fail the headline line."""
+    cmd = [sys.executable, os.path.abspath(__file__)] + SECONDARY_ARGS
+    t0 = time.perf_counter()
+    try:
+        rc, out = _relay_child(cmd)
+    except Exception as e:      # noqa: BLE001
+        return {"error": "could not start the child: %r" % (e,), "cmd": " ".join(cmd[1:])}
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    if rc != 0 or len(lines) != 1:
+        return {"error": "child exited %d with %d JSON lines" % (rc, len(lines)), "cmd": " ".join(cmd[1:])}
+    d = json.loads(lines[0])
+    r = d.get("roofline", {})
+    keep = ("kernel", "bound", "achieved", "peak", "unit", "frac", "mfma_frac", "hbm_frac", "traffic", "traffic_unit",
+            "compulsory_bytes_per_launch", "launches_timed", "avg_launch_ms", "algorithm", "kernels", "step")
+    sec = {k: d[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "precision", "data",
+                             "config", "loss", "hbm_peak_gb", "device_allocs_per_timed_step") if k in d}
+    sec["roofline"] = {k: r[k] for k in keep if k in r}
+    if "streaming" in r:
+        sec["roofline"]["streaming"] = {k: v for k, v in r["streaming"].items() if k != "kernels"}
+    sec["cmd"] = "python bench.py " + " ".join(SECONDARY_ARGS)
+    sec["child_wall_s"] = round(time.perf_counter() - t0, 1)
+    return sec
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -135,24 +211,29 @@ def main():
     ap.add_argument("--mfma-events-only", action="store_true",
                     help="HIP-event brackets around the MFMA launches only (default: around every launch of the library, "
                          "which the whole-step breakdown and the streaming-kernel roofline need)")
-    ap.add_argument("--cpu-seconds", type=float, default=60.0,
-                    help="budget of the CPU-oracle baseline (split over the thread settings n = all cores and n = 8)")
+    ap.add_argument("--cpu-seconds", type=float, default=200.0,
+                    help="budget of the CPU-oracle baseline (split over the thread settings n = all cores and n = 8); the "
+                         "default fits the whole configs[1] batch (B=32, ~28 s per step on 16 cores)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="do not attach BASELINE configs[2] (bf16, B=256) as `secondary` (default at N=1 with the headline "
+                         "configuration: attached)")
     ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam instead of the fused flat Adam")
     ap.add_argument("--no-overlap", action="store_true",
                     help="one gradient all-reduce after backward instead of bucketed all-reduces overlapped with it")
     ap.add_argument("--bucket-mb", type=float, default=32.0)
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def main(args):
+    global torch, dist
+    import torch
+    import torch.distributed as dist
     from onet_amd import Onet, _lib, ops
     from onet_amd import data as odata
     from onet_amd.trainer import FlatAdam, init_distributed, train_step
     _lib.load()                      # fail loudly without the HIP library
-    if args.conv:
-        ops.CONV_ALGO = args.conv
-    bf16 = ops.CONV_ALGO == "bf16"
-    # the loop owns the optimizer step: the loss's NaN assertion (OV:234) is evaluated by FlatAdam.step() before the update
-    # instead of by a device synchronisation between forward and backward (ops.LAZY_NAN_CHECK)
-    ops.LAZY_NAN_CHECK = not args.torch_adam
+    conv = args.conv or ops.CONV_ALGO
+    bf16 = conv == "bf16"
 
     rank, world, local = init_distributed("nccl")
     if world != args.gpus:
@@ -162,6 +243,9 @@ def main():
 
     torch.manual_seed(1981)
     onet = Onet(in_chns=args.chans, binit=True, bshare=True).to(dev)
+    # the model carries its switches (no process globals).  The loop owns the optimizer step: the loss's NaN assertion (OV:234)
+    # is evaluated by FlatAdam.step() before the update instead of by a device synchronisation between forward and backward
+    onet.settings = ops.Settings(conv=conv, lazy_nan=not args.torch_adam)
     opt = (torch.optim.Adam(onet.parameters(), lr=5e-6, betas=(0.9, 0.999), eps=1e-8) if args.torch_adam
            else FlatAdam(onet, lr=5e-6, world_size=world))
     if not args.torch_adam:
@@ -307,6 +391,16 @@ def main():
                "device_allocs_in_timed_steps": int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0)) - dev_allocs0,
                "device_allocs_per_timed_step": [b - a for a, b in zip([dev_allocs0] + allocs_per_step, allocs_per_step)],
                "roofline": roofline}
+        headline = world == 1 and not bf16 and args.size == 256 and args.chans == 1 and args.batch == 32 and not args.torch_adam
+        if headline and not args.no_secondary:
+            # BASELINE configs[2] in the same driver-run line: release this process's HBM first (the child peaks at ~150 GB)
+            del loss, opt, onet, X, prof, prof_all
+            import gc
+            gc.collect()
+            ops._WS.clear()
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            out["secondary"] = {"configs[2]": secondary_config2()}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(X_cpu, args.cpu_seconds)
         print(json.dumps(out), flush=True)
@@ -316,8 +410,11 @@ def main():
 
 
 if __name__ == "__main__":
+    _args = parse_args()
+    if _args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(_self_launch(_args, sys.argv[1:]))      # before any GPU call: the ranks are children of a GPU-free parent
     try:
-        main()
+        main(_args)
     except BaseException as e:      # noqa: BLE001 -- any failure (RCCL included) ends THIS rank at once with a non-zero code:
         if isinstance(e, SystemExit) and e.code in (0, None):      # no in-process retry, no waiting in a collective's
             raise                                                  # destructor; the launcher then stops the other ranks

@@ -56,8 +56,13 @@ int onet_convT2x2_pack_weights(const float* w, float* wp_fwd, float* wp_dgrad,
  * the bias.  wq [Cin][4*Ct] with column c*4 + (2*di + dj); y is the [Ct][Ho][Wo] window (batch stride y_bs) and
  * receives rows pt .. pt+2h-1, columns pl .. pl+2w-1 (the caller zeroes a non-empty F.pad border). */
 int onet_convT2x2_pack_weights_fused(const float* w, float* wq, int Cin, int Cout, void* stream);
+/* operand_bf16 (the forward, both backward GEMMs and their _b / _dbias forms): operand precision of THIS call on the 128 x 128
+ * fast path -- 1 rounds the MFMA operands to bf16 (nearest-even) with fp32 accumulation and fp32 results, i.e.
+ * nn.ConvTranspose2d under torch.autocast(bfloat16), BASELINE configs[2]; 0 = fp32.  (ABI 2: a per-call argument; ABI 1 had a
+ * process-wide switch, which two models of different precision in one process could not share.) */
 int onet_convT2x2_fwd(const float* x, int64_t x_bs, const float* wq, const float* bias, float* y, int64_t y_bs,
-                      int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, void* stream);
+                      int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int operand_bf16,
+        void* stream);
 /* Backward of the same module without materialising the space-to-depth tensor: the 1x1 GEMM kernels gather their
  * dy operand straight from the [Ct][Ho][Wo] window of the concat gradient (dy_bs = its batch stride).
  *   dgrad: dx[b][ci][i][j] = sum_{c,di,dj} dy[b][c][pt+2i+di][pl+2j+dj] * W[ci][c][di][dj]   (wp_dgrad of
@@ -69,22 +74,18 @@ int onet_convT2x2_fwd(const float* x, int64_t x_bs, const float* wq, const float
  * direct kernels.
  *   dbias: db[c] = sum dy[:, c, window]  (scratch: B*C doubles) */
 int onet_convT2x2_dgrad(const float* dy, int64_t dy_bs, const float* wp_dgrad, float* dx, int64_t dx_bs, int B,
-                        int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, void* stream);
+                        int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int operand_bf16,
+        void* stream);
 /* dx and dbias in one launch where the 128 x 128 GEMM path takes the shape (returns 1 and does nothing otherwise: use
  * onet_convT2x2_dgrad + onet_convT2x2_dbias); ws: onet_convT2x2_dgrad_dbias_ws_bytes() bytes of scratch */
 int64_t onet_convT2x2_dgrad_dbias_ws_bytes(int B, int Ct, int h, int w);
 int onet_convT2x2_dgrad_dbias(const float* dy, int64_t dy_bs, const float* wp_dgrad, float* dx, int64_t dx_bs, float* dbias,
-                              void* ws, int64_t ws_bytes, int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl,
-                              void* stream);
-/* Operand precision of the three ConvTranspose2d GEMMs (OV:86) on their 128 x 128 fast path: on = 1 rounds the MFMA operands to
- * bf16 (nearest-even) with fp32 accumulation and fp32 results -- nn.ConvTranspose2d under torch.autocast(bfloat16), BASELINE
- * configs[2]; 0 (default) = fp32.  Process-wide; call before the launches it governs. */
-int onet_convT2x2_set_bf16(int on);
-
+                              void* ws, int64_t ws_bytes, int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int operand_bf16,
+        void* stream);
 int64_t onet_convT2x2_wgrad_ws_bytes(int B, int Cin, int Ct, int h, int w);   /* workspace of onet_convT2x2_wgrad */
 int onet_convT2x2_wgrad(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, float* dw, void* ws,
-                        int64_t ws_bytes, int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl,
-                        void* stream);
+                        int64_t ws_bytes, int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int operand_bf16,
+        void* stream);
 int onet_convT2x2_dbias(const float* dy, int64_t dy_bs, float* dbias, double* scratch, int accumulate, int B,
                         int C, int h, int w, int Ho, int Wo, int pt, int pl, void* stream);
 
@@ -157,7 +158,8 @@ int onet_bn_relu_bwd_apply_b(const float* da, int64_t da_bs, const float* z, int
 int onet_maxpool2_fwd_b(const float* x, int64_t x_bs, float* y, int64_t y_bs, void* y_bf16, int64_t y16_bs, int B, int C, int H,
                         int W, void* stream);                                   /* 1: y written, no bf16 copy (odd / unaligned map) */
 int onet_convT2x2_fwd_b(const float* x, int64_t x_bs, const float* wq, const float* bias, float* y, int64_t y_bs, void* y_bf16,
-                        int64_t y16_bs, int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, void* stream);
+                        int64_t y16_bs, int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int operand_bf16,
+        void* stream);
                                                                                 /* 1: shape outside the GEMM path, nothing done */
 int onet_conv3x3_bf16_fwd_b(const void* x_bf16, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin,
                             int Cout, int H, int W, void* stream);

@@ -758,25 +758,18 @@ static bool convt_gemm_enabled() {
     return on != 0;
 }
 
-// operand precision of the ConvTranspose2d GEMMs (128 x 128 fast path only): 1 = bf16 operands, fp32 accumulation -- what
-// torch.autocast(bfloat16) does to nn.ConvTranspose2d; process-wide, set by the host before the calls it governs
-int onet_convT2x2_set_bf16(int on) {
-    convt_set_bf16(on);
-    return 0;
-}
-
 int64_t onet_convT2x2_wgrad_ws_bytes(int B, int Cin, int Ct, int h, int w) {
     return std::max<int64_t>(onet_conv_wgrad_ws_bytes(B, Cin, 4 * Ct, h, w, 1), convt_gemm_wgrad_ws_bytes(B, Cin, Ct, h, w));
 }
 
 int onet_convT2x2_fwd(const float* x, int64_t x_bs, const float* wq, const float* bias, float* y, int64_t y_bs,
-                      int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, void* stream) {
+                      int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int operand_bf16, void* stream) {
     ONET_REQUIRE(x && wq && y, "convT2x2_fwd: null pointer");
     ONET_REQUIRE(B > 0 && Cin > 0 && Ct > 0 && h > 0 && w > 0, "convT2x2_fwd: bad shape");
     ONET_REQUIRE(pt >= 0 && pl >= 0 && pt + 2 * h <= Ho && pl + 2 * w <= Wo, "convT2x2_fwd: window outside plane");
     ONET_REQUIRE(x_bs >= (int64_t)Cin * h * w && y_bs >= (int64_t)Ct * Ho * Wo, "convT2x2_fwd: batch stride too small");
     if (convt_gemm_enabled()) {
-        const int rc = convt_gemm_fwd(x, x_bs, wq, bias, y, y_bs, nullptr, 0, B, Cin, Ct, h, w, Ho, Wo, pt, pl, as_stream(stream));
+        const int rc = convt_gemm_fwd(x, x_bs, wq, bias, y, y_bs, nullptr, 0, B, Cin, Ct, h, w, Ho, Wo, pt, pl, operand_bf16 != 0, as_stream(stream));
         if (rc <= 0) return rc;          // 1: shape outside the 128 x 128 GEMM's fast path
     }
     ConvArgs a{x, x_bs, wq, y, y_bs, nullptr, B, Cin, 4 * Ct, h, w, 0, 0, 0, bias, Ho, Wo, pt, pl};
@@ -787,24 +780,24 @@ int onet_convT2x2_fwd(const float* x, int64_t x_bs, const float* wq, const float
 // forward + a bf16 copy of the up-sampled tensor (operand storage for the bf16 conv kernels): only on the 128 x 128 GEMM path;
 // returns 1 (and does nothing) elsewhere -- the caller then runs onet_convT2x2_fwd and the consumer reads fp32
 int onet_convT2x2_fwd_b(const float* x, int64_t x_bs, const float* wq, const float* bias, float* y, int64_t y_bs, void* y_bf16,
-                        int64_t y16_bs, int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, void* stream) {
+                        int64_t y16_bs, int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int operand_bf16, void* stream) {
     ONET_REQUIRE(x && wq && y_bf16, "convT2x2_fwd_b: null pointer");       // y may be NULL: bf16 output only
     ONET_REQUIRE(B > 0 && Cin > 0 && Ct > 0 && h > 0 && w > 0, "convT2x2_fwd_b: bad shape");
     ONET_REQUIRE(x_bs >= (int64_t)Cin * h * w && (!y || y_bs >= (int64_t)Ct * Ho * Wo) && y16_bs >= (int64_t)Ct * Ho * Wo,
                  "convT2x2_fwd_b: batch stride too small");
     if (!convt_gemm_enabled()) return 1;
-    return convt_gemm_fwd(x, x_bs, wq, bias, y, y_bs, y_bf16, y16_bs, B, Cin, Ct, h, w, Ho, Wo, pt, pl, as_stream(stream));
+    return convt_gemm_fwd(x, x_bs, wq, bias, y, y_bs, y_bf16, y16_bs, B, Cin, Ct, h, w, Ho, Wo, pt, pl, operand_bf16 != 0, as_stream(stream));
 }
 
 int onet_convT2x2_dgrad(const float* dy, int64_t dy_bs, const float* wp_dgrad, float* dx, int64_t dx_bs, int B,
-                        int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, void* stream) {
+                        int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int operand_bf16, void* stream) {
     ONET_REQUIRE(dy && wp_dgrad && dx, "convT2x2_dgrad: null pointer");
     ONET_REQUIRE(B > 0 && Cin > 0 && Ct > 0 && h > 0 && w > 0, "convT2x2_dgrad: bad shape");
     ONET_REQUIRE(Ct % CI_T == 0, "convT2x2_dgrad: Ct must be a multiple of %d (use onet_space_to_depth2 + onet_conv_fwd)", CI_T);
     ONET_REQUIRE(pt >= 0 && pl >= 0 && pt + 2 * h <= Ho && pl + 2 * w <= Wo, "convT2x2_dgrad: window outside plane");
     ONET_REQUIRE(dy_bs >= (int64_t)Ct * Ho * Wo && dx_bs >= (int64_t)Cin * h * w, "convT2x2_dgrad: batch stride too small");
     if (convt_gemm_enabled()) {
-        const int rc = convt_gemm_dgrad(dy, dy_bs, wp_dgrad, dx, dx_bs, nullptr, nullptr, B, Cin, Ct, h, w, Ho, Wo, pt, pl, as_stream(stream));
+        const int rc = convt_gemm_dgrad(dy, dy_bs, wp_dgrad, dx, dx_bs, nullptr, nullptr, B, Cin, Ct, h, w, Ho, Wo, pt, pl, operand_bf16 != 0, as_stream(stream));
         if (rc <= 0) return rc;
     }
     ConvArgs a{dy, dy_bs, wp_dgrad, dx, dx_bs, nullptr, B, 4 * Ct, Cin, h, w, 0, 0, 0, nullptr, Ho, Wo, pt, pl};
@@ -818,12 +811,12 @@ int64_t onet_convT2x2_dgrad_dbias_ws_bytes(int B, int Ct, int h, int w) { return
 // dgrad GEMM stages anyway (one read of the concat gradient's upper half less); returns 1 (and does nothing) when the shape is
 // outside that path -- the caller then uses onet_convT2x2_dgrad + onet_convT2x2_dbias
 int onet_convT2x2_dgrad_dbias(const float* dy, int64_t dy_bs, const float* wp_dgrad, float* dx, int64_t dx_bs, float* dbias, void* ws,
-                              int64_t ws_bytes, int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, void* stream) {
+                              int64_t ws_bytes, int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int operand_bf16, void* stream) {
     ONET_REQUIRE(dy && wp_dgrad && dx && dbias && ws, "convT2x2_dgrad_dbias: null pointer");
     ONET_REQUIRE(B > 0 && Cin > 0 && Ct > 0 && h > 0 && w > 0, "convT2x2_dgrad_dbias: bad shape");
     ONET_REQUIRE(dy_bs >= (int64_t)Ct * Ho * Wo && dx_bs >= (int64_t)Cin * h * w, "convT2x2_dgrad_dbias: batch stride too small");
     if (!convt_gemm_enabled() || ws_bytes < convt_gemm_dbias_ws_bytes(B, Ct, h, w)) return 1;
-    return convt_gemm_dgrad(dy, dy_bs, wp_dgrad, dx, dx_bs, dbias, (float*)ws, B, Cin, Ct, h, w, Ho, Wo, pt, pl, as_stream(stream));
+    return convt_gemm_dgrad(dy, dy_bs, wp_dgrad, dx, dx_bs, dbias, (float*)ws, B, Cin, Ct, h, w, Ho, Wo, pt, pl, operand_bf16 != 0, as_stream(stream));
 }
 
 int onet_conv_fwd_nparts(int B, int Cout, int H, int W) {
@@ -899,7 +892,7 @@ int onet_conv_wgrad(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs
 }
 
 int onet_convT2x2_wgrad(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, float* dw, void* ws,
-                        int64_t ws_bytes, int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl,
+                        int64_t ws_bytes, int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int operand_bf16,
                         void* stream) {
     ONET_REQUIRE(x && dy && dw && ws, "convT2x2_wgrad: null pointer");
     ONET_REQUIRE(B > 0 && Cin > 0 && Ct > 0 && h > 0 && w > 0, "convT2x2_wgrad: bad shape");
@@ -907,7 +900,7 @@ int onet_convT2x2_wgrad(const float* x, int64_t x_bs, const float* dy, int64_t d
     ONET_REQUIRE(pt >= 0 && pl >= 0 && pt + 2 * h <= Ho && pl + 2 * w <= Wo, "convT2x2_wgrad: window outside plane");
     ONET_REQUIRE(dy_bs >= (int64_t)Ct * Ho * Wo && x_bs >= (int64_t)Cin * h * w, "convT2x2_wgrad: batch stride too small");
     if (convt_gemm_enabled()) {
-        const int rc = convt_gemm_wgrad(x, x_bs, dy, dy_bs, dw, ws, ws_bytes, B, Cin, Ct, h, w, Ho, Wo, pt, pl, as_stream(stream));
+        const int rc = convt_gemm_wgrad(x, x_bs, dy, dy_bs, dw, ws, ws_bytes, B, Cin, Ct, h, w, Ho, Wo, pt, pl, operand_bf16 != 0, as_stream(stream));
         if (rc <= 0) return rc;
     }
     const int Cout = 4 * Ct;

@@ -501,15 +501,12 @@ void wgrad_plan(int B, int Cin, int Ct, int h, int w, int& splitK, int& per) {
 
 namespace onet {
 
-// operand precision of the three GEMMs: 0 fp32 (default), 1 bf16 operands with fp32 accumulation (the bf16 conv path of BASELINE
-// configs[2]; set per call by the host side from its conv algorithm switch: onet_convT2x2_set_bf16)
-static std::atomic<int> g_convt_bf16{0};
-void convt_set_bf16(int on) { g_convt_bf16.store(on ? 1 : 0, std::memory_order_relaxed); }
-bool convt_bf16_operands() { return g_convt_bf16.load(std::memory_order_relaxed) != 0; }
+// `bf`: operand precision of the three GEMMs, per call: false = fp32, true = bf16 operands with fp32 accumulation (the bf16 conv
+// path of BASELINE configs[2]; the `operand_bf16` argument of the onet_convT2x2_* entry points)
 
 // Fast-path predicates + launches; return ONET_NOT_TAKEN (1) when the shape is not taken (caller falls back to conv_mfma.hip)
 int convt_gemm_fwd(const float* x, int64_t x_bs, const float* wq, const float* bias, float* y, int64_t y_bs, void* y16, int64_t y16_bs,
-                   int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, hipStream_t st) {
+                   int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, bool bf, hipStream_t st) {
     const int64_t hw = (int64_t)h * w;
     if (pt || pl || Ho != 2 * h || Wo != 2 * w || (Cin % KC) || (Ct % 32) || (hw % 128) || (w & 1) || !aligned16(x) || !aligned16(wq) ||
         (x_bs & 3) || (reinterpret_cast<uintptr_t>(y) & 7) || (y_bs & 1) || (int64_t)Cin * hw * 4 >= (1ll << 31) ||
@@ -520,7 +517,7 @@ int convt_gemm_fwd(const float* x, int64_t x_bs, const float* wq, const float* b
     GArgs g{wq, x, y, bias, nullptr, (__bf16*)y16, y16_bs, 0, x_bs, y_bs, B, Cin, Ct, h, w, Wo, Ho * Wo, (4 * Ct) / 128, (int)(B * hw / 128), 1, 0};
     const int64_t blocks = (int64_t)g.mTiles * g.nTiles;
     if (blocks <= 0 || blocks >= (1ll << 31)) return 1;
-    if (convt_bf16_operands()) hipLaunchKernelGGL((convt_gemm_kernel<0, true>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    if (bf) hipLaunchKernelGGL((convt_gemm_kernel<0, true>), dim3((unsigned)blocks), dim3(256), 0, st, g);
     else hipLaunchKernelGGL((convt_gemm_kernel<0, false>), dim3((unsigned)blocks), dim3(256), 0, st, g);
     return check_launch("convt_gemm_kernel<0>");
 }
@@ -529,7 +526,7 @@ int64_t convt_gemm_dbias_ws_bytes(int B, int Ct, int h, int w) { return (int64_t
 
 // dbias != NULL: also the ConvTranspose2d bias gradient, taken from the dy rows the GEMM stages anyway (dbias_ws: partials)
 int convt_gemm_dgrad(const float* dy, int64_t dy_bs, const float* wd, float* dx, int64_t dx_bs, float* dbias, float* dbias_ws, int B,
-                     int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, hipStream_t st) {
+                     int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, bool bf, hipStream_t st) {
     const int64_t hw = (int64_t)h * w;
     if (pt || pl || Ho != 2 * h || Wo != 2 * w || (Cin % 128) || (Ct % 4) || (hw % 128) || (w & 1) || !aligned16(dy) || !aligned16(wd) ||
         (dy_bs & 3) || (int64_t)Ct * Ho * Wo * 4 >= (1ll << 31) || (int64_t)Cin * 4 * Ct * 4 >= (1ll << 31))
@@ -538,7 +535,7 @@ int convt_gemm_dgrad(const float* dy, int64_t dy_bs, const float* wd, float* dx,
     GArgs g{wd, dy, dx, nullptr, dbias ? dbias_ws : nullptr, nullptr, 0, 0, dy_bs, dx_bs, B, Cin, Ct, h, w, Wo, Ho * Wo, Cin / 128, (int)(B * hw / 128), 1, 0};
     const int64_t blocks = (int64_t)g.mTiles * g.nTiles;
     if (blocks <= 0 || blocks >= (1ll << 31)) return 1;
-    if (convt_bf16_operands()) hipLaunchKernelGGL((convt_gemm_kernel<1, true>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    if (bf) hipLaunchKernelGGL((convt_gemm_kernel<1, true>), dim3((unsigned)blocks), dim3(256), 0, st, g);
     else hipLaunchKernelGGL((convt_gemm_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, st, g);
     int rc = check_launch("convt_gemm_kernel<1>");
     if (rc || !dbias) return rc;
@@ -554,7 +551,7 @@ int64_t convt_gemm_wgrad_ws_bytes(int B, int Cin, int Ct, int h, int w) {
 }
 
 int convt_gemm_wgrad(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, float* dw, void* ws, int64_t ws_bytes, int B,
-                     int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, hipStream_t st) {
+                     int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, bool bf, hipStream_t st) {
     const int64_t hw = (int64_t)h * w;
     if (pt || pl || Ho != 2 * h || Wo != 2 * w || (Cin % 128) || (Ct % 32) || (hw % KP) || (w & 1) || !aligned16(x) || !aligned16(dy) ||
         !aligned16(dw) || (x_bs & 3) || (dy_bs & 3) || (int64_t)Cin * hw * 4 >= (1ll << 31) || (int64_t)Ct * Ho * Wo * 4 >= (1ll << 31))
@@ -564,7 +561,7 @@ int convt_gemm_wgrad(const float* x, int64_t x_bs, const float* dy, int64_t dy_b
     const int64_t n = (int64_t)Cin * 4 * Ct;
     if (ws_bytes < (int64_t)g.splitK * n * 4) return 1;
     const int64_t blocks = (int64_t)g.splitK * g.mTiles * g.nTiles;
-    if (convt_bf16_operands()) hipLaunchKernelGGL(convt_wgrad_gemm_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, g);
+    if (bf) hipLaunchKernelGGL(convt_wgrad_gemm_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, g);
     else hipLaunchKernelGGL(convt_wgrad_gemm_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, g);
     int rc = check_launch("convt_wgrad_gemm_kernel");
     if (rc) return rc;

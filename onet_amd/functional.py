@@ -10,6 +10,26 @@ import torch
 from . import ops
 
 
+def _carries_settings(cls):
+    """Class decorator for the Functions below: forward remembers the `ops.Settings` record active on the calling thread (the
+    model's, set by `Onet.forward` / `compute_loss`), backward -- run by autograd's own thread, any time later -- re-activates it,
+    so that algorithm / precision choices made in backward are the model's and not whatever another model left behind."""
+    fwd, bwd = cls.forward, cls.backward
+
+    def forward(ctx, *args, **kw):
+        ctx._onet_settings = ops.active_settings()
+        return fwd(ctx, *args, **kw)
+
+    def backward(ctx, *grads):
+        with ops.using(getattr(ctx, "_onet_settings", None)):
+            return bwd(ctx, *grads)
+
+    forward.__doc__, backward.__doc__ = fwd.__doc__, bwd.__doc__
+    cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
+    return cls
+
+
+@_carries_settings
 class ConvBNReLUFn(torch.autograd.Function):
     """Conv2d(3x3, pad 1, no bias) -> BatchNorm2d -> ReLU  (OV:47-49 / OV:51-53).
 
@@ -170,6 +190,7 @@ class ConvBNReLUFn(torch.autograd.Function):
                 None, None, None, None, None)
 
 
+@_carries_settings
 class Conv3x3Fn(torch.autograd.Function):
     """Bare 3x3 convolution (standalone use of the conv parameter holder)."""
 
@@ -190,6 +211,7 @@ class Conv3x3Fn(torch.autograd.Function):
         return dx, dw, None
 
 
+@_carries_settings
 class BNReLUFn(torch.autograd.Function):
     """BatchNorm2d -> ReLU on an existing pre-activation (standalone use)."""
 
@@ -212,6 +234,7 @@ class BNReLUFn(torch.autograd.Function):
         return dz, dgamma, dbeta, None, None, None, None, None
 
 
+@_carries_settings
 class MaxPool2Fn(torch.autograd.Function):
     """nn.MaxPool2d(2)  (OV:67)."""
 
@@ -228,6 +251,7 @@ class MaxPool2Fn(torch.autograd.Function):
         return ops.maxpool2_bwd(x, dy)
 
 
+@_carries_settings
 class SkipPoolFn(torch.autograd.Function):
     """x -> (x, maxpool2(x)[, x]) for an encoder output that feeds both the next Down (OV:67) and an Up's skip concat
     (OV:100) -- and, for the first one, also leaves the U-Net as its first output (OV:152): backward sums the two or
@@ -278,6 +302,7 @@ def _pad_offsets(x1_hw, x2_hw):
     return dY // 2, dX // 2
 
 
+@_carries_settings
 class UpConvTCatFn(torch.autograd.Function):
     """ConvTranspose2d(C, C/2, k=2, s=2) + F.pad + cat([skip, up], 1)  (OV:86, OV:91-100).
 
@@ -353,6 +378,7 @@ class UpConvTCatFn(torch.autograd.Function):
         return dx1, dx2, dw, db, None, None, None
 
 
+@_carries_settings
 class UpBilinearCatFn(torch.autograd.Function):
     """nn.Upsample(x2, bilinear, align_corners=True) + F.pad + cat  (OV:83, OV:91-100)."""
 
@@ -377,6 +403,7 @@ class UpBilinearCatFn(torch.autograd.Function):
         return dx1, dx2
 
 
+@_carries_settings
 class HeadSoftmaxFn(torch.autograd.Function):
     """V = einsum('bpxy,bpxy->bxy', L, H) for both branches + Softmax2d(cat[Vt,Vd])  (OV:176-189)."""
 
@@ -393,6 +420,7 @@ class HeadSoftmaxFn(torch.autograd.Function):
         return dLt, dHt, dLd, dHd
 
 
+@_carries_settings
 class TwinInputFn(torch.autograd.Function):
     """[X ; clip(1 - X + bias, 0, 1)] as one batch of 2B (OV:180 for the second half)."""
 
@@ -416,6 +444,7 @@ class TwinInputFn(torch.autograd.Function):
         return g[:B] - g[B:] * ((y > 0) & (y < 1)).to(g.dtype), None
 
 
+@_carries_settings
 class TwinSplitFn(torch.autograd.Function):
     """full [2B, ...] -> (top half, down half) as views.  The module's own head and loss differentiate the FULL
     tensor directly; this node only carries gradient when a caller uses Lt / Ld in a graph of their own."""
@@ -439,6 +468,7 @@ class TwinSplitFn(torch.autograd.Function):
         return out
 
 
+@_carries_settings
 class HeadSoftmaxTwinFn(torch.autograd.Function):
     """HeadSoftmaxFn on the twin batch: L = [Lt ; Ld], H = [Ht ; Hd] (each [2B, 64, H, W]).  Also returns the per-pixel
     channel sums of Lt and Ld -- all the loss needs of L (OV:231-232: the einsum with a 1-channel S is S * sum_c L) --
@@ -459,6 +489,7 @@ class HeadSoftmaxTwinFn(torch.autograd.Function):
         return dL, dH
 
 
+@_carries_settings
 class JSDSumsFn(torch.autograd.Function):
     """(jsd(Lt, St, Sd), jsd(Ld, Sd, St)) of Onet.compute_loss (OV:253-267) from the channel sums sLt, sLd."""
 
@@ -480,6 +511,7 @@ class JSDSumsFn(torch.autograd.Function):
         return gLt, gLd, dSt_a + dSt_b, dSd_a + dSd_b
 
 
+@_carries_settings
 class JSDFn(torch.autograd.Function):
     """Onet.jensen_shannon_divergence(Li, Si, Sprime)  (OV:221-235) incl. the log1pexp quirk."""
 
@@ -498,6 +530,7 @@ class JSDFn(torch.autograd.Function):
         return gL.expand(ctx.shape), dSi, dSp
 
 
+@_carries_settings
 class Log1pExpFn(torch.autograd.Function):
     """Onet.log1pexp: mutates its argument in place and returns it  (OV:237-251)."""
 
@@ -515,6 +548,7 @@ class Log1pExpFn(torch.autograd.Function):
         return ops.log1pexp_bwd(x0, g)
 
 
+@_carries_settings
 class ComplementClipFn(torch.autograd.Function):
     """Xd = clip(1 - X + bias, 0, 1)  (OV:180)."""
 

@@ -362,9 +362,16 @@ class Onet(nn.Module):
         self.softmax = Softmax2()
         self.bias = 0                       # background bias in [0,1], read every forward (OV:172,180)
         self.check_finite = True            # OV:234 asserts the loss is not NaN (forces a device sync)
+        # this model's switches (conv algorithm / precision, twin batching, deferred NaN check); None fields = process defaults.
+        # Active for everything forward / compute_loss launch and -- captured by the autograd Functions -- for their backward.
+        self.settings = ops.Settings()
 
     def forward(self, X):
-        if self.dwnu is self.topu and ops.TWIN and X.dim() == 4 and X.is_cuda:
+        with ops.using(self.settings):
+            return self._forward(X)
+
+    def _forward(self, X):
+        if self.dwnu is self.topu and ops.twin_enabled() and X.dim() == 4 and X.is_cuda:
             # shared weights: X and 1-X go through every convolution as ONE batch of 2B (twice the blocks per launch,
             # weights packed / weight gradients reduced once); BatchNorm treats the halves as two batches, in the
             # reference's order (X first).  Results: identical activations, weight gradients summed in one
@@ -406,6 +413,10 @@ class Onet(nn.Module):
         return Fn.Log1pExpFn.apply(x)
 
     def compute_loss(self, Lt, St, Ld, Sd):
+        with ops.using(self.settings):
+            return self._compute_loss(Lt, St, Ld, Sd)
+
+    def _compute_loss(self, Lt, St, Ld, Sd):
         tag_t, tag_d = getattr(Lt, "_onet_twin", None), getattr(Ld, "_onet_twin", None)
         twin = None
         if (tag_t is not None and tag_d is not None and tag_t[0] is tag_d[0] and tag_t[1] == 0 and tag_d[1] == 1
@@ -421,11 +432,11 @@ class Onet(nn.Module):
             jsd_top, jsd_dwn = Fn.JSDSumsFn.apply(twin[1], twin[2], St, Sd)
             if self.check_finite:
                 # OV:234 asserts each term right after computing it (two device syncs); both terms exist here
-                # already, so one check answers for the pair -- in place, or (ops.LAZY_NAN_CHECK, set by training
+                # already, so one check answers for the pair -- in place, or (settings.lazy_nan, set by training
                 # loops that own the optimizer step) deferred to FlatAdam.step() / the next compute_loss
                 ops.check_deferred_nan()
                 flag = torch.isnan(jsd_top + jsd_dwn)
-                if ops.LAZY_NAN_CHECK:
+                if ops.lazy_nan_check():
                     ops.defer_nan_check(flag)
                 else:
                     assert not bool(flag), "jsd is NaN"

@@ -13,6 +13,100 @@ from . import _lib
 F32 = torch.float32
 
 
+# ----------------------------------------------------------------------------- per-model settings
+class Settings:
+    """Switches a MODEL carries (`Onet.settings`); a field left at None falls back to the process default (the module
+    attribute of the same purpose below, initialised from the environment).  The active record is thread-local: `Onet.forward`
+    / `compute_loss` activate their model's record for the calls they make, and every autograd Function of
+    onet_amd.functional captures the record active in its forward and re-activates it in its backward (which autograd runs
+    on another thread, possibly after another model has run) -- so two models with different settings in one process, or on
+    two streams / threads, never see each other's.
+
+      conv          3x3 convolution algorithm: "auto" | "winograd4" | "winograd" | "direct" | "bf16"     (default CONV_ALGO)
+      twin          weight-shared Onet: X and 1-X as ONE batch of 2B                                        (default TWIN)
+      convt_bf16    under conv == "bf16": the ConvTranspose2d GEMMs take bf16 operands too                  (default CONVT_BF16)
+      bf16_storage  under conv == "bf16": producers write bf16 copies of the conv operands                  (default BF16_STORAGE)
+      lazy_nan      OV:234's NaN assertion deferred to FlatAdam.step()                                      (default LAZY_NAN_CHECK)"""
+    __slots__ = ("conv", "twin", "convt_bf16", "bf16_storage", "lazy_nan")
+
+    def __init__(self, conv=None, twin=None, convt_bf16=None, bf16_storage=None, lazy_nan=None):
+        self.conv, self.twin, self.convt_bf16, self.bf16_storage, self.lazy_nan = conv, twin, convt_bf16, bf16_storage, lazy_nan
+
+    def replace(self, **kw):
+        out = Settings(*(getattr(self, k) for k in self.__slots__))
+        for k, v in kw.items():
+            setattr(out, k, v)
+        return out
+
+    def __repr__(self):
+        return "Settings(%s)" % ", ".join("%s=%r" % (k, getattr(self, k)) for k in self.__slots__)
+
+
+import threading as _threading
+_TLS = _threading.local()
+
+
+def active_settings():
+    return getattr(_TLS, "cur", None)
+
+
+class using:
+    """`with ops.using(settings):` -- make `settings` the active record of this thread (None: leave the current one)."""
+
+    def __init__(self, settings):
+        self.settings = settings
+
+    def __enter__(self):
+        self.prev = getattr(_TLS, "cur", None)
+        if self.settings is not None:
+            _TLS.cur = self.settings
+        return self.settings
+
+    def __exit__(self, *exc):
+        _TLS.cur = self.prev
+        return False
+
+
+def _setting(field, default):
+    cur = getattr(_TLS, "cur", None)
+    v = None if cur is None else getattr(cur, field)
+    return default if v is None else v
+
+
+def conv_algo():
+    return _setting("conv", CONV_ALGO)
+
+
+def twin_enabled():
+    return bool(_setting("twin", TWIN))
+
+
+def lazy_nan_check():
+    return bool(_setting("lazy_nan", LAZY_NAN_CHECK))
+
+
+def convt_operand_bf16():
+    """operand_bf16 argument of the onet_convT2x2_* entry points for the calling model"""
+    return int(conv_algo() == "bf16" and bool(_setting("convt_bf16", CONVT_BF16)))
+
+
+_CU_COUNT = {}
+
+
+def n_cu(device=None):
+    """compute units of the current device (onet_device_info; 256 on MI355X)"""
+    idx = torch.cuda.current_device() if device is None or device.index is None else device.index
+    n = _CU_COUNT.get(idx)
+    if n is None:
+        import ctypes
+        cu, lds, wave = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        arch = ctypes.create_string_buffer(64)
+        rc = _lib.load().onet_device_info(ctypes.byref(cu), ctypes.byref(lds), ctypes.byref(wave), arch, 64)
+        n = int(cu.value) if rc == 0 and cu.value > 0 else 256
+        _CU_COUNT[idx] = n
+    return n
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -34,7 +128,7 @@ def plane(t):
     """-> (tensor, batch_stride) with the (C,H,W) block of every image contiguous.
     Channel-slices of a concat buffer qualify as they are; anything else is copied."""
     B, C, H, W = t.shape
-    if W > 1 and t.stride(3) == 0:
+    if is_placeholder(t):
         raise RuntimeError("onet_amd: an fp32 placeholder (bf16 storage: tensor kept in bf16 only) reached a kernel that reads fp32")
     ok = (W == 1 or t.stride(3) == 1) and (H == 1 or t.stride(2) == W) and (C == 1 or t.stride(1) == H * W)
     if ok and B > 1 and t.stride(0) < C * H * W:
@@ -184,19 +278,14 @@ def packT2x2_fused(w):
 
 
 # BASELINE configs[2]: under the bf16 conv path the ConvTranspose2d GEMMs take bf16 MFMA operands too (what torch.autocast does to
-# nn.ConvTranspose2d); ONET_CONVT_BF16=0 keeps them fp32.  The switch is process-wide in the library, so it is set per call.
+# nn.ConvTranspose2d); ONET_CONVT_BF16=0 keeps them fp32.  Passed to the library per call (`operand_bf16`).
 CONVT_BF16 = _os.environ.get("ONET_CONVT_BF16", "1") != "0"
-
-
-def _convt_precision():
-    _lib.load().onet_convT2x2_set_bf16(int(CONV_ALGO == "bf16" and CONVT_BF16))
 
 
 def convT2x2_fwd(x, wq, bias, out, Ct, pt, pl, out16=None):
     """out[:, c, pt + 2i + di, pl + 2j + dj] = sum_ci x[:, ci, i, j] * W[ci, c, di, dj] + bias[c]: ConvTranspose2d(k=2, s=2)
     written straight into `out`, a plane-contiguous [B, Ct, Ho, Wo] view (e.g. the second half of a concat buffer).
     out16: the matching bf16 view (bf16 storage) -> returns True if the copy was written (128 x 128 GEMM path only)."""
-    _convt_precision()
     require_gpu(x, wq, out)
     x, xbs = plane(x)
     B, Cin, h, w = x.shape
@@ -208,7 +297,7 @@ def convT2x2_fwd(x, wq, bias, out, Ct, pt, pl, out16=None):
         o16bs = out16.stride(0) if B > 1 else Ct * Ho * Wo
         e0 = _prof_begin()
         rc = _lib.load().onet_convT2x2_fwd_b(_p(x), xbs, _p(wq), _p(bias), _p(out), obs, _p(out16), o16bs, B, Cin, Ct, h, w, Ho, Wo,
-                                             pt, pl, _stream())
+                                             pt, pl, convt_operand_bf16(), _stream())
         _prof_end("convt_gemm_kernel", flops if rc == 0 else 0.0, e0, nb if rc == 0 else 0.0)
         if rc == 0:
             return True
@@ -217,7 +306,8 @@ def convT2x2_fwd(x, wq, bias, out, Ct, pt, pl, out16=None):
     if out is None:
         return False
     e0 = _prof_begin()
-    _lib.call("onet_convT2x2_fwd", _p(x), xbs, _p(wq), _p(bias), _p(out), obs, B, Cin, Ct, h, w, Ho, Wo, pt, pl, _stream())
+    _lib.call("onet_convT2x2_fwd", _p(x), xbs, _p(wq), _p(bias), _p(out), obs, B, Cin, Ct, h, w, Ho, Wo, pt, pl,
+              convt_operand_bf16(), _stream())
     _prof_end("convt_gemm_kernel", flops, e0, nb)
     return False
 
@@ -236,7 +326,6 @@ CONV_ALGO = _os.environ.get("ONET_CONV_ALGO", "auto")
 # (BatchNorm keeps the two halves as separate statistics groups).  ONET_TWIN=0 runs the two passes one after the
 # other, as the reference does.
 TWIN = _os.environ.get("ONET_TWIN", "1") != "0"
-_N_CU = 256
 
 
 # bf16 STORAGE of the conv operands (only with CONV_ALGO == "bf16", BASELINE config 3): the kernels that produce an
@@ -248,7 +337,7 @@ BF = torch.bfloat16
 
 
 def bf16_storage():
-    return BF16_STORAGE and CONV_ALGO == "bf16"
+    return bool(_setting("bf16_storage", BF16_STORAGE)) and conv_algo() == "bf16"
 
 
 def b16_of(t):
@@ -274,10 +363,31 @@ def consumer_reads_bf16(B, Cin, Cout, H, W):
     return bf16_storage() and conv3x3_algo(B, Cin, Cout, H, W) == "bf16" and wgrad_takes_bf16(Cin, H, W) and W % 8 == 0
 
 
+_SENTINEL = {}
+
+
+def _sentinel(device):
+    """The 4-byte storage every fp32 placeholder of `device` points at: what identifies one (an expanded gradient or a user's
+    `.expand()`ed input has zero strides too, but its own storage -- those are ordinary tensors and are copied by `plane`)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    s = _SENTINEL.get(key)
+    if s is None:
+        s = _SENTINEL[key] = torch.zeros(1, dtype=F32, device=device)
+    return s
+
+
+def is_placeholder(t):
+    return bool(_SENTINEL) and t.is_cuda and t.dtype == F32 and \
+        t.untyped_storage().data_ptr() == _sentinel(t.device).untyped_storage().data_ptr()
+
+
 def fp32_placeholder(shape, device):
-    """A zero-stride fp32 tensor of the given shape (4 bytes of storage): what autograd passes around in place of an
-    activation whose only consumers read its bf16 copy (`_onet_b16`).  Never read by a kernel."""
-    return torch.empty(1, dtype=F32, device=device).as_strided(tuple(shape), (0,) * len(shape))
+    """A zero-stride fp32 tensor of the given shape over the device's sentinel storage (4 bytes): what autograd passes around
+    in place of an activation whose only consumers read its bf16 copy (`_onet_b16`).  Never read by a kernel (`plane` raises).
+    Not a view: it has its own version counter, which is what validates the bf16 copy riding on it."""
+    t = torch.empty(0, dtype=F32, device=device)
+    t.set_(_sentinel(t.device).untyped_storage(), 0, tuple(shape), (0,) * len(shape))
+    return t
 
 
 def plane16(t):
@@ -303,7 +413,8 @@ def _in_buffer_range(Cin, Cout, H, W):
 
 def conv3x3_algo(B, Cin, Cout, H, W):
     """-> "winograd4" | "winograd" | "direct" for a conv with Cin inputs and Cout outputs on B maps of H x W."""
-    algo = "winograd" if CONV_ALGO == "winograd2" else CONV_ALGO
+    algo = conv_algo()
+    algo = "winograd" if algo == "winograd2" else algo
     if algo in ("bf16", "winograd4", "auto") and not _in_buffer_range(Cin, Cout, H, W):
         algo = "winograd"
     if algo == "bf16":
@@ -324,14 +435,14 @@ def conv3x3_algo(B, Cin, Cout, H, W):
     if min(H, W) >= 16:
         img = 1 if W > 16 else 2                       # conv_wino4.hip block: 32 tiles of 4x4 px, 64 channels
         blocks = -(-B // img) * -(-W // (32 if W > 16 else 16)) * -(-H // 16) * -(-Cout // 64)
-        if blocks >= (_N_CU * 7) // 8:
+        if blocks >= (n_cu() * 7) // 8:
             return "winograd4"
     return "winograd"
 
 
 def use_winograd(Cin, Cout, H, W):
     """Does the Winograd weight-gradient kernel (F(2x2,3x3)) take this layer?"""
-    return CONV_ALGO != "direct" and _wino_legal(Cin, Cout) and min(H, W) >= 8
+    return conv_algo() != "direct" and _wino_legal(Cin, Cout) and min(H, W) >= 8
 
 
 class Packed3x3(dict):
@@ -654,7 +765,7 @@ def conv3x3_wgrad_bf16(x, dz, dw_shape, out=None, x16=None, dz16=None):
 
 def wgrad_takes_bf16(Cin, H, W):
     """Does conv3x3_wgrad_auto route this layer to the bf16 weight-gradient kernel (given contiguous dz)?"""
-    return CONV_ALGO == "bf16" and Cin >= 16 and W >= 16 and W % 4 == 0 and H >= 8
+    return conv_algo() == "bf16" and Cin >= 16 and W >= 16 and W % 4 == 0 and H >= 8
 
 
 def conv3x3_wgrad_auto(x, dz, dw_shape, out=None, x16=None, dz16=None):
@@ -975,7 +1086,6 @@ def convT2x2_dgrad(dy, wp_dgrad, Cin, h, w, pt, pl, want_dbias=False, db_out=Non
     """dx1 of ConvTranspose2d(k=2, s=2) straight from the [B, Ct, Ho, Wo] window `dy` of the concat gradient.
     want_dbias: -> (dx1, dbias | None): where the 128 x 128 GEMM path takes the shape the bias gradient is summed from the
     dy rows that launch stages anyway; None = not taken (the caller then runs the separate dbias pass)."""
-    _convt_precision()
     require_gpu(dy, wp_dgrad)
     dy, dybs = plane(dy)
     B, Ct, Ho, Wo = dy.shape
@@ -989,7 +1099,7 @@ def convT2x2_dgrad(dy, wp_dgrad, Cin, h, w, pt, pl, want_dbias=False, db_out=Non
             ws = torch.empty(need // 4, dtype=F32, device=dy.device)
             e0 = _prof_begin()
             rc = lib.onet_convT2x2_dgrad_dbias(_p(dy), dybs, _p(wp_dgrad), _p(dx), Cin * h * w, _p(db), _p(ws), need, B, Cin, Ct, h,
-                                               w, Ho, Wo, pt, pl, _stream())
+                                               w, Ho, Wo, pt, pl, convt_operand_bf16(), _stream())
             if rc == 0:
                 _prof_end("convt_gemm_kernel", flops, e0, nbytes)
                 return dx, db
@@ -998,14 +1108,13 @@ def convT2x2_dgrad(dy, wp_dgrad, Cin, h, w, pt, pl, want_dbias=False, db_out=Non
                 raise _lib.OnetHipError(f"onet_convT2x2_dgrad_dbias failed ({rc}): {_lib.last_error()}")
     e0 = _prof_begin()
     _lib.call("onet_convT2x2_dgrad", _p(dy), dybs, _p(wp_dgrad), _p(dx), Cin * h * w, B, Cin, Ct, h, w, Ho, Wo, pt, pl,
-              _stream())
+              convt_operand_bf16(), _stream())
     _prof_end("convt_gemm_kernel", flops, e0, nbytes)
     return (dx, None) if want_dbias else dx
 
 
 def convT2x2_wgrad(x, dy, dw_shape, pt, pl, want_dbias, out=None, db_out=None):
     """(dW [Cin, Ct, 2, 2], dbias | None) of ConvTranspose2d(k=2, s=2) from x1 and the concat-gradient window."""
-    _convt_precision()
     require_gpu(x, dy)
     x, xbs = plane(x)
     dy, dybs = plane(dy)
@@ -1016,7 +1125,7 @@ def convT2x2_wgrad(x, dy, dw_shape, pt, pl, want_dbias, out=None, db_out=None):
     ws = workspace(need, x.device)
     e0 = _prof_begin()
     _lib.call("onet_convT2x2_wgrad", _p(x), xbs, _p(dy), dybs, _p(dw), _p(ws), ws.numel() * 4, B, Cin, Ct, h, w, Ho, Wo,
-              pt, pl, _stream())
+              pt, pl, convt_operand_bf16(), _stream())
     _prof_end("convt_wgrad_gemm_kernel", 2.0 * B * h * w * Cin * 4 * Ct, e0, 4.0 * (B * h * w * (Cin + 4 * Ct) + 4 * Cin * Ct))
     db = None
     if want_dbias:

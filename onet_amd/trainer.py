@@ -173,7 +173,7 @@ class FlatAdam:
                 p.grad = view
 
     def _check_nan_all_ranks(self):
-        """The loss's OV:234 verdict (ops.LAZY_NAN_CHECK), BEFORE the update is applied.  With several ranks the verdict
+        """The loss's OV:234 verdict (Settings.lazy_nan), BEFORE the update is applied.  With several ranks the verdict
         is shared first (one byte over a host-side gloo group: no GPU work, the host runs ahead of the device anyway), so
         that every rank raises in the same step instead of one rank leaving its peers waiting in the all-reduce."""
         try:
@@ -295,14 +295,16 @@ def fit(onet, train_loader, device, epochs, schedule="sim", base_lr=None, eval_f
         out_root=None, model_name="Onet", fused_adam=True, rank=0, world=1, log=print):
     """Epoch loop of TS:201-266 (schedule='sim') / TZ:99-153 (schedule='zy3').
     `train_loader` yields (X, ...) with X a CPU or GPU float32 [B,C,H,W] tensor in [0,1]."""
-    lazy_before = ops.LAZY_NAN_CHECK
-    if fused_adam:
-        ops.LAZY_NAN_CHECK = True     # OV:234's assertion is raised by FlatAdam.step(), before the update, without a mid-step sync
+    before = getattr(onet, "settings", None)
+    if fused_adam and before is not None:
+        # OV:234's assertion is raised by FlatAdam.step(), before the update, without a mid-step sync (this model only)
+        onet.settings = before.replace(lazy_nan=True)
     try:
         return _fit(onet, train_loader, device, epochs, schedule, base_lr, eval_fn, eval_every, out_root, model_name,
                     fused_adam, rank, world, log)
     finally:
-        ops.LAZY_NAN_CHECK = lazy_before
+        if before is not None:
+            onet.settings = before
 
 
 def _fit(onet, train_loader, device, epochs, schedule, base_lr, eval_fn, eval_every, out_root, model_name, fused_adam,

@@ -65,7 +65,30 @@ def test_two_ranks_syncbn_equals_one_rank():
 
 
 def test_bench_exits_nonzero_on_a_failure_inside_main():
-    """No in-process restart: any exception in a rank's main() (an RCCL error included) ends the process with code 1."""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3"], cwd=ROOT, capture_output=True,
-                         text=True, timeout=300, env=dict(os.environ, WORLD_SIZE="1"))
+    """No in-process restart: any exception in a rank's main() (an RCCL error included) ends the process with code 1.
+    Provoked here by a launcher environment that contradicts --gpus (RANK set, so bench.py does not launch ranks itself)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--no-cpu-baseline"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                                  MASTER_PORT=str(_free_port()), ONET_DIST_BACKEND="gloo"))
     assert out.returncode != 0
+    assert "WORLD_SIZE=1" in out.stderr
+
+
+@pytest.mark.timeout(600)
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: the GPU-free parent starts torch.distributed.run as a child,
+    relays rank 0's single JSON line and the exit code (two ranks sharing cuda:0 over gloo, as above)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(ONET_DIST_BACKEND="gloo", ONET_FORCE_LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--bucket-mb", "8", "--batch", "4", "--size", "64"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=540)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["value"] > 0
+    assert "secondary" not in d and "cpu_baseline" not in d          # N = 1 only

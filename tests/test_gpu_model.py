@@ -683,6 +683,35 @@ def test_non_contiguous_and_strided_inputs(dev):
         big[..., ::2] = X
         assert torch.equal(m(big[..., ::2])[4], ref)
         assert torch.equal(m(X.to(memory_format=torch.channels_last))[4], ref)
+        row = X[:, :, :1, :1]
+        assert torch.equal(m(row.expand(B, C, H, W))[4], m(row.repeat(1, 1, H, W))[4])     # zero strides, own storage
+
+
+@pytest.mark.parametrize("conv", ["auto", "bf16"])
+def test_expanded_gradients_are_ordinary_tensors(dev, monkeypatch, conv):
+    """`y.sum().backward()` hands the custom Functions a `grad.expand(...)` whose strides are all zero -- the layout of an
+    fp32 placeholder (bf16 storage), but not one: `ops.plane` must copy it, and only tensors over the sentinel storage may
+    raise.  Checked on a DoubleConv (both units' backward see expanded / dense gradients) and on the whole model."""
+    from onet_amd import DoubleConv, ops
+    monkeypatch.setattr(ops, "CONV_ALGO", conv)
+    torch.manual_seed(3)
+    dc = DoubleConv(16, 32).to(dev).train()
+    x = torch.rand(2, 16, 32, 32, device=dev, requires_grad=True)
+    y = dc(x)
+    y.sum().backward()
+    gx = x.grad.detach().clone()
+    x.grad = None
+    dc.zero_grad()
+    (dc(x) * torch.ones_like(y)).sum().backward()            # the same gradient delivered as a dense tensor
+    assert float((x.grad - gx).norm()) <= 1e-5 * float(gx.norm()) + 1e-12
+    m = _model(1, True, dev)
+    Lt, Vt, Ld, Vd, S = m(orc.det_input(2, 1, 32, 32, seed=4).to(dev))
+    (Lt.sum() + Ld.sum() + Vt.sum()).backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+    ph = ops.fp32_placeholder((2, 4, 8, 8), dev)
+    assert ops.is_placeholder(ph) and not ops.is_placeholder(torch.zeros(1, device=dev).expand(2, 4, 8, 8))
+    with pytest.raises(RuntimeError, match="placeholder"):
+        ops.plane(ph)
 
 
 def test_config3_batch256_single_gpu_fits_and_steps(dev):

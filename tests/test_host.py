@@ -6,6 +6,7 @@ import ctypes
 import inspect
 import math
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -24,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in protos:
         assert hasattr(lib, name), name
     lib2 = _lib.load()
-    assert lib2.onet_abi_version() == 1
+    assert lib2.onet_abi_version() == 2
     assert lib2.onet_jsd_nparts() > 0
     assert lib2.onet_conv_wgrad_ws_bytes(32, 64, 64, 256, 256, 3) > 0
 
@@ -234,3 +235,29 @@ def test_reference_wire_formats(tmp_path):
     assert imgs.dtype == torch.float32 and labels.shape == (3, 32, 32) and snrs.tolist() == [0, 1, 2]
     tr, te = io.split_train_test(10)
     assert len(tr) == 9 and len(te) == 1 and sorted(np.concatenate([tr, te]).tolist()) == list(range(10))
+
+
+def test_bench_self_launch_relays_the_ranks_exit_code():
+    """`python bench.py --gpus 2` outside a launcher starts its ranks as a child `torch.distributed.run` (no GPU call in the
+    parent) and hands back THEIR exit code: on this GPU-less box every rank fails loudly (no device), so must the parent --
+    and it must not have imported torch.cuda state or the HIP library itself to find that out."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: tests/test_gpu_dist.py::test_bench_launches_its_own_ranks covers the success path")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--batch", "2", "--size", "32", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode != 0
+    assert "torch.distributed.run" in out.stderr and "--nproc-per-node 2" in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_parent_is_gpu_free_before_the_launch_decision():
+    """bench.py imports neither torch nor onet_amd at module level (the launcher decision comes first)."""
+    import ast
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
+    names = {a.name.split(".")[0] for n in top if isinstance(n, ast.Import) for a in n.names} | \
+            {n.module.split(".")[0] for n in top if isinstance(n, ast.ImportFrom) and n.module}
+    assert not ({"torch", "onet_amd", "oracle"} & names), names
