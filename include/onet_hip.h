@@ -364,18 +364,24 @@ int onet_argmax2(const float* S, int64_t* Y, int B, int HW, void* stream);
 /* tensor_normal_per_frame (UT:673-689): y = (x - min) / (max - min + np.spacing(1)) per (b, c) plane */
 int onet_normalise_per_frame(const float* x, float* y, int planes, int HW, void* stream);
 
-/* ---- f-4: synthetic K-distributed sea clutter on the GPU (reference generators KD:469-526, RG:63-216; the recipe of
- * onet_amd/data.py).  `frames` frames of 512 x 512 are synthesised (white Philox fields -> FFT colouring -> MNLT to a
- * Gamma(5) texture x coloured complex speckle), `n_targets` rotated 2-D Gaussian extended targets per frame are added
- * (targets [frames][n_targets][6] = centre x, centre y, sigma x, sigma y, cos theta, sin theta in frame pixels; peak
- * amplitude sqrt(10^(snr_db[f] / 10) * mean clutter power)), and the centred H x W crop is written to out [frames][H][W]
- * (label [frames][H][W] = 1 inside a target's e^-2 contour; may be NULL).  Per-frame normalisation to [0,1] is
- * onet_normalise_per_frame (UT:673-689).  Deterministic in (seed, frame index): ranks generate disjoint frame ranges
- * by passing different seeds. */
+/* ---- f-4: synthetic K-distributed sea clutter on the GPU: the frame recipe of the reference's generators (KD:469-526
+ * `generate_K_distributed_noise`, KD:270-297, RG:177-216 `get_k_frame`, RG:63-175; NumPy statement: onet_amd/data.py), statistics
+ * pinned to frames made by the reference's own functions (tests/golden/clutter_stats.npz).  `frames` frames of 400 x 400 (a
+ * window of the 512 x 512 FFT torus) are synthesised: white Philox fields -> FFT colouring with the two complex frequency
+ * responses filt_texture / filt_speckle ([512][512] float2 each, built by the host from the recipe: sqrt(fft2(R_G)) with R_G the
+ * root field of the Hermite-coefficient polynomial, and sqrt(|f|^-0.6) on the recipe's index grid) -> MNLT to the Gamma(5)
+ * texture x complex speckle; `n_targets` rotated Gaussian extended targets per frame are placed in order as
+ * bg += (template > bg) * template (targets [frames][n_targets][8] = window x, window y, half-width, half-height, quadratic form
+ * a, b, c, label threshold; peak amplitude sqrt(10^(snr_db[f] / 10) * mean clutter power)), and the centred H x W crop is
+ * written to out [frames][H][W] (label [frames][H][W], may be NULL; fields [frames][4][400][400] = texture, Re speckle,
+ * Im speckle, clutter amplitude, may be NULL).  Per-frame normalisation to [0,1] is onet_normalise_per_frame (UT:673-689).
+ * Bit-reproducible in (seed, frame index): ranks generate disjoint frame ranges by passing different seeds. */
+int onet_clutter_fft_size(void);
 int onet_clutter_frame_size(void);
 int64_t onet_clutter_ws_bytes(int frames);
-int onet_clutter_generate(float* out, float* label, const float* targets, const float* snr_db, int n_targets, int frames,
-                          int H, int W, uint64_t seed, float corr_len, void* ws, int64_t ws_bytes, void* stream);
+int onet_clutter_generate(float* out, float* label, float* fields, const float* targets, const float* snr_db, int n_targets,
+                          int frames, int H, int W, uint64_t seed, const float* filt_texture, const float* filt_speckle, void* ws,
+                          int64_t ws_bytes, void* stream);
 /* per-image 2-class confusion counts [B][4] = (TP, FP, FN, TN), positive class = 1: the inputs of
  * _acc/_miou/_target_iou/_detection_rate/_false_alarm_rate (UT:100-192) */
 int onet_confusion2(const int64_t* pred, const int64_t* target, int64_t* counts, int B, int HW,

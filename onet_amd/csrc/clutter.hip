@@ -1,19 +1,26 @@
 // "Next" row f-4: the synthetic K-distributed sea-clutter generator on the GPU, so that a weak-scaling run
-// can make each rank's frames in place instead of on the host (onet_amd/data.py is the NumPy statement of the same recipe,
-// itself restating the reference's generators: KD = K_distributed_SeaClutter_Simulation_20210919.py:469-526, RG =
-// Rayleigh_bg_Gaussian_EOT_generator_20230208.py:63-216):
+// can make each rank's frames in place instead of on the host.  It follows the FRAME RECIPE of the reference's generators step
+// by step (KD = K_distributed_SeaClutter_Simulation_20210919.py, RG = Rayleigh_bg_Gaussian_EOT_generator_20230208.py;
+// onet_amd/data.py is the NumPy statement of the same recipe and builds the two filters), and its statistics are pinned to
+// frames made by the reference's own functions (tests/golden/clutter_stats.npz):
 //
-//   white   w  = N(0,1) field from a counter-based generator (Philox4x32-10 + Box-Muller): reproducible from (seed, frame,
-//                pixel) alone, no state, any launch geometry
-//   colour  g  = Re ifft2( fft2(w) * sqrt(PSD) )                 (KD:70-81 `generate_GP_via_gaussianACF`)
-//   texture tau = gammaincinv(nu, Phi(g / std g))                (KD:83-91 `mnlt`; nu = 5: closed-form Gamma(5) CDF, Newton)
-//   speckle s  = ifft2( fft2(w') * sqrt(|f|^-0.6) ), complex     (KD:270-297)
-//   clutter a  = |s| * sqrt(tau)                                 (KD:519-520)
-//   targets    rotated 2-D Gaussian blobs added on top, label = blob > e^-2   (RG:63-175; parameters drawn on the host)
+//   white   w   = N(0,1) field from a counter-based generator (Philox4x32-10 + Box-Muller): reproducible from (seed, frame,
+//                 pixel) alone, no state, any launch geometry
+//   texture g   = Re ifft2( fft2(w) * Ht ),  tau = gammaincinv(5, Phi(g))     (KD:499-503, KD:83-91 `mnlt`; g is NOT normalised:
+//                 the recipe feeds a field of variance 1.109 to the unit-variance transform).  Ht = sqrt(fft2(R_G)) with R_G the
+//                 per-pixel root field of the Hermite-coefficient polynomial (KD:121-164, 483-497), built once on the host
+//   speckle s   = ifft2( fft2(w') * Hs ), complex,  Hs = sqrt((fx^2 + fy^2)^-0.3) on the recipe's index grid   (KD:270-297)
+//   clutter a   = | s * sqrt(tau) |                                            (KD:519-520)
+//   targets     20 rotated un-normalised Gaussians, placed ONE AFTER THE OTHER:  bg += (template > bg) * template, template =
+//               sqrt(10^(snr/10) * mean(a^2)) * kgauss;  label |= kgauss > max - 2 std   (RG:63-175, 189-209; parameters are
+//               drawn and reduced to window / quadratic form / threshold on the host: data.target_params)
+//   frame       400 x 400 (RG:186), centre crop H x W (RG:302)
 //
-// The 2-D FFT is hipFFT-free: n x n frames with n = 512, one 256-thread block per line, radix-2 Stockham in LDS, rows
-// then columns (the column pass reads a line with stride n: 2 MB per frame, L2-resident).  Memory-bound helper code, not
-// on the training path.
+// The reference colours on the 400-torus; the 2-D FFT here is hipFFT-free radix-2 (512 points, one 256-thread block per line,
+// Stockham in LDS, rows then columns), so both filters arrive as the frequency responses of the recipe's convolution kernels
+// placed on the 512-torus with wrapped lags (data._embed_kernel): inside the 400 x 400 window the fields have the recipe's
+// covariance up to the kernels' wrap-around tails (< 0.1 % of the texture kernel's energy).  Memory-bound helper code, not on
+// the training path.
 #include <cmath>
 #include "common.hpp"
 
@@ -21,7 +28,8 @@ using namespace onet;
 
 namespace {
 
-constexpr int FN = 512, FLOG = 9;
+constexpr int FN = 512, FLOG = 9;     // FFT torus
+constexpr int FR = 400;               // the recipe's frame (RG:186), a window of the torus
 
 // ---------------------------------------------------------------- Philox4x32-10
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
@@ -95,108 +103,106 @@ __global__ __launch_bounds__(256) void fft512_kernel(float2* __restrict__ data, 
     base[(int64_t)(t + 256) * elem_stride] = make_float2(buf[cur][t + 256].x * sc, buf[cur][t + 256].y * sc);
 }
 
-// spec[f][y][x] *= filt[y][x]   (filt = sqrt(PSD), real)
-__global__ __launch_bounds__(256) void clutter_filter_kernel(float2* __restrict__ spec, const float* __restrict__ filt, int64_t n, int frames) {
+// spec[f][i] *= filt[i]   (complex: the frequency response of the recipe's convolution kernel on the 512-torus)
+__global__ __launch_bounds__(256) void clutter_filter_kernel(float2* __restrict__ spec, const float2* __restrict__ filt, int64_t n, int frames) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n * frames) return;
-    const float w = filt[i % n];
-    float2 v = spec[i];
-    v.x *= w; v.y *= w;
-    spec[i] = v;
+    const float2 w = filt[i % n];
+    const float2 v = spec[i];
+    spec[i] = make_float2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
 }
 
-// sqrt(PSD) of the texture: PSD = max(Re fft2(acf), 0) with acf = exp(-(dx + dy) / corr_len), d = wrapped distance.
-// acf_spec holds fft2(acf) (computed with the kernels above); out = sqrt(max(Re, 0))
-__global__ __launch_bounds__(256) void clutter_acf_kernel(float2* __restrict__ acf, float corr_len) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= FN * FN) return;
-    const int y = i / FN, x = i % FN;
-    const float dy = (float)min(y, FN - y), dx = (float)min(x, FN - x);
-    acf[i] = make_float2(expf(-(dx + dy) / corr_len), 0.f);
-}
-__global__ __launch_bounds__(256) void clutter_sqrt_psd_kernel(const float2* __restrict__ acf_spec, float* __restrict__ filt) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < FN * FN) filt[i] = sqrtf(fmaxf(acf_spec[i].x, 0.f));
-}
-// speckle: sqrt(PSD) = (fx^2 + fy^2)^(-0.15), f = linspace(0.1, n / 10, n)   (KD:270-297)
-__global__ __launch_bounds__(256) void clutter_speckle_filter_kernel(float* __restrict__ filt) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= FN * FN) return;
-    const float fs = FN / 10.0f, step = (fs - 0.1f) / (FN - 1);
-    const float fy = 0.1f + step * (i / FN), fx = 0.1f + step * (i % FN);
-    filt[i] = powf(fx * fx + fy * fy, -0.15f);
-}
-
-// per-frame sums of (re, re^2) [mode 0] or (|z|^2 * extra) ... -> double partials[f][2]; one block per (frame, slice)
-__global__ __launch_bounds__(256) void clutter_moments_kernel(const float2* __restrict__ g, const float* __restrict__ amp, double* __restrict__ out,
-                                                              int64_t n, int slices) {
-    const int f = blockIdx.x / slices, sl = blockIdx.x % slices;
-    const int64_t per = (n + slices - 1) / slices, i0 = sl * per, i1 = min(n, i0 + per);
-    double s1 = 0.0, s2 = 0.0;
-    for (int64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-        const float v = g ? g[(int64_t)f * n + i].x : amp[(int64_t)f * n + i];
-        s1 += v;
-        s2 += (double)v * v;
-    }
-    __shared__ double sh[8];
-    double v2[2] = {s1, s2};
-    block_sum_256<double, 2>(v2, sh);
-    if (threadIdx.x == 0) {
-        atomicAdd(out + 2 * f, v2[0]);          // a handful of adds per frame; statistics only (the frames themselves are
-        atomicAdd(out + 2 * f + 1, v2[1]);      // reproducible up to the rounding of these two doubles' summation order)
-    }
-}
-
-// Gamma(5) quantile by Newton on P(5, x) = 1 - e^-x (1 + x + x^2/2 + x^3/6 + x^4/24),  p(x) = x^4 e^-x / 24
-__device__ __forceinline__ float gammaincinv5(float u) {
-    // start: Wilson-Hilferty
-    const float zq = -1.41421356f * erfcinvf(2.0f * u);                       // Phi^-1(u)
-    const float c = 1.0f - 1.0f / 45.0f + zq * 0.14907119849998599f;         // 1 - 1/(9 nu) + z / (3 sqrt(nu))
-    float x = fmaxf(5.0f * c * c * c, 1e-3f);
+// Gamma(5) quantile of Phi(z) (KD:83-91 with v = 5), by Newton from the Wilson-Hilferty start.  The lower half solves
+// P(5, x) = Phi(z), the upper half Q(5, x) = 1 - Phi(z), each from erfc of the NEAR tail, so neither loses the tail to the
+// fp32 spacing of numbers next to 1;  Q(5, x) = e^-x (1 + x + x^2/2 + x^3/6 + x^4/24),  P = 1 - Q (series below x = 1),
+// density x^4 e^-x / 24.  fp32, 5 iterations: within 1.5e-5 of scipy's gammaincinv / gammainccinv for |z| <= 7.5 (emulated in
+// NumPy float32 when the kernel was written).
+__device__ __forceinline__ float gamma5_quantile_of_normal(float z) {
+    const float c = 1.0f - 1.0f / 45.0f + z * 0.14907119849998599f;           // 1 - 1/(9 nu) + z / (3 sqrt(nu))
+    const bool upper = z > 0.f;
+    const float p = 0.5f * erfcf(fabsf(z) * 0.70710678118654752f);            // the nearer tail's probability, <= 1/2
+    // far lower tail: P(5, x) ~ x^5 / 120 (Wilson-Hilferty is off by 60 % at z = -6)
+    float x = (z < -2.5f) ? powf(120.0f * p, 0.2f) : fmaxf(5.0f * c * c * c, 0.02f);
 #pragma unroll
-    for (int it = 0; it < 6; ++it) {
+    for (int it = 0; it < 5; ++it) {
         const float e = expf(-x);
-        const float poly = 1.0f + x * (1.0f + x * (0.5f + x * (1.0f / 6.0f + x * (1.0f / 24.0f))));
-        const float cdf = 1.0f - e * poly;
-        const float pdf = e * x * x * x * x * (1.0f / 24.0f);
-        x = fmaxf(x - (cdf - u) / fmaxf(pdf, 1e-30f), 1e-6f);
+        const float x4 = x * x * x * x;
+        const float pdf = fmaxf(e * x4 * (1.0f / 24.0f), 1e-37f);
+        float step;
+        if (upper) {
+            const float q = e * (1.0f + x * (1.0f + x * (0.5f + x * (1.0f / 6.0f + x * (1.0f / 24.0f)))));
+            step = q * logf(q / p) / pdf;                                        // Newton on log Q (Q ~ e^-x: linear Newton crawls)
+        } else {
+            const float cdf = (x < 1.0f)
+                ? e * x4 * x * (1.0f / 120.0f) * (1.0f + x * (1.0f / 6.0f + x * (1.0f / 42.0f + x * (1.0f / 336.0f + x * (1.0f / 3024.0f +
+                                                                                                       x * (1.0f / 30240.0f))))))
+                : 1.0f - e * (1.0f + x * (1.0f + x * (0.5f + x * (1.0f / 6.0f + x * (1.0f / 24.0f)))));
+            step = -(cdf - p) / pdf;
+        }
+        x = fmaxf(x + fminf(fmaxf(step, -0.5f * x), 4.0f), 1e-4f);               // damped: never below half, never a wild jump
     }
     return x;
 }
 
-// amp[f][i] = |speckle[f][i]| * sqrt(gammaincinv(5, Phi(g / std)))      (KD:83-91, 519-520)
-__global__ __launch_bounds__(256) void clutter_combine_kernel(const float2* __restrict__ g, const float2* __restrict__ speckle, const double* __restrict__ mom,
-                                                              float* __restrict__ amp, int64_t n, int frames) {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= n * frames) return;
-    const int f = (int)(i / n);
-    const double m = mom[2 * f] / (double)n, var = mom[2 * f + 1] / (double)n - m * m;
-    const float z = (g[i].x) * (float)(1.0 / sqrt(var > 1e-30 ? var : 1e-30));          // data.py divides by std only (mean ~ 0)
-    float u = 0.5f * erfcf(-z * 0.70710678118654752f);
-    u = fminf(fmaxf(u, 1e-7f), 1.0f - 1e-7f);
-    const float2 s = speckle[i];
-    amp[i] = sqrtf(s.x * s.x + s.y * s.y) * sqrtf(gammaincinv5(u));
+// One block per (frame, row) of the 400 x 400 window: amp = |s| sqrt(tau) (KD:519-520), the row's sum of amp^2 (-> mean clutter
+// power, RG:192) in a fixed order, and on request the three fields themselves (statistics tests).
+__global__ __launch_bounds__(256) void clutter_combine_kernel(const float2* __restrict__ g, const float2* __restrict__ speckle,
+                                                              float* __restrict__ amp, double* __restrict__ row_power,
+                                                              float* __restrict__ fields) {
+    const int f = blockIdx.x / FR, y = blockIdx.x % FR;
+    double s2 = 0.0;
+    for (int x = threadIdx.x; x < FR; x += 256) {
+        const int64_t src = (int64_t)f * FN * FN + (int64_t)y * FN + x;
+        const float tau = gamma5_quantile_of_normal(g[src].x);
+        const float2 s = speckle[src];
+        const float a = sqrtf((s.x * s.x + s.y * s.y) * tau);
+        const int64_t dst = ((int64_t)f * FR + y) * FR + x;
+        amp[dst] = a;
+        s2 += (double)a * a;
+        if (fields) {
+            float* fp = fields + (int64_t)f * 4 * FR * FR + (int64_t)y * FR + x;
+            fp[0] = tau; fp[(int64_t)FR * FR] = s.x; fp[2ll * FR * FR] = s.y; fp[3ll * FR * FR] = a;
+        }
+    }
+    __shared__ double sh[4];
+    double v[1] = {s2};
+    block_sum_256<double, 1>(v, sh);
+    if (threadIdx.x == 0) row_power[blockIdx.x] = v[0];
 }
 
-// out[f][c = 0][y][x] (crop H x W at (y0, x0)) = amp + peak_f * sum_t blob_t;  label = any blob > e^-2
-// targets[f][t] = (cx, cy, sx, sy, cos th, sin th); peak_f = sqrt(10^(snr_f / 10) * mean(amp_f^2))
-__global__ __launch_bounds__(256) void clutter_targets_crop_kernel(const float* __restrict__ amp, const double* __restrict__ mom2, const float* __restrict__ targets,
-                                                                   const float* __restrict__ snr_db, int n_targets, float* __restrict__ out,
-                                                                   float* __restrict__ label, int frames, int H, int W, int y0, int x0) {
+// erc[f] = mean(amp_f^2): the 400 row sums of a frame added in a fixed order (bit-reproducible frames, unlike atomics)
+__global__ __launch_bounds__(64) void clutter_power_kernel(const double* __restrict__ row_power, double* __restrict__ erc) {
+    const int f = blockIdx.x;
+    double s = 0.0;
+    for (int y = threadIdx.x; y < FR; y += 64) s += row_power[(int64_t)f * FR + y];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) erc[f] = s / ((double)FR * FR);
+}
+
+// out[f][0][y][x] = the (y0 + y, x0 + x) pixel of the frame after its targets (RG:207-209: placed in order, each one seeing the
+// frame the previous ones left: bg += (template > bg) * template, RG:156-158); label = any kgauss > its threshold (RG:155,166).
+// targets[f][t] = (lx, ly, kernel_wr, kernel_hr, a, b, c, thr)
+__global__ __launch_bounds__(256) void clutter_targets_crop_kernel(const float* __restrict__ amp, const double* __restrict__ erc,
+                                                                   const float* __restrict__ targets, const float* __restrict__ snr_db,
+                                                                   int n_targets, float* __restrict__ out, float* __restrict__ label,
+                                                                   int frames, int H, int W, int y0, int x0) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= (int64_t)frames * H * W) return;
     const int f = (int)(i / ((int64_t)H * W)), p = (int)(i % ((int64_t)H * W));
     const int y = y0 + p / W, x = x0 + p % W;
-    const float power = (float)(mom2[2 * f + 1] / ((double)FN * FN));
-    const float peak = sqrtf(powf(10.0f, snr_db[f] * 0.1f) * power);
-    float v = amp[(int64_t)f * FN * FN + (int64_t)y * FN + x], lab = 0.f;
-    for (int t = 0; t < n_targets; ++t) {
-        const float* tg = targets + ((int64_t)f * n_targets + t) * 6;
-        const float dx = (float)x - tg[0], dy = (float)y - tg[1];
-        const float xr = dx * tg[4] + dy * tg[5], yr = -dx * tg[5] + dy * tg[4];
-        const float e = -0.5f * ((xr / tg[2]) * (xr / tg[2]) + (yr / tg[3]) * (yr / tg[3]));
-        v += peak * expf(e);
-        if (e > -2.0f) lab = 1.f;
+    float v = amp[((int64_t)f * FR + y) * FR + x], lab = 0.f;
+    if (n_targets > 0) {
+        const float peak = (float)sqrt(pow(10.0, (double)snr_db[f] * 0.1) * erc[f]);                        // RG:89
+        for (int t = 0; t < n_targets; ++t) {
+            const float* tg = targets + ((int64_t)f * n_targets + t) * 8;
+            const int wr = (int)tg[2], hr = (int)tg[3];
+            const int kx = x - (int)tg[0] - wr, ky = y - (int)tg[1] - hr;                                    // RG:43-45,77-85
+            if (kx < -wr || kx > wr || ky < -hr || ky > hr) continue;
+            const float kg = expf(-(tg[4] * (float)(kx * kx) + 2.0f * tg[5] * (float)(kx * ky) + tg[6] * (float)(ky * ky)));
+            const float tm = kg * peak;
+            if (tm > v) v += tm;
+            if (kg > tg[7]) lab = 1.f;
+        }
     }
     out[i] = v;
     if (label) label[i] = lab;
@@ -215,61 +221,52 @@ int fft2(float2* data, int frames, int inverse, hipStream_t st) {
 
 extern "C" {
 
-int onet_clutter_frame_size(void) { return FN; }
+int onet_clutter_fft_size(void) { return FN; }
+int onet_clutter_frame_size(void) { return FR; }
 
 int64_t onet_clutter_ws_bytes(int frames) {
-    // two complex fields [frames][n][n] + amplitude [frames][n][n] + two filters [n][n] + one complex [n][n] + moments
-    return (int64_t)frames * FN * FN * (8 + 8 + 4) + (int64_t)FN * FN * (4 + 4 + 8) + (int64_t)frames * 4 * 8 + 256;
+    // two complex fields [frames][512][512] + amplitude [frames][400][400] + row sums [frames][400] + power [frames]
+    return (int64_t)frames * FN * FN * (8 + 8) + (int64_t)frames * FR * FR * 4 + (int64_t)frames * (FR + 1) * 8 + 256;
 }
 
-int onet_clutter_generate(float* out, float* label, const float* targets, const float* snr_db, int n_targets, int frames, int H, int W,
-                          uint64_t seed, float corr_len, void* ws, int64_t ws_bytes, void* stream) {
-    ONET_REQUIRE(out && ws && (n_targets == 0 || (targets && snr_db)), "clutter_generate: null pointer");
-    ONET_REQUIRE(frames > 0 && H > 0 && W > 0 && H <= FN && W <= FN && n_targets >= 0, "clutter_generate: bad shape (H, W <= %d)", FN);
+int onet_clutter_generate(float* out, float* label, float* fields, const float* targets, const float* snr_db, int n_targets, int frames,
+                          int H, int W, uint64_t seed, const float* filt_texture, const float* filt_speckle, void* ws, int64_t ws_bytes,
+                          void* stream) {
+    ONET_REQUIRE(out && ws && filt_texture && filt_speckle && (n_targets == 0 || (targets && snr_db)), "clutter_generate: null pointer");
+    ONET_REQUIRE(frames > 0 && H > 0 && W > 0 && H <= FR && W <= FR && n_targets >= 0, "clutter_generate: bad shape (H, W <= %d)", FR);
     ONET_REQUIRE(ws_bytes >= onet_clutter_ws_bytes(frames), "clutter_generate: workspace too small");
-    ONET_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, "clutter_generate: workspace must be 16-byte aligned");
+    ONET_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0 && (reinterpret_cast<uintptr_t>(filt_texture) & 7) == 0 &&
+                 (reinterpret_cast<uintptr_t>(filt_speckle) & 7) == 0, "clutter_generate: workspace / filters must be aligned");
     hipStream_t st = as_stream(stream);
     const int64_t n = (int64_t)FN * FN;
     char* p = static_cast<char*>(ws);
     float2* gfield = reinterpret_cast<float2*>(p);  p += frames * n * 8;
     float2* sfield = reinterpret_cast<float2*>(p);  p += frames * n * 8;
-    float* amp = reinterpret_cast<float*>(p);       p += frames * n * 4;
-    float* filt_t = reinterpret_cast<float*>(p);    p += n * 4;
-    float* filt_s = reinterpret_cast<float*>(p);    p += n * 4;
-    float2* acf = reinterpret_cast<float2*>(p);     p += n * 8;
-    double* mom = reinterpret_cast<double*>(p);                              // [frames][2] texture, then [frames][2] amplitude
+    double* row_power = reinterpret_cast<double*>(p);  p += (int64_t)frames * FR * 8;
+    double* erc = reinterpret_cast<double*>(p);        p += (int64_t)frames * 8;
+    float* amp = reinterpret_cast<float*>(p);
     int rc;
-    const unsigned gb = (unsigned)cdiv(n, 256);
-    // filters
-    hipLaunchKernelGGL(clutter_acf_kernel, dim3(gb), dim3(256), 0, st, acf, corr_len);
-    if ((rc = check_launch("clutter_acf_kernel"))) return rc;
-    if ((rc = fft2(acf, 1, 0, st))) return rc;
-    hipLaunchKernelGGL(clutter_sqrt_psd_kernel, dim3(gb), dim3(256), 0, st, (const float2*)acf, filt_t);
-    hipLaunchKernelGGL(clutter_speckle_filter_kernel, dim3(gb), dim3(256), 0, st, filt_s);
-    if ((rc = check_launch("clutter filters"))) return rc;
     // white fields (independent Philox streams 0 / 1), coloured in the frequency domain
     const int64_t quads = (n + 3) / 4 * frames;
     hipLaunchKernelGGL(clutter_white_kernel, dim3((unsigned)cdiv(quads, 256)), dim3(256), 0, st, gfield, n, frames, (uint32_t)seed, (uint32_t)(seed >> 32), 0u);
     hipLaunchKernelGGL(clutter_white_kernel, dim3((unsigned)cdiv(quads, 256)), dim3(256), 0, st, sfield, n, frames, (uint32_t)seed, (uint32_t)(seed >> 32), 1u);
     if ((rc = check_launch("clutter_white_kernel"))) return rc;
-    float2* fields[2] = {gfield, sfield};
-    const float* filts[2] = {filt_t, filt_s};
+    float2* fields2[2] = {gfield, sfield};
+    const float2* filts[2] = {reinterpret_cast<const float2*>(filt_texture), reinterpret_cast<const float2*>(filt_speckle)};
     for (int k = 0; k < 2; ++k) {
-        if ((rc = fft2(fields[k], frames, 0, st))) return rc;
-        hipLaunchKernelGGL(clutter_filter_kernel, dim3((unsigned)cdiv(n * frames, 256)), dim3(256), 0, st, fields[k], filts[k], n, frames);
+        if ((rc = fft2(fields2[k], frames, 0, st))) return rc;
+        hipLaunchKernelGGL(clutter_filter_kernel, dim3((unsigned)cdiv(n * frames, 256)), dim3(256), 0, st, fields2[k], filts[k], n, frames);
         if ((rc = check_launch("clutter_filter_kernel"))) return rc;
-        if ((rc = fft2(fields[k], frames, 1, st))) return rc;
+        if ((rc = fft2(fields2[k], frames, 1, st))) return rc;
     }
-    if (hipMemsetAsync(mom, 0, (size_t)frames * 4 * 8, st) != hipSuccess) { set_error("clutter_generate: memset failed"); return ONET_EHIP; }
-    const int slices = 16;
-    hipLaunchKernelGGL(clutter_moments_kernel, dim3((unsigned)(frames * slices)), dim3(256), 0, st, (const float2*)gfield, (const float*)nullptr, mom, n, slices);
-    hipLaunchKernelGGL(clutter_combine_kernel, dim3((unsigned)cdiv(n * frames, 256)), dim3(256), 0, st, (const float2*)gfield, (const float2*)sfield, (const double*)mom,
-                       amp, n, frames);
-    hipLaunchKernelGGL(clutter_moments_kernel, dim3((unsigned)(frames * slices)), dim3(256), 0, st, (const float2*)nullptr, (const float*)amp, mom + 2 * frames, n, slices);
+    hipLaunchKernelGGL(clutter_combine_kernel, dim3((unsigned)(frames * FR)), dim3(256), 0, st, (const float2*)gfield, (const float2*)sfield, amp,
+                       row_power, fields);
+    hipLaunchKernelGGL(clutter_power_kernel, dim3((unsigned)frames), dim3(64), 0, st, (const double*)row_power, erc);
     if ((rc = check_launch("clutter_combine"))) return rc;
-    const int y0 = (FN - H) / 2, x0 = (FN - W) / 2;
+    // torchvision CenterCrop (RG:302): int(round((400 - H) / 2))
+    const int y0 = (int)lrint((FR - H) / 2.0), x0 = (int)lrint((FR - W) / 2.0);
     hipLaunchKernelGGL(clutter_targets_crop_kernel, dim3((unsigned)cdiv((int64_t)frames * H * W, 256)), dim3(256), 0, st, (const float*)amp,
-                       (const double*)(mom + 2 * frames), targets, snr_db, n_targets, out, label, frames, H, W, y0, x0);
+                       (const double*)erc, targets, snr_db, n_targets, out, label, frames, H, W, y0, x0);
     return check_launch("clutter_targets_crop_kernel");
 }
 

@@ -71,16 +71,28 @@ def _dc_prefix(block: str) -> str:
     return f"{block}.conv.double_conv"
 
 
-def param_table(in_chns: int = 1):
+def unet_channels(bilinear: bool = False):
+    """(encoder rows, decoder rows) of UNet.__init__ (OV:111-120): encoder (block, cin, cout); decoder (block, cin, cout,
+    mid).  bilinear=True (OV:115,83-84): factor 2 -- down4 ends at 512 channels, every Up halves its output once more and its
+    DoubleConv gets mid_channels = in_channels // 2; there is no ConvTranspose2d."""
+    if not bilinear:
+        return ENC, [(n, ci, co, co) for n, ci, co in DEC]
+    enc = ENC[:4] + [("down4", 512, 512)]
+    dec = [("up1", 1024, 256, 512), ("up2", 512, 128, 256), ("up3", 256, 64, 128), ("up4", 128, 64, 64)]
+    return enc, dec
+
+
+def param_table(in_chns: int = 1, bilinear: bool = False):
     """Ordered (name, shape, kind) for one UNet, in nn.Module registration order.
 
     kinds: conv | bn_w | bn_b | bn_rm | bn_rv | bn_nbt | convT_w | convT_b.
-    116 entries (SURVEY.md §5 checkpoint row)."""
+    116 entries (SURVEY.md §5 checkpoint row); bilinear=True (OV:83-84): no `up.*` rows, 108 entries."""
     rows = []
 
-    def dc(block, cin, cout):
+    def dc(block, cin, cout, mid=None):
         p = _dc_prefix(block)
-        for idx, (ci, co) in ((0, (cin, cout)), (3, (cout, cout))):
+        mid = cout if mid is None else mid
+        for idx, (ci, co) in ((0, (cin, mid)), (3, (mid, cout))):
             rows.append((f"{p}.{idx}.weight", (co, ci, 3, 3), "conv"))
             b = idx + 1
             rows.append((f"{p}.{b}.weight", (co,), "bn_w"))
@@ -89,26 +101,29 @@ def param_table(in_chns: int = 1):
             rows.append((f"{p}.{b}.running_var", (co,), "bn_rv"))
             rows.append((f"{p}.{b}.num_batches_tracked", (), "bn_nbt"))
 
-    for name, cin, cout in ENC:
+    enc, dec = unet_channels(bilinear)
+    for name, cin, cout in enc:
         dc(name, in_chns if cin is None else cin, cout)
-    for name, cin, cout in DEC:
-        rows.append((f"{name}.up.weight", (cin, cin // 2, 2, 2), "convT_w"))
-        rows.append((f"{name}.up.bias", (cin // 2,), "convT_b"))
-        dc(name, cin, cout)
+    for name, cin, cout, mid in dec:
+        if not bilinear:
+            rows.append((f"{name}.up.weight", (cin, cin // 2, 2, 2), "convT_w"))
+            rows.append((f"{name}.up.bias", (cin // 2,), "convT_b"))
+        dc(name, cin, cout, mid)
     return rows
 
 
 HEAD_BN = ("inc.double_conv.4", "up4.conv.double_conv.4")     # the BatchNorms whose outputs are L and H of the head
 
 
-def det_state_dict(in_chns: int = 1, seed: int = 1981, randomize_running: bool = True, head_gain: float = 1.0):
+def det_state_dict(in_chns: int = 1, seed: int = 1981, randomize_running: bool = True, head_gain: float = 1.0,
+                   bilinear: bool = False):
     """Deterministic UNet state (un-prefixed keys), independent of torch RNG.
 
     head_gain < 1 scales gamma and beta of the two BatchNorms that feed the head (OV:176-177), i.e. L and H and with
     them |V| ~ head_gain^2: at head_gain = 1 the initial logits reach |V| ~ 47 and the 2-way softmax is saturated on
     a fifth of the pixels; 0.3 gives |V| <= 5 (no pixel beyond S = 0.95)."""
     sd = OrderedDict()
-    for name, shape, kind in param_table(in_chns):
+    for name, shape, kind in param_table(in_chns, bilinear):
         rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
         if kind == "conv":
             fan_in = shape[1] * 9
@@ -244,8 +259,9 @@ def upsample_cat(x1, x2, st, block, bilinear=False):
     return torch.cat([x2, u], dim=1)       # skip first, upsampled second (OV:100)
 
 
-def unet_pass(x, st, training=True, routing=None):
-    """UNet.forward (OV:142-153): returns (x1, y1) = (first-block features, last-block features)."""
+def unet_pass(x, st, training=True, routing=None, bilinear=False):
+    """UNet.forward (OV:142-153): returns (x1, y1) = (first-block features, last-block features).
+    bilinear: the nn.Upsample variant of Up (OV:83-84; Onet itself always builds bilinear=False, OV:162)."""
     feats = [_double_conv(x, st, "inc", training, routing)]
     for name, _, _ in ENC[1:]:
         pooled = F.max_pool2d(feats[-1], 2) if routing is None else routing.maxpool2(feats[-1])
@@ -253,7 +269,7 @@ def unet_pass(x, st, training=True, routing=None):
     y = feats[-1]
     for lvl, (name, _, _) in enumerate(DEC):
         skip = feats[3 - lvl]
-        y = _double_conv(upsample_cat(y, skip, st, name), st, name, training, routing)
+        y = _double_conv(upsample_cat(y, skip, st, name, bilinear), st, name, training, routing)
     return feats[0], y
 
 

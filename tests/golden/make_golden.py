@@ -360,22 +360,59 @@ def run_eval_side():
     print("eval_side", {n: out[f"{n}_metrics"].round(4).tolist() for n in names})
 
 
-def run_wire_formats(ov):
-    """(1) key list of the REAL Onet state_dict (names, shapes, dtypes; 232 entries, TS:264) and of a checkpoint dict as
-    the trainers write it; (2) a small data file written by the reference's own writer `prepare_data` (RG:300-324) --
-    with the frame count per PSNR cut from 150 to 2 and a 48x48 centre crop so that the fixture stays small (the
-    writer's hard-coded `psnrs.extend([psnr] * 150)` is left as it is: 1650 PSNR entries for 22 frames)."""
-    import json
-    sd = ov.Onet(in_chns=1, binit=True, bshare=True).state_dict()
-    sd3 = ov.Onet(in_chns=3, binit=True, bshare=False).state_dict()
-    spec = {"onet_c1_share": [[k, list(v.shape), str(v.dtype)] for k, v in sd.items()],
-            "onet_c3_noshare": [[k, list(v.shape), str(v.dtype)] for k, v in sd3.items()],
-            "checkpoint_keys_sim": ["net", "epoch"], "checkpoint_keys_zy3": ["net", "save_epoch"]}
-    json.dump(spec, open(os.path.join(HERE, "state_dict_keys.json"), "w"))
+def unet_loss(x1, y1):
+    """a scalar the bare-UNet cases differentiate (the reference has no loss for a UNet on its own): couples both outputs"""
+    return (x1 * y1).mean() + 0.5 * (y1 * y1).mean()
+
+
+def run_unet_bilinear(ov, tag="unet_bilinear_b4_c1_40", B=4, C=1, H=40, W=40):
+    """A full `UNet(bilinear=True)` of the REAL reference (OV:104-153 with the nn.Upsample variant of Up, OV:83-84, incl. the
+    F.pad path: 2 -> 4 against a 5-pixel skip): train-mode forward, `unet_loss`, backward -- in fp32 (decisions recorded),
+    fp64 deciding freely and fp64 replaying the fp32 decisions.  Pins oracle.unet_pass(bilinear=True) and its routing."""
+    X = orc.det_input(B, C, H, W)
+    sd = orc.det_state_dict(C, 1981, bilinear=True)
+
+    def build(dtype, routing=None):
+        m = ov.UNet(n_channels=C, n_classes=1, binit=True, bilinear=True)
+        m.load_state_dict(sd)                       # strict: the oracle's 108-row parameter table IS the reference's key set
+        m = m.to(dtype).train()
+        if routing is not None:
+            install_routing(m, routing)
+        x1, y1 = m(X.to(dtype))
+        loss = unet_loss(x1, y1)
+        loss.backward()
+        return m, x1, y1, loss
+
+    r = orc.Routing()
+    m32, x1, y1, l32 = build(torch.float32, r)
+    named = [(n, p.grad) for n, p in m32.named_parameters()]
+    out = {"meta": np.array([B, C, H, W]), "loss": np.float64(l32.item()), "x1": x1.detach().numpy(), "y1": y1.detach().numpy(),
+           "grad_names": np.array([n for n, _ in named])}
+    out["grad_norms"], out["grad_vals"], out["grad_offs"] = grad_samples(named)
+    out["bn_rm"], out["bn_rv"], out["bn_nbt"] = bn_digest(m32)
+    m64, _, _, l64 = build(torch.float64)
+    out["loss64"] = np.float64(l64.item())
+    out["grad_norms64"], out["grad_vals64"], _ = grad_samples([(n, p.grad) for n, p in m64.named_parameters()])
+    m64r, _, _, l64r = build(torch.float64, r.replay())
+    out["loss64r"] = np.float64(l64r.item())
+    out["grad_norms64r"], out["grad_vals64r"], _ = grad_samples([(n, p.grad) for n, p in m64r.named_parameters()])
+    out["routing_audit"] = np.array([[a[1], a[2], a[3]] for a in r.audit], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, f"{tag}.npz"), **out)
+    o = out["grad_offs"]
+
+    def worst(a, b):
+        return max(np.linalg.norm(a[o[i]:o[i + 1]] - b[o[i]:o[i + 1]]) / np.linalg.norm(b[o[i]:o[i + 1]]) for i in range(len(o) - 1))
+    print(tag, "loss", float(l32), float(l64), float(l64r), "| fp32 vs truth %.2e, fp32 vs routed %.2e, flips %d" % (
+        worst(out["grad_vals"], out["grad_vals64"]), worst(out["grad_vals"], out["grad_vals64r"]), int(out["routing_audit"][:, 0].sum())))
+
+
+def import_generators():
+    """-> (KD, RG): the reference's clutter / frame generator modules (torchvision is not installed: the one transform RG:302
+    uses, CenterCrop, is supplied)."""
     tv = types.ModuleType("torchvision")
     tvt = types.ModuleType("torchvision.transforms")
 
-    class CenterCrop:                                   # torchvision is not installed: the one transform RG:302 uses
+    class CenterCrop:
         def __init__(self, size):
             self.size = size
 
@@ -391,9 +428,95 @@ def run_wire_formats(ov):
     cwd = os.getcwd()
     try:
         os.chdir("/tmp")
+        import K_distributed_SeaClutter_Simulation_20210919 as kd
         import Rayleigh_bg_Gaussian_EOT_generator_20230208 as rg
     finally:
         os.chdir(cwd)
+    return kd, rg
+
+
+def run_clutter_stats(n_frames=24):
+    """SURVEY 8f row 4 pinned to the reference: `n_frames` K-clutter frames with targets made by the reference's OWN frame
+    function `get_k_frame` (RG:177-216 -> KD:469-526 `generate_K_distributed_noise`, KD:270-297, RG:63-175) after
+    np.random.seed(1981), PSNR cycling over TS:668's (0, 1, 2); the texture, speckle and clutter fields are picked up on the
+    way out of the reference's functions.  Stored: one value per frame of every statistic of tests/clutter_stats.py, the
+    per-frame polynomial coefficients of KD:491-492, and how far this build's closed-form root rule (onet_amd.data.
+    gaussian_acf_field) is from the reference's numpy.roots field for the same coefficients (frame 0)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import clutter_stats as cs
+    from onet_amd import data as odata
+    kd, rg = import_generators()
+    seen = {}
+    real_k, real_s, real_c, real_solve = (kd.generate_K_distributed_noise, kd.generate_correlated_Gaussian_via_expdecay,
+                                          kd.coeff_acf_polyn, kd.solve_acf_polyn)
+
+    def k_noise(*a, **k):
+        amp, tau = real_k(*a, **k)
+        seen["amp"], seen["tau"] = amp.copy(), tau.copy()
+        return amp, tau
+
+    def speckle(*a, **k):
+        seen["speckle"] = real_s(*a, **k)
+        return seen["speckle"]
+
+    def coeffs(*a, **k):
+        c = real_c(*a, **k)
+        seen["coeffs"] = np.array(c) / c[-1]
+        return c
+
+    def solve(gamma_acf, co):
+        out = real_solve(gamma_acf, co)
+        seen.setdefault("solve0", (np.array(co, dtype=np.float64), out.copy()))
+        return out
+
+    kd.generate_K_distributed_noise, kd.generate_correlated_Gaussian_via_expdecay = k_noise, speckle
+    kd.coeff_acf_polyn, kd.solve_acf_polyn = coeffs, solve
+    rows, coefs = [], []
+    np.random.seed(1981)
+    try:
+        for i in range(n_frames):
+            snr = (0, 1, 2)[i % 3]
+            frame, mask = rg.get_k_frame(snr)
+            r = {"snr": float(snr)}
+            r.update(cs.texture_stats(seen["tau"]))
+            r.update(cs.speckle_stats(seen["speckle"]))
+            r.update(cs.amplitude_stats(seen["amp"].astype(np.float32)))
+            r.update(cs.frame_stats(frame, np.asarray(mask, dtype=np.float64), seen["amp"].astype(np.float32)))
+            rows.append(r)
+            coefs.append(seen["coeffs"])
+            print("clutter frame", i, {k: round(v, 4) for k, v in r.items() if k in ("tex_var", "amp_m4_ratio", "lab_frac", "scr_db")},
+                  flush=True)
+    finally:
+        kd.generate_K_distributed_noise, kd.generate_correlated_Gaussian_via_expdecay = real_k, real_s
+        kd.coeff_acf_polyn, kd.solve_acf_polyn = real_c, real_solve
+    # the closed-form root rule against numpy.roots, on the reference's own field and coefficients (frame 0)
+    co0, field0 = seen["solve0"]
+    odata._COEFFS[5.0] = (co0[0], co0[1], 1.0)
+    mine = odata.gaussian_acf_field(400, 5.0)
+    del odata._COEFFS[5.0]
+    root_rule_err = float(np.abs(mine - field0).max())
+    out = {k: v for k, v in cs.collect(rows).items()}
+    out["poly_coeffs"] = np.asarray(coefs, dtype=np.float64)
+    out["root_rule_max_abs_err"] = np.float64(root_rule_err)
+    out["quadrature_coeffs"] = np.asarray(odata.acf_poly_coeffs(5.0), dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "clutter_stats.npz"), **out)
+    print("clutter_stats:", n_frames, "frames; coefficient mean", out["poly_coeffs"].mean(0), "std", out["poly_coeffs"].std(0),
+          "quadrature", out["quadrature_coeffs"], "root rule err", root_rule_err)
+
+
+def run_wire_formats(ov):
+    """(1) key list of the REAL Onet state_dict (names, shapes, dtypes; 232 entries, TS:264) and of a checkpoint dict as
+    the trainers write it; (2) a small data file written by the reference's own writer `prepare_data` (RG:300-324) --
+    with the frame count per PSNR cut from 150 to 2 and a 48x48 centre crop so that the fixture stays small (the
+    writer's hard-coded `psnrs.extend([psnr] * 150)` is left as it is: 1650 PSNR entries for 22 frames)."""
+    import json
+    sd = ov.Onet(in_chns=1, binit=True, bshare=True).state_dict()
+    sd3 = ov.Onet(in_chns=3, binit=True, bshare=False).state_dict()
+    spec = {"onet_c1_share": [[k, list(v.shape), str(v.dtype)] for k, v in sd.items()],
+            "onet_c3_noshare": [[k, list(v.shape), str(v.dtype)] for k, v in sd3.items()],
+            "checkpoint_keys_sim": ["net", "epoch"], "checkpoint_keys_zy3": ["net", "save_epoch"]}
+    json.dump(spec, open(os.path.join(HERE, "state_dict_keys.json"), "w"))
+    rg = import_generators()[1]
     real = rg.prepare_frames
     rg.prepare_frames = lambda type="rayleigh", fnums=4, snr=10: real(type=type, fnums=2, snr=snr)
     np.random.seed(1981)
@@ -409,6 +532,12 @@ if __name__ == "__main__":
     if os.environ.get("GOLDEN_ONLY") == "evalside":
         run_eval_side()
         run_wire_formats(ov)
+        sys.exit(0)
+    if os.environ.get("GOLDEN_ONLY") == "bilinear":
+        run_unet_bilinear(ov)
+        sys.exit(0)
+    if os.environ.get("GOLDEN_ONLY") == "clutter":
+        run_clutter_stats()
         sys.exit(0)
     if os.environ.get("GOLDEN_ONLY") == "up":
         run_up_block(ov, False, "convT_pad")
@@ -436,7 +565,9 @@ if __name__ == "__main__":
     run_case(ov, "b2_c1_256", 2, 1, 256, 256)         # BASELINE config C1 shape
     run_up_block(ov, False, "convT_pad")
     run_up_block(ov, True, "bilinear_pad")
+    run_unet_bilinear(ov)
     run_routed_case(ov, "routed_b8_c1_128", 8, 1, 128, 128)   # unsaturated head, large N, full / strided gradients
     run_routed_case(ov, "routed_b4_c1_256", 4, 1, 256, 256)
     run_eval_side()
     run_wire_formats(ov)
+    run_clutter_stats()

@@ -39,44 +39,63 @@ def _to64(sd):
     return {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
 
 
-def _hip_step_recording(m, X, monkeypatch, keep):
-    """One HIP training step (TS:210-217 order) with the output of every Conv-BN-ReLU unit captured for the images
-    `keep` (indices into the batch) -> (outputs, loss, acts in the oracle's call order: 18 units of the X pass, then
-    18 of the 1-X pass)."""
+def _record_units(monkeypatch, B, keep, device):
+    """Capture the output of every Conv-BN-ReLU unit for the images `keep`.  -> (rec, finish): `finish()` restores the
+    hook and returns the activations in the ORACLE's call order (18 units of the X pass, then 18 of the 1-X pass),
+    whichever way the model ran: twin batch (18 launches of 2B images: both halves in one) or two passes (36 launches of B)."""
     from onet_amd import functional as Fn
-    from onet_amd import ops
-    assert ops.TWIN and m.dwnu is m.topu
-    B = X.shape[0]
-    idx = torch.tensor(list(keep), device=X.device)
+    idx = torch.tensor(list(keep), device=device)
     rec = []
     real = Fn.ConvBNReLUFn.apply
 
     def apply(*a, **k):
         out = real(*a, **k)
         o = out.detach()
-        assert o.shape[0] == 2 * B
-        rec.append((o[idx].cpu(), o[idx + B].cpu()))
+        if o.shape[0] == 2 * B:
+            rec.append((o[idx].cpu(), o[idx + B].cpu()))
+        else:
+            assert o.shape[0] == B
+            rec.append((o[idx].cpu(),))
         return out
 
     monkeypatch.setattr(Fn.ConvBNReLUFn, "apply", staticmethod(apply))
+
+    def finish():
+        monkeypatch.setattr(Fn.ConvBNReLUFn, "apply", real)
+        if all(len(r) == 2 for r in rec):
+            return [r[0] for r in rec] + [r[1] for r in rec]
+        assert all(len(r) == 1 for r in rec)
+        return [r[0] for r in rec]
+
+    return rec, finish
+
+
+def _hip_step_recording(m, X, monkeypatch, keep):
+    """One HIP training step (TS:210-217 order) with every unit's output captured -> (outputs, loss, acts in the oracle's
+    call order)."""
+    rec, finish = _record_units(monkeypatch, X.shape[0], keep, X.device)
     m.zero_grad()
     Lt, Vt, Ld, Vd, S = m(X)
     loss = m.compute_loss(Lt, S[:, 0].unsqueeze(1), Ld, S[:, 1].unsqueeze(1))
     loss.backward()
-    monkeypatch.setattr(Fn.ConvBNReLUFn, "apply", real)
-    assert len(rec) == 18
-    return (Lt, Vt, Ld, Vd, S), loss, [r[0] for r in rec] + [r[1] for r in rec]
+    acts = finish()
+    assert len(acts) == 36
+    return (Lt, Vt, Ld, Vd, S), loss, acts
 
 
-def _routed_oracle(Xcpu, C, seed, gain, acts):
+def _routed_oracle(Xcpu, C, seed, gain, acts, bshare=True):
     r = orc.Routing.from_activations(acts)
     top = orc.clone_state(_to64(orc.det_state_dict(C, seed, head_gain=gain)))
-    outs, loss, grads = orc.train_mode_step(Xcpu.double(), top, routing=r)
+    dwn = None if bshare else orc.clone_state(_to64(orc.det_state_dict(C, seed + 1, head_gain=gain)))
+    outs, loss, grads = orc.train_mode_step(Xcpu.double(), top, dwn, routing=r)
     return outs, loss, grads, r
 
 
-def _check(m, grads64, routing, what):
-    named = dict(m.topu.named_parameters())
+def _check(m, grads64, routing, what, named=None):
+    """grads64: the oracle's dict -- un-prefixed keys = the top (or only) U-Net, "dwnu." + key = an unshared down U-Net"""
+    if named is None:
+        named = {(k[5:] if k.startswith("topu.") else k): v for k, v in m.named_parameters()}
+    assert set(grads64) == set(named), set(grads64) ^ set(named)
     worst = (0.0, "")
     for k, t in grads64.items():
         a = named[k].grad.detach().cpu().double()
@@ -94,10 +113,10 @@ def _check(m, grads64, routing, what):
           f"{sum(a[2] for a in routing.audit)} decisions differ from the exact ones, farthest {dist:.1e} from the switch")
 
 
-def _model(C, gain, dev, seed=1981):
+def _model(C, gain, dev, seed=1981, bshare=True):
     import Onet_vanilla_20240606 as ov
-    m = ov.Onet(in_chns=C, binit=True, bshare=True)
-    m.load_state_dict(orc.onet_state_dict(C, seed, True, head_gain=gain))
+    m = ov.Onet(in_chns=C, binit=True, bshare=bshare)
+    m.load_state_dict(orc.onet_state_dict(C, seed, bshare, head_gain=gain))
     return m.to(dev).train()
 
 
@@ -204,3 +223,56 @@ def test_benchmark_dispatch_b32_256_every_gradient_element(dev, monkeypatch):
     _, oloss, g64, r = _routed_oracle(x2, 1, 1981, 1.0, acts)
     assert abs(loss.item() - float(oloss)) <= 1e-5 * abs(float(oloss))
     _check(m, g64, r, "B=32 256x256 benchmark dispatch")
+
+
+@pytest.mark.parametrize("mode", ["noshare", "two-pass", "two-pass-winograd4"])
+def test_every_gradient_element_two_pass_and_unshared(dev, mode, monkeypatch):
+    """The reference's own order -- topu(X), then dwnu(1 - X) (OV:174-185) -- instead of the twin batch, at the same 2e-4
+    on every element: "noshare" = `Onet(bshare=False)` (OV:165-166: two U-Nets, 124 parameter gradients, no sum over the
+    passes), "two-pass" = shared weights with `settings.twin = False` (ONET_TWIN=0: autograd sums the two passes'
+    contributions; the weight-gradient slots are taken once and added to once)."""
+    from onet_amd import ops
+    B, C, H, W, gain = 4, 1, 64, 64, 0.3
+    bshare = mode != "noshare"
+    X = orc.det_input(B, C, H, W)
+    m = _model(C, gain, dev, bshare=bshare)
+    m.settings = ops.Settings(twin=False, conv="winograd4" if mode.endswith("winograd4") else None)
+    (Lt, Vt, Ld, Vd, S), loss, acts = _hip_step_recording(m, X.to(dev), monkeypatch, range(B))
+    (oLt, oVt, oLd, oVd, oS), oloss, g64, r = _routed_oracle(X, C, 1981, gain, acts, bshare=bshare)
+    assert len(g64) == (62 if bshare else 124)
+    assert abs(loss.item() - float(oloss)) <= 1e-5 * abs(float(oloss))
+    assert float((Vd.detach().cpu().double() - oVd.detach()).abs().max()) <= 1e-4 * float(oVd.detach().abs().max())
+    _check(m, g64, r, mode)
+
+
+@pytest.mark.parametrize("algo", ["auto", "direct"])
+def test_every_gradient_element_bilinear_unet(dev, algo, monkeypatch):
+    """A full `UNet(bilinear=True)` (OV:83-84 inside OV:104-153; incl. the F.pad path at 40 x 40) on its own: forward,
+    a scalar coupling both outputs, backward -- every element of its 54 parameter gradients against the fp64 oracle under the
+    HIP run's decisions; forward against the golden recorded from the REAL reference's UNet(bilinear=True)."""
+    import Onet_vanilla_20240606 as ov
+    from onet_amd import ops
+    from test_oracle_routing import unet_loss
+    monkeypatch.setattr(ops, "CONV_ALGO", algo)
+    g = np.load(os.path.join(G, "unet_bilinear_b4_c1_40.npz"))
+    B, C, H, W = [int(v) for v in g["meta"]]
+    X = orc.det_input(B, C, H, W)
+    m = ov.UNet(n_channels=C, n_classes=1, binit=True, bilinear=True)
+    m.load_state_dict(orc.det_state_dict(C, 1981, bilinear=True))
+    m = m.to(dev).train()
+    rec, finish = _record_units(monkeypatch, B, range(B), dev)
+    m.zero_grad()
+    x1, y1 = m(X.to(dev))
+    loss = unet_loss(x1, y1)
+    loss.backward()
+    acts = finish()
+    assert len(acts) == 18
+    assert abs(loss.item() - float(g["loss"])) <= 1e-3 * abs(float(g["loss"]))
+    assert np.abs(y1.detach().cpu().numpy() - g["y1"]).max() <= 1e-3 * np.abs(g["y1"]).max()
+    r = orc.Routing.from_activations(acts)
+    sd = orc.clone_state(_to64(orc.det_state_dict(C, 1981, bilinear=True)))
+    ox1, oy1 = orc.unet_pass(X.double(), sd, True, r, True)
+    oloss = unet_loss(ox1, oy1)
+    oloss.backward()
+    assert abs(loss.item() - float(oloss)) <= 1e-5 * abs(float(oloss))
+    _check(m, {k: v.grad for k, v in sd.items() if v.requires_grad}, r, f"UNet(bilinear=True)/{algo}", named=dict(m.named_parameters()))

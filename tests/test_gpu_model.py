@@ -791,3 +791,36 @@ def test_twin_batch_input_gradient(dev, monkeypatch):
         m.compute_loss(Lt, S[:, 0:1], Ld, S[:, 1:2]).backward()
         g[twin] = X.grad.detach().clone()
     assert float((g[False] - g[True]).norm()) <= 2e-5 * float(g[False].norm()) + 1e-12
+
+
+def test_two_models_with_different_settings_in_one_process(dev):
+    """The conv algorithm / precision / twin mode travel with the MODEL (`Onet.settings`, captured by every autograd Function for
+    its backward), not in process globals: two models with different settings, their forwards, losses and backwards interleaved in
+    one process, give bit for bit what each gives alone."""
+    from onet_amd import ops
+    X = orc.det_input(2, 1, 64, 64, seed=21).to(dev)
+    cfgs = {"direct2pass": ops.Settings(conv="direct", twin=False), "bf16": ops.Settings(conv="bf16"),
+            "wino4": ops.Settings(conv="winograd4")}
+
+    def alone(st):
+        m = _model(1, True, dev)
+        m.settings = st
+        (Lt, Vt, Ld, Vd, S), loss = _step(m, X)
+        return loss.detach().clone(), S.detach().clone(), [p.grad.detach().clone() for p in m.parameters()]
+
+    ref = {k: alone(st) for k, st in cfgs.items()}
+    assert not torch.equal(ref["direct2pass"][1], ref["bf16"][1])       # the settings do select different kernels
+    ms = {k: _model(1, True, dev) for k in cfgs}
+    for k, m in ms.items():
+        m.settings = cfgs[k]
+        m.zero_grad()
+    outs = {k: ms[k](X) for k in ("direct2pass", "bf16", "wino4")}
+    losses = {k: ms[k].compute_loss(outs[k][0], outs[k][4][:, 0:1], outs[k][2], outs[k][4][:, 1:2]) for k in ("wino4", "direct2pass", "bf16")}
+    for k in ("bf16", "wino4", "direct2pass"):                           # backward in yet another order
+        losses[k].backward()
+    for k, (rl, rS, rg) in ref.items():
+        assert torch.equal(outs[k][4], rS), k
+        assert torch.equal(losses[k].detach(), rl), k
+        for g, p in zip(rg, ms[k].parameters()):
+            assert torch.equal(p.grad, g), k
+    assert ops.active_settings() is None

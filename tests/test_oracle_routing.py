@@ -100,3 +100,45 @@ def test_routing_from_activations_equals_recorded_routing():
     assert all(a[1] == 0 for a in r2.audit)
     for k in g_rec:
         assert torch.allclose(g_rec[k], g_rep[k], rtol=1e-6, atol=1e-9), k
+
+
+def unet_loss(x1, y1):
+    """the scalar tests/golden/make_golden.py::unet_loss differentiates for a bare UNet"""
+    return (x1 * y1).mean() + 0.5 * (y1 * y1).mean()
+
+
+def unet_step(X, sd, bilinear, routing=None):
+    x1, y1 = orc.unet_pass(X, sd, True, routing, bilinear)
+    loss = unet_loss(x1, y1)
+    loss.backward()
+    return x1, y1, loss, {k: v.grad for k, v in sd.items() if v.requires_grad}
+
+
+def test_bilinear_unet_oracle_matches_reference():
+    """oracle.unet_pass(bilinear=True) -- the nn.Upsample variant of Up inside a FULL UNet (OV:83-84, 115-120; F.pad path
+    2 -> 4 against a 5-pixel skip) -- pinned to the real reference's `UNet(bilinear=True)`: parameter table == its state_dict
+    (the golden was minted with a strict load_state_dict), fp32 outputs / loss / gradients, and the fp64 evaluation under the
+    fp32 run's decisions."""
+    g = np.load(os.path.join(G, "unet_bilinear_b4_c1_40.npz"))
+    B, C, H, W = [int(v) for v in g["meta"]]
+    names, offs = [str(n) for n in g["grad_names"]], g["grad_offs"]
+    X = orc.det_input(B, C, H, W)
+    r = orc.Routing()
+    sd = orc.clone_state(orc.det_state_dict(C, 1981, bilinear=True))
+    assert [k for k, v in sd.items() if v.requires_grad] == names and len(sd) == 108
+    x1, y1, loss, g32 = unet_step(X, sd, True, r)
+    assert abs(float(loss) - float(g["loss"])) <= 2e-6 * abs(float(g["loss"]))
+    np.testing.assert_allclose(x1.detach().numpy(), g["x1"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(y1.detach().numpy(), g["y1"], rtol=1e-4, atol=1e-5)
+
+    def samples(grads):
+        return np.concatenate([(lambda t: (t if t.numel() <= 4096 else t[:: t.numel() // 1024][:1024]).numpy())(
+            grads[n].detach().reshape(-1).double()) for n in names])
+
+    assert _worst(samples(g32), g["grad_vals"], offs) <= 2e-4
+    sd64 = orc.clone_state(_to64(orc.det_state_dict(C, 1981, bilinear=True)))
+    _, _, loss64r, g64r = unet_step(X.double(), sd64, True, r.replay())
+    assert abs(float(loss64r) - float(g["loss64r"])) <= 1e-10 * abs(float(g["loss64r"]))
+    assert _worst(samples(g64r), g["grad_vals64r"], offs) <= 1e-7
+    e_routed, e_free = _worst(g["grad_vals"], g["grad_vals64r"], offs), _worst(g["grad_vals"], g["grad_vals64"], offs)
+    assert e_routed <= 1e-4 and e_free >= 1e-3, (e_routed, e_free)
