@@ -49,9 +49,11 @@ def split_train_test(n, seed=1981, frac=0.9):
 
 
 def load_zy3_dict(path):
-    """{id: {'true_color': [3,H,W], 'mask': [H,W]}} -> (ids, X [N,3,H,W] f32, masks [N,H,W] f32)."""
+    """{id: {'true_color': [3,H,W], 'mask': [H,W]}} -> (ids, X [N,3,H,W] f32, masks [N,H,W] f32), the items in the file's own
+    (insertion) order: the reference's datasets index `list(data_dict.keys())` (DZ:139-141, test branch DZ:163-169 returns the
+    stored `true_color` / `mask` tensors as they are).  Reads what DZ:92-122 reads: a torch-saved dict."""
     d = torch.load(path, map_location="cpu")
-    ids = sorted(d.keys())
+    ids = list(d.keys())
     X = torch.stack([torch.as_tensor(d[k]["true_color"], dtype=torch.float32) for k in ids])
     M = torch.stack([torch.as_tensor(d[k]["mask"], dtype=torch.float32) for k in ids])
     return ids, X, M

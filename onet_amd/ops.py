@@ -408,7 +408,7 @@ def _wino_legal(Cin, Cout):
 def _in_buffer_range(Cin, Cout, H, W):
     """The F(4x4) and bf16 kernels address ONE image (inside a concat buffer of up to twice its channels) through a
     32-bit buffer resource: their entry points reject operands beyond 2 GiB, so the dispatch does not select them there."""
-    return (2 * max(Cin, Cout) + 16) * H * W * 4 < 2 ** 31 and (max(Cin, Cout) + 16) * 36 * min(Cin, Cout) * 4 < 2 ** 31
+    return (2 * max(Cin, Cout) + 16) * H * W * 4 < 2 ** 31 and (max(Cin, Cout) + 16) * 36 * (max(Cin, Cout) + 63) * 4 < 2 ** 31
 
 
 def conv3x3_algo(B, Cin, Cout, H, W):
@@ -598,12 +598,13 @@ def conv3x3_winograd(x, wq, Cout, out=None):
 
 
 def pack3x3_winograd4(w):
-    """F(4x4,3x3) transformed weights: (fwd [Cin][36][Cout], dgrad [Cout][36][Cin])."""
+    """F(4x4,3x3) transformed weights: (fwd [Cin][36][CoutP], dgrad [Cout][36][CinP]) with the row's channel dimension padded to
+    a multiple of 64 and permuted inside 64-blocks as conv_wino4.hip's A operand wants it (written in full by the pack kernel)."""
     require_gpu(w)
     w = w.detach().contiguous()
     Cout, Cin = w.shape[0], w.shape[1]
-    wf = torch.empty(Cin * 36 * Cout, dtype=F32, device=w.device)
-    wd = torch.empty(Cout * 36 * Cin, dtype=F32, device=w.device)
+    wf = torch.empty(Cin * 36 * ((Cout + 63) // 64 * 64), dtype=F32, device=w.device)
+    wd = torch.empty(Cout * 36 * ((Cin + 63) // 64 * 64), dtype=F32, device=w.device)
     _lib.call("onet_conv3x3_pack_weights_winograd4", _p(w), _p(wf), _p(wd), Cout, Cin, _stream())
     return wf, wd
 

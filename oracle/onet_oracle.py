@@ -211,7 +211,12 @@ class Routing:
         flip = (yd > 0) != m
         n = int(flip.sum())
         self.audit.append(("relu", n, m.numel(), float(yd[flip].abs().max() / yd.abs().max()) if n else 0.0))
-        return y * m.to(y.dtype)
+        # torch.where, not `y * mask`: same function and same gradient (g where the mask is set, 0 elsewhere), but its backward
+        # hands on a CONTIGUOUS gradient.  A multiply keeps the layout of the gradient it receives, and at batch size 1 the
+        # backward of the reference's head einsum (OV:176) delivers shape [1,64,H,W] with strides (1,1,64W,64); ATen's CPU
+        # batch_norm backward misreads such a tensor (dgamma, dbeta and dx off by O(1): reproduced standalone on torch 2.10) --
+        # which is why the module-swap replay of the REAL reference gave wrong gradients at B = 1 in round 2.
+        return torch.where(m, y, torch.zeros((), dtype=y.dtype))
 
     def maxpool2(self, a):
         if self.mode == "record":

@@ -544,9 +544,7 @@ if __name__ == "__main__":
         run_up_block(ov, True, "bilinear_pad")
         sys.exit(0)
     if os.environ.get("GOLDEN_ONLY") == "c5":            # BASELINE configs[4]'s tile shape: 3 x 512 x 512 (ZY-3 cloud tiles)
-        # (fp32 + free fp64 evaluations of the reference only: the module-swap replay of this script reproduces the loss but not
-        # the gradients at B = 1 -- the oracle's own routed evaluation agrees with the reference's fp32 gradients to 7e-5 here)
-        run_routed_case(ov, "routed_b1_c3_512", 1, 3, 512, 512, with_routed=False)
+        run_routed_case(ov, "routed_b1_c3_512", 1, 3, 512, 512)
         sys.exit(0)
     if os.environ.get("GOLDEN_ONLY") == "routed":
         run_routed_case(ov, "routed_b8_c1_128", 8, 1, 128, 128)
@@ -568,6 +566,7 @@ if __name__ == "__main__":
     run_unet_bilinear(ov)
     run_routed_case(ov, "routed_b8_c1_128", 8, 1, 128, 128)   # unsaturated head, large N, full / strided gradients
     run_routed_case(ov, "routed_b4_c1_256", 4, 1, 256, 256)
+    run_routed_case(ov, "routed_b1_c3_512", 1, 3, 512, 512)   # BASELINE configs[4]'s tile shape, batch statistics over ONE image
     run_eval_side()
     run_wire_formats(ov)
     run_clutter_stats()

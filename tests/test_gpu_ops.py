@@ -205,7 +205,7 @@ def test_winograd4_fused_bn_statistics(dev, B, Cin, Cout, H, W):
     qf, _ = ops.pack3x3_winograd4(w.to(dev))
     z0 = ops.conv3x3_winograd4(xd, qf, Cout)
     nparts = int(_lib.load().onet_conv3x3_winograd4_nparts(B, H, W))
-    assert nparts == B * (W // 32) * (H // 16)
+    assert nparts == 2 * B * (W // 32) * (H // 16)          # one record per tile half (16 x 16 pixels) of a 16 x 32-pixel block
     z1 = torch.empty_like(z0)
     cm = torch.full((Cout, nparts, 3), float("nan"), device=dev)
     _lib.call("onet_conv3x3_winograd4_fwd_stats", xd.data_ptr(), Cin * H * W, qf.data_ptr(), z1.data_ptr(),

@@ -261,3 +261,25 @@ def test_bench_parent_is_gpu_free_before_the_launch_decision():
     names = {a.name.split(".")[0] for n in top if isinstance(n, ast.Import) for a in n.names} | \
             {n.module.split(".")[0] for n in top if isinstance(n, ast.ImportFrom) and n.module}
     assert not ({"torch", "onet_amd", "oracle"} & names), names
+
+
+def test_zy3_dict_reader(tmp_path):
+    """`io.load_zy3_dict` on a file with the schema the reference's ZY-3 loaders read (dataloader/zy3_cloud_thumbnailv5_20240304.py:
+    92-122 `torch.load` of `{image_id: {'true_color': tensor [3,H,W], 'mask': tensor [H,W]}}`; the Dataset indexes
+    `list(data_dict.keys())`, :139-141, and its test branch hands out the stored tensors unchanged, :163-169): ids in the
+    file's order (not sorted), float32 stacks, values untouched, uint8 / float64 sources converted.  The real dataset is
+    absent (.MISSING_LARGE_BLOBS), so BASELINE configs[4]'s IoU parity itself cannot be run -- this pins the reader only."""
+    from onet_amd import io
+    rng = np.random.Generator(np.random.PCG64(3))
+    d = {}
+    for key, dt in (("ZY3_0007", torch.float32), ("ZY3_0002", torch.float64), ("scene_b", torch.uint8)):
+        rgb = torch.from_numpy(rng.random((3, 24, 20))).to(torch.float32)
+        d[key] = {"true_color": (rgb * 255).to(dt) if dt == torch.uint8 else rgb.to(dt),
+                  "mask": torch.from_numpy((rng.random((24, 20)) > 0.7)).to(dt)}
+    torch.save(d, tmp_path / "zy3.pt")
+    ids, X, M = io.load_zy3_dict(tmp_path / "zy3.pt")
+    assert ids == ["ZY3_0007", "ZY3_0002", "scene_b"]                  # the reference's order: insertion, not sorted
+    assert X.shape == (3, 3, 24, 20) and M.shape == (3, 24, 20) and X.dtype == M.dtype == torch.float32
+    for i, k in enumerate(ids):
+        assert torch.equal(X[i], d[k]["true_color"].to(torch.float32)) and torch.equal(M[i], d[k]["mask"].to(torch.float32))
+    assert set(M.unique().tolist()) <= {0.0, 1.0}
