@@ -151,9 +151,9 @@ struct W4Cfg {
     static constexpr int NIN = (IN_LOGICAL + NTHR - 1) / NTHR;
     static constexpr int X_BASE = 3 * W_FLOATS;            // LDS map: weight ring W[3], then input ring X[2]
     static constexpr int KLOOP_FLOATS = X_BASE + 2 * X_FLOATS;
-    // epilogue exchange: [tile half 2][finishing group 4][sending slot 3][lane 64] x 16 values at a lane stride of 20 floats
-    // (80 B: 16-byte aligned, and the 16 lanes of a b128 group land on 16 distinct 4-bank sets)
-    static constexpr int EX_LANE = 20;
+    // epilogue exchange: [tile half 2][finishing group 4][sending slot 3][lane 64] x 9 values at a lane stride of 12 floats
+    // (48 B: 16-byte aligned, and the 16 lanes of a b128 group land on 16 distinct 4-bank sets)
+    static constexpr int EX_LANE = 12;
     static constexpr int EX_FLOATS = 2 * 4 * 3 * 64 * EX_LANE;
     static constexpr int LDS_FLOATS = (KLOOP_FLOATS > EX_FLOATS) ? KLOOP_FLOATS : EX_FLOATS;
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
@@ -510,11 +510,12 @@ static __device__ __forceinline__ void wino4_body(const Wino4Args& a, float* sme
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (all-zero) staging must land before the LDS is reused
     __syncthreads();
 
-    // ---- epilogue: every wave holds the partial A^T M A of ITS position group for 64 channels x its 16 tiles; the four partials
-    // of a tile half are summed through LDS.  A pass takes one channel block g (accumulator registers r = 0..3 = channels
-    // 16 g + 4 k4 + r): every wave transforms its partial of all four registers, sends three and FINISHES register r = PG (sum,
-    // statistics, store), so summing, BatchNorm records and stores are spread over all eight waves.  Four passes, rolled (the
-    // accumulators of block g + 1 move into block 0's registers), two barriers per pass around the single exchange buffer.
+    // ---- epilogue: every wave holds the 3x3 block of M (the 6x6 matrix of position sums) of ITS position group for 64 channels x
+    // its 16 tiles; the output transform A^T M A needs all four blocks.  A pass takes one channel block g (accumulator registers
+    // r = 0..3 = channels 16 g + 4 k4 + r): every wave sends the raw position values of three registers through LDS and
+    // FINISHES register r = PG (gathers the other three groups' blocks, transforms, statistics, store), so transforms,
+    // BatchNorm records and stores are spread over all eight waves.  Four passes, rolled (the accumulators of block g + 1 move
+    // into block 0's registers), two barriers per pass around the single exchange buffer.
     float* zb[IMG];
 #pragma unroll
     for (int m = 0; m < IMG; ++m) zb[m] = a.z + (int64_t)(b0 + m) * a.z_bs;
@@ -547,31 +548,20 @@ static __device__ __forceinline__ void wino4_body(const Wino4Args& a, float* sme
     float* ex = smem + th * (C::EX_FLOATS / 2);
 #pragma unroll 1
     for (int g = 0; g < 4; ++g) {
-        float yv[4][4][4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float rowp[4][3];                         // A^T (row half) applied to the 3 position rows, per column j
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                float o[4];
-                at3<RH>(acc[0 * 3 + j][0][k], acc[1 * 3 + j][0][k], acc[2 * 3 + j][0][k], o);
-#pragma unroll
-                for (int y = 0; y < 4; ++y) rowp[y][j] = o[y];
-            }
-#pragma unroll
-            for (int y = 0; y < 4; ++y) at3<CH>(rowp[y][0], rowp[y][1], rowp[y][2], yv[k][y]);
-        }
-        // send the three partials this wave does not finish: finisher k, slot = PG's rank among the other three groups
+        // send the accumulator registers this wave does not finish: RAW position values (9 per register -- the 3x3 block of the
+        // 6x6 M this group owns), not partial outputs (16 per register): 27 instead of 48 floats per lane through LDS, and one
+        // full A^T M A per finished register instead of four partial ones per wave (120 instead of 188 VALU per pass)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (k == PG) continue;
             const int slot = (PG < k) ? PG : PG - 1;
-#pragma unroll
-            for (int y = 0; y < 4; ++y)
-                *reinterpret_cast<float4*>(ex + ((k * 3 + slot) * 64 + lane) * C::EX_LANE + y * 4) =
-                    make_float4(yv[k][y][0], yv[k][y][1], yv[k][y][2], yv[k][y][3]);
+            float* dst = ex + ((k * 3 + slot) * 64 + lane) * C::EX_LANE;
+            *reinterpret_cast<float4*>(dst) = make_float4(acc[0][0][k], acc[1][0][k], acc[2][0][k], acc[3][0][k]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(acc[4][0][k], acc[5][0][k], acc[6][0][k], acc[7][0][k]);
+            dst[8] = acc[8][0][k];
         }
         __syncthreads();
+        float yv[1][4][4];
         {
             constexpr int k = PG;
             const int co = co0 + 16 * g + 4 * k4 + PG;    // MFMA row 4 k4 + r of channel block g, r = PG
@@ -584,23 +574,53 @@ static __device__ __forceinline__ void wino4_body(const Wino4Args& a, float* sme
                 br_mean = cn[0]; br_inv = cn[1]; br_sc = cn[2]; br_sh = cn[3];
                 if (g + 1 < 4) br_issue(g + 1);
             }
+            // the full 6x6 M of register PG: own 3x3 block from the accumulators, the other three from LDS
+            float m[6][6];
 #pragma unroll
-            for (int y = 0; y < 4; ++y)
+            for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int s3 = 0; s3 < 3; ++s3) {
-                    const float4 v = *reinterpret_cast<const float4*>(ex + ((k * 3 + s3) * 64 + lane) * C::EX_LANE + y * 4);
-                    yv[k][y][0] += v.x; yv[k][y][1] += v.y; yv[k][y][2] += v.z; yv[k][y][3] += v.w;
-                }
+                for (int j = 0; j < 3; ++j) m[3 * RH + i][3 * CH + j] = acc[i * 3 + j][0][k];
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int src = (s3 < PG) ? s3 : s3 + 1;          // sending group of slot s3
+                const int rh = src >> 1, ch = src & 1;
+                const float* sp = ex + ((k * 3 + s3) * 64 + lane) * C::EX_LANE;
+                const float4 v0 = *reinterpret_cast<const float4*>(sp), v1 = *reinterpret_cast<const float4*>(sp + 4);
+                const float v8 = sp[8];
+                const float vv[9] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v8};
+#pragma unroll
+                for (int q = 0; q < 9; ++q) m[3 * rh + q / 3][3 * ch + q % 3] = vv[q];
+            }
+            // Y = A^T M A,  A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+            float rp[4][6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float s12 = m[1][j] + m[2][j], d12 = m[1][j] - m[2][j], s34 = m[3][j] + m[4][j], d34 = m[3][j] - m[4][j];
+                rp[0][j] = m[0][j] + s12 + s34;
+                rp[1][j] = fmaf(2.f, d34, d12);
+                rp[2][j] = fmaf(4.f, s34, s12);
+                rp[3][j] = fmaf(8.f, d34, d12) + m[5][j];
+            }
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                const float s12 = rp[y][1] + rp[y][2], d12 = rp[y][1] - rp[y][2], s34 = rp[y][3] + rp[y][4], d34 = rp[y][3] - rp[y][4];
+                yv[0][y][0] = rp[y][0] + s12 + s34;
+                yv[0][y][1] = fmaf(2.f, d34, d12);
+                yv[0][y][2] = fmaf(4.f, s34, s12);
+                yv[0][y][3] = fmaf(8.f, d34, d12) + rp[y][5];
+            }
             if constexpr (EP == 1) {
                 static_assert(EP == 0 || IMG == 1, "fused statistics: one image per block");
                 // pivot: the first tile's first pixel of this lane's channel (lane 16 k4 of the wave)
-                const float pv = __shfl(yv[k][0][0], lane & 48, 64);
+                const float pv = __shfl(yv[0][0][0], lane & 48, 64);
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int y = 0; y < 4; ++y)
 #pragma unroll
                     for (int x = 0; x < 4; ++x) {
-                        const float dd = yv[k][y][x] - pv;
+                        const float dd = yv[0][y][x] - pv;
                         s1 += dd;
                         s2 = fmaf(dd, dd, s2);
                     }
@@ -621,7 +641,7 @@ static __device__ __forceinline__ void wino4_body(const Wino4Args& a, float* sme
 #pragma unroll
                     for (int x = 0; x < 4; ++x) {
                         const float zc = zz[x] - br_mean;
-                        const float gg = fmaf(zc, br_sc, br_sh) > 0.f ? yv[k][y][x] : 0.f;   // same mask expression as bn_relu_bwd_*
+                        const float gg = fmaf(zc, br_sc, br_sh) > 0.f ? yv[0][y][x] : 0.f;   // same mask expression as bn_relu_bwd_*
                         s1 += gg;
                         s2 = fmaf(gg, zc, s2);
                     }
@@ -640,11 +660,11 @@ static __device__ __forceinline__ void wino4_body(const Wino4Args& a, float* sme
                 for (int y = 0; y < 4; ++y) {
                     if (oy + y < a.H) {
                         if (vec4) {
-                            *reinterpret_cast<float4*>(o + y * a.W) = make_float4(yv[k][y][0], yv[k][y][1], yv[k][y][2], yv[k][y][3]);
+                            *reinterpret_cast<float4*>(o + y * a.W) = make_float4(yv[0][y][0], yv[0][y][1], yv[0][y][2], yv[0][y][3]);
                         } else {
 #pragma unroll
                             for (int x = 0; x < 4; ++x)
-                                if (ox + x < a.W) o[y * a.W + x] = yv[k][y][x];
+                                if (ox + x < a.W) o[y * a.W + x] = yv[0][y][x];
                         }
                     }
                 }
