@@ -17,7 +17,7 @@
 //  * per 16-channel chunk a wave issues 18 A + 3 x (NT + 2) B ds_read_b128 for 9 x 2 x NT MFMAs of 32 cycles
 //    (NT = 2 image rows per wave: 64 accumulator registers, two 4-wave blocks per CU), the reads one tap ahead of the MFMAs;
 //  * blocks are persistent and the load -> LDS -> MFMA pipeline runs across tile boundaries (see the kernel).
-//  Measured limits (tools/time_bf16.py, ablation builds -DONET_BF_ABL=n, B = 64; table in DESIGN.md 4.2d): the cost that does not
+//  Measured limits (timing-only ablation builds of round 2, B = 64; table in DESIGN.md 4.2d): the cost that does not
 //  hide is the request rate of the NCHW input tile's cache lines (~240 half-used 128-byte lines per chunk): loading the input
 //  once saves 25 %, the weights once 5 %; a quarter of the planes is as good as none; a quarter of the load INSTRUCTIONS for the
 //  same lines (8-byte quad loads + in-register transpose) changes nothing, and neither does a longer prefetch distance (two
@@ -36,15 +36,6 @@ typedef unsigned int u32x4b __attribute__((ext_vector_type(4)));
 typedef float f32x4b __attribute__((ext_vector_type(4)));
 
 constexpr unsigned OOB_B = 0x80000000u;
-
-// experiments (tools/time_bf16.py, onet_amd.build --variant): 1 no global loads after the first chunk, 2 also no LDS commits,
-// 3 no MFMAs, 4 no epilogue stores, 7 weight slice loaded once per block, 8 input tile loaded once.  Wrong results by construction; 0 in every shipped build.
-#ifndef ONET_BF_ABL
-#define ONET_BF_ABL 0
-#endif
-#ifndef ONET_BW_ABL       // the same for the weight-gradient kernel: 1 no loads after the first unit, 2 also no commits, 3 no MFMAs
-#define ONET_BW_ABL 0
-#endif
 
 static __device__ __forceinline__ __amdgpu_buffer_rsrc_t b_rsrc(const void* base, int64_t bytes) {
     const int n = bytes > 0x7fffffffll ? 0x7fffffff : (int)bytes;
@@ -221,7 +212,6 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
     auto issue = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
-            if (ONET_BF_ABL == 8 && (st_chunk | (st_tile - t_first)) != 0) break;
             if constexpr (XB == 2) {
                 xblk[k] = __builtin_amdgcn_raw_buffer_load_b128(xr, in_off[k], (int)cin_bytes, 0);
                 continue;
@@ -238,12 +228,6 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
                     xin[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                                               xr, in_off[k], (int)(cin_bytes + c * plane), 0));
             }
-        }
-        if (ONET_BF_ABL == 7 && (st_chunk | (st_tile - t_first)) != 0) return;     // experiment: weight slice loaded once per block
-        if (ONET_BF_ABL == 8) {                                                      // experiment: input loaded once, weights always
-#pragma unroll
-            for (int k = 0; k < NWI; ++k) wv[k] = __builtin_amdgcn_raw_buffer_load_b128(wr, w_off[k], (int)cw_bytes, 0);
-            return;
         }
 #pragma unroll
         for (int k = 0; k < NWI; ++k)
@@ -316,19 +300,15 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
                 if (idx == 4) {
                     // the other buffer was last read one chunk ago (barrier since): the chunk after this one goes in, and the
                     // loads of the one after that take over the staging registers
-                    if (ONET_BF_ABL != 2) commit(buf ^ 1);
+                    commit(buf ^ 1);
                     advance();
-                    if (ONET_BF_ABL != 1 && ONET_BF_ABL != 2) issue();
+                    issue();
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
-                        if (ONET_BF_ABL == 3) {           // keep the fragment reads alive without the matrix pipe
-                            acc[m][n][0] += __builtin_bit_cast(float, Aq[idx & 1][m][0] ^ Bq[kx & 1][n * RPT + ky][0]);
-                            continue;
-                        }
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Aq[idx & 1][m]),
                                                                             __builtin_bit_cast(bf16x8, Bq[kx & 1][n * RPT + ky]), acc[m][n], 0, 0, 0);
                     }
@@ -403,7 +383,6 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                        if (ONET_BF_ABL == 4 && (r || acc[m][n][r] != 12345.f)) continue;
                         if (co < a.Cout) zb[(int64_t)co * HW + (int64_t)yo * a.W + xo] = acc[m][n][r];
                     }
                 }
@@ -584,9 +563,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_bf16_kernel(BwArgs a) {
 
     issue(u0);
     for (int u = u0; u < u1; ++u) {
-        if (ONET_BW_ABL != 2 || u == u0) commit();
+        commit();
         __syncthreads();
-        if (ONET_BW_ABL != 1 && ONET_BW_ABL != 2) issue(u + 1);
+        issue(u + 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -598,10 +577,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_bf16_kernel(BwArgs a) {
                 const u32x4b s1 = {__builtin_amdgcn_alignbit(q[1], q[0], 16), __builtin_amdgcn_alignbit(q[2], q[1], 16),
                                    __builtin_amdgcn_alignbit(q[3], q[2], 16), __builtin_amdgcn_alignbit(d4, q[3], 16)};
                 const u32x4b s2 = {q[1], q[2], q[3], d4};
-                if (ONET_BW_ABL == 3) {     // fragment reads and shifts without the matrix pipe
-                    acc[ky * 3][0] += __builtin_bit_cast(float, q[0] ^ s1[1] ^ s2[2] ^ __builtin_bit_cast(u32x4b, av)[0]);
-                    continue;
-                }
                 acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, q), acc[ky * 3 + 0], 0, 0, 0);
                 acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, s1), acc[ky * 3 + 1], 0, 0, 0);
                 acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, s2), acc[ky * 3 + 2], 0, 0, 0);

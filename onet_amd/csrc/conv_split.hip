@@ -1,0 +1,464 @@
+// 3x3 convolution forward + dgrad with fp32 tensors and fp32-LEVEL accuracy on the bf16 matrix cores, by OPERAND SPLITTING
+// (F.conv2d / its input gradient at OV:47,51; the default fp32 algorithm of round 3 wherever the map is at least 32 pixels wide).
+//
+//   x = x_hi + x_mid + (x_lo),  w = w_hi + w_mid + (w_lo)   with every part a bf16 number (x_hi = bf16(x), x_mid = bf16(x - x_hi)):
+//   hi + mid carry 16 significant bits, and   x * w  ~=  x_hi w_hi + x_hi w_mid + x_mid w_hi   drops only terms of relative size
+//   2^-16 (mid * mid, hi * lo).  Each product of two bf16 numbers is exact in the fp32 accumulator of
+//   v_mfma_f32_32x32x16_bf16, so the convolution costs THREE bf16 MFMAs per (tap, 16 channels) at 16x the fp32 MFMA rate:
+//   5.3x the fp32 matrix peak, against 4x (x 0.5-0.6 pipe occupancy) for the fp32 Winograd F(4x4,3x3) kernel it replaces.
+//   Measured against fp64 at Cin = 512: 9.7e-7 rms / 4.4e-6 max of the output scale from the split itself
+//   (emulated on the CPU; F(4x4): 2.7e-6 / 4e-5), plus the fp32 accumulation of the MFMA chain as in every other kernel here.
+//
+// Structure: the direct implicit GEMM of conv_bf16.hip (M = output channels, N = 32 consecutive pixels of an image row,
+// K = 16 input channels per MFMA; LDS tiles made of 16-byte slots of 8 channels, the two 8-channel halves apart; persistent
+// blocks whose load -> LDS -> MFMA pipeline runs across tile boundaries), with:
+//  * both parts of both operands in LDS: weights [part][tap][half][co], input halo tile [part][half][pixel] -- the fp32
+//    input is loaded ONCE per chunk (8 channel planes per slot, coalesced along x) and split on the way into LDS (2 x 8
+//    v_cvt_pk_bf16_f32 + 8 v_sub per slot); the weights are split once per optimizer step by the pack kernel;
+//  * 8 waves per block (one block per CU, two waves per SIMD: the doubled tiles need 156 KB of LDS): 64 output channels x 16
+//    image rows x 32 pixels, 2 rows per wave; per 16-channel chunk a wave issues 60 ds_read_b128 for 108 MFMAs of 32 cycles,
+//    and the block moves 39 KB of input + 36 KB of weights per 864 MFMAs -- a third of conv_bf16.hip's bytes and requests per
+//    MFMA, which is what bound that kernel.
+// Requires Cin % 16 == 0 and W > 16; everything else takes the fp32 Winograd / direct kernels.
+#include <algorithm>
+#include <cstdlib>
+#include "common.hpp"
+
+using namespace onet;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr unsigned OOB_S = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t s_rsrc(const void* base, int64_t bytes) {
+    const int n = bytes > 0x7fffffffll ? 0x7fffffff : (int)bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000);
+}
+// (hi, mid) parts of two fp32 values, packed: hi = bf16(v) (round to nearest even), mid = bf16(v - hi)
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& mid) {
+    const bf16x2 h = {(__bf16)a, (__bf16)b};
+    const bf16x2 m = {(__bf16)(a - (float)h[0]), (__bf16)(b - (float)h[1])};
+    hi = __builtin_bit_cast(unsigned, h);
+    mid = __builtin_bit_cast(unsigned, m);
+}
+
+// w [Cout][Cin][3][3] fp32 -> wq [K/16][part 2][9][2][N][8] bf16: chunk of 16 reduction channels, part (hi, mid), tap,
+// 8-channel half, output channel, channel within the half.  which = 0: forward (K = Cin, N = Cout); 1: input gradient
+// (K = Cout rounded up to 16 with a zero tail, N = Cin, taps rotated by 180 degrees).
+__global__ void pack3x3_split_kernel(const float* __restrict__ w, __bf16* __restrict__ wq, int Cout, int Cin, int which) {
+    const int K = which == 0 ? Cin : ((Cout + 15) / 16) * 16, N = which == 0 ? Cout : Cin;
+    const int64_t n = (int64_t)K * 9 * N;                            // elements of ONE part
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int kc = (int)(i & 7);
+        int64_t r = i >> 3;
+        const int nn = (int)(r % N);
+        r /= N;
+        const int half = (int)(r & 1);
+        r >>= 1;
+        const int t = (int)(r % 9), kg = (int)(r / 9);
+        const int k = kg * 16 + half * 8 + kc;
+        float v = 0.f;
+        if (which == 0) v = w[((int64_t)nn * Cin + k) * 9 + t];
+        else if (k < Cout) v = w[((int64_t)k * Cin + nn) * 9 + (8 - t)];
+        const __bf16 hi = (__bf16)v;
+        const __bf16 mid = (__bf16)(v - (float)hi);
+        const int64_t per_chunk_part = (int64_t)9 * 2 * N * 8;
+        const int64_t within = i - (int64_t)kg * per_chunk_part;     // [tap][half][n][8] inside the chunk
+        wq[((int64_t)kg * 2 + 0) * per_chunk_part + within] = hi;
+        wq[((int64_t)kg * 2 + 1) * per_chunk_part + within] = mid;
+    }
+}
+
+struct SpArgs {
+    const float* x;       // fp32 NCHW
+    int64_t x_bs;
+    const __bf16* wq;     // [Cin/16][2][9][2][Cout][8]
+    float* z;
+    int64_t z_bs;
+    int B, Cin, Cout, H, W, tilesX, tilesY, coTiles;
+    float* stats;         // ST: BatchNorm partials [Cout][B * tilesY * tilesX][3] = (n, mean, M2) per tile
+};
+
+// sum over the 32 lanes of a wave half, valid in lanes 31 / 63 (DPP row rotations + row broadcast)
+#define ONET_SP_DPP_ADD(v, ctrl, rmask) \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
+__device__ __forceinline__ float sp_half_sum(float v) {
+    ONET_SP_DPP_ADD(v, 0x128, 0xf);   // row_ror:8
+    ONET_SP_DPP_ADD(v, 0x124, 0xf);   // row_ror:4
+    ONET_SP_DPP_ADD(v, 0x122, 0xf);   // row_ror:2
+    ONET_SP_DPP_ADD(v, 0x121, 0xf);   // row_ror:1
+    ONET_SP_DPP_ADD(v, 0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+    return v;
+}
+#undef ONET_SP_DPP_ADD
+
+struct SpCfg {
+    static constexpr int NW = 8, NT = 2, TW = 32, CO_T = 64;
+    static constexpr int ROWS = NW * NT;                                // 16 image rows per tile
+    static constexpr int IN_ROWS = ROWS + 2, IN_COLS = TW + 2;
+    static constexpr int NPIX = IN_ROWS * IN_COLS;                      // 612 halo pixels
+    static constexpr int NROUND = (NPIX + 31) / 32;                     // 20 wave-rounds of 32 pixels x 2 halves
+    static constexpr int NIT = (NROUND + NW - 1) / NW;                  // 3 rounds per wave (waves 4..7 idle in the last)
+    static constexpr int NPIXP = NROUND * 32;                           // 640 pixel slots per half
+    static constexpr int W_PART = 9 * 2 * CO_T;                         // 1152 slots per part
+    static constexpr int W_SLOTS = 2 * W_PART;                          // hi | mid
+    static constexpr int NWI = (W_SLOTS + 511) / 512;                   // 5
+    static constexpr int IN_PART = 2 * NPIXP;                           // [half][pixel]
+    static constexpr int BUF_SLOTS = W_SLOTS + 2 * IN_PART;             // 4864 slots = 76 KB
+    static constexpr int LDS_BYTES = 2 * BUF_SLOTS * 16;                // two chunk buffers: 152 KB
+    static constexpr int NB = (NT - 1) + 3;                             // distinct B row-fragments per horizontal tap
+};
+
+// PERSISTENT blocks as in conv_bf16.hip: a block walks over output tiles and the chunk pipeline -- global loads two 16-channel
+// chunks ahead of the MFMAs, LDS commit one ahead -- runs ACROSS tile boundaries.
+// ST: the forward of a Conv-BatchNorm pair (OV:47-48, 51-52) also emits the BatchNorm statistics of its output, one (n, mean,
+// M2) record per tile and channel from the final accumulators (pivot-shifted sums per wave, the eight waves merged through LDS).
+template <bool ST>
+__global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
+    using C = SpCfg;
+    constexpr int NT = C::NT, IN_COLS = C::IN_COLS, NIT = C::NIT, NWI = C::NWI, CO_T = C::CO_T, NPIXP = C::NPIXP, NB = C::NB;
+    constexpr int BUF = C::BUF_SLOTS, W_PART = C::W_PART, IN_PART = C::IN_PART, ROWS = C::ROWS, TW = C::TW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
+    u32x4s* lds = reinterpret_cast<u32x4s*>(smem_s);                   // [2 buffers][weights hi|mid | input hi|mid]
+
+    // tiles of this block: every XCD (blockIdx % 8) owns a contiguous range of the tile list (neighbouring tiles share halo
+    // rows and the weight slice in that XCD's L2); its blocks stride through the range
+    const int ntiles = a.tilesX * a.tilesY * a.B * a.coTiles;
+    int t_first, t_end, t_stride;
+    {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int q = ntiles >> 3, r = ntiles & 7;
+        const int start = xcd * q + min(xcd, r);
+        t_stride = (gridDim.x + 7 - xcd) >> 3;
+        t_first = start + j;
+        t_end = start + q + (xcd < r ? 1 : 0);
+    }
+    if (t_first >= t_end) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int HW = a.H * a.W;
+    const int nchunks = a.Cin >> 4;
+
+    const __amdgpu_buffer_rsrc_t wr = s_rsrc(a.wq, (int64_t)a.Cin * 2 * 9 * a.Cout * 2);
+    const unsigned in_step = (unsigned)(16 * HW * 4), w_step = (unsigned)(2 * 9 * 2 * a.Cout * 16);
+    const unsigned plane = (unsigned)(HW * 4);
+
+    // ---- staging side: runs two chunks ahead of the compute side, across tiles.  Round k of wave wn covers halo pixels
+    // 32 (wn + 8 k) .. + 31, lanes 0-31 the channels 0-7 of the chunk, lanes 32-63 the channels 8-15 (coalesced along x); weight
+    // slots i = tid + 512 k = (part, tap, half, co) -> 16 bytes of the slice [chunk][part][tap][half][co][8]
+    unsigned in_off[NIT], w_off[NWI];
+    __amdgpu_buffer_rsrc_t xr;
+    int st_tile = t_first, st_chunk = 0;
+    unsigned cin_bytes = 0, cw_bytes = 0;
+    auto setup_stage = [&]() __attribute__((always_inline)) {
+        const bool live = st_tile < t_end;
+        int v = live ? st_tile : t_first;
+        const int tx = v % a.tilesX;
+        v /= a.tilesX;
+        const int ty = v % a.tilesY;
+        v /= a.tilesY;
+        const int b = v % a.B, co0 = (v / a.B) * CO_T;
+        const int y0 = ty * ROWS, x0 = tx * TW;
+        xr = s_rsrc(a.x + (int64_t)b * a.x_bs, (int64_t)a.Cin * HW * 4);
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int p = (wn + C::NW * k) * 32 + l31;
+            const int r = p / IN_COLS, c = p % IN_COLS;
+            const int yy = y0 - 1 + r, xx = x0 - 1 + c;
+            const bool ok = live && p < C::NPIX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+            in_off[k] = ok ? (unsigned)(((kh * 8) * HW + yy * a.W + xx) * 4) : OOB_S;
+        }
+#pragma unroll
+        for (int k = 0; k < NWI; ++k) {
+            const int i = tid + 512 * k;
+            const int co = i & (CO_T - 1), pth = i >> 6;               // pth = (part * 9 + tap) * 2 + half
+            const bool ok = live && (i < C::W_SLOTS) && (co0 + co < a.Cout);
+            w_off[k] = ok ? (unsigned)((pth * a.Cout + co0 + co) * 16) : OOB_S;
+        }
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
+        ++st_chunk;
+        cin_bytes += in_step;
+        cw_bytes += w_step;
+        if (st_chunk == nchunks) {
+            st_chunk = 0;
+            cin_bytes = cw_bytes = 0;
+            st_tile += t_stride;
+            setup_stage();                           // past the last tile: every slot out of range -> zeros, no traffic
+        }
+    };
+
+    float xin[NIT][8];
+    u32x4s wv[NWI];
+    auto issue = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k)
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                // the chunk / plane part of the address is wave-uniform: it rides in the instruction's scalar offset; the
+                // per-lane part alone decides the range check (OOB_S -> 0)
+                xin[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, in_off[k], (int)(cin_bytes + c * plane), 0));
+#pragma unroll
+        for (int k = 0; k < NWI; ++k) wv[k] = __builtin_amdgcn_raw_buffer_load_b128(wr, w_off[k], (int)cw_bytes, 0);
+    };
+    u32x4s* const w_st = lds + tid;                                     // + 512 k          (+ buffer * BUF)
+    u32x4s* const in_st = lds + C::W_SLOTS + kh * NPIXP + wn * 32 + l31;   // + 256 k, + IN_PART for the mid part
+    auto commit = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            if (wn + C::NW * k >= C::NROUND) continue;                   // (wave-uniform) the last round exists for waves 0..3 only
+            u32x4s hi, mid;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                unsigned h, m;
+                split2(xin[k][2 * c], xin[k][2 * c + 1], h, m);
+                hi[c] = h;
+                mid[c] = m;
+            }
+            in_st[buf * BUF + 256 * k] = hi;
+            in_st[buf * BUF + 256 * k + IN_PART] = mid;
+        }
+#pragma unroll
+        for (int k = 0; k < NWI; ++k)
+            if (tid + 512 * k < C::W_SLOTS) w_st[buf * BUF + 512 * k] = wv[k];
+    };
+
+    // fragments: A (weights) slot = part * W_PART + (tap * 2 + kh) * 64 + m * 32 + l31;
+    //            B (input)   slot = W_SLOTS + part * IN_PART + kh * NPIXP + (2 wn + j) * IN_COLS + l31 + kx
+    const u32x4s* const a_ptr = lds + kh * CO_T + l31;
+    const u32x4s* const b_ptr = lds + C::W_SLOTS + kh * NPIXP + (wn * NT) * IN_COLS + l31;
+
+    setup_stage();
+    issue();
+    commit(0);
+    advance();
+    issue();                                         // second chunk (or the first of the next tile)
+    __syncthreads();
+    int buf = 0;
+    for (int tile = t_first; tile < t_end; tile += t_stride) {
+        f32x16 acc[2][NT];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+        for (int c = 0; c < nchunks; ++c) {
+            const u32x4s* const ab = a_ptr + buf * BUF;
+            const u32x4s* const bb = b_ptr + buf * BUF;
+            // Fragment reads run ONE tap ahead of the MFMAs that consume them (two register sets), the taps in kx-major order
+            // so that the NB row-fragments of a horizontal shift serve its three vertical taps; the row-fragments of the next
+            // shift are fetched during the three taps of the current one.  [part]: 0 = hi, 1 = mid.
+            u32x4s Aq[2][2][2], Bq[2][NB][2];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                Bq[0][j][0] = bb[j * IN_COLS];
+                Bq[0][j][1] = bb[j * IN_COLS + IN_PART];
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                Aq[0][m][0] = ab[m * 32];
+                Aq[0][m][1] = ab[m * 32 + W_PART];
+            }
+#pragma unroll
+            for (int idx = 0; idx < 9; ++idx) {
+                const int kx = idx / 3, ky = idx % 3;
+                if (idx < 8) {
+                    const int nt = ((idx + 1) % 3) * 3 + (idx + 1) / 3;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        Aq[(idx + 1) & 1][m][0] = ab[nt * 2 * CO_T + m * 32];
+                        Aq[(idx + 1) & 1][m][1] = ab[nt * 2 * CO_T + m * 32 + W_PART];
+                    }
+                }
+                if (kx < 2) {
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+                        if (j % 3 == ky) {
+                            Bq[(kx + 1) & 1][j][0] = bb[j * IN_COLS + kx + 1];
+                            Bq[(kx + 1) & 1][j][1] = bb[j * IN_COLS + kx + 1 + IN_PART];
+                        }
+                }
+                if (idx == 4) {
+                    // the other buffer was last read one chunk ago (barrier since): the chunk after this one goes in, and the
+                    // loads of the one after that take over the staging registers
+                    commit(buf ^ 1);
+                    advance();
+                    issue();
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const int tap = ky * 3 + kx;
+                (void)tap;
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, Aq[idx & 1][m][0]), am = __builtin_bit_cast(bf16x8, Aq[idx & 1][m][1]);
+                        const bf16x8 bh = __builtin_bit_cast(bf16x8, Bq[kx & 1][n + ky][0]), bm = __builtin_bit_cast(bf16x8, Bq[kx & 1][n + ky][1]);
+                        // smallest terms first: the two cross terms, then hi * hi
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[m][n], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+            buf ^= 1;
+        }
+
+        int v = tile;
+        const int tx = v % a.tilesX;
+        v /= a.tilesX;
+        const int ty = v % a.tilesY;
+        v /= a.tilesY;
+        const int b = v % a.B, co0 = (v / a.B) * CO_T;
+        const int y0 = ty * ROWS, x0 = tx * TW;
+        if constexpr (ST) {
+            float* sc = reinterpret_cast<float*>(lds + 2 * BUF);       // [8 waves][64 channels][mean, M2]
+            constexpr float npw = (float)(NT * 32), inv_npw = 1.f / npw;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    // lanes 0-31 hold 32 pixels of channel c, lanes 32-63 of channel c + 4; pivot = the wave's first pixel
+                    const int piv = __builtin_bit_cast(int, acc[m][0][r]);
+                    const float p0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(piv, 0));
+                    const float p1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(piv, 32));
+                    const float pv = kh ? p1 : p0;
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const float d = acc[m][n][r] - pv;
+                        s1 += d;
+                        s2 = fmaf(d, d, s2);
+                    }
+                    s1 = sp_half_sum(s1);
+                    s2 = sp_half_sum(s2);
+                    if (l31 == 31) {
+                        const int cl = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                        sc[(wn * 64 + cl) * 2] = fmaf(s1, inv_npw, pv);
+                        sc[(wn * 64 + cl) * 2 + 1] = fmaxf(fmaf(-s1 * inv_npw, s1, s2), 0.f);
+                    }
+                }
+            __syncthreads();
+            if (tid < 64 && co0 + tid < a.Cout) {
+                float mw[8], qw[8];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) {
+                    mw[w] = sc[(w * 64 + tid) * 2];
+                    qw[w] = sc[(w * 64 + tid) * 2 + 1];
+                }
+                const float mean = 0.125f * (((mw[0] + mw[1]) + (mw[2] + mw[3])) + ((mw[4] + mw[5]) + (mw[6] + mw[7])));
+                float m2 = ((qw[0] + qw[1]) + (qw[2] + qw[3])) + ((qw[4] + qw[5]) + (qw[6] + qw[7]));
+#pragma unroll
+                for (int w = 0; w < 8; ++w) m2 = fmaf(npw * (mw[w] - mean), mw[w] - mean, m2);
+                const int64_t nblk = (int64_t)a.B * a.tilesY * a.tilesX;
+                const int64_t blk = ((int64_t)b * a.tilesY + ty) * a.tilesX + tx;
+                float* sp = a.stats + ((int64_t)(co0 + tid) * nblk + blk) * 3;
+                sp[0] = 8.f * npw;
+                sp[1] = mean;
+                sp[2] = m2;
+            }
+            __syncthreads();                         // the scratch is rewritten by the next tile
+        }
+        float* zb = a.z + (int64_t)b * a.z_bs;
+        const int xo = x0 + l31;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int yo = y0 + wn * NT + n;
+                if (yo < a.H && xo < a.W) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                        if (co < a.Cout) zb[(int64_t)co * HW + (int64_t)yo * a.W + xo] = acc[m][n][r];
+                    }
+                }
+            }
+    }
+}
+
+int split_nparts(int B, int H, int W) {
+    if (B <= 0 || W < 32 || (W % SpCfg::TW) || (H % SpCfg::ROWS)) return 0;
+    const int64_t n = (int64_t)B * (H / SpCfg::ROWS) * (W / SpCfg::TW);
+    return n < (1 << 30) ? (int)n : 0;
+}
+
+template <bool ST>
+int launch_split(SpArgs a, hipStream_t st) {
+    using C = SpCfg;
+    const int LDS_BYTES = C::LDS_BYTES + (ST ? C::NW * 64 * 2 * 4 : 0);
+    a.tilesX = cdiv(a.W, C::TW);
+    a.tilesY = cdiv(a.H, C::ROWS);
+    a.coTiles = cdiv(a.Cout, C::CO_T);
+    const int64_t tiles = (int64_t)a.B * a.tilesX * a.tilesY * a.coTiles;
+    ONET_REQUIRE(tiles > 0 && tiles < (1ll << 31), "conv3x3_split: tile count %lld out of range", (long long)tiles);
+    auto kern = conv3x3_split_kernel<ST>;
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    }
+    // persistent grid: one 8-wave block per CU, a multiple of the 8 XCDs
+    const int64_t resident = (int64_t)device_cu_count();
+    const int64_t blocks = std::min<int64_t>((tiles + 7) / 8 * 8, std::max<int64_t>(8, resident / 8 * 8));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), LDS_BYTES, st, a);
+    return check_launch("conv3x3_split_kernel");
+}
+
+int split_fwd(const float* x, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin, int Cout, int H, int W,
+              void* stream, float* stats) {
+    ONET_REQUIRE(x && wq && z, "conv3x3_split_fwd: null pointer");
+    ONET_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 16, "conv3x3_split_fwd: bad shape (maps wider than 16 pixels)");
+    ONET_REQUIRE((Cin % 16) == 0, "conv3x3_split_fwd: Cin must be a multiple of 16 (use onet_conv_fwd)");
+    ONET_REQUIRE(x_bs >= (int64_t)Cin * H * W && z_bs >= (int64_t)Cout * H * W, "conv3x3_split_fwd: batch stride too small");
+    ONET_REQUIRE((int64_t)(Cin + 32) * H * W * 4 < (1ll << 31) && (int64_t)(Cin + 32) * 2 * 9 * Cout * 2 < (1ll << 31),
+                 "conv3x3_split_fwd: operand exceeds the 2 GiB buffer-resource range");
+    SpArgs a{x, x_bs, (const __bf16*)wq, z, z_bs, B, Cin, Cout, H, W, 0, 0, 0, stats};
+    if (stats) {
+        ONET_REQUIRE(split_nparts(B, H, W) > 0, "conv3x3_split_fwd_stats: the map must be made of full 16 x 32 tiles");
+        return launch_split<true>(a, as_stream(stream));
+    }
+    return launch_split<false>(a, as_stream(stream));
+}
+
+}  // namespace
+
+extern "C" {
+
+int onet_conv3x3_split_pack_weights(const float* w, void* wq_fwd, void* wq_dgrad, int Cout, int Cin, void* stream) {
+    ONET_REQUIRE(w && (wq_fwd || wq_dgrad), "conv3x3_split_pack_weights: null pointer");
+    ONET_REQUIRE(Cout > 0 && Cin > 0, "conv3x3_split_pack_weights: bad shape");
+    ONET_REQUIRE(!wq_fwd || (Cin % 16) == 0, "conv3x3_split_pack_weights: the forward pack needs Cin %% 16 == 0");
+    const int64_t n = (int64_t)std::max(Cin, ((Cout + 15) / 16) * 16) * 9 * std::max(Cin, Cout);
+    const int blocks = (int)std::min<int64_t>((n + 255) / 256, 8192);
+    if (wq_fwd) {
+        hipLaunchKernelGGL(pack3x3_split_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, (__bf16*)wq_fwd, Cout, Cin, 0);
+        int rc = check_launch("pack3x3_split_kernel");
+        if (rc) return rc;
+    }
+    if (wq_dgrad) hipLaunchKernelGGL(pack3x3_split_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, (__bf16*)wq_dgrad, Cout, Cin, 1);
+    return check_launch("pack3x3_split_kernel");
+}
+
+int onet_conv3x3_split_fwd(const float* x, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin, int Cout, int H,
+                           int W, void* stream) {
+    return split_fwd(x, x_bs, wq, z, z_bs, B, Cin, Cout, H, W, stream, nullptr);
+}
+
+int onet_conv3x3_split_nparts(int B, int H, int W) { return split_nparts(B, H, W); }
+
+int onet_conv3x3_split_fwd_stats(const float* x, int64_t x_bs, const void* wq, float* z, int64_t z_bs, float* part, int B, int Cin,
+                                 int Cout, int H, int W, void* stream) {
+    ONET_REQUIRE(part, "conv3x3_split_fwd_stats: null pointer");
+    return split_fwd(x, x_bs, wq, z, z_bs, B, Cin, Cout, H, W, stream, part);
+}
+
+}  // extern "C"

@@ -500,6 +500,10 @@ static __device__ __forceinline__ void wino4_body(const Wino4Args& a, float* sme
         avA[0] = lds_a(0u, 0);
         avA[1] = lds_a(0u, 1);
     }
+    // step 0 commits the inputs of chunk 2 into X[0] at its position 6 -- the buffer every wave has just read chunk 0 from.  In
+    // the steady state a chunk barrier separates those two; here this one does (without it a wave held up in its prologue read
+    // chunk 2's inputs as chunk 0: sporadic wrong tiles, found by tools/w4big.py at 128 input channels)
+    __syncthreads();
     const int nch = (a.Cin + CI_T - 1) / CI_T;
     int c = 0;
     for (; c + 2 <= nch; c += 2) {

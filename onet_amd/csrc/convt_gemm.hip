@@ -29,9 +29,6 @@ using namespace onet;
 #ifndef ONET_GEMM_SPREAD
 #define ONET_GEMM_SPREAD 0
 #endif
-#ifndef ONET_GEMM_ABL       // experiments: 1 = no MFMAs (fragment reads kept alive): the data-movement floor of the structure
-#define ONET_GEMM_ABL 0
-#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4g __attribute__((ext_vector_type(4)));
@@ -247,7 +244,6 @@ __global__ __launch_bounds__(256, 2) void convt_gemm_kernel(GArgs g) {
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    if (ONET_GEMM_ABL == 1) { acc[t][u][0] += av[t] * bv[u]; continue; }
                     acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[u], acc[t][u], 0, 0, 0);
                 }
         }
