@@ -204,7 +204,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=32, help="images per GPU (weak scaling)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--chans", type=int, default=1)
-    ap.add_argument("--conv", default=None, choices=["auto", "bf16", "winograd4", "winograd", "direct"],
+    ap.add_argument("--conv", default=None, choices=["auto", "split", "bf16", "winograd4", "winograd", "direct"],
                     help="ops.CONV_ALGO for this run (default: ONET_CONV_ALGO or auto = the fp32 kernels); bf16 = BASELINE "
                          "config 3's bf16-operand MFMA path for forward / input gradient")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -288,9 +288,10 @@ def main(args):
     if rank == 0:
         # multiplies the algorithm issues relative to direct convolution: F(4x4,3x3) 36 per 16 outputs x 9 taps -> 1/4,
         # F(2x2,3x3) 16 per 4 x 9 -> 1/2.25 (the weight-gradient kernels F(3x3,4x4) / F(3x3,2x2) likewise)
+        # (the split-bf16 kernels issue THREE bf16 MFMAs per product term of the direct algorithm: 1/3)
         REDUCTION = {"conv_wino4_kernel": 4.0, "conv_wino_kernel": 2.25, "conv_wino_wgrad_kernel": 2.25,
-                     "conv_wino4_wgrad_kernel": 4.0}
-        BF16 = ("conv3x3_bf16_kernel", "conv3x3_wgrad_bf16_kernel")
+                     "conv_wino4_wgrad_kernel": 4.0, "conv3x3_split_kernel": 1.0 / 3.0, "conv3x3_split_wgrad_kernel": 1.0 / 3.0}
+        BF16 = ("conv3x3_bf16_kernel", "conv3x3_wgrad_bf16_kernel", "conv3x3_split_kernel", "conv3x3_split_wgrad_kernel")
         if bf16 and ops.CONVT_BF16:     # the ConvTranspose2d GEMMs take bf16 operands too (priced against the bf16 peak)
             BF16 += ("convt_gemm_kernel", "convt_wgrad_gemm_kernel")
         ALGO = {"conv_wino_kernel": "Winograd F(2x2,3x3) on fp32 MFMA (fwd + dgrad)",
@@ -299,6 +300,10 @@ def main(args):
                 "conv_wino_wgrad_kernel": "Winograd F(2x2,3x3) weight gradient on fp32 MFMA, deterministic split-K",
                 "conv_wino4_wgrad_kernel": "Winograd F(3x3,4x4) weight gradient on fp32 MFMA, deterministic split-K",
                 "conv3x3_bf16_kernel": "direct implicit GEMM on v_mfma_f32_32x32x16_bf16 (bf16 operands, fp32 accumulate)",
+                "conv3x3_split_kernel": "fp32 convolution (fwd + dgrad) on the bf16 matrix cores by operand splitting: x = hi + mid, "
+                                        "w = hi + mid in bf16, 3 x v_mfma_f32_32x32x16_bf16 per term, fp32 accumulate; error <= the "
+                                        "fp32 Winograd F(4x4) kernel's",
+                "conv3x3_split_wgrad_kernel": "fp32 weight gradient on the bf16 matrix cores by operand splitting, deterministic split-K",
                 "conv3x3_wgrad_bf16_kernel": "split-K weight gradient on v_mfma_f32_32x32x16_bf16",
                 "conv_fwd_kernel": "direct implicit GEMM on fp32 MFMA (stem, tiny maps)",
                 "conv_wgrad_kernel": "direct split-K weight gradient on fp32 MFMA (stem, tiny maps)",

@@ -164,6 +164,28 @@ int onet_convT2x2_fwd_b(const float* x, int64_t x_bs, const float* wq, const flo
 int onet_conv3x3_bf16_fwd_b(const void* x_bf16, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin,
                             int Cout, int H, int W, void* stream);
 
+/* ---- fp32 3x3 convolution on the bf16 matrix cores by OPERAND SPLITTING (conv_split.hip; F.conv2d + input gradient, OV:47,51).
+ * x = x_hi + x_mid, w = w_hi + w_mid with bf16 parts (hi = round-to-nearest-even, mid = bf16 of the remainder: 16 significant
+ * bits together); z = conv(x_hi, w_hi) + conv(x_hi, w_mid) + conv(x_mid, w_hi) on v_mfma_f32_32x32x16_bf16 with fp32
+ * accumulation: fp32 tensors in, fp32 out, error of the split 1e-6 rms of the output scale (below the fp32 Winograd F(4x4)
+ * kernel's), three MFMAs per product term at 16x the fp32 MFMA rate.  wq_fwd [Cin/16][2 parts][9][2][Cout][8] bf16 (2 * 9 * Cin *
+ * Cout elements), wq_dgrad [ceil(Cout/16)][2][9][2][Cin][8] with the taps rotated; either may be NULL.  Requires Cin % 16 == 0 and
+ * W > 16.  _fwd_stats also writes one BatchNorm record (n, mean, M2) per channel and 16 x 32-pixel tile: part [Cout][nparts][3],
+ * nparts = onet_conv3x3_split_nparts(B, H, W) (0: the map is not made of full tiles). */
+int onet_conv3x3_split_pack_weights(const float* w, void* wq_fwd, void* wq_dgrad, int Cout, int Cin, void* stream);
+int onet_conv3x3_split_fwd(const float* x, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin, int Cout, int H,
+                           int W, void* stream);
+int onet_conv3x3_split_nparts(int B, int H, int W);
+int onet_conv3x3_split_fwd_stats(const float* x, int64_t x_bs, const void* wq, float* z, int64_t z_bs, float* part, int B, int Cin,
+                                 int Cout, int H, int W, void* stream);
+/* Weight gradient of the same convolution with both operands (x, dz: fp32 NCHW) split the same way, three MFMAs per term;
+ * row-streaming units (one image row of a 64-pixel strip), deterministic split-K through ws (onet_conv3x3_split_wgrad_ws_bytes).
+ * _ok: 1 where the kernel takes the shape (W >= 64, W % 4 == 0); 16-byte aligned image rows (x_bs, dz_bs % 4 == 0). */
+int onet_conv3x3_split_wgrad_ok(int B, int Cin, int Cout, int H, int W);
+int64_t onet_conv3x3_split_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W);
+int onet_conv3x3_split_wgrad(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs, float* dw, void* ws, int64_t ws_bytes,
+                             int B, int Cin, int Cout, int H, int W, int accumulate, void* stream);
+
 /* The stem: first 3x3 convolution of the U-Net (F.conv2d of `inc`, OV:47, Cin = n_channels in 1..4, no bias) and the batch
  * statistics of its BatchNorm (OV:48) in one streaming pass.  w: the nn.Conv2d weight [Cout][Cin][3][3] as it is (no pack);
  * part [Cout][nparts][3] = (n, mean, M2) per 16 x 64-pixel tile for onet_bn_finalize_cm, or NULL (convolution only).

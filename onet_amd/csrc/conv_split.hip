@@ -30,6 +30,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+typedef float f32x4s __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -196,22 +197,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
 
     float xin[NIT][8];
     u32x4s wv[NWI];
-    auto issue = [&]() __attribute__((always_inline)) {
+    // staging pieces: input round k (8 plane loads -> 2 slots), weight round k (one 16-byte load -> 1 slot)
+    auto issue_in = [&](int k0, int k1) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < NIT; ++k)
+            if (k >= k0 && k < k1)
 #pragma unroll
-            for (int c = 0; c < 8; ++c)
-                // the chunk / plane part of the address is wave-uniform: it rides in the instruction's scalar offset; the
-                // per-lane part alone decides the range check (OOB_S -> 0)
-                xin[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, in_off[k], (int)(cin_bytes + c * plane), 0));
+                for (int c = 0; c < 8; ++c)
+                    // the chunk / plane part of the address is wave-uniform: it rides in the instruction's scalar offset; the
+                    // per-lane part alone decides the range check (OOB_S -> 0)
+                    xin[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, in_off[k], (int)(cin_bytes + c * plane), 0));
+    };
+    auto issue_w = [&](int k0, int k1) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 0; k < NWI; ++k) wv[k] = __builtin_amdgcn_raw_buffer_load_b128(wr, w_off[k], (int)cw_bytes, 0);
+        for (int k = 0; k < NWI; ++k)
+            if (k >= k0 && k < k1) wv[k] = __builtin_amdgcn_raw_buffer_load_b128(wr, w_off[k], (int)cw_bytes, 0);
     };
     u32x4s* const w_st = lds + tid;                                     // + 512 k          (+ buffer * BUF)
     u32x4s* const in_st = lds + C::W_SLOTS + kh * NPIXP + wn * 32 + l31;   // + 256 k, + IN_PART for the mid part
-    auto commit = [&](int buf) __attribute__((always_inline)) {
+    auto commit_in = [&](int buf, int k0, int k1) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
+            if (k < k0 || k >= k1) continue;
             if (wn + C::NW * k >= C::NROUND) continue;                   // (wave-uniform) the last round exists for waves 0..3 only
             u32x4s hi, mid;
 #pragma unroll
@@ -224,9 +231,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
             in_st[buf * BUF + 256 * k] = hi;
             in_st[buf * BUF + 256 * k + IN_PART] = mid;
         }
+    };
+    auto commit_w = [&](int buf, int k0, int k1) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < NWI; ++k)
-            if (tid + 512 * k < C::W_SLOTS) w_st[buf * BUF + 512 * k] = wv[k];
+            if (k >= k0 && k < k1 && tid + 512 * k < C::W_SLOTS) w_st[buf * BUF + 512 * k] = wv[k];
     };
 
     // fragments: A (weights) slot = part * W_PART + (tap * 2 + kh) * 64 + m * 32 + l31;
@@ -235,10 +244,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
     const u32x4s* const b_ptr = lds + C::W_SLOTS + kh * NPIXP + (wn * NT) * IN_COLS + l31;
 
     setup_stage();
-    issue();
-    commit(0);
+    issue_in(0, NIT);
+    issue_w(0, NWI);
+    commit_in(0, 0, NIT);
+    commit_w(0, 0, NWI);
     advance();
-    issue();                                         // second chunk (or the first of the next tile)
+    issue_in(0, NIT);                                // second chunk (or the first of the next tile)
+    issue_w(0, NWI);
     __syncthreads();
     int buf = 0;
     for (int tile = t_first; tile < t_end; tile += t_stride) {
@@ -286,12 +298,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
                             Bq[(kx + 1) & 1][j][1] = bb[j * IN_COLS + kx + 1 + IN_PART];
                         }
                 }
-                if (idx == 4) {
-                    // the other buffer was last read one chunk ago (barrier since): the chunk after this one goes in, and the
-                    // loads of the one after that take over the staging registers
-                    commit(buf ^ 1);
-                    advance();
-                    issue();
+                // Staging, spread over the taps so that no wave sits in a burst of 29 VMEM issues while its SIMD partner does the
+                // same: the other buffer was last read one chunk ago (barrier since), so the chunk after this one goes in piece
+                // by piece -- and as soon as a piece's registers are committed they take the loads of the chunk after that
+                // (every load keeps a full chunk of MFMAs between issue and use).  Inputs: rounds 0, 1, 2 at taps 0, 2, 4; weights:
+                // taps 1, 3, 5, 6, 7.
+                if (idx == 0) advance();
+                if (idx == 0 || idx == 2 || idx == 4) {
+                    commit_in(buf ^ 1, idx / 2, idx / 2 + 1);
+                    issue_in(idx / 2, idx / 2 + 1);
+                }
+                if (idx == 1 || idx == 3 || idx >= 5) {
+                    const int kw = idx == 1 ? 0 : idx == 3 ? 1 : idx - 3;
+                    if (kw < NWI) {
+                        commit_w(buf ^ 1, kw, kw + 1);
+                        issue_w(kw, kw + 1);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const int tap = ky * 3 + kx;
@@ -429,9 +451,230 @@ int split_fwd(const float* x, int64_t x_bs, const void* wq, float* z, int64_t z_
     return launch_split<false>(a, as_stream(stream));
 }
 
+
+// ------------------------------------------------------------------ weight gradient, split operands
+//   dW[co][ci][ky][kx] = sum_{b,y,x} dz[b][co][y][x] * X[b][ci][y+ky-1][x+kx-1]:  M = co, N = ci, K = pixels, one accumulator per
+//   tap, v_mfma_f32_32x32x16_bf16 with the 8 K-values of a lane = 8 consecutive pixels of one channel row.  The row-streaming
+//   structure of conv3x3_wgrad_bf16_row_kernel (conv_bf16.hip): a unit is ONE image row of a 64-pixel strip -- dz [64 co][64 px],
+//   x rows y-1, y, y+1 [64 ci][66 px] in a 4-slot ring, a block walks down its strip and loads one new row of each operand per
+//   unit as whole 128-byte lines -- with both operands split on the way into LDS (hi | mid parts of dz and of x) and three MFMAs
+//   per (16-pixel segment, tap): dz_mid x_hi + dz_hi x_mid + dz_hi x_hi.  110 KB of LDS: one block per CU, of EIGHT waves -- two
+//   groups of four that split a unit's four segments between them and keep their own accumulators (a split over K inside the
+//   block: 4 waves at one per SIMD had nothing to cover the barrier, the commit and the fragment reads, 0.33 of the bf16 peak);
+//   54 MFMAs per wave and unit.  Split-K over (image, strip, row) units, raw slabs [split][tap][co][ci] reduced deterministically by
+//   wgrad_reduce_kernel (conv_mfma.hip).  Requires W >= 64, W % 4 == 0.
+struct SwArgs {
+    const float* x;
+    int64_t x_bs;
+    const float* dz;
+    int64_t dz_bs;
+    float* slab;
+    int B, Cin, Cout, H, W, ciTiles, coTiles, splitK, tilesX;
+};
+
+constexpr int SR_SDZ = 36, SR_SX = 148, SR_SLOT = 36;      // dword strides: per co; per ci (4 x odd); per ring slot
+constexpr int SR_DZ_PART = 64 * SR_SDZ, SR_X_PART = 64 * SR_SX;
+
+__global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned dz_lds[2 * 2 * SR_DZ_PART];     // [buf][part][64 co][SR_SDZ]
+    __shared__ __attribute__((aligned(16))) unsigned x_lds[2 * SR_X_PART];           // [part][64 ci][SR_SX]
+
+    int bid;
+    {
+        const int n = gridDim.x, q = n >> 3, r = n & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int tiles = a.ciTiles * a.coTiles;
+    const int ks = bid / tiles, tile = bid % tiles;
+    const int ci0 = (tile % a.ciTiles) * 64, co0 = (tile / a.ciTiles) * 64;
+    const int nunits = a.B * a.tilesX * a.H;                   // unit = (image, 64-pixel strip, row), rows fastest
+    const int per = (nunits + a.splitK - 1) / a.splitK;
+    const int u0 = ks * per, u1 = min(u0 + per, nunits);
+
+    // 8 waves = 2 pixel groups x (2 x 2) quadrants of the 64 co x 64 ci tile: group g takes the 16-pixel segments 2g, 2g + 1 of
+    // every unit (a split over K inside the block: two waves per SIMD, each group writes its own slab)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int grp = wid >> 2, wm = (wid >> 1) & 1, wn = wid & 1;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int HW = a.H * a.W;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // staging roles: thread = (channel = tid / 8, 8-pixel segment = tid % 8) of the dz row and of the x row
+    const int st_c = tid >> 3, st_s = tid & 7;
+    u32x4s dzv[2], xq[2];
+    float xh[2];
+    // loads of one dz row and / or one x row of strip (b, x0): row < 0 or >= H -> zeros
+    auto issue_dz = [&](int b, int x0, int y) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t dr = s_rsrc(a.dz + (int64_t)b * a.dz_bs, (int64_t)a.Cout * HW * 4);
+        const int xs = x0 + 8 * st_s;
+        const bool ok = y >= 0 && y < a.H && co0 + st_c < a.Cout;
+        const unsigned base = (unsigned)(((co0 + st_c) * HW + y * a.W + xs) * 4);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) dzv[k] = __builtin_amdgcn_raw_buffer_load_b128(dr, (ok && xs + 4 * k < a.W) ? base + 16 * k : OOB_S, 0, 0);
+    };
+    auto issue_x = [&](int b, int x0, int y) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t xr = s_rsrc(a.x + (int64_t)b * a.x_bs, (int64_t)a.Cin * HW * 4);
+        const int xs = x0 + 8 * st_s;
+        const bool ok = y >= 0 && y < a.H && ci0 + st_c < a.Cin;
+        const unsigned base = (unsigned)(((ci0 + st_c) * HW + y * a.W + xs) * 4);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) xq[k] = __builtin_amdgcn_raw_buffer_load_b128(xr, (ok && xs + 4 * k < a.W) ? base + 16 * k : OOB_S, 0, 0);
+        xh[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (ok && xs > 0 && xs - 1 < a.W) ? base - 4 : OOB_S, 0, 0));
+        xh[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (ok && st_s == 7 && xs + 8 < a.W) ? base + 32 : OOB_S, 0, 0));
+    };
+    auto commit_dz = [&](int buf) __attribute__((always_inline)) {
+        unsigned* d = dz_lds + buf * 2 * SR_DZ_PART + st_c * SR_SDZ + st_s * 4;
+        // (the whole vector is re-typed, then indexed: element-wise bit casts of the loaded vector's lanes came out as four
+        // copies of lane 0 with hipcc 7.2 -- found with delta-function inputs)
+        const f32x4s lo = __builtin_bit_cast(f32x4s, dzv[0]), hv = __builtin_bit_cast(f32x4s, dzv[1]);
+        const float f[8] = {lo[0], lo[1], lo[2], lo[3], hv[0], hv[1], hv[2], hv[3]};
+        u32x4s hi, mid;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            unsigned hh, mm;
+            split2(f[2 * c], f[2 * c + 1], hh, mm);
+            hi[c] = hh;
+            mid[c] = mm;
+        }
+        *reinterpret_cast<u32x4s*>(d) = hi;
+        *reinterpret_cast<u32x4s*>(d + SR_DZ_PART) = mid;
+    };
+    // row element e = column x0 - 1 + e; dword p = (e[2p], e[2p+1]) = (f[2p-1], f[2p]) of the interior row f: an 8-pixel segment's
+    // four dwords start with (pixel left of the segment, its first pixel); its last pixel opens the next segment's first dword
+    // (loaded there as that segment's left neighbour); the strip's last dword (f[63], right halo) is segment 7's
+    auto commit_x = [&](int slot) __attribute__((always_inline)) {
+        unsigned* row = x_lds + st_c * SR_SX + slot * SR_SLOT + st_s * 4;
+        const f32x4s f0 = __builtin_bit_cast(f32x4s, xq[0]), f1 = __builtin_bit_cast(f32x4s, xq[1]);
+        const float e[10] = {xh[0], f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3], xh[1]};
+        unsigned hi[5], mid[5];
+#pragma unroll
+        for (int p2 = 0; p2 < 5; ++p2) split2(e[2 * p2], e[2 * p2 + 1], hi[p2], mid[p2]);
+        *reinterpret_cast<u32x4s*>(row) = u32x4s{hi[0], hi[1], hi[2], hi[3]};
+        *reinterpret_cast<u32x4s*>(row + SR_X_PART) = u32x4s{mid[0], mid[1], mid[2], mid[3]};
+        if (st_s == 7) {
+            row[4] = hi[4];
+            row[SR_X_PART + 4] = mid[4];
+        }
+    };
+
+    const unsigned* a_ptr = dz_lds + (wm * 32 + l31) * SR_SDZ + kh * 4 + grp * 16;
+    const unsigned* b_ptr = x_lds + (wn * 32 + l31) * SR_SX + kh * 4 + grp * 16;
+
+    int u = u0;
+    while (u < u1) {
+        // a run of rows inside one strip: y = yb .. ye - 1
+        const int yb = u % a.H, sb = u / a.H;
+        const int tx = sb % a.tilesX, b = sb / a.tilesX;
+        const int x0 = tx * 64;
+        const int ye = min(a.H, yb + (u1 - u));
+        // run prologue: rows yb - 1 and yb of x into the ring (synchronously), then the dz row and the next x row of the first unit
+        __syncthreads();                              // every wave is done with the previous run's ring and dz buffers
+        issue_x(b, x0, yb - 1);
+        commit_x((yb - 1) & 3);
+        issue_x(b, x0, yb);
+        commit_x(yb & 3);
+        issue_dz(b, x0, yb);
+        issue_x(b, x0, yb + 1);
+        for (int y = yb; y < ye; ++y) {
+            const int buf = y & 1;
+            commit_dz(buf);
+            commit_x((y + 1) & 3);                    // slot of row y - 3: last read two barriers ago
+            __syncthreads();
+            if (y + 1 < ye) {
+                issue_dz(b, x0, y + 1);
+                issue_x(b, x0, y + 2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned* ab = a_ptr + buf * 2 * SR_DZ_PART;
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg) {
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4s*>(ab + sg * 8));
+                const bf16x8 am = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4s*>(ab + SR_DZ_PART + sg * 8));
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const unsigned* br = b_ptr + ((y - 1 + ky) & 3) * SR_SLOT + sg * 8;
+                    u32x4s sh[2][3];                  // [part][horizontal shift]
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt) {
+                        const u32x4s q = *reinterpret_cast<const u32x4s*>(br + pt * SR_X_PART);
+                        const unsigned d4 = br[pt * SR_X_PART + 4];
+                        sh[pt][0] = q;
+                        sh[pt][1] = u32x4s{__builtin_amdgcn_alignbit(q[1], q[0], 16), __builtin_amdgcn_alignbit(q[2], q[1], 16),
+                                           __builtin_amdgcn_alignbit(q[3], q[2], 16), __builtin_amdgcn_alignbit(d4, q[3], 16)};
+                        sh[pt][2] = u32x4s{q[1], q[2], q[3], d4};
+                    }
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const bf16x8 bh = __builtin_bit_cast(bf16x8, sh[0][j]), bm = __builtin_bit_cast(bf16x8, sh[1][j]);
+                        acc[ky * 3 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[ky * 3 + j], 0, 0, 0);
+                        acc[ky * 3 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[ky * 3 + j], 0, 0, 0);
+                        acc[ky * 3 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[ky * 3 + j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        u += ye - yb;
+    }
+
+    const int64_t n = (int64_t)a.Cout * a.Cin;
+    const int ci = ci0 + wn * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float* o = a.slab + ((int64_t)(ks * 2 + grp) * 9 + t) * n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (co < a.Cout && ci < a.Cin) o[(int64_t)co * a.Cin + ci] = acc[t][r];
+        }
+    }
+}
+
+void split_wgrad_plan(int B, int Cin, int Cout, int H, int W, int& splitK, int& tilesX) {
+    tilesX = cdiv(W, 64);
+    const int64_t units = (int64_t)B * H * tilesX;
+    const int tiles = cdiv(Cin, 64) * cdiv(Cout, 64);
+    int64_t k = std::max<int64_t>(1, device_cu_count() / tiles);    // one 4-wave block per CU (110 KB of LDS), one round
+    k = std::min<int64_t>(k, std::max<int64_t>(1, units / 16));      // at least 16 rows per block
+    splitK = (int)k;
+}
+
 }  // namespace
 
 extern "C" {
+
+int onet_conv3x3_split_wgrad_ok(int B, int Cin, int Cout, int H, int W) {
+    return (B > 0 && Cin > 0 && Cout > 0 && H > 0 && W >= 64 && (W & 3) == 0) ? 1 : 0;
+}
+
+int64_t onet_conv3x3_split_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W) {
+    int splitK, tx;
+    split_wgrad_plan(B, Cin, Cout, H, W, splitK, tx);
+    return (int64_t)splitK * 2 * 9 * Cout * Cin * 4;       // two pixel groups per block, a slab each
+}
+
+int onet_conv3x3_split_wgrad(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs, float* dw, void* ws, int64_t ws_bytes,
+                             int B, int Cin, int Cout, int H, int W, int accumulate, void* stream) {
+    ONET_REQUIRE(x && dz && dw && ws, "conv3x3_split_wgrad: null pointer");
+    ONET_REQUIRE(onet_conv3x3_split_wgrad_ok(B, Cin, Cout, H, W), "conv3x3_split_wgrad: needs W >= 64 and W %% 4 == 0 (use onet_conv3x3_winograd_wgrad)");
+    ONET_REQUIRE((x_bs & 3) == 0 && (dz_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dz) & 15) == 0,
+                 "conv3x3_split_wgrad: 16-byte aligned image rows required");
+    ONET_REQUIRE(x_bs >= (int64_t)Cin * H * W && dz_bs >= (int64_t)Cout * H * W, "conv3x3_split_wgrad: batch stride too small");
+    ONET_REQUIRE((int64_t)std::max(Cin, Cout) * H * W * 4 < (1ll << 31), "conv3x3_split_wgrad: image exceeds the 2 GiB buffer-resource range");
+    SwArgs a{x, x_bs, dz, dz_bs, (float*)ws, B, Cin, Cout, H, W, cdiv(Cin, 64), cdiv(Cout, 64), 1, 1};
+    split_wgrad_plan(B, Cin, Cout, H, W, a.splitK, a.tilesX);
+    const int64_t need = (int64_t)a.splitK * 2 * 9 * Cout * Cin * 4;
+    ONET_REQUIRE(ws_bytes >= need, "conv3x3_split_wgrad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
+    const int64_t blocks = (int64_t)a.splitK * a.ciTiles * a.coTiles;
+    hipLaunchKernelGGL(conv3x3_split_wgrad_kernel, dim3((unsigned)blocks), dim3(512), 0, as_stream(stream), a);
+    int rc = check_launch("conv3x3_split_wgrad_kernel");
+    if (rc) return rc;
+    return launch_wgrad_reduce((const float*)ws, dw, a.splitK * 2, 9, Cout, Cin, 0, accumulate, as_stream(stream));
+}
 
 int onet_conv3x3_split_pack_weights(const float* w, void* wq_fwd, void* wq_dgrad, int Cout, int Cin, void* stream) {
     ONET_REQUIRE(w && (wq_fwd || wq_dgrad), "conv3x3_split_pack_weights: null pointer");

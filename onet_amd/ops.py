@@ -313,8 +313,10 @@ def convT2x2_fwd(x, wq, bias, out, Ct, pt, pl, out16=None):
 
 
 # 3x3 convolution algorithm for fwd/dgrad, chosen per call from the layer shape (ONET_CONV_ALGO overrides):
-#   "auto" (default)  Winograd F(4x4,3x3) where its 64-channel x 32-tile blocks fill the chip, else F(2x2,3x3),
-#                     else the direct implicit-GEMM kernel
+#   "auto" (default)  the split-bf16 kernel (fp32 accuracy on the bf16 matrix cores, conv_split.hip) on maps at least 32 pixels wide
+#                     with Cin % 16 == 0 and enough tiles to fill the chip; else Winograd F(4x4,3x3) where its 64-channel x
+#                     32-tile blocks fill the chip, else F(2x2,3x3), else the direct implicit-GEMM kernel
+#   "split"           the split-bf16 kernel on every legal layer (parity tests)
 #   "winograd4"       F(4x4,3x3) on every legal layer with maps >= 8x8 (parity tests)      "winograd" / "winograd2"  F(2x2,3x3)
 #   "direct"          implicit GEMM only
 #   "bf16"            BASELINE config 3: bf16-operand MFMA kernel (conv_bf16.hip) for forward / input gradient on every
@@ -411,12 +413,26 @@ def _in_buffer_range(Cin, Cout, H, W):
     return (2 * max(Cin, Cout) + 16) * H * W * 4 < 2 ** 31 and (max(Cin, Cout) + 16) * 36 * (max(Cin, Cout) + 63) * 4 < 2 ** 31
 
 
+def _split_legal(Cin, Cout, H, W):
+    return Cin % 16 == 0 and W > 16 and H >= 8
+
+
 def conv3x3_algo(B, Cin, Cout, H, W):
-    """-> "winograd4" | "winograd" | "direct" for a conv with Cin inputs and Cout outputs on B maps of H x W."""
+    """-> "split" | "winograd4" | "winograd" | "direct" | "bf16" for a conv with Cin inputs and Cout outputs on B maps of H x W."""
     algo = conv_algo()
     algo = "winograd" if algo == "winograd2" else algo
-    if algo in ("bf16", "winograd4", "auto") and not _in_buffer_range(Cin, Cout, H, W):
+    if algo in ("bf16", "winograd4", "auto", "split") and not _in_buffer_range(Cin, Cout, H, W):
         algo = "winograd"
+    if algo == "split":
+        if _split_legal(Cin, Cout, H, W):
+            return "split"
+        algo = "auto_nosplit"
+    if algo == "auto" and SPLIT_AUTO and _split_legal(Cin, Cout, H, W):
+        # persistent 8-wave blocks, one per CU, tiles of 64 channels x 16 rows x 32 pixels: worth it once every CU gets a tile
+        if B * -(-H // 16) * -(-W // 32) * -(-Cout // 64) >= (n_cu() * 3) // 4:
+            return "split"
+    if algo == "auto_nosplit":
+        algo = "auto"
     if algo == "bf16":
         if Cin % 16 == 0 and Cout % 4 == 0 and W >= 16 and H >= 8:
             return "bf16"
@@ -455,7 +471,7 @@ class Packed3x3(dict):
     def get_pack(self, algo):
         if algo not in self:
             self[algo] = {"direct": pack3x3, "winograd": pack3x3_winograd, "winograd4": pack3x3_winograd4,
-                          "bf16": pack3x3_bf16}[algo](self.w)
+                          "bf16": pack3x3_bf16, "split": pack3x3_split}[algo](self.w)
         return self[algo]
 
 
@@ -474,6 +490,8 @@ def conv3x3_auto(x, pk, direction, out=None, x16=None):
     wq = pk.get_pack(algo)[direction]
     if algo == "winograd4":
         return conv3x3_winograd4(x, wq, Co, out=out)
+    if algo == "split":
+        return conv3x3_split(x, wq, Co, out=out)
     if algo == "bf16":
         return conv3x3_bf16(x, wq, Co, out=out, x16=x16)
     if algo == "winograd":
@@ -482,6 +500,7 @@ def conv3x3_auto(x, pk, direction, out=None, x16=None):
 
 
 FUSE_BN_STATS = _os.environ.get("ONET_FUSE_BN_STATS", "1") != "0"
+SPLIT_AUTO = _os.environ.get("ONET_SPLIT", "1") != "0"          # 0: "auto" never selects the split-bf16 kernel (round-2 dispatch)
 STEM_FUSED = _os.environ.get("ONET_STEM_FUSED", "1") != "0"      # 0: the stem takes the direct MFMA kernel + a statistics pass
 
 
@@ -526,6 +545,18 @@ def conv3x3_fwd_bn_partials(x, pk, x16=None):
                       B * H * W * ((2.0 if x16p is not None else 4.0) * Ci + 4.0 * Co) + 18.0 * Ci * Co)
             return out, cm
         nparts = 0
+    if algo == "split" and FUSE_BN_STATS and not SYNC_BN and x is not None:
+        nparts = int(_lib.load().onet_conv3x3_split_nparts(B, H, W))
+        if nparts > 0:
+            wq = pk.get_pack(algo)[0]
+            require_gpu(x)
+            xs, xbs = plane(x)
+            out = torch.empty((B, Co, H, W), dtype=F32, device=x.device)
+            cm = torch.empty((Co, nparts, 3), dtype=F32, device=x.device)
+            e0 = _prof_begin()
+            _lib.call("onet_conv3x3_split_fwd_stats", _p(xs), xbs, _p(wq), _p(out), Co * H * W, _p(cm), B, Ci, Co, H, W, _stream())
+            _prof_end("conv3x3_split_kernel", 2.0 * B * H * W * Ci * Co * 9, e0, 4.0 * (B * H * W * (Ci + Co) + 9 * Ci * Co))
+            return out, cm
     if nparts <= 0:
         return conv3x3_auto(x, pk, 0, x16=x16), None
     wq = pk.get_pack(algo)[0]
@@ -665,6 +696,57 @@ def conv3x3_bf16(x, wq, Cout, out=None, x16=None):
     return out
 
 
+def pack3x3_split(w):
+    """bf16 (hi, mid) packs of a 3x3 weight for conv_split.hip: (fwd [Cin/16][2][9][2][Cout][8], dgrad [ceil(Cout/16)][2][9][2][Cin][8]);
+    a pack whose reduction dimension is not a multiple of 16 on the forward side is None."""
+    require_gpu(w)
+    w = w.detach().contiguous()
+    Cout, Cin = w.shape[0], w.shape[1]
+    wf = torch.empty(2 * Cin * 9 * Cout, dtype=BF, device=w.device) if Cin % 16 == 0 else None
+    wd = torch.empty(2 * (-(-Cout // 16) * 16) * 9 * Cin, dtype=BF, device=w.device)
+    _lib.call("onet_conv3x3_split_pack_weights", _p(w), _p(wf), _p(wd), Cout, Cin, _stream())
+    return wf, wd
+
+
+def conv3x3_split(x, wq, Cout, out=None):
+    """z = conv3x3(x) in fp32 accuracy on the bf16 matrix cores (operands split into two bf16 parts, three MFMAs per term)."""
+    if wq is None or not wq.is_cuda or wq.dtype != torch.bfloat16:
+        raise TypeError("conv3x3_split: wq must be a split pack on the GPU (pack3x3_split)")
+    require_gpu(x)
+    x, xbs = plane(x)
+    B, Cin, H, W = x.shape
+    if out is None:
+        out = torch.empty((B, Cout, H, W), dtype=F32, device=x.device)
+    zbs = out.stride(0) if B > 1 else Cout * H * W
+    e0 = _prof_begin()
+    _lib.call("onet_conv3x3_split_fwd", _p(x), xbs, _p(wq), _p(out), zbs, B, Cin, Cout, H, W, _stream())
+    _prof_end("conv3x3_split_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
+    return out
+
+
+def split_wgrad_ok(x, dz):
+    B, Cin, H, W = x.shape
+    return bool(_lib.load().onet_conv3x3_split_wgrad_ok(B, Cin, dz.shape[1], H, W)) and \
+        x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and dz.is_contiguous() and dz.data_ptr() % 16 == 0 and \
+        max(Cin, dz.shape[1]) * H * W * 4 < 2 ** 31
+
+
+def conv3x3_split_wgrad(x, dz, dw_shape, out=None):
+    """dW of a 3x3 convolution in fp32 accuracy on the bf16 matrix cores (conv_split.hip: both operands split, three MFMAs per term)."""
+    require_gpu(x, dz)
+    x, xbs = plane(x)
+    dz, dzbs = plane(dz)
+    B, Cin, H, W = x.shape
+    Cout = dz.shape[1]
+    dw = torch.empty(dw_shape, dtype=F32, device=x.device) if out is None else out
+    need = _lib.load().onet_conv3x3_split_wgrad_ws_bytes(B, Cin, Cout, H, W)
+    ws = workspace(need, x.device)
+    e0 = _prof_begin()
+    _lib.call("onet_conv3x3_split_wgrad", _p(x), xbs, _p(dz), dzbs, _p(dw), _p(ws), ws.numel() * 4, B, Cin, Cout, H, W, 0, _stream())
+    _prof_end("conv3x3_split_wgrad_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
+    return dw
+
+
 def grad_slot_if_free(param):
     """FlatAdam registers, per parameter, its slice of the flat gradient buffer.  When the parameter has no .grad yet
     (FlatAdam.zero_grad sets it to None) a backward kernel may write its result straight into that slice and hand the
@@ -774,6 +856,9 @@ def conv3x3_wgrad_auto(x, dz, dw_shape, out=None, x16=None, dz16=None):
     shp = (x if x is not None else x16).shape
     if wgrad_takes_bf16(Cin, shp[2], shp[3]) and (dz16 is not None or dz.is_contiguous()):
         return conv3x3_wgrad_bf16(x, dz, dw_shape, out=out, x16=x16, dz16=dz16)
+    # fp32 tensors, maps at least 64 pixels wide: the split-bf16 row kernel (the stem, Cin < 16, keeps its own VALU kernel)
+    if conv_algo() in ("auto", "split") and (SPLIT_AUTO or conv_algo() == "split") and x is not None and Cin >= 16 and split_wgrad_ok(x, dz):
+        return conv3x3_split_wgrad(x, dz, dw_shape, out=out)
     if use_winograd(Cin, Cout, x.shape[2], x.shape[3]):
         if WGRAD4 != "0" and (WGRAD4 == "1" or Cin >= 256 or (Cin >= 128 and Cout >= 256)) and winograd4_wgrad_ok(x, dz):
             return conv3x3_winograd4_wgrad(x, dz, dw_shape, out=out)

@@ -116,6 +116,64 @@ def test_conv3x3_winograd4_fwd_dgrad(dev, B, Cin, Cout, H, W):
     close(ops.conv3x3_winograd4(g.to(dev), qd, Cin), xr.grad, tol=2e-4, what="winograd4 dgrad")
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 64, 64, 24, 64), (1, 32, 128, 64, 64), (3, 16, 36, 33, 68), (2, 128, 80, 16, 192),
+                                             (5, 48, 64, 37, 128), (2, 24, 20, 9, 100)])
+def test_conv3x3_split_wgrad(dev, B, Cin, Cout, H, W):
+    """conv3x3_split_wgrad_kernel (both operands split into bf16 hi + mid, three MFMAs per term, row-streaming units,
+    deterministic split-K) against the fp64 weight gradient at 2e-5 of its scale; ragged strips (W % 64 != 0), odd heights,
+    channel tails, runs crossing image boundaries; bitwise reproducible."""
+    from onet_amd import ops
+    x = rnd(B, Cin, H, W, seed=11)
+    g = rnd(B, Cout, H, W, seed=12)
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w, None, 1, 1).backward(g.double())
+    assert ops.split_wgrad_ok(x.to(dev), g.to(dev))
+    dw = ops.conv3x3_split_wgrad(x.to(dev), g.to(dev), (Cout, Cin, 3, 3))
+    close(dw, w.grad, tol=2e-5, what="split wgrad")
+    assert torch.equal(dw, ops.conv3x3_split_wgrad(x.to(dev), g.to(dev), (Cout, Cin, 3, 3)))
+    assert not ops.split_wgrad_ok(x[..., :32].contiguous().to(dev), g[..., :32].contiguous().to(dev))      # W < 64: other kernels
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 64, 64, 40, 48), (1, 32, 128, 64, 64), (3, 16, 36, 33, 31), (2, 128, 80, 16, 96),
+                                             (9, 48, 64, 32, 32), (1, 512, 64, 17, 40)])
+def test_conv3x3_split_fwd_dgrad_stats(dev, B, Cin, Cout, H, W):
+    """conv_split.hip -- fp32 convolution on the bf16 matrix cores by operand splitting (x = hi + mid, w = hi + mid, three MFMAs
+    per term) -- against the fp64 convolution: forward and input-gradient orientation at 2e-5 of the output scale (measured
+    5e-6; the fp32 Winograd F(4x4) kernel it replaces in the default dispatch: 1e-5 .. 4e-5), ragged edges, channel tails,
+    several tiles per persistent block (B = 9), long reductions; fused BatchNorm statistics == the separate pass."""
+    from onet_amd import _lib, ops
+    x = rnd(B, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=(2.0 / (Cin * 9)) ** 0.5)
+    g = rnd(B, Cout, H, W, seed=3)
+    xr = x.double().clone().requires_grad_(True)
+    zr = F.conv2d(xr, w.double(), None, 1, 1)
+    zr.backward(g.double())
+    qf, qd = ops.pack3x3_split(w.to(dev))
+    z = ops.conv3x3_split(x.to(dev), qf, Cout)
+    close(z, zr, tol=2e-5, what="split fwd")
+    if Cout % 16 == 0:
+        close(ops.conv3x3_split(g.to(dev), qd, Cin), xr.grad, tol=2e-5, what="split dgrad")
+    assert torch.equal(z, ops.conv3x3_split(x.to(dev), qf, Cout)), "bitwise reproducible"
+    nparts = int(_lib.load().onet_conv3x3_split_nparts(B, H, W))
+    if W % 32 or H % 16:
+        assert nparts == 0
+        return
+    assert nparts == B * (H // 16) * (W // 32)
+    z1 = torch.empty_like(z)
+    cm = torch.full((Cout, nparts, 3), float("nan"), device=dev)
+    _lib.call("onet_conv3x3_split_fwd_stats", x.to(dev).data_ptr(), Cin * H * W, qf.data_ptr(), z1.data_ptr(), Cout * H * W,
+              cm.data_ptr(), B, Cin, Cout, H, W, torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(z, z1) and torch.isfinite(cm).all()
+    assert float(cm[:, :, 0].sum(1).min()) == float(cm[:, :, 0].sum(1).max()) == B * H * W
+    gamma, beta = (1 + 0.1 * rnd(Cout, seed=33)).to(dev), (0.1 * rnd(Cout, seed=34)).to(dev)
+    rm0, rv0 = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
+    rm1, rv1 = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
+    s0 = ops.bn_train_coeffs(z, gamma, beta, rm0, rv0, 0.1, 1e-5)
+    s1 = ops.bn_train_coeffs(z, gamma, beta, rm1, rv1, 0.1, 1e-5, cm=(cm, 0, nparts))
+    sd = float(z.std())
+    assert float((s0[0] - s1[0]).abs().max()) <= 2e-6 * sd and float(((s0[1] - s1[1]) / s0[1]).abs().max()) <= 1e-5
+
+
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 64, 64, 40, 48), (2, 16, 64, 16, 16), (1, 32, 128, 64, 64),
                                              (2, 128, 256, 16, 16), (2, 24, 36, 9, 7), (3, 16, 64, 33, 31),
                                              (2, 1024, 512, 4, 4), (4, 64, 64, 128, 128)])
