@@ -329,7 +329,14 @@ def main(args):
         dom = max(kern, key=lambda k: kern[k]["ms_total"])
         d = kern[dom]
         traffic = pmc_traffic(dom, bf16, args.batch)
-        if dom in BF16:
+        SPLIT = ("conv3x3_split_kernel", "conv3x3_split_wgrad_kernel")
+        if dom in SPLIT:
+            # fp32 tensors, fp32-level results, computed on the bf16 matrix pipe by operand splitting: MFMA-bound, priced against
+            # the DENSE bf16 MFMA peak with the FLOPs the kernel issues (three bf16 MFMAs per product term of the direct algorithm)
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": d["issued_mfma_tflops"], "peak": BF16_MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": d["mfma_frac"], "hbm_frac": d["hbm_frac"],
+                        "fp32_mfma_peak_equivalent": round(d["direct_equivalent_tflops"] / FP32_MFMA_PEAK_TFLOPS, 3)}
+        elif dom in BF16:
             # in bf16 the 64- and 128-channel layers sit below the ridge (312 FLOP/B): the launch is priced
             # against HBM; `achieved` = compulsory bytes (operands once + result once, fp32 storage) / time
             roofline = {"kernel": dom, "bound": "hbm", "achieved": d["compulsory_gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -380,7 +387,12 @@ def main(args):
                "vs_baseline": None,
                "dtype": "bf16" if bf16 else "f32",
                "precision": ("bf16 MFMA operands (3x3 conv fwd/dgrad/wgrad, ConvTranspose2d GEMMs), f32 accumulation, f32 conv outputs, "
-                             "BatchNorm, loss, master weights and optimizer") if bf16 else "f32 throughout",
+                             "BatchNorm, loss, master weights and optimizer") if bf16 else
+                            ("f32 tensors and f32-level results throughout; the 3x3 convolutions on maps >= 32 px wide run on the bf16 matrix "
+                             "pipe by operand splitting (x = hi + mid, w = hi + mid in bf16, 3 MFMAs per term, f32 accumulate: error vs fp64 "
+                             "1e-6 rms / 5e-6 max of the output scale, at or below the fp32 Winograd F(4x4) kernel's 3e-7..9e-7 / 7e-6..2e-5; "
+                             "every gradient element within 2e-4 of the fp64 oracle, tests/test_gpu_gradients.py); ONET_SPLIT=0 keeps the "
+                             "fp32-MFMA Winograd kernels") if (conv in ("auto", "split") and ops.SPLIT_AUTO) else "f32 throughout (fp32 MFMA)",
                "data": "synthetic",
                "config": {"workload": "%s: batch=%d/GPU %dx%dx%d synthetic K-clutter, %s, twin U-Net "
                                       "fwd+JSD loss+bwd+Adam" % (cfg_name, args.batch, args.chans,

@@ -104,7 +104,6 @@ struct SpCfg {
     static constexpr int IN_ROWS = ROWS + 2, IN_COLS = TW + 2;
     static constexpr int NPIX = IN_ROWS * IN_COLS;                      // 612 halo pixels
     static constexpr int NROUND = (NPIX + 31) / 32;                     // 20 wave-rounds of 32 pixels x 2 halves
-    static constexpr int NIT = (NROUND + NW - 1) / NW;                  // 3 rounds per wave (waves 4..7 idle in the last)
     static constexpr int NPIXP = NROUND * 32;                           // 640 pixel slots per half
     static constexpr int W_PART = 9 * 2 * CO_T;                         // 1152 slots per part
     static constexpr int W_SLOTS = 2 * W_PART;                          // hi | mid
@@ -122,7 +121,7 @@ struct SpCfg {
 template <bool ST>
 __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
     using C = SpCfg;
-    constexpr int NT = C::NT, IN_COLS = C::IN_COLS, NIT = C::NIT, NWI = C::NWI, CO_T = C::CO_T, NPIXP = C::NPIXP, NB = C::NB;
+    constexpr int NT = C::NT, IN_COLS = C::IN_COLS, NWI = C::NWI, CO_T = C::CO_T, NPIXP = C::NPIXP, NB = C::NB;
     constexpr int BUF = C::BUF_SLOTS, W_PART = C::W_PART, IN_PART = C::IN_PART, ROWS = C::ROWS, TW = C::TW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
     u32x4s* lds = reinterpret_cast<u32x4s*>(smem_s);                   // [2 buffers][weights hi|mid | input hi|mid]
@@ -150,10 +149,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
     const unsigned in_step = (unsigned)(16 * HW * 4), w_step = (unsigned)(2 * 9 * 2 * a.Cout * 16);
     const unsigned plane = (unsigned)(HW * 4);
 
-    // ---- staging side: runs two chunks ahead of the compute side, across tiles.  Round k of wave wn covers halo pixels
-    // 32 (wn + 8 k) .. + 31, lanes 0-31 the channels 0-7 of the chunk, lanes 32-63 the channels 8-15 (coalesced along x); weight
-    // slots i = tid + 512 k = (part, tap, half, co) -> 16 bytes of the slice [chunk][part][tap][half][co][8]
-    unsigned in_off[NIT], w_off[NWI];
+    // ---- staging side: runs two chunks ahead of the compute side, across tiles.  Input roles (wave-uniform):
+    //   waves 0..4, item it = tid < 288 = (half h, halo row r, 4-pixel group g):  8 x buffer_load_dwordx4 -- the 4 interior pixels
+    //              x0 + 4g .. + 3 of row r in the 8 channel planes of half h -- give the 4 slots (8 channels x 1 pixel) of those pixels;
+    //   waves 5..6, item tid - 320 < 72 = (half, row, side): the halo column x0 - 1 / x0 + 32, 8 x buffer_load_dword, one slot.
+    // (Round 3's first version loaded every slot as 8 dwords, one pixel per lane: 24 VMEM instructions per thread and chunk, 232 per
+    // block; a timing build without them ran 19-22 % faster.  Now 8 per staging thread, ~100 per block, the same bytes.)
+    // Requires W % 4 == 0 and 16-byte aligned image rows (host-checked): a float4 is entirely inside or outside the image.
+    // Weight slots i = tid + 512 k = (part, tap, half, co) -> 16 bytes of the slice [chunk][part][tap][half][co][8].
+    unsigned in_off, w_off[NWI];
+    const int role = wn < 5 ? 0 : (wn < 7 ? 1 : 2);                    // 0 interior, 1 halo column, 2 none
+    const int it = role == 0 ? tid : tid - 320;
+    const int it_h = role == 0 ? it / 144 : it / 36;
+    const int it_r = role == 0 ? (it % 144) / 8 : (it % 36) / 2;
+    const int it_g = role == 0 ? (it & 7) : (it & 1);                  // 4-pixel group / side
+    const bool it_ok = role == 0 ? it < 288 : (role == 1 && it < 72);
     __amdgpu_buffer_rsrc_t xr;
     int st_tile = t_first, st_chunk = 0;
     unsigned cin_bytes = 0, cw_bytes = 0;
@@ -167,13 +177,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
         const int b = v % a.B, co0 = (v / a.B) * CO_T;
         const int y0 = ty * ROWS, x0 = tx * TW;
         xr = s_rsrc(a.x + (int64_t)b * a.x_bs, (int64_t)a.Cin * HW * 4);
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            const int p = (wn + C::NW * k) * 32 + l31;
-            const int r = p / IN_COLS, c = p % IN_COLS;
-            const int yy = y0 - 1 + r, xx = x0 - 1 + c;
-            const bool ok = live && p < C::NPIX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-            in_off[k] = ok ? (unsigned)(((kh * 8) * HW + yy * a.W + xx) * 4) : OOB_S;
+        {
+            const int yy = y0 - 1 + it_r;
+            const int xx = role == 0 ? x0 + 4 * it_g : (it_g ? x0 + TW : x0 - 1);
+            const bool ok = live && it_ok && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+            in_off = ok ? (unsigned)(((it_h * 8) * HW + yy * a.W + xx) * 4) : OOB_S;
         }
 #pragma unroll
         for (int k = 0; k < NWI; ++k) {
@@ -195,18 +203,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
         }
     };
 
-    float xin[NIT][8];
+    u32x4s xin[8];                                   // plane c of the item: 4 pixels (interior) or 1 pixel in lane 0 (halo column)
     u32x4s wv[NWI];
-    // staging pieces: input round k (8 plane loads -> 2 slots), weight round k (one 16-byte load -> 1 slot)
-    auto issue_in = [&](int k0, int k1) __attribute__((always_inline)) {
+    // loads of planes [c0, c1) of this thread's item; the chunk / plane part of the address is wave-uniform and rides in the
+    // instruction's scalar offset, the per-lane part alone decides the range check (OOB_S -> 0)
+    auto issue_in = [&](int c0, int c1) __attribute__((always_inline)) {
+        if (role == 0) {
 #pragma unroll
-        for (int k = 0; k < NIT; ++k)
-            if (k >= k0 && k < k1)
+            for (int c = 0; c < 8; ++c)
+                if (c >= c0 && c < c1) xin[c] = __builtin_amdgcn_raw_buffer_load_b128(xr, in_off, (int)(cin_bytes + c * plane), 0);
+        } else if (role == 1) {
 #pragma unroll
-                for (int c = 0; c < 8; ++c)
-                    // the chunk / plane part of the address is wave-uniform: it rides in the instruction's scalar offset; the
-                    // per-lane part alone decides the range check (OOB_S -> 0)
-                    xin[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, in_off[k], (int)(cin_bytes + c * plane), 0));
+            for (int c = 0; c < 8; ++c)
+                if (c >= c0 && c < c1) xin[c][0] = __builtin_amdgcn_raw_buffer_load_b32(xr, in_off, (int)(cin_bytes + c * plane), 0);
+        }
     };
     auto issue_w = [&](int k0, int k1) __attribute__((always_inline)) {
 #pragma unroll
@@ -214,22 +224,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
             if (k >= k0 && k < k1) wv[k] = __builtin_amdgcn_raw_buffer_load_b128(wr, w_off[k], (int)cw_bytes, 0);
     };
     u32x4s* const w_st = lds + tid;                                     // + 512 k          (+ buffer * BUF)
-    u32x4s* const in_st = lds + C::W_SLOTS + kh * NPIXP + wn * 32 + l31;   // + 256 k, + IN_PART for the mid part
-    auto commit_in = [&](int buf, int k0, int k1) __attribute__((always_inline)) {
+    // slot of halo pixel (row r, column c) = W_SLOTS + part * IN_PART + half * NPIXP + r * IN_COLS + c
+    u32x4s* const in_st = lds + C::W_SLOTS + it_h * NPIXP + it_r * IN_COLS + (role == 0 ? 1 + 4 * it_g : (it_g ? IN_COLS - 1 : 0));
+    // pixels [p0, p1) of the item (interior: 4 pixels, halo column: pixel 0 only): 8 channels -> one slot per part
+    auto commit_in = [&](int buf, int p0, int p1) __attribute__((always_inline)) {
+        if (role == 2 || !it_ok) return;
+        f32x4s f[8];
 #pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            if (k < k0 || k >= k1) continue;
-            if (wn + C::NW * k >= C::NROUND) continue;                   // (wave-uniform) the last round exists for waves 0..3 only
+        for (int c = 0; c < 8; ++c) f[c] = __builtin_bit_cast(f32x4s, xin[c]);      // (re-typed as a whole: see commit_dz below)
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            if (px < p0 || px >= p1 || (role == 1 && px > 0)) continue;
             u32x4s hi, mid;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 unsigned h, m;
-                split2(xin[k][2 * c], xin[k][2 * c + 1], h, m);
+                split2(f[2 * c][px], f[2 * c + 1][px], h, m);
                 hi[c] = h;
                 mid[c] = m;
             }
-            in_st[buf * BUF + 256 * k] = hi;
-            in_st[buf * BUF + 256 * k + IN_PART] = mid;
+            in_st[buf * BUF + px] = hi;
+            in_st[buf * BUF + px + IN_PART] = mid;
         }
     };
     auto commit_w = [&](int buf, int k0, int k1) __attribute__((always_inline)) {
@@ -244,12 +259,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
     const u32x4s* const b_ptr = lds + C::W_SLOTS + kh * NPIXP + (wn * NT) * IN_COLS + l31;
 
     setup_stage();
-    issue_in(0, NIT);
+    issue_in(0, 8);
     issue_w(0, NWI);
-    commit_in(0, 0, NIT);
+    commit_in(0, 0, 4);
     commit_w(0, 0, NWI);
     advance();
-    issue_in(0, NIT);                                // second chunk (or the first of the next tile)
+    issue_in(0, 8);                                  // second chunk (or the first of the next tile)
     issue_w(0, NWI);
     __syncthreads();
     int buf = 0;
@@ -298,22 +313,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
                             Bq[(kx + 1) & 1][j][1] = bb[j * IN_COLS + kx + 1 + IN_PART];
                         }
                 }
-                // Staging, spread over the taps so that no wave sits in a burst of 29 VMEM issues while its SIMD partner does the
-                // same: the other buffer was last read one chunk ago (barrier since), so the chunk after this one goes in piece
-                // by piece -- and as soon as a piece's registers are committed they take the loads of the chunk after that
-                // (every load keeps a full chunk of MFMAs between issue and use).  Inputs: rounds 0, 1, 2 at taps 0, 2, 4; weights:
-                // taps 1, 3, 5, 6, 7.
+                // Staging, spread over the taps so that no wave sits in a burst of VMEM issues while its SIMD partner does the same:
+                // the other buffer was last read one chunk ago (barrier since), so the chunk after this one goes in piece by piece
+                // -- and once an item's pixels are committed its registers take the loads of the chunk after that (every load
+                // keeps most of a chunk of MFMAs between issue and use).  Inputs: pixels 0, 1 at tap 0, pixels 2, 3 at tap 1, the
+                // eight plane loads two per tap at taps 2..5; weights: commit + reload of slot k at taps 4..8.
                 if (idx == 0) advance();
-                if (idx == 0 || idx == 2 || idx == 4) {
-                    commit_in(buf ^ 1, idx / 2, idx / 2 + 1);
-                    issue_in(idx / 2, idx / 2 + 1);
-                }
-                if (idx == 1 || idx == 3 || idx >= 5) {
-                    const int kw = idx == 1 ? 0 : idx == 3 ? 1 : idx - 3;
-                    if (kw < NWI) {
-                        commit_w(buf ^ 1, kw, kw + 1);
-                        issue_w(kw, kw + 1);
-                    }
+                if (idx == 0) commit_in(buf ^ 1, 0, 2);
+                if (idx == 1) commit_in(buf ^ 1, 2, 4);
+                if (idx >= 2 && idx <= 5) issue_in(2 * (idx - 2), 2 * (idx - 2) + 2);
+                if (idx >= 4) {
+                    commit_w(buf ^ 1, idx - 4, idx - 3);
+                    issue_w(idx - 4, idx - 3);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const int tap = ky * 3 + kx;
@@ -440,6 +451,8 @@ int split_fwd(const float* x, int64_t x_bs, const void* wq, float* z, int64_t z_
     ONET_REQUIRE(x && wq && z, "conv3x3_split_fwd: null pointer");
     ONET_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 16, "conv3x3_split_fwd: bad shape (maps wider than 16 pixels)");
     ONET_REQUIRE((Cin % 16) == 0, "conv3x3_split_fwd: Cin must be a multiple of 16 (use onet_conv_fwd)");
+    ONET_REQUIRE((W & 3) == 0 && (x_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0,
+                 "conv3x3_split_fwd: W %% 4 == 0 and 16-byte aligned image rows required (use onet_conv3x3_winograd4_fwd)");
     ONET_REQUIRE(x_bs >= (int64_t)Cin * H * W && z_bs >= (int64_t)Cout * H * W, "conv3x3_split_fwd: batch stride too small");
     ONET_REQUIRE((int64_t)(Cin + 32) * H * W * 4 < (1ll << 31) && (int64_t)(Cin + 32) * 2 * 9 * Cout * 2 < (1ll << 31),
                  "conv3x3_split_fwd: operand exceeds the 2 GiB buffer-resource range");

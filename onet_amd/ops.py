@@ -414,7 +414,7 @@ def _in_buffer_range(Cin, Cout, H, W):
 
 
 def _split_legal(Cin, Cout, H, W):
-    return Cin % 16 == 0 and W > 16 and H >= 8
+    return Cin % 16 == 0 and W > 16 and W % 4 == 0 and H >= 8
 
 
 def conv3x3_algo(B, Cin, Cout, H, W):
@@ -551,6 +551,9 @@ def conv3x3_fwd_bn_partials(x, pk, x16=None):
             wq = pk.get_pack(algo)[0]
             require_gpu(x)
             xs, xbs = plane(x)
+            if xs.data_ptr() % 16 or xbs % 4:
+                xs = xs.contiguous()
+                xbs = xs.stride(0) if B > 1 else xs[0].numel()
             out = torch.empty((B, Co, H, W), dtype=F32, device=x.device)
             cm = torch.empty((Co, nparts, 3), dtype=F32, device=x.device)
             e0 = _prof_begin()
@@ -714,6 +717,9 @@ def conv3x3_split(x, wq, Cout, out=None):
         raise TypeError("conv3x3_split: wq must be a split pack on the GPU (pack3x3_split)")
     require_gpu(x)
     x, xbs = plane(x)
+    if x.data_ptr() % 16 or xbs % 4:                 # the kernel stages whole float4s: 16-byte aligned image rows
+        x = x.contiguous()
+        xbs = x.stride(0) if x.shape[0] > 1 else x[0].numel()
     B, Cin, H, W = x.shape
     if out is None:
         out = torch.empty((B, Cout, H, W), dtype=F32, device=x.device)

@@ -134,7 +134,7 @@ def test_conv3x3_split_wgrad(dev, B, Cin, Cout, H, W):
     assert not ops.split_wgrad_ok(x[..., :32].contiguous().to(dev), g[..., :32].contiguous().to(dev))      # W < 64: other kernels
 
 
-@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 64, 64, 40, 48), (1, 32, 128, 64, 64), (3, 16, 36, 33, 31), (2, 128, 80, 16, 96),
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 64, 64, 40, 48), (1, 32, 128, 64, 64), (3, 16, 36, 33, 28), (2, 128, 80, 16, 96),
                                              (9, 48, 64, 32, 32), (1, 512, 64, 17, 40)])
 def test_conv3x3_split_fwd_dgrad_stats(dev, B, Cin, Cout, H, W):
     """conv_split.hip -- fp32 convolution on the bf16 matrix cores by operand splitting (x = hi + mid, w = hi + mid, three MFMAs
