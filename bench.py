@@ -214,6 +214,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=200.0,
                     help="budget of the CPU-oracle baseline (split over the thread settings n = all cores and n = 8); the "
                          "default fits the whole configs[1] batch (B=32, ~28 s per step on 16 cores)")
+    ap.add_argument("--no-f32-mfma-only", action="store_true",
+                    help="skip the extra loop with the fp32-MFMA kernels only (profiling runs: keeps the kernel trace to the headline's kernels)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="do not attach BASELINE configs[2] (bf16, B=256) as `secondary` (default at N=1 with the headline "
                          "configuration: attached)")
@@ -279,6 +281,25 @@ def main(args):
     barrier()
     elapsed = time.perf_counter() - t0
     prof, prof_all = ops.profile_stop()
+    # the same loop with the fp32-MFMA kernels only (Winograd F(4x4) / F(2x2) / direct: round 2's dispatch), for the record next to
+    # the headline, whose 3x3 convolutions run on the bf16 matrix pipe by operand splitting (same fp32 tensors and results)
+    f32_mfma_only = None
+    if world == 1 and not bf16 and conv in ("auto", "split") and ops.SPLIT_AUTO and not args.torch_adam and not args.no_f32_mfma_only:
+        keep = onet.settings
+        onet.settings = keep.replace(conv="auto", split=False)
+        for _ in range(3):
+            loss2 = train_step(onet, opt, X)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n2 = max(5, args.steps // 2)
+        for _ in range(n2):
+            loss2 = train_step(onet, opt, X)
+        torch.cuda.synchronize()
+        e2 = time.perf_counter() - t1
+        f32_mfma_only = {"value": round(args.batch * n2 / e2, 3), "unit": "images/s", "ms_per_step": round(e2 / n2 * 1e3, 3), "steps": n2,
+                         "warmup": 3, "kernels": "fp32 MFMA only: Winograd F(4x4,3x3) / F(2x2,3x3) / direct (ONET_SPLIT=0)"}
+        del loss2
+        onet.settings = keep
     if distributed:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -392,7 +413,7 @@ def main(args):
                              "pipe by operand splitting (x = hi + mid, w = hi + mid in bf16, 3 MFMAs per term, f32 accumulate: error vs fp64 "
                              "1e-6 rms / 5e-6 max of the output scale, at or below the fp32 Winograd F(4x4) kernel's 3e-7..9e-7 / 7e-6..2e-5; "
                              "every gradient element within 2e-4 of the fp64 oracle, tests/test_gpu_gradients.py); ONET_SPLIT=0 keeps the "
-                             "fp32-MFMA Winograd kernels") if (conv in ("auto", "split") and ops.SPLIT_AUTO) else "f32 throughout (fp32 MFMA)",
+                             "fp32-MFMA Winograd kernels") if (conv in ("auto", "split") and ops.split_enabled()) else "f32 throughout (fp32 MFMA)",
                "data": "synthetic",
                "config": {"workload": "%s: batch=%d/GPU %dx%dx%d synthetic K-clutter, %s, twin U-Net "
                                       "fwd+JSD loss+bwd+Adam" % (cfg_name, args.batch, args.chans,
@@ -408,6 +429,8 @@ def main(args):
                "device_allocs_in_timed_steps": int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0)) - dev_allocs0,
                "device_allocs_per_timed_step": [b - a for a, b in zip([dev_allocs0] + allocs_per_step, allocs_per_step)],
                "roofline": roofline}
+        if f32_mfma_only is not None:
+            out["f32_mfma_only"] = f32_mfma_only
         headline = world == 1 and not bf16 and args.size == 256 and args.chans == 1 and args.batch == 32 and not args.torch_adam
         if headline and not args.no_secondary:
             # BASELINE configs[2] in the same driver-run line: release this process's HBM first (the child peaks at ~150 GB)

@@ -26,11 +26,13 @@ class Settings:
       twin          weight-shared Onet: X and 1-X as ONE batch of 2B                                        (default TWIN)
       convt_bf16    under conv == "bf16": the ConvTranspose2d GEMMs take bf16 operands too                  (default CONVT_BF16)
       bf16_storage  under conv == "bf16": producers write bf16 copies of the conv operands                  (default BF16_STORAGE)
-      lazy_nan      OV:234's NaN assertion deferred to FlatAdam.step()                                      (default LAZY_NAN_CHECK)"""
-    __slots__ = ("conv", "twin", "convt_bf16", "bf16_storage", "lazy_nan")
+      lazy_nan      OV:234's NaN assertion deferred to FlatAdam.step()                                      (default LAZY_NAN_CHECK)
+      split         under conv == "auto": fp32 3x3 convolutions on the bf16 matrix pipe by operand splitting   (default SPLIT_AUTO)"""
+    __slots__ = ("conv", "twin", "convt_bf16", "bf16_storage", "lazy_nan", "split")
 
-    def __init__(self, conv=None, twin=None, convt_bf16=None, bf16_storage=None, lazy_nan=None):
+    def __init__(self, conv=None, twin=None, convt_bf16=None, bf16_storage=None, lazy_nan=None, split=None):
         self.conv, self.twin, self.convt_bf16, self.bf16_storage, self.lazy_nan = conv, twin, convt_bf16, bf16_storage, lazy_nan
+        self.split = split
 
     def replace(self, **kw):
         out = Settings(*(getattr(self, k) for k in self.__slots__))
@@ -83,6 +85,10 @@ def twin_enabled():
 
 def lazy_nan_check():
     return bool(_setting("lazy_nan", LAZY_NAN_CHECK))
+
+
+def split_enabled():
+    return bool(_setting("split", SPLIT_AUTO))
 
 
 def convt_operand_bf16():
@@ -427,7 +433,7 @@ def conv3x3_algo(B, Cin, Cout, H, W):
         if _split_legal(Cin, Cout, H, W):
             return "split"
         algo = "auto_nosplit"
-    if algo == "auto" and SPLIT_AUTO and _split_legal(Cin, Cout, H, W):
+    if algo == "auto" and split_enabled() and _split_legal(Cin, Cout, H, W):
         # persistent 8-wave blocks, one per CU, tiles of 64 channels x 16 rows x 32 pixels: worth it once every CU gets a tile
         if B * -(-H // 16) * -(-W // 32) * -(-Cout // 64) >= (n_cu() * 3) // 4:
             return "split"
@@ -863,7 +869,7 @@ def conv3x3_wgrad_auto(x, dz, dw_shape, out=None, x16=None, dz16=None):
     if wgrad_takes_bf16(Cin, shp[2], shp[3]) and (dz16 is not None or dz.is_contiguous()):
         return conv3x3_wgrad_bf16(x, dz, dw_shape, out=out, x16=x16, dz16=dz16)
     # fp32 tensors, maps at least 64 pixels wide: the split-bf16 row kernel (the stem, Cin < 16, keeps its own VALU kernel)
-    if conv_algo() in ("auto", "split") and (SPLIT_AUTO or conv_algo() == "split") and x is not None and Cin >= 16 and split_wgrad_ok(x, dz):
+    if conv_algo() in ("auto", "split") and (split_enabled() or conv_algo() == "split") and x is not None and Cin >= 16 and split_wgrad_ok(x, dz):
         return conv3x3_split_wgrad(x, dz, dw_shape, out=out)
     if use_winograd(Cin, Cout, x.shape[2], x.shape[3]):
         if WGRAD4 != "0" and (WGRAD4 == "1" or Cin >= 256 or (Cin >= 128 and Cout >= 256)) and winograd4_wgrad_ok(x, dz):
