@@ -315,6 +315,11 @@ def main(args):
         BF16 = ("conv3x3_bf16_kernel", "conv3x3_wgrad_bf16_kernel", "conv3x3_split_kernel", "conv3x3_split_wgrad_kernel")
         if bf16 and ops.CONVT_BF16:     # the ConvTranspose2d GEMMs take bf16 operands too (priced against the bf16 peak)
             BF16 += ("convt_gemm_kernel", "convt_wgrad_gemm_kernel")
+        with ops.using(onet.settings):
+            convt_split = ops.convt_operand_bf16() == 2
+        if convt_split:                 # ... or split bf16 operands (three bf16 MFMAs per term, fp32-level results)
+            BF16 += ("convt_gemm_kernel", "convt_wgrad_gemm_kernel")
+            REDUCTION.update({"convt_gemm_kernel": 1.0 / 3.0, "convt_wgrad_gemm_kernel": 1.0 / 3.0})
         ALGO = {"conv_wino_kernel": "Winograd F(2x2,3x3) on fp32 MFMA (fwd + dgrad)",
                 "conv_wino4_kernel": "Winograd F(4x4,3x3) on fp32 MFMA (fwd + dgrad; BatchNorm statistics / backward-reduce "
                                      "epilogues)",
@@ -330,10 +335,10 @@ def main(args):
                 "conv_wgrad_kernel": "direct split-K weight gradient on fp32 MFMA (stem, tiny maps)",
                 "stem_conv_stats_kernel": "stem convolution (Cin = n_channels) + BatchNorm statistics, one streaming VALU pass "
                                           "(bound by writing z: see hbm_frac)",
-                "convt_gemm_kernel": "ConvTranspose2d forward / input-gradient GEMMs, 128x128 DMA-fed tiles (fp32 MFMA; bf16 "
-                                     "operands under --conv bf16)",
-                "convt_wgrad_gemm_kernel": "ConvTranspose2d weight-gradient GEMM, split-K (fp32 MFMA; bf16 operands under "
-                                           "--conv bf16)"}
+                "convt_gemm_kernel": "ConvTranspose2d forward / input-gradient GEMMs, 128x128 DMA-fed tiles (split bf16 "
+                                     "operands, fp32-level results, by default; fp32 MFMA under ONET_SPLIT=0; bf16 operands under --conv bf16)",
+                "convt_wgrad_gemm_kernel": "ConvTranspose2d weight-gradient GEMM, split-K (split bf16 operands by default; fp32 MFMA "
+                                           "under ONET_SPLIT=0; bf16 operands under --conv bf16)"}
         kern = {}
         for kind, recs in prof.items():
             ms = sum(r[1].elapsed_time(r[2]) for r in recs)
@@ -409,7 +414,7 @@ def main(args):
                "dtype": "bf16" if bf16 else "f32",
                "precision": ("bf16 MFMA operands (3x3 conv fwd/dgrad/wgrad, ConvTranspose2d GEMMs), f32 accumulation, f32 conv outputs, "
                              "BatchNorm, loss, master weights and optimizer") if bf16 else
-                            ("f32 tensors and f32-level results throughout; the 3x3 convolutions on maps >= 32 px wide run on the bf16 matrix "
+                            ("f32 tensors and f32-level results throughout; the 3x3 convolutions on maps >= 32 px wide and the ConvTranspose2d GEMMs run on the bf16 matrix "
                              "pipe by operand splitting (x = hi + mid, w = hi + mid in bf16, 3 MFMAs per term, f32 accumulate: error vs fp64 "
                              "1e-6 rms / 5e-6 max of the output scale, at or below the fp32 Winograd F(4x4) kernel's 3e-7..9e-7 / 7e-6..2e-5; "
                              "every gradient element within 2e-4 of the fp64 oracle, tests/test_gpu_gradients.py); ONET_SPLIT=0 keeps the "

@@ -58,8 +58,10 @@ int onet_convT2x2_pack_weights(const float* w, float* wp_fwd, float* wp_dgrad,
 int onet_convT2x2_pack_weights_fused(const float* w, float* wq, int Cin, int Cout, void* stream);
 /* operand_bf16 (the forward, both backward GEMMs and their _b / _dbias forms): operand precision of THIS call on the 128 x 128
  * fast path -- 1 rounds the MFMA operands to bf16 (nearest-even) with fp32 accumulation and fp32 results, i.e.
- * nn.ConvTranspose2d under torch.autocast(bfloat16), BASELINE configs[2]; 0 = fp32.  (ABI 2: a per-call argument; ABI 1 had a
- * process-wide switch, which two models of different precision in one process could not share.) */
+ * nn.ConvTranspose2d under torch.autocast(bfloat16), BASELINE configs[2]; 0 = fp32 MFMA; 2 = fp32-level results on the bf16 matrix
+ * cores by operand splitting (each operand = hi + mid bf16 parts, three MFMAs per term, as onet_conv3x3_split_*: the default of
+ * the fp32 model since round 3).  Shapes outside the fast path run the fp32 kernels whatever the value.  (ABI 2: a per-call
+ * argument; ABI 1 had a process-wide switch, which two models of different precision in one process could not share.) */
 int onet_convT2x2_fwd(const float* x, int64_t x_bs, const float* wq, const float* bias, float* y, int64_t y_bs,
                       int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int operand_bf16,
         void* stream);

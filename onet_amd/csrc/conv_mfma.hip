@@ -769,7 +769,7 @@ int onet_convT2x2_fwd(const float* x, int64_t x_bs, const float* wq, const float
     ONET_REQUIRE(pt >= 0 && pl >= 0 && pt + 2 * h <= Ho && pl + 2 * w <= Wo, "convT2x2_fwd: window outside plane");
     ONET_REQUIRE(x_bs >= (int64_t)Cin * h * w && y_bs >= (int64_t)Ct * Ho * Wo, "convT2x2_fwd: batch stride too small");
     if (convt_gemm_enabled()) {
-        const int rc = convt_gemm_fwd(x, x_bs, wq, bias, y, y_bs, nullptr, 0, B, Cin, Ct, h, w, Ho, Wo, pt, pl, operand_bf16 != 0, as_stream(stream));
+        const int rc = convt_gemm_fwd(x, x_bs, wq, bias, y, y_bs, nullptr, 0, B, Cin, Ct, h, w, Ho, Wo, pt, pl, operand_bf16, as_stream(stream));
         if (rc <= 0) return rc;          // 1: shape outside the 128 x 128 GEMM's fast path
     }
     ConvArgs a{x, x_bs, wq, y, y_bs, nullptr, B, Cin, 4 * Ct, h, w, 0, 0, 0, bias, Ho, Wo, pt, pl};
@@ -786,7 +786,7 @@ int onet_convT2x2_fwd_b(const float* x, int64_t x_bs, const float* wq, const flo
     ONET_REQUIRE(x_bs >= (int64_t)Cin * h * w && (!y || y_bs >= (int64_t)Ct * Ho * Wo) && y16_bs >= (int64_t)Ct * Ho * Wo,
                  "convT2x2_fwd_b: batch stride too small");
     if (!convt_gemm_enabled()) return 1;
-    return convt_gemm_fwd(x, x_bs, wq, bias, y, y_bs, y_bf16, y16_bs, B, Cin, Ct, h, w, Ho, Wo, pt, pl, operand_bf16 != 0, as_stream(stream));
+    return convt_gemm_fwd(x, x_bs, wq, bias, y, y_bs, y_bf16, y16_bs, B, Cin, Ct, h, w, Ho, Wo, pt, pl, operand_bf16, as_stream(stream));
 }
 
 int onet_convT2x2_dgrad(const float* dy, int64_t dy_bs, const float* wp_dgrad, float* dx, int64_t dx_bs, int B,
@@ -797,7 +797,7 @@ int onet_convT2x2_dgrad(const float* dy, int64_t dy_bs, const float* wp_dgrad, f
     ONET_REQUIRE(pt >= 0 && pl >= 0 && pt + 2 * h <= Ho && pl + 2 * w <= Wo, "convT2x2_dgrad: window outside plane");
     ONET_REQUIRE(dy_bs >= (int64_t)Ct * Ho * Wo && dx_bs >= (int64_t)Cin * h * w, "convT2x2_dgrad: batch stride too small");
     if (convt_gemm_enabled()) {
-        const int rc = convt_gemm_dgrad(dy, dy_bs, wp_dgrad, dx, dx_bs, nullptr, nullptr, B, Cin, Ct, h, w, Ho, Wo, pt, pl, operand_bf16 != 0, as_stream(stream));
+        const int rc = convt_gemm_dgrad(dy, dy_bs, wp_dgrad, dx, dx_bs, nullptr, nullptr, B, Cin, Ct, h, w, Ho, Wo, pt, pl, operand_bf16, as_stream(stream));
         if (rc <= 0) return rc;
     }
     ConvArgs a{dy, dy_bs, wp_dgrad, dx, dx_bs, nullptr, B, 4 * Ct, Cin, h, w, 0, 0, 0, nullptr, Ho, Wo, pt, pl};
@@ -816,7 +816,7 @@ int onet_convT2x2_dgrad_dbias(const float* dy, int64_t dy_bs, const float* wp_dg
     ONET_REQUIRE(B > 0 && Cin > 0 && Ct > 0 && h > 0 && w > 0, "convT2x2_dgrad_dbias: bad shape");
     ONET_REQUIRE(dy_bs >= (int64_t)Ct * Ho * Wo && dx_bs >= (int64_t)Cin * h * w, "convT2x2_dgrad_dbias: batch stride too small");
     if (!convt_gemm_enabled() || ws_bytes < convt_gemm_dbias_ws_bytes(B, Ct, h, w)) return 1;
-    return convt_gemm_dgrad(dy, dy_bs, wp_dgrad, dx, dx_bs, dbias, (float*)ws, B, Cin, Ct, h, w, Ho, Wo, pt, pl, operand_bf16 != 0, as_stream(stream));
+    return convt_gemm_dgrad(dy, dy_bs, wp_dgrad, dx, dx_bs, dbias, (float*)ws, B, Cin, Ct, h, w, Ho, Wo, pt, pl, operand_bf16, as_stream(stream));
 }
 
 int onet_conv_fwd_nparts(int B, int Cout, int H, int W) {
@@ -900,7 +900,7 @@ int onet_convT2x2_wgrad(const float* x, int64_t x_bs, const float* dy, int64_t d
     ONET_REQUIRE(pt >= 0 && pl >= 0 && pt + 2 * h <= Ho && pl + 2 * w <= Wo, "convT2x2_wgrad: window outside plane");
     ONET_REQUIRE(dy_bs >= (int64_t)Ct * Ho * Wo && x_bs >= (int64_t)Cin * h * w, "convT2x2_wgrad: batch stride too small");
     if (convt_gemm_enabled()) {
-        const int rc = convt_gemm_wgrad(x, x_bs, dy, dy_bs, dw, ws, ws_bytes, B, Cin, Ct, h, w, Ho, Wo, pt, pl, operand_bf16 != 0, as_stream(stream));
+        const int rc = convt_gemm_wgrad(x, x_bs, dy, dy_bs, dw, ws, ws_bytes, B, Cin, Ct, h, w, Ho, Wo, pt, pl, operand_bf16, as_stream(stream));
         if (rc <= 0) return rc;
     }
     const int Cout = 4 * Ct;

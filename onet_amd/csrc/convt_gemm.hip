@@ -78,6 +78,56 @@ __device__ __forceinline__ bf16x8g g_pack8(const float (&v)[8]) {
     return __builtin_bit_cast(bf16x8g, q);
 }
 
+// PREC 2 (round 3): fp32-level results on the bf16 pipe by operand splitting, as conv_split.hip: v = hi + mid with hi = bf16(v),
+// mid = bf16(v - hi); a.b ~ a_mid.b_hi + a_hi.b_mid + a_hi.b_hi (three MFMAs per accumulator and K-chunk; every bf16 product is
+// exact in the fp32 accumulator, the dropped terms are ~2^-16 relative).  The split runs on the gathered fragments (6 VALU per
+// value pair): 3/16 of the fp32 kernel's matrix-pipe time.
+__device__ __forceinline__ void g_split8(const float (&v)[8], bf16x8g& hi, bf16x8g& mid) {
+    u32x4g qh, qm;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const unsigned h = g_pack(v[2 * p], v[2 * p + 1]);
+        const float h0 = __builtin_bit_cast(float, h << 16), h1 = __builtin_bit_cast(float, h & 0xffff0000u);
+        qh[p] = h;
+        qm[p] = g_pack(v[2 * p] - h0, v[2 * p + 1] - h1);
+    }
+    hi = __builtin_bit_cast(bf16x8g, qh);
+    mid = __builtin_bit_cast(bf16x8g, qm);
+}
+// acc += a.b at the precision PREC selects (1: bf16 operands, 2: split) for a wave's 2 x 2 accumulators
+template <int PREC>
+__device__ __forceinline__ void g_mma16(const float (&af)[2][8], const float (&bf)[2][8], f32x16 (&acc)[2][2]) {
+    if constexpr (PREC == 1) {
+        bf16x8g a8[2], b8[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) a8[t] = g_pack8(af[t]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) b8[u] = g_pack8(bf[u]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[t], b8[u], acc[t][u], 0, 0, 0);
+    } else {
+        bf16x8g ah[2], am[2], bh[2], bm[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) g_split8(af[t], ah[t], am[t]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) g_split8(bf[u], bh[u], bm[u]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t], bh[u], acc[t][u], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bm[u], acc[t][u], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bh[u], acc[t][u], 0, 0, 0);
+    }
+}
+
 struct GArgs {
     const float* a;       // forward: wq [Cin][4Ct];  dgrad: wd [4Ct][Cin] (row q*Ct + c);  wgrad: x
     const float* b;       // forward: x;              dgrad: dy window;                       wgrad: dy window
@@ -115,7 +165,7 @@ constexpr int TILE_F = KC * 128;       // floats of one operand tile
 // ------------------------------------------------------------------------------------------------ forward and dgrad
 // MODE 0: forward (A rows = wq[k][m], B rows = x[b][k][pixels]);  MODE 1: dgrad (A rows = wd[q*Ct + c][ci], B rows =
 // dy[b][c][2y + di][...] as they lie: 256 floats per (c, di) for the tile's 128 pixels)
-template <int MODE, bool BF = false>
+template <int MODE, int PREC = 0>
 __global__ __launch_bounds__(256, 2) void convt_gemm_kernel(GArgs g) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * TILE_F];      // [buf][A | B]
     int bid = xcd_order(gridDim.x);
@@ -190,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void convt_gemm_kernel(GArgs g) {
             const float other = __shfl(sb, 63, 64);
             if (lane == 31) g.dbias_part[(int64_t)nt * g.Ct + 4 * c + wid] = sb + other;
         }
-        if constexpr (BF) {
+        if constexpr (PREC != 0) {
             if (more) issue(c + 1, buf ^ 1);
             // one K = 16 MFMA per accumulator: lane (i, kh) holds K-values 8 kh .. 8 kh + 7 of the chunk
             float af[2][8], bf[2][8];
@@ -213,15 +263,7 @@ __global__ __launch_bounds__(256, 2) void convt_gemm_kernel(GArgs g) {
                     }
                 }
             }
-            bf16x8g a8[2], b8[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) a8[t] = g_pack8(af[t]);
-#pragma unroll
-            for (int u = 0; u < 2; ++u) b8[u] = g_pack8(bf[u]);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[t], b8[u], acc[t][u], 0, 0, 0);
+            g_mma16<PREC>(af, bf, acc);
         } else {
 #pragma unroll
         for (int s = 0; s < KC / 2; ++s) {
@@ -301,7 +343,7 @@ constexpr int KP = 32;                          // pixels per chunk (16 K-steps)
 constexpr int WA_F = 128 * KP;                  // A tile: 128 ci rows x 32 px
 constexpr int WB_F = 64 * 2 * KP;               // B tile: 64 (c, di) rows x (32 px x dj)
 
-template <bool BF = false>
+template <int PREC = 0>
 __global__ __launch_bounds__(256, 2) void convt_wgrad_gemm_kernel(GArgs g) {
     __shared__ __attribute__((aligned(16))) float lds[2 * (WA_F + WB_F)];
     int bid = xcd_order(gridDim.x);
@@ -369,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void convt_wgrad_gemm_kernel(GArgs g) {
         const bool more = c + 1 < ch1;
         const float* A = lds + buf * (WA_F + WB_F);
         const float* Bt = A + WA_F;
-        if constexpr (BF) {
+        if constexpr (PREC != 0) {
             if (more) issue(c + 1, buf ^ 1, 0, 4);
             // K = 16 pixels per MFMA: lane (i, kh) holds pixels 8 gg + 4 kh + 0..3 of two consecutive 8-pixel groups
 #pragma unroll
@@ -393,15 +435,7 @@ __global__ __launch_bounds__(256, 2) void convt_wgrad_gemm_kernel(GArgs g) {
                             bf[u][4 * h2 + 2 * e + 1] = dj ? v[3] : v[2];
                         }
                 }
-                bf16x8g a8[2], b8[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) a8[t] = g_pack8(af[t]);
-#pragma unroll
-                for (int u = 0; u < 2; ++u) b8[u] = g_pack8(bf[u]);
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[t], b8[u], acc[t][u], 0, 0, 0);
+                g_mma16<PREC>(af, bf, acc);
             }
         } else {
 #pragma unroll
@@ -497,12 +531,13 @@ void wgrad_plan(int B, int Cin, int Ct, int h, int w, int& splitK, int& per) {
 
 namespace onet {
 
-// `bf`: operand precision of the three GEMMs, per call: false = fp32, true = bf16 operands with fp32 accumulation (the bf16 conv
-// path of BASELINE configs[2]; the `operand_bf16` argument of the onet_convT2x2_* entry points)
+// `prec`: operand precision of the three GEMMs, per call (the `operand_bf16` argument of the onet_convT2x2_* entry points):
+// 0 = fp32 MFMA, 1 = bf16 operands with fp32 accumulation (the bf16 conv path of BASELINE configs[2]), 2 = split bf16 operands
+// (fp32-level results on the bf16 pipe)
 
 // Fast-path predicates + launches; return ONET_NOT_TAKEN (1) when the shape is not taken (caller falls back to conv_mfma.hip)
 int convt_gemm_fwd(const float* x, int64_t x_bs, const float* wq, const float* bias, float* y, int64_t y_bs, void* y16, int64_t y16_bs,
-                   int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, bool bf, hipStream_t st) {
+                   int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int prec, hipStream_t st) {
     const int64_t hw = (int64_t)h * w;
     if (pt || pl || Ho != 2 * h || Wo != 2 * w || (Cin % KC) || (Ct % 32) || (hw % 128) || (w & 1) || !aligned16(x) || !aligned16(wq) ||
         (x_bs & 3) || (reinterpret_cast<uintptr_t>(y) & 7) || (y_bs & 1) || (int64_t)Cin * hw * 4 >= (1ll << 31) ||
@@ -513,8 +548,9 @@ int convt_gemm_fwd(const float* x, int64_t x_bs, const float* wq, const float* b
     GArgs g{wq, x, y, bias, nullptr, (__bf16*)y16, y16_bs, 0, x_bs, y_bs, B, Cin, Ct, h, w, Wo, Ho * Wo, (4 * Ct) / 128, (int)(B * hw / 128), 1, 0};
     const int64_t blocks = (int64_t)g.mTiles * g.nTiles;
     if (blocks <= 0 || blocks >= (1ll << 31)) return 1;
-    if (bf) hipLaunchKernelGGL((convt_gemm_kernel<0, true>), dim3((unsigned)blocks), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((convt_gemm_kernel<0, false>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    if (prec == 2) hipLaunchKernelGGL((convt_gemm_kernel<0, 2>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    else if (prec) hipLaunchKernelGGL((convt_gemm_kernel<0, 1>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((convt_gemm_kernel<0, 0>), dim3((unsigned)blocks), dim3(256), 0, st, g);
     return check_launch("convt_gemm_kernel<0>");
 }
 
@@ -522,7 +558,7 @@ int64_t convt_gemm_dbias_ws_bytes(int B, int Ct, int h, int w) { return (int64_t
 
 // dbias != NULL: also the ConvTranspose2d bias gradient, taken from the dy rows the GEMM stages anyway (dbias_ws: partials)
 int convt_gemm_dgrad(const float* dy, int64_t dy_bs, const float* wd, float* dx, int64_t dx_bs, float* dbias, float* dbias_ws, int B,
-                     int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, bool bf, hipStream_t st) {
+                     int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int prec, hipStream_t st) {
     const int64_t hw = (int64_t)h * w;
     if (pt || pl || Ho != 2 * h || Wo != 2 * w || (Cin % 128) || (Ct % 4) || (hw % 128) || (w & 1) || !aligned16(dy) || !aligned16(wd) ||
         (dy_bs & 3) || (int64_t)Ct * Ho * Wo * 4 >= (1ll << 31) || (int64_t)Cin * 4 * Ct * 4 >= (1ll << 31))
@@ -531,8 +567,9 @@ int convt_gemm_dgrad(const float* dy, int64_t dy_bs, const float* wd, float* dx,
     GArgs g{wd, dy, dx, nullptr, dbias ? dbias_ws : nullptr, nullptr, 0, 0, dy_bs, dx_bs, B, Cin, Ct, h, w, Wo, Ho * Wo, Cin / 128, (int)(B * hw / 128), 1, 0};
     const int64_t blocks = (int64_t)g.mTiles * g.nTiles;
     if (blocks <= 0 || blocks >= (1ll << 31)) return 1;
-    if (bf) hipLaunchKernelGGL((convt_gemm_kernel<1, true>), dim3((unsigned)blocks), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((convt_gemm_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    if (prec == 2) hipLaunchKernelGGL((convt_gemm_kernel<1, 2>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    else if (prec) hipLaunchKernelGGL((convt_gemm_kernel<1, 1>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((convt_gemm_kernel<1, 0>), dim3((unsigned)blocks), dim3(256), 0, st, g);
     int rc = check_launch("convt_gemm_kernel<1>");
     if (rc || !dbias) return rc;
     hipLaunchKernelGGL(convt_dbias_reduce_kernel, dim3((unsigned)Ct), dim3(256), 0, st, (const float*)dbias_ws, dbias, g.nTiles, Ct);
@@ -547,7 +584,7 @@ int64_t convt_gemm_wgrad_ws_bytes(int B, int Cin, int Ct, int h, int w) {
 }
 
 int convt_gemm_wgrad(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, float* dw, void* ws, int64_t ws_bytes, int B,
-                     int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, bool bf, hipStream_t st) {
+                     int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int prec, hipStream_t st) {
     const int64_t hw = (int64_t)h * w;
     if (pt || pl || Ho != 2 * h || Wo != 2 * w || (Cin % 128) || (Ct % 32) || (hw % KP) || (w & 1) || !aligned16(x) || !aligned16(dy) ||
         !aligned16(dw) || (x_bs & 3) || (dy_bs & 3) || (int64_t)Cin * hw * 4 >= (1ll << 31) || (int64_t)Ct * Ho * Wo * 4 >= (1ll << 31))
@@ -557,8 +594,9 @@ int convt_gemm_wgrad(const float* x, int64_t x_bs, const float* dy, int64_t dy_b
     const int64_t n = (int64_t)Cin * 4 * Ct;
     if (ws_bytes < (int64_t)g.splitK * n * 4) return 1;
     const int64_t blocks = (int64_t)g.splitK * g.mTiles * g.nTiles;
-    if (bf) hipLaunchKernelGGL(convt_wgrad_gemm_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL(convt_wgrad_gemm_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, g);
+    if (prec == 2) hipLaunchKernelGGL(convt_wgrad_gemm_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, g);
+    else if (prec) hipLaunchKernelGGL(convt_wgrad_gemm_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(convt_wgrad_gemm_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, g);
     int rc = check_launch("convt_wgrad_gemm_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(convt_wgrad_reduce_kernel, dim3((unsigned)cdiv(n / 4, 256)), dim3(256), 0, st, (const float*)ws, dw, g.splitK,

@@ -92,8 +92,12 @@ def split_enabled():
 
 
 def convt_operand_bf16():
-    """operand_bf16 argument of the onet_convT2x2_* entry points for the calling model"""
-    return int(conv_algo() == "bf16" and bool(_setting("convt_bf16", CONVT_BF16)))
+    """operand_bf16 argument of the onet_convT2x2_* entry points for the calling model: 1 = bf16 operands (the bf16 conv path),
+    2 = split bf16 operands (fp32-level results; with the split 3x3 kernels under "auto"), 0 = fp32 MFMA"""
+    algo = conv_algo()
+    if algo == "bf16":
+        return int(bool(_setting("convt_bf16", CONVT_BF16)))
+    return 2 if (algo in ("auto", "split") and split_enabled() and CONVT_SPLIT) else 0
 
 
 _CU_COUNT = {}
@@ -506,6 +510,7 @@ def conv3x3_auto(x, pk, direction, out=None, x16=None):
 
 
 FUSE_BN_STATS = _os.environ.get("ONET_FUSE_BN_STATS", "1") != "0"
+CONVT_SPLIT = _os.environ.get("ONET_CONVT_SPLIT", "1") != "0"     # 0: the ConvTranspose2d GEMMs stay on the fp32 MFMA pipe
 SPLIT_AUTO = _os.environ.get("ONET_SPLIT", "1") != "0"          # 0: "auto" never selects the split-bf16 kernel (round-2 dispatch)
 STEM_FUSED = _os.environ.get("ONET_STEM_FUSED", "1") != "0"      # 0: the stem takes the direct MFMA kernel + a statistics pass
 

@@ -695,6 +695,41 @@ def test_up_convT_cat_bf16_operands(dev, h, w, Cin, Ct, monkeypatch):
         assert torch.equal(again[i], f32[i]), what + ": bf16 switch leaked into an fp32 call"
 
 
+@pytest.mark.parametrize("h,w,Cin,Ct", [(32, 32, 128, 64), (16, 16, 256, 128), (64, 64, 128, 64), (8, 32, 384, 192), (16, 16, 1024, 512)])
+def test_up_convT_cat_split_operands(dev, h, w, Cin, Ct, monkeypatch):
+    """Round 3 default of the fp32 model: the three ConvTranspose2d GEMMs (128 x 128 fast path) on the bf16 matrix cores with
+    SPLIT operands (hi + mid bf16 parts, three MFMAs per term) -- each must equal the fp64 result of the UNROUNDED operands to
+    2e-5 of its scale (measured 1e-6 .. 5e-6; plain bf16 operands: 2e-3), the split kernels must really have run (results differ
+    from the fp32-MFMA kernels' in the last bits) and ONET_CONVT_SPLIT=0 / Settings(split=False) must give the fp32-MFMA result."""
+    from onet_amd import functional as Fn
+    from onet_amd import ops
+    B, C2, Ho, Wo = 2, Ct, 2 * h, 2 * w
+    x1, x2 = rnd(B, Cin, h, w, seed=15), rnd(B, C2, Ho, Wo, seed=16)
+    wt, bt = rnd(Cin, Ct, 2, 2, seed=17, scale=0.1), rnd(Ct, seed=18, scale=0.1)
+    g = rnd(B, C2 + Ct, Ho, Wo, seed=19)
+    a, c = x1.double().requires_grad_(True), wt.double().requires_grad_(True)
+    u = F.conv_transpose2d(a, c, bt.double(), stride=2)
+    u.backward(g[:, C2:].double())
+
+    def run(settings):
+        with ops.using(settings):
+            A, Bt, Cw, Db = [t.to(dev).requires_grad_(True) for t in (x1, x2, wt, bt)]
+            out = Fn.UpConvTCatFn.apply(A, Bt, Cw, Db, (ops.packT2x2_fused(Cw), ops.packT2x2(Cw)[1]))
+            out.backward(g.to(dev))
+        return out.detach()[:, C2:].cpu().double(), A.grad.cpu().double(), Cw.grad.cpu().double()
+
+    sp = run(ops.Settings(conv="auto", split=True))
+    f32 = run(ops.Settings(conv="auto", split=False))
+    monkeypatch.setattr(ops, "CONVT_SPLIT", False)
+    off = run(ops.Settings(conv="auto", split=True))
+    for got, ref, what in ((sp[0], u.detach(), "up fwd"), (sp[1], a.grad, "dx1"), (sp[2], c.grad, "dW")):
+        sc = float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= 2e-5 * sc, what
+    for i, what in enumerate(("up fwd", "dx1", "dW")):
+        assert not torch.equal(sp[i], f32[i]), what + ": the split kernels did not run"
+        assert torch.equal(off[i], f32[i]), what + ": ONET_CONVT_SPLIT=0 did not restore the fp32 kernels"
+
+
 @pytest.mark.parametrize("h,w,Ho,Wo", [(8, 8, 16, 16), (12, 12, 25, 25), (1, 1, 2, 2)])
 def test_up_bilinear_cat(dev, h, w, Ho, Wo):
     from onet_amd import functional as Fn
