@@ -316,7 +316,7 @@ def main(args):
         if bf16 and ops.CONVT_BF16:     # the ConvTranspose2d GEMMs take bf16 operands too (priced against the bf16 peak)
             BF16 += ("convt_gemm_kernel", "convt_wgrad_gemm_kernel")
         with ops.using(onet.settings):
-            convt_split = ops.convt_operand_bf16() == 2
+            convt_split = ops.convt_operand_bf16(2 * args.batch, args.size // 2, args.size // 2, 64) == 2     # the last Up block's GEMM
         if convt_split:                 # ... or split bf16 operands (three bf16 MFMAs per term, fp32-level results)
             BF16 += ("convt_gemm_kernel", "convt_wgrad_gemm_kernel")
             REDUCTION.update({"convt_gemm_kernel": 1.0 / 3.0, "convt_wgrad_gemm_kernel": 1.0 / 3.0})

@@ -182,7 +182,9 @@ int onet_conv3x3_split_fwd_stats(const float* x, int64_t x_bs, const void* wq, f
                                  int Cout, int H, int W, void* stream);
 /* Weight gradient of the same convolution with both operands (x, dz: fp32 NCHW) split the same way, three MFMAs per term;
  * row-streaming units (one image row of a 64-pixel strip), deterministic split-K through ws (onet_conv3x3_split_wgrad_ws_bytes).
- * _ok: 1 where the kernel takes the shape (W >= 64, W % 4 == 0); 16-byte aligned image rows (x_bs, dz_bs % 4 == 0). */
+ * _ok: 1 where the kernel takes the shape: W >= 64 with W % 4 == 0, or W = 32 / 16 with B a multiple of 64 / W (that many images
+ * side by side make one unit; the whole batch of x and of dz must then lie within 2 GiB); 16-byte aligned image rows (x_bs,
+ * dz_bs % 4 == 0). */
 int onet_conv3x3_split_wgrad_ok(int B, int Cin, int Cout, int H, int W);
 int64_t onet_conv3x3_split_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W);
 int onet_conv3x3_split_wgrad(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs, float* dw, void* ws, int64_t ws_bytes,

@@ -475,7 +475,7 @@ int split_fwd(const float* x, int64_t x_bs, const void* wq, float* z, int64_t z_
 //   groups of four that split a unit's four segments between them and keep their own accumulators (a split over K inside the
 //   block: 4 waves at one per SIMD had nothing to cover the barrier, the commit and the fragment reads, 0.33 of the bf16 peak);
 //   54 MFMAs per wave and unit.  Split-K over (image, strip, row) units, raw slabs [split][tap][co][ci] reduced deterministically by
-//   wgrad_reduce_kernel (conv_mfma.hip).  Requires W >= 64, W % 4 == 0.
+//   wgrad_reduce_kernel (conv_mfma.hip).  Requires W >= 64 with W % 4 == 0, or W = 32 / 16 (below).
 struct SwArgs {
     const float* x;
     int64_t x_bs;
@@ -485,10 +485,29 @@ struct SwArgs {
     int B, Cin, Cout, H, W, ciTiles, coTiles, splitK, tilesX;
 };
 
-constexpr int SR_SDZ = 36, SR_SX = 148, SR_SLOT = 36;      // dword strides: per co; per ci (4 x odd); per ring slot
-constexpr int SR_DZ_PART = 64 * SR_SDZ, SR_X_PART = 64 * SR_SX;
+#ifndef SW_COMMIT_AT
+#define SW_COMMIT_AT 3
+#endif
+// Maps narrower than a strip (G = 64 / W = 2 or 4: the 32- and 16-pixel levels): a unit is row y of G IMAGES side by side -- the dz
+// row is their 64 pixels back to back, the x row keeps each image's own halo (sub-row pitch SR_P dwords: W / 2 data dwords + the
+// right-halo dword, rounded to 16 bytes), so a horizontal shift never reads a neighbouring image's pixel.  Everything else -- the
+// ring over rows, the two pixel groups, the commit inside the MFMA block -- is the 64-pixel strip's.
+constexpr int SR_SDZ = 36;                                  // dword stride per co
+constexpr int SR_DZ_PART = 64 * SR_SDZ;
+template <int G> struct SwCfg {
+    static constexpr int SPG = 8 / G;                       // 8-pixel segments per sub-row
+    static constexpr int P = G == 1 ? 36 : (G == 2 ? 20 : 12);
+    static constexpr int SLOT = G * P;                      // 36 / 40 / 48 dwords per ring slot
+    static constexpr int SX = 4 * SLOT + 4;                 // per ci: 148 / 164 / 196 = 4 x odd
+    static constexpr int X_PART = 64 * SX;
+    static constexpr int GOFF = G == 1 ? 16 : (G == 2 ? 20 : 24);   // fragment offset of pixel group 1 / of segment 1
+    static constexpr int SOFF = G == 4 ? 12 : 8;
+};
 
+template <int G>
 __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
+    using C = SwCfg<G>;
+    constexpr int SR_SX = C::SX, SR_SLOT = C::SLOT, SR_X_PART = C::X_PART;
     __shared__ __attribute__((aligned(16))) unsigned dz_lds[2 * 2 * SR_DZ_PART];     // [buf][part][64 co][SR_SDZ]
     __shared__ __attribute__((aligned(16))) unsigned x_lds[2 * SR_X_PART];           // [part][64 ci][SR_SX]
 
@@ -500,7 +519,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
     const int tiles = a.ciTiles * a.coTiles;
     const int ks = bid / tiles, tile = bid % tiles;
     const int ci0 = (tile % a.ciTiles) * 64, co0 = (tile / a.ciTiles) * 64;
-    const int nunits = a.B * a.tilesX * a.H;                   // unit = (image, 64-pixel strip, row), rows fastest
+    const int nunits = (a.B / G) * a.tilesX * a.H;             // unit = (image [group of G], 64-pixel strip, row), rows fastest
     const int per = (nunits + a.splitK - 1) / a.splitK;
     const int u0 = ks * per, u1 = min(u0 + per, nunits);
 
@@ -519,26 +538,31 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
 
     // staging roles: thread = (channel = tid / 8, 8-pixel segment = tid % 8) of the dz row and of the x row
     const int st_c = tid >> 3, st_s = tid & 7;
+    const int st_sub = st_s / C::SPG, st_w = st_s % C::SPG;     // image of the group, 8-pixel segment of its row
     u32x4s dzv[2], xq[2];
     float xh[2];
-    // loads of one dz row and / or one x row of strip (b, x0): row < 0 or >= H -> zeros
+    // loads of one dz row and / or one x row of strip (b, x0): row < 0 or >= H -> zeros.  G == 1: one buffer resource per image
+    // (a 256 x 256 level's batch exceeds the 2 GiB range); G > 1: the lanes of a wave address different images, so the resource
+    // spans the whole (small) tensor and the image offset goes into the lane's byte offset (range checked by the host)
     auto issue_dz = [&](int b, int x0, int y) __attribute__((always_inline)) {
-        const __amdgpu_buffer_rsrc_t dr = s_rsrc(a.dz + (int64_t)b * a.dz_bs, (int64_t)a.Cout * HW * 4);
-        const int xs = x0 + 8 * st_s;
+        const __amdgpu_buffer_rsrc_t dr = G == 1 ? s_rsrc(a.dz + (int64_t)b * a.dz_bs, (int64_t)a.Cout * HW * 4)
+                                                 : s_rsrc(a.dz, ((int64_t)(a.B - 1) * a.dz_bs + (int64_t)a.Cout * HW) * 4);
+        const int xs = x0 + 8 * st_w;
         const bool ok = y >= 0 && y < a.H && co0 + st_c < a.Cout;
-        const unsigned base = (unsigned)(((co0 + st_c) * HW + y * a.W + xs) * 4);
+        const unsigned base = (unsigned)(((co0 + st_c) * HW + y * a.W + xs) * 4) + (G == 1 ? 0u : (unsigned)((int64_t)(b * G + st_sub) * a.dz_bs * 4));
 #pragma unroll
         for (int k = 0; k < 2; ++k) dzv[k] = __builtin_amdgcn_raw_buffer_load_b128(dr, (ok && xs + 4 * k < a.W) ? base + 16 * k : OOB_S, 0, 0);
     };
     auto issue_x = [&](int b, int x0, int y) __attribute__((always_inline)) {
-        const __amdgpu_buffer_rsrc_t xr = s_rsrc(a.x + (int64_t)b * a.x_bs, (int64_t)a.Cin * HW * 4);
-        const int xs = x0 + 8 * st_s;
+        const __amdgpu_buffer_rsrc_t xr = G == 1 ? s_rsrc(a.x + (int64_t)b * a.x_bs, (int64_t)a.Cin * HW * 4)
+                                                 : s_rsrc(a.x, ((int64_t)(a.B - 1) * a.x_bs + (int64_t)a.Cin * HW) * 4);
+        const int xs = x0 + 8 * st_w;
         const bool ok = y >= 0 && y < a.H && ci0 + st_c < a.Cin;
-        const unsigned base = (unsigned)(((ci0 + st_c) * HW + y * a.W + xs) * 4);
+        const unsigned base = (unsigned)(((ci0 + st_c) * HW + y * a.W + xs) * 4) + (G == 1 ? 0u : (unsigned)((int64_t)(b * G + st_sub) * a.x_bs * 4));
 #pragma unroll
         for (int k = 0; k < 2; ++k) xq[k] = __builtin_amdgcn_raw_buffer_load_b128(xr, (ok && xs + 4 * k < a.W) ? base + 16 * k : OOB_S, 0, 0);
         xh[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (ok && xs > 0 && xs - 1 < a.W) ? base - 4 : OOB_S, 0, 0));
-        xh[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (ok && st_s == 7 && xs + 8 < a.W) ? base + 32 : OOB_S, 0, 0));
+        xh[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (ok && st_w == C::SPG - 1 && xs + 8 < a.W) ? base + 32 : OOB_S, 0, 0));
     };
     auto commit_dz = [&](int buf) __attribute__((always_inline)) {
         unsigned* d = dz_lds + buf * 2 * SR_DZ_PART + st_c * SR_SDZ + st_s * 4;
@@ -561,7 +585,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
     // four dwords start with (pixel left of the segment, its first pixel); its last pixel opens the next segment's first dword
     // (loaded there as that segment's left neighbour); the strip's last dword (f[63], right halo) is segment 7's
     auto commit_x = [&](int slot) __attribute__((always_inline)) {
-        unsigned* row = x_lds + st_c * SR_SX + slot * SR_SLOT + st_s * 4;
+        unsigned* row = x_lds + st_c * SR_SX + slot * SR_SLOT + st_sub * C::P + st_w * 4;
         const f32x4s f0 = __builtin_bit_cast(f32x4s, xq[0]), f1 = __builtin_bit_cast(f32x4s, xq[1]);
         const float e[10] = {xh[0], f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3], xh[1]};
         unsigned hi[5], mid[5];
@@ -569,21 +593,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
         for (int p2 = 0; p2 < 5; ++p2) split2(e[2 * p2], e[2 * p2 + 1], hi[p2], mid[p2]);
         *reinterpret_cast<u32x4s*>(row) = u32x4s{hi[0], hi[1], hi[2], hi[3]};
         *reinterpret_cast<u32x4s*>(row + SR_X_PART) = u32x4s{mid[0], mid[1], mid[2], mid[3]};
-        if (st_s == 7) {
+        if (st_w == C::SPG - 1) {
             row[4] = hi[4];
             row[SR_X_PART + 4] = mid[4];
         }
     };
 
     const unsigned* a_ptr = dz_lds + (wm * 32 + l31) * SR_SDZ + kh * 4 + grp * 16;
-    const unsigned* b_ptr = x_lds + (wn * 32 + l31) * SR_SX + kh * 4 + grp * 16;
+    const unsigned* b_ptr = x_lds + (wn * 32 + l31) * SR_SX + kh * 4 + grp * C::GOFF;
 
     int u = u0;
     while (u < u1) {
         // a run of rows inside one strip: y = yb .. ye - 1
         const int yb = u % a.H, sb = u / a.H;
         const int tx = sb % a.tilesX, b = sb / a.tilesX;
-        const int x0 = tx * 64;
+        const int x0 = G == 1 ? tx * 64 : 0;
         const int ye = min(a.H, yb + (u1 - u));
         // run prologue: rows yb - 1 and yb of x into the ring (synchronously), then the dz row and the next x row of the first unit
         __syncthreads();                              // every wave is done with the previous run's ring and dz buffers
@@ -593,43 +617,59 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
         commit_x(yb & 3);
         issue_dz(b, x0, yb);
         issue_x(b, x0, yb + 1);
+        commit_dz(yb & 1);
+        commit_x((yb + 1) & 3);
+        __syncthreads();
+        if (yb + 1 < ye) {
+            issue_dz(b, x0, yb + 1);
+            issue_x(b, x0, yb + 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         for (int y = yb; y < ye; ++y) {
+            // unit y: MFMAs on dz buffer y & 1 and ring rows y - 1 .. y + 1; the NEXT unit's rows (loaded since the barrier that
+            // opened this unit) are split and committed SW_COMMIT_AT sixths of the way through -- into the other dz buffer and
+            // the ring slot of row y - 2, both last read in unit y - 1 -- so the commit's VALU / LDS-write work sits between
+            // MFMAs instead of in front of the barrier, where all eight waves did it at once with the matrix pipe idle
             const int buf = y & 1;
-            commit_dz(buf);
-            commit_x((y + 1) & 3);                    // slot of row y - 3: last read two barriers ago
-            __syncthreads();
-            if (y + 1 < ye) {
-                issue_dz(b, x0, y + 1);
-                issue_x(b, x0, y + 2);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            const bool more = y + 1 < ye;
             const unsigned* ab = a_ptr + buf * 2 * SR_DZ_PART;
+            bf16x8 ah, am;
 #pragma unroll
-            for (int sg = 0; sg < 2; ++sg) {
-                const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4s*>(ab + sg * 8));
-                const bf16x8 am = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4s*>(ab + SR_DZ_PART + sg * 8));
+            for (int gk = 0; gk < 6; ++gk) {
+                const int sg = gk / 3, ky = gk % 3;
+                if (gk == SW_COMMIT_AT && more) {
+                    commit_dz(buf ^ 1);
+                    commit_x((y + 2) & 3);
+                }
+                if (ky == 0) {
+                    ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4s*>(ab + sg * 8));
+                    am = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4s*>(ab + SR_DZ_PART + sg * 8));
+                }
+                const unsigned* br = b_ptr + ((y - 1 + ky) & 3) * SR_SLOT + sg * C::SOFF;
+                u32x4s sh[2][3];                  // [part][horizontal shift]
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const unsigned* br = b_ptr + ((y - 1 + ky) & 3) * SR_SLOT + sg * 8;
-                    u32x4s sh[2][3];                  // [part][horizontal shift]
+                for (int pt = 0; pt < 2; ++pt) {
+                    const u32x4s q = *reinterpret_cast<const u32x4s*>(br + pt * SR_X_PART);
+                    const unsigned d4 = br[pt * SR_X_PART + 4];
+                    sh[pt][0] = q;
+                    sh[pt][1] = u32x4s{__builtin_amdgcn_alignbit(q[1], q[0], 16), __builtin_amdgcn_alignbit(q[2], q[1], 16),
+                                       __builtin_amdgcn_alignbit(q[3], q[2], 16), __builtin_amdgcn_alignbit(d4, q[3], 16)};
+                    sh[pt][2] = u32x4s{q[1], q[2], q[3], d4};
+                }
 #pragma unroll
-                    for (int pt = 0; pt < 2; ++pt) {
-                        const u32x4s q = *reinterpret_cast<const u32x4s*>(br + pt * SR_X_PART);
-                        const unsigned d4 = br[pt * SR_X_PART + 4];
-                        sh[pt][0] = q;
-                        sh[pt][1] = u32x4s{__builtin_amdgcn_alignbit(q[1], q[0], 16), __builtin_amdgcn_alignbit(q[2], q[1], 16),
-                                           __builtin_amdgcn_alignbit(q[3], q[2], 16), __builtin_amdgcn_alignbit(d4, q[3], 16)};
-                        sh[pt][2] = u32x4s{q[1], q[2], q[3], d4};
-                    }
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        const bf16x8 bh = __builtin_bit_cast(bf16x8, sh[0][j]), bm = __builtin_bit_cast(bf16x8, sh[1][j]);
-                        acc[ky * 3 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[ky * 3 + j], 0, 0, 0);
-                        acc[ky * 3 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[ky * 3 + j], 0, 0, 0);
-                        acc[ky * 3 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[ky * 3 + j], 0, 0, 0);
-                    }
+                for (int j = 0; j < 3; ++j) {
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, sh[0][j]), bm = __builtin_bit_cast(bf16x8, sh[1][j]);
+                    acc[ky * 3 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[ky * 3 + j], 0, 0, 0);
+                    acc[ky * 3 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[ky * 3 + j], 0, 0, 0);
+                    acc[ky * 3 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[ky * 3 + j], 0, 0, 0);
                 }
             }
+            __syncthreads();
+            if (y + 2 < ye) {
+                issue_dz(b, x0, y + 2);
+                issue_x(b, x0, y + 3);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         u += ye - yb;
     }
@@ -647,9 +687,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
     }
 }
 
+int split_wgrad_group(int W) { return W >= 64 ? 1 : 64 / W; }      // images per unit: 1, 2 (W = 32), 4 (W = 16)
+
 void split_wgrad_plan(int B, int Cin, int Cout, int H, int W, int& splitK, int& tilesX) {
-    tilesX = cdiv(W, 64);
-    const int64_t units = (int64_t)B * H * tilesX;
+    tilesX = W >= 64 ? cdiv(W, 64) : 1;
+    const int64_t units = (int64_t)(B / split_wgrad_group(W)) * H * tilesX;
     const int tiles = cdiv(Cin, 64) * cdiv(Cout, 64);
     int64_t k = std::max<int64_t>(1, device_cu_count() / tiles);    // one 4-wave block per CU (110 KB of LDS), one round
     k = std::min<int64_t>(k, std::max<int64_t>(1, units / 16));      // at least 16 rows per block
@@ -661,7 +703,9 @@ void split_wgrad_plan(int B, int Cin, int Cout, int H, int W, int& splitK, int& 
 extern "C" {
 
 int onet_conv3x3_split_wgrad_ok(int B, int Cin, int Cout, int H, int W) {
-    return (B > 0 && Cin > 0 && Cout > 0 && H > 0 && W >= 64 && (W & 3) == 0) ? 1 : 0;
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0) return 0;
+    if (W >= 64) return (W & 3) == 0 ? 1 : 0;
+    return ((W == 32 || W == 16) && B % (64 / W) == 0) ? 1 : 0;         // narrower maps: 64 / W images side by side per unit
 }
 
 int64_t onet_conv3x3_split_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W) {
@@ -673,17 +717,24 @@ int64_t onet_conv3x3_split_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W
 int onet_conv3x3_split_wgrad(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs, float* dw, void* ws, int64_t ws_bytes,
                              int B, int Cin, int Cout, int H, int W, int accumulate, void* stream) {
     ONET_REQUIRE(x && dz && dw && ws, "conv3x3_split_wgrad: null pointer");
-    ONET_REQUIRE(onet_conv3x3_split_wgrad_ok(B, Cin, Cout, H, W), "conv3x3_split_wgrad: needs W >= 64 and W %% 4 == 0 (use onet_conv3x3_winograd_wgrad)");
+    ONET_REQUIRE(onet_conv3x3_split_wgrad_ok(B, Cin, Cout, H, W),
+                 "conv3x3_split_wgrad: needs W >= 64 with W %% 4 == 0, or W = 32 / 16 with B %% (64 / W) == 0 (use onet_conv3x3_winograd_wgrad)");
     ONET_REQUIRE((x_bs & 3) == 0 && (dz_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dz) & 15) == 0,
                  "conv3x3_split_wgrad: 16-byte aligned image rows required");
     ONET_REQUIRE(x_bs >= (int64_t)Cin * H * W && dz_bs >= (int64_t)Cout * H * W, "conv3x3_split_wgrad: batch stride too small");
     ONET_REQUIRE((int64_t)std::max(Cin, Cout) * H * W * 4 < (1ll << 31), "conv3x3_split_wgrad: image exceeds the 2 GiB buffer-resource range");
+    const int G = split_wgrad_group(W);
+    ONET_REQUIRE(G == 1 || (((int64_t)(B - 1) * x_bs + (int64_t)Cin * H * W) * 4 < (1ll << 31) &&
+                            ((int64_t)(B - 1) * dz_bs + (int64_t)Cout * H * W) * 4 < (1ll << 31)),
+                 "conv3x3_split_wgrad: on maps narrower than 64 pixels the whole batch must lie within the 2 GiB buffer-resource range");
     SwArgs a{x, x_bs, dz, dz_bs, (float*)ws, B, Cin, Cout, H, W, cdiv(Cin, 64), cdiv(Cout, 64), 1, 1};
     split_wgrad_plan(B, Cin, Cout, H, W, a.splitK, a.tilesX);
     const int64_t need = (int64_t)a.splitK * 2 * 9 * Cout * Cin * 4;
     ONET_REQUIRE(ws_bytes >= need, "conv3x3_split_wgrad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
     const int64_t blocks = (int64_t)a.splitK * a.ciTiles * a.coTiles;
-    hipLaunchKernelGGL(conv3x3_split_wgrad_kernel, dim3((unsigned)blocks), dim3(512), 0, as_stream(stream), a);
+    if (G == 1) hipLaunchKernelGGL(conv3x3_split_wgrad_kernel<1>, dim3((unsigned)blocks), dim3(512), 0, as_stream(stream), a);
+    else if (G == 2) hipLaunchKernelGGL(conv3x3_split_wgrad_kernel<2>, dim3((unsigned)blocks), dim3(512), 0, as_stream(stream), a);
+    else hipLaunchKernelGGL(conv3x3_split_wgrad_kernel<4>, dim3((unsigned)blocks), dim3(512), 0, as_stream(stream), a);
     int rc = check_launch("conv3x3_split_wgrad_kernel");
     if (rc) return rc;
     return launch_wgrad_reduce((const float*)ws, dw, a.splitK * 2, 9, Cout, Cin, 0, accumulate, as_stream(stream));

@@ -91,13 +91,18 @@ def split_enabled():
     return bool(_setting("split", SPLIT_AUTO))
 
 
-def convt_operand_bf16():
-    """operand_bf16 argument of the onet_convT2x2_* entry points for the calling model: 1 = bf16 operands (the bf16 conv path),
-    2 = split bf16 operands (fp32-level results; with the split 3x3 kernels under "auto"), 0 = fp32 MFMA"""
+def convt_operand_bf16(B, h, w, Ct):
+    """operand_bf16 argument of the onet_convT2x2_* entry points for the calling model and layer: 1 = bf16 operands (the bf16
+    conv path), 2 = split bf16 operands (fp32-level results; with the split 3x3 kernels under "auto", on layers whose forward
+    GEMM has at least CONVT_SPLIT_MIN_BLOCKS 128 x 128 tiles -- half the CUs by default: like conv3x3_algo, small problems
+    keep the fp32 kernels, where there is nothing to gain), 0 = fp32 MFMA"""
     algo = conv_algo()
     if algo == "bf16":
         return int(bool(_setting("convt_bf16", CONVT_BF16)))
-    return 2 if (algo in ("auto", "split") and split_enabled() and CONVT_SPLIT) else 0
+    if not (algo in ("auto", "split") and split_enabled() and CONVT_SPLIT):
+        return 0
+    min_blocks = CONVT_SPLIT_MIN_BLOCKS if CONVT_SPLIT_MIN_BLOCKS is not None else n_cu() // 2
+    return 2 if (B * h * w // 128) * (4 * Ct // 128) >= min_blocks else 0
 
 
 _CU_COUNT = {}
@@ -307,7 +312,7 @@ def convT2x2_fwd(x, wq, bias, out, Ct, pt, pl, out16=None):
         o16bs = out16.stride(0) if B > 1 else Ct * Ho * Wo
         e0 = _prof_begin()
         rc = _lib.load().onet_convT2x2_fwd_b(_p(x), xbs, _p(wq), _p(bias), _p(out), obs, _p(out16), o16bs, B, Cin, Ct, h, w, Ho, Wo,
-                                             pt, pl, convt_operand_bf16(), _stream())
+                                             pt, pl, convt_operand_bf16(B, h, w, Ct), _stream())
         _prof_end("convt_gemm_kernel", flops if rc == 0 else 0.0, e0, nb if rc == 0 else 0.0)
         if rc == 0:
             return True
@@ -317,7 +322,7 @@ def convT2x2_fwd(x, wq, bias, out, Ct, pt, pl, out16=None):
         return False
     e0 = _prof_begin()
     _lib.call("onet_convT2x2_fwd", _p(x), xbs, _p(wq), _p(bias), _p(out), obs, B, Cin, Ct, h, w, Ho, Wo, pt, pl,
-              convt_operand_bf16(), _stream())
+              convt_operand_bf16(B, h, w, Ct), _stream())
     _prof_end("convt_gemm_kernel", flops, e0, nb)
     return False
 
@@ -510,7 +515,9 @@ def conv3x3_auto(x, pk, direction, out=None, x16=None):
 
 
 FUSE_BN_STATS = _os.environ.get("ONET_FUSE_BN_STATS", "1") != "0"
+CONVT_SPLIT_MIN_BLOCKS = int(_os.environ["ONET_CONVT_SPLIT_MIN_BLOCKS"]) if "ONET_CONVT_SPLIT_MIN_BLOCKS" in _os.environ else None
 CONVT_SPLIT = _os.environ.get("ONET_CONVT_SPLIT", "1") != "0"     # 0: the ConvTranspose2d GEMMs stay on the fp32 MFMA pipe
+SPLIT_WGRAD_MINW = int(_os.environ.get("ONET_SPLIT_WGRAD_MINW", "16"))   # 64: the 32- and 16-pixel levels keep the Winograd weight gradients
 SPLIT_AUTO = _os.environ.get("ONET_SPLIT", "1") != "0"          # 0: "auto" never selects the split-bf16 kernel (round-2 dispatch)
 STEM_FUSED = _os.environ.get("ONET_STEM_FUSED", "1") != "0"      # 0: the stem takes the direct MFMA kernel + a statistics pass
 
@@ -743,9 +750,12 @@ def conv3x3_split(x, wq, Cout, out=None):
 
 def split_wgrad_ok(x, dz):
     B, Cin, H, W = x.shape
-    return bool(_lib.load().onet_conv3x3_split_wgrad_ok(B, Cin, dz.shape[1], H, W)) and \
+    ok = bool(_lib.load().onet_conv3x3_split_wgrad_ok(B, Cin, dz.shape[1], H, W)) and \
         x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and dz.is_contiguous() and dz.data_ptr() % 16 == 0 and \
         max(Cin, dz.shape[1]) * H * W * 4 < 2 ** 31
+    if ok and W < 64:        # 64 / W images side by side per unit: one buffer resource over the whole batch
+        ok = ((B - 1) * x.stride(0) + Cin * H * W) * 4 < 2 ** 31 and B * dz.shape[1] * H * W * 4 < 2 ** 31
+    return ok
 
 
 def conv3x3_split_wgrad(x, dz, dw_shape, out=None):
@@ -873,8 +883,9 @@ def conv3x3_wgrad_auto(x, dz, dw_shape, out=None, x16=None, dz16=None):
     shp = (x if x is not None else x16).shape
     if wgrad_takes_bf16(Cin, shp[2], shp[3]) and (dz16 is not None or dz.is_contiguous()):
         return conv3x3_wgrad_bf16(x, dz, dw_shape, out=out, x16=x16, dz16=dz16)
-    # fp32 tensors, maps at least 64 pixels wide: the split-bf16 row kernel (the stem, Cin < 16, keeps its own VALU kernel)
-    if conv_algo() in ("auto", "split") and (split_enabled() or conv_algo() == "split") and x is not None and Cin >= 16 and split_wgrad_ok(x, dz):
+    # fp32 tensors, maps 16 / 32 / >= 64 pixels wide: the split-bf16 row kernel (the stem, Cin < 16, keeps its own VALU kernel)
+    if conv_algo() in ("auto", "split") and (split_enabled() or conv_algo() == "split") and x is not None and Cin >= 16 and \
+            x.shape[3] >= SPLIT_WGRAD_MINW and split_wgrad_ok(x, dz):
         return conv3x3_split_wgrad(x, dz, dw_shape, out=out)
     if use_winograd(Cin, Cout, x.shape[2], x.shape[3]):
         if WGRAD4 != "0" and (WGRAD4 == "1" or Cin >= 256 or (Cin >= 128 and Cout >= 256)) and winograd4_wgrad_ok(x, dz):
@@ -1202,7 +1213,7 @@ def convT2x2_dgrad(dy, wp_dgrad, Cin, h, w, pt, pl, want_dbias=False, db_out=Non
             ws = torch.empty(need // 4, dtype=F32, device=dy.device)
             e0 = _prof_begin()
             rc = lib.onet_convT2x2_dgrad_dbias(_p(dy), dybs, _p(wp_dgrad), _p(dx), Cin * h * w, _p(db), _p(ws), need, B, Cin, Ct, h,
-                                               w, Ho, Wo, pt, pl, convt_operand_bf16(), _stream())
+                                               w, Ho, Wo, pt, pl, convt_operand_bf16(B, h, w, Ct), _stream())
             if rc == 0:
                 _prof_end("convt_gemm_kernel", flops, e0, nbytes)
                 return dx, db
@@ -1211,7 +1222,7 @@ def convT2x2_dgrad(dy, wp_dgrad, Cin, h, w, pt, pl, want_dbias=False, db_out=Non
                 raise _lib.OnetHipError(f"onet_convT2x2_dgrad_dbias failed ({rc}): {_lib.last_error()}")
     e0 = _prof_begin()
     _lib.call("onet_convT2x2_dgrad", _p(dy), dybs, _p(wp_dgrad), _p(dx), Cin * h * w, B, Cin, Ct, h, w, Ho, Wo, pt, pl,
-              convt_operand_bf16(), _stream())
+              convt_operand_bf16(B, h, w, Ct), _stream())
     _prof_end("convt_gemm_kernel", flops, e0, nbytes)
     return (dx, None) if want_dbias else dx
 
@@ -1228,7 +1239,7 @@ def convT2x2_wgrad(x, dy, dw_shape, pt, pl, want_dbias, out=None, db_out=None):
     ws = workspace(need, x.device)
     e0 = _prof_begin()
     _lib.call("onet_convT2x2_wgrad", _p(x), xbs, _p(dy), dybs, _p(dw), _p(ws), ws.numel() * 4, B, Cin, Ct, h, w, Ho, Wo,
-              pt, pl, convt_operand_bf16(), _stream())
+              pt, pl, convt_operand_bf16(B, h, w, Ct), _stream())
     _prof_end("convt_wgrad_gemm_kernel", 2.0 * B * h * w * Cin * 4 * Ct, e0, 4.0 * (B * h * w * (Cin + 4 * Ct) + 4 * Cin * Ct))
     db = None
     if want_dbias:

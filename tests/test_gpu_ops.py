@@ -117,11 +117,13 @@ def test_conv3x3_winograd4_fwd_dgrad(dev, B, Cin, Cout, H, W):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 64, 64, 24, 64), (1, 32, 128, 64, 64), (3, 16, 36, 33, 68), (2, 128, 80, 16, 192),
-                                             (5, 48, 64, 37, 128), (2, 24, 20, 9, 100)])
+                                             (5, 48, 64, 37, 128), (2, 24, 20, 9, 100),
+                                             (4, 64, 64, 32, 32), (6, 80, 48, 19, 32), (8, 128, 64, 16, 16), (12, 32, 96, 7, 16)])
 def test_conv3x3_split_wgrad(dev, B, Cin, Cout, H, W):
     """conv3x3_split_wgrad_kernel (both operands split into bf16 hi + mid, three MFMAs per term, row-streaming units,
     deterministic split-K) against the fp64 weight gradient at 2e-5 of its scale; ragged strips (W % 64 != 0), odd heights,
-    channel tails, runs crossing image boundaries; bitwise reproducible."""
+    channel tails, runs crossing image boundaries; 32- and 16-pixel-wide maps (2 / 4 images side by side per unit, each with
+    its own zero halo); bitwise reproducible."""
     from onet_amd import ops
     x = rnd(B, Cin, H, W, seed=11)
     g = rnd(B, Cout, H, W, seed=12)
@@ -131,7 +133,13 @@ def test_conv3x3_split_wgrad(dev, B, Cin, Cout, H, W):
     dw = ops.conv3x3_split_wgrad(x.to(dev), g.to(dev), (Cout, Cin, 3, 3))
     close(dw, w.grad, tol=2e-5, what="split wgrad")
     assert torch.equal(dw, ops.conv3x3_split_wgrad(x.to(dev), g.to(dev), (Cout, Cin, 3, 3)))
-    assert not ops.split_wgrad_ok(x[..., :32].contiguous().to(dev), g[..., :32].contiguous().to(dev))      # W < 64: other kernels
+    if W >= 64:     # narrower maps: only 32 / 16 pixels wide with a whole number of image groups
+        assert not ops.split_wgrad_ok(x[..., :24].contiguous().to(dev), g[..., :24].contiguous().to(dev))
+        assert ops.split_wgrad_ok(x[..., :32].contiguous().to(dev), g[..., :32].contiguous().to(dev)) == (B % 2 == 0)
+    # a channel slice of a wider buffer as x (the decoder's concat buffers): batch stride != Cin * H * W
+    wide = torch.zeros(B, Cin + 16, H, W)
+    wide[:, 16:] = x
+    assert torch.equal(dw, ops.conv3x3_split_wgrad(wide.to(dev)[:, 16:], g.to(dev), (Cout, Cin, 3, 3)))
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 64, 64, 40, 48), (1, 32, 128, 64, 64), (3, 16, 36, 33, 28), (2, 128, 80, 16, 96),
@@ -718,6 +726,7 @@ def test_up_convT_cat_split_operands(dev, h, w, Cin, Ct, monkeypatch):
             out.backward(g.to(dev))
         return out.detach()[:, C2:].cpu().double(), A.grad.cpu().double(), Cw.grad.cpu().double()
 
+    monkeypatch.setattr(ops, "CONVT_SPLIT_MIN_BLOCKS", 0)       # (the dispatch keeps the fp32 kernels on problems this small)
     sp = run(ops.Settings(conv="auto", split=True))
     f32 = run(ops.Settings(conv="auto", split=False))
     monkeypatch.setattr(ops, "CONVT_SPLIT", False)

@@ -12,7 +12,10 @@ def timeit(fn):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / N
 tot = [0.0, 0.0]
-for ci, co, H in [(64, 64, 256), (128, 64, 256), (64, 128, 128), (128, 128, 128), (256, 128, 128), (128, 256, 64), (256, 256, 64), (512, 256, 64)]:
+for ci, co, H in [(64, 64, 256), (128, 64, 256), (64, 128, 128), (128, 128, 128), (256, 128, 128), (128, 256, 64), (256, 256, 64), (512, 256, 64),
+                  (256, 512, 32), (512, 512, 32), (1024, 512, 32), (512, 1024, 16), (1024, 1024, 16)]:
+    if H < int(os.environ.get("MINW", "16")):
+        continue
     x = torch.randn(B, ci, H, H, device="cuda"); g = torch.randn(B, co, H, H, device="cuda")
     shp = (co, ci, 3, 3)
     tw = timeit(lambda: ops.conv3x3_winograd4_wgrad(x, g, shp) if (ci >= 256 or (ci >= 128 and co >= 256)) and ops.winograd4_wgrad_ok(x, g) else ops.conv3x3_winograd_wgrad(x, g, shp))
