@@ -493,7 +493,6 @@ struct SwArgs {
 // right-halo dword, rounded to 16 bytes), so a horizontal shift never reads a neighbouring image's pixel.  Everything else -- the
 // ring over rows, the two pixel groups, the commit inside the MFMA block -- is the 64-pixel strip's.
 constexpr int SR_SDZ = 36;                                  // dword stride per co
-constexpr int SR_DZ_PART = 64 * SR_SDZ;
 template <int G> struct SwCfg {
     static constexpr int SPG = 8 / G;                       // 8-pixel segments per sub-row
     static constexpr int P = G == 1 ? 36 : (G == 2 ? 20 : 12);
@@ -504,11 +503,18 @@ template <int G> struct SwCfg {
     static constexpr int SOFF = G == 4 ? 12 : 8;
 };
 
-template <int G>
+// COT = output channels per block.  64: the 8 waves are two K-groups x (2 x 2) quadrants, group g takes the 16-pixel segments 2g,
+// 2g + 1 of a unit and writes its own slab (54 MFMAs per wave between barriers).  128 (Cout % 128 == 0, G < 4: the LDS holds
+// it): 4 x 2 quadrants, every wave takes all four segments -- 108 MFMAs per wave between barriers, the x rows staged once per
+// 128 output channels, one slab per block.
+template <int G, int COT>
 __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
     using C = SwCfg<G>;
     constexpr int SR_SX = C::SX, SR_SLOT = C::SLOT, SR_X_PART = C::X_PART;
-    __shared__ __attribute__((aligned(16))) unsigned dz_lds[2 * 2 * SR_DZ_PART];     // [buf][part][64 co][SR_SDZ]
+    constexpr int SR_DZ_PART = COT * SR_SDZ;
+    constexpr int NSEG = COT == 64 ? 2 : 4;                  // 16-pixel segments per wave and unit
+    constexpr int DZI = COT / 64;                            // dz staging items (8 pixels of one channel) per thread
+    __shared__ __attribute__((aligned(16))) unsigned dz_lds[2 * 2 * SR_DZ_PART];     // [buf][part][COT co][SR_SDZ]
     __shared__ __attribute__((aligned(16))) unsigned x_lds[2 * SR_X_PART];           // [part][64 ci][SR_SX]
 
     int bid;
@@ -518,15 +524,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
     }
     const int tiles = a.ciTiles * a.coTiles;
     const int ks = bid / tiles, tile = bid % tiles;
-    const int ci0 = (tile % a.ciTiles) * 64, co0 = (tile / a.ciTiles) * 64;
+    const int ci0 = (tile % a.ciTiles) * 64, co0 = (tile / a.ciTiles) * COT;
     const int nunits = (a.B / G) * a.tilesX * a.H;             // unit = (image [group of G], 64-pixel strip, row), rows fastest
     const int per = (nunits + a.splitK - 1) / a.splitK;
     const int u0 = ks * per, u1 = min(u0 + per, nunits);
 
-    // 8 waves = 2 pixel groups x (2 x 2) quadrants of the 64 co x 64 ci tile: group g takes the 16-pixel segments 2g, 2g + 1 of
-    // every unit (a split over K inside the block: two waves per SIMD, each group writes its own slab)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int grp = wid >> 2, wm = (wid >> 1) & 1, wn = wid & 1;
+    const int grp = COT == 64 ? wid >> 2 : 0, wm = COT == 64 ? (wid >> 1) & 1 : wid >> 1, wn = wid & 1;
     const int l31 = lane & 31, kh = lane >> 5;
     const int HW = a.H * a.W;
 
@@ -539,7 +543,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
     // staging roles: thread = (channel = tid / 8, 8-pixel segment = tid % 8) of the dz row and of the x row
     const int st_c = tid >> 3, st_s = tid & 7;
     const int st_sub = st_s / C::SPG, st_w = st_s % C::SPG;     // image of the group, 8-pixel segment of its row
-    u32x4s dzv[2], xq[2];
+    u32x4s dzv[2 * DZI], xq[2];
     float xh[2];
     // loads of one dz row and / or one x row of strip (b, x0): row < 0 or >= H -> zeros.  G == 1: one buffer resource per image
     // (a 256 x 256 level's batch exceeds the 2 GiB range); G > 1: the lanes of a wave address different images, so the resource
@@ -548,10 +552,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
         const __amdgpu_buffer_rsrc_t dr = G == 1 ? s_rsrc(a.dz + (int64_t)b * a.dz_bs, (int64_t)a.Cout * HW * 4)
                                                  : s_rsrc(a.dz, ((int64_t)(a.B - 1) * a.dz_bs + (int64_t)a.Cout * HW) * 4);
         const int xs = x0 + 8 * st_w;
-        const bool ok = y >= 0 && y < a.H && co0 + st_c < a.Cout;
-        const unsigned base = (unsigned)(((co0 + st_c) * HW + y * a.W + xs) * 4) + (G == 1 ? 0u : (unsigned)((int64_t)(b * G + st_sub) * a.dz_bs * 4));
 #pragma unroll
-        for (int k = 0; k < 2; ++k) dzv[k] = __builtin_amdgcn_raw_buffer_load_b128(dr, (ok && xs + 4 * k < a.W) ? base + 16 * k : OOB_S, 0, 0);
+        for (int i = 0; i < DZI; ++i) {
+            const int co = co0 + st_c + 64 * i;
+            const bool ok = y >= 0 && y < a.H && co < a.Cout;
+            const unsigned base = (unsigned)((co * HW + y * a.W + xs) * 4) + (G == 1 ? 0u : (unsigned)((int64_t)(b * G + st_sub) * a.dz_bs * 4));
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                dzv[2 * i + k] = __builtin_amdgcn_raw_buffer_load_b128(dr, (ok && xs + 4 * k < a.W) ? base + 16 * k : OOB_S, 0, 0);
+        }
     };
     auto issue_x = [&](int b, int x0, int y) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t xr = G == 1 ? s_rsrc(a.x + (int64_t)b * a.x_bs, (int64_t)a.Cin * HW * 4)
@@ -565,21 +574,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
         xh[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (ok && st_w == C::SPG - 1 && xs + 8 < a.W) ? base + 32 : OOB_S, 0, 0));
     };
     auto commit_dz = [&](int buf) __attribute__((always_inline)) {
-        unsigned* d = dz_lds + buf * 2 * SR_DZ_PART + st_c * SR_SDZ + st_s * 4;
-        // (the whole vector is re-typed, then indexed: element-wise bit casts of the loaded vector's lanes came out as four
-        // copies of lane 0 with hipcc 7.2 -- found with delta-function inputs)
-        const f32x4s lo = __builtin_bit_cast(f32x4s, dzv[0]), hv = __builtin_bit_cast(f32x4s, dzv[1]);
-        const float f[8] = {lo[0], lo[1], lo[2], lo[3], hv[0], hv[1], hv[2], hv[3]};
-        u32x4s hi, mid;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            unsigned hh, mm;
-            split2(f[2 * c], f[2 * c + 1], hh, mm);
-            hi[c] = hh;
-            mid[c] = mm;
+        for (int i = 0; i < DZI; ++i) {
+            unsigned* d = dz_lds + buf * 2 * SR_DZ_PART + (st_c + 64 * i) * SR_SDZ + st_s * 4;
+            // (the whole vector is re-typed, then indexed: element-wise bit casts of the loaded vector's lanes came out as four
+            // copies of lane 0 with hipcc 7.2 -- found with delta-function inputs)
+            const f32x4s lo = __builtin_bit_cast(f32x4s, dzv[2 * i]), hv = __builtin_bit_cast(f32x4s, dzv[2 * i + 1]);
+            const float f[8] = {lo[0], lo[1], lo[2], lo[3], hv[0], hv[1], hv[2], hv[3]};
+            u32x4s hi, mid;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                unsigned hh, mm;
+                split2(f[2 * c], f[2 * c + 1], hh, mm);
+                hi[c] = hh;
+                mid[c] = mm;
+            }
+            *reinterpret_cast<u32x4s*>(d) = hi;
+            *reinterpret_cast<u32x4s*>(d + SR_DZ_PART) = mid;
         }
-        *reinterpret_cast<u32x4s*>(d) = hi;
-        *reinterpret_cast<u32x4s*>(d + SR_DZ_PART) = mid;
     };
     // row element e = column x0 - 1 + e; dword p = (e[2p], e[2p+1]) = (f[2p-1], f[2p]) of the interior row f: an 8-pixel segment's
     // four dwords start with (pixel left of the segment, its first pixel); its last pixel opens the next segment's first dword
@@ -601,6 +613,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
 
     const unsigned* a_ptr = dz_lds + (wm * 32 + l31) * SR_SDZ + kh * 4 + grp * 16;
     const unsigned* b_ptr = x_lds + (wn * 32 + l31) * SR_SX + kh * 4 + grp * C::GOFF;
+    // x-row dword offset of segment s of a wave: pixel groups 2 s, 2 s + 1 -> sub-row (2 s) / SPG, position (2 s) % SPG
+    auto seg_off = [](int sg) { return G == 1 ? sg * 8 : (G == 2 ? (sg >> 1) * 20 + (sg & 1) * 8 : sg * 12); };
 
     int u = u0;
     while (u < u1) {
@@ -635,9 +649,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
             const unsigned* ab = a_ptr + buf * 2 * SR_DZ_PART;
             bf16x8 ah, am;
 #pragma unroll
-            for (int gk = 0; gk < 6; ++gk) {
+            for (int gk = 0; gk < 3 * NSEG; ++gk) {
                 const int sg = gk / 3, ky = gk % 3;
-                if (gk == SW_COMMIT_AT && more) {
+                if (gk == (COT == 64 ? SW_COMMIT_AT : 2 * SW_COMMIT_AT) && more) {
                     commit_dz(buf ^ 1);
                     commit_x((y + 2) & 3);
                 }
@@ -645,7 +659,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
                     ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4s*>(ab + sg * 8));
                     am = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4s*>(ab + SR_DZ_PART + sg * 8));
                 }
-                const unsigned* br = b_ptr + ((y - 1 + ky) & 3) * SR_SLOT + sg * C::SOFF;
+                const unsigned* br = b_ptr + ((y - 1 + ky) & 3) * SR_SLOT + seg_off(sg);
                 u32x4s sh[2][3];                  // [part][horizontal shift]
 #pragma unroll
                 for (int pt = 0; pt < 2; ++pt) {
@@ -678,7 +692,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
     const int ci = ci0 + wn * 32 + l31;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-        float* o = a.slab + ((int64_t)(ks * 2 + grp) * 9 + t) * n;
+        float* o = a.slab + ((int64_t)(COT == 64 ? ks * 2 + grp : ks) * 9 + t) * n;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
@@ -689,10 +703,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
 
 int split_wgrad_group(int W) { return W >= 64 ? 1 : 64 / W; }      // images per unit: 1, 2 (W = 32), 4 (W = 16)
 
+#ifndef SW_COT128
+#define SW_COT128 1
+#endif
+int split_wgrad_cot(int Cout, int W) { return (SW_COT128 && Cout % 128 == 0 && W >= 32) ? 128 : 64; }    // output channels per block
+
 void split_wgrad_plan(int B, int Cin, int Cout, int H, int W, int& splitK, int& tilesX) {
     tilesX = W >= 64 ? cdiv(W, 64) : 1;
     const int64_t units = (int64_t)(B / split_wgrad_group(W)) * H * tilesX;
-    const int tiles = cdiv(Cin, 64) * cdiv(Cout, 64);
+    const int tiles = cdiv(Cin, 64) * cdiv(Cout, split_wgrad_cot(Cout, W));
     int64_t k = std::max<int64_t>(1, device_cu_count() / tiles);    // one 4-wave block per CU (110 KB of LDS), one round
     k = std::min<int64_t>(k, std::max<int64_t>(1, units / 16));      // at least 16 rows per block
     splitK = (int)k;
@@ -711,7 +730,7 @@ int onet_conv3x3_split_wgrad_ok(int B, int Cin, int Cout, int H, int W) {
 int64_t onet_conv3x3_split_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W) {
     int splitK, tx;
     split_wgrad_plan(B, Cin, Cout, H, W, splitK, tx);
-    return (int64_t)splitK * 2 * 9 * Cout * Cin * 4;       // two pixel groups per block, a slab each
+    return (int64_t)splitK * (split_wgrad_cot(Cout, W) == 64 ? 2 : 1) * 9 * Cout * Cin * 4;    // 64-channel tiles: two K-groups per block, a slab each
 }
 
 int onet_conv3x3_split_wgrad(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs, float* dw, void* ws, int64_t ws_bytes,
@@ -727,17 +746,22 @@ int onet_conv3x3_split_wgrad(const float* x, int64_t x_bs, const float* dz, int6
     ONET_REQUIRE(G == 1 || (((int64_t)(B - 1) * x_bs + (int64_t)Cin * H * W) * 4 < (1ll << 31) &&
                             ((int64_t)(B - 1) * dz_bs + (int64_t)Cout * H * W) * 4 < (1ll << 31)),
                  "conv3x3_split_wgrad: on maps narrower than 64 pixels the whole batch must lie within the 2 GiB buffer-resource range");
-    SwArgs a{x, x_bs, dz, dz_bs, (float*)ws, B, Cin, Cout, H, W, cdiv(Cin, 64), cdiv(Cout, 64), 1, 1};
+    const int COT = split_wgrad_cot(Cout, W), slabs = COT == 64 ? 2 : 1;
+    SwArgs a{x, x_bs, dz, dz_bs, (float*)ws, B, Cin, Cout, H, W, cdiv(Cin, 64), cdiv(Cout, COT), 1, 1};
     split_wgrad_plan(B, Cin, Cout, H, W, a.splitK, a.tilesX);
-    const int64_t need = (int64_t)a.splitK * 2 * 9 * Cout * Cin * 4;
+    const int64_t need = (int64_t)a.splitK * slabs * 9 * Cout * Cin * 4;
     ONET_REQUIRE(ws_bytes >= need, "conv3x3_split_wgrad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
     const int64_t blocks = (int64_t)a.splitK * a.ciTiles * a.coTiles;
-    if (G == 1) hipLaunchKernelGGL(conv3x3_split_wgrad_kernel<1>, dim3((unsigned)blocks), dim3(512), 0, as_stream(stream), a);
-    else if (G == 2) hipLaunchKernelGGL(conv3x3_split_wgrad_kernel<2>, dim3((unsigned)blocks), dim3(512), 0, as_stream(stream), a);
-    else hipLaunchKernelGGL(conv3x3_split_wgrad_kernel<4>, dim3((unsigned)blocks), dim3(512), 0, as_stream(stream), a);
+    const dim3 grid((unsigned)blocks), blk(512);
+    if (COT == 128) {
+        if (G == 1) hipLaunchKernelGGL((conv3x3_split_wgrad_kernel<1, 128>), grid, blk, 0, as_stream(stream), a);
+        else hipLaunchKernelGGL((conv3x3_split_wgrad_kernel<2, 128>), grid, blk, 0, as_stream(stream), a);
+    } else if (G == 1) hipLaunchKernelGGL((conv3x3_split_wgrad_kernel<1, 64>), grid, blk, 0, as_stream(stream), a);
+    else if (G == 2) hipLaunchKernelGGL((conv3x3_split_wgrad_kernel<2, 64>), grid, blk, 0, as_stream(stream), a);
+    else hipLaunchKernelGGL((conv3x3_split_wgrad_kernel<4, 64>), grid, blk, 0, as_stream(stream), a);
     int rc = check_launch("conv3x3_split_wgrad_kernel");
     if (rc) return rc;
-    return launch_wgrad_reduce((const float*)ws, dw, a.splitK * 2, 9, Cout, Cin, 0, accumulate, as_stream(stream));
+    return launch_wgrad_reduce((const float*)ws, dw, a.splitK * slabs, 9, Cout, Cin, 0, accumulate, as_stream(stream));
 }
 
 int onet_conv3x3_split_pack_weights(const float* w, void* wq_fwd, void* wq_dgrad, int Cout, int Cin, void* stream) {

@@ -76,18 +76,28 @@ class FlatAdam:
         self.direct_grads = bool(self.gflat.is_cuda)
         invalidate_packed(model)
         self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)]
-        self.step_count = 0
+        self.step_count = 0           # steps taken by a parameter that never skipped one (torch: state['step'])
+        self._steps = None            # per-parameter counts, kept only once some parameter has skipped a step
         self.pg = process_group
         self.world_size = world_size
         self._buckets = None          # set by enable_overlap()
         # host-side group for the per-step NaN verdict (see _check_nan_all_ranks); created collectively, here
         self._flag_pg = None
         if world_size > 1 and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            err = None
             try:
                 self._flag_pg = dist.new_group(backend="gloo")
-            except Exception as e:      # no gloo in this build / rendezvous refused: every rank fails alike -> per-rank verdicts
+            except Exception as e:      # no gloo in this build / rendezvous refused on this rank
+                err = e
+            # the ranks must AGREE on whether the side group exists: one that holds it would wait in the per-step all-reduce for
+            # peers that skip it.  One MIN over the default group (a device tensor where that group is RCCL) settles it.
+            ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32,
+                              device=dev if dist.get_backend(process_group) == "nccl" else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=process_group)
+            if int(ok.item()) == 0:
                 import warnings
-                warnings.warn(f"onet_amd: no host-side group for the shared NaN verdict ({e}); a NaN loss raises on its own rank only")
+                warnings.warn("onet_amd: no host-side group for the shared NaN verdict on at least one rank"
+                              + (f" (here: {err})" if err is not None else "") + "; a NaN loss raises on its own rank only")
                 self._flag_pg = None
 
     # ------------------------------------------------------------------ bucketed all-reduce overlapped with backward
@@ -174,8 +184,10 @@ class FlatAdam:
 
     def _check_nan_all_ranks(self):
         """The loss's OV:234 verdict (Settings.lazy_nan), BEFORE the update is applied.  With several ranks the verdict
-        is shared first (one byte over a host-side gloo group: no GPU work, the host runs ahead of the device anyway), so
-        that every rank raises in the same step instead of one rank leaving its peers waiting in the all-reduce."""
+        is shared first (one byte over a host-side gloo group), so that every rank raises in the same step instead of one rank
+        leaving its peers waiting in the all-reduce.  Cost: `check_deferred_nan` waits for the event behind the loss kernel and
+        the host collective then lines the ranks' hosts up once per step -- the backward launches are already queued by then,
+        so the devices keep running, but the hosts cannot run further ahead than one step."""
         try:
             ops.check_deferred_nan()
             bad = None
@@ -195,33 +207,40 @@ class FlatAdam:
             raise bad
 
     def _segments_with_grads(self):
-        """torch.optim.Adam skips parameters whose .grad is None (frozen or unused branches keep p, m and v untouched).
-        -> None when every parameter has a gradient (one launch over the whole buffer), else the [start, end) element
-        ranges of the maximal runs of parameters that do."""
+        """torch.optim.Adam skips parameters whose .grad is None (frozen or unused branches keep p, m and v untouched) and
+        bias-corrects every parameter with ITS OWN step count (state['step']).  -> [(start, end, step)]: element ranges of the
+        maximal runs of parameters that have a gradient and share a step count, with the count this update is their n-th;
+        one range over the whole buffer as long as no parameter has ever skipped a step."""
         have = [p.grad is not None for p in self.params]
-        if all(have):
-            return None
-        segs, start = [], None
+        if self._steps is None:
+            if all(have):
+                self.step_count += 1
+                return [(0, self.numel, self.step_count)]
+            self._steps = [self.step_count] * len(self.params)
+        segs, start, cur = [], None, None
         for i, h in enumerate(have):
-            if h and start is None:
-                start = self.offsets[i]
-            if not h and start is not None:
-                segs.append((start, self.offsets[i]))
+            if h:
+                self._steps[i] += 1
+            st = self._steps[i] if h else None
+            if start is not None and st != cur:
+                segs.append((start, self.offsets[i], cur))
                 start = None
+            if h and start is None:
+                start, cur = self.offsets[i], st
         if start is not None:
-            segs.append((start, self.numel))
+            segs.append((start, self.numel, cur))
+        self.step_count = max(self._steps)
         return segs
 
     def step(self):
         self._check_nan_all_ranks()
         g = self.param_groups[0]
-        segs = self._segments_with_grads() if self.direct_grads else None
+        segs = self._segments_with_grads()
         self._gather_stray_grads()
         self.all_reduce_grads()
-        self.step_count += 1
-        for a, b in ([(0, self.numel)] if segs is None else segs):
+        for a, b, n in segs:
             ops.adam_step(self.flat[a:b], self.gflat[a:b], self.m[a:b], self.v[a:b], g["lr"], g["betas"][0], g["betas"][1],
-                          g["eps"], g["weight_decay"], self.step_count, grad_scale=1.0 / self.world_size)
+                          g["eps"], g["weight_decay"], n, grad_scale=1.0 / self.world_size)
         invalidate_packed(self.model)
 
     def broadcast_params(self, src=0):
@@ -328,6 +347,8 @@ def _fit(onet, train_loader, device, epochs, schedule, base_lr, eval_fn, eval_ev
         losses, n_img, t0 = [], 0, time.time()
         for batch in train_loader:
             X = batch[0] if isinstance(batch, (tuple, list)) else batch
+            if X.shape[0] < world:        # an epoch's short last batch with fewer images than ranks (the reference's loaders have
+                continue                  # no drop_last): every rank sees the same global batch, so every rank skips it
             X = shard_batch(X, rank, world, drop_remainder=True).to(device, non_blocking=True)
             loss = train_step(onet, opt, X)
             losses.append(loss.item())            # device->host sync every step, as TS:219

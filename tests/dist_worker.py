@@ -43,9 +43,14 @@ def main():
     # (SyncBN takes the stem through the direct kernel + all-gathered partials; the 1-rank comparison run below must take the same
     # stem kernel: z differs by 1e-7 between the two, which flips the sign of rounding-level gradients of the 9-element stem filters,
     # and Adam turns a sign flip into a full lr-sized step -- 1e-3 of the stem BatchNorm's running mean after two steps)
+    # For the same reason both runs stay on the fp32-MFMA kernels (Settings(split=False)): the split-bf16 kernels carry 16-bit
+    # operands (8e-7 rms per layer against 2e-7), their unit / tile partition depends on the per-rank batch, and every gradient
+    # element whose sign that moves is a full lr-sized difference after Adam's first step.  What is compared here is the
+    # data-parallel mechanics; the split kernels under two ranks run in test_bench_two_ranks_sharing_one_gpu_over_gloo (default dispatch).
     ops.STEM_FUSED = False
     ops.set_sync_bn(True)
     m = build(rank)
+    m.settings = ops.Settings(split=False)
     opt = FlatAdam(m, lr=1e-4, world_size=world)
     opt.broadcast_params(0)
     opt.enable_overlap(bucket_mb=8)
@@ -73,6 +78,7 @@ def main():
     # ---- one rank on the concatenated batch (no collective in it: both ranks compute it, rank 0 compares)
     ops.set_sync_bn(False)
     m1 = build(0)
+    m1.settings = ops.Settings(split=False)
     opt1 = FlatAdam(m1, lr=1e-4, world_size=1)
     opt1.all_reduce_grads = lambda: None                    # a single replica inside an initialised group: nothing to reduce
     r1 = step(m1, opt1, X)

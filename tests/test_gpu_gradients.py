@@ -91,7 +91,7 @@ def _routed_oracle(Xcpu, C, seed, gain, acts, bshare=True):
     return outs, loss, grads, r
 
 
-def _check(m, grads64, routing, what, named=None, tol=None):
+def _check(m, grads64, routing, what, named=None, tol=None, flip_dist=None, flip_frac=None):
     """grads64: the oracle's dict -- un-prefixed keys = the top (or only) U-Net, "dwnu." + key = an unshared down U-Net"""
     if named is None:
         named = {(k[5:] if k.startswith("topu.") else k): v for k, v in m.named_parameters()}
@@ -107,8 +107,8 @@ def _check(m, grads64, routing, what, named=None, tol=None):
     flips = sum(a[1] for a in routing.audit)
     dist = max(a[3] for a in routing.audit)
     frac = max(a[1] / a[2] for a in routing.audit)
-    assert dist <= FLIP_DIST, (what, "a decision differs from the exact one far from its switching point", dist)
-    assert frac <= FLIP_FRAC, (what, "too many decisions differ from the exact ones", frac)
+    assert dist <= (flip_dist or FLIP_DIST), (what, "a decision differs from the exact one far from its switching point", dist)
+    assert frac <= (flip_frac or FLIP_FRAC), (what, "too many decisions differ from the exact ones", frac)
     print(f"{what}: worst gradient error {worst[0]:.2e} ({worst[1]}); {flips} of "
           f"{sum(a[2] for a in routing.audit)} decisions differ from the exact ones, farthest {dist:.1e} from the switch")
 
@@ -217,10 +217,11 @@ def test_benchmark_dispatch_b32_256_every_gradient_element(dev, monkeypatch):
     (Lt, Vt, Ld, Vd, S), loss, acts = _hip_step_recording(m, X, monkeypatch, range(2))
     assert all(copies) and len(copies) == 18, "tile copies took different ReLU decisions"
     # the benchmark's kernels really ran: forward with fused statistics (split-bf16 kernel on the 32-pixel-and-wider levels, fp32
-    # Winograd F(4x4) on the 16-pixel level), split-bf16 input gradients and weight gradients (maps >= 64 pixels wide), the
-    # fp32 Winograd weight gradients on the narrower levels, the ConvTranspose2d GEMMs
+    # Winograd F(4x4) on the 16-pixel level), split-bf16 input gradients, split-bf16 weight gradients of all 17 layers with
+    # >= 16 input channels (round 3: also the 32- and 16-pixel levels), the ConvTranspose2d GEMMs
     assert used.get("conv3x3_fwd_bn_partials", 0) >= 14 and used.get("conv3x3_split", 0) >= 10, used
-    assert used.get("conv3x3_split_wgrad", 0) >= 9 and used.get("conv3x3_winograd4_wgrad", 0) + used.get("conv3x3_winograd_wgrad", 0) >= 6, used
+    if ops.SPLIT_AUTO:
+        assert used.get("conv3x3_split_wgrad", 0) == 17 and used.get("conv3x3_winograd4_wgrad", 0) + used.get("conv3x3_winograd_wgrad", 0) == 0, used
     assert used.get("convT2x2_wgrad", 0) == 4 and used.get("conv3x3_winograd4", 0) >= 1, used
     assert abs(loss.item() - g["losses"][0]) <= 1e-3 * abs(g["losses"][0])
     assert np.abs(Vt.detach().cpu().numpy()[:2, :, ::37, :] - g["Vt"]).max() <= 1e-3 * np.abs(g["Vt"]).max()
@@ -251,6 +252,102 @@ def test_every_gradient_element_two_pass_and_unshared(dev, mode, monkeypatch):
     assert abs(loss.item() - float(oloss)) <= 1e-5 * abs(float(oloss))
     assert float((Vd.detach().cpu().double() - oVd.detach()).abs().max()) <= 1e-4 * float(oVd.detach().abs().max())
     _check(m, g64, r, mode)
+
+
+def _bf16_rule(kind, xs, ws):
+    """Which matrix products of the model the bf16 conv path (ops.conv3x3_algo / wgrad_takes_bf16 under "bf16", the 128 x 128
+    ConvTranspose2d GEMMs) evaluates with bf16-rounded operands."""
+    if kind == "conv3x3":
+        _, Cin, H, W = xs
+        return Cin % 16 == 0 and ws[0] % 4 == 0 and W >= 16 and W % 4 == 0 and H >= 8
+    # ConvTranspose2d: the forward and input-gradient GEMMs tile 128 pixels, the weight-gradient GEMM 32 (convt_gemm.hip) --
+    # on an 8 x 8 map only the weight gradient takes the bf16-operand fast path
+    _, Cin, h, w = xs
+    if Cin % 128 or ws[1] % 32:
+        return False
+    return {"fwd", "dgrad", "wgrad"} if (h * w) % 128 == 0 else ({"wgrad"} if (h * w) % 32 == 0 else False)
+
+
+BF16_GRAD_TOL = 1e-4     # per parameter tensor, relative L2, with the HIP run's rounded operands replayed (measured 7.1e-6 at
+                         # B=8 128 x 128, 1.3e-5 at B=4 256 x 256; free rounding: 2e-2; against the unrounded gradients: 5e-2)
+
+
+def _record_bf16_operands(monkeypatch, B):
+    """Capture the fp32 operands of every 3x3 weight-gradient call (x = the unit's forward input, dz = the gradient of its
+    pre-activation: the operands of all three products of the unit) and of every ConvTranspose2d weight-gradient call (x1,
+    the concat-gradient window), rounded to bf16 as the kernels round them on load.  -> finish() -> replay lists in the
+    ORACLE's call order (18 units / 4 Up blocks of the X pass, then of the 1-X pass; the twin batch holds both passes)."""
+    from onet_amd import ops
+    rb = lambda t: t.detach().to(torch.bfloat16).cpu()          # RNE, == v_cvt_pk_bf16_f32 (tests/test_gpu_ops.py)
+    conv, convt = [], []
+    real_w, real_t = ops.conv3x3_wgrad_auto, ops.convT2x2_wgrad
+
+    def wgrad(x, dz, *a, **k):
+        assert x is not None and dz is not None and x.shape[0] == 2 * B
+        conv.append((rb(x), rb(dz)))
+        return real_w(x, dz, *a, **k)
+
+    def wgrad_t(x, dy, *a, **k):
+        assert x.shape[0] == 2 * B
+        convt.append((rb(x), rb(dy)))
+        return real_t(x, dy, *a, **k)
+
+    monkeypatch.setattr(ops, "conv3x3_wgrad_auto", wgrad)
+    monkeypatch.setattr(ops, "convT2x2_wgrad", wgrad_t)
+
+    def finish():
+        monkeypatch.setattr(ops, "conv3x3_wgrad_auto", real_w)
+        monkeypatch.setattr(ops, "convT2x2_wgrad", real_t)
+        assert len(conv) == 18 and len(convt) == 4
+        out = {"conv3x3": [], "convT2x2": []}
+        for p in range(2):                                       # backward visits the units last to first
+            out["conv3x3"] += [(x[p * B:(p + 1) * B], g[p * B:(p + 1) * B]) for x, g in reversed(conv)]
+            out["convT2x2"] += [(x[p * B:(p + 1) * B], g[p * B:(p + 1) * B]) for x, g in reversed(convt)]
+        return out
+
+    return finish
+
+
+@pytest.mark.parametrize("tag", ["b8_c1_128", "b4_c1_256"])
+def test_bf16_path_every_gradient_element_vs_routed_rounded_oracle(dev, tag, monkeypatch):
+    """BASELINE configs[2]'s arithmetic held to the fp32 path's element-wise statement instead of "gradient norms within 10 %": the
+    fp64 oracle evaluates the function the bf16 conv path computes -- every bf16 matrix product (forward, input gradient, weight
+    gradient of the 3x3 layers and of the ConvTranspose2d GEMMs the path takes) on bf16-rounded operands, everything else
+    unrounded (oracle.operand_rounding) -- under the HIP run's DECISIONS: its ReLU masks and pooling indices, and its roundings.
+    The roundings must be replayed for the same reason as the masks: free rounding is chaotic (the oracle's note; the test
+    measures it: with free rounding the two evaluations differ by ~1e-2 of the head logits' scale), while on the same rounded
+    operands the two differ by fp32 summation only."""
+    from onet_amd import ops
+    B, C, H, W, gain, _ = CASES[tag]
+    monkeypatch.setattr(ops, "CONV_ALGO", "bf16")
+    # fp32 operand storage, rounded on load: bit-identical to bf16 storage (test_bf16_storage_is_bit_identical_to_rounding_on_load),
+    # and every fp32 activation / gradient exists to be recorded (with bf16 storage half of them are placeholders)
+    monkeypatch.setattr(ops, "BF16_STORAGE", False)
+    X = orc.det_input(B, C, H, W)
+    m = _model(C, gain, dev)
+    finish_ops = _record_bf16_operands(monkeypatch, B)
+    ops.profile_start(everything=False)
+    try:
+        (Lt, Vt, Ld, Vd, S), loss, acts = _hip_step_recording(m, X.to(dev), monkeypatch, range(B))
+    finally:
+        prof, _ = ops.profile_stop()
+    replay = finish_ops()
+    assert len(prof.get("conv3x3_bf16_kernel", [])) >= 24 and len(prof.get("conv3x3_wgrad_bf16_kernel", [])) >= 12, {k: len(v) for k, v in prof.items()}
+    with orc.operand_rounding(_bf16_rule, replay):
+        (oLt, oVt, oLd, oVd, oS), oloss, g64, r = _routed_oracle(X, C, 1981, gain, acts)
+    assert abs(loss.item() - float(oloss)) <= 1e-5 * abs(float(oloss))
+    assert float((Vt.detach().cpu().double() - oVt.detach()).abs().max()) <= 1e-4 * float(oVt.detach().abs().max())
+    _check(m, g64, r, f"bf16 path {tag}, roundings replayed", tol=BF16_GRAD_TOL)
+    # for the record (and so that the replay is not vacuous): the same evaluation with FREE rounding, and without any rounding
+    with orc.operand_rounding(_bf16_rule):
+        (_, fVt, _, _, _), _, gfree, _ = _routed_oracle(X, C, 1981, gain, acts)
+    _, _, gexact, _ = _routed_oracle(X, C, 1981, gain, acts)
+    free_v = float((fVt.detach() - oVt.detach()).abs().max() / oVt.detach().abs().max())
+    free_g = max(float((gfree[k] - g64[k]).norm() / g64[k].norm()) for k in g64)
+    moved = max(float((gexact[k] - g64[k]).norm() / g64[k].norm()) for k in g64)
+    print(f"bf16 path {tag}: free rounding moves the head logits by {free_v:.1e} and the gradients by up to {free_g:.1e}; "
+          f"bf16 operands move the exact gradients by up to {moved:.1e}")
+    assert free_g > 10 * BF16_GRAD_TOL and moved > 10 * BF16_GRAD_TOL, "rounding does not matter here: the check would be vacuous"
 
 
 @pytest.mark.parametrize("algo", ["auto", "direct"])

@@ -372,6 +372,29 @@ def test_adam_loss_sequence_vs_reference_golden(dev, fused_adam, monkeypatch):
     assert nbt[0] == 2 * steps
 
 
+def test_flat_adam_skipped_parameters_follow_torch_adam(dev):
+    """torch.optim.Adam leaves a parameter whose .grad is None untouched (p, exp_avg, exp_avg_sq) and bias-corrects every
+    parameter with ITS OWN step count: a parameter that sat out two of five updates is on step 3 when the others are on 5.
+    FlatAdam (one fused launch per run of parameters with equal counts) must land on the same values."""
+    from onet_amd.trainer import FlatAdam
+    torch.manual_seed(5)
+    mk = lambda: torch.nn.Sequential(torch.nn.Linear(24, 40), torch.nn.Linear(40, 8), torch.nn.Linear(8, 8)).to(dev)
+    a, b = mk(), mk()
+    b.load_state_dict(a.state_dict())
+    oa, ob = FlatAdam(a, lr=1e-2, weight_decay=1e-3), torch.optim.Adam(b.parameters(), lr=1e-2, weight_decay=1e-3)
+    x = torch.randn(16, 24, device=dev)
+    for it in range(5):
+        for m, o in ((a, oa), (b, ob)):
+            o.zero_grad(set_to_none=True)
+            h = m[1](m[0](x))
+            out = h if it in (1, 2) else m[2](h)        # steps 1 and 2: the last layer takes no part -> its .grad stays None
+            out.square().mean().backward()
+            o.step()
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert float((pa - pb).abs().max()) <= 2e-6 * float(pb.abs().max()), "FlatAdam != torch.optim.Adam with skipped parameters"
+    assert oa._steps is not None and sorted(set(oa._steps)) == [3, 5]
+
+
 def _step_nozero(m, X):
     Lt, Vt, Ld, Vd, S = m(X)
     loss = m.compute_loss(Lt, S[:, 0].unsqueeze(1), Ld, S[:, 1].unsqueeze(1))

@@ -118,12 +118,13 @@ def test_conv3x3_winograd4_fwd_dgrad(dev, B, Cin, Cout, H, W):
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 64, 64, 24, 64), (1, 32, 128, 64, 64), (3, 16, 36, 33, 68), (2, 128, 80, 16, 192),
                                              (5, 48, 64, 37, 128), (2, 24, 20, 9, 100),
-                                             (4, 64, 64, 32, 32), (6, 80, 48, 19, 32), (8, 128, 64, 16, 16), (12, 32, 96, 7, 16)])
+                                             (4, 64, 64, 32, 32), (6, 80, 48, 19, 32), (8, 128, 64, 16, 16), (12, 32, 96, 7, 16),
+                                             (2, 64, 128, 24, 64), (3, 40, 256, 17, 128), (4, 48, 256, 20, 32), (4, 64, 128, 9, 16)])
 def test_conv3x3_split_wgrad(dev, B, Cin, Cout, H, W):
     """conv3x3_split_wgrad_kernel (both operands split into bf16 hi + mid, three MFMAs per term, row-streaming units,
     deterministic split-K) against the fp64 weight gradient at 2e-5 of its scale; ragged strips (W % 64 != 0), odd heights,
     channel tails, runs crossing image boundaries; 32- and 16-pixel-wide maps (2 / 4 images side by side per unit, each with
-    its own zero halo); bitwise reproducible."""
+    its own zero halo); Cout % 128 == 0 on maps >= 32 pixels wide: the 128-channel block tile; bitwise reproducible."""
     from onet_amd import ops
     x = rnd(B, Cin, H, W, seed=11)
     g = rnd(B, Cout, H, W, seed=12)
