@@ -142,3 +142,32 @@ def test_bilinear_unet_oracle_matches_reference():
     assert _worst(samples(g64r), g["grad_vals64r"], offs) <= 1e-7
     e_routed, e_free = _worst(g["grad_vals"], g["grad_vals64r"], offs), _worst(g["grad_vals"], g["grad_vals64"], offs)
     assert e_routed <= 1e-4 and e_free >= 1e-3, (e_routed, e_free)
+
+
+def test_rounded_operand_functions_reduce_to_autograd_on_bf16_representable_operands():
+    """oracle.operand_rounding's two autograd Functions (the checker of the bf16 gradient-parity test): on operands that are
+    already bf16 numbers rounding is the identity, so forward, input gradient, weight gradient and bias gradient must equal
+    autograd's -- for every subset of products that takes rounded operands; on general operands the forward must equal the
+    convolution of the rounded operands, and a replayed operand must be used instead of the function's own rounding."""
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    rb = lambda t: t.to(torch.bfloat16).double()
+    x, w, g = rb(torch.randn(2, 5, 8, 8)).requires_grad_(True), rb(torch.randn(7, 5, 3, 3)).requires_grad_(True), rb(torch.randn(2, 7, 8, 8))
+    F.conv2d(x, w, None, 1, 1).backward(g)
+    ref = (x.grad.clone(), w.grad.clone())
+    for prods in ({"fwd", "dgrad", "wgrad"}, {"wgrad"}, {"fwd"}):
+        x.grad = w.grad = None
+        orc._RoundedConv3x3.apply(x, w, prods).backward(g)
+        assert torch.equal(x.grad, ref[0]) and torch.equal(w.grad, ref[1])
+    xt, wt, bt = rb(torch.randn(2, 6, 4, 4)).requires_grad_(True), rb(torch.randn(6, 3, 2, 2)).requires_grad_(True), torch.randn(3, dtype=torch.float64, requires_grad=True)
+    gt = rb(torch.randn(2, 3, 8, 8))
+    F.conv_transpose2d(xt, wt, bt, stride=2).backward(gt)
+    ref = (xt.grad.clone(), wt.grad.clone(), bt.grad.clone())
+    for prods in ({"fwd", "dgrad", "wgrad"}, {"wgrad"}):
+        xt.grad = wt.grad = bt.grad = None
+        orc._RoundedConvT2x2.apply(xt, wt, bt, prods).backward(gt)
+        assert torch.allclose(xt.grad, ref[0], rtol=0, atol=1e-12) and torch.allclose(wt.grad, ref[1], rtol=0, atol=1e-12) and torch.equal(bt.grad, ref[2])
+    y, v = torch.randn(1, 4, 6, 6, dtype=torch.float64), torch.randn(3, 4, 3, 3, dtype=torch.float64)
+    assert torch.equal(orc._RoundedConv3x3.apply(y, v, {"fwd"}), F.conv2d(rb(y), rb(v), None, 1, 1))
+    other = rb(torch.randn(1, 4, 6, 6))
+    assert torch.equal(orc._RoundedConv3x3.apply(y, v, {"fwd"}, other, None), F.conv2d(other, rb(v), None, 1, 1))
