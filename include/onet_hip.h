@@ -186,6 +186,17 @@ int onet_conv3x3_split_fwd_stats(const float* x, int64_t x_bs, const void* wq, f
  * side by side make one unit; the whole batch of x and of dz must then lie within 2 GiB); 16-byte aligned image rows (x_bs,
  * dz_bs % 4 == 0). */
 int onet_conv3x3_split_wgrad_ok(int B, int Cin, int Cout, int H, int W);
+/* Normalise on load (the second convolution of a DoubleConv, OV:51, without a materialised activation of the first, OV:49):
+ * z_prev = the PRE-activation of the Conv-BatchNorm-ReLU unit below, save = its BatchNorm coefficients [n_groups][4][Cin] (rows
+ * mean, invstd, scale, shift as onet_bn_train_coeffs writes them; statistics groups = n_groups equal runs of consecutive
+ * images).  The staging threads compute max(fma(z - mean, scale, shift), 0) -- bit for bit what onet_bn_relu_apply writes --
+ * before splitting; zero padding stays zero.  _fwd_norm: part != NULL also emits the statistics records (as _fwd_stats);
+ * _wgrad_norm: n_groups 1 or 2.  Results are bit-identical to the plain entry points on the materialised activation. */
+int onet_conv3x3_split_fwd_norm(const float* z_prev, int64_t z_bs, const float* save, int n_groups, const void* wq, float* z,
+                                int64_t zo_bs, float* part, int B, int Cin, int Cout, int H, int W, void* stream);
+int onet_conv3x3_split_wgrad_norm(const float* z_prev, int64_t z_bs, const float* save, int n_groups, const float* dz, int64_t dz_bs,
+                                  float* dw, void* ws, int64_t ws_bytes, int B, int Cin, int Cout, int H, int W, int accumulate,
+                                  void* stream);
 int64_t onet_conv3x3_split_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W);
 int onet_conv3x3_split_wgrad(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs, float* dw, void* ws, int64_t ws_bytes,
                              int B, int Cin, int Cout, int H, int W, int accumulate, void* stream);

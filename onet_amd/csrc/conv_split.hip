@@ -83,6 +83,8 @@ struct SpArgs {
     int64_t z_bs;
     int B, Cin, Cout, H, W, tilesX, tilesY, coTiles;
     float* stats;         // ST: BatchNorm partials [Cout][B * tilesY * tilesX][3] = (n, mean, M2) per tile
+    const float* nsave;   // NORM: x is the PRE-activation of the Conv-BatchNorm-ReLU unit below; its coefficients [groups][4][Cin]
+    int nimg;             //       (rows mean, invstd, scale, shift; bn.hip) for statistics groups of nimg consecutive images
 };
 
 // sum over the 32 lanes of a wave half, valid in lanes 31 / 63 (DPP row rotations + row broadcast)
@@ -118,7 +120,11 @@ struct SpCfg {
 // chunks ahead of the MFMAs, LDS commit one ahead -- runs ACROSS tile boundaries.
 // ST: the forward of a Conv-BatchNorm pair (OV:47-48, 51-52) also emits the BatchNorm statistics of its output, one (n, mean,
 // M2) record per tile and channel from the final accumulators (pivot-shifted sums per wave, the eight waves merged through LDS).
-template <bool ST>
+// NORM (normalise on load): the input is the pre-activation z of the unit below and the staging threads apply that unit's
+// BatchNorm + ReLU -- max(fma(z - mean, scale, shift), 0), the expression of bn_relu_apply_kernel, so the operand is bit for
+// bit the activation that pass would have written -- before splitting; zero padding stays zero.  The second convolution of a
+// DoubleConv (OV:51) then needs no materialised activation of the first (OV:49): one write and one read of the tensor less.
+template <bool ST, bool NORM>
 __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
     using C = SpCfg;
     constexpr int NT = C::NT, IN_COLS = C::IN_COLS, NWI = C::NWI, CO_T = C::CO_T, NPIXP = C::NPIXP, NB = C::NB;
@@ -165,8 +171,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
     const int it_g = role == 0 ? (it & 7) : (it & 1);                  // 4-pixel group / side
     const bool it_ok = role == 0 ? it < 288 : (role == 1 && it < 72);
     __amdgpu_buffer_rsrc_t xr;
-    int st_tile = t_first, st_chunk = 0;
+    int st_tile = t_first, st_chunk = 0, st_b = 0;
     unsigned cin_bytes = 0, cw_bytes = 0;
+    // NORM: the BatchNorm coefficients of a chunk's 16 channels travel beside its data -- 48 floats (mean, scale, shift) fetched
+    // by the one wave without a staging role and parked in LDS [chunk buffer][half][channel][4], where the staging threads pick
+    // them up at commit time (per-lane vector loads would double the staging VMEM count, 48 scalar loads spilled the SGPR file)
+    float* const coef = reinterpret_cast<float*>(lds + 2 * BUF) + (ST ? C::NW * 64 * 2 : 0);
+    float pend_cv = 0.f;
+    bool pend_keep = false;                          // validity of the item whose loads are in flight
     auto setup_stage = [&]() __attribute__((always_inline)) {
         const bool live = st_tile < t_end;
         int v = live ? st_tile : t_first;
@@ -176,6 +188,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
         v /= a.tilesY;
         const int b = v % a.B, co0 = (v / a.B) * CO_T;
         const int y0 = ty * ROWS, x0 = tx * TW;
+        st_b = b;
         xr = s_rsrc(a.x + (int64_t)b * a.x_bs, (int64_t)a.Cin * HW * 4);
         {
             const int yy = y0 - 1 + it_r;
@@ -208,6 +221,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
     // loads of planes [c0, c1) of this thread's item; the chunk / plane part of the address is wave-uniform and rides in the
     // instruction's scalar offset, the per-lane part alone decides the range check (OOB_S -> 0)
     auto issue_in = [&](int c0, int c1) __attribute__((always_inline)) {
+        if (NORM && c0 == 0) {
+            pend_keep = in_off != OOB_S;
+            if (wn == 7 && lane < 48) {              // lane = kind * 16 + channel; rows of `save`: 0 mean, 2 scale, 3 shift
+                const int k = lane >> 4, row = k == 0 ? 0 : k + 1;
+                pend_cv = st_tile < t_end ? a.nsave[(int64_t)((st_b / a.nimg) * 4 + row) * a.Cin + st_chunk * 16 + (lane & 15)] : 0.f;
+            }
+        }
         if (role == 0) {
 #pragma unroll
             for (int c = 0; c < 8; ++c)
@@ -232,6 +252,34 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
         f32x4s f[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) f[c] = __builtin_bit_cast(f32x4s, xin[c]);      // (re-typed as a whole: see commit_dz below)
+        if constexpr (NORM) {
+            // channel pairs outermost (a dword of a slot = two neighbouring channels): six coefficients live at a time
+            const f32x4s* cfp = reinterpret_cast<const f32x4s*>(coef) + (buf * 2 + it_h) * 8;
+            u32x4s hi[4], mid[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4s ca = cfp[2 * c], cb = cfp[2 * c + 1];
+#pragma unroll
+                for (int px = 0; px < 4; ++px) {
+                    if (px < p0 || px >= p1 || (role == 1 && px > 0)) continue;
+                    float va = fmaxf(fmaf(f[2 * c][px] - ca[0], ca[1], ca[2]), 0.f);
+                    float vb = fmaxf(fmaf(f[2 * c + 1][px] - cb[0], cb[1], cb[2]), 0.f);
+                    va = pend_keep ? va : 0.f;               // outside the image: the convolution's zero padding
+                    vb = pend_keep ? vb : 0.f;
+                    unsigned h, m;
+                    split2(va, vb, h, m);
+                    hi[px][c] = h;
+                    mid[px][c] = m;
+                }
+            }
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                if (px < p0 || px >= p1 || (role == 1 && px > 0)) continue;
+                in_st[buf * BUF + px] = hi[px];
+                in_st[buf * BUF + px + IN_PART] = mid[px];
+            }
+            return;
+        }
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
             if (px < p0 || px >= p1 || (role == 1 && px > 0)) continue;
@@ -253,6 +301,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
             if (k >= k0 && k < k1 && tid + 512 * k < C::W_SLOTS) w_st[buf * BUF + 512 * k] = wv[k];
     };
 
+    auto commit_coef = [&](int cb) __attribute__((always_inline)) {
+        if (NORM && wn == 7 && lane < 48) coef[((cb * 2 + ((lane >> 3) & 1)) * 8 + (lane & 7)) * 4 + (lane >> 4)] = pend_cv;
+    };
+
     // fragments: A (weights) slot = part * W_PART + (tap * 2 + kh) * 64 + m * 32 + l31;
     //            B (input)   slot = W_SLOTS + part * IN_PART + kh * NPIXP + (2 wn + j) * IN_COLS + l31 + kx
     const u32x4s* const a_ptr = lds + kh * CO_T + l31;
@@ -261,11 +313,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
     setup_stage();
     issue_in(0, 8);
     issue_w(0, NWI);
+    if constexpr (NORM) {
+        commit_coef(0);
+        __syncthreads();
+    }
     commit_in(0, 0, 4);
     commit_w(0, 0, NWI);
     advance();
     issue_in(0, 8);                                  // second chunk (or the first of the next tile)
     issue_w(0, NWI);
+    commit_coef(1);
     __syncthreads();
     int buf = 0;
     for (int tile = t_first; tile < t_end; tile += t_stride) {
@@ -326,6 +383,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
                     commit_w(buf ^ 1, idx - 4, idx - 3);
                     issue_w(idx - 4, idx - 3);
                 }
+                if (idx == 8) commit_coef(buf);      // for the chunk whose loads went out at taps 2..5: committed into `buf` next
                 __builtin_amdgcn_sched_barrier(0);
                 const int tap = ky * 3 + kx;
                 (void)tap;
@@ -425,16 +483,16 @@ int split_nparts(int B, int H, int W) {
     return n < (1 << 30) ? (int)n : 0;
 }
 
-template <bool ST>
+template <bool ST, bool NORM>
 int launch_split(SpArgs a, hipStream_t st) {
     using C = SpCfg;
-    const int LDS_BYTES = C::LDS_BYTES + (ST ? C::NW * 64 * 2 * 4 : 0);
+    const int LDS_BYTES = C::LDS_BYTES + (ST ? C::NW * 64 * 2 * 4 : 0) + (NORM ? 2 * 2 * 8 * 4 * 4 : 0);
     a.tilesX = cdiv(a.W, C::TW);
     a.tilesY = cdiv(a.H, C::ROWS);
     a.coTiles = cdiv(a.Cout, C::CO_T);
     const int64_t tiles = (int64_t)a.B * a.tilesX * a.tilesY * a.coTiles;
     ONET_REQUIRE(tiles > 0 && tiles < (1ll << 31), "conv3x3_split: tile count %lld out of range", (long long)tiles);
-    auto kern = conv3x3_split_kernel<ST>;
+    auto kern = conv3x3_split_kernel<ST, NORM>;
     static PerDeviceOnce attr_once;
     if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -447,7 +505,7 @@ int launch_split(SpArgs a, hipStream_t st) {
 }
 
 int split_fwd(const float* x, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin, int Cout, int H, int W,
-              void* stream, float* stats) {
+              void* stream, float* stats, const float* nsave = nullptr, int n_groups = 0) {
     ONET_REQUIRE(x && wq && z, "conv3x3_split_fwd: null pointer");
     ONET_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 16, "conv3x3_split_fwd: bad shape (maps wider than 16 pixels)");
     ONET_REQUIRE((Cin % 16) == 0, "conv3x3_split_fwd: Cin must be a multiple of 16 (use onet_conv_fwd)");
@@ -456,12 +514,14 @@ int split_fwd(const float* x, int64_t x_bs, const void* wq, float* z, int64_t z_
     ONET_REQUIRE(x_bs >= (int64_t)Cin * H * W && z_bs >= (int64_t)Cout * H * W, "conv3x3_split_fwd: batch stride too small");
     ONET_REQUIRE((int64_t)(Cin + 32) * H * W * 4 < (1ll << 31) && (int64_t)(Cin + 32) * 2 * 9 * Cout * 2 < (1ll << 31),
                  "conv3x3_split_fwd: operand exceeds the 2 GiB buffer-resource range");
-    SpArgs a{x, x_bs, (const __bf16*)wq, z, z_bs, B, Cin, Cout, H, W, 0, 0, 0, stats};
-    if (stats) {
-        ONET_REQUIRE(split_nparts(B, H, W) > 0, "conv3x3_split_fwd_stats: the map must be made of full 16 x 32 tiles");
-        return launch_split<true>(a, as_stream(stream));
+    SpArgs a{x, x_bs, (const __bf16*)wq, z, z_bs, B, Cin, Cout, H, W, 0, 0, 0, stats, nsave, 1};
+    if (stats) ONET_REQUIRE(split_nparts(B, H, W) > 0, "conv3x3_split_fwd_stats: the map must be made of full 16 x 32 tiles");
+    if (nsave) {
+        ONET_REQUIRE(n_groups > 0 && B % n_groups == 0, "conv3x3_split_fwd_norm: the batch must hold n_groups equal statistics groups");
+        a.nimg = B / n_groups;
+        return stats ? launch_split<true, true>(a, as_stream(stream)) : launch_split<false, true>(a, as_stream(stream));
     }
-    return launch_split<false>(a, as_stream(stream));
+    return stats ? launch_split<true, false>(a, as_stream(stream)) : launch_split<false, false>(a, as_stream(stream));
 }
 
 
@@ -483,6 +543,8 @@ struct SwArgs {
     int64_t dz_bs;
     float* slab;
     int B, Cin, Cout, H, W, ciTiles, coTiles, splitK, tilesX;
+    const float* nsave;   // NORM: x is the pre-activation of the unit below, normalised on load (see conv3x3_split_kernel): its
+    int nimg;             //       coefficients [groups <= 2][4][Cin], statistics groups of nimg consecutive images
 };
 
 #ifndef SW_COMMIT_AT
@@ -507,7 +569,7 @@ template <int G> struct SwCfg {
 // 2g + 1 of a unit and writes its own slab (54 MFMAs per wave between barriers).  128 (Cout % 128 == 0, G < 4: the LDS holds
 // it): 4 x 2 quadrants, every wave takes all four segments -- 108 MFMAs per wave between barriers, the x rows staged once per
 // 128 output channels, one slab per block.
-template <int G, int COT>
+template <int G, int COT, bool NORM>
 __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
     using C = SwCfg<G>;
     constexpr int SR_SX = C::SX, SR_SLOT = C::SLOT, SR_X_PART = C::X_PART;
@@ -545,6 +607,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
     const int st_sub = st_s / C::SPG, st_w = st_s % C::SPG;     // image of the group, 8-pixel segment of its row
     u32x4s dzv[2 * DZI], xq[2];
     float xh[2];
+    // NORM: BatchNorm coefficients of this thread's x channel for the (at most two) statistics groups; the group and the
+    // validity of the row whose loads are in flight
+    float n_mean[2] = {0.f, 0.f}, n_sc[2] = {0.f, 0.f}, n_sh[2] = {0.f, 0.f};
+    bool pend_v[4] = {false, false, false, false}, pend_g1 = false;      // left halo | pixels 0-3 | pixels 4-7 | right halo
+    if constexpr (NORM) {
+        const int ch = min(ci0 + st_c, a.Cin - 1), last = a.B / a.nimg - 1;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const float* sv = a.nsave + (int64_t)min(g, last) * 4 * a.Cin + ch;
+            n_mean[g] = sv[0];
+            n_sc[g] = sv[2 * a.Cin];
+            n_sh[g] = sv[3 * a.Cin];
+        }
+    }
     // loads of one dz row and / or one x row of strip (b, x0): row < 0 or >= H -> zeros.  G == 1: one buffer resource per image
     // (a 256 x 256 level's batch exceeds the 2 GiB range); G > 1: the lanes of a wave address different images, so the resource
     // spans the whole (small) tensor and the image offset goes into the lane's byte offset (range checked by the host)
@@ -568,6 +644,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
         const int xs = x0 + 8 * st_w;
         const bool ok = y >= 0 && y < a.H && ci0 + st_c < a.Cin;
         const unsigned base = (unsigned)(((ci0 + st_c) * HW + y * a.W + xs) * 4) + (G == 1 ? 0u : (unsigned)((int64_t)(b * G + st_sub) * a.x_bs * 4));
+        if constexpr (NORM) {
+            pend_v[0] = ok && xs > 0 && xs - 1 < a.W;
+            pend_v[1] = ok && xs < a.W;
+            pend_v[2] = ok && xs + 4 < a.W;
+            pend_v[3] = ok && st_w == C::SPG - 1 && xs + 8 < a.W;
+            pend_g1 = (G == 1 ? b : b * G + st_sub) >= a.nimg;
+        }
 #pragma unroll
         for (int k = 0; k < 2; ++k) xq[k] = __builtin_amdgcn_raw_buffer_load_b128(xr, (ok && xs + 4 * k < a.W) ? base + 16 * k : OOB_S, 0, 0);
         xh[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (ok && xs > 0 && xs - 1 < a.W) ? base - 4 : OOB_S, 0, 0));
@@ -599,7 +682,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
     auto commit_x = [&](int slot) __attribute__((always_inline)) {
         unsigned* row = x_lds + st_c * SR_SX + slot * SR_SLOT + st_sub * C::P + st_w * 4;
         const f32x4s f0 = __builtin_bit_cast(f32x4s, xq[0]), f1 = __builtin_bit_cast(f32x4s, xq[1]);
-        const float e[10] = {xh[0], f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3], xh[1]};
+        float e[10] = {xh[0], f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3], xh[1]};
+        if constexpr (NORM) {
+            // the activation bn_relu_apply_kernel would have written, element for element; what lies outside the image (rows
+            // above / below, the strip's halo columns at the image border) is the convolution's zero padding and stays zero
+            const float mean = pend_g1 ? n_mean[1] : n_mean[0], sc = pend_g1 ? n_sc[1] : n_sc[0], sh = pend_g1 ? n_sh[1] : n_sh[0];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                const float v = fmaxf(fmaf(e[k] - mean, sc, sh), 0.f);
+                e[k] = pend_v[k == 0 ? 0 : (k <= 4 ? 1 : (k <= 8 ? 2 : 3))] ? v : 0.f;
+            }
+        }
         unsigned hi[5], mid[5];
 #pragma unroll
         for (int p2 = 0; p2 < 5; ++p2) split2(e[2 * p2], e[2 * p2 + 1], hi[p2], mid[p2]);
@@ -733,9 +826,11 @@ int64_t onet_conv3x3_split_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W
     return (int64_t)splitK * (split_wgrad_cot(Cout, W) == 64 ? 2 : 1) * 9 * Cout * Cin * 4;    // 64-channel tiles: two K-groups per block, a slab each
 }
 
-int onet_conv3x3_split_wgrad(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs, float* dw, void* ws, int64_t ws_bytes,
-                             int B, int Cin, int Cout, int H, int W, int accumulate, void* stream) {
+static int split_wgrad_impl(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs, float* dw, void* ws, int64_t ws_bytes,
+                            int B, int Cin, int Cout, int H, int W, int accumulate, void* stream, const float* nsave, int n_groups) {
     ONET_REQUIRE(x && dz && dw && ws, "conv3x3_split_wgrad: null pointer");
+    ONET_REQUIRE(!nsave || ((n_groups == 1 || n_groups == 2) && B % n_groups == 0),
+                 "conv3x3_split_wgrad_norm: one or two statistics groups of equal size");
     ONET_REQUIRE(onet_conv3x3_split_wgrad_ok(B, Cin, Cout, H, W),
                  "conv3x3_split_wgrad: needs W >= 64 with W %% 4 == 0, or W = 32 / 16 with B %% (64 / W) == 0 (use onet_conv3x3_winograd_wgrad)");
     ONET_REQUIRE((x_bs & 3) == 0 && (dz_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dz) & 15) == 0,
@@ -747,21 +842,40 @@ int onet_conv3x3_split_wgrad(const float* x, int64_t x_bs, const float* dz, int6
                             ((int64_t)(B - 1) * dz_bs + (int64_t)Cout * H * W) * 4 < (1ll << 31)),
                  "conv3x3_split_wgrad: on maps narrower than 64 pixels the whole batch must lie within the 2 GiB buffer-resource range");
     const int COT = split_wgrad_cot(Cout, W), slabs = COT == 64 ? 2 : 1;
-    SwArgs a{x, x_bs, dz, dz_bs, (float*)ws, B, Cin, Cout, H, W, cdiv(Cin, 64), cdiv(Cout, COT), 1, 1};
+    SwArgs a{x, x_bs, dz, dz_bs, (float*)ws, B, Cin, Cout, H, W, cdiv(Cin, 64), cdiv(Cout, COT), 1, 1, nsave, nsave ? B / n_groups : B};
     split_wgrad_plan(B, Cin, Cout, H, W, a.splitK, a.tilesX);
     const int64_t need = (int64_t)a.splitK * slabs * 9 * Cout * Cin * 4;
     ONET_REQUIRE(ws_bytes >= need, "conv3x3_split_wgrad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
     const int64_t blocks = (int64_t)a.splitK * a.ciTiles * a.coTiles;
     const dim3 grid((unsigned)blocks), blk(512);
+    hipStream_t st = as_stream(stream);
+#define ONET_SW_LAUNCH(G_, COT_)                                                                              \
+    do {                                                                                                      \
+        if (nsave) hipLaunchKernelGGL((conv3x3_split_wgrad_kernel<G_, COT_, true>), grid, blk, 0, st, a);     \
+        else hipLaunchKernelGGL((conv3x3_split_wgrad_kernel<G_, COT_, false>), grid, blk, 0, st, a);          \
+    } while (0)
     if (COT == 128) {
-        if (G == 1) hipLaunchKernelGGL((conv3x3_split_wgrad_kernel<1, 128>), grid, blk, 0, as_stream(stream), a);
-        else hipLaunchKernelGGL((conv3x3_split_wgrad_kernel<2, 128>), grid, blk, 0, as_stream(stream), a);
-    } else if (G == 1) hipLaunchKernelGGL((conv3x3_split_wgrad_kernel<1, 64>), grid, blk, 0, as_stream(stream), a);
-    else if (G == 2) hipLaunchKernelGGL((conv3x3_split_wgrad_kernel<2, 64>), grid, blk, 0, as_stream(stream), a);
-    else hipLaunchKernelGGL((conv3x3_split_wgrad_kernel<4, 64>), grid, blk, 0, as_stream(stream), a);
+        if (G == 1) ONET_SW_LAUNCH(1, 128);
+        else ONET_SW_LAUNCH(2, 128);
+    } else if (G == 1) ONET_SW_LAUNCH(1, 64);
+    else if (G == 2) ONET_SW_LAUNCH(2, 64);
+    else ONET_SW_LAUNCH(4, 64);
+#undef ONET_SW_LAUNCH
     int rc = check_launch("conv3x3_split_wgrad_kernel");
     if (rc) return rc;
     return launch_wgrad_reduce((const float*)ws, dw, a.splitK * slabs, 9, Cout, Cin, 0, accumulate, as_stream(stream));
+}
+
+int onet_conv3x3_split_wgrad(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs, float* dw, void* ws, int64_t ws_bytes,
+                             int B, int Cin, int Cout, int H, int W, int accumulate, void* stream) {
+    return split_wgrad_impl(x, x_bs, dz, dz_bs, dw, ws, ws_bytes, B, Cin, Cout, H, W, accumulate, stream, nullptr, 0);
+}
+
+int onet_conv3x3_split_wgrad_norm(const float* z_prev, int64_t z_bs, const float* save, int n_groups, const float* dz, int64_t dz_bs,
+                                  float* dw, void* ws, int64_t ws_bytes, int B, int Cin, int Cout, int H, int W, int accumulate,
+                                  void* stream) {
+    ONET_REQUIRE(save, "conv3x3_split_wgrad_norm: null pointer");
+    return split_wgrad_impl(z_prev, z_bs, dz, dz_bs, dw, ws, ws_bytes, B, Cin, Cout, H, W, accumulate, stream, save, n_groups);
 }
 
 int onet_conv3x3_split_pack_weights(const float* w, void* wq_fwd, void* wq_dgrad, int Cout, int Cin, void* stream) {
@@ -782,6 +896,12 @@ int onet_conv3x3_split_pack_weights(const float* w, void* wq_fwd, void* wq_dgrad
 int onet_conv3x3_split_fwd(const float* x, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin, int Cout, int H,
                            int W, void* stream) {
     return split_fwd(x, x_bs, wq, z, z_bs, B, Cin, Cout, H, W, stream, nullptr);
+}
+
+int onet_conv3x3_split_fwd_norm(const float* z_prev, int64_t z_bs, const float* save, int n_groups, const void* wq, float* z,
+                                int64_t zo_bs, float* part, int B, int Cin, int Cout, int H, int W, void* stream) {
+    ONET_REQUIRE(save, "conv3x3_split_fwd_norm: null pointer");
+    return split_fwd(z_prev, z_bs, wq, z, zo_bs, B, Cin, Cout, H, W, stream, part, save, n_groups);
 }
 
 int onet_conv3x3_split_nparts(int B, int H, int W) { return split_nparts(B, H, W); }

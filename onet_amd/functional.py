@@ -50,9 +50,21 @@ class ConvBNReLUFn(torch.autograd.Function):
         # an encoder output that is max-pooled next: {"bf16_only": bool} left in the link dict by UNet.forward (read before the dict
         # is refilled below); the pooled tensor goes back through the same dict for SkipPoolFn
         want_pool = link_out.pop("want_pool", None) if link_out is not None else None
+        # normalise on load (ops.norm_on_load_ok, decided by DoubleConv for the pair): as the FIRST unit, this launch computes
+        # z and the BatchNorm coefficients and stops there -- the second unit's convolution applies BatchNorm + ReLU in its own
+        # operand staging, forward and weight gradient, and a placeholder stands in for the activation in the graph; as the
+        # SECOND unit, x is that placeholder and the operand comes from (z, save) of the first
+        defer = bool(link_out.pop("defer", False)) if link_out is not None else False
+        defer = defer and training and b16 is None and out is None and want_pool is None
+        norm = None
+        if link_in is not None and link_in.get("deferred"):
+            norm = (link_in["z"], link_in["save"])
         x16 = None if b16 is None else b16.get("x16")
         # training: the F(4x4) kernel emits the BatchNorm statistics records from its epilogue (cm), where it can
-        z, cm = ops.conv3x3_fwd_bn_partials(x, packed, x16=x16) if training else (ops.conv3x3_auto(x, packed, 0, x16=x16), None)
+        if norm is not None:
+            z, cm = ops.conv3x3_fwd_bn_partials(None, packed, norm=norm)
+        else:
+            z, cm = ops.conv3x3_fwd_bn_partials(x, packed, x16=x16) if training else (ops.conv3x3_auto(x, packed, 0, x16=x16), None)
         # `out` is None or a 1-tuple holding a plane-contiguous destination view (kept out of autograd's sight)
         dst = None if out is None else out[0]
         G = groups if (training and groups > 1) else 1
@@ -77,6 +89,8 @@ class ConvBNReLUFn(torch.autograd.Function):
         def apply(zg, sv, o, o16, sl):
             """BatchNorm + ReLU of one statistics group (batch slice sl), with the pooled output where it was asked for"""
             nonlocal pooled
+            if defer:
+                return None
             if pooled is not None:
                 if o is None and not drop:
                     o = torch.empty_like(zg)
@@ -93,26 +107,26 @@ class ConvBNReLUFn(torch.autograd.Function):
             else:
                 ops.bn_eval_coeffs(gamma, beta, running_mean, running_var, eps, save=save_all[0])
             a = apply(z, save_all[0], dst, a16, slice(0, Bz))
-            if drop:
+            if drop or defer:
                 a = ops.fp32_placeholder(z.shape, z.device)
         else:
             # twin batch: the G batch slices are separate BatchNorm batches (own statistics, running stats updated
             # slice after slice, exactly as G consecutive forward passes would)
             B = z.shape[0]
             Bg = B // G
-            a = dst if dst is not None else (ops.fp32_placeholder(z.shape, z.device) if drop else torch.empty_like(z))
+            a = dst if dst is not None else (ops.fp32_placeholder(z.shape, z.device) if (drop or defer) else torch.empty_like(z))
             for g in range(G):
                 zg = z[g * Bg:(g + 1) * Bg]
                 npg = 0 if cm is None else cm.shape[1] // G
                 ops.bn_train_coeffs(zg, gamma, beta, running_mean, running_var, momentum, eps,
                                     cm=None if cm is None else (cm, g * npg, npg), save=save_all[g])
-                apply(zg, save_all[g], None if drop else a[g * Bg:(g + 1) * Bg],
+                apply(zg, save_all[g], None if (drop or defer) else a[g * Bg:(g + 1) * Bg],
                       None if a16 is None else a16[g * Bg:(g + 1) * Bg], slice(g * Bg, (g + 1) * Bg))
         if b16 is not None:
             b16["a16"] = a16
         # (the weight gradient reads the bf16 copy too; saved WITH the tensors so that backward releases it -- a ctx attribute
         # would live as long as the caller holds the loss)
-        ctx.save_for_backward(x, z, save_all, x16)
+        ctx.save_for_backward(x, z, save_all, x16, None if norm is None else norm[0], None if norm is None else norm[1])
         ctx.training = training
         ctx.packed = packed
         ctx.wshape = tuple(weight.shape)
@@ -121,6 +135,8 @@ class ConvBNReLUFn(torch.autograd.Function):
         if training and link_out is not None:
             link_out.clear()
             link_out.update(z=z, save=save_all)
+            if defer:
+                link_out["deferred"] = True
             ctx.link_out = link_out
         if training and link_in is not None and "z" in link_in:
             ctx.link_in = link_in
@@ -130,7 +146,7 @@ class ConvBNReLUFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, da):
-        x, z, save_all, x16 = ctx.saved_tensors
+        x, z, save_all, x16, nz, nsave = ctx.saved_tensors
         need_x, need_w, need_g, need_b = ctx.needs_input_grad[:4]
         pw, pg, pb = ctx.params
         aff = (ops.grad_slot_if_free(pg) if need_g else None, ops.grad_slot_if_free(pb) if need_b else None)
@@ -167,7 +183,10 @@ class ConvBNReLUFn(torch.autograd.Function):
                                                    red=None if rec is None else (rec, g * npg, npg),
                                                    red4=None if rec4 is None else (rec4, g * np4, np4),
                                                    out16=None if dz16 is None else dz16[sl])
-        dw = ops.conv3x3_wgrad_auto(x, dz, ctx.wshape, out=ops.grad_slot_if_free(pw), x16=x16, dz16=dz16) if need_w else None
+        if need_w and nz is not None:      # normalise on load: the operand is relu(bn(nz)) of the unit below, applied in the staging
+            dw = ops.conv3x3_split_wgrad(nz, dz, ctx.wshape, out=ops.grad_slot_if_free(pw), norm=nsave)
+        else:
+            dw = ops.conv3x3_wgrad_auto(x, dz, ctx.wshape, out=ops.grad_slot_if_free(pw), x16=x16, dz16=dz16) if need_w else None
         dx = None
         if need_x and dz16 is not None:
             dx = ops.conv3x3_auto(None, ctx.packed, 1, x16=dz16)

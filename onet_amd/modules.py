@@ -136,6 +136,11 @@ class DoubleConv(nn.Module):
         # bf16 storage: unit 1's output feeds unit 2's convolution only -- where that reads the bf16 copy (forward and weight
         # gradient), unit 1 writes no fp32 activation at all
         drop1 = x.dim() == 4 and ops.consumer_reads_bf16(x.shape[0], s[3].in_channels, s[3].out_channels, x.shape[2], x.shape[3])
+        # fp32 model, split-bf16 kernels: unit 2's convolution (forward and weight gradient) applies unit 1's BatchNorm + ReLU
+        # on load -- unit 1 writes no activation (functional.ConvBNReLUFn; bit-identical to the materialised form)
+        if (x.dim() == 4 and not drop1 and s[1].training and s[4].training and s[1].running_mean is not None
+                and ops.norm_on_load_ok(x.shape[0], s[3].in_channels, s[3].out_channels, x.shape[2], x.shape[3], groups)):
+            link["defer"] = True
         a1 = self._unit(x, s[0], s[1], None, groups, link_out=link, drop_fp32=drop1)
         return self._unit(a1, s[3], s[4], None if out is None else (out,), groups, link_out=pool_link, link_in=link,
                           out16=out16)

@@ -27,12 +27,13 @@ class Settings:
       convt_bf16    under conv == "bf16": the ConvTranspose2d GEMMs take bf16 operands too                  (default CONVT_BF16)
       bf16_storage  under conv == "bf16": producers write bf16 copies of the conv operands                  (default BF16_STORAGE)
       lazy_nan      OV:234's NaN assertion deferred to FlatAdam.step()                                      (default LAZY_NAN_CHECK)
-      split         under conv == "auto": fp32 3x3 convolutions on the bf16 matrix pipe by operand splitting   (default SPLIT_AUTO)"""
-    __slots__ = ("conv", "twin", "convt_bf16", "bf16_storage", "lazy_nan", "split")
+      split         under conv == "auto": fp32 3x3 convolutions on the bf16 matrix pipe by operand splitting   (default SPLIT_AUTO)
+      bn_on_load    the second convolution of a DoubleConv applies the first unit's BatchNorm + ReLU on load     (default BN_ON_LOAD)"""
+    __slots__ = ("conv", "twin", "convt_bf16", "bf16_storage", "lazy_nan", "split", "bn_on_load")
 
-    def __init__(self, conv=None, twin=None, convt_bf16=None, bf16_storage=None, lazy_nan=None, split=None):
+    def __init__(self, conv=None, twin=None, convt_bf16=None, bf16_storage=None, lazy_nan=None, split=None, bn_on_load=None):
         self.conv, self.twin, self.convt_bf16, self.bf16_storage, self.lazy_nan = conv, twin, convt_bf16, bf16_storage, lazy_nan
-        self.split = split
+        self.split, self.bn_on_load = split, bn_on_load
 
     def replace(self, **kw):
         out = Settings(*(getattr(self, k) for k in self.__slots__))
@@ -515,6 +516,7 @@ def conv3x3_auto(x, pk, direction, out=None, x16=None):
 
 
 FUSE_BN_STATS = _os.environ.get("ONET_FUSE_BN_STATS", "1") != "0"
+BN_ON_LOAD = _os.environ.get("ONET_BN_ON_LOAD", "1") != "0"        # 0: every BatchNorm + ReLU output is materialised
 CONVT_SPLIT_MIN_BLOCKS = int(_os.environ["ONET_CONVT_SPLIT_MIN_BLOCKS"]) if "ONET_CONVT_SPLIT_MIN_BLOCKS" in _os.environ else None
 CONVT_SPLIT = _os.environ.get("ONET_CONVT_SPLIT", "1") != "0"     # 0: the ConvTranspose2d GEMMs stay on the fp32 MFMA pipe
 SPLIT_WGRAD_MINW = int(_os.environ.get("ONET_SPLIT_WGRAD_MINW", "16"))   # 64: the 32- and 16-pixel levels keep the Winograd weight gradients
@@ -522,11 +524,26 @@ SPLIT_AUTO = _os.environ.get("ONET_SPLIT", "1") != "0"          # 0: "auto" neve
 STEM_FUSED = _os.environ.get("ONET_STEM_FUSED", "1") != "0"      # 0: the stem takes the direct MFMA kernel + a statistics pass
 
 
-def conv3x3_fwd_bn_partials(x, pk, x16=None):
+def conv3x3_fwd_bn_partials(x, pk, x16=None, norm=None):
     """Forward 3x3 convolution of a Conv-BatchNorm pair (OV:47-48, 51-52): -> (z, cm).  cm = the channel-major
     BatchNorm records [Cout, nparts, 3] the F(4x4) kernel's epilogue emits (image-major: nparts / B per image), or None
-    where the selected kernel does not emit them (then `bn_train_coeffs` runs its own statistics pass)."""
+    where the selected kernel does not emit them (then `bn_train_coeffs` runs its own statistics pass).
+    norm = (z_prev, save [G, 4, Cin]): normalise on load -- x is NOT read; the input is relu(bn(z_prev)) of the unit below,
+    applied in the split kernel's staging (the caller has checked norm_on_load_ok)."""
     Ci, Co = pk["Cin"], pk["Cout"]
+    if norm is not None:
+        z_prev, save = norm
+        require_gpu(z_prev, save)
+        zs, zbs = plane(z_prev)
+        B, _, H, W = zs.shape
+        nparts = int(_lib.load().onet_conv3x3_split_nparts(B, H, W)) if (FUSE_BN_STATS and not SYNC_BN) else 0
+        out = torch.empty((B, Co, H, W), dtype=F32, device=zs.device)
+        cm = torch.empty((Co, nparts, 3), dtype=F32, device=zs.device) if nparts > 0 else None
+        e0 = _prof_begin()
+        _lib.call("onet_conv3x3_split_fwd_norm", _p(zs), zbs, _p(save), save.shape[0], _p(pk.get_pack("split")[0]), _p(out),
+                  Co * H * W, _p(cm), B, Ci, Co, H, W, _stream())
+        _prof_end("conv3x3_split_kernel", 2.0 * B * H * W * Ci * Co * 9, e0, 4.0 * (B * H * W * (Ci + Co) + 9 * Ci * Co))
+        return out, cm
     B, _, H, W = (x if x is not None else x16).shape
     if Ci <= 4 and x is not None and STEM_FUSED and FUSE_BN_STATS and not SYNC_BN and hasattr(pk, "w"):
         # the stem (Cin = n_channels): one streaming pass writes z and its statistics records (stem.hip)
@@ -729,11 +746,23 @@ def pack3x3_split(w):
     return wf, wd
 
 
-def conv3x3_split(x, wq, Cout, out=None):
-    """z = conv3x3(x) in fp32 accuracy on the bf16 matrix cores (operands split into two bf16 parts, three MFMAs per term)."""
+def conv3x3_split(x, wq, Cout, out=None, norm=None):
+    """z = conv3x3(x) in fp32 accuracy on the bf16 matrix cores (operands split into two bf16 parts, three MFMAs per term).
+    norm = save [G, 4, Cin]: x is a pre-activation; the kernel convolves relu(bn(x)), applied in its staging."""
     if wq is None or not wq.is_cuda or wq.dtype != torch.bfloat16:
         raise TypeError("conv3x3_split: wq must be a split pack on the GPU (pack3x3_split)")
     require_gpu(x)
+    if norm is not None:
+        require_gpu(norm)
+        x, xbs = plane(x)
+        B, Cin, H, W = x.shape
+        if out is None:
+            out = torch.empty((B, Cout, H, W), dtype=F32, device=x.device)
+        e0 = _prof_begin()
+        _lib.call("onet_conv3x3_split_fwd_norm", _p(x), xbs, _p(norm), norm.shape[0], _p(wq), _p(out),
+                  out.stride(0) if B > 1 else Cout * H * W, None, B, Cin, Cout, H, W, _stream())
+        _prof_end("conv3x3_split_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
+        return out
     x, xbs = plane(x)
     if x.data_ptr() % 16 or xbs % 4:                 # the kernel stages whole float4s: 16-byte aligned image rows
         x = x.contiguous()
@@ -758,8 +787,35 @@ def split_wgrad_ok(x, dz):
     return ok
 
 
-def conv3x3_split_wgrad(x, dz, dw_shape, out=None):
-    """dW of a 3x3 convolution in fp32 accuracy on the bf16 matrix cores (conv_split.hip: both operands split, three MFMAs per term)."""
+def norm_on_load_ok(B, Cmid, Cout, H, W, groups):
+    """May the second convolution of a DoubleConv (Cmid -> Cout on B maps of H x W, `groups` BatchNorm statistics groups) take
+    the first unit's BatchNorm + ReLU into its own operand staging -- forward AND weight gradient -- so that the first unit's
+    activation is never written?  Both must be the split-bf16 kernels (fp32 model, default dispatch)."""
+    if not (BN_ON_LOAD and _setting("bn_on_load", True)) or SYNC_BN or conv_algo() not in ("auto", "split") or groups not in (1, 2) or B % groups:
+        return False
+    if conv3x3_algo(B, Cmid, Cout, H, W) != "split" or W < SPLIT_WGRAD_MINW:
+        return False
+    if not _lib.load().onet_conv3x3_split_wgrad_ok(B, Cmid, Cout, H, W) or max(Cmid, Cout) * H * W * 4 >= 2 ** 31:
+        return False
+    return W >= 64 or B * max(Cmid, Cout) * H * W * 4 < 2 ** 31
+
+
+def conv3x3_split_wgrad(x, dz, dw_shape, out=None, norm=None):
+    """dW of a 3x3 convolution in fp32 accuracy on the bf16 matrix cores (conv_split.hip: both operands split, three MFMAs per term).
+    norm = save [G, 4, Cin]: x is the pre-activation of the unit below, normalised (BatchNorm + ReLU) on load."""
+    if norm is not None:
+        require_gpu(x, dz, norm)
+        x, xbs = plane(x)
+        dz, dzbs = plane(dz)
+        B, Cin, H, W = x.shape
+        Cout = dz.shape[1]
+        dw = torch.empty(dw_shape, dtype=F32, device=x.device) if out is None else out
+        ws = workspace(_lib.load().onet_conv3x3_split_wgrad_ws_bytes(B, Cin, Cout, H, W), x.device)
+        e0 = _prof_begin()
+        _lib.call("onet_conv3x3_split_wgrad_norm", _p(x), xbs, _p(norm), norm.shape[0], _p(dz), dzbs, _p(dw), _p(ws), ws.numel() * 4,
+                  B, Cin, Cout, H, W, 0, _stream())
+        _prof_end("conv3x3_split_wgrad_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
+        return dw
     require_gpu(x, dz)
     x, xbs = plane(x)
     dz, dzbs = plane(dz)

@@ -372,6 +372,46 @@ def test_adam_loss_sequence_vs_reference_golden(dev, fused_adam, monkeypatch):
     assert nbt[0] == 2 * steps
 
 
+def test_bn_on_load_model_step_is_bit_identical(dev, monkeypatch):
+    """Settings.bn_on_load (default): wherever the second convolution of a DoubleConv runs on the split-bf16 kernels, it applies
+    the first unit's BatchNorm + ReLU in its operand staging (forward and weight gradient) and the first unit writes no
+    activation.  Loss, outputs, every gradient and the BatchNorm buffers must equal, bit for bit, the step that materialises
+    every activation -- which is what the gradient-parity tests (they record every unit's output) run."""
+    from onet_amd import ops
+    B, C, H, W = 8, 1, 128, 128
+    X = orc.det_input(B, C, H, W, seed=23).to(dev)
+    calls = {"fwd": 0, "wgrad": 0}
+    real_f, real_w = ops.conv3x3_fwd_bn_partials, ops.conv3x3_split_wgrad
+
+    def spy_f(x, pk, x16=None, norm=None):
+        calls["fwd"] += norm is not None
+        return real_f(x, pk, x16=x16, norm=norm)
+
+    def spy_w(x, dz, shp, out=None, norm=None):
+        calls["wgrad"] += norm is not None
+        return real_w(x, dz, shp, out=out, norm=norm)
+
+    monkeypatch.setattr(ops, "conv3x3_fwd_bn_partials", spy_f)
+    monkeypatch.setattr(ops, "conv3x3_split_wgrad", spy_w)
+    res = {}
+    for on in (True, False):
+        m = _model(C, True, dev)
+        m.settings = ops.Settings(bn_on_load=on)
+        (Lt, Vt, Ld, Vd, S), loss = _step(m, X)
+        res[on] = (loss.detach().clone(), Lt.detach().clone(), S.detach().clone(),
+                   [p.grad.detach().clone() for p in m.parameters()], [b.detach().clone() for b in m.buffers()])
+        if on:
+            assert calls["fwd"] >= 4 and calls["wgrad"] == calls["fwd"], calls
+            n_on = dict(calls)
+        else:
+            assert calls == n_on, "bn_on_load=False still normalised on load"
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][2], res[False][2])
+    for a, b in zip(res[True][3], res[False][3]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[True][4], res[False][4]):
+        assert torch.equal(a, b)
+
+
 def test_flat_adam_skipped_parameters_follow_torch_adam(dev):
     """torch.optim.Adam leaves a parameter whose .grad is None untouched (p, exp_avg, exp_avg_sq) and bias-corrects every
     parameter with ITS OWN step count: a parameter that sat out two of five updates is on step 3 when the others are on 5.

@@ -143,6 +143,39 @@ def test_conv3x3_split_wgrad(dev, B, Cin, Cout, H, W):
     assert torch.equal(dw, ops.conv3x3_split_wgrad(wide.to(dev)[:, 16:], g.to(dev), (Cout, Cin, 3, 3)))
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W,G", [(4, 64, 64, 32, 64, 2), (2, 32, 48, 20, 40, 1), (4, 128, 128, 16, 32, 2), (6, 48, 256, 33, 96, 1),
+                                               (8, 64, 128, 16, 16, 2), (2, 16, 64, 48, 128, 2)])
+def test_conv3x3_split_norm_on_load_is_bit_identical(dev, B, Cin, Cout, H, W, G):
+    """Normalise on load: the split forward kernel and the split weight-gradient kernel given the PRE-activation of the unit
+    below plus its BatchNorm coefficients (one or two statistics groups) must produce, bit for bit, what they produce on the
+    activation bn_relu_apply materialises -- interior, zero padding (the halo must stay zero, not relu(shift)), ragged tiles,
+    the 128-channel weight-gradient tiles, 32- / 16-pixel-wide maps (weight gradient only at 16)."""
+    from onet_amd import ops
+    zp = rnd(B, Cin, H, W, seed=41).to(dev)
+    save = torch.empty(G, 4, Cin)
+    g = torch.Generator().manual_seed(42)
+    save[:, 0] = torch.randn(G, Cin, generator=g) * 0.3                  # mean
+    save[:, 1] = torch.rand(G, Cin, generator=g) + 0.5                   # invstd
+    save[:, 2] = save[:, 1] * (torch.rand(G, Cin, generator=g) + 0.5)    # scale = gamma * invstd
+    save[:, 3] = torch.randn(G, Cin, generator=g) * 0.5 + 0.2            # shift = beta (positive on average: relu(shift) != 0)
+    save = save.to(dev)
+    Bg = B // G
+    a = torch.cat([ops.bn_relu_apply(zp[i * Bg:(i + 1) * Bg], save[i]) for i in range(G)])
+    w = rnd(Cout, Cin, 3, 3, seed=43, scale=(2.0 / (Cin * 9)) ** 0.5).to(dev)
+    dz = rnd(B, Cout, H, W, seed=44).to(dev)
+    if W > 16:
+        qf, _ = ops.pack3x3_split(w)
+        ref = ops.conv3x3_split(a, qf, Cout)
+        got = ops.conv3x3_split(zp, qf, Cout, norm=save)
+        assert torch.equal(got, ref), float((got - ref).abs().max())
+    if ops.split_wgrad_ok(a, dz):
+        ref = ops.conv3x3_split_wgrad(a, dz, (Cout, Cin, 3, 3))
+        got = ops.conv3x3_split_wgrad(zp, dz, (Cout, Cin, 3, 3), norm=save)
+        assert torch.equal(got, ref), float((got - ref).abs().max())
+    else:
+        assert W < 64 and W != 32          # (the weight-gradient kernel takes maps >= 64 or exactly 32 / 16 pixels wide)
+
+
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 64, 64, 40, 48), (1, 32, 128, 64, 64), (3, 16, 36, 33, 28), (2, 128, 80, 16, 96),
                                              (9, 48, 64, 32, 32), (1, 512, 64, 17, 40)])
 def test_conv3x3_split_fwd_dgrad_stats(dev, B, Cin, Cout, H, W):
