@@ -138,7 +138,7 @@ class DoubleConv(nn.Module):
         drop1 = x.dim() == 4 and ops.consumer_reads_bf16(x.shape[0], s[3].in_channels, s[3].out_channels, x.shape[2], x.shape[3])
         # fp32 model, split-bf16 kernels: unit 2's convolution (forward and weight gradient) applies unit 1's BatchNorm + ReLU
         # on load -- unit 1 writes no activation (functional.ConvBNReLUFn; bit-identical to the materialised form)
-        if (x.dim() == 4 and not drop1 and s[1].training and s[4].training and s[1].running_mean is not None
+        if (x.dim() == 4 and x.is_cuda and not drop1 and s[1].training and s[4].training and s[1].running_mean is not None
                 and ops.norm_on_load_ok(x.shape[0], s[3].in_channels, s[3].out_channels, x.shape[2], x.shape[3], groups)):
             link["defer"] = True
         a1 = self._unit(x, s[0], s[1], None, groups, link_out=link, drop_fp32=drop1)
