@@ -547,8 +547,12 @@ struct SwArgs {
     int nimg;             //       coefficients [groups <= 2][4][Cin], statistics groups of nimg consecutive images
 };
 
-#ifndef SW_COMMIT_AT
-#define SW_COMMIT_AT 3
+// MFMA groups of a unit (6 with 64-channel tiles, 12 with 128) before the next unit's rows are committed
+#ifndef SW_CAT64
+#define SW_CAT64 2
+#endif
+#ifndef SW_CAT128
+#define SW_CAT128 5
 #endif
 // Maps narrower than a strip (G = 64 / W = 2 or 4: the 32- and 16-pixel levels): a unit is row y of G IMAGES side by side -- the dz
 // row is their 64 pixels back to back, the x row keeps each image's own halo (sub-row pitch SR_P dwords: W / 2 data dwords + the
@@ -624,7 +628,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
     // loads of one dz row and / or one x row of strip (b, x0): row < 0 or >= H -> zeros.  G == 1: one buffer resource per image
     // (a 256 x 256 level's batch exceeds the 2 GiB range); G > 1: the lanes of a wave address different images, so the resource
     // spans the whole (small) tensor and the image offset goes into the lane's byte offset (range checked by the host)
-    auto issue_dz = [&](int b, int x0, int y) __attribute__((always_inline)) {
+    auto issue_dz = [&](int b, int x0, int y, int p0 = 0, int p1 = 64) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t dr = G == 1 ? s_rsrc(a.dz + (int64_t)b * a.dz_bs, (int64_t)a.Cout * HW * 4)
                                                  : s_rsrc(a.dz, ((int64_t)(a.B - 1) * a.dz_bs + (int64_t)a.Cout * HW) * 4);
         const int xs = x0 + 8 * st_w;
@@ -635,16 +639,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
             const unsigned base = (unsigned)((co * HW + y * a.W + xs) * 4) + (G == 1 ? 0u : (unsigned)((int64_t)(b * G + st_sub) * a.dz_bs * 4));
 #pragma unroll
             for (int k = 0; k < 2; ++k)
-                dzv[2 * i + k] = __builtin_amdgcn_raw_buffer_load_b128(dr, (ok && xs + 4 * k < a.W) ? base + 16 * k : OOB_S, 0, 0);
+                if (2 * i + k >= p0 && 2 * i + k < p1)
+                    dzv[2 * i + k] = __builtin_amdgcn_raw_buffer_load_b128(dr, (ok && xs + 4 * k < a.W) ? base + 16 * k : OOB_S, 0, 0);
         }
     };
-    auto issue_x = [&](int b, int x0, int y) __attribute__((always_inline)) {
+    auto issue_x = [&](int b, int x0, int y, int p0 = 0, int p1 = 64) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t xr = G == 1 ? s_rsrc(a.x + (int64_t)b * a.x_bs, (int64_t)a.Cin * HW * 4)
                                                  : s_rsrc(a.x, ((int64_t)(a.B - 1) * a.x_bs + (int64_t)a.Cin * HW) * 4);
         const int xs = x0 + 8 * st_w;
         const bool ok = y >= 0 && y < a.H && ci0 + st_c < a.Cin;
         const unsigned base = (unsigned)(((ci0 + st_c) * HW + y * a.W + xs) * 4) + (G == 1 ? 0u : (unsigned)((int64_t)(b * G + st_sub) * a.x_bs * 4));
-        if constexpr (NORM) {
+        if (NORM && p0 == 0) {
             pend_v[0] = ok && xs > 0 && xs - 1 < a.W;
             pend_v[1] = ok && xs < a.W;
             pend_v[2] = ok && xs + 4 < a.W;
@@ -652,9 +657,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
             pend_g1 = (G == 1 ? b : b * G + st_sub) >= a.nimg;
         }
 #pragma unroll
-        for (int k = 0; k < 2; ++k) xq[k] = __builtin_amdgcn_raw_buffer_load_b128(xr, (ok && xs + 4 * k < a.W) ? base + 16 * k : OOB_S, 0, 0);
-        xh[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (ok && xs > 0 && xs - 1 < a.W) ? base - 4 : OOB_S, 0, 0));
-        xh[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (ok && st_w == C::SPG - 1 && xs + 8 < a.W) ? base + 32 : OOB_S, 0, 0));
+        for (int k = 0; k < 2; ++k)
+            if (k >= p0 && k < p1) xq[k] = __builtin_amdgcn_raw_buffer_load_b128(xr, (ok && xs + 4 * k < a.W) ? base + 16 * k : OOB_S, 0, 0);
+        if (2 >= p0 && 2 < p1)
+            xh[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (ok && xs > 0 && xs - 1 < a.W) ? base - 4 : OOB_S, 0, 0));
+        if (3 >= p0 && 3 < p1)
+            xh[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (ok && st_w == C::SPG - 1 && xs + 8 < a.W) ? base + 32 : OOB_S, 0, 0));
     };
     auto commit_dz = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -733,20 +741,36 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
         for (int y = yb; y < ye; ++y) {
-            // unit y: MFMAs on dz buffer y & 1 and ring rows y - 1 .. y + 1; the NEXT unit's rows (loaded since the barrier that
-            // opened this unit) are split and committed SW_COMMIT_AT sixths of the way through -- into the other dz buffer and
-            // the ring slot of row y - 2, both last read in unit y - 1 -- so the commit's VALU / LDS-write work sits between
-            // MFMAs instead of in front of the barrier, where all eight waves did it at once with the matrix pipe idle
+            // unit y: MFMAs on dz buffer y & 1 and ring rows y - 1 .. y + 1.  Staging rides inside the MFMA block: the rows of unit
+            // y + 1 (in registers since the previous unit) are split and committed after the first MFMA group -- into the other dz
+            // buffer and the ring slot of row y - 2, both last read in unit y - 1 -- and the loads of unit y + 2's rows then go
+            // out ONE PER MFMA GROUP.  (Issued as a burst behind the barrier, by all eight waves at once, they held every wave's
+            // issue port while the matrix pipe idled: a timing build without them ran 16 % faster, one without the barrier 4 %.)
             const int buf = y & 1;
-            const bool more = y + 1 < ye;
+            const bool more = y + 1 < ye, more2 = y + 2 < ye;
             const unsigned* ab = a_ptr + buf * 2 * SR_DZ_PART;
             bf16x8 ah, am;
+            constexpr int CAT = COT == 64 ? SW_CAT64 : SW_CAT128;
 #pragma unroll
             for (int gk = 0; gk < 3 * NSEG; ++gk) {
                 const int sg = gk / 3, ky = gk % 3;
-                if (gk == (COT == 64 ? SW_COMMIT_AT : 2 * SW_COMMIT_AT) && more) {
+                if (gk == CAT && more) {
                     commit_dz(buf ^ 1);
                     commit_x((y + 2) & 3);
+                }
+                if (more2) {
+                    // pieces: 2 DZI dz loads, then the four x loads; groups CAT + 1 ... (two or more pieces each where
+                    // they do not fit one per group)
+                    constexpr int NP = 2 * DZI + 4, NG = 3 * NSEG - CAT - 1, PER = (NP + NG - 1) / NG;
+                    const int g0 = gk - CAT - 1;
+                    if (g0 >= 0) {
+#pragma unroll
+                        for (int q = 0; q < PER; ++q) {
+                            const int pc = g0 * PER + q;
+                            if (pc < 2 * DZI) issue_dz(b, x0, y + 2, pc, pc + 1);
+                            else if (pc < NP) issue_x(b, x0, y + 3, pc - 2 * DZI, pc - 2 * DZI + 1);
+                        }
+                    }
                 }
                 if (ky == 0) {
                     ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4s*>(ab + sg * 8));
@@ -770,13 +794,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
                     acc[ky * 3 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[ky * 3 + j], 0, 0, 0);
                     acc[ky * 3 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[ky * 3 + j], 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();
-            if (y + 2 < ye) {
-                issue_dz(b, x0, y + 2);
-                issue_x(b, x0, y + 3);
-            }
-            __builtin_amdgcn_sched_barrier(0);
         }
         u += ye - yb;
     }
