@@ -173,13 +173,17 @@ int onet_conv3x3_bf16_fwd_b(const void* x_bf16, int64_t x_bs, const void* wq, fl
  * kernel's), three MFMAs per product term at 16x the fp32 MFMA rate.  wq_fwd [Cin/16][2 parts][9][2][Cout][8] bf16 (2 * 9 * Cin *
  * Cout elements), wq_dgrad [ceil(Cout/16)][2][9][2][Cin][8] with the taps rotated; either may be NULL.  Requires Cin % 16 == 0 and
  * W > 16.  _fwd_stats also writes one BatchNorm record (n, mean, M2) per channel and 16 x 32-pixel tile: part [Cout][nparts][3],
- * nparts = onet_conv3x3_split_nparts(B, H, W) (0: the map is not made of full tiles). */
-int onet_conv3x3_split_pack_weights(const float* w, void* wq_fwd, void* wq_dgrad, int Cout, int Cin, void* stream);
-int onet_conv3x3_split_fwd(const float* x, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin, int Cout, int H,
-                           int W, void* stream);
+ * nparts = onet_conv3x3_split_nparts(B, H, W) (0: the map is not made of full tiles).
+ * fp16 parts (fwd_f16 / wq_f16 = 1; the forward convolution's default): hi = fp16(v), mid = fp16(v - hi) carry 22 significant bits
+ * instead of 16 at the same three MFMAs per term (v_mfma_f32_32x32x16_f16): error at the fp32 direct kernel's level.  The pack
+ * holds 2^8 w (undone on the accumulators); the input must stay within fp16's range (|x| < 65504: activations, not gradients --
+ * an input gradient is computed with wq_dgrad, whose parts are always bf16, and wq_f16 = 0). */
+int onet_conv3x3_split_pack_weights(const float* w, void* wq_fwd, void* wq_dgrad, int Cout, int Cin, int fwd_f16, void* stream);
+int onet_conv3x3_split_fwd(const float* x, int64_t x_bs, const void* wq, int wq_f16, float* z, int64_t z_bs, int B, int Cin, int Cout,
+                           int H, int W, void* stream);
 int onet_conv3x3_split_nparts(int B, int H, int W);
-int onet_conv3x3_split_fwd_stats(const float* x, int64_t x_bs, const void* wq, float* z, int64_t z_bs, float* part, int B, int Cin,
-                                 int Cout, int H, int W, void* stream);
+int onet_conv3x3_split_fwd_stats(const float* x, int64_t x_bs, const void* wq, int wq_f16, float* z, int64_t z_bs, float* part, int B,
+                                 int Cin, int Cout, int H, int W, void* stream);
 /* Weight gradient of the same convolution with both operands (x, dz: fp32 NCHW) split the same way, three MFMAs per term;
  * row-streaming units (one image row of a 64-pixel strip), deterministic split-K through ws (onet_conv3x3_split_wgrad_ws_bytes).
  * _ok: 1 where the kernel takes the shape: W >= 64 with W % 4 == 0, or W = 32 / 16 with B a multiple of 64 / W (that many images
@@ -192,8 +196,8 @@ int onet_conv3x3_split_wgrad_ok(int B, int Cin, int Cout, int H, int W);
  * images).  The staging threads compute max(fma(z - mean, scale, shift), 0) -- bit for bit what onet_bn_relu_apply writes --
  * before splitting; zero padding stays zero.  _fwd_norm: part != NULL also emits the statistics records (as _fwd_stats);
  * _wgrad_norm: n_groups 1 or 2.  Results are bit-identical to the plain entry points on the materialised activation. */
-int onet_conv3x3_split_fwd_norm(const float* z_prev, int64_t z_bs, const float* save, int n_groups, const void* wq, float* z,
-                                int64_t zo_bs, float* part, int B, int Cin, int Cout, int H, int W, void* stream);
+int onet_conv3x3_split_fwd_norm(const float* z_prev, int64_t z_bs, const float* save, int n_groups, const void* wq, int wq_f16,
+                                float* z, int64_t zo_bs, float* part, int B, int Cin, int Cout, int H, int W, void* stream);
 int onet_conv3x3_split_wgrad_norm(const float* z_prev, int64_t z_bs, const float* save, int n_groups, const float* dz, int64_t dz_bs,
                                   float* dw, void* ws, int64_t ws_bytes, int B, int Cin, int Cout, int H, int W, int accumulate,
                                   void* stream);

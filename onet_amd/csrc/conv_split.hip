@@ -48,10 +48,26 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
     mid = __builtin_bit_cast(unsigned, m);
 }
 
+// The FORWARD convolution splits into fp16 parts instead (F16): hi = fp16(v), mid = fp16(v - hi) carry 22 significant bits where
+// the bf16 pair carries 16, at the same three MFMAs per term (v_mfma_f32_32x32x16_f16, same rate) -- the forward error drops from
+// 8e-7 rms of the output scale to the fp32 direct kernel's level, which is what the saturated B = 32 gradient check needed (the
+// forward kernel alone put it at 3.3e-4; input and weight gradients contribute nothing measurable).  fp16's range is the price:
+// activations (BatchNorm outputs, |x| << 65504) fit as they are, weights are packed times 2^8 so that their mid parts stay normal
+// numbers (undone on the accumulators, exactly); gradients -- whose magnitude is anyone's guess -- keep the bf16 split.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr float F16_WSCALE = 256.f;
+__device__ __forceinline__ void split2h(float a, float b, unsigned& hi, unsigned& mid) {
+    const f16x2 h = {(_Float16)a, (_Float16)b};
+    const f16x2 m = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
+    hi = __builtin_bit_cast(unsigned, h);
+    mid = __builtin_bit_cast(unsigned, m);
+}
+
 // w [Cout][Cin][3][3] fp32 -> wq [K/16][part 2][9][2][N][8] bf16: chunk of 16 reduction channels, part (hi, mid), tap,
 // 8-channel half, output channel, channel within the half.  which = 0: forward (K = Cin, N = Cout); 1: input gradient
 // (K = Cout rounded up to 16 with a zero tail, N = Cin, taps rotated by 180 degrees).
-__global__ void pack3x3_split_kernel(const float* __restrict__ w, __bf16* __restrict__ wq, int Cout, int Cin, int which) {
+__global__ void pack3x3_split_kernel(const float* __restrict__ w, __bf16* __restrict__ wq, int Cout, int Cin, int which, int f16) {
     const int K = which == 0 ? Cin : ((Cout + 15) / 16) * 16, N = which == 0 ? Cout : Cin;
     const int64_t n = (int64_t)K * 9 * N;                            // elements of ONE part
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -66,12 +82,19 @@ __global__ void pack3x3_split_kernel(const float* __restrict__ w, __bf16* __rest
         float v = 0.f;
         if (which == 0) v = w[((int64_t)nn * Cin + k) * 9 + t];
         else if (k < Cout) v = w[((int64_t)k * Cin + nn) * 9 + (8 - t)];
-        const __bf16 hi = (__bf16)v;
-        const __bf16 mid = (__bf16)(v - (float)hi);
         const int64_t per_chunk_part = (int64_t)9 * 2 * N * 8;
         const int64_t within = i - (int64_t)kg * per_chunk_part;     // [tap][half][n][8] inside the chunk
-        wq[((int64_t)kg * 2 + 0) * per_chunk_part + within] = hi;
-        wq[((int64_t)kg * 2 + 1) * per_chunk_part + within] = mid;
+        if (f16) {                                                   // fp16 parts of 2^8 w (forward pack only)
+            _Float16* wh = reinterpret_cast<_Float16*>(wq);
+            const float vs = v * F16_WSCALE;
+            const _Float16 hi = (_Float16)vs;
+            wh[((int64_t)kg * 2 + 0) * per_chunk_part + within] = hi;
+            wh[((int64_t)kg * 2 + 1) * per_chunk_part + within] = (_Float16)(vs - (float)hi);
+        } else {
+            const __bf16 hi = (__bf16)v;
+            wq[((int64_t)kg * 2 + 0) * per_chunk_part + within] = hi;
+            wq[((int64_t)kg * 2 + 1) * per_chunk_part + within] = (__bf16)(v - (float)hi);
+        }
     }
 }
 
@@ -124,7 +147,7 @@ struct SpCfg {
 // BatchNorm + ReLU -- max(fma(z - mean, scale, shift), 0), the expression of bn_relu_apply_kernel, so the operand is bit for
 // bit the activation that pass would have written -- before splitting; zero padding stays zero.  The second convolution of a
 // DoubleConv (OV:51) then needs no materialised activation of the first (OV:49): one write and one read of the tensor less.
-template <bool ST, bool NORM>
+template <bool ST, bool NORM, bool F16>
 __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
     using C = SpCfg;
     constexpr int NT = C::NT, IN_COLS = C::IN_COLS, NWI = C::NWI, CO_T = C::CO_T, NPIXP = C::NPIXP, NB = C::NB;
@@ -267,7 +290,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
                     va = pend_keep ? va : 0.f;               // outside the image: the convolution's zero padding
                     vb = pend_keep ? vb : 0.f;
                     unsigned h, m;
-                    split2(va, vb, h, m);
+                    if constexpr (F16) split2h(va, vb, h, m);
+                    else split2(va, vb, h, m);
                     hi[px][c] = h;
                     mid[px][c] = m;
                 }
@@ -287,7 +311,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 unsigned h, m;
-                split2(f[2 * c][px], f[2 * c + 1][px], h, m);
+                if constexpr (F16) split2h(f[2 * c][px], f[2 * c + 1][px], h, m);
+                else split2(f[2 * c][px], f[2 * c + 1][px], h, m);
                 hi[c] = h;
                 mid[c] = m;
             }
@@ -391,12 +416,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
-                        const bf16x8 ah = __builtin_bit_cast(bf16x8, Aq[idx & 1][m][0]), am = __builtin_bit_cast(bf16x8, Aq[idx & 1][m][1]);
-                        const bf16x8 bh = __builtin_bit_cast(bf16x8, Bq[kx & 1][n + ky][0]), bm = __builtin_bit_cast(bf16x8, Bq[kx & 1][n + ky][1]);
                         // smallest terms first: the two cross terms, then hi * hi
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[m][n], 0, 0, 0);
+                        if constexpr (F16) {
+                            const f16x8 ah = __builtin_bit_cast(f16x8, Aq[idx & 1][m][0]), am = __builtin_bit_cast(f16x8, Aq[idx & 1][m][1]);
+                            const f16x8 bh = __builtin_bit_cast(f16x8, Bq[kx & 1][n + ky][0]), bm = __builtin_bit_cast(f16x8, Bq[kx & 1][n + ky][1]);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, bh, acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bm, acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[m][n], 0, 0, 0);
+                        } else {
+                            const bf16x8 ah = __builtin_bit_cast(bf16x8, Aq[idx & 1][m][0]), am = __builtin_bit_cast(bf16x8, Aq[idx & 1][m][1]);
+                            const bf16x8 bh = __builtin_bit_cast(bf16x8, Bq[kx & 1][n + ky][0]), bm = __builtin_bit_cast(bf16x8, Bq[kx & 1][n + ky][1]);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[m][n], 0, 0, 0);
+                        }
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -404,6 +437,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
             buf ^= 1;
         }
 
+        if constexpr (F16) {                         // the weights were packed times 2^8
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][n][r] *= (1.f / F16_WSCALE);
+        }
         int v = tile;
         const int tx = v % a.tilesX;
         v /= a.tilesX;
@@ -483,7 +524,7 @@ int split_nparts(int B, int H, int W) {
     return n < (1 << 30) ? (int)n : 0;
 }
 
-template <bool ST, bool NORM>
+template <bool ST, bool NORM, bool F16>
 int launch_split(SpArgs a, hipStream_t st) {
     using C = SpCfg;
     const int LDS_BYTES = C::LDS_BYTES + (ST ? C::NW * 64 * 2 * 4 : 0) + (NORM ? 2 * 2 * 8 * 4 * 4 : 0);
@@ -492,7 +533,7 @@ int launch_split(SpArgs a, hipStream_t st) {
     a.coTiles = cdiv(a.Cout, C::CO_T);
     const int64_t tiles = (int64_t)a.B * a.tilesX * a.tilesY * a.coTiles;
     ONET_REQUIRE(tiles > 0 && tiles < (1ll << 31), "conv3x3_split: tile count %lld out of range", (long long)tiles);
-    auto kern = conv3x3_split_kernel<ST, NORM>;
+    auto kern = conv3x3_split_kernel<ST, NORM, F16>;
     static PerDeviceOnce attr_once;
     if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -505,7 +546,7 @@ int launch_split(SpArgs a, hipStream_t st) {
 }
 
 int split_fwd(const float* x, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin, int Cout, int H, int W,
-              void* stream, float* stats, const float* nsave = nullptr, int n_groups = 0) {
+              void* stream, float* stats, int wq_f16, const float* nsave = nullptr, int n_groups = 0) {
     ONET_REQUIRE(x && wq && z, "conv3x3_split_fwd: null pointer");
     ONET_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 16, "conv3x3_split_fwd: bad shape (maps wider than 16 pixels)");
     ONET_REQUIRE((Cin % 16) == 0, "conv3x3_split_fwd: Cin must be a multiple of 16 (use onet_conv_fwd)");
@@ -519,9 +560,11 @@ int split_fwd(const float* x, int64_t x_bs, const void* wq, float* z, int64_t z_
     if (nsave) {
         ONET_REQUIRE(n_groups > 0 && B % n_groups == 0, "conv3x3_split_fwd_norm: the batch must hold n_groups equal statistics groups");
         a.nimg = B / n_groups;
-        return stats ? launch_split<true, true>(a, as_stream(stream)) : launch_split<false, true>(a, as_stream(stream));
+        if (wq_f16) return stats ? launch_split<true, true, true>(a, as_stream(stream)) : launch_split<false, true, true>(a, as_stream(stream));
+        return stats ? launch_split<true, true, false>(a, as_stream(stream)) : launch_split<false, true, false>(a, as_stream(stream));
     }
-    return stats ? launch_split<true, false>(a, as_stream(stream)) : launch_split<false, false>(a, as_stream(stream));
+    if (wq_f16) return stats ? launch_split<true, false, true>(a, as_stream(stream)) : launch_split<false, false, true>(a, as_stream(stream));
+    return stats ? launch_split<true, false, false>(a, as_stream(stream)) : launch_split<false, false, false>(a, as_stream(stream));
 }
 
 
@@ -898,38 +941,38 @@ int onet_conv3x3_split_wgrad_norm(const float* z_prev, int64_t z_bs, const float
     return split_wgrad_impl(z_prev, z_bs, dz, dz_bs, dw, ws, ws_bytes, B, Cin, Cout, H, W, accumulate, stream, save, n_groups);
 }
 
-int onet_conv3x3_split_pack_weights(const float* w, void* wq_fwd, void* wq_dgrad, int Cout, int Cin, void* stream) {
+int onet_conv3x3_split_pack_weights(const float* w, void* wq_fwd, void* wq_dgrad, int Cout, int Cin, int fwd_f16, void* stream) {
     ONET_REQUIRE(w && (wq_fwd || wq_dgrad), "conv3x3_split_pack_weights: null pointer");
     ONET_REQUIRE(Cout > 0 && Cin > 0, "conv3x3_split_pack_weights: bad shape");
     ONET_REQUIRE(!wq_fwd || (Cin % 16) == 0, "conv3x3_split_pack_weights: the forward pack needs Cin %% 16 == 0");
     const int64_t n = (int64_t)std::max(Cin, ((Cout + 15) / 16) * 16) * 9 * std::max(Cin, Cout);
     const int blocks = (int)std::min<int64_t>((n + 255) / 256, 8192);
     if (wq_fwd) {
-        hipLaunchKernelGGL(pack3x3_split_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, (__bf16*)wq_fwd, Cout, Cin, 0);
+        hipLaunchKernelGGL(pack3x3_split_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, (__bf16*)wq_fwd, Cout, Cin, 0, fwd_f16 != 0);
         int rc = check_launch("pack3x3_split_kernel");
         if (rc) return rc;
     }
-    if (wq_dgrad) hipLaunchKernelGGL(pack3x3_split_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, (__bf16*)wq_dgrad, Cout, Cin, 1);
+    if (wq_dgrad) hipLaunchKernelGGL(pack3x3_split_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, (__bf16*)wq_dgrad, Cout, Cin, 1, 0);
     return check_launch("pack3x3_split_kernel");
 }
 
-int onet_conv3x3_split_fwd(const float* x, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin, int Cout, int H,
-                           int W, void* stream) {
-    return split_fwd(x, x_bs, wq, z, z_bs, B, Cin, Cout, H, W, stream, nullptr);
+int onet_conv3x3_split_fwd(const float* x, int64_t x_bs, const void* wq, int wq_f16, float* z, int64_t z_bs, int B, int Cin, int Cout,
+                           int H, int W, void* stream) {
+    return split_fwd(x, x_bs, wq, z, z_bs, B, Cin, Cout, H, W, stream, nullptr, wq_f16);
 }
 
-int onet_conv3x3_split_fwd_norm(const float* z_prev, int64_t z_bs, const float* save, int n_groups, const void* wq, float* z,
-                                int64_t zo_bs, float* part, int B, int Cin, int Cout, int H, int W, void* stream) {
+int onet_conv3x3_split_fwd_norm(const float* z_prev, int64_t z_bs, const float* save, int n_groups, const void* wq, int wq_f16,
+                                float* z, int64_t zo_bs, float* part, int B, int Cin, int Cout, int H, int W, void* stream) {
     ONET_REQUIRE(save, "conv3x3_split_fwd_norm: null pointer");
-    return split_fwd(z_prev, z_bs, wq, z, zo_bs, B, Cin, Cout, H, W, stream, part, save, n_groups);
+    return split_fwd(z_prev, z_bs, wq, z, zo_bs, B, Cin, Cout, H, W, stream, part, wq_f16, save, n_groups);
 }
 
 int onet_conv3x3_split_nparts(int B, int H, int W) { return split_nparts(B, H, W); }
 
-int onet_conv3x3_split_fwd_stats(const float* x, int64_t x_bs, const void* wq, float* z, int64_t z_bs, float* part, int B, int Cin,
-                                 int Cout, int H, int W, void* stream) {
+int onet_conv3x3_split_fwd_stats(const float* x, int64_t x_bs, const void* wq, int wq_f16, float* z, int64_t z_bs, float* part, int B,
+                                 int Cin, int Cout, int H, int W, void* stream) {
     ONET_REQUIRE(part, "conv3x3_split_fwd_stats: null pointer");
-    return split_fwd(x, x_bs, wq, z, z_bs, B, Cin, Cout, H, W, stream, part);
+    return split_fwd(x, x_bs, wq, z, z_bs, B, Cin, Cout, H, W, stream, part, wq_f16);
 }
 
 }  // extern "C"

@@ -503,6 +503,9 @@ def conv3x3_auto(x, pk, direction, out=None, x16=None):
     Ci, Co = (pk["Cin"], pk["Cout"]) if direction == 0 else (pk["Cout"], pk["Cin"])
     shp = (x if x is not None else x16).shape
     algo = conv3x3_algo(shp[0], Ci, Co, shp[2], shp[3])
+    if algo == "split" and direction == 1 and not SPLIT_DGRAD:       # diagnostic: input gradients on the fp32-MFMA kernels
+        with using(active_settings().replace(split=False) if active_settings() is not None else Settings(split=False)):
+            algo = conv3x3_algo(shp[0], Ci, Co, shp[2], shp[3])
     wq = pk.get_pack(algo)[direction]
     if algo == "winograd4":
         return conv3x3_winograd4(x, wq, Co, out=out)
@@ -519,6 +522,8 @@ FUSE_BN_STATS = _os.environ.get("ONET_FUSE_BN_STATS", "1") != "0"
 BN_ON_LOAD = _os.environ.get("ONET_BN_ON_LOAD", "1") != "0"        # 0: every BatchNorm + ReLU output is materialised
 CONVT_SPLIT_MIN_BLOCKS = int(_os.environ["ONET_CONVT_SPLIT_MIN_BLOCKS"]) if "ONET_CONVT_SPLIT_MIN_BLOCKS" in _os.environ else None
 CONVT_SPLIT = _os.environ.get("ONET_CONVT_SPLIT", "1") != "0"     # 0: the ConvTranspose2d GEMMs stay on the fp32 MFMA pipe
+SPLIT_F16 = _os.environ.get("ONET_SPLIT_F16", "1") != "0"         # 0: the forward split kernel takes bf16 parts like the gradients
+SPLIT_DGRAD = _os.environ.get("ONET_SPLIT_DGRAD", "1") != "0"     # 0 (diagnostic): input gradients stay on the fp32-MFMA kernels
 SPLIT_WGRAD_MINW = int(_os.environ.get("ONET_SPLIT_WGRAD_MINW", "16"))   # 64: the 32- and 16-pixel levels keep the Winograd weight gradients
 SPLIT_AUTO = _os.environ.get("ONET_SPLIT", "1") != "0"          # 0: "auto" never selects the split-bf16 kernel (round-2 dispatch)
 STEM_FUSED = _os.environ.get("ONET_STEM_FUSED", "1") != "0"      # 0: the stem takes the direct MFMA kernel + a statistics pass
@@ -540,7 +545,8 @@ def conv3x3_fwd_bn_partials(x, pk, x16=None, norm=None):
         out = torch.empty((B, Co, H, W), dtype=F32, device=zs.device)
         cm = torch.empty((Co, nparts, 3), dtype=F32, device=zs.device) if nparts > 0 else None
         e0 = _prof_begin()
-        _lib.call("onet_conv3x3_split_fwd_norm", _p(zs), zbs, _p(save), save.shape[0], _p(pk.get_pack("split")[0]), _p(out),
+        wq = pk.get_pack("split")[0]
+        _lib.call("onet_conv3x3_split_fwd_norm", _p(zs), zbs, _p(save), save.shape[0], _p(wq), int(wq.dtype == torch.float16), _p(out),
                   Co * H * W, _p(cm), B, Ci, Co, H, W, _stream())
         _prof_end("conv3x3_split_kernel", 2.0 * B * H * W * Ci * Co * 9, e0, 4.0 * (B * H * W * (Ci + Co) + 9 * Ci * Co))
         return out, cm
@@ -592,7 +598,8 @@ def conv3x3_fwd_bn_partials(x, pk, x16=None, norm=None):
             out = torch.empty((B, Co, H, W), dtype=F32, device=x.device)
             cm = torch.empty((Co, nparts, 3), dtype=F32, device=x.device)
             e0 = _prof_begin()
-            _lib.call("onet_conv3x3_split_fwd_stats", _p(xs), xbs, _p(wq), _p(out), Co * H * W, _p(cm), B, Ci, Co, H, W, _stream())
+            _lib.call("onet_conv3x3_split_fwd_stats", _p(xs), xbs, _p(wq), int(wq.dtype == torch.float16), _p(out), Co * H * W, _p(cm),
+                      B, Ci, Co, H, W, _stream())
             _prof_end("conv3x3_split_kernel", 2.0 * B * H * W * Ci * Co * 9, e0, 4.0 * (B * H * W * (Ci + Co) + 9 * Ci * Co))
             return out, cm
     if nparts <= 0:
@@ -740,17 +747,19 @@ def pack3x3_split(w):
     require_gpu(w)
     w = w.detach().contiguous()
     Cout, Cin = w.shape[0], w.shape[1]
-    wf = torch.empty(2 * Cin * 9 * Cout, dtype=BF, device=w.device) if Cin % 16 == 0 else None
+    # the forward pack's parts are fp16 (of 2^8 w) by default -- its dtype tells conv3x3_split which arithmetic the pack is for
+    wf = torch.empty(2 * Cin * 9 * Cout, dtype=torch.float16 if SPLIT_F16 else BF, device=w.device) if Cin % 16 == 0 else None
     wd = torch.empty(2 * (-(-Cout // 16) * 16) * 9 * Cin, dtype=BF, device=w.device)
-    _lib.call("onet_conv3x3_split_pack_weights", _p(w), _p(wf), _p(wd), Cout, Cin, _stream())
+    _lib.call("onet_conv3x3_split_pack_weights", _p(w), _p(wf), _p(wd), Cout, Cin, int(SPLIT_F16), _stream())
     return wf, wd
 
 
 def conv3x3_split(x, wq, Cout, out=None, norm=None):
     """z = conv3x3(x) in fp32 accuracy on the bf16 matrix cores (operands split into two bf16 parts, three MFMAs per term).
     norm = save [G, 4, Cin]: x is a pre-activation; the kernel convolves relu(bn(x)), applied in its staging."""
-    if wq is None or not wq.is_cuda or wq.dtype != torch.bfloat16:
+    if wq is None or not wq.is_cuda or wq.dtype not in (torch.bfloat16, torch.float16):
         raise TypeError("conv3x3_split: wq must be a split pack on the GPU (pack3x3_split)")
+    f16 = int(wq.dtype == torch.float16)
     require_gpu(x)
     if norm is not None:
         require_gpu(norm)
@@ -759,7 +768,7 @@ def conv3x3_split(x, wq, Cout, out=None, norm=None):
         if out is None:
             out = torch.empty((B, Cout, H, W), dtype=F32, device=x.device)
         e0 = _prof_begin()
-        _lib.call("onet_conv3x3_split_fwd_norm", _p(x), xbs, _p(norm), norm.shape[0], _p(wq), _p(out),
+        _lib.call("onet_conv3x3_split_fwd_norm", _p(x), xbs, _p(norm), norm.shape[0], _p(wq), f16, _p(out),
                   out.stride(0) if B > 1 else Cout * H * W, None, B, Cin, Cout, H, W, _stream())
         _prof_end("conv3x3_split_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
         return out
@@ -772,7 +781,7 @@ def conv3x3_split(x, wq, Cout, out=None, norm=None):
         out = torch.empty((B, Cout, H, W), dtype=F32, device=x.device)
     zbs = out.stride(0) if B > 1 else Cout * H * W
     e0 = _prof_begin()
-    _lib.call("onet_conv3x3_split_fwd", _p(x), xbs, _p(wq), _p(out), zbs, B, Cin, Cout, H, W, _stream())
+    _lib.call("onet_conv3x3_split_fwd", _p(x), xbs, _p(wq), f16, _p(out), zbs, B, Cin, Cout, H, W, _stream())
     _prof_end("conv3x3_split_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
     return out
 

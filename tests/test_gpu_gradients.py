@@ -223,8 +223,9 @@ def test_benchmark_dispatch_b32_256_every_gradient_element(dev, monkeypatch):
     # the benchmark's kernels really ran: forward with fused statistics (split-bf16 kernel on the 32-pixel-and-wider levels, fp32
     # Winograd F(4x4) on the 16-pixel level), split-bf16 input gradients, split-bf16 weight gradients of all 17 layers with
     # >= 16 input channels (round 3: also the 32- and 16-pixel levels), the ConvTranspose2d GEMMs
-    assert used.get("conv3x3_fwd_bn_partials", 0) >= 14 and used.get("conv3x3_split", 0) >= 10, used
-    if ops.SPLIT_AUTO:
+    diag = bool(os.environ.get("ONET_DIAG"))        # diagnostic runs with parts of the dispatch switched off (ONET_SPLIT_DGRAD=0 ...)
+    assert diag or (used.get("conv3x3_fwd_bn_partials", 0) >= 14 and used.get("conv3x3_split", 0) >= 10), used
+    if ops.SPLIT_AUTO and not diag:
         assert used.get("conv3x3_split_wgrad", 0) == 17 and used.get("conv3x3_winograd4_wgrad", 0) + used.get("conv3x3_winograd_wgrad", 0) == 0, used
     assert used.get("convT2x2_wgrad", 0) == 4 and used.get("conv3x3_winograd4", 0) >= 1, used
     assert abs(loss.item() - g["losses"][0]) <= 1e-3 * abs(g["losses"][0])
@@ -232,10 +233,11 @@ def test_benchmark_dispatch_b32_256_every_gradient_element(dev, monkeypatch):
     _, oloss, g64, r = _routed_oracle(x2, 1, 1981, 1.0, acts)
     assert abs(loss.item() - float(oloss)) <= 1e-5 * abs(float(oloss))
     # This batch has the SATURATED head of the reference's initialisation (|V| up to 47: a fifth of the pixels at S = 0 / 1 to fp32
-    # precision), which amplifies every rounding difference of the layers below: the fp32-MFMA Winograd dispatch of round 2 measured
-    # 1.0e-4 here, the split-bf16 kernels (operands carried to 16 bits: 8e-7 rms per layer against 3e-7 .. 9e-7 for F(4x4)) measure
-    # 2.8e-4; the unsaturated cases above hold 2e-4 with either.  Bound: 4e-4 (ONET_SPLIT=0 restores the fp32-MFMA kernels).
-    _check(m, g64, r, "B=32 256x256 benchmark dispatch", tol=4e-4 if ops.SPLIT_AUTO else None)
+    # precision), which amplifies every rounding difference of the FORWARD pass: the fp32-MFMA Winograd dispatch of round 2 measured
+    # 1.0e-4 here; the split kernels with bf16 parts in the forward convolution (16-bit operands) 3.3e-4 -- all of it from the forward
+    # kernel, the split input / weight gradients and ConvTranspose2d GEMMs add nothing (ONET_SPLIT_DGRAD=0 etc.: 3.26e-4) -- and with
+    # fp16 parts in the forward convolution (22-bit operands, the default) 1.0e-4 again.  The bound is the common 2e-4.
+    _check(m, g64, r, "B=32 256x256 benchmark dispatch", tol=None if ops.SPLIT_F16 else 4e-4)
 
 
 @pytest.mark.parametrize("mode", ["noshare", "two-pass", "two-pass-winograd4"])
