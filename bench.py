@@ -326,9 +326,9 @@ def main(args):
                 "conv_wino_wgrad_kernel": "Winograd F(2x2,3x3) weight gradient on fp32 MFMA, deterministic split-K",
                 "conv_wino4_wgrad_kernel": "Winograd F(3x3,4x4) weight gradient on fp32 MFMA, deterministic split-K",
                 "conv3x3_bf16_kernel": "direct implicit GEMM on v_mfma_f32_32x32x16_bf16 (bf16 operands, fp32 accumulate)",
-                "conv3x3_split_kernel": "fp32 convolution (fwd + dgrad) on the bf16 matrix cores by operand splitting: x = hi + mid, "
-                                        "w = hi + mid in bf16, 3 x v_mfma_f32_32x32x16_bf16 per term, fp32 accumulate; error <= the "
-                                        "fp32 Winograd F(4x4) kernel's",
+                "conv3x3_split_kernel": "fp32 convolution (fwd + dgrad) on the 16-bit matrix cores by operand splitting: x = hi + mid, "
+                                        "w = hi + mid (forward: fp16 parts, input gradient: bf16 parts), 3 x v_mfma_f32_32x32x16_{f16,bf16} "
+                                        "per term, fp32 accumulate; error <= the fp32 Winograd F(4x4) kernel's (forward: the direct kernel's)",
                 "conv3x3_split_wgrad_kernel": "fp32 weight gradient on the bf16 matrix cores by operand splitting, deterministic split-K",
                 "conv3x3_wgrad_bf16_kernel": "split-K weight gradient on v_mfma_f32_32x32x16_bf16",
                 "conv_fwd_kernel": "direct implicit GEMM on fp32 MFMA (stem, tiny maps)",
@@ -414,11 +414,14 @@ def main(args):
                "dtype": "bf16" if bf16 else "f32",
                "precision": ("bf16 MFMA operands (3x3 conv fwd/dgrad/wgrad, ConvTranspose2d GEMMs), f32 accumulation, f32 conv outputs, "
                              "BatchNorm, loss, master weights and optimizer") if bf16 else
-                            ("f32 tensors and f32-level results throughout; the 3x3 convolutions on maps >= 32 px wide and the ConvTranspose2d GEMMs run on the bf16 matrix "
-                             "pipe by operand splitting (x = hi + mid, w = hi + mid in bf16, 3 MFMAs per term, f32 accumulate: error vs fp64 "
-                             "1e-6 rms / 5e-6 max of the output scale, at or below the fp32 Winograd F(4x4) kernel's 3e-7..9e-7 / 7e-6..2e-5; "
-                             "every gradient element within 2e-4 of the fp64 oracle, tests/test_gpu_gradients.py); ONET_SPLIT=0 keeps the "
-                             "fp32-MFMA Winograd kernels") if (conv in ("auto", "split") and ops.split_enabled()) else "f32 throughout (fp32 MFMA)",
+                            ("f32 tensors and f32-level results throughout; the 3x3 convolutions on maps >= 32 px wide and the ConvTranspose2d GEMMs run on "
+                             "the 16-bit matrix pipe by operand splitting (each operand = hi + mid, 3 MFMAs per term, f32 accumulate): forward "
+                             "convolutions on fp16 parts (22-bit operands; error vs fp64 5e-8..1.5e-7 rms / <= 2e-6 max of the output scale, "
+                             "the fp32 direct kernel's level), input / weight gradients and the ConvTranspose2d GEMMs on bf16 parts (16-bit "
+                             "operands: 1e-6 rms / 5e-6 max, at or below the fp32 Winograd F(4x4) kernel's 3e-7..9e-7 / 7e-6..2e-5); every "
+                             "gradient element within 2e-4 of the fp64 oracle under the run's own decisions, incl. this B=32 dispatch "
+                             "(tests/test_gpu_gradients.py: 1.0e-4, as with the fp32-MFMA kernels); ONET_SPLIT=0 keeps the fp32-MFMA Winograd "
+                             "kernels (timed in f32_mfma_only)") if (conv in ("auto", "split") and ops.split_enabled()) else "f32 throughout (fp32 MFMA)",
                "data": "synthetic",
                "config": {"workload": "%s: batch=%d/GPU %dx%dx%d synthetic K-clutter, %s, twin U-Net "
                                       "fwd+JSD loss+bwd+Adam" % (cfg_name, args.batch, args.chans,
