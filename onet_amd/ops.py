@@ -520,6 +520,7 @@ def conv3x3_auto(x, pk, direction, out=None, x16=None):
 
 FUSE_BN_STATS = _os.environ.get("ONET_FUSE_BN_STATS", "1") != "0"
 BN_ON_LOAD = _os.environ.get("ONET_BN_ON_LOAD", "1") != "0"        # 0: every BatchNorm + ReLU output is materialised
+BN_ON_LOAD_MAX_COUT = int(_os.environ.get("ONET_BN_ON_LOAD_MAX_COUT", "128"))
 CONVT_SPLIT_MIN_BLOCKS = int(_os.environ["ONET_CONVT_SPLIT_MIN_BLOCKS"]) if "ONET_CONVT_SPLIT_MIN_BLOCKS" in _os.environ else None
 CONVT_SPLIT = _os.environ.get("ONET_CONVT_SPLIT", "1") != "0"     # 0: the ConvTranspose2d GEMMs stay on the fp32 MFMA pipe
 SPLIT_F16 = _os.environ.get("ONET_SPLIT_F16", "1") != "0"         # 0: the forward split kernel takes bf16 parts like the gradients
@@ -803,6 +804,10 @@ def norm_on_load_ok(B, Cmid, Cout, H, W, groups):
     if not (BN_ON_LOAD and _setting("bn_on_load", True)) or SYNC_BN or conv_algo() not in ("auto", "split") or groups not in (1, 2) or B % groups:
         return False
     if conv3x3_algo(B, Cmid, Cout, H, W) != "split" or W < SPLIT_WGRAD_MINW:
+        return False
+    # every 64-channel output tile of the forward kernel normalises the input tile again: the extra staging work grows with
+    # Cout / 64 while the saved pass does not -- measured worth it up to two output tiles (the 256- and 128-pixel levels)
+    if Cout > BN_ON_LOAD_MAX_COUT:
         return False
     if not _lib.load().onet_conv3x3_split_wgrad_ok(B, Cmid, Cout, H, W) or max(Cmid, Cout) * H * W * 4 >= 2 ** 31:
         return False
