@@ -794,9 +794,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
             const unsigned* ab = a_ptr + buf * 2 * SR_DZ_PART;
             bf16x8 ah, am;
             constexpr int CAT = COT == 64 ? SW_CAT64 : SW_CAT128;
+            // Segments run LAST TO FIRST: a lane's 8-pixel fragment is one aligned ds_read_b128 (4 dwords); the fifth dword its
+            // shifted copies need is the first dword of the NEXT 8-pixel group -- for the kh = 0 half that of its kh = 1 partner in
+            // the same read, for the kh = 1 half that of the kh = 0 lane of the segment read one group earlier: both arrive by
+            // v_permlane32_swap instead of a ds_read_b32, which on a row stride that is a multiple of 4 dwords is a 4-way bank
+            // conflict (20 l mod 32 repeats every 8 lanes; SQ_LDS_BANK_CONFLICT was 63 % of the kernel's LDS cycles, the LDS 70 %
+            // busy).  Only where the next group is another image's or the strip's halo does the dword still come from LDS.
+            unsigned lo_prev[3][2] = {};
 #pragma unroll
             for (int gk = 0; gk < 3 * NSEG; ++gk) {
-                const int sg = gk / 3, ky = gk % 3;
+                const int sg = NSEG - 1 - gk / 3, ky = gk % 3;
+                const bool from_prev = (sg + 1 < NSEG) && (G == 1 || (G == 2 && (sg & 1) == 0));
                 if (gk == CAT && more) {
                     commit_dz(buf ^ 1);
                     commit_x((y + 2) & 3);
@@ -824,7 +832,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
 #pragma unroll
                 for (int pt = 0; pt < 2; ++pt) {
                     const u32x4s q = *reinterpret_cast<const u32x4s*>(br + pt * SR_X_PART);
-                    const unsigned d4 = br[pt * SR_X_PART + 4];
+                    unsigned d4;
+                    if (G == 4) {
+                        d4 = br[pt * SR_X_PART + 4];
+                    } else {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(q[0], q[0], false, false);   // [0]: the kh = 0 value in
+                        const unsigned nxt = from_prev ? lo_prev[ky][pt] : br[pt * SR_X_PART + 4];       // both halves, [1]: kh = 1's
+                        d4 = kh ? nxt : sw[1];
+                        lo_prev[ky][pt] = sw[0];
+                    }
                     sh[pt][0] = q;
                     sh[pt][1] = u32x4s{__builtin_amdgcn_alignbit(q[1], q[0], 16), __builtin_amdgcn_alignbit(q[2], q[1], 16),
                                        __builtin_amdgcn_alignbit(q[3], q[2], 16), __builtin_amdgcn_alignbit(d4, q[3], 16)};

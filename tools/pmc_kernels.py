@@ -28,6 +28,11 @@ for ci, co, H in shapes:
         rep(lambda: ops.conv3x3_winograd4_wgrad(x, dz, (co, ci, 3, 3)))
     if "winow" in which:
         rep(lambda: ops.conv3x3_winograd_wgrad(x, dz, (co, ci, 3, 3)))
+    if "split" in which:                    # the round-3 default kernels: forward (fp16 parts), input gradient, weight gradient
+        sf, sd = ops.pack3x3_split(w)
+        rep(lambda: ops.conv3x3_split(x, sf, co))
+        rep(lambda: ops.conv3x3_split(dz, sd, ci))
+        rep(lambda: ops.conv3x3_split_wgrad(x, dz, (co, ci, 3, 3)))
     if "bf16" in which:                     # bf16 STORAGE variants (operands read as bf16 copies)
         x16, dz16 = x.to(torch.bfloat16), dz.to(torch.bfloat16)
         bf, bd = ops.pack3x3_bf16(w)
