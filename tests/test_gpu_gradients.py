@@ -344,6 +344,8 @@ def test_bf16_path_every_gradient_element_vs_routed_rounded_oracle(dev, tag, mon
     assert abs(loss.item() - float(oloss)) <= 1e-5 * abs(float(oloss))
     assert float((Vt.detach().cpu().double() - oVt.detach()).abs().max()) <= 1e-4 * float(oVt.detach().abs().max())
     _check(m, g64, r, f"bf16 path {tag}, roundings replayed", tol=BF16_GRAD_TOL)
+    if tag != "b8_c1_128":
+        return                                       # (the two extra fp64 evaluations below cost a minute at 256 x 256)
     # for the record (and so that the replay is not vacuous): the same evaluation with FREE rounding, and without any rounding
     with orc.operand_rounding(_bf16_rule):
         (_, fVt, _, _, _), _, gfree, _ = _routed_oracle(X, C, 1981, gain, acts)
