@@ -744,14 +744,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_bf16_row_kernel(BwArgs a
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const unsigned* ab = a_ptr + buf * 64 * BR_SDZ;
+                // segments last to first: the fifth dword of a lane's shifted fragments is the first dword of the next 8-pixel
+                // group -- the kh = 1 partner's of the same read for the kh = 0 half, the kh = 0 lane's of the segment read one
+                // step earlier for the kh = 1 half: v_permlane32_swap instead of a ds_read_b32 that is a 4-way bank conflict on
+                // a row stride of 4 x odd dwords (conv_split.hip's weight gradient: LDS cycles / 5); only the strip's last
+                // dword still comes from LDS
+                unsigned lo_prev[3] = {0, 0, 0};
 #pragma unroll
-                for (int sg = 0; sg < 4; ++sg) {
+                for (int sgi = 0; sgi < 4; ++sgi) {
+                    const int sg = 3 - sgi;
                     const bf16x8 av = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4b*>(ab + sg * 8));
 #pragma unroll
                     for (int ky = 0; ky < 3; ++ky) {
                         const unsigned* br = b_ptr + ((y - 1 + ky) & 3) * BR_SLOT + sg * 8;
                         const u32x4b q = *reinterpret_cast<const u32x4b*>(br);
-                        const unsigned d4 = br[4];
+                        const auto sw = __builtin_amdgcn_permlane32_swap(q[0], q[0], false, false);
+                        const unsigned nxt = sg == 3 ? br[4] : lo_prev[ky];
+                        const unsigned d4 = kh ? nxt : sw[1];
+                        lo_prev[ky] = sw[0];
                         const u32x4b s1 = {__builtin_amdgcn_alignbit(q[1], q[0], 16), __builtin_amdgcn_alignbit(q[2], q[1], 16),
                                            __builtin_amdgcn_alignbit(q[3], q[2], 16), __builtin_amdgcn_alignbit(d4, q[3], 16)};
                         const u32x4b s2 = {q[1], q[2], q[3], d4};
