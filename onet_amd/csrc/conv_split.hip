@@ -155,8 +155,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
     u32x4s* lds = reinterpret_cast<u32x4s*>(smem_s);                   // [2 buffers][weights hi|mid | input hi|mid]
 
-    // tiles of this block: every XCD (blockIdx % 8) owns a contiguous range of the tile list (neighbouring tiles share halo
-    // rows and the weight slice in that XCD's L2); its blocks stride through the range
+    // tiles of this block: every XCD (blockIdx % 8) owns a contiguous range of the tile list; its blocks stride through the range.
+    // Tile list order: OUTPUT-CHANNEL tile fastest, then x, y, image -- the Cout / 64 blocks that need the same input tile run on
+    // one XCD at the same time and share it in that L2 (with the channel tile slowest every one of the Cout / 64 passes over the
+    // batch streamed the whole input from HBM again: 1.8 x the compulsory bytes per launch on average); the weight slices of
+    // all channel tiles (<= 9 MB) then live in L2 / MALL instead of one slice at a time
     const int ntiles = a.tilesX * a.tilesY * a.B * a.coTiles;
     int t_first, t_end, t_stride;
     {
@@ -205,11 +208,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
     auto setup_stage = [&]() __attribute__((always_inline)) {
         const bool live = st_tile < t_end;
         int v = live ? st_tile : t_first;
+        const int co0 = (v % a.coTiles) * CO_T;      // output-channel tile fastest: see the tile order note at the top of the kernel
+        v /= a.coTiles;
         const int tx = v % a.tilesX;
         v /= a.tilesX;
         const int ty = v % a.tilesY;
-        v /= a.tilesY;
-        const int b = v % a.B, co0 = (v / a.B) * CO_T;
+        const int b = v / a.tilesY;
         const int y0 = ty * ROWS, x0 = tx * TW;
         st_b = b;
         xr = s_rsrc(a.x + (int64_t)b * a.x_bs, (int64_t)a.Cin * HW * 4);
@@ -446,11 +450,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
                     for (int r = 0; r < 16; ++r) acc[m][n][r] *= (1.f / F16_WSCALE);
         }
         int v = tile;
+        const int co0 = (v % a.coTiles) * CO_T;      // output-channel tile fastest: see the tile order note at the top of the kernel
+        v /= a.coTiles;
         const int tx = v % a.tilesX;
         v /= a.tilesX;
         const int ty = v % a.tilesY;
-        v /= a.tilesY;
-        const int b = v % a.B, co0 = (v / a.B) * CO_T;
+        const int b = v / a.tilesY;
         const int y0 = ty * ROWS, x0 = tx * TW;
         if constexpr (ST) {
             float* sc = reinterpret_cast<float*>(lds + 2 * BUF);       // [8 waves][64 channels][mean, M2]
