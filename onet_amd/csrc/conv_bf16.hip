@@ -170,11 +170,14 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
     auto setup_stage = [&]() __attribute__((always_inline)) {
         const bool live = st_tile < t_end;
         int v = live ? st_tile : t_first;
+        // output-channel tile fastest in the tile list (as conv_split.hip): the blocks that need the same input tile run on one XCD
+        // at the same time and share it in that L2 instead of every channel-tile pass streaming the input from HBM again
+        const int co0 = (v % a.coTiles) * CO_T;
+        v /= a.coTiles;
         const int tx = v % a.tilesX;
         v /= a.tilesX;
         const int ty = v % a.tilesY;
-        v /= a.tilesY;
-        const int b = v % a.B, co0 = (v / a.B) * CO_T;
+        const int b = v / a.tilesY;
         const int y0 = ty * ROWS, x0 = tx * TW;
         xr = b_rsrc(static_cast<const char*>(a.x) + (int64_t)b * a.x_bs * XE, (int64_t)a.Cin * HW * XE);
 #pragma unroll
@@ -319,11 +322,12 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_bf16_kernel(BfArgs a) {
         }
 
         int v = tile;
+        const int co0 = (v % a.coTiles) * CO_T;
+        v /= a.coTiles;
         const int tx = v % a.tilesX;
         v /= a.tilesX;
         const int ty = v % a.tilesY;
-        v /= a.tilesY;
-        const int b = v % a.B, co0 = (v / a.B) * CO_T;
+        const int b = v / a.tilesY;
         const int y0 = ty * ROWS, x0 = tx * TW;
         if constexpr (ST) {
             float* sc = reinterpret_cast<float*>(lds + 2 * BUF);       // [4 waves][64 channels][mean, M2]
