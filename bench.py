@@ -129,6 +129,39 @@ def cpu_baseline(X_cpu, seconds_budget):
                          X_cpu.shape[2], X_cpu.shape[3], "/".join(str(nsteps[k]) for k in by_threads))}
 
 
+def comm_curve(onet, opt, X, train_step, barrier, dev, nsteps, overlap):
+    """SURVEY 8e's with / without-overlap curve, measured behind the timed region on the same replicas: the same step with
+    (a) ONE all-reduce of the flat gradient after backward, (b) the bucketed all-reduces overlapped with backward, (c) NO
+    all-reduce at all (compute only; the replicas drift apart, which is why this runs last).  Max over ranks of each;
+    allreduce_exposed_ms = the headline's ms/step - (c).  The mode the headline ran is not timed twice."""
+    import torch.distributed as dist
+
+    def timed():
+        for _ in range(2):
+            train_step(onet, opt, X)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            train_step(onet, opt, X)
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return round(float(t.item()) / nsteps * 1e3, 3)
+
+    out = {"steps": nsteps}
+    if overlap:
+        opt.disable_overlap()
+        out["no_overlap_ms"] = timed()
+    else:
+        opt.enable_overlap()
+        out["overlap_ms"] = timed()
+        opt.disable_overlap()
+    opt.skip_allreduce = True
+    out["no_allreduce_ms"] = timed()
+    opt.skip_allreduce = False
+    return out
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -145,10 +178,26 @@ def _relay_child(cmd, env=None):
     return proc.returncode, out or ""
 
 
+def _preflight(n_gpus, local=None):
+    """A clear message BEFORE any rank is started / any collective is entered when the node has fewer GPUs than --gpus asks for.
+    `torch.cuda.device_count()` enumerates through the driver without initialising HIP in this process (so the launcher parent
+    may call it).  ONET_FORCE_LOCAL_RANK (the one-GPU rehearsal: N ranks sharing cuda:0 over gloo) waives the check."""
+    if "ONET_FORCE_LOCAL_RANK" in os.environ:
+        return
+    import torch as _t
+    have = _t.cuda.device_count()
+    if have < n_gpus or (local is not None and local >= have):
+        sys.stderr.write("[bench] --gpus %d, but this node exposes %d GPU(s) to the process (torch.cuda.device_count(); check "
+                         "HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES): nothing was launched\n" % (n_gpus, have))
+        sys.stderr.flush()
+        raise SystemExit(2)
+
+
 def _self_launch(args, argv):
     """`python bench.py --gpus N` (N > 1) outside a launcher: THIS process (which has not imported torch.cuda / onet_amd and
     makes no GPU call) starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`
     as a child, relays rank 0's JSON line and exits with the child's code.  No exec, no retry."""
+    _preflight(args.gpus)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
@@ -223,6 +272,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-overlap", action="store_true",
                     help="one gradient all-reduce after backward instead of bucketed all-reduces overlapped with it")
     ap.add_argument("--bucket-mb", type=float, default=32.0)
+    ap.add_argument("--host-data", action="store_true", help="synthesise the batch with the NumPy generator on the host")
+    ap.add_argument("--no-comm-curve", action="store_true",
+                    help="N > 1: skip the two extra loops (single all-reduce after backward; no all-reduce) behind the timed region")
     return ap.parse_args(argv)
 
 
@@ -237,9 +289,10 @@ def main(args):
     conv = args.conv or ops.CONV_ALGO
     bf16 = conv == "bf16"
 
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%s" % (args.gpus, os.environ.get("WORLD_SIZE", "1")))
+    _preflight(args.gpus, int(os.environ.get("LOCAL_RANK", "0")))
     rank, world, local = init_distributed("nccl")
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -258,16 +311,24 @@ def main(args):
         opt.enable_overlap(args.bucket_mb)
     onet.train()
 
-    X_cpu = torch.from_numpy(odata.make_clutter_batch(args.batch, args.size, args.size, seed=1981 + rank,
-                                                      channels=args.chans))
-    X = X_cpu.to(dev)                # inputs resident in HBM before the timed region
+    # the rank's shard of the synthetic batch, made ON its GPU (csrc/clutter.hip: frames depend on (seed, frame index) only, so
+    # seed + rank gives every rank its own frames without N hosts' worth of SciPy gammaincinv before the first barrier); shapes the
+    # GPU generator does not cover (3-channel 512 x 512 tiles) keep the NumPy statement of the same recipe
+    if args.chans == 1 and max(args.size, args.size) <= odata.FRAME and not args.host_data:
+        X = odata.make_clutter_batch_gpu(args.batch, args.size, args.size, seed=1981 + rank, device=dev)
+        data_src = "synthetic K-clutter generated on the GPU (onet_clutter_generate, seed 1981 + rank)"
+    else:
+        X = torch.from_numpy(odata.make_clutter_batch(args.batch, args.size, args.size, seed=1981 + rank,
+                                                      channels=args.chans)).to(dev)
+        data_src = "synthetic K-clutter generated on the host (NumPy statement of the same recipe, seed 1981 + rank)"
+    X = X.contiguous()               # inputs resident in HBM before the timed region
 
     def barrier():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    loss = None
+    loss = X_cpu = None
     for _ in range(args.warmup):
         loss = train_step(onet, opt, X)      # (held like in the timed loop: the caching allocator sees the same liveness pattern)
     barrier()
@@ -300,10 +361,20 @@ def main(args):
                          "warmup": 3, "kernels": "fp32 MFMA only: Winograd F(4x4,3x3) / F(2x2,3x3) / direct (ONET_SPLIT=0)"}
         del loss2
         onet.settings = keep
+    per_rank_ms, comm = None, None
     if distributed:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        mine = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_ms = [round(float(t.item()) / args.steps * 1e3, 3) for t in every]
+        t = mine.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        if not args.torch_adam and not args.no_comm_curve:
+            comm = comm_curve(onet, opt, X, train_step, barrier, dev, max(3, args.steps // 2), overlap)
+            comm["overlap_ms" if overlap else "no_overlap_ms"] = round(elapsed / args.steps * 1e3, 3)
+            if "no_allreduce_ms" in comm:
+                comm["allreduce_exposed_ms"] = round(comm["overlap_ms" if overlap else "no_overlap_ms"] - comm["no_allreduce_ms"], 3)
     loss_val = float(loss.item())
 
     if rank == 0:
@@ -423,6 +494,7 @@ def main(args):
                              "(tests/test_gpu_gradients.py: 1.0e-4, as with the fp32-MFMA kernels); ONET_SPLIT=0 keeps the fp32-MFMA Winograd "
                              "kernels (timed in f32_mfma_only)") if (conv in ("auto", "split") and ops.split_enabled()) else "f32 throughout (fp32 MFMA)",
                "data": "synthetic",
+               "data_source": data_src,
                "config": {"workload": "%s: batch=%d/GPU %dx%dx%d synthetic K-clutter, %s, twin U-Net "
                                       "fwd+JSD loss+bwd+Adam" % (cfg_name, args.batch, args.chans,
                                                                  args.size, args.size, "bf16 MFMA conv path" if bf16 else "fp32"),
@@ -430,18 +502,34 @@ def main(args):
                           "optimizer": "torch.optim.Adam" if args.torch_adam else "fused flat Adam (HIP)",
                           "grad_allreduce": ("none (1 process)" if not distributed else
                                              "%g MB buckets overlapped with backward" % args.bucket_mb if overlap
-                                             else "single all-reduce after backward")},
+                                             else "single all-reduce after backward"),
+                          # where the timed step differs from the reference loop TS:209-219, stated in the line itself:
+                          "per_step_host_sync": False,      # TS:219's loss.item() every step is NOT in the timed loop (the
+                                                            # loss's NaN verdict, OV:234, travels behind an event instead)
+                          "inputs_resident": True},         # TS:211's per-step X.to(device) is not in the timed loop
+
                "loss": loss_val, "hbm_peak_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
                "hbm_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 2),
                "alloc_retries": int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0)),
                "device_allocs_in_timed_steps": int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0)) - dev_allocs0,
                "device_allocs_per_timed_step": [b - a for a, b in zip([dev_allocs0] + allocs_per_step, allocs_per_step)],
                "roofline": roofline}
+        if distributed:
+            out["rccl_world"] = world if dist.get_backend() == "nccl" else 0
+            out["dist_backend"] = dist.get_backend()
+            try:
+                out["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:      # noqa: BLE001
+                out["nccl_version"] = None
+            out["per_rank_ms"] = per_rank_ms
+            if comm is not None:
+                out["comm"] = comm
         if f32_mfma_only is not None:
             out["f32_mfma_only"] = f32_mfma_only
         headline = world == 1 and not bf16 and args.size == 256 and args.chans == 1 and args.batch == 32 and not args.torch_adam
         if headline and not args.no_secondary:
             # BASELINE configs[2] in the same driver-run line: release this process's HBM first (the child peaks at ~150 GB)
+            X_cpu = X.cpu()
             del loss, opt, onet, X, prof, prof_all
             import gc
             gc.collect()
@@ -450,6 +538,8 @@ def main(args):
             torch.cuda.empty_cache()
             out["secondary"] = {"configs[2]": secondary_config2()}
         if world == 1 and not args.no_cpu_baseline:
+            if X_cpu is None:
+                X_cpu = X.cpu()
             out["cpu_baseline"] = cpu_baseline(X_cpu, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if distributed:

@@ -81,9 +81,12 @@ class FlatAdam:
         self.pg = process_group
         self.world_size = world_size
         self._buckets = None          # set by enable_overlap()
+        self.skip_allreduce = False   # measurement only (bench.py's compute-only loop): the replicas drift apart
         # host-side group for the per-step NaN verdict (see _check_nan_all_ranks); created collectively, here
         self._flag_pg = None
-        if world_size > 1 and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # (also in an initialised group of ONE rank -- `torch.distributed.run --nproc-per-node 1` -- so that a one-GPU box runs
+        # the same code the 8-GPU node does: tests/test_gpu_dist.py::test_bench_one_rank_over_rccl)
+        if dist.is_available() and dist.is_initialized() and (world_size > 1 or dist.get_world_size() == 1):
             err = None
             try:
                 self._flag_pg = dist.new_group(backend="gloo")
@@ -124,6 +127,17 @@ class FlatAdam:
         self._hooks = [p.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_grad(i))
                        for i, p in enumerate(self.params)]
 
+    def disable_overlap(self):
+        """Back to ONE all-reduce of the flat buffer after backward (pending asynchronous buckets are waited for first)."""
+        if self._buckets is None:
+            return
+        for bk in self._buckets:
+            if bk["work"] is not None:
+                bk["work"].wait()
+        for h in self._hooks:
+            h.remove()
+        self._buckets = self._hooks = None
+
     def _launch_bucket(self, bk, async_op=True):
         view = self.gflat[bk["start"]:bk["end"]]
         bk["work"] = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op)
@@ -137,7 +151,7 @@ class FlatAdam:
             p.grad = view
         bk = self._buckets[self._bucket_of[i]]
         bk["pending"] -= 1
-        if bk["pending"] == 0 and not bk["launched"] and dist.is_available() and dist.is_initialized():
+        if bk["pending"] == 0 and not bk["launched"] and not self.skip_allreduce and dist.is_available() and dist.is_initialized():
             self._launch_bucket(bk)
 
     def _finish_overlap(self):
@@ -168,6 +182,11 @@ class FlatAdam:
                 bk.update(pending=len(bk["params"]), work=None, launched=False)
 
     def all_reduce_grads(self):
+        if self.skip_allreduce:
+            if self._buckets is not None:
+                for bk in self._buckets:
+                    bk.update(pending=len(bk["params"]), work=None, launched=False)
+            return
         if self.world_size > 1 or (dist.is_available() and dist.is_initialized()):
             if self._buckets is not None:
                 self._finish_overlap()

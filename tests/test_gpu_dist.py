@@ -64,6 +64,34 @@ def test_two_ranks_syncbn_equals_one_rank():
     assert "DIST_OK" in out.stdout, out.stdout[-1500:]
 
 
+@pytest.mark.timeout(600)
+def test_bench_one_rank_over_rccl():
+    """The RCCL code path before the 8-GPU node sees it: `torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` with the
+    DEFAULT backend (nccl = RCCL; no ONET_DIST_BACKEND / ONET_FORCE_LOCAL_RANK in the environment) -- init_process_group(nccl,
+    device_id=...), broadcast of the flat parameters and BatchNorm buffers, the bucketed asynchronous all-reduces issued from the
+    backward hooks on RCCL's stream, the device-tensor MIN all-reduce that settles the gloo side group, the all-gathered per-rank
+    times and the with / without-overlap loops behind the timed region."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("ONET_DIST_BACKEND", "ONET_FORCE_LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "4", "--size", "64",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--bucket-mb", "8"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["dist_backend"] == "nccl" and d["rccl_world"] == 1 and d["n_gpus"] == 1
+    assert "overlapped with backward" in d["config"]["grad_allreduce"]
+    assert len(d["per_rank_ms"]) == 1 and d["per_rank_ms"][0] > 0
+    assert {"overlap_ms", "no_overlap_ms", "no_allreduce_ms", "allreduce_exposed_ms"} <= set(d["comm"])
+    assert d["config"]["per_step_host_sync"] is False and d["config"]["inputs_resident"] is True
+    assert "generated on the GPU" in d["data_source"]
+    assert d["value"] > 0 and d["loss"] == d["loss"]
+
+
 def test_bench_exits_nonzero_on_a_failure_inside_main():
     """No in-process restart: any exception in a rank's main() (an RCCL error included) ends the process with code 1.
     Provoked here by a launcher environment that contradicts --gpus (RANK set, so bench.py does not launch ranks itself)."""

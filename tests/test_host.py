@@ -243,6 +243,7 @@ def test_bench_self_launch_relays_the_ranks_exit_code():
     and it must not have imported torch.cuda state or the HIP library itself to find that out."""
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["ONET_FORCE_LOCAL_RANK"] = "0"          # the one-GPU rehearsal switch waives the device-count preflight (tested below)
     if torch.cuda.is_available():
         pytest.skip("a GPU is present: tests/test_gpu_dist.py::test_bench_launches_its_own_ranks covers the success path")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
@@ -251,6 +252,18 @@ def test_bench_self_launch_relays_the_ranks_exit_code():
     assert out.returncode != 0
     assert "torch.distributed.run" in out.stderr and "--nproc-per-node 2" in out.stderr
     assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_preflight_refuses_more_gpus_than_the_node_has():
+    """`python bench.py --gpus 64` on a box with fewer GPUs: exit code 2 and a message naming both numbers, before any rank or
+    collective is started."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "ONET_FORCE_LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--no-cpu-baseline"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 2, (out.returncode, out.stderr[-1000:])
+    assert "--gpus 64" in out.stderr and "nothing was launched" in out.stderr
+    assert "torch.distributed.run" not in out.stderr
 
 
 def test_bench_parent_is_gpu_free_before_the_launch_decision():
