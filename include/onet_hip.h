@@ -182,6 +182,17 @@ int onet_conv3x3_split_pack_weights(const float* w, void* wq_fwd, void* wq_dgrad
 int onet_conv3x3_split_fwd(const float* x, int64_t x_bs, const void* wq, int wq_f16, float* z, int64_t z_bs, int B, int Cin, int Cout,
                            int H, int W, void* stream);
 int onet_conv3x3_split_nparts(int B, int H, int W);
+/* Round 4 -- PRE-SPLIT operands.  The activation of a 3x3 convolution (OV:47,51) arrives already split, in the slot layout the
+ * MFMA tile wants:  xs [B][C/8][H][part 2][W][8] 16-bit (part 0 = hi, 1 = mid; fp16 when f16 != 0, else bf16): 4 bytes per element,
+ * the fp32 tensor's footprint; batch stride xs_bs in 4-byte units.  The producers write it (BatchNorm + ReLU apply / pooling, the
+ * BatchNorm backward apply, the ConvTranspose2d epilogue); onet_split_pack_act converts an fp32 NCHW tensor (times `scale`, a power
+ * of two) for tests and for producers without a fused variant.  _fwd_pre: z = out_scale * conv(xs, wq) with the weight pack of
+ * onet_conv3x3_split_pack_weights (same arithmetic as onet_conv3x3_split_fwd: bit-identical results for the same parts); staging
+ * is an LDS-DMA copy.  part != NULL: BatchNorm statistics records as onet_conv3x3_split_fwd_stats. */
+int onet_split_pack_act(const float* x, int64_t x_bs, void* xs, int64_t xs_bs, int B, int C, int H, int W, int f16, float scale,
+                        void* stream);
+int onet_conv3x3_split_fwd_pre(const void* xs, int64_t xs_bs, const void* wq, int wq_f16, float out_scale, float* z, int64_t z_bs,
+                               float* part, int B, int Cin, int Cout, int H, int W, void* stream);
 int onet_conv3x3_split_fwd_stats(const float* x, int64_t x_bs, const void* wq, int wq_f16, float* z, int64_t z_bs, float* part, int B,
                                  int Cin, int Cout, int H, int W, void* stream);
 /* Weight gradient of the same convolution with both operands (x, dz: fp32 NCHW) split the same way, three MFMAs per term;

@@ -523,6 +523,352 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------ pre-split operands (round 4)
+// The activation arrives ALREADY split, in the slot layout the tile wants:
+//     xs [B][C/8][H][part 2][W][8] 16-bit   (part 0 = hi, 1 = mid; fp16 or bf16; 4 bytes per element -- the fp32 tensor's footprint)
+// written by the producers (bn.hip: BatchNorm + ReLU apply / pooling, BatchNorm backward apply; convt_gemm.hip epilogue).  The
+// MFMA kernel's staging is then a COPY: every 16-byte slot of the halo tile and of the weight slice goes HBM -> LDS by LDS-DMA
+// (buffer_load_dwordx4 ... lds: no staging registers, no conversion VALU, no ds_write -- the round-3 kernel spent 19-26 % of its
+// time there, with 4-way bank conflicts on its ds_write_b128), one chunk ahead of the MFMAs into the other chunk buffer.
+typedef int i32x4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4s sp_rsrc4(const void* base, int64_t bytes) {
+    const uint64_t p = reinterpret_cast<uint64_t>(base);
+    i32x4s r;
+    r.x = (int)(p & 0xffffffffu);
+    r.y = (int)((p >> 32) & 0xffffu);
+    r.z = bytes > 0x7fffffffll ? 0x7fffffff : (int)bytes;
+    r.w = 0x00020000;
+    return r;
+}
+// LDS-DMA of 64 x 16 bytes: lane l's 16 bytes at (rsrc base + voff + soff) land at LDS byte address lds_base + 16 l; a lane
+// whose address is out of range (voff = OOB_S) writes zeros.  Inline asm: the compiler must not see a load (it would order every
+// later ds_read behind a vmcnt(0)); m0 is restored because the compiler does not know it was touched.
+__device__ __forceinline__ void sp_dma16(i32x4s rsrc, unsigned lds_base, unsigned voff, unsigned soff) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(lds_base), "s"(soff)
+                 : "memory");
+}
+
+// fp32 NCHW -> the slot layout above (tests, tools, and producers that have no fused variant yet)
+__global__ void split_pack_act_kernel(const float* __restrict__ x, int64_t x_bs, unsigned* __restrict__ xs, int64_t xs_bs, int B, int C8,
+                                      int H, int W, int f16, float scale) {
+    const int64_t n = (int64_t)B * C8 * H * W;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % W);
+        int64_t r = i / W;
+        const int y = (int)(r % H);
+        r /= H;
+        const int c8 = (int)(r % C8), b = (int)(r / C8);
+        const float* src = x + (int64_t)b * x_bs + ((int64_t)c8 * 8 * H + y) * W + xx;
+        u32x4s hi, mid;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float va = src[(int64_t)(2 * c) * H * W] * scale, vb = src[(int64_t)(2 * c + 1) * H * W] * scale;
+            unsigned h, m;
+            if (f16) split2h(va, vb, h, m);
+            else split2(va, vb, h, m);
+            hi[c] = h;
+            mid[c] = m;
+        }
+        u32x4s* dst = reinterpret_cast<u32x4s*>(xs + (int64_t)b * xs_bs) + (((int64_t)c8 * H + y) * 2) * W + xx;
+        dst[0] = hi;
+        dst[W] = mid;
+    }
+}
+
+struct SpPreArgs {
+    const void* xs;       // pre-split activation, slot layout
+    int64_t xs_bs;        // batch stride in 4-byte units (= C * H * W for a dense tensor)
+    const __bf16* wq;     // [Cin/16][2][9][2][Cout][8]
+    float* z;
+    int64_t z_bs;
+    int B, Cin, Cout, H, W, tilesX, tilesY, coTiles;
+    float* stats;         // ST: BatchNorm partials (as conv3x3_split_kernel)
+    float out_scale;      // applied to the accumulators (undoes the power-of-two scales of the two operands)
+};
+
+#ifndef SP_PRE_LAST_TAP
+#define SP_PRE_LAST_TAP 4   // the next chunk's DMA pieces go out during taps 0 .. SP_PRE_LAST_TAP
+#endif
+template <bool ST, bool F16>
+__global__ __launch_bounds__(512, 2) void conv3x3_split_pre_kernel(SpPreArgs a) {
+    using C = SpCfg;
+    constexpr int NT = C::NT, IN_COLS = C::IN_COLS, NWI = C::NWI, CO_T = C::CO_T, NPIXP = C::NPIXP, NB = C::NB;
+    constexpr int BUF = C::BUF_SLOTS, W_PART = C::W_PART, IN_PART = C::IN_PART, ROWS = C::ROWS, TW = C::TW;
+    constexpr int NII = (2 * IN_PART) / 512;                           // 5 input DMA rounds per wave and chunk (2560 slot positions)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
+    u32x4s* lds = reinterpret_cast<u32x4s*>(smem_s);                   // [2 buffers][weights hi|mid | input hi|mid]
+
+    const int ntiles = a.tilesX * a.tilesY * a.B * a.coTiles;          // tile list order: see conv3x3_split_kernel
+    int t_first, t_end, t_stride;
+    {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int q = ntiles >> 3, r = ntiles & 7;
+        const int start = xcd * q + min(xcd, r);
+        t_stride = (gridDim.x + 7 - xcd) >> 3;
+        t_first = start + j;
+        t_end = start + q + (xcd < r ? 1 : 0);
+    }
+    if (t_first >= t_end) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int HW = a.H * a.W;
+    const int nchunks = a.Cin >> 4;
+
+    const i32x4s wr = sp_rsrc4(a.wq, (int64_t)a.Cin * 2 * 9 * a.Cout * 2);
+    const unsigned in_step = (unsigned)(16 * HW * 4), w_step = (unsigned)(2 * 9 * 2 * a.Cout * 16);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_s;
+
+    // ---- staging: slot position i = (wn + 8 k) * 64 + lane of the chunk image.  Input k < NII: i = (part * 2 + half) * NPIXP + pix,
+    // pix = r * IN_COLS + c (pix >= 612: padding of the image, zeros).  Weights k < NWI: i = (part * 9 + tap) * 2 + half) * 64 + co.
+    unsigned in_off[NII], w_off[NWI];
+    i32x4s xr;
+    int st_tile = t_first, st_chunk = 0;
+    unsigned cin_bytes = 0, cw_bytes = 0;
+    auto setup_stage = [&]() __attribute__((always_inline)) {
+        const bool live = st_tile < t_end;
+        int v = live ? st_tile : t_first;
+        const int co0 = (v % a.coTiles) * CO_T;
+        v /= a.coTiles;
+        const int tx = v % a.tilesX;
+        v /= a.tilesX;
+        const int ty = v % a.tilesY;
+        const int b = v / a.tilesY;
+        const int y0 = ty * ROWS, x0 = tx * TW;
+        xr = sp_rsrc4(reinterpret_cast<const unsigned*>(a.xs) + (int64_t)b * a.xs_bs, (int64_t)a.Cin * HW * 4);
+#pragma unroll
+        for (int k = 0; k < NII; ++k) {
+            const int i = (wn + 8 * k) * 64 + lane;
+            const int ph = i / NPIXP, pix = i % NPIXP;                 // ph = part * 2 + half
+            const int r = pix / IN_COLS, c = pix % IN_COLS;
+            const int yy = y0 - 1 + r, xx = x0 - 1 + c;
+            const bool ok = live && pix < C::NPIX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+            in_off[k] = ok ? (unsigned)(((((ph & 1) * a.H + yy) * 2 + (ph >> 1)) * a.W + xx) * 16) : OOB_S;
+        }
+#pragma unroll
+        for (int k = 0; k < NWI; ++k) {
+            const int i = tid + 512 * k;
+            const int co = i & (CO_T - 1), pth = i >> 6;
+            const bool ok = live && (i < C::W_SLOTS) && (co0 + co < a.Cout);
+            w_off[k] = ok ? (unsigned)((pth * a.Cout + co0 + co) * 16) : OOB_S;
+        }
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
+        ++st_chunk;
+        cin_bytes += in_step;
+        cw_bytes += w_step;
+        if (st_chunk == nchunks) {
+            st_chunk = 0;
+            cin_bytes = cw_bytes = 0;
+            st_tile += t_stride;
+            setup_stage();
+        }
+    };
+    // piece k of the chunk the staging state points at, into chunk buffer `buf`
+    auto dma_in = [&](int buf, int k) __attribute__((always_inline)) {
+        sp_dma16(xr, lds0 + (unsigned)((buf * BUF + C::W_SLOTS + (wn + 8 * k) * 64) * 16), in_off[k], cin_bytes);
+    };
+    auto dma_w = [&](int buf, int k) __attribute__((always_inline)) {
+        if (k < NWI - 1 || wn < (C::W_SLOTS - 512 * (NWI - 1)) / 64)
+            sp_dma16(wr, lds0 + (unsigned)((buf * BUF + (wn + 8 * k) * 64) * 16), w_off[k], cw_bytes);
+    };
+
+    const u32x4s* const a_ptr = lds + kh * CO_T + l31;
+    const u32x4s* const b_ptr = lds + C::W_SLOTS + kh * NPIXP + (wn * NT) * IN_COLS + l31;
+
+    setup_stage();
+#pragma unroll
+    for (int k = 0; k < NII; ++k) dma_in(0, k);
+#pragma unroll
+    for (int k = 0; k < NWI; ++k) dma_w(0, k);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0;
+    for (int tile = t_first; tile < t_end; tile += t_stride) {
+        f32x16 acc[2][NT];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+        for (int c = 0; c < nchunks; ++c) {
+            const u32x4s* const ab = a_ptr + buf * BUF;
+            const u32x4s* const bb = b_ptr + buf * BUF;
+            u32x4s Aq[2][2][2], Bq[2][NB][2];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                Bq[0][j][0] = bb[j * IN_COLS];
+                Bq[0][j][1] = bb[j * IN_COLS + IN_PART];
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                Aq[0][m][0] = ab[m * 32];
+                Aq[0][m][1] = ab[m * 32 + W_PART];
+            }
+#pragma unroll
+            for (int idx = 0; idx < 9; ++idx) {
+                const int kx = idx / 3, ky = idx % 3;
+                if (idx < 8) {
+                    const int nt = ((idx + 1) % 3) * 3 + (idx + 1) / 3;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        Aq[(idx + 1) & 1][m][0] = ab[nt * 2 * CO_T + m * 32];
+                        Aq[(idx + 1) & 1][m][1] = ab[nt * 2 * CO_T + m * 32 + W_PART];
+                    }
+                }
+                if (kx < 2) {
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+                        if (j % 3 == ky) {
+                            Bq[(kx + 1) & 1][j][0] = bb[j * IN_COLS + kx + 1];
+                            Bq[(kx + 1) & 1][j][1] = bb[j * IN_COLS + kx + 1 + IN_PART];
+                        }
+                }
+                // the other chunk buffer was last read one chunk ago (barrier since): the next chunk's slots go in by DMA, a piece
+                // or two per tap during the first taps, so that they have the rest of the chunk's MFMAs to land
+                if (idx == 0) advance();
+                {
+                    constexpr int NPIECE = NII + NWI, PER = (NPIECE + SP_PRE_LAST_TAP) / (SP_PRE_LAST_TAP + 1);
+#pragma unroll
+                    for (int q = 0; q < PER; ++q) {
+                        const int pc = idx * PER + q;
+                        if (idx <= SP_PRE_LAST_TAP && pc < NPIECE) {
+                            if (pc & 1) { if (pc / 2 < NWI) dma_w(buf ^ 1, pc / 2); else dma_in(buf ^ 1, pc - NWI); }
+                            else { if (pc / 2 < NII) dma_in(buf ^ 1, pc / 2); else dma_w(buf ^ 1, pc - NII); }
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        if constexpr (F16) {
+                            const f16x8 ah = __builtin_bit_cast(f16x8, Aq[idx & 1][m][0]), am = __builtin_bit_cast(f16x8, Aq[idx & 1][m][1]);
+                            const f16x8 bh = __builtin_bit_cast(f16x8, Bq[kx & 1][n + ky][0]), bm = __builtin_bit_cast(f16x8, Bq[kx & 1][n + ky][1]);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, bh, acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bm, acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[m][n], 0, 0, 0);
+                        } else {
+                            const bf16x8 ah = __builtin_bit_cast(bf16x8, Aq[idx & 1][m][0]), am = __builtin_bit_cast(bf16x8, Aq[idx & 1][m][1]);
+                            const bf16x8 bh = __builtin_bit_cast(bf16x8, Bq[kx & 1][n + ky][0]), bm = __builtin_bit_cast(bf16x8, Bq[kx & 1][n + ky][1]);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[m][n], 0, 0, 0);
+                        }
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next chunk's slots have landed ...
+            __syncthreads();                                        // ... and every wave is done with this buffer
+            buf ^= 1;
+        }
+
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] *= a.out_scale;
+        int v = tile;
+        const int co0 = (v % a.coTiles) * CO_T;
+        v /= a.coTiles;
+        const int tx = v % a.tilesX;
+        v /= a.tilesX;
+        const int ty = v % a.tilesY;
+        const int b = v / a.tilesY;
+        const int y0 = ty * ROWS, x0 = tx * TW;
+        if constexpr (ST) {
+            float* sc = reinterpret_cast<float*>(lds + 2 * BUF);       // [8 waves][64 channels][mean, M2]
+            constexpr float npw = (float)(NT * 32), inv_npw = 1.f / npw;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int piv = __builtin_bit_cast(int, acc[m][0][r]);
+                    const float p0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(piv, 0));
+                    const float p1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(piv, 32));
+                    const float pv = kh ? p1 : p0;
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const float d = acc[m][n][r] - pv;
+                        s1 += d;
+                        s2 = fmaf(d, d, s2);
+                    }
+                    s1 = sp_half_sum(s1);
+                    s2 = sp_half_sum(s2);
+                    if (l31 == 31) {
+                        const int cl = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                        sc[(wn * 64 + cl) * 2] = fmaf(s1, inv_npw, pv);
+                        sc[(wn * 64 + cl) * 2 + 1] = fmaxf(fmaf(-s1 * inv_npw, s1, s2), 0.f);
+                    }
+                }
+            __syncthreads();
+            if (tid < 64 && co0 + tid < a.Cout) {
+                float mw[8], qw[8];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) {
+                    mw[w] = sc[(w * 64 + tid) * 2];
+                    qw[w] = sc[(w * 64 + tid) * 2 + 1];
+                }
+                const float mean = 0.125f * (((mw[0] + mw[1]) + (mw[2] + mw[3])) + ((mw[4] + mw[5]) + (mw[6] + mw[7])));
+                float m2 = ((qw[0] + qw[1]) + (qw[2] + qw[3])) + ((qw[4] + qw[5]) + (qw[6] + qw[7]));
+#pragma unroll
+                for (int w = 0; w < 8; ++w) m2 = fmaf(npw * (mw[w] - mean), mw[w] - mean, m2);
+                const int64_t nblk = (int64_t)a.B * a.tilesY * a.tilesX;
+                const int64_t blk = ((int64_t)b * a.tilesY + ty) * a.tilesX + tx;
+                float* sp = a.stats + ((int64_t)(co0 + tid) * nblk + blk) * 3;
+                sp[0] = 8.f * npw;
+                sp[1] = mean;
+                sp[2] = m2;
+            }
+            __syncthreads();
+        }
+        float* zb = a.z + (int64_t)b * a.z_bs;
+        const int xo = x0 + l31;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int yo = y0 + wn * NT + n;
+                if (yo < a.H && xo < a.W) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                        if (co < a.Cout) zb[(int64_t)co * HW + (int64_t)yo * a.W + xo] = acc[m][n][r];
+                    }
+                }
+            }
+    }
+}
+
+template <bool ST, bool F16>
+int launch_split_pre(SpPreArgs a, hipStream_t st) {
+    using C = SpCfg;
+    const int LDS_BYTES = C::LDS_BYTES + (ST ? C::NW * 64 * 2 * 4 : 0);
+    a.tilesX = cdiv(a.W, C::TW);
+    a.tilesY = cdiv(a.H, C::ROWS);
+    a.coTiles = cdiv(a.Cout, C::CO_T);
+    const int64_t tiles = (int64_t)a.B * a.tilesX * a.tilesY * a.coTiles;
+    ONET_REQUIRE(tiles > 0 && tiles < (1ll << 31), "conv3x3_split_pre: tile count %lld out of range", (long long)tiles);
+    auto kern = conv3x3_split_pre_kernel<ST, F16>;
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    }
+    const int64_t resident = (int64_t)device_cu_count();
+    const int64_t blocks = std::min<int64_t>((tiles + 7) / 8 * 8, std::max<int64_t>(8, resident / 8 * 8));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), LDS_BYTES, st, a);
+    return check_launch("conv3x3_split_pre_kernel");
+}
+
 int split_nparts(int B, int H, int W) {
     if (B <= 0 || W < 32 || (W % SpCfg::TW) || (H % SpCfg::ROWS)) return 0;
     const int64_t n = (int64_t)B * (H / SpCfg::ROWS) * (W / SpCfg::TW);
@@ -986,6 +1332,33 @@ int onet_conv3x3_split_fwd_norm(const float* z_prev, int64_t z_bs, const float* 
                                 float* z, int64_t zo_bs, float* part, int B, int Cin, int Cout, int H, int W, void* stream) {
     ONET_REQUIRE(save, "conv3x3_split_fwd_norm: null pointer");
     return split_fwd(z_prev, z_bs, wq, z, zo_bs, B, Cin, Cout, H, W, stream, part, wq_f16, save, n_groups);
+}
+
+int onet_split_pack_act(const float* x, int64_t x_bs, void* xs, int64_t xs_bs, int B, int C, int H, int W, int f16, float scale,
+                        void* stream) {
+    ONET_REQUIRE(x && xs, "split_pack_act: null pointer");
+    ONET_REQUIRE(B > 0 && C > 0 && (C % 8) == 0 && H > 0 && W > 0, "split_pack_act: C must be a multiple of 8");
+    ONET_REQUIRE((reinterpret_cast<uintptr_t>(xs) & 15) == 0 && (xs_bs & 3) == 0, "split_pack_act: 16-byte aligned slots required");
+    const int64_t n = (int64_t)B * (C / 8) * H * W;
+    const int blocks = (int)std::min<int64_t>((n + 255) / 256, 1 << 20);
+    hipLaunchKernelGGL(split_pack_act_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, x_bs, (unsigned*)xs, xs_bs, B, C / 8, H, W,
+                       f16, scale);
+    return check_launch("split_pack_act_kernel");
+}
+
+int onet_conv3x3_split_fwd_pre(const void* xs, int64_t xs_bs, const void* wq, int wq_f16, float out_scale, float* z, int64_t z_bs,
+                               float* part, int B, int Cin, int Cout, int H, int W, void* stream) {
+    ONET_REQUIRE(xs && wq && z, "conv3x3_split_fwd_pre: null pointer");
+    ONET_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 16, "conv3x3_split_fwd_pre: bad shape (maps wider than 16 pixels)");
+    ONET_REQUIRE((Cin % 16) == 0, "conv3x3_split_fwd_pre: Cin must be a multiple of 16");
+    ONET_REQUIRE((xs_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(xs) & 15) == 0, "conv3x3_split_fwd_pre: 16-byte aligned slots required");
+    ONET_REQUIRE(xs_bs >= (int64_t)Cin * H * W && z_bs >= (int64_t)Cout * H * W, "conv3x3_split_fwd_pre: batch stride too small");
+    ONET_REQUIRE((int64_t)(Cin + 32) * H * W * 4 < (1ll << 31) && (int64_t)(Cin + 32) * 2 * 9 * Cout * 2 < (1ll << 31),
+                 "conv3x3_split_fwd_pre: operand exceeds the 2 GiB buffer-resource range");
+    SpPreArgs a{xs, xs_bs, (const __bf16*)wq, z, z_bs, B, Cin, Cout, H, W, 0, 0, 0, part, out_scale};
+    if (part) ONET_REQUIRE(split_nparts(B, H, W) > 0, "conv3x3_split_fwd_pre: statistics need a map made of full 16 x 32 tiles");
+    if (wq_f16) return part ? launch_split_pre<true, true>(a, as_stream(stream)) : launch_split_pre<false, true>(a, as_stream(stream));
+    return part ? launch_split_pre<true, false>(a, as_stream(stream)) : launch_split_pre<false, false>(a, as_stream(stream));
 }
 
 int onet_conv3x3_split_nparts(int B, int H, int W) { return split_nparts(B, H, W); }

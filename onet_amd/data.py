@@ -196,6 +196,30 @@ def make_clutter_batch(B, H=256, W=256, seed=1981, snr_choices=(0, 1, 2), channe
     return X
 
 
+def make_blob_tiles(B, H=512, W=512, seed=4242, channels=3, n_blobs=2):
+    """Stand-in for BASELINE configs[4]'s ZY-3 cloud tiles, which are not in the image (SURVEY 8d "C5": uniform-[0,1] RGB tiles
+    with a synthetic bright-blob mask): per tile a dark textured background (0.35 * uniform noise per channel) plus `n_blobs`
+    bright Gaussian blobs (sigma 6 % .. 12 % of the tile side, peak 0.55 .. 0.75, the same shape in every channel with a
+    per-channel gain of 0.9 .. 1.0), clipped to [0, 1].  -> (X float32 [B, channels, H, W], mask float32 [B, H, W] = blob
+    intensity > 0.25, the reference's label dtype).  Depends on (seed, B, H, W, channels, n_blobs) only."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    X = np.empty((B, channels, H, W), dtype=np.float32)
+    M = np.empty((B, H, W), dtype=np.float32)
+    side = float(min(H, W))
+    for b in range(B):
+        blob = np.zeros((H, W), dtype=np.float64)
+        for _ in range(n_blobs):
+            cy, cx = rng.uniform(0.2, 0.8) * H, rng.uniform(0.2, 0.8) * W
+            sy, sx = rng.uniform(0.06, 0.12, size=2) * side
+            blob = np.maximum(blob, rng.uniform(0.55, 0.75) * np.exp(-0.5 * (((yy - cy) / sy) ** 2 + ((xx - cx) / sx) ** 2)))
+        gain = rng.uniform(0.9, 1.0, size=channels)
+        bg = 0.35 * rng.random((channels, H, W))
+        X[b] = np.clip(bg + gain[:, None, None] * blob[None], 0.0, 1.0).astype(np.float32)
+        M[b] = (blob > 0.25).astype(np.float32)
+    return X, M
+
+
 # ----------------------------------------------------------------------------- on the GPU (csrc/clutter.hip, SURVEY 8f-4)
 def _embed_kernel(kern, N):
     """The reference's colouring is a CIRCULAR convolution of white noise on the n-torus with k = ifft2(filter).  The GPU

@@ -787,6 +787,39 @@ def conv3x3_split(x, wq, Cout, out=None, norm=None):
     return out
 
 
+def split_pack_act(x, f16=True, scale=1.0, out=None):
+    """fp32 NCHW -> the pre-split slot layout of conv_split.hip: [B, C/8, H, 2 (hi | mid), W, 8] fp16 (or bf16) parts of
+    scale * x; 4 bytes per element, the fp32 tensor's footprint."""
+    require_gpu(x)
+    x, xbs = plane(x)
+    B, C, H, W = x.shape
+    if out is None:
+        out = torch.empty((B, C // 8, H, 2, W, 8), dtype=torch.float16 if f16 else BF, device=x.device)
+    _lib.call("onet_split_pack_act", _p(x), xbs, _p(out), out.stride(0) // 2 if B > 1 else C * H * W, B, C, H, W, int(f16), float(scale),
+              _stream())
+    return out
+
+
+def conv3x3_split_pre(xs, wq, Cout, out=None, out_scale=None, stats=None):
+    """z = out_scale * conv3x3 of a PRE-SPLIT activation xs [B, Cin/8, H, 2, W, 8] (split_pack_act / the producers' fused variants)
+    with the split weight pack wq: the arithmetic of conv3x3_split, staging by LDS-DMA.  out_scale defaults to what undoes the
+    pack's own scale (2^-8 for the fp16 pack)."""
+    if wq is None or not wq.is_cuda or wq.dtype not in (torch.bfloat16, torch.float16) or xs.dtype != wq.dtype:
+        raise TypeError("conv3x3_split_pre: xs and wq must be split packs of the same 16-bit type on the GPU")
+    f16 = int(wq.dtype == torch.float16)
+    B, C8, H, two, W, eight = xs.shape
+    Cin = C8 * 8
+    if out is None:
+        out = torch.empty((B, Cout, H, W), dtype=F32, device=xs.device)
+    if out_scale is None:
+        out_scale = 1.0 / 256.0 if f16 else 1.0
+    e0 = _prof_begin()
+    _lib.call("onet_conv3x3_split_fwd_pre", _p(xs), xs.stride(0) // 2 if B > 1 else Cin * H * W, _p(wq), f16, float(out_scale), _p(out),
+              out.stride(0) if B > 1 else Cout * H * W, _p(stats), B, Cin, Cout, H, W, _stream())
+    _prof_end("conv3x3_split_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
+    return out
+
+
 def split_wgrad_ok(x, dz):
     B, Cin, H, W = x.shape
     ok = bool(_lib.load().onet_conv3x3_split_wgrad_ok(B, Cin, dz.shape[1], H, W)) and \

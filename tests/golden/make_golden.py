@@ -527,8 +527,62 @@ def run_wire_formats(ov):
                                                                   for k, v in d.items()})
 
 
+def run_train_behaviour(ov, tag="train_b4_c3_64", B=4, C=3, H=64, W=64, steps=40):
+    """The reachable part of BASELINE configs[4]'s "IoU parity": the REAL reference `Onet(in_chns=3)` trained for `steps` epochs of
+    ONE batch each in the order of TZ:99-128 -- onet.train(); zero_grad; forward; slice S; compute_loss; backward; Adam(lr 1e-4)
+    step; loss.item(); CosineAnnealingWarmRestarts(T_0=300, T_mult=2, eta_min=1e-6).step() per epoch -- on synthetic bright-blob
+    tiles (SURVEY 8d's C5 stand-in, onet_amd.data.make_blob_tiles: the ZY-3 tiles are not in the image), then evaluated as
+    UZ:160-181 does: eval(); no_grad forward; predict_label; reorder_segmentation; evaluate_segmentation -> (acc, mIoU), with the
+    reference's OWN utils_20231218 functions.  Stored: the fp32 loss sequence, the same loop in fp64 (how far fp32 training itself
+    drifts from exact arithmetic: the yardstick for the build's tolerance), final label maps, acc / mIoU of both, lr sequence."""
+    import utils_20231218 as ut
+    from onet_amd.data import make_blob_tiles
+    Xn, Mn = make_blob_tiles(B, H, W, seed=4242, channels=C)
+    out = {"meta": np.array([B, C, H, W, steps]), "x_sum": np.float64(Xn.astype(np.float64).sum()), "mask": Mn.astype(np.uint8)}
+    for dtype, key in ((torch.float32, "32"), (torch.float64, "64")):
+        torch.manual_seed(0)
+        onet = ov.Onet(in_chns=C, binit=True, bshare=True)
+        onet.load_state_dict(orc.onet_state_dict(C, 1981, True))
+        onet = onet.to(dtype)
+        X, label = torch.from_numpy(Xn).to(dtype), torch.from_numpy(Mn)
+        opt = torch.optim.Adam(onet.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-08, weight_decay=0, amsgrad=False)
+        sch = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt, T_0=300, T_mult=2, eta_min=0.000001, last_epoch=-1)
+        losses, lrs = [], []
+        for epoch in range(steps):
+            onet.train()
+            lrs.append(opt.param_groups[0]["lr"])
+            onet.zero_grad()
+            Lt, Vt, Ld, Vd, S = onet(X)
+            St = S[:, 0, :, :].unsqueeze(dim=1)
+            Sd = S[:, 1, :, :].unsqueeze(dim=1)
+            loss = onet.compute_loss(Lt, St, Ld, Sd)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+            sch.step()
+        onet.eval()
+        with torch.no_grad():
+            Lt, Vt, Ld, Vd, S = onet(X)
+            pred = onet.predict_label(S)
+            Y = ut.reorder_segmentation(pred, label)
+            tl = onet.compute_loss(Lt, S[:, 0:1], Ld, S[:, 1:2]).item()
+            acc, miou = ut.evaluate_segmentation(Y, label, gt_k=2)
+        out["losses" + key], out["lrs"] = np.array(losses, dtype=np.float64), np.array(lrs, dtype=np.float64)
+        out["eval_loss" + key], out["acc" + key], out["miou" + key] = np.float64(tl), np.float64(acc), np.float64(miou)
+        out["pred" + key], out["Y" + key] = pred.numpy().astype(np.uint8), Y.numpy().astype(np.uint8)
+        out["Vt_eval" + key] = Vt.float().numpy()
+        print("train", tag, key, "loss %.5f -> %.5f  eval %.5f  acc %.4f miou %.4f" % (losses[0], losses[-1], tl, acc, miou), flush=True)
+    out["loss_drift_32_vs_64"] = np.float64(np.max(np.abs(out["losses32"] - out["losses64"]) / np.abs(out["losses64"])))
+    np.savez_compressed(os.path.join(HERE, f"{tag}.npz"), **out)
+    print("train", tag, "max relative loss drift fp32 vs fp64 over %d steps: %.2e; labels differing: %d px"
+          % (steps, float(out["loss_drift_32_vs_64"]), int((out["pred32"] != out["pred64"]).sum())))
+
+
 if __name__ == "__main__":
     ov = import_reference()
+    if os.environ.get("GOLDEN_ONLY") == "train":         # configs[4]: training behaviour + IoU on blob tiles
+        run_train_behaviour(ov)
+        sys.exit(0)
     if os.environ.get("GOLDEN_ONLY") == "evalside":
         run_eval_side()
         run_wire_formats(ov)
@@ -570,3 +624,4 @@ if __name__ == "__main__":
     run_eval_side()
     run_wire_formats(ov)
     run_clutter_stats()
+    run_train_behaviour(ov)
