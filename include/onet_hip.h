@@ -178,7 +178,24 @@ int onet_conv3x3_bf16_fwd_b(const void* x_bf16, int64_t x_bs, const void* wq, fl
  * instead of 16 at the same three MFMAs per term (v_mfma_f32_32x32x16_f16): error at the fp32 direct kernel's level.  The pack
  * holds 2^8 w (undone on the accumulators); the input must stay within fp16's range (|x| < 65504: activations, not gradients --
  * an input gradient is computed with wq_dgrad, whose parts are always bf16, and wq_f16 = 0). */
-int onet_conv3x3_split_pack_weights(const float* w, void* wq_fwd, void* wq_dgrad, int Cout, int Cin, int fwd_f16, void* stream);
+int onet_conv3x3_split_pack_weights(const float* w, void* wq_fwd, void* wq_dgrad, void* amax_ws, int Cout, int Cin, int fwd_f16,
+                                    int dgrad_f16, void* stream);
+/* ABI 3 (round 4) -- fp16 parts with per-tensor power-of-two scales.  An fp16 pack holds the parts of 2^k w with k chosen from the
+ * tensor's largest magnitude (amax_ws: 8 KB of device scratch) and carries (2^k, 2^-k) as two floats BEHIND the pack (buffers:
+ * 2 * K * 9 * N 16-bit elements + 16 bytes).  Activations / gradients carry their largest magnitude in 64 "magnitude slots"
+ * (unsigned[64 * 32]: one slot per 128-byte line, fp32 bit patterns, maximum over the slots; written with atomicMax by the producers: onet_bn_relu_apply_amax,
+ * onet_bn_relu_bwd_apply_amax).  _conv_amax: forward (scale_always = 0: x is scaled only when its magnitude would leave fp16's
+ * range -- a guard) or input gradient (scale_always = 1, the dgrad pack: the operand's amax is brought to [2^13, 2^14)) of a 3x3
+ * convolution on fp16 parts, three v_mfma_f32_32x32x16_f16 per term; x_amax = NULL: unscaled.  part as _fwd_stats.
+ * _wgrad_f16: the weight gradient on fp16 parts of x (guard, may be NULL) and dz (always scaled; required); save != NULL:
+ * normalise on load as _wgrad_norm. */
+/* max |x| over n contiguous floats into 64 magnitude slots (atomicMax: the slots must be zeroed, or hold an earlier maximum) */
+int onet_absmax_slots(const float* x, int64_t n, void* slots, void* stream);
+int onet_conv3x3_split_conv_amax(const float* x, int64_t x_bs, const void* x_amax, int scale_always, const void* wq, float* z, int64_t z_bs,
+                                 float* part, int B, int Cin, int Cout, int H, int W, void* stream);
+int onet_conv3x3_split_wgrad_f16(const float* x, int64_t x_bs, const void* x_amax, const float* save, int n_groups, const float* dz,
+                                 int64_t dz_bs, const void* dz_amax, float* dw, void* ws, int64_t ws_bytes, int B, int Cin, int Cout,
+                                 int H, int W, int accumulate, void* stream);
 int onet_conv3x3_split_fwd(const float* x, int64_t x_bs, const void* wq, int wq_f16, float* z, int64_t z_bs, int B, int Cin, int Cout,
                            int H, int W, void* stream);
 int onet_conv3x3_split_nparts(int B, int H, int W);
@@ -193,6 +210,12 @@ int onet_split_pack_act(const float* x, int64_t x_bs, void* xs, int64_t xs_bs, i
                         void* stream);
 int onet_conv3x3_split_fwd_pre(const void* xs, int64_t xs_bs, const void* wq, int wq_f16, float out_scale, float* z, int64_t z_bs,
                                float* part, int B, int Cin, int Cout, int H, int W, void* stream);
+/* Weight gradient (OV:47,51 backward) from pre-split x and dz (both in the slot layout, same 16-bit type): fragments by the gfx950
+ * transposing LDS read, staging by LDS-DMA; dw = out_scale * sum dz x, deterministic split-K through ws
+ * (onet_conv3x3_split_wgrad_ws_bytes).  _ok: W >= 64, or W = 32 with an even batch; Cin, Cout multiples of 8. */
+int onet_conv3x3_split_wgrad_pre_ok(int B, int Cin, int Cout, int H, int W);
+int onet_conv3x3_split_wgrad_pre(const void* xs, int64_t xs_bs, const void* dzs, int64_t dzs_bs, int f16, float out_scale, float* dw,
+                                 void* ws, int64_t ws_bytes, int B, int Cin, int Cout, int H, int W, int accumulate, void* stream);
 int onet_conv3x3_split_fwd_stats(const float* x, int64_t x_bs, const void* wq, int wq_f16, float* z, int64_t z_bs, float* part, int B,
                                  int Cin, int Cout, int H, int W, void* stream);
 /* Weight gradient of the same convolution with both operands (x, dz: fp32 NCHW) split the same way, three MFMAs per term;
@@ -317,6 +340,18 @@ int onet_bn_bwd_finalize_cm(const float* part2, int nparts, int64_t c_stride, in
 int onet_bn_relu_bwd_apply(const float* da, int64_t da_bs, const float* z, int64_t z_bs,
                            const float* save, const float* coef, float* dz, int64_t dz_bs,
                            int B, int C, int HW, void* stream);
+/* onet_bn_relu_apply / onet_bn_relu_apply_pool that also record max a (a >= 0) in 64 magnitude slots (zeroed by the caller; the
+ * statistics groups of a twin batch share them; the pooled tensor has the same maximum): the overflow guard of the fp16-split
+ * convolution that consumes the activation.  _pool_amax returns 1 when the shape is not taken (as onet_bn_relu_apply_pool). */
+int onet_bn_relu_apply_amax(const float* z, int64_t z_bs, float* a, int64_t a_bs, const float* save, void* amax, int B, int C, int HW,
+                            void* stream);
+int onet_bn_relu_apply_pool_amax(const float* z, int64_t z_bs, float* a, int64_t a_bs, float* y, int64_t y_bs, const float* save,
+                                 void* amax, int B, int C, int H, int W, void* stream);
+/* ... the same pass, also recording max |dz| in 64 magnitude slots (unsigned[64 * 32], zeroed by the caller; several launches -- the
+ * statistics groups of a twin batch -- may share them): what the fp16-split gradient kernels scale dz by (onet_conv3x3_split_conv_amax,
+ * onet_conv3x3_split_wgrad_f16). */
+int onet_bn_relu_bwd_apply_amax(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save, const float* coef,
+                                float* dz, int64_t dz_bs, void* amax, int B, int C, int HW, void* stream);
 
 /* ---- K4: MaxPool2d(2) (OV:67) ------------------------------------------- */
 int onet_maxpool2_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs,

@@ -180,13 +180,38 @@ static __device__ __forceinline__ void store_bf16x4(__bf16* p, float4 q) {     /
     *reinterpret_cast<bn_bf16x4*>(p) = v;
 }
 
+// block maximum of v into one of the 64 magnitude slots.  The slots are 128 bytes apart (one cache line each: the updates of a launch's
+// tens of thousands of blocks spread over 64 lines / L2 channels instead of queueing on one) and a block commits ONCE: wave maxima
+// through LDS, then a plain read of the slot first -- once it holds a value >= the block's, after the first few blocks almost
+// always, no atomic is issued.  atomicMax on the fp32 bit pattern of a non-negative value is an order-independent maximum.
+// Every thread of a 256-thread block must call this (it contains a barrier).
+constexpr int AMAX_STRIDE = 32;     // unsigned words between slots
+__device__ __forceinline__ void amax_commit(float v, unsigned* slots) {
+    if (!slots) return;
+    __shared__ float wave_max[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+        if (m == m) {
+            unsigned* s = slots + (blockIdx.x & 63) * AMAX_STRIDE;
+            const unsigned bits = __builtin_bit_cast(unsigned, m);
+            if (__builtin_nontemporal_load(s) < bits) atomicMax(s, bits);
+        }
+    }
+}
+
 // a16 (optional): a bf16 copy of the activation for the bf16 conv kernels (bf16 STORAGE of their operands); a may be NULL
 // when only the bf16 copy is wanted
 __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restrict__ z, int64_t z_bs,
                                                             float* __restrict__ a, int64_t a_bs,
                                                             const float* __restrict__ save, int C, int HW,
                                                             int chunks, __bf16* __restrict__ a16 = nullptr,
-                                                            int64_t a16_bs = 0) {
+                                                            int64_t a16_bs = 0, unsigned* __restrict__ amax = nullptr) {
+    // amax: 64 magnitude slots of the activation (the range guard of the fp16-split convolution that consumes it)
+    float vmax = 0.f;
     const int plane = blockIdx.x / chunks, ch = blockIdx.x % chunks;
     const int b = plane / C, c = plane % C;
     const float mean = save[c], sc = save[2 * C + c], sh = save[3 * C + c];
@@ -209,7 +234,9 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restr
                 q[k].w = fmaxf(fmaf(q[k].w - mean, sc, sh), 0.f);
                 if (dst) *reinterpret_cast<float4*>(dst + i0 + 1024 * k) = q[k];
                 if (d16) store_bf16x4(d16 + i0 + 1024 * k, q[k]);
+                vmax = fmaxf(fmaxf(vmax, fmaxf(q[k].x, q[k].y)), fmaxf(q[k].z, q[k].w));
             }
+            amax_commit(vmax, amax);
             return;
         }
 #endif
@@ -221,14 +248,17 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restr
             q.w = fmaxf(fmaf(q.w - mean, sc, sh), 0.f);
             if (dst) *reinterpret_cast<float4*>(dst + i) = q;
             if (d16) store_bf16x4(d16 + i, q);
+            vmax = fmaxf(fmaxf(vmax, fmaxf(q.x, q.y)), fmaxf(q.z, q.w));
         }
     } else {
         for (int i = beg + threadIdx.x; i < end; i += 256) {
             const float v = fmaxf(fmaf(src[i] - mean, sc, sh), 0.f);
             if (dst) dst[i] = v;
             if (d16) d16[i] = (__bf16)v;
+            vmax = fmaxf(vmax, v);
         }
     }
+    amax_commit(vmax, amax);
 }
 
 // The same pass for an encoder output that is max-pooled next (OV:49/53 -> nn.MaxPool2d(2), OV:67): a thread owns a 2 x 4 patch,
@@ -240,13 +270,16 @@ __global__ __launch_bounds__(256) void bn_relu_apply_pool_kernel(const float* __
                                                                  int64_t a_bs, __bf16* __restrict__ a16, int64_t a16_bs,
                                                                  float* __restrict__ y, int64_t y_bs, __bf16* __restrict__ y16,
                                                                  int64_t y16_bs, const float* __restrict__ save, int C, int H, int W,
-                                                                 int blocks_per_plane) {
+                                                                 int blocks_per_plane, unsigned* __restrict__ amax = nullptr) {
     const int plane = blockIdx.x / blocks_per_plane, blk = blockIdx.x % blocks_per_plane;
     const int b = plane / C, c = plane % C;
     const float mean = save[c], sc = save[2 * C + c], sh = save[3 * C + c];
     const int qw = W >> 2, npatch = (H >> 1) * qw;
     const int i = blk * 256 + threadIdx.x;
-    if (i >= npatch) return;
+    if (i >= npatch) {
+        amax_commit(0.f, amax);                     // (every thread of the block takes part in the reduction)
+        return;
+    }
     const int pr = i / qw, q = i % qw;
     const int64_t off = (int64_t)c * H * W + (int64_t)(2 * pr) * W + 4 * q;
     const float* src = z + (int64_t)b * z_bs + off;
@@ -269,6 +302,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_pool_kernel(const float* __
     const int64_t yo = (int64_t)c * (H >> 1) * (W >> 1) + (int64_t)pr * (W >> 1) + 2 * q;
     if (y) *reinterpret_cast<float2*>(y + (int64_t)b * y_bs + yo) = make_float2(m0, m1);
     if (y16) *reinterpret_cast<bn_bf16x2*>(y16 + (int64_t)b * y16_bs + yo) = bn_bf16x2{(__bf16)m0, (__bf16)m1};
+    amax_commit(fmaxf(m0, m1), amax);               // the pooled tensor has the same maximum: one set of slots serves both
 }
 
 // backward pass 1: part2[p][c] = (sum dy, sum dy*xhat), dy = da * [(z-mean)*scale+beta > 0].
@@ -404,7 +438,10 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
                                                                 const float* __restrict__ coef,
                                                                 float* __restrict__ dz, int64_t dz_bs, int C,
                                                                 int HW, int chunks, __bf16* __restrict__ dz16 = nullptr,
-                                                                int64_t dz16_bs = 0) {
+                                                                int64_t dz16_bs = 0, unsigned* __restrict__ amax = nullptr) {
+    // amax: 64 magnitude slots of dz (fp32 bit patterns; atomicMax is an order-independent maximum): the fp16-split convolution
+    // kernels that consume dz scale it by a power of two chosen from this (conv_split.hip, amax_scale)
+    float vmax = 0.f;
     const int plane = blockIdx.x / chunks, ch = blockIdx.x % chunks;
     const int b = plane / C, c = plane % C;
     const float mean = save[c], invstd = save[C + c], sc = save[2 * C + c], sh = save[3 * C + c];
@@ -437,7 +474,9 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
                 }
                 if (out) *reinterpret_cast<float4*>(out + i0 + 1024 * k) = make_float4(o[0], o[1], o[2], o[3]);
                 if (o16) store_bf16x4(o16 + i0 + 1024 * k, make_float4(o[0], o[1], o[2], o[3]));
+                vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
             }
+            amax_commit(vmax, amax);
             return;
         }
 #endif
@@ -453,6 +492,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
             }
             if (out) *reinterpret_cast<float4*>(out + i) = make_float4(o[0], o[1], o[2], o[3]);
             if (o16) store_bf16x4(o16 + i, make_float4(o[0], o[1], o[2], o[3]));
+            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
         }
     } else {
         for (int i = beg + threadIdx.x; i < end; i += 256) {
@@ -460,8 +500,10 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
             const float v = (float)(scd * (dy - c1 - (((double)zs[i] - meand) * invd) * c2));
             if (out) out[i] = v;
             if (o16) o16[i] = (__bf16)v;
+            vmax = fmaxf(vmax, fabsf(v));
         }
     }
+    amax_commit(vmax, amax);
 }
 
 // nparts must be B * chunks with chunks = ceil(HW / chunk_len); we derive chunk_len from nparts
@@ -521,6 +563,30 @@ int onet_bn_relu_apply(const float* z, int64_t z_bs, float* a, int64_t a_bs, con
     hipLaunchKernelGGL(bn_relu_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), z, z_bs, a,
                        a_bs, save, C, HW, chunks);
     return check_launch("bn_relu_apply_kernel");
+}
+
+int onet_bn_relu_apply_amax(const float* z, int64_t z_bs, float* a, int64_t a_bs, const float* save, void* amax, int B, int C, int HW,
+                            void* stream) {
+    ONET_REQUIRE(z && a && save && amax && B > 0 && C > 0 && HW > 0, "bn_relu_apply_amax: bad args");
+    const int chunks = cdiv(HW, 4096);
+    const int64_t blocks = (int64_t)B * C * chunks;
+    ONET_REQUIRE(blocks < (1ll << 31), "bn_relu_apply_amax: grid too large");
+    hipLaunchKernelGGL(bn_relu_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), z, z_bs, a, a_bs, save, C, HW,
+                       chunks, (__bf16*)nullptr, (int64_t)0, (unsigned*)amax);
+    return check_launch("bn_relu_apply_kernel");
+}
+
+int onet_bn_relu_apply_pool_amax(const float* z, int64_t z_bs, float* a, int64_t a_bs, float* y, int64_t y_bs, const float* save,
+                                 void* amax, int B, int C, int H, int W, void* stream) {
+    ONET_REQUIRE(z && a && y && save && amax && B > 0 && C > 0 && H > 0 && W > 0, "bn_relu_apply_pool_amax: bad args");
+    auto al = [](const void* p, uintptr_t m) { return (reinterpret_cast<uintptr_t>(p) & m) == 0; };
+    if ((H & 1) || (W & 3) || (z_bs & 3) || (a_bs & 3) || (y_bs & 1) || !al(z, 15) || !al(a, 15) || !al(y, 7)) return 1;
+    const int npatch = (H / 2) * (W / 4), bpp = cdiv(npatch, 256);
+    const int64_t blocks = (int64_t)B * C * bpp;
+    ONET_REQUIRE(blocks < (1ll << 31), "bn_relu_apply_pool_amax: grid too large");
+    hipLaunchKernelGGL(bn_relu_apply_pool_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), z, z_bs, a, a_bs,
+                       (__bf16*)nullptr, (int64_t)0, y, y_bs, (__bf16*)nullptr, (int64_t)0, save, C, H, W, bpp, (unsigned*)amax);
+    return check_launch("bn_relu_apply_pool_kernel");
 }
 
 int onet_bn_relu_apply_b(const float* z, int64_t z_bs, float* a, int64_t a_bs, void* a_bf16, int64_t a16_bs, const float* save, int B,
@@ -583,6 +649,17 @@ int onet_bn_relu_bwd_apply(const float* da, int64_t da_bs, const float* z, int64
     ONET_REQUIRE(blocks < (1ll << 31), "bn_relu_bwd_apply: grid too large");
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), da, da_bs,
                        z, z_bs, save, coef, dz, dz_bs, C, HW, chunks);
+    return check_launch("bn_relu_bwd_apply_kernel");
+}
+
+int onet_bn_relu_bwd_apply_amax(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save, const float* coef,
+                                float* dz, int64_t dz_bs, void* amax, int B, int C, int HW, void* stream) {
+    ONET_REQUIRE(da && z && save && dz && amax && B > 0 && C > 0 && HW > 0, "bn_relu_bwd_apply_amax: bad args");
+    const int chunks = cdiv(HW, 4096);
+    const int64_t blocks = (int64_t)B * C * chunks;
+    ONET_REQUIRE(blocks < (1ll << 31), "bn_relu_bwd_apply_amax: grid too large");
+    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), da, da_bs, z, z_bs, save, coef,
+                       dz, dz_bs, C, HW, chunks, (__bf16*)nullptr, (int64_t)0, (unsigned*)amax);
     return check_launch("bn_relu_bwd_apply_kernel");
 }
 

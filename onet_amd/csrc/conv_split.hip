@@ -56,7 +56,6 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
 // numbers (undone on the accumulators, exactly); gradients -- whose magnitude is anyone's guess -- keep the bf16 split.
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-constexpr float F16_WSCALE = 256.f;
 __device__ __forceinline__ void split2h(float a, float b, unsigned& hi, unsigned& mid) {
     const f16x2 h = {(_Float16)a, (_Float16)b};
     const f16x2 m = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
@@ -64,12 +63,70 @@ __device__ __forceinline__ void split2h(float a, float b, unsigned& hi, unsigned
     mid = __builtin_bit_cast(unsigned, m);
 }
 
+// Scaled fp16 split in FOUR VALU per value pair: hi = fp16(s v), mid = fp16(s v - hi) with v_fma_mixlo/mixhi_f16 -- the fma of
+// fp32 operands (and, for mid, the fp16 hi part read straight from its register half) rounded once to fp16 into the low / high
+// half of the destination.  s is a power of two, so s v is exact and hi, mid are bit for bit what split2h gives for s v (which the
+// compiler builds from v_cvt_pk_f16_f32 + two v_cvt_f32_f16 + two v_sub + v_cvt_pk: six VALU per pair): the scale rides free.
+__device__ __forceinline__ void split2h_s(float a, float b, float s, unsigned& hi, unsigned& mid) {
+    unsigned h, m;
+    asm("v_fma_mixlo_f16 %0, %1, %3, 0 op_sel_hi:[0,0,0]\n\tv_fma_mixhi_f16 %0, %2, %3, 0 op_sel_hi:[0,0,0]"
+        : "=&v"(h) : "v"(a), "v"(b), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(m) : "v"(a), "v"(b), "v"(s), "v"(h));
+    hi = h;
+    mid = m;
+}
+
+// Per-tensor magnitude slots: 64 unsigned words holding max |v| as fp32 bits (non-negative floats order like their bit patterns,
+// so atomicMax on the bits is an order-independent, i.e. deterministic, maximum); producers (bn.hip, the weight pack) spread their
+// updates over the 64 words by block index, readers take the maximum of all 64.  -> wave-uniform fp32 amax (0: no information).
+constexpr int AMAX_SLOTS = 64, AMAX_STRIDE = 32;      // 64 slots, one per 128-byte line (bn.hip: amax_commit)
+__device__ __forceinline__ float amax_read(const unsigned* slots) {
+    if (!slots) return 0.f;
+    unsigned v = slots[(threadIdx.x & (AMAX_SLOTS - 1)) * AMAX_STRIDE];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 64));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(v));
+}
+// power-of-two scale for an fp16 split of a tensor whose largest magnitude is amax: `always` -> amax lands in [2^13, 2^14) (the
+// gradients: their magnitude is anyone's guess and fp16's 5-bit exponent is narrow); otherwise only when amax >= 2^15 would leave
+// fp16's range (the forward activations: a range GUARD that leaves ordinary tensors -- and the bit-identity statements made about
+// them -- untouched).  -> scale s = 2^k; the caller undoes it with 2^-k on the accumulators (exact).
+__device__ __forceinline__ float amax_scale(float amax, bool always, float& inv) {
+    const unsigned bits = __builtin_bit_cast(unsigned, amax);
+    const int e = (int)((bits >> 23) & 255u) - 127;                    // floor(log2(amax))
+    int k = 0;
+    if (bits != 0u && e < 128) k = (always || e >= 15) ? 13 - e : 0;
+    k = max(-100, min(100, k));
+    inv = __builtin_bit_cast(float, (unsigned)(127 - k) << 23);
+    return __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
+}
+__global__ void absmax_slots_kernel(const float* __restrict__ v, int64_t n, unsigned* __restrict__ slots) {
+    float m = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(v[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0)
+        atomicMax(slots + ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (AMAX_SLOTS - 1)) * AMAX_STRIDE, __builtin_bit_cast(unsigned, m));
+}
+
 // w [Cout][Cin][3][3] fp32 -> wq [K/16][part 2][9][2][N][8] bf16: chunk of 16 reduction channels, part (hi, mid), tap,
 // 8-channel half, output channel, channel within the half.  which = 0: forward (K = Cin, N = Cout); 1: input gradient
 // (K = Cout rounded up to 16 with a zero tail, N = Cin, taps rotated by 180 degrees).
-__global__ void pack3x3_split_kernel(const float* __restrict__ w, __bf16* __restrict__ wq, int Cout, int Cin, int which, int f16) {
+// f16: fp16 parts of s w with s = 2^k chosen from the tensor's largest magnitude (wamax slots; amax lands in [2^13, 2^14): the mid
+// parts stay normal numbers down to 2^-27 of the largest weight, and no weight overflows whatever a loaded checkpoint holds);
+// the two floats (s, 1 / s) are stored BEHIND the pack (element offset 2 K 9 N) for the convolution to undo s on its accumulators.
+__global__ void pack3x3_split_kernel(const float* __restrict__ w, __bf16* __restrict__ wq, int Cout, int Cin, int which, int f16,
+                                     const unsigned* __restrict__ wamax) {
     const int K = which == 0 ? Cin : ((Cout + 15) / 16) * 16, N = which == 0 ? Cout : Cin;
     const int64_t n = (int64_t)K * 9 * N;                            // elements of ONE part
+    float winv = 1.f;
+    const float wscale = f16 ? amax_scale(amax_read(wamax), true, winv) : 1.f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float* meta = reinterpret_cast<float*>(wq + 2 * n);
+        meta[0] = wscale;
+        meta[1] = winv;
+    }
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int kc = (int)(i & 7);
         int64_t r = i >> 3;
@@ -86,7 +143,7 @@ __global__ void pack3x3_split_kernel(const float* __restrict__ w, __bf16* __rest
         const int64_t within = i - (int64_t)kg * per_chunk_part;     // [tap][half][n][8] inside the chunk
         if (f16) {                                                   // fp16 parts of 2^8 w (forward pack only)
             _Float16* wh = reinterpret_cast<_Float16*>(wq);
-            const float vs = v * F16_WSCALE;
+            const float vs = v * wscale;
             const _Float16 hi = (_Float16)vs;
             wh[((int64_t)kg * 2 + 0) * per_chunk_part + within] = hi;
             wh[((int64_t)kg * 2 + 1) * per_chunk_part + within] = (_Float16)(vs - (float)hi);
@@ -108,6 +165,8 @@ struct SpArgs {
     float* stats;         // ST: BatchNorm partials [Cout][B * tilesY * tilesX][3] = (n, mean, M2) per tile
     const float* nsave;   // NORM: x is the PRE-activation of the Conv-BatchNorm-ReLU unit below; its coefficients [groups][4][Cin]
     int nimg;             //       (rows mean, invstd, scale, shift; bn.hip) for statistics groups of nimg consecutive images
+    const unsigned* x_amax;   // F16: magnitude slots of x (NULL: no scaling)
+    int x_always;             //      1: scale x so that its amax lands in [2^13, 2^14) (gradients); 0: only as an overflow guard
 };
 
 // sum over the 32 lanes of a wave half, valid in lanes 31 / 63 (DPP row rotations + row broadcast)
@@ -176,6 +235,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
     const int l31 = lane & 31, kh = lane >> 5;
     const int HW = a.H * a.W;
     const int nchunks = a.Cin >> 4;
+    // F16: the operand scales (powers of two): x by its magnitude slots, the weights by the pack's own (stored behind the pack)
+    float xs_inv = 1.f;
+    const float xs_scale = F16 ? amax_scale(amax_read(a.x_amax), a.x_always != 0, xs_inv) : 1.f;
+    const float acc_scale = F16 ? xs_inv * reinterpret_cast<const float*>(a.wq + (int64_t)a.Cin * 2 * 9 * a.Cout)[1] : 1.f;
 
     const __amdgpu_buffer_rsrc_t wr = s_rsrc(a.wq, (int64_t)a.Cin * 2 * 9 * a.Cout * 2);
     const unsigned in_step = (unsigned)(16 * HW * 4), w_step = (unsigned)(2 * 9 * 2 * a.Cout * 16);
@@ -294,7 +357,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
                     va = pend_keep ? va : 0.f;               // outside the image: the convolution's zero padding
                     vb = pend_keep ? vb : 0.f;
                     unsigned h, m;
-                    if constexpr (F16) split2h(va, vb, h, m);
+                    if constexpr (F16) split2h_s(va, vb, xs_scale, h, m);
                     else split2(va, vb, h, m);
                     hi[px][c] = h;
                     mid[px][c] = m;
@@ -315,7 +378,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 unsigned h, m;
-                if constexpr (F16) split2h(f[2 * c][px], f[2 * c + 1][px], h, m);
+                if constexpr (F16) split2h_s(f[2 * c][px], f[2 * c + 1][px], xs_scale, h, m);
                 else split2(f[2 * c][px], f[2 * c + 1][px], h, m);
                 hi[c] = h;
                 mid[c] = m;
@@ -441,13 +504,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SpArgs a) {
             buf ^= 1;
         }
 
-        if constexpr (F16) {                         // the weights were packed times 2^8
+        if constexpr (F16) {                         // undo the operands' power-of-two scales (exact)
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[m][n][r] *= (1.f / F16_WSCALE);
+                    for (int r = 0; r < 16; ++r) acc[m][n][r] *= acc_scale;
         }
         int v = tile;
         const int co0 = (v % a.coTiles) * CO_T;      // output-channel tile fastest: see the tile order note at the top of the kernel
@@ -587,7 +650,7 @@ struct SpPreArgs {
     int64_t z_bs;
     int B, Cin, Cout, H, W, tilesX, tilesY, coTiles;
     float* stats;         // ST: BatchNorm partials (as conv3x3_split_kernel)
-    float out_scale;      // applied to the accumulators (undoes the power-of-two scales of the two operands)
+    float out_scale;      // applied to the accumulators (undoes the activation's power-of-two scale; the fp16 pack's own is read from the pack)
 };
 
 #ifndef SP_PRE_LAST_TAP
@@ -620,6 +683,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_pre_kernel(SpPreArgs a) 
     const int nchunks = a.Cin >> 4;
 
     const i32x4s wr = sp_rsrc4(a.wq, (int64_t)a.Cin * 2 * 9 * a.Cout * 2);
+    const float acc_scale = a.out_scale * (F16 ? reinterpret_cast<const float*>(a.wq + (int64_t)a.Cin * 2 * 9 * a.Cout)[1] : 1.f);
     const unsigned in_step = (unsigned)(16 * HW * 4), w_step = (unsigned)(2 * 9 * 2 * a.Cout * 16);
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_s;
 
@@ -775,7 +839,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_pre_kernel(SpPreArgs a) 
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][n][r] *= a.out_scale;
+                for (int r = 0; r < 16; ++r) acc[m][n][r] *= acc_scale;
         int v = tile;
         const int co0 = (v % a.coTiles) * CO_T;
         v /= a.coTiles;
@@ -897,7 +961,8 @@ int launch_split(SpArgs a, hipStream_t st) {
 }
 
 int split_fwd(const float* x, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin, int Cout, int H, int W,
-              void* stream, float* stats, int wq_f16, const float* nsave = nullptr, int n_groups = 0) {
+              void* stream, float* stats, int wq_f16, const float* nsave = nullptr, int n_groups = 0, const unsigned* x_amax = nullptr,
+              int x_always = 0) {
     ONET_REQUIRE(x && wq && z, "conv3x3_split_fwd: null pointer");
     ONET_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 16, "conv3x3_split_fwd: bad shape (maps wider than 16 pixels)");
     ONET_REQUIRE((Cin % 16) == 0, "conv3x3_split_fwd: Cin must be a multiple of 16 (use onet_conv_fwd)");
@@ -906,7 +971,8 @@ int split_fwd(const float* x, int64_t x_bs, const void* wq, float* z, int64_t z_
     ONET_REQUIRE(x_bs >= (int64_t)Cin * H * W && z_bs >= (int64_t)Cout * H * W, "conv3x3_split_fwd: batch stride too small");
     ONET_REQUIRE((int64_t)(Cin + 32) * H * W * 4 < (1ll << 31) && (int64_t)(Cin + 32) * 2 * 9 * Cout * 2 < (1ll << 31),
                  "conv3x3_split_fwd: operand exceeds the 2 GiB buffer-resource range");
-    SpArgs a{x, x_bs, (const __bf16*)wq, z, z_bs, B, Cin, Cout, H, W, 0, 0, 0, stats, nsave, 1};
+    SpArgs a{x, x_bs, (const __bf16*)wq, z, z_bs, B, Cin, Cout, H, W, 0, 0, 0, stats, nsave, 1, x_amax, x_always};
+    ONET_REQUIRE(!x_amax || wq_f16, "conv3x3_split: magnitude slots go with the fp16 pack");
     if (stats) ONET_REQUIRE(split_nparts(B, H, W) > 0, "conv3x3_split_fwd_stats: the map must be made of full 16 x 32 tiles");
     if (nsave) {
         ONET_REQUIRE(n_groups > 0 && B % n_groups == 0, "conv3x3_split_fwd_norm: the batch must hold n_groups equal statistics groups");
@@ -939,6 +1005,8 @@ struct SwArgs {
     int B, Cin, Cout, H, W, ciTiles, coTiles, splitK, tilesX;
     const float* nsave;   // NORM: x is the pre-activation of the unit below, normalised on load (see conv3x3_split_kernel): its
     int nimg;             //       coefficients [groups <= 2][4][Cin], statistics groups of nimg consecutive images
+    const unsigned* x_amax;    // F16: magnitude slots of x (overflow guard only; NULL: unscaled) and of dz (always scaled: amax
+    const unsigned* dz_amax;   //      lands in [2^13, 2^14)); the slab store undoes both scales
 };
 
 // MFMA groups of a unit (6 with 64-channel tiles, 12 with 128) before the next unit's rows are committed
@@ -967,7 +1035,8 @@ template <int G> struct SwCfg {
 // 2g + 1 of a unit and writes its own slab (54 MFMAs per wave between barriers).  128 (Cout % 128 == 0, G < 4: the LDS holds
 // it): 4 x 2 quadrants, every wave takes all four segments -- 108 MFMAs per wave between barriers, the x rows staged once per
 // 128 output channels, one slab per block.
-template <int G, int COT, bool NORM>
+// F16: fp16 parts (22 significant bits per operand instead of bf16's 16) of 2^kx x and 2^kd dz -- see amax_scale
+template <int G, int COT, bool NORM, bool F16>
 __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
     using C = SwCfg<G>;
     constexpr int SR_SX = C::SX, SR_SLOT = C::SLOT, SR_X_PART = C::X_PART;
@@ -999,6 +1068,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float x_inv = 1.f, dz_inv = 1.f;
+    const float x_scale = F16 ? amax_scale(amax_read(a.x_amax), false, x_inv) : 1.f;
+    const float dz_scale = F16 ? amax_scale(amax_read(a.dz_amax), true, dz_inv) : 1.f;
 
     // staging roles: thread = (channel = tid / 8, 8-pixel segment = tid % 8) of the dz row and of the x row
     const int st_c = tid >> 3, st_s = tid & 7;
@@ -1070,7 +1142,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 unsigned hh, mm;
-                split2(f[2 * c], f[2 * c + 1], hh, mm);
+                if constexpr (F16) split2h_s(f[2 * c], f[2 * c + 1], dz_scale, hh, mm);
+                else split2(f[2 * c], f[2 * c + 1], hh, mm);
                 hi[c] = hh;
                 mid[c] = mm;
             }
@@ -1097,7 +1170,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
         }
         unsigned hi[5], mid[5];
 #pragma unroll
-        for (int p2 = 0; p2 < 5; ++p2) split2(e[2 * p2], e[2 * p2 + 1], hi[p2], mid[p2]);
+        for (int p2 = 0; p2 < 5; ++p2) {
+            if constexpr (F16) split2h_s(e[2 * p2], e[2 * p2 + 1], x_scale, hi[p2], mid[p2]);
+            else split2(e[2 * p2], e[2 * p2 + 1], hi[p2], mid[p2]);
+        }
         *reinterpret_cast<u32x4s*>(row) = u32x4s{hi[0], hi[1], hi[2], hi[3]};
         *reinterpret_cast<u32x4s*>(row + SR_X_PART) = u32x4s{mid[0], mid[1], mid[2], mid[3]};
         if (st_w == C::SPG - 1) {
@@ -1143,7 +1219,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
             const int buf = y & 1;
             const bool more = y + 1 < ye, more2 = y + 2 < ye;
             const unsigned* ab = a_ptr + buf * 2 * SR_DZ_PART;
-            bf16x8 ah, am;
+            u32x4s ah, am;
             constexpr int CAT = COT == 64 ? SW_CAT64 : SW_CAT128;
             // Segments run LAST TO FIRST: a lane's 8-pixel fragment is one aligned ds_read_b128 (4 dwords); the fifth dword its
             // shifted copies need is the first dword of the NEXT 8-pixel group -- for the kh = 0 half that of its kh = 1 partner in
@@ -1175,8 +1251,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
                     }
                 }
                 if (ky == 0) {
-                    ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4s*>(ab + sg * 8));
-                    am = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4s*>(ab + SR_DZ_PART + sg * 8));
+                    ah = *reinterpret_cast<const u32x4s*>(ab + sg * 8);
+                    am = *reinterpret_cast<const u32x4s*>(ab + SR_DZ_PART + sg * 8);
                 }
                 const unsigned* br = b_ptr + ((y - 1 + ky) & 3) * SR_SLOT + seg_off(sg);
                 u32x4s sh[2][3];                  // [part][horizontal shift]
@@ -1199,10 +1275,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
                 }
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    const bf16x8 bh = __builtin_bit_cast(bf16x8, sh[0][j]), bm = __builtin_bit_cast(bf16x8, sh[1][j]);
-                    acc[ky * 3 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[ky * 3 + j], 0, 0, 0);
-                    acc[ky * 3 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[ky * 3 + j], 0, 0, 0);
-                    acc[ky * 3 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[ky * 3 + j], 0, 0, 0);
+                    if constexpr (F16) {
+                        const f16x8 a_h = __builtin_bit_cast(f16x8, ah), a_m = __builtin_bit_cast(f16x8, am);
+                        const f16x8 bh = __builtin_bit_cast(f16x8, sh[0][j]), bm = __builtin_bit_cast(f16x8, sh[1][j]);
+                        acc[ky * 3 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_m, bh, acc[ky * 3 + j], 0, 0, 0);
+                        acc[ky * 3 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h, bm, acc[ky * 3 + j], 0, 0, 0);
+                        acc[ky * 3 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h, bh, acc[ky * 3 + j], 0, 0, 0);
+                    } else {
+                        const bf16x8 a_h = __builtin_bit_cast(bf16x8, ah), a_m = __builtin_bit_cast(bf16x8, am);
+                        const bf16x8 bh = __builtin_bit_cast(bf16x8, sh[0][j]), bm = __builtin_bit_cast(bf16x8, sh[1][j]);
+                        acc[ky * 3 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m, bh, acc[ky * 3 + j], 0, 0, 0);
+                        acc[ky * 3 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, bm, acc[ky * 3 + j], 0, 0, 0);
+                        acc[ky * 3 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, bh, acc[ky * 3 + j], 0, 0, 0);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1219,7 +1304,203 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (co < a.Cout && ci < a.Cin) o[(int64_t)co * a.Cin + ci] = acc[t][r];
+            if (co < a.Cout && ci < a.Cin) o[(int64_t)co * a.Cin + ci] = F16 ? acc[t][r] * (x_inv * dz_inv) : acc[t][r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ weight gradient from PRE-SPLIT operands (round 4)
+// Both operands arrive in the slot layout [B][C/8][H][part][W][8] (16 bytes = 8 channels of one pixel), i.e. with the reduction
+// index (pixels) running ACROSS slots.  The MFMA wants 8 consecutive pixels of one channel per lane, so the fragments are read
+// with the gfx950 transposing LDS read ds_read_b64_tr_b16 (a 16-lane group fetches 4 pixel rows x 16 channels and every lane
+// receives ITS channel's four pixels): no in-kernel split, no transposition VALU, and a tap's horizontal shift is a pixel-row
+// offset of the read address (the round-3 kernel rebuilt shifted fragments with v_alignbit + v_permlane32_swap).  Staging is a
+// lane-linear LDS-DMA copy as in conv3x3_split_pre_kernel.  Unit, ring over rows, split-K and slabs as conv3x3_split_wgrad_kernel.
+//   x ring : [4 row slots][part][8 channel groups][PXP = 68 pixel slots]   (G = 1: x0-1 .. x0+64 + 2 pad; G = 2: two images' 34)
+//   dz     : [2 buffers] [part][COT / 8 groups]  [PXP = 68]                (64 pixels + 4 pad)
+// A channel group's plane of 68 slots = 272 dwords = 16 banks (mod 64): the 4 pixel rows x (2 groups x 2 half-slots) a 32-lane
+// half reads fall on 64 different banks -- conflict-free without a swizzle.
+typedef short s16x4w __attribute__((ext_vector_type(4)));
+struct SwPreArgs {
+    const void* xs;
+    int64_t xs_bs;        // batch strides in 4-byte units
+    const void* dzs;
+    int64_t dzs_bs;
+    float* slab;
+    int B, Cin, Cout, H, W, ciTiles, coTiles, splitK, tilesX;
+    float out_scale;
+};
+constexpr int SWP_PXP = 68;
+
+__device__ __forceinline__ u32x4s swp_frag(unsigned addr) {      // 8 consecutive pixels (K) of this lane's channel: two transposed reads
+    const s16x4w lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4w*)(uintptr_t)addr);
+    const s16x4w hv = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4w*)(uintptr_t)(addr + 64));
+    const unsigned long long a = __builtin_bit_cast(unsigned long long, lo), b = __builtin_bit_cast(unsigned long long, hv);
+    return u32x4s{(unsigned)a, (unsigned)(a >> 32), (unsigned)b, (unsigned)(b >> 32)};
+}
+
+template <int G, int COT, bool F16>
+__global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_pre_kernel(SwPreArgs a) {
+    constexpr int PXP = SWP_PXP;
+    constexpr int XS = 8, DS = COT / 8;                        // channel groups per image
+    constexpr int X_PART = XS * PXP, X_ROW = 2 * X_PART;       // slots
+    constexpr int DZ_PART = DS * PXP, DZ_BUF = 2 * DZ_PART;
+    constexpr int NXI = (X_ROW + 511) / 512, NDI = (DZ_BUF + 511) / 512;      // DMA rounds per wave (64 slots each, 8 waves)
+    constexpr int NKS = COT == 64 ? 2 : 4;                     // k-steps (16 pixels) per wave and unit
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_w;
+    const unsigned x_base = lds0, dz_base = lds0 + 4 * X_ROW * 16;
+
+    int bid;
+    {
+        const int n = gridDim.x, q = n >> 3, r = n & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int tiles = a.ciTiles * a.coTiles;
+    const int ks = bid / tiles, tile = bid % tiles;
+    const int ci0 = (tile % a.ciTiles) * 64, co0 = (tile / a.ciTiles) * COT;
+    const int nunits = (a.B / G) * a.tilesX * a.H;
+    const int per = (nunits + a.splitK - 1) / a.splitK;
+    const int u0 = ks * per, u1 = min(u0 + per, nunits);
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = COT == 64 ? wid >> 2 : 0, wm = COT == 64 ? (wid >> 1) & 1 : wid >> 1, wn = wid & 1;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int HW = a.H * a.W;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // transposed-read lane bases (bytes): lane = 16 g + 4 q + p supplies pixel row q, channels 4 p .. 4 p + 3 of the channel half g & 1
+    const int tq = (lane >> 2) & 3, tp = lane & 3, tg = (lane >> 4) & 1;
+    const unsigned a_lane = (unsigned)((((wm * 4 + 2 * tg + (tp >> 1)) * PXP + 8 * kh + tq) * 16) + (tp & 1) * 8);
+    const unsigned b_lane = (unsigned)((((wn * 4 + 2 * tg + (tp >> 1)) * PXP + 8 * kh + tq) * 16) + (tp & 1) * 8);
+
+    // ---- staging: slot position i = (wid + 8 k) * 64 + lane of a row image [part][group][PXP]
+    i32x4s xr, dr;
+    unsigned x_off[NXI], d_off[NDI];
+    auto setup_strip = [&](int b, int x0) __attribute__((always_inline)) {
+        if (G == 1) {
+            xr = sp_rsrc4(reinterpret_cast<const unsigned*>(a.xs) + (int64_t)b * a.xs_bs, (int64_t)a.Cin * HW * 4);
+            dr = sp_rsrc4(reinterpret_cast<const unsigned*>(a.dzs) + (int64_t)b * a.dzs_bs, (int64_t)a.Cout * HW * 4);
+        } else {
+            xr = sp_rsrc4(a.xs, ((int64_t)(a.B - 1) * a.xs_bs + (int64_t)a.Cin * HW) * 4);
+            dr = sp_rsrc4(a.dzs, ((int64_t)(a.B - 1) * a.dzs_bs + (int64_t)a.Cout * HW) * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < NXI; ++k) {
+            const int i = (wid + 8 * k) * 64 + lane;
+            const int part = i / X_PART, s = (i % X_PART) / PXP, pi = i % PXP;
+            const int img = G == 1 ? 0 : pi / (a.W + 2), xx = G == 1 ? x0 - 1 + pi : pi % (a.W + 2) - 1;
+            const bool ok = i < X_ROW && pi < (G == 1 ? 66 : G * (a.W + 2)) && xx >= 0 && xx < a.W && ci0 + 8 * s < a.Cin;
+            const int64_t img_off = G == 1 ? 0 : (int64_t)(b * G + img) * a.xs_bs * 4;
+            x_off[k] = ok ? (unsigned)(img_off + ((int64_t)((ci0 / 8 + s) * a.H) * 2 + part) * a.W * 16 + xx * 16) : OOB_S;
+        }
+#pragma unroll
+        for (int k = 0; k < NDI; ++k) {
+            const int i = (wid + 8 * k) * 64 + lane;
+            const int part = i / DZ_PART, s = (i % DZ_PART) / PXP, pi = i % PXP;
+            const int img = G == 1 ? 0 : pi / a.W, xx = G == 1 ? x0 + pi : pi % a.W;
+            const bool ok = i < DZ_BUF && pi < 64 && xx < a.W && co0 + 8 * s < a.Cout;
+            const int64_t img_off = G == 1 ? 0 : (int64_t)(b * G + img) * a.dzs_bs * 4;
+            d_off[k] = ok ? (unsigned)(img_off + ((int64_t)((co0 / 8 + s) * a.H) * 2 + part) * a.W * 16 + xx * 16) : OOB_S;
+        }
+    };
+    // row y of the strip into ring slot / dz buffer; rows outside the image are zeros (every lane out of range)
+    auto dma_x = [&](int y, int k) __attribute__((always_inline)) {
+        if ((wid + 8 * k) * 64 < X_ROW) {
+            const bool ok = y >= 0 && y < a.H;
+            sp_dma16(xr, x_base + (unsigned)(((y & 3) * X_ROW + (wid + 8 * k) * 64) * 16), ok ? x_off[k] : OOB_S, ok ? (unsigned)(y * 2 * a.W * 16) : 0u);
+        }
+    };
+    auto dma_dz = [&](int y, int k) __attribute__((always_inline)) {
+        if ((wid + 8 * k) * 64 < DZ_BUF) {
+            const bool ok = y >= 0 && y < a.H;
+            sp_dma16(dr, dz_base + (unsigned)(((y & 1) * DZ_BUF + (wid + 8 * k) * 64) * 16), ok ? d_off[k] : OOB_S, ok ? (unsigned)(y * 2 * a.W * 16) : 0u);
+        }
+    };
+
+    int u = u0;
+    while (u < u1) {
+        const int yb = u % a.H, sb = u / a.H;
+        const int tx = sb % a.tilesX, b = sb / a.tilesX;
+        const int x0 = G == 1 ? tx * 64 : 0;
+        const int ye = min(a.H, yb + (u1 - u));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                              // every wave is done with the previous run's ring and dz buffers
+        setup_strip(b, x0);
+#pragma unroll
+        for (int k = 0; k < NXI; ++k) {
+            dma_x(yb - 1, k);
+            dma_x(yb, k);
+            dma_x(yb + 1, k);
+        }
+#pragma unroll
+        for (int k = 0; k < NDI; ++k) dma_dz(yb, k);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int y = yb; y < ye; ++y) {
+            // unit y: MFMAs on dz buffer y & 1 and ring rows y - 1 .. y + 1; the rows of unit y + 1 (dz row y + 1, x row y + 2) go
+            // by DMA into the other dz buffer and the ring slot of row y - 2 (both last read in unit y - 1), spread over the k-steps
+            const bool more = y + 1 < ye;
+            const unsigned ab = dz_base + (unsigned)((y & 1) * DZ_BUF * 16) + a_lane;
+            unsigned bb[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) bb[ky] = x_base + (unsigned)((((y - 1 + ky) & 3) * X_ROW) * 16) + b_lane;
+#pragma unroll
+            for (int kk = 0; kk < NKS; ++kk) {
+                const int kst = grp * 2 + kk;                                  // 16-pixel k-step of the unit
+                const int dpx = 16 * kst;                                      // dz pixel slot
+                const int xpx = G == 1 ? 16 * kst : (kst >> 1) * 34 + (kst & 1) * 16;      // x pixel slot of tap kx = 0
+                if (more) {
+                    constexpr int NP = NXI + NDI, PER = (NP + NKS - 1) / NKS;
+#pragma unroll
+                    for (int q = 0; q < PER; ++q) {
+                        const int pc = kk * PER + q;
+                        if (pc < NDI) dma_dz(y + 1, pc);
+                        else if (pc < NP) dma_x(y + 2, pc - NDI);
+                    }
+                }
+                const u32x4s Ah = swp_frag(ab + dpx * 16), Am = swp_frag(ab + (DZ_PART + dpx) * 16);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const u32x4s Bh = swp_frag(bb[ky] + (xpx + kx) * 16), Bm = swp_frag(bb[ky] + (X_PART + xpx + kx) * 16);
+                        const int t = ky * 3 + kx;
+                        if constexpr (F16) {
+                            const f16x8 ah = __builtin_bit_cast(f16x8, Ah), am = __builtin_bit_cast(f16x8, Am);
+                            const f16x8 bh = __builtin_bit_cast(f16x8, Bh), bm = __builtin_bit_cast(f16x8, Bm);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, bh, acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bm, acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+                        } else {
+                            const bf16x8 ah = __builtin_bit_cast(bf16x8, Ah), am = __builtin_bit_cast(bf16x8, Am);
+                            const bf16x8 bh = __builtin_bit_cast(bf16x8, Bh), bm = __builtin_bit_cast(bf16x8, Bm);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+                        }
+                    }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        u += ye - yb;
+    }
+
+    const int64_t n = (int64_t)a.Cout * a.Cin;
+    const int ci = ci0 + wn * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float* o = a.slab + ((int64_t)(COT == 64 ? ks * 2 + grp : ks) * 9 + t) * n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (co < a.Cout && ci < a.Cin) o[(int64_t)co * a.Cin + ci] = acc[t][r] * a.out_scale;
         }
     }
 }
@@ -1257,7 +1538,8 @@ int64_t onet_conv3x3_split_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W
 }
 
 static int split_wgrad_impl(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs, float* dw, void* ws, int64_t ws_bytes,
-                            int B, int Cin, int Cout, int H, int W, int accumulate, void* stream, const float* nsave, int n_groups) {
+                            int B, int Cin, int Cout, int H, int W, int accumulate, void* stream, const float* nsave, int n_groups,
+                            int f16 = 0, const unsigned* x_amax = nullptr, const unsigned* dz_amax = nullptr) {
     ONET_REQUIRE(x && dz && dw && ws, "conv3x3_split_wgrad: null pointer");
     ONET_REQUIRE(!nsave || ((n_groups == 1 || n_groups == 2) && B % n_groups == 0),
                  "conv3x3_split_wgrad_norm: one or two statistics groups of equal size");
@@ -1272,17 +1554,21 @@ static int split_wgrad_impl(const float* x, int64_t x_bs, const float* dz, int64
                             ((int64_t)(B - 1) * dz_bs + (int64_t)Cout * H * W) * 4 < (1ll << 31)),
                  "conv3x3_split_wgrad: on maps narrower than 64 pixels the whole batch must lie within the 2 GiB buffer-resource range");
     const int COT = split_wgrad_cot(Cout, W), slabs = COT == 64 ? 2 : 1;
-    SwArgs a{x, x_bs, dz, dz_bs, (float*)ws, B, Cin, Cout, H, W, cdiv(Cin, 64), cdiv(Cout, COT), 1, 1, nsave, nsave ? B / n_groups : B};
+    ONET_REQUIRE(!f16 || dz_amax, "conv3x3_split_wgrad_f16: the fp16 parts need the magnitude slots of dz");
+    SwArgs a{x, x_bs, dz, dz_bs, (float*)ws, B, Cin, Cout, H, W, cdiv(Cin, 64), cdiv(Cout, COT), 1, 1, nsave, nsave ? B / n_groups : B,
+             x_amax, dz_amax};
     split_wgrad_plan(B, Cin, Cout, H, W, a.splitK, a.tilesX);
     const int64_t need = (int64_t)a.splitK * slabs * 9 * Cout * Cin * 4;
     ONET_REQUIRE(ws_bytes >= need, "conv3x3_split_wgrad: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
     const int64_t blocks = (int64_t)a.splitK * a.ciTiles * a.coTiles;
     const dim3 grid((unsigned)blocks), blk(512);
     hipStream_t st = as_stream(stream);
-#define ONET_SW_LAUNCH(G_, COT_)                                                                              \
-    do {                                                                                                      \
-        if (nsave) hipLaunchKernelGGL((conv3x3_split_wgrad_kernel<G_, COT_, true>), grid, blk, 0, st, a);     \
-        else hipLaunchKernelGGL((conv3x3_split_wgrad_kernel<G_, COT_, false>), grid, blk, 0, st, a);          \
+#define ONET_SW_LAUNCH(G_, COT_)                                                                                      \
+    do {                                                                                                              \
+        if (nsave && f16) hipLaunchKernelGGL((conv3x3_split_wgrad_kernel<G_, COT_, true, true>), grid, blk, 0, st, a);    \
+        else if (nsave) hipLaunchKernelGGL((conv3x3_split_wgrad_kernel<G_, COT_, true, false>), grid, blk, 0, st, a);     \
+        else if (f16) hipLaunchKernelGGL((conv3x3_split_wgrad_kernel<G_, COT_, false, true>), grid, blk, 0, st, a);       \
+        else hipLaunchKernelGGL((conv3x3_split_wgrad_kernel<G_, COT_, false, false>), grid, blk, 0, st, a);               \
     } while (0)
     if (COT == 128) {
         if (G == 1) ONET_SW_LAUNCH(1, 128);
@@ -1308,24 +1594,103 @@ int onet_conv3x3_split_wgrad_norm(const float* z_prev, int64_t z_bs, const float
     return split_wgrad_impl(z_prev, z_bs, dz, dz_bs, dw, ws, ws_bytes, B, Cin, Cout, H, W, accumulate, stream, save, n_groups);
 }
 
-int onet_conv3x3_split_pack_weights(const float* w, void* wq_fwd, void* wq_dgrad, int Cout, int Cin, int fwd_f16, void* stream) {
+int onet_conv3x3_split_wgrad_pre_ok(int B, int Cin, int Cout, int H, int W) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || (Cin % 8) || (Cout % 8)) return 0;
+    if (W >= 64) return 1;
+    return (W == 32 && B % 2 == 0) ? 1 : 0;
+}
+
+int onet_conv3x3_split_wgrad_pre(const void* xs, int64_t xs_bs, const void* dzs, int64_t dzs_bs, int f16, float out_scale, float* dw,
+                                 void* ws, int64_t ws_bytes, int B, int Cin, int Cout, int H, int W, int accumulate, void* stream) {
+    ONET_REQUIRE(xs && dzs && dw && ws, "conv3x3_split_wgrad_pre: null pointer");
+    ONET_REQUIRE(onet_conv3x3_split_wgrad_pre_ok(B, Cin, Cout, H, W),
+                 "conv3x3_split_wgrad_pre: needs Cin, Cout %% 8 == 0 and W >= 64, or W = 32 with an even batch");
+    ONET_REQUIRE((xs_bs & 3) == 0 && (dzs_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(xs) & 15) == 0 && (reinterpret_cast<uintptr_t>(dzs) & 15) == 0,
+                 "conv3x3_split_wgrad_pre: 16-byte aligned slots required");
+    ONET_REQUIRE(xs_bs >= (int64_t)Cin * H * W && dzs_bs >= (int64_t)Cout * H * W, "conv3x3_split_wgrad_pre: batch stride too small");
+    ONET_REQUIRE((int64_t)std::max(Cin, Cout) * H * W * 4 < (1ll << 31), "conv3x3_split_wgrad_pre: image exceeds the 2 GiB buffer-resource range");
+    const int G = split_wgrad_group(W);
+    ONET_REQUIRE(G == 1 || (((int64_t)(B - 1) * xs_bs + (int64_t)Cin * H * W) * 4 < (1ll << 31) &&
+                            ((int64_t)(B - 1) * dzs_bs + (int64_t)Cout * H * W) * 4 < (1ll << 31)),
+                 "conv3x3_split_wgrad_pre: on 32-pixel maps the whole batch must lie within the 2 GiB buffer-resource range");
+    const int COT = split_wgrad_cot(Cout, W), slabs = COT == 64 ? 2 : 1;
+    SwPreArgs a{xs, xs_bs, dzs, dzs_bs, (float*)ws, B, Cin, Cout, H, W, cdiv(Cin, 64), cdiv(Cout, COT), 1, 1, out_scale};
+    split_wgrad_plan(B, Cin, Cout, H, W, a.splitK, a.tilesX);
+    const int64_t need = (int64_t)a.splitK * slabs * 9 * Cout * Cin * 4;
+    ONET_REQUIRE(ws_bytes >= need, "conv3x3_split_wgrad_pre: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
+    const int64_t blocks = (int64_t)a.splitK * a.ciTiles * a.coTiles;
+    const dim3 grid((unsigned)blocks), blk(512);
+    hipStream_t st = as_stream(stream);
+    const int lds = (4 * 2 * 8 * SWP_PXP + 2 * 2 * (COT / 8) * SWP_PXP) * 16;
+#define ONET_SWP_LAUNCH(G_, COT_, F_)                                                                              \
+    do {                                                                                                           \
+        auto kern = conv3x3_split_wgrad_pre_kernel<G_, COT_, F_>;                                                  \
+        static PerDeviceOnce once;                                                                                 \
+        if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        hipLaunchKernelGGL(kern, grid, blk, lds, st, a);                                                           \
+    } while (0)
+#define ONET_SWP_F(G_, COT_) do { if (f16) ONET_SWP_LAUNCH(G_, COT_, true); else ONET_SWP_LAUNCH(G_, COT_, false); } while (0)
+    if (COT == 128) {
+        if (G == 1) ONET_SWP_F(1, 128);
+        else ONET_SWP_F(2, 128);
+    } else if (G == 1) ONET_SWP_F(1, 64);
+    else ONET_SWP_F(2, 64);
+#undef ONET_SWP_F
+#undef ONET_SWP_LAUNCH
+    int rc = check_launch("conv3x3_split_wgrad_pre_kernel");
+    if (rc) return rc;
+    return launch_wgrad_reduce((const float*)ws, dw, a.splitK * slabs, 9, Cout, Cin, 0, accumulate, as_stream(stream));
+}
+
+int onet_conv3x3_split_pack_weights(const float* w, void* wq_fwd, void* wq_dgrad, void* amax_ws, int Cout, int Cin, int fwd_f16,
+                                    int dgrad_f16, void* stream) {
     ONET_REQUIRE(w && (wq_fwd || wq_dgrad), "conv3x3_split_pack_weights: null pointer");
+    ONET_REQUIRE(amax_ws || !(fwd_f16 || dgrad_f16), "conv3x3_split_pack_weights: the fp16 packs need the 8 KB magnitude workspace");
+    if (fwd_f16 || dgrad_f16) {
+        (void)hipMemsetAsync(amax_ws, 0, AMAX_SLOTS * AMAX_STRIDE * sizeof(unsigned), as_stream(stream));
+        const int64_t nw = (int64_t)Cout * Cin * 9;
+        hipLaunchKernelGGL(absmax_slots_kernel, dim3((unsigned)std::min<int64_t>((nw + 1023) / 1024, 1024)), dim3(256), 0, as_stream(stream), w,
+                           nw, (unsigned*)amax_ws);
+        int rc0 = check_launch("absmax_slots_kernel");
+        if (rc0) return rc0;
+    }
     ONET_REQUIRE(Cout > 0 && Cin > 0, "conv3x3_split_pack_weights: bad shape");
     ONET_REQUIRE(!wq_fwd || (Cin % 16) == 0, "conv3x3_split_pack_weights: the forward pack needs Cin %% 16 == 0");
     const int64_t n = (int64_t)std::max(Cin, ((Cout + 15) / 16) * 16) * 9 * std::max(Cin, Cout);
     const int blocks = (int)std::min<int64_t>((n + 255) / 256, 8192);
     if (wq_fwd) {
-        hipLaunchKernelGGL(pack3x3_split_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, (__bf16*)wq_fwd, Cout, Cin, 0, fwd_f16 != 0);
+        hipLaunchKernelGGL(pack3x3_split_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, (__bf16*)wq_fwd, Cout, Cin, 0, fwd_f16 != 0,
+                           (const unsigned*)amax_ws);
         int rc = check_launch("pack3x3_split_kernel");
         if (rc) return rc;
     }
-    if (wq_dgrad) hipLaunchKernelGGL(pack3x3_split_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, (__bf16*)wq_dgrad, Cout, Cin, 1, 0);
+    if (wq_dgrad) hipLaunchKernelGGL(pack3x3_split_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, (__bf16*)wq_dgrad, Cout, Cin, 1,
+                                     dgrad_f16 != 0, (const unsigned*)amax_ws);
     return check_launch("pack3x3_split_kernel");
 }
 
 int onet_conv3x3_split_fwd(const float* x, int64_t x_bs, const void* wq, int wq_f16, float* z, int64_t z_bs, int B, int Cin, int Cout,
                            int H, int W, void* stream) {
     return split_fwd(x, x_bs, wq, z, z_bs, B, Cin, Cout, H, W, stream, nullptr, wq_f16);
+}
+
+int onet_absmax_slots(const float* x, int64_t n, void* slots, void* stream) {
+    ONET_REQUIRE(x && slots && n > 0, "absmax_slots: bad args");
+    hipLaunchKernelGGL(absmax_slots_kernel, dim3((unsigned)std::min<int64_t>((n + 1023) / 1024, 4096)), dim3(256), 0, as_stream(stream), x, n,
+                       (unsigned*)slots);
+    return check_launch("absmax_slots_kernel");
+}
+
+int onet_conv3x3_split_conv_amax(const float* x, int64_t x_bs, const void* x_amax, int scale_always, const void* wq, float* z, int64_t z_bs,
+                                 float* part, int B, int Cin, int Cout, int H, int W, void* stream) {
+    return split_fwd(x, x_bs, wq, z, z_bs, B, Cin, Cout, H, W, stream, part, 1, nullptr, 0, (const unsigned*)x_amax, scale_always);
+}
+
+int onet_conv3x3_split_wgrad_f16(const float* x, int64_t x_bs, const void* x_amax, const float* save, int n_groups, const float* dz,
+                                 int64_t dz_bs, const void* dz_amax, float* dw, void* ws, int64_t ws_bytes, int B, int Cin, int Cout,
+                                 int H, int W, int accumulate, void* stream) {
+    return split_wgrad_impl(x, x_bs, dz, dz_bs, dw, ws, ws_bytes, B, Cin, Cout, H, W, accumulate, stream, save, save ? n_groups : 0, 1,
+                            (const unsigned*)x_amax, (const unsigned*)dz_amax);
 }
 
 int onet_conv3x3_split_fwd_norm(const float* z_prev, int64_t z_bs, const float* save, int n_groups, const void* wq, int wq_f16,

@@ -42,7 +42,7 @@ class ConvBNReLUFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, running_mean, running_var, training, momentum, eps, packed, out, groups=1,
-                link_out=None, link_in=None, b16=None):
+                link_out=None, link_in=None, b16=None, aux=None):
         """b16 (bf16 storage, BASELINE config 3 only): dict with "x16" = the bf16 copy of x written by its producer (or None),
         "out16" = a plane-contiguous bf16 destination for the copy of the output (or None: allocated); forward leaves the
         output's copy in b16["a16"] for the caller to attach to the returned tensor."""
@@ -60,11 +60,15 @@ class ConvBNReLUFn(torch.autograd.Function):
         if link_in is not None and link_in.get("deferred"):
             norm = (link_in["z"], link_in["save"])
         x16 = None if b16 is None else b16.get("x16")
+        # the magnitude slots x's producer left on it (ops.tag_amax): the fp16-split kernel's overflow guard
+        # (aux: {"x_amax": slots of x or None} in, {"a_amax": slots of the output} out -- DoubleConv._unit tags the tensors)
+        x_amax = aux.get("x_amax") if (aux is not None and b16 is None and norm is None) else None
         # training: the F(4x4) kernel emits the BatchNorm statistics records from its epilogue (cm), where it can
         if norm is not None:
             z, cm = ops.conv3x3_fwd_bn_partials(None, packed, norm=norm)
         else:
-            z, cm = ops.conv3x3_fwd_bn_partials(x, packed, x16=x16) if training else (ops.conv3x3_auto(x, packed, 0, x16=x16), None)
+            z, cm = ops.conv3x3_fwd_bn_partials(x, packed, x16=x16, amax=x_amax) if training else \
+                (ops.conv3x3_auto(x, packed, 0, x16=x16, amax=x_amax), None)
         # `out` is None or a 1-tuple holding a plane-contiguous destination view (kept out of autograd's sight)
         dst = None if out is None else out[0]
         G = groups if (training and groups > 1) else 1
@@ -80,6 +84,9 @@ class ConvBNReLUFn(torch.autograd.Function):
         save_all = torch.empty((G, 4, C), dtype=torch.float32, device=z.device)
         Bz, _, Hz, Wz = z.shape
         pooled = None
+        # magnitude slots of the activation written here (all statistics groups share them), for the convolution that consumes it
+        a_amax = ops.new_amax(z.device) if (b16 is None and not defer and z.is_cuda and ops.split_f16() and ops.split_enabled()
+                                            and ops.conv_algo() in ("auto", "split")) else None
         if want_pool is not None and ops.FUSE_POOL and not drop and Hz % 2 == 0 and Wz % 4 == 0:
             only16 = bool(want_pool.get("bf16_only")) and a16 is not None
             py = None if only16 else torch.empty((Bz, C, Hz // 2, Wz // 2), dtype=torch.float32, device=z.device)
@@ -95,10 +102,10 @@ class ConvBNReLUFn(torch.autograd.Function):
                 if o is None and not drop:
                     o = torch.empty_like(zg)
                 if ops.bn_relu_apply_pool(zg, sv, o, o16, None if pooled[0] is None else pooled[0][sl],
-                                          None if pooled[1] is None else pooled[1][sl]):
+                                          None if pooled[1] is None else pooled[1][sl], amax=a_amax):
                     return o
                 pooled = None                       # shape not taken: the separate pooling pass runs as before
-            return ops.bn_relu_apply(zg, sv, out=o, out16=o16, no_fp32=drop)
+            return ops.bn_relu_apply(zg, sv, out=o, out16=o16, no_fp32=drop, amax=a_amax)
 
         if G == 1:
             if training:
@@ -124,6 +131,8 @@ class ConvBNReLUFn(torch.autograd.Function):
                       None if a16 is None else a16[g * Bg:(g + 1) * Bg], slice(g * Bg, (g + 1) * Bg))
         if b16 is not None:
             b16["a16"] = a16
+        if aux is not None:
+            aux["a_amax"] = a_amax
         # (the weight gradient reads the bf16 copy too; saved WITH the tensors so that backward releases it -- a ctx attribute
         # would live as long as the caller holds the loss)
         ctx.save_for_backward(x, z, save_all, x16, None if norm is None else norm[0], None if norm is None else norm[1])
@@ -165,10 +174,14 @@ class ConvBNReLUFn(torch.autograd.Function):
         if (ops.bf16_storage() and ops.wgrad_takes_bf16(ctx.wshape[1], Hz, Wz) and Wz % 8 == 0 and
                 (not need_x or ops.conv3x3_algo(Bz, Cz, ctx.wshape[1], Hz, Wz) == "bf16")):
             dz16 = torch.empty(z.shape, dtype=torch.bfloat16, device=z.device)
+        # fp16-split gradient kernels (Settings.grad_f16): the BatchNorm backward records max |dz| on its way out, and the input- and
+        # weight-gradient kernels that consume dz scale it by a power of two chosen from that before splitting it into fp16 parts
+        dz_amax = ops.new_amax(z.device) if (dz16 is None and ops.grad_f16() and ops.conv_algo() in ("auto", "split")
+                                             and ops.split_enabled() and Wz >= 16) else None
         if G == 1:
             dz, dgamma, dbeta = ops.bn_relu_bwd(da, z, save_all[0], ctx.training, need_affine_grads=(need_g or need_b),
                                                 affine_out=aff, red=None if rec is None else (rec, 0, rec.shape[1]),
-                                                red4=None if rec4 is None else (rec4, 0, rec4.shape[0]), out16=dz16)
+                                                red4=None if rec4 is None else (rec4, 0, rec4.shape[0]), out16=dz16, amax=dz_amax)
         else:
             Bg = z.shape[0] // G
             dz = torch.empty_like(z) if dz16 is None else None
@@ -182,11 +195,12 @@ class ConvBNReLUFn(torch.autograd.Function):
                                                    affine_out=aff if g == 0 else None,
                                                    red=None if rec is None else (rec, g * npg, npg),
                                                    red4=None if rec4 is None else (rec4, g * np4, np4),
-                                                   out16=None if dz16 is None else dz16[sl])
+                                                   out16=None if dz16 is None else dz16[sl], amax=dz_amax)
         if need_w and nz is not None:      # normalise on load: the operand is relu(bn(nz)) of the unit below, applied in the staging
-            dw = ops.conv3x3_split_wgrad(nz, dz, ctx.wshape, out=ops.grad_slot_if_free(pw), norm=nsave)
+            dw = ops.conv3x3_split_wgrad(nz, dz, ctx.wshape, out=ops.grad_slot_if_free(pw), norm=nsave, dz_amax=dz_amax)
         else:
-            dw = ops.conv3x3_wgrad_auto(x, dz, ctx.wshape, out=ops.grad_slot_if_free(pw), x16=x16, dz16=dz16) if need_w else None
+            dw = ops.conv3x3_wgrad_auto(x, dz, ctx.wshape, out=ops.grad_slot_if_free(pw), x16=x16, dz16=dz16,
+                                        dz_amax=dz_amax) if need_w else None
         dx = None
         if need_x and dz16 is not None:
             dx = ops.conv3x3_auto(None, ctx.packed, 1, x16=dz16)
@@ -201,12 +215,12 @@ class ConvBNReLUFn(torch.autograd.Function):
                 dx, r = fused
                 lk["da"], lk["rec"] = dx, r
             else:
-                dx = ops.conv3x3_auto(dz, ctx.packed, 1)
+                dx = ops.conv3x3_auto(dz, ctx.packed, 1, amax=dz_amax)
         if ctx.link_in is not None:                 # whatever path ran: the unit below's (z, save) must not outlive this backward
             ctx.link_in.pop("z", None)
             ctx.link_in.pop("save", None)
         return (dx, dw, (dgamma if need_g else None), (dbeta if need_b else None), None, None, None, None, None, None,
-                None, None, None, None, None)
+                None, None, None, None, None, None)
 
 
 @_carries_settings

@@ -120,11 +120,13 @@ class DoubleConv(nn.Module):
             bn.num_batches_tracked.add_(groups)
         # bf16 storage (BASELINE config 3): the bf16 copy of x its producer left, a destination for the copy of the output
         b16 = {"x16": ops.b16_of(x), "out16": out16, "drop_fp32": drop_fp32} if ops.bf16_storage() else None
+        # magnitude slots (ops.tag_amax): what x's producer recorded of it goes in, what this unit records of its output comes out
+        aux = {"x_amax": ops.amax_of(x)}
         a = Fn.ConvBNReLUFn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                  training, bn.momentum, bn.eps, conv.packed(), out, groups, link_out, link_in, b16)
+                                  training, bn.momentum, bn.eps, conv.packed(), out, groups, link_out, link_in, b16, aux)
         if b16 is not None:
             ops.tag_b16(a, b16.get("a16"))
-        return a
+        return ops.tag_amax(a, aux.get("a_amax"))
 
     def forward(self, x, out=None, groups=1, pool_link=None, out16=None):
         """`out`: optional plane-contiguous [B, Cout, H, W] destination view (the skip half of a concat buffer);
@@ -306,9 +308,11 @@ class UNet(nn.Module):
                     c = nxt.maxpool_conv[1].double_conv[0]
                     b16 = {"bf16_only": ops.consumer_reads_bf16(t.shape[0], c.in_channels, c.out_channels, t.shape[2] // 2,
                                                                 t.shape[3] // 2)}
+                am = ops.amax_of(t)
                 outs = Fn.SkipPoolFn.apply(t, returned, link, b16)
                 if b16 is not None:
                     ops.tag_b16(outs[1], b16.get("y16"))     # the pooled tensor's bf16 copy, for the next block's first conv
+                ops.tag_amax(outs[1], am)                    # max-pooling keeps the maximum: the same slots bound the pooled tensor
                 return outs
             return (t, None, t) if returned else (t, None)
 

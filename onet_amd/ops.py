@@ -28,12 +28,20 @@ class Settings:
       bf16_storage  under conv == "bf16": producers write bf16 copies of the conv operands                  (default BF16_STORAGE)
       lazy_nan      OV:234's NaN assertion deferred to FlatAdam.step()                                      (default LAZY_NAN_CHECK)
       split         under conv == "auto": fp32 3x3 convolutions on the bf16 matrix pipe by operand splitting   (default SPLIT_AUTO)
-      bn_on_load    the second convolution of a DoubleConv applies the first unit's BatchNorm + ReLU on load     (default BN_ON_LOAD)"""
-    __slots__ = ("conv", "twin", "convt_bf16", "bf16_storage", "lazy_nan", "split", "bn_on_load")
+      bn_on_load    the second convolution of a DoubleConv applies the first unit's BatchNorm + ReLU on load     (default BN_ON_LOAD)
+      split_f16     split forward convolution on fp16 parts (22-bit operands); False: bf16 parts (16-bit)         (default SPLIT_F16)
+      grad_f16      split input / weight gradients on fp16 parts of power-of-two-scaled operands; False: bf16      (default SPLIT_GRAD_F16)
+      split_dgrad   input gradients may take the split kernels (False: diagnostic, fp32-MFMA kernels)             (default SPLIT_DGRAD)
+      stem_fused    the stem convolution + its BatchNorm statistics in one streaming pass                          (default STEM_FUSED)
+      sync_bn       BatchNorm statistics all-gathered over the process group                                       (default SYNC_BN)"""
+    __slots__ = ("conv", "twin", "convt_bf16", "bf16_storage", "lazy_nan", "split", "bn_on_load", "split_f16", "grad_f16", "split_dgrad",
+                 "stem_fused", "sync_bn")
 
-    def __init__(self, conv=None, twin=None, convt_bf16=None, bf16_storage=None, lazy_nan=None, split=None, bn_on_load=None):
+    def __init__(self, conv=None, twin=None, convt_bf16=None, bf16_storage=None, lazy_nan=None, split=None, bn_on_load=None,
+                 split_f16=None, grad_f16=None, split_dgrad=None, stem_fused=None, sync_bn=None):
         self.conv, self.twin, self.convt_bf16, self.bf16_storage, self.lazy_nan = conv, twin, convt_bf16, bf16_storage, lazy_nan
         self.split, self.bn_on_load = split, bn_on_load
+        self.split_f16, self.grad_f16, self.split_dgrad, self.stem_fused, self.sync_bn = split_f16, grad_f16, split_dgrad, stem_fused, sync_bn
 
     def replace(self, **kw):
         out = Settings(*(getattr(self, k) for k in self.__slots__))
@@ -86,6 +94,26 @@ def twin_enabled():
 
 def lazy_nan_check():
     return bool(_setting("lazy_nan", LAZY_NAN_CHECK))
+
+
+def split_f16():
+    return bool(_setting("split_f16", SPLIT_F16))
+
+
+def grad_f16():
+    return bool(_setting("grad_f16", SPLIT_GRAD_F16))
+
+
+def split_dgrad():
+    return bool(_setting("split_dgrad", SPLIT_DGRAD))
+
+
+def stem_fused():
+    return bool(_setting("stem_fused", STEM_FUSED))
+
+
+def sync_bn():
+    return bool(_setting("sync_bn", SYNC_BN))
 
 
 def split_enabled():
@@ -497,20 +525,21 @@ def pack3x3_auto(w):
     return Packed3x3(w)
 
 
-def conv3x3_auto(x, pk, direction, out=None, x16=None):
+def conv3x3_auto(x, pk, direction, out=None, x16=None, amax=None):
     """direction 0: forward (Cin -> Cout); 1: dgrad (Cout -> Cin) with the flipped/transposed pack.
-    x16: a bf16 copy of x (bf16 storage); x itself may then be None (shape taken from x16)."""
+    x16: a bf16 copy of x (bf16 storage); x itself may then be None (shape taken from x16).
+    amax: the 64 magnitude slots of x (int32 [64], written by its producer): what the fp16 split kernels scale x by."""
     Ci, Co = (pk["Cin"], pk["Cout"]) if direction == 0 else (pk["Cout"], pk["Cin"])
     shp = (x if x is not None else x16).shape
     algo = conv3x3_algo(shp[0], Ci, Co, shp[2], shp[3])
-    if algo == "split" and direction == 1 and not SPLIT_DGRAD:       # diagnostic: input gradients on the fp32-MFMA kernels
+    if algo == "split" and direction == 1 and not split_dgrad():     # diagnostic: input gradients on the fp32-MFMA kernels
         with using(active_settings().replace(split=False) if active_settings() is not None else Settings(split=False)):
             algo = conv3x3_algo(shp[0], Ci, Co, shp[2], shp[3])
     wq = pk.get_pack(algo)[direction]
     if algo == "winograd4":
         return conv3x3_winograd4(x, wq, Co, out=out)
     if algo == "split":
-        return conv3x3_split(x, wq, Co, out=out)
+        return conv3x3_split(x, wq, Co, out=out, amax=amax, always=direction == 1)
     if algo == "bf16":
         return conv3x3_bf16(x, wq, Co, out=out, x16=x16)
     if algo == "winograd":
@@ -525,12 +554,16 @@ CONVT_SPLIT_MIN_BLOCKS = int(_os.environ["ONET_CONVT_SPLIT_MIN_BLOCKS"]) if "ONE
 CONVT_SPLIT = _os.environ.get("ONET_CONVT_SPLIT", "1") != "0"     # 0: the ConvTranspose2d GEMMs stay on the fp32 MFMA pipe
 SPLIT_F16 = _os.environ.get("ONET_SPLIT_F16", "1") != "0"         # 0: the forward split kernel takes bf16 parts like the gradients
 SPLIT_DGRAD = _os.environ.get("ONET_SPLIT_DGRAD", "1") != "0"     # 0 (diagnostic): input gradients stay on the fp32-MFMA kernels
+# 1: split input / weight gradients on fp16 parts of power-of-two-scaled operands (22-bit operands; 15x lower per-layer error than
+# the bf16 parts, but no change in the model-level worst gradient error -- 9.4e-5 either way on b4_c1_256 -- and +1.3 ms/step: the
+# fp16 MFMAs hold a lower clock); default 0: bf16 parts, as in round 3
+SPLIT_GRAD_F16 = _os.environ.get("ONET_SPLIT_GRAD_F16", "0") != "0"
 SPLIT_WGRAD_MINW = int(_os.environ.get("ONET_SPLIT_WGRAD_MINW", "16"))   # 64: the 32- and 16-pixel levels keep the Winograd weight gradients
 SPLIT_AUTO = _os.environ.get("ONET_SPLIT", "1") != "0"          # 0: "auto" never selects the split-bf16 kernel (round-2 dispatch)
 STEM_FUSED = _os.environ.get("ONET_STEM_FUSED", "1") != "0"      # 0: the stem takes the direct MFMA kernel + a statistics pass
 
 
-def conv3x3_fwd_bn_partials(x, pk, x16=None, norm=None):
+def conv3x3_fwd_bn_partials(x, pk, x16=None, norm=None, amax=None):
     """Forward 3x3 convolution of a Conv-BatchNorm pair (OV:47-48, 51-52): -> (z, cm).  cm = the channel-major
     BatchNorm records [Cout, nparts, 3] the F(4x4) kernel's epilogue emits (image-major: nparts / B per image), or None
     where the selected kernel does not emit them (then `bn_train_coeffs` runs its own statistics pass).
@@ -542,7 +575,7 @@ def conv3x3_fwd_bn_partials(x, pk, x16=None, norm=None):
         require_gpu(z_prev, save)
         zs, zbs = plane(z_prev)
         B, _, H, W = zs.shape
-        nparts = int(_lib.load().onet_conv3x3_split_nparts(B, H, W)) if (FUSE_BN_STATS and not SYNC_BN) else 0
+        nparts = int(_lib.load().onet_conv3x3_split_nparts(B, H, W)) if (FUSE_BN_STATS and not sync_bn()) else 0
         out = torch.empty((B, Co, H, W), dtype=F32, device=zs.device)
         cm = torch.empty((Co, nparts, 3), dtype=F32, device=zs.device) if nparts > 0 else None
         e0 = _prof_begin()
@@ -552,7 +585,7 @@ def conv3x3_fwd_bn_partials(x, pk, x16=None, norm=None):
         _prof_end("conv3x3_split_kernel", 2.0 * B * H * W * Ci * Co * 9, e0, 4.0 * (B * H * W * (Ci + Co) + 9 * Ci * Co))
         return out, cm
     B, _, H, W = (x if x is not None else x16).shape
-    if Ci <= 4 and x is not None and STEM_FUSED and FUSE_BN_STATS and not SYNC_BN and hasattr(pk, "w"):
+    if Ci <= 4 and x is not None and stem_fused() and FUSE_BN_STATS and not sync_bn() and hasattr(pk, "w"):
         # the stem (Cin = n_channels): one streaming pass writes z and its statistics records (stem.hip)
         nparts = int(_lib.load().onet_conv3x3_stem_nparts(B, Ci, Co, H, W))
         if nparts > 0:
@@ -567,9 +600,9 @@ def conv3x3_fwd_bn_partials(x, pk, x16=None, norm=None):
             return out, cm
     algo = conv3x3_algo(B, Ci, Co, H, W)
     nparts = 0
-    if algo == "winograd4" and FUSE_BN_STATS and not SYNC_BN:
+    if algo == "winograd4" and FUSE_BN_STATS and not sync_bn():
         nparts = int(_lib.load().onet_conv3x3_winograd4_nparts(B, H, W))
-    if algo == "bf16" and FUSE_BN_STATS and not SYNC_BN:
+    if algo == "bf16" and FUSE_BN_STATS and not sync_bn():
         nparts = int(_lib.load().onet_conv3x3_bf16_nparts(B, H, W))
         x16p, x16bs = plane16(x16)
         if nparts > 0 and (x16p is not None or x is not None):
@@ -587,7 +620,7 @@ def conv3x3_fwd_bn_partials(x, pk, x16=None, norm=None):
                       B * H * W * ((2.0 if x16p is not None else 4.0) * Ci + 4.0 * Co) + 18.0 * Ci * Co)
             return out, cm
         nparts = 0
-    if algo == "split" and FUSE_BN_STATS and not SYNC_BN and x is not None:
+    if algo == "split" and FUSE_BN_STATS and not sync_bn() and x is not None:
         nparts = int(_lib.load().onet_conv3x3_split_nparts(B, H, W))
         if nparts > 0:
             wq = pk.get_pack(algo)[0]
@@ -599,12 +632,15 @@ def conv3x3_fwd_bn_partials(x, pk, x16=None, norm=None):
             out = torch.empty((B, Co, H, W), dtype=F32, device=x.device)
             cm = torch.empty((Co, nparts, 3), dtype=F32, device=x.device)
             e0 = _prof_begin()
-            _lib.call("onet_conv3x3_split_fwd_stats", _p(xs), xbs, _p(wq), int(wq.dtype == torch.float16), _p(out), Co * H * W, _p(cm),
-                      B, Ci, Co, H, W, _stream())
+            if wq.dtype == torch.float16:
+                _lib.call("onet_conv3x3_split_conv_amax", _p(xs), xbs, _p(amax), 0, _p(wq), _p(out), Co * H * W, _p(cm), B, Ci, Co, H, W,
+                          _stream())
+            else:
+                _lib.call("onet_conv3x3_split_fwd_stats", _p(xs), xbs, _p(wq), 0, _p(out), Co * H * W, _p(cm), B, Ci, Co, H, W, _stream())
             _prof_end("conv3x3_split_kernel", 2.0 * B * H * W * Ci * Co * 9, e0, 4.0 * (B * H * W * (Ci + Co) + 9 * Ci * Co))
             return out, cm
     if nparts <= 0:
-        return conv3x3_auto(x, pk, 0, x16=x16), None
+        return conv3x3_auto(x, pk, 0, x16=x16, amax=amax), None
     wq = pk.get_pack(algo)[0]
     require_gpu(x, wq)
     x, xbs = plane(x)
@@ -625,7 +661,7 @@ def conv3x3_dgrad_bnreduce(dz, pk, z_prev, save_prev):
     pass of the layer BELOW folded into the epilogue: -> (da, records [Cin, nparts, 2]) or None where the F(4x4) kernel
     is not the one selected / the map is not made of full blocks.  save_prev: [G, 4, Cin] coefficients of the G
     statistics groups (consecutive batch slices) of the layer below; z_prev its pre-activation."""
-    if not FUSE_BN_REDUCE or SYNC_BN:
+    if not FUSE_BN_REDUCE or sync_bn():
         return None
     Ci, Co = pk["Cout"], pk["Cin"]                       # dgrad: Cout -> Cin
     B, _, H, W = dz.shape
@@ -748,16 +784,39 @@ def pack3x3_split(w):
     require_gpu(w)
     w = w.detach().contiguous()
     Cout, Cin = w.shape[0], w.shape[1]
-    # the forward pack's parts are fp16 (of 2^8 w) by default -- its dtype tells conv3x3_split which arithmetic the pack is for
-    wf = torch.empty(2 * Cin * 9 * Cout, dtype=torch.float16 if SPLIT_F16 else BF, device=w.device) if Cin % 16 == 0 else None
-    wd = torch.empty(2 * (-(-Cout // 16) * 16) * 9 * Cin, dtype=BF, device=w.device)
-    _lib.call("onet_conv3x3_split_pack_weights", _p(w), _p(wf), _p(wd), Cout, Cin, int(SPLIT_F16), _stream())
+    # a pack's parts are fp16 (of 2^k w, k from the tensor's largest magnitude; (2^k, 2^-k) stored behind the pack: + 8 elements)
+    # or bf16 -- its dtype tells conv3x3_split which arithmetic the pack is for
+    f_fwd, f_dg = split_f16(), grad_f16()
+    wf = torch.empty(2 * Cin * 9 * Cout + 8, dtype=torch.float16 if f_fwd else BF, device=w.device) if Cin % 16 == 0 else None
+    wd = torch.empty(2 * (-(-Cout // 16) * 16) * 9 * Cin + 8, dtype=torch.float16 if f_dg else BF, device=w.device)
+    ws = torch.empty(AMAX_SLOTS, dtype=torch.int32, device=w.device) if (f_fwd or f_dg) else None
+    _lib.call("onet_conv3x3_split_pack_weights", _p(w), _p(wf), _p(wd), _p(ws), Cout, Cin, int(f_fwd), int(f_dg), _stream())
     return wf, wd
 
 
-def conv3x3_split(x, wq, Cout, out=None, norm=None):
-    """z = conv3x3(x) in fp32 accuracy on the bf16 matrix cores (operands split into two bf16 parts, three MFMAs per term).
-    norm = save [G, 4, Cin]: x is a pre-activation; the kernel convolves relu(bn(x)), applied in its staging."""
+AMAX_SLOTS = 64 * 32       # 64 magnitude slots, one per 128-byte line (bn.hip: amax_commit)
+
+
+def new_amax(device):
+    """64 zeroed magnitude slots (8 KB: a cache line each; conv_split.hip: amax_read / amax_scale) for a tensor its producer is
+    about to write."""
+    return torch.zeros(AMAX_SLOTS, dtype=torch.int32, device=device)
+
+
+def absmax_slots(x):
+    """Magnitude slots of an existing tensor (one extra pass over it: for callers whose producer did not record them)."""
+    require_gpu(x)
+    xc = x.contiguous()
+    slots = new_amax(x.device)
+    _lib.call("onet_absmax_slots", _p(xc), xc.numel(), _p(slots), _stream())
+    return slots
+
+
+def conv3x3_split(x, wq, Cout, out=None, norm=None, amax=None, always=False):
+    """z = conv3x3(x) in fp32 accuracy on the 16-bit matrix cores (operands split into two fp16 / bf16 parts, three MFMAs per term).
+    norm = save [G, 4, Cin]: x is a pre-activation; the kernel convolves relu(bn(x)), applied in its staging.
+    fp16 pack: amax = the magnitude slots of x; always = True (input gradients): x is scaled so that its amax lands in [2^13, 2^14)
+    -- the slots are then REQUIRED and computed here when the caller has none; always = False: overflow guard only."""
     if wq is None or not wq.is_cuda or wq.dtype not in (torch.bfloat16, torch.float16):
         raise TypeError("conv3x3_split: wq must be a split pack on the GPU (pack3x3_split)")
     f16 = int(wq.dtype == torch.float16)
@@ -781,8 +840,13 @@ def conv3x3_split(x, wq, Cout, out=None, norm=None):
     if out is None:
         out = torch.empty((B, Cout, H, W), dtype=F32, device=x.device)
     zbs = out.stride(0) if B > 1 else Cout * H * W
+    if f16 and always and amax is None:
+        amax = absmax_slots(x)
     e0 = _prof_begin()
-    _lib.call("onet_conv3x3_split_fwd", _p(x), xbs, _p(wq), f16, _p(out), zbs, B, Cin, Cout, H, W, _stream())
+    if f16:
+        _lib.call("onet_conv3x3_split_conv_amax", _p(x), xbs, _p(amax), int(always), _p(wq), _p(out), zbs, None, B, Cin, Cout, H, W, _stream())
+    else:
+        _lib.call("onet_conv3x3_split_fwd", _p(x), xbs, _p(wq), 0, _p(out), zbs, B, Cin, Cout, H, W, _stream())
     _prof_end("conv3x3_split_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
     return out
 
@@ -802,8 +866,8 @@ def split_pack_act(x, f16=True, scale=1.0, out=None):
 
 def conv3x3_split_pre(xs, wq, Cout, out=None, out_scale=None, stats=None):
     """z = out_scale * conv3x3 of a PRE-SPLIT activation xs [B, Cin/8, H, 2, W, 8] (split_pack_act / the producers' fused variants)
-    with the split weight pack wq: the arithmetic of conv3x3_split, staging by LDS-DMA.  out_scale defaults to what undoes the
-    pack's own scale (2^-8 for the fp16 pack)."""
+    with the split weight pack wq: the arithmetic of conv3x3_split, staging by LDS-DMA.  out_scale undoes a power-of-two scale
+    applied to xs by its producer (the fp16 pack's own scale is undone by the kernel from the pack)."""
     if wq is None or not wq.is_cuda or wq.dtype not in (torch.bfloat16, torch.float16) or xs.dtype != wq.dtype:
         raise TypeError("conv3x3_split_pre: xs and wq must be split packs of the same 16-bit type on the GPU")
     f16 = int(wq.dtype == torch.float16)
@@ -812,12 +876,31 @@ def conv3x3_split_pre(xs, wq, Cout, out=None, out_scale=None, stats=None):
     if out is None:
         out = torch.empty((B, Cout, H, W), dtype=F32, device=xs.device)
     if out_scale is None:
-        out_scale = 1.0 / 256.0 if f16 else 1.0
+        out_scale = 1.0
     e0 = _prof_begin()
     _lib.call("onet_conv3x3_split_fwd_pre", _p(xs), xs.stride(0) // 2 if B > 1 else Cin * H * W, _p(wq), f16, float(out_scale), _p(out),
               out.stride(0) if B > 1 else Cout * H * W, _p(stats), B, Cin, Cout, H, W, _stream())
     _prof_end("conv3x3_split_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
     return out
+
+
+def conv3x3_split_wgrad_pre(xs, dzs, dw_shape, out=None, out_scale=1.0):
+    """dw = out_scale * (weight gradient of a 3x3 convolution) from PRE-SPLIT x and dz (split_pack_act layout, same 16-bit
+    type): conv3x3_split_wgrad's arithmetic with LDS-DMA staging and transposed fragment reads."""
+    if xs.dtype != dzs.dtype or xs.dtype not in (torch.bfloat16, torch.float16):
+        raise TypeError("conv3x3_split_wgrad_pre: xs and dzs must be pre-split tensors of the same 16-bit type")
+    B, C8, H, two, W, eight = xs.shape
+    Cin, Cout = C8 * 8, dzs.shape[1] * 8
+    assert tuple(dw_shape) == (Cout, Cin, 3, 3)
+    dw = out if out is not None else torch.empty(dw_shape, dtype=F32, device=xs.device)
+    need = _lib.load().onet_conv3x3_split_wgrad_ws_bytes(B, Cin, Cout, H, W)
+    ws = workspace(need, xs.device)
+    e0 = _prof_begin()
+    _lib.call("onet_conv3x3_split_wgrad_pre", _p(xs), xs.stride(0) // 2 if B > 1 else Cin * H * W, _p(dzs),
+              dzs.stride(0) // 2 if B > 1 else Cout * H * W, int(xs.dtype == torch.float16), float(out_scale), _p(dw), _p(ws),
+              ws.numel() * 4, B, Cin, Cout, H, W, 0, _stream())
+    _prof_end("conv3x3_split_wgrad_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
+    return dw
 
 
 def split_wgrad_ok(x, dz):
@@ -834,7 +917,7 @@ def norm_on_load_ok(B, Cmid, Cout, H, W, groups):
     """May the second convolution of a DoubleConv (Cmid -> Cout on B maps of H x W, `groups` BatchNorm statistics groups) take
     the first unit's BatchNorm + ReLU into its own operand staging -- forward AND weight gradient -- so that the first unit's
     activation is never written?  Both must be the split-bf16 kernels (fp32 model, default dispatch)."""
-    if not (BN_ON_LOAD and _setting("bn_on_load", True)) or SYNC_BN or conv_algo() not in ("auto", "split") or groups not in (1, 2) or B % groups:
+    if not _setting("bn_on_load", BN_ON_LOAD) or sync_bn() or conv_algo() not in ("auto", "split") or groups not in (1, 2) or B % groups:
         return False
     if conv3x3_algo(B, Cmid, Cout, H, W) != "split" or W < SPLIT_WGRAD_MINW:
         return False
@@ -847,9 +930,24 @@ def norm_on_load_ok(B, Cmid, Cout, H, W, groups):
     return W >= 64 or B * max(Cmid, Cout) * H * W * 4 < 2 ** 31
 
 
-def conv3x3_split_wgrad(x, dz, dw_shape, out=None, norm=None):
-    """dW of a 3x3 convolution in fp32 accuracy on the bf16 matrix cores (conv_split.hip: both operands split, three MFMAs per term).
-    norm = save [G, 4, Cin]: x is the pre-activation of the unit below, normalised (BatchNorm + ReLU) on load."""
+def conv3x3_split_wgrad(x, dz, dw_shape, out=None, norm=None, dz_amax=None, x_amax=None):
+    """dW of a 3x3 convolution in fp32 accuracy on the 16-bit matrix cores (conv_split.hip: both operands split, three MFMAs per term).
+    norm = save [G, 4, Cin]: x is the pre-activation of the unit below, normalised (BatchNorm + ReLU) on load.
+    dz_amax (magnitude slots of dz, from onet_bn_relu_bwd_apply_amax): fp16 parts of the scaled operands (22-bit operands; x_amax:
+    the overflow guard for x); None: bf16 parts (16-bit operands), the round-3 arithmetic."""
+    if dz_amax is not None:
+        require_gpu(x, dz)
+        x, xbs = plane(x)
+        dz, dzbs = plane(dz)
+        B, Cin, H, W = x.shape
+        Cout = dz.shape[1]
+        dw = torch.empty(dw_shape, dtype=F32, device=x.device) if out is None else out
+        ws = workspace(_lib.load().onet_conv3x3_split_wgrad_ws_bytes(B, Cin, Cout, H, W), x.device)
+        e0 = _prof_begin()
+        _lib.call("onet_conv3x3_split_wgrad_f16", _p(x), xbs, _p(x_amax), _p(norm), 0 if norm is None else norm.shape[0], _p(dz), dzbs,
+                  _p(dz_amax), _p(dw), _p(ws), ws.numel() * 4, B, Cin, Cout, H, W, 0, _stream())
+        _prof_end("conv3x3_split_wgrad_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
+        return dw
     if norm is not None:
         require_gpu(x, dz, norm)
         x, xbs = plane(x)
@@ -981,7 +1079,7 @@ def wgrad_takes_bf16(Cin, H, W):
     return conv_algo() == "bf16" and Cin >= 16 and W >= 16 and W % 4 == 0 and H >= 8
 
 
-def conv3x3_wgrad_auto(x, dz, dw_shape, out=None, x16=None, dz16=None):
+def conv3x3_wgrad_auto(x, dz, dw_shape, out=None, x16=None, dz16=None, dz_amax=None, x_amax=None):
     Cout, Cin = dw_shape[0], dw_shape[1]
     shp = (x if x is not None else x16).shape
     if wgrad_takes_bf16(Cin, shp[2], shp[3]) and (dz16 is not None or dz.is_contiguous()):
@@ -989,7 +1087,7 @@ def conv3x3_wgrad_auto(x, dz, dw_shape, out=None, x16=None, dz16=None):
     # fp32 tensors, maps 16 / 32 / >= 64 pixels wide: the split-bf16 row kernel (the stem, Cin < 16, keeps its own VALU kernel)
     if conv_algo() in ("auto", "split") and (split_enabled() or conv_algo() == "split") and x is not None and Cin >= 16 and \
             x.shape[3] >= SPLIT_WGRAD_MINW and split_wgrad_ok(x, dz):
-        return conv3x3_split_wgrad(x, dz, dw_shape, out=out)
+        return conv3x3_split_wgrad(x, dz, dw_shape, out=out, dz_amax=dz_amax if grad_f16() else None, x_amax=x_amax)
     if use_winograd(Cin, Cout, x.shape[2], x.shape[3]):
         if WGRAD4 != "0" and (WGRAD4 == "1" or Cin >= 256 or (Cin >= 128 and Cout >= 256)) and winograd4_wgrad_ok(x, dz):
             return conv3x3_winograd4_wgrad(x, dz, dw_shape, out=out)
@@ -1044,7 +1142,7 @@ def set_sync_bn(flag: bool):
 def _gather_partials(part):
     """[nparts, C, k] -> [world*nparts, C, k] over the default process group (RCCL)."""
     import torch.distributed as dist
-    if not (SYNC_BN and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+    if not (sync_bn() and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
         return part, 1
     world = dist.get_world_size()
     out = torch.empty((world * part.shape[0],) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device)
@@ -1096,11 +1194,32 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps, save=None):
     return save
 
 
-def bn_relu_apply(z, save, out=None, out16=None, no_fp32=False):
+def amax_of(t):
+    """The valid magnitude slots riding on activation `t` (tag_amax), or None."""
+    tag = getattr(t, "_onet_amax", None)
+    if tag is None:
+        return None
+    slots, ver = tag
+    return slots if ver == t._version else None
+
+
+def tag_amax(t, slots):
+    if slots is not None and t is not None:
+        t._onet_amax = (slots, t._version)
+    return t
+
+
+def bn_relu_apply(z, save, out=None, out16=None, no_fp32=False, amax=None):
     """a = relu(bn(z)); out16: plane-contiguous bf16 destination for a copy of a (bf16 storage of the conv operands);
-    no_fp32 (with out16): write the bf16 copy ONLY and return None."""
+    no_fp32 (with out16): write the bf16 copy ONLY and return None.  amax: magnitude slots that receive max a (fp32 output only)."""
     z, zbs = plane(z)
     B, C, H, W = z.shape
+    if amax is not None and out16 is None:
+        if out is None:
+            out = torch.empty((B, C, H, W), dtype=F32, device=z.device)
+        _lib.call("onet_bn_relu_apply_amax", _p(z), zbs, _p(out), out.stride(0) if B > 1 else C * H * W, _p(save), _p(amax), B, C, H * W,
+                  _stream(), nbytes=8 * z.numel())
+        return out
     if out16 is not None and no_fp32:
         o16bs = out16.stride(0) if B > 1 else C * H * W
         _lib.call("onet_bn_relu_apply_b", _p(z), zbs, None, 0, _p(out16), o16bs, _p(save), B, C, H * W, _stream(),
@@ -1121,10 +1240,10 @@ def bn_relu_apply(z, save, out=None, out16=None, no_fp32=False):
 FUSE_POOL = _os.environ.get("ONET_FUSE_POOL", "1") != "0"       # 0: separate max-pool pass after BatchNorm + ReLU
 
 
-def bn_relu_apply_pool(z, save, out, out16, y, y16):
+def bn_relu_apply_pool(z, save, out, out16, y, y16, amax=None):
     """a = relu(bn(z)) and y = maxpool2(a) in one pass (an encoder block's output that is pooled next); out / out16 and y / y16:
     fp32 destination and / or its bf16 copy (plane-contiguous; at least one of each pair).  -> False (nothing done) where the
-    fused kernel does not take the shape."""
+    fused kernel does not take the shape.  amax: magnitude slots that receive max a = max y (fp32 outputs only)."""
     z, zbs = plane(z)
     B, C, H, W = z.shape
     if H % 2 or W % 4:
@@ -1133,6 +1252,12 @@ def bn_relu_apply_pool(z, save, out, out16, y, y16):
     def bs(t, n):
         return 0 if t is None else (t.stride(0) if B > 1 else n)
     n, m = C * H * W, C * (H // 2) * (W // 2)
+    if amax is not None and out16 is None and y16 is None and out is not None and y is not None:
+        rc = _lib.load().onet_bn_relu_apply_pool_amax(_p(z), zbs, _p(out), bs(out, n), _p(y), bs(y, m), _p(save), _p(amax), B, C, H, W,
+                                                      _stream())
+        if rc < 0:
+            raise _lib.OnetHipError(f"onet_bn_relu_apply_pool_amax failed ({rc}): {_lib.last_error()}")
+        return rc == 0
     rc = _lib.load().onet_bn_relu_apply_pool(_p(z), zbs, _p(out), bs(out, n), _p(out16), bs(out16, n), _p(y), bs(y, m), _p(y16),
                                             bs(y16, m), _p(save), B, C, H, W, _stream())
     if rc < 0:
@@ -1141,7 +1266,7 @@ def bn_relu_apply_pool(z, save, out, out16, y, y16):
 
 
 def bn_relu_bwd(da, z, save, training, need_affine_grads=True, out=None, acc=None, affine_out=None, red=None, red4=None,
-                out16=None):
+                out16=None, amax=None):
     """-> dz, dgamma, dbeta.  `out`: plane-contiguous destination for dz (a batch slice of a larger buffer);
     `acc` = (dgamma, dbeta) of another statistics group of the same layer to accumulate into; `affine_out` =
     (dgamma, dbeta) destinations to overwrite (None entries are allocated); `red` = (records [C, NP, 2], first, count):
@@ -1149,7 +1274,8 @@ def bn_relu_bwd(da, z, save, training, need_affine_grads=True, out=None, acc=Non
     `da` (`conv3x3_dgrad_bnreduce`), so the reduce pass over (da, z) is skipped; `red4` = (records [NP, C, 4], first,
     count): the same in the reduce kernel's own record format (written by the pooling-backward kernel).
     `out16`: plane-contiguous bf16 destination -- dz is then written in bf16 ONLY (its consumers are the bf16 dgrad and
-    weight-gradient kernels) and the returned dz is None."""
+    weight-gradient kernels) and the returned dz is None.  `amax`: 64 zeroed magnitude slots (new_amax) in which the apply pass
+    records max |dz| for the fp16-split gradient kernels (several statistics groups of one tensor share them)."""
     da, dabs = plane(da)
     z, zbs = plane(z)
     B, C, H, W = z.shape
@@ -1202,6 +1328,10 @@ def bn_relu_bwd(da, z, save, training, need_affine_grads=True, out=None, acc=Non
         return None, dgamma, dbeta
     dz = torch.empty((B, C, H, W), dtype=F32, device=dev) if out is None else out
     dzbs = dz.stride(0) if B > 1 else C * HW
+    if amax is not None:
+        _lib.call("onet_bn_relu_bwd_apply_amax", _p(da), dabs, _p(z), zbs, _p(save), _p(coef), _p(dz), dzbs, _p(amax), B, C, HW,
+                  _stream(), nbytes=12 * z.numel())
+        return dz, dgamma, dbeta
     _lib.call("onet_bn_relu_bwd_apply", _p(da), dabs, _p(z), zbs, _p(save), _p(coef), _p(dz), dzbs, B, C, HW,
               _stream(), nbytes=12 * z.numel())
     return dz, dgamma, dbeta
@@ -1244,7 +1374,7 @@ def maxpool2_bwd(x, dy, add=None, add2=None, bn=None):
     a2, a2bs = plane(add2) if add2 is not None else (None, 0)
     if bn is not None:
         z, save_all = bn
-        bands = int(_lib.load().onet_maxpool2_bwd_bn_bands(H, W)) if (FUSE_BN_REDUCE and not SYNC_BN) else 0
+        bands = int(_lib.load().onet_maxpool2_bwd_bn_bands(H, W)) if (FUSE_BN_REDUCE and not sync_bn()) else 0
         z, zbs = plane(z)
         G = save_all.shape[0]
         aligned = all(t is None or (t.data_ptr() & 15) == 0 for t in (x, z, a1, a2)) and (dy.data_ptr() & 7) == 0 and \

@@ -126,7 +126,8 @@ def _model(C, gain, dev, seed=1981, bshare=True):
 
 CASES = {
     # tag: (B, C, H, W, head_gain, algorithms)
-    "b8_c1_128": (8, 1, 128, 128, 0.3, ("auto", "split", "winograd4", "winograd", "direct")),
+    # ("split_f16grad": the split kernels with Settings.grad_f16 -- input / weight gradients on fp16 parts of scaled operands)
+    "b8_c1_128": (8, 1, 128, 128, 0.3, ("auto", "split", "split_f16grad", "winograd4", "winograd", "direct")),
     "b4_c1_256": (4, 1, 256, 256, 0.3, ("auto", "split", "winograd4")),
     "b2_c3_64_saturated": (2, 3, 64, 64, 1.0, ("auto", "winograd4")),
     "b3_c1_40_padpath": (3, 1, 40, 40, 1.0, ("auto",)),
@@ -134,14 +135,16 @@ CASES = {
 }
 
 
-@pytest.mark.parametrize("algo", ["auto", "split", "winograd4", "winograd", "direct"])
+@pytest.mark.parametrize("algo", ["auto", "split", "split_f16grad", "winograd4", "winograd", "direct"])
 @pytest.mark.parametrize("tag", list(CASES))
 def test_every_gradient_element_vs_routed_fp64_oracle(dev, tag, algo, monkeypatch):
     from onet_amd import ops
     B, C, H, W, gain, algos = CASES[tag]
     if algo not in algos:
         pytest.skip("algorithm not forced on this case")
-    monkeypatch.setattr(ops, "CONV_ALGO", algo)
+    monkeypatch.setattr(ops, "CONV_ALGO", "split" if algo == "split_f16grad" else algo)
+    if algo == "split_f16grad":
+        monkeypatch.setattr(ops, "SPLIT_GRAD_F16", True)
     X = orc.det_input(B, C, H, W)
     m = _model(C, gain, dev)
     (Lt, Vt, Ld, Vd, S), loss, acts = _hip_step_recording(m, X.to(dev), monkeypatch, range(B))

@@ -383,13 +383,13 @@ def test_bn_on_load_model_step_is_bit_identical(dev, monkeypatch):
     calls = {"fwd": 0, "wgrad": 0}
     real_f, real_w = ops.conv3x3_fwd_bn_partials, ops.conv3x3_split_wgrad
 
-    def spy_f(x, pk, x16=None, norm=None):
+    def spy_f(x, pk, x16=None, norm=None, **kw):
         calls["fwd"] += norm is not None
-        return real_f(x, pk, x16=x16, norm=norm)
+        return real_f(x, pk, x16=x16, norm=norm, **kw)
 
-    def spy_w(x, dz, shp, out=None, norm=None):
+    def spy_w(x, dz, shp, out=None, norm=None, **kw):
         calls["wgrad"] += norm is not None
-        return real_w(x, dz, shp, out=out, norm=norm)
+        return real_w(x, dz, shp, out=out, norm=norm, **kw)
 
     monkeypatch.setattr(ops, "conv3x3_fwd_bn_partials", spy_f)
     monkeypatch.setattr(ops, "conv3x3_split_wgrad", spy_w)

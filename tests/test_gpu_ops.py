@@ -141,6 +141,61 @@ def test_conv3x3_split_wgrad(dev, B, Cin, Cout, H, W):
     wide = torch.zeros(B, Cin + 16, H, W)
     wide[:, 16:] = x
     assert torch.equal(dw, ops.conv3x3_split_wgrad(wide.to(dev)[:, 16:], g.to(dev), (Cout, Cin, 3, 3)))
+    # round 4: fp16 parts of the scaled operands (dz at a gradient's magnitude, scaled from its magnitude slots): 2e-6 of scale
+    tiny = (3e-6 * g).to(dev)
+    dwh = ops.conv3x3_split_wgrad(x.to(dev), tiny, (Cout, Cin, 3, 3), dz_amax=ops.absmax_slots(tiny))
+    close(dwh / 3e-6, w.grad, tol=2e-6, what="split wgrad, fp16 parts")
+    assert torch.equal(dwh, ops.conv3x3_split_wgrad(x.to(dev), tiny, (Cout, Cin, 3, 3), dz_amax=ops.absmax_slots(tiny)))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 64, 64, 64, 64), (2, 64, 128, 32, 64), (3, 72, 64, 16, 96), (4, 64, 128, 32, 32),
+                                             (2, 128, 64, 32, 32), (1, 64, 64, 8, 128)])
+def test_conv3x3_split_presplit_kernels(dev, B, Cin, Cout, H, W):
+    """Round 4, pre-split operands (slot layout [B][C/8][H][hi|mid][W][8] of 16-bit parts, written by onet_split_pack_act):
+    conv3x3_split_pre_kernel (staging = LDS-DMA copy) must reproduce conv3x3_split_kernel on the same parts BIT FOR BIT, for fp16
+    and bf16 parts; conv3x3_split_wgrad_pre_kernel (LDS-DMA + ds_read_b64_tr_b16 fragments, another summation order) is held to
+    the fp64 weight gradient: 2e-6 of scale with fp16 parts, 3e-5 with bf16 parts; 32-pixel maps pair two images per unit."""
+    from onet_amd import ops
+    x = rnd(B, Cin, H, W, seed=51).to(dev)
+    g = rnd(B, Cout, H, W, seed=52).to(dev)
+    w = rnd(Cout, Cin, 3, 3, seed=53, scale=(2.0 / (Cin * 9)) ** 0.5).to(dev)
+    if Cin % 16 == 0 and W > 16:
+        qf, _ = ops.pack3x3_split(w)
+        ref = ops.conv3x3_split(x, qf, Cout)
+        got = ops.conv3x3_split_pre(ops.split_pack_act(x, f16=True), qf, Cout)
+        assert torch.equal(ref, got), float((ref - got).abs().max())
+    wz = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double().cpu(), wz, None, 1, 1).backward(g.double().cpu())
+    for f16, tol in ((True, 2e-6), (False, 3e-5)):
+        dw = ops.conv3x3_split_wgrad_pre(ops.split_pack_act(x, f16=f16), ops.split_pack_act(g, f16=f16), (Cout, Cin, 3, 3))
+        close(dw, wz.grad, tol=tol, what="pre-split wgrad " + ("fp16" if f16 else "bf16"))
+
+
+def test_split_f16_range_guard(dev):
+    """Round 4 (review item: fp16 range unguarded).  (a) Weights beyond fp16's range times the old fixed 2^8 (|w| = 400 > 255.9):
+    the pack now takes its power of two from the tensor's largest magnitude.  (b) An activation beyond 65504 (a loaded checkpoint
+    with a large BatchNorm gamma): with the magnitude slots its producer recorded, the kernel scales it into range; without them
+    the fp16 parts overflow (shown, so that the guard is known to be what saves the result).  Both against the fp32-MFMA direct
+    kernel at 1e-5 of the output scale."""
+    from onet_amd import ops
+    B, Cin, Cout, H, W = 2, 64, 64, 32, 64
+    x = rnd(B, Cin, H, W, seed=61).to(dev)
+    w = (rnd(Cout, Cin, 3, 3, seed=62) * 400.0 / 4.0).to(dev)
+    assert float(w.abs().max()) > 255.9
+    wd, _ = ops.pack3x3(w)
+    ref = ops.conv_fwd(x, wd, Cout, 3)
+    qf, qd = ops.pack3x3_split(w)
+    close(ops.conv3x3_split(x, qf, Cout), ref.double().cpu(), tol=1e-5, what="split fwd, |w| = 400")
+    xb = torch.relu(x) * 3e5
+    assert float(xb.max()) > 65504
+    w1 = rnd(Cout, Cin, 3, 3, seed=63, scale=(2.0 / (Cin * 9)) ** 0.5).to(dev)
+    wd1, _ = ops.pack3x3(w1)
+    ref = ops.conv_fwd(xb, wd1, Cout, 3)
+    q1, _ = ops.pack3x3_split(w1)
+    close(ops.conv3x3_split(xb, q1, Cout, amax=ops.absmax_slots(xb)), ref.double().cpu(), tol=1e-5, what="split fwd, |x| = 3e5, guarded")
+    assert not torch.isfinite(ops.conv3x3_split(xb, q1, Cout)).all()        # unguarded: fp16(3e5) = inf
+    # an ordinary tensor is untouched by the guard: bit-identical with and without its slots
+    assert torch.equal(ops.conv3x3_split(x, q1, Cout), ops.conv3x3_split(x, q1, Cout, amax=ops.absmax_slots(x)))
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W,G", [(4, 64, 64, 32, 64, 2), (2, 32, 48, 20, 40, 1), (4, 128, 128, 16, 32, 2), (6, 48, 256, 33, 96, 1),
@@ -192,17 +247,29 @@ def test_conv3x3_split_fwd_dgrad_stats(dev, B, Cin, Cout, H, W, monkeypatch):
     zr.backward(g.double())
     qf, qd = ops.pack3x3_split(w.to(dev))
     z = ops.conv3x3_split(x.to(dev), qf, Cout)
-    # forward: fp16 parts (22 significant bits) -- 2e-6 of the output scale (measured 6e-7 .. 1.9e-6 max, 5e-8 .. 1.5e-7 rms: the
-    # fp32 direct kernel's level); input gradient: bf16 parts (16 bits), 2e-5 (measured 5e-6)
-    assert qf.dtype == torch.float16 and qd.dtype == torch.bfloat16
+    # fp16 parts (22 significant bits) in both orientations -- 2e-6 of the output scale (measured 6e-7 .. 1.9e-6 max, 5e-8 .. 1.5e-7
+    # rms: the fp32 direct kernel's level; round 4: the input gradient too, on a power-of-two-scaled operand); bf16 parts
+    # (16 bits; Settings.split_f16 / grad_f16 = False, round 3's gradients): 2e-5 (measured 5e-6)
+    monkeypatch.setattr(ops, "SPLIT_GRAD_F16", True)
+    qf, qd = ops.pack3x3_split(w.to(dev))
+    assert qf.dtype == torch.float16 and qd.dtype == torch.float16
     close(z, zr, tol=2e-6 if Cin <= 128 else 4e-6, what="split fwd")
     monkeypatch.setattr(ops, "SPLIT_F16", False)
-    qb, _ = ops.pack3x3_split(w.to(dev))
+    monkeypatch.setattr(ops, "SPLIT_GRAD_F16", False)
+    qb, qdb = ops.pack3x3_split(w.to(dev))
     monkeypatch.setattr(ops, "SPLIT_F16", True)
-    assert qb.dtype == torch.bfloat16
+    assert qb.dtype == torch.bfloat16 and qdb.dtype == torch.bfloat16
     close(ops.conv3x3_split(x.to(dev), qb, Cout), zr, tol=2e-5, what="split fwd, bf16 parts")
     if Cout % 16 == 0:
-        close(ops.conv3x3_split(g.to(dev), qd, Cin), xr.grad, tol=2e-5, what="split dgrad")
+        close(ops.conv3x3_split(g.to(dev), qdb, Cin), xr.grad, tol=2e-5, what="split dgrad, bf16 parts")
+        # the gradient operand at a gradient's magnitude: 1e-7 g underflows fp16 unscaled; scaled from its magnitude slots
+        # (computed here, always=True; in the model bn_relu_bwd_apply records them) the error stays at the fp16-parts level
+        tiny = (1e-7 * g).to(dev)
+        dgt = ops.conv3x3_split(tiny, qd, Cin, always=True)
+        close(dgt * 1e7, xr.grad, tol=2e-6 if Cout <= 128 else 4e-6, what="split dgrad, fp16 parts of the scaled operand")
+        am = ops.absmax_slots(tiny)
+        assert abs(float(am.view(torch.float32).max()) - float(tiny.abs().max())) == 0.0
+        assert torch.equal(dgt, ops.conv3x3_split(tiny, qd, Cin, amax=am, always=True))
     assert torch.equal(z, ops.conv3x3_split(x.to(dev), qf, Cout)), "bitwise reproducible"
     nparts = int(_lib.load().onet_conv3x3_split_nparts(B, H, W))
     if W % 32 or H % 16:

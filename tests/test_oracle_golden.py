@@ -123,3 +123,29 @@ def test_adam_loss_sequence_matches_reference():
     np.testing.assert_allclose(losses, g["losses"], rtol=5e-6)
     nbt = [int(v) for k, v in top.items() if k.endswith("num_batches_tracked")]
     assert nbt[0] == 2 * steps
+
+
+def test_oracle_follows_the_reference_training_run():
+    """tests/golden/train_b4_c3_64.npz (the real reference trained for 40 one-batch epochs, TZ:99-128 order): the first five steps of
+    the CPU oracle under the same Adam + cosine schedule reproduce the reference's loss sequence, and the build's host-side
+    schedule function gives the reference's learning rates."""
+    from onet_amd.data import make_blob_tiles
+    from onet_amd.trainer import cosine_warm_restarts_lr
+    g = _load("train_b4_c3_64.npz")
+    B, C, H, W, steps = [int(v) for v in g["meta"]]
+    Xn, Mn = make_blob_tiles(B, H, W, seed=4242, channels=C)
+    assert np.array_equal(Mn.astype(np.uint8), g["mask"])
+    np.testing.assert_allclose([cosine_warm_restarts_lr(e, 1e-4) for e in range(steps)], g["lrs"], rtol=1e-9)
+    X = torch.from_numpy(Xn)
+    top = orc.clone_state(orc.det_state_dict(C, 1981))
+    params = [v for v in top.values() if v.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8)
+    losses = []
+    for e in range(5):
+        opt.param_groups[0]["lr"] = float(g["lrs"][e])
+        opt.zero_grad()
+        _, loss, _ = orc.train_mode_step(X, top)
+        opt.step()
+        losses.append(float(loss))
+    np.testing.assert_allclose(losses, g["losses32"][:5], rtol=2e-5)
+    assert 0.75 < float(g["miou32"]) < 0.9 and float(g["loss_drift_32_vs_64"]) < 1e-3
