@@ -162,6 +162,10 @@ int onet_maxpool2_fwd_b(const float* x, int64_t x_bs, float* y, int64_t y_bs, vo
 int onet_convT2x2_fwd_b(const float* x, int64_t x_bs, const float* wq, const float* bias, float* y, int64_t y_bs, void* y_bf16,
                         int64_t y16_bs, int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int operand_bf16,
         void* stream);
+/* ... the up-sampled tensor written pre-split (round 4: fp16 hi | mid slots [B][Ct/8][Ho][2][Wo][8], batch stride in 4-byte units), e.g.
+ * into the up-sampled channel groups of a pre-split concat buffer; no fp32 output.  Returns 1 (nothing done) outside the GEMM fast path. */
+int onet_convT2x2_fwd_p(const float* x, int64_t x_bs, const float* wq, const float* bias, void* yP, int64_t yP_bs, int B, int Cin, int Ct,
+                        int h, int w, int Ho, int Wo, int pt, int pl, int operand_bf16, void* stream);
                                                                                 /* 1: shape outside the GEMM path, nothing done */
 int onet_conv3x3_bf16_fwd_b(const void* x_bf16, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin,
                             int Cout, int H, int W, void* stream);
@@ -203,19 +207,23 @@ int onet_conv3x3_split_nparts(int B, int H, int W);
  * MFMA tile wants:  xs [B][C/8][H][part 2][W][8] 16-bit (part 0 = hi, 1 = mid; fp16 when f16 != 0, else bf16): 4 bytes per element,
  * the fp32 tensor's footprint; batch stride xs_bs in 4-byte units.  The producers write it (BatchNorm + ReLU apply / pooling, the
  * BatchNorm backward apply, the ConvTranspose2d epilogue); onet_split_pack_act converts an fp32 NCHW tensor (times `scale`, a power
- * of two) for tests and for producers without a fused variant.  _fwd_pre: z = out_scale * conv(xs, wq) with the weight pack of
+ * of two) for tests and for producers without a fused variant.  _fwd_pre: z = conv(xs, wq) with the weight pack of
  * onet_conv3x3_split_pack_weights (same arithmetic as onet_conv3x3_split_fwd: bit-identical results for the same parts); staging
- * is an LDS-DMA copy.  part != NULL: BatchNorm statistics records as onet_conv3x3_split_fwd_stats. */
+ * is an LDS-DMA copy.  x_amax / scale_always: the magnitude slots and rule (amax_scale) the PRODUCER scaled xs by -- the kernel
+ * undoes that power of two on its accumulators; NULL: xs is unscaled.  part != NULL: BatchNorm statistics records as
+ * onet_conv3x3_split_fwd_stats. */
 int onet_split_pack_act(const float* x, int64_t x_bs, void* xs, int64_t xs_bs, int B, int C, int H, int W, int f16, float scale,
                         void* stream);
-int onet_conv3x3_split_fwd_pre(const void* xs, int64_t xs_bs, const void* wq, int wq_f16, float out_scale, float* z, int64_t z_bs,
-                               float* part, int B, int Cin, int Cout, int H, int W, void* stream);
+int onet_conv3x3_split_fwd_pre(const void* xs, int64_t xs_bs, const void* x_amax, int scale_always, const void* wq, int wq_f16, float* z,
+                               int64_t z_bs, float* part, int B, int Cin, int Cout, int H, int W, void* stream);
 /* Weight gradient (OV:47,51 backward) from pre-split x and dz (both in the slot layout, same 16-bit type): fragments by the gfx950
- * transposing LDS read, staging by LDS-DMA; dw = out_scale * sum dz x, deterministic split-K through ws
+ * transposing LDS read, staging by LDS-DMA; the producers' power-of-two scales (x_amax: guard rule, dz_amax: always; NULL:
+ * unscaled) are undone on the slabs; deterministic split-K through ws
  * (onet_conv3x3_split_wgrad_ws_bytes).  _ok: W >= 64, or W = 32 with an even batch; Cin, Cout multiples of 8. */
 int onet_conv3x3_split_wgrad_pre_ok(int B, int Cin, int Cout, int H, int W);
-int onet_conv3x3_split_wgrad_pre(const void* xs, int64_t xs_bs, const void* dzs, int64_t dzs_bs, int f16, float out_scale, float* dw,
-                                 void* ws, int64_t ws_bytes, int B, int Cin, int Cout, int H, int W, int accumulate, void* stream);
+int onet_conv3x3_split_wgrad_pre(const void* xs, int64_t xs_bs, const void* x_amax, const void* dzs, int64_t dzs_bs, const void* dz_amax,
+                                 int f16, float* dw, void* ws, int64_t ws_bytes, int B, int Cin, int Cout, int H, int W, int accumulate,
+                                 void* stream);
 int onet_conv3x3_split_fwd_stats(const float* x, int64_t x_bs, const void* wq, int wq_f16, float* z, int64_t z_bs, float* part, int B,
                                  int Cin, int Cout, int H, int W, void* stream);
 /* Weight gradient of the same convolution with both operands (x, dz: fp32 NCHW) split the same way, three MFMAs per term;
@@ -340,6 +348,27 @@ int onet_bn_bwd_finalize_cm(const float* part2, int nparts, int64_t c_stride, in
 int onet_bn_relu_bwd_apply(const float* da, int64_t da_bs, const float* z, int64_t z_bs,
                            const float* save, const float* coef, float* dz, int64_t dz_bs,
                            int B, int C, int HW, void* stream);
+/* ---- Round 4, pre-split producers (bn.hip).  The BatchNorm + ReLU passes (OV:48-49, 52-53 and their backward) write their result
+ * straight in the operand form of the split-fp16 convolution that consumes it: fp16 (hi, mid) parts in the slot layout
+ * [B][C/8][H][2][W][8] (onet_split_pack_act's; batch strides in 4-byte units; C % 8 == 0).  Values are bit for bit those of the fp32
+ * passes.  _apply_split: xs (+ the fp32 tensor a when not NULL).  _apply_pool_split: the activation to xs and / or a, the
+ * 2 x 2-pooled values to ys (pre-split) or y (fp32); returns 1 when the shape is not taken (odd H / W, alignment).
+ * _bwd_apply_split: dz as parts of 2^k dz, k chosen (conv_split.hip: amax_scale, always) from the magnitude slots dz_amax, which
+ * must hold an upper bound of |dz| BEFORE the launch: onet_bn_bwd_bound writes it from the layer's coefficients and the exact
+ * max |da| (da_amax: recorded by onet_bn_relu_bwd_reduce_amax or onet_absmax_slots); the consumers read the same slots. */
+int onet_bn_relu_apply_split(const float* z, int64_t z_bs, void* xs, int64_t xs_bs, float* a, int64_t a_bs, const float* save, int B, int C,
+                             int H, int W, void* stream);
+int onet_bn_relu_apply_pool_split(const float* z, int64_t z_bs, void* xs, int64_t xs_bs, float* a, int64_t a_bs, void* ys, int64_t ys_bs,
+                                  float* y, int64_t y_bs, const float* save, int B, int C, int H, int W, void* stream);
+int onet_bn_relu_bwd_reduce_amax(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save, float* part2, int nparts,
+                                 void* da_amax, int B, int C, int HW, void* stream);
+int onet_bn_bwd_bound(const float* save, const float* coef, const void* da_amax, int64_t count, void* dz_amax, int C, void* stream);
+/* onet_bn_bwd_finalize that also writes the bound of |dz| (as onet_bn_bwd_bound) into dz_amax: da_amax must be complete, i.e. every
+ * reduce launch of the tensor precedes the first finalize. */
+int onet_bn_bwd_finalize_bound(const float* part2, int nparts, int64_t count, float* dgamma, float* dbeta, float* coef, int accumulate,
+                               int C, const float* save, const void* da_amax, void* dz_amax, void* stream);
+int onet_bn_relu_bwd_apply_split(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save, const float* coef,
+                                 void* dzs, int64_t dzs_bs, const void* dz_amax, int B, int C, int H, int W, void* stream);
 /* onet_bn_relu_apply / onet_bn_relu_apply_pool that also record max a (a >= 0) in 64 magnitude slots (zeroed by the caller; the
  * statistics groups of a twin batch share them; the pooled tensor has the same maximum): the overflow guard of the fp16-split
  * convolution that consumes the activation.  _pool_amax returns 1 when the shape is not taken (as onet_bn_relu_apply_pool). */
@@ -376,6 +405,12 @@ int onet_maxpool2_bwd_add_bnreduce(const float* x, int64_t x_bs, const float* dy
                                    int64_t add_bs, const float* add2, int64_t add2_bs, float* dx, int64_t dx_bs,
                                    const float* z, int64_t z_bs, const float* save, int group_images,
                                    float* part2, int B, int C, int H, int W, void* stream);
+/* ... x may be NULL (pre-split storage: x = relu(bn(z)) is recomputed from z and the coefficients, the same bits); dx_amax: 64
+ * magnitude slots that receive max |dx| (dx is the producing layer's activation gradient: onet_bn_bwd_bound). */
+int onet_maxpool2_bwd_add_bnreduce_amax(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, const float* add, int64_t add_bs,
+                                        const float* add2, int64_t add2_bs, float* dx, int64_t dx_bs, const float* z, int64_t z_bs,
+                                        const float* save, int group_images, float* part2, void* dx_amax, int B, int C, int H, int W,
+                                        void* stream);
 
 /* ---- K5/K6: ConvTranspose2d(k=2,s=2) pixel shuffle + pad + concat (OV:86-100) ---- */
 /* sub [B][4*C][h][w] (1x1-conv output, channel q*C+co, q=dy*2+dx) + bias ->

@@ -185,7 +185,6 @@ static __device__ __forceinline__ void store_bf16x4(__bf16* p, float4 q) {     /
 // through LDS, then a plain read of the slot first -- once it holds a value >= the block's, after the first few blocks almost
 // always, no atomic is issued.  atomicMax on the fp32 bit pattern of a non-negative value is an order-independent maximum.
 // Every thread of a 256-thread block must call this (it contains a barrier).
-constexpr int AMAX_STRIDE = 32;     // unsigned words between slots
 __device__ __forceinline__ void amax_commit(float v, unsigned* slots) {
     if (!slots) return;
     __shared__ float wave_max[4];
@@ -305,6 +304,254 @@ __global__ __launch_bounds__(256) void bn_relu_apply_pool_kernel(const float* __
     amax_commit(fmaxf(m0, m1), amax);               // the pooled tensor has the same maximum: one set of slots serves both
 }
 
+// ------------------------------------------------------------------ pre-split producers (round 4)
+// The consumers of these activations / gradients are the split-fp16 convolution kernels (conv_split.hip), which want every operand
+// as fp16 (hi, mid) parts in the slot layout  xs [B][C/8][H][part 2][W][8]  (16 bytes = 8 channels of one pixel; 4 bytes per
+// element, the fp32 tensor's footprint).  Written HERE, by the pass that produces the values, the MFMA kernels' staging becomes an
+// LDS-DMA copy (no conversion VALU, no ds_write).  A thread owns 8 channels of one pixel: 8 coalesced 4-byte loads (one per channel
+// plane), the arithmetic of the fp32 pass -- the values split are bit for bit the ones bn_relu_apply_kernel / bn_relu_bwd_apply_kernel
+// write -- and two 16-byte stores.  C % 8 == 0.
+typedef unsigned bn_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void bn_pixel_of(int p, int W, int& y, int& x) {          // p = y W + x without an integer division
+    y = (int)((float)p * (1.0f / (float)W));
+    if (y * W > p) --y;
+    if ((y + 1) * W <= p) ++y;
+    x = p - y * W;
+}
+__device__ __forceinline__ void bn_store_slots(unsigned* __restrict__ xs, int64_t slot, int W, const float (&v)[8], float s) {
+    bn_u32x4 hi, mid;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        unsigned h, m;
+        split2h_s(v[2 * k], v[2 * k + 1], s, h, m);
+        hi[k] = h;
+        mid[k] = m;
+    }
+    bn_u32x4* d = reinterpret_cast<bn_u32x4*>(xs) + slot;
+    d[0] = hi;
+    d[W] = mid;
+}
+
+// The values of FOUR consecutive pixels per thread (float4 loads along x: the fp32 passes' instruction mix) leave as 16-byte slots of
+// ONE pixel each -- written from the loading thread, a store instruction's 64 lanes hit 16 bytes out of every 64 (quarter-filled
+// write transactions: measured 0.108 against 0.085 ms per launch for the forward pass).  So a 256-thread block trades its 1024
+// pixels x 2 parts through LDS (one padding slot per four: the 64-byte lane stride of the writes becomes 80 bytes, conflict-free
+// per 16 lanes) and stores lane-linear: every store instruction writes 1 KB of consecutive slots.
+constexpr int BN_TR_SLOTS = 2 * (1024 + 256);       // 40 KB of LDS per block
+#ifndef BN_APPLY_SPLIT_TR
+#define BN_APPLY_SPLIT_TR 1
+#endif
+__device__ __forceinline__ void bn_store_slots_block(bn_u32x4* lds, unsigned* __restrict__ xs, int c8, int H, int W, int p_blk, int HW,
+                                                     const float (&v)[4][8], float s) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        bn_u32x4 hi, mid;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned h, m;
+            split2h_s(v[q][2 * k], v[q][2 * k + 1], s, h, m);
+            hi[k] = h;
+            mid[k] = m;
+        }
+        lds[5 * t + q] = hi;
+        lds[1280 + 5 * t + q] = mid;
+    }
+    __syncthreads();
+    bn_u32x4* dst = reinterpret_cast<bn_u32x4*>(xs);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int part = j >> 2, px = (j & 3) * 256 + t, p = p_blk + px;
+        if (p < HW) {
+            int y, x;
+            bn_pixel_of(p, W, y, x);
+            dst[((int64_t)(c8 * H + y) * 2 + part) * W + x] = lds[part * 1280 + px + (px >> 2)];
+        }
+    }
+}
+
+// a = relu(bn(z)) -> xs (pre-split) and, where `a` is given, the fp32 tensor too.  A thread owns 8 channels of four pixels 64 apart
+// (a wave covers 256 consecutive pixels, four times 64): every load is a coalesced 256-byte row piece of one channel plane and
+// every 16-byte slot store lands next to its neighbour lanes' (1 KB contiguous per store instruction).  Measured against the
+// variant with four CONSECUTIVE pixels per thread (float4 loads, slot stores 64 bytes apart between lanes): 0.085 vs 0.108 ms per
+// launch -- the strided 16-byte stores cost more than the narrower loads.
+__global__ __launch_bounds__(256) void bn_relu_apply_split_kernel(const float* __restrict__ z, int64_t z_bs, unsigned* __restrict__ xs,
+                                                                  int64_t xs_bs, float* __restrict__ a, int64_t a_bs,
+                                                                  const float* __restrict__ save, int C, int H, int W, int bpp) {
+    const int plane = blockIdx.x / bpp, blk = blockIdx.x % bpp;
+    const int C8 = C >> 3, b = plane / C8, c8 = plane % C8;
+#if BN_APPLY_SPLIT_TR
+    {   // variant: four CONSECUTIVE pixels per thread (float4 loads) and the block's slots traded through LDS for coalesced stores
+        __shared__ bn_u32x4 tr[BN_TR_SLOTS];
+        const int HW = H * W, p = (blk * 256 + threadIdx.x) * 4;
+        const bool live = p < HW;
+        const float* src = z + (int64_t)b * z_bs + (int64_t)c8 * 8 * HW + p;
+        float v[4][8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = c8 * 8 + k;
+            const float mean = save[c], sc = save[2 * C + c], sh = save[3 * C + c];
+            const float4 q = live ? *reinterpret_cast<const float4*>(src + (int64_t)k * HW) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[0][k] = fmaxf(fmaf(q.x - mean, sc, sh), 0.f);
+            v[1][k] = fmaxf(fmaf(q.y - mean, sc, sh), 0.f);
+            v[2][k] = fmaxf(fmaf(q.z - mean, sc, sh), 0.f);
+            v[3][k] = fmaxf(fmaf(q.w - mean, sc, sh), 0.f);
+        }
+        if (a && live) {
+            float* d = a + (int64_t)b * a_bs + (int64_t)c8 * 8 * HW + p;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) *reinterpret_cast<float4*>(d + (int64_t)k * HW) = make_float4(v[0][k], v[1][k], v[2][k], v[3][k]);
+        }
+        bn_store_slots_block(tr, xs + (int64_t)b * xs_bs, c8, H, W, blk * 1024, HW, v, 1.f);
+        return;
+    }
+#endif
+    const int HW = H * W, lane = threadIdx.x & 63, p0 = blk * 1024 + (threadIdx.x >> 6) * 256 + lane;
+    const float* src = z + (int64_t)b * z_bs + (int64_t)c8 * 8 * HW;
+    float v[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = p0 + 64 * j;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[j][k] = p < HW ? src[(int64_t)k * HW + p] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = c8 * 8 + k;
+        const float mean = save[c], sc = save[2 * C + c], sh = save[3 * C + c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j][k] = fmaxf(fmaf(v[j][k] - mean, sc, sh), 0.f);
+    }
+    unsigned* o = xs + (int64_t)b * xs_bs;
+    float* d = a ? a + (int64_t)b * a_bs + (int64_t)c8 * 8 * HW : nullptr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = p0 + 64 * j;
+        if (p >= HW) continue;
+        int y, x;
+        bn_pixel_of(p, W, y, x);
+        if (d) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d[(int64_t)k * HW + p] = v[j][k];
+        }
+        bn_store_slots(o, ((int64_t)(c8 * H + y) * 2) * W + x, W, v[j], 1.f);
+    }
+}
+
+// ... of an encoder output that is max-pooled next: a thread owns 8 channels of a 2 x 4 pixel patch (W % 4 == 0), writes the activation
+// pre-split (xs: the skip groups of a concat buffer) and / or in fp32 (a), and the two pooled pixels pre-split (ys) or in fp32 (yf)
+__global__ __launch_bounds__(256) void bn_relu_apply_pool_split_kernel(const float* __restrict__ z, int64_t z_bs, unsigned* __restrict__ xs,
+                                                                       int64_t xs_bs, float* __restrict__ a, int64_t a_bs,
+                                                                       unsigned* __restrict__ ys, int64_t ys_bs, float* __restrict__ yf,
+                                                                       int64_t yf_bs, const float* __restrict__ save, int C, int H, int W,
+                                                                       int bpp) {
+    const int plane = blockIdx.x / bpp, blk = blockIdx.x % bpp;
+    const int C8 = C >> 3, b = plane / C8, c8 = plane % C8;
+    const int Hp = H >> 1, Wp = W >> 1, W4 = W >> 2, HW = H * W, i = blk * 256 + threadIdx.x;
+    if (i >= Hp * W4) return;
+    int yo, q;
+    bn_pixel_of(i, W4, yo, q);
+    const int64_t in_off = (int64_t)c8 * 8 * HW + (int64_t)(2 * yo) * W + 4 * q;
+    const float* src = z + (int64_t)b * z_bs + in_off;
+    float v[8][8], m[2][8];                     // [pixel: row 0 cols 0-3, row 1 cols 0-3][channel]; [pooled pixel][channel]
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = c8 * 8 + k;
+        const float mean = save[c], sc = save[2 * C + c], sh = save[3 * C + c];
+        const float4 r0 = *reinterpret_cast<const float4*>(src + (int64_t)k * HW), r1 = *reinterpret_cast<const float4*>(src + (int64_t)k * HW + W);
+        v[0][k] = fmaxf(fmaf(r0.x - mean, sc, sh), 0.f);
+        v[1][k] = fmaxf(fmaf(r0.y - mean, sc, sh), 0.f);
+        v[2][k] = fmaxf(fmaf(r0.z - mean, sc, sh), 0.f);
+        v[3][k] = fmaxf(fmaf(r0.w - mean, sc, sh), 0.f);
+        v[4][k] = fmaxf(fmaf(r1.x - mean, sc, sh), 0.f);
+        v[5][k] = fmaxf(fmaf(r1.y - mean, sc, sh), 0.f);
+        v[6][k] = fmaxf(fmaf(r1.z - mean, sc, sh), 0.f);
+        v[7][k] = fmaxf(fmaf(r1.w - mean, sc, sh), 0.f);
+        m[0][k] = fmaxf(fmaxf(v[0][k], v[1][k]), fmaxf(v[4][k], v[5][k]));
+        m[1][k] = fmaxf(fmaxf(v[2][k], v[3][k]), fmaxf(v[6][k], v[7][k]));
+    }
+    if (a) {
+        float* d = a + (int64_t)b * a_bs + in_off;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            *reinterpret_cast<float4*>(d + (int64_t)k * HW) = make_float4(v[0][k], v[1][k], v[2][k], v[3][k]);
+            *reinterpret_cast<float4*>(d + (int64_t)k * HW + W) = make_float4(v[4][k], v[5][k], v[6][k], v[7][k]);
+        }
+    }
+    if (xs) {
+        unsigned* o = xs + (int64_t)b * xs_bs;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            bn_store_slots(o, ((int64_t)(c8 * H + 2 * yo + (e >> 2)) * 2) * W + 4 * q + (e & 3), W, v[e], 1.f);
+    }
+    if (ys) {
+        unsigned* o = ys + (int64_t)b * ys_bs;
+        bn_store_slots(o, ((int64_t)(c8 * Hp + yo) * 2) * Wp + 2 * q, Wp, m[0], 1.f);
+        bn_store_slots(o, ((int64_t)(c8 * Hp + yo) * 2) * Wp + 2 * q + 1, Wp, m[1], 1.f);
+    }
+    if (yf) {
+        float* d = yf + (int64_t)b * yf_bs + (int64_t)c8 * 8 * Hp * Wp + (int64_t)yo * Wp + 2 * q;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) *reinterpret_cast<float2*>(d + (int64_t)k * Hp * Wp) = make_float2(m[0][k], m[1][k]);
+    }
+}
+
+// dz of the BatchNorm + ReLU backward (bn_relu_bwd_apply_kernel's arithmetic: fp64 per element, rounded once) pre-split: fp16 parts
+// of 2^k dz with k = amax_scale(bound) from the magnitude slots (`slots`: an upper bound of |dz| written by bn_bwd_bound_kernel
+// BEFORE this pass; the consumers read the same slots and undo 2^k on their accumulators).  8 channels x 4 pixels per thread.
+__global__ __launch_bounds__(256) void bn_relu_bwd_apply_split_kernel(const float* __restrict__ da, int64_t da_bs, const float* __restrict__ z,
+                                                                      int64_t z_bs, const float* __restrict__ save, const float* __restrict__ coef,
+                                                                      unsigned* __restrict__ dzs, int64_t dzs_bs, const unsigned* __restrict__ slots,
+                                                                      int C, int H, int W, int bpp) {
+    float inv;
+    const float s = amax_scale(amax_read(slots), true, inv);
+    const int plane = blockIdx.x / bpp, blk = blockIdx.x % bpp;
+    const int C8 = C >> 3, b = plane / C8, c8 = plane % C8;
+    __shared__ bn_u32x4 tr[BN_TR_SLOTS];
+    const int HW = H * W, p = (blk * 256 + threadIdx.x) * 4;
+    const bool live = p < HW;                     // (HW % 4 == 0: a thread's four pixels are all inside or all outside)
+    const float* zs = z + (int64_t)b * z_bs + (int64_t)c8 * 8 * HW + p;
+    const float* ds = da + (int64_t)b * da_bs + (int64_t)c8 * 8 * HW + p;
+    float4 zq[8], gq[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {                 // all sixteen 16-byte loads in flight before the first use
+        zq[k] = live ? *reinterpret_cast<const float4*>(zs + (int64_t)k * HW) : make_float4(0.f, 0.f, 0.f, 0.f);
+        gq[k] = live ? *reinterpret_cast<const float4*>(ds + (int64_t)k * HW) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float v[4][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = c8 * 8 + k;
+        const float mean = save[c], invstd = save[C + c], sc = save[2 * C + c], sh = save[3 * C + c];
+        const double c1 = coef ? (double)coef[c] + (double)coef[C + c] : 0.0;
+        const double c2 = coef ? (double)coef[2 * C + c] + (double)coef[3 * C + c] : 0.0;
+        const float zz[4] = {zq[k].x, zq[k].y, zq[k].z, zq[k].w}, gg[4] = {gq[k].x, gq[k].y, gq[k].z, gq[k].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const double dy = fmaf(zz[e] - mean, sc, sh) > 0.f ? (double)gg[e] : 0.0;
+            v[e][k] = (float)((double)sc * (dy - c1 - (((double)zz[e] - (double)mean) * (double)invstd) * c2));
+        }
+    }
+    bn_store_slots_block(tr, dzs + (int64_t)b * dzs_bs, c8, H, W, blk * 1024, HW, v, s);
+}
+
+// |dz| <= |scale_c| (max |da| + |c1| + |c2| max |xhat|) with |xhat| <= sqrt(N - 1) for a channel of N values: the maximum over the
+// channels goes into the dz magnitude slots (atomicMax; the launches of a twin batch's statistics groups share them).  da_slots:
+// the exact max |da| recorded by the pass that reduced da (bn_relu_bwd_reduce_amax and the fused producers).
+__global__ __launch_bounds__(64) void bn_bwd_bound_kernel(const float* __restrict__ save, const float* __restrict__ coef,
+                                                          const unsigned* __restrict__ da_slots, float xhat_max, unsigned* __restrict__ dz_slots,
+                                                          int C) {
+    const float da_max = amax_read(da_slots);
+    float bound = 0.f;
+    for (int c = blockIdx.x * 64 + threadIdx.x; c < C; c += gridDim.x * 64) {
+        const float c1 = coef ? fabsf(coef[c]) + fabsf(coef[C + c]) : 0.f, c2 = coef ? fabsf(coef[2 * C + c]) + fabsf(coef[3 * C + c]) : 0.f;
+        bound = fmaxf(bound, fabsf(save[2 * C + c]) * (da_max + c1 + c2 * xhat_max));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bound = fmaxf(bound, __shfl_xor(bound, o, 64));
+    if (threadIdx.x == 0 && bound == bound) atomicMax(dz_slots + (blockIdx.x & 63) * AMAX_STRIDE, __builtin_bit_cast(unsigned, bound));
+}
+
 // backward pass 1: part2[p][c] = (sum dy, sum dy*xhat), dy = da * [(z-mean)*scale+beta > 0].
 // Sums are taken in fp64 (ATen's CPU kernel accumulates in double): both sums cancel heavily
 // (BN outputs are zero-mean), so fp32 accumulation would cost orders of magnitude of accuracy.
@@ -312,8 +559,9 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const float* __
                                                                  const float* __restrict__ z, int64_t z_bs,
                                                                  const float* __restrict__ save,
                                                                  float* __restrict__ part2, int C, int HW,
-                                                                 int chunks, int chunk_len) {
+                                                                 int chunks, int chunk_len, unsigned* __restrict__ amax = nullptr) {
     __shared__ double red[8];
+    float vmax = 0.f;                           // amax: magnitude slots of da (what bounds the dz this layer's apply pass writes)
     const int c = blockIdx.x % C;
     const int p = blockIdx.x / C;
     const int b = p / chunks, ch = p % chunks;
@@ -341,6 +589,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const float* __
                     const double dy = fmaf(zz[e] - mean, sc, sh) > 0.f ? (double)gg[e] : 0.0;
                     v[0] += dy;
                     v[1] += dy * (((double)zz[e] - meand) * invd);
+                    vmax = fmaxf(vmax, fabsf(gg[e]));
                 }
             }
         }
@@ -354,6 +603,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const float* __
                 const double dy = fmaf(zz[k] - mean, sc, sh) > 0.f ? (double)gg[k] : 0.0;
                 v[0] += dy;
                 v[1] += dy * (((double)zz[k] - meand) * invd);
+                vmax = fmaxf(vmax, fabsf(gg[k]));
             }
         }
     } else {
@@ -361,8 +611,10 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const float* __
             const double dy = fmaf(zs[i] - mean, sc, sh) > 0.f ? (double)ds[i] : 0.0;
             v[0] += dy;
             v[1] += dy * (((double)zs[i] - meand) * invd);
+            vmax = fmaxf(vmax, fabsf(ds[i]));
         }
     }
+    amax_commit(vmax, amax);
     block_sum_256<double, 2>(v, red);
     if (threadIdx.x == 0) {
         // two floats per sum (hi + lo) keep ~48 bits through the float partial buffer
@@ -376,7 +628,12 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const float* __
 
 __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ part2, int nparts,
                                                              double count, float* dgamma, float* dbeta,
-                                                             float* coef, int accumulate, int C) {
+                                                             float* coef, int accumulate, int C, const float* __restrict__ save = nullptr,
+                                                             const unsigned* __restrict__ da_slots = nullptr,
+                                                             unsigned* __restrict__ dz_slots = nullptr, float xhat_max = 0.f) {
+    // dz_slots (pre-split storage): this channel's bound of |dz| (see bn_bwd_bound_kernel) goes into the dz magnitude slots here,
+    // saving that launch; da_slots must be complete (every reduce launch of the tensor precedes the first finalize)
+    const float da_max = dz_slots ? amax_read(da_slots) : 0.f;
     const int c = blockIdx.x;
     double s = 0.0, sx = 0.0;
     for (int p = threadIdx.x; p < nparts; p += 64) {
@@ -395,6 +652,11 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __rest
             coef[C + c] = (float)(c1 - (double)(float)c1);
             coef[2 * C + c] = (float)c2;
             coef[3 * C + c] = (float)(c2 - (double)(float)c2);
+        }
+        if (dz_slots) {
+            const double c1 = coef ? s / count : 0.0, c2 = coef ? sx / count : 0.0;
+            const float bound = fabsf(save[2 * C + c]) * (da_max + (float)fabs(c1) * 1.0000002f + (float)fabs(c2) * 1.0000002f * xhat_max);
+            if (bound == bound) atomicMax(dz_slots + (c & 63) * AMAX_STRIDE, __builtin_bit_cast(unsigned, bound));
         }
     }
 }
@@ -625,6 +887,64 @@ int onet_bn_relu_bwd_reduce(const float* da, int64_t da_bs, const float* z, int6
     return check_launch("bn_relu_bwd_reduce_kernel");
 }
 
+int onet_bn_relu_bwd_reduce_amax(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save, float* part2, int nparts,
+                                 void* da_amax, int B, int C, int HW, void* stream) {
+    ONET_REQUIRE(da && z && save && part2 && da_amax && B > 0 && C > 0 && HW > 0, "bn_relu_bwd_reduce_amax: bad args");
+    int chunks, chunk_len;
+    ONET_REQUIRE(split_plan(nparts, B, HW, chunks, chunk_len), "bn_relu_bwd_reduce_amax: nparts=%d must be a multiple of B=%d", nparts, B);
+    hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3((unsigned)((int64_t)nparts * C)), dim3(256), 0, as_stream(stream), da, da_bs, z, z_bs,
+                       save, part2, C, HW, chunks, chunk_len, (unsigned*)da_amax);
+    return check_launch("bn_relu_bwd_reduce_kernel");
+}
+
+int onet_bn_bwd_bound(const float* save, const float* coef, const void* da_amax, int64_t count, void* dz_amax, int C, void* stream) {
+    ONET_REQUIRE(save && da_amax && dz_amax && count > 0 && C > 0, "bn_bwd_bound: bad args");
+    hipLaunchKernelGGL(bn_bwd_bound_kernel, dim3(cdiv(C, 64)), dim3(64), 0, as_stream(stream), save, coef, (const unsigned*)da_amax,
+                       sqrtf((float)(count > 1 ? count - 1 : 1)), (unsigned*)dz_amax, C);
+    return check_launch("bn_bwd_bound_kernel");
+}
+
+int onet_bn_relu_apply_split(const float* z, int64_t z_bs, void* xs, int64_t xs_bs, float* a, int64_t a_bs, const float* save, int B, int C,
+                             int H, int W, void* stream) {
+    ONET_REQUIRE(z && xs && save && B > 0 && C > 0 && (C % 8) == 0 && H > 0 && W > 0 && (W % 4) == 0, "bn_relu_apply_split: bad args (C %% 8 == 0, W %% 4 == 0)");
+    ONET_REQUIRE((reinterpret_cast<uintptr_t>(xs) & 15) == 0 && (xs_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(z) & 15) == 0 && (z_bs & 3) == 0 &&
+                 (reinterpret_cast<uintptr_t>(a) & 15) == 0 && (a_bs & 3) == 0, "bn_relu_apply_split: 16-byte aligned rows and slots required");
+    const int bpp = cdiv((int64_t)H * W, 1024);
+    const int64_t blocks = (int64_t)B * (C / 8) * bpp;
+    ONET_REQUIRE(blocks < (1ll << 31) && (int64_t)H * W < (1 << 24), "bn_relu_apply_split: grid too large");
+    hipLaunchKernelGGL(bn_relu_apply_split_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), z, z_bs, (unsigned*)xs, xs_bs, a,
+                       a_bs, save, C, H, W, bpp);
+    return check_launch("bn_relu_apply_split_kernel");
+}
+
+int onet_bn_relu_apply_pool_split(const float* z, int64_t z_bs, void* xs, int64_t xs_bs, float* a, int64_t a_bs, void* ys, int64_t ys_bs,
+                                  float* y, int64_t y_bs, const float* save, int B, int C, int H, int W, void* stream) {
+    ONET_REQUIRE(z && (xs || a) && (ys || y) && save && B > 0 && C > 0 && (C % 8) == 0 && H > 0 && W > 0, "bn_relu_apply_pool_split: bad args");
+    auto al = [](const void* p, uintptr_t m) { return (reinterpret_cast<uintptr_t>(p) & m) == 0; };
+    if ((H & 1) || (W & 3) || (z_bs & 3) || (a_bs & 3) || (xs_bs & 3) || (ys_bs & 3) || (y_bs & 1) || !al(z, 15) || !al(a, 15) || !al(xs, 15) ||
+        !al(ys, 15) || !al(y, 7))
+        return 1;                                  // not taken
+    const int bpp = cdiv((int64_t)(H / 2) * (W / 4), 256);
+    const int64_t blocks = (int64_t)B * (C / 8) * bpp;
+    ONET_REQUIRE(blocks < (1ll << 31) && (int64_t)H * W < (1 << 24), "bn_relu_apply_pool_split: grid too large");
+    hipLaunchKernelGGL(bn_relu_apply_pool_split_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), z, z_bs, (unsigned*)xs, xs_bs,
+                       a, a_bs, (unsigned*)ys, ys_bs, y, y_bs, save, C, H, W, bpp);
+    return check_launch("bn_relu_apply_pool_split_kernel");
+}
+
+int onet_bn_relu_bwd_apply_split(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save, const float* coef,
+                                 void* dzs, int64_t dzs_bs, const void* dz_amax, int B, int C, int H, int W, void* stream) {
+    ONET_REQUIRE(da && z && save && dzs && dz_amax && B > 0 && C > 0 && (C % 8) == 0 && H > 0 && W > 0 && (W % 4) == 0, "bn_relu_bwd_apply_split: bad args");
+    ONET_REQUIRE((reinterpret_cast<uintptr_t>(dzs) & 15) == 0 && (dzs_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(z) & 15) == 0 && (z_bs & 3) == 0 &&
+                 (reinterpret_cast<uintptr_t>(da) & 15) == 0 && (da_bs & 3) == 0, "bn_relu_bwd_apply_split: 16-byte aligned rows and slots required");
+    const int bpp = cdiv((int64_t)H * W, 1024);
+    const int64_t blocks = (int64_t)B * (C / 8) * bpp;
+    ONET_REQUIRE(blocks < (1ll << 31) && (int64_t)H * W < (1 << 24), "bn_relu_bwd_apply_split: grid too large");
+    hipLaunchKernelGGL(bn_relu_bwd_apply_split_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), da, da_bs, z, z_bs, save, coef,
+                       (unsigned*)dzs, dzs_bs, (const unsigned*)dz_amax, C, H, W, bpp);
+    return check_launch("bn_relu_bwd_apply_split_kernel");
+}
+
 int onet_bn_bwd_finalize_cm(const float* part2, int nparts, int64_t c_stride, int64_t count, float* dgamma, float* dbeta,
                             float* coef, int accumulate, int C, void* stream) {
     ONET_REQUIRE(part2 && nparts > 0 && count > 0 && C > 0 && c_stride >= (int64_t)nparts * 2, "bn_bwd_finalize_cm: bad args");
@@ -638,6 +958,14 @@ int onet_bn_bwd_finalize(const float* part2, int nparts, int64_t count, float* d
     ONET_REQUIRE(part2 && nparts > 0 && count > 0 && C > 0, "bn_bwd_finalize: bad args");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, as_stream(stream), part2, nparts,
                        (double)count, dgamma, dbeta, coef, accumulate, C);
+    return check_launch("bn_bwd_finalize_kernel");
+}
+
+int onet_bn_bwd_finalize_bound(const float* part2, int nparts, int64_t count, float* dgamma, float* dbeta, float* coef, int accumulate,
+                               int C, const float* save, const void* da_amax, void* dz_amax, void* stream) {
+    ONET_REQUIRE(part2 && nparts > 0 && count > 0 && C > 0 && save && da_amax && dz_amax, "bn_bwd_finalize_bound: bad args");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, as_stream(stream), part2, nparts, (double)count, dgamma, dbeta, coef,
+                       accumulate, C, save, (const unsigned*)da_amax, (unsigned*)dz_amax, sqrtf((float)(count > 1 ? count - 1 : 1)));
     return check_launch("bn_bwd_finalize_kernel");
 }
 

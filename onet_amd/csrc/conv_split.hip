@@ -63,44 +63,6 @@ __device__ __forceinline__ void split2h(float a, float b, unsigned& hi, unsigned
     mid = __builtin_bit_cast(unsigned, m);
 }
 
-// Scaled fp16 split in FOUR VALU per value pair: hi = fp16(s v), mid = fp16(s v - hi) with v_fma_mixlo/mixhi_f16 -- the fma of
-// fp32 operands (and, for mid, the fp16 hi part read straight from its register half) rounded once to fp16 into the low / high
-// half of the destination.  s is a power of two, so s v is exact and hi, mid are bit for bit what split2h gives for s v (which the
-// compiler builds from v_cvt_pk_f16_f32 + two v_cvt_f32_f16 + two v_sub + v_cvt_pk: six VALU per pair): the scale rides free.
-__device__ __forceinline__ void split2h_s(float a, float b, float s, unsigned& hi, unsigned& mid) {
-    unsigned h, m;
-    asm("v_fma_mixlo_f16 %0, %1, %3, 0 op_sel_hi:[0,0,0]\n\tv_fma_mixhi_f16 %0, %2, %3, 0 op_sel_hi:[0,0,0]"
-        : "=&v"(h) : "v"(a), "v"(b), "v"(s));
-    asm("v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-        : "=&v"(m) : "v"(a), "v"(b), "v"(s), "v"(h));
-    hi = h;
-    mid = m;
-}
-
-// Per-tensor magnitude slots: 64 unsigned words holding max |v| as fp32 bits (non-negative floats order like their bit patterns,
-// so atomicMax on the bits is an order-independent, i.e. deterministic, maximum); producers (bn.hip, the weight pack) spread their
-// updates over the 64 words by block index, readers take the maximum of all 64.  -> wave-uniform fp32 amax (0: no information).
-constexpr int AMAX_SLOTS = 64, AMAX_STRIDE = 32;      // 64 slots, one per 128-byte line (bn.hip: amax_commit)
-__device__ __forceinline__ float amax_read(const unsigned* slots) {
-    if (!slots) return 0.f;
-    unsigned v = slots[(threadIdx.x & (AMAX_SLOTS - 1)) * AMAX_STRIDE];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 64));
-    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(v));
-}
-// power-of-two scale for an fp16 split of a tensor whose largest magnitude is amax: `always` -> amax lands in [2^13, 2^14) (the
-// gradients: their magnitude is anyone's guess and fp16's 5-bit exponent is narrow); otherwise only when amax >= 2^15 would leave
-// fp16's range (the forward activations: a range GUARD that leaves ordinary tensors -- and the bit-identity statements made about
-// them -- untouched).  -> scale s = 2^k; the caller undoes it with 2^-k on the accumulators (exact).
-__device__ __forceinline__ float amax_scale(float amax, bool always, float& inv) {
-    const unsigned bits = __builtin_bit_cast(unsigned, amax);
-    const int e = (int)((bits >> 23) & 255u) - 127;                    // floor(log2(amax))
-    int k = 0;
-    if (bits != 0u && e < 128) k = (always || e >= 15) ? 13 - e : 0;
-    k = max(-100, min(100, k));
-    inv = __builtin_bit_cast(float, (unsigned)(127 - k) << 23);
-    return __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
-}
 __global__ void absmax_slots_kernel(const float* __restrict__ v, int64_t n, unsigned* __restrict__ slots) {
     float m = 0.f;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(v[i]));
@@ -650,7 +612,8 @@ struct SpPreArgs {
     int64_t z_bs;
     int B, Cin, Cout, H, W, tilesX, tilesY, coTiles;
     float* stats;         // ST: BatchNorm partials (as conv3x3_split_kernel)
-    float out_scale;      // applied to the accumulators (undoes the activation's power-of-two scale; the fp16 pack's own is read from the pack)
+    const unsigned* x_slots;   // magnitude slots the producer scaled xs by (NULL: unscaled); x_always: the rule it used (amax_scale)
+    int x_always;
 };
 
 #ifndef SP_PRE_LAST_TAP
@@ -683,7 +646,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_pre_kernel(SpPreArgs a) 
     const int nchunks = a.Cin >> 4;
 
     const i32x4s wr = sp_rsrc4(a.wq, (int64_t)a.Cin * 2 * 9 * a.Cout * 2);
-    const float acc_scale = a.out_scale * (F16 ? reinterpret_cast<const float*>(a.wq + (int64_t)a.Cin * 2 * 9 * a.Cout)[1] : 1.f);
+    float xs_inv = 1.f;
+    (void)amax_scale(amax_read(a.x_slots), a.x_always != 0, xs_inv);
+    const float acc_scale = xs_inv * (F16 ? reinterpret_cast<const float*>(a.wq + (int64_t)a.Cin * 2 * 9 * a.Cout)[1] : 1.f);
     const unsigned in_step = (unsigned)(16 * HW * 4), w_step = (unsigned)(2 * 9 * 2 * a.Cout * 16);
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_s;
 
@@ -1328,7 +1293,8 @@ struct SwPreArgs {
     int64_t dzs_bs;
     float* slab;
     int B, Cin, Cout, H, W, ciTiles, coTiles, splitK, tilesX;
-    float out_scale;
+    const unsigned* x_slots;    // magnitude slots the producers scaled the operands by (NULL: unscaled); x: guard rule, dz: always
+    const unsigned* dz_slots;
 };
 constexpr int SWP_PXP = 68;
 
@@ -1492,6 +1458,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_pre_kernel(SwPreAr
         u += ye - yb;
     }
 
+    float x_inv = 1.f, dz_inv = 1.f;
+    (void)amax_scale(amax_read(a.x_slots), false, x_inv);
+    (void)amax_scale(amax_read(a.dz_slots), true, dz_inv);
+    const float out_scale = (a.x_slots ? x_inv : 1.f) * (a.dz_slots ? dz_inv : 1.f);
     const int64_t n = (int64_t)a.Cout * a.Cin;
     const int ci = ci0 + wn * 32 + l31;
 #pragma unroll
@@ -1500,7 +1470,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_pre_kernel(SwPreAr
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (co < a.Cout && ci < a.Cin) o[(int64_t)co * a.Cin + ci] = acc[t][r] * a.out_scale;
+            if (co < a.Cout && ci < a.Cin) o[(int64_t)co * a.Cin + ci] = acc[t][r] * out_scale;
         }
     }
 }
@@ -1600,8 +1570,9 @@ int onet_conv3x3_split_wgrad_pre_ok(int B, int Cin, int Cout, int H, int W) {
     return (W == 32 && B % 2 == 0) ? 1 : 0;
 }
 
-int onet_conv3x3_split_wgrad_pre(const void* xs, int64_t xs_bs, const void* dzs, int64_t dzs_bs, int f16, float out_scale, float* dw,
-                                 void* ws, int64_t ws_bytes, int B, int Cin, int Cout, int H, int W, int accumulate, void* stream) {
+int onet_conv3x3_split_wgrad_pre(const void* xs, int64_t xs_bs, const void* x_amax, const void* dzs, int64_t dzs_bs, const void* dz_amax,
+                                 int f16, float* dw, void* ws, int64_t ws_bytes, int B, int Cin, int Cout, int H, int W, int accumulate,
+                                 void* stream) {
     ONET_REQUIRE(xs && dzs && dw && ws, "conv3x3_split_wgrad_pre: null pointer");
     ONET_REQUIRE(onet_conv3x3_split_wgrad_pre_ok(B, Cin, Cout, H, W),
                  "conv3x3_split_wgrad_pre: needs Cin, Cout %% 8 == 0 and W >= 64, or W = 32 with an even batch");
@@ -1614,7 +1585,8 @@ int onet_conv3x3_split_wgrad_pre(const void* xs, int64_t xs_bs, const void* dzs,
                             ((int64_t)(B - 1) * dzs_bs + (int64_t)Cout * H * W) * 4 < (1ll << 31)),
                  "conv3x3_split_wgrad_pre: on 32-pixel maps the whole batch must lie within the 2 GiB buffer-resource range");
     const int COT = split_wgrad_cot(Cout, W), slabs = COT == 64 ? 2 : 1;
-    SwPreArgs a{xs, xs_bs, dzs, dzs_bs, (float*)ws, B, Cin, Cout, H, W, cdiv(Cin, 64), cdiv(Cout, COT), 1, 1, out_scale};
+    SwPreArgs a{xs, xs_bs, dzs, dzs_bs, (float*)ws, B, Cin, Cout, H, W, cdiv(Cin, 64), cdiv(Cout, COT), 1, 1, (const unsigned*)x_amax,
+                (const unsigned*)dz_amax};
     split_wgrad_plan(B, Cin, Cout, H, W, a.splitK, a.tilesX);
     const int64_t need = (int64_t)a.splitK * slabs * 9 * Cout * Cin * 4;
     ONET_REQUIRE(ws_bytes >= need, "conv3x3_split_wgrad_pre: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
@@ -1711,8 +1683,8 @@ int onet_split_pack_act(const float* x, int64_t x_bs, void* xs, int64_t xs_bs, i
     return check_launch("split_pack_act_kernel");
 }
 
-int onet_conv3x3_split_fwd_pre(const void* xs, int64_t xs_bs, const void* wq, int wq_f16, float out_scale, float* z, int64_t z_bs,
-                               float* part, int B, int Cin, int Cout, int H, int W, void* stream) {
+int onet_conv3x3_split_fwd_pre(const void* xs, int64_t xs_bs, const void* x_amax, int scale_always, const void* wq, int wq_f16, float* z,
+                               int64_t z_bs, float* part, int B, int Cin, int Cout, int H, int W, void* stream) {
     ONET_REQUIRE(xs && wq && z, "conv3x3_split_fwd_pre: null pointer");
     ONET_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 16, "conv3x3_split_fwd_pre: bad shape (maps wider than 16 pixels)");
     ONET_REQUIRE((Cin % 16) == 0, "conv3x3_split_fwd_pre: Cin must be a multiple of 16");
@@ -1720,7 +1692,7 @@ int onet_conv3x3_split_fwd_pre(const void* xs, int64_t xs_bs, const void* wq, in
     ONET_REQUIRE(xs_bs >= (int64_t)Cin * H * W && z_bs >= (int64_t)Cout * H * W, "conv3x3_split_fwd_pre: batch stride too small");
     ONET_REQUIRE((int64_t)(Cin + 32) * H * W * 4 < (1ll << 31) && (int64_t)(Cin + 32) * 2 * 9 * Cout * 2 < (1ll << 31),
                  "conv3x3_split_fwd_pre: operand exceeds the 2 GiB buffer-resource range");
-    SpPreArgs a{xs, xs_bs, (const __bf16*)wq, z, z_bs, B, Cin, Cout, H, W, 0, 0, 0, part, out_scale};
+    SpPreArgs a{xs, xs_bs, (const __bf16*)wq, z, z_bs, B, Cin, Cout, H, W, 0, 0, 0, part, (const unsigned*)x_amax, scale_always};
     if (part) ONET_REQUIRE(split_nparts(B, H, W) > 0, "conv3x3_split_fwd_pre: statistics need a map made of full 16 x 32 tiles");
     if (wq_f16) return part ? launch_split_pre<true, true>(a, as_stream(stream)) : launch_split_pre<false, true>(a, as_stream(stream));
     return part ? launch_split_pre<true, false>(a, as_stream(stream)) : launch_split_pre<false, false>(a, as_stream(stream));

@@ -139,6 +139,8 @@ struct GArgs {
     int64_t a_bs, b_bs, out_bs;
     int B, Cin, Ct, h, w, Wo, HoWo;   // y / dy plane: Ho x Wo with Ho = 2h, Wo = 2w (fast path: no F.pad offsets)
     int mTiles, nTiles, splitK, chunksPerSplit;
+    int out16_split;      // forward: out16 is NOT a bf16 copy but the PRE-SPLIT destination (fp16 hi | mid slots [B][Ct/8][Ho][2][Wo][8],
+                          // conv_split.hip; out16_bs in 4-byte units): the up-sampled groups of a pre-split concat buffer
 };
 
 __device__ __forceinline__ int xcd_order(int n) {
@@ -314,11 +316,49 @@ __global__ __launch_bounds__(256, 2) void convt_gemm_kernel(GArgs g) {
                         *reinterpret_cast<float2*>(o) = make_float2(v0, v1);
                         *reinterpret_cast<float2*>(o + g.Wo) = make_float2(v2, v3);
                     }
-                    if (g.out16) {
+                    if (g.out16 && !g.out16_split) {
                         typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
                         __bf16* o16 = g.out16 + (int64_t)b * g.out16_bs + oo;
                         *reinterpret_cast<bf2*>(o16) = bf2{(__bf16)v0, (__bf16)v1};
                         *reinterpret_cast<bf2*>(o16 + g.Wo) = bf2{(__bf16)v2, (__bf16)v3};
+                    }
+                }
+                if (g.out16 && g.out16_split) {
+                    // Pre-split output.  A lane holds, of the 8 channels c8 * 8 + {0 .. 7} of this 32-row group, those of its parity
+                    // (kh = 0: even, kh = 1: odd; channel 2 gq + kh in acc[4 gq ..]) with all four sub-pixels (di, dj) of input pixel
+                    // p.  v_permlane32_swap trades the half it does not keep with the partner lane: afterwards a kh = 0 lane owns
+                    // the two output pixels of row di = 0 and a kh = 1 lane those of row di = 1, all 8 channels each = whole slots.
+                    const int c8 = (m0 + wr * 64 + t * 32) >> 5;
+                    float px[2][8];                         // [dj][channel of the group]
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int ch = ((m0 + wr * 64 + t * 32 + 8 * gq + 4 * kh) >> 2);
+                        const float bs = g.bias ? g.bias[ch] : 0.f;
+#pragma unroll
+                        for (int dj = 0; dj < 2; ++dj) {
+                            const unsigned d0 = __builtin_bit_cast(unsigned, acc[t][u][4 * gq + dj] + bs);
+                            const unsigned d1 = __builtin_bit_cast(unsigned, acc[t][u][4 * gq + 2 + dj] + bs);
+                            const auto sw = __builtin_amdgcn_permlane32_swap(d0, d1, false, false);
+                            // (scalars first: __builtin_bit_cast applied to a vector ELEMENT yields element 0 with hipcc 7.2)
+                            const unsigned even = sw[0], odd = sw[1];
+                            px[dj][2 * gq] = __builtin_bit_cast(float, even);           // even channel of the lane's row
+                            px[dj][2 * gq + 1] = __builtin_bit_cast(float, odd);        // odd channel
+                        }
+                    }
+                    u32x4g* dst = reinterpret_cast<u32x4g*>(reinterpret_cast<unsigned*>(g.out16) + (int64_t)b * g.out16_bs) +
+                                  ((int64_t)(c8 * (2 * g.h) + 2 * y + kh) * 2) * g.Wo + 2 * x;
+#pragma unroll
+                    for (int dj = 0; dj < 2; ++dj) {
+                        u32x4g hi, mid;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            unsigned hh, mm;
+                            split2h_s(px[dj][2 * k], px[dj][2 * k + 1], 1.f, hh, mm);
+                            hi[k] = hh;
+                            mid[k] = mm;
+                        }
+                        dst[dj] = hi;
+                        dst[g.Wo + dj] = mid;
                     }
                 }
             }
@@ -537,15 +577,16 @@ namespace onet {
 
 // Fast-path predicates + launches; return ONET_NOT_TAKEN (1) when the shape is not taken (caller falls back to conv_mfma.hip)
 int convt_gemm_fwd(const float* x, int64_t x_bs, const float* wq, const float* bias, float* y, int64_t y_bs, void* y16, int64_t y16_bs,
-                   int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int prec, hipStream_t st) {
+                   int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int prec, hipStream_t st, int y16_split) {
     const int64_t hw = (int64_t)h * w;
     if (pt || pl || Ho != 2 * h || Wo != 2 * w || (Cin % KC) || (Ct % 32) || (hw % 128) || (w & 1) || !aligned16(x) || !aligned16(wq) ||
         (x_bs & 3) || (reinterpret_cast<uintptr_t>(y) & 7) || (y_bs & 1) || (int64_t)Cin * hw * 4 >= (1ll << 31) ||
         (int64_t)Cin * 4 * Ct * 4 >= (1ll << 31))
         return 1;
-    if (y16 && ((reinterpret_cast<uintptr_t>(y16) & 3) || (y16_bs & 1))) return 1;
+    if (y16 && !y16_split && ((reinterpret_cast<uintptr_t>(y16) & 3) || (y16_bs & 1))) return 1;
+    if (y16 && y16_split && ((reinterpret_cast<uintptr_t>(y16) & 15) || (y16_bs & 3) || (Ct % 32))) return 1;
     if (!y && !y16) return 1;
-    GArgs g{wq, x, y, bias, nullptr, (__bf16*)y16, y16_bs, 0, x_bs, y_bs, B, Cin, Ct, h, w, Wo, Ho * Wo, (4 * Ct) / 128, (int)(B * hw / 128), 1, 0};
+    GArgs g{wq, x, y, bias, nullptr, (__bf16*)y16, y16_bs, 0, x_bs, y_bs, B, Cin, Ct, h, w, Wo, Ho * Wo, (4 * Ct) / 128, (int)(B * hw / 128), 1, 0, y16_split};
     const int64_t blocks = (int64_t)g.mTiles * g.nTiles;
     if (blocks <= 0 || blocks >= (1ll << 31)) return 1;
     if (prec == 2) hipLaunchKernelGGL((convt_gemm_kernel<0, 2>), dim3((unsigned)blocks), dim3(256), 0, st, g);

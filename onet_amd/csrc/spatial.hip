@@ -313,8 +313,9 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_bn_kernel(const float* __res
                                                               const float* __restrict__ z, int64_t z_bs,
                                                               const float* __restrict__ save, int group_images,
                                                               float* __restrict__ part2, int C, int H, int W, int bands,
-                                                              int band_rows) {
+                                                              int band_rows, unsigned* __restrict__ amax = nullptr) {
     __shared__ double red[8];
+    float vmax = 0.f;                           // amax: magnitude slots of dx (= the producing layer's da; bn.hip: bn_bwd_bound_kernel)
     const int c = blockIdx.x % C, p = blockIdx.x / C;
     const int b = p / bands, band = p % bands;
     const int Ho = H >> 1, Wo = W >> 1, W4 = W >> 2;
@@ -327,10 +328,20 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_bn_kernel(const float* __res
     for (int i = threadIdx.x; i < npatch; i += 256) {
         const int q = i % W4, oy = oy0 + i / W4;
         const int64_t in_off = (int64_t)c * H * W + (int64_t)(2 * oy) * W + 4 * q;
-        const float4 r0 = *reinterpret_cast<const float4*>(x + (int64_t)b * x_bs + in_off);
-        const float4 r1 = *reinterpret_cast<const float4*>(x + (int64_t)b * x_bs + in_off + W);
         const float4 z0 = *reinterpret_cast<const float4*>(z + (int64_t)b * z_bs + in_off);
         const float4 z1 = *reinterpret_cast<const float4*>(z + (int64_t)b * z_bs + in_off + W);
+        float4 r0, r1;
+        if (x) {
+            r0 = *reinterpret_cast<const float4*>(x + (int64_t)b * x_bs + in_off);
+            r1 = *reinterpret_cast<const float4*>(x + (int64_t)b * x_bs + in_off + W);
+        } else {
+            // x == NULL (pre-split storage: the activation exists only as the split operand of its consumers): x = relu(bn(z)) is
+            // recomputed with bn_relu_apply_kernel's expression -- the same bits, and one tensor read less
+            r0 = make_float4(fmaxf(fmaf(z0.x - mean, sc, sh), 0.f), fmaxf(fmaf(z0.y - mean, sc, sh), 0.f),
+                             fmaxf(fmaf(z0.z - mean, sc, sh), 0.f), fmaxf(fmaf(z0.w - mean, sc, sh), 0.f));
+            r1 = make_float4(fmaxf(fmaf(z1.x - mean, sc, sh), 0.f), fmaxf(fmaf(z1.y - mean, sc, sh), 0.f),
+                             fmaxf(fmaf(z1.z - mean, sc, sh), 0.f), fmaxf(fmaf(z1.w - mean, sc, sh), 0.f));
+        }
         const float2 g = *reinterpret_cast<const float2*>(dy + (int64_t)b * dy_bs + (int64_t)c * Ho * Wo + (int64_t)oy * Wo + 2 * q);
         int a0 = 0, a1 = 0;
         float m0 = r0.x, m1 = r0.z;
@@ -361,6 +372,20 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_bn_kernel(const float* __res
             const double dyk = fmaf(zz[k] - mean, sc, sh) > 0.f ? (double)o[k] : 0.0;
             v[0] += dyk;
             v[1] += dyk * (((double)zz[k] - meand) * invd);
+            vmax = fmaxf(vmax, fabsf(o[k]));
+        }
+    }
+    if (amax) {                                 // block maximum into one of the 64 slots (as bn.hip: amax_commit)
+        __shared__ float wmax[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = vmax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+            unsigned* sl = amax + (blockIdx.x & 63) * 32;
+            const unsigned bits = __builtin_bit_cast(unsigned, m);
+            if (m == m && __builtin_nontemporal_load(sl) < bits) atomicMax(sl, bits);
         }
     }
     block_sum_256<double, 2>(v, red);
@@ -450,10 +475,32 @@ int onet_maxpool2_bwd_bn_bands(int H, int W) {
     return bands;
 }
 
+static int maxpool2_bwd_add_bnreduce_impl(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, const float* add, int64_t add_bs,
+                                          const float* add2, int64_t add2_bs, float* dx, int64_t dx_bs, const float* z, int64_t z_bs,
+                                          const float* save, int group_images, float* part2, unsigned* amax, int B, int C, int H, int W,
+                                          void* stream);
+
 int onet_maxpool2_bwd_add_bnreduce(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, const float* add, int64_t add_bs,
                                    const float* add2, int64_t add2_bs, float* dx, int64_t dx_bs, const float* z, int64_t z_bs,
                                    const float* save, int group_images, float* part2, int B, int C, int H, int W, void* stream) {
-    ONET_REQUIRE(x && dy && dx && z && save && part2 && B > 0 && C > 0, "maxpool2_bwd_add_bnreduce: bad args");
+    ONET_REQUIRE(x, "maxpool2_bwd_add_bnreduce: bad args");
+    return maxpool2_bwd_add_bnreduce_impl(x, x_bs, dy, dy_bs, add, add_bs, add2, add2_bs, dx, dx_bs, z, z_bs, save, group_images, part2,
+                                          nullptr, B, C, H, W, stream);
+}
+
+int onet_maxpool2_bwd_add_bnreduce_amax(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, const float* add, int64_t add_bs,
+                                        const float* add2, int64_t add2_bs, float* dx, int64_t dx_bs, const float* z, int64_t z_bs,
+                                        const float* save, int group_images, float* part2, void* dx_amax, int B, int C, int H, int W,
+                                        void* stream) {
+    return maxpool2_bwd_add_bnreduce_impl(x, x_bs, dy, dy_bs, add, add_bs, add2, add2_bs, dx, dx_bs, z, z_bs, save, group_images, part2,
+                                          (unsigned*)dx_amax, B, C, H, W, stream);
+}
+
+static int maxpool2_bwd_add_bnreduce_impl(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, const float* add, int64_t add_bs,
+                                          const float* add2, int64_t add2_bs, float* dx, int64_t dx_bs, const float* z, int64_t z_bs,
+                                          const float* save, int group_images, float* part2, unsigned* amax, int B, int C, int H, int W,
+                                          void* stream) {
+    ONET_REQUIRE(dy && dx && z && save && part2 && B > 0 && C > 0, "maxpool2_bwd_add_bnreduce: bad args");
     ONET_REQUIRE(group_images > 0 && (B % group_images) == 0, "maxpool2_bwd_add_bnreduce: bad statistics groups");
     const bool ok = H >= 2 && W >= 4 && ((W & 3) == 0) && ((H & 1) == 0) && ((x_bs & 3) == 0) && ((dx_bs & 3) == 0) &&
                     ((z_bs & 3) == 0) && ((dy_bs & 1) == 0) && ((add_bs & 3) == 0) && ((add2_bs & 3) == 0) &&
@@ -466,7 +513,7 @@ int onet_maxpool2_bwd_add_bnreduce(const float* x, int64_t x_bs, const float* dy
     const int64_t blocks = (int64_t)B * bands * C;
     ONET_REQUIRE(blocks < (1ll << 31), "maxpool2_bwd_add_bnreduce: grid too large");
     hipLaunchKernelGGL(maxpool2_bwd_bn_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, x_bs, dy, dy_bs, add,
-                       add_bs, add2, add2_bs, dx, dx_bs, z, z_bs, save, group_images, part2, C, H, W, bands, rows);
+                       add_bs, add2, add2_bs, dx, dx_bs, z, z_bs, save, group_images, part2, C, H, W, bands, rows, amax);
     return check_launch("maxpool2_bwd_bn_kernel");
 }
 

@@ -42,11 +42,15 @@ class ConvBNReLUFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, running_mean, running_var, training, momentum, eps, packed, out, groups=1,
-                link_out=None, link_in=None, b16=None, aux=None):
+                link_out=None, link_in=None, b16=None, aux=None, p16=None):
         """b16 (bf16 storage, BASELINE config 3 only): dict with "x16" = the bf16 copy of x written by its producer (or None),
         "out16" = a plane-contiguous bf16 destination for the copy of the output (or None: allocated); forward leaves the
         output's copy in b16["a16"] for the caller to attach to the returned tensor."""
         ops.require_gpu(x, weight, gamma, beta)
+        if p16 is not None and (p16.get("x") is not None or p16.get("want")):
+            return ConvBNReLUFn._forward_pre(ctx, x, weight, gamma, beta, running_mean, running_var, training, momentum, eps, packed,
+                                             groups, link_out, link_in, p16)
+        ctx.pre = False
         # an encoder output that is max-pooled next: {"bf16_only": bool} left in the link dict by UNet.forward (read before the dict
         # is refilled below); the pooled tensor goes back through the same dict for SkipPoolFn
         want_pool = link_out.pop("want_pool", None) if link_out is not None else None
@@ -154,7 +158,119 @@ class ConvBNReLUFn(torch.autograd.Function):
         return a
 
     @staticmethod
+    def _forward_pre(ctx, x, weight, gamma, beta, running_mean, running_var, training, momentum, eps, packed, groups, link_out,
+                     link_in, p16):
+        """Pre-split storage (Settings.presplit).  p16 in: "x" = the pre-split form of x (then the convolution, its input gradient
+        and weight gradient run on pre-split operands, ops.pre_layer_ok) or None; "want": write the output activation pre-split
+        ("out": its destination, e.g. the skip groups of a concat buffer; else allocated); "keep_fp32": write the fp32 activation too
+        (it has fp32 readers); with a pooling request in link_out (UNet.forward: {"p16": the pooled tensor is wanted pre-split}).
+        p16 out: "a" = the pre-split output.  The graph carries placeholders where no fp32 tensor exists."""
+        want_pool = link_out.pop("want_pool", None) if link_out is not None else None
+        if link_out is not None:
+            link_out.pop("defer", None)
+        xP = p16.get("x")
+        if xP is not None:
+            z, cm = ops.conv3x3_pre_bn_partials(xP, packed)
+        else:
+            z, cm = ops.conv3x3_fwd_bn_partials(x, packed) if training else (ops.conv3x3_auto(x, packed, 0), None)
+        G = groups if (training and groups > 1) else 1
+        Bz, C, Hz, Wz = z.shape
+        Bg = Bz // G
+        save_all = torch.empty((G, 4, C), dtype=torch.float32, device=z.device)
+        want = bool(p16.get("want"))
+        keep = bool(p16.get("keep_fp32")) or not want or ops.PRESPLIT_KEEP_FP32
+        aP = None
+        if want:
+            aP = p16.get("out")
+            if aP is None:
+                aP = ops.p16_empty(Bz, C, Hz, Wz, z.device)
+        a = torch.empty_like(z) if keep else ops.fp32_placeholder(z.shape, z.device)
+        pooled = None
+        if want_pool is not None and Hz % 2 == 0 and Wz % 2 == 0:
+            if want_pool.get("p16"):
+                pooled = (None, None, ops.p16_empty(Bz, C, Hz // 2, Wz // 2, z.device))
+            else:
+                pooled = (torch.empty((Bz, C, Hz // 2, Wz // 2), dtype=torch.float32, device=z.device), None, None)
+        for g in range(G):
+            sl = slice(g * Bg, (g + 1) * Bg)
+            zg = z[sl]
+            if training:
+                npg = 0 if cm is None else cm.shape[1] // G
+                ops.bn_train_coeffs(zg, gamma, beta, running_mean, running_var, momentum, eps,
+                                    cm=None if cm is None else (cm, g * npg, npg), save=save_all[g])
+            else:
+                ops.bn_eval_coeffs(gamma, beta, running_mean, running_var, eps, save=save_all[g])
+        for g in range(G):
+            sl = slice(g * Bg, (g + 1) * Bg)
+            if pooled is not None:
+                if not ops.bn_relu_apply_pool_split(z[sl], save_all[g], None if aP is None else aP[sl], a[sl] if keep else None,
+                                                    None if pooled[2] is None else pooled[2][sl],
+                                                    None if pooled[0] is None else pooled[0][sl]):
+                    raise RuntimeError("onet_amd: pre-split BatchNorm + pooling pass refused a shape ops.pre_layer_ok accepted")
+            elif aP is not None:
+                ops.bn_relu_apply_split(z[sl], save_all[g], aP[sl], a=a[sl] if keep else None)
+            else:
+                ops.bn_relu_apply(z[sl], save_all[g], out=a[sl])
+        p16["a"] = aP
+        ctx.save_for_backward(x, z, save_all, xP)
+        ctx.pre = True
+        ctx.training = training
+        ctx.packed = packed
+        ctx.wshape = tuple(weight.shape)
+        ctx.params = (weight, gamma, beta)
+        ctx.link_out = ctx.link_in = None
+        if training and link_out is not None:
+            link_out.clear()
+            link_out.update(z=z, save=save_all)
+            ctx.link_out = link_out
+        if training and link_in is not None and "z" in link_in:
+            ctx.link_in = link_in
+        if pooled is not None and link_out is not None:
+            link_out["pooled"] = pooled
+        return a
+
+    @staticmethod
+    def _backward_pre(ctx, da):
+        x, z, save_all, xP = ctx.saved_tensors
+        need_x, need_w, need_g, need_b = ctx.needs_input_grad[:4]
+        pw, pg, pb = ctx.params
+        aff = (ops.grad_slot_if_free(pg) if need_g else None, ops.grad_slot_if_free(pb) if need_b else None)
+        rec4, da_amax = None, None
+        lk = ctx.link_out
+        if lk is not None and "rec4" in lk:
+            rda, rec4, da_amax = lk.pop("da"), lk.pop("rec4", None), lk.pop("da_amax", None)
+            lk.pop("rec", None)
+            if rda.data_ptr() != da.data_ptr() or rda.shape != da.shape or rda.stride() != da.stride():
+                rec4 = da_amax = None
+        if ctx.link_in is not None:                 # the unit below's (z, save) must not outlive this backward
+            ctx.link_in.pop("z", None)
+            ctx.link_in.pop("save", None)
+        nones = (None,) * 13
+        if xP is None:
+            # fp32 input (the stem): dz in fp32 for the fp32-input kernels; no input gradient path on pre-split operands
+            G = save_all.shape[0]
+            Bg = z.shape[0] // G
+            dz = torch.empty_like(z)
+            dgamma = dbeta = None
+            for g in range(G):
+                sl = slice(g * Bg, (g + 1) * Bg)
+                np4 = 0 if rec4 is None else rec4.shape[0] // G
+                _, dgamma, dbeta = ops.bn_relu_bwd(da[sl], z[sl], save_all[g], ctx.training, need_affine_grads=True, out=dz[sl],
+                                                   acc=None if g == 0 else (dgamma, dbeta), affine_out=aff if g == 0 else None,
+                                                   red4=None if rec4 is None else (rec4, g * np4, np4))
+            dw = ops.conv3x3_wgrad_auto(x, dz, ctx.wshape, out=ops.grad_slot_if_free(pw)) if need_w else None
+            dx = ops.conv3x3_auto(dz, ctx.packed, 1) if need_x else None
+            return (dx, dw, (dgamma if need_g else None), (dbeta if need_b else None)) + nones
+        dzP, dz_slots, dgamma, dbeta = ops.bn_relu_bwd_split(da, z, save_all, ctx.training, need_affine_grads=(need_g or need_b),
+                                                             affine_out=aff, rec4=rec4, da_amax=da_amax)
+        dw = ops.conv3x3_split_wgrad_pre(xP, dzP, ctx.wshape, out=ops.grad_slot_if_free(pw), dz_slots=dz_slots) if need_w else None
+        dx = ops.conv3x3_split_pre(dzP, ctx.packed.get_pack("split")[1], ctx.wshape[1], slots=dz_slots, always=True) if need_x else None
+        return (dx, dw, (dgamma if need_g else None), (dbeta if need_b else None)) + nones
+
+    @staticmethod
     def backward(ctx, da):
+        if ctx.pre:
+            return ConvBNReLUFn._backward_pre(ctx, da)
         x, z, save_all, x16, nz, nsave = ctx.saved_tensors
         need_x, need_w, need_g, need_b = ctx.needs_input_grad[:4]
         pw, pg, pb = ctx.params
@@ -220,7 +336,7 @@ class ConvBNReLUFn(torch.autograd.Function):
             ctx.link_in.pop("z", None)
             ctx.link_in.pop("save", None)
         return (dx, dw, (dgamma if need_g else None), (dbeta if need_b else None), None, None, None, None, None, None,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
 @_carries_settings
@@ -297,7 +413,14 @@ class SkipPoolFn(torch.autograd.Function):
     def forward(ctx, x, returned=False, link=None, b16=None):
         ops.require_gpu(x)
         pooled = link.pop("pooled", None) if link is not None else None
-        if pooled is not None and tuple((pooled[0] if pooled[0] is not None else pooled[1]).shape) == \
+        if pooled is not None and len(pooled) == 3:
+            # pre-split storage: the producing pass wrote the pooled tensor pre-split (pooled[2]) or in fp32 (pooled[0])
+            shp = (x.shape[0], x.shape[1], x.shape[2] // 2, x.shape[3] // 2)
+            y = pooled[0] if pooled[0] is not None else ops.fp32_placeholder(shp, x.device)
+            if b16 is not None:
+                b16["yP"] = pooled[2]
+            ctx.pre = True
+        elif pooled is not None and tuple((pooled[0] if pooled[0] is not None else pooled[1]).shape) == \
                 (x.shape[0], x.shape[1], x.shape[2] // 2, x.shape[3] // 2):
             # the producing BatchNorm + ReLU pass already wrote the pooled tensor (onet_bn_relu_apply_pool)
             y = pooled[0] if pooled[0] is not None else ops.fp32_placeholder(pooled[1].shape, x.device)
@@ -319,9 +442,12 @@ class SkipPoolFn(torch.autograd.Function):
             return (sum(gs[1:], gs[0]) if gs else None), None, None, None
         lk = ctx.link
         if lk is not None and "z" in lk:
-            dx, part2 = ops.maxpool2_bwd(x, g_pool, add=g_skip, add2=g_ret, bn=(lk.pop("z"), lk.pop("save")))
+            am = ops.new_amax(g_pool.device) if getattr(ctx, "pre", False) else None
+            dx, part2 = ops.maxpool2_bwd(x, g_pool, add=g_skip, add2=g_ret, bn=(lk.pop("z"), lk.pop("save")), dx_amax=am)
             if part2 is not None:
                 lk["da"], lk["rec4"] = dx, part2
+                if am is not None:
+                    lk["da_amax"] = am
             return dx, None, None, None
         return ops.maxpool2_bwd(x, g_pool, add=g_skip, add2=g_ret), None, None, None
 
@@ -343,15 +469,29 @@ class UpConvTCatFn(torch.autograd.Function):
     pixel-shuffle that writes straight into the second half of the concat buffer."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, packed, cat_holder=None, b16=None):
+    def forward(ctx, x1, x2, weight, bias, packed, cat_holder=None, b16=None, p16=None):
         """b16 (bf16 storage): dict with "cat16" = the bf16 twin of the concat buffer whose skip half the encoder already
-        wrote; the up-sampled half is written here and b16["ok"] tells the caller whether the twin is complete."""
+        wrote; the up-sampled half is written here and b16["ok"] tells the caller whether the twin is complete.
+        p16 (pre-split storage): {"catP": the pre-split concat buffer, skip groups written by the encoder}: the up-sampled groups
+        are written here and NO fp32 concat exists (a placeholder goes through the graph)."""
         ops.require_gpu(x1, x2, weight, bias)
         wp_fused, wp_dgrad = packed
         B, Cin, h, w = x1.shape
         Ct = weight.shape[1]
         C2, Ho, Wo = x2.shape[1], x2.shape[2], x2.shape[3]
         pt, pl = _pad_offsets((h, w), (Ho, Wo))
+        if p16 is not None:
+            catP = p16["catP"]
+            assert (Ho, Wo) == (2 * h, 2 * w) and catP.shape[1] * 8 == C2 + Ct and C2 % 8 == 0
+            # the GEMM's epilogue writes whole pre-split slots; shapes outside its fast path: fp32 + one conversion pass
+            if not ops.convT2x2_fwd_p(x1, wp_fused, bias, catP[:, C2 // 8:], Ct, pt, pl):
+                up = torch.empty((B, Ct, Ho, Wo), dtype=torch.float32, device=x1.device)
+                ops.convT2x2_fwd(x1, wp_fused, bias, up, Ct, pt, pl)
+                ops.split_pack_act(up, f16=True, out=catP[:, C2 // 8:])
+            ctx.save_for_backward(x1, wp_dgrad)
+            ctx.meta = (C2, Ct, h, w, pt, pl, tuple(weight.shape), bias is not None)
+            ctx.params = (weight, bias)
+            return ops.fp32_placeholder((B, C2 + Ct, Ho, Wo), x1.device)
         cat = None if cat_holder is None else cat_holder[0]
         if b16 is not None and b16.get("bf16_only") and b16.get("cat16") is not None:
             # bf16 storage, the consuming convolution reads only the bf16 twin of the concat buffer: the skip half is there
@@ -408,7 +548,7 @@ class UpConvTCatFn(torch.autograd.Function):
                 dw = ops.conv_wgrad(x1, dsub, wshape, 1, out_layout=1)
             if need_x1:
                 dx1 = ops.conv_fwd(dsub, wp_dgrad, wshape[0], 1)
-        return dx1, dx2, dw, db, None, None, None
+        return dx1, dx2, dw, db, None, None, None, None
 
 
 @_carries_settings

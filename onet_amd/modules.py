@@ -106,7 +106,7 @@ class DoubleConv(nn.Module):
         )
 
     @staticmethod
-    def _unit(x, conv, bn, out=None, groups=1, link_out=None, link_in=None, out16=None, drop_fp32=False):
+    def _unit(x, conv, bn, out=None, groups=1, link_out=None, link_in=None, out16=None, drop_fp32=False, p16=None):
         training = bn.training or (bn.running_mean is None)
         if x.dim() != 4:
             raise ValueError(f"expected 4D input (got {x.dim()}D input)")
@@ -123,18 +123,35 @@ class DoubleConv(nn.Module):
         # magnitude slots (ops.tag_amax): what x's producer recorded of it goes in, what this unit records of its output comes out
         aux = {"x_amax": ops.amax_of(x)}
         a = Fn.ConvBNReLUFn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                  training, bn.momentum, bn.eps, conv.packed(), out, groups, link_out, link_in, b16, aux)
+                                  training, bn.momentum, bn.eps, conv.packed(), out, groups, link_out, link_in, b16, aux, p16)
         if b16 is not None:
             ops.tag_b16(a, b16.get("a16"))
+        if p16 is not None:
+            ops.tag_p16(a, p16.get("a"))            # pre-split storage: the output's pre-split form rides on it
         return ops.tag_amax(a, aux.get("a_amax"))
 
-    def forward(self, x, out=None, groups=1, pool_link=None, out16=None):
+    def forward(self, x, out=None, groups=1, pool_link=None, out16=None, p16_out=None):
         """`out`: optional plane-contiguous [B, Cout, H, W] destination view (the skip half of a concat buffer);
         `groups`: the batch holds that many independent BatchNorm batches (twin pass); `pool_link`: dict the second
         unit publishes its (z, save) in for the SkipPoolFn that consumes the block's output; `out16`: the matching view
-        of the concat buffer's bf16 twin (bf16 storage)."""
+        of the concat buffer's bf16 twin (bf16 storage); `p16_out` (pre-split storage): {"out": pre-split destination of the
+        block's output (the skip groups of a pre-split concat buffer), "keep_fp32": the fp32 tensor is needed too}."""
         s = self.double_conv
         link = {}       # unit 1 -> unit 2: lets unit 2's dgrad launch take unit 1's BatchNorm-backward reduce pass with it
+        if x.dim() == 4 and x.is_cuda and ops.presplit() and s[1].training and s[4].training and s[1].running_mean is not None:
+            # pre-split storage: a tensor is written pre-split exactly where ops.pre_layer_ok says its consuming convolution runs
+            # all three of its kernels on pre-split operands (the producer of x decided with the same function)
+            B, _, H, W = x.shape
+            xP = ops.p16_of(x)
+            pre2 = ops.pre_layer_ok(B, s[3].in_channels, s[3].out_channels, H, W)
+            if xP is not None or pre2 or p16_out is not None:
+                if xP is None and ops.is_placeholder(x):
+                    raise RuntimeError("onet_amd: a tensor kept only pre-split reached a DoubleConv without its pre-split form")
+                p1 = {"x": xP, "want": pre2}
+                a1 = self._unit(x, s[0], s[1], None, groups, link_out=link, p16=p1)
+                p2 = {"x": p1.get("a"), "want": p16_out is not None, "out": None if p16_out is None else p16_out.get("out"),
+                      "keep_fp32": True if p16_out is None else bool(p16_out.get("keep_fp32"))}
+                return self._unit(a1, s[3], s[4], None, groups, link_out=pool_link, link_in=link, p16=p2)
         # bf16 storage: unit 1's output feeds unit 2's convolution only -- where that reads the bf16 copy (forward and weight
         # gradient), unit 1 writes no fp32 activation at all
         drop1 = x.dim() == 4 and ops.consumer_reads_bf16(x.shape[0], s[3].in_channels, s[3].out_channels, x.shape[2], x.shape[3])
@@ -168,11 +185,11 @@ class Down(nn.Module):
         super().__init__()
         self.maxpool_conv = nn.Sequential(MaxPool2(), DoubleConv(in_channels, out_channels))
 
-    def forward(self, x, out=None, groups=1, pooled=None, pool_link=None, out16=None):
+    def forward(self, x, out=None, groups=1, pooled=None, pool_link=None, out16=None, p16_out=None):
         """`pooled`: maxpool2(x) when the caller already has it (UNet.forward pools skip tensors with SkipPoolFn);
-        `pool_link`, `out16`: see DoubleConv.forward."""
+        `pool_link`, `out16`, `p16_out`: see DoubleConv.forward."""
         p = self.maxpool_conv[0](x) if pooled is None else pooled
-        return self.maxpool_conv[1](p, out=out, groups=groups, pool_link=pool_link, out16=out16)
+        return self.maxpool_conv[1](p, out=out, groups=groups, pool_link=pool_link, out16=out16, p16_out=p16_out)
 
 
 class ConvT2x2(nn.ConvTranspose2d, _Packable):
@@ -215,10 +232,15 @@ class Up(nn.Module):
             self.up = ConvT2x2(in_channels, in_channels // 2)
             self.conv = DoubleConv(in_channels, out_channels)
 
-    def forward(self, x1, x2, cat=None, groups=1, cat16=None):
+    def forward(self, x1, x2, cat=None, groups=1, cat16=None, catP=None):
         """`cat`: optional concat buffer whose first channels already ARE x2 (UNet.forward lets the encoder write its
         skip outputs there, so torch.cat's copy of the skip tensor, OV:100, never happens); `cat16`: its bf16 twin (bf16
-        storage), skip half already written."""
+        storage), skip half already written; `catP` (pre-split storage): the pre-split concat buffer, skip groups already written."""
+        if isinstance(self.up, ConvT2x2) and catP is not None:
+            p16 = {"catP": catP}
+            x = Fn.UpConvTCatFn.apply(x1, x2, self.up.weight, self.up.bias, self.up.packed(), None, None, p16)
+            ops.tag_p16(x, catP)
+            return self.conv(x, groups=groups)
         if isinstance(self.up, ConvT2x2):
             dc = self.conv.double_conv[0]
             b16 = None
@@ -291,8 +313,28 @@ class UNet(nn.Module):
                         cats[k] = torch.empty((B, 2 * C, h, w), dtype=torch.float32, device=x.device)
                 h, w = h // 2, w // 2
 
+        # pre-split storage: where the decoder's first convolution runs on pre-split operands (ops.pre_layer_ok), the concat buffer
+        # exists ONLY pre-split: the encoder's BatchNorm pass writes the skip groups, the Up block the up-sampled ones
+        catsP = [None] * 4
+        pool_p = [False] * 4                                # the pooled tensor of encoder level k feeds a pre-split convolution
+        if not self.bilinear and x.dim() == 4 and x.is_cuda and ops.presplit() and self.training:
+            B, h, w = x.shape[0], x.shape[2], x.shape[3]
+            for k, enc in enumerate((self.inc, self.down1.maxpool_conv[1], self.down2.maxpool_conv[1], self.down3.maxpool_conv[1])):
+                C = enc.double_conv[3].out_channels
+                dec = (self.up4, self.up3, self.up2, self.up1)[k].conv.double_conv[0]
+                nxt = (self.down1, self.down2, self.down3, self.down4)[k].maxpool_conv[1].double_conv[0]
+                if h % 16 == 0 and w % 16 == 0 and dec.in_channels == 2 * C and ops.pre_layer_ok(B, dec.in_channels, dec.out_channels, h, w) \
+                        and enc.double_conv[4].training:
+                    catsP[k] = ops.p16_empty(B, 2 * C, h, w, x.device)
+                    cats[k] = None
+                pool_p[k] = h % 2 == 0 and w % 2 == 0 and ops.pre_layer_ok(B, nxt.in_channels, nxt.out_channels, h // 2, w // 2)
+                h, w = h // 2, w // 2
+
         def skip(k, C):
             return None if cats[k] is None else cats[k][:, :C]
+
+        def skipP(k, C, keep_fp32=False):
+            return None if catsP[k] is None else {"out": catsP[k][:, :C // 8], "keep_fp32": keep_fp32}
 
         def skip16(k, C):
             return None if cats16[k] is None else cats16[k][:, :C]
@@ -309,9 +351,12 @@ class UNet(nn.Module):
                     b16 = {"bf16_only": ops.consumer_reads_bf16(t.shape[0], c.in_channels, c.out_channels, t.shape[2] // 2,
                                                                 t.shape[3] // 2)}
                 am = ops.amax_of(t)
+                if b16 is None and ops.presplit():
+                    b16 = {}                                  # (carries the pooled tensor's pre-split form back: "yP")
                 outs = Fn.SkipPoolFn.apply(t, returned, link, b16)
                 if b16 is not None:
                     ops.tag_b16(outs[1], b16.get("y16"))     # the pooled tensor's bf16 copy, for the next block's first conv
+                    ops.tag_p16(outs[1], b16.get("yP"))      # ... or its pre-split form (pre-split storage)
                 ops.tag_amax(outs[1], am)                    # max-pooling keeps the maximum: the same slots bound the pooled tensor
                 return outs
             return (t, None, t) if returned else (t, None)
@@ -327,21 +372,23 @@ class UNet(nn.Module):
             hh, ww = x.shape[2], x.shape[3]
             for i, nxt in enumerate((self.down1, self.down2, self.down3, self.down4)):
                 cv = nxt.maxpool_conv[1].double_conv[0]
-                pl[i]["want_pool"] = {"bf16_only": ops.consumer_reads_bf16(x.shape[0], cv.in_channels, cv.out_channels, hh // 2, ww // 2)}
+                pl[i]["want_pool"] = {"bf16_only": ops.consumer_reads_bf16(x.shape[0], cv.in_channels, cv.out_channels, hh // 2, ww // 2),
+                                      "p16": pool_p[i]}
                 hh, ww = hh // 2, ww // 2
-        x1 = self.inc(x, out=skip(0, c0), groups=g, pool_link=pl[0], out16=skip16(0, c0))
+        # (pre-split storage: x1 leaves the U-Net and feeds the head, so it keeps its fp32 tensor beside the pre-split skip groups)
+        x1 = self.inc(x, out=skip(0, c0), groups=g, pool_link=pl[0], out16=skip16(0, c0), p16_out=skipP(0, c0, True))
         x1, p1, x1_out = fork(x1, True, pl[0], self.down1)
-        x2 = self.down1(x1, out=skip(1, c1), groups=g, pooled=p1, pool_link=pl[1], out16=skip16(1, c1))
+        x2 = self.down1(x1, out=skip(1, c1), groups=g, pooled=p1, pool_link=pl[1], out16=skip16(1, c1), p16_out=skipP(1, c1))
         x2, p2 = fork(x2, False, pl[1], self.down2)
-        x3 = self.down2(x2, out=skip(2, c2), groups=g, pooled=p2, pool_link=pl[2], out16=skip16(2, c2))
+        x3 = self.down2(x2, out=skip(2, c2), groups=g, pooled=p2, pool_link=pl[2], out16=skip16(2, c2), p16_out=skipP(2, c2))
         x3, p3 = fork(x3, False, pl[2], self.down3)
-        x4 = self.down3(x3, out=skip(3, c3), groups=g, pooled=p3, pool_link=pl[3], out16=skip16(3, c3))
+        x4 = self.down3(x3, out=skip(3, c3), groups=g, pooled=p3, pool_link=pl[3], out16=skip16(3, c3), p16_out=skipP(3, c3))
         x4, p4 = fork(x4, False, pl[3], self.down4)
         x5 = self.down4(x4, groups=g, pooled=p4)
-        y4 = self.up1(x5, x4, cat=cats[3], groups=g, cat16=cats16[3])
-        y3 = self.up2(y4, x3, cat=cats[2], groups=g, cat16=cats16[2])
-        y2 = self.up3(y3, x2, cat=cats[1], groups=g, cat16=cats16[1])
-        y1 = self.up4(y2, x1, cat=cats[0], groups=g, cat16=cats16[0])
+        y4 = self.up1(x5, x4, cat=cats[3], groups=g, cat16=cats16[3], catP=catsP[3])
+        y3 = self.up2(y4, x3, cat=cats[2], groups=g, cat16=cats16[2], catP=catsP[2])
+        y2 = self.up3(y3, x2, cat=cats[1], groups=g, cat16=cats16[1], catP=catsP[1])
+        y1 = self.up4(y2, x1, cat=cats[0], groups=g, cat16=cats16[0], catP=catsP[0])
         return x1_out, y1
 
 
@@ -380,6 +427,8 @@ class Onet(nn.Module):
             return self._forward(X)
 
     def _forward(self, X):
+        if X.dim() == 4 and X.is_cuda and ops.split_enabled():
+            ops.amax_arena_reset(X.device)          # this step's magnitude slots: one fill instead of one per tensor
         if self.dwnu is self.topu and ops.twin_enabled() and X.dim() == 4 and X.is_cuda:
             # shared weights: X and 1-X go through every convolution as ONE batch of 2B (twice the blocks per launch,
             # weights packed / weight gradients reduced once); BatchNorm treats the halves as two batches, in the

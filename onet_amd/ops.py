@@ -33,12 +33,14 @@ class Settings:
       grad_f16      split input / weight gradients on fp16 parts of power-of-two-scaled operands; False: bf16      (default SPLIT_GRAD_F16)
       split_dgrad   input gradients may take the split kernels (False: diagnostic, fp32-MFMA kernels)             (default SPLIT_DGRAD)
       stem_fused    the stem convolution + its BatchNorm statistics in one streaming pass                          (default STEM_FUSED)
-      sync_bn       BatchNorm statistics all-gathered over the process group                                       (default SYNC_BN)"""
+      sync_bn       BatchNorm statistics all-gathered over the process group                                       (default SYNC_BN)
+      presplit      the split kernels' operands are written pre-split (fp16 hi | mid slots) by their producers     (default PRESPLIT)"""
     __slots__ = ("conv", "twin", "convt_bf16", "bf16_storage", "lazy_nan", "split", "bn_on_load", "split_f16", "grad_f16", "split_dgrad",
-                 "stem_fused", "sync_bn")
+                 "stem_fused", "sync_bn", "presplit")
 
     def __init__(self, conv=None, twin=None, convt_bf16=None, bf16_storage=None, lazy_nan=None, split=None, bn_on_load=None,
-                 split_f16=None, grad_f16=None, split_dgrad=None, stem_fused=None, sync_bn=None):
+                 split_f16=None, grad_f16=None, split_dgrad=None, stem_fused=None, sync_bn=None, presplit=None):
+        self.presplit = presplit
         self.conv, self.twin, self.convt_bf16, self.bf16_storage, self.lazy_nan = conv, twin, convt_bf16, bf16_storage, lazy_nan
         self.split, self.bn_on_load = split, bn_on_load
         self.split_f16, self.grad_f16, self.split_dgrad, self.stem_fused, self.sync_bn = split_f16, grad_f16, split_dgrad, stem_fused, sync_bn
@@ -114,6 +116,13 @@ def stem_fused():
 
 def sync_bn():
     return bool(_setting("sync_bn", SYNC_BN))
+
+
+def presplit():
+    """Pre-split storage (round 4): activations and BatchNorm-backward gradients whose consumers are the split convolution kernels
+    are written by their producers as fp16 (hi, mid) parts in the kernels' slot layout; the MFMA kernels' staging is an LDS-DMA copy."""
+    return bool(_setting("presplit", PRESPLIT)) and split_enabled() and conv_algo() in ("auto", "split") and split_f16() and \
+        split_dgrad() and not sync_bn() and FUSE_BN_STATS and FUSE_BN_REDUCE and FUSE_POOL
 
 
 def split_enabled():
@@ -356,6 +365,23 @@ def convT2x2_fwd(x, wq, bias, out, Ct, pt, pl, out16=None):
     return False
 
 
+def convT2x2_fwd_p(x, wq, bias, outP, Ct, pt, pl):
+    """ConvTranspose2d(k=2, s=2) + bias written PRE-SPLIT into outP [B, Ct/8, Ho, 2, Wo, 8] (the up-sampled channel groups of a pre-split
+    concat buffer): no fp32 tensor.  -> False where the GEMM fast path does not take the shape (nothing written)."""
+    require_gpu(x, wq)
+    x, xbs = plane(x)
+    B, Cin, h, w = x.shape
+    Ho, Wo = outP.shape[2], outP.shape[4]
+    e0 = _prof_begin()
+    rc = _lib.load().onet_convT2x2_fwd_p(_p(x), xbs, _p(wq), _p(bias), _p(outP), _pbs(outP), B, Cin, Ct, h, w, Ho, Wo, pt, pl,
+                                         convt_operand_bf16(B, h, w, Ct), _stream())
+    flops, nb = 2.0 * B * h * w * Cin * 4 * Ct, 4.0 * (B * h * w * (Cin + 4 * Ct) + 4 * Cin * Ct)
+    _prof_end("convt_gemm_kernel", flops if rc == 0 else 0.0, e0, nb if rc == 0 else 0.0)
+    if rc < 0:
+        raise _lib.OnetHipError(f"onet_convT2x2_fwd_p failed ({rc}): {_lib.last_error()}")
+    return rc == 0
+
+
 # 3x3 convolution algorithm for fwd/dgrad, chosen per call from the layer shape (ONET_CONV_ALGO overrides):
 #   "auto" (default)  the split-bf16 kernel (fp32 accuracy on the bf16 matrix cores, conv_split.hip) on maps at least 32 pixels wide
 #                     with Cin % 16 == 0 and enough tiles to fill the chip; else Winograd F(4x4,3x3) where its 64-channel x
@@ -554,6 +580,10 @@ CONVT_SPLIT_MIN_BLOCKS = int(_os.environ["ONET_CONVT_SPLIT_MIN_BLOCKS"]) if "ONE
 CONVT_SPLIT = _os.environ.get("ONET_CONVT_SPLIT", "1") != "0"     # 0: the ConvTranspose2d GEMMs stay on the fp32 MFMA pipe
 SPLIT_F16 = _os.environ.get("ONET_SPLIT_F16", "1") != "0"         # 0: the forward split kernel takes bf16 parts like the gradients
 SPLIT_DGRAD = _os.environ.get("ONET_SPLIT_DGRAD", "1") != "0"     # 0 (diagnostic): input gradients stay on the fp32-MFMA kernels
+PRESPLIT = _os.environ.get("ONET_PRESPLIT", "1") != "0"           # 1: pre-split operand storage (Settings.presplit)
+# diagnostic / tests: every activation written pre-split ALSO leaves its fp32 tensor (same values: the parts are split from them), so
+# that a harness can read each unit's output; the kernels that consume the pre-split forms are unchanged
+PRESPLIT_KEEP_FP32 = _os.environ.get("ONET_PRESPLIT_KEEP_FP32", "0") != "0"
 # 1: split input / weight gradients on fp16 parts of power-of-two-scaled operands (22-bit operands; 15x lower per-layer error than
 # the bf16 parts, but no change in the model-level worst gradient error -- 9.4e-5 either way on b4_c1_256 -- and +1.3 ms/step: the
 # fp16 MFMAs hold a lower clock); default 0: bf16 parts, as in round 3
@@ -786,7 +816,7 @@ def pack3x3_split(w):
     Cout, Cin = w.shape[0], w.shape[1]
     # a pack's parts are fp16 (of 2^k w, k from the tensor's largest magnitude; (2^k, 2^-k) stored behind the pack: + 8 elements)
     # or bf16 -- its dtype tells conv3x3_split which arithmetic the pack is for
-    f_fwd, f_dg = split_f16(), grad_f16()
+    f_fwd, f_dg = split_f16(), grad_f16() or presplit()
     wf = torch.empty(2 * Cin * 9 * Cout + 8, dtype=torch.float16 if f_fwd else BF, device=w.device) if Cin % 16 == 0 else None
     wd = torch.empty(2 * (-(-Cout // 16) * 16) * 9 * Cin + 8, dtype=torch.float16 if f_dg else BF, device=w.device)
     ws = torch.empty(AMAX_SLOTS, dtype=torch.int32, device=w.device) if (f_fwd or f_dg) else None
@@ -797,9 +827,30 @@ def pack3x3_split(w):
 AMAX_SLOTS = 64 * 32       # 64 magnitude slots, one per 128-byte line (bn.hip: amax_commit)
 
 
+_AMAX_ARENA = {}            # device -> [tensor [N, AMAX_SLOTS] int32, next free row]
+AMAX_ARENA_ROWS = 192
+
+
+def amax_arena_reset(device):
+    """One fill zeroes a step's worth of magnitude slots (Onet.forward calls this; ~70 sets per training step): new_amax then hands
+    out rows instead of launching a fill each.  Everything is ordered on the one stream the model runs on; a set handed out before a
+    reset is only ever read by kernels launched before it."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    ar = _AMAX_ARENA.get(key)
+    if ar is None:
+        ar = _AMAX_ARENA[key] = [torch.empty((AMAX_ARENA_ROWS, AMAX_SLOTS), dtype=torch.int32, device=device), 0]
+    fill(ar[0].view(torch.float32), 0.0)
+    ar[1] = 0
+
+
 def new_amax(device):
     """64 zeroed magnitude slots (8 KB: a cache line each; conv_split.hip: amax_read / amax_scale) for a tensor its producer is
     about to write."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    ar = _AMAX_ARENA.get(key)
+    if ar is not None and ar[1] < AMAX_ARENA_ROWS:
+        ar[1] += 1
+        return ar[0][ar[1] - 1]
     return torch.zeros(AMAX_SLOTS, dtype=torch.int32, device=device)
 
 
@@ -864,10 +915,10 @@ def split_pack_act(x, f16=True, scale=1.0, out=None):
     return out
 
 
-def conv3x3_split_pre(xs, wq, Cout, out=None, out_scale=None, stats=None):
-    """z = out_scale * conv3x3 of a PRE-SPLIT activation xs [B, Cin/8, H, 2, W, 8] (split_pack_act / the producers' fused variants)
-    with the split weight pack wq: the arithmetic of conv3x3_split, staging by LDS-DMA.  out_scale undoes a power-of-two scale
-    applied to xs by its producer (the fp16 pack's own scale is undone by the kernel from the pack)."""
+def conv3x3_split_pre(xs, wq, Cout, out=None, slots=None, always=False, stats=None):
+    """z = conv3x3 of a PRE-SPLIT activation xs [B, Cin/8, H, 2, W, 8] (split_pack_act / the producers' fused variants) with the split
+    weight pack wq: the arithmetic of conv3x3_split, staging by LDS-DMA.  slots / always: the magnitude slots and rule the producer
+    scaled xs by (undone by the kernel; None: unscaled)."""
     if wq is None or not wq.is_cuda or wq.dtype not in (torch.bfloat16, torch.float16) or xs.dtype != wq.dtype:
         raise TypeError("conv3x3_split_pre: xs and wq must be split packs of the same 16-bit type on the GPU")
     f16 = int(wq.dtype == torch.float16)
@@ -875,18 +926,17 @@ def conv3x3_split_pre(xs, wq, Cout, out=None, out_scale=None, stats=None):
     Cin = C8 * 8
     if out is None:
         out = torch.empty((B, Cout, H, W), dtype=F32, device=xs.device)
-    if out_scale is None:
-        out_scale = 1.0
     e0 = _prof_begin()
-    _lib.call("onet_conv3x3_split_fwd_pre", _p(xs), xs.stride(0) // 2 if B > 1 else Cin * H * W, _p(wq), f16, float(out_scale), _p(out),
+    _lib.call("onet_conv3x3_split_fwd_pre", _p(xs), xs.stride(0) // 2 if B > 1 else Cin * H * W, _p(slots), int(always), _p(wq), f16, _p(out),
               out.stride(0) if B > 1 else Cout * H * W, _p(stats), B, Cin, Cout, H, W, _stream())
     _prof_end("conv3x3_split_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
     return out
 
 
-def conv3x3_split_wgrad_pre(xs, dzs, dw_shape, out=None, out_scale=1.0):
-    """dw = out_scale * (weight gradient of a 3x3 convolution) from PRE-SPLIT x and dz (split_pack_act layout, same 16-bit
-    type): conv3x3_split_wgrad's arithmetic with LDS-DMA staging and transposed fragment reads."""
+def conv3x3_split_wgrad_pre(xs, dzs, dw_shape, out=None, x_slots=None, dz_slots=None):
+    """Weight gradient of a 3x3 convolution from PRE-SPLIT x and dz (split_pack_act layout, same 16-bit type):
+    conv3x3_split_wgrad's arithmetic with LDS-DMA staging and transposed fragment reads; x_slots / dz_slots: the magnitude slots the
+    producers scaled the operands by (undone on the result)."""
     if xs.dtype != dzs.dtype or xs.dtype not in (torch.bfloat16, torch.float16):
         raise TypeError("conv3x3_split_wgrad_pre: xs and dzs must be pre-split tensors of the same 16-bit type")
     B, C8, H, two, W, eight = xs.shape
@@ -896,11 +946,131 @@ def conv3x3_split_wgrad_pre(xs, dzs, dw_shape, out=None, out_scale=1.0):
     need = _lib.load().onet_conv3x3_split_wgrad_ws_bytes(B, Cin, Cout, H, W)
     ws = workspace(need, xs.device)
     e0 = _prof_begin()
-    _lib.call("onet_conv3x3_split_wgrad_pre", _p(xs), xs.stride(0) // 2 if B > 1 else Cin * H * W, _p(dzs),
-              dzs.stride(0) // 2 if B > 1 else Cout * H * W, int(xs.dtype == torch.float16), float(out_scale), _p(dw), _p(ws),
+    _lib.call("onet_conv3x3_split_wgrad_pre", _p(xs), xs.stride(0) // 2 if B > 1 else Cin * H * W, _p(x_slots), _p(dzs),
+              dzs.stride(0) // 2 if B > 1 else Cout * H * W, _p(dz_slots), int(xs.dtype == torch.float16), _p(dw), _p(ws),
               ws.numel() * 4, B, Cin, Cout, H, W, 0, _stream())
     _prof_end("conv3x3_split_wgrad_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
     return dw
+
+
+# ----------------------------------------------------------------------------- pre-split storage (Settings.presplit)
+def pre_layer_ok(B, Cin, Cout, H, W):
+    """Can a 3x3 convolution layer (Cin -> Cout on B maps of H x W) run ALL THREE of its kernels on pre-split operands -- forward and
+    input gradient by conv3x3_split_pre_kernel, weight gradient by conv3x3_split_wgrad_pre_kernel?  Producers write the pre-split
+    form of a tensor only where this says yes for its consumer (the decision is a function of shapes and settings, so producer and
+    consumer agree without talking)."""
+    if not presplit() or Cin % 16 or Cout % 16 or W < 32 or W % 32 or H % 16 or H * W >= 2 ** 24:
+        return False
+    if W == 32 and B * max(Cin, Cout) * H * W * 4 >= 2 ** 31:      # weight-gradient units pair images: one buffer resource over the batch
+        return False
+    lib = _lib.load()
+    return conv3x3_algo(B, Cin, Cout, H, W) == "split" and conv3x3_algo(B, Cout, Cin, H, W) == "split" and \
+        bool(lib.onet_conv3x3_split_wgrad_pre_ok(B, Cin, Cout, H, W)) and int(lib.onet_conv3x3_split_nparts(B, H, W)) > 0 and \
+        int(lib.onet_maxpool2_bwd_bn_bands(H, W)) > 0
+
+
+def p16_empty(B, C, H, W, device):
+    """An uninitialised pre-split tensor: fp16 (hi | mid) parts in the slot layout [B, C/8, H, 2, W, 8] (4 bytes per element)."""
+    return torch.empty((B, C // 8, H, 2, W, 8), dtype=torch.float16, device=device)
+
+
+def p16_of(t):
+    """The valid pre-split form riding on tensor `t` (tag_p16), or None."""
+    tag = getattr(t, "_onet_p16", None)
+    if tag is None:
+        return None
+    P, ver = tag
+    return P if ver == t._version else None
+
+
+def tag_p16(t, P):
+    if P is not None and t is not None:
+        t._onet_p16 = (P, t._version)
+    return t
+
+
+def _pbs(P):
+    """batch stride of a pre-split tensor (or of a channel-group slice of one) in 4-byte units"""
+    return P.stride(0) // 2 if P.shape[0] > 1 else P.shape[1] * P.shape[2] * P.shape[4] * 8
+
+
+def bn_relu_apply_split(z, save, xs, a=None):
+    """relu(bn(z)) written pre-split into xs [B, C/8, H, 2, W, 8] (a whole tensor or the leading channel groups of a concat buffer)
+    and, when `a` is given, in fp32 too.  The same values, bit for bit, as bn_relu_apply."""
+    z, zbs = plane(z)
+    B, C, H, W = z.shape
+    _lib.call("onet_bn_relu_apply_split", _p(z), zbs, _p(xs), _pbs(xs), _p(a), 0 if a is None else (a.stride(0) if B > 1 else C * H * W),
+              _p(save), B, C, H, W, _stream(), nbytes=(8 + 4 * (a is not None)) * z.numel())
+
+
+def bn_relu_apply_pool_split(z, save, xs, a, ys, y):
+    """relu(bn(z)) and its 2 x 2 max-pooling in one pass: the activation pre-split (xs) and / or fp32 (a), the pooled tensor pre-split
+    (ys) or fp32 (y).  -> False where the kernel does not take the shape."""
+    z, zbs = plane(z)
+    B, C, H, W = z.shape
+    n, m = C * H * W, C * (H // 2) * (W // 2)
+    rc = _lib.load().onet_bn_relu_apply_pool_split(_p(z), zbs, _p(xs), 0 if xs is None else _pbs(xs), _p(a),
+                                                  0 if a is None else (a.stride(0) if B > 1 else n), _p(ys), 0 if ys is None else _pbs(ys),
+                                                  _p(y), 0 if y is None else (y.stride(0) if B > 1 else m), _p(save), B, C, H, W, _stream())
+    if rc < 0:
+        raise _lib.OnetHipError(f"onet_bn_relu_apply_pool_split failed ({rc}): {_lib.last_error()}")
+    return rc == 0
+
+
+def conv3x3_pre_bn_partials(xP, pk):
+    """conv3x3_fwd_bn_partials for a pre-split input: -> (z, cm) with the BatchNorm statistics records of the epilogue."""
+    B, C8, H, _, W, _ = xP.shape
+    Co = pk["Cout"]
+    wq = pk.get_pack("split")[0]
+    nparts = int(_lib.load().onet_conv3x3_split_nparts(B, H, W))
+    cm = torch.empty((Co, nparts, 3), dtype=F32, device=xP.device) if nparts > 0 else None
+    return conv3x3_split_pre(xP, wq, Co, stats=cm), cm
+
+
+def bn_relu_bwd_split(da, z, save_all, training, need_affine_grads=True, affine_out=None, rec=None, rec4=None, da_amax=None):
+    """BatchNorm + ReLU backward of a layer whose dz is consumed by the pre-split kernels.  Per statistics group: the reduce pass
+    (also recording max |da|, unless the records -- and da's magnitude slots -- came fused from da's producer), then the finalize
+    pass, which also writes the bound of |dz| into fresh magnitude slots (all reduce passes first: the bound needs the complete
+    max |da|), then dz written pre-split, scaled by the power of two those slots select.  -> (dzP, dz_slots, dgamma, dbeta)."""
+    da, dabs = plane(da)
+    z, zbs = plane(z)
+    B, C, H, W = z.shape
+    HW = H * W
+    G = save_all.shape[0]
+    Bg = B // G
+    dev = z.device
+    dzP = p16_empty(B, C, H, W, dev)
+    dz_slots = new_amax(dev)
+    if rec4 is not None and da_amax is None:
+        da_amax = absmax_slots(da)                  # records fused by a producer that did not record the magnitude: one extra pass
+    parts = []
+    if rec4 is None:
+        da_amax = new_amax(dev)
+        nparts = _bn_nparts(Bg, HW)
+        for g in range(G):
+            sl = slice(g * Bg, (g + 1) * Bg)
+            part2 = torch.empty((nparts, C, 4), dtype=F32, device=dev)
+            _lib.call("onet_bn_relu_bwd_reduce_amax", _p(da[sl]), dabs, _p(z[sl]), zbs, _p(save_all[g]), _p(part2), nparts, _p(da_amax),
+                      Bg, C, HW, _stream(), nbytes=8 * z[sl].numel())
+            parts.append((part2, nparts))
+    else:
+        np4 = rec4.shape[0] // G
+        assert rec4.shape[1] == C and rec4.shape[2] == 4
+        parts = [(rec4[g * np4:(g + 1) * np4], np4) for g in range(G)]
+    og, ob = affine_out if affine_out is not None else (None, None)
+    dgamma = torch.empty(C, dtype=F32, device=dev) if og is None else og
+    dbeta = torch.empty(C, dtype=F32, device=dev) if ob is None else ob
+    coefs = []
+    for g in range(G):
+        coef = torch.empty((4, C), dtype=F32, device=dev) if training else None
+        _lib.call("onet_bn_bwd_finalize_bound", _p(parts[g][0]), parts[g][1], Bg * HW, _p(dgamma), _p(dbeta), _p(coef), int(g > 0), C,
+                  _p(save_all[g]), _p(da_amax), _p(dz_slots), _stream())
+        coefs.append(coef)
+    for g in range(G):
+        sl = slice(g * Bg, (g + 1) * Bg)
+        _lib.call("onet_bn_relu_bwd_apply_split", _p(da[sl]), dabs, _p(z[sl]), zbs, _p(save_all[g]), _p(coefs[g]), _p(dzP[sl]), _pbs(dzP),
+                  _p(dz_slots), Bg, C, H, W, _stream(), nbytes=12 * z[sl].numel())
+    return dzP, dz_slots, dgamma, dbeta
 
 
 def split_wgrad_ok(x, dz):
@@ -1265,17 +1435,9 @@ def bn_relu_apply_pool(z, save, out, out16, y, y16, amax=None):
     return rc == 0
 
 
-def bn_relu_bwd(da, z, save, training, need_affine_grads=True, out=None, acc=None, affine_out=None, red=None, red4=None,
-                out16=None, amax=None):
-    """-> dz, dgamma, dbeta.  `out`: plane-contiguous destination for dz (a batch slice of a larger buffer);
-    `acc` = (dgamma, dbeta) of another statistics group of the same layer to accumulate into; `affine_out` =
-    (dgamma, dbeta) destinations to overwrite (None entries are allocated); `red` = (records [C, NP, 2], first, count):
-    the (sum dy, sum dy*xhat) records of this batch slice were already written by the dgrad launch that produced
-    `da` (`conv3x3_dgrad_bnreduce`), so the reduce pass over (da, z) is skipped; `red4` = (records [NP, C, 4], first,
-    count): the same in the reduce kernel's own record format (written by the pooling-backward kernel).
-    `out16`: plane-contiguous bf16 destination -- dz is then written in bf16 ONLY (its consumers are the bf16 dgrad and
-    weight-gradient kernels) and the returned dz is None.  `amax`: 64 zeroed magnitude slots (new_amax) in which the apply pass
-    records max |dz| for the fp16-split gradient kernels (several statistics groups of one tensor share them)."""
+def bn_bwd_coefs(da, z, save, training, need_affine_grads=True, acc=None, affine_out=None, red=None, red4=None, da_amax=None):
+    """The reduce + finalize passes of bn_relu_bwd for one statistics group: -> (coef [4, C] | None, dgamma, dbeta).  da_amax: magnitude
+    slots in which the (standalone) reduce pass records max |da|."""
     da, dabs = plane(da)
     z, zbs = plane(z)
     B, C, H, W = z.shape
@@ -1302,8 +1464,12 @@ def bn_relu_bwd(da, z, save, training, need_affine_grads=True, out=None, acc=Non
             part2, nparts = rec4[first:first + count], count
         else:
             part2 = torch.empty((nparts, C, 4), dtype=F32, device=dev)
-            _lib.call("onet_bn_relu_bwd_reduce", _p(da), dabs, _p(z), zbs, _p(save), _p(part2), nparts, B, C, HW, _stream(),
-                      nbytes=8 * z.numel())
+            if da_amax is not None:
+                _lib.call("onet_bn_relu_bwd_reduce_amax", _p(da), dabs, _p(z), zbs, _p(save), _p(part2), nparts, _p(da_amax), B, C, HW,
+                          _stream(), nbytes=8 * z.numel())
+            else:
+                _lib.call("onet_bn_relu_bwd_reduce", _p(da), dabs, _p(z), zbs, _p(save), _p(part2), nparts, B, C, HW, _stream(),
+                          nbytes=8 * z.numel())
         if acc is None:
             og, ob = affine_out if affine_out is not None else (None, None)
             dgamma = torch.empty(C, dtype=F32, device=dev) if og is None else og
@@ -1321,6 +1487,26 @@ def bn_relu_bwd(da, z, save, training, need_affine_grads=True, out=None, acc=Non
             _lib.call("onet_bn_bwd_finalize", _p(part2), nparts, B * HW, _p(dgamma), _p(dbeta), None, accf, C, _stream())
             _lib.call("onet_bn_bwd_finalize", _p(gathered), nparts * world, B * HW * world, None, None, _p(coef), 0, C,
                       _stream())
+    return coef, dgamma, dbeta
+
+
+def bn_relu_bwd(da, z, save, training, need_affine_grads=True, out=None, acc=None, affine_out=None, red=None, red4=None,
+                out16=None, amax=None):
+    """-> dz, dgamma, dbeta.  `out`: plane-contiguous destination for dz (a batch slice of a larger buffer);
+    `acc` = (dgamma, dbeta) of another statistics group of the same layer to accumulate into; `affine_out` =
+    (dgamma, dbeta) destinations to overwrite (None entries are allocated); `red` = (records [C, NP, 2], first, count):
+    the (sum dy, sum dy*xhat) records of this batch slice were already written by the dgrad launch that produced
+    `da` (`conv3x3_dgrad_bnreduce`), so the reduce pass over (da, z) is skipped; `red4` = (records [NP, C, 4], first,
+    count): the same in the reduce kernel's own record format (written by the pooling-backward kernel).
+    `out16`: plane-contiguous bf16 destination -- dz is then written in bf16 ONLY (its consumers are the bf16 dgrad and
+    weight-gradient kernels) and the returned dz is None.  `amax`: 64 zeroed magnitude slots (new_amax) in which the apply pass
+    records max |dz| for the fp16-split gradient kernels (several statistics groups of one tensor share them)."""
+    coef, dgamma, dbeta = bn_bwd_coefs(da, z, save, training, need_affine_grads, acc, affine_out, red, red4)
+    da, dabs = plane(da)
+    z, zbs = plane(z)
+    B, C, H, W = z.shape
+    HW = H * W
+    dev = z.device
     if out16 is not None:
         o16bs = out16.stride(0) if B > 1 else C * HW
         _lib.call("onet_bn_relu_bwd_apply_b", _p(da), dabs, _p(z), zbs, _p(save), _p(coef), None, 0, _p(out16), o16bs, B, C, HW,
@@ -1359,15 +1545,22 @@ def maxpool2_fwd(x, bf16_only=False):
     return y
 
 
-def maxpool2_bwd(x, dy, add=None, add2=None, bn=None):
+def maxpool2_bwd(x, dy, add=None, add2=None, bn=None, dx_amax=None):
     """dx of MaxPool2d(2); `add`, `add2`: other gradients of x (plane-contiguous, e.g. a slice of a concat gradient)
     summed in the same pass.  `bn` = (z, save_all [G, 4, C]): x is the output relu(bn(z)) of a Conv-BN-ReLU unit with G
     statistics groups -- the unit's BatchNorm-backward reduce records are taken on the way: -> (dx, part2 [B * bands, C, 4])
-    (or (dx, None) where the fused form is not available)."""
-    x, xbs = plane(x)
+    (or (dx, None) where the fused form is not available).  Pre-split storage: x may be a placeholder (the activation exists only
+    pre-split; with `bn` the kernel recomputes it from z) and dx_amax = magnitude slots that receive max |dx|."""
+    if is_placeholder(x):
+        if bn is None:
+            raise RuntimeError("onet_amd: max-pooling backward of an activation kept only pre-split needs its (z, coefficients)")
+        B, C, H, W = x.shape
+        x, xbs = None, C * H * W
+    else:
+        x, xbs = plane(x)
+        B, C, H, W = x.shape
     dy, dybs = plane(dy)
-    B, C, H, W = x.shape
-    dx = torch.empty((B, C, H, W), dtype=F32, device=x.device)
+    dx = torch.empty((B, C, H, W), dtype=F32, device=dy.device)
     if add is None and add2 is not None:
         add, add2 = add2, None
     a1, a1bs = plane(add) if add is not None else (None, 0)
@@ -1380,11 +1573,18 @@ def maxpool2_bwd(x, dy, add=None, add2=None, bn=None):
         aligned = all(t is None or (t.data_ptr() & 15) == 0 for t in (x, z, a1, a2)) and (dy.data_ptr() & 7) == 0 and \
             all((v & 3) == 0 for v in (xbs, zbs, a1bs, a2bs)) and (dybs & 1) == 0
         if bands > 0 and aligned and B % G == 0 and tuple(z.shape) == (B, C, H, W) and save_all.is_contiguous():
-            part2 = torch.empty((B * bands, C, 4), dtype=F32, device=x.device)
-            _lib.call("onet_maxpool2_bwd_add_bnreduce", _p(x), xbs, _p(dy), dybs, _p(a1), a1bs, _p(a2), a2bs, _p(dx),
-                      C * H * W, _p(z), zbs, _p(save_all), B // G, _p(part2), B, C, H, W, _stream(),
-                      nbytes=(13 + 4 * (a1 is not None) + 4 * (a2 is not None)) * x.numel())
+            part2 = torch.empty((B * bands, C, 4), dtype=F32, device=dy.device)
+            if x is None or dx_amax is not None:
+                _lib.call("onet_maxpool2_bwd_add_bnreduce_amax", _p(x), xbs, _p(dy), dybs, _p(a1), a1bs, _p(a2), a2bs, _p(dx),
+                          C * H * W, _p(z), zbs, _p(save_all), B // G, _p(part2), _p(dx_amax), B, C, H, W, _stream(),
+                          nbytes=(9 + 4 * (x is not None) + 4 * (a1 is not None) + 4 * (a2 is not None)) * dx.numel())
+            else:
+                _lib.call("onet_maxpool2_bwd_add_bnreduce", _p(x), xbs, _p(dy), dybs, _p(a1), a1bs, _p(a2), a2bs, _p(dx),
+                          C * H * W, _p(z), zbs, _p(save_all), B // G, _p(part2), B, C, H, W, _stream(),
+                          nbytes=(13 + 4 * (a1 is not None) + 4 * (a2 is not None)) * x.numel())
             return dx, part2
+        if x is None:
+            raise RuntimeError("onet_amd: max-pooling backward of an activation kept only pre-split: the fused kernel does not take this shape")
     if add is None:
         _lib.call("onet_maxpool2_bwd", _p(x), xbs, _p(dy), dybs, _p(dx), C * H * W, B, C, H, W, 0, _stream(),
                   nbytes=9 * x.numel())

@@ -51,6 +51,9 @@ def _record_units(monkeypatch, B, keep, device):
     # every unit's activation must exist to be read: normalise-on-load (which leaves a placeholder where the first unit of a
     # DoubleConv would write its output) is switched off; it is bit-identical (test_bn_on_load_model_step_is_bit_identical)
     monkeypatch.setattr(ops, "BN_ON_LOAD", False)
+    # ... and under pre-split storage (the default) every unit also leaves its fp32 activation -- the tensor its pre-split parts are
+    # split from -- beside the pre-split form its consumers read (ops.PRESPLIT_KEEP_FP32: the kernels that run are unchanged)
+    monkeypatch.setattr(ops, "PRESPLIT_KEEP_FP32", True)
 
     def apply(*a, **k):
         out = real(*a, **k)
@@ -200,7 +203,8 @@ def test_benchmark_dispatch_b32_256_every_gradient_element(dev, monkeypatch):
     m = _model(1, 1.0, dev)
     used = {}
     for name in ("conv3x3_fwd_bn_partials", "conv3x3_dgrad_bnreduce", "conv3x3_split", "conv3x3_split_wgrad", "conv3x3_winograd4",
-                 "conv3x3_winograd4_wgrad", "conv3x3_winograd_wgrad", "convT2x2_wgrad", "convT2x2_dgrad"):
+                 "conv3x3_winograd4_wgrad", "conv3x3_winograd_wgrad", "convT2x2_wgrad", "convT2x2_dgrad", "conv3x3_pre_bn_partials",
+                 "conv3x3_split_pre", "conv3x3_split_wgrad_pre", "bn_relu_bwd_split", "convT2x2_fwd_p"):
         real = getattr(ops, name)
 
         def spy(*a, _real=real, _name=name, **k):
@@ -227,9 +231,17 @@ def test_benchmark_dispatch_b32_256_every_gradient_element(dev, monkeypatch):
     # Winograd F(4x4) on the 16-pixel level), split-bf16 input gradients, split-bf16 weight gradients of all 17 layers with
     # >= 16 input channels (round 3: also the 32- and 16-pixel levels), the ConvTranspose2d GEMMs
     diag = bool(os.environ.get("ONET_DIAG"))        # diagnostic runs with parts of the dispatch switched off (ONET_SPLIT_DGRAD=0 ...)
-    assert diag or (used.get("conv3x3_fwd_bn_partials", 0) >= 14 and used.get("conv3x3_split", 0) >= 10), used
-    if ops.SPLIT_AUTO and not diag:
-        assert used.get("conv3x3_split_wgrad", 0) == 17 and used.get("conv3x3_winograd4_wgrad", 0) + used.get("conv3x3_winograd_wgrad", 0) == 0, used
+    if ops.PRESPLIT and not diag:
+        # round 4, pre-split storage: the 15 layers on maps >= 32 pixels wide with >= 16 input channels run forward (with fused
+        # statistics), input gradient and weight gradient on pre-split operands (LDS-DMA staged kernels); the stem and the 16-pixel
+        # level keep the fp32-operand kernels (2 split weight gradients there); the up-sampled concat halves leave the GEMM pre-split
+        assert used.get("conv3x3_pre_bn_partials", 0) == 15 and used.get("conv3x3_split_wgrad_pre", 0) == 15, used
+        assert used.get("conv3x3_split_pre", 0) == 15 + 15 and used.get("bn_relu_bwd_split", 0) == 15 and used.get("convT2x2_fwd_p", 0) == 4, used
+        assert used.get("conv3x3_split_wgrad", 0) == 2 and used.get("conv3x3_winograd4_wgrad", 0) + used.get("conv3x3_winograd_wgrad", 0) == 0, used
+    else:
+        assert diag or (used.get("conv3x3_fwd_bn_partials", 0) >= 14 and used.get("conv3x3_split", 0) >= 10), used
+        if ops.SPLIT_AUTO and not diag:
+            assert used.get("conv3x3_split_wgrad", 0) == 17 and used.get("conv3x3_winograd4_wgrad", 0) + used.get("conv3x3_winograd_wgrad", 0) == 0, used
     assert used.get("convT2x2_wgrad", 0) == 4 and used.get("conv3x3_winograd4", 0) >= 1, used
     assert abs(loss.item() - g["losses"][0]) <= 1e-3 * abs(g["losses"][0])
     assert np.abs(Vt.detach().cpu().numpy()[:2, :, ::37, :] - g["Vt"]).max() <= 1e-3 * np.abs(g["Vt"]).max()

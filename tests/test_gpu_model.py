@@ -396,7 +396,7 @@ def test_bn_on_load_model_step_is_bit_identical(dev, monkeypatch):
     res = {}
     for on in (True, False):
         m = _model(C, True, dev)
-        m.settings = ops.Settings(bn_on_load=on)
+        m.settings = ops.Settings(bn_on_load=on, presplit=False)       # (pre-split storage, the default, supersedes normalise-on-load)
         (Lt, Vt, Ld, Vd, S), loss = _step(m, X)
         res[on] = (loss.detach().clone(), Lt.detach().clone(), S.detach().clone(),
                    [p.grad.detach().clone() for p in m.parameters()], [b.detach().clone() for b in m.buffers()])
@@ -938,3 +938,33 @@ def test_training_behaviour_vs_reference_fixture(dev, mode):
     assert abs(miou - float(g["miou32"])) <= mtol and abs(acc - float(g["acc32"])) <= mtol
     assert abs(eval_loss - float(g["eval_loss32"])) <= 5 * ltol * abs(float(g["eval_loss32"]))
     assert diff_px <= (0.03 if mode == "bf16" else 0.01) * Y.numel()
+
+
+@pytest.mark.parametrize("B,H,algo", [(4, 128, "auto"), (4, 256, "split"), (2, 64, "split")])
+def test_presplit_storage_step_vs_fp32_storage(dev, B, H, algo, monkeypatch):
+    """Round 4: pre-split storage (Settings.presplit, the default) against the same step with every operand kept in fp32 and split by
+    the consuming kernels: the FORWARD (every output, the loss, the BatchNorm buffers) must be bit-identical -- the producers split
+    exactly the values the fp32 passes write and the LDS-DMA staged kernel runs the same MFMA sequence on them -- and every parameter
+    gradient agrees to rounding (fp16 parts of power-of-two-scaled gradients against bf16 parts; another summation order in the
+    weight gradient)."""
+    from onet_amd import ops
+    monkeypatch.setattr(ops, "CONV_ALGO", algo)
+    X = orc.det_input(B, 1, H, H, seed=23).to(dev)
+    res = {}
+    for name, st in (("fp32", ops.Settings(presplit=False, bn_on_load=False)), ("presplit", ops.Settings(presplit=True))):
+        import Onet_vanilla_20240606 as ov
+        m = ov.Onet(in_chns=1, binit=True, bshare=True)
+        m.load_state_dict(orc.onet_state_dict(1, 1981, True, head_gain=0.3))
+        m = m.to(dev).train()
+        m.settings = st
+        (Lt, Vt, Ld, Vd, S), loss = _step(m, X)
+        res[name] = (loss.detach().clone(), Lt.detach().clone(), Vt.detach().clone(), S.detach().clone(),
+                     {k: p.grad.detach().clone() for k, p in m.named_parameters()}, [b.detach().clone() for b in m.buffers()])
+    a, b = res["fp32"], res["presplit"]
+    for i in range(4):
+        assert torch.equal(a[i], b[i]), i
+    for p, q in zip(a[5], b[5]):
+        assert torch.equal(p, q)
+    worst = max((float((a[4][k] - b[4][k]).norm() / a[4][k].norm()), k) for k in a[4])
+    print(f"pre-split vs fp32 storage [{B}x{H}x{H}, {algo}]: forward bit-identical; worst relative gradient difference {worst[0]:.2e} ({worst[1]})")
+    assert worst[0] <= 1e-4, worst

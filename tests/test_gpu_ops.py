@@ -1027,3 +1027,63 @@ def test_gpu_clutter_generator_vs_reference_fixture(dev):
     # targets raise the amplitude inside their labels
     assert float(X[:, 0][lab > 0].mean()) > float(X[:, 0][lab == 0].mean())
 
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 64, 32, 64), (3, 16, 16, 32), (2, 128, 64, 32)])
+def test_presplit_producers_are_bit_identical_to_the_fp32_passes(dev, B, C, H, W):
+    """Round 4, pre-split storage: the BatchNorm passes that write their result as fp16 (hi | mid) slots for the split convolution
+    kernels must produce exactly onet_split_pack_act of what the fp32 passes write -- forward apply (whole tensor / leading groups of
+    a concat buffer / + fp32 copy), apply + 2 x 2 pooling (slots or fp32 for either output), backward apply (scaled by the power of
+    two its magnitude slots select; the slots hold an upper bound of |dz| within a small factor of the true maximum)."""
+    from onet_amd import ops
+    g = torch.Generator().manual_seed(7)
+    z = (torch.randn(B, C, H, W, generator=g) * 2 + 0.3).to(dev)
+    save = torch.empty(4, C)
+    save[0] = torch.randn(C, generator=g) * 0.3
+    save[1] = torch.rand(C, generator=g) + 0.5
+    save[2] = save[1] * (torch.rand(C, generator=g) + 0.5)
+    save[3] = torch.randn(C, generator=g) * 0.5 + 0.2
+    save = save.to(dev)
+    a = ops.bn_relu_apply(z, save)
+    aP = ops.split_pack_act(a, f16=True)
+    xs, a2 = ops.p16_empty(B, C, H, W, dev), torch.empty_like(a)
+    ops.bn_relu_apply_split(z, save, xs, a=a2)
+    assert torch.equal(xs, aP) and torch.equal(a2, a)
+    wide = torch.zeros((B, 2 * C // 8, H, 2, W, 8), dtype=torch.float16, device=dev)
+    ops.bn_relu_apply_split(z, save, wide[:, :C // 8])
+    assert torch.equal(wide[:, :C // 8], aP) and float(wide[:, C // 8:].float().abs().max()) == 0.0
+    y = ops.maxpool2_fwd(a)
+    xs2, ys, a3, yf = ops.p16_empty(B, C, H, W, dev), ops.p16_empty(B, C, H // 2, W // 2, dev), torch.empty_like(a), torch.empty_like(y)
+    assert ops.bn_relu_apply_pool_split(z, save, xs2, a3, ys, None)
+    assert torch.equal(xs2, aP) and torch.equal(a3, a) and torch.equal(ys, ops.split_pack_act(y, f16=True))
+    assert ops.bn_relu_apply_pool_split(z, save, None, a3, None, yf) and torch.equal(yf, y)
+    da = (torch.randn(B, C, H, W, generator=g) * 1e-4).to(dev)
+    dz, dg, db = ops.bn_relu_bwd(da, z, save, True)
+    dzP, slots, dg2, db2 = ops.bn_relu_bwd_split(da, z, save.view(1, 4, C), True)
+    bound, amax = float(slots.view(torch.float32).max()), float(dz.abs().max())
+    assert amax <= bound <= 8 * amax, (bound, amax)
+    k = 13 - int(np.floor(np.log2(bound)))
+    assert torch.equal(dzP, ops.split_pack_act(dz, f16=True, scale=2.0 ** k)) and torch.equal(dg2, dg) and torch.equal(db2, db)
+    # two statistics groups share the slots and the scale
+    if B % 2 == 0:
+        save2 = torch.stack([save, save * 1.1])
+        dzP2, slots2, _, _ = ops.bn_relu_bwd_split(da, z, save2, True)
+        ref = torch.cat([ops.bn_relu_bwd(da[:B // 2], z[:B // 2], save2[0], True)[0], ops.bn_relu_bwd(da[B // 2:], z[B // 2:], save2[1], True)[0]])
+        k2 = 13 - int(np.floor(np.log2(float(slots2.view(torch.float32).max()))))
+        assert torch.equal(dzP2, ops.split_pack_act(ref, f16=True, scale=2.0 ** k2))
+
+
+@pytest.mark.parametrize("B,Cin,h,w", [(2, 128, 16, 32), (4, 256, 16, 16), (2, 1024, 16, 16)])
+def test_convT_presplit_epilogue(dev, B, Cin, h, w):
+    """ConvTranspose2d forward writing the up-sampled channel groups of a pre-split concat buffer (whole slots per lane after a
+    v_permlane32_swap exchange in the GEMM's epilogue): bit-identical to splitting the fp32 output; the skip groups stay untouched."""
+    from onet_amd import ops
+    Ct = Cin // 2
+    x, wt, bias = rnd(B, Cin, h, w, seed=71).to(dev), rnd(Cin, Ct, 2, 2, seed=72, scale=0.05).to(dev), rnd(Ct, seed=73).to(dev)
+    wf = ops.packT2x2_fused(wt)
+    ref = torch.empty(B, Ct, 2 * h, 2 * w, device=dev)
+    ops.convT2x2_fwd(x, wf, bias, ref, Ct, 0, 0)
+    cat = torch.zeros((B, 2 * Ct // 8, 2 * h, 2, 2 * w, 8), dtype=torch.float16, device=dev)
+    assert ops.convT2x2_fwd_p(x, wf, bias, cat[:, Ct // 8:], Ct, 0, 0)
+    assert torch.equal(cat[:, Ct // 8:], ops.split_pack_act(ref, f16=True))
+    assert float(cat[:, :Ct // 8].float().abs().max()) == 0.0
