@@ -341,6 +341,34 @@ constexpr int BN_TR_SLOTS = 2 * (1024 + 256);       // 40 KB of LDS per block
 #ifndef BN_APPLY_SPLIT_TR
 #define BN_APPLY_SPLIT_TR 1
 #endif
+// addr(px) -> global slot index of the hi part of the block's pixel px (0 .. 1023; < 0: outside), mid_off = slots from hi to mid
+template <typename AddrFn>
+__device__ __forceinline__ void bn_store_slots_block_fn(bn_u32x4* lds, unsigned* __restrict__ xs, int mid_off, const float (&v)[4][8], float s,
+                                                        AddrFn addr) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        bn_u32x4 hi, mid;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned h, m;
+            split2h_s(v[q][2 * k], v[q][2 * k + 1], s, h, m);
+            hi[k] = h;
+            mid[k] = m;
+        }
+        lds[5 * t + q] = hi;
+        lds[1280 + 5 * t + q] = mid;
+    }
+    __syncthreads();
+    bn_u32x4* dst = reinterpret_cast<bn_u32x4*>(xs);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int part = j >> 2, px = (j & 3) * 256 + t;
+        const int64_t a = addr(px);
+        if (a >= 0) dst[a + (int64_t)part * mid_off] = lds[part * 1280 + px + (px >> 2)];
+    }
+}
+
 __device__ __forceinline__ void bn_store_slots_block(bn_u32x4* lds, unsigned* __restrict__ xs, int c8, int H, int W, int p_blk, int HW,
                                                      const float (&v)[4][8], float s) {
     const int t = threadIdx.x;
@@ -448,9 +476,9 @@ __global__ __launch_bounds__(256) void bn_relu_apply_pool_split_kernel(const flo
     const int plane = blockIdx.x / bpp, blk = blockIdx.x % bpp;
     const int C8 = C >> 3, b = plane / C8, c8 = plane % C8;
     const int Hp = H >> 1, Wp = W >> 1, W4 = W >> 2, HW = H * W, i = blk * 256 + threadIdx.x;
-    if (i >= Hp * W4) return;
+    const bool live = i < Hp * W4;                  // (no early return: the block transposes its slots through LDS together)
     int yo, q;
-    bn_pixel_of(i, W4, yo, q);
+    bn_pixel_of(live ? i : 0, W4, yo, q);
     const int64_t in_off = (int64_t)c8 * 8 * HW + (int64_t)(2 * yo) * W + 4 * q;
     const float* src = z + (int64_t)b * z_bs + in_off;
     float v[8][8], m[2][8];                     // [pixel: row 0 cols 0-3, row 1 cols 0-3][channel]; [pooled pixel][channel]
@@ -470,7 +498,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_pool_split_kernel(const flo
         m[0][k] = fmaxf(fmaxf(v[0][k], v[1][k]), fmaxf(v[4][k], v[5][k]));
         m[1][k] = fmaxf(fmaxf(v[2][k], v[3][k]), fmaxf(v[6][k], v[7][k]));
     }
-    if (a) {
+    if (a && live) {
         float* d = a + (int64_t)b * a_bs + in_off;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -479,11 +507,29 @@ __global__ __launch_bounds__(256) void bn_relu_apply_pool_split_kernel(const flo
         }
     }
     if (xs) {
+        // the patch rows' slots leave through the block transpose (coalesced stores), one round per patch row: block pixel px =
+        // (thread px / 4, column px % 4) of that row
+        __shared__ bn_u32x4 tr[BN_TR_SLOTS];
         unsigned* o = xs + (int64_t)b * xs_bs;
+        const int npatch = Hp * W4, patch0 = blk * 256;
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-            bn_store_slots(o, ((int64_t)(c8 * H + 2 * yo + (e >> 2)) * 2) * W + 4 * q + (e & 3), W, v[e], 1.f);
+        for (int r = 0; r < 2; ++r) {
+            if (r) __syncthreads();
+            float vr[4][8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) vr[e][k] = live ? v[4 * r + e][k] : 0.f;
+            bn_store_slots_block_fn(tr, o, W, vr, 1.f, [&](int px) -> int64_t {
+                const int pi = patch0 + (px >> 2);
+                if (pi >= npatch) return -1;
+                int py, pq;
+                bn_pixel_of(pi, W4, py, pq);
+                return ((int64_t)(c8 * H + 2 * py + r) * 2) * W + 4 * pq + (px & 3);
+            });
+        }
     }
+    if (!live) return;
     if (ys) {
         unsigned* o = ys + (int64_t)b * ys_bs;
         bn_store_slots(o, ((int64_t)(c8 * Hp + yo) * 2) * Wp + 2 * q, Wp, m[0], 1.f);

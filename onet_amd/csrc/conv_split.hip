@@ -1286,6 +1286,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_kernel(SwArgs a) {
 // A channel group's plane of 68 slots = 272 dwords = 16 banks (mod 64): the 4 pixel rows x (2 groups x 2 half-slots) a 32-lane
 // half reads fall on 64 different banks -- conflict-free without a swizzle.
 typedef short s16x4w __attribute__((ext_vector_type(4)));
+#ifndef SWP_SHARE_B
+#define SWP_SHARE_B 1
+#endif
 struct SwPreArgs {
     const void* xs;
     int64_t xs_bs;        // batch strides in 4-byte units
@@ -1432,10 +1435,31 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_pre_kernel(SwPreAr
                 }
                 const u32x4s Ah = swp_frag(ab + dpx * 16), Am = swp_frag(ab + (DZ_PART + dpx) * 16);
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
+                for (int ky = 0; ky < 3; ++ky) {
+#if SWP_SHARE_B
+                    // the three horizontal taps of a row read pixels 8 kh + kx .. + 7: ONE set of three transposed reads (12 pixels, six
+                    // dwords of two pixels each) serves all three -- kx = 0: dwords 0-3, kx = 2: dwords 1-4, kx = 1: the 16-bit-shifted
+                    // pairs (v_alignbit) -- instead of two reads per tap and part (40 -> 22 LDS reads per 27 MFMAs)
+                    u32x4s Bs[2][3];
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt) {
+                        const unsigned ba = bb[ky] + (pt * X_PART + xpx) * 16;
+                        const u32x4s lo = swp_frag(ba);                                       // pixels 0 .. 7 of the lane's window
+                        const s16x4w r2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4w*)(uintptr_t)(ba + 128));
+                        const unsigned d4 = (unsigned)__builtin_bit_cast(unsigned long long, r2);   // pixels 8, 9
+                        Bs[pt][0] = lo;
+                        Bs[pt][1] = u32x4s{__builtin_amdgcn_alignbit(lo[1], lo[0], 16), __builtin_amdgcn_alignbit(lo[2], lo[1], 16),
+                                           __builtin_amdgcn_alignbit(lo[3], lo[2], 16), __builtin_amdgcn_alignbit(d4, lo[3], 16)};
+                        Bs[pt][2] = u32x4s{lo[1], lo[2], lo[3], d4};
+                    }
+#endif
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
+#if SWP_SHARE_B
+                        const u32x4s Bh = Bs[0][kx], Bm = Bs[1][kx];
+#else
                         const u32x4s Bh = swp_frag(bb[ky] + (xpx + kx) * 16), Bm = swp_frag(bb[ky] + (X_PART + xpx + kx) * 16);
+#endif
                         const int t = ky * 3 + kx;
                         if constexpr (F16) {
                             const f16x8 ah = __builtin_bit_cast(f16x8, Ah), am = __builtin_bit_cast(f16x8, Am);
@@ -1451,6 +1475,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_pre_kernel(SwPreAr
                             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
                         }
                     }
+                }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
