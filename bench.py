@@ -388,6 +388,8 @@ def main(args):
             BF16 += ("convt_gemm_kernel", "convt_wgrad_gemm_kernel")
         with ops.using(onet.settings):
             convt_split = ops.convt_operand_bf16(2 * args.batch, args.size // 2, args.size // 2, 64) == 2     # the last Up block's GEMM
+        if bf16:                        # conv == "bf16" through the pre-split kernels with ONE part: one MFMA per product term
+            REDUCTION.update({"conv3x3_split_kernel": 1.0, "conv3x3_split_wgrad_kernel": 1.0})
         if convt_split:                 # ... or split bf16 operands (three bf16 MFMAs per term, fp32-level results)
             BF16 += ("convt_gemm_kernel", "convt_wgrad_gemm_kernel")
             REDUCTION.update({"convt_gemm_kernel": 1.0 / 3.0, "convt_wgrad_gemm_kernel": 1.0 / 3.0})

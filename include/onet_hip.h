@@ -164,8 +164,8 @@ int onet_convT2x2_fwd_b(const float* x, int64_t x_bs, const float* wq, const flo
         void* stream);
 /* ... the up-sampled tensor written pre-split (round 4: fp16 hi | mid slots [B][Ct/8][Ho][2][Wo][8], batch stride in 4-byte units), e.g.
  * into the up-sampled channel groups of a pre-split concat buffer; no fp32 output.  Returns 1 (nothing done) outside the GEMM fast path. */
-int onet_convT2x2_fwd_p(const float* x, int64_t x_bs, const float* wq, const float* bias, void* yP, int64_t yP_bs, int B, int Cin, int Ct,
-                        int h, int w, int Ho, int Wo, int pt, int pl, int operand_bf16, void* stream);
+int onet_convT2x2_fwd_p(const float* x, int64_t x_bs, const float* wq, const float* bias, void* yP, int64_t yP_bs, int nparts, int B, int Cin,
+                        int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int operand_bf16, void* stream);
                                                                                 /* 1: shape outside the GEMM path, nothing done */
 int onet_conv3x3_bf16_fwd_b(const void* x_bf16, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin,
                             int Cout, int H, int W, void* stream);
@@ -355,11 +355,14 @@ int onet_bn_relu_bwd_apply(const float* da, int64_t da_bs, const float* z, int64
  * 2 x 2-pooled values to ys (pre-split) or y (fp32); returns 1 when the shape is not taken (odd H / W, alignment).
  * _bwd_apply_split: dz as parts of 2^k dz, k chosen (conv_split.hip: amax_scale, always) from the magnitude slots dz_amax, which
  * must hold an upper bound of |dz| BEFORE the launch: onet_bn_bwd_bound writes it from the layer's coefficients and the exact
- * max |da| (da_amax: recorded by onet_bn_relu_bwd_reduce_amax or onet_absmax_slots); the consumers read the same slots. */
-int onet_bn_relu_apply_split(const float* z, int64_t z_bs, void* xs, int64_t xs_bs, float* a, int64_t a_bs, const float* save, int B, int C,
-                             int H, int W, void* stream);
+ * max |da| (da_amax: recorded by onet_bn_relu_bwd_reduce_amax or onet_absmax_slots); the consumers read the same slots.
+ * nparts = 2: the fp16 (hi | mid) slots above; nparts = 1: PLAIN bf16 operands, one part -- [B][C/8][H][W][8] bf16, rounded to
+ * nearest even, unscaled (dz_amax may be NULL) -- for BASELINE configs[2]'s bf16 MFMA conv path (the same LDS-DMA staged kernels
+ * with one part: wq_f16 / f16 = 2 in onet_conv3x3_split_fwd_pre / _wgrad_pre / _pack_weights / onet_split_pack_act). */
+int onet_bn_relu_apply_split(const float* z, int64_t z_bs, void* xs, int64_t xs_bs, float* a, int64_t a_bs, const float* save, int nparts,
+                             int B, int C, int H, int W, void* stream);
 int onet_bn_relu_apply_pool_split(const float* z, int64_t z_bs, void* xs, int64_t xs_bs, float* a, int64_t a_bs, void* ys, int64_t ys_bs,
-                                  float* y, int64_t y_bs, const float* save, int B, int C, int H, int W, void* stream);
+                                  float* y, int64_t y_bs, const float* save, int nparts, int B, int C, int H, int W, void* stream);
 int onet_bn_relu_bwd_reduce_amax(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save, float* part2, int nparts,
                                  void* da_amax, int B, int C, int HW, void* stream);
 int onet_bn_bwd_bound(const float* save, const float* coef, const void* da_amax, int64_t count, void* dz_amax, int C, void* stream);
@@ -368,7 +371,7 @@ int onet_bn_bwd_bound(const float* save, const float* coef, const void* da_amax,
 int onet_bn_bwd_finalize_bound(const float* part2, int nparts, int64_t count, float* dgamma, float* dbeta, float* coef, int accumulate,
                                int C, const float* save, const void* da_amax, void* dz_amax, void* stream);
 int onet_bn_relu_bwd_apply_split(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save, const float* coef,
-                                 void* dzs, int64_t dzs_bs, const void* dz_amax, int B, int C, int H, int W, void* stream);
+                                 void* dzs, int64_t dzs_bs, const void* dz_amax, int nparts, int B, int C, int H, int W, void* stream);
 /* onet_bn_relu_apply / onet_bn_relu_apply_pool that also record max a (a >= 0) in 64 magnitude slots (zeroed by the caller; the
  * statistics groups of a twin batch share them; the pooled tensor has the same maximum): the overflow guard of the fp16-split
  * convolution that consumes the activation.  _pool_amax returns 1 when the shape is not taken (as onet_bn_relu_apply_pool). */

@@ -318,8 +318,21 @@ __device__ __forceinline__ void bn_pixel_of(int p, int W, int& y, int& x) {     
     if ((y + 1) * W <= p) ++y;
     x = p - y * W;
 }
-__device__ __forceinline__ void bn_store_slots(unsigned* __restrict__ xs, int64_t slot, int W, const float (&v)[8], float s) {
+// np = 2: fp16 (hi | mid) parts of s v (the split kernels); np = 1: ONE part, bf16(v) rounded to nearest even (BASELINE configs[2]'s
+// plain-bf16 kernels: the rounding the bf16 convolution kernels apply to their operands)
+__device__ __forceinline__ unsigned bn_pack_bf16(float a, float b) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    const bf2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void bn_store_slots(unsigned* __restrict__ xs, int64_t slot, int W, const float (&v)[8], float s, int np = 2) {
     bn_u32x4 hi, mid;
+    if (np == 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) hi[k] = bn_pack_bf16(v[2 * k], v[2 * k + 1]);
+        reinterpret_cast<bn_u32x4*>(xs)[slot] = hi;
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         unsigned h, m;
@@ -344,11 +357,17 @@ constexpr int BN_TR_SLOTS = 2 * (1024 + 256);       // 40 KB of LDS per block
 // addr(px) -> global slot index of the hi part of the block's pixel px (0 .. 1023; < 0: outside), mid_off = slots from hi to mid
 template <typename AddrFn>
 __device__ __forceinline__ void bn_store_slots_block_fn(bn_u32x4* lds, unsigned* __restrict__ xs, int mid_off, const float (&v)[4][8], float s,
-                                                        AddrFn addr) {
+                                                        AddrFn addr, int np = 2) {
     const int t = threadIdx.x;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         bn_u32x4 hi, mid;
+        if (np == 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) hi[k] = bn_pack_bf16(v[q][2 * k], v[q][2 * k + 1]);
+            lds[5 * t + q] = hi;
+            continue;
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             unsigned h, m;
@@ -364,13 +383,24 @@ __device__ __forceinline__ void bn_store_slots_block_fn(bn_u32x4* lds, unsigned*
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int part = j >> 2, px = (j & 3) * 256 + t;
+        if (part >= np) break;
         const int64_t a = addr(px);
         if (a >= 0) dst[a + (int64_t)part * mid_off] = lds[part * 1280 + px + (px >> 2)];
     }
 }
 
 __device__ __forceinline__ void bn_store_slots_block(bn_u32x4* lds, unsigned* __restrict__ xs, int c8, int H, int W, int p_blk, int HW,
-                                                     const float (&v)[4][8], float s) {
+                                                     const float (&v)[4][8], float s, int np = 2) {
+    if (np == 1) {
+        bn_store_slots_block_fn(lds, xs, 0, v, s, [&](int px) -> int64_t {
+            const int p = p_blk + px;
+            if (p >= HW) return -1;
+            int y, x;
+            bn_pixel_of(p, W, y, x);
+            return (int64_t)(c8 * H + y) * W + x;
+        }, 1);
+        return;
+    }
     const int t = threadIdx.x;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -405,7 +435,7 @@ __device__ __forceinline__ void bn_store_slots_block(bn_u32x4* lds, unsigned* __
 // launch -- the strided 16-byte stores cost more than the narrower loads.
 __global__ __launch_bounds__(256) void bn_relu_apply_split_kernel(const float* __restrict__ z, int64_t z_bs, unsigned* __restrict__ xs,
                                                                   int64_t xs_bs, float* __restrict__ a, int64_t a_bs,
-                                                                  const float* __restrict__ save, int C, int H, int W, int bpp) {
+                                                                  const float* __restrict__ save, int C, int H, int W, int bpp, int np) {
     const int plane = blockIdx.x / bpp, blk = blockIdx.x % bpp;
     const int C8 = C >> 3, b = plane / C8, c8 = plane % C8;
 #if BN_APPLY_SPLIT_TR
@@ -430,7 +460,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_split_kernel(const float* _
 #pragma unroll
             for (int k = 0; k < 8; ++k) *reinterpret_cast<float4*>(d + (int64_t)k * HW) = make_float4(v[0][k], v[1][k], v[2][k], v[3][k]);
         }
-        bn_store_slots_block(tr, xs + (int64_t)b * xs_bs, c8, H, W, blk * 1024, HW, v, 1.f);
+        bn_store_slots_block(tr, xs + (int64_t)b * xs_bs, c8, H, W, blk * 1024, HW, v, 1.f, np);
         return;
     }
 #endif
@@ -462,7 +492,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_split_kernel(const float* _
 #pragma unroll
             for (int k = 0; k < 8; ++k) d[(int64_t)k * HW + p] = v[j][k];
         }
-        bn_store_slots(o, ((int64_t)(c8 * H + y) * 2) * W + x, W, v[j], 1.f);
+        bn_store_slots(o, ((int64_t)(c8 * H + y) * np) * W + x, W, v[j], 1.f, np);
     }
 }
 
@@ -472,7 +502,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_pool_split_kernel(const flo
                                                                        int64_t xs_bs, float* __restrict__ a, int64_t a_bs,
                                                                        unsigned* __restrict__ ys, int64_t ys_bs, float* __restrict__ yf,
                                                                        int64_t yf_bs, const float* __restrict__ save, int C, int H, int W,
-                                                                       int bpp) {
+                                                                       int bpp, int np) {
     const int plane = blockIdx.x / bpp, blk = blockIdx.x % bpp;
     const int C8 = C >> 3, b = plane / C8, c8 = plane % C8;
     const int Hp = H >> 1, Wp = W >> 1, W4 = W >> 2, HW = H * W, i = blk * 256 + threadIdx.x;
@@ -525,15 +555,15 @@ __global__ __launch_bounds__(256) void bn_relu_apply_pool_split_kernel(const flo
                 if (pi >= npatch) return -1;
                 int py, pq;
                 bn_pixel_of(pi, W4, py, pq);
-                return ((int64_t)(c8 * H + 2 * py + r) * 2) * W + 4 * pq + (px & 3);
-            });
+                return ((int64_t)(c8 * H + 2 * py + r) * np) * W + 4 * pq + (px & 3);
+            }, np);
         }
     }
     if (!live) return;
     if (ys) {
         unsigned* o = ys + (int64_t)b * ys_bs;
-        bn_store_slots(o, ((int64_t)(c8 * Hp + yo) * 2) * Wp + 2 * q, Wp, m[0], 1.f);
-        bn_store_slots(o, ((int64_t)(c8 * Hp + yo) * 2) * Wp + 2 * q + 1, Wp, m[1], 1.f);
+        bn_store_slots(o, ((int64_t)(c8 * Hp + yo) * np) * Wp + 2 * q, Wp, m[0], 1.f, np);
+        bn_store_slots(o, ((int64_t)(c8 * Hp + yo) * np) * Wp + 2 * q + 1, Wp, m[1], 1.f, np);
     }
     if (yf) {
         float* d = yf + (int64_t)b * yf_bs + (int64_t)c8 * 8 * Hp * Wp + (int64_t)yo * Wp + 2 * q;
@@ -548,9 +578,9 @@ __global__ __launch_bounds__(256) void bn_relu_apply_pool_split_kernel(const flo
 __global__ __launch_bounds__(256) void bn_relu_bwd_apply_split_kernel(const float* __restrict__ da, int64_t da_bs, const float* __restrict__ z,
                                                                       int64_t z_bs, const float* __restrict__ save, const float* __restrict__ coef,
                                                                       unsigned* __restrict__ dzs, int64_t dzs_bs, const unsigned* __restrict__ slots,
-                                                                      int C, int H, int W, int bpp) {
+                                                                      int C, int H, int W, int bpp, int np) {
     float inv;
-    const float s = amax_scale(amax_read(slots), true, inv);
+    const float s = np == 1 ? 1.f : amax_scale(amax_read(slots), true, inv);     // (plain bf16: fp32's exponent range, no scale)
     const int plane = blockIdx.x / bpp, blk = blockIdx.x % bpp;
     const int C8 = C >> 3, b = plane / C8, c8 = plane % C8;
     __shared__ bn_u32x4 tr[BN_TR_SLOTS];
@@ -578,7 +608,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_split_kernel(const floa
             v[e][k] = (float)((double)sc * (dy - c1 - (((double)zz[e] - (double)mean) * (double)invstd) * c2));
         }
     }
-    bn_store_slots_block(tr, dzs + (int64_t)b * dzs_bs, c8, H, W, blk * 1024, HW, v, s);
+    bn_store_slots_block(tr, dzs + (int64_t)b * dzs_bs, c8, H, W, blk * 1024, HW, v, s, np);
 }
 
 // |dz| <= |scale_c| (max |da| + |c1| + |c2| max |xhat|) with |xhat| <= sqrt(N - 1) for a channel of N values: the maximum over the
@@ -950,8 +980,9 @@ int onet_bn_bwd_bound(const float* save, const float* coef, const void* da_amax,
     return check_launch("bn_bwd_bound_kernel");
 }
 
-int onet_bn_relu_apply_split(const float* z, int64_t z_bs, void* xs, int64_t xs_bs, float* a, int64_t a_bs, const float* save, int B, int C,
-                             int H, int W, void* stream) {
+int onet_bn_relu_apply_split(const float* z, int64_t z_bs, void* xs, int64_t xs_bs, float* a, int64_t a_bs, const float* save, int nparts,
+                             int B, int C, int H, int W, void* stream) {
+    ONET_REQUIRE(nparts == 1 || nparts == 2, "bn_relu_apply_split: nparts must be 2 (fp16 hi | mid) or 1 (plain bf16)");
     ONET_REQUIRE(z && xs && save && B > 0 && C > 0 && (C % 8) == 0 && H > 0 && W > 0 && (W % 4) == 0, "bn_relu_apply_split: bad args (C %% 8 == 0, W %% 4 == 0)");
     ONET_REQUIRE((reinterpret_cast<uintptr_t>(xs) & 15) == 0 && (xs_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(z) & 15) == 0 && (z_bs & 3) == 0 &&
                  (reinterpret_cast<uintptr_t>(a) & 15) == 0 && (a_bs & 3) == 0, "bn_relu_apply_split: 16-byte aligned rows and slots required");
@@ -959,12 +990,13 @@ int onet_bn_relu_apply_split(const float* z, int64_t z_bs, void* xs, int64_t xs_
     const int64_t blocks = (int64_t)B * (C / 8) * bpp;
     ONET_REQUIRE(blocks < (1ll << 31) && (int64_t)H * W < (1 << 24), "bn_relu_apply_split: grid too large");
     hipLaunchKernelGGL(bn_relu_apply_split_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), z, z_bs, (unsigned*)xs, xs_bs, a,
-                       a_bs, save, C, H, W, bpp);
+                       a_bs, save, C, H, W, bpp, nparts);
     return check_launch("bn_relu_apply_split_kernel");
 }
 
 int onet_bn_relu_apply_pool_split(const float* z, int64_t z_bs, void* xs, int64_t xs_bs, float* a, int64_t a_bs, void* ys, int64_t ys_bs,
-                                  float* y, int64_t y_bs, const float* save, int B, int C, int H, int W, void* stream) {
+                                  float* y, int64_t y_bs, const float* save, int nparts, int B, int C, int H, int W, void* stream) {
+    ONET_REQUIRE(nparts == 1 || nparts == 2, "bn_relu_apply_pool_split: nparts must be 2 (fp16 hi | mid) or 1 (plain bf16)");
     ONET_REQUIRE(z && (xs || a) && (ys || y) && save && B > 0 && C > 0 && (C % 8) == 0 && H > 0 && W > 0, "bn_relu_apply_pool_split: bad args");
     auto al = [](const void* p, uintptr_t m) { return (reinterpret_cast<uintptr_t>(p) & m) == 0; };
     if ((H & 1) || (W & 3) || (z_bs & 3) || (a_bs & 3) || (xs_bs & 3) || (ys_bs & 3) || (y_bs & 1) || !al(z, 15) || !al(a, 15) || !al(xs, 15) ||
@@ -974,20 +1006,22 @@ int onet_bn_relu_apply_pool_split(const float* z, int64_t z_bs, void* xs, int64_
     const int64_t blocks = (int64_t)B * (C / 8) * bpp;
     ONET_REQUIRE(blocks < (1ll << 31) && (int64_t)H * W < (1 << 24), "bn_relu_apply_pool_split: grid too large");
     hipLaunchKernelGGL(bn_relu_apply_pool_split_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), z, z_bs, (unsigned*)xs, xs_bs,
-                       a, a_bs, (unsigned*)ys, ys_bs, y, y_bs, save, C, H, W, bpp);
+                       a, a_bs, (unsigned*)ys, ys_bs, y, y_bs, save, C, H, W, bpp, nparts);
     return check_launch("bn_relu_apply_pool_split_kernel");
 }
 
 int onet_bn_relu_bwd_apply_split(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save, const float* coef,
-                                 void* dzs, int64_t dzs_bs, const void* dz_amax, int B, int C, int H, int W, void* stream) {
-    ONET_REQUIRE(da && z && save && dzs && dz_amax && B > 0 && C > 0 && (C % 8) == 0 && H > 0 && W > 0 && (W % 4) == 0, "bn_relu_bwd_apply_split: bad args");
+                                 void* dzs, int64_t dzs_bs, const void* dz_amax, int nparts, int B, int C, int H, int W, void* stream) {
+    ONET_REQUIRE(nparts == 1 || nparts == 2, "bn_relu_bwd_apply_split: nparts must be 2 (fp16 hi | mid) or 1 (plain bf16)");
+    ONET_REQUIRE(da && z && save && dzs && (dz_amax || nparts == 1) && B > 0 && C > 0 && (C % 8) == 0 && H > 0 && W > 0 && (W % 4) == 0,
+                 "bn_relu_bwd_apply_split: bad args");
     ONET_REQUIRE((reinterpret_cast<uintptr_t>(dzs) & 15) == 0 && (dzs_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(z) & 15) == 0 && (z_bs & 3) == 0 &&
                  (reinterpret_cast<uintptr_t>(da) & 15) == 0 && (da_bs & 3) == 0, "bn_relu_bwd_apply_split: 16-byte aligned rows and slots required");
     const int bpp = cdiv((int64_t)H * W, 1024);
     const int64_t blocks = (int64_t)B * (C / 8) * bpp;
     ONET_REQUIRE(blocks < (1ll << 31) && (int64_t)H * W < (1 << 24), "bn_relu_bwd_apply_split: grid too large");
     hipLaunchKernelGGL(bn_relu_bwd_apply_split_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), da, da_bs, z, z_bs, save, coef,
-                       (unsigned*)dzs, dzs_bs, (const unsigned*)dz_amax, C, H, W, bpp);
+                       (unsigned*)dzs, dzs_bs, (const unsigned*)dz_amax, C, H, W, bpp, nparts);
     return check_launch("bn_relu_bwd_apply_split_kernel");
 }
 

@@ -78,14 +78,18 @@ __global__ void absmax_slots_kernel(const float* __restrict__ v, int64_t n, unsi
 // f16: fp16 parts of s w with s = 2^k chosen from the tensor's largest magnitude (wamax slots; amax lands in [2^13, 2^14): the mid
 // parts stay normal numbers down to 2^-27 of the largest weight, and no weight overflows whatever a loaded checkpoint holds);
 // the two floats (s, 1 / s) are stored BEHIND the pack (element offset 2 K 9 N) for the convolution to undo s on its accumulators.
+// f16 == 2: ONE part, bf16(w) (BASELINE configs[2]: plain bf16 operands), same slot order -- [K/16][9][2][N][8], i.e. two consecutive
+// 16-channel chunks look exactly like the (hi | mid) pair of the split packs, which is how the 32-channel chunks of the plain-bf16
+// kernels read them.
 __global__ void pack3x3_split_kernel(const float* __restrict__ w, __bf16* __restrict__ wq, int Cout, int Cin, int which, int f16,
                                      const unsigned* __restrict__ wamax) {
     const int K = which == 0 ? Cin : ((Cout + 15) / 16) * 16, N = which == 0 ? Cout : Cin;
     const int64_t n = (int64_t)K * 9 * N;                            // elements of ONE part
+    const int nparts = f16 == 2 ? 1 : 2;
     float winv = 1.f;
-    const float wscale = f16 ? amax_scale(amax_read(wamax), true, winv) : 1.f;
+    const float wscale = f16 == 1 ? amax_scale(amax_read(wamax), true, winv) : 1.f;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        float* meta = reinterpret_cast<float*>(wq + 2 * n);
+        float* meta = reinterpret_cast<float*>(wq + nparts * n);
         meta[0] = wscale;
         meta[1] = winv;
     }
@@ -103,7 +107,9 @@ __global__ void pack3x3_split_kernel(const float* __restrict__ w, __bf16* __rest
         else if (k < Cout) v = w[((int64_t)k * Cin + nn) * 9 + (8 - t)];
         const int64_t per_chunk_part = (int64_t)9 * 2 * N * 8;
         const int64_t within = i - (int64_t)kg * per_chunk_part;     // [tap][half][n][8] inside the chunk
-        if (f16) {                                                   // fp16 parts of 2^8 w (forward pack only)
+        if (f16 == 2) {
+            wq[(int64_t)kg * per_chunk_part + within] = (__bf16)v;
+        } else if (f16) {                                            // fp16 parts of 2^k w
             _Float16* wh = reinterpret_cast<_Float16*>(wq);
             const float vs = v * wscale;
             const _Float16 hi = (_Float16)vs;
@@ -578,6 +584,7 @@ __device__ __forceinline__ void sp_dma16(i32x4s rsrc, unsigned lds_base, unsigne
 }
 
 // fp32 NCHW -> the slot layout above (tests, tools, and producers that have no fused variant yet)
+// f16 == 2: plain bf16, one part: xs [B][C/8][H][W][8]
 __global__ void split_pack_act_kernel(const float* __restrict__ x, int64_t x_bs, unsigned* __restrict__ xs, int64_t xs_bs, int B, int C8,
                                       int H, int W, int f16, float scale) {
     const int64_t n = (int64_t)B * C8 * H * W;
@@ -593,10 +600,14 @@ __global__ void split_pack_act_kernel(const float* __restrict__ x, int64_t x_bs,
         for (int c = 0; c < 4; ++c) {
             const float va = src[(int64_t)(2 * c) * H * W] * scale, vb = src[(int64_t)(2 * c + 1) * H * W] * scale;
             unsigned h, m;
-            if (f16) split2h(va, vb, h, m);
+            if (f16 == 1) split2h(va, vb, h, m);
             else split2(va, vb, h, m);
             hi[c] = h;
             mid[c] = m;
+        }
+        if (f16 == 2) {
+            reinterpret_cast<u32x4s*>(xs + (int64_t)b * xs_bs)[((int64_t)c8 * H + y) * W + xx] = hi;
+            continue;
         }
         u32x4s* dst = reinterpret_cast<u32x4s*>(xs + (int64_t)b * xs_bs) + (((int64_t)c8 * H + y) * 2) * W + xx;
         dst[0] = hi;
@@ -619,8 +630,12 @@ struct SpPreArgs {
 #ifndef SP_PRE_LAST_TAP
 #define SP_PRE_LAST_TAP 4   // the next chunk's DMA pieces go out during taps 0 .. SP_PRE_LAST_TAP
 #endif
-template <bool ST, bool F16>
+// PM: 0 = bf16 (hi | mid) parts, 1 = fp16 (hi | mid) parts -- three MFMAs per term on 16-channel chunks; 2 = PLAIN bf16 operands
+// (BASELINE configs[2]'s bf16 MFMA conv path: xs [B][C/8][H][W][8] bf16, one part): the same LDS image and DMA schedule with the
+// "part" index standing for the second 16 channels of a 32-channel chunk, two MFMAs per term (one per 16 channels).
+template <bool ST, int PM>
 __global__ __launch_bounds__(512, 2) void conv3x3_split_pre_kernel(SpPreArgs a) {
+    constexpr bool F16 = PM == 1;
     using C = SpCfg;
     constexpr int NT = C::NT, IN_COLS = C::IN_COLS, NWI = C::NWI, CO_T = C::CO_T, NPIXP = C::NPIXP, NB = C::NB;
     constexpr int BUF = C::BUF_SLOTS, W_PART = C::W_PART, IN_PART = C::IN_PART, ROWS = C::ROWS, TW = C::TW;
@@ -643,9 +658,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_pre_kernel(SpPreArgs a) 
     const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kh = lane >> 5;
     const int HW = a.H * a.W;
-    const int nchunks = a.Cin >> 4;
+    const int nchunks = PM == 2 ? a.Cin >> 5 : a.Cin >> 4;
 
-    const i32x4s wr = sp_rsrc4(a.wq, (int64_t)a.Cin * 2 * 9 * a.Cout * 2);
+    const i32x4s wr = sp_rsrc4(a.wq, (int64_t)a.Cin * (PM == 2 ? 1 : 2) * 9 * a.Cout * 2);
     float xs_inv = 1.f;
     (void)amax_scale(amax_read(a.x_slots), a.x_always != 0, xs_inv);
     const float acc_scale = xs_inv * (F16 ? reinterpret_cast<const float*>(a.wq + (int64_t)a.Cin * 2 * 9 * a.Cout)[1] : 1.f);
@@ -668,15 +683,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_pre_kernel(SpPreArgs a) 
         const int ty = v % a.tilesY;
         const int b = v / a.tilesY;
         const int y0 = ty * ROWS, x0 = tx * TW;
-        xr = sp_rsrc4(reinterpret_cast<const unsigned*>(a.xs) + (int64_t)b * a.xs_bs, (int64_t)a.Cin * HW * 4);
+        xr = sp_rsrc4(reinterpret_cast<const unsigned*>(a.xs) + (int64_t)b * a.xs_bs, (int64_t)a.Cin * HW * (PM == 2 ? 2 : 4));
 #pragma unroll
         for (int k = 0; k < NII; ++k) {
             const int i = (wn + 8 * k) * 64 + lane;
-            const int ph = i / NPIXP, pix = i % NPIXP;                 // ph = part * 2 + half
+            const int ph = i / NPIXP, pix = i % NPIXP;                 // ph = part * 2 + half (PM 2: the chunk's channel group 0 .. 3)
             const int r = pix / IN_COLS, c = pix % IN_COLS;
             const int yy = y0 - 1 + r, xx = x0 - 1 + c;
             const bool ok = live && pix < C::NPIX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-            in_off[k] = ok ? (unsigned)(((((ph & 1) * a.H + yy) * 2 + (ph >> 1)) * a.W + xx) * 16) : OOB_S;
+            in_off[k] = !ok ? OOB_S : PM == 2 ? (unsigned)(((ph * a.H + yy) * a.W + xx) * 16)
+                                              : (unsigned)(((((ph & 1) * a.H + yy) * 2 + (ph >> 1)) * a.W + xx) * 16);
         }
 #pragma unroll
         for (int k = 0; k < NWI; ++k) {
@@ -778,7 +794,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_pre_kernel(SpPreArgs a) 
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
-                        if constexpr (F16) {
+                        if constexpr (PM == 2) {         // plain bf16: channels 0-15 of the chunk, then 16-31
+                            const bf16x8 a0 = __builtin_bit_cast(bf16x8, Aq[idx & 1][m][0]), a1 = __builtin_bit_cast(bf16x8, Aq[idx & 1][m][1]);
+                            const bf16x8 b0 = __builtin_bit_cast(bf16x8, Bq[kx & 1][n + ky][0]), b1 = __builtin_bit_cast(bf16x8, Bq[kx & 1][n + ky][1]);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[m][n], 0, 0, 0);
+                        } else if constexpr (F16) {
                             const f16x8 ah = __builtin_bit_cast(f16x8, Aq[idx & 1][m][0]), am = __builtin_bit_cast(f16x8, Aq[idx & 1][m][1]);
                             const f16x8 bh = __builtin_bit_cast(f16x8, Bq[kx & 1][n + ky][0]), bm = __builtin_bit_cast(f16x8, Bq[kx & 1][n + ky][1]);
                             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, bh, acc[m][n], 0, 0, 0);
@@ -878,7 +899,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_pre_kernel(SpPreArgs a) 
     }
 }
 
-template <bool ST, bool F16>
+template <bool ST, int PM>
 int launch_split_pre(SpPreArgs a, hipStream_t st) {
     using C = SpCfg;
     const int LDS_BYTES = C::LDS_BYTES + (ST ? C::NW * 64 * 2 * 4 : 0);
@@ -887,7 +908,7 @@ int launch_split_pre(SpPreArgs a, hipStream_t st) {
     a.coTiles = cdiv(a.Cout, C::CO_T);
     const int64_t tiles = (int64_t)a.B * a.tilesX * a.tilesY * a.coTiles;
     ONET_REQUIRE(tiles > 0 && tiles < (1ll << 31), "conv3x3_split_pre: tile count %lld out of range", (long long)tiles);
-    auto kern = conv3x3_split_pre_kernel<ST, F16>;
+    auto kern = conv3x3_split_pre_kernel<ST, PM>;
     static PerDeviceOnce attr_once;
     if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -1308,12 +1329,17 @@ __device__ __forceinline__ u32x4s swp_frag(unsigned addr) {      // 8 consecutiv
     return u32x4s{(unsigned)a, (unsigned)(a >> 32), (unsigned)b, (unsigned)(b >> 32)};
 }
 
-template <int G, int COT, bool F16>
+// PM: 0 bf16 (hi | mid), 1 fp16 (hi | mid) -- three MFMAs per term; 2: PLAIN bf16 operands, one part (BASELINE configs[2]), one MFMA
+template <int G, int COT, int PM>
 __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_pre_kernel(SwPreArgs a) {
+    constexpr bool F16 = PM == 1;
+    constexpr int NP = PM == 2 ? 1 : 2;                        // parts per operand
     constexpr int PXP = SWP_PXP;
     constexpr int XS = 8, DS = COT / 8;                        // channel groups per image
-    constexpr int X_PART = XS * PXP, X_ROW = 2 * X_PART;       // slots
-    constexpr int DZ_PART = DS * PXP, DZ_BUF = 2 * DZ_PART;
+    // (row images padded to whole 64-slot DMA pieces: the lanes of a piece beyond the image write zeros, which must not land in the
+    // next ring slot / buffer)
+    constexpr int X_PART = XS * PXP, X_ROW = (NP * X_PART + 63) / 64 * 64;      // slots
+    constexpr int DZ_PART = DS * PXP, DZ_BUF = (NP * DZ_PART + 63) / 64 * 64;
     constexpr int NXI = (X_ROW + 511) / 512, NDI = (DZ_BUF + 511) / 512;      // DMA rounds per wave (64 slots each, 8 waves)
     constexpr int NKS = COT == 64 ? 2 : 4;                     // k-steps (16 pixels) per wave and unit
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
@@ -1353,42 +1379,42 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_pre_kernel(SwPreAr
     unsigned x_off[NXI], d_off[NDI];
     auto setup_strip = [&](int b, int x0) __attribute__((always_inline)) {
         if (G == 1) {
-            xr = sp_rsrc4(reinterpret_cast<const unsigned*>(a.xs) + (int64_t)b * a.xs_bs, (int64_t)a.Cin * HW * 4);
-            dr = sp_rsrc4(reinterpret_cast<const unsigned*>(a.dzs) + (int64_t)b * a.dzs_bs, (int64_t)a.Cout * HW * 4);
+            xr = sp_rsrc4(reinterpret_cast<const unsigned*>(a.xs) + (int64_t)b * a.xs_bs, (int64_t)a.Cin * HW * 2 * NP);
+            dr = sp_rsrc4(reinterpret_cast<const unsigned*>(a.dzs) + (int64_t)b * a.dzs_bs, (int64_t)a.Cout * HW * 2 * NP);
         } else {
-            xr = sp_rsrc4(a.xs, ((int64_t)(a.B - 1) * a.xs_bs + (int64_t)a.Cin * HW) * 4);
-            dr = sp_rsrc4(a.dzs, ((int64_t)(a.B - 1) * a.dzs_bs + (int64_t)a.Cout * HW) * 4);
+            xr = sp_rsrc4(a.xs, (int64_t)(a.B - 1) * a.xs_bs * 4 + (int64_t)a.Cin * HW * 2 * NP);
+            dr = sp_rsrc4(a.dzs, (int64_t)(a.B - 1) * a.dzs_bs * 4 + (int64_t)a.Cout * HW * 2 * NP);
         }
 #pragma unroll
         for (int k = 0; k < NXI; ++k) {
             const int i = (wid + 8 * k) * 64 + lane;
             const int part = i / X_PART, s = (i % X_PART) / PXP, pi = i % PXP;
             const int img = G == 1 ? 0 : pi / (a.W + 2), xx = G == 1 ? x0 - 1 + pi : pi % (a.W + 2) - 1;
-            const bool ok = i < X_ROW && pi < (G == 1 ? 66 : G * (a.W + 2)) && xx >= 0 && xx < a.W && ci0 + 8 * s < a.Cin;
+            const bool ok = i < NP * X_PART && pi < (G == 1 ? 66 : G * (a.W + 2)) && xx >= 0 && xx < a.W && ci0 + 8 * s < a.Cin;
             const int64_t img_off = G == 1 ? 0 : (int64_t)(b * G + img) * a.xs_bs * 4;
-            x_off[k] = ok ? (unsigned)(img_off + ((int64_t)((ci0 / 8 + s) * a.H) * 2 + part) * a.W * 16 + xx * 16) : OOB_S;
+            x_off[k] = ok ? (unsigned)(img_off + ((int64_t)((ci0 / 8 + s) * a.H) * NP + part) * a.W * 16 + xx * 16) : OOB_S;
         }
 #pragma unroll
         for (int k = 0; k < NDI; ++k) {
             const int i = (wid + 8 * k) * 64 + lane;
             const int part = i / DZ_PART, s = (i % DZ_PART) / PXP, pi = i % PXP;
             const int img = G == 1 ? 0 : pi / a.W, xx = G == 1 ? x0 + pi : pi % a.W;
-            const bool ok = i < DZ_BUF && pi < 64 && xx < a.W && co0 + 8 * s < a.Cout;
+            const bool ok = i < NP * DZ_PART && pi < 64 && xx < a.W && co0 + 8 * s < a.Cout;
             const int64_t img_off = G == 1 ? 0 : (int64_t)(b * G + img) * a.dzs_bs * 4;
-            d_off[k] = ok ? (unsigned)(img_off + ((int64_t)((co0 / 8 + s) * a.H) * 2 + part) * a.W * 16 + xx * 16) : OOB_S;
+            d_off[k] = ok ? (unsigned)(img_off + ((int64_t)((co0 / 8 + s) * a.H) * NP + part) * a.W * 16 + xx * 16) : OOB_S;
         }
     };
     // row y of the strip into ring slot / dz buffer; rows outside the image are zeros (every lane out of range)
     auto dma_x = [&](int y, int k) __attribute__((always_inline)) {
         if ((wid + 8 * k) * 64 < X_ROW) {
             const bool ok = y >= 0 && y < a.H;
-            sp_dma16(xr, x_base + (unsigned)(((y & 3) * X_ROW + (wid + 8 * k) * 64) * 16), ok ? x_off[k] : OOB_S, ok ? (unsigned)(y * 2 * a.W * 16) : 0u);
+            sp_dma16(xr, x_base + (unsigned)(((y & 3) * X_ROW + (wid + 8 * k) * 64) * 16), ok ? x_off[k] : OOB_S, ok ? (unsigned)(y * NP * a.W * 16) : 0u);
         }
     };
     auto dma_dz = [&](int y, int k) __attribute__((always_inline)) {
         if ((wid + 8 * k) * 64 < DZ_BUF) {
             const bool ok = y >= 0 && y < a.H;
-            sp_dma16(dr, dz_base + (unsigned)(((y & 1) * DZ_BUF + (wid + 8 * k) * 64) * 16), ok ? d_off[k] : OOB_S, ok ? (unsigned)(y * 2 * a.W * 16) : 0u);
+            sp_dma16(dr, dz_base + (unsigned)(((y & 1) * DZ_BUF + (wid + 8 * k) * 64) * 16), ok ? d_off[k] : OOB_S, ok ? (unsigned)(y * NP * a.W * 16) : 0u);
         }
     };
 
@@ -1433,7 +1459,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_pre_kernel(SwPreAr
                         else if (pc < NP) dma_x(y + 2, pc - NDI);
                     }
                 }
-                const u32x4s Ah = swp_frag(ab + dpx * 16), Am = swp_frag(ab + (DZ_PART + dpx) * 16);
+                const u32x4s Ah = swp_frag(ab + dpx * 16), Am = NP == 2 ? swp_frag(ab + (DZ_PART + dpx) * 16) : Ah;
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
 #if SWP_SHARE_B
@@ -1442,7 +1468,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_pre_kernel(SwPreAr
                     // pairs (v_alignbit) -- instead of two reads per tap and part (40 -> 22 LDS reads per 27 MFMAs)
                     u32x4s Bs[2][3];
 #pragma unroll
-                    for (int pt = 0; pt < 2; ++pt) {
+                    for (int pt = 0; pt < NP; ++pt) {
                         const unsigned ba = bb[ky] + (pt * X_PART + xpx) * 16;
                         const u32x4s lo = swp_frag(ba);                                       // pixels 0 .. 7 of the lane's window
                         const s16x4w r2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4w*)(uintptr_t)(ba + 128));
@@ -1456,12 +1482,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_pre_kernel(SwPreAr
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
 #if SWP_SHARE_B
-                        const u32x4s Bh = Bs[0][kx], Bm = Bs[1][kx];
+                        const u32x4s Bh = Bs[0][kx], Bm = NP == 2 ? Bs[1][kx] : Bs[0][kx];
 #else
-                        const u32x4s Bh = swp_frag(bb[ky] + (xpx + kx) * 16), Bm = swp_frag(bb[ky] + (X_PART + xpx + kx) * 16);
+                        const u32x4s Bh = swp_frag(bb[ky] + (xpx + kx) * 16), Bm = NP == 2 ? swp_frag(bb[ky] + (X_PART + xpx + kx) * 16) : Bh;
 #endif
                         const int t = ky * 3 + kx;
-                        if constexpr (F16) {
+                        if constexpr (PM == 2) {
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Ah), __builtin_bit_cast(bf16x8, Bh), acc[t], 0, 0, 0);
+                        } else if constexpr (F16) {
                             const f16x8 ah = __builtin_bit_cast(f16x8, Ah), am = __builtin_bit_cast(f16x8, Am);
                             const f16x8 bh = __builtin_bit_cast(f16x8, Bh), bm = __builtin_bit_cast(f16x8, Bm);
                             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, bh, acc[t], 0, 0, 0);
@@ -1603,7 +1631,8 @@ int onet_conv3x3_split_wgrad_pre(const void* xs, int64_t xs_bs, const void* x_am
                  "conv3x3_split_wgrad_pre: needs Cin, Cout %% 8 == 0 and W >= 64, or W = 32 with an even batch");
     ONET_REQUIRE((xs_bs & 3) == 0 && (dzs_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(xs) & 15) == 0 && (reinterpret_cast<uintptr_t>(dzs) & 15) == 0,
                  "conv3x3_split_wgrad_pre: 16-byte aligned slots required");
-    ONET_REQUIRE(xs_bs >= (int64_t)Cin * H * W && dzs_bs >= (int64_t)Cout * H * W, "conv3x3_split_wgrad_pre: batch stride too small");
+    ONET_REQUIRE(xs_bs >= (int64_t)Cin * H * W / (f16 == 2 ? 2 : 1) && dzs_bs >= (int64_t)Cout * H * W / (f16 == 2 ? 2 : 1),
+                 "conv3x3_split_wgrad_pre: batch stride too small");
     ONET_REQUIRE((int64_t)std::max(Cin, Cout) * H * W * 4 < (1ll << 31), "conv3x3_split_wgrad_pre: image exceeds the 2 GiB buffer-resource range");
     const int G = split_wgrad_group(W);
     ONET_REQUIRE(G == 1 || (((int64_t)(B - 1) * xs_bs + (int64_t)Cin * H * W) * 4 < (1ll << 31) &&
@@ -1618,7 +1647,8 @@ int onet_conv3x3_split_wgrad_pre(const void* xs, int64_t xs_bs, const void* x_am
     const int64_t blocks = (int64_t)a.splitK * a.ciTiles * a.coTiles;
     const dim3 grid((unsigned)blocks), blk(512);
     hipStream_t st = as_stream(stream);
-    const int lds = (4 * 2 * 8 * SWP_PXP + 2 * 2 * (COT / 8) * SWP_PXP) * 16;
+    const int np = f16 == 2 ? 1 : 2;
+    const int lds = (4 * ((np * 8 * SWP_PXP + 63) / 64 * 64) + 2 * ((np * (COT / 8) * SWP_PXP + 63) / 64 * 64)) * 16;
 #define ONET_SWP_LAUNCH(G_, COT_, F_)                                                                              \
     do {                                                                                                           \
         auto kern = conv3x3_split_wgrad_pre_kernel<G_, COT_, F_>;                                                  \
@@ -1626,7 +1656,7 @@ int onet_conv3x3_split_wgrad_pre(const void* xs, int64_t xs_bs, const void* x_am
         if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
         hipLaunchKernelGGL(kern, grid, blk, lds, st, a);                                                           \
     } while (0)
-#define ONET_SWP_F(G_, COT_) do { if (f16) ONET_SWP_LAUNCH(G_, COT_, true); else ONET_SWP_LAUNCH(G_, COT_, false); } while (0)
+#define ONET_SWP_F(G_, COT_) do { if (f16 == 2) ONET_SWP_LAUNCH(G_, COT_, 2); else if (f16) ONET_SWP_LAUNCH(G_, COT_, 1); else ONET_SWP_LAUNCH(G_, COT_, 0); } while (0)
     if (COT == 128) {
         if (G == 1) ONET_SWP_F(1, 128);
         else ONET_SWP_F(2, 128);
@@ -1642,8 +1672,8 @@ int onet_conv3x3_split_wgrad_pre(const void* xs, int64_t xs_bs, const void* x_am
 int onet_conv3x3_split_pack_weights(const float* w, void* wq_fwd, void* wq_dgrad, void* amax_ws, int Cout, int Cin, int fwd_f16,
                                     int dgrad_f16, void* stream) {
     ONET_REQUIRE(w && (wq_fwd || wq_dgrad), "conv3x3_split_pack_weights: null pointer");
-    ONET_REQUIRE(amax_ws || !(fwd_f16 || dgrad_f16), "conv3x3_split_pack_weights: the fp16 packs need the 8 KB magnitude workspace");
-    if (fwd_f16 || dgrad_f16) {
+    ONET_REQUIRE(amax_ws || !(fwd_f16 == 1 || dgrad_f16 == 1), "conv3x3_split_pack_weights: the fp16 packs need the 8 KB magnitude workspace");
+    if (fwd_f16 == 1 || dgrad_f16 == 1) {
         (void)hipMemsetAsync(amax_ws, 0, AMAX_SLOTS * AMAX_STRIDE * sizeof(unsigned), as_stream(stream));
         const int64_t nw = (int64_t)Cout * Cin * 9;
         hipLaunchKernelGGL(absmax_slots_kernel, dim3((unsigned)std::min<int64_t>((nw + 1023) / 1024, 1024)), dim3(256), 0, as_stream(stream), w,
@@ -1656,13 +1686,13 @@ int onet_conv3x3_split_pack_weights(const float* w, void* wq_fwd, void* wq_dgrad
     const int64_t n = (int64_t)std::max(Cin, ((Cout + 15) / 16) * 16) * 9 * std::max(Cin, Cout);
     const int blocks = (int)std::min<int64_t>((n + 255) / 256, 8192);
     if (wq_fwd) {
-        hipLaunchKernelGGL(pack3x3_split_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, (__bf16*)wq_fwd, Cout, Cin, 0, fwd_f16 != 0,
+        hipLaunchKernelGGL(pack3x3_split_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, (__bf16*)wq_fwd, Cout, Cin, 0, fwd_f16,
                            (const unsigned*)amax_ws);
         int rc = check_launch("pack3x3_split_kernel");
         if (rc) return rc;
     }
     if (wq_dgrad) hipLaunchKernelGGL(pack3x3_split_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, (__bf16*)wq_dgrad, Cout, Cin, 1,
-                                     dgrad_f16 != 0, (const unsigned*)amax_ws);
+                                     dgrad_f16, (const unsigned*)amax_ws);
     return check_launch("pack3x3_split_kernel");
 }
 
@@ -1712,15 +1742,16 @@ int onet_conv3x3_split_fwd_pre(const void* xs, int64_t xs_bs, const void* x_amax
                                int64_t z_bs, float* part, int B, int Cin, int Cout, int H, int W, void* stream) {
     ONET_REQUIRE(xs && wq && z, "conv3x3_split_fwd_pre: null pointer");
     ONET_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 16, "conv3x3_split_fwd_pre: bad shape (maps wider than 16 pixels)");
-    ONET_REQUIRE((Cin % 16) == 0, "conv3x3_split_fwd_pre: Cin must be a multiple of 16");
+    ONET_REQUIRE((Cin % (wq_f16 == 2 ? 32 : 16)) == 0, "conv3x3_split_fwd_pre: Cin must be a multiple of 16 (32 for plain bf16 operands)");
     ONET_REQUIRE((xs_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(xs) & 15) == 0, "conv3x3_split_fwd_pre: 16-byte aligned slots required");
-    ONET_REQUIRE(xs_bs >= (int64_t)Cin * H * W && z_bs >= (int64_t)Cout * H * W, "conv3x3_split_fwd_pre: batch stride too small");
+    ONET_REQUIRE(xs_bs >= (int64_t)Cin * H * W / (wq_f16 == 2 ? 2 : 1) && z_bs >= (int64_t)Cout * H * W, "conv3x3_split_fwd_pre: batch stride too small");
     ONET_REQUIRE((int64_t)(Cin + 32) * H * W * 4 < (1ll << 31) && (int64_t)(Cin + 32) * 2 * 9 * Cout * 2 < (1ll << 31),
                  "conv3x3_split_fwd_pre: operand exceeds the 2 GiB buffer-resource range");
     SpPreArgs a{xs, xs_bs, (const __bf16*)wq, z, z_bs, B, Cin, Cout, H, W, 0, 0, 0, part, (const unsigned*)x_amax, scale_always};
     if (part) ONET_REQUIRE(split_nparts(B, H, W) > 0, "conv3x3_split_fwd_pre: statistics need a map made of full 16 x 32 tiles");
-    if (wq_f16) return part ? launch_split_pre<true, true>(a, as_stream(stream)) : launch_split_pre<false, true>(a, as_stream(stream));
-    return part ? launch_split_pre<true, false>(a, as_stream(stream)) : launch_split_pre<false, false>(a, as_stream(stream));
+    if (wq_f16 == 2) return part ? launch_split_pre<true, 2>(a, as_stream(stream)) : launch_split_pre<false, 2>(a, as_stream(stream));
+    if (wq_f16) return part ? launch_split_pre<true, 1>(a, as_stream(stream)) : launch_split_pre<false, 1>(a, as_stream(stream));
+    return part ? launch_split_pre<true, 0>(a, as_stream(stream)) : launch_split_pre<false, 0>(a, as_stream(stream));
 }
 
 int onet_conv3x3_split_nparts(int B, int H, int W) { return split_nparts(B, H, W); }

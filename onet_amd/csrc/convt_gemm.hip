@@ -345,8 +345,10 @@ __global__ __launch_bounds__(256, 2) void convt_gemm_kernel(GArgs g) {
                             px[dj][2 * gq + 1] = __builtin_bit_cast(float, odd);        // odd channel
                         }
                     }
+                    // out16_split == 2: plain bf16, one part (BASELINE configs[2]): [Ct/8][Ho][Wo][8]
+                    const int np = g.out16_split == 2 ? 1 : 2;
                     u32x4g* dst = reinterpret_cast<u32x4g*>(reinterpret_cast<unsigned*>(g.out16) + (int64_t)b * g.out16_bs) +
-                                  ((int64_t)(c8 * (2 * g.h) + 2 * y + kh) * 2) * g.Wo + 2 * x;
+                                  ((int64_t)(c8 * (2 * g.h) + 2 * y + kh) * np) * g.Wo + 2 * x;
 #pragma unroll
                     for (int dj = 0; dj < 2; ++dj) {
                         u32x4g hi, mid;
@@ -354,11 +356,11 @@ __global__ __launch_bounds__(256, 2) void convt_gemm_kernel(GArgs g) {
                         for (int k = 0; k < 4; ++k) {
                             unsigned hh, mm;
                             split2h_s(px[dj][2 * k], px[dj][2 * k + 1], 1.f, hh, mm);
-                            hi[k] = hh;
+                            hi[k] = np == 1 ? g_pack(px[dj][2 * k], px[dj][2 * k + 1]) : hh;
                             mid[k] = mm;
                         }
                         dst[dj] = hi;
-                        dst[g.Wo + dj] = mid;
+                        if (np == 2) dst[g.Wo + dj] = mid;
                     }
                 }
             }

@@ -264,7 +264,8 @@ class ConvBNReLUFn(torch.autograd.Function):
         dzP, dz_slots, dgamma, dbeta = ops.bn_relu_bwd_split(da, z, save_all, ctx.training, need_affine_grads=(need_g or need_b),
                                                              affine_out=aff, rec4=rec4, da_amax=da_amax)
         dw = ops.conv3x3_split_wgrad_pre(xP, dzP, ctx.wshape, out=ops.grad_slot_if_free(pw), dz_slots=dz_slots) if need_w else None
-        dx = ops.conv3x3_split_pre(dzP, ctx.packed.get_pack("split")[1], ctx.wshape[1], slots=dz_slots, always=True) if need_x else None
+        dpack = ctx.packed.get_pack("split" if dzP.shape[3] == 2 else "plain16")[1]
+        dx = ops.conv3x3_split_pre(dzP, dpack, ctx.wshape[1], slots=dz_slots, always=dz_slots is not None) if need_x else None
         return (dx, dw, (dgamma if need_g else None), (dbeta if need_b else None)) + nones
 
     @staticmethod
@@ -442,7 +443,7 @@ class SkipPoolFn(torch.autograd.Function):
             return (sum(gs[1:], gs[0]) if gs else None), None, None, None
         lk = ctx.link
         if lk is not None and "z" in lk:
-            am = ops.new_amax(g_pool.device) if getattr(ctx, "pre", False) else None
+            am = ops.new_amax(g_pool.device) if (getattr(ctx, "pre", False) and ops.p16_parts() == 2) else None
             dx, part2 = ops.maxpool2_bwd(x, g_pool, add=g_skip, add2=g_ret, bn=(lk.pop("z"), lk.pop("save")), dx_amax=am)
             if part2 is not None:
                 lk["da"], lk["rec4"] = dx, part2
@@ -487,7 +488,7 @@ class UpConvTCatFn(torch.autograd.Function):
             if not ops.convT2x2_fwd_p(x1, wp_fused, bias, catP[:, C2 // 8:], Ct, pt, pl):
                 up = torch.empty((B, Ct, Ho, Wo), dtype=torch.float32, device=x1.device)
                 ops.convT2x2_fwd(x1, wp_fused, bias, up, Ct, pt, pl)
-                ops.split_pack_act(up, f16=True, out=catP[:, C2 // 8:])
+                ops.split_pack_act(up, out=catP[:, C2 // 8:])
             ctx.save_for_backward(x1, wp_dgrad)
             ctx.meta = (C2, Ct, h, w, pt, pl, tuple(weight.shape), bias is not None)
             ctx.params = (weight, bias)

@@ -121,8 +121,16 @@ def sync_bn():
 def presplit():
     """Pre-split storage (round 4): activations and BatchNorm-backward gradients whose consumers are the split convolution kernels
     are written by their producers as fp16 (hi, mid) parts in the kernels' slot layout; the MFMA kernels' staging is an LDS-DMA copy."""
-    return bool(_setting("presplit", PRESPLIT)) and split_enabled() and conv_algo() in ("auto", "split") and split_f16() and \
-        split_dgrad() and not sync_bn() and FUSE_BN_STATS and FUSE_BN_REDUCE and FUSE_POOL
+    if not bool(_setting("presplit", PRESPLIT)) or sync_bn() or not (FUSE_BN_STATS and FUSE_BN_REDUCE and FUSE_POOL):
+        return False
+    if conv_algo() == "bf16":           # BASELINE configs[2]: the same machinery with ONE part of plain bf16 operands (p16_parts() == 1)
+        return PRESPLIT_BF16
+    return split_enabled() and conv_algo() in ("auto", "split") and split_f16() and split_dgrad()
+
+
+def p16_parts():
+    """Parts per pre-split operand: 2 = fp16 (hi | mid) of the split kernels (fp32-level results), 1 = plain bf16 (conv == "bf16")."""
+    return 1 if conv_algo() == "bf16" else 2
 
 
 def split_enabled():
@@ -373,7 +381,7 @@ def convT2x2_fwd_p(x, wq, bias, outP, Ct, pt, pl):
     B, Cin, h, w = x.shape
     Ho, Wo = outP.shape[2], outP.shape[4]
     e0 = _prof_begin()
-    rc = _lib.load().onet_convT2x2_fwd_p(_p(x), xbs, _p(wq), _p(bias), _p(outP), _pbs(outP), B, Cin, Ct, h, w, Ho, Wo, pt, pl,
+    rc = _lib.load().onet_convT2x2_fwd_p(_p(x), xbs, _p(wq), _p(bias), _p(outP), _pbs(outP), outP.shape[3], B, Cin, Ct, h, w, Ho, Wo, pt, pl,
                                          convt_operand_bf16(B, h, w, Ct), _stream())
     flops, nb = 2.0 * B * h * w * Cin * 4 * Ct, 4.0 * (B * h * w * (Cin + 4 * Ct) + 4 * Cin * Ct)
     _prof_end("convt_gemm_kernel", flops if rc == 0 else 0.0, e0, nb if rc == 0 else 0.0)
@@ -409,7 +417,7 @@ BF = torch.bfloat16
 
 
 def bf16_storage():
-    return bool(_setting("bf16_storage", BF16_STORAGE)) and conv_algo() == "bf16"
+    return bool(_setting("bf16_storage", BF16_STORAGE)) and conv_algo() == "bf16" and not presplit()
 
 
 def b16_of(t):
@@ -541,7 +549,7 @@ class Packed3x3(dict):
     def get_pack(self, algo):
         if algo not in self:
             self[algo] = {"direct": pack3x3, "winograd": pack3x3_winograd, "winograd4": pack3x3_winograd4,
-                          "bf16": pack3x3_bf16, "split": pack3x3_split}[algo](self.w)
+                          "bf16": pack3x3_bf16, "split": pack3x3_split, "plain16": pack3x3_plain16}[algo](self.w)
         return self[algo]
 
 
@@ -581,6 +589,7 @@ CONVT_SPLIT = _os.environ.get("ONET_CONVT_SPLIT", "1") != "0"     # 0: the ConvT
 SPLIT_F16 = _os.environ.get("ONET_SPLIT_F16", "1") != "0"         # 0: the forward split kernel takes bf16 parts like the gradients
 SPLIT_DGRAD = _os.environ.get("ONET_SPLIT_DGRAD", "1") != "0"     # 0 (diagnostic): input gradients stay on the fp32-MFMA kernels
 PRESPLIT = _os.environ.get("ONET_PRESPLIT", "1") != "0"           # 1: pre-split operand storage (Settings.presplit)
+PRESPLIT_BF16 = _os.environ.get("ONET_PRESPLIT_BF16", "1") != "0"  # ... also under conv == "bf16" (0: round 3's bf16 kernels + bf16 storage)
 # diagnostic / tests: every activation written pre-split ALSO leaves its fp32 tensor (same values: the parts are split from them), so
 # that a harness can read each unit's output; the kernels that consume the pre-split forms are unchanged
 PRESPLIT_KEEP_FP32 = _os.environ.get("ONET_PRESPLIT_KEEP_FP32", "0") != "0"
@@ -808,6 +817,18 @@ def conv3x3_bf16(x, wq, Cout, out=None, x16=None):
     return out
 
 
+def pack3x3_plain16(w):
+    """Plain bf16 packs (ONE part, bf16(w)) in the split kernels' slot order, for the pre-split kernels under conv == "bf16":
+    (fwd [Cin/16][9][2][Cout][8], dgrad [ceil(Cout/16)][9][2][Cin][8])."""
+    require_gpu(w)
+    w = w.detach().contiguous()
+    Cout, Cin = w.shape[0], w.shape[1]
+    wf = torch.empty(Cin * 9 * Cout + 8, dtype=BF, device=w.device) if Cin % 16 == 0 else None
+    wd = torch.empty((-(-Cout // 16) * 16) * 9 * Cin + 8, dtype=BF, device=w.device)
+    _lib.call("onet_conv3x3_split_pack_weights", _p(w), _p(wf), _p(wd), None, Cout, Cin, 2, 2, _stream())
+    return wf, wd
+
+
 def pack3x3_split(w):
     """bf16 (hi, mid) packs of a 3x3 weight for conv_split.hip: (fwd [Cin/16][2][9][2][Cout][8], dgrad [ceil(Cout/16)][2][9][2][Cin][8]);
     a pack whose reduction dimension is not a multiple of 16 on the forward side is None."""
@@ -902,16 +923,17 @@ def conv3x3_split(x, wq, Cout, out=None, norm=None, amax=None, always=False):
     return out
 
 
-def split_pack_act(x, f16=True, scale=1.0, out=None):
+def split_pack_act(x, f16=True, scale=1.0, out=None, parts=2):
     """fp32 NCHW -> the pre-split slot layout of conv_split.hip: [B, C/8, H, 2 (hi | mid), W, 8] fp16 (or bf16) parts of
-    scale * x; 4 bytes per element, the fp32 tensor's footprint."""
+    scale * x; 4 bytes per element, the fp32 tensor's footprint.  parts = 1: plain bf16, [B, C/8, H, 1, W, 8]."""
     require_gpu(x)
     x, xbs = plane(x)
     B, C, H, W = x.shape
+    if out is not None:
+        parts = out.shape[3]
     if out is None:
-        out = torch.empty((B, C // 8, H, 2, W, 8), dtype=torch.float16 if f16 else BF, device=x.device)
-    _lib.call("onet_split_pack_act", _p(x), xbs, _p(out), out.stride(0) // 2 if B > 1 else C * H * W, B, C, H, W, int(f16), float(scale),
-              _stream())
+        out = torch.empty((B, C // 8, H, parts, W, 8), dtype=torch.float16 if (f16 and parts == 2) else BF, device=x.device)
+    _lib.call("onet_split_pack_act", _p(x), xbs, _p(out), _pbs(out), B, C, H, W, 2 if parts == 1 else int(f16), float(scale), _stream())
     return out
 
 
@@ -921,8 +943,8 @@ def conv3x3_split_pre(xs, wq, Cout, out=None, slots=None, always=False, stats=No
     scaled xs by (undone by the kernel; None: unscaled)."""
     if wq is None or not wq.is_cuda or wq.dtype not in (torch.bfloat16, torch.float16) or xs.dtype != wq.dtype:
         raise TypeError("conv3x3_split_pre: xs and wq must be split packs of the same 16-bit type on the GPU")
-    f16 = int(wq.dtype == torch.float16)
     B, C8, H, two, W, eight = xs.shape
+    f16 = 2 if two == 1 else int(wq.dtype == torch.float16)            # 2: plain bf16, one part
     Cin = C8 * 8
     if out is None:
         out = torch.empty((B, Cout, H, W), dtype=F32, device=xs.device)
@@ -941,13 +963,13 @@ def conv3x3_split_wgrad_pre(xs, dzs, dw_shape, out=None, x_slots=None, dz_slots=
         raise TypeError("conv3x3_split_wgrad_pre: xs and dzs must be pre-split tensors of the same 16-bit type")
     B, C8, H, two, W, eight = xs.shape
     Cin, Cout = C8 * 8, dzs.shape[1] * 8
-    assert tuple(dw_shape) == (Cout, Cin, 3, 3)
+    assert tuple(dw_shape) == (Cout, Cin, 3, 3) and dzs.shape[3] == two
     dw = out if out is not None else torch.empty(dw_shape, dtype=F32, device=xs.device)
     need = _lib.load().onet_conv3x3_split_wgrad_ws_bytes(B, Cin, Cout, H, W)
     ws = workspace(need, xs.device)
     e0 = _prof_begin()
     _lib.call("onet_conv3x3_split_wgrad_pre", _p(xs), xs.stride(0) // 2 if B > 1 else Cin * H * W, _p(x_slots), _p(dzs),
-              dzs.stride(0) // 2 if B > 1 else Cout * H * W, _p(dz_slots), int(xs.dtype == torch.float16), _p(dw), _p(ws),
+              dzs.stride(0) // 2 if B > 1 else Cout * H * W, _p(dz_slots), 2 if two == 1 else int(xs.dtype == torch.float16), _p(dw), _p(ws),
               ws.numel() * 4, B, Cin, Cout, H, W, 0, _stream())
     _prof_end("conv3x3_split_wgrad_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
     return dw
@@ -961,17 +983,23 @@ def pre_layer_ok(B, Cin, Cout, H, W):
     consumer agree without talking)."""
     if not presplit() or Cin % 16 or Cout % 16 or W < 32 or W % 32 or H % 16 or H * W >= 2 ** 24:
         return False
-    if W == 32 and B * max(Cin, Cout) * H * W * 4 >= 2 ** 31:      # weight-gradient units pair images: one buffer resource over the batch
+    np_ = p16_parts()
+    if np_ == 1 and (Cin % 32 or Cout % 32):                         # plain bf16: 32-channel chunks
+        return False
+    if W == 32 and B * max(Cin, Cout) * H * W * 2 * np_ >= 2 ** 31:  # weight-gradient units pair images: one buffer resource over the batch
         return False
     lib = _lib.load()
-    return conv3x3_algo(B, Cin, Cout, H, W) == "split" and conv3x3_algo(B, Cout, Cin, H, W) == "split" and \
+    want = "bf16" if np_ == 1 else "split"
+    return conv3x3_algo(B, Cin, Cout, H, W) == want and conv3x3_algo(B, Cout, Cin, H, W) == want and \
         bool(lib.onet_conv3x3_split_wgrad_pre_ok(B, Cin, Cout, H, W)) and int(lib.onet_conv3x3_split_nparts(B, H, W)) > 0 and \
         int(lib.onet_maxpool2_bwd_bn_bands(H, W)) > 0
 
 
-def p16_empty(B, C, H, W, device):
-    """An uninitialised pre-split tensor: fp16 (hi | mid) parts in the slot layout [B, C/8, H, 2, W, 8] (4 bytes per element)."""
-    return torch.empty((B, C // 8, H, 2, W, 8), dtype=torch.float16, device=device)
+def p16_empty(B, C, H, W, device, parts=None):
+    """An uninitialised pre-split tensor in the slot layout [B, C/8, H, parts, W, 8]: fp16 (hi | mid) parts (4 bytes per element) or,
+    under conv == "bf16", one part of plain bf16 (2 bytes per element)."""
+    parts = p16_parts() if parts is None else parts
+    return torch.empty((B, C // 8, H, parts, W, 8), dtype=torch.float16 if parts == 2 else BF, device=device)
 
 
 def p16_of(t):
@@ -991,7 +1019,7 @@ def tag_p16(t, P):
 
 def _pbs(P):
     """batch stride of a pre-split tensor (or of a channel-group slice of one) in 4-byte units"""
-    return P.stride(0) // 2 if P.shape[0] > 1 else P.shape[1] * P.shape[2] * P.shape[4] * 8
+    return P.stride(0) // 2 if P.shape[0] > 1 else P.shape[1] * P.shape[2] * P.shape[3] * P.shape[4] * 4
 
 
 def bn_relu_apply_split(z, save, xs, a=None):
@@ -1000,7 +1028,7 @@ def bn_relu_apply_split(z, save, xs, a=None):
     z, zbs = plane(z)
     B, C, H, W = z.shape
     _lib.call("onet_bn_relu_apply_split", _p(z), zbs, _p(xs), _pbs(xs), _p(a), 0 if a is None else (a.stride(0) if B > 1 else C * H * W),
-              _p(save), B, C, H, W, _stream(), nbytes=(8 + 4 * (a is not None)) * z.numel())
+              _p(save), xs.shape[3], B, C, H, W, _stream(), nbytes=(4 + 2 * xs.shape[3] + 4 * (a is not None)) * z.numel())
 
 
 def bn_relu_apply_pool_split(z, save, xs, a, ys, y):
@@ -1011,7 +1039,9 @@ def bn_relu_apply_pool_split(z, save, xs, a, ys, y):
     n, m = C * H * W, C * (H // 2) * (W // 2)
     rc = _lib.load().onet_bn_relu_apply_pool_split(_p(z), zbs, _p(xs), 0 if xs is None else _pbs(xs), _p(a),
                                                   0 if a is None else (a.stride(0) if B > 1 else n), _p(ys), 0 if ys is None else _pbs(ys),
-                                                  _p(y), 0 if y is None else (y.stride(0) if B > 1 else m), _p(save), B, C, H, W, _stream())
+                                                  _p(y), 0 if y is None else (y.stride(0) if B > 1 else m), _p(save),
+                                                  (xs if xs is not None else ys).shape[3] if (xs is not None or ys is not None) else 2,
+                                                  B, C, H, W, _stream())
     if rc < 0:
         raise _lib.OnetHipError(f"onet_bn_relu_apply_pool_split failed ({rc}): {_lib.last_error()}")
     return rc == 0
@@ -1019,9 +1049,9 @@ def bn_relu_apply_pool_split(z, save, xs, a, ys, y):
 
 def conv3x3_pre_bn_partials(xP, pk):
     """conv3x3_fwd_bn_partials for a pre-split input: -> (z, cm) with the BatchNorm statistics records of the epilogue."""
-    B, C8, H, _, W, _ = xP.shape
+    B, C8, H, np_, W, _ = xP.shape
     Co = pk["Cout"]
-    wq = pk.get_pack("split")[0]
+    wq = pk.get_pack("split" if np_ == 2 else "plain16")[0]
     nparts = int(_lib.load().onet_conv3x3_split_nparts(B, H, W))
     cm = torch.empty((Co, nparts, 3), dtype=F32, device=xP.device) if nparts > 0 else None
     return conv3x3_split_pre(xP, wq, Co, stats=cm), cm
@@ -1031,7 +1061,8 @@ def bn_relu_bwd_split(da, z, save_all, training, need_affine_grads=True, affine_
     """BatchNorm + ReLU backward of a layer whose dz is consumed by the pre-split kernels.  Per statistics group: the reduce pass
     (also recording max |da|, unless the records -- and da's magnitude slots -- came fused from da's producer), then the finalize
     pass, which also writes the bound of |dz| into fresh magnitude slots (all reduce passes first: the bound needs the complete
-    max |da|), then dz written pre-split, scaled by the power of two those slots select.  -> (dzP, dz_slots, dgamma, dbeta)."""
+    max |da|), then dz written pre-split, scaled by the power of two those slots select.  Plain bf16 operands (conv == "bf16",
+    one part): no magnitudes, no scale.  -> (dzP, dz_slots | None, dgamma, dbeta)."""
     da, dabs = plane(da)
     z, zbs = plane(z)
     B, C, H, W = z.shape
@@ -1039,19 +1070,25 @@ def bn_relu_bwd_split(da, z, save_all, training, need_affine_grads=True, affine_
     G = save_all.shape[0]
     Bg = B // G
     dev = z.device
-    dzP = p16_empty(B, C, H, W, dev)
-    dz_slots = new_amax(dev)
-    if rec4 is not None and da_amax is None:
+    np_ = p16_parts()
+    dzP = p16_empty(B, C, H, W, dev, np_)
+    scaled = np_ == 2
+    dz_slots = new_amax(dev) if scaled else None
+    if scaled and rec4 is not None and da_amax is None:
         da_amax = absmax_slots(da)                  # records fused by a producer that did not record the magnitude: one extra pass
     parts = []
     if rec4 is None:
-        da_amax = new_amax(dev)
+        da_amax = new_amax(dev) if scaled else None
         nparts = _bn_nparts(Bg, HW)
         for g in range(G):
             sl = slice(g * Bg, (g + 1) * Bg)
             part2 = torch.empty((nparts, C, 4), dtype=F32, device=dev)
-            _lib.call("onet_bn_relu_bwd_reduce_amax", _p(da[sl]), dabs, _p(z[sl]), zbs, _p(save_all[g]), _p(part2), nparts, _p(da_amax),
-                      Bg, C, HW, _stream(), nbytes=8 * z[sl].numel())
+            if scaled:
+                _lib.call("onet_bn_relu_bwd_reduce_amax", _p(da[sl]), dabs, _p(z[sl]), zbs, _p(save_all[g]), _p(part2), nparts,
+                          _p(da_amax), Bg, C, HW, _stream(), nbytes=8 * z[sl].numel())
+            else:
+                _lib.call("onet_bn_relu_bwd_reduce", _p(da[sl]), dabs, _p(z[sl]), zbs, _p(save_all[g]), _p(part2), nparts, Bg, C, HW,
+                          _stream(), nbytes=8 * z[sl].numel())
             parts.append((part2, nparts))
     else:
         np4 = rec4.shape[0] // G
@@ -1063,13 +1100,16 @@ def bn_relu_bwd_split(da, z, save_all, training, need_affine_grads=True, affine_
     coefs = []
     for g in range(G):
         coef = torch.empty((4, C), dtype=F32, device=dev) if training else None
-        _lib.call("onet_bn_bwd_finalize_bound", _p(parts[g][0]), parts[g][1], Bg * HW, _p(dgamma), _p(dbeta), _p(coef), int(g > 0), C,
-                  _p(save_all[g]), _p(da_amax), _p(dz_slots), _stream())
+        if scaled:
+            _lib.call("onet_bn_bwd_finalize_bound", _p(parts[g][0]), parts[g][1], Bg * HW, _p(dgamma), _p(dbeta), _p(coef), int(g > 0), C,
+                      _p(save_all[g]), _p(da_amax), _p(dz_slots), _stream())
+        else:
+            _lib.call("onet_bn_bwd_finalize", _p(parts[g][0]), parts[g][1], Bg * HW, _p(dgamma), _p(dbeta), _p(coef), int(g > 0), C, _stream())
         coefs.append(coef)
     for g in range(G):
         sl = slice(g * Bg, (g + 1) * Bg)
         _lib.call("onet_bn_relu_bwd_apply_split", _p(da[sl]), dabs, _p(z[sl]), zbs, _p(save_all[g]), _p(coefs[g]), _p(dzP[sl]), _pbs(dzP),
-                  _p(dz_slots), Bg, C, H, W, _stream(), nbytes=12 * z[sl].numel())
+                  _p(dz_slots), np_, Bg, C, H, W, _stream(), nbytes=(8 + 2 * np_) * z[sl].numel())
     return dzP, dz_slots, dgamma, dbeta
 
 

@@ -301,12 +301,19 @@ def _record_bf16_operands(monkeypatch, B):
     from onet_amd import ops
     rb = lambda t: t.detach().to(torch.bfloat16).cpu()          # RNE, == v_cvt_pk_bf16_f32 (tests/test_gpu_ops.py)
     conv, convt = [], []
-    real_w, real_t = ops.conv3x3_wgrad_auto, ops.convT2x2_wgrad
+    real_w, real_t, real_p = ops.conv3x3_wgrad_auto, ops.convT2x2_wgrad, ops.conv3x3_split_wgrad_pre
 
     def wgrad(x, dz, *a, **k):
         assert x is not None and dz is not None and x.shape[0] == 2 * B
         conv.append((rb(x), rb(dz)))
         return real_w(x, dz, *a, **k)
+
+    def wgrad_pre(xP, dzP, *a, **k):
+        # pre-split storage with ONE part of plain bf16 (round 4): the operands the kernels consumed, as their producers rounded them
+        assert xP.shape[0] == 2 * B and xP.shape[3] == 1 and xP.dtype == torch.bfloat16
+        nchw = lambda P: P.detach()[:, :, :, 0].permute(0, 1, 4, 2, 3).reshape(P.shape[0], P.shape[1] * 8, P.shape[2], P.shape[4]).cpu()
+        conv.append((nchw(xP), nchw(dzP)))
+        return real_p(xP, dzP, *a, **k)
 
     def wgrad_t(x, dy, *a, **k):
         assert x.shape[0] == 2 * B
@@ -315,10 +322,12 @@ def _record_bf16_operands(monkeypatch, B):
 
     monkeypatch.setattr(ops, "conv3x3_wgrad_auto", wgrad)
     monkeypatch.setattr(ops, "convT2x2_wgrad", wgrad_t)
+    monkeypatch.setattr(ops, "conv3x3_split_wgrad_pre", wgrad_pre)
 
     def finish():
         monkeypatch.setattr(ops, "conv3x3_wgrad_auto", real_w)
         monkeypatch.setattr(ops, "convT2x2_wgrad", real_t)
+        monkeypatch.setattr(ops, "conv3x3_split_wgrad_pre", real_p)
         assert len(conv) == 18 and len(convt) == 4
         out = {"conv3x3": [], "convT2x2": []}
         for p in range(2):                                       # backward visits the units last to first
@@ -329,8 +338,8 @@ def _record_bf16_operands(monkeypatch, B):
     return finish
 
 
-@pytest.mark.parametrize("tag", ["b8_c1_128", "b4_c1_256"])
-def test_bf16_path_every_gradient_element_vs_routed_rounded_oracle(dev, tag, monkeypatch):
+@pytest.mark.parametrize("tag,kernels", [("b8_c1_128", "presplit"), ("b4_c1_256", "presplit"), ("b8_c1_128", "round3")])
+def test_bf16_path_every_gradient_element_vs_routed_rounded_oracle(dev, tag, kernels, monkeypatch):
     """BASELINE configs[2]'s arithmetic held to the fp32 path's element-wise statement instead of "gradient norms within 10 %": the
     fp64 oracle evaluates the function the bf16 conv path computes -- every bf16 matrix product (forward, input gradient, weight
     gradient of the 3x3 layers and of the ConvTranspose2d GEMMs the path takes) on bf16-rounded operands, everything else
@@ -341,6 +350,9 @@ def test_bf16_path_every_gradient_element_vs_routed_rounded_oracle(dev, tag, mon
     from onet_amd import ops
     B, C, H, W, gain, _ = CASES[tag]
     monkeypatch.setattr(ops, "CONV_ALGO", "bf16")
+    # kernels = "presplit" (round 4, the default): the layers >= 32 pixels wide run the LDS-DMA staged kernels on ONE part of plain
+    # bf16 operands written by their producers (same roundings, nearest even); "round3": conv_bf16.hip's kernels everywhere
+    monkeypatch.setattr(ops, "PRESPLIT_BF16", kernels == "presplit")
     # fp32 operand storage, rounded on load: bit-identical to bf16 storage (test_bf16_storage_is_bit_identical_to_rounding_on_load),
     # and every fp32 activation / gradient exists to be recorded (with bf16 storage half of them are placeholders)
     monkeypatch.setattr(ops, "BF16_STORAGE", False)
@@ -353,13 +365,16 @@ def test_bf16_path_every_gradient_element_vs_routed_rounded_oracle(dev, tag, mon
     finally:
         prof, _ = ops.profile_stop()
     replay = finish_ops()
-    assert len(prof.get("conv3x3_bf16_kernel", [])) >= 24 and len(prof.get("conv3x3_wgrad_bf16_kernel", [])) >= 12, {k: len(v) for k, v in prof.items()}
+    if kernels == "presplit":
+        assert len(prof.get("conv3x3_split_kernel", [])) >= 10 and len(prof.get("conv3x3_split_wgrad_kernel", [])) >= 5, {k: len(v) for k, v in prof.items()}
+    else:
+        assert len(prof.get("conv3x3_bf16_kernel", [])) >= 24 and len(prof.get("conv3x3_wgrad_bf16_kernel", [])) >= 12, {k: len(v) for k, v in prof.items()}
     with orc.operand_rounding(_bf16_rule, replay):
         (oLt, oVt, oLd, oVd, oS), oloss, g64, r = _routed_oracle(X, C, 1981, gain, acts)
     assert abs(loss.item() - float(oloss)) <= 1e-5 * abs(float(oloss))
     assert float((Vt.detach().cpu().double() - oVt.detach()).abs().max()) <= 1e-4 * float(oVt.detach().abs().max())
-    _check(m, g64, r, f"bf16 path {tag}, roundings replayed", tol=BF16_GRAD_TOL)
-    if tag != "b8_c1_128":
+    _check(m, g64, r, f"bf16 path {tag} [{kernels}], roundings replayed", tol=BF16_GRAD_TOL)
+    if tag != "b8_c1_128" or kernels != "presplit":
         return                                       # (the two extra fp64 evaluations below cost a minute at 256 x 256)
     # for the record (and so that the replay is not vacuous): the same evaluation with FREE rounding, and without any rounding
     with orc.operand_rounding(_bf16_rule):

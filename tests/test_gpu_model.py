@@ -162,8 +162,14 @@ def test_bf16_conv_path_vs_reference_golden(dev, monkeypatch):
         (Lt, Vt, Ld, Vd, S), loss = _step(m, X)
     finally:
         prof, _ = ops.profile_stop()
-    used = len(prof.get("conv3x3_bf16_kernel", []))
+    # (round 4: the layers >= 32 pixels wide run the pre-split, LDS-DMA staged kernels on one part of plain bf16 -- profiled under the
+    # split kernels' names -- and conv_bf16.hip's kernels keep the 16-pixel level; the strict statement about this arithmetic is
+    # tests/test_gpu_gradients.py::test_bf16_path_every_gradient_element_vs_routed_rounded_oracle: every gradient element at 1e-4 with
+    # the run's roundings replayed.  The bounds HERE are wide because free bf16 rounding is chaotic: two correct evaluations that
+    # round differently differ by ~1e-2 of the logits' scale and by up to 8 % in one gradient norm.)
+    used = len(prof.get("conv3x3_bf16_kernel", [])) + len(prof.get("conv3x3_split_kernel", []))
     assert used >= 2 * 12, f"bf16 kernel launches: {used}"
+    assert not ops.PRESPLIT_BF16 or len(prof.get("conv3x3_split_kernel", [])) >= 20
     rel = abs(loss.item() - g["losses"][0]) / abs(g["losses"][0])
     assert rel <= 1e-3, ("loss", loss.item(), g["losses"][0], rel)          # measured 3e-5
     for name, t in (("Vt", Vt), ("Vd", Vd)):
@@ -192,6 +198,7 @@ def test_bf16_storage_is_bit_identical_to_rounding_on_load(dev, shape, monkeypat
     F.pad path builds an ordinary fp32 concat buffer."""
     from onet_amd import _lib, ops
     monkeypatch.setattr(ops, "CONV_ALGO", "bf16")
+    monkeypatch.setattr(ops, "PRESPLIT_BF16", False)        # round 3's bf16 kernels and their operand storage (ONET_PRESPLIT_BF16=0)
     B, C, H, W = shape
     X = orc.det_input(B, C, H, W, seed=12).to(dev)
     res, used = {}, {}
@@ -231,6 +238,7 @@ def test_fused_pooling_is_bit_identical(dev, algo, monkeypatch):
     and the separate pass must really be gone."""
     from onet_amd import _lib, ops
     monkeypatch.setattr(ops, "CONV_ALGO", algo)
+    monkeypatch.setattr(ops, "PRESPLIT", False)     # (pre-split storage has its own fused pass, bn_relu_apply_pool_split: test_gpu_ops.py)
     X = orc.det_input(3, 1, 64, 96, seed=14).to(dev)
     res, pools = {}, {}
     for fused in (False, True):
