@@ -33,6 +33,16 @@ for ci, co, H in shapes:
         rep(lambda: ops.conv3x3_split(x, sf, co))
         rep(lambda: ops.conv3x3_split(dz, sd, ci))
         rep(lambda: ops.conv3x3_split_wgrad(x, dz, (co, ci, 3, 3)))
+    if "presplit" in which:                 # round 4: pre-split operands, LDS-DMA staged kernels (fp16 hi | mid parts)
+        import onet_amd.ops as _o
+        keep = _o.SPLIT_GRAD_F16
+        _o.SPLIT_GRAD_F16 = True
+        pf, pd = ops.pack3x3_split(w)
+        _o.SPLIT_GRAD_F16 = keep
+        xP, dzP = ops.split_pack_act(x, f16=True), ops.split_pack_act(dz, f16=True)
+        rep(lambda: ops.conv3x3_split_pre(xP, pf, co))
+        rep(lambda: ops.conv3x3_split_pre(dzP, pd, ci))
+        rep(lambda: ops.conv3x3_split_wgrad_pre(xP, dzP, (co, ci, 3, 3)))
     if "bf16" in which:                     # bf16 STORAGE variants (operands read as bf16 copies)
         x16, dz16 = x.to(torch.bfloat16), dz.to(torch.bfloat16)
         bf, bd = ops.pack3x3_bf16(w)
