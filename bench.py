@@ -382,14 +382,16 @@ def main(args):
         # F(2x2,3x3) 16 per 4 x 9 -> 1/2.25 (the weight-gradient kernels F(3x3,4x4) / F(3x3,2x2) likewise)
         # (the split-bf16 kernels issue THREE bf16 MFMAs per product term of the direct algorithm: 1/3)
         REDUCTION = {"conv_wino4_kernel": 4.0, "conv_wino_kernel": 2.25, "conv_wino_wgrad_kernel": 2.25,
-                     "conv_wino4_wgrad_kernel": 4.0, "conv3x3_split_kernel": 1.0 / 3.0, "conv3x3_split_wgrad_kernel": 1.0 / 3.0}
-        BF16 = ("conv3x3_bf16_kernel", "conv3x3_wgrad_bf16_kernel", "conv3x3_split_kernel", "conv3x3_split_wgrad_kernel")
+                     "conv_wino4_wgrad_kernel": 4.0, "conv3x3_split_kernel": 1.0 / 3.0, "conv3x3_split_wgrad_kernel": 1.0 / 3.0,
+                     "conv3x3_split_pre_kernel": 1.0 / 3.0, "conv3x3_split_wgrad_pre_kernel": 1.0 / 3.0}
+        BF16 = ("conv3x3_bf16_kernel", "conv3x3_wgrad_bf16_kernel", "conv3x3_split_kernel", "conv3x3_split_wgrad_kernel",
+                "conv3x3_split_pre_kernel", "conv3x3_split_wgrad_pre_kernel")
         if bf16 and ops.CONVT_BF16:     # the ConvTranspose2d GEMMs take bf16 operands too (priced against the bf16 peak)
             BF16 += ("convt_gemm_kernel", "convt_wgrad_gemm_kernel")
         with ops.using(onet.settings):
             convt_split = ops.convt_operand_bf16(2 * args.batch, args.size // 2, args.size // 2, 64) == 2     # the last Up block's GEMM
         if bf16:                        # conv == "bf16" through the pre-split kernels with ONE part: one MFMA per product term
-            REDUCTION.update({"conv3x3_split_kernel": 1.0, "conv3x3_split_wgrad_kernel": 1.0})
+            REDUCTION.update({"conv3x3_split_pre_kernel": 1.0, "conv3x3_split_wgrad_pre_kernel": 1.0})
         if convt_split:                 # ... or split bf16 operands (three bf16 MFMAs per term, fp32-level results)
             BF16 += ("convt_gemm_kernel", "convt_wgrad_gemm_kernel")
             REDUCTION.update({"convt_gemm_kernel": 1.0 / 3.0, "convt_wgrad_gemm_kernel": 1.0 / 3.0})
@@ -403,6 +405,12 @@ def main(args):
                                         "w = hi + mid (forward: fp16 parts, input gradient: bf16 parts), 3 x v_mfma_f32_32x32x16_{f16,bf16} "
                                         "per term, fp32 accumulate; error <= the fp32 Winograd F(4x4) kernel's (forward: the direct kernel's)",
                 "conv3x3_split_wgrad_kernel": "fp32 weight gradient on the bf16 matrix cores by operand splitting, deterministic split-K",
+                "conv3x3_split_pre_kernel": "fp32-level convolution (fwd + dgrad) on the 16-bit matrix cores, operands PRE-SPLIT by their producers "
+                                            "(fp16 hi | mid slots [C/8][H][part][W][8]; under --conv bf16: one part of plain bf16): staging is an "
+                                            "LDS-DMA copy, 3 x v_mfma_f32_32x32x16_f16 per term (plain bf16: 1), f32 accumulate, BatchNorm "
+                                            "statistics from the accumulators",
+                "conv3x3_split_wgrad_pre_kernel": "weight gradient from pre-split x and dz: LDS-DMA staging, fragments by ds_read_b64_tr_b16 "
+                                                  "(transposing LDS read), 3 MFMAs per term (plain bf16: 1), deterministic split-K",
                 "conv3x3_wgrad_bf16_kernel": "split-K weight gradient on v_mfma_f32_32x32x16_bf16",
                 "conv_fwd_kernel": "direct implicit GEMM on fp32 MFMA (stem, tiny maps)",
                 "conv_wgrad_kernel": "direct split-K weight gradient on fp32 MFMA (stem, tiny maps)",
@@ -428,8 +436,8 @@ def main(args):
         dom = max(kern, key=lambda k: kern[k]["ms_total"])
         d = kern[dom]
         traffic = pmc_traffic(dom, bf16, args.batch)
-        SPLIT = ("conv3x3_split_kernel", "conv3x3_split_wgrad_kernel")
-        if dom in SPLIT:
+        SPLIT = ("conv3x3_split_kernel", "conv3x3_split_wgrad_kernel", "conv3x3_split_pre_kernel", "conv3x3_split_wgrad_pre_kernel")
+        if dom in SPLIT and not bf16:
             # fp32 tensors, fp32-level results, computed on the bf16 matrix pipe by operand splitting: MFMA-bound, priced against
             # the DENSE bf16 MFMA peak with the FLOPs the kernel issues (three bf16 MFMAs per product term of the direct algorithm)
             roofline = {"kernel": dom, "bound": "mfma", "achieved": d["issued_mfma_tflops"], "peak": BF16_MFMA_PEAK_TFLOPS,
@@ -485,16 +493,17 @@ def main(args):
                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None,
                "dtype": "bf16" if bf16 else "f32",
-               "precision": ("bf16 MFMA operands (3x3 conv fwd/dgrad/wgrad, ConvTranspose2d GEMMs), f32 accumulation, f32 conv outputs, "
-                             "BatchNorm, loss, master weights and optimizer") if bf16 else
-                            ("f32 tensors and f32-level results throughout; the 3x3 convolutions on maps >= 32 px wide and the ConvTranspose2d GEMMs run on "
-                             "the 16-bit matrix pipe by operand splitting (each operand = hi + mid, 3 MFMAs per term, f32 accumulate): forward "
-                             "convolutions on fp16 parts (22-bit operands; error vs fp64 5e-8..1.5e-7 rms / <= 2e-6 max of the output scale, "
-                             "the fp32 direct kernel's level), input / weight gradients and the ConvTranspose2d GEMMs on bf16 parts (16-bit "
-                             "operands: 1e-6 rms / 5e-6 max, at or below the fp32 Winograd F(4x4) kernel's 3e-7..9e-7 / 7e-6..2e-5); every "
-                             "gradient element within 2e-4 of the fp64 oracle under the run's own decisions, incl. this B=32 dispatch "
-                             "(tests/test_gpu_gradients.py: 1.0e-4, as with the fp32-MFMA kernels); ONET_SPLIT=0 keeps the fp32-MFMA Winograd "
-                             "kernels (timed in f32_mfma_only)") if (conv in ("auto", "split") and ops.split_enabled()) else "f32 throughout (fp32 MFMA)",
+               "precision": ("bf16 MFMA operands (3x3 conv fwd/dgrad/wgrad: written as bf16 slots by their producers, round to nearest even; "
+                             "ConvTranspose2d GEMMs), f32 accumulation, f32 conv outputs, BatchNorm, loss, master weights and optimizer") if bf16 else
+                            ("f32 master tensors (inputs, outputs, conv outputs z, activation gradients, weights, optimizer) and f32-level results; "
+                             "the 3x3 convolutions on maps >= 32 px wide run on the 16-bit matrix pipe by operand splitting (each operand = hi + mid "
+                             "fp16 parts of a power-of-two-scaled value: 22-bit operands, 3 MFMAs per term, f32 accumulate; error vs fp64 5e-8..1.5e-7 "
+                             "rms of the output scale forward, 3e-7 max on the weight gradient), their operands stored PRE-SPLIT by the producing "
+                             "BatchNorm / pooling / ConvTranspose2d kernels (same values as the fp32 passes: forward bit-identical to fp32 storage); "
+                             "ConvTranspose2d GEMMs on bf16 parts split in registers (16-bit operands); every gradient element within 2e-4 of the "
+                             "fp64 oracle under the run's own decisions incl. this B=32 dispatch (tests/test_gpu_gradients.py: 9.5e-5; the "
+                             "fp32-MFMA-only dispatch: 4.6e-5 on the comparable case); ONET_SPLIT=0 keeps the fp32-MFMA Winograd kernels "
+                             "(timed in f32_mfma_only)") if (conv in ("auto", "split") and ops.split_enabled()) else "f32 throughout (fp32 MFMA)",
                "data": "synthetic",
                "data_source": data_src,
                "config": {"workload": "%s: batch=%d/GPU %dx%dx%d synthetic K-clutter, %s, twin U-Net "

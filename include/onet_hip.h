@@ -164,8 +164,12 @@ int onet_convT2x2_fwd_b(const float* x, int64_t x_bs, const float* wq, const flo
         void* stream);
 /* ... the up-sampled tensor written pre-split (round 4: fp16 hi | mid slots [B][Ct/8][Ho][2][Wo][8], batch stride in 4-byte units), e.g.
  * into the up-sampled channel groups of a pre-split concat buffer; no fp32 output.  Returns 1 (nothing done) outside the GEMM fast path. */
-int onet_convT2x2_fwd_p(const float* x, int64_t x_bs, const float* wq, const float* bias, void* yP, int64_t yP_bs, int nparts, int B, int Cin,
-                        int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int operand_bf16, void* stream);
+int onet_convT2x2_fwd_p(const float* x, int64_t x_bs, const float* wq, const float* bias, void* yP, int64_t yP_bs, const void* y_amax,
+                        int nparts, int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int operand_bf16, void* stream);
+/* y_amax (may be NULL: unscaled): magnitude slots holding a bound of the up-sampled tensor, written by onet_convT2x2_out_bound from the
+ * weights (nn.ConvTranspose2d layout [Cin][Ct][2][2]), the bias and the exact max |x| (x_amax, recorded by the pass that wrote x): the
+ * fp16 parts are those of 2^k y with the guard exponent the slots select. */
+int onet_convT2x2_out_bound(const float* w, const float* bias, int Cin, int Ct, const void* x_amax, void* y_amax, void* stream);
                                                                                 /* 1: shape outside the GEMM path, nothing done */
 int onet_conv3x3_bf16_fwd_b(const void* x_bf16, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin,
                             int Cout, int H, int W, void* stream);
@@ -210,20 +214,22 @@ int onet_conv3x3_split_nparts(int B, int H, int W);
  * of two) for tests and for producers without a fused variant.  _fwd_pre: z = conv(xs, wq) with the weight pack of
  * onet_conv3x3_split_pack_weights (same arithmetic as onet_conv3x3_split_fwd: bit-identical results for the same parts); staging
  * is an LDS-DMA copy.  x_amax / scale_always: the magnitude slots and rule (amax_scale) the PRODUCER scaled xs by -- the kernel
- * undoes that power of two on its accumulators; NULL: xs is unscaled.  part != NULL: BatchNorm statistics records as
- * onet_conv3x3_split_fwd_stats. */
+ * undoes that power of two on its accumulators; NULL: xs is unscaled.  x_amax2 / split_ch: the input is a concat buffer whose
+ * channels >= split_ch (0: none) were scaled by a second producer with its own slots.  part != NULL: BatchNorm statistics records
+ * as onet_conv3x3_split_fwd_stats. */
 int onet_split_pack_act(const float* x, int64_t x_bs, void* xs, int64_t xs_bs, int B, int C, int H, int W, int f16, float scale,
                         void* stream);
-int onet_conv3x3_split_fwd_pre(const void* xs, int64_t xs_bs, const void* x_amax, int scale_always, const void* wq, int wq_f16, float* z,
-                               int64_t z_bs, float* part, int B, int Cin, int Cout, int H, int W, void* stream);
+int onet_conv3x3_split_fwd_pre(const void* xs, int64_t xs_bs, const void* x_amax, int scale_always, const void* x_amax2, int split_ch,
+                               const void* wq, int wq_f16, float* z, int64_t z_bs, float* part, int B, int Cin, int Cout, int H, int W,
+                               void* stream);
 /* Weight gradient (OV:47,51 backward) from pre-split x and dz (both in the slot layout, same 16-bit type): fragments by the gfx950
  * transposing LDS read, staging by LDS-DMA; the producers' power-of-two scales (x_amax: guard rule, dz_amax: always; NULL:
  * unscaled) are undone on the slabs; deterministic split-K through ws
  * (onet_conv3x3_split_wgrad_ws_bytes).  _ok: W >= 64, or W = 32 with an even batch; Cin, Cout multiples of 8. */
 int onet_conv3x3_split_wgrad_pre_ok(int B, int Cin, int Cout, int H, int W);
-int onet_conv3x3_split_wgrad_pre(const void* xs, int64_t xs_bs, const void* x_amax, const void* dzs, int64_t dzs_bs, const void* dz_amax,
-                                 int f16, float* dw, void* ws, int64_t ws_bytes, int B, int Cin, int Cout, int H, int W, int accumulate,
-                                 void* stream);
+int onet_conv3x3_split_wgrad_pre(const void* xs, int64_t xs_bs, const void* x_amax, const void* x_amax2, int split_ch, const void* dzs,
+                                 int64_t dzs_bs, const void* dz_amax, int f16, float* dw, void* ws, int64_t ws_bytes, int B, int Cin,
+                                 int Cout, int H, int W, int accumulate, void* stream);
 int onet_conv3x3_split_fwd_stats(const float* x, int64_t x_bs, const void* wq, int wq_f16, float* z, int64_t z_bs, float* part, int B,
                                  int Cin, int Cout, int H, int W, void* stream);
 /* Weight gradient of the same convolution with both operands (x, dz: fp32 NCHW) split the same way, three MFMAs per term;
@@ -359,10 +365,19 @@ int onet_bn_relu_bwd_apply(const float* da, int64_t da_bs, const float* z, int64
  * nparts = 2: the fp16 (hi | mid) slots above; nparts = 1: PLAIN bf16 operands, one part -- [B][C/8][H][W][8] bf16, rounded to
  * nearest even, unscaled (dz_amax may be NULL) -- for BASELINE configs[2]'s bf16 MFMA conv path (the same LDS-DMA staged kernels
  * with one part: wq_f16 / f16 = 2 in onet_conv3x3_split_fwd_pre / _wgrad_pre / _pack_weights / onet_split_pack_act). */
-int onet_bn_relu_apply_split(const float* z, int64_t z_bs, void* xs, int64_t xs_bs, float* a, int64_t a_bs, const float* save, int nparts,
-                             int B, int C, int H, int W, void* stream);
+int onet_bn_relu_apply_split(const float* z, int64_t z_bs, void* xs, int64_t xs_bs, float* a, int64_t a_bs, const float* save,
+                             const void* act_amax, int nparts, int B, int C, int H, int W, void* stream);
 int onet_bn_relu_apply_pool_split(const float* z, int64_t z_bs, void* xs, int64_t xs_bs, float* a, int64_t a_bs, void* ys, int64_t ys_bs,
-                                  float* y, int64_t y_bs, const float* save, int nparts, int B, int C, int H, int W, void* stream);
+                                  float* y, int64_t y_bs, const float* save, const void* act_amax, int nparts, int B, int C, int H, int W,
+                                  void* stream);
+/* act_amax (may be NULL: unscaled): the activation's magnitude slots holding the bound |gamma| sqrt(N - 1) + |beta| written by
+ * onet_bn_finalize_act / _cm_act (onet_bn_finalize / _cm that also record it); the fp16 parts are those of 2^k a with the GUARD
+ * exponent the slots select (0 unless the bound reaches 2^15: a loaded checkpoint with a huge gamma), undone by the consumers, which
+ * read the same slots.  A concat buffer has one set of slots per producer (skip groups / up-sampled groups). */
+int onet_bn_finalize_act(const float* part, int nparts, int64_t count, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, float momentum, float eps, float* save, void* act_amax, int C, void* stream);
+int onet_bn_finalize_cm_act(const float* part, int nparts, int64_t c_stride, const float* gamma, const float* beta, float* running_mean,
+                            float* running_var, float momentum, float eps, float* save, void* act_amax, int C, void* stream);
 int onet_bn_relu_bwd_reduce_amax(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save, float* part2, int nparts,
                                  void* da_amax, int B, int C, int HW, void* stream);
 int onet_bn_bwd_bound(const float* save, const float* coef, const void* da_amax, int64_t count, void* dz_amax, int C, void* stream);

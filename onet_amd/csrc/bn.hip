@@ -76,7 +76,10 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* running_mean,
                                                          float* running_var, float momentum, float eps,
-                                                         float* __restrict__ save, int C) {
+                                                         float* __restrict__ save, int C, unsigned* __restrict__ act_slots = nullptr) {
+    // act_slots (pre-split storage): an upper bound of relu(bn(z)) over the channels goes into the activation's magnitude slots --
+    // |gamma| sqrt(N - 1) + |beta|, since |z - mean| invstd <= sqrt(N - 1) for the N values the statistics were taken over --
+    // from which the pass that writes the activation as fp16 parts takes its (guard) scale: 1 unless the bound reaches 2^15
     const int c = blockIdx.x;
     double n = 0.0, s = 0.0;
     for (int p = threadIdx.x; p < nparts; p += 64) {
@@ -103,6 +106,10 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict
         save[C + c] = invstd;
         save[2 * C + c] = scale;
         save[3 * C + c] = bt;
+        if (act_slots) {
+            const float bound = fabsf(g) * sqrtf((float)(n > 1.0 ? n - 1.0 : 1.0)) * 1.000001f + fabsf(bt);
+            if (bound == bound) atomicMax(act_slots + (c & 63) * AMAX_STRIDE, __builtin_bit_cast(unsigned, bound));
+        }
         if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
         if (running_var) {
             const double unb = n > 1.0 ? m2 / (n - 1.0) : var;
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(256) void bn_finalize_cm_kernel(const float* __rest
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* running_mean,
                                                             float* running_var, float momentum, float eps,
-                                                            float* __restrict__ save, int C) {
+                                                            float* __restrict__ save, int C, unsigned* __restrict__ act_slots = nullptr) {
     __shared__ double red[16];
     __shared__ double bc[2];
     const int c = blockIdx.x;
@@ -152,6 +159,10 @@ __global__ __launch_bounds__(256) void bn_finalize_cm_kernel(const float* __rest
         save[C + c] = invstd;
         save[2 * C + c] = g * invstd;
         save[3 * C + c] = bt;
+        if (act_slots) {                            // (see bn_finalize_kernel)
+            const float bound = fabsf(g) * sqrtf((float)(n > 1.0 ? n - 1.0 : 1.0)) * 1.000001f + fabsf(bt);
+            if (bound == bound) atomicMax(act_slots + (c & 63) * AMAX_STRIDE, __builtin_bit_cast(unsigned, bound));
+        }
         if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
         if (running_var) {
             const double unb = n > 1.0 ? m2 / (n - 1.0) : var;
@@ -435,7 +446,12 @@ __device__ __forceinline__ void bn_store_slots_block(bn_u32x4* lds, unsigned* __
 // launch -- the strided 16-byte stores cost more than the narrower loads.
 __global__ __launch_bounds__(256) void bn_relu_apply_split_kernel(const float* __restrict__ z, int64_t z_bs, unsigned* __restrict__ xs,
                                                                   int64_t xs_bs, float* __restrict__ a, int64_t a_bs,
-                                                                  const float* __restrict__ save, int C, int H, int W, int bpp, int np) {
+                                                                  const float* __restrict__ save, int C, int H, int W, int bpp, int np,
+                                                                  const unsigned* __restrict__ slots) {
+    // slots: the activation's magnitude slots (the bound bn_finalize wrote): the fp16 parts are those of s a with the guard scale
+    // s = 2^k they select -- 1 unless the bound reaches 2^15 -- and the consumers undo s; plain bf16 (np = 1) needs none
+    float s_inv;
+    const float s_act = np == 1 ? 1.f : amax_scale(amax_read(slots), false, s_inv);
     const int plane = blockIdx.x / bpp, blk = blockIdx.x % bpp;
     const int C8 = C >> 3, b = plane / C8, c8 = plane % C8;
 #if BN_APPLY_SPLIT_TR
@@ -460,7 +476,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_split_kernel(const float* _
 #pragma unroll
             for (int k = 0; k < 8; ++k) *reinterpret_cast<float4*>(d + (int64_t)k * HW) = make_float4(v[0][k], v[1][k], v[2][k], v[3][k]);
         }
-        bn_store_slots_block(tr, xs + (int64_t)b * xs_bs, c8, H, W, blk * 1024, HW, v, 1.f, np);
+        bn_store_slots_block(tr, xs + (int64_t)b * xs_bs, c8, H, W, blk * 1024, HW, v, s_act, np);
         return;
     }
 #endif
@@ -492,7 +508,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_split_kernel(const float* _
 #pragma unroll
             for (int k = 0; k < 8; ++k) d[(int64_t)k * HW + p] = v[j][k];
         }
-        bn_store_slots(o, ((int64_t)(c8 * H + y) * np) * W + x, W, v[j], 1.f, np);
+        bn_store_slots(o, ((int64_t)(c8 * H + y) * np) * W + x, W, v[j], s_act, np);
     }
 }
 
@@ -502,7 +518,9 @@ __global__ __launch_bounds__(256) void bn_relu_apply_pool_split_kernel(const flo
                                                                        int64_t xs_bs, float* __restrict__ a, int64_t a_bs,
                                                                        unsigned* __restrict__ ys, int64_t ys_bs, float* __restrict__ yf,
                                                                        int64_t yf_bs, const float* __restrict__ save, int C, int H, int W,
-                                                                       int bpp, int np) {
+                                                                       int bpp, int np, const unsigned* __restrict__ slots) {
+    float s_inv;
+    const float s_act = np == 1 ? 1.f : amax_scale(amax_read(slots), false, s_inv);      // (see bn_relu_apply_split_kernel)
     const int plane = blockIdx.x / bpp, blk = blockIdx.x % bpp;
     const int C8 = C >> 3, b = plane / C8, c8 = plane % C8;
     const int Hp = H >> 1, Wp = W >> 1, W4 = W >> 2, HW = H * W, i = blk * 256 + threadIdx.x;
@@ -550,7 +568,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_pool_split_kernel(const flo
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) vr[e][k] = live ? v[4 * r + e][k] : 0.f;
-            bn_store_slots_block_fn(tr, o, W, vr, 1.f, [&](int px) -> int64_t {
+            bn_store_slots_block_fn(tr, o, W, vr, s_act, [&](int px) -> int64_t {
                 const int pi = patch0 + (px >> 2);
                 if (pi >= npatch) return -1;
                 int py, pq;
@@ -562,8 +580,8 @@ __global__ __launch_bounds__(256) void bn_relu_apply_pool_split_kernel(const flo
     if (!live) return;
     if (ys) {
         unsigned* o = ys + (int64_t)b * ys_bs;
-        bn_store_slots(o, ((int64_t)(c8 * Hp + yo) * np) * Wp + 2 * q, Wp, m[0], 1.f, np);
-        bn_store_slots(o, ((int64_t)(c8 * Hp + yo) * np) * Wp + 2 * q + 1, Wp, m[1], 1.f, np);
+        bn_store_slots(o, ((int64_t)(c8 * Hp + yo) * np) * Wp + 2 * q, Wp, m[0], s_act, np);
+        bn_store_slots(o, ((int64_t)(c8 * Hp + yo) * np) * Wp + 2 * q + 1, Wp, m[1], s_act, np);
     }
     if (yf) {
         float* d = yf + (int64_t)b * yf_bs + (int64_t)c8 * 8 * Hp * Wp + (int64_t)yo * Wp + 2 * q;
@@ -884,6 +902,22 @@ int onet_bn_finalize_cm(const float* part, int nparts, int64_t c_stride, const f
     return check_launch("bn_finalize_cm_kernel");
 }
 
+int onet_bn_finalize_act(const float* part, int nparts, int64_t count, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, float momentum, float eps, float* save, void* act_amax, int C, void* stream) {
+    ONET_REQUIRE(part && save && act_amax && nparts > 0 && count > 0 && C > 0, "bn_finalize_act: bad args");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, as_stream(stream), part, nparts, gamma, beta, running_mean, running_var,
+                       momentum, eps, save, C, (unsigned*)act_amax);
+    return check_launch("bn_finalize_kernel");
+}
+
+int onet_bn_finalize_cm_act(const float* part, int nparts, int64_t c_stride, const float* gamma, const float* beta, float* running_mean,
+                            float* running_var, float momentum, float eps, float* save, void* act_amax, int C, void* stream) {
+    ONET_REQUIRE(part && save && act_amax && nparts > 0 && C > 0 && c_stride >= (int64_t)nparts * 3, "bn_finalize_cm_act: bad args");
+    hipLaunchKernelGGL(bn_finalize_cm_kernel, dim3(C), dim3(256), 0, as_stream(stream), part, nparts, c_stride, gamma, beta, running_mean,
+                       running_var, momentum, eps, save, C, (unsigned*)act_amax);
+    return check_launch("bn_finalize_cm_kernel");
+}
+
 int onet_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, float* save, int C, void* stream) {
     ONET_REQUIRE(running_mean && running_var && save && C > 0, "bn_eval_coeffs: bad args");
@@ -980,8 +1014,8 @@ int onet_bn_bwd_bound(const float* save, const float* coef, const void* da_amax,
     return check_launch("bn_bwd_bound_kernel");
 }
 
-int onet_bn_relu_apply_split(const float* z, int64_t z_bs, void* xs, int64_t xs_bs, float* a, int64_t a_bs, const float* save, int nparts,
-                             int B, int C, int H, int W, void* stream) {
+int onet_bn_relu_apply_split(const float* z, int64_t z_bs, void* xs, int64_t xs_bs, float* a, int64_t a_bs, const float* save,
+                             const void* act_amax, int nparts, int B, int C, int H, int W, void* stream) {
     ONET_REQUIRE(nparts == 1 || nparts == 2, "bn_relu_apply_split: nparts must be 2 (fp16 hi | mid) or 1 (plain bf16)");
     ONET_REQUIRE(z && xs && save && B > 0 && C > 0 && (C % 8) == 0 && H > 0 && W > 0 && (W % 4) == 0, "bn_relu_apply_split: bad args (C %% 8 == 0, W %% 4 == 0)");
     ONET_REQUIRE((reinterpret_cast<uintptr_t>(xs) & 15) == 0 && (xs_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(z) & 15) == 0 && (z_bs & 3) == 0 &&
@@ -990,12 +1024,13 @@ int onet_bn_relu_apply_split(const float* z, int64_t z_bs, void* xs, int64_t xs_
     const int64_t blocks = (int64_t)B * (C / 8) * bpp;
     ONET_REQUIRE(blocks < (1ll << 31) && (int64_t)H * W < (1 << 24), "bn_relu_apply_split: grid too large");
     hipLaunchKernelGGL(bn_relu_apply_split_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), z, z_bs, (unsigned*)xs, xs_bs, a,
-                       a_bs, save, C, H, W, bpp, nparts);
+                       a_bs, save, C, H, W, bpp, nparts, (const unsigned*)act_amax);
     return check_launch("bn_relu_apply_split_kernel");
 }
 
 int onet_bn_relu_apply_pool_split(const float* z, int64_t z_bs, void* xs, int64_t xs_bs, float* a, int64_t a_bs, void* ys, int64_t ys_bs,
-                                  float* y, int64_t y_bs, const float* save, int nparts, int B, int C, int H, int W, void* stream) {
+                                  float* y, int64_t y_bs, const float* save, const void* act_amax, int nparts, int B, int C, int H, int W,
+                                  void* stream) {
     ONET_REQUIRE(nparts == 1 || nparts == 2, "bn_relu_apply_pool_split: nparts must be 2 (fp16 hi | mid) or 1 (plain bf16)");
     ONET_REQUIRE(z && (xs || a) && (ys || y) && save && B > 0 && C > 0 && (C % 8) == 0 && H > 0 && W > 0, "bn_relu_apply_pool_split: bad args");
     auto al = [](const void* p, uintptr_t m) { return (reinterpret_cast<uintptr_t>(p) & m) == 0; };
@@ -1006,7 +1041,7 @@ int onet_bn_relu_apply_pool_split(const float* z, int64_t z_bs, void* xs, int64_
     const int64_t blocks = (int64_t)B * (C / 8) * bpp;
     ONET_REQUIRE(blocks < (1ll << 31) && (int64_t)H * W < (1 << 24), "bn_relu_apply_pool_split: grid too large");
     hipLaunchKernelGGL(bn_relu_apply_pool_split_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), z, z_bs, (unsigned*)xs, xs_bs,
-                       a, a_bs, (unsigned*)ys, ys_bs, y, y_bs, save, C, H, W, bpp, nparts);
+                       a, a_bs, (unsigned*)ys, ys_bs, y, y_bs, save, C, H, W, bpp, nparts, (const unsigned*)act_amax);
     return check_launch("bn_relu_apply_pool_split_kernel");
 }
 

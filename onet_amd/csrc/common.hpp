@@ -119,7 +119,9 @@ int launch_wgrad_reduce(const float* slab, float* dw, int splitK, int taps, int 
 
 // convt_gemm.hip: DMA-fed 128 x 128 GEMMs of ConvTranspose2d(k=2, s=2); return 1 when the shape is outside their fast path
 int convt_gemm_fwd(const float* x, int64_t x_bs, const float* wq, const float* bias, float* y, int64_t y_bs, void* y16, int64_t y16_bs,
-                   int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int prec, hipStream_t st, int y16_split = 0);
+                   int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int prec, hipStream_t st, int y16_split = 0,
+                   const void* out_slots = nullptr);
+int convt_out_bound(const float* w, const float* bias, int Cin, int Ct, const void* x_slots, void* out_slots, hipStream_t st);
 int64_t convt_gemm_dbias_ws_bytes(int B, int Ct, int h, int w);
 int convt_gemm_dgrad(const float* dy, int64_t dy_bs, const float* wd, float* dx, int64_t dx_bs, float* dbias, float* dbias_ws, int B,
                      int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int prec, hipStream_t st);

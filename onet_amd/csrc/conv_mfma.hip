@@ -792,11 +792,17 @@ int onet_convT2x2_fwd_b(const float* x, int64_t x_bs, const float* wq, const flo
 // ... with the up-sampled tensor written PRE-SPLIT (fp16 hi | mid slots, conv_split.hip) into yP [B][Ct/8][Ho][2][Wo][8], e.g. the
 // up-sampled channel groups of a pre-split concat buffer (yP_bs: batch stride in 4-byte units); no fp32 output.  Fast path only:
 // returns 1 (nothing done) elsewhere.
-int onet_convT2x2_fwd_p(const float* x, int64_t x_bs, const float* wq, const float* bias, void* yP, int64_t yP_bs, int nparts, int B, int Cin,
-                        int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int operand_bf16, void* stream) {
+int onet_convT2x2_fwd_p(const float* x, int64_t x_bs, const float* wq, const float* bias, void* yP, int64_t yP_bs, const void* y_amax,
+                        int nparts, int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int operand_bf16, void* stream) {
     ONET_REQUIRE(x && wq && yP && B > 0 && Cin > 0 && Ct > 0 && h > 0 && w > 0 && (nparts == 1 || nparts == 2), "convT2x2_fwd_p: bad args");
     return convt_gemm_fwd(x, x_bs, wq, bias, nullptr, 0, yP, yP_bs, B, Cin, Ct, h, w, Ho, Wo, pt, pl, operand_bf16, as_stream(stream),
-                          nparts == 1 ? 2 : 1);
+                          nparts == 1 ? 2 : 1, y_amax);
+}
+
+// the bound of |ConvTranspose2d(x) + bias| from the weights (nn layout [Cin][Ct][2][2]) and the exact max |x| (x_amax), into y_amax
+int onet_convT2x2_out_bound(const float* w, const float* bias, int Cin, int Ct, const void* x_amax, void* y_amax, void* stream) {
+    ONET_REQUIRE(w && x_amax && y_amax && Cin > 0 && Ct > 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0, "convT2x2_out_bound: bad args");
+    return convt_out_bound(w, bias, Cin, Ct, x_amax, y_amax, as_stream(stream));
 }
 
 int onet_convT2x2_dgrad(const float* dy, int64_t dy_bs, const float* wp_dgrad, float* dx, int64_t dx_bs, int B,

@@ -625,6 +625,8 @@ struct SpPreArgs {
     float* stats;         // ST: BatchNorm partials (as conv3x3_split_kernel)
     const unsigned* x_slots;   // magnitude slots the producer scaled xs by (NULL: unscaled); x_always: the rule it used (amax_scale)
     int x_always;
+    const unsigned* x_slots2;  // a concat buffer has two producers: channels >= split_ch were scaled by these slots (NULL: unscaled)
+    int split_ch;              // 0: one group
 };
 
 #ifndef SP_PRE_LAST_TAP
@@ -661,9 +663,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_pre_kernel(SpPreArgs a) 
     const int nchunks = PM == 2 ? a.Cin >> 5 : a.Cin >> 4;
 
     const i32x4s wr = sp_rsrc4(a.wq, (int64_t)a.Cin * (PM == 2 ? 1 : 2) * 9 * a.Cout * 2);
-    float xs_inv = 1.f;
+    float xs_inv = 1.f, xs_inv2 = 1.f;
     (void)amax_scale(amax_read(a.x_slots), a.x_always != 0, xs_inv);
-    const float acc_scale = xs_inv * (F16 ? reinterpret_cast<const float*>(a.wq + (int64_t)a.Cin * 2 * 9 * a.Cout)[1] : 1.f);
+    (void)amax_scale(amax_read(a.x_slots2), a.x_always != 0, xs_inv2);
+    // two groups: sum = inv1 A1 + inv2 A2 = inv2 ((inv1 / inv2) A1 + A2): the accumulators are rescaled once, at the first chunk of
+    // group 2, by a power of two (1 in every ordinary network: nothing is done then)
+    const int split_chunk = a.split_ch ? (PM == 2 ? a.split_ch >> 5 : a.split_ch >> 4) : 0;
+    const float grp_ratio = split_chunk ? xs_inv / xs_inv2 : 1.f;
+    const float acc_scale = (split_chunk ? xs_inv2 : xs_inv) * (F16 ? reinterpret_cast<const float*>(a.wq + (int64_t)a.Cin * 2 * 9 * a.Cout)[1] : 1.f);
     const unsigned in_step = (unsigned)(16 * HW * 4), w_step = (unsigned)(2 * 9 * 2 * a.Cout * 16);
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_s;
 
@@ -743,6 +750,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_pre_kernel(SpPreArgs a) 
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
         for (int c = 0; c < nchunks; ++c) {
+            if (split_chunk && c == split_chunk && grp_ratio != 1.f) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[m][n][r] *= grp_ratio;
+            }
             const u32x4s* const ab = a_ptr + buf * BUF;
             const u32x4s* const bb = b_ptr + buf * BUF;
             u32x4s Aq[2][2][2], Bq[2][NB][2];
@@ -1319,6 +1334,8 @@ struct SwPreArgs {
     int B, Cin, Cout, H, W, ciTiles, coTiles, splitK, tilesX;
     const unsigned* x_slots;    // magnitude slots the producers scaled the operands by (NULL: unscaled); x: guard rule, dz: always
     const unsigned* dz_slots;
+    const unsigned* x_slots2;   // concat buffer: input channels >= split_ch (a multiple of 64) were scaled by these (NULL: unscaled)
+    int split_ch;
 };
 constexpr int SWP_PXP = 68;
 
@@ -1512,9 +1529,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_pre_kernel(SwPreAr
     }
 
     float x_inv = 1.f, dz_inv = 1.f;
-    (void)amax_scale(amax_read(a.x_slots), false, x_inv);
+    const unsigned* xsl = (a.split_ch && ci0 >= a.split_ch) ? a.x_slots2 : a.x_slots;      // this block's 64 input channels
+    (void)amax_scale(amax_read(xsl), false, x_inv);
     (void)amax_scale(amax_read(a.dz_slots), true, dz_inv);
-    const float out_scale = (a.x_slots ? x_inv : 1.f) * (a.dz_slots ? dz_inv : 1.f);
+    const float out_scale = (xsl ? x_inv : 1.f) * (a.dz_slots ? dz_inv : 1.f);
     const int64_t n = (int64_t)a.Cout * a.Cin;
     const int ci = ci0 + wn * 32 + l31;
 #pragma unroll
@@ -1623,9 +1641,10 @@ int onet_conv3x3_split_wgrad_pre_ok(int B, int Cin, int Cout, int H, int W) {
     return (W == 32 && B % 2 == 0) ? 1 : 0;
 }
 
-int onet_conv3x3_split_wgrad_pre(const void* xs, int64_t xs_bs, const void* x_amax, const void* dzs, int64_t dzs_bs, const void* dz_amax,
-                                 int f16, float* dw, void* ws, int64_t ws_bytes, int B, int Cin, int Cout, int H, int W, int accumulate,
-                                 void* stream) {
+int onet_conv3x3_split_wgrad_pre(const void* xs, int64_t xs_bs, const void* x_amax, const void* x_amax2, int split_ch, const void* dzs,
+                                 int64_t dzs_bs, const void* dz_amax, int f16, float* dw, void* ws, int64_t ws_bytes, int B, int Cin,
+                                 int Cout, int H, int W, int accumulate, void* stream) {
+    ONET_REQUIRE(split_ch >= 0 && split_ch < Cin && (split_ch % 64) == 0, "conv3x3_split_wgrad_pre: split_ch must be a multiple of 64 inside Cin");
     ONET_REQUIRE(xs && dzs && dw && ws, "conv3x3_split_wgrad_pre: null pointer");
     ONET_REQUIRE(onet_conv3x3_split_wgrad_pre_ok(B, Cin, Cout, H, W),
                  "conv3x3_split_wgrad_pre: needs Cin, Cout %% 8 == 0 and W >= 64, or W = 32 with an even batch");
@@ -1640,7 +1659,7 @@ int onet_conv3x3_split_wgrad_pre(const void* xs, int64_t xs_bs, const void* x_am
                  "conv3x3_split_wgrad_pre: on 32-pixel maps the whole batch must lie within the 2 GiB buffer-resource range");
     const int COT = split_wgrad_cot(Cout, W), slabs = COT == 64 ? 2 : 1;
     SwPreArgs a{xs, xs_bs, dzs, dzs_bs, (float*)ws, B, Cin, Cout, H, W, cdiv(Cin, 64), cdiv(Cout, COT), 1, 1, (const unsigned*)x_amax,
-                (const unsigned*)dz_amax};
+                (const unsigned*)dz_amax, (const unsigned*)x_amax2, split_ch};
     split_wgrad_plan(B, Cin, Cout, H, W, a.splitK, a.tilesX);
     const int64_t need = (int64_t)a.splitK * slabs * 9 * Cout * Cin * 4;
     ONET_REQUIRE(ws_bytes >= need, "conv3x3_split_wgrad_pre: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
@@ -1738,8 +1757,10 @@ int onet_split_pack_act(const float* x, int64_t x_bs, void* xs, int64_t xs_bs, i
     return check_launch("split_pack_act_kernel");
 }
 
-int onet_conv3x3_split_fwd_pre(const void* xs, int64_t xs_bs, const void* x_amax, int scale_always, const void* wq, int wq_f16, float* z,
-                               int64_t z_bs, float* part, int B, int Cin, int Cout, int H, int W, void* stream) {
+int onet_conv3x3_split_fwd_pre(const void* xs, int64_t xs_bs, const void* x_amax, int scale_always, const void* x_amax2, int split_ch,
+                               const void* wq, int wq_f16, float* z, int64_t z_bs, float* part, int B, int Cin, int Cout, int H, int W,
+                               void* stream) {
+    ONET_REQUIRE(split_ch >= 0 && split_ch < Cin && (split_ch % 32) == 0, "conv3x3_split_fwd_pre: split_ch must be a multiple of 32 inside Cin");
     ONET_REQUIRE(xs && wq && z, "conv3x3_split_fwd_pre: null pointer");
     ONET_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 16, "conv3x3_split_fwd_pre: bad shape (maps wider than 16 pixels)");
     ONET_REQUIRE((Cin % (wq_f16 == 2 ? 32 : 16)) == 0, "conv3x3_split_fwd_pre: Cin must be a multiple of 16 (32 for plain bf16 operands)");
@@ -1747,7 +1768,8 @@ int onet_conv3x3_split_fwd_pre(const void* xs, int64_t xs_bs, const void* x_amax
     ONET_REQUIRE(xs_bs >= (int64_t)Cin * H * W / (wq_f16 == 2 ? 2 : 1) && z_bs >= (int64_t)Cout * H * W, "conv3x3_split_fwd_pre: batch stride too small");
     ONET_REQUIRE((int64_t)(Cin + 32) * H * W * 4 < (1ll << 31) && (int64_t)(Cin + 32) * 2 * 9 * Cout * 2 < (1ll << 31),
                  "conv3x3_split_fwd_pre: operand exceeds the 2 GiB buffer-resource range");
-    SpPreArgs a{xs, xs_bs, (const __bf16*)wq, z, z_bs, B, Cin, Cout, H, W, 0, 0, 0, part, (const unsigned*)x_amax, scale_always};
+    SpPreArgs a{xs, xs_bs, (const __bf16*)wq, z, z_bs, B, Cin, Cout, H, W, 0, 0, 0, part, (const unsigned*)x_amax, scale_always,
+                (const unsigned*)x_amax2, split_ch};
     if (part) ONET_REQUIRE(split_nparts(B, H, W) > 0, "conv3x3_split_fwd_pre: statistics need a map made of full 16 x 32 tiles");
     if (wq_f16 == 2) return part ? launch_split_pre<true, 2>(a, as_stream(stream)) : launch_split_pre<false, 2>(a, as_stream(stream));
     if (wq_f16) return part ? launch_split_pre<true, 1>(a, as_stream(stream)) : launch_split_pre<false, 1>(a, as_stream(stream));

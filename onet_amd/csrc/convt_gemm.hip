@@ -141,6 +141,7 @@ struct GArgs {
     int mTiles, nTiles, splitK, chunksPerSplit;
     int out16_split;      // forward: out16 is NOT a bf16 copy but the PRE-SPLIT destination (fp16 hi | mid slots [B][Ct/8][Ho][2][Wo][8],
                           // conv_split.hip; out16_bs in 4-byte units): the up-sampled groups of a pre-split concat buffer
+    const unsigned* out_slots;   // ... whose fp16 parts are those of 2^k y, k = the guard exponent these magnitude slots select (NULL: k = 0)
 };
 
 __device__ __forceinline__ int xcd_order(int n) {
@@ -347,6 +348,8 @@ __global__ __launch_bounds__(256, 2) void convt_gemm_kernel(GArgs g) {
                     }
                     // out16_split == 2: plain bf16, one part (BASELINE configs[2]): [Ct/8][Ho][Wo][8]
                     const int np = g.out16_split == 2 ? 1 : 2;
+                    float s_inv;
+                    const float s_up = np == 1 ? 1.f : amax_scale(amax_read(g.out_slots), false, s_inv);
                     u32x4g* dst = reinterpret_cast<u32x4g*>(reinterpret_cast<unsigned*>(g.out16) + (int64_t)b * g.out16_bs) +
                                   ((int64_t)(c8 * (2 * g.h) + 2 * y + kh) * np) * g.Wo + 2 * x;
 #pragma unroll
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void convt_gemm_kernel(GArgs g) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             unsigned hh, mm;
-                            split2h_s(px[dj][2 * k], px[dj][2 * k + 1], 1.f, hh, mm);
+                            split2h_s(px[dj][2 * k], px[dj][2 * k + 1], s_up, hh, mm);
                             hi[k] = np == 1 ? g_pack(px[dj][2 * k], px[dj][2 * k + 1]) : hh;
                             mid[k] = mm;
                         }
@@ -579,7 +582,8 @@ namespace onet {
 
 // Fast-path predicates + launches; return ONET_NOT_TAKEN (1) when the shape is not taken (caller falls back to conv_mfma.hip)
 int convt_gemm_fwd(const float* x, int64_t x_bs, const float* wq, const float* bias, float* y, int64_t y_bs, void* y16, int64_t y16_bs,
-                   int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int prec, hipStream_t st, int y16_split) {
+                   int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int prec, hipStream_t st, int y16_split,
+                   const void* out_slots) {
     const int64_t hw = (int64_t)h * w;
     if (pt || pl || Ho != 2 * h || Wo != 2 * w || (Cin % KC) || (Ct % 32) || (hw % 128) || (w & 1) || !aligned16(x) || !aligned16(wq) ||
         (x_bs & 3) || (reinterpret_cast<uintptr_t>(y) & 7) || (y_bs & 1) || (int64_t)Cin * hw * 4 >= (1ll << 31) ||
@@ -588,13 +592,50 @@ int convt_gemm_fwd(const float* x, int64_t x_bs, const float* wq, const float* b
     if (y16 && !y16_split && ((reinterpret_cast<uintptr_t>(y16) & 3) || (y16_bs & 1))) return 1;
     if (y16 && y16_split && ((reinterpret_cast<uintptr_t>(y16) & 15) || (y16_bs & 3) || (Ct % 32))) return 1;
     if (!y && !y16) return 1;
-    GArgs g{wq, x, y, bias, nullptr, (__bf16*)y16, y16_bs, 0, x_bs, y_bs, B, Cin, Ct, h, w, Wo, Ho * Wo, (4 * Ct) / 128, (int)(B * hw / 128), 1, 0, y16_split};
+    GArgs g{wq, x, y, bias, nullptr, (__bf16*)y16, y16_bs, 0, x_bs, y_bs, B, Cin, Ct, h, w, Wo, Ho * Wo, (4 * Ct) / 128, (int)(B * hw / 128), 1, 0, y16_split, (const unsigned*)out_slots};
     const int64_t blocks = (int64_t)g.mTiles * g.nTiles;
     if (blocks <= 0 || blocks >= (1ll << 31)) return 1;
     if (prec == 2) hipLaunchKernelGGL((convt_gemm_kernel<0, 2>), dim3((unsigned)blocks), dim3(256), 0, st, g);
     else if (prec) hipLaunchKernelGGL((convt_gemm_kernel<0, 1>), dim3((unsigned)blocks), dim3(256), 0, st, g);
     else hipLaunchKernelGGL((convt_gemm_kernel<0, 0>), dim3((unsigned)blocks), dim3(256), 0, st, g);
     return check_launch("convt_gemm_kernel<0>");
+}
+
+// |y[co]| <= max over the four sub-pixel filters of sum_ci |W[ci][co][di][dj]| * max |x| + |bias[co]|: the bound of the up-sampled tensor
+// from the exact maximum of its input (x_slots) -- one block per output channel, atomicMax into the output's magnitude slots
+__global__ __launch_bounds__(256) void convt_out_bound_kernel(const float* __restrict__ w, const float* __restrict__ bias, int Cin, int Ct,
+                                                              const unsigned* __restrict__ x_slots, unsigned* __restrict__ out_slots) {
+    __shared__ float red[4][4];
+    const float xmax = amax_read(x_slots);
+    const int co = blockIdx.x;
+    float sm[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int ci = threadIdx.x; ci < Cin; ci += 256) {
+        const f32x4g v = *reinterpret_cast<const f32x4g*>(w + ((int64_t)ci * Ct + co) * 4);
+        sm[0] += fabsf(v[0]);
+        sm[1] += fabsf(v[1]);
+        sm[2] += fabsf(v[2]);
+        sm[3] += fabsf(v[3]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sm[k] += __shfl_xor(sm[k], o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = sm[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m = fmaxf(m, (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]));
+        const float bound = m * xmax * 1.00001f + (bias ? fabsf(bias[co]) : 0.f);
+        if (bound == bound) atomicMax(out_slots + (co & 63) * AMAX_STRIDE, __builtin_bit_cast(unsigned, bound));
+    }
+}
+
+int convt_out_bound(const float* w, const float* bias, int Cin, int Ct, const void* x_slots, void* out_slots, hipStream_t st) {
+    hipLaunchKernelGGL(convt_out_bound_kernel, dim3((unsigned)Ct), dim3(256), 0, st, w, bias, Cin, Ct, (const unsigned*)x_slots,
+                       (unsigned*)out_slots);
+    return check_launch("convt_out_bound_kernel");
 }
 
 int64_t convt_gemm_dbias_ws_bytes(int B, int Ct, int h, int w) { return (int64_t)B * h * w / 128 * Ct * 4; }

@@ -169,8 +169,9 @@ class ConvBNReLUFn(torch.autograd.Function):
         if link_out is not None:
             link_out.pop("defer", None)
         xP = p16.get("x")
+        x_slots = p16.get("x_slots") if xP is not None else None
         if xP is not None:
-            z, cm = ops.conv3x3_pre_bn_partials(xP, packed)
+            z, cm = ops.conv3x3_pre_bn_partials(xP, packed, x_slots)
         else:
             z, cm = ops.conv3x3_fwd_bn_partials(x, packed) if training else (ops.conv3x3_auto(x, packed, 0), None)
         G = groups if (training and groups > 1) else 1
@@ -185,6 +186,12 @@ class ConvBNReLUFn(torch.autograd.Function):
             if aP is None:
                 aP = ops.p16_empty(Bz, C, Hz, Wz, z.device)
         a = torch.empty_like(z) if keep else ops.fp32_placeholder(z.shape, z.device)
+        # magnitude slots: of a pre-split output the BOUND |gamma| sqrt(N - 1) + |beta| (written by the statistics finalize, before
+        # the pass that needs it as the guard scale); of an fp32-only output the exact maximum (recorded by the pass that writes
+        # it: what bounds a ConvTranspose2d's pre-split output downstream)
+        parts2 = ops.p16_parts() == 2
+        act_slots = ops.new_amax(z.device) if (want and parts2 and training) else None
+        a_amax = ops.new_amax(z.device) if (not want and parts2) else None
         pooled = None
         if want_pool is not None and Hz % 2 == 0 and Wz % 2 == 0:
             if want_pool.get("p16"):
@@ -197,7 +204,7 @@ class ConvBNReLUFn(torch.autograd.Function):
             if training:
                 npg = 0 if cm is None else cm.shape[1] // G
                 ops.bn_train_coeffs(zg, gamma, beta, running_mean, running_var, momentum, eps,
-                                    cm=None if cm is None else (cm, g * npg, npg), save=save_all[g])
+                                    cm=None if cm is None else (cm, g * npg, npg), save=save_all[g], act_slots=act_slots)
             else:
                 ops.bn_eval_coeffs(gamma, beta, running_mean, running_var, eps, save=save_all[g])
         for g in range(G):
@@ -205,13 +212,14 @@ class ConvBNReLUFn(torch.autograd.Function):
             if pooled is not None:
                 if not ops.bn_relu_apply_pool_split(z[sl], save_all[g], None if aP is None else aP[sl], a[sl] if keep else None,
                                                     None if pooled[2] is None else pooled[2][sl],
-                                                    None if pooled[0] is None else pooled[0][sl]):
+                                                    None if pooled[0] is None else pooled[0][sl], slots=act_slots):
                     raise RuntimeError("onet_amd: pre-split BatchNorm + pooling pass refused a shape ops.pre_layer_ok accepted")
             elif aP is not None:
-                ops.bn_relu_apply_split(z[sl], save_all[g], aP[sl], a=a[sl] if keep else None)
+                ops.bn_relu_apply_split(z[sl], save_all[g], aP[sl], a=a[sl] if keep else None, slots=act_slots)
             else:
-                ops.bn_relu_apply(z[sl], save_all[g], out=a[sl])
-        p16["a"] = aP
+                ops.bn_relu_apply(z[sl], save_all[g], out=a[sl], amax=a_amax)
+        p16["a"], p16["a_slots"], p16["a_amax"] = aP, act_slots, a_amax
+        ctx.x_slots = x_slots
         ctx.save_for_backward(x, z, save_all, xP)
         ctx.pre = True
         ctx.training = training
@@ -263,7 +271,9 @@ class ConvBNReLUFn(torch.autograd.Function):
             return (dx, dw, (dgamma if need_g else None), (dbeta if need_b else None)) + nones
         dzP, dz_slots, dgamma, dbeta = ops.bn_relu_bwd_split(da, z, save_all, ctx.training, need_affine_grads=(need_g or need_b),
                                                              affine_out=aff, rec4=rec4, da_amax=da_amax)
-        dw = ops.conv3x3_split_wgrad_pre(xP, dzP, ctx.wshape, out=ops.grad_slot_if_free(pw), dz_slots=dz_slots) if need_w else None
+        s1, s2, sc = ops._slots3(getattr(ctx, "x_slots", None))
+        dw = ops.conv3x3_split_wgrad_pre(xP, dzP, ctx.wshape, out=ops.grad_slot_if_free(pw), x_slots=s1, dz_slots=dz_slots, x_slots2=s2,
+                                         split_ch=sc) if need_w else None
         dpack = ctx.packed.get_pack("split" if dzP.shape[3] == 2 else "plain16")[1]
         dx = ops.conv3x3_split_pre(dzP, dpack, ctx.wshape[1], slots=dz_slots, always=dz_slots is not None) if need_x else None
         return (dx, dw, (dgamma if need_g else None), (dbeta if need_b else None)) + nones
@@ -485,7 +495,9 @@ class UpConvTCatFn(torch.autograd.Function):
             catP = p16["catP"]
             assert (Ho, Wo) == (2 * h, 2 * w) and catP.shape[1] * 8 == C2 + Ct and C2 % 8 == 0
             # the GEMM's epilogue writes whole pre-split slots; shapes outside its fast path: fp32 + one conversion pass
-            if not ops.convT2x2_fwd_p(x1, wp_fused, bias, catP[:, C2 // 8:], Ct, pt, pl):
+            if not ops.convT2x2_fwd_p(x1, wp_fused, bias, catP[:, C2 // 8:], Ct, pt, pl, slots=p16.get("up_slots")):
+                if p16.get("up_slots") is not None:
+                    raise RuntimeError("onet_amd: scaled pre-split ConvTranspose2d output outside the GEMM fast path")
                 up = torch.empty((B, Ct, Ho, Wo), dtype=torch.float32, device=x1.device)
                 ops.convT2x2_fwd(x1, wp_fused, bias, up, Ct, pt, pl)
                 ops.split_pack_act(up, out=catP[:, C2 // 8:])

@@ -127,7 +127,9 @@ class DoubleConv(nn.Module):
         if b16 is not None:
             ops.tag_b16(a, b16.get("a16"))
         if p16 is not None:
-            ops.tag_p16(a, p16.get("a"))            # pre-split storage: the output's pre-split form rides on it
+            ops.tag_p16(a, p16.get("a"), p16.get("a_slots"))      # pre-split storage: the output's pre-split form (+ its scale slots) rides on it
+            if p16.get("a_amax") is not None:
+                return ops.tag_amax(a, p16["a_amax"])
         return ops.tag_amax(a, aux.get("a_amax"))
 
     def forward(self, x, out=None, groups=1, pool_link=None, out16=None, p16_out=None):
@@ -147,9 +149,10 @@ class DoubleConv(nn.Module):
             if xP is not None or pre2 or p16_out is not None:
                 if xP is None and ops.is_placeholder(x):
                     raise RuntimeError("onet_amd: a tensor kept only pre-split reached a DoubleConv without its pre-split form")
-                p1 = {"x": xP, "want": pre2}
+                p1 = {"x": xP, "x_slots": ops.p16_slots(x), "want": pre2}
                 a1 = self._unit(x, s[0], s[1], None, groups, link_out=link, p16=p1)
-                p2 = {"x": p1.get("a"), "want": p16_out is not None, "out": None if p16_out is None else p16_out.get("out"),
+                p2 = {"x": p1.get("a"), "x_slots": p1.get("a_slots"), "want": p16_out is not None,
+                      "out": None if p16_out is None else p16_out.get("out"),
                       "keep_fp32": True if p16_out is None else bool(p16_out.get("keep_fp32"))}
                 return self._unit(a1, s[3], s[4], None, groups, link_out=pool_link, link_in=link, p16=p2)
         # bf16 storage: unit 1's output feeds unit 2's convolution only -- where that reads the bf16 copy (forward and weight
@@ -237,9 +240,13 @@ class Up(nn.Module):
         skip outputs there, so torch.cat's copy of the skip tensor, OV:100, never happens); `cat16`: its bf16 twin (bf16
         storage), skip half already written; `catP` (pre-split storage): the pre-split concat buffer, skip groups already written."""
         if isinstance(self.up, ConvT2x2) and catP is not None:
-            p16 = {"catP": catP}
+            # scales of the two producers of the concat buffer: the skip groups' (the encoder's BatchNorm bound), the up-sampled groups'
+            # (a bound from this layer's weights and the exact maximum of x1, where its producer recorded one)
+            s_skip, x1_amax = ops.p16_slots(x2), ops.amax_of(x1)
+            s_up = ops.convT2x2_out_bound(self.up.weight, self.up.bias, x1_amax) if (x1_amax is not None and catP.shape[3] == 2) else None
+            p16 = {"catP": catP, "up_slots": s_up}
             x = Fn.UpConvTCatFn.apply(x1, x2, self.up.weight, self.up.bias, self.up.packed(), None, None, p16)
-            ops.tag_p16(x, catP)
+            ops.tag_p16(x, catP, (s_skip, s_up, x2.shape[1]) if (s_skip is not None or s_up is not None) else None)
             return self.conv(x, groups=groups)
         if isinstance(self.up, ConvT2x2):
             dc = self.conv.double_conv[0]
@@ -356,7 +363,8 @@ class UNet(nn.Module):
                 outs = Fn.SkipPoolFn.apply(t, returned, link, b16)
                 if b16 is not None:
                     ops.tag_b16(outs[1], b16.get("y16"))     # the pooled tensor's bf16 copy, for the next block's first conv
-                    ops.tag_p16(outs[1], b16.get("yP"))      # ... or its pre-split form (pre-split storage)
+                    ops.tag_p16(outs[1], b16.get("yP"), ops.p16_slots(t))    # ... or its pre-split form (max-pooling keeps the bound)
+                    ops.tag_p16(outs[0], ops.p16_of(t), ops.p16_slots(t))     # the skip view keeps the tensor's pre-split form
                 ops.tag_amax(outs[1], am)                    # max-pooling keeps the maximum: the same slots bound the pooled tensor
                 return outs
             return (t, None, t) if returned else (t, None)

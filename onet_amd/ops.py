@@ -373,7 +373,16 @@ def convT2x2_fwd(x, wq, bias, out, Ct, pt, pl, out16=None):
     return False
 
 
-def convT2x2_fwd_p(x, wq, bias, outP, Ct, pt, pl):
+def convT2x2_out_bound(weight, bias, x_amax):
+    """Magnitude slots bounding |ConvTranspose2d(x) + bias| from the layer's weights and the exact max |x| its producer recorded."""
+    w = weight.detach()
+    w = w if w.is_contiguous() else w.contiguous()
+    slots = new_amax(w.device)
+    _lib.call("onet_convT2x2_out_bound", _p(w), _p(bias), w.shape[0], w.shape[1], _p(x_amax), _p(slots), _stream())
+    return slots
+
+
+def convT2x2_fwd_p(x, wq, bias, outP, Ct, pt, pl, slots=None):
     """ConvTranspose2d(k=2, s=2) + bias written PRE-SPLIT into outP [B, Ct/8, Ho, 2, Wo, 8] (the up-sampled channel groups of a pre-split
     concat buffer): no fp32 tensor.  -> False where the GEMM fast path does not take the shape (nothing written)."""
     require_gpu(x, wq)
@@ -381,7 +390,7 @@ def convT2x2_fwd_p(x, wq, bias, outP, Ct, pt, pl):
     B, Cin, h, w = x.shape
     Ho, Wo = outP.shape[2], outP.shape[4]
     e0 = _prof_begin()
-    rc = _lib.load().onet_convT2x2_fwd_p(_p(x), xbs, _p(wq), _p(bias), _p(outP), _pbs(outP), outP.shape[3], B, Cin, Ct, h, w, Ho, Wo, pt, pl,
+    rc = _lib.load().onet_convT2x2_fwd_p(_p(x), xbs, _p(wq), _p(bias), _p(outP), _pbs(outP), _p(slots), outP.shape[3], B, Cin, Ct, h, w, Ho, Wo, pt, pl,
                                          convt_operand_bf16(B, h, w, Ct), _stream())
     flops, nb = 2.0 * B * h * w * Cin * 4 * Ct, 4.0 * (B * h * w * (Cin + 4 * Ct) + 4 * Cin * Ct)
     _prof_end("convt_gemm_kernel", flops if rc == 0 else 0.0, e0, nb if rc == 0 else 0.0)
@@ -937,7 +946,7 @@ def split_pack_act(x, f16=True, scale=1.0, out=None, parts=2):
     return out
 
 
-def conv3x3_split_pre(xs, wq, Cout, out=None, slots=None, always=False, stats=None):
+def conv3x3_split_pre(xs, wq, Cout, out=None, slots=None, always=False, stats=None, slots2=None, split_ch=0):
     """z = conv3x3 of a PRE-SPLIT activation xs [B, Cin/8, H, 2, W, 8] (split_pack_act / the producers' fused variants) with the split
     weight pack wq: the arithmetic of conv3x3_split, staging by LDS-DMA.  slots / always: the magnitude slots and rule the producer
     scaled xs by (undone by the kernel; None: unscaled)."""
@@ -949,13 +958,15 @@ def conv3x3_split_pre(xs, wq, Cout, out=None, slots=None, always=False, stats=No
     if out is None:
         out = torch.empty((B, Cout, H, W), dtype=F32, device=xs.device)
     e0 = _prof_begin()
-    _lib.call("onet_conv3x3_split_fwd_pre", _p(xs), xs.stride(0) // 2 if B > 1 else Cin * H * W, _p(slots), int(always), _p(wq), f16, _p(out),
+    _lib.call("onet_conv3x3_split_fwd_pre", _p(xs), _pbs(xs), _p(slots), int(always), _p(slots2), int(split_ch if slots2 is not None or slots is not None else 0),
+              _p(wq), f16, _p(out),
               out.stride(0) if B > 1 else Cout * H * W, _p(stats), B, Cin, Cout, H, W, _stream())
-    _prof_end("conv3x3_split_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
+    _prof_end("conv3x3_split_pre_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0,
+              B * H * W * (2.0 * two * Cin + 4.0 * Cout) + 2.0 * two * 9 * Cin * Cout)
     return out
 
 
-def conv3x3_split_wgrad_pre(xs, dzs, dw_shape, out=None, x_slots=None, dz_slots=None):
+def conv3x3_split_wgrad_pre(xs, dzs, dw_shape, out=None, x_slots=None, dz_slots=None, x_slots2=None, split_ch=0):
     """Weight gradient of a 3x3 convolution from PRE-SPLIT x and dz (split_pack_act layout, same 16-bit type):
     conv3x3_split_wgrad's arithmetic with LDS-DMA staging and transposed fragment reads; x_slots / dz_slots: the magnitude slots the
     producers scaled the operands by (undone on the result)."""
@@ -968,10 +979,11 @@ def conv3x3_split_wgrad_pre(xs, dzs, dw_shape, out=None, x_slots=None, dz_slots=
     need = _lib.load().onet_conv3x3_split_wgrad_ws_bytes(B, Cin, Cout, H, W)
     ws = workspace(need, xs.device)
     e0 = _prof_begin()
-    _lib.call("onet_conv3x3_split_wgrad_pre", _p(xs), xs.stride(0) // 2 if B > 1 else Cin * H * W, _p(x_slots), _p(dzs),
-              dzs.stride(0) // 2 if B > 1 else Cout * H * W, _p(dz_slots), 2 if two == 1 else int(xs.dtype == torch.float16), _p(dw), _p(ws),
+    _lib.call("onet_conv3x3_split_wgrad_pre", _p(xs), _pbs(xs), _p(x_slots), _p(x_slots2), int(split_ch), _p(dzs),
+              _pbs(dzs), _p(dz_slots), 2 if two == 1 else int(xs.dtype == torch.float16), _p(dw), _p(ws),
               ws.numel() * 4, B, Cin, Cout, H, W, 0, _stream())
-    _prof_end("conv3x3_split_wgrad_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
+    _prof_end("conv3x3_split_wgrad_pre_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0,
+              2.0 * two * B * H * W * (Cin + Cout) + 4.0 * 9 * Cin * Cout)
     return dw
 
 
@@ -1007,14 +1019,29 @@ def p16_of(t):
     tag = getattr(t, "_onet_p16", None)
     if tag is None:
         return None
-    P, ver = tag
-    return P if ver == t._version else None
+    return tag[0] if tag[1] == t._version else None
 
 
-def tag_p16(t, P):
+def p16_slots(t):
+    """The magnitude slots the pre-split form of `t` was scaled by: None (unscaled), one set, or (skip set, up-sampled set, first
+    channel of the second group) for a concat buffer with two producers."""
+    tag = getattr(t, "_onet_p16", None)
+    if tag is None or tag[1] != t._version:
+        return None
+    return tag[2]
+
+
+def tag_p16(t, P, slots=None):
     if P is not None and t is not None:
-        t._onet_p16 = (P, t._version)
+        t._onet_p16 = (P, t._version, slots)
     return t
+
+
+def _slots3(info):
+    """-> (slots of the first group | None, slots of the second group | None, first channel of the second group or 0)"""
+    if isinstance(info, tuple):
+        return info
+    return info, None, 0
 
 
 def _pbs(P):
@@ -1022,16 +1049,17 @@ def _pbs(P):
     return P.stride(0) // 2 if P.shape[0] > 1 else P.shape[1] * P.shape[2] * P.shape[3] * P.shape[4] * 4
 
 
-def bn_relu_apply_split(z, save, xs, a=None):
+def bn_relu_apply_split(z, save, xs, a=None, slots=None):
     """relu(bn(z)) written pre-split into xs [B, C/8, H, 2, W, 8] (a whole tensor or the leading channel groups of a concat buffer)
-    and, when `a` is given, in fp32 too.  The same values, bit for bit, as bn_relu_apply."""
+    and, when `a` is given, in fp32 too.  The same values, bit for bit, as bn_relu_apply (times the power of two the magnitude
+    slots select -- 1 unless the activation's bound reaches 2^15)."""
     z, zbs = plane(z)
     B, C, H, W = z.shape
     _lib.call("onet_bn_relu_apply_split", _p(z), zbs, _p(xs), _pbs(xs), _p(a), 0 if a is None else (a.stride(0) if B > 1 else C * H * W),
-              _p(save), xs.shape[3], B, C, H, W, _stream(), nbytes=(4 + 2 * xs.shape[3] + 4 * (a is not None)) * z.numel())
+              _p(save), _p(slots), xs.shape[3], B, C, H, W, _stream(), nbytes=(4 + 2 * xs.shape[3] + 4 * (a is not None)) * z.numel())
 
 
-def bn_relu_apply_pool_split(z, save, xs, a, ys, y):
+def bn_relu_apply_pool_split(z, save, xs, a, ys, y, slots=None):
     """relu(bn(z)) and its 2 x 2 max-pooling in one pass: the activation pre-split (xs) and / or fp32 (a), the pooled tensor pre-split
     (ys) or fp32 (y).  -> False where the kernel does not take the shape."""
     z, zbs = plane(z)
@@ -1039,7 +1067,7 @@ def bn_relu_apply_pool_split(z, save, xs, a, ys, y):
     n, m = C * H * W, C * (H // 2) * (W // 2)
     rc = _lib.load().onet_bn_relu_apply_pool_split(_p(z), zbs, _p(xs), 0 if xs is None else _pbs(xs), _p(a),
                                                   0 if a is None else (a.stride(0) if B > 1 else n), _p(ys), 0 if ys is None else _pbs(ys),
-                                                  _p(y), 0 if y is None else (y.stride(0) if B > 1 else m), _p(save),
+                                                  _p(y), 0 if y is None else (y.stride(0) if B > 1 else m), _p(save), _p(slots),
                                                   (xs if xs is not None else ys).shape[3] if (xs is not None or ys is not None) else 2,
                                                   B, C, H, W, _stream())
     if rc < 0:
@@ -1047,14 +1075,16 @@ def bn_relu_apply_pool_split(z, save, xs, a, ys, y):
     return rc == 0
 
 
-def conv3x3_pre_bn_partials(xP, pk):
-    """conv3x3_fwd_bn_partials for a pre-split input: -> (z, cm) with the BatchNorm statistics records of the epilogue."""
+def conv3x3_pre_bn_partials(xP, pk, slots=None):
+    """conv3x3_fwd_bn_partials for a pre-split input: -> (z, cm) with the BatchNorm statistics records of the epilogue.
+    slots: what xP's producer(s) scaled it by (p16_slots)."""
     B, C8, H, np_, W, _ = xP.shape
     Co = pk["Cout"]
     wq = pk.get_pack("split" if np_ == 2 else "plain16")[0]
     nparts = int(_lib.load().onet_conv3x3_split_nparts(B, H, W))
     cm = torch.empty((Co, nparts, 3), dtype=F32, device=xP.device) if nparts > 0 else None
-    return conv3x3_split_pre(xP, wq, Co, stats=cm), cm
+    s1, s2, sc = _slots3(slots)
+    return conv3x3_split_pre(xP, wq, Co, slots=s1, stats=cm, slots2=s2, split_ch=sc), cm
 
 
 def bn_relu_bwd_split(da, z, save_all, training, need_affine_grads=True, affine_out=None, rec=None, rec4=None, da_amax=None):
@@ -1367,7 +1397,7 @@ def _bn_nparts(B, HW):
     return B * max(1, (HW + 16383) // 16384)
 
 
-def bn_train_coeffs(z, gamma, beta, running_mean, running_var, momentum, eps, cm=None, save=None):
+def bn_train_coeffs(z, gamma, beta, running_mean, running_var, momentum, eps, cm=None, save=None, act_slots=None):
     """batch statistics -> save [4][C] = (mean, invstd, scale, shift); updates running stats in place.
     `cm` = (records [C, NP, 3], first, count): the convolution already produced this batch's statistics records
     (`conv3x3_fwd_bn_partials`), records first .. first+count-1 of every channel belong to `z`."""
@@ -1380,6 +1410,10 @@ def bn_train_coeffs(z, gamma, beta, running_mean, running_var, momentum, eps, cm
         assert rec.shape[0] == C and rec.shape[2] == 3 and 0 <= first and first + count <= rec.shape[1]
         if save is None:
             save = torch.empty((4, C), dtype=F32, device=z.device)
+        if act_slots is not None:      # ... also the bound of relu(bn(z)) into the activation's magnitude slots (pre-split storage)
+            _lib.call("onet_bn_finalize_cm_act", rec.data_ptr() + first * 12, count, rec.shape[1] * 3, _p(gamma), _p(beta),
+                      _p(running_mean), _p(running_var), float(momentum), float(eps), _p(save), _p(act_slots), C, _stream())
+            return save
         _lib.call("onet_bn_finalize_cm", rec.data_ptr() + first * 12, count, rec.shape[1] * 3, _p(gamma), _p(beta),
                   _p(running_mean), _p(running_var), float(momentum), float(eps), _p(save), C, _stream())
         return save
@@ -1390,6 +1424,10 @@ def bn_train_coeffs(z, gamma, beta, running_mean, running_var, momentum, eps, cm
     nparts *= world
     if save is None:
         save = torch.empty((4, C), dtype=F32, device=z.device)
+    if act_slots is not None:
+        _lib.call("onet_bn_finalize_act", _p(part), nparts, B * H * W * world, _p(gamma), _p(beta), _p(running_mean),
+                  _p(running_var), float(momentum), float(eps), _p(save), _p(act_slots), C, _stream())
+        return save
     _lib.call("onet_bn_finalize", _p(part), nparts, B * H * W * world, _p(gamma), _p(beta), _p(running_mean),
               _p(running_var), float(momentum), float(eps), _p(save), C, _stream())
     return save

@@ -366,7 +366,7 @@ def test_bf16_path_every_gradient_element_vs_routed_rounded_oracle(dev, tag, ker
         prof, _ = ops.profile_stop()
     replay = finish_ops()
     if kernels == "presplit":
-        assert len(prof.get("conv3x3_split_kernel", [])) >= 10 and len(prof.get("conv3x3_split_wgrad_kernel", [])) >= 5, {k: len(v) for k, v in prof.items()}
+        assert len(prof.get("conv3x3_split_pre_kernel", [])) >= 10 and len(prof.get("conv3x3_split_wgrad_pre_kernel", [])) >= 5, {k: len(v) for k, v in prof.items()}
     else:
         assert len(prof.get("conv3x3_bf16_kernel", [])) >= 24 and len(prof.get("conv3x3_wgrad_bf16_kernel", [])) >= 12, {k: len(v) for k, v in prof.items()}
     with orc.operand_rounding(_bf16_rule, replay):
