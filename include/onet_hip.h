@@ -225,7 +225,9 @@ int onet_conv3x3_split_fwd_pre(const void* xs, int64_t xs_bs, const void* x_amax
 /* Weight gradient (OV:47,51 backward) from pre-split x and dz (both in the slot layout, same 16-bit type): fragments by the gfx950
  * transposing LDS read, staging by LDS-DMA; the producers' power-of-two scales (x_amax: guard rule, dz_amax: always; NULL:
  * unscaled) are undone on the slabs; deterministic split-K through ws
- * (onet_conv3x3_split_wgrad_ws_bytes).  _ok: W >= 64, or W = 32 with an even batch; Cin, Cout multiples of 8. */
+ * (onet_conv3x3_split_wgrad_ws_bytes).  _ok: W >= 64, or W = 32 / 16 with the batch a multiple of 2 / 4; Cin, Cout multiples of 8.
+ * _fwd_pre also takes maps exactly 16 pixels wide (even batch, H % 16 == 0): two images side by side per tile. */
+int onet_conv3x3_split_pre_nparts(int B, int H, int W);    /* statistics records of _fwd_pre (16-pixel-wide maps: one per image pair) */
 int onet_conv3x3_split_wgrad_pre_ok(int B, int Cin, int Cout, int H, int W);
 int onet_conv3x3_split_wgrad_pre(const void* xs, int64_t xs_bs, const void* x_amax, const void* x_amax2, int split_ch, const void* dzs,
                                  int64_t dzs_bs, const void* dz_amax, int f16, float* dw, void* ws, int64_t ws_bytes, int B, int Cin,

@@ -635,13 +635,26 @@ struct SpPreArgs {
 // PM: 0 = bf16 (hi | mid) parts, 1 = fp16 (hi | mid) parts -- three MFMAs per term on 16-channel chunks; 2 = PLAIN bf16 operands
 // (BASELINE configs[2]'s bf16 MFMA conv path: xs [B][C/8][H][W][8] bf16, one part): the same LDS image and DMA schedule with the
 // "part" index standing for the second 16 channels of a 32-channel chunk, two MFMAs per term (one per 16 channels).
-template <bool ST, int PM>
+// W16: maps 16 pixels wide (the U-Net's 16-pixel level): a tile's 32 pixel columns are TWO IMAGES side by side, each with its own halo
+// columns in the LDS image (18 + 18 columns), so a horizontal tap never reads the neighbour image; a.B counts image PAIRS.
+template <bool W16> struct SpPreCfg {
+    static constexpr int NW = 8, NT = 2, TW = 32, CO_T = 64, ROWS = NW * NT;
+    static constexpr int IN_ROWS = ROWS + 2, IN_COLS = W16 ? 36 : 34;
+    static constexpr int NPIX = IN_ROWS * IN_COLS;                      // 612 / 648 halo pixels
+    static constexpr int NPIXP = W16 ? 656 : 640;                       // pixel slots per half (4 NPIXP = whole 64-slot DMA pieces)
+    static constexpr int W_PART = 9 * 2 * CO_T, W_SLOTS = 2 * W_PART, NWI = (W_SLOTS + 511) / 512;
+    static constexpr int IN_PART = 2 * NPIXP;
+    static constexpr int BUF_SLOTS = W_SLOTS + 2 * IN_PART;             // 76 / 77 KB
+    static constexpr int LDS_BYTES = 2 * BUF_SLOTS * 16;
+    static constexpr int NB = (NT - 1) + 3;
+};
+template <bool ST, int PM, bool W16>
 __global__ __launch_bounds__(512, 2) void conv3x3_split_pre_kernel(SpPreArgs a) {
     constexpr bool F16 = PM == 1;
-    using C = SpCfg;
+    using C = SpPreCfg<W16>;
     constexpr int NT = C::NT, IN_COLS = C::IN_COLS, NWI = C::NWI, CO_T = C::CO_T, NPIXP = C::NPIXP, NB = C::NB;
     constexpr int BUF = C::BUF_SLOTS, W_PART = C::W_PART, IN_PART = C::IN_PART, ROWS = C::ROWS, TW = C::TW;
-    constexpr int NII = (2 * IN_PART) / 512;                           // 5 input DMA rounds per wave and chunk (2560 slot positions)
+    constexpr int NII = (2 * IN_PART + 511) / 512;                     // 5 (6) input DMA rounds per wave and chunk (2560 / 2624 slot positions)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
     u32x4s* lds = reinterpret_cast<u32x4s*>(smem_s);                   // [2 buffers][weights hi|mid | input hi|mid]
 
@@ -690,16 +703,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_pre_kernel(SpPreArgs a) 
         const int ty = v % a.tilesY;
         const int b = v / a.tilesY;
         const int y0 = ty * ROWS, x0 = tx * TW;
-        xr = sp_rsrc4(reinterpret_cast<const unsigned*>(a.xs) + (int64_t)b * a.xs_bs, (int64_t)a.Cin * HW * (PM == 2 ? 2 : 4));
+        // (W16: b is the image PAIR; the resource spans both images, the second one's offset rides in the lane's byte offset)
+        xr = sp_rsrc4(reinterpret_cast<const unsigned*>(a.xs) + (int64_t)(W16 ? 2 * b : b) * a.xs_bs,
+                      (W16 ? a.xs_bs * 4 : 0) + (int64_t)a.Cin * HW * (PM == 2 ? 2 : 4));
 #pragma unroll
         for (int k = 0; k < NII; ++k) {
             const int i = (wn + 8 * k) * 64 + lane;
             const int ph = i / NPIXP, pix = i % NPIXP;                 // ph = part * 2 + half (PM 2: the chunk's channel group 0 .. 3)
             const int r = pix / IN_COLS, c = pix % IN_COLS;
-            const int yy = y0 - 1 + r, xx = x0 - 1 + c;
-            const bool ok = live && pix < C::NPIX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-            in_off[k] = !ok ? OOB_S : PM == 2 ? (unsigned)(((ph * a.H + yy) * a.W + xx) * 16)
-                                              : (unsigned)(((((ph & 1) * a.H + yy) * 2 + (ph >> 1)) * a.W + xx) * 16);
+            const int img = W16 ? c / 18 : 0;
+            const int yy = y0 - 1 + r, xx = W16 ? c % 18 - 1 : x0 - 1 + c;
+            const bool ok = live && i < 2 * IN_PART && pix < C::NPIX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+            const unsigned io = W16 ? (unsigned)(img * a.xs_bs * 4) : 0u;
+            in_off[k] = !ok ? OOB_S : PM == 2 ? io + (unsigned)(((ph * a.H + yy) * a.W + xx) * 16)
+                                              : io + (unsigned)(((((ph & 1) * a.H + yy) * 2 + (ph >> 1)) * a.W + xx) * 16);
         }
 #pragma unroll
         for (int k = 0; k < NWI; ++k) {
@@ -722,7 +739,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_pre_kernel(SpPreArgs a) 
     };
     // piece k of the chunk the staging state points at, into chunk buffer `buf`
     auto dma_in = [&](int buf, int k) __attribute__((always_inline)) {
-        sp_dma16(xr, lds0 + (unsigned)((buf * BUF + C::W_SLOTS + (wn + 8 * k) * 64) * 16), in_off[k], cin_bytes);
+        if ((wn + 8 * k) * 64 < 2 * IN_PART)
+            sp_dma16(xr, lds0 + (unsigned)((buf * BUF + C::W_SLOTS + (wn + 8 * k) * 64) * 16), in_off[k], cin_bytes);
     };
     auto dma_w = [&](int buf, int k) __attribute__((always_inline)) {
         if (k < NWI - 1 || wn < (C::W_SLOTS - 512 * (NWI - 1)) / 64)
@@ -730,7 +748,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_pre_kernel(SpPreArgs a) 
     };
 
     const u32x4s* const a_ptr = lds + kh * CO_T + l31;
-    const u32x4s* const b_ptr = lds + C::W_SLOTS + kh * NPIXP + (wn * NT) * IN_COLS + l31;
+    const u32x4s* const b_ptr = lds + C::W_SLOTS + kh * NPIXP + (wn * NT) * IN_COLS + (W16 ? (l31 >> 4) * 18 + (l31 & 15) : l31);
 
     setup_stage();
 #pragma unroll
@@ -896,8 +914,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_pre_kernel(SpPreArgs a) 
             }
             __syncthreads();
         }
-        float* zb = a.z + (int64_t)b * a.z_bs;
-        const int xo = x0 + l31;
+        float* zb = a.z + (int64_t)(W16 ? 2 * b + (l31 >> 4) : b) * a.z_bs;      // (W16: b is the image pair, lanes 16-31 hold the second image)
+        const int xo = W16 ? (l31 & 15) : x0 + l31;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -914,16 +932,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_pre_kernel(SpPreArgs a) 
     }
 }
 
-template <bool ST, int PM>
+template <bool ST, int PM, bool W16>
 int launch_split_pre(SpPreArgs a, hipStream_t st) {
-    using C = SpCfg;
+    using C = SpPreCfg<W16>;
     const int LDS_BYTES = C::LDS_BYTES + (ST ? C::NW * 64 * 2 * 4 : 0);
-    a.tilesX = cdiv(a.W, C::TW);
+    a.tilesX = W16 ? 1 : cdiv(a.W, C::TW);
     a.tilesY = cdiv(a.H, C::ROWS);
     a.coTiles = cdiv(a.Cout, C::CO_T);
+    if (W16) a.B /= 2;                               // tiles hold image pairs
     const int64_t tiles = (int64_t)a.B * a.tilesX * a.tilesY * a.coTiles;
     ONET_REQUIRE(tiles > 0 && tiles < (1ll << 31), "conv3x3_split_pre: tile count %lld out of range", (long long)tiles);
-    auto kern = conv3x3_split_pre_kernel<ST, PM>;
+    auto kern = conv3x3_split_pre_kernel<ST, PM, W16>;
     static PerDeviceOnce attr_once;
     if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -1337,7 +1356,7 @@ struct SwPreArgs {
     const unsigned* x_slots2;   // concat buffer: input channels >= split_ch (a multiple of 64) were scaled by these (NULL: unscaled)
     int split_ch;
 };
-constexpr int SWP_PXP = 68;
+constexpr int SWP_PXP = 68;          // G = 4 (16-pixel maps: four images of 18 slots each): 76 (304 dwords = 48 banks mod 64: conflict-free too)
 
 __device__ __forceinline__ u32x4s swp_frag(unsigned addr) {      // 8 consecutive pixels (K) of this lane's channel: two transposed reads
     const s16x4w lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4w*)(uintptr_t)addr);
@@ -1351,7 +1370,7 @@ template <int G, int COT, int PM>
 __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_pre_kernel(SwPreArgs a) {
     constexpr bool F16 = PM == 1;
     constexpr int NP = PM == 2 ? 1 : 2;                        // parts per operand
-    constexpr int PXP = SWP_PXP;
+    constexpr int PXP = G == 4 ? 76 : SWP_PXP;
     constexpr int XS = 8, DS = COT / 8;                        // channel groups per image
     // (row images padded to whole 64-slot DMA pieces: the lanes of a piece beyond the image write zeros, which must not land in the
     // next ring slot / buffer)
@@ -1466,7 +1485,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_pre_kernel(SwPreAr
             for (int kk = 0; kk < NKS; ++kk) {
                 const int kst = grp * 2 + kk;                                  // 16-pixel k-step of the unit
                 const int dpx = 16 * kst;                                      // dz pixel slot
-                const int xpx = G == 1 ? 16 * kst : (kst >> 1) * 34 + (kst & 1) * 16;      // x pixel slot of tap kx = 0
+                const int xpx = G == 1 ? 16 * kst : (G == 2 ? (kst >> 1) * 34 + (kst & 1) * 16 : kst * 18);      // x pixel slot of tap kx = 0
                 if (more) {
                     constexpr int NP = NXI + NDI, PER = (NP + NKS - 1) / NKS;
 #pragma unroll
@@ -1638,7 +1657,7 @@ int onet_conv3x3_split_wgrad_norm(const float* z_prev, int64_t z_bs, const float
 int onet_conv3x3_split_wgrad_pre_ok(int B, int Cin, int Cout, int H, int W) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || (Cin % 8) || (Cout % 8)) return 0;
     if (W >= 64) return 1;
-    return (W == 32 && B % 2 == 0) ? 1 : 0;
+    return ((W == 32 && B % 2 == 0) || (W == 16 && B % 4 == 0)) ? 1 : 0;
 }
 
 int onet_conv3x3_split_wgrad_pre(const void* xs, int64_t xs_bs, const void* x_amax, const void* x_amax2, int split_ch, const void* dzs,
@@ -1647,7 +1666,7 @@ int onet_conv3x3_split_wgrad_pre(const void* xs, int64_t xs_bs, const void* x_am
     ONET_REQUIRE(split_ch >= 0 && split_ch < Cin && (split_ch % 64) == 0, "conv3x3_split_wgrad_pre: split_ch must be a multiple of 64 inside Cin");
     ONET_REQUIRE(xs && dzs && dw && ws, "conv3x3_split_wgrad_pre: null pointer");
     ONET_REQUIRE(onet_conv3x3_split_wgrad_pre_ok(B, Cin, Cout, H, W),
-                 "conv3x3_split_wgrad_pre: needs Cin, Cout %% 8 == 0 and W >= 64, or W = 32 with an even batch");
+                 "conv3x3_split_wgrad_pre: needs Cin, Cout %% 8 == 0 and W >= 64, or W = 32 / 16 with a batch multiple of 2 / 4");
     ONET_REQUIRE((xs_bs & 3) == 0 && (dzs_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(xs) & 15) == 0 && (reinterpret_cast<uintptr_t>(dzs) & 15) == 0,
                  "conv3x3_split_wgrad_pre: 16-byte aligned slots required");
     ONET_REQUIRE(xs_bs >= (int64_t)Cin * H * W / (f16 == 2 ? 2 : 1) && dzs_bs >= (int64_t)Cout * H * W / (f16 == 2 ? 2 : 1),
@@ -1666,8 +1685,8 @@ int onet_conv3x3_split_wgrad_pre(const void* xs, int64_t xs_bs, const void* x_am
     const int64_t blocks = (int64_t)a.splitK * a.ciTiles * a.coTiles;
     const dim3 grid((unsigned)blocks), blk(512);
     hipStream_t st = as_stream(stream);
-    const int np = f16 == 2 ? 1 : 2;
-    const int lds = (4 * ((np * 8 * SWP_PXP + 63) / 64 * 64) + 2 * ((np * (COT / 8) * SWP_PXP + 63) / 64 * 64)) * 16;
+    const int np = f16 == 2 ? 1 : 2, pxp = G == 4 ? 76 : SWP_PXP;
+    const int lds = (4 * ((np * 8 * pxp + 63) / 64 * 64) + 2 * ((np * (COT / 8) * pxp + 63) / 64 * 64)) * 16;
 #define ONET_SWP_LAUNCH(G_, COT_, F_)                                                                              \
     do {                                                                                                           \
         auto kern = conv3x3_split_wgrad_pre_kernel<G_, COT_, F_>;                                                  \
@@ -1678,9 +1697,11 @@ int onet_conv3x3_split_wgrad_pre(const void* xs, int64_t xs_bs, const void* x_am
 #define ONET_SWP_F(G_, COT_) do { if (f16 == 2) ONET_SWP_LAUNCH(G_, COT_, 2); else if (f16) ONET_SWP_LAUNCH(G_, COT_, 1); else ONET_SWP_LAUNCH(G_, COT_, 0); } while (0)
     if (COT == 128) {
         if (G == 1) ONET_SWP_F(1, 128);
-        else ONET_SWP_F(2, 128);
+        else if (G == 2) ONET_SWP_F(2, 128);
+        else ONET_SWP_F(4, 128);
     } else if (G == 1) ONET_SWP_F(1, 64);
-    else ONET_SWP_F(2, 64);
+    else if (G == 2) ONET_SWP_F(2, 64);
+    else ONET_SWP_F(4, 64);
 #undef ONET_SWP_F
 #undef ONET_SWP_LAUNCH
     int rc = check_launch("conv3x3_split_wgrad_pre_kernel");
@@ -1757,12 +1778,19 @@ int onet_split_pack_act(const float* x, int64_t x_bs, void* xs, int64_t xs_bs, i
     return check_launch("split_pack_act_kernel");
 }
 
+// BatchNorm statistics records of onet_conv3x3_split_fwd_pre: one per 16 x 32 tile; 16-pixel-wide maps: one per image PAIR and 16 rows
+int onet_conv3x3_split_pre_nparts(int B, int H, int W) {
+    if (W == 16) return (B > 0 && (B % 2) == 0 && (H % 16) == 0) ? (B / 2) * (H / 16) : 0;
+    return split_nparts(B, H, W);
+}
+
 int onet_conv3x3_split_fwd_pre(const void* xs, int64_t xs_bs, const void* x_amax, int scale_always, const void* x_amax2, int split_ch,
                                const void* wq, int wq_f16, float* z, int64_t z_bs, float* part, int B, int Cin, int Cout, int H, int W,
                                void* stream) {
     ONET_REQUIRE(split_ch >= 0 && split_ch < Cin && (split_ch % 32) == 0, "conv3x3_split_fwd_pre: split_ch must be a multiple of 32 inside Cin");
     ONET_REQUIRE(xs && wq && z, "conv3x3_split_fwd_pre: null pointer");
-    ONET_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 16, "conv3x3_split_fwd_pre: bad shape (maps wider than 16 pixels)");
+    ONET_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && (W > 16 || (W == 16 && (B % 2) == 0 && (H % 16) == 0)),
+                 "conv3x3_split_fwd_pre: bad shape (maps wider than 16 pixels, or exactly 16 wide with an even batch and H %% 16 == 0)");
     ONET_REQUIRE((Cin % (wq_f16 == 2 ? 32 : 16)) == 0, "conv3x3_split_fwd_pre: Cin must be a multiple of 16 (32 for plain bf16 operands)");
     ONET_REQUIRE((xs_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(xs) & 15) == 0, "conv3x3_split_fwd_pre: 16-byte aligned slots required");
     ONET_REQUIRE(xs_bs >= (int64_t)Cin * H * W / (wq_f16 == 2 ? 2 : 1) && z_bs >= (int64_t)Cout * H * W, "conv3x3_split_fwd_pre: batch stride too small");
@@ -1770,10 +1798,17 @@ int onet_conv3x3_split_fwd_pre(const void* xs, int64_t xs_bs, const void* x_amax
                  "conv3x3_split_fwd_pre: operand exceeds the 2 GiB buffer-resource range");
     SpPreArgs a{xs, xs_bs, (const __bf16*)wq, z, z_bs, B, Cin, Cout, H, W, 0, 0, 0, part, (const unsigned*)x_amax, scale_always,
                 (const unsigned*)x_amax2, split_ch};
-    if (part) ONET_REQUIRE(split_nparts(B, H, W) > 0, "conv3x3_split_fwd_pre: statistics need a map made of full 16 x 32 tiles");
-    if (wq_f16 == 2) return part ? launch_split_pre<true, 2>(a, as_stream(stream)) : launch_split_pre<false, 2>(a, as_stream(stream));
-    if (wq_f16) return part ? launch_split_pre<true, 1>(a, as_stream(stream)) : launch_split_pre<false, 1>(a, as_stream(stream));
-    return part ? launch_split_pre<true, 0>(a, as_stream(stream)) : launch_split_pre<false, 0>(a, as_stream(stream));
+    if (part) ONET_REQUIRE(onet_conv3x3_split_pre_nparts(B, H, W) > 0, "conv3x3_split_fwd_pre: statistics need a map made of full 16 x 32 tiles");
+    hipStream_t st = as_stream(stream);
+    if (W == 16) {
+        ONET_REQUIRE(xs_bs * 4 + (int64_t)Cin * H * W * 4 < (1ll << 31), "conv3x3_split_fwd_pre: image pair exceeds the buffer-resource range");
+        if (wq_f16 == 2) return part ? launch_split_pre<true, 2, true>(a, st) : launch_split_pre<false, 2, true>(a, st);
+        if (wq_f16) return part ? launch_split_pre<true, 1, true>(a, st) : launch_split_pre<false, 1, true>(a, st);
+        return part ? launch_split_pre<true, 0, true>(a, st) : launch_split_pre<false, 0, true>(a, st);
+    }
+    if (wq_f16 == 2) return part ? launch_split_pre<true, 2, false>(a, st) : launch_split_pre<false, 2, false>(a, st);
+    if (wq_f16) return part ? launch_split_pre<true, 1, false>(a, st) : launch_split_pre<false, 1, false>(a, st);
+    return part ? launch_split_pre<true, 0, false>(a, st) : launch_split_pre<false, 0, false>(a, st);
 }
 
 int onet_conv3x3_split_nparts(int B, int H, int W) { return split_nparts(B, H, W); }

@@ -599,6 +599,7 @@ SPLIT_F16 = _os.environ.get("ONET_SPLIT_F16", "1") != "0"         # 0: the forwa
 SPLIT_DGRAD = _os.environ.get("ONET_SPLIT_DGRAD", "1") != "0"     # 0 (diagnostic): input gradients stay on the fp32-MFMA kernels
 PRESPLIT = _os.environ.get("ONET_PRESPLIT", "1") != "0"           # 1: pre-split operand storage (Settings.presplit)
 PRESPLIT_BF16 = _os.environ.get("ONET_PRESPLIT_BF16", "1") != "0"  # ... also under conv == "bf16" (0: round 3's bf16 kernels + bf16 storage)
+PRESPLIT_W16 = _os.environ.get("ONET_PRESPLIT_W16", "1") != "0"    # ... also the 16-pixel level (0: fp32 Winograd F(4x4) there, as in round 3)
 # diagnostic / tests: every activation written pre-split ALSO leaves its fp32 tensor (same values: the parts are split from them), so
 # that a harness can read each unit's output; the kernels that consume the pre-split forms are unchanged
 PRESPLIT_KEEP_FP32 = _os.environ.get("ONET_PRESPLIT_KEEP_FP32", "0") != "0"
@@ -993,14 +994,19 @@ def pre_layer_ok(B, Cin, Cout, H, W):
     input gradient by conv3x3_split_pre_kernel, weight gradient by conv3x3_split_wgrad_pre_kernel?  Producers write the pre-split
     form of a tensor only where this says yes for its consumer (the decision is a function of shapes and settings, so producer and
     consumer agree without talking)."""
-    if not presplit() or Cin % 16 or Cout % 16 or W < 32 or W % 32 or H % 16 or H * W >= 2 ** 24:
+    if not presplit() or Cin % 16 or Cout % 16 or W < 16 or (W % 32 and W != 16) or H % 16 or H * W >= 2 ** 24:
         return False
     np_ = p16_parts()
     if np_ == 1 and (Cin % 32 or Cout % 32):                         # plain bf16: 32-channel chunks
         return False
-    if W == 32 and B * max(Cin, Cout) * H * W * 2 * np_ >= 2 ** 31:  # weight-gradient units pair images: one buffer resource over the batch
+    if W <= 32 and B * max(Cin, Cout) * H * W * 2 * np_ >= 2 ** 31:  # weight-gradient units pair images: one buffer resource over the batch
         return False
     lib = _lib.load()
+    if W == 16:
+        # the 16-pixel level: two images side by side per forward tile, four per weight-gradient unit; worth it once the tiles fill
+        # the chip (the dispatch of the fp32-operand kernels has no split kernel for this width, so the decision is made here)
+        return PRESPLIT_W16 and B % 4 == 0 and (B // 2) * -(-min(Cin, Cout) // 64) >= (n_cu() * 3) // 4 and \
+            bool(lib.onet_conv3x3_split_wgrad_pre_ok(B, Cin, Cout, H, W)) and int(lib.onet_maxpool2_bwd_bn_bands(H, W)) >= 0
     want = "bf16" if np_ == 1 else "split"
     return conv3x3_algo(B, Cin, Cout, H, W) == want and conv3x3_algo(B, Cout, Cin, H, W) == want and \
         bool(lib.onet_conv3x3_split_wgrad_pre_ok(B, Cin, Cout, H, W)) and int(lib.onet_conv3x3_split_nparts(B, H, W)) > 0 and \
@@ -1081,7 +1087,7 @@ def conv3x3_pre_bn_partials(xP, pk, slots=None):
     B, C8, H, np_, W, _ = xP.shape
     Co = pk["Cout"]
     wq = pk.get_pack("split" if np_ == 2 else "plain16")[0]
-    nparts = int(_lib.load().onet_conv3x3_split_nparts(B, H, W))
+    nparts = int(_lib.load().onet_conv3x3_split_pre_nparts(B, H, W))
     cm = torch.empty((Co, nparts, 3), dtype=F32, device=xP.device) if nparts > 0 else None
     s1, s2, sc = _slots3(slots)
     return conv3x3_split_pre(xP, wq, Co, slots=s1, stats=cm, slots2=s2, split_ch=sc), cm

@@ -235,14 +235,17 @@ def test_benchmark_dispatch_b32_256_every_gradient_element(dev, monkeypatch):
         # round 4, pre-split storage: the 15 layers on maps >= 32 pixels wide with >= 16 input channels run forward (with fused
         # statistics), input gradient and weight gradient on pre-split operands (LDS-DMA staged kernels); the stem and the 16-pixel
         # level keep the fp32-operand kernels (2 split weight gradients there); the up-sampled concat halves leave the GEMM pre-split
-        assert used.get("conv3x3_pre_bn_partials", 0) == 15 and used.get("conv3x3_split_wgrad_pre", 0) == 15, used
-        assert used.get("conv3x3_split_pre", 0) == 15 + 15 and used.get("bn_relu_bwd_split", 0) == 15 and used.get("convT2x2_fwd_p", 0) == 4, used
-        assert used.get("conv3x3_split_wgrad", 0) == 2 and used.get("conv3x3_winograd4_wgrad", 0) + used.get("conv3x3_winograd_wgrad", 0) == 0, used
+        # (+ the two layers of the 16-pixel level with ops.PRESPLIT_W16, the default: two images side by side per forward tile)
+        n = 17 if ops.PRESPLIT_W16 else 15
+        assert used.get("conv3x3_pre_bn_partials", 0) == n and used.get("conv3x3_split_wgrad_pre", 0) == n, used
+        assert used.get("conv3x3_split_pre", 0) == n + n and used.get("bn_relu_bwd_split", 0) == n and used.get("convT2x2_fwd_p", 0) == 4, used
+        assert used.get("conv3x3_split_wgrad", 0) == 17 - n and used.get("conv3x3_winograd4_wgrad", 0) + used.get("conv3x3_winograd_wgrad", 0) == 0, used
+        assert used.get("conv3x3_winograd4", 0) == (0 if ops.PRESPLIT_W16 else 4), used
     else:
         assert diag or (used.get("conv3x3_fwd_bn_partials", 0) >= 14 and used.get("conv3x3_split", 0) >= 10), used
         if ops.SPLIT_AUTO and not diag:
             assert used.get("conv3x3_split_wgrad", 0) == 17 and used.get("conv3x3_winograd4_wgrad", 0) + used.get("conv3x3_winograd_wgrad", 0) == 0, used
-    assert used.get("convT2x2_wgrad", 0) == 4 and used.get("conv3x3_winograd4", 0) >= 1, used
+    assert used.get("convT2x2_wgrad", 0) == 4 and (ops.PRESPLIT or used.get("conv3x3_winograd4", 0) >= 1), used
     assert abs(loss.item() - g["losses"][0]) <= 1e-3 * abs(g["losses"][0])
     assert np.abs(Vt.detach().cpu().numpy()[:2, :, ::37, :] - g["Vt"]).max() <= 1e-3 * np.abs(g["Vt"]).max()
     _, oloss, g64, r = _routed_oracle(x2, 1, 1981, 1.0, acts)

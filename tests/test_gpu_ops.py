@@ -11,6 +11,11 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
+
+def _lib_load():
+    from onet_amd import _lib
+    return _lib.load()
+
 G = os.path.join(os.path.dirname(__file__), "golden")
 
 
@@ -149,7 +154,7 @@ def test_conv3x3_split_wgrad(dev, B, Cin, Cout, H, W):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 64, 64, 64, 64), (2, 64, 128, 32, 64), (3, 72, 64, 16, 96), (4, 64, 128, 32, 32),
-                                             (2, 128, 64, 32, 32), (1, 64, 64, 8, 128)])
+                                             (2, 128, 64, 32, 32), (1, 64, 64, 8, 128), (4, 64, 128, 16, 16), (8, 128, 64, 32, 16)])
 def test_conv3x3_split_presplit_kernels(dev, B, Cin, Cout, H, W):
     """Round 4, pre-split operands (slot layout [B][C/8][H][hi|mid][W][8] of 16-bit parts, written by onet_split_pack_act):
     conv3x3_split_pre_kernel (staging = LDS-DMA copy) must reproduce conv3x3_split_kernel on the same parts BIT FOR BIT, for fp16
@@ -164,6 +169,21 @@ def test_conv3x3_split_presplit_kernels(dev, B, Cin, Cout, H, W):
         ref = ops.conv3x3_split(x, qf, Cout)
         got = ops.conv3x3_split_pre(ops.split_pack_act(x, f16=True), qf, Cout)
         assert torch.equal(ref, got), float((ref - got).abs().max())
+    if W == 16:
+        # maps 16 pixels wide (two images side by side per tile; the fp32-operand split kernel has no such variant): against fp64,
+        # forward with the statistics epilogue == the separate statistics pass, and the input-gradient orientation
+        qf, qd = ops.pack3x3_split(w)
+        zr = F.conv2d(x.double().cpu(), w.double().cpu(), None, 1, 1)
+        nparts = int(_lib_load().onet_conv3x3_split_pre_nparts(B, H, W))
+        assert nparts == (B // 2) * (H // 16)
+        cm = torch.full((Cout, nparts, 3), float("nan"), device=dev)
+        z = ops.conv3x3_split_pre(ops.split_pack_act(x, f16=True), qf, Cout, stats=cm)
+        close(z, zr, tol=2e-6, what="pre-split fwd, 16-pixel maps")
+        assert torch.isfinite(cm).all() and float(cm[:, :, 0].sum(1).min()) == float(cm[:, :, 0].sum(1).max()) == B * H * W
+        gamma, beta = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
+        s0 = ops.bn_train_coeffs(z, gamma, beta, None, None, 0.1, 1e-5)
+        s1 = ops.bn_train_coeffs(z, gamma, beta, None, None, 0.1, 1e-5, cm=(cm, 0, nparts))
+        assert float((s0[0] - s1[0]).abs().max()) <= 2e-6 * float(z.std()) and float(((s0[1] - s1[1]) / s0[1]).abs().max()) <= 1e-5
     wz = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
     F.conv2d(x.double().cpu(), wz, None, 1, 1).backward(g.double().cpu())
     for f16, tol in ((True, 2e-6), (False, 3e-5)):
