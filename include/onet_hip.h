@@ -366,12 +366,17 @@ int onet_bn_relu_bwd_apply(const float* da, int64_t da_bs, const float* z, int64
  * max |da| (da_amax: recorded by onet_bn_relu_bwd_reduce_amax or onet_absmax_slots); the consumers read the same slots.
  * nparts = 2: the fp16 (hi | mid) slots above; nparts = 1: PLAIN bf16 operands, one part -- [B][C/8][H][W][8] bf16, rounded to
  * nearest even, unscaled (dz_amax may be NULL) -- for BASELINE configs[2]'s bf16 MFMA conv path (the same LDS-DMA staged kernels
- * with one part: wq_f16 / f16 = 2 in onet_conv3x3_split_fwd_pre / _wgrad_pre / _pack_weights / onet_split_pack_act). */
+ * with one part: wq_f16 / f16 = 2 in onet_conv3x3_split_fwd_pre / _wgrad_pre / _pack_weights / onet_split_pack_act).
+ * STATISTICS GROUPS IN ONE LAUNCH (group_images / groups in the entry points below): the weight-shared twin batch [X ; 1 - X] is one
+ * tensor whose halves are normalised separately (OV:178-179 runs the U-Net twice).  group_images > 0: images g * group_images ..
+ * (g + 1) * group_images - 1 of the batch form group g and save / coef are [G][4][C]; 0: one group, save / coef [4][C].  The
+ * finalize entry points take `groups`: records of group g follow those of group g - 1 (nparts records each), running statistics and
+ * dgamma / dbeta take the groups' contributions in order -- the same bits as one launch per group. */
 int onet_bn_relu_apply_split(const float* z, int64_t z_bs, void* xs, int64_t xs_bs, float* a, int64_t a_bs, const float* save,
-                             const void* act_amax, int nparts, int B, int C, int H, int W, void* stream);
+                             const void* act_amax, int nparts, int group_images, int B, int C, int H, int W, void* stream);
 int onet_bn_relu_apply_pool_split(const float* z, int64_t z_bs, void* xs, int64_t xs_bs, float* a, int64_t a_bs, void* ys, int64_t ys_bs,
-                                  float* y, int64_t y_bs, const float* save, const void* act_amax, int nparts, int B, int C, int H, int W,
-                                  void* stream);
+                                  float* y, int64_t y_bs, const float* save, const void* act_amax, int nparts, int group_images, int B, int C,
+                                  int H, int W, void* stream);
 /* act_amax (may be NULL: unscaled): the activation's magnitude slots holding the bound |gamma| sqrt(N - 1) + |beta| written by
  * onet_bn_finalize_act / _cm_act (onet_bn_finalize / _cm that also record it); the fp16 parts are those of 2^k a with the GUARD
  * exponent the slots select (0 unless the bound reaches 2^15: a loaded checkpoint with a huge gamma), undone by the consumers, which
@@ -379,28 +384,33 @@ int onet_bn_relu_apply_pool_split(const float* z, int64_t z_bs, void* xs, int64_
 int onet_bn_finalize_act(const float* part, int nparts, int64_t count, const float* gamma, const float* beta, float* running_mean,
                          float* running_var, float momentum, float eps, float* save, void* act_amax, int C, void* stream);
 int onet_bn_finalize_cm_act(const float* part, int nparts, int64_t c_stride, const float* gamma, const float* beta, float* running_mean,
-                            float* running_var, float momentum, float eps, float* save, void* act_amax, int C, void* stream);
+                            float* running_var, float momentum, float eps, float* save, void* act_amax, int groups, int C, void* stream);
+/* (_cm_act: act_amax may be NULL; c_stride >= groups * nparts * 3.  _bwd_reduce_amax: da_amax may be NULL; part2 [nparts][C][4] with
+ * nparts a multiple of B: the records of image b's chunks are rows b * chunks .., so a group's records are consecutive rows) */
 int onet_bn_relu_bwd_reduce_amax(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save, float* part2, int nparts,
-                                 void* da_amax, int B, int C, int HW, void* stream);
+                                 void* da_amax, int group_images, int B, int C, int HW, void* stream);
 int onet_bn_bwd_bound(const float* save, const float* coef, const void* da_amax, int64_t count, void* dz_amax, int C, void* stream);
 /* onet_bn_bwd_finalize that also writes the bound of |dz| (as onet_bn_bwd_bound) into dz_amax: da_amax must be complete, i.e. every
- * reduce launch of the tensor precedes the first finalize. */
+ * reduce launch of the tensor precedes the first finalize.  nparts, count: per group; part2 [groups][nparts][C][4], coef [groups][4][C];
+ * dz_amax NULL: no bound (plain bf16 operands), then save / da_amax may be NULL too. */
 int onet_bn_bwd_finalize_bound(const float* part2, int nparts, int64_t count, float* dgamma, float* dbeta, float* coef, int accumulate,
-                               int C, const float* save, const void* da_amax, void* dz_amax, void* stream);
+                               int groups, int C, const float* save, const void* da_amax, void* dz_amax, void* stream);
 int onet_bn_relu_bwd_apply_split(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save, const float* coef,
-                                 void* dzs, int64_t dzs_bs, const void* dz_amax, int nparts, int B, int C, int H, int W, void* stream);
+                                 void* dzs, int64_t dzs_bs, const void* dz_amax, int nparts, int group_images, int B, int C, int H, int W,
+                                 void* stream);
 /* onet_bn_relu_apply / onet_bn_relu_apply_pool that also record max a (a >= 0) in 64 magnitude slots (zeroed by the caller; the
  * statistics groups of a twin batch share them; the pooled tensor has the same maximum): the overflow guard of the fp16-split
- * convolution that consumes the activation.  _pool_amax returns 1 when the shape is not taken (as onet_bn_relu_apply_pool). */
-int onet_bn_relu_apply_amax(const float* z, int64_t z_bs, float* a, int64_t a_bs, const float* save, void* amax, int B, int C, int HW,
-                            void* stream);
+ * convolution that consumes the activation (_apply_amax, _bwd_apply_amax: amax may be NULL; group_images as above).  _pool_amax
+ * returns 1 when the shape is not taken (as onet_bn_relu_apply_pool). */
+int onet_bn_relu_apply_amax(const float* z, int64_t z_bs, float* a, int64_t a_bs, const float* save, void* amax, int group_images, int B,
+                            int C, int HW, void* stream);
 int onet_bn_relu_apply_pool_amax(const float* z, int64_t z_bs, float* a, int64_t a_bs, float* y, int64_t y_bs, const float* save,
                                  void* amax, int B, int C, int H, int W, void* stream);
 /* ... the same pass, also recording max |dz| in 64 magnitude slots (unsigned[64 * 32], zeroed by the caller; several launches -- the
  * statistics groups of a twin batch -- may share them): what the fp16-split gradient kernels scale dz by (onet_conv3x3_split_conv_amax,
  * onet_conv3x3_split_wgrad_f16). */
 int onet_bn_relu_bwd_apply_amax(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save, const float* coef,
-                                float* dz, int64_t dz_bs, void* amax, int B, int C, int HW, void* stream);
+                                float* dz, int64_t dz_bs, void* amax, int group_images, int B, int C, int HW, void* stream);
 
 /* ---- K4: MaxPool2d(2) (OV:67) ------------------------------------------- */
 int onet_maxpool2_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs,

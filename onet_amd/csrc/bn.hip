@@ -124,49 +124,56 @@ __global__ __launch_bounds__(256) void bn_finalize_cm_kernel(const float* __rest
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* running_mean,
                                                             float* running_var, float momentum, float eps,
-                                                            float* __restrict__ save, int C, unsigned* __restrict__ act_slots = nullptr) {
+                                                            float* __restrict__ save, int C, unsigned* __restrict__ act_slots = nullptr,
+                                                            int groups = 1) {
+    // groups > 1: the statistics groups of a twin batch in one launch -- group g owns records g * nparts .. (g + 1) * nparts - 1 of
+    // every channel and save[g][4][C]; the running statistics take the groups' updates in order, as one launch per group did
     __shared__ double red[16];
     __shared__ double bc[2];
     const int c = blockIdx.x;
-    const float* src = part + (int64_t)c * c_stride;
-    double v[2] = {0.0, 0.0};
-    for (int p = threadIdx.x; p < nparts; p += 256) {
-        const float* o = src + (int64_t)p * 3;
-        v[0] += (double)o[0];
-        v[1] += (double)o[0] * (double)o[1];
-    }
-    block_sum_256<double, 2>(v, red);
-    if (threadIdx.x == 0) {
-        bc[0] = v[0];
-        bc[1] = v[1] / v[0];
-    }
-    __syncthreads();
-    const double n = bc[0], mean = bc[1];
-    double w[1] = {0.0};
-    for (int p = threadIdx.x; p < nparts; p += 256) {
-        const float* o = src + (int64_t)p * 3;
-        const double d = (double)o[1] - mean;
-        w[0] += (double)o[2] + (double)o[0] * d * d;
-    }
-    __syncthreads();
-    block_sum_256<double, 1>(w, red);
-    if (threadIdx.x == 0) {
-        const double m2 = w[0];
-        const double var = m2 / n;
-        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
-        save[c] = (float)mean;
-        save[C + c] = invstd;
-        save[2 * C + c] = g * invstd;
-        save[3 * C + c] = bt;
-        if (act_slots) {                            // (see bn_finalize_kernel)
-            const float bound = fabsf(g) * sqrtf((float)(n > 1.0 ? n - 1.0 : 1.0)) * 1.000001f + fabsf(bt);
-            if (bound == bound) atomicMax(act_slots + (c & 63) * AMAX_STRIDE, __builtin_bit_cast(unsigned, bound));
+    for (int g = 0; g < groups; ++g) {
+        const float* src = part + (int64_t)c * c_stride + (int64_t)g * nparts * 3;
+        float* sv = save + (int64_t)g * 4 * C;
+        double v[2] = {0.0, 0.0};
+        for (int p = threadIdx.x; p < nparts; p += 256) {
+            const float* o = src + (int64_t)p * 3;
+            v[0] += (double)o[0];
+            v[1] += (double)o[0] * (double)o[1];
         }
-        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-        if (running_var) {
-            const double unb = n > 1.0 ? m2 / (n - 1.0) : var;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+        if (g) __syncthreads();                     // (the previous group's readers of red / bc are done)
+        block_sum_256<double, 2>(v, red);
+        if (threadIdx.x == 0) {
+            bc[0] = v[0];
+            bc[1] = v[1] / v[0];
+        }
+        __syncthreads();
+        const double n = bc[0], mean = bc[1];
+        double w[1] = {0.0};
+        for (int p = threadIdx.x; p < nparts; p += 256) {
+            const float* o = src + (int64_t)p * 3;
+            const double d = (double)o[1] - mean;
+            w[0] += (double)o[2] + (double)o[0] * d * d;
+        }
+        __syncthreads();
+        block_sum_256<double, 1>(w, red);
+        if (threadIdx.x == 0) {
+            const double m2 = w[0];
+            const double var = m2 / n;
+            const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+            const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+            sv[c] = (float)mean;
+            sv[C + c] = invstd;
+            sv[2 * C + c] = gm * invstd;
+            sv[3 * C + c] = bt;
+            if (act_slots) {                            // (see bn_finalize_kernel)
+                const float bound = fabsf(gm) * sqrtf((float)(n > 1.0 ? n - 1.0 : 1.0)) * 1.000001f + fabsf(bt);
+                if (bound == bound) atomicMax(act_slots + (c & 63) * AMAX_STRIDE, __builtin_bit_cast(unsigned, bound));
+            }
+            if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            if (running_var) {
+                const double unb = n > 1.0 ? m2 / (n - 1.0) : var;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+            }
         }
     }
 }
@@ -219,11 +226,12 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restr
                                                             float* __restrict__ a, int64_t a_bs,
                                                             const float* __restrict__ save, int C, int HW,
                                                             int chunks, __bf16* __restrict__ a16 = nullptr,
-                                                            int64_t a16_bs = 0, unsigned* __restrict__ amax = nullptr) {
+                                                            int64_t a16_bs = 0, unsigned* __restrict__ amax = nullptr, int gimg = 0) {
     // amax: 64 magnitude slots of the activation (the range guard of the fp16-split convolution that consumes it)
     float vmax = 0.f;
     const int plane = blockIdx.x / chunks, ch = blockIdx.x % chunks;
     const int b = plane / C, c = plane % C;
+    if (gimg) save += (int64_t)(b / gimg) * 4 * C;        // statistics groups = consecutive batch slices of gimg images, save [G][4][C]
     const float mean = save[c], sc = save[2 * C + c], sh = save[3 * C + c];
     const float* src = z + (int64_t)b * z_bs + (int64_t)c * HW;
     float* dst = a ? a + (int64_t)b * a_bs + (int64_t)c * HW : nullptr;
@@ -447,13 +455,14 @@ __device__ __forceinline__ void bn_store_slots_block(bn_u32x4* lds, unsigned* __
 __global__ __launch_bounds__(256) void bn_relu_apply_split_kernel(const float* __restrict__ z, int64_t z_bs, unsigned* __restrict__ xs,
                                                                   int64_t xs_bs, float* __restrict__ a, int64_t a_bs,
                                                                   const float* __restrict__ save, int C, int H, int W, int bpp, int np,
-                                                                  const unsigned* __restrict__ slots) {
+                                                                  const unsigned* __restrict__ slots, int gimg) {
     // slots: the activation's magnitude slots (the bound bn_finalize wrote): the fp16 parts are those of s a with the guard scale
     // s = 2^k they select -- 1 unless the bound reaches 2^15 -- and the consumers undo s; plain bf16 (np = 1) needs none
     float s_inv;
     const float s_act = np == 1 ? 1.f : amax_scale(amax_read(slots), false, s_inv);
     const int plane = blockIdx.x / bpp, blk = blockIdx.x % bpp;
     const int C8 = C >> 3, b = plane / C8, c8 = plane % C8;
+    if (gimg) save += (int64_t)(b / gimg) * 4 * C;        // statistics groups = consecutive batch slices of gimg images, save [G][4][C]
 #if BN_APPLY_SPLIT_TR
     {   // variant: four CONSECUTIVE pixels per thread (float4 loads) and the block's slots traded through LDS for coalesced stores
         __shared__ bn_u32x4 tr[BN_TR_SLOTS];
@@ -518,11 +527,12 @@ __global__ __launch_bounds__(256) void bn_relu_apply_pool_split_kernel(const flo
                                                                        int64_t xs_bs, float* __restrict__ a, int64_t a_bs,
                                                                        unsigned* __restrict__ ys, int64_t ys_bs, float* __restrict__ yf,
                                                                        int64_t yf_bs, const float* __restrict__ save, int C, int H, int W,
-                                                                       int bpp, int np, const unsigned* __restrict__ slots) {
+                                                                       int bpp, int np, const unsigned* __restrict__ slots, int gimg) {
     float s_inv;
     const float s_act = np == 1 ? 1.f : amax_scale(amax_read(slots), false, s_inv);      // (see bn_relu_apply_split_kernel)
     const int plane = blockIdx.x / bpp, blk = blockIdx.x % bpp;
     const int C8 = C >> 3, b = plane / C8, c8 = plane % C8;
+    if (gimg) save += (int64_t)(b / gimg) * 4 * C;        // statistics groups = consecutive batch slices of gimg images, save [G][4][C]
     const int Hp = H >> 1, Wp = W >> 1, W4 = W >> 2, HW = H * W, i = blk * 256 + threadIdx.x;
     const bool live = i < Hp * W4;                  // (no early return: the block transposes its slots through LDS together)
     int yo, q;
@@ -596,11 +606,15 @@ __global__ __launch_bounds__(256) void bn_relu_apply_pool_split_kernel(const flo
 __global__ __launch_bounds__(256) void bn_relu_bwd_apply_split_kernel(const float* __restrict__ da, int64_t da_bs, const float* __restrict__ z,
                                                                       int64_t z_bs, const float* __restrict__ save, const float* __restrict__ coef,
                                                                       unsigned* __restrict__ dzs, int64_t dzs_bs, const unsigned* __restrict__ slots,
-                                                                      int C, int H, int W, int bpp, int np) {
+                                                                      int C, int H, int W, int bpp, int np, int gimg) {
     float inv;
     const float s = np == 1 ? 1.f : amax_scale(amax_read(slots), true, inv);     // (plain bf16: fp32's exponent range, no scale)
     const int plane = blockIdx.x / bpp, blk = blockIdx.x % bpp;
     const int C8 = C >> 3, b = plane / C8, c8 = plane % C8;
+    if (gimg) {                                           // statistics groups: save, coef [G][4][C]
+        save += (int64_t)(b / gimg) * 4 * C;
+        if (coef) coef += (int64_t)(b / gimg) * 4 * C;
+    }
     __shared__ bn_u32x4 tr[BN_TR_SLOTS];
     const int HW = H * W, p = (blk * 256 + threadIdx.x) * 4;
     const bool live = p < HW;                     // (HW % 4 == 0: a thread's four pixels are all inside or all outside)
@@ -653,12 +667,14 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const float* __
                                                                  const float* __restrict__ z, int64_t z_bs,
                                                                  const float* __restrict__ save,
                                                                  float* __restrict__ part2, int C, int HW,
-                                                                 int chunks, int chunk_len, unsigned* __restrict__ amax = nullptr) {
+                                                                 int chunks, int chunk_len, unsigned* __restrict__ amax = nullptr,
+                                                                 int gimg = 0) {
     __shared__ double red[8];
     float vmax = 0.f;                           // amax: magnitude slots of da (what bounds the dz this layer's apply pass writes)
     const int c = blockIdx.x % C;
     const int p = blockIdx.x / C;
     const int b = p / chunks, ch = p % chunks;
+    if (gimg) save += (int64_t)(b / gimg) * 4 * C;        // statistics groups = consecutive batch slices of gimg images, save [G][4][C]
     const float mean = save[c], invstd = save[C + c], sc = save[2 * C + c], sh = save[3 * C + c];
     const double meand = mean, invd = invstd;
     const float* zs = z + (int64_t)b * z_bs + (int64_t)c * HW;
@@ -724,34 +740,51 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __rest
                                                              double count, float* dgamma, float* dbeta,
                                                              float* coef, int accumulate, int C, const float* __restrict__ save = nullptr,
                                                              const unsigned* __restrict__ da_slots = nullptr,
-                                                             unsigned* __restrict__ dz_slots = nullptr, float xhat_max = 0.f) {
+                                                             unsigned* __restrict__ dz_slots = nullptr, float xhat_max = 0.f, int groups = 1) {
     // dz_slots (pre-split storage): this channel's bound of |dz| (see bn_bwd_bound_kernel) goes into the dz magnitude slots here,
-    // saving that launch; da_slots must be complete (every reduce launch of the tensor precedes the first finalize)
+    // saving that launch; da_slots must be complete (every reduce launch of the tensor precedes the first finalize).
+    // groups > 1: the statistics groups of a twin batch in one launch: records [g][nparts][C][4], coef / save [g][4][C]; dgamma / dbeta
+    // take the groups' sums one after the other in fp32, as one accumulating launch per group did
     const float da_max = dz_slots ? amax_read(da_slots) : 0.f;
     const int c = blockIdx.x;
-    double s = 0.0, sx = 0.0;
-    for (int p = threadIdx.x; p < nparts; p += 64) {
-        const float* o = part2 + ((int64_t)p * C + c) * 4;
-        s += (double)o[0] + (double)o[1];
-        sx += (double)o[2] + (double)o[3];
+    float acc_b = 0.f, acc_g = 0.f;
+    if (accumulate && threadIdx.x == 0) {
+        acc_b = dbeta ? dbeta[c] : 0.f;
+        acc_g = dgamma ? dgamma[c] : 0.f;
     }
-    s = wave_sum(s);
-    sx = wave_sum(sx);
+    for (int g = 0; g < groups; ++g) {
+        const float* rec = part2 + (int64_t)g * nparts * C * 4;
+        double s = 0.0, sx = 0.0;
+        for (int p = threadIdx.x; p < nparts; p += 64) {
+            const float* o = rec + ((int64_t)p * C + c) * 4;
+            s += (double)o[0] + (double)o[1];
+            sx += (double)o[2] + (double)o[3];
+        }
+        s = wave_sum(s);
+        sx = wave_sum(sx);
+        if (threadIdx.x == 0) {
+            const bool first = g == 0 && !accumulate;
+            acc_b = first ? (float)s : acc_b + (float)s;
+            acc_g = first ? (float)sx : acc_g + (float)sx;
+            float* cf = coef ? coef + (int64_t)g * 4 * C : nullptr;
+            if (cf) {   // (hi, lo) float pairs of c1 = sum dy / N and c2 = sum dy*xhat / N
+                const double c1 = s / count, c2 = sx / count;
+                cf[c] = (float)c1;
+                cf[C + c] = (float)(c1 - (double)(float)c1);
+                cf[2 * C + c] = (float)c2;
+                cf[3 * C + c] = (float)(c2 - (double)(float)c2);
+            }
+            if (dz_slots) {
+                const double c1 = cf ? s / count : 0.0, c2 = cf ? sx / count : 0.0;
+                const float bound = fabsf(save[(int64_t)g * 4 * C + 2 * C + c]) *
+                                    (da_max + (float)fabs(c1) * 1.0000002f + (float)fabs(c2) * 1.0000002f * xhat_max);
+                if (bound == bound) atomicMax(dz_slots + (c & 63) * AMAX_STRIDE, __builtin_bit_cast(unsigned, bound));
+            }
+        }
+    }
     if (threadIdx.x == 0) {
-        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s : (float)s;
-        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)sx : (float)sx;
-        if (coef) {   // (hi, lo) float pairs of c1 = sum dy / N and c2 = sum dy*xhat / N
-            const double c1 = s / count, c2 = sx / count;
-            coef[c] = (float)c1;
-            coef[C + c] = (float)(c1 - (double)(float)c1);
-            coef[2 * C + c] = (float)c2;
-            coef[3 * C + c] = (float)(c2 - (double)(float)c2);
-        }
-        if (dz_slots) {
-            const double c1 = coef ? s / count : 0.0, c2 = coef ? sx / count : 0.0;
-            const float bound = fabsf(save[2 * C + c]) * (da_max + (float)fabs(c1) * 1.0000002f + (float)fabs(c2) * 1.0000002f * xhat_max);
-            if (bound == bound) atomicMax(dz_slots + (c & 63) * AMAX_STRIDE, __builtin_bit_cast(unsigned, bound));
-        }
+        if (dbeta) dbeta[c] = acc_b;
+        if (dgamma) dgamma[c] = acc_g;
     }
 }
 
@@ -794,12 +827,16 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
                                                                 const float* __restrict__ coef,
                                                                 float* __restrict__ dz, int64_t dz_bs, int C,
                                                                 int HW, int chunks, __bf16* __restrict__ dz16 = nullptr,
-                                                                int64_t dz16_bs = 0, unsigned* __restrict__ amax = nullptr) {
+                                                                int64_t dz16_bs = 0, unsigned* __restrict__ amax = nullptr, int gimg = 0) {
     // amax: 64 magnitude slots of dz (fp32 bit patterns; atomicMax is an order-independent maximum): the fp16-split convolution
     // kernels that consume dz scale it by a power of two chosen from this (conv_split.hip, amax_scale)
     float vmax = 0.f;
     const int plane = blockIdx.x / chunks, ch = blockIdx.x % chunks;
     const int b = plane / C, c = plane % C;
+    if (gimg) {                                           // statistics groups: save, coef [G][4][C]
+        save += (int64_t)(b / gimg) * 4 * C;
+        if (coef) coef += (int64_t)(b / gimg) * 4 * C;
+    }
     const float mean = save[c], invstd = save[C + c], sc = save[2 * C + c], sh = save[3 * C + c];
     const double meand = mean, invd = invstd, scd = sc;
     const double c1 = coef ? (double)coef[c] + (double)coef[C + c] : 0.0;
@@ -911,10 +948,10 @@ int onet_bn_finalize_act(const float* part, int nparts, int64_t count, const flo
 }
 
 int onet_bn_finalize_cm_act(const float* part, int nparts, int64_t c_stride, const float* gamma, const float* beta, float* running_mean,
-                            float* running_var, float momentum, float eps, float* save, void* act_amax, int C, void* stream) {
-    ONET_REQUIRE(part && save && act_amax && nparts > 0 && C > 0 && c_stride >= (int64_t)nparts * 3, "bn_finalize_cm_act: bad args");
+                            float* running_var, float momentum, float eps, float* save, void* act_amax, int groups, int C, void* stream) {
+    ONET_REQUIRE(part && save && nparts > 0 && C > 0 && groups >= 1 && c_stride >= (int64_t)nparts * groups * 3, "bn_finalize_cm_act: bad args");
     hipLaunchKernelGGL(bn_finalize_cm_kernel, dim3(C), dim3(256), 0, as_stream(stream), part, nparts, c_stride, gamma, beta, running_mean,
-                       running_var, momentum, eps, save, C, (unsigned*)act_amax);
+                       running_var, momentum, eps, save, C, (unsigned*)act_amax, groups);
     return check_launch("bn_finalize_cm_kernel");
 }
 
@@ -937,14 +974,14 @@ int onet_bn_relu_apply(const float* z, int64_t z_bs, float* a, int64_t a_bs, con
     return check_launch("bn_relu_apply_kernel");
 }
 
-int onet_bn_relu_apply_amax(const float* z, int64_t z_bs, float* a, int64_t a_bs, const float* save, void* amax, int B, int C, int HW,
-                            void* stream) {
-    ONET_REQUIRE(z && a && save && amax && B > 0 && C > 0 && HW > 0, "bn_relu_apply_amax: bad args");
+int onet_bn_relu_apply_amax(const float* z, int64_t z_bs, float* a, int64_t a_bs, const float* save, void* amax, int group_images, int B,
+                            int C, int HW, void* stream) {
+    ONET_REQUIRE(z && a && save && B > 0 && C > 0 && HW > 0 && group_images >= 0, "bn_relu_apply_amax: bad args");
     const int chunks = cdiv(HW, 4096);
     const int64_t blocks = (int64_t)B * C * chunks;
     ONET_REQUIRE(blocks < (1ll << 31), "bn_relu_apply_amax: grid too large");
     hipLaunchKernelGGL(bn_relu_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), z, z_bs, a, a_bs, save, C, HW,
-                       chunks, (__bf16*)nullptr, (int64_t)0, (unsigned*)amax);
+                       chunks, (__bf16*)nullptr, (int64_t)0, (unsigned*)amax, group_images);
     return check_launch("bn_relu_apply_kernel");
 }
 
@@ -998,12 +1035,12 @@ int onet_bn_relu_bwd_reduce(const float* da, int64_t da_bs, const float* z, int6
 }
 
 int onet_bn_relu_bwd_reduce_amax(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save, float* part2, int nparts,
-                                 void* da_amax, int B, int C, int HW, void* stream) {
-    ONET_REQUIRE(da && z && save && part2 && da_amax && B > 0 && C > 0 && HW > 0, "bn_relu_bwd_reduce_amax: bad args");
+                                 void* da_amax, int group_images, int B, int C, int HW, void* stream) {
+    ONET_REQUIRE(da && z && save && part2 && B > 0 && C > 0 && HW > 0 && group_images >= 0, "bn_relu_bwd_reduce_amax: bad args");
     int chunks, chunk_len;
     ONET_REQUIRE(split_plan(nparts, B, HW, chunks, chunk_len), "bn_relu_bwd_reduce_amax: nparts=%d must be a multiple of B=%d", nparts, B);
     hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3((unsigned)((int64_t)nparts * C)), dim3(256), 0, as_stream(stream), da, da_bs, z, z_bs,
-                       save, part2, C, HW, chunks, chunk_len, (unsigned*)da_amax);
+                       save, part2, C, HW, chunks, chunk_len, (unsigned*)da_amax, group_images);
     return check_launch("bn_relu_bwd_reduce_kernel");
 }
 
@@ -1015,7 +1052,7 @@ int onet_bn_bwd_bound(const float* save, const float* coef, const void* da_amax,
 }
 
 int onet_bn_relu_apply_split(const float* z, int64_t z_bs, void* xs, int64_t xs_bs, float* a, int64_t a_bs, const float* save,
-                             const void* act_amax, int nparts, int B, int C, int H, int W, void* stream) {
+                             const void* act_amax, int nparts, int group_images, int B, int C, int H, int W, void* stream) {
     ONET_REQUIRE(nparts == 1 || nparts == 2, "bn_relu_apply_split: nparts must be 2 (fp16 hi | mid) or 1 (plain bf16)");
     ONET_REQUIRE(z && xs && save && B > 0 && C > 0 && (C % 8) == 0 && H > 0 && W > 0 && (W % 4) == 0, "bn_relu_apply_split: bad args (C %% 8 == 0, W %% 4 == 0)");
     ONET_REQUIRE((reinterpret_cast<uintptr_t>(xs) & 15) == 0 && (xs_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(z) & 15) == 0 && (z_bs & 3) == 0 &&
@@ -1024,13 +1061,13 @@ int onet_bn_relu_apply_split(const float* z, int64_t z_bs, void* xs, int64_t xs_
     const int64_t blocks = (int64_t)B * (C / 8) * bpp;
     ONET_REQUIRE(blocks < (1ll << 31) && (int64_t)H * W < (1 << 24), "bn_relu_apply_split: grid too large");
     hipLaunchKernelGGL(bn_relu_apply_split_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), z, z_bs, (unsigned*)xs, xs_bs, a,
-                       a_bs, save, C, H, W, bpp, nparts, (const unsigned*)act_amax);
+                       a_bs, save, C, H, W, bpp, nparts, (const unsigned*)act_amax, group_images);
     return check_launch("bn_relu_apply_split_kernel");
 }
 
 int onet_bn_relu_apply_pool_split(const float* z, int64_t z_bs, void* xs, int64_t xs_bs, float* a, int64_t a_bs, void* ys, int64_t ys_bs,
-                                  float* y, int64_t y_bs, const float* save, const void* act_amax, int nparts, int B, int C, int H, int W,
-                                  void* stream) {
+                                  float* y, int64_t y_bs, const float* save, const void* act_amax, int nparts, int group_images, int B, int C,
+                                  int H, int W, void* stream) {
     ONET_REQUIRE(nparts == 1 || nparts == 2, "bn_relu_apply_pool_split: nparts must be 2 (fp16 hi | mid) or 1 (plain bf16)");
     ONET_REQUIRE(z && (xs || a) && (ys || y) && save && B > 0 && C > 0 && (C % 8) == 0 && H > 0 && W > 0, "bn_relu_apply_pool_split: bad args");
     auto al = [](const void* p, uintptr_t m) { return (reinterpret_cast<uintptr_t>(p) & m) == 0; };
@@ -1041,12 +1078,13 @@ int onet_bn_relu_apply_pool_split(const float* z, int64_t z_bs, void* xs, int64_
     const int64_t blocks = (int64_t)B * (C / 8) * bpp;
     ONET_REQUIRE(blocks < (1ll << 31) && (int64_t)H * W < (1 << 24), "bn_relu_apply_pool_split: grid too large");
     hipLaunchKernelGGL(bn_relu_apply_pool_split_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), z, z_bs, (unsigned*)xs, xs_bs,
-                       a, a_bs, (unsigned*)ys, ys_bs, y, y_bs, save, C, H, W, bpp, nparts, (const unsigned*)act_amax);
+                       a, a_bs, (unsigned*)ys, ys_bs, y, y_bs, save, C, H, W, bpp, nparts, (const unsigned*)act_amax, group_images);
     return check_launch("bn_relu_apply_pool_split_kernel");
 }
 
 int onet_bn_relu_bwd_apply_split(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save, const float* coef,
-                                 void* dzs, int64_t dzs_bs, const void* dz_amax, int nparts, int B, int C, int H, int W, void* stream) {
+                                 void* dzs, int64_t dzs_bs, const void* dz_amax, int nparts, int group_images, int B, int C, int H, int W,
+                                 void* stream) {
     ONET_REQUIRE(nparts == 1 || nparts == 2, "bn_relu_bwd_apply_split: nparts must be 2 (fp16 hi | mid) or 1 (plain bf16)");
     ONET_REQUIRE(da && z && save && dzs && (dz_amax || nparts == 1) && B > 0 && C > 0 && (C % 8) == 0 && H > 0 && W > 0 && (W % 4) == 0,
                  "bn_relu_bwd_apply_split: bad args");
@@ -1056,7 +1094,7 @@ int onet_bn_relu_bwd_apply_split(const float* da, int64_t da_bs, const float* z,
     const int64_t blocks = (int64_t)B * (C / 8) * bpp;
     ONET_REQUIRE(blocks < (1ll << 31) && (int64_t)H * W < (1 << 24), "bn_relu_bwd_apply_split: grid too large");
     hipLaunchKernelGGL(bn_relu_bwd_apply_split_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), da, da_bs, z, z_bs, save, coef,
-                       (unsigned*)dzs, dzs_bs, (const unsigned*)dz_amax, C, H, W, bpp, nparts);
+                       (unsigned*)dzs, dzs_bs, (const unsigned*)dz_amax, C, H, W, bpp, nparts, group_images);
     return check_launch("bn_relu_bwd_apply_split_kernel");
 }
 
@@ -1077,10 +1115,10 @@ int onet_bn_bwd_finalize(const float* part2, int nparts, int64_t count, float* d
 }
 
 int onet_bn_bwd_finalize_bound(const float* part2, int nparts, int64_t count, float* dgamma, float* dbeta, float* coef, int accumulate,
-                               int C, const float* save, const void* da_amax, void* dz_amax, void* stream) {
-    ONET_REQUIRE(part2 && nparts > 0 && count > 0 && C > 0 && save && da_amax && dz_amax, "bn_bwd_finalize_bound: bad args");
+                               int groups, int C, const float* save, const void* da_amax, void* dz_amax, void* stream) {
+    ONET_REQUIRE(part2 && nparts > 0 && count > 0 && C > 0 && groups >= 1 && (!dz_amax || (save && da_amax)), "bn_bwd_finalize_bound: bad args");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, as_stream(stream), part2, nparts, (double)count, dgamma, dbeta, coef,
-                       accumulate, C, save, (const unsigned*)da_amax, (unsigned*)dz_amax, sqrtf((float)(count > 1 ? count - 1 : 1)));
+                       accumulate, C, save, (const unsigned*)da_amax, (unsigned*)dz_amax, sqrtf((float)(count > 1 ? count - 1 : 1)), groups);
     return check_launch("bn_bwd_finalize_kernel");
 }
 
@@ -1096,13 +1134,13 @@ int onet_bn_relu_bwd_apply(const float* da, int64_t da_bs, const float* z, int64
 }
 
 int onet_bn_relu_bwd_apply_amax(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save, const float* coef,
-                                float* dz, int64_t dz_bs, void* amax, int B, int C, int HW, void* stream) {
-    ONET_REQUIRE(da && z && save && dz && amax && B > 0 && C > 0 && HW > 0, "bn_relu_bwd_apply_amax: bad args");
+                                float* dz, int64_t dz_bs, void* amax, int group_images, int B, int C, int HW, void* stream) {
+    ONET_REQUIRE(da && z && save && dz && B > 0 && C > 0 && HW > 0 && group_images >= 0, "bn_relu_bwd_apply_amax: bad args");
     const int chunks = cdiv(HW, 4096);
     const int64_t blocks = (int64_t)B * C * chunks;
     ONET_REQUIRE(blocks < (1ll << 31), "bn_relu_bwd_apply_amax: grid too large");
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), da, da_bs, z, z_bs, save, coef,
-                       dz, dz_bs, C, HW, chunks, (__bf16*)nullptr, (int64_t)0, (unsigned*)amax);
+                       dz, dz_bs, C, HW, chunks, (__bf16*)nullptr, (int64_t)0, (unsigned*)amax, group_images);
     return check_launch("bn_relu_bwd_apply_kernel");
 }
 

@@ -198,26 +198,26 @@ class ConvBNReLUFn(torch.autograd.Function):
                 pooled = (None, None, ops.p16_empty(Bz, C, Hz // 2, Wz // 2, z.device))
             else:
                 pooled = (torch.empty((Bz, C, Hz // 2, Wz // 2), dtype=torch.float32, device=z.device), None, None)
-        for g in range(G):
-            sl = slice(g * Bg, (g + 1) * Bg)
-            zg = z[sl]
-            if training:
-                npg = 0 if cm is None else cm.shape[1] // G
-                ops.bn_train_coeffs(zg, gamma, beta, running_mean, running_var, momentum, eps,
-                                    cm=None if cm is None else (cm, g * npg, npg), save=save_all[g], act_slots=act_slots)
-            else:
-                ops.bn_eval_coeffs(gamma, beta, running_mean, running_var, eps, save=save_all[g])
-        for g in range(G):
-            sl = slice(g * Bg, (g + 1) * Bg)
-            if pooled is not None:
-                if not ops.bn_relu_apply_pool_split(z[sl], save_all[g], None if aP is None else aP[sl], a[sl] if keep else None,
-                                                    None if pooled[2] is None else pooled[2][sl],
-                                                    None if pooled[0] is None else pooled[0][sl], slots=act_slots):
-                    raise RuntimeError("onet_amd: pre-split BatchNorm + pooling pass refused a shape ops.pre_layer_ok accepted")
-            elif aP is not None:
-                ops.bn_relu_apply_split(z[sl], save_all[g], aP[sl], a=a[sl] if keep else None, slots=act_slots)
-            else:
-                ops.bn_relu_apply(z[sl], save_all[g], out=a[sl], amax=a_amax)
+        # the statistics groups of a twin batch (consecutive batch slices) go through every pass in ONE launch: the kernels pick a
+        # group's coefficients from save_all [G][4][C] by image index
+        if training and cm is not None:
+            ops.bn_train_coeffs(z[:Bg], gamma, beta, running_mean, running_var, momentum, eps, cm=(cm, 0, cm.shape[1] // G), save=save_all,
+                                act_slots=act_slots, groups=G)
+        else:
+            for g in range(G):
+                if training:
+                    ops.bn_train_coeffs(z[g * Bg:(g + 1) * Bg], gamma, beta, running_mean, running_var, momentum, eps, save=save_all[g],
+                                        act_slots=act_slots)
+                else:
+                    ops.bn_eval_coeffs(gamma, beta, running_mean, running_var, eps, save=save_all[g])
+        gi = Bg if G > 1 else 0
+        if pooled is not None:
+            if not ops.bn_relu_apply_pool_split(z, save_all, aP, a if keep else None, pooled[2], pooled[0], slots=act_slots, group_images=gi):
+                raise RuntimeError("onet_amd: pre-split BatchNorm + pooling pass refused a shape ops.pre_layer_ok accepted")
+        elif aP is not None:
+            ops.bn_relu_apply_split(z, save_all, aP, a=a if keep else None, slots=act_slots, group_images=gi)
+        else:
+            ops.bn_relu_apply(z, save_all, out=a, amax=a_amax, group_images=gi)
         p16["a"], p16["a_slots"], p16["a_amax"] = aP, act_slots, a_amax
         ctx.x_slots = x_slots
         ctx.save_for_backward(x, z, save_all, xP)
@@ -256,16 +256,7 @@ class ConvBNReLUFn(torch.autograd.Function):
         nones = (None,) * 13
         if xP is None:
             # fp32 input (the stem): dz in fp32 for the fp32-input kernels; no input gradient path on pre-split operands
-            G = save_all.shape[0]
-            Bg = z.shape[0] // G
-            dz = torch.empty_like(z)
-            dgamma = dbeta = None
-            for g in range(G):
-                sl = slice(g * Bg, (g + 1) * Bg)
-                np4 = 0 if rec4 is None else rec4.shape[0] // G
-                _, dgamma, dbeta = ops.bn_relu_bwd(da[sl], z[sl], save_all[g], ctx.training, need_affine_grads=True, out=dz[sl],
-                                                   acc=None if g == 0 else (dgamma, dbeta), affine_out=aff if g == 0 else None,
-                                                   red4=None if rec4 is None else (rec4, g * np4, np4))
+            dz, dgamma, dbeta = ops.bn_relu_bwd_groups(da, z, save_all, ctx.training, affine_out=aff, rec4=rec4)
             dw = ops.conv3x3_wgrad_auto(x, dz, ctx.wshape, out=ops.grad_slot_if_free(pw)) if need_w else None
             dx = ops.conv3x3_auto(dz, ctx.packed, 1) if need_x else None
             return (dx, dw, (dgamma if need_g else None), (dbeta if need_b else None)) + nones

@@ -1055,27 +1055,31 @@ def _pbs(P):
     return P.stride(0) // 2 if P.shape[0] > 1 else P.shape[1] * P.shape[2] * P.shape[3] * P.shape[4] * 4
 
 
-def bn_relu_apply_split(z, save, xs, a=None, slots=None):
+def bn_relu_apply_split(z, save, xs, a=None, slots=None, group_images=0):
     """relu(bn(z)) written pre-split into xs [B, C/8, H, 2, W, 8] (a whole tensor or the leading channel groups of a concat buffer)
     and, when `a` is given, in fp32 too.  The same values, bit for bit, as bn_relu_apply (times the power of two the magnitude
-    slots select -- 1 unless the activation's bound reaches 2^15)."""
+    slots select -- 1 unless the activation's bound reaches 2^15).  group_images > 0: `save` is [G][4][C], one set of coefficients
+    per group of that many consecutive images (the statistics groups of a twin batch in one launch)."""
     z, zbs = plane(z)
     B, C, H, W = z.shape
+    assert group_images == 0 or (B % group_images == 0 and save.numel() == (B // group_images) * 4 * C and save.is_contiguous())
     _lib.call("onet_bn_relu_apply_split", _p(z), zbs, _p(xs), _pbs(xs), _p(a), 0 if a is None else (a.stride(0) if B > 1 else C * H * W),
-              _p(save), _p(slots), xs.shape[3], B, C, H, W, _stream(), nbytes=(4 + 2 * xs.shape[3] + 4 * (a is not None)) * z.numel())
+              _p(save), _p(slots), xs.shape[3], group_images, B, C, H, W, _stream(),
+              nbytes=(4 + 2 * xs.shape[3] + 4 * (a is not None)) * z.numel())
 
 
-def bn_relu_apply_pool_split(z, save, xs, a, ys, y, slots=None):
+def bn_relu_apply_pool_split(z, save, xs, a, ys, y, slots=None, group_images=0):
     """relu(bn(z)) and its 2 x 2 max-pooling in one pass: the activation pre-split (xs) and / or fp32 (a), the pooled tensor pre-split
-    (ys) or fp32 (y).  -> False where the kernel does not take the shape."""
+    (ys) or fp32 (y).  -> False where the kernel does not take the shape.  group_images: as bn_relu_apply_split."""
     z, zbs = plane(z)
     B, C, H, W = z.shape
+    assert group_images == 0 or (B % group_images == 0 and save.numel() == (B // group_images) * 4 * C and save.is_contiguous())
     n, m = C * H * W, C * (H // 2) * (W // 2)
     rc = _lib.load().onet_bn_relu_apply_pool_split(_p(z), zbs, _p(xs), 0 if xs is None else _pbs(xs), _p(a),
                                                   0 if a is None else (a.stride(0) if B > 1 else n), _p(ys), 0 if ys is None else _pbs(ys),
                                                   _p(y), 0 if y is None else (y.stride(0) if B > 1 else m), _p(save), _p(slots),
                                                   (xs if xs is not None else ys).shape[3] if (xs is not None or ys is not None) else 2,
-                                                  B, C, H, W, _stream())
+                                                  group_images, B, C, H, W, _stream())
     if rc < 0:
         raise _lib.OnetHipError(f"onet_bn_relu_apply_pool_split failed ({rc}): {_lib.last_error()}")
     return rc == 0
@@ -1093,18 +1097,42 @@ def conv3x3_pre_bn_partials(xP, pk, slots=None):
     return conv3x3_split_pre(xP, wq, Co, slots=s1, stats=cm, slots2=s2, split_ch=sc), cm
 
 
-def bn_relu_bwd_split(da, z, save_all, training, need_affine_grads=True, affine_out=None, rec=None, rec4=None, da_amax=None):
-    """BatchNorm + ReLU backward of a layer whose dz is consumed by the pre-split kernels.  Per statistics group: the reduce pass
-    (also recording max |da|, unless the records -- and da's magnitude slots -- came fused from da's producer), then the finalize
-    pass, which also writes the bound of |dz| into fresh magnitude slots (all reduce passes first: the bound needs the complete
-    max |da|), then dz written pre-split, scaled by the power of two those slots select.  Plain bf16 operands (conv == "bf16",
-    one part): no magnitudes, no scale.  -> (dzP, dz_slots | None, dgamma, dbeta)."""
-    da, dabs = plane(da)
-    z, zbs = plane(z)
+def _bn_bwd_groups(da, dabs, z, zbs, save_all, training, affine_out, rec4, da_amax, dz_slots):
+    """Reduce + finalize of a BatchNorm + ReLU backward over ALL statistics groups of the tensor (consecutive batch slices; save_all
+    [G][4][C]) in one launch each: -> (coef [G][4][C] | None, dgamma, dbeta).  rec4: the reduce records [G * np][C][4] a producer of
+    da already wrote; da_amax: magnitude slots the reduce pass records max |da| in; dz_slots: slots that receive the bound of |dz|."""
     B, C, H, W = z.shape
     HW = H * W
     G = save_all.shape[0]
     Bg = B // G
+    dev = z.device
+    assert B % G == 0 and save_all.is_contiguous()
+    if rec4 is None:
+        nparts = _bn_nparts(Bg, HW)
+        rec4 = torch.empty((G * nparts, C, 4), dtype=F32, device=dev)
+        _lib.call("onet_bn_relu_bwd_reduce_amax", _p(da), dabs, _p(z), zbs, _p(save_all), _p(rec4), G * nparts, _p(da_amax), Bg if G > 1 else 0,
+                  B, C, HW, _stream(), nbytes=8 * z.numel())
+    else:
+        assert rec4.shape[0] % G == 0 and rec4.shape[1] == C and rec4.shape[2] == 4 and rec4.is_contiguous()
+    og, ob = affine_out if affine_out is not None else (None, None)
+    dgamma = torch.empty(C, dtype=F32, device=dev) if og is None else og
+    dbeta = torch.empty(C, dtype=F32, device=dev) if ob is None else ob
+    coef = torch.empty((G, 4, C), dtype=F32, device=dev) if training else None
+    _lib.call("onet_bn_bwd_finalize_bound", _p(rec4), rec4.shape[0] // G, Bg * HW, _p(dgamma), _p(dbeta), _p(coef), 0, G, C, _p(save_all),
+              _p(da_amax), _p(dz_slots), _stream())
+    return coef, dgamma, dbeta
+
+
+def bn_relu_bwd_split(da, z, save_all, training, need_affine_grads=True, affine_out=None, rec=None, rec4=None, da_amax=None):
+    """BatchNorm + ReLU backward of a layer whose dz is consumed by the pre-split kernels, all statistics groups of the tensor per
+    launch: the reduce pass (also recording max |da|, unless the records -- and da's magnitude slots -- came fused from da's producer),
+    then the finalize pass, which also writes the bound of |dz| into fresh magnitude slots, then dz written pre-split, scaled by the
+    power of two those slots select.  Plain bf16 operands (conv == "bf16", one part): no magnitudes, no scale.
+    -> (dzP, dz_slots | None, dgamma, dbeta)."""
+    da, dabs = plane(da)
+    z, zbs = plane(z)
+    B, C, H, W = z.shape
+    G = save_all.shape[0]
     dev = z.device
     np_ = p16_parts()
     dzP = p16_empty(B, C, H, W, dev, np_)
@@ -1112,41 +1140,25 @@ def bn_relu_bwd_split(da, z, save_all, training, need_affine_grads=True, affine_
     dz_slots = new_amax(dev) if scaled else None
     if scaled and rec4 is not None and da_amax is None:
         da_amax = absmax_slots(da)                  # records fused by a producer that did not record the magnitude: one extra pass
-    parts = []
     if rec4 is None:
         da_amax = new_amax(dev) if scaled else None
-        nparts = _bn_nparts(Bg, HW)
-        for g in range(G):
-            sl = slice(g * Bg, (g + 1) * Bg)
-            part2 = torch.empty((nparts, C, 4), dtype=F32, device=dev)
-            if scaled:
-                _lib.call("onet_bn_relu_bwd_reduce_amax", _p(da[sl]), dabs, _p(z[sl]), zbs, _p(save_all[g]), _p(part2), nparts,
-                          _p(da_amax), Bg, C, HW, _stream(), nbytes=8 * z[sl].numel())
-            else:
-                _lib.call("onet_bn_relu_bwd_reduce", _p(da[sl]), dabs, _p(z[sl]), zbs, _p(save_all[g]), _p(part2), nparts, Bg, C, HW,
-                          _stream(), nbytes=8 * z[sl].numel())
-            parts.append((part2, nparts))
-    else:
-        np4 = rec4.shape[0] // G
-        assert rec4.shape[1] == C and rec4.shape[2] == 4
-        parts = [(rec4[g * np4:(g + 1) * np4], np4) for g in range(G)]
-    og, ob = affine_out if affine_out is not None else (None, None)
-    dgamma = torch.empty(C, dtype=F32, device=dev) if og is None else og
-    dbeta = torch.empty(C, dtype=F32, device=dev) if ob is None else ob
-    coefs = []
-    for g in range(G):
-        coef = torch.empty((4, C), dtype=F32, device=dev) if training else None
-        if scaled:
-            _lib.call("onet_bn_bwd_finalize_bound", _p(parts[g][0]), parts[g][1], Bg * HW, _p(dgamma), _p(dbeta), _p(coef), int(g > 0), C,
-                      _p(save_all[g]), _p(da_amax), _p(dz_slots), _stream())
-        else:
-            _lib.call("onet_bn_bwd_finalize", _p(parts[g][0]), parts[g][1], Bg * HW, _p(dgamma), _p(dbeta), _p(coef), int(g > 0), C, _stream())
-        coefs.append(coef)
-    for g in range(G):
-        sl = slice(g * Bg, (g + 1) * Bg)
-        _lib.call("onet_bn_relu_bwd_apply_split", _p(da[sl]), dabs, _p(z[sl]), zbs, _p(save_all[g]), _p(coefs[g]), _p(dzP[sl]), _pbs(dzP),
-                  _p(dz_slots), np_, Bg, C, H, W, _stream(), nbytes=(8 + 2 * np_) * z[sl].numel())
+    coef, dgamma, dbeta = _bn_bwd_groups(da, dabs, z, zbs, save_all, training, affine_out, rec4, da_amax, dz_slots)
+    _lib.call("onet_bn_relu_bwd_apply_split", _p(da), dabs, _p(z), zbs, _p(save_all), _p(coef), _p(dzP), _pbs(dzP), _p(dz_slots), np_,
+              B // G if G > 1 else 0, B, C, H, W, _stream(), nbytes=(8 + 2 * np_) * z.numel())
     return dzP, dz_slots, dgamma, dbeta
+
+
+def bn_relu_bwd_groups(da, z, save_all, training, affine_out=None, rec4=None):
+    """The same for a layer whose dz stays fp32 (the stem under pre-split storage): -> (dz, dgamma, dbeta)."""
+    da, dabs = plane(da)
+    z, zbs = plane(z)
+    B, C, H, W = z.shape
+    G = save_all.shape[0]
+    coef, dgamma, dbeta = _bn_bwd_groups(da, dabs, z, zbs, save_all, training, affine_out, rec4, None, None)
+    dz = torch.empty((B, C, H, W), dtype=F32, device=z.device)
+    _lib.call("onet_bn_relu_bwd_apply_amax", _p(da), dabs, _p(z), zbs, _p(save_all), _p(coef), _p(dz), C * H * W, None, B // G if G > 1 else 0,
+              B, C, H * W, _stream(), nbytes=12 * z.numel())
+    return dz, dgamma, dbeta
 
 
 def split_wgrad_ok(x, dz):
@@ -1403,10 +1415,12 @@ def _bn_nparts(B, HW):
     return B * max(1, (HW + 16383) // 16384)
 
 
-def bn_train_coeffs(z, gamma, beta, running_mean, running_var, momentum, eps, cm=None, save=None, act_slots=None):
+def bn_train_coeffs(z, gamma, beta, running_mean, running_var, momentum, eps, cm=None, save=None, act_slots=None, groups=1):
     """batch statistics -> save [4][C] = (mean, invstd, scale, shift); updates running stats in place.
     `cm` = (records [C, NP, 3], first, count): the convolution already produced this batch's statistics records
-    (`conv3x3_fwd_bn_partials`), records first .. first+count-1 of every channel belong to `z`."""
+    (`conv3x3_fwd_bn_partials`), records first .. first+count-1 of every channel belong to `z`.
+    groups > 1 (with `cm`): z is ONE statistics group of a twin batch and the records of the others follow (count each): all groups in
+    one launch, save [groups][4][C], the running statistics updated group after group."""
     z, zbs = plane(z)
     B, C, H, W = z.shape
     if B * H * W <= 1:
@@ -1416,13 +1430,15 @@ def bn_train_coeffs(z, gamma, beta, running_mean, running_var, momentum, eps, cm
         assert rec.shape[0] == C and rec.shape[2] == 3 and 0 <= first and first + count <= rec.shape[1]
         if save is None:
             save = torch.empty((4, C), dtype=F32, device=z.device)
-        if act_slots is not None:      # ... also the bound of relu(bn(z)) into the activation's magnitude slots (pre-split storage)
+        assert groups == 1 or (first + groups * count <= rec.shape[1] and save.shape[0] == groups and save.is_contiguous())
+        if act_slots is not None or groups > 1:   # ... also the bound of relu(bn(z)) into the activation's magnitude slots (pre-split storage)
             _lib.call("onet_bn_finalize_cm_act", rec.data_ptr() + first * 12, count, rec.shape[1] * 3, _p(gamma), _p(beta),
-                      _p(running_mean), _p(running_var), float(momentum), float(eps), _p(save), _p(act_slots), C, _stream())
+                      _p(running_mean), _p(running_var), float(momentum), float(eps), _p(save), _p(act_slots), groups, C, _stream())
             return save
         _lib.call("onet_bn_finalize_cm", rec.data_ptr() + first * 12, count, rec.shape[1] * 3, _p(gamma), _p(beta),
                   _p(running_mean), _p(running_var), float(momentum), float(eps), _p(save), C, _stream())
         return save
+    assert groups == 1
     nparts = _bn_nparts(B, H * W)
     part = torch.empty((nparts, C, 3), dtype=F32, device=z.device)
     _lib.call("onet_bn_stats_partial", _p(z), zbs, _p(part), nparts, B, C, H * W, _stream(), nbytes=4 * z.numel())
@@ -1463,16 +1479,18 @@ def tag_amax(t, slots):
     return t
 
 
-def bn_relu_apply(z, save, out=None, out16=None, no_fp32=False, amax=None):
+def bn_relu_apply(z, save, out=None, out16=None, no_fp32=False, amax=None, group_images=0):
     """a = relu(bn(z)); out16: plane-contiguous bf16 destination for a copy of a (bf16 storage of the conv operands);
-    no_fp32 (with out16): write the bf16 copy ONLY and return None.  amax: magnitude slots that receive max a (fp32 output only)."""
+    no_fp32 (with out16): write the bf16 copy ONLY and return None.  amax: magnitude slots that receive max a (fp32 output only).
+    group_images > 0 (fp32 output only): save is [G][4][C], one set per group of that many consecutive images."""
     z, zbs = plane(z)
     B, C, H, W = z.shape
-    if amax is not None and out16 is None:
+    assert group_images == 0 or (out16 is None and B % group_images == 0 and save.numel() == (B // group_images) * 4 * C and save.is_contiguous())
+    if (amax is not None or group_images) and out16 is None:
         if out is None:
             out = torch.empty((B, C, H, W), dtype=F32, device=z.device)
-        _lib.call("onet_bn_relu_apply_amax", _p(z), zbs, _p(out), out.stride(0) if B > 1 else C * H * W, _p(save), _p(amax), B, C, H * W,
-                  _stream(), nbytes=8 * z.numel())
+        _lib.call("onet_bn_relu_apply_amax", _p(z), zbs, _p(out), out.stride(0) if B > 1 else C * H * W, _p(save), _p(amax), group_images,
+                  B, C, H * W, _stream(), nbytes=8 * z.numel())
         return out
     if out16 is not None and no_fp32:
         o16bs = out16.stride(0) if B > 1 else C * H * W
@@ -1549,7 +1567,7 @@ def bn_bwd_coefs(da, z, save, training, need_affine_grads=True, acc=None, affine
         else:
             part2 = torch.empty((nparts, C, 4), dtype=F32, device=dev)
             if da_amax is not None:
-                _lib.call("onet_bn_relu_bwd_reduce_amax", _p(da), dabs, _p(z), zbs, _p(save), _p(part2), nparts, _p(da_amax), B, C, HW,
+                _lib.call("onet_bn_relu_bwd_reduce_amax", _p(da), dabs, _p(z), zbs, _p(save), _p(part2), nparts, _p(da_amax), 0, B, C, HW,
                           _stream(), nbytes=8 * z.numel())
             else:
                 _lib.call("onet_bn_relu_bwd_reduce", _p(da), dabs, _p(z), zbs, _p(save), _p(part2), nparts, B, C, HW, _stream(),
@@ -1599,7 +1617,7 @@ def bn_relu_bwd(da, z, save, training, need_affine_grads=True, out=None, acc=Non
     dz = torch.empty((B, C, H, W), dtype=F32, device=dev) if out is None else out
     dzbs = dz.stride(0) if B > 1 else C * HW
     if amax is not None:
-        _lib.call("onet_bn_relu_bwd_apply_amax", _p(da), dabs, _p(z), zbs, _p(save), _p(coef), _p(dz), dzbs, _p(amax), B, C, HW,
+        _lib.call("onet_bn_relu_bwd_apply_amax", _p(da), dabs, _p(z), zbs, _p(save), _p(coef), _p(dz), dzbs, _p(amax), 0, B, C, HW,
                   _stream(), nbytes=12 * z.numel())
         return dz, dgamma, dbeta
     _lib.call("onet_bn_relu_bwd_apply", _p(da), dabs, _p(z), zbs, _p(save), _p(coef), _p(dz), dzbs, B, C, HW,
