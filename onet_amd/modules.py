@@ -117,7 +117,7 @@ class DoubleConv(nn.Module):
             raise ValueError(f"Expected more than 1 value per channel when training, got input size "
                              f"{[x.shape[0] // groups, conv.out_channels, x.shape[2], x.shape[3]]}")
         if training and bn.track_running_stats:
-            bn.num_batches_tracked.add_(groups)
+            ops.count_batches(bn.num_batches_tracked, groups)
         # bf16 storage (BASELINE config 3): the bf16 copy of x its producer left, a destination for the copy of the output
         b16 = {"x16": ops.b16_of(x), "out16": out16, "drop_fp32": drop_fp32} if ops.bf16_storage() else None
         # magnitude slots (ops.tag_amax): what x's producer recorded of it goes in, what this unit records of its output comes out
@@ -301,6 +301,11 @@ class UNet(nn.Module):
                 m.bias.data.zero_()
 
     def forward(self, x, groups=1):
+        # the 18 num_batches_tracked counters of a pass take their increments in one multi-tensor launch when the pass is through
+        with ops.counting_batches():
+            return self._forward(x, groups)
+
+    def _forward(self, x, groups=1):
         # ConvTranspose path: the four skip tensors are produced directly inside the first half of their concat
         # buffers (allocated here, before the encoder runs), the decoder fills the second half
         cats = [None] * 4

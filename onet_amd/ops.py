@@ -855,6 +855,40 @@ def pack3x3_split(w):
     return wf, wd
 
 
+COUNT_FOREACH = _os.environ.get("ONET_COUNT_FOREACH", "1") != "0"    # 0 (diagnostic): one add_ launch per BatchNorm counter
+
+
+class counting_batches:
+    """Within the block BatchNorm's num_batches_tracked increments (count_batches) are collected and applied in ONE multi-tensor launch
+    at the end (also when the block raises: the units that ran have updated their running statistics)."""
+
+    def __enter__(self):
+        self.outer = getattr(_TLS, "counters", None)
+        _TLS.counters = [] if COUNT_FOREACH else None
+        return self
+
+    def __exit__(self, *exc):
+        pending, _TLS.counters = _TLS.counters or [], self.outer
+        by_inc = {}
+        for t, n in pending:
+            by_inc.setdefault(n, []).append(t)
+        for n, ts in by_inc.items():
+            if len(ts) > 1 and all(t.is_cuda for t in ts):
+                torch._foreach_add_(ts, n)
+            else:
+                for t in ts:
+                    t.add_(n)
+        return False
+
+
+def count_batches(counter, n):
+    pending = getattr(_TLS, "counters", None)
+    if pending is None:
+        counter.add_(n)
+    else:
+        pending.append((counter, n))
+
+
 AMAX_SLOTS = 64 * 32       # 64 magnitude slots, one per 128-byte line (bn.hip: amax_commit)
 
 
