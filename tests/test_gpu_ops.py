@@ -1107,3 +1107,62 @@ def test_convT_presplit_epilogue(dev, B, Cin, h, w):
     assert ops.convT2x2_fwd_p(x, wf, bias, cat[:, Ct // 8:], Ct, 0, 0)
     assert torch.equal(cat[:, Ct // 8:], ops.split_pack_act(ref, f16=True))
     assert float(cat[:, :Ct // 8].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("Cout,Cin", [(64, 64), (128, 64), (72, 48), (512, 256), (40, 16)])
+def test_split_weight_packs_bit_for_bit(dev, Cout, Cin, monkeypatch):
+    """The weight packs of conv_split.hip ([K/16][part][tap][half][N][8], written by pack3x3_split_kernel) against their definition in
+    torch: forward (K = Cin) and input gradient (K = Cout rounded up to 16, taps rotated) orientation; fp16 (hi, mid) parts of
+    2^k w with the stored scale putting max |w| into [2^13, 2^14), bf16 (hi, mid) parts, plain bf16; channel counts that do not fill
+    the 64-channel tiles."""
+    from onet_amd import ops
+    w = rnd(Cout, Cin, 3, 3, seed=5, scale=0.07)
+    w[3, 5, 1, 1] = 3.1                                   # the maximum the fp16 scale is chosen from
+
+    def layout(v):                                        # v [K][N][9] -> [K/16][tap][half][N][8]
+        K, N = v.shape[0], v.shape[1]
+        return v.reshape(K // 16, 2, 8, N, 9).permute(0, 4, 1, 3, 2).contiguous()
+
+    def operand(which):
+        if which == 0:
+            return w.reshape(Cout, Cin, 9).permute(1, 0, 2)
+        K = -(-Cout // 16) * 16
+        v = torch.zeros(K, Cin, 9)
+        v[:Cout] = w.reshape(Cout, Cin, 9).flip(-1)
+        return v
+
+    def check(pack, which, mode):
+        v = layout(operand(which))
+        n = v.numel()
+        if mode == 2:
+            assert torch.equal(pack[:n].cpu().view(v.shape), v.to(torch.bfloat16))
+            return
+        got = pack[:2 * n].cpu().view(v.shape[0], 2, *v.shape[1:])
+        if mode == 1:
+            scale, inv = [float(t) for t in pack[2 * n:2 * n + 4].view(torch.float32).cpu()]
+            assert scale * inv == 1.0 and 2.0 ** 13 <= 3.1 * scale < 2.0 ** 14
+            vs = v * scale
+            hi = vs.to(torch.float16)
+            mid = (vs - hi.float()).to(torch.float16)
+        else:
+            hi = v.to(torch.bfloat16)
+            mid = (v - hi.float()).to(torch.bfloat16)
+        assert torch.equal(got[:, 0], hi) and torch.equal(got[:, 1], mid)
+
+    monkeypatch.setattr(ops, "SPLIT_GRAD_F16", True)
+    qf, qd = ops.pack3x3_split(w.to(dev))
+    if Cin % 16 == 0:
+        check(qf, 0, 1)
+    check(qd, 1, 1)
+    monkeypatch.setattr(ops, "SPLIT_F16", False)
+    monkeypatch.setattr(ops, "SPLIT_GRAD_F16", False)
+    monkeypatch.setattr(ops, "PRESPLIT", False)
+    qf, qd = ops.pack3x3_split(w.to(dev))
+    assert qd.dtype == torch.bfloat16
+    if Cin % 16 == 0:
+        check(qf, 0, 0)
+    check(qd, 1, 0)
+    if Cin % 32 == 0 and Cout % 32 == 0:
+        pf, pd = ops.pack3x3_plain16(w.to(dev))
+        check(pf, 0, 2)
+        check(pd, 1, 2)
