@@ -226,10 +226,16 @@ class _AllHook:
         PROFILE_ALL.setdefault(name, []).append((nbytes, e0, e1))
 
 
-def profile_start(everything=True):
-    global PROFILE, PROFILE_ALL
+PROFILE_ONLY = None
+
+
+def profile_start(everything=True, only=None):
+    """everything: bracket every launch of the library (MFMA kernels -> PROFILE, all others -> PROFILE_ALL); else the MFMA kernels
+    only -- or, with `only` = a set of kinds, those kinds alone (bench.py's timed region: the dominant kernel)."""
+    global PROFILE, PROFILE_ALL, PROFILE_ONLY
     PROFILE = {}
     PROFILE_ALL = {} if everything else None
+    PROFILE_ONLY = None if (everything or only is None) else frozenset(only)
     _lib.PROFILE_HOOK = _AllHook if everything else None
 
 
@@ -242,9 +248,9 @@ def profile_stop():
     return out
 
 
-def _prof_begin():
+def _prof_begin(kind=None):
     global _IN_MFMA_BRACKET
-    if PROFILE is None:
+    if PROFILE is None or (PROFILE_ONLY is not None and kind not in PROFILE_ONLY):
         return None
     e0 = torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -356,7 +362,7 @@ def convT2x2_fwd(x, wq, bias, out, Ct, pt, pl, out16=None):
     flops, nb = 2.0 * B * h * w * Cin * 4 * Ct, 4.0 * (B * h * w * (Cin + 4 * Ct) + 4 * Cin * Ct)
     if out16 is not None:
         o16bs = out16.stride(0) if B > 1 else Ct * Ho * Wo
-        e0 = _prof_begin()
+        e0 = _prof_begin("convt_gemm_kernel")
         rc = _lib.load().onet_convT2x2_fwd_b(_p(x), xbs, _p(wq), _p(bias), _p(out), obs, _p(out16), o16bs, B, Cin, Ct, h, w, Ho, Wo,
                                              pt, pl, convt_operand_bf16(B, h, w, Ct), _stream())
         _prof_end("convt_gemm_kernel", flops if rc == 0 else 0.0, e0, nb if rc == 0 else 0.0)
@@ -366,7 +372,7 @@ def convT2x2_fwd(x, wq, bias, out, Ct, pt, pl, out16=None):
             raise _lib.OnetHipError(f"onet_convT2x2_fwd_b failed ({rc}): {_lib.last_error()}")
     if out is None:
         return False
-    e0 = _prof_begin()
+    e0 = _prof_begin("convt_gemm_kernel")
     _lib.call("onet_convT2x2_fwd", _p(x), xbs, _p(wq), _p(bias), _p(out), obs, B, Cin, Ct, h, w, Ho, Wo, pt, pl,
               convt_operand_bf16(B, h, w, Ct), _stream())
     _prof_end("convt_gemm_kernel", flops, e0, nb)
@@ -389,7 +395,7 @@ def convT2x2_fwd_p(x, wq, bias, outP, Ct, pt, pl, slots=None):
     x, xbs = plane(x)
     B, Cin, h, w = x.shape
     Ho, Wo = outP.shape[2], outP.shape[4]
-    e0 = _prof_begin()
+    e0 = _prof_begin("convt_gemm_kernel")
     rc = _lib.load().onet_convT2x2_fwd_p(_p(x), xbs, _p(wq), _p(bias), _p(outP), _pbs(outP), _p(slots), outP.shape[3], B, Cin, Ct, h, w, Ho, Wo, pt, pl,
                                          convt_operand_bf16(B, h, w, Ct), _stream())
     flops, nb = 2.0 * B * h * w * Cin * 4 * Ct, 4.0 * (B * h * w * (Cin + 4 * Ct) + 4 * Cin * Ct)
@@ -627,7 +633,7 @@ def conv3x3_fwd_bn_partials(x, pk, x16=None, norm=None, amax=None):
         nparts = int(_lib.load().onet_conv3x3_split_nparts(B, H, W)) if (FUSE_BN_STATS and not sync_bn()) else 0
         out = torch.empty((B, Co, H, W), dtype=F32, device=zs.device)
         cm = torch.empty((Co, nparts, 3), dtype=F32, device=zs.device) if nparts > 0 else None
-        e0 = _prof_begin()
+        e0 = _prof_begin("conv3x3_split_kernel")
         wq = pk.get_pack("split")[0]
         _lib.call("onet_conv3x3_split_fwd_norm", _p(zs), zbs, _p(save), save.shape[0], _p(wq), int(wq.dtype == torch.float16), _p(out),
                   Co * H * W, _p(cm), B, Ci, Co, H, W, _stream())
@@ -643,7 +649,7 @@ def conv3x3_fwd_bn_partials(x, pk, x16=None, norm=None, amax=None):
             w = pk.w if pk.w.is_contiguous() else pk.w.contiguous()
             out = torch.empty((B, Co, H, W), dtype=F32, device=x.device)
             cm = torch.empty((Co, nparts, 3), dtype=F32, device=x.device)
-            e0 = _prof_begin()
+            e0 = _prof_begin("stem_conv_stats_kernel")
             _lib.call("onet_conv3x3_stem_fwd_stats", _p(xs), xbs, _p(w), _p(out), Co * H * W, _p(cm), B, Ci, Co, H, W, _stream())
             _prof_end("stem_conv_stats_kernel", 2.0 * B * H * W * Ci * Co * 9, e0, 4.0 * (B * H * W * (Ci + Co) + 9 * Ci * Co))
             return out, cm
@@ -662,7 +668,7 @@ def conv3x3_fwd_bn_partials(x, pk, x16=None, norm=None, amax=None):
             dev = (x16p if x16p is not None else x).device
             out = torch.empty((B, Co, H, W), dtype=F32, device=dev)
             cm = torch.empty((Co, nparts, 3), dtype=F32, device=dev)
-            e0 = _prof_begin()
+            e0 = _prof_begin("conv3x3_bf16_kernel")
             _lib.call("onet_conv3x3_bf16_fwd_stats", _p(x16p if x16p is not None else xs), int(x16p is not None),
                       x16bs if x16p is not None else xbs, _p(wq), _p(out), Co * H * W, _p(cm), B, Ci, Co, H, W, _stream())
             _prof_end("conv3x3_bf16_kernel", 2.0 * B * H * W * Ci * Co * 9, e0,
@@ -680,7 +686,7 @@ def conv3x3_fwd_bn_partials(x, pk, x16=None, norm=None, amax=None):
                 xbs = xs.stride(0) if B > 1 else xs[0].numel()
             out = torch.empty((B, Co, H, W), dtype=F32, device=x.device)
             cm = torch.empty((Co, nparts, 3), dtype=F32, device=x.device)
-            e0 = _prof_begin()
+            e0 = _prof_begin("conv3x3_split_kernel")
             if wq.dtype == torch.float16:
                 _lib.call("onet_conv3x3_split_conv_amax", _p(xs), xbs, _p(amax), 0, _p(wq), _p(out), Co * H * W, _p(cm), B, Ci, Co, H, W,
                           _stream())
@@ -695,7 +701,7 @@ def conv3x3_fwd_bn_partials(x, pk, x16=None, norm=None, amax=None):
     x, xbs = plane(x)
     out = torch.empty((B, Co, H, W), dtype=F32, device=x.device)
     cm = torch.empty((Co, nparts, 3), dtype=F32, device=x.device)
-    e0 = _prof_begin()
+    e0 = _prof_begin("conv_wino4_kernel")
     _lib.call("onet_conv3x3_winograd4_fwd_stats", _p(x), xbs, _p(wq), _p(out), Co * H * W, _p(cm), B, Ci, Co, H, W,
               _stream())
     _prof_end("conv_wino4_kernel", 2.0 * B * H * W * Ci * Co * 9, e0, 4.0 * (B * H * W * (Ci + Co) + 9 * Ci * Co))
@@ -728,7 +734,7 @@ def conv3x3_dgrad_bnreduce(dz, pk, z_prev, save_prev):
     dz, dbs = plane(dz)
     da = torch.empty((B, Co, H, W), dtype=F32, device=dz.device)
     rec = torch.empty((Co, nparts, 2), dtype=F32, device=dz.device)
-    e0 = _prof_begin()
+    e0 = _prof_begin("conv_wino4_kernel")
     _lib.call("onet_conv3x3_winograd4_dgrad_bnreduce", _p(dz), dbs, _p(wq), _p(da), Co * H * W, _p(z_prev), zbs,
               _p(save_prev), B // G, _p(rec), B, Ci, Co, H, W, _stream())
     _prof_end("conv_wino4_kernel", 2.0 * B * H * W * Ci * Co * 9, e0, 4.0 * (B * H * W * (Ci + Co) + 9 * Ci * Co))
@@ -753,7 +759,7 @@ def conv3x3_winograd(x, wq, Cout, out=None):
     if out is None:
         out = torch.empty((B, Cout, H, W), dtype=F32, device=x.device)
     zbs = out.stride(0) if B > 1 else Cout * H * W
-    e0 = _prof_begin()
+    e0 = _prof_begin("conv_wino_kernel")
     _lib.call("onet_conv3x3_winograd_fwd", _p(x), xbs, _p(wq), _p(out), zbs, B, Cin, Cout, H, W, _stream())
     _prof_end("conv_wino_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
     return out
@@ -779,7 +785,7 @@ def conv3x3_winograd4(x, wq, Cout, out=None):
     if out is None:
         out = torch.empty((B, Cout, H, W), dtype=F32, device=x.device)
     zbs = out.stride(0) if B > 1 else Cout * H * W
-    e0 = _prof_begin()
+    e0 = _prof_begin("conv_wino4_kernel")
     _lib.call("onet_conv3x3_winograd4_fwd", _p(x), xbs, _p(wq), _p(out), zbs, B, Cin, Cout, H, W, _stream())
     _prof_end("conv_wino4_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
     return out
@@ -816,7 +822,7 @@ def conv3x3_bf16(x, wq, Cout, out=None, x16=None):
     if out is None:
         out = torch.empty((B, Cout, H, W), dtype=F32, device=dev)
     zbs = out.stride(0) if B > 1 else Cout * H * W
-    e0 = _prof_begin()
+    e0 = _prof_begin("conv3x3_bf16_kernel")
     if x16 is not None:
         _lib.call("onet_conv3x3_bf16_fwd_b", _p(x16), x16bs, _p(wq), _p(out), zbs, B, Cin, Cout, H, W, _stream())
         nb = B * H * W * (2.0 * Cin + 4.0 * Cout) + 18.0 * Cin * Cout
@@ -943,7 +949,7 @@ def conv3x3_split(x, wq, Cout, out=None, norm=None, amax=None, always=False):
         B, Cin, H, W = x.shape
         if out is None:
             out = torch.empty((B, Cout, H, W), dtype=F32, device=x.device)
-        e0 = _prof_begin()
+        e0 = _prof_begin("conv3x3_split_kernel")
         _lib.call("onet_conv3x3_split_fwd_norm", _p(x), xbs, _p(norm), norm.shape[0], _p(wq), f16, _p(out),
                   out.stride(0) if B > 1 else Cout * H * W, None, B, Cin, Cout, H, W, _stream())
         _prof_end("conv3x3_split_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
@@ -958,7 +964,7 @@ def conv3x3_split(x, wq, Cout, out=None, norm=None, amax=None, always=False):
     zbs = out.stride(0) if B > 1 else Cout * H * W
     if f16 and always and amax is None:
         amax = absmax_slots(x)
-    e0 = _prof_begin()
+    e0 = _prof_begin("conv3x3_split_kernel")
     if f16:
         _lib.call("onet_conv3x3_split_conv_amax", _p(x), xbs, _p(amax), int(always), _p(wq), _p(out), zbs, None, B, Cin, Cout, H, W, _stream())
     else:
@@ -992,7 +998,7 @@ def conv3x3_split_pre(xs, wq, Cout, out=None, slots=None, always=False, stats=No
     Cin = C8 * 8
     if out is None:
         out = torch.empty((B, Cout, H, W), dtype=F32, device=xs.device)
-    e0 = _prof_begin()
+    e0 = _prof_begin("conv3x3_split_pre_kernel")
     _lib.call("onet_conv3x3_split_fwd_pre", _p(xs), _pbs(xs), _p(slots), int(always), _p(slots2), int(split_ch if slots2 is not None or slots is not None else 0),
               _p(wq), f16, _p(out),
               out.stride(0) if B > 1 else Cout * H * W, _p(stats), B, Cin, Cout, H, W, _stream())
@@ -1013,7 +1019,7 @@ def conv3x3_split_wgrad_pre(xs, dzs, dw_shape, out=None, x_slots=None, dz_slots=
     dw = out if out is not None else torch.empty(dw_shape, dtype=F32, device=xs.device)
     need = _lib.load().onet_conv3x3_split_wgrad_ws_bytes(B, Cin, Cout, H, W)
     ws = workspace(need, xs.device)
-    e0 = _prof_begin()
+    e0 = _prof_begin("conv3x3_split_wgrad_pre_kernel")
     _lib.call("onet_conv3x3_split_wgrad_pre", _p(xs), _pbs(xs), _p(x_slots), _p(x_slots2), int(split_ch), _p(dzs),
               _pbs(dzs), _p(dz_slots), 2 if two == 1 else int(xs.dtype == torch.float16), _p(dw), _p(ws),
               ws.numel() * 4, B, Cin, Cout, H, W, 0, _stream())
@@ -1235,7 +1241,7 @@ def conv3x3_split_wgrad(x, dz, dw_shape, out=None, norm=None, dz_amax=None, x_am
         Cout = dz.shape[1]
         dw = torch.empty(dw_shape, dtype=F32, device=x.device) if out is None else out
         ws = workspace(_lib.load().onet_conv3x3_split_wgrad_ws_bytes(B, Cin, Cout, H, W), x.device)
-        e0 = _prof_begin()
+        e0 = _prof_begin("conv3x3_split_wgrad_kernel")
         _lib.call("onet_conv3x3_split_wgrad_f16", _p(x), xbs, _p(x_amax), _p(norm), 0 if norm is None else norm.shape[0], _p(dz), dzbs,
                   _p(dz_amax), _p(dw), _p(ws), ws.numel() * 4, B, Cin, Cout, H, W, 0, _stream())
         _prof_end("conv3x3_split_wgrad_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
@@ -1248,7 +1254,7 @@ def conv3x3_split_wgrad(x, dz, dw_shape, out=None, norm=None, dz_amax=None, x_am
         Cout = dz.shape[1]
         dw = torch.empty(dw_shape, dtype=F32, device=x.device) if out is None else out
         ws = workspace(_lib.load().onet_conv3x3_split_wgrad_ws_bytes(B, Cin, Cout, H, W), x.device)
-        e0 = _prof_begin()
+        e0 = _prof_begin("conv3x3_split_wgrad_kernel")
         _lib.call("onet_conv3x3_split_wgrad_norm", _p(x), xbs, _p(norm), norm.shape[0], _p(dz), dzbs, _p(dw), _p(ws), ws.numel() * 4,
                   B, Cin, Cout, H, W, 0, _stream())
         _prof_end("conv3x3_split_wgrad_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
@@ -1261,7 +1267,7 @@ def conv3x3_split_wgrad(x, dz, dw_shape, out=None, norm=None, dz_amax=None, x_am
     dw = torch.empty(dw_shape, dtype=F32, device=x.device) if out is None else out
     need = _lib.load().onet_conv3x3_split_wgrad_ws_bytes(B, Cin, Cout, H, W)
     ws = workspace(need, x.device)
-    e0 = _prof_begin()
+    e0 = _prof_begin("conv3x3_split_wgrad_kernel")
     _lib.call("onet_conv3x3_split_wgrad", _p(x), xbs, _p(dz), dzbs, _p(dw), _p(ws), ws.numel() * 4, B, Cin, Cout, H, W, 0, _stream())
     _prof_end("conv3x3_split_wgrad_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
     return dw
@@ -1291,7 +1297,7 @@ def conv3x3_winograd_wgrad(x, dz, dw_shape, out=None):
     dw = torch.empty(dw_shape, dtype=F32, device=x.device) if out is None else out
     need = _lib.load().onet_conv3x3_winograd_wgrad_ws_bytes(B, Cin, Cout, H, W)
     ws = workspace(need, x.device)
-    e0 = _prof_begin()
+    e0 = _prof_begin("conv_wino_wgrad_kernel")
     _lib.call("onet_conv3x3_winograd_wgrad", _p(x), xbs, _p(dz), dzbs, _p(dw), _p(ws), ws.numel() * 4, B, Cin, Cout,
               H, W, 0, _stream())
     _prof_end("conv_wino_wgrad_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
@@ -1308,7 +1314,7 @@ def conv3x3_winograd4_wgrad(x, dz, dw_shape, out=None):
     dw = torch.empty(dw_shape, dtype=F32, device=x.device) if out is None else out
     need = _lib.load().onet_conv3x3_winograd4_wgrad_ws_bytes(B, Cin, Cout, H, W)
     ws = workspace(need, x.device)
-    e0 = _prof_begin()
+    e0 = _prof_begin("conv_wino4_wgrad_kernel")
     _lib.call("onet_conv3x3_winograd4_wgrad", _p(x), xbs, _p(dz), dzbs, _p(dw), _p(ws), ws.numel() * 4, B, Cin, Cout, H, W,
               0, _stream())
     _prof_end("conv_wino4_wgrad_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
@@ -1353,7 +1359,7 @@ def conv3x3_wgrad_bf16(x, dz, dw_shape, out=None, x16=None, dz16=None):
     dw = torch.empty(dw_shape, dtype=F32, device=dev) if out is None else out
     need = _lib.load().onet_conv3x3_wgrad_bf16_ws_bytes(B, Cin, Cout, H, W)
     ws = workspace(need, dev)
-    e0 = _prof_begin()
+    e0 = _prof_begin("conv3x3_wgrad_bf16_kernel")
     if x16 is None and dz16 is None:
         _lib.call("onet_conv3x3_wgrad_bf16", _p(x), xbs, _p(dz), dzbs, _p(dw), _p(ws), ws.numel() * 4, B, Cin, Cout, H, W, 0,
                   _stream())
@@ -1395,7 +1401,7 @@ def conv_fwd(x, wp, Cout, ks, out=None):
     if out is None:
         out = torch.empty((B, Cout, H, W), dtype=F32, device=x.device)
     zbs = out.stride(0) if B > 1 else Cout * H * W
-    e0 = _prof_begin()
+    e0 = _prof_begin("conv_fwd_kernel")
     _lib.call("onet_conv_fwd", _p(x), xbs, _p(wp), _p(out), zbs, None, B, Cin, Cout, H, W, ks, _stream())
     _prof_end("conv_fwd_kernel", 2.0 * B * H * W * Cin * Cout * ks * ks, e0,
               4.0 * (B * H * W * (Cin + Cout) + ks * ks * Cin * Cout))
@@ -1411,7 +1417,7 @@ def conv_wgrad(x, dz, dw_shape, ks, out_layout=0, out=None):
     dw = torch.empty(dw_shape, dtype=F32, device=x.device) if out is None else out
     need = _lib.load().onet_conv_wgrad_ws_bytes(B, Cin, Cout, H, W, ks)
     ws = workspace(need, x.device)
-    e0 = _prof_begin()
+    e0 = _prof_begin("conv_wgrad_kernel")
     _lib.call("onet_conv_wgrad", _p(x), xbs, _p(dz), dzbs, _p(dw), _p(ws), ws.numel() * 4, B, Cin, Cout, H, W, ks,
               out_layout, 0, _stream())
     _prof_end("conv_wgrad_kernel", 2.0 * B * H * W * Cin * Cout * ks * ks, e0,
@@ -1780,7 +1786,7 @@ def convT2x2_dgrad(dy, wp_dgrad, Cin, h, w, pt, pl, want_dbias=False, db_out=Non
         if need > 0:
             db = torch.empty(Ct, dtype=F32, device=dy.device) if db_out is None else db_out
             ws = torch.empty(need // 4, dtype=F32, device=dy.device)
-            e0 = _prof_begin()
+            e0 = _prof_begin("convt_gemm_kernel")
             rc = lib.onet_convT2x2_dgrad_dbias(_p(dy), dybs, _p(wp_dgrad), _p(dx), Cin * h * w, _p(db), _p(ws), need, B, Cin, Ct, h,
                                                w, Ho, Wo, pt, pl, convt_operand_bf16(B, h, w, Ct), _stream())
             if rc == 0:
@@ -1789,7 +1795,7 @@ def convT2x2_dgrad(dy, wp_dgrad, Cin, h, w, pt, pl, want_dbias=False, db_out=Non
             _prof_end("convt_gemm_kernel", 0.0, e0, 0.0)
             if rc < 0:
                 raise _lib.OnetHipError(f"onet_convT2x2_dgrad_dbias failed ({rc}): {_lib.last_error()}")
-    e0 = _prof_begin()
+    e0 = _prof_begin("convt_gemm_kernel")
     _lib.call("onet_convT2x2_dgrad", _p(dy), dybs, _p(wp_dgrad), _p(dx), Cin * h * w, B, Cin, Ct, h, w, Ho, Wo, pt, pl,
               convt_operand_bf16(B, h, w, Ct), _stream())
     _prof_end("convt_gemm_kernel", flops, e0, nbytes)
@@ -1806,7 +1812,7 @@ def convT2x2_wgrad(x, dy, dw_shape, pt, pl, want_dbias, out=None, db_out=None):
     dw = torch.empty(dw_shape, dtype=F32, device=x.device) if out is None else out
     need = _lib.load().onet_convT2x2_wgrad_ws_bytes(B, Cin, Ct, h, w)
     ws = workspace(need, x.device)
-    e0 = _prof_begin()
+    e0 = _prof_begin("convt_wgrad_gemm_kernel")
     _lib.call("onet_convT2x2_wgrad", _p(x), xbs, _p(dy), dybs, _p(dw), _p(ws), ws.numel() * 4, B, Cin, Ct, h, w, Ho, Wo,
               pt, pl, convt_operand_bf16(B, h, w, Ct), _stream())
     _prof_end("convt_wgrad_gemm_kernel", 2.0 * B * h * w * Cin * 4 * Ct, e0, 4.0 * (B * h * w * (Cin + 4 * Ct) + 4 * Cin * Ct))
