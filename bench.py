@@ -535,7 +535,7 @@ def main(args):
                "precision": ("bf16 MFMA operands (3x3 conv fwd/dgrad/wgrad: written as bf16 slots by their producers, round to nearest even; "
                              "ConvTranspose2d GEMMs), f32 accumulation, f32 conv outputs, BatchNorm, loss, master weights and optimizer") if bf16 else
                             ("f32 master tensors (inputs, outputs, conv outputs z, activation gradients, weights, optimizer) and f32-level results; "
-                             "the 3x3 convolutions on maps >= 32 px wide run on the 16-bit matrix pipe by operand splitting (each operand = hi + mid "
+                             "the 3x3 convolutions on maps >= 16 px wide (all but the Cin=1 stem) run on the 16-bit matrix pipe by operand splitting (each operand = hi + mid "
                              "fp16 parts of a power-of-two-scaled value: 22-bit operands, 3 MFMAs per term, f32 accumulate; error vs fp64 5e-8..1.5e-7 "
                              "rms of the output scale forward, 3e-7 max on the weight gradient), their operands stored PRE-SPLIT by the producing "
                              "BatchNorm / pooling / ConvTranspose2d kernels (same values as the fp32 passes: forward bit-identical to fp32 storage); "
