@@ -23,8 +23,9 @@ steady = None
 if tr:
     ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(tr[0])))
     adam = [i for i, e in enumerate(ev) if e[2].startswith("adam_kernel")]
-    if len(adam) >= 4:
-        adam = adam[-4:]                     # the last three optimizer-delimited steps
+    nb = 0 if "--bracket-all" in extra else 3          # bench.py's fully bracketed breakdown loop runs AFTER the timed steps
+    if len(adam) >= 4 + nb:
+        adam = adam[-(4 + nb):len(adam) - nb]   # the three TIMED optimizer-delimited steps
         ev = ev[adam[0] + 1:adam[-1] + 1]
         agg = collections.defaultdict(lambda: [0, 0])
         for s0, e0, n in ev:
@@ -40,8 +41,10 @@ with open(f"profiles/{tag}_kernel_stats_{sfx}.md", "w") as f:
     f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 3 --no-cpu-baseline {extra} ({desc})\n\n")
     _w = re.findall(r"--warmup\s+(\d+)", "--warmup 3 " + extra)
     nwarm = int(_w[-1])
-    f.write(f"MI355X, {what}; {nwarm + 3} training steps traced ({nwarm} warm-up + 3 timed).  Total kernel time {tot/1e6:.1f} ms = "
-            f"{tot/1e6/(nwarm + 3):.1f} ms/step over all of them.")
+    nbk = 0 if "--bracket-all" in extra else 3
+    f.write(f"MI355X, {what}; {nwarm + 3 + nbk} training steps traced ({nwarm} warm-up + 3 timed" +
+            (f" + {nbk} of bench.py's fully bracketed breakdown loop" if nbk else "") + f").  Total kernel time {tot/1e6:.1f} ms = "
+            f"{tot/1e6/(nwarm + 3 + nbk):.1f} ms/step over all of them.")
     if bench:
         dom = bench["roofline"]["kernel"]
         f.write(f"  bench under the profiler: {bench['ms_per_step']} ms/step, {bench['value']} images/s.\n"
