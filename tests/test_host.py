@@ -296,3 +296,25 @@ def test_zy3_dict_reader(tmp_path):
     for i, k in enumerate(ids):
         assert torch.equal(X[i], d[k]["true_color"].to(torch.float32)) and torch.equal(M[i], d[k]["mask"].to(torch.float32))
     assert set(M.unique().tolist()) <= {0.0, 1.0}
+
+
+def test_batch_counters_are_collected_and_applied_once():
+    """ops.counting_batches (UNet.forward: the 18 BatchNorm num_batches_tracked increments of a pass in one multi-tensor launch):
+    increments made inside the block land when it ends -- also when it raises -- and immediately outside of one."""
+    from onet_amd import ops
+    a, b = torch.zeros((), dtype=torch.int64), torch.zeros((), dtype=torch.int64)
+    with ops.counting_batches():
+        ops.count_batches(a, 2)
+        ops.count_batches(b, 2)
+        assert int(a) == 0 and int(b) == 0
+        with ops.counting_batches():                     # nested (an unshared second U-Net inside another model's pass)
+            ops.count_batches(a, 1)
+        assert int(a) == 1
+    assert int(a) == 3 and int(b) == 2
+    ops.count_batches(b, 1)
+    assert int(b) == 3
+    with pytest.raises(ValueError):
+        with ops.counting_batches():
+            ops.count_batches(a, 1)
+            raise ValueError("a unit refused its input")
+    assert int(a) == 4
