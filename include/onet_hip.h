@@ -304,6 +304,14 @@ int64_t onet_conv3x3_winograd_wgrad_ws_bytes(int B, int Cin, int Cout, int H, in
 int onet_conv_wgrad(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs, float* dw,
                     void* ws, int64_t ws_bytes, int B, int Cin, int Cout, int H, int W, int ks,
                     int out_layout, int accumulate, void* stream);
+/* Round 4: the stem's weight gradient (Cin <= 4: nn.Conv2d(n_channels, 64, 3) of OV:111, whose input has no gradient) with the
+ * BatchNorm + ReLU backward of its unit applied on load: dz is not materialised -- the kernel computes it per element from da (the
+ * gradient of the unit's output), the pre-activation z and the layer's coefficients (save, coef [G][4][Cout]; group_images as in the
+ * BatchNorm entry points) with onet_bn_relu_bwd_apply's arithmetic: the same bits as that pass followed by onet_conv_wgrad.
+ * Workspace: onet_conv_wgrad_ws_bytes(..., ks = 3). */
+int onet_conv3x3_stem_wgrad_bn(const float* x, int64_t x_bs, const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save,
+                               const float* coef, int group_images, float* dw, void* ws, int64_t ws_bytes, int B, int Cin, int Cout, int H,
+                               int W, int accumulate, void* stream);
 int64_t onet_conv_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W, int ks);
 
 /* ---- K2/K3: BatchNorm2d (+ReLU) ---------------------------------------- */

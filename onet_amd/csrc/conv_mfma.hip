@@ -402,6 +402,13 @@ struct WgArgs {
     // ConvTranspose2d weight-grad (S2D kernels): dz is the [Ct][Ho][Wo] window of dcat, GEMM row q*Ct + c at pixel
     // (i, j) is dy[c][pt + 2i + di][pl + 2j + dj]
     int s2d_Ct = 0, Ho = 0, Wo = 0, pt = 0, pl = 0;
+    // stem weight gradient with the BatchNorm + ReLU backward applied on load (conv3x3_stem_wgrad_kernel<.., true>): `dz` is then da
+    // (the gradient of the unit's OUTPUT), bn_z the pre-activation, bn_save / bn_coef [G][4][Cout] (bn.hip), bn_gimg images per group
+    const float* bn_z = nullptr;
+    int64_t bn_z_bs = 0;
+    const float* bn_save = nullptr;
+    const float* bn_coef = nullptr;
+    int bn_gimg = 0;
 };
 
 template <int KS, int PW>
@@ -619,23 +626,49 @@ int launch_wgrad_reduce(const float* slab, float* dw, int splitK, int taps, int 
 // Stem wgrad (Cin <= 4: the 1- or 3-channel input image, OV:111): dW[co][ci][tap] has only 64*Cin*9
 // entries but reduces over every pixel, so it is an HBM-bound streaming reduction over dz, not a GEMM
 // (the MFMA tile would be 63/64 padding).  One block per (image, 32-row band, group of COG output
-// channels): a thread owns pixel columns and walks down the band with a 3x3 sliding window of the
-// input in registers (3 new loads per row), COG*CIN*9 accumulators, then wave-shuffle + LDS
+// channels); a wave takes 8 rows of the band, a thread FOUR neighbouring pixel columns (one 16-byte load per
+// row and channel plane: 1 KB per wave-instruction in flight instead of 256 B) and walks down its rows with a
+// 3 x 6 sliding window of the input in registers, COG*CIN*9 accumulators, then wave-shuffle + LDS
 // reduction; partial slab [image*band][tap][co][ci] for wgrad_reduce_kernel (deterministic).
+// BN: dz is not read but computed per element from (da, z) and the layer's BatchNorm-backward coefficients -- the arithmetic of
+// bn_relu_bwd_apply_kernel (fp64 per element, rounded once), so the result is bit for bit the weight gradient of the dz that pass
+// would have written: the stem's input has no gradient, its dz no other reader, and the 12 B/element pass + this kernel's 4 B/element
+// read become one 8 B/element read.
 constexpr int STEM_ROWS = 32;
-template <int CIN, int COG>
+template <int CIN, int COG, bool BN = false>
 __global__ __launch_bounds__(256) void conv3x3_stem_wgrad_kernel(WgArgs a) {
     constexpr int NV = COG * CIN * 9;
     __shared__ float red[4][NV];
     const int cogs = (a.Cout + COG - 1) / COG;
     const int bandsY = (a.H + STEM_ROWS - 1) / STEM_ROWS;
     const int cg = blockIdx.x % cogs, bb = blockIdx.x / cogs;
-    const int b = bb / bandsY, y0 = (bb % bandsY) * STEM_ROWS;
+    const int b = bb / bandsY, yb = (bb % bandsY) * STEM_ROWS;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int HW = a.H * a.W, W = a.W, H = a.H;
     const float* xb = a.x + (int64_t)b * a.x_bs;
     const float* dzb = a.dz + (int64_t)b * a.dz_bs + (int64_t)cg * COG * HW;
-    const int y1 = min(y0 + STEM_ROWS, H);
+    const float* zb = BN ? a.bn_z + (int64_t)b * a.bn_z_bs + (int64_t)cg * COG * HW : nullptr;
+    const int y0 = yb + wid * (STEM_ROWS / 4), y1 = min(y0 + STEM_ROWS / 4, H);
+    // 16-byte loads of the gradient planes need aligned rows
+    const bool vec = (W & 3) == 0 && (a.dz_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(a.dz) & 15) == 0 &&
+                     (!BN || ((a.bn_z_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(a.bn_z) & 15) == 0));
+    float bmean[COG], binv[COG], bsc[COG], bsh[COG];       // (few live registers: this streaming loop lives on occupancy)
+    double bc1[COG], bc2[COG];
+    if (BN) {
+        const int grp = a.bn_gimg ? b / a.bn_gimg : 0;
+        const float* sv = a.bn_save + (int64_t)grp * 4 * a.Cout;
+        const float* cf = a.bn_coef ? a.bn_coef + (int64_t)grp * 4 * a.Cout : nullptr;
+#pragma unroll
+        for (int g = 0; g < COG; ++g) {
+            const int c = min(cg * COG + g, a.Cout - 1);
+            bmean[g] = sv[c];
+            binv[g] = sv[a.Cout + c];
+            bsc[g] = sv[2 * a.Cout + c];
+            bsh[g] = sv[3 * a.Cout + c];
+            bc1[g] = cf ? (double)cf[c] + (double)cf[a.Cout + c] : 0.0;
+            bc2[g] = cf ? (double)cf[2 * a.Cout + c] + (double)cf[3 * a.Cout + c] : 0.0;
+        }
+    }
     float acc[COG][CIN][9];
 #pragma unroll
     for (int g = 0; g < COG; ++g)
@@ -643,34 +676,67 @@ __global__ __launch_bounds__(256) void conv3x3_stem_wgrad_kernel(WgArgs a) {
         for (int c = 0; c < CIN; ++c)
 #pragma unroll
             for (int t = 0; t < 9; ++t) acc[g][c][t] = 0.f;
-    for (int x = tid; x < W; x += 256) {
-        float win[CIN][3][3];   // rows y-1, y, y+1 ; cols x-1, x, x+1
+    auto in_row = [&](int c, int yy, int x0, float (&r)[6]) __attribute__((always_inline)) {       // input columns x0 - 1 .. x0 + 4 of row yy
+        const bool rowok = yy >= 0 && yy < H;
+        const float* p = xb + (int64_t)c * HW + (int64_t)yy * W;
 #pragma unroll
-        for (int c = 0; c < CIN; ++c)
+        for (int k = 0; k < 6; ++k) {
+            const int xx = x0 - 1 + k;
+            r[k] = (rowok && xx >= 0 && xx < W) ? p[xx] : 0.f;
+        }
+    };
+    for (int x0 = lane * 4; x0 < W && y0 < y1; x0 += 256) {
+        float win[CIN][3][6];   // rows y-1, y, y+1 ; cols x0-1 .. x0+4
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const int yy = y0 - 1 + r, xx = x - 1 + k;
-                    win[c][r + 1][k] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? xb[(int64_t)c * HW + (int64_t)yy * W + xx] : 0.f;
-                }
+        for (int c = 0; c < CIN; ++c) {
+            in_row(c, y0 - 1, x0, win[c][1]);
+            in_row(c, y0, x0, win[c][2]);
+        }
         for (int y = y0; y < y1; ++y) {
 #pragma unroll
-            for (int c = 0; c < CIN; ++c)
+            for (int c = 0; c < CIN; ++c) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
+                for (int k = 0; k < 6; ++k) {
                     win[c][0][k] = win[c][1][k];
                     win[c][1][k] = win[c][2][k];
-                    const int yy = y + 1, xx = x - 1 + k;
-                    win[c][2][k] = (yy < H && xx >= 0 && xx < W) ? xb[(int64_t)c * HW + (int64_t)yy * W + xx] : 0.f;
                 }
+                in_row(c, y + 1, x0, win[c][2]);
+            }
 #pragma unroll
             for (int g = 0; g < COG; ++g) {
-                const float gz = (cg * COG + g < a.Cout) ? dzb[(int64_t)g * HW + (int64_t)y * W + x] : 0.f;
+                float gz[4] = {0.f, 0.f, 0.f, 0.f}, zz[4] = {0.f, 0.f, 0.f, 0.f};
+                if (cg * COG + g < a.Cout) {
+                    const int64_t o = (int64_t)g * HW + (int64_t)y * W + x0;
+                    if (vec) {
+                        const float4 q = *reinterpret_cast<const float4*>(dzb + o);
+                        gz[0] = q.x; gz[1] = q.y; gz[2] = q.z; gz[3] = q.w;
+                        if (BN) {
+                            const float4 r = *reinterpret_cast<const float4*>(zb + o);
+                            zz[0] = r.x; zz[1] = r.y; zz[2] = r.z; zz[3] = r.w;
+                        }
+                    } else {
 #pragma unroll
-                for (int c = 0; c < CIN; ++c)
+                        for (int p = 0; p < 4; ++p)
+                            if (x0 + p < W) {
+                                gz[p] = dzb[o + p];
+                                if (BN) zz[p] = zb[o + p];
+                            }
+                    }
+                    if (BN) {
 #pragma unroll
-                    for (int t = 0; t < 9; ++t) acc[g][c][t] = fmaf(gz, win[c][t / 3][t % 3], acc[g][c][t]);
+                        for (int p = 0; p < 4; ++p) {
+                            const double dy = fmaf(zz[p] - bmean[g], bsc[g], bsh[g]) > 0.f ? (double)gz[p] : 0.0;
+                            const float v = (float)((double)bsc[g] * (dy - bc1[g] - (((double)zz[p] - (double)bmean[g]) * (double)binv[g]) * bc2[g]));
+                            gz[p] = (vec || x0 + p < W) ? v : 0.f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int c = 0; c < CIN; ++c)
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) acc[g][c][t] = fmaf(gz[p], win[c][t / 3][p + t % 3], acc[g][c][t]);
             }
         }
     }
@@ -862,6 +928,35 @@ int64_t onet_conv_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W, int ks)
     return (int64_t)splitK * ks * ks * Cout * Cin * 4;
 }
 
+int onet_conv3x3_stem_wgrad_bn(const float* x, int64_t x_bs, const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save,
+                               const float* coef, int group_images, float* dw, void* ws, int64_t ws_bytes, int B, int Cin, int Cout, int H,
+                               int W, int accumulate, void* stream) {
+    ONET_REQUIRE(x && da && z && save && dw && ws, "conv3x3_stem_wgrad_bn: null pointer");
+    ONET_REQUIRE(B > 0 && Cin > 0 && Cin <= 4 && Cout > 0 && H > 0 && W > 0 && group_images >= 0 && (group_images == 0 || B % group_images == 0),
+                 "conv3x3_stem_wgrad_bn: bad shape (Cin <= 4)");
+    WgArgs a{x, x_bs, da, da_bs, (float*)ws, B, Cin, Cout, H, W, 1, cdiv(Cout, 64), 1, 1, 1};
+    a.bn_z = z;
+    a.bn_z_bs = z_bs;
+    a.bn_save = save;
+    a.bn_coef = coef;
+    a.bn_gimg = group_images;
+    const int nb = stem_blocks(B, H);
+    const int64_t need = (int64_t)nb * 9 * Cout * Cin * 4;
+    ONET_REQUIRE(ws_bytes >= need, "conv3x3_stem_wgrad_bn: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
+    hipStream_t st = as_stream(stream);
+    switch (Cin) {
+        case 1: hipLaunchKernelGGL((conv3x3_stem_wgrad_kernel<1, 4, true>), dim3(nb * cdiv(Cout, 4)), dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((conv3x3_stem_wgrad_kernel<2, 2, true>), dim3(nb * cdiv(Cout, 2)), dim3(256), 0, st, a); break;
+        case 3: hipLaunchKernelGGL((conv3x3_stem_wgrad_kernel<3, 2, true>), dim3(nb * cdiv(Cout, 2)), dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL((conv3x3_stem_wgrad_kernel<4, 1, true>), dim3(nb * cdiv(Cout, 1)), dim3(256), 0, st, a); break;
+    }
+    int rc = check_launch("conv3x3_stem_wgrad_kernel");
+    if (rc) return rc;
+    const int64_t n = (int64_t)Cout * Cin;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv(n, 64), 9u), dim3(256), 0, st, (const float*)ws, dw, nb, 9, Cout, Cin, 0, accumulate);
+    return check_launch("wgrad_reduce_kernel");
+}
+
 int onet_conv_wgrad(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs, float* dw, void* ws,
                     int64_t ws_bytes, int B, int Cin, int Cout, int H, int W, int ks, int out_layout,
                     int accumulate, void* stream) {
@@ -876,10 +971,10 @@ int onet_conv_wgrad(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs
         ONET_REQUIRE(ws_bytes >= need, "conv_wgrad(stem): workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);
         hipStream_t st = as_stream(stream);
         switch (Cin) {
-            case 1: hipLaunchKernelGGL((conv3x3_stem_wgrad_kernel<1, 8>), dim3(nb * cdiv(Cout, 8)), dim3(256), 0, st, a); break;
-            case 2: hipLaunchKernelGGL((conv3x3_stem_wgrad_kernel<2, 4>), dim3(nb * cdiv(Cout, 4)), dim3(256), 0, st, a); break;
+            case 1: hipLaunchKernelGGL((conv3x3_stem_wgrad_kernel<1, 4>), dim3(nb * cdiv(Cout, 4)), dim3(256), 0, st, a); break;
+            case 2: hipLaunchKernelGGL((conv3x3_stem_wgrad_kernel<2, 2>), dim3(nb * cdiv(Cout, 2)), dim3(256), 0, st, a); break;
             case 3: hipLaunchKernelGGL((conv3x3_stem_wgrad_kernel<3, 2>), dim3(nb * cdiv(Cout, 2)), dim3(256), 0, st, a); break;
-            default: hipLaunchKernelGGL((conv3x3_stem_wgrad_kernel<4, 2>), dim3(nb * cdiv(Cout, 2)), dim3(256), 0, st, a); break;
+            default: hipLaunchKernelGGL((conv3x3_stem_wgrad_kernel<4, 1>), dim3(nb * cdiv(Cout, 1)), dim3(256), 0, st, a); break;
         }
         int rc = check_launch("conv3x3_stem_wgrad_kernel");
         if (rc) return rc;

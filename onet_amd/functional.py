@@ -256,6 +256,11 @@ class ConvBNReLUFn(torch.autograd.Function):
         nones = (None,) * 13
         if xP is None:
             # fp32 input (the stem): dz in fp32 for the fp32-input kernels; no input gradient path on pre-split operands
+            if need_w and not need_x and x.shape[1] <= 4 and ops.STEM_WGRAD_BN and not ops.is_placeholder(x):
+                # the stem: dz has one reader, the weight gradient -- formed on load there, never written
+                dw, dgamma, dbeta = ops.stem_wgrad_bn(x, da, z, save_all, ctx.training, ctx.wshape, affine_out=aff, rec4=rec4,
+                                                      out=ops.grad_slot_if_free(pw))
+                return (None, dw, (dgamma if need_g else None), (dbeta if need_b else None)) + nones
             dz, dgamma, dbeta = ops.bn_relu_bwd_groups(da, z, save_all, ctx.training, affine_out=aff, rec4=rec4)
             dw = ops.conv3x3_wgrad_auto(x, dz, ctx.wshape, out=ops.grad_slot_if_free(pw)) if need_w else None
             dx = ops.conv3x3_auto(dz, ctx.packed, 1) if need_x else None

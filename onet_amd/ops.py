@@ -1188,6 +1188,30 @@ def bn_relu_bwd_split(da, z, save_all, training, need_affine_grads=True, affine_
     return dzP, dz_slots, dgamma, dbeta
 
 
+def stem_wgrad_bn(x, da, z, save_all, training, dw_shape, affine_out=None, rec4=None, out=None):
+    """BatchNorm + ReLU backward and weight gradient of the stem unit (Cin <= 4; its input has no gradient, so dz has no other reader):
+    reduce + finalize as bn_relu_bwd_groups, then ONE pass over (da, z) that forms dz per element and accumulates dW -- the apply pass
+    and its dz tensor are gone.  Same bits as bn_relu_bwd_groups + conv_wgrad.  -> (dw, dgamma, dbeta)."""
+    require_gpu(x, da, z)
+    x, xbs = plane(x)
+    da, dabs = plane(da)
+    z, zbs = plane(z)
+    B, Cin, H, W = x.shape
+    Cout = z.shape[1]
+    G = save_all.shape[0]
+    coef, dgamma, dbeta = _bn_bwd_groups(da, dabs, z, zbs, save_all, training, affine_out, rec4, None, None)
+    dw = torch.empty(dw_shape, dtype=F32, device=x.device) if out is None else out
+    ws = workspace(_lib.load().onet_conv_wgrad_ws_bytes(B, Cin, Cout, H, W, 3), x.device)
+    e0 = _prof_begin("conv_wgrad_kernel")
+    _lib.call("onet_conv3x3_stem_wgrad_bn", _p(x), xbs, _p(da), dabs, _p(z), zbs, _p(save_all), _p(coef), B // G if G > 1 else 0, _p(dw),
+              _p(ws), ws.numel() * 4, B, Cin, Cout, H, W, 0, _stream())
+    _prof_end("conv_wgrad_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + 2 * Cout) + 9 * Cin * Cout))
+    return dw, dgamma, dbeta
+
+
+STEM_WGRAD_BN = _os.environ.get("ONET_STEM_WGRAD_BN", "1") != "0"     # 0 (diagnostic): the stem's dz is materialised by the apply pass
+
+
 def bn_relu_bwd_groups(da, z, save_all, training, affine_out=None, rec4=None):
     """The same for a layer whose dz stays fp32 (the stem under pre-split storage): -> (dz, dgamma, dbeta)."""
     da, dabs = plane(da)

@@ -1166,3 +1166,26 @@ def test_split_weight_packs_bit_for_bit(dev, Cout, Cin, monkeypatch):
         pf, pd = ops.pack3x3_plain16(w.to(dev))
         check(pf, 0, 2)
         check(pd, 1, 2)
+
+
+@pytest.mark.parametrize("B,Cin,H,W,G", [(4, 1, 64, 64, 2), (3, 3, 40, 56, 1), (2, 4, 32, 32, 2)])
+def test_stem_wgrad_with_bn_backward_on_load(dev, B, Cin, H, W, G):
+    """conv3x3_stem_wgrad_kernel<.., true>: the stem's weight gradient formed from (da, z) and the BatchNorm-backward coefficients
+    without materialising dz -- bit for bit the weight gradient (and dgamma / dbeta) of the apply pass followed by the stem kernel,
+    one and two statistics groups, train and eval coefficients."""
+    from onet_amd import ops
+    Cout = 24
+    x, z, da = rnd(B, Cin, H, W, seed=11).to(dev), rnd(B, Cout, H, W, seed=12).to(dev), rnd(B, Cout, H, W, seed=13, scale=1e-3).to(dev)
+    gamma, beta = (1.0 + 0.1 * rnd(Cout, seed=14)).to(dev), (0.1 * rnd(Cout, seed=15)).to(dev)
+    save = torch.empty(G, 4, Cout, device=dev)
+    for g in range(G):
+        ops.bn_train_coeffs(z[g * (B // G):(g + 1) * (B // G)], gamma, beta, None, None, 0.1, 1e-5, save=save[g])
+    for training in (True, False):
+        dz, dg0, db0 = ops.bn_relu_bwd_groups(da, z, save, training)
+        dw0 = ops.conv_wgrad(x, dz, (Cout, Cin, 3, 3), 3)
+        dw1, dg1, db1 = ops.stem_wgrad_bn(x, da, z, save, training, (Cout, Cin, 3, 3))
+        assert torch.equal(dw0, dw1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    ref = F.conv2d(x.double().cpu().requires_grad_(True), torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True), None, 1, 1)
+    wr = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double().cpu(), wr, None, 1, 1).backward(dz.double().cpu())
+    close(dw1, wr.grad, tol=2e-5, what="stem weight gradient")
