@@ -326,6 +326,9 @@ def _record_bf16_operands(monkeypatch, B):
     monkeypatch.setattr(ops, "conv3x3_wgrad_auto", wgrad)
     monkeypatch.setattr(ops, "convT2x2_wgrad", wgrad_t)
     monkeypatch.setattr(ops, "conv3x3_split_wgrad_pre", wgrad_pre)
+    # the stem's dz is recorded too: materialise it (by default its weight gradient forms it on load -- the same bits,
+    # tests/test_gpu_ops.py::test_stem_wgrad_with_bn_backward_on_load)
+    monkeypatch.setattr(ops, "STEM_WGRAD_BN", False)
 
     def finish():
         monkeypatch.setattr(ops, "conv3x3_wgrad_auto", real_w)
