@@ -129,11 +129,12 @@ def cpu_baseline(X_cpu, seconds_budget):
                          X_cpu.shape[2], X_cpu.shape[3], "/".join(str(nsteps[k]) for k in by_threads))}
 
 
-def comm_curve(onet, opt, X, train_step, barrier, dev, nsteps, overlap):
+def comm_curve(onet, opt, X, train_step, barrier, dev, nsteps, overlap, bucket_mb):
     """SURVEY 8e's with / without-overlap curve, measured behind the timed region on the same replicas: the same step with
-    (a) ONE all-reduce of the flat gradient after backward, (b) the bucketed all-reduces overlapped with backward, (c) NO
-    all-reduce at all (compute only; the replicas drift apart, which is why this runs last).  Max over ranks of each;
-    allreduce_exposed_ms = the headline's ms/step - (c).  The mode the headline ran is not timed twice."""
+    (a) ONE all-reduce of the flat gradient after backward, (b) the bucketed all-reduces overlapped with backward (the headline's
+    --bucket-mb), (c) NO all-reduce at all (compute only; the replicas drift apart, which is why this runs last and why the
+    caller reads the loss BEFORE calling this).  Max over ranks of each; allreduce_exposed_ms = the headline's ms/step - (c).
+    The mode the headline ran is not timed twice, and the optimizer is handed back in the headline's mode."""
     import torch.distributed as dist
 
     def timed():
@@ -148,17 +149,19 @@ def comm_curve(onet, opt, X, train_step, barrier, dev, nsteps, overlap):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return round(float(t.item()) / nsteps * 1e3, 3)
 
-    out = {"steps": nsteps}
+    out = {"steps": nsteps, "bucket_mb": bucket_mb}
     if overlap:
         opt.disable_overlap()
         out["no_overlap_ms"] = timed()
     else:
-        opt.enable_overlap()
+        opt.enable_overlap(bucket_mb)
         out["overlap_ms"] = timed()
         opt.disable_overlap()
     opt.skip_allreduce = True
     out["no_allreduce_ms"] = timed()
     opt.skip_allreduce = False
+    if overlap:                      # back to the headline's mode
+        opt.enable_overlap(bucket_mb)
     return out
 
 
@@ -178,24 +181,57 @@ def _relay_child(cmd, env=None):
     return proc.returncode, out or ""
 
 
-def _preflight(n_gpus, local=None):
+def _visible_gpu_count():
+    """GPUs this process tree will see, WITHOUT touching the HIP runtime (the launcher parent must stay GPU-free: it starts the
+    ranks as children): KFD topology nodes with compute units (/sys/class/kfd/kfd/topology/nodes/*/properties: simd_count > 0),
+    narrowed by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when they list indices.  -> 0 without a KFD driver,
+    None if the topology exists but cannot be read (then nothing is checked here; the ranks check for themselves)."""
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.isdir("/sys/class/kfd"):
+        return 0                  # no KFD driver on this host: no AMD GPU for any process
+    try:
+        n = 0
+        for node in os.listdir(root):
+            try:
+                props = dict(ln.split()[:2] for ln in open(os.path.join(root, node, "properties")) if len(ln.split()) >= 2)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except OSError:
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            ids = [t for t in v.split(",") if t.strip() != ""]
+            n = min(n, len(ids))
+    return n
+
+
+def _preflight(n_gpus, local=None, in_rank=False):
     """A clear message BEFORE any rank is started / any collective is entered when the node has fewer GPUs than --gpus asks for.
-    `torch.cuda.device_count()` enumerates through the driver without initialising HIP in this process (so the launcher parent
-    may call it).  ONET_FORCE_LOCAL_RANK (the one-GPU rehearsal: N ranks sharing cuda:0 over gloo) waives the check."""
+    The launcher parent counts KFD topology nodes (no HIP call: it must not initialise the runtime it then spawns ranks under);
+    a rank (in_rank) asks torch.cuda.device_count(), which is what it will actually be able to open.  ONET_FORCE_LOCAL_RANK (the
+    one-GPU rehearsal: N ranks sharing cuda:0 over gloo) waives the check."""
     if "ONET_FORCE_LOCAL_RANK" in os.environ:
         return
-    import torch as _t
-    have = _t.cuda.device_count()
+    if in_rank:
+        import torch as _t
+        have, how = _t.cuda.device_count(), "torch.cuda.device_count()"
+    else:
+        have, how = _visible_gpu_count(), "KFD topology + *_VISIBLE_DEVICES"
+        if have is None:
+            return
     if have < n_gpus or (local is not None and local >= have):
-        sys.stderr.write("[bench] --gpus %d, but this node exposes %d GPU(s) to the process (torch.cuda.device_count(); check "
-                         "HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES): nothing was launched\n" % (n_gpus, have))
+        sys.stderr.write("[bench] --gpus %d, but this node exposes %d GPU(s) to the process (%s; check "
+                         "HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES): nothing was launched\n" % (n_gpus, have, how))
         sys.stderr.flush()
         raise SystemExit(2)
 
 
 def _self_launch(args, argv):
-    """`python bench.py --gpus N` (N > 1) outside a launcher: THIS process (which has not imported torch.cuda / onet_amd and
-    makes no GPU call) starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`
+    """`python bench.py --gpus N` (N > 1) outside a launcher: THIS process (which has not imported torch / onet_amd and
+    makes no GPU call: the preflight reads sysfs) starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`
     as a child, relays rank 0's JSON line and exits with the child's code.  No exec, no retry."""
     _preflight(args.gpus)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
@@ -215,7 +251,7 @@ def _self_launch(args, argv):
 
 
 SECONDARY_ARGS = ["--gpus", "1", "--conv", "bf16", "--batch", "256", "--warmup", "8", "--steps", "5",
-                  "--no-cpu-baseline", "--no-secondary"]
+                  "--no-cpu-baseline", "--no-secondary", "--no-reference-loop"]
 
 
 def secondary_config2():
@@ -267,6 +303,8 @@ def parse_args(argv=None):
                          "default fits the whole configs[1] batch (B=32, ~28 s per step on 16 cores)")
     ap.add_argument("--no-f32-mfma-only", action="store_true",
                     help="skip the extra loop with the fp32-MFMA kernels only (profiling runs: keeps the kernel trace to the headline's kernels)")
+    ap.add_argument("--no-reference-loop", action="store_true",
+                    help="skip the extra loop that restores TS:211's per-step host-to-device copy and TS:219's per-step loss.item()")
     ap.add_argument("--no-secondary", action="store_true",
                     help="do not attach BASELINE configs[2] (bf16, B=256) as `secondary` (default at N=1 with the headline "
                          "configuration: attached)")
@@ -293,7 +331,7 @@ def main(args):
 
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%s" % (args.gpus, os.environ.get("WORLD_SIZE", "1")))
-    _preflight(args.gpus, int(os.environ.get("LOCAL_RANK", "0")))
+    _preflight(args.gpus, int(os.environ.get("LOCAL_RANK", "0")), in_rank=True)
     rank, world, local = init_distributed("nccl")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -388,21 +426,53 @@ def main(args):
                          "warmup": 3, "kernels": "fp32 MFMA only: Winograd F(4x4,3x3) / F(2x2,3x3) / direct (ONET_SPLIT=0)"}
         del loss2
         onet.settings = keep
-    per_rank_ms, comm = None, None
+    per_rank_ms, comm, per_rank, replicas_identical = None, None, None, None
+    loss_val = float(loss.item())            # (before the comm loops below: their last mode lets the replicas drift apart)
+    hbm_peak_gb = round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)
     if distributed:
-        mine = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        # one record per rank: elapsed seconds, loss, HBM peak, and a checksum of the flat parameter buffer (data-parallel
+        # replicas that saw the same reduced gradients hold the same bits: sum and sum of squares in fp64 must agree exactly)
+        flat = opt.flat.double() if not args.torch_adam else torch.cat([p.detach().reshape(-1) for p in onet.parameters()]).double()
+        mine = torch.tensor([elapsed, loss_val, hbm_peak_gb, float(flat.sum().item()), float((flat * flat).sum().item())],
+                            device=dev, dtype=torch.float64)
+        del flat
         every = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
-        per_rank_ms = [round(float(t.item()) / args.steps * 1e3, 3) for t in every]
-        t = mine.clone()
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        every = [[float(v) for v in t.tolist()] for t in every]
+        per_rank_ms = [round(r[0] / args.steps * 1e3, 3) for r in every]
+        per_rank = {"loss": [r[1] for r in every], "hbm_peak_gb": [r[2] for r in every]}
+        replicas_identical = all(r[3] == every[0][3] and r[4] == every[0][4] for r in every)
+        elapsed = max(r[0] for r in every)
+        bad = [i for i, r in enumerate(every) if not (r[1] == r[1] and abs(r[1]) != float("inf"))]
+        if bad:                              # every rank sees the same record: every rank leaves with the same code
+            raise SystemExit("[bench] non-finite loss on rank(s) %s: %s" % (bad, per_rank["loss"]))
+        if "ONET_FORCE_LOCAL_RANK" not in os.environ and (dist.get_backend() != "nccl" or dist.get_world_size() != args.gpus):
+            raise SystemExit("[bench] --gpus %d but the process group is %s with %d rank(s): not an RCCL run of the requested size"
+                             % (args.gpus, dist.get_backend(), dist.get_world_size()))
         if not args.torch_adam and not args.no_comm_curve:
-            comm = comm_curve(onet, opt, X, train_step, barrier, dev, max(3, args.steps // 2), overlap)
+            comm = comm_curve(onet, opt, X, train_step, barrier, dev, max(3, args.steps // 2), overlap, args.bucket_mb)
             comm["overlap_ms" if overlap else "no_overlap_ms"] = round(elapsed / args.steps * 1e3, 3)
             if "no_allreduce_ms" in comm:
                 comm["allreduce_exposed_ms"] = round(comm["overlap_ms" if overlap else "no_overlap_ms"] - comm["no_allreduce_ms"], 3)
-    loss_val = float(loss.item())
+    # the reference's own loop shape (TS:209-219), for the record next to the headline: the same steps with the batch copied from
+    # pinned host memory every step (TS:211 X.to(device)) and loss.item() every step (TS:219)
+    reference_loop = None
+    if world == 1 and not args.no_reference_loop:
+        Xh = X.cpu().pin_memory()
+        for _ in range(2):
+            float(train_step(onet, opt, Xh.to(dev, non_blocking=False)).item())
+        torch.cuda.synchronize()
+        tr0 = time.perf_counter()
+        for _ in range(args.steps):
+            float(train_step(onet, opt, Xh.to(dev, non_blocking=False)).item())
+        torch.cuda.synchronize()
+        er = time.perf_counter() - tr0
+        reference_loop = {"value": round(args.batch * args.steps / er, 3), "unit": "images/s", "ms_per_step": round(er / args.steps * 1e3, 3),
+                          "steps": args.steps, "warmup": 2,
+                          "what": "the headline's step with TS:211's per-step X.to(device) (from pinned host memory, %.1f MB) and TS:219's "
+                                  "per-step loss.item() restored; the headline omits both (config.inputs_resident / per_step_host_sync)"
+                                  % (Xh.numel() * 4 / 2 ** 20)}
+        del Xh
 
     if rank == 0:
         # multiplies the algorithm issues relative to direct convolution: F(4x4,3x3) 36 per 16 outputs x 9 taps -> 1/4,
@@ -558,7 +628,7 @@ def main(args):
                                                             # loss's NaN verdict, OV:234, travels behind an event instead)
                           "inputs_resident": True},         # TS:211's per-step X.to(device) is not in the timed loop
 
-               "loss": loss_val, "hbm_peak_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
+               "loss": loss_val, "hbm_peak_gb": hbm_peak_gb,
                "hbm_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 2),
                "alloc_retries": int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0)),
                "device_allocs_in_timed_steps": int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0)) - dev_allocs0,
@@ -572,10 +642,14 @@ def main(args):
             except Exception:      # noqa: BLE001
                 out["nccl_version"] = None
             out["per_rank_ms"] = per_rank_ms
+            out["per_rank"] = per_rank
+            out["replicas_identical"] = replicas_identical
             if comm is not None:
                 out["comm"] = comm
         if f32_mfma_only is not None:
             out["f32_mfma_only"] = f32_mfma_only
+        if reference_loop is not None:
+            out["reference_loop"] = reference_loop
         headline = world == 1 and not bf16 and args.size == 256 and args.chans == 1 and args.batch == 32 and not args.torch_adam
         if headline and not args.no_secondary:
             # BASELINE configs[2] in the same driver-run line: release this process's HBM first (the child peaks at ~150 GB)

@@ -218,6 +218,7 @@ int onet_conv3x3_split_nparts(int B, int H, int W);
  * channels >= split_ch (0: none) were scaled by a second producer with its own slots.  part != NULL: BatchNorm statistics records
  * as onet_conv3x3_split_fwd_stats. */
 int onet_split_pack_act(const float* x, int64_t x_bs, void* xs, int64_t xs_bs, int B, int C, int H, int W, int f16, float scale,
+                        const void* slots /* NULL | magnitude slots: their guard scale (amax_scale, not always) multiplies `scale` */,
                         void* stream);
 int onet_conv3x3_split_fwd_pre(const void* xs, int64_t xs_bs, const void* x_amax, int scale_always, const void* x_amax2, int split_ch,
                                const void* wq, int wq_f16, float* z, int64_t z_bs, float* part, int B, int Cin, int Cout, int H, int W,
@@ -259,10 +260,13 @@ int onet_conv3x3_split_wgrad(const float* x, int64_t x_bs, const float* dz, int6
  * statistics of its BatchNorm (OV:48) in one streaming pass.  w: the nn.Conv2d weight [Cout][Cin][3][3] as it is (no pack);
  * part [Cout][nparts][3] = (n, mean, M2) per 16 x 64-pixel tile for onet_bn_finalize_cm, or NULL (convolution only).
  * nparts = onet_conv3x3_stem_nparts(B, Cin, Cout, H, W); 0 = not applicable (Cin > 4, Cout > 128, H % 16 or W % 64): use
- * onet_conv_fwd + onet_bn_stats_partial. */
+ * onet_conv_fwd + onet_bn_stats_partial.
+ * ABI 4 -- K7 fused (OV:180): twin_B > 0 says the batch of B = 2 twin_B images is the twin batch
+ * [X ; clip(1 - X + twin_bias, 0, 1)] of which only X exists (x holds twin_B images): image b >= twin_B is formed from image
+ * b - twin_B while the halo tile is loaded, with onet_complement_clip's expression.  twin_B = 0: an ordinary batch of B images. */
 int onet_conv3x3_stem_nparts(int B, int Cin, int Cout, int H, int W);
 int onet_conv3x3_stem_fwd_stats(const float* x, int64_t x_bs, const float* w, float* z, int64_t z_bs, float* part, int B, int Cin,
-                                int Cout, int H, int W, void* stream);
+                                int Cout, int H, int W, int twin_B, float twin_bias, void* stream);
 
 /* EXPERIMENT (groundwork for a channel-blocked bf16 operand layout): onet_conv3x3_bf16_fwd_b with the bf16 copy of x laid out as
  * [C/8][H][W][8] per image (x_bs in elements, 16-byte aligned).  Not used by the module yet. */
@@ -308,10 +312,11 @@ int onet_conv_wgrad(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs
  * BatchNorm + ReLU backward of its unit applied on load: dz is not materialised -- the kernel computes it per element from da (the
  * gradient of the unit's output), the pre-activation z and the layer's coefficients (save, coef [G][4][Cout]; group_images as in the
  * BatchNorm entry points) with onet_bn_relu_bwd_apply's arithmetic: the same bits as that pass followed by onet_conv_wgrad.
- * Workspace: onet_conv_wgrad_ws_bytes(..., ks = 3). */
+ * Workspace: onet_conv_wgrad_ws_bytes(..., ks = 3).  twin_B / twin_bias: as onet_conv3x3_stem_fwd_stats (x = the first half of the
+ * twin batch; the complement half is formed on load). */
 int onet_conv3x3_stem_wgrad_bn(const float* x, int64_t x_bs, const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save,
                                const float* coef, int group_images, float* dw, void* ws, int64_t ws_bytes, int B, int Cin, int Cout, int H,
-                               int W, int accumulate, void* stream);
+                               int W, int accumulate, int twin_B, float twin_bias, void* stream);
 int64_t onet_conv_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W, int ks);
 
 /* ---- K2/K3: BatchNorm2d (+ReLU) ---------------------------------------- */
@@ -467,7 +472,8 @@ int onet_copy_strided(const float* src, int64_t src_bs, float* dst, int64_t dst_
 /* ---- K5': bilinear x2, align_corners=True (OV:83) ------------------------- */
 int onet_bilinear2x_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs, int B, int C,
                         int h, int w, int Ho, int Wo, int pt, int pl, void* stream);
-/* dx must be zero-initialised (scatter-add of <= 9 contributions per element) */
+/* gather form (ABI 4): every dx element sums the <= 6 x 6 output pixels whose stencil touches it, in a fixed order -- no atomics,
+ * bitwise reproducible, dx needs no initialisation */
 int onet_bilinear2x_bwd(const float* dy, int64_t dy_bs, float* dx, int64_t dx_bs, int B, int C,
                         int h, int w, int Ho, int Wo, int pt, int pl, void* stream);
 

@@ -27,7 +27,7 @@ extern "C" {
 
 const char* onet_last_error(void) { return onet::g_err; }
 
-int onet_abi_version(void) { return 3; }
+int onet_abi_version(void) { return 4; }
 
 int onet_device_info(int* cu_count, int* lds_bytes, int* wave_size, char* arch, int arch_len) {
     int dev = 0;

@@ -409,6 +409,9 @@ struct WgArgs {
     const float* bn_save = nullptr;
     const float* bn_coef = nullptr;
     int bn_gimg = 0;
+    // stem kernels: x is the first half of the twin batch [X ; clip(1 - X + bias, 0, 1)] (stem.hip: StemArgs); 0: ordinary batch
+    int twin_B = 0;
+    float twin_bias = 0.f;
 };
 
 template <int KS, int PW>
@@ -645,7 +648,8 @@ __global__ __launch_bounds__(256) void conv3x3_stem_wgrad_kernel(WgArgs a) {
     const int b = bb / bandsY, yb = (bb % bandsY) * STEM_ROWS;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int HW = a.H * a.W, W = a.W, H = a.H;
-    const float* xb = a.x + (int64_t)b * a.x_bs;
+    const bool comp = a.twin_B > 0 && b >= a.twin_B;          // K7 on load (OV:180): the complement half of a twin batch
+    const float* xb = a.x + (int64_t)(comp ? b - a.twin_B : b) * a.x_bs;
     const float* dzb = a.dz + (int64_t)b * a.dz_bs + (int64_t)cg * COG * HW;
     const float* zb = BN ? a.bn_z + (int64_t)b * a.bn_z_bs + (int64_t)cg * COG * HW : nullptr;
     const int y0 = yb + wid * (STEM_ROWS / 4), y1 = min(y0 + STEM_ROWS / 4, H);
@@ -682,7 +686,10 @@ __global__ __launch_bounds__(256) void conv3x3_stem_wgrad_kernel(WgArgs a) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             const int xx = x0 - 1 + k;
-            r[k] = (rowok && xx >= 0 && xx < W) ? p[xx] : 0.f;
+            const bool ok = rowok && xx >= 0 && xx < W;
+            float v = ok ? p[xx] : 0.f;
+            if (comp && ok) v = fminf(fmaxf(1.f - v + a.twin_bias, 0.f), 1.f);
+            r[k] = v;
         }
     };
     for (int x0 = lane * 4; x0 < W && y0 < y1; x0 += 256) {
@@ -930,7 +937,7 @@ int64_t onet_conv_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W, int ks)
 
 int onet_conv3x3_stem_wgrad_bn(const float* x, int64_t x_bs, const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save,
                                const float* coef, int group_images, float* dw, void* ws, int64_t ws_bytes, int B, int Cin, int Cout, int H,
-                               int W, int accumulate, void* stream) {
+                               int W, int accumulate, int twin_B, float twin_bias, void* stream) {
     ONET_REQUIRE(x && da && z && save && dw && ws, "conv3x3_stem_wgrad_bn: null pointer");
     ONET_REQUIRE(B > 0 && Cin > 0 && Cin <= 4 && Cout > 0 && H > 0 && W > 0 && group_images >= 0 && (group_images == 0 || B % group_images == 0),
                  "conv3x3_stem_wgrad_bn: bad shape (Cin <= 4)");
@@ -940,6 +947,9 @@ int onet_conv3x3_stem_wgrad_bn(const float* x, int64_t x_bs, const float* da, in
     a.bn_save = save;
     a.bn_coef = coef;
     a.bn_gimg = group_images;
+    ONET_REQUIRE(twin_B == 0 || 2 * twin_B == B, "conv3x3_stem_wgrad_bn: a twin batch holds twin_B = B / 2 images in memory");
+    a.twin_B = twin_B;
+    a.twin_bias = twin_bias;
     const int nb = stem_blocks(B, H);
     const int64_t need = (int64_t)nb * 9 * Cout * Cin * 4;
     ONET_REQUIRE(ws_bytes >= need, "conv3x3_stem_wgrad_bn: workspace %lld < %lld bytes", (long long)ws_bytes, (long long)need);

@@ -585,8 +585,14 @@ __device__ __forceinline__ void sp_dma16(i32x4s rsrc, unsigned lds_base, unsigne
 
 // fp32 NCHW -> the slot layout above (tests, tools, and producers that have no fused variant yet)
 // f16 == 2: plain bf16, one part: xs [B][C/8][H][W][8]
+// slots != NULL: the tensor's magnitude slots -- the guard scale of amax_scale(.., always = false) multiplies `scale` (what a fused
+// producer with the same slots would have applied; the consumer undoes it from the same slots)
 __global__ void split_pack_act_kernel(const float* __restrict__ x, int64_t x_bs, unsigned* __restrict__ xs, int64_t xs_bs, int B, int C8,
-                                      int H, int W, int f16, float scale) {
+                                      int H, int W, int f16, float scale, const unsigned* __restrict__ slots) {
+    if (slots) {
+        float inv;
+        scale *= amax_scale(amax_read(slots), false, inv);
+    }
     const int64_t n = (int64_t)B * C8 * H * W;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int xx = (int)(i % W);
@@ -637,24 +643,28 @@ struct SpPreArgs {
 // "part" index standing for the second 16 channels of a 32-channel chunk, two MFMAs per term (one per 16 channels).
 // W16: maps 16 pixels wide (the U-Net's 16-pixel level): a tile's 32 pixel columns are TWO IMAGES side by side, each with its own halo
 // columns in the LDS image (18 + 18 columns), so a horizontal tap never reads the neighbour image; a.B counts image PAIRS.
+#ifndef SP_PRE_NW
+#define SP_PRE_NW 8      // waves per block (8: two rows per wave; 4 (timing experiment): four rows per wave, one wave per SIMD)
+#endif
 template <bool W16> struct SpPreCfg {
-    static constexpr int NW = 8, NT = 2, TW = 32, CO_T = 64, ROWS = NW * NT;
+    static constexpr int NW = SP_PRE_NW, NT = 16 / NW, TW = 32, CO_T = 64, ROWS = NW * NT;
     static constexpr int IN_ROWS = ROWS + 2, IN_COLS = W16 ? 36 : 34;
     static constexpr int NPIX = IN_ROWS * IN_COLS;                      // 612 / 648 halo pixels
     static constexpr int NPIXP = W16 ? 656 : 640;                       // pixel slots per half (4 NPIXP = whole 64-slot DMA pieces)
-    static constexpr int W_PART = 9 * 2 * CO_T, W_SLOTS = 2 * W_PART, NWI = (W_SLOTS + 511) / 512;
+    static constexpr int W_PART = 9 * 2 * CO_T, W_SLOTS = 2 * W_PART, NWI = (W_SLOTS + NW * 64 - 1) / (NW * 64);
     static constexpr int IN_PART = 2 * NPIXP;
     static constexpr int BUF_SLOTS = W_SLOTS + 2 * IN_PART;             // 76 / 77 KB
     static constexpr int LDS_BYTES = 2 * BUF_SLOTS * 16;
     static constexpr int NB = (NT - 1) + 3;
 };
 template <bool ST, int PM, bool W16>
-__global__ __launch_bounds__(512, 2) void conv3x3_split_pre_kernel(SpPreArgs a) {
+__global__ __launch_bounds__(SP_PRE_NW * 64, SP_PRE_NW / 4) void conv3x3_split_pre_kernel(SpPreArgs a) {
     constexpr bool F16 = PM == 1;
     using C = SpPreCfg<W16>;
     constexpr int NT = C::NT, IN_COLS = C::IN_COLS, NWI = C::NWI, CO_T = C::CO_T, NPIXP = C::NPIXP, NB = C::NB;
     constexpr int BUF = C::BUF_SLOTS, W_PART = C::W_PART, IN_PART = C::IN_PART, ROWS = C::ROWS, TW = C::TW;
-    constexpr int NII = (2 * IN_PART + 511) / 512;                     // 5 (6) input DMA rounds per wave and chunk (2560 / 2624 slot positions)
+    constexpr int NWV = C::NW, NTH = NWV * 64;
+    constexpr int NII = (2 * IN_PART + NTH - 1) / NTH;                     // 5 (6) input DMA rounds per wave and chunk (2560 / 2624 slot positions)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
     u32x4s* lds = reinterpret_cast<u32x4s*>(smem_s);                   // [2 buffers][weights hi|mid | input hi|mid]
 
@@ -708,7 +718,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_pre_kernel(SpPreArgs a) 
                       (W16 ? a.xs_bs * 4 : 0) + (int64_t)a.Cin * HW * (PM == 2 ? 2 : 4));
 #pragma unroll
         for (int k = 0; k < NII; ++k) {
-            const int i = (wn + 8 * k) * 64 + lane;
+            const int i = (wn + NWV * k) * 64 + lane;
             const int ph = i / NPIXP, pix = i % NPIXP;                 // ph = part * 2 + half (PM 2: the chunk's channel group 0 .. 3)
             const int r = pix / IN_COLS, c = pix % IN_COLS;
             const int img = W16 ? c / 18 : 0;
@@ -720,7 +730,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_pre_kernel(SpPreArgs a) 
         }
 #pragma unroll
         for (int k = 0; k < NWI; ++k) {
-            const int i = tid + 512 * k;
+            const int i = tid + NTH * k;
             const int co = i & (CO_T - 1), pth = i >> 6;
             const bool ok = live && (i < C::W_SLOTS) && (co0 + co < a.Cout);
             w_off[k] = ok ? (unsigned)((pth * a.Cout + co0 + co) * 16) : OOB_S;
@@ -739,12 +749,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_pre_kernel(SpPreArgs a) 
     };
     // piece k of the chunk the staging state points at, into chunk buffer `buf`
     auto dma_in = [&](int buf, int k) __attribute__((always_inline)) {
-        if ((wn + 8 * k) * 64 < 2 * IN_PART)
-            sp_dma16(xr, lds0 + (unsigned)((buf * BUF + C::W_SLOTS + (wn + 8 * k) * 64) * 16), in_off[k], cin_bytes);
+        if ((wn + NWV * k) * 64 < 2 * IN_PART)
+            sp_dma16(xr, lds0 + (unsigned)((buf * BUF + C::W_SLOTS + (wn + NWV * k) * 64) * 16), in_off[k], cin_bytes);
     };
     auto dma_w = [&](int buf, int k) __attribute__((always_inline)) {
-        if (k < NWI - 1 || wn < (C::W_SLOTS - 512 * (NWI - 1)) / 64)
-            sp_dma16(wr, lds0 + (unsigned)((buf * BUF + (wn + 8 * k) * 64) * 16), w_off[k], cw_bytes);
+        if (k < NWI - 1 || wn < (C::W_SLOTS - NTH * (NWI - 1)) / 64)
+            sp_dma16(wr, lds0 + (unsigned)((buf * BUF + (wn + NWV * k) * 64) * 16), w_off[k], cw_bytes);
     };
 
     const u32x4s* const a_ptr = lds + kh * CO_T + l31;
@@ -835,6 +845,37 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_pre_kernel(SpPreArgs a) 
                         } else if constexpr (F16) {
                             const f16x8 ah = __builtin_bit_cast(f16x8, Aq[idx & 1][m][0]), am = __builtin_bit_cast(f16x8, Aq[idx & 1][m][1]);
                             const f16x8 bh = __builtin_bit_cast(f16x8, Bq[kx & 1][n + ky][0]), bm = __builtin_bit_cast(f16x8, Bq[kx & 1][n + ky][1]);
+#ifdef SP_PRE_TIMING_MFMA16      // TIMING ONLY (wrong results): the same matrix work as six v_mfma_f32_16x16x32_f16 on accumulator quarters
+                            {
+                                f32x4s q0 = __builtin_shufflevector(acc[m][n], acc[m][n], 0, 1, 2, 3), q1 = __builtin_shufflevector(acc[m][n], acc[m][n], 4, 5, 6, 7);
+                                f32x4s q2 = __builtin_shufflevector(acc[m][n], acc[m][n], 8, 9, 10, 11), q3 = __builtin_shufflevector(acc[m][n], acc[m][n], 12, 13, 14, 15);
+                                q0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(am, bh, q0, 0, 0, 0);
+                                q1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bm, q1, 0, 0, 0);
+                                q2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, q2, 0, 0, 0);
+                                q3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(am, bh, q3, 0, 0, 0);
+                                q0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bm, q0, 0, 0, 0);
+                                q1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, q1, 0, 0, 0);
+                                const auto lo = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7), hi = __builtin_shufflevector(q2, q3, 0, 1, 2, 3, 4, 5, 6, 7);
+                                acc[m][n] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+                            }
+#ifdef SP_PRE_TIMING_EXTRA        // ... plus what the real K-packed kernel adds: one wasted half MFMA per tile and chunk, 36 more fragment reads
+                            if (idx == 8 && n == 0) {
+                                f32x4s q0 = __builtin_shufflevector(acc[m][1], acc[m][1], 0, 1, 2, 3), q1 = __builtin_shufflevector(acc[m][1], acc[m][1], 4, 5, 6, 7);
+                                f32x4s q2 = __builtin_shufflevector(acc[m][1], acc[m][1], 8, 9, 10, 11), q3 = __builtin_shufflevector(acc[m][1], acc[m][1], 12, 13, 14, 15);
+                                q0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(am, bm, q0, 0, 0, 0);
+                                q1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(am, bm, q1, 0, 0, 0);
+                                q2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(am, bm, q2, 0, 0, 0);
+                                q3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(am, bm, q3, 0, 0, 0);
+                                const auto lo = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7), hi = __builtin_shufflevector(q2, q3, 0, 1, 2, 3, 4, 5, 6, 7);
+                                acc[m][1] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+                            }
+                            if (n == 0) {
+                                const u32x4s e0 = ab[(idx * 2 + m) * 64 + 16], e1 = bb[(idx + m) * IN_COLS + 2 + IN_PART];
+                                asm volatile("" :: "v"(e0), "v"(e1));
+                            }
+#endif
+                            continue;
+#endif
                             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, bh, acc[m][n], 0, 0, 0);
                             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bm, acc[m][n], 0, 0, 0);
                             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[m][n], 0, 0, 0);
@@ -932,6 +973,330 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_pre_kernel(SpPreArgs a) 
     }
 }
 
+
+// ------------------------------------------------------------------ the same tile on v_mfma_f32_16x16x32 (round 5)
+// MI355X_MICROARCH.md, 'DVFS give-back' (7): in clock-limited MFMA loops the chip holds a higher clock on the 16x16x32 shape than on
+// 32x32x16 at equal cycles per FLOP (half the accumulator traffic per FLOP).  Measured in this kernel (profiles/r05_mfma_shape_ab.md):
+// the same matrix work issued as 16x16x32 runs 8-9 % faster on every layer shape.  So: the block, its LDS image, the DMA schedule and
+// the persistent tile walk of conv3x3_split_pre_kernel, with the wave's 64 channels x 2 rows x 32 pixels held as SIXTEEN 16 x 16
+// accumulators, M = 16 pixels of a row (A = input fragment), N = 16 output channels (B = weight fragment): a lane then owns four
+// CONSECUTIVE pixels of one channel -- the epilogue stores float4s (16 store instructions per wave and tile instead of 64) and the
+// BatchNorm statistics need in-lane sums plus two cross-lane steps per channel tile (the 32x32 form: 5 DPP steps per register).
+// K = 32 per instruction:
+//  * PM == 2 (plain bf16, 32-channel chunks): K = the chunk's 32 channels -- lane group q = lane / 16 reads channel group q.  Nine
+//    steps of 16 MFMAs per chunk, the fragment reads of the 32x32 form (36 weight + 24 input per wave and chunk).
+//  * split operands (16-channel chunks, three product terms per tap): K-packing.
+//      'a' step (tap):          A = [x_hi | x_hi]            B = [w_hi(tap) | w_mid(tap)]      -> x_hi w_hi + x_hi w_mid
+//      'H' step (ky), taps (ky,0), (ky,1):  A = [x_mid(kx=0) | x_mid(kx=1)]  B = [w_hi(ky,0) | w_hi(ky,1)]
+//      'V' step, taps (0,2), (1,2):         A = [x_mid(row n) | x_mid(row n+1)] at kx = 2,  B = [w_hi(0,2) | w_hi(1,2)]
+//      'S' step, tap (2,2):                 A = [x_mid(row n+2) | same],  B = [w_hi(2,2) | 0]   (27 K16 products are an odd number:
+//    one half instruction per tile and chunk is padding -- 14 steps for 13.5 steps' worth, +3.7 %; the zero half reads the zero padding
+//    behind the halo image).  Lanes pick their K group by address: every fragment is still ONE conflict-free ds_read_b128.
+template <bool ST, int PM, bool W16>
+__global__ __launch_bounds__(512, 2) void conv3x3_pre16_kernel(SpPreArgs a) {
+    constexpr bool F16 = PM == 1;
+    using C = SpPreCfg<W16>;
+    static_assert(C::NW == 8 && C::NT == 2, "conv3x3_pre16_kernel: 8 waves of 2 rows");
+    constexpr int NT = 2, IN_COLS = C::IN_COLS, NWI = C::NWI, CO_T = C::CO_T, NPIXP = C::NPIXP;
+    constexpr int BUF = C::BUF_SLOTS, W_PART = C::W_PART, IN_PART = C::IN_PART, ROWS = C::ROWS, TW = C::TW;
+    constexpr int NII = (2 * IN_PART + 511) / 512;
+    constexpr int CH_OFF = W16 ? 18 : 16;                              // column of the second 16-pixel tile in the halo image
+    constexpr int NSTEP = PM == 2 ? 9 : 14;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
+    u32x4s* lds = reinterpret_cast<u32x4s*>(smem_s);
+
+    const int ntiles = a.tilesX * a.tilesY * a.B * a.coTiles;
+    int t_first, t_end, t_stride;
+    {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int q = ntiles >> 3, r = ntiles & 7;
+        const int start = xcd * q + min(xcd, r);
+        t_stride = (gridDim.x + 7 - xcd) >> 3;
+        t_first = start + j;
+        t_end = start + q + (xcd < r ? 1 : 0);
+    }
+    if (t_first >= t_end) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, lq = lane >> 4, hq = lq & 1, gq = lq >> 1;
+    const int HW = a.H * a.W;
+    const int nchunks = PM == 2 ? a.Cin >> 5 : a.Cin >> 4;
+
+    const i32x4s wr = sp_rsrc4(a.wq, (int64_t)a.Cin * (PM == 2 ? 1 : 2) * 9 * a.Cout * 2);
+    float xs_inv = 1.f, xs_inv2 = 1.f;
+    (void)amax_scale(amax_read(a.x_slots), a.x_always != 0, xs_inv);
+    (void)amax_scale(amax_read(a.x_slots2), a.x_always != 0, xs_inv2);
+    const int split_chunk = a.split_ch ? (PM == 2 ? a.split_ch >> 5 : a.split_ch >> 4) : 0;
+    const float grp_ratio = split_chunk ? xs_inv / xs_inv2 : 1.f;
+    const float acc_scale = (split_chunk ? xs_inv2 : xs_inv) * (F16 ? reinterpret_cast<const float*>(a.wq + (int64_t)a.Cin * 2 * 9 * a.Cout)[1] : 1.f);
+    const unsigned in_step = (unsigned)(16 * HW * 4), w_step = (unsigned)(2 * 9 * 2 * a.Cout * 16);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_s;
+
+    // ---- staging (conv3x3_split_pre_kernel's): slot position i = (wn + 8 k) * 64 + lane of the chunk image
+    unsigned in_off[NII], w_off[NWI];
+    i32x4s xr;
+    int st_tile = t_first, st_chunk = 0;
+    unsigned cin_bytes = 0, cw_bytes = 0;
+    auto setup_stage = [&]() __attribute__((always_inline)) {
+        const bool live = st_tile < t_end;
+        int v = live ? st_tile : t_first;
+        const int co0 = (v % a.coTiles) * CO_T;
+        v /= a.coTiles;
+        const int tx = v % a.tilesX;
+        v /= a.tilesX;
+        const int ty = v % a.tilesY;
+        const int b = v / a.tilesY;
+        const int y0 = ty * ROWS, x0 = tx * TW;
+        xr = sp_rsrc4(reinterpret_cast<const unsigned*>(a.xs) + (int64_t)(W16 ? 2 * b : b) * a.xs_bs,
+                      (W16 ? a.xs_bs * 4 : 0) + (int64_t)a.Cin * HW * (PM == 2 ? 2 : 4));
+#pragma unroll
+        for (int k = 0; k < NII; ++k) {
+            const int i = (wn + 8 * k) * 64 + lane;
+            const int ph = i / NPIXP, pix = i % NPIXP;
+            const int r = pix / IN_COLS, c = pix % IN_COLS;
+            const int img = W16 ? c / 18 : 0;
+            const int yy = y0 - 1 + r, xx = W16 ? c % 18 - 1 : x0 - 1 + c;
+            const bool ok = live && i < 2 * IN_PART && pix < C::NPIX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+            const unsigned io = W16 ? (unsigned)(img * a.xs_bs * 4) : 0u;
+            in_off[k] = !ok ? OOB_S : PM == 2 ? io + (unsigned)(((ph * a.H + yy) * a.W + xx) * 16)
+                                              : io + (unsigned)(((((ph & 1) * a.H + yy) * 2 + (ph >> 1)) * a.W + xx) * 16);
+        }
+#pragma unroll
+        for (int k = 0; k < NWI; ++k) {
+            const int i = tid + 512 * k;
+            const int co = i & (CO_T - 1), pth = i >> 6;
+            const bool ok = live && (i < C::W_SLOTS) && (co0 + co < a.Cout);
+            w_off[k] = ok ? (unsigned)((pth * a.Cout + co0 + co) * 16) : OOB_S;
+        }
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
+        ++st_chunk;
+        cin_bytes += in_step;
+        cw_bytes += w_step;
+        if (st_chunk == nchunks) {
+            st_chunk = 0;
+            cin_bytes = cw_bytes = 0;
+            st_tile += t_stride;
+            setup_stage();
+        }
+    };
+    auto dma_in = [&](int buf, int k) __attribute__((always_inline)) {
+        if ((wn + 8 * k) * 64 < 2 * IN_PART)
+            sp_dma16(xr, lds0 + (unsigned)((buf * BUF + C::W_SLOTS + (wn + 8 * k) * 64) * 16), in_off[k], cin_bytes);
+    };
+    auto dma_w = [&](int buf, int k) __attribute__((always_inline)) {
+        if (k < NWI - 1 || wn < (C::W_SLOTS - 512 * (NWI - 1)) / 64)
+            sp_dma16(wr, lds0 + (unsigned)((buf * BUF + (wn + 8 * k) * 64) * 16), w_off[k], cw_bytes);
+    };
+
+    // ---- fragment bases (slots inside a chunk buffer).  Lane (r16, lq): row / column r16 of the 16 x 16 tile, K group lq (8 values)
+    const int xrow0 = (wn * NT) * IN_COLS + r16;
+    const u32x4s* const xa_p = lds + C::W_SLOTS + (PM == 2 ? lq : hq) * NPIXP + xrow0;        // + row * IN_COLS + ch * CH_OFF + kx
+    const u32x4s* const xh_p = lds + C::W_SLOTS + (2 + hq) * NPIXP + xrow0 + gq;                // 'H': x_mid, kx = gq
+    const u32x4s* const xv_p = lds + C::W_SLOTS + (2 + hq) * NPIXP + xrow0 + gq * IN_COLS + 2;  // 'V': x_mid, rows n + gq, kx = 2
+    const u32x4s* const xs_p = lds + C::W_SLOTS + (2 + hq) * NPIXP + xrow0 + 2;                 // 'S': x_mid, kx = 2 (both K halves)
+    const u32x4s* const wa_p = lds + (gq * 9 * 2 + hq) * CO_T + r16;                            // + tap * 2 CO_T + ct * 16: [w_hi | w_mid] (PM 2: 32 channels)
+    const u32x4s* const wh_p = lds + (gq * 2 + hq) * CO_T + r16;                                // 'H': + ky * 6 CO_T + ct * 16: taps (ky, gq)
+    const u32x4s* const wv_p = lds + ((3 * gq + 2) * 2 + hq) * CO_T + r16;                      // 'V': taps (gq, 2)
+    const u32x4s* const ws_p = gq == 0 ? lds + (8 * 2 + hq) * CO_T + r16 : lds + C::W_SLOTS + C::NPIX;   // 'S': tap (2,2) | zeros
+    const int ws_ct = gq == 0 ? 16 : 0;
+
+    setup_stage();
+#pragma unroll
+    for (int k = 0; k < NII; ++k) dma_in(0, k);
+#pragma unroll
+    for (int k = 0; k < NWI; ++k) dma_w(0, k);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0;
+    for (int tile = t_first; tile < t_end; tile += t_stride) {
+        f32x4s acc[4][NT][2];                       // [channel tile][row][16-pixel tile]
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) acc[ct][n][ch] = f32x4s{0.f, 0.f, 0.f, 0.f};
+
+        for (int c = 0; c < nchunks; ++c) {
+            if (split_chunk && c == split_chunk && grp_ratio != 1.f) {
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+#pragma unroll
+                        for (int ch = 0; ch < 2; ++ch) acc[ct][n][ch] *= grp_ratio;
+            }
+            const int bo = buf * BUF;
+            u32x4s Xp[2][NT + 2][2], Wf[2][4];
+            // the input fragments of pool p for phase ph (0..2: 'a' at kx = ph; 3: 'H'; 4: 'V' rows 0..1 + 'S' rows 2..3), fragment f
+            auto load_x = [&](int ph, int f) __attribute__((always_inline)) {
+                const int j = f >> 1, ch = f & 1, p = ph & 1;
+                if (ph < 3) Xp[p][j][ch] = xa_p[bo + j * IN_COLS + ch * CH_OFF + ph];
+                else if (ph == 3) Xp[p][j][ch] = xh_p[bo + j * IN_COLS + ch * CH_OFF];
+                else if (j < NT) Xp[p][j][ch] = xv_p[bo + j * IN_COLS + ch * CH_OFF];
+                else Xp[p][j][ch] = xs_p[bo + j * IN_COLS + ch * CH_OFF];
+            };
+            auto load_w = [&](int s) __attribute__((always_inline)) {       // the weight fragments of step s
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    if (s < 9) Wf[s & 1][ct] = wa_p[bo + ((s % 3) * 3 + s / 3) * 2 * CO_T + ct * 16];
+                    else if (s < 12) Wf[s & 1][ct] = wh_p[bo + (s - 9) * 6 * CO_T + ct * 16];
+                    else if (s == 12) Wf[s & 1][ct] = wv_p[bo + ct * 16];
+                    else Wf[s & 1][ct] = ws_p[bo + ct * ws_ct];
+                }
+            };
+#pragma unroll
+            for (int f = 0; f < 2 * (NT + 2); ++f) load_x(0, f);
+            load_w(0);
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                const int ph = s < 9 ? s / 3 : (s < 12 ? 3 : 4);           // phase of this step; its fragments sit in pool ph & 1
+                const int ro = s < 9 ? s % 3 : (s < 12 ? s - 9 : (s == 12 ? 0 : NT));   // first fragment row of output row 0
+                if (s + 1 < NSTEP) load_w(s + 1);
+                if (s < 12 && ph + 1 < (PM == 2 ? 3 : 5)) {                // the next phase's input fragments, a third per step
+#pragma unroll
+                    for (int f = 0; f < 2 * (NT + 2); ++f)
+                        if (f % 3 == s % 3) load_x(ph + 1, f);
+                }
+                if (s == 0) advance();
+                {
+                    constexpr int NPIECE = NII + NWI, PER = (NPIECE + SP_PRE_LAST_TAP) / (SP_PRE_LAST_TAP + 1);
+#pragma unroll
+                    for (int q = 0; q < PER; ++q) {
+                        const int pc = s * PER + q;
+                        if (s <= SP_PRE_LAST_TAP && pc < NPIECE) {
+                            if (pc & 1) { if (pc / 2 < NWI) dma_w(buf ^ 1, pc / 2); else dma_in(buf ^ 1, pc - NWI); }
+                            else { if (pc / 2 < NII) dma_in(buf ^ 1, pc / 2); else dma_w(buf ^ 1, pc - NII); }
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+#pragma unroll
+                        for (int ch = 0; ch < 2; ++ch) {
+                            if constexpr (F16)
+                                acc[ct][n][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Xp[ph & 1][ro + n][ch]),
+                                                                                        __builtin_bit_cast(f16x8, Wf[s & 1][ct]), acc[ct][n][ch], 0, 0, 0);
+                            else
+                                acc[ct][n][ch] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Xp[ph & 1][ro + n][ch]),
+                                                                                         __builtin_bit_cast(bf16x8, Wf[s & 1][ct]), acc[ct][n][ch], 0, 0, 0);
+                        }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            buf ^= 1;
+        }
+
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) acc[ct][n][ch] *= acc_scale;
+        int v = tile;
+        const int co0 = (v % a.coTiles) * CO_T;
+        v /= a.coTiles;
+        const int tx = v % a.tilesX;
+        v /= a.tilesX;
+        const int ty = v % a.tilesY;
+        const int b = v / a.tilesY;
+        const int y0 = ty * ROWS, x0 = tx * TW;
+        if constexpr (ST) {
+            // BatchNorm (n, mean, M2) record of the tile per channel.  Lane = channel r16 of tile ct, 16 pixel values in registers:
+            // own pivot-shifted sums -> (mean, M2) of 16; the four lane groups merged pairwise (equal counts: Chan's formula); the
+            // eight waves through LDS -- in the chunk buffer nobody reads until the next chunk's DMA (issued behind the barriers below)
+            float* sc = reinterpret_cast<float*>(lds + (buf ^ 1) * BUF);       // [8 waves][64 channels][mean, M2]
+            constexpr float npw = (float)(NT * 32);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const float pv = acc[ct][0][0][0];
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float d = acc[ct][n][ch][r] - pv;
+                            s1 += d;
+                            s2 = fmaf(d, d, s2);
+                        }
+                float mean = fmaf(s1, 1.f / 16.f, pv), m2 = fmaxf(fmaf(-s1 * (1.f / 16.f), s1, s2), 0.f), cnt = 16.f;
+#pragma unroll
+                for (int o = 16; o <= 32; o <<= 1) {
+                    const float mo = __shfl_xor(mean, o, 64), qo = __shfl_xor(m2, o, 64);
+                    const float dlt = mo - mean;
+                    m2 = (m2 + qo) + (0.5f * cnt) * dlt * dlt;
+                    mean = 0.5f * (mean + mo);
+                    cnt *= 2.f;
+                }
+                if (lq == 0) {
+                    sc[(wn * 64 + ct * 16 + r16) * 2] = mean;
+                    sc[(wn * 64 + ct * 16 + r16) * 2 + 1] = m2;
+                }
+            }
+            __syncthreads();
+            if (tid < 64 && co0 + tid < a.Cout) {
+                float mw[8], qw[8];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) {
+                    mw[w] = sc[(w * 64 + tid) * 2];
+                    qw[w] = sc[(w * 64 + tid) * 2 + 1];
+                }
+                const float mean = 0.125f * (((mw[0] + mw[1]) + (mw[2] + mw[3])) + ((mw[4] + mw[5]) + (mw[6] + mw[7])));
+                float m2 = ((qw[0] + qw[1]) + (qw[2] + qw[3])) + ((qw[4] + qw[5]) + (qw[6] + qw[7]));
+#pragma unroll
+                for (int w = 0; w < 8; ++w) m2 = fmaf(npw * (mw[w] - mean), mw[w] - mean, m2);
+                const int64_t nblk = (int64_t)a.B * a.tilesY * a.tilesX;
+                const int64_t blk = ((int64_t)b * a.tilesY + ty) * a.tilesX + tx;
+                float* sp = a.stats + ((int64_t)(co0 + tid) * nblk + blk) * 3;
+                sp[0] = 8.f * npw;
+                sp[1] = mean;
+                sp[2] = m2;
+            }
+            __syncthreads();
+        }
+        // A lane holds, per (channel tile, row), channel r16's pixels 4 lq .. + 3 of BOTH 16-pixel tiles: stored as they stand, an
+        // instruction would write 64-byte half lines (16 channels x 4 lanes x 16 B).  Lanes r16 >= 8 of the first tile and lanes
+        // r16 < 8 of the second trade places (two masked row_ror:8 DPP moves per register) so that each store instruction writes
+        // eight channels' WHOLE 128-byte lines: instruction 1 channels 0-7 (pixels 0-15 from lanes r16 < 8, 16-31 from lanes r16 >= 8),
+        // instruction 2 channels 8-15.
+        {
+            const int half = r16 >> 3, c8 = r16 & 7;
+            float* zb = a.z + (int64_t)(W16 ? 2 * b + half : b) * a.z_bs;      // (W16: the second 16-pixel tile is the pair's second image)
+            const int xo = (W16 ? 0 : x0 + 16 * half) + 4 * lq;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int yo = y0 + wn * NT + n;
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    f32x4s d1, d2;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int va = __builtin_bit_cast(int, acc[ct][n][0][r]), vb = __builtin_bit_cast(int, acc[ct][n][1][r]);
+                        d1[r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(va, vb, 0x128, 0xf, 0xc, false));   // lanes 8-15 <- tile 1 of channel r16 - 8
+                        d2[r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(vb, va, 0x128, 0xf, 0x3, false));   // lanes 0-7  <- tile 0 of channel r16 + 8
+                    }
+                    if (yo < a.H && xo < a.W) {
+                        const int co = co0 + ct * 16 + c8;
+                        float* o = zb + (int64_t)co * HW + (int64_t)yo * a.W + xo;
+                        if (co < a.Cout) *reinterpret_cast<f32x4s*>(o) = d1;
+                        if (co + 8 < a.Cout) *reinterpret_cast<f32x4s*>(o + (int64_t)8 * HW) = d2;
+                    }
+                }
+            }
+        }
+    }
+}
+
+#ifndef SP_PRE16
+#define SP_PRE16 1      // 1: conv3x3_pre16_kernel (v_mfma_f32_16x16x32); 0: conv3x3_split_pre_kernel (32x32x16) -- same-box A/B builds
+#endif
 template <bool ST, int PM, bool W16>
 int launch_split_pre(SpPreArgs a, hipStream_t st) {
     using C = SpPreCfg<W16>;
@@ -942,14 +1307,14 @@ int launch_split_pre(SpPreArgs a, hipStream_t st) {
     if (W16) a.B /= 2;                               // tiles hold image pairs
     const int64_t tiles = (int64_t)a.B * a.tilesX * a.tilesY * a.coTiles;
     ONET_REQUIRE(tiles > 0 && tiles < (1ll << 31), "conv3x3_split_pre: tile count %lld out of range", (long long)tiles);
-    auto kern = conv3x3_split_pre_kernel<ST, PM, W16>;
+    auto kern = (SP_PRE16 && (SP_PRE16 > 1 || PM == 2)) ? conv3x3_pre16_kernel<ST, PM, W16> : conv3x3_split_pre_kernel<ST, PM, W16>;
     static PerDeviceOnce attr_once;
     if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     }
     const int64_t resident = (int64_t)device_cu_count();
     const int64_t blocks = std::min<int64_t>((tiles + 7) / 8 * 8, std::max<int64_t>(8, resident / 8 * 8));
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), LDS_BYTES, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::NW * 64), LDS_BYTES, st, a);
     return check_launch("conv3x3_split_pre_kernel");
 }
 
@@ -1565,6 +1930,225 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wgrad_pre_kernel(SwPreAr
     }
 }
 
+// Round 5: the same kernel on v_mfma_f32_16x16x32 (profiles/r05_mfma_shape_ab.md: the shape the chip clocks higher on).  K = pixels here,
+// so K = 32 is natural -- one instruction takes 32 consecutive pixels of a unit's row (two of the 32x32x16 form's 16-pixel k-steps),
+// no K-packing, the same LDS image, DMA schedule and fragment bytes.  A wave's 32 x 32 channel tile per tap is four 16 x 16
+// accumulators; M = input channels (A = x fragment), N = output channels (B = dz fragment), so a lane owns four CONSECUTIVE input
+// channels of one output channel and the slab leaves as float4 stores.  Lane group lg = lane / 16 takes pixels 8 lg .. 8 lg + 7 of the
+// step (G = 4, four 16-pixel images per unit: lane groups 0-1 / 2-3 sit in two different images' sub-rows).
+template <int G, int COT, int PM>
+__global__ __launch_bounds__(512, 2) void conv3x3_wgrad_pre16_kernel(SwPreArgs a) {
+    constexpr bool F16 = PM == 1;
+    constexpr int NP = PM == 2 ? 1 : 2;                        // parts per operand
+    constexpr int PXP = G == 4 ? 76 : SWP_PXP;
+    constexpr int XS = 8, DS = COT / 8;                        // channel groups per image
+    // (row images padded to whole 64-slot DMA pieces: the lanes of a piece beyond the image write zeros, which must not land in the
+    // next ring slot / buffer)
+    constexpr int X_PART = XS * PXP, X_ROW = (NP * X_PART + 63) / 64 * 64;      // slots
+    constexpr int DZ_PART = DS * PXP, DZ_BUF = (NP * DZ_PART + 63) / 64 * 64;
+    constexpr int NXI = (X_ROW + 511) / 512, NDI = (DZ_BUF + 511) / 512;      // DMA rounds per wave (64 slots each, 8 waves)
+    constexpr int NKS = COT == 64 ? 1 : 2;                     // k-steps (32 pixels) per wave and unit
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_w;
+    const unsigned x_base = lds0, dz_base = lds0 + 4 * X_ROW * 16;
+
+    int bid;
+    {
+        const int n = gridDim.x, q = n >> 3, r = n & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int tiles = a.ciTiles * a.coTiles;
+    const int ks = bid / tiles, tile = bid % tiles;
+    const int ci0 = (tile % a.ciTiles) * 64, co0 = (tile / a.ciTiles) * COT;
+    const int nunits = (a.B / G) * a.tilesX * a.H;
+    const int per = (nunits + a.splitK - 1) / a.splitK;
+    const int u0 = ks * per, u1 = min(u0 + per, nunits);
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = COT == 64 ? wid >> 2 : 0, wm = COT == 64 ? (wid >> 1) & 1 : wid >> 1, wn = wid & 1;
+    const int r16 = lane & 15, lg = lane >> 4;
+    const int HW = a.H * a.W;
+
+    f32x4s acc[9][2][2];                                        // [tap][input-channel half (M)][output-channel half (N)]
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][i >> 1][i & 1] = f32x4s{0.f, 0.f, 0.f, 0.f};
+
+    // transposed-read lane bases (bytes): lane = 16 lg + 4 q + p supplies pixel row q (of the group's 8 pixels), channels 4 p .. 4 p + 3
+    // of the 16-channel half; the wave's second half sits two channel groups (2 PXP slots) further
+    const int tq = (lane >> 2) & 3, tp = lane & 3;
+    const int xg = G == 4 ? (lg >> 1) * 18 + 8 * (lg & 1) : 8 * lg;              // x pixel slot of the lane group inside a 32-pixel step
+    const unsigned a_lane = (unsigned)((((wm * 4 + (tp >> 1)) * PXP + 8 * lg + tq) * 16) + (tp & 1) * 8);       // dz
+    const unsigned b_lane = (unsigned)((((wn * 4 + (tp >> 1)) * PXP + xg + tq) * 16) + (tp & 1) * 8);           // x
+    constexpr unsigned HALF = 2 * PXP * 16;
+
+    // ---- staging: slot position i = (wid + 8 k) * 64 + lane of a row image [part][group][PXP]
+    i32x4s xr, dr;
+    unsigned x_off[NXI], d_off[NDI];
+    auto setup_strip = [&](int b, int x0) __attribute__((always_inline)) {
+        if (G == 1) {
+            xr = sp_rsrc4(reinterpret_cast<const unsigned*>(a.xs) + (int64_t)b * a.xs_bs, (int64_t)a.Cin * HW * 2 * NP);
+            dr = sp_rsrc4(reinterpret_cast<const unsigned*>(a.dzs) + (int64_t)b * a.dzs_bs, (int64_t)a.Cout * HW * 2 * NP);
+        } else {
+            xr = sp_rsrc4(a.xs, (int64_t)(a.B - 1) * a.xs_bs * 4 + (int64_t)a.Cin * HW * 2 * NP);
+            dr = sp_rsrc4(a.dzs, (int64_t)(a.B - 1) * a.dzs_bs * 4 + (int64_t)a.Cout * HW * 2 * NP);
+        }
+#pragma unroll
+        for (int k = 0; k < NXI; ++k) {
+            const int i = (wid + 8 * k) * 64 + lane;
+            const int part = i / X_PART, s = (i % X_PART) / PXP, pi = i % PXP;
+            const int img = G == 1 ? 0 : pi / (a.W + 2), xx = G == 1 ? x0 - 1 + pi : pi % (a.W + 2) - 1;
+            const bool ok = i < NP * X_PART && pi < (G == 1 ? 66 : G * (a.W + 2)) && xx >= 0 && xx < a.W && ci0 + 8 * s < a.Cin;
+            const int64_t img_off = G == 1 ? 0 : (int64_t)(b * G + img) * a.xs_bs * 4;
+            x_off[k] = ok ? (unsigned)(img_off + ((int64_t)((ci0 / 8 + s) * a.H) * NP + part) * a.W * 16 + xx * 16) : OOB_S;
+        }
+#pragma unroll
+        for (int k = 0; k < NDI; ++k) {
+            const int i = (wid + 8 * k) * 64 + lane;
+            const int part = i / DZ_PART, s = (i % DZ_PART) / PXP, pi = i % PXP;
+            const int img = G == 1 ? 0 : pi / a.W, xx = G == 1 ? x0 + pi : pi % a.W;
+            const bool ok = i < NP * DZ_PART && pi < 64 && xx < a.W && co0 + 8 * s < a.Cout;
+            const int64_t img_off = G == 1 ? 0 : (int64_t)(b * G + img) * a.dzs_bs * 4;
+            d_off[k] = ok ? (unsigned)(img_off + ((int64_t)((co0 / 8 + s) * a.H) * NP + part) * a.W * 16 + xx * 16) : OOB_S;
+        }
+    };
+    // row y of the strip into ring slot / dz buffer; rows outside the image are zeros (every lane out of range)
+    auto dma_x = [&](int y, int k) __attribute__((always_inline)) {
+        if ((wid + 8 * k) * 64 < X_ROW) {
+            const bool ok = y >= 0 && y < a.H;
+            sp_dma16(xr, x_base + (unsigned)(((y & 3) * X_ROW + (wid + 8 * k) * 64) * 16), ok ? x_off[k] : OOB_S, ok ? (unsigned)(y * NP * a.W * 16) : 0u);
+        }
+    };
+    auto dma_dz = [&](int y, int k) __attribute__((always_inline)) {
+        if ((wid + 8 * k) * 64 < DZ_BUF) {
+            const bool ok = y >= 0 && y < a.H;
+            sp_dma16(dr, dz_base + (unsigned)(((y & 1) * DZ_BUF + (wid + 8 * k) * 64) * 16), ok ? d_off[k] : OOB_S, ok ? (unsigned)(y * NP * a.W * 16) : 0u);
+        }
+    };
+
+    int u = u0;
+    while (u < u1) {
+        const int yb = u % a.H, sb = u / a.H;
+        const int tx = sb % a.tilesX, b = sb / a.tilesX;
+        const int x0 = G == 1 ? tx * 64 : 0;
+        const int ye = min(a.H, yb + (u1 - u));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                              // every wave is done with the previous run's ring and dz buffers
+        setup_strip(b, x0);
+#pragma unroll
+        for (int k = 0; k < NXI; ++k) {
+            dma_x(yb - 1, k);
+            dma_x(yb, k);
+            dma_x(yb + 1, k);
+        }
+#pragma unroll
+        for (int k = 0; k < NDI; ++k) dma_dz(yb, k);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int y = yb; y < ye; ++y) {
+            // unit y: MFMAs on dz buffer y & 1 and ring rows y - 1 .. y + 1; the rows of unit y + 1 (dz row y + 1, x row y + 2) go
+            // by DMA into the other dz buffer and the ring slot of row y - 2 (both last read in unit y - 1), spread over the k-steps
+            const bool more = y + 1 < ye;
+            const unsigned ab = dz_base + (unsigned)((y & 1) * DZ_BUF * 16) + a_lane;
+            unsigned bb[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) bb[ky] = x_base + (unsigned)((((y - 1 + ky) & 3) * X_ROW) * 16) + b_lane;
+#pragma unroll
+            for (int kk = 0; kk < NKS; ++kk) {
+                const int kst = COT == 64 ? grp : kk;                          // 32-pixel k-step of the unit
+                const int dpx = 32 * kst;                                      // dz pixel slot
+                const int xpx = G == 1 ? 32 * kst : (G == 2 ? kst * 34 : kst * 36);      // x pixel slot of tap kx = 0 (G = 4: image pair)
+                if (more) {
+                    constexpr int NP = NXI + NDI, PER = (NP + NKS - 1) / NKS;
+#pragma unroll
+                    for (int q = 0; q < PER; ++q) {
+                        const int pc = kk * PER + q;
+                        if (pc < NDI) dma_dz(y + 1, pc);
+                        else if (pc < NP) dma_x(y + 2, pc - NDI);
+                    }
+                }
+                u32x4s Dh[2], Dm[2];                                           // dz fragments of the two output-channel halves
+#pragma unroll
+                for (int hd = 0; hd < 2; ++hd) {
+                    Dh[hd] = swp_frag(ab + hd * HALF + dpx * 16);
+                    Dm[hd] = NP == 2 ? swp_frag(ab + hd * HALF + (DZ_PART + dpx) * 16) : Dh[hd];
+                }
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    // the three horizontal taps of a row read pixels 8 lg + kx .. + 7: ONE set of three transposed reads (12 pixels, six
+                    // dwords of two pixels each) serves all three -- kx = 0: dwords 0-3, kx = 2: dwords 1-4, kx = 1: the 16-bit-shifted
+                    // pairs (v_alignbit)
+#pragma unroll
+                    for (int hx = 0; hx < 2; ++hx) {
+                        u32x4s Bs[2][3];
+#pragma unroll
+                        for (int pt = 0; pt < NP; ++pt) {
+                            const unsigned ba = bb[ky] + hx * HALF + (pt * X_PART + xpx) * 16;
+                            const u32x4s lo = swp_frag(ba);                                       // pixels 0 .. 7 of the lane's window
+                            const s16x4w r2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4w*)(uintptr_t)(ba + 128));
+                            const unsigned d4 = (unsigned)__builtin_bit_cast(unsigned long long, r2);   // pixels 8, 9
+                            Bs[pt][0] = lo;
+                            Bs[pt][1] = u32x4s{__builtin_amdgcn_alignbit(lo[1], lo[0], 16), __builtin_amdgcn_alignbit(lo[2], lo[1], 16),
+                                               __builtin_amdgcn_alignbit(lo[3], lo[2], 16), __builtin_amdgcn_alignbit(d4, lo[3], 16)};
+                            Bs[pt][2] = u32x4s{lo[1], lo[2], lo[3], d4};
+                        }
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const u32x4s Xh = Bs[0][kx], Xm = NP == 2 ? Bs[1][kx] : Bs[0][kx];
+                            const int t = ky * 3 + kx;
+#pragma unroll
+                            for (int hd = 0; hd < 2; ++hd) {
+                                if constexpr (PM == 2) {
+                                    acc[t][hx][hd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Xh), __builtin_bit_cast(bf16x8, Dh[hd]), acc[t][hx][hd], 0, 0, 0);
+                                } else if constexpr (F16) {
+                                    const f16x8 xh = __builtin_bit_cast(f16x8, Xh), xm = __builtin_bit_cast(f16x8, Xm);
+                                    const f16x8 dh = __builtin_bit_cast(f16x8, Dh[hd]), dm = __builtin_bit_cast(f16x8, Dm[hd]);
+                                    acc[t][hx][hd] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, dm, acc[t][hx][hd], 0, 0, 0);
+                                    acc[t][hx][hd] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xm, dh, acc[t][hx][hd], 0, 0, 0);
+                                    acc[t][hx][hd] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, dh, acc[t][hx][hd], 0, 0, 0);
+                                } else {
+                                    const bf16x8 xh = __builtin_bit_cast(bf16x8, Xh), xm = __builtin_bit_cast(bf16x8, Xm);
+                                    const bf16x8 dh = __builtin_bit_cast(bf16x8, Dh[hd]), dm = __builtin_bit_cast(bf16x8, Dm[hd]);
+                                    acc[t][hx][hd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, dm, acc[t][hx][hd], 0, 0, 0);
+                                    acc[t][hx][hd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, dh, acc[t][hx][hd], 0, 0, 0);
+                                    acc[t][hx][hd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, dh, acc[t][hx][hd], 0, 0, 0);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        u += ye - yb;
+    }
+
+    float x_inv = 1.f, dz_inv = 1.f;
+    const unsigned* xsl = (a.split_ch && ci0 >= a.split_ch) ? a.x_slots2 : a.x_slots;      // this block's 64 input channels
+    (void)amax_scale(amax_read(xsl), false, x_inv);
+    (void)amax_scale(amax_read(a.dz_slots), true, dz_inv);
+    const float out_scale = (xsl ? x_inv : 1.f) * (a.dz_slots ? dz_inv : 1.f);
+    const int64_t n = (int64_t)a.Cout * a.Cin;
+    // lane: output channel co0 + 32 wm + 16 hd + r16, input channels ci0 + 32 wn + 16 hx + 4 lg .. + 3: one float4 (Cin % 8 == 0)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float* o = a.slab + ((int64_t)(COT == 64 ? ks * 2 + grp : ks) * 9 + t) * n;
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx)
+#pragma unroll
+            for (int hd = 0; hd < 2; ++hd) {
+                const int co = co0 + wm * 32 + 16 * hd + r16, ci = ci0 + wn * 32 + 16 * hx + 4 * lg;
+                if (co < a.Cout && ci < a.Cin) *reinterpret_cast<f32x4s*>(o + (int64_t)co * a.Cin + ci) = acc[t][hx][hd] * out_scale;
+            }
+    }
+}
+
+#ifndef SP_WGRAD16
+#define SP_WGRAD16 1     // 1: conv3x3_wgrad_pre16_kernel (v_mfma_f32_16x16x32); 0: conv3x3_split_wgrad_pre_kernel -- same-box A/B builds
+#endif
+
 int split_wgrad_group(int W) { return W >= 64 ? 1 : 64 / W; }      // images per unit: 1, 2 (W = 32), 4 (W = 16)
 
 #ifndef SW_COT128
@@ -1689,7 +2273,7 @@ int onet_conv3x3_split_wgrad_pre(const void* xs, int64_t xs_bs, const void* x_am
     const int lds = (4 * ((np * 8 * pxp + 63) / 64 * 64) + 2 * ((np * (COT / 8) * pxp + 63) / 64 * 64)) * 16;
 #define ONET_SWP_LAUNCH(G_, COT_, F_)                                                                              \
     do {                                                                                                           \
-        auto kern = conv3x3_split_wgrad_pre_kernel<G_, COT_, F_>;                                                  \
+        auto kern = SP_WGRAD16 ? conv3x3_wgrad_pre16_kernel<G_, COT_, F_> : conv3x3_split_wgrad_pre_kernel<G_, COT_, F_>; \
         static PerDeviceOnce once;                                                                                 \
         if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
         hipLaunchKernelGGL(kern, grid, blk, lds, st, a);                                                           \
@@ -1767,14 +2351,14 @@ int onet_conv3x3_split_fwd_norm(const float* z_prev, int64_t z_bs, const float* 
 }
 
 int onet_split_pack_act(const float* x, int64_t x_bs, void* xs, int64_t xs_bs, int B, int C, int H, int W, int f16, float scale,
-                        void* stream) {
+                        const void* slots, void* stream) {
     ONET_REQUIRE(x && xs, "split_pack_act: null pointer");
     ONET_REQUIRE(B > 0 && C > 0 && (C % 8) == 0 && H > 0 && W > 0, "split_pack_act: C must be a multiple of 8");
     ONET_REQUIRE((reinterpret_cast<uintptr_t>(xs) & 15) == 0 && (xs_bs & 3) == 0, "split_pack_act: 16-byte aligned slots required");
     const int64_t n = (int64_t)B * (C / 8) * H * W;
     const int blocks = (int)std::min<int64_t>((n + 255) / 256, 1 << 20);
     hipLaunchKernelGGL(split_pack_act_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, x_bs, (unsigned*)xs, xs_bs, B, C / 8, H, W,
-                       f16, scale);
+                       f16, scale, (const unsigned*)slots);
     return check_launch("split_pack_act_kernel");
 }
 

@@ -253,27 +253,61 @@ __global__ void bilinear2x_fwd_kernel(const float* __restrict__ x, int64_t x_bs,
     }
 }
 
-// scatter-add into a zero-initialised dx (float atomics; <= 9 contributions per element)
+// GATHER form of the backward: one thread per dx element sums, in a fixed order (rows, then columns of the up-sampled plane), the
+// contributions of the output pixels whose interpolation stencil touches it -- those o with floor(o * scale) in {i - 1, i}, found by
+// running the FORWARD's own index computation (bil_src) over a conservative range, so forward and backward agree on every rounding.
+// No atomics: results are bitwise reproducible and leave as plain coalesced stores; dx needs no zero-initialisation.
+constexpr int BIL_MAXC = 8;       // candidates per axis: o in [(i - 1) / scale - 1, (i + 1) / scale + 1], scale = (n - 1) / (2 n - 1) in (1/3, 1/2)
+__device__ __forceinline__ int bil_candidates(int i, int in, int out, int& lo, float* wgt) {
+    const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    int hi;
+    if (scale == 0.f) {           // in == 1: every output pixel reads input 0
+        lo = 0;
+        hi = out - 1;
+    } else {
+        lo = max(0, (int)floorf((float)(i - 1) / scale) - 1);
+        hi = min(out - 1, (int)ceilf((float)(i + 1) / scale) + 1);
+    }
+    // trim to the pixels that actually touch i (both ends), so that at most BIL_MAXC remain
+    int n = 0, first = lo;
+    for (int o = lo; o <= hi; ++o) {
+        int i0, i1;
+        float l1;
+        bil_src(o, in, out, i0, i1, l1);
+        const float wv = (i0 == i ? 1.f - l1 : 0.f) + (i1 == i ? l1 : 0.f);
+        const bool touches = i0 == i || i1 == i;
+        if (!touches) {
+            if (n == 0) first = o + 1;
+            continue;
+        }
+        if (n < BIL_MAXC) wgt[n] = wv;
+        // (pixels between two touching ones always touch: floor(o * scale) is monotone)
+        ++n;
+    }
+    lo = first;
+    return min(n, BIL_MAXC);
+}
+
 __global__ void bilinear2x_bwd_kernel(const float* __restrict__ dy, int64_t dy_bs, float* __restrict__ dx,
                                       int64_t dx_bs, int B, int C, int h, int w, int Ho, int Wo, int pt, int pl) {
-    const int64_t n = (int64_t)B * C * 4 * h * w;
+    const int64_t n = (int64_t)B * C * h * w;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int ux = (int)(i % (2 * w));
-        int64_t r = i / (2 * w);
-        const int uy = (int)(r % (2 * h));
-        r /= (2 * h);
+        const int ix = (int)(i % w);
+        int64_t r = i / w;
+        const int iy = (int)(r % h);
+        r /= h;
         const int c = (int)(r % C), b = (int)(r / C);
-        const float g = dy[(int64_t)b * dy_bs + (int64_t)c * Ho * Wo + (int64_t)(uy + pt) * Wo + ux + pl];
-        int y0, y1, x0, x1;
-        float ly, lx;
-        bil_src(uy, h, 2 * h, y0, y1, ly);
-        bil_src(ux, w, 2 * w, x0, x1, lx);
-        float* p = dx + (int64_t)b * dx_bs + (int64_t)c * h * w;
-        const float hy = 1.f - ly, hx = 1.f - lx;
-        atomicAdd(p + y0 * w + x0, hy * hx * g);
-        atomicAdd(p + y0 * w + x1, hy * lx * g);
-        atomicAdd(p + y1 * w + x0, ly * hx * g);
-        atomicAdd(p + y1 * w + x1, ly * lx * g);
+        float wy[BIL_MAXC], wx[BIL_MAXC];
+        int ylo, xlo;
+        const int ny = bil_candidates(iy, h, 2 * h, ylo, wy), nx = bil_candidates(ix, w, 2 * w, xlo, wx);
+        const float* g = dy + (int64_t)b * dy_bs + (int64_t)c * Ho * Wo + (int64_t)(ylo + pt) * Wo + xlo + pl;
+        float acc = 0.f;
+        for (int ky = 0; ky < ny; ++ky) {
+            float row = 0.f;
+            for (int kx = 0; kx < nx; ++kx) row = fmaf(wx[kx], g[(int64_t)ky * Wo + kx], row);
+            acc = fmaf(wy[ky], row, acc);
+        }
+        dx[(int64_t)b * dx_bs + (int64_t)c * h * w + (int64_t)iy * w + ix] = acc;
     }
 }
 
@@ -606,12 +640,12 @@ extern "C" int onet_convT2x2_dbias(const float* dy, int64_t dy_bs, float* dbias,
     return check_launch("convT_dbias_final_kernel");
 }
 
-// dx must be zero-initialised by the caller (scatter-add)
+// every element of dx is written (gather form: no atomics, no zero-initialisation needed)
 extern "C" int onet_bilinear2x_bwd(const float* dy, int64_t dy_bs, float* dx, int64_t dx_bs, int B, int C, int h,
                                    int w, int Ho, int Wo, int pt, int pl, void* stream) {
     ONET_REQUIRE(dy && dx && B > 0 && C > 0 && h > 0 && w > 0, "bilinear2x_bwd: bad args");
     ONET_REQUIRE(pt >= 0 && pl >= 0 && pt + 2 * h <= Ho && pl + 2 * w <= Wo, "bilinear2x_bwd: window outside plane");
-    const int64_t n = (int64_t)B * C * 4 * h * w;
+    const int64_t n = (int64_t)B * C * h * w;
     hipLaunchKernelGGL(bilinear2x_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), dy, dy_bs, dx, dx_bs, B,
                        C, h, w, Ho, Wo, pt, pl);
     return check_launch("bilinear2x_bwd_kernel");

@@ -23,6 +23,10 @@ struct StemArgs {
     int64_t z_bs;
     float* part;          // [Cout][B * tilesY * tilesX][3] = (n, mean, M2) per tile, or NULL
     int B, Cout, H, W, tilesX, tilesY;
+    // K7 (OV:180) on load: the batch is the TWIN batch [X ; clip(1 - X + bias, 0, 1)] of which only X (twin_B images) exists in
+    // memory -- image b >= twin_B is formed from image b - twin_B while the halo tile is filled (twin_B = 0: an ordinary batch)
+    int twin_B;
+    float twin_bias;
 };
 
 constexpr int ST_TH = 16, ST_TW = 64, ST_LR = ST_TH + 2, ST_LC = ST_TW + 4;   // LDS tile: 18 rows x 66 columns, row stride 68
@@ -54,13 +58,16 @@ __global__ __launch_bounds__(256) void stem_conv_stats_kernel(StemArgs a) {
     const int y0 = ty * ST_TH, x0 = tx * ST_TW;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int HW = a.H * a.W;
-    const float* xb = a.x + (int64_t)b * a.x_bs;
+    const bool comp = a.twin_B > 0 && b >= a.twin_B;          // the complement half of a twin batch
+    const float* xb = a.x + (int64_t)(comp ? b - a.twin_B : b) * a.x_bs;
 
     for (int i = tid; i < CIN * ST_LR * 66; i += 256) {
         const int ci = i / (ST_LR * 66), r = (i / 66) % ST_LR, c = i % 66;
         const int yy = y0 - 1 + r, xx = x0 - 1 + c;
         const bool ok = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-        tile[ci][r][c] = ok ? xb[(int64_t)ci * HW + (int64_t)yy * a.W + xx] : 0.f;
+        float v = ok ? xb[(int64_t)ci * HW + (int64_t)yy * a.W + xx] : 0.f;
+        if (comp && ok) v = fminf(fmaxf(1.f - v + a.twin_bias, 0.f), 1.f);      // complement_clip_kernel's expression (zero padding stays zero)
+        tile[ci][r][c] = v;
     }
     __syncthreads();
 
@@ -141,14 +148,15 @@ extern "C" {
 int onet_conv3x3_stem_nparts(int B, int Cin, int Cout, int H, int W) { return stem_nparts(B, Cin, Cout, H, W); }
 
 int onet_conv3x3_stem_fwd_stats(const float* x, int64_t x_bs, const float* w, float* z, int64_t z_bs, float* part, int B, int Cin,
-                                int Cout, int H, int W, void* stream) {
+                                int Cout, int H, int W, int twin_B, float twin_bias, void* stream) {
     ONET_REQUIRE(x && w && z, "conv3x3_stem_fwd_stats: null pointer");
     ONET_REQUIRE(stem_nparts(B, Cin, Cout, H, W) > 0,
                  "conv3x3_stem_fwd_stats: needs 1 <= Cin <= 4, Cout <= %d and a map made of full 16 x 64 tiles (onet_conv3x3_stem_nparts() == 0 elsewhere)",
                  ST_MAXC);
     ONET_REQUIRE(x_bs >= (int64_t)Cin * H * W && z_bs >= (int64_t)Cout * H * W, "conv3x3_stem_fwd_stats: batch stride too small");
     ONET_REQUIRE((z_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(z) & 15) == 0, "conv3x3_stem_fwd_stats: 16-byte aligned output rows required");
-    StemArgs a{x, x_bs, w, z, z_bs, part, B, Cout, H, W, W / ST_TW, H / ST_TH};
+    ONET_REQUIRE(twin_B == 0 || 2 * twin_B == B, "conv3x3_stem_fwd_stats: a twin batch holds twin_B = B / 2 images in memory");
+    StemArgs a{x, x_bs, w, z, z_bs, part, B, Cout, H, W, W / ST_TW, H / ST_TH, twin_B, twin_bias};
     const int64_t blocks = (int64_t)B * a.tilesX * a.tilesY;
     const dim3 g((unsigned)blocks), t(256);
     switch (Cin) {

@@ -139,6 +139,7 @@ class ConvBNReLUFn(torch.autograd.Function):
             aux["a_amax"] = a_amax
         # (the weight gradient reads the bf16 copy too; saved WITH the tensors so that backward releases it -- a ctx attribute
         # would live as long as the caller holds the loss)
+        ctx.twin = ops.twin_src_of(x)       # a virtual twin batch (placeholder + (X, bias)): backward re-attaches the tag
         ctx.save_for_backward(x, z, save_all, x16, None if norm is None else norm[0], None if norm is None else norm[1])
         ctx.training = training
         ctx.packed = packed
@@ -220,6 +221,7 @@ class ConvBNReLUFn(torch.autograd.Function):
             ops.bn_relu_apply(z, save_all, out=a, amax=a_amax, group_images=gi)
         p16["a"], p16["a_slots"], p16["a_amax"] = aP, act_slots, a_amax
         ctx.x_slots = x_slots
+        ctx.twin = ops.twin_src_of(x)       # a virtual twin batch (placeholder + (X, bias)): backward re-attaches the tag
         ctx.save_for_backward(x, z, save_all, xP)
         ctx.pre = True
         ctx.training = training
@@ -238,8 +240,17 @@ class ConvBNReLUFn(torch.autograd.Function):
         return a
 
     @staticmethod
+    def _retag_twin(ctx, x):
+        """x as saved by forward; a virtual twin batch gets its (X, bias) tag back should the saved object have lost it."""
+        tw = getattr(ctx, "twin", None)
+        if tw is not None and x is not None and ops.twin_src_of(x) is None:
+            x._onet_twin_src = [tw[0], tw[1], None]
+        return x
+
+    @staticmethod
     def _backward_pre(ctx, da):
         x, z, save_all, xP = ctx.saved_tensors
+        x = ConvBNReLUFn._retag_twin(ctx, x)
         need_x, need_w, need_g, need_b = ctx.needs_input_grad[:4]
         pw, pg, pb = ctx.params
         aff = (ops.grad_slot_if_free(pg) if need_g else None, ops.grad_slot_if_free(pb) if need_b else None)
@@ -256,7 +267,7 @@ class ConvBNReLUFn(torch.autograd.Function):
         nones = (None,) * 13
         if xP is None:
             # fp32 input (the stem): dz in fp32 for the fp32-input kernels; no input gradient path on pre-split operands
-            if need_w and not need_x and x.shape[1] <= 4 and ops.STEM_WGRAD_BN and not ops.is_placeholder(x):
+            if need_w and not need_x and x.shape[1] <= 4 and ops.STEM_WGRAD_BN and (not ops.is_placeholder(x) or ops.twin_src_of(x) is not None):
                 # the stem: dz has one reader, the weight gradient -- formed on load there, never written
                 dw, dgamma, dbeta = ops.stem_wgrad_bn(x, da, z, save_all, ctx.training, ctx.wshape, affine_out=aff, rec4=rec4,
                                                       out=ops.grad_slot_if_free(pw))
@@ -279,6 +290,7 @@ class ConvBNReLUFn(torch.autograd.Function):
         if ctx.pre:
             return ConvBNReLUFn._backward_pre(ctx, da)
         x, z, save_all, x16, nz, nsave = ctx.saved_tensors
+        x = ConvBNReLUFn._retag_twin(ctx, x)
         need_x, need_w, need_g, need_b = ctx.needs_input_grad[:4]
         pw, pg, pb = ctx.params
         aff = (ops.grad_slot_if_free(pg) if need_g else None, ops.grad_slot_if_free(pb) if need_b else None)
@@ -492,11 +504,11 @@ class UpConvTCatFn(torch.autograd.Function):
             assert (Ho, Wo) == (2 * h, 2 * w) and catP.shape[1] * 8 == C2 + Ct and C2 % 8 == 0
             # the GEMM's epilogue writes whole pre-split slots; shapes outside its fast path: fp32 + one conversion pass
             if not ops.convT2x2_fwd_p(x1, wp_fused, bias, catP[:, C2 // 8:], Ct, pt, pl, slots=p16.get("up_slots")):
-                if p16.get("up_slots") is not None:
-                    raise RuntimeError("onet_amd: scaled pre-split ConvTranspose2d output outside the GEMM fast path")
+                # (e.g. an 8 x 8 input map: h w % 128 != 0.)  The conversion pass applies the guard scale of the same slots the
+                # fused epilogue would have used, so the consumer's rescale stays right
                 up = torch.empty((B, Ct, Ho, Wo), dtype=torch.float32, device=x1.device)
                 ops.convT2x2_fwd(x1, wp_fused, bias, up, Ct, pt, pl)
-                ops.split_pack_act(up, out=catP[:, C2 // 8:])
+                ops.split_pack_act(up, out=catP[:, C2 // 8:], slots=p16.get("up_slots"))
             ctx.save_for_backward(x1, wp_dgrad)
             ctx.meta = (C2, Ct, h, w, pt, pl, tuple(weight.shape), bias is not None)
             ctx.params = (weight, bias)
@@ -610,19 +622,20 @@ class TwinInputFn(torch.autograd.Function):
     def forward(ctx, x, bias):
         ops.require_gpu(x)
         x = x.contiguous()
-        B = x.shape[0]
-        xx = torch.empty((2 * B,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
-        xx[:B].copy_(x)
-        ops.complement_clip(x, bias, out=xx[B:])
-        ctx.save_for_backward(xx)
-        return xx
+        ctx.save_for_backward(x)
+        ctx.bias = bias
+        if ops.TWIN_VIRTUAL:
+            # K7 as SURVEY 2 states it: the complement half is formed by the stem kernels while they load X; the 2B-image tensor
+            # exists only if some other reader asks for it (ops.plane materialises it once)
+            return ops.twin_virtual(x, bias)
+        return ops.twin_materialize(src=(x, bias))
 
     @staticmethod
     def backward(ctx, g):
         # only reached when the caller asks for d/dX (never on the training path): plumbing
-        (xx,) = ctx.saved_tensors
-        B = xx.shape[0] // 2
-        y = xx[B:]
+        (x,) = ctx.saved_tensors
+        B = x.shape[0]
+        y = ops.complement_clip(x, ctx.bias)
         return g[:B] - g[B:] * ((y > 0) & (y < 1)).to(g.dtype), None
 
 

@@ -105,6 +105,13 @@ class DoubleConv(nn.Module):
             FusedReLU(),
         )
 
+    def pre_capable(self):
+        """Does forward() take its pre-split branch (the only one that reads or writes pre-split tensors)?  UNet._forward allocates a
+        concat buffer in pre-split form ONLY where both the encoder block that writes its skip groups and the decoder block that
+        reads it answer yes -- a block with a frozen (eval) BatchNorm or without running statistics keeps fp32 tensors."""
+        s = self.double_conv
+        return bool(ops.presplit() and s[1].training and s[4].training and s[1].running_mean is not None)
+
     @staticmethod
     def _unit(x, conv, bn, out=None, groups=1, link_out=None, link_in=None, out16=None, drop_fp32=False, p16=None):
         training = bn.training or (bn.running_mean is None)
@@ -140,14 +147,14 @@ class DoubleConv(nn.Module):
         block's output (the skip groups of a pre-split concat buffer), "keep_fp32": the fp32 tensor is needed too}."""
         s = self.double_conv
         link = {}       # unit 1 -> unit 2: lets unit 2's dgrad launch take unit 1's BatchNorm-backward reduce pass with it
-        if x.dim() == 4 and x.is_cuda and ops.presplit() and s[1].training and s[4].training and s[1].running_mean is not None:
+        if x.dim() == 4 and x.is_cuda and self.pre_capable():
             # pre-split storage: a tensor is written pre-split exactly where ops.pre_layer_ok says its consuming convolution runs
             # all three of its kernels on pre-split operands (the producer of x decided with the same function)
             B, _, H, W = x.shape
             xP = ops.p16_of(x)
             pre2 = ops.pre_layer_ok(B, s[3].in_channels, s[3].out_channels, H, W)
             if xP is not None or pre2 or p16_out is not None:
-                if xP is None and ops.is_placeholder(x):
+                if xP is None and ops.is_placeholder(x) and ops.twin_src_of(x) is None:
                     raise RuntimeError("onet_amd: a tensor kept only pre-split reached a DoubleConv without its pre-split form")
                 p1 = {"x": xP, "x_slots": ops.p16_slots(x), "want": pre2}
                 a1 = self._unit(x, s[0], s[1], None, groups, link_out=link, p16=p1)
@@ -335,11 +342,16 @@ class UNet(nn.Module):
                 C = enc.double_conv[3].out_channels
                 dec = (self.up4, self.up3, self.up2, self.up1)[k].conv.double_conv[0]
                 nxt = (self.down1, self.down2, self.down3, self.down4)[k].maxpool_conv[1].double_conv[0]
+                dec_blk = (self.up4, self.up3, self.up2, self.up1)[k].conv
+                nxt_blk = (self.down1, self.down2, self.down3, self.down4)[k].maxpool_conv[1]
+                # (producer AND consumer must take their pre-split branches: DoubleConv.pre_capable -- a partially frozen network keeps
+                # fp32 tensors at the levels concerned, as it did before pre-split storage)
                 if h % 16 == 0 and w % 16 == 0 and dec.in_channels == 2 * C and ops.pre_layer_ok(B, dec.in_channels, dec.out_channels, h, w) \
-                        and enc.double_conv[4].training:
+                        and enc.pre_capable() and dec_blk.pre_capable():
                     catsP[k] = ops.p16_empty(B, 2 * C, h, w, x.device)
                     cats[k] = None
-                pool_p[k] = h % 2 == 0 and w % 2 == 0 and ops.pre_layer_ok(B, nxt.in_channels, nxt.out_channels, h // 2, w // 2)
+                pool_p[k] = h % 2 == 0 and w % 2 == 0 and ops.pre_layer_ok(B, nxt.in_channels, nxt.out_channels, h // 2, w // 2) \
+                    and nxt_blk.pre_capable()
                 h, w = h // 2, w // 2
 
         def skip(k, C):

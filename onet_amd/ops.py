@@ -189,6 +189,8 @@ def plane(t):
     """-> (tensor, batch_stride) with the (C,H,W) block of every image contiguous.
     Channel-slices of a concat buffer qualify as they are; anything else is copied."""
     B, C, H, W = t.shape
+    if is_placeholder(t) and getattr(t, "_onet_twin_src", None) is not None:
+        t = twin_materialize(t)          # a reader other than the stem kernels: the twin batch as a real tensor
     if is_placeholder(t):
         raise RuntimeError("onet_amd: an fp32 placeholder (bf16 storage: tensor kept in bf16 only) reached a kernel that reads fp32")
     ok = (W == 1 or t.stride(3) == 1) and (H == 1 or t.stride(2) == W) and (C == 1 or t.stride(1) == H * W)
@@ -485,6 +487,40 @@ def fp32_placeholder(shape, device):
     return t
 
 
+TWIN_VIRTUAL = True      # False (tests): TwinInputFn materialises the twin batch, the stem kernels read it like any batch
+
+
+def twin_virtual(x, bias):
+    """The twin batch [X ; clip(1 - X + bias, 0, 1)] (OV:178-180 as one batch of 2B) WITHOUT its tensor: a placeholder of that shape
+    carrying (X, bias).  The stem kernels (forward + statistics, weight gradient) form the complement half while they load X
+    (clip(1 - X + bias) fused into the stem's load); any other reader gets the real tensor from `plane`, which
+    materialises it once (twin_materialize)."""
+    t = fp32_placeholder((2 * x.shape[0],) + tuple(x.shape[1:]), x.device)
+    t._onet_twin_src = [x, float(bias), None]
+    return t
+
+
+def twin_src_of(t):
+    """(X, bias) if `t` is a virtual twin batch whose tensor does not exist, else None."""
+    tag = getattr(t, "_onet_twin_src", None)
+    return None if tag is None else (tag[0], tag[1])
+
+
+def twin_materialize(t=None, src=None):
+    """The real [2B, C, H, W] tensor of a virtual twin batch (made once per forward, cached on the tag)."""
+    tag = getattr(t, "_onet_twin_src", None) if t is not None else None
+    if tag is not None and tag[2] is not None:
+        return tag[2]
+    x, bias = (tag[0], tag[1]) if tag is not None else src
+    B = x.shape[0]
+    xx = torch.empty((2 * B,) + tuple(x.shape[1:]), dtype=F32, device=x.device)
+    xx[:B].copy_(x)
+    complement_clip(x, bias, out=xx[B:])
+    if tag is not None:
+        tag[2] = xx
+    return xx
+
+
 def plane16(t):
     """-> (bf16 tensor, batch stride in elements) if its (C,H,W) block is contiguous per image, else (None, 0)."""
     if t is None:
@@ -645,12 +681,14 @@ def conv3x3_fwd_bn_partials(x, pk, x16=None, norm=None, amax=None):
         nparts = int(_lib.load().onet_conv3x3_stem_nparts(B, Ci, Co, H, W))
         if nparts > 0:
             require_gpu(x)
-            xs, xbs = plane(x)
+            tw = twin_src_of(x)          # virtual twin batch: the kernel reads X and forms the complement half on load (K7)
+            xs, xbs = plane(tw[0] if tw is not None else x)
             w = pk.w if pk.w.is_contiguous() else pk.w.contiguous()
             out = torch.empty((B, Co, H, W), dtype=F32, device=x.device)
             cm = torch.empty((Co, nparts, 3), dtype=F32, device=x.device)
             e0 = _prof_begin("stem_conv_stats_kernel")
-            _lib.call("onet_conv3x3_stem_fwd_stats", _p(xs), xbs, _p(w), _p(out), Co * H * W, _p(cm), B, Ci, Co, H, W, _stream())
+            _lib.call("onet_conv3x3_stem_fwd_stats", _p(xs), xbs, _p(w), _p(out), Co * H * W, _p(cm), B, Ci, Co, H, W,
+                      B // 2 if tw is not None else 0, tw[1] if tw is not None else 0.0, _stream())
             _prof_end("stem_conv_stats_kernel", 2.0 * B * H * W * Ci * Co * 9, e0, 4.0 * (B * H * W * (Ci + Co) + 9 * Ci * Co))
             return out, cm
     algo = conv3x3_algo(B, Ci, Co, H, W)
@@ -973,9 +1011,11 @@ def conv3x3_split(x, wq, Cout, out=None, norm=None, amax=None, always=False):
     return out
 
 
-def split_pack_act(x, f16=True, scale=1.0, out=None, parts=2):
+def split_pack_act(x, f16=True, scale=1.0, out=None, parts=2, slots=None):
     """fp32 NCHW -> the pre-split slot layout of conv_split.hip: [B, C/8, H, 2 (hi | mid), W, 8] fp16 (or bf16) parts of
-    scale * x; 4 bytes per element, the fp32 tensor's footprint.  parts = 1: plain bf16, [B, C/8, H, 1, W, 8]."""
+    scale * x; 4 bytes per element, the fp32 tensor's footprint.  parts = 1: plain bf16, [B, C/8, H, 1, W, 8].
+    slots: the tensor's magnitude slots -- x is additionally scaled by their guard scale (2^0 unless the bound reaches 2^15), which
+    the consumer undoes from the same slots (what the fused producers do)."""
     require_gpu(x)
     x, xbs = plane(x)
     B, C, H, W = x.shape
@@ -983,7 +1023,8 @@ def split_pack_act(x, f16=True, scale=1.0, out=None, parts=2):
         parts = out.shape[3]
     if out is None:
         out = torch.empty((B, C // 8, H, parts, W, 8), dtype=torch.float16 if (f16 and parts == 2) else BF, device=x.device)
-    _lib.call("onet_split_pack_act", _p(x), xbs, _p(out), _pbs(out), B, C, H, W, 2 if parts == 1 else int(f16), float(scale), _stream())
+    _lib.call("onet_split_pack_act", _p(x), xbs, _p(out), _pbs(out), B, C, H, W, 2 if parts == 1 else int(f16), float(scale), _p(slots),
+              _stream())
     return out
 
 
@@ -1188,15 +1229,17 @@ def bn_relu_bwd_split(da, z, save_all, training, need_affine_grads=True, affine_
     return dzP, dz_slots, dgamma, dbeta
 
 
-def stem_wgrad_bn(x, da, z, save_all, training, dw_shape, affine_out=None, rec4=None, out=None):
+def stem_wgrad_bn(x, da, z, save_all, training, dw_shape, affine_out=None, rec4=None, out=None, twin=None):
     """BatchNorm + ReLU backward and weight gradient of the stem unit (Cin <= 4; its input has no gradient, so dz has no other reader):
     reduce + finalize as bn_relu_bwd_groups, then ONE pass over (da, z) that forms dz per element and accumulates dW -- the apply pass
     and its dz tensor are gone.  Same bits as bn_relu_bwd_groups + conv_wgrad.  -> (dw, dgamma, dbeta)."""
     require_gpu(x, da, z)
-    x, xbs = plane(x)
+    if twin is None:
+        twin = twin_src_of(x)            # (X, bias) of a virtual twin batch: x is then only its placeholder
+    B, Cin, H, W = x.shape
+    x, xbs = plane(twin[0] if twin is not None else x)
     da, dabs = plane(da)
     z, zbs = plane(z)
-    B, Cin, H, W = x.shape
     Cout = z.shape[1]
     G = save_all.shape[0]
     coef, dgamma, dbeta = _bn_bwd_groups(da, dabs, z, zbs, save_all, training, affine_out, rec4, None, None)
@@ -1204,7 +1247,7 @@ def stem_wgrad_bn(x, da, z, save_all, training, dw_shape, affine_out=None, rec4=
     ws = workspace(_lib.load().onet_conv_wgrad_ws_bytes(B, Cin, Cout, H, W, 3), x.device)
     e0 = _prof_begin("conv_wgrad_kernel")
     _lib.call("onet_conv3x3_stem_wgrad_bn", _p(x), xbs, _p(da), dabs, _p(z), zbs, _p(save_all), _p(coef), B // G if G > 1 else 0, _p(dw),
-              _p(ws), ws.numel() * 4, B, Cin, Cout, H, W, 0, _stream())
+              _p(ws), ws.numel() * 4, B, Cin, Cout, H, W, 0, B // 2 if twin is not None else 0, twin[1] if twin is not None else 0.0, _stream())
     _prof_end("conv_wgrad_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + 2 * Cout) + 9 * Cin * Cout))
     return dw, dgamma, dbeta
 
@@ -1860,8 +1903,7 @@ def bilinear2x_fwd(x, out, pt, pl):
 def bilinear2x_bwd(dy, h, w, pt, pl):
     dy, dybs = plane(dy)
     B, C, Ho, Wo = dy.shape
-    dx = torch.empty((B, C, h, w), dtype=F32, device=dy.device)
-    fill(dx, 0.0)
+    dx = torch.empty((B, C, h, w), dtype=F32, device=dy.device)      # (gather kernel: every element written, no atomics)
     _lib.call("onet_bilinear2x_bwd", _p(dy), dybs, _p(dx), C * h * w, B, C, h, w, Ho, Wo, pt, pl, _stream())
     return dx
 

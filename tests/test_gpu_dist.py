@@ -51,6 +51,31 @@ def test_bench_two_ranks_sharing_one_gpu_over_gloo(shape):
 
 
 @pytest.mark.timeout(600)
+def test_bench_two_ranks_at_the_configs3_per_gpu_workload():
+    """The step the 8-GPU node will run, rehearsed before it gets there: BASELINE configs[3]'s PER-GPU workload (32 images of
+    1x256x256 per rank) with the DEFAULT bucket schedule (the 124 MB flat gradient in four 32 MB buckets, reduced from the backward
+    hooks), two ranks sharing cuda:0 over gloo.  Asserted: the replicas hold bit-identical parameters after the timed steps
+    (checksums all-gathered by bench.py), every rank's loss is finite and its HBM peak is reported, the with / without-overlap
+    loops ran and `allreduce_exposed_ms` is in the line."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    out = _torchrun(os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 64 and "batch=32/GPU 1x256x256" in d["config"]["workload"]
+    assert d["config"]["grad_allreduce"] == "32 MB buckets overlapped with backward"
+    assert d["replicas_identical"] is True
+    assert len(d["per_rank"]["loss"]) == 2 and all(v == v for v in d["per_rank"]["loss"])
+    assert len(d["per_rank"]["hbm_peak_gb"]) == 2 and all(10 < v < 60 for v in d["per_rank"]["hbm_peak_gb"])
+    assert len(d["per_rank_ms"]) == 2
+    assert {"overlap_ms", "no_overlap_ms", "no_allreduce_ms", "allreduce_exposed_ms", "bucket_mb"} <= set(d["comm"])
+    assert d["comm"]["bucket_mb"] == 32.0
+    assert d["dist_backend"] == "gloo" and d["rccl_world"] == 0        # the rehearsal's backend; the node's line must say nccl / N
+
+
+@pytest.mark.timeout(600)
 def test_two_ranks_syncbn_equals_one_rank():
     """tests/dist_worker.py: replicas bit-identical after 2 steps; 2-rank SyncBN == 1 rank on the concatenated batch
     (ops._gather_partials over a real process group)."""
@@ -84,6 +109,7 @@ def test_bench_one_rank_over_rccl():
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["dist_backend"] == "nccl" and d["rccl_world"] == 1 and d["n_gpus"] == 1
+    assert d["replicas_identical"] is True and len(d["per_rank"]["hbm_peak_gb"]) == 1
     assert "overlapped with backward" in d["config"]["grad_allreduce"]
     assert len(d["per_rank_ms"]) == 1 and d["per_rank_ms"][0] > 0
     assert {"overlap_ms", "no_overlap_ms", "no_allreduce_ms", "allreduce_exposed_ms"} <= set(d["comm"])
@@ -101,6 +127,23 @@ def test_bench_exits_nonzero_on_a_failure_inside_main():
                                   MASTER_PORT=str(_free_port()), ONET_DIST_BACKEND="gloo"))
     assert out.returncode != 0
     assert "WORLD_SIZE=1" in out.stderr
+
+
+@pytest.mark.timeout(600)
+def test_bench_refuses_a_group_that_is_not_rccl_of_the_requested_size():
+    """`--gpus N` must mean N ranks over RCCL: outside the one-GPU rehearsal (ONET_FORCE_LOCAL_RANK) a process group on another
+    backend ends every rank with a non-zero code instead of printing a line that looks like a multi-GPU measurement."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k != "ONET_FORCE_LOCAL_RANK"}
+    env.update(ONET_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "4", "--size", "64",
+           "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-comm-curve"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
+    assert out.returncode != 0
+    assert "not an RCCL run of the requested size" in out.stderr, out.stderr[-2000:]
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
 
 
 @pytest.mark.timeout(600)

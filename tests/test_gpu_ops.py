@@ -479,13 +479,25 @@ def test_stem_conv_fused_bn_statistics(dev, B, Cin, Cout, H, W):
     cm = torch.full((Cout, nparts, 3), float("nan"), device=dev)
     st = torch.cuda.current_stream().cuda_stream
     _lib.call("onet_conv3x3_stem_fwd_stats", xd.data_ptr(), Cin * H * W, wd.data_ptr(), z.data_ptr(), Cout * H * W, cm.data_ptr(),
-              B, Cin, Cout, H, W, st)
+              B, Cin, Cout, H, W, 0, 0.0, st)
     ref = F.conv2d(x.double(), w.double(), None, 1, 1)
     assert float((z.cpu().double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
     z2 = torch.empty_like(z)                                  # convolution only
     _lib.call("onet_conv3x3_stem_fwd_stats", xd.data_ptr(), Cin * H * W, wd.data_ptr(), z2.data_ptr(), Cout * H * W, None,
-              B, Cin, Cout, H, W, st)
+              B, Cin, Cout, H, W, 0, 0.0, st)
     assert torch.equal(z, z2)
+    # K7 on load (round 5): the twin batch [X ; clip(1 - X + bias, 0, 1)] from X alone == the kernel on the materialised twin batch
+    from onet_amd import ops
+    bias = 0.125
+    xx = torch.cat([xd, ops.complement_clip(xd, bias)], 0).contiguous()
+    np2 = int(lib.onet_conv3x3_stem_nparts(2 * B, Cin, Cout, H, W))
+    zt, zm = torch.empty((2 * B, Cout, H, W), device=dev), torch.empty((2 * B, Cout, H, W), device=dev)
+    cmt, cmm = torch.empty((Cout, np2, 3), device=dev), torch.empty((Cout, np2, 3), device=dev)
+    _lib.call("onet_conv3x3_stem_fwd_stats", xd.data_ptr(), Cin * H * W, wd.data_ptr(), zt.data_ptr(), Cout * H * W, cmt.data_ptr(),
+              2 * B, Cin, Cout, H, W, B, bias, st)
+    _lib.call("onet_conv3x3_stem_fwd_stats", xx.data_ptr(), Cin * H * W, wd.data_ptr(), zm.data_ptr(), Cout * H * W, cmm.data_ptr(),
+              2 * B, Cin, Cout, H, W, 0, 0.0, st)
+    assert torch.equal(zt, zm) and torch.equal(cmt, cmm)
     assert torch.isfinite(cm).all()
     assert float(cm[:, :, 0].sum(1).min()) == float(cm[:, :, 0].sum(1).max()) == B * H * W
     gamma = (1 + 0.1 * rnd(Cout, seed=33)).to(dev)
@@ -1189,3 +1201,11 @@ def test_stem_wgrad_with_bn_backward_on_load(dev, B, Cin, H, W, G):
     wr = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
     F.conv2d(x.double().cpu(), wr, None, 1, 1).backward(dz.double().cpu())
     close(dw1, wr.grad, tol=2e-5, what="stem weight gradient")
+    # K7 on load (round 5): x = the first half of a twin batch -- the same bits as the kernel on the materialised twin batch
+    if B % 2 == 0 and G in (1, 2):
+        bias = 0.25
+        xh = x[:B // 2].contiguous()
+        xx = torch.cat([xh, ops.complement_clip(xh, bias)], 0).contiguous()
+        dwm, _, _ = ops.stem_wgrad_bn(xx, da, z, save, True, (Cout, Cin, 3, 3))
+        dwt, _, _ = ops.stem_wgrad_bn(ops.twin_virtual(xh, bias), da, z, save, True, (Cout, Cin, 3, 3))
+        assert torch.equal(dwm, dwt)

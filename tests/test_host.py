@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in protos:
         assert hasattr(lib, name), name
     lib2 = _lib.load()
-    assert lib2.onet_abi_version() == 3
+    assert lib2.onet_abi_version() == 4
     assert lib2.onet_jsd_nparts() > 0
     assert lib2.onet_conv_wgrad_ws_bytes(32, 64, 64, 256, 256, 3) > 0
 

@@ -1,0 +1,110 @@
+"""conv3x3_pre16_kernel (v_mfma_f32_16x16x32, K-packed split operands / 32-channel plain bf16) against fp64 on the same operands:
+forward and input-gradient orientation, statistics epilogue, 16-pixel maps, two-scale concat inputs; then HIP-event timings per
+layer shape for the fp16-split and the plain-bf16 mode.   python tools/pre16_check.py [time]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+from onet_amd import ops, _lib
+dev = torch.device("cuda:0")
+lib = _lib.load()
+rb = lambda t: t.to(torch.bfloat16).double()
+torch.manual_seed(5)
+bad = 0
+for (B, Cin, Cout, H, W) in [(2, 64, 64, 64, 64), (2, 64, 128, 32, 64), (4, 128, 64, 32, 32), (2, 96, 64, 16, 96), (1, 64, 64, 8, 128),
+                             (4, 64, 128, 16, 16), (8, 128, 64, 32, 16), (3, 32, 48, 40, 96), (2, 256, 64, 48, 32)]:
+    x = torch.randn(B, Cin, H, W, device=dev); w = torch.randn(Cout, Cin, 3, 3, device=dev) * (2.0 / (9 * Cin)) ** 0.5
+    zr = F.conv2d(x.double().cpu(), w.double().cpu(), None, 1, 1)
+    sc = float(zr.abs().max())
+    line = f"{B}x{Cin}->{Cout} {H}x{W}:"
+    # fp16 split parts
+    qf, qd = ops.pack3x3_split(w)
+    xP = ops.split_pack_act(x, f16=True)
+    nparts = int(lib.onet_conv3x3_split_pre_nparts(B, H, W))
+    cm = torch.full((Cout, nparts, 3), float("nan"), device=dev) if nparts > 0 else None
+    z = ops.conv3x3_split_pre(xP, qf, Cout, stats=cm)
+    e = float((z.double().cpu() - zr).abs().max()) / sc
+    line += f" f16 {e:.1e}"
+    bad += e > 2e-6
+    z2 = ops.conv3x3_split_pre(xP, qf, Cout)
+    bad += not torch.equal(z, z2)
+    if cm is not None:
+        gamma, beta = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
+        s0 = ops.bn_train_coeffs(z, gamma, beta, None, None, 0.1, 1e-5)
+        s1 = ops.bn_train_coeffs(z, gamma, beta, None, None, 0.1, 1e-5, cm=(cm, 0, nparts))
+        em, ev = float((s0[0] - s1[0]).abs().max()) / float(z.std()), float(((s0[1] - s1[1]) / s0[1]).abs().max())
+        ok = bool(torch.isfinite(cm).all()) and float(cm[:, :, 0].sum(1).min()) == float(cm[:, :, 0].sum(1).max()) == B * H * W
+        line += f" stats {em:.1e}/{ev:.1e}{'' if ok else ' COUNT!'}"
+        bad += (em > 2e-6) + (ev > 1e-5) + (not ok)
+    # input-gradient orientation (fp16 parts of a scaled gradient)
+    g = torch.randn(B, Cout, H, W, device=dev) * 3e-4
+    xg = x.double().cpu().requires_grad_(True)
+    F.conv2d(xg, w.double().cpu(), None, 1, 1).backward(g.double().cpu())
+    sl = ops.absmax_slots(g)
+    # (the producers scale by the slots' rule; here: unscaled parts of a tensor scaled by hand)
+    dx = ops.conv3x3_split_pre(ops.split_pack_act(g * 4096.0, f16=True), qd, Cin) / 4096.0
+    e = float((dx.double().cpu() - xg.grad).abs().max()) / float(xg.grad.abs().max())
+    line += f" dgrad {e:.1e}"
+    bad += e > 2e-6
+    # bf16 split parts
+    with ops.using(ops.Settings(split_f16=False, grad_f16=False, presplit=False)):
+        qb, _ = ops.pack3x3_split(w)
+    assert qb.dtype == torch.bfloat16
+    zb = ops.conv3x3_split_pre(ops.split_pack_act(x, f16=False), qb, Cout)
+    e = float((zb.double().cpu() - zr).abs().max()) / sc
+    line += f" bf16-split {e:.1e}"
+    bad += e > 4e-5
+    # plain bf16 (32-channel chunks)
+    if Cin % 32 == 0 and Cout % 32 == 0:
+        wf, wd = ops.pack3x3_plain16(w)
+        zrb = F.conv2d(rb(x).cpu(), rb(w).cpu(), None, 1, 1)
+        cm2 = torch.full((Cout, nparts, 3), float("nan"), device=dev) if nparts > 0 else None
+        zp = ops.conv3x3_split_pre(ops.split_pack_act(x, parts=1), wf, Cout, stats=cm2)
+        e = float((zp.double().cpu() - zrb).abs().max()) / float(zrb.abs().max())
+        line += f" plain {e:.1e}"
+        bad += e > 2e-6
+        if cm2 is not None:
+            s0 = ops.bn_train_coeffs(zp, gamma, beta, None, None, 0.1, 1e-5)
+            s1 = ops.bn_train_coeffs(zp, gamma, beta, None, None, 0.1, 1e-5, cm=(cm2, 0, nparts))
+            em = float((s0[0] - s1[0]).abs().max()) / float(zp.std())
+            line += f" stats {em:.1e}"
+            bad += em > 2e-6
+    print(line, flush=True)
+# two-scale concat input: channels >= split_ch scaled by another power of two
+B, Cin, Cout, H, W = 2, 128, 64, 32, 64
+x = torch.randn(B, Cin, H, W, device=dev); w = torch.randn(Cout, Cin, 3, 3, device=dev) * 0.03
+x[:, 64:] *= 7e4                                  # second group beyond fp16's range: needs its guard scale
+zr = F.conv2d(x.double().cpu(), w.double().cpu(), None, 1, 1)
+qf, _ = ops.pack3x3_split(w)
+s1, s2 = ops.absmax_slots(x[:, :64].contiguous()), ops.absmax_slots(x[:, 64:].contiguous())
+xP = ops.p16_empty(B, Cin, H, W, dev)
+ops.split_pack_act(x[:, :64].contiguous(), out=xP[:, :8], slots=s1)
+ops.split_pack_act(x[:, 64:].contiguous(), out=xP[:, 8:], slots=s2)
+z = ops.conv3x3_split_pre(xP, qf, Cout, slots=s1, slots2=s2, split_ch=64)
+e = float((z.double().cpu() - zr).abs().max()) / float(zr.abs().max())
+print(f"two-scale concat input: {e:.1e}")
+bad += e > 2e-6
+print("FAILURES:", bad)
+if len(sys.argv) > 1:
+    N = 10
+    def timeit(fn):
+        for _ in range(3): fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(N): fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / N
+    for mode in ("f16", "f16+stats", "plain", "plain+stats"):
+        res = []
+        for ci, co, H, B in [(64, 64, 256, 64), (128, 64, 256, 64), (64, 128, 128, 64), (128, 128, 128, 64), (256, 128, 128, 64), (128, 256, 64, 64), (256, 256, 64, 64), (512, 512, 32, 64), (1024, 1024, 16, 64)]:
+            x = torch.randn(B, ci, H, H, device=dev); w = torch.randn(co, ci, 3, 3, device=dev) * 0.05
+            out = torch.empty(B, co, H, H, device=dev)
+            nparts = int(lib.onet_conv3x3_split_pre_nparts(B, H, H))
+            cm = torch.empty(co, nparts, 3, device=dev) if "stats" in mode else None
+            if mode.startswith("f16"):
+                sf, _ = ops.pack3x3_split(w); xs = ops.split_pack_act(x, f16=True)
+            else:
+                sf, _ = ops.pack3x3_plain16(w); xs = ops.split_pack_act(x, parts=1)
+            res.append(timeit(lambda: ops.conv3x3_split_pre(xs, sf, co, out=out, stats=cm)))
+            del x, out, xs
+        print(os.path.basename(os.environ.get("ONET_HIP_LIB", "default")), mode, " ".join(f"{t:7.4f}" for t in res), f"sum {sum(res):.4f}", flush=True)
