@@ -43,9 +43,13 @@ def pmc_traffic(kernel_prefix, bf16=False, batch=32):
         d = json.load(open(path))
     except Exception:
         return None
+    # bench.py names a kernel FAMILY by the label its Python wrapper times it under; since round 5 a family has two device kernels
+    # (the v_mfma_f32_16x16x32 forms) and the profile's keys are device kernel names
+    prefixes = {"conv3x3_split_pre_kernel": ("conv3x3_split_pre_kernel", "conv3x3_pre16_kernel"),
+                "conv3x3_split_wgrad_pre_kernel": ("conv3x3_split_wgrad_pre_kernel", "conv3x3_wgrad_pre16_kernel")}.get(kernel_prefix, (kernel_prefix,))
     tot_b = tot_n = 0
     for k, v in d.items():
-        if k.startswith(kernel_prefix) and "hbm_bytes_per_launch" in v:
+        if k.startswith(prefixes) and "hbm_bytes_per_launch" in v:
             n = v["FETCH_SIZE"]["launches"]
             tot_b += v["hbm_bytes_per_launch"] * n
             tot_n += n

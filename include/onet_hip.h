@@ -220,8 +220,19 @@ int onet_conv3x3_split_nparts(int B, int H, int W);
 int onet_split_pack_act(const float* x, int64_t x_bs, void* xs, int64_t xs_bs, int B, int C, int H, int W, int f16, float scale,
                         const void* slots /* NULL | magnitude slots: their guard scale (amax_scale, not always) multiplies `scale` */,
                         void* stream);
+/* Round 5 -- input gradient of the SECOND convolution of a DoubleConv (OV:51's backward) from pre-split dz, with the BatchNorm-backward
+ * reduce pass of the FIRST unit (OV:48-49's backward: sum dy, sum dy xhat per channel, dy = da where the unit's output was positive)
+ * taken from the accumulator tile in the epilogue -- this launch's output IS that unit's da.  z_prev / save: the first unit's
+ * pre-activation [B][Cout][H][W] fp32 and coefficients [G][4][Cout] (group_images per statistics group; 0: one group); rec4
+ * [onet_conv3x3_split_pre_nparts(B, H, W)][Cout][4]: records in onet_bn_relu_bwd_reduce's format, ready for onet_bn_bwd_finalize(_bound);
+ * da_amax (may be NULL): magnitude slots that receive max |da|.  Here Cin = channels of dz (the reduction), Cout = channels of da.
+ * Returns 1, nothing launched, where the shape is not taken (maps not made of full 16 x 32 tiles; 16-pixel maps with (hi | mid) parts). */
+int onet_conv3x3_split_dgrad_pre_bnreduce(const void* dzs, int64_t dzs_bs, const void* dz_amax, int scale_always, const void* wq, int wq_f16,
+                                          float* da, int64_t da_bs, const void* z_prev, int z_bf16, int64_t z_bs, const float* save, int group_images,
+                                          float* rec4, void* da_amax, int B, int Cin, int Cout, int H, int W, void* stream);
 int onet_conv3x3_split_fwd_pre(const void* xs, int64_t xs_bs, const void* x_amax, int scale_always, const void* x_amax2, int split_ch,
-                               const void* wq, int wq_f16, float* z, int64_t z_bs, float* part, int B, int Cin, int Cout, int H, int W,
+                               const void* wq, int wq_f16, void* z, int z_bf16 /* 1: z stored as bf16 (plain-bf16 operands only) */, int64_t z_bs,
+                               float* part, int B, int Cin, int Cout, int H, int W,
                                void* stream);
 /* Weight gradient (OV:47,51 backward) from pre-split x and dz (both in the slot layout, same 16-bit type): fragments by the gfx950
  * transposing LDS read, staging by LDS-DMA; the producers' power-of-two scales (x_amax: guard rule, dz_amax: always; NULL:
@@ -384,10 +395,13 @@ int onet_bn_relu_bwd_apply(const float* da, int64_t da_bs, const float* z, int64
  * tensor whose halves are normalised separately (OV:178-179 runs the U-Net twice).  group_images > 0: images g * group_images ..
  * (g + 1) * group_images - 1 of the batch form group g and save / coef are [G][4][C]; 0: one group, save / coef [4][C].  The
  * finalize entry points take `groups`: records of group g follow those of group g - 1 (nparts records each), running statistics and
- * dgamma / dbeta take the groups' contributions in order -- the same bits as one launch per group. */
-int onet_bn_relu_apply_split(const float* z, int64_t z_bs, void* xs, int64_t xs_bs, float* a, int64_t a_bs, const float* save,
+ * dgamma / dbeta take the groups' contributions in order -- the same bits as one launch per group.
+ * ABI 4 -- z_bf16 (the entry points that READ the convolution output z): 0 = z is fp32; 1 = z is stored as bf16 [B][C][H][W] (BASELINE
+ * configs[2], conv == "bf16": onet_conv3x3_split_fwd_pre rounds z once in its epilogue, the statistics come from its fp32
+ * accumulators) -- batch strides stay in ELEMENTS, rows 8-byte aligned; every pass that reads z then moves half the bytes. */
+int onet_bn_relu_apply_split(const void* z, int z_bf16, int64_t z_bs, void* xs, int64_t xs_bs, float* a, int64_t a_bs, const float* save,
                              const void* act_amax, int nparts, int group_images, int B, int C, int H, int W, void* stream);
-int onet_bn_relu_apply_pool_split(const float* z, int64_t z_bs, void* xs, int64_t xs_bs, float* a, int64_t a_bs, void* ys, int64_t ys_bs,
+int onet_bn_relu_apply_pool_split(const void* z, int z_bf16, int64_t z_bs, void* xs, int64_t xs_bs, float* a, int64_t a_bs, void* ys, int64_t ys_bs,
                                   float* y, int64_t y_bs, const float* save, const void* act_amax, int nparts, int group_images, int B, int C,
                                   int H, int W, void* stream);
 /* act_amax (may be NULL: unscaled): the activation's magnitude slots holding the bound |gamma| sqrt(N - 1) + |beta| written by
@@ -400,23 +414,23 @@ int onet_bn_finalize_cm_act(const float* part, int nparts, int64_t c_stride, con
                             float* running_var, float momentum, float eps, float* save, void* act_amax, int groups, int C, void* stream);
 /* (_cm_act: act_amax may be NULL; c_stride >= groups * nparts * 3.  _bwd_reduce_amax: da_amax may be NULL; part2 [nparts][C][4] with
  * nparts a multiple of B: the records of image b's chunks are rows b * chunks .., so a group's records are consecutive rows) */
-int onet_bn_relu_bwd_reduce_amax(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save, float* part2, int nparts,
-                                 void* da_amax, int group_images, int B, int C, int HW, void* stream);
+int onet_bn_relu_bwd_reduce_amax(const float* da, int64_t da_bs, const void* z, int z_bf16, int64_t z_bs, const float* save, float* part2,
+                                 int nparts, void* da_amax, int group_images, int B, int C, int HW, void* stream);
 int onet_bn_bwd_bound(const float* save, const float* coef, const void* da_amax, int64_t count, void* dz_amax, int C, void* stream);
 /* onet_bn_bwd_finalize that also writes the bound of |dz| (as onet_bn_bwd_bound) into dz_amax: da_amax must be complete, i.e. every
  * reduce launch of the tensor precedes the first finalize.  nparts, count: per group; part2 [groups][nparts][C][4], coef [groups][4][C];
  * dz_amax NULL: no bound (plain bf16 operands), then save / da_amax may be NULL too. */
 int onet_bn_bwd_finalize_bound(const float* part2, int nparts, int64_t count, float* dgamma, float* dbeta, float* coef, int accumulate,
                                int groups, int C, const float* save, const void* da_amax, void* dz_amax, void* stream);
-int onet_bn_relu_bwd_apply_split(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save, const float* coef,
+int onet_bn_relu_bwd_apply_split(const float* da, int64_t da_bs, const void* z, int z_bf16, int64_t z_bs, const float* save, const float* coef,
                                  void* dzs, int64_t dzs_bs, const void* dz_amax, int nparts, int group_images, int B, int C, int H, int W,
                                  void* stream);
 /* onet_bn_relu_apply / onet_bn_relu_apply_pool that also record max a (a >= 0) in 64 magnitude slots (zeroed by the caller; the
  * statistics groups of a twin batch share them; the pooled tensor has the same maximum): the overflow guard of the fp16-split
  * convolution that consumes the activation (_apply_amax, _bwd_apply_amax: amax may be NULL; group_images as above).  _pool_amax
  * returns 1 when the shape is not taken (as onet_bn_relu_apply_pool). */
-int onet_bn_relu_apply_amax(const float* z, int64_t z_bs, float* a, int64_t a_bs, const float* save, void* amax, int group_images, int B,
-                            int C, int HW, void* stream);
+int onet_bn_relu_apply_amax(const void* z, int z_bf16, int64_t z_bs, float* a, int64_t a_bs, const float* save, void* amax, int group_images,
+                            int B, int C, int HW, void* stream);
 int onet_bn_relu_apply_pool_amax(const float* z, int64_t z_bs, float* a, int64_t a_bs, float* y, int64_t y_bs, const float* save,
                                  void* amax, int B, int C, int H, int W, void* stream);
 /* ... the same pass, also recording max |dz| in 64 magnitude slots (unsigned[64 * 32], zeroed by the caller; several launches -- the
@@ -451,7 +465,7 @@ int onet_maxpool2_bwd_add_bnreduce(const float* x, int64_t x_bs, const float* dy
 /* ... x may be NULL (pre-split storage: x = relu(bn(z)) is recomputed from z and the coefficients, the same bits); dx_amax: 64
  * magnitude slots that receive max |dx| (dx is the producing layer's activation gradient: onet_bn_bwd_bound). */
 int onet_maxpool2_bwd_add_bnreduce_amax(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, const float* add, int64_t add_bs,
-                                        const float* add2, int64_t add2_bs, float* dx, int64_t dx_bs, const float* z, int64_t z_bs,
+                                        const float* add2, int64_t add2_bs, float* dx, int64_t dx_bs, const void* z, int z_bf16, int64_t z_bs,
                                         const float* save, int group_images, float* part2, void* dx_amax, int B, int C, int H, int W,
                                         void* stream);
 

@@ -220,9 +220,24 @@ __device__ __forceinline__ void amax_commit(float v, unsigned* slots) {
     }
 }
 
+// Round 5, BASELINE configs[2]: the convolution outputs z may be STORED as bf16 (conv == "bf16" with pre-split operands: z is rounded
+// once, to nearest even, by the convolution's epilogue; the BatchNorm statistics still come from the fp32 accumulators) -- every pass
+// that reads z then moves half the bytes.  The kernels below that read z are templates over its element type ZT.
+template <typename ZT> __device__ __forceinline__ float bn_ldz(const ZT* p);
+template <> __device__ __forceinline__ float bn_ldz<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float bn_ldz<__bf16>(const __bf16* p) { return (float)*p; }
+template <typename ZT> __device__ __forceinline__ float4 bn_ldz4(const ZT* p);      // four consecutive elements (16 / 8 byte aligned)
+template <> __device__ __forceinline__ float4 bn_ldz4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 bn_ldz4<__bf16>(const __bf16* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                       __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+}
+
 // a16 (optional): a bf16 copy of the activation for the bf16 conv kernels (bf16 STORAGE of their operands); a may be NULL
 // when only the bf16 copy is wanted
-__global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restrict__ z, int64_t z_bs,
+template <typename ZT = float>
+__global__ __launch_bounds__(256) void bn_relu_apply_kernel(const ZT* __restrict__ z, int64_t z_bs,
                                                             float* __restrict__ a, int64_t a_bs,
                                                             const float* __restrict__ save, int C, int HW,
                                                             int chunks, __bf16* __restrict__ a16 = nullptr,
@@ -233,7 +248,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restr
     const int b = plane / C, c = plane % C;
     if (gimg) save += (int64_t)(b / gimg) * 4 * C;        // statistics groups = consecutive batch slices of gimg images, save [G][4][C]
     const float mean = save[c], sc = save[2 * C + c], sh = save[3 * C + c];
-    const float* src = z + (int64_t)b * z_bs + (int64_t)c * HW;
+    const ZT* src = z + (int64_t)b * z_bs + (int64_t)c * HW;
     float* dst = a ? a + (int64_t)b * a_bs + (int64_t)c * HW : nullptr;
     __bf16* d16 = a16 ? a16 + (int64_t)b * a16_bs + (int64_t)c * HW : nullptr;
     const int beg = ch * 4096, end = min(beg + 4096, HW);
@@ -243,7 +258,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restr
             const int i0 = beg + threadIdx.x * 4;
             float4 q[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) q[k] = *reinterpret_cast<const float4*>(src + i0 + 1024 * k);
+            for (int k = 0; k < 4; ++k) q[k] = bn_ldz4<ZT>(src + i0 + 1024 * k);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 q[k].x = fmaxf(fmaf(q[k].x - mean, sc, sh), 0.f);
@@ -259,7 +274,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restr
         }
 #endif
         for (int i = beg + threadIdx.x * 4; i < end; i += 1024) {
-            float4 q = *reinterpret_cast<const float4*>(src + i);
+            float4 q = bn_ldz4<ZT>(src + i);
             q.x = fmaxf(fmaf(q.x - mean, sc, sh), 0.f);
             q.y = fmaxf(fmaf(q.y - mean, sc, sh), 0.f);
             q.z = fmaxf(fmaf(q.z - mean, sc, sh), 0.f);
@@ -270,7 +285,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restr
         }
     } else {
         for (int i = beg + threadIdx.x; i < end; i += 256) {
-            const float v = fmaxf(fmaf(src[i] - mean, sc, sh), 0.f);
+            const float v = fmaxf(fmaf(bn_ldz<ZT>(src + i) - mean, sc, sh), 0.f);
             if (dst) dst[i] = v;
             if (d16) d16[i] = (__bf16)v;
             vmax = fmaxf(vmax, v);
@@ -452,7 +467,8 @@ __device__ __forceinline__ void bn_store_slots_block(bn_u32x4* lds, unsigned* __
 // every 16-byte slot store lands next to its neighbour lanes' (1 KB contiguous per store instruction).  Measured against the
 // variant with four CONSECUTIVE pixels per thread (float4 loads, slot stores 64 bytes apart between lanes): 0.085 vs 0.108 ms per
 // launch -- the strided 16-byte stores cost more than the narrower loads.
-__global__ __launch_bounds__(256) void bn_relu_apply_split_kernel(const float* __restrict__ z, int64_t z_bs, unsigned* __restrict__ xs,
+template <typename ZT = float>
+__global__ __launch_bounds__(256) void bn_relu_apply_split_kernel(const ZT* __restrict__ z, int64_t z_bs, unsigned* __restrict__ xs,
                                                                   int64_t xs_bs, float* __restrict__ a, int64_t a_bs,
                                                                   const float* __restrict__ save, int C, int H, int W, int bpp, int np,
                                                                   const unsigned* __restrict__ slots, int gimg) {
@@ -468,13 +484,13 @@ __global__ __launch_bounds__(256) void bn_relu_apply_split_kernel(const float* _
         __shared__ bn_u32x4 tr[BN_TR_SLOTS];
         const int HW = H * W, p = (blk * 256 + threadIdx.x) * 4;
         const bool live = p < HW;
-        const float* src = z + (int64_t)b * z_bs + (int64_t)c8 * 8 * HW + p;
+        const ZT* src = z + (int64_t)b * z_bs + (int64_t)c8 * 8 * HW + p;
         float v[4][8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int c = c8 * 8 + k;
             const float mean = save[c], sc = save[2 * C + c], sh = save[3 * C + c];
-            const float4 q = live ? *reinterpret_cast<const float4*>(src + (int64_t)k * HW) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 q = live ? bn_ldz4<ZT>(src + (int64_t)k * HW) : make_float4(0.f, 0.f, 0.f, 0.f);
             v[0][k] = fmaxf(fmaf(q.x - mean, sc, sh), 0.f);
             v[1][k] = fmaxf(fmaf(q.y - mean, sc, sh), 0.f);
             v[2][k] = fmaxf(fmaf(q.z - mean, sc, sh), 0.f);
@@ -490,13 +506,13 @@ __global__ __launch_bounds__(256) void bn_relu_apply_split_kernel(const float* _
     }
 #endif
     const int HW = H * W, lane = threadIdx.x & 63, p0 = blk * 1024 + (threadIdx.x >> 6) * 256 + lane;
-    const float* src = z + (int64_t)b * z_bs + (int64_t)c8 * 8 * HW;
+    const ZT* src = z + (int64_t)b * z_bs + (int64_t)c8 * 8 * HW;
     float v[4][8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int p = p0 + 64 * j;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[j][k] = p < HW ? src[(int64_t)k * HW + p] : 0.f;
+        for (int k = 0; k < 8; ++k) v[j][k] = p < HW ? bn_ldz<ZT>(src + (int64_t)k * HW + p) : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -523,7 +539,8 @@ __global__ __launch_bounds__(256) void bn_relu_apply_split_kernel(const float* _
 
 // ... of an encoder output that is max-pooled next: a thread owns 8 channels of a 2 x 4 pixel patch (W % 4 == 0), writes the activation
 // pre-split (xs: the skip groups of a concat buffer) and / or in fp32 (a), and the two pooled pixels pre-split (ys) or in fp32 (yf)
-__global__ __launch_bounds__(256) void bn_relu_apply_pool_split_kernel(const float* __restrict__ z, int64_t z_bs, unsigned* __restrict__ xs,
+template <typename ZT = float>
+__global__ __launch_bounds__(256) void bn_relu_apply_pool_split_kernel(const ZT* __restrict__ z, int64_t z_bs, unsigned* __restrict__ xs,
                                                                        int64_t xs_bs, float* __restrict__ a, int64_t a_bs,
                                                                        unsigned* __restrict__ ys, int64_t ys_bs, float* __restrict__ yf,
                                                                        int64_t yf_bs, const float* __restrict__ save, int C, int H, int W,
@@ -538,13 +555,13 @@ __global__ __launch_bounds__(256) void bn_relu_apply_pool_split_kernel(const flo
     int yo, q;
     bn_pixel_of(live ? i : 0, W4, yo, q);
     const int64_t in_off = (int64_t)c8 * 8 * HW + (int64_t)(2 * yo) * W + 4 * q;
-    const float* src = z + (int64_t)b * z_bs + in_off;
+    const ZT* src = z + (int64_t)b * z_bs + in_off;
     float v[8][8], m[2][8];                     // [pixel: row 0 cols 0-3, row 1 cols 0-3][channel]; [pooled pixel][channel]
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int c = c8 * 8 + k;
         const float mean = save[c], sc = save[2 * C + c], sh = save[3 * C + c];
-        const float4 r0 = *reinterpret_cast<const float4*>(src + (int64_t)k * HW), r1 = *reinterpret_cast<const float4*>(src + (int64_t)k * HW + W);
+        const float4 r0 = bn_ldz4<ZT>(src + (int64_t)k * HW), r1 = bn_ldz4<ZT>(src + (int64_t)k * HW + W);
         v[0][k] = fmaxf(fmaf(r0.x - mean, sc, sh), 0.f);
         v[1][k] = fmaxf(fmaf(r0.y - mean, sc, sh), 0.f);
         v[2][k] = fmaxf(fmaf(r0.z - mean, sc, sh), 0.f);
@@ -603,7 +620,8 @@ __global__ __launch_bounds__(256) void bn_relu_apply_pool_split_kernel(const flo
 // dz of the BatchNorm + ReLU backward (bn_relu_bwd_apply_kernel's arithmetic: fp64 per element, rounded once) pre-split: fp16 parts
 // of 2^k dz with k = amax_scale(bound) from the magnitude slots (`slots`: an upper bound of |dz| written by bn_bwd_bound_kernel
 // BEFORE this pass; the consumers read the same slots and undo 2^k on their accumulators).  8 channels x 4 pixels per thread.
-__global__ __launch_bounds__(256) void bn_relu_bwd_apply_split_kernel(const float* __restrict__ da, int64_t da_bs, const float* __restrict__ z,
+template <typename ZT = float>
+__global__ __launch_bounds__(256) void bn_relu_bwd_apply_split_kernel(const float* __restrict__ da, int64_t da_bs, const ZT* __restrict__ z,
                                                                       int64_t z_bs, const float* __restrict__ save, const float* __restrict__ coef,
                                                                       unsigned* __restrict__ dzs, int64_t dzs_bs, const unsigned* __restrict__ slots,
                                                                       int C, int H, int W, int bpp, int np, int gimg) {
@@ -618,12 +636,12 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_split_kernel(const floa
     __shared__ bn_u32x4 tr[BN_TR_SLOTS];
     const int HW = H * W, p = (blk * 256 + threadIdx.x) * 4;
     const bool live = p < HW;                     // (HW % 4 == 0: a thread's four pixels are all inside or all outside)
-    const float* zs = z + (int64_t)b * z_bs + (int64_t)c8 * 8 * HW + p;
+    const ZT* zs = z + (int64_t)b * z_bs + (int64_t)c8 * 8 * HW + p;
     const float* ds = da + (int64_t)b * da_bs + (int64_t)c8 * 8 * HW + p;
     float4 zq[8], gq[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {                 // all sixteen 16-byte loads in flight before the first use
-        zq[k] = live ? *reinterpret_cast<const float4*>(zs + (int64_t)k * HW) : make_float4(0.f, 0.f, 0.f, 0.f);
+        zq[k] = live ? bn_ldz4<ZT>(zs + (int64_t)k * HW) : make_float4(0.f, 0.f, 0.f, 0.f);
         gq[k] = live ? *reinterpret_cast<const float4*>(ds + (int64_t)k * HW) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float v[4][8];
@@ -663,8 +681,9 @@ __global__ __launch_bounds__(64) void bn_bwd_bound_kernel(const float* __restric
 // backward pass 1: part2[p][c] = (sum dy, sum dy*xhat), dy = da * [(z-mean)*scale+beta > 0].
 // Sums are taken in fp64 (ATen's CPU kernel accumulates in double): both sums cancel heavily
 // (BN outputs are zero-mean), so fp32 accumulation would cost orders of magnitude of accuracy.
+template <typename ZT = float>
 __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const float* __restrict__ da, int64_t da_bs,
-                                                                 const float* __restrict__ z, int64_t z_bs,
+                                                                 const ZT* __restrict__ z, int64_t z_bs,
                                                                  const float* __restrict__ save,
                                                                  float* __restrict__ part2, int C, int HW,
                                                                  int chunks, int chunk_len, unsigned* __restrict__ amax = nullptr,
@@ -677,7 +696,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const float* __
     if (gimg) save += (int64_t)(b / gimg) * 4 * C;        // statistics groups = consecutive batch slices of gimg images, save [G][4][C]
     const float mean = save[c], invstd = save[C + c], sc = save[2 * C + c], sh = save[3 * C + c];
     const double meand = mean, invd = invstd;
-    const float* zs = z + (int64_t)b * z_bs + (int64_t)c * HW;
+    const ZT* zs = z + (int64_t)b * z_bs + (int64_t)c * HW;
     const float* ds = da + (int64_t)b * da_bs + (int64_t)c * HW;
     const int beg = ch * chunk_len, end = min(beg + chunk_len, HW);
     double v[2] = {0.0, 0.0};
@@ -688,7 +707,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const float* __
             float4 q[4], g[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                q[k] = *reinterpret_cast<const float4*>(zs + i + 1024 * k);
+                q[k] = bn_ldz4<ZT>(zs + i + 1024 * k);
                 g[k] = *reinterpret_cast<const float4*>(ds + i + 1024 * k);
             }
 #pragma unroll
@@ -705,7 +724,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const float* __
         }
 #endif
         for (; i < end; i += 1024) {
-            const float4 q = *reinterpret_cast<const float4*>(zs + i);
+            const float4 q = bn_ldz4<ZT>(zs + i);
             const float4 g = *reinterpret_cast<const float4*>(ds + i);
             const float zz[4] = {q.x, q.y, q.z, q.w}, gg[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
@@ -718,9 +737,10 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const float* __
         }
     } else {
         for (int i = beg + threadIdx.x; i < end; i += 256) {
-            const double dy = fmaf(zs[i] - mean, sc, sh) > 0.f ? (double)ds[i] : 0.0;
+            const float zi = bn_ldz<ZT>(zs + i);
+            const double dy = fmaf(zi - mean, sc, sh) > 0.f ? (double)ds[i] : 0.0;
             v[0] += dy;
-            v[1] += dy * (((double)zs[i] - meand) * invd);
+            v[1] += dy * (((double)zi - meand) * invd);
             vmax = fmaxf(vmax, fabsf(ds[i]));
         }
     }
@@ -974,14 +994,20 @@ int onet_bn_relu_apply(const float* z, int64_t z_bs, float* a, int64_t a_bs, con
     return check_launch("bn_relu_apply_kernel");
 }
 
-int onet_bn_relu_apply_amax(const float* z, int64_t z_bs, float* a, int64_t a_bs, const float* save, void* amax, int group_images, int B,
-                            int C, int HW, void* stream) {
+int onet_bn_relu_apply_amax(const void* z, int z_bf16, int64_t z_bs, float* a, int64_t a_bs, const float* save, void* amax, int group_images,
+                            int B, int C, int HW, void* stream) {
     ONET_REQUIRE(z && a && save && B > 0 && C > 0 && HW > 0 && group_images >= 0, "bn_relu_apply_amax: bad args");
     const int chunks = cdiv(HW, 4096);
     const int64_t blocks = (int64_t)B * C * chunks;
     ONET_REQUIRE(blocks < (1ll << 31), "bn_relu_apply_amax: grid too large");
-    hipLaunchKernelGGL(bn_relu_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), z, z_bs, a, a_bs, save, C, HW,
-                       chunks, (__bf16*)nullptr, (int64_t)0, (unsigned*)amax, group_images);
+    if (z_bf16) {
+        ONET_REQUIRE((reinterpret_cast<uintptr_t>(z) & 7) == 0, "bn_relu_apply_amax: 8-byte aligned bf16 rows required");
+        hipLaunchKernelGGL(bn_relu_apply_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const __bf16*)z, z_bs, a, a_bs,
+                           save, C, HW, chunks, (__bf16*)nullptr, (int64_t)0, (unsigned*)amax, group_images);
+    } else {
+        hipLaunchKernelGGL(bn_relu_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)z, z_bs, a, a_bs,
+                           save, C, HW, chunks, (__bf16*)nullptr, (int64_t)0, (unsigned*)amax, group_images);
+    }
     return check_launch("bn_relu_apply_kernel");
 }
 
@@ -1034,13 +1060,20 @@ int onet_bn_relu_bwd_reduce(const float* da, int64_t da_bs, const float* z, int6
     return check_launch("bn_relu_bwd_reduce_kernel");
 }
 
-int onet_bn_relu_bwd_reduce_amax(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save, float* part2, int nparts,
-                                 void* da_amax, int group_images, int B, int C, int HW, void* stream) {
+int onet_bn_relu_bwd_reduce_amax(const float* da, int64_t da_bs, const void* z, int z_bf16, int64_t z_bs, const float* save, float* part2,
+                                 int nparts, void* da_amax, int group_images, int B, int C, int HW, void* stream) {
     ONET_REQUIRE(da && z && save && part2 && B > 0 && C > 0 && HW > 0 && group_images >= 0, "bn_relu_bwd_reduce_amax: bad args");
     int chunks, chunk_len;
     ONET_REQUIRE(split_plan(nparts, B, HW, chunks, chunk_len), "bn_relu_bwd_reduce_amax: nparts=%d must be a multiple of B=%d", nparts, B);
-    hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3((unsigned)((int64_t)nparts * C)), dim3(256), 0, as_stream(stream), da, da_bs, z, z_bs,
-                       save, part2, C, HW, chunks, chunk_len, (unsigned*)da_amax, group_images);
+    const dim3 grid((unsigned)((int64_t)nparts * C));
+    if (z_bf16) {
+        ONET_REQUIRE((reinterpret_cast<uintptr_t>(z) & 7) == 0, "bn_relu_bwd_reduce_amax: 8-byte aligned bf16 rows required");
+        hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel<__bf16>, grid, dim3(256), 0, as_stream(stream), da, da_bs, (const __bf16*)z, z_bs, save,
+                           part2, C, HW, chunks, chunk_len, (unsigned*)da_amax, group_images);
+    } else {
+        hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel<float>, grid, dim3(256), 0, as_stream(stream), da, da_bs, (const float*)z, z_bs, save,
+                           part2, C, HW, chunks, chunk_len, (unsigned*)da_amax, group_images);
+    }
     return check_launch("bn_relu_bwd_reduce_kernel");
 }
 
@@ -1051,7 +1084,7 @@ int onet_bn_bwd_bound(const float* save, const float* coef, const void* da_amax,
     return check_launch("bn_bwd_bound_kernel");
 }
 
-int onet_bn_relu_apply_split(const float* z, int64_t z_bs, void* xs, int64_t xs_bs, float* a, int64_t a_bs, const float* save,
+int onet_bn_relu_apply_split(const void* z, int z_bf16, int64_t z_bs, void* xs, int64_t xs_bs, float* a, int64_t a_bs, const float* save,
                              const void* act_amax, int nparts, int group_images, int B, int C, int H, int W, void* stream) {
     ONET_REQUIRE(nparts == 1 || nparts == 2, "bn_relu_apply_split: nparts must be 2 (fp16 hi | mid) or 1 (plain bf16)");
     ONET_REQUIRE(z && xs && save && B > 0 && C > 0 && (C % 8) == 0 && H > 0 && W > 0 && (W % 4) == 0, "bn_relu_apply_split: bad args (C %% 8 == 0, W %% 4 == 0)");
@@ -1060,12 +1093,16 @@ int onet_bn_relu_apply_split(const float* z, int64_t z_bs, void* xs, int64_t xs_
     const int bpp = cdiv((int64_t)H * W, 1024);
     const int64_t blocks = (int64_t)B * (C / 8) * bpp;
     ONET_REQUIRE(blocks < (1ll << 31) && (int64_t)H * W < (1 << 24), "bn_relu_apply_split: grid too large");
-    hipLaunchKernelGGL(bn_relu_apply_split_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), z, z_bs, (unsigned*)xs, xs_bs, a,
-                       a_bs, save, C, H, W, bpp, nparts, (const unsigned*)act_amax, group_images);
+    if (z_bf16)
+        hipLaunchKernelGGL(bn_relu_apply_split_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const __bf16*)z, z_bs,
+                           (unsigned*)xs, xs_bs, a, a_bs, save, C, H, W, bpp, nparts, (const unsigned*)act_amax, group_images);
+    else
+        hipLaunchKernelGGL(bn_relu_apply_split_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)z, z_bs,
+                           (unsigned*)xs, xs_bs, a, a_bs, save, C, H, W, bpp, nparts, (const unsigned*)act_amax, group_images);
     return check_launch("bn_relu_apply_split_kernel");
 }
 
-int onet_bn_relu_apply_pool_split(const float* z, int64_t z_bs, void* xs, int64_t xs_bs, float* a, int64_t a_bs, void* ys, int64_t ys_bs,
+int onet_bn_relu_apply_pool_split(const void* z, int z_bf16, int64_t z_bs, void* xs, int64_t xs_bs, float* a, int64_t a_bs, void* ys, int64_t ys_bs,
                                   float* y, int64_t y_bs, const float* save, const void* act_amax, int nparts, int group_images, int B, int C,
                                   int H, int W, void* stream) {
     ONET_REQUIRE(nparts == 1 || nparts == 2, "bn_relu_apply_pool_split: nparts must be 2 (fp16 hi | mid) or 1 (plain bf16)");
@@ -1077,12 +1114,18 @@ int onet_bn_relu_apply_pool_split(const float* z, int64_t z_bs, void* xs, int64_
     const int bpp = cdiv((int64_t)(H / 2) * (W / 4), 256);
     const int64_t blocks = (int64_t)B * (C / 8) * bpp;
     ONET_REQUIRE(blocks < (1ll << 31) && (int64_t)H * W < (1 << 24), "bn_relu_apply_pool_split: grid too large");
-    hipLaunchKernelGGL(bn_relu_apply_pool_split_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), z, z_bs, (unsigned*)xs, xs_bs,
-                       a, a_bs, (unsigned*)ys, ys_bs, y, y_bs, save, C, H, W, bpp, nparts, (const unsigned*)act_amax, group_images);
+    if (z_bf16)
+        hipLaunchKernelGGL(bn_relu_apply_pool_split_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const __bf16*)z, z_bs,
+                           (unsigned*)xs, xs_bs, a, a_bs, (unsigned*)ys, ys_bs, y, y_bs, save, C, H, W, bpp, nparts, (const unsigned*)act_amax,
+                           group_images);
+    else
+        hipLaunchKernelGGL(bn_relu_apply_pool_split_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)z, z_bs,
+                           (unsigned*)xs, xs_bs, a, a_bs, (unsigned*)ys, ys_bs, y, y_bs, save, C, H, W, bpp, nparts, (const unsigned*)act_amax,
+                           group_images);
     return check_launch("bn_relu_apply_pool_split_kernel");
 }
 
-int onet_bn_relu_bwd_apply_split(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save, const float* coef,
+int onet_bn_relu_bwd_apply_split(const float* da, int64_t da_bs, const void* z, int z_bf16, int64_t z_bs, const float* save, const float* coef,
                                  void* dzs, int64_t dzs_bs, const void* dz_amax, int nparts, int group_images, int B, int C, int H, int W,
                                  void* stream) {
     ONET_REQUIRE(nparts == 1 || nparts == 2, "bn_relu_bwd_apply_split: nparts must be 2 (fp16 hi | mid) or 1 (plain bf16)");
@@ -1093,8 +1136,12 @@ int onet_bn_relu_bwd_apply_split(const float* da, int64_t da_bs, const float* z,
     const int bpp = cdiv((int64_t)H * W, 1024);
     const int64_t blocks = (int64_t)B * (C / 8) * bpp;
     ONET_REQUIRE(blocks < (1ll << 31) && (int64_t)H * W < (1 << 24), "bn_relu_bwd_apply_split: grid too large");
-    hipLaunchKernelGGL(bn_relu_bwd_apply_split_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), da, da_bs, z, z_bs, save, coef,
-                       (unsigned*)dzs, dzs_bs, (const unsigned*)dz_amax, C, H, W, bpp, nparts, group_images);
+    if (z_bf16)
+        hipLaunchKernelGGL(bn_relu_bwd_apply_split_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), da, da_bs,
+                           (const __bf16*)z, z_bs, save, coef, (unsigned*)dzs, dzs_bs, (const unsigned*)dz_amax, C, H, W, bpp, nparts, group_images);
+    else
+        hipLaunchKernelGGL(bn_relu_bwd_apply_split_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), da, da_bs,
+                           (const float*)z, z_bs, save, coef, (unsigned*)dzs, dzs_bs, (const unsigned*)dz_amax, C, H, W, bpp, nparts, group_images);
     return check_launch("bn_relu_bwd_apply_split_kernel");
 }
 

@@ -633,6 +633,19 @@ struct SpPreArgs {
     int x_always;
     const unsigned* x_slots2;  // a concat buffer has two producers: channels >= split_ch were scaled by these slots (NULL: unscaled)
     int split_ch;              // 0: one group
+    // RD (conv3x3_pre16_kernel, input-gradient launches): the output z IS the gradient da of the Conv-BatchNorm-ReLU unit below; its
+    // BatchNorm-backward reduce pass rides in the epilogue: rd_z = that unit's pre-activation [B][Cout][H][W] fp32, rd_save its
+    // coefficients [G][4][Cout] (groups of rd_gimg images; 0: one group), rd_rec [tiles][Cout][4] receives (sum dy, 0, sum dy xhat, 0)
+    // per tile (bn_relu_bwd_reduce_kernel's record format), rd_amax (may be NULL) the magnitude slots of da.
+    const float* rd_z = nullptr;
+    int64_t rd_z_bs = 0;
+    const float* rd_save = nullptr;
+    int rd_gimg = 0;
+    float* rd_rec = nullptr;
+    unsigned* rd_amax = nullptr;
+    // conv3x3_pre16_kernel, plain bf16 operands (BASELINE configs[2]): z16 -- the output z is STORED as bf16 (rounded once, to nearest
+    // even; the statistics epilogue still reads the fp32 accumulators), z_bs in elements; rd_z16 -- rd_z is such a bf16 tensor
+    int z16 = 0, rd_z16 = 0;
 };
 
 #ifndef SP_PRE_LAST_TAP
@@ -992,7 +1005,7 @@ __global__ __launch_bounds__(SP_PRE_NW * 64, SP_PRE_NW / 4) void conv3x3_split_p
 //      'S' step, tap (2,2):                 A = [x_mid(row n+2) | same],  B = [w_hi(2,2) | 0]   (27 K16 products are an odd number:
 //    one half instruction per tile and chunk is padding -- 14 steps for 13.5 steps' worth, +3.7 %; the zero half reads the zero padding
 //    behind the halo image).  Lanes pick their K group by address: every fragment is still ONE conflict-free ds_read_b128.
-template <bool ST, int PM, bool W16>
+template <bool ST, int PM, bool W16, bool RD = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_pre16_kernel(SpPreArgs a) {
     constexpr bool F16 = PM == 1;
     using C = SpPreCfg<W16>;
@@ -1261,6 +1274,76 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pre16_kernel(SpPreArgs a) {
             }
             __syncthreads();
         }
+        if constexpr (RD) {
+            // BatchNorm-backward reduce of the unit below (bn_relu_bwd_reduce_kernel's sums) from the tile in registers: dy = da where that
+            // unit's output was positive, (sum dy, sum dy xhat) per channel.  Lane = channel, 16 pixel values: in-lane fp32 sums, the four
+            // lane groups by two shuffles, the eight waves through LDS in fp64 -> one record per tile and channel.  The pass that read
+            // (da, z) -- 8 bytes per element -- becomes a 4-byte read of z here.
+            float* sc = reinterpret_cast<float*>(lds + (buf ^ 1) * BUF);       // [8 waves][64 channels][s, sx]
+            const int img0 = W16 ? 2 * b : b;
+            const float* sv = a.rd_save + (int64_t)(a.rd_gimg ? img0 / a.rd_gimg : 0) * 4 * a.Cout;
+            float vmax = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const int co = co0 + ct * 16 + r16, cc = min(co, a.Cout - 1);
+                const float mean = sv[cc], invstd = sv[a.Cout + cc], scl = sv[2 * a.Cout + cc], sh = sv[3 * a.Cout + cc];
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch) {
+                        const int yo = y0 + wn * NT + n, xo = (W16 ? 0 : x0 + 16 * ch) + 4 * lq;
+                        if (co < a.Cout && yo < a.H && xo < a.W) {
+                            const int64_t zo = (int64_t)(W16 ? img0 + ch : img0) * a.rd_z_bs + (int64_t)co * HW + (int64_t)yo * a.W + xo;
+                            f32x4s zz;
+                            if (a.rd_z16) {
+                                const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const __bf16*>(a.rd_z) + zo);
+                                zz = f32x4s{__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                                            __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u)};
+                            } else {
+                                zz = *reinterpret_cast<const f32x4s*>(a.rd_z + zo);
+                            }
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float da = acc[ct][n][ch][r], d = zz[r] - mean;
+                                const float dy = fmaf(d, scl, sh) > 0.f ? da : 0.f;
+                                s1 += dy;
+                                s2 = fmaf(dy, d * invstd, s2);
+                                vmax = fmaxf(vmax, fabsf(da));
+                            }
+                        }
+                    }
+                s1 += __shfl_xor(s1, 16, 64);
+                s2 += __shfl_xor(s2, 16, 64);
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (lq == 0) {
+                    sc[(wn * 64 + ct * 16 + r16) * 2] = s1;
+                    sc[(wn * 64 + ct * 16 + r16) * 2 + 1] = s2;
+                }
+            }
+            if (a.rd_amax) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+                if (lane == 0 && vmax == vmax) atomicMax(a.rd_amax + ((blockIdx.x * 8 + wn) & (AMAX_SLOTS - 1)) * AMAX_STRIDE, __builtin_bit_cast(unsigned, vmax));
+            }
+            __syncthreads();
+            if (tid < 64 && co0 + tid < a.Cout) {
+                double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) {
+                    t1 += (double)sc[(w * 64 + tid) * 2];
+                    t2 += (double)sc[(w * 64 + tid) * 2 + 1];
+                }
+                const int64_t blk = ((int64_t)b * a.tilesY + ty) * a.tilesX + tx;
+                float* o = a.rd_rec + (blk * a.Cout + co0 + tid) * 4;
+                o[0] = (float)t1;
+                o[1] = (float)(t1 - (double)o[0]);
+                o[2] = (float)t2;
+                o[3] = (float)(t2 - (double)o[2]);
+            }
+            __syncthreads();
+        }
         // A lane holds, per (channel tile, row), channel r16's pixels 4 lq .. + 3 of BOTH 16-pixel tiles: stored as they stand, an
         // instruction would write 64-byte half lines (16 channels x 4 lanes x 16 B).  Lanes r16 >= 8 of the first tile and lanes
         // r16 < 8 of the second trade places (two masked row_ror:8 DPP moves per register) so that each store instruction writes
@@ -1275,18 +1358,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pre16_kernel(SpPreArgs a) {
                 const int yo = y0 + wn * NT + n;
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) {
-                    f32x4s d1, d2;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int va = __builtin_bit_cast(int, acc[ct][n][0][r]), vb = __builtin_bit_cast(int, acc[ct][n][1][r]);
-                        d1[r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(va, vb, 0x128, 0xf, 0xc, false));   // lanes 8-15 <- tile 1 of channel r16 - 8
-                        d2[r] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(vb, va, 0x128, 0xf, 0x3, false));   // lanes 0-7  <- tile 0 of channel r16 + 8
-                    }
+                    const i32x4s va = __builtin_bit_cast(i32x4s, acc[ct][n][0]), vb = __builtin_bit_cast(i32x4s, acc[ct][n][1]);
+                    // d1: lanes 8-15 <- tile 1 of channel r16 - 8;  d2: lanes 0-7 <- tile 0 of channel r16 + 8
+                    const i32x4s e1 = {__builtin_amdgcn_update_dpp(va.x, vb.x, 0x128, 0xf, 0xc, false), __builtin_amdgcn_update_dpp(va.y, vb.y, 0x128, 0xf, 0xc, false),
+                                       __builtin_amdgcn_update_dpp(va.z, vb.z, 0x128, 0xf, 0xc, false), __builtin_amdgcn_update_dpp(va.w, vb.w, 0x128, 0xf, 0xc, false)};
+                    const i32x4s e2 = {__builtin_amdgcn_update_dpp(vb.x, va.x, 0x128, 0xf, 0x3, false), __builtin_amdgcn_update_dpp(vb.y, va.y, 0x128, 0xf, 0x3, false),
+                                       __builtin_amdgcn_update_dpp(vb.z, va.z, 0x128, 0xf, 0x3, false), __builtin_amdgcn_update_dpp(vb.w, va.w, 0x128, 0xf, 0x3, false)};
+                    const f32x4s d1 = __builtin_bit_cast(f32x4s, e1), d2 = __builtin_bit_cast(f32x4s, e2);
                     if (yo < a.H && xo < a.W) {
                         const int co = co0 + ct * 16 + c8;
-                        float* o = zb + (int64_t)co * HW + (int64_t)yo * a.W + xo;
-                        if (co < a.Cout) *reinterpret_cast<f32x4s*>(o) = d1;
-                        if (co + 8 < a.Cout) *reinterpret_cast<f32x4s*>(o + (int64_t)8 * HW) = d2;
+                        const int64_t off = (int64_t)co * HW + (int64_t)yo * a.W + xo;
+                        if (a.z16) {          // z stored as bf16: 8 bytes per lane, 64 contiguous bytes per channel row and instruction
+                            __bf16* o = reinterpret_cast<__bf16*>(a.z) + (int64_t)(W16 ? 2 * b + half : b) * a.z_bs + off;
+                            const bf16x2 p0 = {(__bf16)d1[0], (__bf16)d1[1]}, p1 = {(__bf16)d1[2], (__bf16)d1[3]};
+                            const bf16x2 q0 = {(__bf16)d2[0], (__bf16)d2[1]}, q1 = {(__bf16)d2[2], (__bf16)d2[3]};
+                            if (co < a.Cout) *reinterpret_cast<uint2*>(o) = uint2{__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)};
+                            if (co + 8 < a.Cout) *reinterpret_cast<uint2*>(o + (int64_t)8 * HW) = uint2{__builtin_bit_cast(unsigned, q0), __builtin_bit_cast(unsigned, q1)};
+                        } else {
+                            float* o = zb + off;
+                            if (co < a.Cout) *reinterpret_cast<f32x4s*>(o) = d1;
+                            if (co + 8 < a.Cout) *reinterpret_cast<f32x4s*>(o + (int64_t)8 * HW) = d2;
+                        }
                     }
                 }
             }
@@ -1297,7 +1389,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pre16_kernel(SpPreArgs a) {
 #ifndef SP_PRE16
 #define SP_PRE16 1      // 1: conv3x3_pre16_kernel (v_mfma_f32_16x16x32); 0: conv3x3_split_pre_kernel (32x32x16) -- same-box A/B builds
 #endif
-template <bool ST, int PM, bool W16>
+template <bool ST, int PM, bool W16, bool RD = false>
 int launch_split_pre(SpPreArgs a, hipStream_t st) {
     using C = SpPreCfg<W16>;
     const int LDS_BYTES = C::LDS_BYTES + (ST ? C::NW * 64 * 2 * 4 : 0);
@@ -1307,7 +1399,12 @@ int launch_split_pre(SpPreArgs a, hipStream_t st) {
     if (W16) a.B /= 2;                               // tiles hold image pairs
     const int64_t tiles = (int64_t)a.B * a.tilesX * a.tilesY * a.coTiles;
     ONET_REQUIRE(tiles > 0 && tiles < (1ll << 31), "conv3x3_split_pre: tile count %lld out of range", (long long)tiles);
-    auto kern = (SP_PRE16 && (SP_PRE16 > 1 || PM == 2)) ? conv3x3_pre16_kernel<ST, PM, W16> : conv3x3_split_pre_kernel<ST, PM, W16>;
+    // which launches take the 16x16x32 kernel (profiles/r05_mfma_shape_ab.md): plain bf16 operands (K = 32 channels: no packing) always; the
+    // (hi | mid) forward WITH the statistics epilogue and the input gradients that carry the fused reduce (the lane layout's cheap
+    // epilogues: -5 %); the plain (hi | mid) input gradient keeps the 32x32x16 kernel (equal speed), and so does the (hi | mid) 16-pixel
+    // level (that instance of the new kernel exceeds the register budget).  SP_PRE16 = 2 / 0: everything / nothing (A-B builds).
+    constexpr bool P16 = RD || (SP_PRE16 > 1) || (SP_PRE16 == 1 && (PM == 2 || (ST && !W16)));
+    auto kern = P16 ? conv3x3_pre16_kernel<ST, PM, W16, RD> : conv3x3_split_pre_kernel<ST, PM, W16>;
     static PerDeviceOnce attr_once;
     if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -2369,8 +2466,10 @@ int onet_conv3x3_split_pre_nparts(int B, int H, int W) {
 }
 
 int onet_conv3x3_split_fwd_pre(const void* xs, int64_t xs_bs, const void* x_amax, int scale_always, const void* x_amax2, int split_ch,
-                               const void* wq, int wq_f16, float* z, int64_t z_bs, float* part, int B, int Cin, int Cout, int H, int W,
+                               const void* wq, int wq_f16, void* z, int z_bf16, int64_t z_bs, float* part, int B, int Cin, int Cout, int H, int W,
                                void* stream) {
+    ONET_REQUIRE(!z_bf16 || (wq_f16 == 2 && SP_PRE16 && (z_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(z) & 7) == 0),
+                 "conv3x3_split_fwd_pre: a bf16 output goes with plain bf16 operands (wq_f16 == 2), 8-byte aligned rows");
     ONET_REQUIRE(split_ch >= 0 && split_ch < Cin && (split_ch % 32) == 0, "conv3x3_split_fwd_pre: split_ch must be a multiple of 32 inside Cin");
     ONET_REQUIRE(xs && wq && z, "conv3x3_split_fwd_pre: null pointer");
     ONET_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && (W > 16 || (W == 16 && (B % 2) == 0 && (H % 16) == 0)),
@@ -2380,8 +2479,9 @@ int onet_conv3x3_split_fwd_pre(const void* xs, int64_t xs_bs, const void* x_amax
     ONET_REQUIRE(xs_bs >= (int64_t)Cin * H * W / (wq_f16 == 2 ? 2 : 1) && z_bs >= (int64_t)Cout * H * W, "conv3x3_split_fwd_pre: batch stride too small");
     ONET_REQUIRE((int64_t)(Cin + 32) * H * W * 4 < (1ll << 31) && (int64_t)(Cin + 32) * 2 * 9 * Cout * 2 < (1ll << 31),
                  "conv3x3_split_fwd_pre: operand exceeds the 2 GiB buffer-resource range");
-    SpPreArgs a{xs, xs_bs, (const __bf16*)wq, z, z_bs, B, Cin, Cout, H, W, 0, 0, 0, part, (const unsigned*)x_amax, scale_always,
+    SpPreArgs a{xs, xs_bs, (const __bf16*)wq, (float*)z, z_bs, B, Cin, Cout, H, W, 0, 0, 0, part, (const unsigned*)x_amax, scale_always,
                 (const unsigned*)x_amax2, split_ch};
+    a.z16 = z_bf16 ? 1 : 0;
     if (part) ONET_REQUIRE(onet_conv3x3_split_pre_nparts(B, H, W) > 0, "conv3x3_split_fwd_pre: statistics need a map made of full 16 x 32 tiles");
     hipStream_t st = as_stream(stream);
     if (W == 16) {
@@ -2393,6 +2493,41 @@ int onet_conv3x3_split_fwd_pre(const void* xs, int64_t xs_bs, const void* x_amax
     if (wq_f16 == 2) return part ? launch_split_pre<true, 2, false>(a, st) : launch_split_pre<false, 2, false>(a, st);
     if (wq_f16) return part ? launch_split_pre<true, 1, false>(a, st) : launch_split_pre<false, 1, false>(a, st);
     return part ? launch_split_pre<true, 0, false>(a, st) : launch_split_pre<false, 0, false>(a, st);
+}
+
+// Input gradient of the SECOND convolution of a DoubleConv from pre-split dz, with the BatchNorm-backward reduce pass of the FIRST unit
+// (whose output gradient this launch produces) in the epilogue: see SpPreArgs::rd_*.  Returns 1 (nothing launched) where the map is not
+// made of full tiles.  rec4: [onet_conv3x3_split_pre_nparts(B, H, W)][Cout][4] floats.
+int onet_conv3x3_split_dgrad_pre_bnreduce(const void* dzs, int64_t dzs_bs, const void* dz_amax, int scale_always, const void* wq, int wq_f16,
+                                          float* da, int64_t da_bs, const void* z_prev, int z_bf16, int64_t z_bs, const float* save, int group_images,
+                                          float* rec4, void* da_amax, int B, int Cin, int Cout, int H, int W, void* stream) {
+    ONET_REQUIRE(dzs && wq && da && z_prev && save && rec4, "conv3x3_split_dgrad_pre_bnreduce: null pointer");
+    if (onet_conv3x3_split_pre_nparts(B, H, W) <= 0 || (W != 16 && (W % 32)) || (Cout % 16)) return 1;
+    if (W == 16 && ((group_images % 2) || wq_f16 != 2)) return 1;    // a tile's image pair must lie in one statistics group; (hi | mid)
+                                                                     // parts on 16-pixel maps: not built (register budget of that instance)
+    ONET_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && (Cin % (wq_f16 == 2 ? 32 : 16)) == 0, "conv3x3_split_dgrad_pre_bnreduce: bad shape");
+    ONET_REQUIRE(group_images >= 0 && (group_images == 0 || B % group_images == 0), "conv3x3_split_dgrad_pre_bnreduce: bad statistics groups");
+    ONET_REQUIRE((dzs_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(dzs) & 15) == 0 && (z_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(z_prev) & (z_bf16 ? 7 : 15)) == 0 &&
+                 (da_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(da) & 15) == 0, "conv3x3_split_dgrad_pre_bnreduce: 16-byte aligned rows required");
+    ONET_REQUIRE(dzs_bs >= (int64_t)Cin * H * W / (wq_f16 == 2 ? 2 : 1) && da_bs >= (int64_t)Cout * H * W && z_bs >= (int64_t)Cout * H * W,
+                 "conv3x3_split_dgrad_pre_bnreduce: batch stride too small");
+    ONET_REQUIRE((int64_t)(Cin + 32) * H * W * 4 < (1ll << 31) && (int64_t)(Cin + 32) * 2 * 9 * Cout * 2 < (1ll << 31),
+                 "conv3x3_split_dgrad_pre_bnreduce: operand exceeds the 2 GiB buffer-resource range");
+    SpPreArgs a{dzs, dzs_bs, (const __bf16*)wq, da, da_bs, B, Cin, Cout, H, W, 0, 0, 0, nullptr, (const unsigned*)dz_amax, scale_always, nullptr, 0};
+    a.rd_z = (const float*)z_prev;
+    a.rd_z16 = z_bf16 ? 1 : 0;
+    a.rd_z_bs = z_bs;
+    a.rd_save = save;
+    a.rd_gimg = group_images;
+    a.rd_rec = rec4;
+    a.rd_amax = (unsigned*)da_amax;
+    hipStream_t st = as_stream(stream);
+    if (W == 16) {
+        ONET_REQUIRE(dzs_bs * 4 + (int64_t)Cin * H * W * 4 < (1ll << 31), "conv3x3_split_dgrad_pre_bnreduce: image pair exceeds the buffer-resource range");
+        return launch_split_pre<false, 2, true, true>(a, st);
+    }
+    if (wq_f16 == 2) return launch_split_pre<false, 2, false, true>(a, st);
+    return wq_f16 ? launch_split_pre<false, 1, false, true>(a, st) : launch_split_pre<false, 0, false, true>(a, st);
 }
 
 int onet_conv3x3_split_nparts(int B, int H, int W) { return split_nparts(B, H, W); }

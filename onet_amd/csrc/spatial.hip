@@ -339,12 +339,20 @@ __global__ void axpy_kernel(const float* __restrict__ x, int64_t x_bs, float* __
 // (sum dy, sum dy * xhat) records of bn_relu_bwd_reduce_kernel (bn.hip; same mask expression, fp64 sums, hi/lo float
 // pairs, [image * bands + band][C][4]) can be taken on the way out instead of re-reading dx.  One block per (image,
 // channel, band of rows).
+template <typename ZT> __device__ __forceinline__ float4 pool_ldz4(const ZT* p);      // z may be stored as bf16 (bn.hip: bn_ldz4)
+template <> __device__ __forceinline__ float4 pool_ldz4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 pool_ldz4<__bf16>(const __bf16* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                       __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+}
+template <typename ZT = float>
 __global__ __launch_bounds__(256) void maxpool2_bwd_bn_kernel(const float* __restrict__ x, int64_t x_bs,
                                                               const float* __restrict__ dy, int64_t dy_bs,
                                                               const float* __restrict__ add, int64_t add_bs,
                                                               const float* __restrict__ add2, int64_t add2_bs,
                                                               float* __restrict__ dx, int64_t dx_bs,
-                                                              const float* __restrict__ z, int64_t z_bs,
+                                                              const ZT* __restrict__ z, int64_t z_bs,
                                                               const float* __restrict__ save, int group_images,
                                                               float* __restrict__ part2, int C, int H, int W, int bands,
                                                               int band_rows, unsigned* __restrict__ amax = nullptr) {
@@ -362,8 +370,8 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_bn_kernel(const float* __res
     for (int i = threadIdx.x; i < npatch; i += 256) {
         const int q = i % W4, oy = oy0 + i / W4;
         const int64_t in_off = (int64_t)c * H * W + (int64_t)(2 * oy) * W + 4 * q;
-        const float4 z0 = *reinterpret_cast<const float4*>(z + (int64_t)b * z_bs + in_off);
-        const float4 z1 = *reinterpret_cast<const float4*>(z + (int64_t)b * z_bs + in_off + W);
+        const float4 z0 = pool_ldz4<ZT>(z + (int64_t)b * z_bs + in_off);
+        const float4 z1 = pool_ldz4<ZT>(z + (int64_t)b * z_bs + in_off + W);
         float4 r0, r1;
         if (x) {
             r0 = *reinterpret_cast<const float4*>(x + (int64_t)b * x_bs + in_off);
@@ -510,7 +518,7 @@ int onet_maxpool2_bwd_bn_bands(int H, int W) {
 }
 
 static int maxpool2_bwd_add_bnreduce_impl(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, const float* add, int64_t add_bs,
-                                          const float* add2, int64_t add2_bs, float* dx, int64_t dx_bs, const float* z, int64_t z_bs,
+                                          const float* add2, int64_t add2_bs, float* dx, int64_t dx_bs, const void* z, int z_bf16, int64_t z_bs,
                                           const float* save, int group_images, float* part2, unsigned* amax, int B, int C, int H, int W,
                                           void* stream);
 
@@ -518,20 +526,20 @@ int onet_maxpool2_bwd_add_bnreduce(const float* x, int64_t x_bs, const float* dy
                                    const float* add2, int64_t add2_bs, float* dx, int64_t dx_bs, const float* z, int64_t z_bs,
                                    const float* save, int group_images, float* part2, int B, int C, int H, int W, void* stream) {
     ONET_REQUIRE(x, "maxpool2_bwd_add_bnreduce: bad args");
-    return maxpool2_bwd_add_bnreduce_impl(x, x_bs, dy, dy_bs, add, add_bs, add2, add2_bs, dx, dx_bs, z, z_bs, save, group_images, part2,
+    return maxpool2_bwd_add_bnreduce_impl(x, x_bs, dy, dy_bs, add, add_bs, add2, add2_bs, dx, dx_bs, z, 0, z_bs, save, group_images, part2,
                                           nullptr, B, C, H, W, stream);
 }
 
 int onet_maxpool2_bwd_add_bnreduce_amax(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, const float* add, int64_t add_bs,
-                                        const float* add2, int64_t add2_bs, float* dx, int64_t dx_bs, const float* z, int64_t z_bs,
+                                        const float* add2, int64_t add2_bs, float* dx, int64_t dx_bs, const void* z, int z_bf16, int64_t z_bs,
                                         const float* save, int group_images, float* part2, void* dx_amax, int B, int C, int H, int W,
                                         void* stream) {
-    return maxpool2_bwd_add_bnreduce_impl(x, x_bs, dy, dy_bs, add, add_bs, add2, add2_bs, dx, dx_bs, z, z_bs, save, group_images, part2,
+    return maxpool2_bwd_add_bnreduce_impl(x, x_bs, dy, dy_bs, add, add_bs, add2, add2_bs, dx, dx_bs, z, z_bf16, z_bs, save, group_images, part2,
                                           (unsigned*)dx_amax, B, C, H, W, stream);
 }
 
 static int maxpool2_bwd_add_bnreduce_impl(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, const float* add, int64_t add_bs,
-                                          const float* add2, int64_t add2_bs, float* dx, int64_t dx_bs, const float* z, int64_t z_bs,
+                                          const float* add2, int64_t add2_bs, float* dx, int64_t dx_bs, const void* z, int z_bf16, int64_t z_bs,
                                           const float* save, int group_images, float* part2, unsigned* amax, int B, int C, int H, int W,
                                           void* stream) {
     ONET_REQUIRE(dy && dx && z && save && part2 && B > 0 && C > 0, "maxpool2_bwd_add_bnreduce: bad args");
@@ -546,8 +554,12 @@ static int maxpool2_bwd_add_bnreduce_impl(const float* x, int64_t x_bs, const fl
     pool_bn_plan(H, W, bands, rows);
     const int64_t blocks = (int64_t)B * bands * C;
     ONET_REQUIRE(blocks < (1ll << 31), "maxpool2_bwd_add_bnreduce: grid too large");
-    hipLaunchKernelGGL(maxpool2_bwd_bn_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, x_bs, dy, dy_bs, add,
-                       add_bs, add2, add2_bs, dx, dx_bs, z, z_bs, save, group_images, part2, C, H, W, bands, rows, amax);
+    if (z_bf16)
+        hipLaunchKernelGGL(maxpool2_bwd_bn_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, x_bs, dy, dy_bs, add,
+                           add_bs, add2, add2_bs, dx, dx_bs, (const __bf16*)z, z_bs, save, group_images, part2, C, H, W, bands, rows, amax);
+    else
+        hipLaunchKernelGGL(maxpool2_bwd_bn_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, x_bs, dy, dy_bs, add,
+                           add_bs, add2, add2_bs, dx, dx_bs, (const float*)z, z_bs, save, group_images, part2, C, H, W, bands, rows, amax);
     return check_launch("maxpool2_bwd_bn_kernel");
 }
 

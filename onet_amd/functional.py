@@ -186,7 +186,7 @@ class ConvBNReLUFn(torch.autograd.Function):
             aP = p16.get("out")
             if aP is None:
                 aP = ops.p16_empty(Bz, C, Hz, Wz, z.device)
-        a = torch.empty_like(z) if keep else ops.fp32_placeholder(z.shape, z.device)
+        a = torch.empty(z.shape, dtype=torch.float32, device=z.device) if keep else ops.fp32_placeholder(z.shape, z.device)      # (z may be stored as bf16)
         # magnitude slots: of a pre-split output the BOUND |gamma| sqrt(N - 1) + |beta| (written by the statistics finalize, before
         # the pass that needs it as the guard scale); of an fp32-only output the exact maximum (recorded by the pass that writes
         # it: what bounds a ConvTranspose2d's pre-split output downstream)
@@ -261,9 +261,9 @@ class ConvBNReLUFn(torch.autograd.Function):
             lk.pop("rec", None)
             if rda.data_ptr() != da.data_ptr() or rda.shape != da.shape or rda.stride() != da.stride():
                 rec4 = da_amax = None
+        z_below = save_below = None
         if ctx.link_in is not None:                 # the unit below's (z, save) must not outlive this backward
-            ctx.link_in.pop("z", None)
-            ctx.link_in.pop("save", None)
+            z_below, save_below = ctx.link_in.pop("z", None), ctx.link_in.pop("save", None)
         nones = (None,) * 13
         if xP is None:
             # fp32 input (the stem): dz in fp32 for the fp32-input kernels; no input gradient path on pre-split operands
@@ -282,7 +282,19 @@ class ConvBNReLUFn(torch.autograd.Function):
         dw = ops.conv3x3_split_wgrad_pre(xP, dzP, ctx.wshape, out=ops.grad_slot_if_free(pw), x_slots=s1, dz_slots=dz_slots, x_slots2=s2,
                                          split_ch=sc) if need_w else None
         dpack = ctx.packed.get_pack("split" if dzP.shape[3] == 2 else "plain16")[1]
-        dx = ops.conv3x3_split_pre(dzP, dpack, ctx.wshape[1], slots=dz_slots, always=dz_slots is not None) if need_x else None
+        dx = None
+        if need_x and z_below is not None and save_below is not None and ctx.training:
+            # the unit below's BatchNorm-backward reduce rides in this launch's epilogue (its da IS this dx): the records (and max |da|)
+            # go back through the shared dict, where that unit's backward looks for them
+            fused = ops.conv3x3_split_dgrad_pre_bnreduce(dzP, dpack, ctx.wshape[1], z_below, save_below, slots=dz_slots,
+                                                         always=dz_slots is not None, want_amax=ops.p16_parts() == 2)
+            if fused is not None:
+                dx, rec_below, am_below = fused
+                ctx.link_in["da"], ctx.link_in["rec4"] = dx, rec_below
+                if am_below is not None:
+                    ctx.link_in["da_amax"] = am_below
+        if need_x and dx is None:
+            dx = ops.conv3x3_split_pre(dzP, dpack, ctx.wshape[1], slots=dz_slots, always=dz_slots is not None)
         return (dx, dw, (dgamma if need_g else None), (dbeta if need_b else None)) + nones
 
     @staticmethod

@@ -175,7 +175,7 @@ class DoubleConv(nn.Module):
                           out16=out16)
 
 
-_SKIPPOOL = os.environ.get("ONET_SKIPPOOL", "1") != "0"
+_SKIPPOOL = ops._flag("SKIPPOOL", True)
 
 
 class MaxPool2(nn.MaxPool2d):

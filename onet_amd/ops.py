@@ -14,6 +14,36 @@ F32 = torch.float32
 
 
 # ----------------------------------------------------------------------------- per-model settings
+import os as _os
+
+
+def _flags_from_env():
+    """ONET_FLAGS="NAME=VALUE,NAME=VALUE": diagnostic overrides of the module switches below (the values a fresh process starts with;
+    tests and tools may also set the attributes directly).  The product has three environment switches of its own -- ONET_HIP_LIB
+    (another build of the library), ONET_CONV_ALGO (the default algorithm) and this one; models carry their switches in `Settings`."""
+    out = {}
+    for item in _os.environ.get("ONET_FLAGS", "").split(","):
+        if "=" in item:
+            k, v = item.split("=", 1)
+            out[k.strip()] = v.strip()
+    return out
+
+
+_FLAGS = _flags_from_env()
+
+
+def _flag(name, default):
+    """Process default of switch `name`: ONET_FLAGS' value if given (bool switches: "0" = off; ints and strings as written)."""
+    v = _FLAGS.get(name)
+    if v is None:
+        return default
+    if isinstance(default, bool):
+        return v != "0"
+    if isinstance(default, int):
+        return int(v)
+    return v
+
+
 class Settings:
     """Switches a MODEL carries (`Onet.settings`); a field left at None falls back to the process default (the module
     attribute of the same purpose below, initialised from the environment).  The active record is thread-local: `Onet.forward`
@@ -34,13 +64,15 @@ class Settings:
       split_dgrad   input gradients may take the split kernels (False: diagnostic, fp32-MFMA kernels)             (default SPLIT_DGRAD)
       stem_fused    the stem convolution + its BatchNorm statistics in one streaming pass                          (default STEM_FUSED)
       sync_bn       BatchNorm statistics all-gathered over the process group                                       (default SYNC_BN)
-      presplit      the split kernels' operands are written pre-split (fp16 hi | mid slots) by their producers     (default PRESPLIT)"""
+      presplit      the split kernels' operands are written pre-split (fp16 hi | mid slots) by their producers     (default PRESPLIT)
+      z_bf16        under conv == "bf16" with pre-split operands: the convolution outputs z are STORED as bf16          (default Z_BF16)"""
     __slots__ = ("conv", "twin", "convt_bf16", "bf16_storage", "lazy_nan", "split", "bn_on_load", "split_f16", "grad_f16", "split_dgrad",
-                 "stem_fused", "sync_bn", "presplit")
+                 "stem_fused", "sync_bn", "presplit", "z_bf16")
 
     def __init__(self, conv=None, twin=None, convt_bf16=None, bf16_storage=None, lazy_nan=None, split=None, bn_on_load=None,
-                 split_f16=None, grad_f16=None, split_dgrad=None, stem_fused=None, sync_bn=None, presplit=None):
+                 split_f16=None, grad_f16=None, split_dgrad=None, stem_fused=None, sync_bn=None, presplit=None, z_bf16=None):
         self.presplit = presplit
+        self.z_bf16 = z_bf16
         self.conv, self.twin, self.convt_bf16, self.bf16_storage, self.lazy_nan = conv, twin, convt_bf16, bf16_storage, lazy_nan
         self.split, self.bn_on_load = split, bn_on_load
         self.split_f16, self.grad_f16, self.split_dgrad, self.stem_fused, self.sync_bn = split_f16, grad_f16, split_dgrad, stem_fused, sync_bn
@@ -126,6 +158,17 @@ def presplit():
     if conv_algo() == "bf16":           # BASELINE configs[2]: the same machinery with ONE part of plain bf16 operands (p16_parts() == 1)
         return PRESPLIT_BF16
     return split_enabled() and conv_algo() in ("auto", "split") and split_f16() and split_dgrad()
+
+
+Z_BF16 = _flag("Z_BF16", True)       # BASELINE configs[2] (conv == "bf16", pre-split operands): conv outputs stored as bf16 (Settings.z_bf16)
+
+
+def z16_storage():
+    """Round 5: under conv == "bf16" with pre-split (plain bf16) operands the 3x3 convolutions STORE their output z as bf16 -- rounded
+    once, to nearest even, in the epilogue; the BatchNorm statistics still come from the fp32 accumulators -- and every pass that
+    reads z (normalise + ReLU, both backward passes, the pooling backward) moves half the bytes.  z is an internal tensor: nothing
+    the reference's callers can see changes type."""
+    return conv_algo() == "bf16" and bool(_setting("z_bf16", Z_BF16)) and presplit() and p16_parts() == 1
 
 
 def p16_parts():
@@ -278,7 +321,8 @@ def _prof_end(kind, flops, e0, nbytes=0.0):
 # event, and `check_deferred_nan()` -- called by FlatAdam.step() BEFORE the update is applied, and by the next
 # compute_loss -- raises the same AssertionError without draining the queue.  Default: strict (assert in place).
 import os as _os
-LAZY_NAN_CHECK = _os.environ.get("ONET_LAZY_NAN_CHECK", "0") != "0"
+
+LAZY_NAN_CHECK = _flag("LAZY_NAN_CHECK", False)
 _NAN_PENDING = []
 _NAN_POOL = []
 
@@ -348,7 +392,7 @@ def packT2x2_fused(w):
 
 # BASELINE configs[2]: under the bf16 conv path the ConvTranspose2d GEMMs take bf16 MFMA operands too (what torch.autocast does to
 # nn.ConvTranspose2d); ONET_CONVT_BF16=0 keeps them fp32.  Passed to the library per call (`operand_bf16`).
-CONVT_BF16 = _os.environ.get("ONET_CONVT_BF16", "1") != "0"
+CONVT_BF16 = _flag("CONVT_BF16", True)
 
 
 def convT2x2_fwd(x, wq, bias, out, Ct, pt, pl, out16=None):
@@ -422,14 +466,14 @@ CONV_ALGO = _os.environ.get("ONET_CONV_ALGO", "auto")
 # Weight-shared Onet (dwnu is topu): run the X and the 1-X pass as ONE batch of 2B through every convolution
 # (BatchNorm keeps the two halves as separate statistics groups).  ONET_TWIN=0 runs the two passes one after the
 # other, as the reference does.
-TWIN = _os.environ.get("ONET_TWIN", "1") != "0"
+TWIN = _flag("TWIN", True)
 
 
 # bf16 STORAGE of the conv operands (only with CONV_ALGO == "bf16", BASELINE config 3): the kernels that produce an
 # activation or a pre-activation gradient also write a bf16 copy, and the bf16 conv kernels read that copy instead of rounding
 # the fp32 tensor on the way into LDS -- same rounding (nearest even), so bit-identical results at half the operand bytes.
 # A tensor carries its copy as `t._onet_b16 = (bf16 tensor, t._version)`.  ONET_BF16_STORAGE=0 keeps fp32 operands.
-BF16_STORAGE = _os.environ.get("ONET_BF16_STORAGE", "1") != "0"
+BF16_STORAGE = _flag("BF16_STORAGE", True)
 BF = torch.bfloat16
 
 
@@ -487,7 +531,7 @@ def fp32_placeholder(shape, device):
     return t
 
 
-TWIN_VIRTUAL = True      # False (tests): TwinInputFn materialises the twin batch, the stem kernels read it like any batch
+TWIN_VIRTUAL = _flag("TWIN_VIRTUAL", True)      # False (tests): TwinInputFn materialises the twin batch, the stem kernels read it like any batch
 
 
 def twin_virtual(x, bias):
@@ -519,6 +563,12 @@ def twin_materialize(t=None, src=None):
     if tag is not None:
         tag[2] = xx
     return xx
+
+
+def _z16(z):
+    """1 if the convolution output z is stored as bf16 (BASELINE configs[2] with Settings.z_bf16), else 0 (fp32): what the entry points
+    that read z take as `z_bf16`; batch strides stay in elements."""
+    return int(z.dtype == torch.bfloat16)
 
 
 def plane16(t):
@@ -632,26 +682,26 @@ def conv3x3_auto(x, pk, direction, out=None, x16=None, amax=None):
     return conv_fwd(x, wq, Co, 3, out=out)
 
 
-FUSE_BN_STATS = _os.environ.get("ONET_FUSE_BN_STATS", "1") != "0"
-BN_ON_LOAD = _os.environ.get("ONET_BN_ON_LOAD", "1") != "0"        # 0: every BatchNorm + ReLU output is materialised
-BN_ON_LOAD_MAX_COUT = int(_os.environ.get("ONET_BN_ON_LOAD_MAX_COUT", "128"))
-CONVT_SPLIT_MIN_BLOCKS = int(_os.environ["ONET_CONVT_SPLIT_MIN_BLOCKS"]) if "ONET_CONVT_SPLIT_MIN_BLOCKS" in _os.environ else None
-CONVT_SPLIT = _os.environ.get("ONET_CONVT_SPLIT", "1") != "0"     # 0: the ConvTranspose2d GEMMs stay on the fp32 MFMA pipe
-SPLIT_F16 = _os.environ.get("ONET_SPLIT_F16", "1") != "0"         # 0: the forward split kernel takes bf16 parts like the gradients
-SPLIT_DGRAD = _os.environ.get("ONET_SPLIT_DGRAD", "1") != "0"     # 0 (diagnostic): input gradients stay on the fp32-MFMA kernels
-PRESPLIT = _os.environ.get("ONET_PRESPLIT", "1") != "0"           # 1: pre-split operand storage (Settings.presplit)
-PRESPLIT_BF16 = _os.environ.get("ONET_PRESPLIT_BF16", "1") != "0"  # ... also under conv == "bf16" (0: round 3's bf16 kernels + bf16 storage)
-PRESPLIT_W16 = _os.environ.get("ONET_PRESPLIT_W16", "1") != "0"    # ... also the 16-pixel level (0: fp32 Winograd F(4x4) there, as in round 3)
+FUSE_BN_STATS = _flag("FUSE_BN_STATS", True)
+BN_ON_LOAD = _flag("BN_ON_LOAD", True)        # 0: every BatchNorm + ReLU output is materialised
+BN_ON_LOAD_MAX_COUT = _flag("BN_ON_LOAD_MAX_COUT", 128)
+CONVT_SPLIT_MIN_BLOCKS = (int(_FLAGS["CONVT_SPLIT_MIN_BLOCKS"]) if "CONVT_SPLIT_MIN_BLOCKS" in _FLAGS else None)
+CONVT_SPLIT = _flag("CONVT_SPLIT", True)     # 0: the ConvTranspose2d GEMMs stay on the fp32 MFMA pipe
+SPLIT_F16 = _flag("SPLIT_F16", True)         # 0: the forward split kernel takes bf16 parts like the gradients
+SPLIT_DGRAD = _flag("SPLIT_DGRAD", True)     # 0 (diagnostic): input gradients stay on the fp32-MFMA kernels
+PRESPLIT = _flag("PRESPLIT", True)           # 1: pre-split operand storage (Settings.presplit)
+PRESPLIT_BF16 = _flag("PRESPLIT_BF16", True)  # ... also under conv == "bf16" (0: round 3's bf16 kernels + bf16 storage)
+PRESPLIT_W16 = _flag("PRESPLIT_W16", True)    # ... also the 16-pixel level (0: fp32 Winograd F(4x4) there, as in round 3)
 # diagnostic / tests: every activation written pre-split ALSO leaves its fp32 tensor (same values: the parts are split from them), so
 # that a harness can read each unit's output; the kernels that consume the pre-split forms are unchanged
-PRESPLIT_KEEP_FP32 = _os.environ.get("ONET_PRESPLIT_KEEP_FP32", "0") != "0"
+PRESPLIT_KEEP_FP32 = _flag("PRESPLIT_KEEP_FP32", False)
 # 1: split input / weight gradients on fp16 parts of power-of-two-scaled operands (22-bit operands; 15x lower per-layer error than
 # the bf16 parts, but no change in the model-level worst gradient error -- 9.4e-5 either way on b4_c1_256 -- and +1.3 ms/step: the
 # fp16 MFMAs hold a lower clock); default 0: bf16 parts, as in round 3
-SPLIT_GRAD_F16 = _os.environ.get("ONET_SPLIT_GRAD_F16", "0") != "0"
-SPLIT_WGRAD_MINW = int(_os.environ.get("ONET_SPLIT_WGRAD_MINW", "16"))   # 64: the 32- and 16-pixel levels keep the Winograd weight gradients
-SPLIT_AUTO = _os.environ.get("ONET_SPLIT", "1") != "0"          # 0: "auto" never selects the split-bf16 kernel (round-2 dispatch)
-STEM_FUSED = _os.environ.get("ONET_STEM_FUSED", "1") != "0"      # 0: the stem takes the direct MFMA kernel + a statistics pass
+SPLIT_GRAD_F16 = _flag("SPLIT_GRAD_F16", False)
+SPLIT_WGRAD_MINW = _flag("SPLIT_WGRAD_MINW", 16)   # 64: the 32- and 16-pixel levels keep the Winograd weight gradients
+SPLIT_AUTO = _flag("SPLIT", True)          # 0: "auto" never selects the split-bf16 kernel (round-2 dispatch)
+STEM_FUSED = _flag("STEM_FUSED", True)      # 0: the stem takes the direct MFMA kernel + a statistics pass
 
 
 def conv3x3_fwd_bn_partials(x, pk, x16=None, norm=None, amax=None):
@@ -746,7 +796,7 @@ def conv3x3_fwd_bn_partials(x, pk, x16=None, norm=None, amax=None):
     return out, cm
 
 
-FUSE_BN_REDUCE = _os.environ.get("ONET_FUSE_BN_REDUCE", "1") != "0"
+FUSE_BN_REDUCE = _flag("FUSE_BN_REDUCE", True)
 
 
 def conv3x3_dgrad_bnreduce(dz, pk, z_prev, save_prev):
@@ -899,7 +949,7 @@ def pack3x3_split(w):
     return wf, wd
 
 
-COUNT_FOREACH = _os.environ.get("ONET_COUNT_FOREACH", "1") != "0"    # 0 (diagnostic): one add_ launch per BatchNorm counter
+COUNT_FOREACH = _flag("COUNT_FOREACH", True)    # 0 (diagnostic): one add_ launch per BatchNorm counter
 
 
 class counting_batches:
@@ -1028,7 +1078,7 @@ def split_pack_act(x, f16=True, scale=1.0, out=None, parts=2, slots=None):
     return out
 
 
-def conv3x3_split_pre(xs, wq, Cout, out=None, slots=None, always=False, stats=None, slots2=None, split_ch=0):
+def conv3x3_split_pre(xs, wq, Cout, out=None, slots=None, always=False, stats=None, slots2=None, split_ch=0, z16=False):
     """z = conv3x3 of a PRE-SPLIT activation xs [B, Cin/8, H, 2, W, 8] (split_pack_act / the producers' fused variants) with the split
     weight pack wq: the arithmetic of conv3x3_split, staging by LDS-DMA.  slots / always: the magnitude slots and rule the producer
     scaled xs by (undone by the kernel; None: unscaled)."""
@@ -1037,15 +1087,49 @@ def conv3x3_split_pre(xs, wq, Cout, out=None, slots=None, always=False, stats=No
     B, C8, H, two, W, eight = xs.shape
     f16 = 2 if two == 1 else int(wq.dtype == torch.float16)            # 2: plain bf16, one part
     Cin = C8 * 8
-    if out is None:
-        out = torch.empty((B, Cout, H, W), dtype=F32, device=xs.device)
+    if out is None:           # z16 (plain bf16 operands only): the output is stored as bf16, rounded once in the epilogue
+        out = torch.empty((B, Cout, H, W), dtype=BF if (z16 and two == 1) else F32, device=xs.device)
     e0 = _prof_begin("conv3x3_split_pre_kernel")
     _lib.call("onet_conv3x3_split_fwd_pre", _p(xs), _pbs(xs), _p(slots), int(always), _p(slots2), int(split_ch if slots2 is not None or slots is not None else 0),
-              _p(wq), f16, _p(out),
+              _p(wq), f16, _p(out), _z16(out),
               out.stride(0) if B > 1 else Cout * H * W, _p(stats), B, Cin, Cout, H, W, _stream())
     _prof_end("conv3x3_split_pre_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0,
-              B * H * W * (2.0 * two * Cin + 4.0 * Cout) + 2.0 * two * 9 * Cin * Cout)
+              B * H * W * (2.0 * two * Cin + out.element_size() * Cout) + 2.0 * two * 9 * Cin * Cout)
     return out
+
+
+def conv3x3_split_dgrad_pre_bnreduce(dzP, wq, Cout, z_prev, save_prev, slots=None, always=False, want_amax=False):
+    """da = input gradient of a DoubleConv's second convolution from pre-split dz (conv3x3_split_pre's arithmetic) with the
+    BatchNorm-backward REDUCE of the first unit -- whose output gradient da is -- in the kernel's epilogue: -> (da, rec4, da_amax | None),
+    or None where the kernel does not take the shape.  z_prev / save_prev [G, 4, Cout]: the first unit's pre-activation and coefficients
+    (G statistics groups = consecutive batch slices).  rec4 [nparts, Cout, 4] is bn_relu_bwd_reduce's record format (_bn_bwd_groups)."""
+    if not FUSE_BN_REDUCE or sync_bn() or not FUSE_DGRAD_REDUCE:
+        return None
+    B, C8, H, two, W, _ = dzP.shape
+    Cin = C8 * 8
+    G = save_prev.shape[0]
+    if tuple(z_prev.shape) != (B, Cout, H, W) or B % G or not save_prev.is_contiguous() or wq.dtype != dzP.dtype:
+        return None
+    lib = _lib.load()
+    nparts = int(lib.onet_conv3x3_split_pre_nparts(B, H, W))
+    z_prev, zbs = plane(z_prev)
+    if nparts <= 0 or nparts % G or (zbs & 3) or (z_prev.data_ptr() & 15):
+        return None
+    f16 = 2 if two == 1 else int(wq.dtype == torch.float16)
+    da = torch.empty((B, Cout, H, W), dtype=F32, device=dzP.device)
+    rec4 = torch.empty((nparts, Cout, 4), dtype=F32, device=dzP.device)
+    am = new_amax(dzP.device) if want_amax else None
+    e0 = _prof_begin("conv3x3_split_pre_kernel")
+    rc = lib.onet_conv3x3_split_dgrad_pre_bnreduce(_p(dzP), _pbs(dzP), _p(slots), int(always), _p(wq), f16, _p(da), Cout * H * W, _p(z_prev), _z16(z_prev), zbs,
+                                                   _p(save_prev), B // G if G > 1 else 0, _p(rec4), _p(am), B, Cin, Cout, H, W, _stream())
+    _prof_end("conv3x3_split_pre_kernel", 2.0 * B * H * W * Cin * Cout * 9 if rc == 0 else 0.0, e0,
+              (B * H * W * (2.0 * two * Cin + (4.0 + z_prev.element_size()) * Cout) + 2.0 * two * 9 * Cin * Cout) if rc == 0 else 0.0)
+    if rc < 0:
+        raise _lib.OnetHipError(f"onet_conv3x3_split_dgrad_pre_bnreduce failed ({rc}): {_lib.last_error()}")
+    return (da, rec4, am) if rc == 0 else None
+
+
+FUSE_DGRAD_REDUCE = _flag("FUSE_DGRAD_REDUCE", True)      # False (tests / A-B): the first unit of a DoubleConv runs its own BatchNorm-backward reduce pass
 
 
 def conv3x3_split_wgrad_pre(xs, dzs, dw_shape, out=None, x_slots=None, dz_slots=None, x_slots2=None, split_ch=0):
@@ -1144,9 +1228,9 @@ def bn_relu_apply_split(z, save, xs, a=None, slots=None, group_images=0):
     z, zbs = plane(z)
     B, C, H, W = z.shape
     assert group_images == 0 or (B % group_images == 0 and save.numel() == (B // group_images) * 4 * C and save.is_contiguous())
-    _lib.call("onet_bn_relu_apply_split", _p(z), zbs, _p(xs), _pbs(xs), _p(a), 0 if a is None else (a.stride(0) if B > 1 else C * H * W),
+    _lib.call("onet_bn_relu_apply_split", _p(z), _z16(z), zbs, _p(xs), _pbs(xs), _p(a), 0 if a is None else (a.stride(0) if B > 1 else C * H * W),
               _p(save), _p(slots), xs.shape[3], group_images, B, C, H, W, _stream(),
-              nbytes=(4 + 2 * xs.shape[3] + 4 * (a is not None)) * z.numel())
+              nbytes=(z.element_size() + 2 * xs.shape[3] + 4 * (a is not None)) * z.numel())
 
 
 def bn_relu_apply_pool_split(z, save, xs, a, ys, y, slots=None, group_images=0):
@@ -1156,7 +1240,7 @@ def bn_relu_apply_pool_split(z, save, xs, a, ys, y, slots=None, group_images=0):
     B, C, H, W = z.shape
     assert group_images == 0 or (B % group_images == 0 and save.numel() == (B // group_images) * 4 * C and save.is_contiguous())
     n, m = C * H * W, C * (H // 2) * (W // 2)
-    rc = _lib.load().onet_bn_relu_apply_pool_split(_p(z), zbs, _p(xs), 0 if xs is None else _pbs(xs), _p(a),
+    rc = _lib.load().onet_bn_relu_apply_pool_split(_p(z), _z16(z), zbs, _p(xs), 0 if xs is None else _pbs(xs), _p(a),
                                                   0 if a is None else (a.stride(0) if B > 1 else n), _p(ys), 0 if ys is None else _pbs(ys),
                                                   _p(y), 0 if y is None else (y.stride(0) if B > 1 else m), _p(save), _p(slots),
                                                   (xs if xs is not None else ys).shape[3] if (xs is not None or ys is not None) else 2,
@@ -1175,7 +1259,8 @@ def conv3x3_pre_bn_partials(xP, pk, slots=None):
     nparts = int(_lib.load().onet_conv3x3_split_pre_nparts(B, H, W))
     cm = torch.empty((Co, nparts, 3), dtype=F32, device=xP.device) if nparts > 0 else None
     s1, s2, sc = _slots3(slots)
-    return conv3x3_split_pre(xP, wq, Co, slots=s1, stats=cm, slots2=s2, split_ch=sc), cm
+    # (z stored as bf16 only where the statistics come from the epilogue: a separate statistics pass would read the rounded values)
+    return conv3x3_split_pre(xP, wq, Co, slots=s1, stats=cm, slots2=s2, split_ch=sc, z16=cm is not None and np_ == 1 and z16_storage()), cm
 
 
 def _bn_bwd_groups(da, dabs, z, zbs, save_all, training, affine_out, rec4, da_amax, dz_slots):
@@ -1191,8 +1276,8 @@ def _bn_bwd_groups(da, dabs, z, zbs, save_all, training, affine_out, rec4, da_am
     if rec4 is None:
         nparts = _bn_nparts(Bg, HW)
         rec4 = torch.empty((G * nparts, C, 4), dtype=F32, device=dev)
-        _lib.call("onet_bn_relu_bwd_reduce_amax", _p(da), dabs, _p(z), zbs, _p(save_all), _p(rec4), G * nparts, _p(da_amax), Bg if G > 1 else 0,
-                  B, C, HW, _stream(), nbytes=8 * z.numel())
+        _lib.call("onet_bn_relu_bwd_reduce_amax", _p(da), dabs, _p(z), _z16(z), zbs, _p(save_all), _p(rec4), G * nparts, _p(da_amax), Bg if G > 1 else 0,
+                  B, C, HW, _stream(), nbytes=(4 + z.element_size()) * z.numel())
     else:
         assert rec4.shape[0] % G == 0 and rec4.shape[1] == C and rec4.shape[2] == 4 and rec4.is_contiguous()
     og, ob = affine_out if affine_out is not None else (None, None)
@@ -1224,8 +1309,8 @@ def bn_relu_bwd_split(da, z, save_all, training, need_affine_grads=True, affine_
     if rec4 is None:
         da_amax = new_amax(dev) if scaled else None
     coef, dgamma, dbeta = _bn_bwd_groups(da, dabs, z, zbs, save_all, training, affine_out, rec4, da_amax, dz_slots)
-    _lib.call("onet_bn_relu_bwd_apply_split", _p(da), dabs, _p(z), zbs, _p(save_all), _p(coef), _p(dzP), _pbs(dzP), _p(dz_slots), np_,
-              B // G if G > 1 else 0, B, C, H, W, _stream(), nbytes=(8 + 2 * np_) * z.numel())
+    _lib.call("onet_bn_relu_bwd_apply_split", _p(da), dabs, _p(z), _z16(z), zbs, _p(save_all), _p(coef), _p(dzP), _pbs(dzP), _p(dz_slots), np_,
+              B // G if G > 1 else 0, B, C, H, W, _stream(), nbytes=(4 + z.element_size() + 2 * np_) * z.numel())
     return dzP, dz_slots, dgamma, dbeta
 
 
@@ -1252,7 +1337,7 @@ def stem_wgrad_bn(x, da, z, save_all, training, dw_shape, affine_out=None, rec4=
     return dw, dgamma, dbeta
 
 
-STEM_WGRAD_BN = _os.environ.get("ONET_STEM_WGRAD_BN", "1") != "0"     # 0 (diagnostic): the stem's dz is materialised by the apply pass
+STEM_WGRAD_BN = _flag("STEM_WGRAD_BN", True)     # 0 (diagnostic): the stem's dz is materialised by the apply pass
 
 
 def bn_relu_bwd_groups(da, z, save_all, training, affine_out=None, rec4=None):
@@ -1393,7 +1478,7 @@ def conv3x3_winograd4_wgrad(x, dz, dw_shape, out=None):
 # up3.c1 of the 256x256 U-Net: 224-298 TF against 205-238); below that its one-unit prefetch does not cover HBM latency
 # (64-channel layers: 130 TF against 200) or it only ties (128 -> 128).
 # "1": wherever legal; "0": never.
-WGRAD4 = _os.environ.get("ONET_WGRAD4", "auto")
+WGRAD4 = _flag("WGRAD4", "auto")
 
 
 def winograd4_wgrad_ok(x, dz):
@@ -1593,11 +1678,11 @@ def bn_relu_apply(z, save, out=None, out16=None, no_fp32=False, amax=None, group
     z, zbs = plane(z)
     B, C, H, W = z.shape
     assert group_images == 0 or (out16 is None and B % group_images == 0 and save.numel() == (B // group_images) * 4 * C and save.is_contiguous())
-    if (amax is not None or group_images) and out16 is None:
+    if (amax is not None or group_images or _z16(z)) and out16 is None:
         if out is None:
             out = torch.empty((B, C, H, W), dtype=F32, device=z.device)
-        _lib.call("onet_bn_relu_apply_amax", _p(z), zbs, _p(out), out.stride(0) if B > 1 else C * H * W, _p(save), _p(amax), group_images,
-                  B, C, H * W, _stream(), nbytes=8 * z.numel())
+        _lib.call("onet_bn_relu_apply_amax", _p(z), _z16(z), zbs, _p(out), out.stride(0) if B > 1 else C * H * W, _p(save), _p(amax), group_images,
+                  B, C, H * W, _stream(), nbytes=(4 + z.element_size()) * z.numel())
         return out
     if out16 is not None and no_fp32:
         o16bs = out16.stride(0) if B > 1 else C * H * W
@@ -1616,7 +1701,7 @@ def bn_relu_apply(z, save, out=None, out16=None, no_fp32=False, amax=None, group
     return out
 
 
-FUSE_POOL = _os.environ.get("ONET_FUSE_POOL", "1") != "0"       # 0: separate max-pool pass after BatchNorm + ReLU
+FUSE_POOL = _flag("FUSE_POOL", True)       # 0: separate max-pool pass after BatchNorm + ReLU
 
 
 def bn_relu_apply_pool(z, save, out, out16, y, y16, amax=None):
@@ -1674,7 +1759,7 @@ def bn_bwd_coefs(da, z, save, training, need_affine_grads=True, acc=None, affine
         else:
             part2 = torch.empty((nparts, C, 4), dtype=F32, device=dev)
             if da_amax is not None:
-                _lib.call("onet_bn_relu_bwd_reduce_amax", _p(da), dabs, _p(z), zbs, _p(save), _p(part2), nparts, _p(da_amax), 0, B, C, HW,
+                _lib.call("onet_bn_relu_bwd_reduce_amax", _p(da), dabs, _p(z), _z16(z), zbs, _p(save), _p(part2), nparts, _p(da_amax), 0, B, C, HW,
                           _stream(), nbytes=8 * z.numel())
             else:
                 _lib.call("onet_bn_relu_bwd_reduce", _p(da), dabs, _p(z), zbs, _p(save), _p(part2), nparts, B, C, HW, _stream(),
@@ -1779,14 +1864,14 @@ def maxpool2_bwd(x, dy, add=None, add2=None, bn=None, dx_amax=None):
         bands = int(_lib.load().onet_maxpool2_bwd_bn_bands(H, W)) if (FUSE_BN_REDUCE and not sync_bn()) else 0
         z, zbs = plane(z)
         G = save_all.shape[0]
-        aligned = all(t is None or (t.data_ptr() & 15) == 0 for t in (x, z, a1, a2)) and (dy.data_ptr() & 7) == 0 and \
-            all((v & 3) == 0 for v in (xbs, zbs, a1bs, a2bs)) and (dybs & 1) == 0
+        aligned = all(t is None or (t.data_ptr() & 15) == 0 for t in (x, a1, a2)) and (z.data_ptr() & (7 if _z16(z) else 15)) == 0 and \
+            (dy.data_ptr() & 7) == 0 and all((v & 3) == 0 for v in (xbs, zbs, a1bs, a2bs)) and (dybs & 1) == 0
         if bands > 0 and aligned and B % G == 0 and tuple(z.shape) == (B, C, H, W) and save_all.is_contiguous():
             part2 = torch.empty((B * bands, C, 4), dtype=F32, device=dy.device)
-            if x is None or dx_amax is not None:
+            if x is None or dx_amax is not None or _z16(z):
                 _lib.call("onet_maxpool2_bwd_add_bnreduce_amax", _p(x), xbs, _p(dy), dybs, _p(a1), a1bs, _p(a2), a2bs, _p(dx),
-                          C * H * W, _p(z), zbs, _p(save_all), B // G, _p(part2), _p(dx_amax), B, C, H, W, _stream(),
-                          nbytes=(9 + 4 * (x is not None) + 4 * (a1 is not None) + 4 * (a2 is not None)) * dx.numel())
+                          C * H * W, _p(z), _z16(z), zbs, _p(save_all), B // G, _p(part2), _p(dx_amax), B, C, H, W, _stream(),
+                          nbytes=(5 + z.element_size() + 4 * (x is not None) + 4 * (a1 is not None) + 4 * (a2 is not None)) * dx.numel())
             else:
                 _lib.call("onet_maxpool2_bwd_add_bnreduce", _p(x), xbs, _p(dy), dybs, _p(a1), a1bs, _p(a2), a2bs, _p(dx),
                           C * H * W, _p(z), zbs, _p(save_all), B // G, _p(part2), B, C, H, W, _stream(),

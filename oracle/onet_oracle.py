@@ -251,9 +251,16 @@ class Routing:
 # TAKE the other implementation's rounded operands: replay = {"conv3x3": [(x_r, g_r)] per call, "convT2x2": [(x_r, g_r)] per
 # call} (already rounded, in this module's call order; weights are identical numbers in both and round identically).  What
 # remains is a smooth function of the same operands, and the two must agree to summation accuracy.
+#
+# Round 5 -- STORED bf16 conv outputs (Settings.z_bf16 of the HIP path under conv == "bf16"): the convolution rounds its output z once,
+# to bf16, when it stores it; the BatchNorm STATISTICS are taken from the unrounded accumulators, everything that READS z (normalise,
+# ReLU decision, both backward passes) sees the rounded value.  kind "bn_z" of the rule says which units do that; the replay list
+# "bn_z" holds the HIP run's stored z per unit (None: that unit kept fp32).  `_BNStoredZ` states the arithmetic -- forward from
+# (mean, var)(z) and z_r, backward by the usual BatchNorm formula evaluated at xhat_r = (z_r - mean) invstd, which is what the
+# kernels compute; it is NOT the derivative of the rounded forward (same remark as for the operand rounding above).
 _ROUNDING_RULE = None
 _ROUNDING_REPLAY = None
-_ROUNDING_CALLS = {"conv3x3": 0, "convT2x2": 0}
+_ROUNDING_CALLS = {"conv3x3": 0, "convT2x2": 0, "bn_z": 0}
 
 
 def _rb(t):
@@ -268,7 +275,7 @@ class operand_rounding:
         global _ROUNDING_RULE, _ROUNDING_REPLAY
         self.prev = (_ROUNDING_RULE, _ROUNDING_REPLAY)
         _ROUNDING_RULE, _ROUNDING_REPLAY = self.rule, self.replay
-        _ROUNDING_CALLS.update(conv3x3=0, convT2x2=0)
+        _ROUNDING_CALLS.update(conv3x3=0, convT2x2=0, bn_z=0)
         return self
 
     def __exit__(self, *exc):
@@ -342,10 +349,53 @@ def _conv3x3(x, w):
     return F.conv2d(x, w, None, 1, 1)
 
 
+class _BNStoredZ(torch.autograd.Function):
+    """Train-mode BatchNorm whose input was stored rounded (z_r) while its statistics come from the exact z."""
+
+    @staticmethod
+    def forward(ctx, z, z_r, gamma, beta, eps):
+        mean = z.mean((0, 2, 3), keepdim=True)
+        var = z.var((0, 2, 3), unbiased=False, keepdim=True)
+        invstd = (var + eps).rsqrt()
+        xhat = (z_r - mean) * invstd
+        ctx.save_for_backward(xhat, invstd, gamma)
+        return xhat * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        xhat, invstd, gamma = ctx.saved_tensors
+        c1 = g.mean((0, 2, 3), keepdim=True)
+        c2 = (g * xhat).mean((0, 2, 3), keepdim=True)
+        dz = gamma.view(1, -1, 1, 1) * invstd * (g - c1 - xhat * c2)
+        return dz, None, (g * xhat).sum((0, 2, 3)), g.sum((0, 2, 3)), None
+
+
+def _stored_z(z, w):
+    """-> the rounded z this unit stored (replayed, or bf16(z) under free rounding), or None where the unit keeps its output in fp32."""
+    if _ROUNDING_RULE is None:
+        return None
+    i = _ROUNDING_CALLS["bn_z"]
+    _ROUNDING_CALLS["bn_z"] = i + 1
+    if _ROUNDING_REPLAY is not None and "bn_z" in _ROUNDING_REPLAY:
+        z_r = _ROUNDING_REPLAY["bn_z"][i]
+        return None if z_r is None else z_r.to(z.dtype)
+    return _rb(z.detach()) if _ROUNDING_RULE("bn_z", tuple(z.shape), tuple(w.shape)) else None
+
+
 def _conv_bn_relu(x, st, p, idx, training, routing=None):
     """conv3x3(pad 1, no bias) -> BN -> ReLU  (OV:47-49 / OV:51-53)."""
     z = _conv3x3(x, st[f"{p}.{idx}.weight"])
     b = idx + 1
+    z_r = _stored_z(z, st[f"{p}.{idx}.weight"]) if training else None
+    if z_r is not None:
+        assert z_r.shape == z.shape
+        with torch.no_grad():       # running statistics: from the exact z, F.batch_norm's update (unbiased variance, momentum 0.1)
+            n = z.numel() // z.shape[1]
+            st[f"{p}.{b}.running_mean"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * z.detach().mean((0, 2, 3)))
+            st[f"{p}.{b}.running_var"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * z.detach().var((0, 2, 3), unbiased=True) if n > 1 else 0.0)
+        y = _BNStoredZ.apply(z, z_r, st[f"{p}.{b}.weight"], st[f"{p}.{b}.bias"], BN_EPS)
+        st[f"{p}.{b}.num_batches_tracked"] += 1
+        return F.relu(y) if routing is None else routing.relu(y)
     y = F.batch_norm(z, st[f"{p}.{b}.running_mean"], st[f"{p}.{b}.running_var"],
                      st[f"{p}.{b}.weight"], st[f"{p}.{b}.bias"],
                      training, BN_MOMENTUM, BN_EPS)

@@ -204,7 +204,7 @@ def test_benchmark_dispatch_b32_256_every_gradient_element(dev, monkeypatch):
     used = {}
     for name in ("conv3x3_fwd_bn_partials", "conv3x3_dgrad_bnreduce", "conv3x3_split", "conv3x3_split_wgrad", "conv3x3_winograd4",
                  "conv3x3_winograd4_wgrad", "conv3x3_winograd_wgrad", "convT2x2_wgrad", "convT2x2_dgrad", "conv3x3_pre_bn_partials",
-                 "conv3x3_split_pre", "conv3x3_split_wgrad_pre", "bn_relu_bwd_split", "convT2x2_fwd_p"):
+                 "conv3x3_split_pre", "conv3x3_split_wgrad_pre", "bn_relu_bwd_split", "convT2x2_fwd_p", "conv3x3_split_dgrad_pre_bnreduce"):
         real = getattr(ops, name)
 
         def spy(*a, _real=real, _name=name, **k):
@@ -238,7 +238,12 @@ def test_benchmark_dispatch_b32_256_every_gradient_element(dev, monkeypatch):
         # (+ the two layers of the 16-pixel level with ops.PRESPLIT_W16, the default: two images side by side per forward tile)
         n = 17 if ops.PRESPLIT_W16 else 15
         assert used.get("conv3x3_pre_bn_partials", 0) == n and used.get("conv3x3_split_wgrad_pre", 0) == n, used
-        assert used.get("conv3x3_split_pre", 0) == n + n and used.get("bn_relu_bwd_split", 0) == n and used.get("convT2x2_fwd_p", 0) == 4, used
+        # (round 5: the second convolution of each DoubleConv on maps >= 32 pixels runs its input gradient with the first unit's
+        # BatchNorm-backward reduce in the epilogue: 8 of the 17 input-gradient launches; the fused launch does not count as
+        # conv3x3_split_pre)
+        fused = used.get("conv3x3_split_dgrad_pre_bnreduce", 0)
+        assert fused == (8 if ops.FUSE_DGRAD_REDUCE else 0), used
+        assert used.get("conv3x3_split_pre", 0) + fused == n + n and used.get("bn_relu_bwd_split", 0) == n and used.get("convT2x2_fwd_p", 0) == 4, used
         assert used.get("conv3x3_split_wgrad", 0) == 17 - n and used.get("conv3x3_winograd4_wgrad", 0) + used.get("conv3x3_winograd_wgrad", 0) == 0, used
         assert used.get("conv3x3_winograd4", 0) == (0 if ops.PRESPLIT_W16 else 4), used
     else:
@@ -281,6 +286,9 @@ def test_every_gradient_element_two_pass_and_unshared(dev, mode, monkeypatch):
 def _bf16_rule(kind, xs, ws):
     """Which matrix products of the model the bf16 conv path (ops.conv3x3_algo / wgrad_takes_bf16 under "bf16", the 128 x 128
     ConvTranspose2d GEMMs) evaluates with bf16-rounded operands."""
+    if kind == "bn_z":       # which units STORE their conv output as bf16 (ops.z16_storage: the pre-split plain-bf16 layers, full 16 x 32 tiles)
+        _, Cout, H, W = xs
+        return ws[1] % 32 == 0 and Cout % 32 == 0 and H % 16 == 0 and (W % 32 == 0 or W == 16)
     if kind == "conv3x3":
         _, Cin, H, W = xs
         return Cin % 16 == 0 and ws[0] % 4 == 0 and W >= 16 and W % 4 == 0 and H >= 8
@@ -303,8 +311,25 @@ def _record_bf16_operands(monkeypatch, B):
     ORACLE's call order (18 units / 4 Up blocks of the X pass, then of the 1-X pass; the twin batch holds both passes)."""
     from onet_amd import ops
     rb = lambda t: t.detach().to(torch.bfloat16).cpu()          # RNE, == v_cvt_pk_bf16_f32 (tests/test_gpu_ops.py)
-    conv, convt = [], []
+    conv, convt, zs = [], [], []
     real_w, real_t, real_p = ops.conv3x3_wgrad_auto, ops.convT2x2_wgrad, ops.conv3x3_split_wgrad_pre
+    real_zp, real_zf = ops.conv3x3_pre_bn_partials, ops.conv3x3_fwd_bn_partials
+
+    # the conv output z of every unit AS STORED (round 5: bf16 where ops.z16_storage() says so; None for a unit that keeps fp32): the
+    # oracle normalises the stored values with the statistics of its own exact z (oracle._BNStoredZ)
+    def z_pre(*a, **k):
+        z, cm = real_zp(*a, **k)
+        assert z.shape[0] == 2 * B
+        zs.append(z.detach().cpu() if z.dtype == torch.bfloat16 else None)
+        return z, cm
+
+    def z_fp32(*a, **k):
+        z, cm = real_zf(*a, **k)
+        zs.append(None)
+        return z, cm
+
+    monkeypatch.setattr(ops, "conv3x3_pre_bn_partials", z_pre)
+    monkeypatch.setattr(ops, "conv3x3_fwd_bn_partials", z_fp32)
 
     def wgrad(x, dz, *a, **k):
         assert x is not None and dz is not None and x.shape[0] == 2 * B
@@ -334,11 +359,14 @@ def _record_bf16_operands(monkeypatch, B):
         monkeypatch.setattr(ops, "conv3x3_wgrad_auto", real_w)
         monkeypatch.setattr(ops, "convT2x2_wgrad", real_t)
         monkeypatch.setattr(ops, "conv3x3_split_wgrad_pre", real_p)
-        assert len(conv) == 18 and len(convt) == 4
-        out = {"conv3x3": [], "convT2x2": []}
+        monkeypatch.setattr(ops, "conv3x3_pre_bn_partials", real_zp)
+        monkeypatch.setattr(ops, "conv3x3_fwd_bn_partials", real_zf)
+        assert len(conv) == 18 and len(convt) == 4 and len(zs) == 18, (len(conv), len(convt), len(zs))
+        out = {"conv3x3": [], "convT2x2": [], "bn_z": []}
         for p in range(2):                                       # backward visits the units last to first
             out["conv3x3"] += [(x[p * B:(p + 1) * B], g[p * B:(p + 1) * B]) for x, g in reversed(conv)]
             out["convT2x2"] += [(x[p * B:(p + 1) * B], g[p * B:(p + 1) * B]) for x, g in reversed(convt)]
+            out["bn_z"] += [None if z is None else z[p * B:(p + 1) * B] for z in zs]     # (forward order)
         return out
 
     return finish
@@ -372,6 +400,9 @@ def test_bf16_path_every_gradient_element_vs_routed_rounded_oracle(dev, tag, ker
         prof, _ = ops.profile_stop()
     replay = finish_ops()
     if kernels == "presplit":
+        # (round 5: the pre-split layers store their conv output as bf16 -- 11 of 18 units per pass at 128 x 128 with B = 8: the levels
+        # 32 pixels wide and wider except the stem)
+        assert sum(z is not None for z in replay["bn_z"]) >= 20, [None if z is None else tuple(z.shape) for z in replay["bn_z"]]
         assert len(prof.get("conv3x3_split_pre_kernel", [])) >= 10 and len(prof.get("conv3x3_split_wgrad_pre_kernel", [])) >= 5, {k: len(v) for k, v in prof.items()}
     else:
         assert len(prof.get("conv3x3_bf16_kernel", [])) >= 24 and len(prof.get("conv3x3_wgrad_bf16_kernel", [])) >= 12, {k: len(v) for k, v in prof.items()}

@@ -183,8 +183,11 @@ def test_bf16_conv_path_vs_reference_golden(dev, monkeypatch):
     worst = max(abs(float(named[str(n)].grad.double().norm()) - n64[i]) / n64[i] for i, n in enumerate(g["grad_names"]))
     # measured 6.0 / 7.7 / 8.2 % for three builds that differ only in fp32 summation order (tap order of the bf16 kernel, fused vs
     # separate BatchNorm statistics): the worst case is always one BatchNorm gamma of down1 on this ill-conditioned B = 2 input
-    # (median over the parameters 0.6 %), so the bound is that spread plus margin
-    assert worst <= 0.10, ("gradient norm", worst)
+    # (median over the parameters 0.6 %), so the bound is that spread plus margin.  Round 5: the pre-split layers also STORE their conv
+    # output z as bf16 (what torch.autocast(bfloat16) does to an nn.Conv2d output; ops.z16_storage) -- one more free rounding per
+    # element in front of every BatchNorm: measured 11.3 % on the same gamma; the strict statement (roundings replayed, 1e-4 per
+    # element) is unchanged and includes the stored z
+    assert worst <= 0.15, ("gradient norm", worst)
     print(f"bf16 path: loss rel {rel:.2e}, worst gradient-norm error {worst:.2e}")
 
 
@@ -790,21 +793,27 @@ def test_expanded_gradients_are_ordinary_tensors(dev, monkeypatch, conv):
         ops.plane(ph)
 
 
-def test_config3_batch256_single_gpu_fits_and_steps(dev):
-    """BASELINE config 3's shape (B=256, 1x256x256 on ONE MI355X) in fp32: the step must fit the 288 GB of HBM
-    (measured peak 175 GB) and give a finite loss and finite gradients; the loss of the B=256 batch built by
+@pytest.mark.parametrize("conv", ["auto", "bf16"])
+def test_config3_batch256_single_gpu_fits_and_steps(dev, conv):
+    """BASELINE config 3's shape (B=256, 1x256x256 on ONE MI355X), in fp32 and with `conv="bf16"` -- configs[2]'s own setting: plain
+    bf16 MFMA operands written by their producers, conv outputs stored as bf16 (round 5): the step must fit the 288 GB of HBM
+    (measured peak 175 GB in fp32) and give a finite loss and finite gradients; the loss of the B=256 batch built by
     tiling the B=2 golden input 128 times equals the golden loss (BatchNorm statistics of a tiled batch are those
-    of the tile; the JSD means are over B*H*W)."""
+    of the tile; the JSD means are over B*H*W) -- to 1e-3 in fp32, to the bf16 golden test's 2e-2 under bf16 operands."""
+    from onet_amd import ops
     free, _total = torch.cuda.mem_get_info(dev)
     if free < 200 * 2 ** 30:
         pytest.skip("needs ~175 GB of free HBM")
     g = np.load(os.path.join(G, "onet_b2_c1_256.npz"))
     X = orc.det_input(2, 1, 256, 256).to(dev).repeat(128, 1, 1, 1)
     m = _model(1, True, dev)
+    m.settings = ops.Settings(conv=conv)
+    torch.cuda.reset_peak_memory_stats(dev)
     (_, _, _, _, S), loss = _step(m, X)
     assert S.shape == (256, 2, 256, 256)
-    assert abs(loss.item() - g["losses"][0]) <= RTOL * abs(g["losses"][0])
+    assert abs(loss.item() - g["losses"][0]) <= (RTOL if conv == "auto" else 2e-2) * abs(g["losses"][0])
     assert all(bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+    print(f"B=256 1x256x256 conv={conv}: peak HBM {torch.cuda.max_memory_allocated(dev) / 2 ** 30:.1f} GB, loss {loss.item():.5f}")
     del m, X, S, loss
     torch.cuda.empty_cache()
 
@@ -951,8 +960,8 @@ def test_training_behaviour_vs_reference_fixture(dev, mode):
 @pytest.mark.parametrize("B,H,algo", [(4, 128, "auto"), (4, 256, "split"), (2, 64, "split")])
 def test_presplit_storage_step_vs_fp32_storage(dev, B, H, algo, monkeypatch):
     """Round 4: pre-split storage (Settings.presplit, the default) against the same step with every operand kept in fp32 and split by
-    the consuming kernels: the FORWARD (every output, the loss, the BatchNorm buffers) must be bit-identical -- the producers split
-    exactly the values the fp32 passes write and the LDS-DMA staged kernel runs the same MFMA sequence on them -- and every parameter
+    the consuming kernels: the FORWARD (every output, the loss, the BatchNorm buffers) agrees to fp32 summation rounding -- the
+    producers split exactly the values the fp32 passes write, the products are the same exact fp16 x fp16 products -- and every parameter
     gradient agrees to rounding (fp16 parts of power-of-two-scaled gradients against bf16 parts; another summation order in the
     weight gradient)."""
     from onet_amd import ops
@@ -969,12 +978,16 @@ def test_presplit_storage_step_vs_fp32_storage(dev, B, H, algo, monkeypatch):
         res[name] = (loss.detach().clone(), Lt.detach().clone(), Vt.detach().clone(), S.detach().clone(),
                      {k: p.grad.detach().clone() for k, p in m.named_parameters()}, [b.detach().clone() for b in m.buffers()])
     a, b = res["fp32"], res["presplit"]
-    for i in range(4):
-        assert torch.equal(a[i], b[i]), i
+    # (round 4 held the forward to bit-identity: the pre-split kernel ran the in-staging kernel's MFMA sequence.  Round 5's forward
+    # kernel packs two product terms into one v_mfma_f32_16x16x32 -- the same exact products, another fp32 summation order -- so the
+    # two storages now agree to summation rounding: 2e-6 of each output's scale, 1e-6 on the loss and the BatchNorm buffers)
+    assert abs(float(a[0]) - float(b[0])) <= 1e-6 * abs(float(a[0]))
+    for i, tol in ((1, 2e-6), (2, 2e-5), (3, 2e-5)):          # Lt; Vt and S behind the head, which amplifies (|V| up to 47)
+        assert float((a[i] - b[i]).abs().max()) <= tol * float(a[i].abs().max()), i
     for p, q in zip(a[5], b[5]):
-        assert torch.equal(p, q)
+        assert float((p.double() - q.double()).abs().max()) <= 1e-6 * max(1.0, float(p.double().abs().max()))
     worst = max((float((a[4][k] - b[4][k]).norm() / a[4][k].norm()), k) for k in a[4])
-    print(f"pre-split vs fp32 storage [{B}x{H}x{H}, {algo}]: forward bit-identical; worst relative gradient difference {worst[0]:.2e} ({worst[1]})")
+    print(f"pre-split vs fp32 storage [{B}x{H}x{H}, {algo}]: forward to summation rounding; worst relative gradient difference {worst[0]:.2e} ({worst[1]})")
     assert worst[0] <= 1e-4, worst
 
 
@@ -983,7 +996,9 @@ def test_presplit_concat_level_fed_by_an_8x8_map(dev):
     ConvTranspose2d that feeds its concat buffer reads an 8 x 8 map -- outside the GEMM fast path (h w % 128 != 0), with a scaled
     output (its input carries magnitude slots).  That combination used to raise; it now takes the fp32 up-sample + one conversion
     pass that applies the same guard scale.  The step must run and agree with fp32 storage: outputs to 1e-5 of their scale (the
-    16-pixel level runs other kernels there, so not bit for bit), every parameter gradient to 2e-3 relative."""
+    16-pixel level runs other kernels there, so not bit for bit), every parameter gradient to 2e-2 relative -- the ReLU / pooling
+    decisions are free here, and two correct fp32 evaluations that flip a handful of them differ by 6e-3 .. 9e-3 on every parameter
+    of this network (test_presplit_range_guard_large_gamma's note; measured here 8.4e-3)."""
     from onet_amd import ops
     import Onet_vanilla_20240606 as ov
     B, H = 24, 128
@@ -1008,14 +1023,15 @@ def test_presplit_concat_level_fed_by_an_8x8_map(dev):
         assert e <= 1e-5, (i, e)
     worst = max((float((a[4][k] - b[4][k]).norm() / a[4][k].norm()), k) for k in a[4])
     print(f"pre-split 16-pixel level behind an 8x8 ConvTranspose2d input: worst relative gradient difference {worst[0]:.2e} ({worst[1]})")
-    assert worst[0] <= 2e-3, worst
+    assert worst[0] <= 2e-2, worst
 
 
 def test_partially_frozen_batchnorm_keeps_fp32_tensors(dev):
     """Round 5 (advisor): a network whose BatchNorm layers are PARTLY in eval mode (a frozen encoder stage, a frozen decoder stage)
     must run as it did before pre-split storage: UNet._forward allocates a concat buffer pre-split only where the encoder block that
     writes its skip groups AND the decoder block that reads it take their pre-split branches (DoubleConv.pre_capable).  Each
-    partially frozen model is held to the same model under Settings(presplit=False): outputs to 1e-5, gradients to 2e-3."""
+    partially frozen model is held to the same model under Settings(presplit=False): outputs to 1e-5, gradients to 2e-2 (free ReLU /
+    pooling decisions: see test_presplit_concat_level_fed_by_an_8x8_map)."""
     from onet_amd import ops
     import Onet_vanilla_20240606 as ov
     B, H = 4, 128
@@ -1048,7 +1064,7 @@ def test_partially_frozen_batchnorm_keeps_fp32_tensors(dev):
             assert e <= 1e-5, (freeze, i, e)
         assert a[3].keys() == b[3].keys()
         worst = max((float((a[3][k] - b[3][k]).norm() / (a[3][k].norm() + 1e-30)), k) for k in a[3])
-        assert worst[0] <= 2e-3, (freeze, worst)
+        assert worst[0] <= 2e-2, (freeze, worst)
 
 
 @pytest.mark.parametrize("gamma", [50.0, 3.0e4])

@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-secondary --no-f32-mfma-only $BENCH_ARGS"     # BENCH_ARGS e.g. "--conv bf16"
+CMD="python3 $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-secondary --no-f32-mfma-only --no-reference-loop $BENCH_ARGS"     # BENCH_ARGS e.g. "--conv bf16"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- $CMD > $OUT/stats.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- $CMD > $OUT/fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- $CMD > $OUT/write.log 2>&1
