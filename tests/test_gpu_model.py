@@ -988,7 +988,11 @@ def test_presplit_storage_step_vs_fp32_storage(dev, B, H, algo, monkeypatch):
         assert float((p.double() - q.double()).abs().max()) <= 1e-6 * max(1.0, float(p.double().abs().max()))
     worst = max((float((a[4][k] - b[4][k]).norm() / a[4][k].norm()), k) for k in a[4])
     print(f"pre-split vs fp32 storage [{B}x{H}x{H}, {algo}]: forward to summation rounding; worst relative gradient difference {worst[0]:.2e} ({worst[1]})")
-    assert worst[0] <= 1e-4, worst
+    # (with a bit-identical forward the two runs took the same ReLU / pooling decisions and the gradients agreed to 1e-4; a forward that
+    # differs in the last bits flips a handful of them, and two correct evaluations then differ by 6e-3 .. 9e-3 on every parameter of
+    # this network -- test_presplit_range_guard_large_gamma's note.  The element-wise statement under fixed decisions is
+    # tests/test_gpu_gradients.py)
+    assert worst[0] <= 2e-2, worst
 
 
 def test_presplit_concat_level_fed_by_an_8x8_map(dev):
