@@ -102,17 +102,10 @@ int onet_conv_fwd(const float* x, int64_t x_bs, const float* wp, float* z, int64
                   float* bn_part, int B, int Cin, int Cout, int H, int W, int ks, void* stream);
 int onet_conv_fwd_nparts(int B, int Cout, int H, int W);
 
-/* Fast path for ks=3: Winograd F(2x2,3x3) on the fp32 matrix cores (2.25x fewer multiplies; same
- * call sites OV:47,51).  wq_fwd [Cin][16][Cout] = G g G^T, wq_dgrad [Cout][16][Cin] = G rot180(g) G^T;
- * input transform B^T d B in registers from the LDS halo tile, output transform A^T M A in the
- * epilogue.  Requires Cout % 4 == 0 (otherwise use onet_conv_fwd). */
-int onet_conv3x3_pack_weights_winograd(const float* w, float* wq_fwd, float* wq_dgrad,
-                                       int Cout, int Cin, void* stream);
-int onet_conv3x3_winograd_fwd(const float* x, int64_t x_bs, const float* wq, float* z, int64_t z_bs,
-                              int B, int Cin, int Cout, int H, int W, void* stream);
-/* Larger-tile variant for fwd / dgrad: Winograd F(4x4,3x3) (4x fewer multiplies; 6x6 input tiles, interpolation
+/* Fast fp32 path for ks=3, fwd / dgrad: Winograd F(4x4,3x3) on the fp32 matrix cores (4x fewer multiplies; 6x6 input tiles, interpolation
  * points 0, +-1, +-2; fp32 error ~3e-6 rms per layer).  wq_fwd [Cin][36][Cout], wq_dgrad [Cout][36][Cin].
- * Requires Cin % 4 == 0 and Cout % 4 == 0.  Same call sites as onet_conv3x3_winograd_fwd. */
+ * Requires Cin % 4 == 0 and Cout % 4 == 0.  Same call sites as onet_conv_fwd (OV:47,51).  (Round 5: the F(2x2,3x3) kernels
+ * of round 1 are gone; layers too small for these blocks take onet_conv_fwd / onet_conv_wgrad.) */
 int onet_conv3x3_pack_weights_winograd4(const float* w, float* wq_fwd, float* wq_dgrad,
                                         int Cout, int Cin, void* stream);
 int onet_conv3x3_winograd4_fwd(const float* x, int64_t x_bs, const float* wq, float* z, int64_t z_bs,
@@ -297,17 +290,11 @@ int onet_conv3x3_wgrad_bf16_b(const void* x, int x_is_bf16, int64_t x_bs, const 
 /* Larger-tile weight gradient: Winograd F(3x3,4x4) (4x fewer multiplies than direct, 1.78x fewer than the F(2x2,3x3)
  * kernel below; 6x6 input tiles, 4x4 tiles of dz in the filter's role, the points of onet_conv3x3_winograd4_fwd; split-K
  * 36-position slabs folded by A'^T . A').  Where onet_conv3x3_winograd4_wgrad_ok() returns 1 (W % 32 == 0, H % 4 == 0,
- * Cin % 32 == 0); same result contract as onet_conv3x3_winograd_wgrad. */
+ * Cin % 32 == 0); dW = G^T [ sum_tiles (A dY A^T) (.) (B^T d B) ] G, split-K, deterministic slab reduction; dw is [Cout][Cin][3][3]. */
 int onet_conv3x3_winograd4_wgrad_ok(int B, int Cin, int Cout, int H, int W);
 int64_t onet_conv3x3_winograd4_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W);
 int onet_conv3x3_winograd4_wgrad(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs, float* dw, void* ws,
                                  int64_t ws_bytes, int B, int Cin, int Cout, int H, int W, int accumulate, void* stream);
-/* Winograd weight gradient: dW = G^T [ sum_tiles (A dY A^T) (.) (B^T d B) ] G, split-K over pixel strips,
- * deterministic slab reduction; dw is [Cout][Cin][3][3]. */
-int onet_conv3x3_winograd_wgrad(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs, float* dw,
-                                void* ws, int64_t ws_bytes, int B, int Cin, int Cout, int H, int W,
-                                int accumulate, void* stream);
-int64_t onet_conv3x3_winograd_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W);
 
 /* wgrad: dw[co][ci][ky][kx] (+)= sum_{b,y,x} dz[b][co][y][x] * x[b][ci][y+ky-p][x+kx-p]
  * (autograd of F.conv2d wrt weight; reference: implicit via loss.backward(), TS:217).

@@ -229,7 +229,7 @@ template <> __device__ __forceinline__ float bn_ldz<__bf16>(const __bf16* p) { r
 template <typename ZT> __device__ __forceinline__ float4 bn_ldz4(const ZT* p);      // four consecutive elements (16 / 8 byte aligned)
 template <> __device__ __forceinline__ float4 bn_ldz4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
 template <> __device__ __forceinline__ float4 bn_ldz4<__bf16>(const __bf16* p) {
-    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    const uint2 u = *reinterpret_cast<const uint2*>(p);      // (a 16-byte load of the aligned group with the half picked out: no faster, measured)
     return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
                        __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
 }

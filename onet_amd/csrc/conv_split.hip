@@ -1274,28 +1274,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pre16_kernel(SpPreArgs a) {
             }
             __syncthreads();
         }
+        // RD, part 1: the z tile of the unit below goes into registers FIRST (16 loads in flight; the fragment registers of the main loop
+        // are dead here), the da stores below run while they travel, and the sums are taken after the stores
+        f32x4s zr[4][NT][2];
+        const float* rd_sv = nullptr;
         if constexpr (RD) {
-            // BatchNorm-backward reduce of the unit below (bn_relu_bwd_reduce_kernel's sums) from the tile in registers: dy = da where that
-            // unit's output was positive, (sum dy, sum dy xhat) per channel.  Lane = channel, 16 pixel values: in-lane fp32 sums, the four
-            // lane groups by two shuffles, the eight waves through LDS in fp64 -> one record per tile and channel.  The pass that read
-            // (da, z) -- 8 bytes per element -- becomes a 4-byte read of z here.
-            float* sc = reinterpret_cast<float*>(lds + (buf ^ 1) * BUF);       // [8 waves][64 channels][s, sx]
             const int img0 = W16 ? 2 * b : b;
-            const float* sv = a.rd_save + (int64_t)(a.rd_gimg ? img0 / a.rd_gimg : 0) * 4 * a.Cout;
-            float vmax = 0.f;
+            rd_sv = a.rd_save + (int64_t)(a.rd_gimg ? img0 / a.rd_gimg : 0) * 4 * a.Cout;
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                const int co = co0 + ct * 16 + r16, cc = min(co, a.Cout - 1);
-                const float mean = sv[cc], invstd = sv[a.Cout + cc], scl = sv[2 * a.Cout + cc], sh = sv[3 * a.Cout + cc];
-                float s1 = 0.f, s2 = 0.f;
+            for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
 #pragma unroll
                     for (int ch = 0; ch < 2; ++ch) {
-                        const int yo = y0 + wn * NT + n, xo = (W16 ? 0 : x0 + 16 * ch) + 4 * lq;
+                        const int co = co0 + ct * 16 + r16, yo = y0 + wn * NT + n, xo = (W16 ? 0 : x0 + 16 * ch) + 4 * lq;
+                        f32x4s zz = {0.f, 0.f, 0.f, 0.f};
                         if (co < a.Cout && yo < a.H && xo < a.W) {
                             const int64_t zo = (int64_t)(W16 ? img0 + ch : img0) * a.rd_z_bs + (int64_t)co * HW + (int64_t)yo * a.W + xo;
-                            f32x4s zz;
                             if (a.rd_z16) {
                                 const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const __bf16*>(a.rd_z) + zo);
                                 zz = f32x4s{__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
@@ -1303,46 +1298,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pre16_kernel(SpPreArgs a) {
                             } else {
                                 zz = *reinterpret_cast<const f32x4s*>(a.rd_z + zo);
                             }
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float da = acc[ct][n][ch][r], d = zz[r] - mean;
-                                const float dy = fmaf(d, scl, sh) > 0.f ? da : 0.f;
-                                s1 += dy;
-                                s2 = fmaf(dy, d * invstd, s2);
-                                vmax = fmaxf(vmax, fabsf(da));
-                            }
                         }
+                        zr[ct][n][ch] = zz;
                     }
-                s1 += __shfl_xor(s1, 16, 64);
-                s2 += __shfl_xor(s2, 16, 64);
-                s1 += __shfl_xor(s1, 32, 64);
-                s2 += __shfl_xor(s2, 32, 64);
-                if (lq == 0) {
-                    sc[(wn * 64 + ct * 16 + r16) * 2] = s1;
-                    sc[(wn * 64 + ct * 16 + r16) * 2 + 1] = s2;
-                }
-            }
-            if (a.rd_amax) {
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
-                if (lane == 0 && vmax == vmax) atomicMax(a.rd_amax + ((blockIdx.x * 8 + wn) & (AMAX_SLOTS - 1)) * AMAX_STRIDE, __builtin_bit_cast(unsigned, vmax));
-            }
-            __syncthreads();
-            if (tid < 64 && co0 + tid < a.Cout) {
-                double t1 = 0.0, t2 = 0.0;
-#pragma unroll
-                for (int w = 0; w < 8; ++w) {
-                    t1 += (double)sc[(w * 64 + tid) * 2];
-                    t2 += (double)sc[(w * 64 + tid) * 2 + 1];
-                }
-                const int64_t blk = ((int64_t)b * a.tilesY + ty) * a.tilesX + tx;
-                float* o = a.rd_rec + (blk * a.Cout + co0 + tid) * 4;
-                o[0] = (float)t1;
-                o[1] = (float)(t1 - (double)o[0]);
-                o[2] = (float)t2;
-                o[3] = (float)(t2 - (double)o[2]);
-            }
-            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
         }
         // A lane holds, per (channel tile, row), channel r16's pixels 4 lq .. + 3 of BOTH 16-pixel tiles: stored as they stand, an
         // instruction would write 64-byte half lines (16 channels x 4 lanes x 16 B).  Lanes r16 >= 8 of the first tile and lanes
@@ -1383,6 +1342,66 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pre16_kernel(SpPreArgs a) {
                 }
             }
         }
+        if constexpr (RD) {
+            // RD, part 2: BatchNorm-backward reduce of the unit below (bn_relu_bwd_reduce_kernel's sums) from the tile in registers: dy = da
+            // where that unit's output was positive, (sum dy, sum dy xhat) per channel.  Lane = channel, 16 pixel values: in-lane fp32
+            // sums, the four lane groups by two shuffles, the eight waves through LDS in fp64 -> one record per tile and channel.  The
+            // pass that read (da, z) -- 8 bytes per element -- becomes a 4-byte (2-byte: stored bf16) read of z here.
+            __builtin_amdgcn_sched_barrier(0);
+            float* sc = reinterpret_cast<float*>(lds + (buf ^ 1) * BUF);       // [8 waves][64 channels][s, sx]
+            float vmax = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const int co = co0 + ct * 16 + r16, cc = min(co, a.Cout - 1);
+                const float mean = rd_sv[cc], invstd = rd_sv[a.Cout + cc], scl = rd_sv[2 * a.Cout + cc], sh = rd_sv[3 * a.Cout + cc];
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch) {
+                        const int yo = y0 + wn * NT + n, xo = (W16 ? 0 : x0 + 16 * ch) + 4 * lq;
+                        if (co < a.Cout && yo < a.H && xo < a.W) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float da = acc[ct][n][ch][r], d = zr[ct][n][ch][r] - mean;
+                                const float dy = fmaf(d, scl, sh) > 0.f ? da : 0.f;
+                                s1 += dy;
+                                s2 = fmaf(dy, d * invstd, s2);
+                                vmax = fmaxf(vmax, fabsf(da));
+                            }
+                        }
+                    }
+                s1 += __shfl_xor(s1, 16, 64);
+                s2 += __shfl_xor(s2, 16, 64);
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (lq == 0) {
+                    sc[(wn * 64 + ct * 16 + r16) * 2] = s1;
+                    sc[(wn * 64 + ct * 16 + r16) * 2 + 1] = s2;
+                }
+            }
+            if (a.rd_amax) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+                if (lane == 0 && vmax == vmax) atomicMax(a.rd_amax + ((blockIdx.x * 8 + wn) & (AMAX_SLOTS - 1)) * AMAX_STRIDE, __builtin_bit_cast(unsigned, vmax));
+            }
+            __syncthreads();
+            if (tid < 64 && co0 + tid < a.Cout) {
+                double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) {
+                    t1 += (double)sc[(w * 64 + tid) * 2];
+                    t2 += (double)sc[(w * 64 + tid) * 2 + 1];
+                }
+                const int64_t blk = ((int64_t)b * a.tilesY + ty) * a.tilesX + tx;
+                float* o = a.rd_rec + (blk * a.Cout + co0 + tid) * 4;
+                o[0] = (float)t1;
+                o[1] = (float)(t1 - (double)o[0]);
+                o[2] = (float)t2;
+                o[3] = (float)(t2 - (double)o[2]);
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -1404,7 +1423,9 @@ int launch_split_pre(SpPreArgs a, hipStream_t st) {
     // epilogues: -5 %); the plain (hi | mid) input gradient keeps the 32x32x16 kernel (equal speed), and so does the (hi | mid) 16-pixel
     // level (that instance of the new kernel exceeds the register budget).  SP_PRE16 = 2 / 0: everything / nothing (A-B builds).
     constexpr bool P16 = RD || (SP_PRE16 > 1) || (SP_PRE16 == 1 && (PM == 2 || (ST && !W16)));
-    auto kern = P16 ? conv3x3_pre16_kernel<ST, PM, W16, RD> : conv3x3_split_pre_kernel<ST, PM, W16>;
+    void (*kern)(SpPreArgs);
+    if constexpr (P16) kern = conv3x3_pre16_kernel<ST, PM, W16, RD>;      // (constexpr: the instances not dispatched are not built)
+    else kern = conv3x3_split_pre_kernel<ST, PM, W16>;
     static PerDeviceOnce attr_once;
     if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);

@@ -52,7 +52,7 @@ class Settings:
     on another thread, possibly after another model has run) -- so two models with different settings in one process, or on
     two streams / threads, never see each other's.
 
-      conv          3x3 convolution algorithm: "auto" | "winograd4" | "winograd" | "direct" | "bf16"     (default CONV_ALGO)
+      conv          3x3 convolution algorithm: "auto" | "split" | "winograd4" | "direct" | "bf16"         (default CONV_ALGO)
       twin          weight-shared Onet: X and 1-X as ONE batch of 2B                                        (default TWIN)
       convt_bf16    under conv == "bf16": the ConvTranspose2d GEMMs take bf16 operands too                  (default CONVT_BF16)
       bf16_storage  under conv == "bf16": producers write bf16 copies of the conv operands                  (default BF16_STORAGE)
@@ -456,7 +456,7 @@ def convT2x2_fwd_p(x, wq, bias, outP, Ct, pt, pl, slots=None):
 #                     with Cin % 16 == 0 and enough tiles to fill the chip; else Winograd F(4x4,3x3) where its 64-channel x
 #                     32-tile blocks fill the chip, else F(2x2,3x3), else the direct implicit-GEMM kernel
 #   "split"           the split-bf16 kernel on every legal layer (parity tests)
-#   "winograd4"       F(4x4,3x3) on every legal layer with maps >= 8x8 (parity tests)      "winograd" / "winograd2"  F(2x2,3x3)
+#   "winograd4"       F(4x4,3x3) on every legal layer with maps >= 8x8 (parity tests; the fp32-MFMA reference dispatch of bench.py)
 #   "direct"          implicit GEMM only
 #   "bf16"            BASELINE config 3: bf16-operand MFMA kernel (conv_bf16.hip) for forward / input gradient on every
 #                     layer with Cin % 16 == 0 and the weight gradient of every layer with Cin >= 16, on maps >= 16 px wide; "auto" (fp32) elsewhere
@@ -597,11 +597,10 @@ def _split_legal(Cin, Cout, H, W):
 
 
 def conv3x3_algo(B, Cin, Cout, H, W):
-    """-> "split" | "winograd4" | "winograd" | "direct" | "bf16" for a conv with Cin inputs and Cout outputs on B maps of H x W."""
+    """-> "split" | "winograd4" | "direct" | "bf16" for a conv with Cin inputs and Cout outputs on B maps of H x W."""
     algo = conv_algo()
-    algo = "winograd" if algo == "winograd2" else algo
     if algo in ("bf16", "winograd4", "auto", "split") and not _in_buffer_range(Cin, Cout, H, W):
-        algo = "winograd"
+        algo = "direct"               # (operands beyond the 2 GiB buffer-resource range: the direct kernel addresses with 64-bit pointers)
     if algo == "split":
         if _split_legal(Cin, Cout, H, W):
             return "split"
@@ -625,18 +624,16 @@ def conv3x3_algo(B, Cin, Cout, H, W):
         return "direct"
     if algo == "winograd4":
         return "winograd4"
-    if algo == "winograd":
-        return "winograd"
     if min(H, W) >= 16:
         img = 1 if W > 16 else 2                       # conv_wino4.hip block: 32 tiles of 4x4 px, 64 channels
         blocks = -(-B // img) * -(-W // (32 if W > 16 else 16)) * -(-H // 16) * -(-Cout // 64)
         if blocks >= (n_cu() * 7) // 8:
             return "winograd4"
-    return "winograd"
+    return "direct"                   # (round 5: the F(2x2,3x3) kernels that used to take the layers too small to fill the chip are gone)
 
 
 def use_winograd(Cin, Cout, H, W):
-    """Does the Winograd weight-gradient kernel (F(2x2,3x3)) take this layer?"""
+    """May a Winograd weight-gradient kernel (F(3x3,4x4)) take this layer?"""
     return conv_algo() != "direct" and _wino_legal(Cin, Cout) and min(H, W) >= 8
 
 
@@ -649,7 +646,7 @@ class Packed3x3(dict):
 
     def get_pack(self, algo):
         if algo not in self:
-            self[algo] = {"direct": pack3x3, "winograd": pack3x3_winograd, "winograd4": pack3x3_winograd4,
+            self[algo] = {"direct": pack3x3, "winograd4": pack3x3_winograd4,
                           "bf16": pack3x3_bf16, "split": pack3x3_split, "plain16": pack3x3_plain16}[algo](self.w)
         return self[algo]
 
@@ -677,8 +674,6 @@ def conv3x3_auto(x, pk, direction, out=None, x16=None, amax=None):
         return conv3x3_split(x, wq, Co, out=out, amax=amax, always=direction == 1)
     if algo == "bf16":
         return conv3x3_bf16(x, wq, Co, out=out, x16=x16)
-    if algo == "winograd":
-        return conv3x3_winograd(x, wq, Co, out=out)
     return conv_fwd(x, wq, Co, 3, out=out)
 
 
@@ -829,28 +824,8 @@ def conv3x3_dgrad_bnreduce(dz, pk, z_prev, save_prev):
     return da, rec
 
 
-def pack3x3_winograd(w):
-    require_gpu(w)
-    w = w.detach().contiguous()
-    Cout, Cin = w.shape[0], w.shape[1]
-    wf = torch.empty(Cin * 16 * Cout, dtype=F32, device=w.device)
-    wd = torch.empty(Cout * 16 * Cin, dtype=F32, device=w.device)
-    _lib.call("onet_conv3x3_pack_weights_winograd", _p(w), _p(wf), _p(wd), Cout, Cin, _stream())
-    return wf, wd
 
 
-def conv3x3_winograd(x, wq, Cout, out=None):
-    """z = conv3x3(x) by Winograd F(2x2,3x3) with transformed weights wq ([Cin][16][Cout]); fwd and dgrad."""
-    require_gpu(x, wq)
-    x, xbs = plane(x)
-    B, Cin, H, W = x.shape
-    if out is None:
-        out = torch.empty((B, Cout, H, W), dtype=F32, device=x.device)
-    zbs = out.stride(0) if B > 1 else Cout * H * W
-    e0 = _prof_begin("conv_wino_kernel")
-    _lib.call("onet_conv3x3_winograd_fwd", _p(x), xbs, _p(wq), _p(out), zbs, B, Cin, Cout, H, W, _stream())
-    _prof_end("conv_wino_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
-    return out
 
 
 def pack3x3_winograd4(w):
@@ -1440,20 +1415,6 @@ def grad_slot_if_free(param):
     return flat[off:off + n].view(shape)
 
 
-def conv3x3_winograd_wgrad(x, dz, dw_shape, out=None):
-    require_gpu(x, dz)
-    x, xbs = plane(x)
-    dz, dzbs = plane(dz)
-    B, Cin, H, W = x.shape
-    Cout = dz.shape[1]
-    dw = torch.empty(dw_shape, dtype=F32, device=x.device) if out is None else out
-    need = _lib.load().onet_conv3x3_winograd_wgrad_ws_bytes(B, Cin, Cout, H, W)
-    ws = workspace(need, x.device)
-    e0 = _prof_begin("conv_wino_wgrad_kernel")
-    _lib.call("onet_conv3x3_winograd_wgrad", _p(x), xbs, _p(dz), dzbs, _p(dw), _p(ws), ws.numel() * 4, B, Cin, Cout,
-              H, W, 0, _stream())
-    _prof_end("conv_wino_wgrad_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
-    return dw
 
 
 def conv3x3_winograd4_wgrad(x, dz, dw_shape, out=None):
@@ -1539,9 +1500,8 @@ def conv3x3_wgrad_auto(x, dz, dw_shape, out=None, x16=None, dz16=None, dz_amax=N
             x.shape[3] >= SPLIT_WGRAD_MINW and split_wgrad_ok(x, dz):
         return conv3x3_split_wgrad(x, dz, dw_shape, out=out, dz_amax=dz_amax if grad_f16() else None, x_amax=x_amax)
     if use_winograd(Cin, Cout, x.shape[2], x.shape[3]):
-        if WGRAD4 != "0" and (WGRAD4 == "1" or Cin >= 256 or (Cin >= 128 and Cout >= 256)) and winograd4_wgrad_ok(x, dz):
+        if WGRAD4 != "0" and winograd4_wgrad_ok(x, dz):
             return conv3x3_winograd4_wgrad(x, dz, dw_shape, out=out)
-        return conv3x3_winograd_wgrad(x, dz, dw_shape, out=out)
     return conv_wgrad(x, dz, dw_shape, 3, out=out)
 
 

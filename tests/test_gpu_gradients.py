@@ -130,7 +130,7 @@ def _model(C, gain, dev, seed=1981, bshare=True):
 CASES = {
     # tag: (B, C, H, W, head_gain, algorithms)
     # ("split_f16grad": the split kernels with Settings.grad_f16 -- input / weight gradients on fp16 parts of scaled operands)
-    "b8_c1_128": (8, 1, 128, 128, 0.3, ("auto", "split", "split_f16grad", "winograd4", "winograd", "direct")),
+    "b8_c1_128": (8, 1, 128, 128, 0.3, ("auto", "split", "split_f16grad", "winograd4", "direct")),
     "b4_c1_256": (4, 1, 256, 256, 0.3, ("auto", "split", "winograd4")),
     "b2_c3_64_saturated": (2, 3, 64, 64, 1.0, ("auto", "winograd4")),
     "b3_c1_40_padpath": (3, 1, 40, 40, 1.0, ("auto",)),
@@ -138,13 +138,10 @@ CASES = {
 }
 
 
-@pytest.mark.parametrize("algo", ["auto", "split", "split_f16grad", "winograd4", "winograd", "direct"])
-@pytest.mark.parametrize("tag", list(CASES))
+@pytest.mark.parametrize("tag,algo", [(t, a) for t, c in CASES.items() for a in c[5]])
 def test_every_gradient_element_vs_routed_fp64_oracle(dev, tag, algo, monkeypatch):
     from onet_amd import ops
     B, C, H, W, gain, algos = CASES[tag]
-    if algo not in algos:
-        pytest.skip("algorithm not forced on this case")
     monkeypatch.setattr(ops, "CONV_ALGO", "split" if algo == "split_f16grad" else algo)
     if algo == "split_f16grad":
         monkeypatch.setattr(ops, "SPLIT_GRAD_F16", True)
@@ -203,7 +200,7 @@ def test_benchmark_dispatch_b32_256_every_gradient_element(dev, monkeypatch):
     m = _model(1, 1.0, dev)
     used = {}
     for name in ("conv3x3_fwd_bn_partials", "conv3x3_dgrad_bnreduce", "conv3x3_split", "conv3x3_split_wgrad", "conv3x3_winograd4",
-                 "conv3x3_winograd4_wgrad", "conv3x3_winograd_wgrad", "convT2x2_wgrad", "convT2x2_dgrad", "conv3x3_pre_bn_partials",
+                 "conv3x3_winograd4_wgrad", "convT2x2_wgrad", "convT2x2_dgrad", "conv3x3_pre_bn_partials",
                  "conv3x3_split_pre", "conv3x3_split_wgrad_pre", "bn_relu_bwd_split", "convT2x2_fwd_p", "conv3x3_split_dgrad_pre_bnreduce"):
         real = getattr(ops, name)
 
@@ -244,12 +241,12 @@ def test_benchmark_dispatch_b32_256_every_gradient_element(dev, monkeypatch):
         fused = used.get("conv3x3_split_dgrad_pre_bnreduce", 0)
         assert fused == (8 if ops.FUSE_DGRAD_REDUCE else 0), used
         assert used.get("conv3x3_split_pre", 0) + fused == n + n and used.get("bn_relu_bwd_split", 0) == n and used.get("convT2x2_fwd_p", 0) == 4, used
-        assert used.get("conv3x3_split_wgrad", 0) == 17 - n and used.get("conv3x3_winograd4_wgrad", 0) + used.get("conv3x3_winograd_wgrad", 0) == 0, used
+        assert used.get("conv3x3_split_wgrad", 0) == 17 - n and used.get("conv3x3_winograd4_wgrad", 0) == 0, used
         assert used.get("conv3x3_winograd4", 0) == (0 if ops.PRESPLIT_W16 else 4), used
     else:
         assert diag or (used.get("conv3x3_fwd_bn_partials", 0) >= 14 and used.get("conv3x3_split", 0) >= 10), used
         if ops.SPLIT_AUTO and not diag:
-            assert used.get("conv3x3_split_wgrad", 0) == 17 and used.get("conv3x3_winograd4_wgrad", 0) + used.get("conv3x3_winograd_wgrad", 0) == 0, used
+            assert used.get("conv3x3_split_wgrad", 0) == 17 and used.get("conv3x3_winograd4_wgrad", 0) == 0, used
     assert used.get("convT2x2_wgrad", 0) == 4 and (ops.PRESPLIT or used.get("conv3x3_winograd4", 0) >= 1), used
     assert abs(loss.item() - g["losses"][0]) <= 1e-3 * abs(g["losses"][0])
     assert np.abs(Vt.detach().cpu().numpy()[:2, :, ::37, :] - g["Vt"]).max() <= 1e-3 * np.abs(g["Vt"]).max()

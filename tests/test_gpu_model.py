@@ -74,32 +74,22 @@ def _step(m, X):
 CASES = ["b2_c1_16", "b2_c1_32", "b2_c3_32", "b2_c1_40", "b3_c1_32", "b2_c1_32_noshare", "b2_c1_256"]
 
 
-@pytest.mark.parametrize("algo", ["auto", "split", "winograd4", "auto-two-pass", "winograd", "direct"])
-@pytest.mark.parametrize("tag", CASES)
+# (tag, algorithm) pairs, listed -- no self-skipping product: "auto" on every golden; the reference's two-pass order on three; the split
+# kernels forced on the 256-pixel golden (their gradients are held to 2e-4 element-wise in test_gpu_gradients.py); the direct kernel and
+# F(4x4,3x3) forced on the two well-conditioned cases (on the 16- / 32-pixel goldens -- BatchNorm over 2..8 values per channel -- the
+# coarser rounding of F(4x4) flips more ReLU kinks than this test's bound allows; ops.conv3x3_algo never selects it for such grids)
+GOLDEN_RUNS = [(t, "auto") for t in CASES] + [(t, "auto-two-pass") for t in ("b2_c1_32", "b2_c1_40", "b2_c1_256")] + \
+    [("b2_c1_256", "split")] + [(t, a) for a in ("winograd4", "direct") for t in ("b2_c1_40", "b2_c1_256")]
+
+
+@pytest.mark.parametrize("tag,algo", GOLDEN_RUNS)
 def test_train_step_vs_reference_golden(dev, tag, algo, monkeypatch):
-    """algo "auto": the shape heuristic of ops.conv3x3_algo (small batches mostly land on F(2x2,3x3) and direct);
-    "winograd4": F(4x4,3x3) forced on every legal layer, the kernel the B=32 benchmark spends most time in."""
+    """algo "auto": the shape heuristic of ops.conv3x3_algo (small batches mostly land on the direct kernel);
+    "winograd4": F(4x4,3x3) forced on every legal layer (the fp32-MFMA reference dispatch of bench.py)."""
     from onet_amd import ops
     if algo == "auto-two-pass":                 # the reference's order: topu(X) then dwnu(1 - X), no twin batch
-        if tag not in ("b2_c1_32", "b2_c1_40", "b2_c1_256"):
-            pytest.skip("two-pass mode is covered on three cases")
         monkeypatch.setattr(ops, "TWIN", False)
         algo = "auto"
-    if algo in ("winograd", "direct") and tag not in ("b2_c1_40", "b2_c1_256"):
-        pytest.skip("forced F(2x2,3x3) / direct kernels are covered on two cases")
-    if algo == "split" and tag != "b2_c1_256":
-        # (on the 40-pixel case the kink-flip bound of this test is a matter of luck for any kernel noisier than the direct one
-        # -- measured 0.025 against 0.022 -- as for F(4x4) on the 16- / 32-pixel cases below; the strict statement for the split
-        # kernel is tests/test_gpu_gradients.py: every gradient element at 2e-4 under the run's own decisions)
-        pytest.skip("the split-bf16 kernel is forced on the 256-pixel golden; its gradients are held to 2e-4 in test_gpu_gradients.py")
-    if algo == "winograd4" and tag not in ("b2_c1_40", "b2_c1_256"):
-        # F(4x4,3x3) rounds ~6x coarser than F(2x2,3x3) (2.7e-6 vs 4e-7 of the output scale per layer).  The
-        # 16- and 32-pixel goldens are conditioned at 1e-2 already (BatchNorm over 2..8 values per channel);
-        # there the extra noise flips more ReLU kinks than the two the bound allows (measured 0.030 vs 0.022; the 32-pixel
-        # noshare case sat on the edge: it passed or failed with the summation ORDER of the BatchNorm statistics).
-        # ops.conv3x3_algo never selects F(4x4) for such grids (it needs >= 224 blocks of 32 tiles), so only
-        # the well-conditioned cases are forced through it.
-        pytest.skip("F(4x4,3x3) is not dispatched on tiny, ill-conditioned grids")
     monkeypatch.setattr(ops, "CONV_ALGO", algo)
     g = np.load(os.path.join(G, f"onet_{tag}.npz"))
     B, C, H, W, bshare, train, steps = [int(v) for v in g["meta"]]
