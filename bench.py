@@ -411,7 +411,7 @@ def main(args):
         barrier()
         wall_b = (time.perf_counter() - tb0) / n_break * 1e3
         prof_b, prof_all = ops.profile_stop()
-    # the same loop with the fp32-MFMA kernels only (Winograd F(4x4) / F(2x2) / direct: round 2's dispatch), for the record next to
+    # the same loop with the fp32-MFMA kernels only (Winograd F(4x4) / direct), for the record next to
     # the headline, whose 3x3 convolutions run on the bf16 matrix pipe by operand splitting (same fp32 tensors and results)
     f32_mfma_only = None
     if world == 1 and not bf16 and conv in ("auto", "split") and ops.SPLIT_AUTO and not args.torch_adam and not args.no_f32_mfma_only:
@@ -427,7 +427,7 @@ def main(args):
         torch.cuda.synchronize()
         e2 = time.perf_counter() - t1
         f32_mfma_only = {"value": round(args.batch * n2 / e2, 3), "unit": "images/s", "ms_per_step": round(e2 / n2 * 1e3, 3), "steps": n2,
-                         "warmup": 3, "kernels": "fp32 MFMA only: Winograd F(4x4,3x3) / F(2x2,3x3) / direct (ONET_SPLIT=0)"}
+                         "warmup": 3, "kernels": "fp32 MFMA only: Winograd F(4x4,3x3) / direct (Settings(split=False))"}
         del loss2
         onet.settings = keep
     per_rank_ms, comm, per_rank, replicas_identical = None, None, None, None
@@ -479,13 +479,13 @@ def main(args):
         del Xh
 
     if rank == 0:
-        # multiplies the algorithm issues relative to direct convolution: F(4x4,3x3) 36 per 16 outputs x 9 taps -> 1/4,
-        # F(2x2,3x3) 16 per 4 x 9 -> 1/2.25 (the weight-gradient kernels F(3x3,4x4) / F(3x3,2x2) likewise)
-        # (the split-bf16 kernels issue THREE bf16 MFMAs per product term of the direct algorithm: 1/3)
-        REDUCTION = {"conv_wino4_kernel": 4.0, "conv_wino_kernel": 2.25, "conv_wino_wgrad_kernel": 2.25,
+        # multiplies the algorithm issues relative to direct convolution: F(4x4,3x3) 36 per 16 outputs x 9 taps -> 1/4 (the
+        # weight-gradient kernel F(3x3,4x4) likewise); the split kernels issue THREE 16-bit MFMAs per product term of the direct
+        # algorithm: 1/3
+        REDUCTION = {"conv_wino4_kernel": 4.0,
                      "conv_wino4_wgrad_kernel": 4.0, "conv3x3_split_kernel": 1.0 / 3.0, "conv3x3_split_wgrad_kernel": 1.0 / 3.0,
                      "conv3x3_split_pre_kernel": 1.0 / 3.0, "conv3x3_split_wgrad_pre_kernel": 1.0 / 3.0}
-        BF16 = ("conv3x3_bf16_kernel", "conv3x3_wgrad_bf16_kernel", "conv3x3_split_kernel", "conv3x3_split_wgrad_kernel",
+        BF16 = ("conv3x3_split_kernel", "conv3x3_split_wgrad_kernel",
                 "conv3x3_split_pre_kernel", "conv3x3_split_wgrad_pre_kernel")
         if bf16 and ops.CONVT_BF16:     # the ConvTranspose2d GEMMs take bf16 operands too (priced against the bf16 peak)
             BF16 += ("convt_gemm_kernel", "convt_wgrad_gemm_kernel")
@@ -496,12 +496,9 @@ def main(args):
         if convt_split:                 # ... or split bf16 operands (three bf16 MFMAs per term, fp32-level results)
             BF16 += ("convt_gemm_kernel", "convt_wgrad_gemm_kernel")
             REDUCTION.update({"convt_gemm_kernel": 1.0 / 3.0, "convt_wgrad_gemm_kernel": 1.0 / 3.0})
-        ALGO = {"conv_wino_kernel": "Winograd F(2x2,3x3) on fp32 MFMA (fwd + dgrad)",
-                "conv_wino4_kernel": "Winograd F(4x4,3x3) on fp32 MFMA (fwd + dgrad; BatchNorm statistics / backward-reduce "
+        ALGO = {"conv_wino4_kernel": "Winograd F(4x4,3x3) on fp32 MFMA (fwd + dgrad; BatchNorm statistics / backward-reduce "
                                      "epilogues)",
-                "conv_wino_wgrad_kernel": "Winograd F(2x2,3x3) weight gradient on fp32 MFMA, deterministic split-K",
                 "conv_wino4_wgrad_kernel": "Winograd F(3x3,4x4) weight gradient on fp32 MFMA, deterministic split-K",
-                "conv3x3_bf16_kernel": "direct implicit GEMM on v_mfma_f32_32x32x16_bf16 (bf16 operands, fp32 accumulate)",
                 "conv3x3_split_kernel": "fp32 convolution (fwd + dgrad) on the 16-bit matrix cores by operand splitting: x = hi + mid, "
                                         "w = hi + mid (forward: fp16 parts, input gradient: bf16 parts), 3 x v_mfma_f32_32x32x16_{f16,bf16} "
                                         "per term, fp32 accumulate; error <= the fp32 Winograd F(4x4) kernel's (forward: the direct kernel's)",
@@ -509,18 +506,19 @@ def main(args):
                 "conv3x3_split_pre_kernel": "fp32-level convolution (fwd + dgrad) on the 16-bit matrix cores, operands PRE-SPLIT by their producers "
                                             "(fp16 hi | mid slots [C/8][H][part][W][8]; under --conv bf16: one part of plain bf16): staging is an "
                                             "LDS-DMA copy, 3 x v_mfma_f32_32x32x16_f16 per term (plain bf16: 1), f32 accumulate, BatchNorm "
-                                            "statistics from the accumulators",
+                                            "statistics from the accumulators; round 5: the forward launches with statistics, the input "
+                                            "gradients with the BatchNorm-backward reduce in their epilogue and every plain-bf16 launch run "
+                                            "the v_mfma_f32_16x16x32 form (K-packed hi | mid operands)",
                 "conv3x3_split_wgrad_pre_kernel": "weight gradient from pre-split x and dz: LDS-DMA staging, fragments by ds_read_b64_tr_b16 "
-                                                  "(transposing LDS read), 3 MFMAs per term (plain bf16: 1), deterministic split-K",
-                "conv3x3_wgrad_bf16_kernel": "split-K weight gradient on v_mfma_f32_32x32x16_bf16",
+                                                  "(transposing LDS read), 3 x v_mfma_f32_16x16x32_f16 per term (plain bf16: 1), deterministic split-K",
                 "conv_fwd_kernel": "direct implicit GEMM on fp32 MFMA (stem, tiny maps)",
                 "conv_wgrad_kernel": "direct split-K weight gradient on fp32 MFMA (stem, tiny maps)",
                 "stem_conv_stats_kernel": "stem convolution (Cin = n_channels) + BatchNorm statistics, one streaming VALU pass "
                                           "(bound by writing z: see hbm_frac)",
                 "convt_gemm_kernel": "ConvTranspose2d forward / input-gradient GEMMs, 128x128 DMA-fed tiles (split bf16 "
-                                     "operands, fp32-level results, by default; fp32 MFMA under ONET_SPLIT=0; bf16 operands under --conv bf16)",
+                                     "operands, fp32-level results, by default; fp32 MFMA with Settings.split off; bf16 operands under --conv bf16)",
                 "convt_wgrad_gemm_kernel": "ConvTranspose2d weight-gradient GEMM, split-K (split bf16 operands by default; fp32 MFMA "
-                                           "under ONET_SPLIT=0; bf16 operands under --conv bf16)"}
+                                           "with Settings.split off; bf16 operands under --conv bf16)"}
         def kernel_table(records, where):
             tab = {}
             for kind, recs in records.items():
@@ -607,7 +605,9 @@ def main(args):
                "vs_baseline": None,
                "dtype": "bf16" if bf16 else "f32",
                "precision": ("bf16 MFMA operands (3x3 conv fwd/dgrad/wgrad: written as bf16 slots by their producers, round to nearest even; "
-                             "ConvTranspose2d GEMMs), f32 accumulation, f32 conv outputs, BatchNorm, loss, master weights and optimizer") if bf16 else
+                             "ConvTranspose2d GEMMs), f32 accumulation; conv outputs z of those layers STORED as bf16 (rounded once in the "
+                             "conv epilogue, as torch.autocast(bfloat16) stores an nn.Conv2d output; BatchNorm statistics from the f32 "
+                             "accumulators); BatchNorm arithmetic, activation gradients, loss, master weights and optimizer in f32") if bf16 else
                             ("f32 master tensors (inputs, outputs, conv outputs z, activation gradients, weights, optimizer) and f32-level results; "
                              "the 3x3 convolutions on maps >= 16 px wide (all but the Cin=1 stem) run on the 16-bit matrix pipe by operand splitting (each operand = hi + mid "
                              "fp16 parts of a power-of-two-scaled value: 22-bit operands, 3 MFMAs per term, f32 accumulate; error vs fp64 5e-8..1.5e-7 "
@@ -615,7 +615,7 @@ def main(args):
                              "BatchNorm / pooling / ConvTranspose2d kernels (same values as the fp32 passes: forward bit-identical to fp32 storage); "
                              "ConvTranspose2d GEMMs on bf16 parts split in registers (16-bit operands); every gradient element within 2e-4 of the "
                              "fp64 oracle under the run's own decisions incl. this B=32 dispatch (tests/test_gpu_gradients.py: 9.5e-5; the "
-                             "fp32-MFMA-only dispatch: 4.6e-5 on the comparable case); ONET_SPLIT=0 keeps the fp32-MFMA Winograd kernels "
+                             "fp32-MFMA-only dispatch: 4.6e-5 on the comparable case); Settings(split=False) keeps the fp32-MFMA Winograd kernels "
                              "(timed in f32_mfma_only)") if (conv in ("auto", "split") and ops.split_enabled()) else "f32 throughout (fp32 MFMA)",
                "data": "synthetic",
                "data_source": data_src,

@@ -128,34 +128,7 @@ int onet_conv3x3_winograd4_dgrad_bnreduce(const float* dz, int64_t dz_bs, const 
                                           int64_t da_bs, const float* z_prev, int64_t z_prev_bs,
                                           const float* save_prev, int group_images, float* part2,
                                           int B, int Cdz, int Cda, int H, int W, void* stream);
-/* BASELINE config 3's "bf16 MFMA conv path" for the same call sites (OV:47,51; forward and input gradient): bf16
- * OPERANDS on v_mfma_f32_32x32x16_bf16, fp32 tensors in HBM, fp32 accumulation.  The activations are rounded to bf16
- * (nearest-even) on their way into LDS, the weights once per optimizer step by the pack: wq_fwd [Cin/16][9][Cout][16],
- * wq_dgrad [Cout/16][9][Cin][16] (taps rotated), both bf16.  Requires Cin % 16 == 0 and Cout % 4 == 0 in the
- * orientation of the call.  Result == an fp32 convolution of the bf16-rounded operands up to summation order. */
-int onet_conv3x3_pack_weights_bf16(const float* w, void* wq_fwd, void* wq_dgrad, int Cout, int Cin, void* stream);
-int onet_conv3x3_bf16_fwd(const float* x, int64_t x_bs, const void* wq, float* z, int64_t z_bs,
-                          int B, int Cin, int Cout, int H, int W, void* stream);
-/* ... and the weight gradient of the same layers with bf16 operands (x and dz rounded on the way into LDS, fp32
- * accumulation, deterministic split-K): dw [Cout][Cin][3][3] fp32.  W % 4 == 0. */
-int64_t onet_conv3x3_wgrad_bf16_ws_bytes(int B, int Cin, int Cout, int H, int W);
-int onet_conv3x3_wgrad_bf16(const float* x, int64_t x_bs, const float* dz, int64_t dz_bs, float* dw, void* ws,
-                            int64_t ws_bytes, int B, int Cin, int Cout, int H, int W, int accumulate, void* stream);
-/* bf16 STORAGE of the conv operands (BASELINE config 3): the same kernels reading bf16 NCHW tensors (strides in elements)
- * that the producing kernels wrote next to their fp32 outputs (onet_bn_relu_apply_b, onet_bn_relu_bwd_apply_b,
- * onet_maxpool2_fwd_b, onet_convT2x2_fwd_b).  The fp32-input forms round to bf16 (nearest even) on the way into LDS, the
- * producers round the same way, so the results are bit-identical; the operand bytes halve.  x_is_bf16 / dz_is_bf16 select
- * per operand.  W % 8 == 0 and 16-byte aligned rows for the weight gradient. */
-int onet_bn_relu_apply_b(const float* z, int64_t z_bs, float* a, int64_t a_bs, void* a_bf16, int64_t a16_bs, const float* save,
-                         int B, int C, int HW, void* stream);                  /* a and / or its bf16 copy (either may be NULL) */
-int onet_bn_relu_bwd_apply_b(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save, const float* coef,
-                             float* dz, int64_t dz_bs, void* dz_bf16, int64_t dz16_bs, int B, int C, int HW, void* stream);
-int onet_maxpool2_fwd_b(const float* x, int64_t x_bs, float* y, int64_t y_bs, void* y_bf16, int64_t y16_bs, int B, int C, int H,
-                        int W, void* stream);                                   /* 1: y written, no bf16 copy (odd / unaligned map) */
-int onet_convT2x2_fwd_b(const float* x, int64_t x_bs, const float* wq, const float* bias, float* y, int64_t y_bs, void* y_bf16,
-                        int64_t y16_bs, int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int operand_bf16,
-        void* stream);
-/* ... the up-sampled tensor written pre-split (round 4: fp16 hi | mid slots [B][Ct/8][Ho][2][Wo][8], batch stride in 4-byte units), e.g.
+/* nn.ConvTranspose2d(k=2,s=2) forward with the up-sampled tensor written pre-split (round 4: fp16 hi | mid slots [B][Ct/8][Ho][2][Wo][8], batch stride in 4-byte units), e.g.
  * into the up-sampled channel groups of a pre-split concat buffer; no fp32 output.  Returns 1 (nothing done) outside the GEMM fast path. */
 int onet_convT2x2_fwd_p(const float* x, int64_t x_bs, const float* wq, const float* bias, void* yP, int64_t yP_bs, const void* y_amax,
                         int nparts, int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int operand_bf16, void* stream);
@@ -163,9 +136,6 @@ int onet_convT2x2_fwd_p(const float* x, int64_t x_bs, const float* wq, const flo
  * weights (nn.ConvTranspose2d layout [Cin][Ct][2][2]), the bias and the exact max |x| (x_amax, recorded by the pass that wrote x): the
  * fp16 parts are those of 2^k y with the guard exponent the slots select. */
 int onet_convT2x2_out_bound(const float* w, const float* bias, int Cin, int Ct, const void* x_amax, void* y_amax, void* stream);
-                                                                                /* 1: shape outside the GEMM path, nothing done */
-int onet_conv3x3_bf16_fwd_b(const void* x_bf16, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin,
-                            int Cout, int H, int W, void* stream);
 
 /* ---- fp32 3x3 convolution on the bf16 matrix cores by OPERAND SPLITTING (conv_split.hip; F.conv2d + input gradient, OV:47,51).
  * x = x_hi + x_mid, w = w_hi + w_mid with bf16 parts (hi = round-to-nearest-even, mid = bf16 of the remainder: 16 significant
@@ -184,8 +154,8 @@ int onet_conv3x3_split_pack_weights(const float* w, void* wq_fwd, void* wq_dgrad
 /* ABI 3 (round 4) -- fp16 parts with per-tensor power-of-two scales.  An fp16 pack holds the parts of 2^k w with k chosen from the
  * tensor's largest magnitude (amax_ws: 8 KB of device scratch) and carries (2^k, 2^-k) as two floats BEHIND the pack (buffers:
  * 2 * K * 9 * N 16-bit elements + 16 bytes).  Activations / gradients carry their largest magnitude in 64 "magnitude slots"
- * (unsigned[64 * 32]: one slot per 128-byte line, fp32 bit patterns, maximum over the slots; written with atomicMax by the producers: onet_bn_relu_apply_amax,
- * onet_bn_relu_bwd_apply_amax).  _conv_amax: forward (scale_always = 0: x is scaled only when its magnitude would leave fp16's
+ * (unsigned[64 * 32]: one slot per 128-byte line, fp32 bit patterns, maximum over the slots; written with atomicMax by the producers: onet_bn_relu_apply,
+ * onet_bn_relu_bwd_apply).  _conv_amax: forward (scale_always = 0: x is scaled only when its magnitude would leave fp16's
  * range -- a guard) or input gradient (scale_always = 1, the dgrad pack: the operand's amax is brought to [2^13, 2^14)) of a 3x3
  * convolution on fp16 parts, three v_mfma_f32_32x32x16_f16 per term; x_amax = NULL: unscaled.  part as _fwd_stats.
  * _wgrad_f16: the weight gradient on fp16 parts of x (guard, may be NULL) and dz (always scaled; required); save != NULL:
@@ -217,9 +187,10 @@ int onet_split_pack_act(const float* x, int64_t x_bs, void* xs, int64_t xs_bs, i
  * reduce pass of the FIRST unit (OV:48-49's backward: sum dy, sum dy xhat per channel, dy = da where the unit's output was positive)
  * taken from the accumulator tile in the epilogue -- this launch's output IS that unit's da.  z_prev / save: the first unit's
  * pre-activation [B][Cout][H][W] fp32 and coefficients [G][4][Cout] (group_images per statistics group; 0: one group); rec4
- * [onet_conv3x3_split_pre_nparts(B, H, W)][Cout][4]: records in onet_bn_relu_bwd_reduce's format, ready for onet_bn_bwd_finalize(_bound);
+ * [onet_conv3x3_split_pre_nparts(B, H, W)][Cout][4]: records in onet_bn_relu_bwd_reduce's format, ready for onet_bn_bwd_finalize;
  * da_amax (may be NULL): magnitude slots that receive max |da|.  Here Cin = channels of dz (the reduction), Cout = channels of da.
- * Returns 1, nothing launched, where the shape is not taken (maps not made of full 16 x 32 tiles; 16-pixel maps with (hi | mid) parts). */
+ * Returns 1, nothing launched, where the shape is not taken (maps not made of full 16 x 32 tiles; 16-pixel maps with (hi | mid) parts;
+ * fewer than four K chunks per tile, where the epilogue's z loads are not covered). */
 int onet_conv3x3_split_dgrad_pre_bnreduce(const void* dzs, int64_t dzs_bs, const void* dz_amax, int scale_always, const void* wq, int wq_f16,
                                           float* da, int64_t da_bs, const void* z_prev, int z_bf16, int64_t z_bs, const float* save, int group_images,
                                           float* rec4, void* da_amax, int B, int Cin, int Cout, int H, int W, void* stream);
@@ -272,21 +243,6 @@ int onet_conv3x3_stem_nparts(int B, int Cin, int Cout, int H, int W);
 int onet_conv3x3_stem_fwd_stats(const float* x, int64_t x_bs, const float* w, float* z, int64_t z_bs, float* part, int B, int Cin,
                                 int Cout, int H, int W, int twin_B, float twin_bias, void* stream);
 
-/* EXPERIMENT (groundwork for a channel-blocked bf16 operand layout): onet_conv3x3_bf16_fwd_b with the bf16 copy of x laid out as
- * [C/8][H][W][8] per image (x_bs in elements, 16-byte aligned).  Not used by the module yet. */
-int onet_conv3x3_bf16_fwd_blk(const void* x_blk, int64_t x_bs, const void* wq, float* z, int64_t z_bs, int B, int Cin, int Cout,
-                              int H, int W, void* stream);
-
-/* Forward of a Conv-BatchNorm pair on the bf16 kernels with the BatchNorm batch statistics of z taken from the final
- * accumulators (F.conv2d + the statistics half of nn.BatchNorm2d, OV:47-48 / 51-52): part [Cout][nparts][3] = (n, mean, M2) per
- * tile, consumed by onet_bn_finalize_cm.  nparts = onet_conv3x3_bf16_nparts(B, H, W); 0 = the map is not made of full tiles
- * (use onet_conv3x3_bf16_fwd[_b] + onet_bn_stats_partial).  x: fp32, or the bf16 copy when x_is_bf16. */
-int onet_conv3x3_bf16_nparts(int B, int H, int W);
-int onet_conv3x3_bf16_fwd_stats(const void* x, int x_is_bf16, int64_t x_bs, const void* wq, float* z, int64_t z_bs, float* part, int B,
-                                int Cin, int Cout, int H, int W, void* stream);
-int onet_conv3x3_wgrad_bf16_b(const void* x, int x_is_bf16, int64_t x_bs, const void* dz, int dz_is_bf16, int64_t dz_bs,
-                              float* dw, void* ws, int64_t ws_bytes, int B, int Cin, int Cout, int H, int W, int accumulate,
-                              void* stream);
 /* Larger-tile weight gradient: Winograd F(3x3,4x4) (4x fewer multiplies than direct, 1.78x fewer than the F(2x2,3x3)
  * kernel below; 6x6 input tiles, 4x4 tiles of dz in the filter's role, the points of onet_conv3x3_winograd4_fwd; split-K
  * 36-position slabs folded by A'^T . A').  Where onet_conv3x3_winograd4_wgrad_ok() returns 1 (W % 32 == 0, H % 4 == 0,
@@ -328,45 +284,51 @@ int onet_bn_stats_partial(const float* z, int64_t z_bs, float* part, int nparts,
  *   scale = gamma*invstd
  *   running_mean = (1-m)*running_mean + m*mean
  *   running_var  = (1-m)*running_var  + m*var*N/(N-1)     (unbiased, verified SURVEY §8c)
- * save = [4][C]: mean, invstd, scale, beta.  running_* may be NULL. */
-int onet_bn_finalize(const float* part, int nparts, int64_t count, const float* gamma,
-                     const float* beta, float* running_mean, float* running_var,
-                     float momentum, float eps, float* save, int C, void* stream);
-/* onet_bn_finalize for channel-major partials: channel c's records are part[c * c_stride + 3 * p], p < nparts. */
-int onet_bn_finalize_cm(const float* part, int nparts, int64_t c_stride, const float* gamma,
-                        const float* beta, float* running_mean, float* running_var,
-                        float momentum, float eps, float* save, int C, void* stream);
+ * save = [4][C]: mean, invstd, scale, beta.  running_* may be NULL.
+ * act_amax (may be NULL): 64 magnitude slots that receive the bound |gamma| sqrt(N - 1) + |beta| of the activation relu(bn(z)) -- what
+ * the pre-split producers below scale by (round 5: the former _act forms are these entry points). */
+int onet_bn_finalize(const float* part, int nparts, int64_t count, const float* gamma, const float* beta, float* running_mean,
+                     float* running_var, float momentum, float eps, float* save, void* act_amax, int C, void* stream);
+/* onet_bn_finalize for channel-major partials: channel c's records are part[c * c_stride + 3 * p], p < groups * nparts (groups >= 1
+ * statistics groups, see below; c_stride >= groups * nparts * 3). */
+int onet_bn_finalize_cm(const float* part, int nparts, int64_t c_stride, const float* gamma, const float* beta, float* running_mean,
+                        float* running_var, float momentum, float eps, float* save, void* act_amax, int groups, int C, void* stream);
 /* eval-mode coefficients from running stats: same `save` layout. */
 int onet_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, float* save, int C, void* stream);
-/* a = max(0, (z-mean)*scale + beta)   (BN + nn.ReLU, OV:48-49) */
-int onet_bn_relu_apply(const float* z, int64_t z_bs, float* a, int64_t a_bs, const float* save,
+/* a = max(0, (z-mean)*scale + beta)   (BN + nn.ReLU, OV:48-49).  z_bf16: z is stored as bf16 (ABI 4, below).  amax (may be NULL): 64
+ * magnitude slots (zeroed by the caller; the statistics groups of a twin batch share them) that receive max a -- the overflow guard
+ * of the fp16-split convolution that consumes the activation.  group_images: statistics groups, below. */
+int onet_bn_relu_apply(const void* z, int z_bf16, int64_t z_bs, float* a, int64_t a_bs, const float* save, void* amax, int group_images,
                        int B, int C, int HW, void* stream);
 /* relu(bn(z)) AND its 2x2 max-pooling in one pass (nn.BatchNorm2d + nn.ReLU of an encoder block followed by nn.MaxPool2d(2),
- * OV:48-49 / 52-53 -> OV:67): a [B,C,H,W] (and / or its bf16 copy a_bf16), y [B,C,H/2,W/2] (and / or y_bf16); any of the four may be
- * NULL as long as one of each pair is given.  Bit-identical to onet_bn_relu_apply[_b] followed by onet_maxpool2_fwd[_b].
- * Returns 1 (nothing done) unless H % 2 == 0, W % 4 == 0 and rows are 16-byte aligned. */
-int onet_bn_relu_apply_pool(const float* z, int64_t z_bs, float* a, int64_t a_bs, void* a_bf16, int64_t a16_bs, float* y, int64_t y_bs,
-                            void* y_bf16, int64_t y16_bs, const float* save, int B, int C, int H, int W, void* stream);
+ * OV:48-49 / 52-53 -> OV:67): a [B,C,H,W], y [B,C,H/2,W/2].  Bit-identical to onet_bn_relu_apply followed by onet_maxpool2_fwd; amax
+ * as above (the pooled tensor has the same maximum).  Returns 1 (nothing done) unless H % 2 == 0, W % 4 == 0 and rows are 16-byte
+ * aligned. */
+int onet_bn_relu_apply_pool(const float* z, int64_t z_bs, float* a, int64_t a_bs, float* y, int64_t y_bs, const float* save,
+                            void* amax, int B, int C, int H, int W, void* stream);
 
 /* backward of BN(train)+ReLU.  dy = da * ((z-mean)*scale+beta > 0);
- * pass 1: part2 [nparts][C][4] = (sum dy, sum dy*xhat) as (hi, lo) float pairs of fp64 sums;
+ * pass 1: part2 [nparts][C][4] = (sum dy, sum dy*xhat) as (hi, lo) float pairs of fp64 sums (nparts a multiple of B: the records of
+ *         image b's chunks are rows b * chunks .., so a statistics group's records are consecutive rows); da_amax (may be NULL): 64
+ *         magnitude slots that receive max |da|;
  * finalize: dgamma (+)= sum dy*xhat, dbeta (+)= sum dy, coef [4][C] = (hi, lo) pairs of
- *           c1 = sum dy / N and c2 = sum dy*xhat / N;
+ *           c1 = sum dy / N and c2 = sum dy*xhat / N; nparts, count: per group; part2 [groups][nparts][C][4], coef [groups][4][C];
+ *           dz_amax (may be NULL, then save / da_amax may be NULL too): receives the bound of |dz| (as onet_bn_bwd_bound) -- da_amax
+ *           must be complete, i.e. every reduce launch of the tensor precedes the first finalize;
  * pass 2: dz = scale * (dy - c1 - xhat*c2)     [train]   or  dz = scale*dy [eval: coef NULL],
- *         evaluated in fp64 per element like ATen's CPU kernel (accscalar_t = double). */
-int onet_bn_relu_bwd_reduce(const float* da, int64_t da_bs, const float* z, int64_t z_bs,
-                            const float* save, float* part2, int nparts, int B, int C, int HW,
-                            void* stream);
-int onet_bn_bwd_finalize(const float* part2, int nparts, int64_t count, float* dgamma, float* dbeta,
-                         float* coef, int accumulate, int C, void* stream);
+ *         evaluated in fp64 per element like ATen's CPU kernel (accscalar_t = double); amax (may be NULL): 64 magnitude slots that
+ *         receive max |dz|, what the fp16-split gradient kernels scale dz by (onet_conv3x3_split_conv_amax, onet_conv3x3_split_wgrad_f16). */
+int onet_bn_relu_bwd_reduce(const float* da, int64_t da_bs, const void* z, int z_bf16, int64_t z_bs, const float* save, float* part2,
+                            int nparts, void* da_amax, int group_images, int B, int C, int HW, void* stream);
+int onet_bn_bwd_finalize(const float* part2, int nparts, int64_t count, float* dgamma, float* dbeta, float* coef, int accumulate,
+                         int groups, int C, const float* save, const void* da_amax, void* dz_amax, void* stream);
 /* onet_bn_bwd_finalize for the channel-major two-float records of onet_conv3x3_winograd4_dgrad_bnreduce:
  * channel c's records are part2[c * c_stride + 2 * p], p < nparts. */
 int onet_bn_bwd_finalize_cm(const float* part2, int nparts, int64_t c_stride, int64_t count, float* dgamma,
                             float* dbeta, float* coef, int accumulate, int C, void* stream);
-int onet_bn_relu_bwd_apply(const float* da, int64_t da_bs, const float* z, int64_t z_bs,
-                           const float* save, const float* coef, float* dz, int64_t dz_bs,
-                           int B, int C, int HW, void* stream);
+int onet_bn_relu_bwd_apply(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save, const float* coef,
+                           float* dz, int64_t dz_bs, void* amax, int group_images, int B, int C, int HW, void* stream);
 /* ---- Round 4, pre-split producers (bn.hip).  The BatchNorm + ReLU passes (OV:48-49, 52-53 and their backward) write their result
  * straight in the operand form of the split-fp16 convolution that consumes it: fp16 (hi, mid) parts in the slot layout
  * [B][C/8][H][2][W][8] (onet_split_pack_act's; batch strides in 4-byte units; C % 8 == 0).  Values are bit for bit those of the fp32
@@ -374,7 +336,7 @@ int onet_bn_relu_bwd_apply(const float* da, int64_t da_bs, const float* z, int64
  * 2 x 2-pooled values to ys (pre-split) or y (fp32); returns 1 when the shape is not taken (odd H / W, alignment).
  * _bwd_apply_split: dz as parts of 2^k dz, k chosen (conv_split.hip: amax_scale, always) from the magnitude slots dz_amax, which
  * must hold an upper bound of |dz| BEFORE the launch: onet_bn_bwd_bound writes it from the layer's coefficients and the exact
- * max |da| (da_amax: recorded by onet_bn_relu_bwd_reduce_amax or onet_absmax_slots); the consumers read the same slots.
+ * max |da| (da_amax: recorded by onet_bn_relu_bwd_reduce or onet_absmax_slots); the consumers read the same slots.
  * nparts = 2: the fp16 (hi | mid) slots above; nparts = 1: PLAIN bf16 operands, one part -- [B][C/8][H][W][8] bf16, rounded to
  * nearest even, unscaled (dz_amax may be NULL) -- for BASELINE configs[2]'s bf16 MFMA conv path (the same LDS-DMA staged kernels
  * with one part: wq_f16 / f16 = 2 in onet_conv3x3_split_fwd_pre / _wgrad_pre / _pack_weights / onet_split_pack_act).
@@ -392,66 +354,33 @@ int onet_bn_relu_apply_pool_split(const void* z, int z_bf16, int64_t z_bs, void*
                                   float* y, int64_t y_bs, const float* save, const void* act_amax, int nparts, int group_images, int B, int C,
                                   int H, int W, void* stream);
 /* act_amax (may be NULL: unscaled): the activation's magnitude slots holding the bound |gamma| sqrt(N - 1) + |beta| written by
- * onet_bn_finalize_act / _cm_act (onet_bn_finalize / _cm that also record it); the fp16 parts are those of 2^k a with the GUARD
+ * onet_bn_finalize / _cm; the fp16 parts are those of 2^k a with the GUARD
  * exponent the slots select (0 unless the bound reaches 2^15: a loaded checkpoint with a huge gamma), undone by the consumers, which
  * read the same slots.  A concat buffer has one set of slots per producer (skip groups / up-sampled groups). */
-int onet_bn_finalize_act(const float* part, int nparts, int64_t count, const float* gamma, const float* beta, float* running_mean,
-                         float* running_var, float momentum, float eps, float* save, void* act_amax, int C, void* stream);
-int onet_bn_finalize_cm_act(const float* part, int nparts, int64_t c_stride, const float* gamma, const float* beta, float* running_mean,
-                            float* running_var, float momentum, float eps, float* save, void* act_amax, int groups, int C, void* stream);
-/* (_cm_act: act_amax may be NULL; c_stride >= groups * nparts * 3.  _bwd_reduce_amax: da_amax may be NULL; part2 [nparts][C][4] with
- * nparts a multiple of B: the records of image b's chunks are rows b * chunks .., so a group's records are consecutive rows) */
-int onet_bn_relu_bwd_reduce_amax(const float* da, int64_t da_bs, const void* z, int z_bf16, int64_t z_bs, const float* save, float* part2,
-                                 int nparts, void* da_amax, int group_images, int B, int C, int HW, void* stream);
 int onet_bn_bwd_bound(const float* save, const float* coef, const void* da_amax, int64_t count, void* dz_amax, int C, void* stream);
-/* onet_bn_bwd_finalize that also writes the bound of |dz| (as onet_bn_bwd_bound) into dz_amax: da_amax must be complete, i.e. every
- * reduce launch of the tensor precedes the first finalize.  nparts, count: per group; part2 [groups][nparts][C][4], coef [groups][4][C];
- * dz_amax NULL: no bound (plain bf16 operands), then save / da_amax may be NULL too. */
-int onet_bn_bwd_finalize_bound(const float* part2, int nparts, int64_t count, float* dgamma, float* dbeta, float* coef, int accumulate,
-                               int groups, int C, const float* save, const void* da_amax, void* dz_amax, void* stream);
 int onet_bn_relu_bwd_apply_split(const float* da, int64_t da_bs, const void* z, int z_bf16, int64_t z_bs, const float* save, const float* coef,
                                  void* dzs, int64_t dzs_bs, const void* dz_amax, int nparts, int group_images, int B, int C, int H, int W,
                                  void* stream);
-/* onet_bn_relu_apply / onet_bn_relu_apply_pool that also record max a (a >= 0) in 64 magnitude slots (zeroed by the caller; the
- * statistics groups of a twin batch share them; the pooled tensor has the same maximum): the overflow guard of the fp16-split
- * convolution that consumes the activation (_apply_amax, _bwd_apply_amax: amax may be NULL; group_images as above).  _pool_amax
- * returns 1 when the shape is not taken (as onet_bn_relu_apply_pool). */
-int onet_bn_relu_apply_amax(const void* z, int z_bf16, int64_t z_bs, float* a, int64_t a_bs, const float* save, void* amax, int group_images,
-                            int B, int C, int HW, void* stream);
-int onet_bn_relu_apply_pool_amax(const float* z, int64_t z_bs, float* a, int64_t a_bs, float* y, int64_t y_bs, const float* save,
-                                 void* amax, int B, int C, int H, int W, void* stream);
-/* ... the same pass, also recording max |dz| in 64 magnitude slots (unsigned[64 * 32], zeroed by the caller; several launches -- the
- * statistics groups of a twin batch -- may share them): what the fp16-split gradient kernels scale dz by (onet_conv3x3_split_conv_amax,
- * onet_conv3x3_split_wgrad_f16). */
-int onet_bn_relu_bwd_apply_amax(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save, const float* coef,
-                                float* dz, int64_t dz_bs, void* amax, int group_images, int B, int C, int HW, void* stream);
 
 /* ---- K4: MaxPool2d(2) (OV:67) ------------------------------------------- */
 int onet_maxpool2_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs,
                       int B, int C, int H, int W, void* stream);
 /* dx = route dy to the first maximum of each 2x2 window (recomputed from x); rows/cols
- * beyond 2*floor(H/2) get 0.  accumulate: dx += instead of dx =. */
-int onet_maxpool2_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs,
-                      float* dx, int64_t dx_bs, int B, int C, int H, int W, int accumulate,
+ * beyond 2*floor(H/2) get 0.  accumulate: dx += instead of dx = (add must be NULL then).
+ * add [+ add2] (nullable): dx = maxpool2 backward + add [+ add2] -- the gradient of a tensor that feeds BOTH the pooling and a skip
+ * connection (OV:141-149: x1..x4 go to the next Down and to an Up's torch.cat; x1 is also returned, OV:152, and enters the head:
+ * add2) in one pass instead of autograd's separate full-tensor adds. */
+int onet_maxpool2_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, const float* add, int64_t add_bs,
+                      const float* add2, int64_t add2_bs, float* dx, int64_t dx_bs, int B, int C, int H, int W, int accumulate,
                       void* stream);
-/* dx = maxpool2 backward + add [+ add2]: the gradient of a tensor that feeds BOTH the pooling and a skip connection
- * (OV:141-149: x1..x4 go to the next Down and to an Up's torch.cat; x1 is also returned, OV:152, and enters the
- * head: add2, nullable) in one pass instead of autograd's separate full-tensor adds. */
-int onet_maxpool2_bwd_add(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, const float* add,
-                          int64_t add_bs, const float* add2, int64_t add2_bs, float* dx, int64_t dx_bs,
-                          int B, int C, int H, int W, void* stream);
-/* onet_maxpool2_bwd_add for an x that is the OUTPUT a = relu(bn(z)) of a Conv-BN-ReLU unit (OV:58 -> 67): the sum it
+/* onet_maxpool2_bwd (with add / add2) for an x that is the OUTPUT a = relu(bn(z)) of a Conv-BN-ReLU unit (OV:58 -> 67): the sum it
  * writes is that unit's activation gradient, so the unit's first BatchNorm-backward pass rides along: part2
  * [B * bands][C][4] = onet_bn_relu_bwd_reduce's records (bands = onet_maxpool2_bwd_bn_bands(H, W), 0 = fused form not
  * available), save [B / group_images][4][C].  add / add2 nullable. */
 int onet_maxpool2_bwd_bn_bands(int H, int W);
-int onet_maxpool2_bwd_add_bnreduce(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, const float* add,
-                                   int64_t add_bs, const float* add2, int64_t add2_bs, float* dx, int64_t dx_bs,
-                                   const float* z, int64_t z_bs, const float* save, int group_images,
-                                   float* part2, int B, int C, int H, int W, void* stream);
-/* ... x may be NULL (pre-split storage: x = relu(bn(z)) is recomputed from z and the coefficients, the same bits); dx_amax: 64
- * magnitude slots that receive max |dx| (dx is the producing layer's activation gradient: onet_bn_bwd_bound). */
-int onet_maxpool2_bwd_add_bnreduce_amax(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, const float* add, int64_t add_bs,
+/* x may be NULL (pre-split storage: x = relu(bn(z)) is recomputed from z and the coefficients, the same bits); dx_amax (may be NULL): 64
+ * magnitude slots that receive max |dx| (dx is the producing layer's activation gradient: onet_bn_bwd_bound); z_bf16: ABI 4, above. */
+int onet_maxpool2_bwd_add_bnreduce(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, const float* add, int64_t add_bs,
                                         const float* add2, int64_t add2_bs, float* dx, int64_t dx_bs, const void* z, int z_bf16, int64_t z_bs,
                                         const float* save, int group_images, float* part2, void* dx_amax, int B, int C, int H, int W,
                                         void* stream);

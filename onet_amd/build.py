@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libonet_hip.so")
-SOURCES = ["abi.cpp", "conv_mfma.hip", "conv_wino4.hip", "conv_wino4w.hip", "conv_bf16.hip", "conv_split.hip", "convt_gemm.hip", "stem.hip", "bn.hip", "spatial.hip", "head_loss.hip", "optim.hip", "evalside.hip", "clutter.hip"]
+SOURCES = ["abi.cpp", "conv_mfma.hip", "conv_wino4.hip", "conv_wino4w.hip", "conv_split.hip", "convt_gemm.hip", "stem.hip", "bn.hip", "spatial.hip", "head_loss.hip", "optim.hip", "evalside.hip", "clutter.hip"]
 ARCH = "gfx950"
 
 

@@ -192,11 +192,6 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
 }
 
 // a = max(0, (z-mean)*scale + beta)  (the centred form: z*scale+shift cancels badly when |mean| >> std); one block per 4096-element chunk of a (b, c) plane
-typedef __bf16 bn_bf16x4 __attribute__((ext_vector_type(4)));
-static __device__ __forceinline__ void store_bf16x4(__bf16* p, float4 q) {     // round to nearest even, as the conv kernels' staging
-    bn_bf16x4 v = {(__bf16)q.x, (__bf16)q.y, (__bf16)q.z, (__bf16)q.w};
-    *reinterpret_cast<bn_bf16x4*>(p) = v;
-}
 
 // block maximum of v into one of the 64 magnitude slots.  The slots are 128 bytes apart (one cache line each: the updates of a launch's
 // tens of thousands of blocks spread over 64 lines / L2 channels instead of queueing on one) and a block commits ONCE: wave maxima
@@ -234,14 +229,11 @@ template <> __device__ __forceinline__ float4 bn_ldz4<__bf16>(const __bf16* p) {
                        __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
 }
 
-// a16 (optional): a bf16 copy of the activation for the bf16 conv kernels (bf16 STORAGE of their operands); a may be NULL
-// when only the bf16 copy is wanted
 template <typename ZT = float>
 __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const ZT* __restrict__ z, int64_t z_bs,
                                                             float* __restrict__ a, int64_t a_bs,
                                                             const float* __restrict__ save, int C, int HW,
-                                                            int chunks, __bf16* __restrict__ a16 = nullptr,
-                                                            int64_t a16_bs = 0, unsigned* __restrict__ amax = nullptr, int gimg = 0) {
+                                                            int chunks, unsigned* __restrict__ amax = nullptr, int gimg = 0) {
     // amax: 64 magnitude slots of the activation (the range guard of the fp16-split convolution that consumes it)
     float vmax = 0.f;
     const int plane = blockIdx.x / chunks, ch = blockIdx.x % chunks;
@@ -249,10 +241,9 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const ZT* __restrict
     if (gimg) save += (int64_t)(b / gimg) * 4 * C;        // statistics groups = consecutive batch slices of gimg images, save [G][4][C]
     const float mean = save[c], sc = save[2 * C + c], sh = save[3 * C + c];
     const ZT* src = z + (int64_t)b * z_bs + (int64_t)c * HW;
-    float* dst = a ? a + (int64_t)b * a_bs + (int64_t)c * HW : nullptr;
-    __bf16* d16 = a16 ? a16 + (int64_t)b * a16_bs + (int64_t)c * HW : nullptr;
+    float* dst = a + (int64_t)b * a_bs + (int64_t)c * HW;
     const int beg = ch * 4096, end = min(beg + 4096, HW);
-    if (((HW & 3) == 0) && ((z_bs & 3) == 0) && ((a_bs & 3) == 0) && ((a16_bs & 3) == 0)) {
+    if (((HW & 3) == 0) && ((z_bs & 3) == 0) && ((a_bs & 3) == 0)) {
 #if ONET_BN_BATCH
         if (end - beg == 4096) {          // full chunk: all four 16-byte loads of the thread in flight before the first use
             const int i0 = beg + threadIdx.x * 4;
@@ -265,8 +256,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const ZT* __restrict
                 q[k].y = fmaxf(fmaf(q[k].y - mean, sc, sh), 0.f);
                 q[k].z = fmaxf(fmaf(q[k].z - mean, sc, sh), 0.f);
                 q[k].w = fmaxf(fmaf(q[k].w - mean, sc, sh), 0.f);
-                if (dst) *reinterpret_cast<float4*>(dst + i0 + 1024 * k) = q[k];
-                if (d16) store_bf16x4(d16 + i0 + 1024 * k, q[k]);
+                *reinterpret_cast<float4*>(dst + i0 + 1024 * k) = q[k];
                 vmax = fmaxf(fmaxf(vmax, fmaxf(q[k].x, q[k].y)), fmaxf(q[k].z, q[k].w));
             }
             amax_commit(vmax, amax);
@@ -279,15 +269,13 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const ZT* __restrict
             q.y = fmaxf(fmaf(q.y - mean, sc, sh), 0.f);
             q.z = fmaxf(fmaf(q.z - mean, sc, sh), 0.f);
             q.w = fmaxf(fmaf(q.w - mean, sc, sh), 0.f);
-            if (dst) *reinterpret_cast<float4*>(dst + i) = q;
-            if (d16) store_bf16x4(d16 + i, q);
+            *reinterpret_cast<float4*>(dst + i) = q;
             vmax = fmaxf(fmaxf(vmax, fmaxf(q.x, q.y)), fmaxf(q.z, q.w));
         }
     } else {
         for (int i = beg + threadIdx.x; i < end; i += 256) {
             const float v = fmaxf(fmaf(bn_ldz<ZT>(src + i) - mean, sc, sh), 0.f);
-            if (dst) dst[i] = v;
-            if (d16) d16[i] = (__bf16)v;
+            dst[i] = v;
             vmax = fmaxf(vmax, v);
         }
     }
@@ -295,14 +283,12 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const ZT* __restrict
 }
 
 // The same pass for an encoder output that is max-pooled next (OV:49/53 -> nn.MaxPool2d(2), OV:67): a thread owns a 2 x 4 patch,
-// writes the activation (and / or its bf16 copy) and the two pooled values of the patch (and / or their bf16 copies) -- the
+// writes the activation and the two pooled values of the patch -- the
 // separate pooling pass re-read the whole activation.  Same arithmetic as bn_relu_apply_kernel + maxpool2_fwd_kernel: identical
 // bits.  Requires H % 2 == 0, W % 4 == 0 and 16-byte aligned rows (host-checked).
-typedef __bf16 bn_bf16x2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void bn_relu_apply_pool_kernel(const float* __restrict__ z, int64_t z_bs, float* __restrict__ a,
-                                                                 int64_t a_bs, __bf16* __restrict__ a16, int64_t a16_bs,
-                                                                 float* __restrict__ y, int64_t y_bs, __bf16* __restrict__ y16,
-                                                                 int64_t y16_bs, const float* __restrict__ save, int C, int H, int W,
+                                                                 int64_t a_bs, float* __restrict__ y, int64_t y_bs,
+                                                                 const float* __restrict__ save, int C, int H, int W,
                                                                  int blocks_per_plane, unsigned* __restrict__ amax = nullptr) {
     const int plane = blockIdx.x / blocks_per_plane, blk = blockIdx.x % blocks_per_plane;
     const int b = plane / C, c = plane % C;
@@ -321,20 +307,12 @@ __global__ __launch_bounds__(256) void bn_relu_apply_pool_kernel(const float* __
     r0.z = fmaxf(fmaf(r0.z - mean, sc, sh), 0.f); r0.w = fmaxf(fmaf(r0.w - mean, sc, sh), 0.f);
     r1.x = fmaxf(fmaf(r1.x - mean, sc, sh), 0.f); r1.y = fmaxf(fmaf(r1.y - mean, sc, sh), 0.f);
     r1.z = fmaxf(fmaf(r1.z - mean, sc, sh), 0.f); r1.w = fmaxf(fmaf(r1.w - mean, sc, sh), 0.f);
-    if (a) {
-        float* d = a + (int64_t)b * a_bs + off;
-        *reinterpret_cast<float4*>(d) = r0;
-        *reinterpret_cast<float4*>(d + W) = r1;
-    }
-    if (a16) {
-        __bf16* d = a16 + (int64_t)b * a16_bs + off;
-        store_bf16x4(d, r0);
-        store_bf16x4(d + W, r1);
-    }
+    float* d = a + (int64_t)b * a_bs + off;
+    *reinterpret_cast<float4*>(d) = r0;
+    *reinterpret_cast<float4*>(d + W) = r1;
     const float m0 = fmaxf(fmaxf(r0.x, r0.y), fmaxf(r1.x, r1.y)), m1 = fmaxf(fmaxf(r0.z, r0.w), fmaxf(r1.z, r1.w));
     const int64_t yo = (int64_t)c * (H >> 1) * (W >> 1) + (int64_t)pr * (W >> 1) + 2 * q;
-    if (y) *reinterpret_cast<float2*>(y + (int64_t)b * y_bs + yo) = make_float2(m0, m1);
-    if (y16) *reinterpret_cast<bn_bf16x2*>(y16 + (int64_t)b * y16_bs + yo) = bn_bf16x2{(__bf16)m0, (__bf16)m1};
+    *reinterpret_cast<float2*>(y + (int64_t)b * y_bs + yo) = make_float2(m0, m1);
     amax_commit(fmaxf(m0, m1), amax);               // the pooled tensor has the same maximum: one set of slots serves both
 }
 
@@ -846,8 +824,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
                                                                 const float* __restrict__ save,
                                                                 const float* __restrict__ coef,
                                                                 float* __restrict__ dz, int64_t dz_bs, int C,
-                                                                int HW, int chunks, __bf16* __restrict__ dz16 = nullptr,
-                                                                int64_t dz16_bs = 0, unsigned* __restrict__ amax = nullptr, int gimg = 0) {
+                                                                int HW, int chunks, unsigned* __restrict__ amax = nullptr, int gimg = 0) {
     // amax: 64 magnitude slots of dz (fp32 bit patterns; atomicMax is an order-independent maximum): the fp16-split convolution
     // kernels that consume dz scale it by a power of two chosen from this (conv_split.hip, amax_scale)
     float vmax = 0.f;
@@ -863,10 +840,9 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
     const double c2 = coef ? (double)coef[2 * C + c] + (double)coef[3 * C + c] : 0.0;
     const float* zs = z + (int64_t)b * z_bs + (int64_t)c * HW;
     const float* ds = da + (int64_t)b * da_bs + (int64_t)c * HW;
-    float* out = dz ? dz + (int64_t)b * dz_bs + (int64_t)c * HW : nullptr;
-    __bf16* o16 = dz16 ? dz16 + (int64_t)b * dz16_bs + (int64_t)c * HW : nullptr;
+    float* out = dz + (int64_t)b * dz_bs + (int64_t)c * HW;
     const int beg = ch * 4096, end = min(beg + 4096, HW);
-    if (((HW & 3) == 0) && ((z_bs & 3) == 0) && ((da_bs & 3) == 0) && ((dz_bs & 3) == 0) && ((dz16_bs & 3) == 0)) {
+    if (((HW & 3) == 0) && ((z_bs & 3) == 0) && ((da_bs & 3) == 0) && ((dz_bs & 3) == 0)) {
 #if ONET_BN_BATCH
         if (end - beg == 4096) {          // full chunk: the thread's eight 16-byte loads in flight before the first use
             const int i0 = beg + threadIdx.x * 4;
@@ -885,8 +861,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
                     const double dy = fmaf(zz[e] - mean, sc, sh) > 0.f ? (double)gg[e] : 0.0;
                     o[e] = (float)(scd * (dy - c1 - (((double)zz[e] - meand) * invd) * c2));
                 }
-                if (out) *reinterpret_cast<float4*>(out + i0 + 1024 * k) = make_float4(o[0], o[1], o[2], o[3]);
-                if (o16) store_bf16x4(o16 + i0 + 1024 * k, make_float4(o[0], o[1], o[2], o[3]));
+                *reinterpret_cast<float4*>(out + i0 + 1024 * k) = make_float4(o[0], o[1], o[2], o[3]);
                 vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
             }
             amax_commit(vmax, amax);
@@ -903,16 +878,14 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
                 const double dy = fmaf(zz[k] - mean, sc, sh) > 0.f ? (double)gg[k] : 0.0;
                 o[k] = (float)(scd * (dy - c1 - (((double)zz[k] - meand) * invd) * c2));
             }
-            if (out) *reinterpret_cast<float4*>(out + i) = make_float4(o[0], o[1], o[2], o[3]);
-            if (o16) store_bf16x4(o16 + i, make_float4(o[0], o[1], o[2], o[3]));
+            *reinterpret_cast<float4*>(out + i) = make_float4(o[0], o[1], o[2], o[3]);
             vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
         }
     } else {
         for (int i = beg + threadIdx.x; i < end; i += 256) {
             const double dy = fmaf(zs[i] - mean, sc, sh) > 0.f ? (double)ds[i] : 0.0;
             const float v = (float)(scd * (dy - c1 - (((double)zs[i] - meand) * invd) * c2));
-            if (out) out[i] = v;
-            if (o16) o16[i] = (__bf16)v;
+            out[i] = v;
             vmax = fmaxf(vmax, fabsf(v));
         }
     }
@@ -940,36 +913,18 @@ int onet_bn_stats_partial(const float* z, int64_t z_bs, float* part, int nparts,
     return check_launch("bn_stats_partial_kernel");
 }
 
-int onet_bn_finalize(const float* part, int nparts, int64_t count, const float* gamma, const float* beta,
-                     float* running_mean, float* running_var, float momentum, float eps, float* save, int C,
-                     void* stream) {
+int onet_bn_finalize(const float* part, int nparts, int64_t count, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, float momentum, float eps, float* save, void* act_amax, int C, void* stream) {
     ONET_REQUIRE(part && save && nparts > 0 && count > 0 && C > 0, "bn_finalize: bad args");
     (void)count;   // the partials carry their own counts
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, as_stream(stream), part, nparts, gamma, beta,
-                       running_mean, running_var, momentum, eps, save, C);
-    return check_launch("bn_finalize_kernel");
-}
-
-int onet_bn_finalize_cm(const float* part, int nparts, int64_t c_stride, const float* gamma, const float* beta,
-                        float* running_mean, float* running_var, float momentum, float eps, float* save, int C,
-                        void* stream) {
-    ONET_REQUIRE(part && save && nparts > 0 && C > 0 && c_stride >= (int64_t)nparts * 3, "bn_finalize_cm: bad args");
-    hipLaunchKernelGGL(bn_finalize_cm_kernel, dim3(C), dim3(256), 0, as_stream(stream), part, nparts, c_stride, gamma,
-                       beta, running_mean, running_var, momentum, eps, save, C);
-    return check_launch("bn_finalize_cm_kernel");
-}
-
-int onet_bn_finalize_act(const float* part, int nparts, int64_t count, const float* gamma, const float* beta, float* running_mean,
-                         float* running_var, float momentum, float eps, float* save, void* act_amax, int C, void* stream) {
-    ONET_REQUIRE(part && save && act_amax && nparts > 0 && count > 0 && C > 0, "bn_finalize_act: bad args");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, as_stream(stream), part, nparts, gamma, beta, running_mean, running_var,
                        momentum, eps, save, C, (unsigned*)act_amax);
     return check_launch("bn_finalize_kernel");
 }
 
-int onet_bn_finalize_cm_act(const float* part, int nparts, int64_t c_stride, const float* gamma, const float* beta, float* running_mean,
+int onet_bn_finalize_cm(const float* part, int nparts, int64_t c_stride, const float* gamma, const float* beta, float* running_mean,
                             float* running_var, float momentum, float eps, float* save, void* act_amax, int groups, int C, void* stream) {
-    ONET_REQUIRE(part && save && nparts > 0 && C > 0 && groups >= 1 && c_stride >= (int64_t)nparts * groups * 3, "bn_finalize_cm_act: bad args");
+    ONET_REQUIRE(part && save && nparts > 0 && C > 0 && groups >= 1 && c_stride >= (int64_t)nparts * groups * 3, "bn_finalize_cm: bad args");
     hipLaunchKernelGGL(bn_finalize_cm_kernel, dim3(C), dim3(256), 0, as_stream(stream), part, nparts, c_stride, gamma, beta, running_mean,
                        running_var, momentum, eps, save, C, (unsigned*)act_amax, groups);
     return check_launch("bn_finalize_cm_kernel");
@@ -983,91 +938,44 @@ int onet_bn_eval_coeffs(const float* gamma, const float* beta, const float* runn
     return check_launch("bn_eval_coeffs_kernel");
 }
 
-int onet_bn_relu_apply(const float* z, int64_t z_bs, float* a, int64_t a_bs, const float* save, int B, int C,
-                       int HW, void* stream) {
-    ONET_REQUIRE(z && a && save && B > 0 && C > 0 && HW > 0, "bn_relu_apply: bad args");
+int onet_bn_relu_apply(const void* z, int z_bf16, int64_t z_bs, float* a, int64_t a_bs, const float* save, void* amax, int group_images,
+                            int B, int C, int HW, void* stream) {
+    ONET_REQUIRE(z && a && save && B > 0 && C > 0 && HW > 0 && group_images >= 0, "bn_relu_apply: bad args");
     const int chunks = cdiv(HW, 4096);
     const int64_t blocks = (int64_t)B * C * chunks;
     ONET_REQUIRE(blocks < (1ll << 31), "bn_relu_apply: grid too large");
-    hipLaunchKernelGGL(bn_relu_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), z, z_bs, a,
-                       a_bs, save, C, HW, chunks);
-    return check_launch("bn_relu_apply_kernel");
-}
-
-int onet_bn_relu_apply_amax(const void* z, int z_bf16, int64_t z_bs, float* a, int64_t a_bs, const float* save, void* amax, int group_images,
-                            int B, int C, int HW, void* stream) {
-    ONET_REQUIRE(z && a && save && B > 0 && C > 0 && HW > 0 && group_images >= 0, "bn_relu_apply_amax: bad args");
-    const int chunks = cdiv(HW, 4096);
-    const int64_t blocks = (int64_t)B * C * chunks;
-    ONET_REQUIRE(blocks < (1ll << 31), "bn_relu_apply_amax: grid too large");
     if (z_bf16) {
-        ONET_REQUIRE((reinterpret_cast<uintptr_t>(z) & 7) == 0, "bn_relu_apply_amax: 8-byte aligned bf16 rows required");
+        ONET_REQUIRE((reinterpret_cast<uintptr_t>(z) & 7) == 0, "bn_relu_apply: 8-byte aligned bf16 rows required");
         hipLaunchKernelGGL(bn_relu_apply_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const __bf16*)z, z_bs, a, a_bs,
-                           save, C, HW, chunks, (__bf16*)nullptr, (int64_t)0, (unsigned*)amax, group_images);
+                           save, C, HW, chunks, (unsigned*)amax, group_images);
     } else {
         hipLaunchKernelGGL(bn_relu_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)z, z_bs, a, a_bs,
-                           save, C, HW, chunks, (__bf16*)nullptr, (int64_t)0, (unsigned*)amax, group_images);
+                           save, C, HW, chunks, (unsigned*)amax, group_images);
     }
     return check_launch("bn_relu_apply_kernel");
 }
 
-int onet_bn_relu_apply_pool_amax(const float* z, int64_t z_bs, float* a, int64_t a_bs, float* y, int64_t y_bs, const float* save,
+int onet_bn_relu_apply_pool(const float* z, int64_t z_bs, float* a, int64_t a_bs, float* y, int64_t y_bs, const float* save,
                                  void* amax, int B, int C, int H, int W, void* stream) {
-    ONET_REQUIRE(z && a && y && save && amax && B > 0 && C > 0 && H > 0 && W > 0, "bn_relu_apply_pool_amax: bad args");
+    ONET_REQUIRE(z && a && y && save && B > 0 && C > 0 && H > 0 && W > 0, "bn_relu_apply_pool: bad args");
     auto al = [](const void* p, uintptr_t m) { return (reinterpret_cast<uintptr_t>(p) & m) == 0; };
     if ((H & 1) || (W & 3) || (z_bs & 3) || (a_bs & 3) || (y_bs & 1) || !al(z, 15) || !al(a, 15) || !al(y, 7)) return 1;
     const int npatch = (H / 2) * (W / 4), bpp = cdiv(npatch, 256);
     const int64_t blocks = (int64_t)B * C * bpp;
-    ONET_REQUIRE(blocks < (1ll << 31), "bn_relu_apply_pool_amax: grid too large");
-    hipLaunchKernelGGL(bn_relu_apply_pool_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), z, z_bs, a, a_bs,
-                       (__bf16*)nullptr, (int64_t)0, y, y_bs, (__bf16*)nullptr, (int64_t)0, save, C, H, W, bpp, (unsigned*)amax);
-    return check_launch("bn_relu_apply_pool_kernel");
-}
-
-int onet_bn_relu_apply_b(const float* z, int64_t z_bs, float* a, int64_t a_bs, void* a_bf16, int64_t a16_bs, const float* save, int B,
-                         int C, int HW, void* stream) {
-    ONET_REQUIRE(z && (a || a_bf16) && save && B > 0 && C > 0 && HW > 0, "bn_relu_apply_b: bad args");
-    const int chunks = cdiv(HW, 4096);
-    const int64_t blocks = (int64_t)B * C * chunks;
-    ONET_REQUIRE(blocks < (1ll << 31), "bn_relu_apply_b: grid too large");
-    hipLaunchKernelGGL(bn_relu_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), z, z_bs, a, a_bs, save, C, HW,
-                       chunks, (__bf16*)a_bf16, a16_bs);
-    return check_launch("bn_relu_apply_kernel");
-}
-
-int onet_bn_relu_apply_pool(const float* z, int64_t z_bs, float* a, int64_t a_bs, void* a_bf16, int64_t a16_bs, float* y, int64_t y_bs,
-                            void* y_bf16, int64_t y16_bs, const float* save, int B, int C, int H, int W, void* stream) {
-    ONET_REQUIRE(z && (a || a_bf16) && (y || y_bf16) && save && B > 0 && C > 0 && H > 0 && W > 0, "bn_relu_apply_pool: bad args");
-    auto al = [](const void* p, uintptr_t m) { return (reinterpret_cast<uintptr_t>(p) & m) == 0; };
-    if ((H & 1) || (W & 3) || (z_bs & 3) || (a_bs & 3) || (a16_bs & 3) || (y_bs & 1) || (y16_bs & 1) || !al(z, 15) || !al(a, 15) ||
-        !al(a_bf16, 7) || !al(y, 7) || !al(y_bf16, 3))
-        return 1;                                  // not taken: run onet_bn_relu_apply[_b] and onet_maxpool2_fwd[_b]
-    const int npatch = (H / 2) * (W / 4), bpp = cdiv(npatch, 256);
-    const int64_t blocks = (int64_t)B * C * bpp;
     ONET_REQUIRE(blocks < (1ll << 31), "bn_relu_apply_pool: grid too large");
     hipLaunchKernelGGL(bn_relu_apply_pool_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), z, z_bs, a, a_bs,
-                       (__bf16*)a_bf16, a16_bs, y, y_bs, (__bf16*)y_bf16, y16_bs, save, C, H, W, bpp);
+                       y, y_bs, save, C, H, W, bpp, (unsigned*)amax);
     return check_launch("bn_relu_apply_pool_kernel");
 }
 
-int onet_bn_relu_bwd_reduce(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save,
-                            float* part2, int nparts, int B, int C, int HW, void* stream) {
-    ONET_REQUIRE(da && z && save && part2 && B > 0 && C > 0 && HW > 0, "bn_relu_bwd_reduce: bad args");
+int onet_bn_relu_bwd_reduce(const float* da, int64_t da_bs, const void* z, int z_bf16, int64_t z_bs, const float* save, float* part2,
+                                 int nparts, void* da_amax, int group_images, int B, int C, int HW, void* stream) {
+    ONET_REQUIRE(da && z && save && part2 && B > 0 && C > 0 && HW > 0 && group_images >= 0, "bn_relu_bwd_reduce: bad args");
     int chunks, chunk_len;
     ONET_REQUIRE(split_plan(nparts, B, HW, chunks, chunk_len), "bn_relu_bwd_reduce: nparts=%d must be a multiple of B=%d", nparts, B);
-    hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3((unsigned)((int64_t)nparts * C)), dim3(256), 0,
-                       as_stream(stream), da, da_bs, z, z_bs, save, part2, C, HW, chunks, chunk_len);
-    return check_launch("bn_relu_bwd_reduce_kernel");
-}
-
-int onet_bn_relu_bwd_reduce_amax(const float* da, int64_t da_bs, const void* z, int z_bf16, int64_t z_bs, const float* save, float* part2,
-                                 int nparts, void* da_amax, int group_images, int B, int C, int HW, void* stream) {
-    ONET_REQUIRE(da && z && save && part2 && B > 0 && C > 0 && HW > 0 && group_images >= 0, "bn_relu_bwd_reduce_amax: bad args");
-    int chunks, chunk_len;
-    ONET_REQUIRE(split_plan(nparts, B, HW, chunks, chunk_len), "bn_relu_bwd_reduce_amax: nparts=%d must be a multiple of B=%d", nparts, B);
     const dim3 grid((unsigned)((int64_t)nparts * C));
     if (z_bf16) {
-        ONET_REQUIRE((reinterpret_cast<uintptr_t>(z) & 7) == 0, "bn_relu_bwd_reduce_amax: 8-byte aligned bf16 rows required");
+        ONET_REQUIRE((reinterpret_cast<uintptr_t>(z) & 7) == 0, "bn_relu_bwd_reduce: 8-byte aligned bf16 rows required");
         hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel<__bf16>, grid, dim3(256), 0, as_stream(stream), da, da_bs, (const __bf16*)z, z_bs, save,
                            part2, C, HW, chunks, chunk_len, (unsigned*)da_amax, group_images);
     } else {
@@ -1153,52 +1061,22 @@ int onet_bn_bwd_finalize_cm(const float* part2, int nparts, int64_t c_stride, in
     return check_launch("bn_bwd_finalize_cm_kernel");
 }
 
-int onet_bn_bwd_finalize(const float* part2, int nparts, int64_t count, float* dgamma, float* dbeta, float* coef,
-                         int accumulate, int C, void* stream) {
-    ONET_REQUIRE(part2 && nparts > 0 && count > 0 && C > 0, "bn_bwd_finalize: bad args");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, as_stream(stream), part2, nparts,
-                       (double)count, dgamma, dbeta, coef, accumulate, C);
-    return check_launch("bn_bwd_finalize_kernel");
-}
-
-int onet_bn_bwd_finalize_bound(const float* part2, int nparts, int64_t count, float* dgamma, float* dbeta, float* coef, int accumulate,
+int onet_bn_bwd_finalize(const float* part2, int nparts, int64_t count, float* dgamma, float* dbeta, float* coef, int accumulate,
                                int groups, int C, const float* save, const void* da_amax, void* dz_amax, void* stream) {
-    ONET_REQUIRE(part2 && nparts > 0 && count > 0 && C > 0 && groups >= 1 && (!dz_amax || (save && da_amax)), "bn_bwd_finalize_bound: bad args");
+    ONET_REQUIRE(part2 && nparts > 0 && count > 0 && C > 0 && groups >= 1 && (!dz_amax || (save && da_amax)), "bn_bwd_finalize: bad args");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, as_stream(stream), part2, nparts, (double)count, dgamma, dbeta, coef,
                        accumulate, C, save, (const unsigned*)da_amax, (unsigned*)dz_amax, sqrtf((float)(count > 1 ? count - 1 : 1)), groups);
     return check_launch("bn_bwd_finalize_kernel");
 }
 
-int onet_bn_relu_bwd_apply(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save,
-                           const float* coef, float* dz, int64_t dz_bs, int B, int C, int HW, void* stream) {
-    ONET_REQUIRE(da && z && save && dz && B > 0 && C > 0 && HW > 0, "bn_relu_bwd_apply: bad args");
+int onet_bn_relu_bwd_apply(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save, const float* coef,
+                                float* dz, int64_t dz_bs, void* amax, int group_images, int B, int C, int HW, void* stream) {
+    ONET_REQUIRE(da && z && save && dz && B > 0 && C > 0 && HW > 0 && group_images >= 0, "bn_relu_bwd_apply: bad args");
     const int chunks = cdiv(HW, 4096);
     const int64_t blocks = (int64_t)B * C * chunks;
     ONET_REQUIRE(blocks < (1ll << 31), "bn_relu_bwd_apply: grid too large");
-    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), da, da_bs,
-                       z, z_bs, save, coef, dz, dz_bs, C, HW, chunks);
-    return check_launch("bn_relu_bwd_apply_kernel");
-}
-
-int onet_bn_relu_bwd_apply_amax(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save, const float* coef,
-                                float* dz, int64_t dz_bs, void* amax, int group_images, int B, int C, int HW, void* stream) {
-    ONET_REQUIRE(da && z && save && dz && B > 0 && C > 0 && HW > 0 && group_images >= 0, "bn_relu_bwd_apply_amax: bad args");
-    const int chunks = cdiv(HW, 4096);
-    const int64_t blocks = (int64_t)B * C * chunks;
-    ONET_REQUIRE(blocks < (1ll << 31), "bn_relu_bwd_apply_amax: grid too large");
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), da, da_bs, z, z_bs, save, coef,
-                       dz, dz_bs, C, HW, chunks, (__bf16*)nullptr, (int64_t)0, (unsigned*)amax, group_images);
-    return check_launch("bn_relu_bwd_apply_kernel");
-}
-
-int onet_bn_relu_bwd_apply_b(const float* da, int64_t da_bs, const float* z, int64_t z_bs, const float* save, const float* coef,
-                             float* dz, int64_t dz_bs, void* dz_bf16, int64_t dz16_bs, int B, int C, int HW, void* stream) {
-    ONET_REQUIRE(da && z && save && (dz || dz_bf16) && B > 0 && C > 0 && HW > 0, "bn_relu_bwd_apply_b: bad args");
-    const int chunks = cdiv(HW, 4096);
-    const int64_t blocks = (int64_t)B * C * chunks;
-    ONET_REQUIRE(blocks < (1ll << 31), "bn_relu_bwd_apply_b: grid too large");
-    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), da, da_bs, z, z_bs, save, coef,
-                       dz, dz_bs, C, HW, chunks, (__bf16*)dz_bf16, dz16_bs);
+                       dz, dz_bs, C, HW, chunks, (unsigned*)amax, group_images);
     return check_launch("bn_relu_bwd_apply_kernel");
 }
 

@@ -850,18 +850,6 @@ int onet_convT2x2_fwd(const float* x, int64_t x_bs, const float* wq, const float
                     : launch_fwd<1, 2, 2, 1, 4, 16, 1>(a, as_stream(stream));
 }
 
-// forward + a bf16 copy of the up-sampled tensor (operand storage for the bf16 conv kernels): only on the 128 x 128 GEMM path;
-// returns 1 (and does nothing) elsewhere -- the caller then runs onet_convT2x2_fwd and the consumer reads fp32
-int onet_convT2x2_fwd_b(const float* x, int64_t x_bs, const float* wq, const float* bias, float* y, int64_t y_bs, void* y_bf16,
-                        int64_t y16_bs, int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int operand_bf16, void* stream) {
-    ONET_REQUIRE(x && wq && y_bf16, "convT2x2_fwd_b: null pointer");       // y may be NULL: bf16 output only
-    ONET_REQUIRE(B > 0 && Cin > 0 && Ct > 0 && h > 0 && w > 0, "convT2x2_fwd_b: bad shape");
-    ONET_REQUIRE(x_bs >= (int64_t)Cin * h * w && (!y || y_bs >= (int64_t)Ct * Ho * Wo) && y16_bs >= (int64_t)Ct * Ho * Wo,
-                 "convT2x2_fwd_b: batch stride too small");
-    if (!convt_gemm_enabled()) return 1;
-    return convt_gemm_fwd(x, x_bs, wq, bias, y, y_bs, y_bf16, y16_bs, B, Cin, Ct, h, w, Ho, Wo, pt, pl, operand_bf16, as_stream(stream));
-}
-
 // ... with the up-sampled tensor written PRE-SPLIT (fp16 hi | mid slots, conv_split.hip) into yP [B][Ct/8][Ho][2][Wo][8], e.g. the
 // up-sampled channel groups of a pre-split concat buffer (yP_bs: batch stride in 4-byte units); no fp32 output.  Fast path only:
 // returns 1 (nothing done) elsewhere.

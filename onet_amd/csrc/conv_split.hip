@@ -9,7 +9,7 @@
 //   Measured against fp64 at Cin = 512: 9.7e-7 rms / 4.4e-6 max of the output scale from the split itself
 //   (emulated on the CPU; F(4x4): 2.7e-6 / 4e-5), plus the fp32 accumulation of the MFMA chain as in every other kernel here.
 //
-// Structure: the direct implicit GEMM of conv_bf16.hip (M = output channels, N = 32 consecutive pixels of an image row,
+// Structure: a direct implicit GEMM (M = output channels, N = 32 consecutive pixels of an image row,
 // K = 16 input channels per MFMA; LDS tiles made of 16-byte slots of 8 channels, the two 8-channel halves apart; persistent
 // blocks whose load -> LDS -> MFMA pipeline runs across tile boundaries), with:
 //  * both parts of both operands in LDS: weights [part][tap][half][co], input halo tile [part][half][pixel] -- the fp32
@@ -17,8 +17,8 @@
 //    v_cvt_pk_bf16_f32 + 8 v_sub per slot); the weights are split once per optimizer step by the pack kernel;
 //  * 8 waves per block (one block per CU, two waves per SIMD: the doubled tiles need 156 KB of LDS): 64 output channels x 16
 //    image rows x 32 pixels, 2 rows per wave; per 16-channel chunk a wave issues 60 ds_read_b128 for 108 MFMAs of 32 cycles,
-//    and the block moves 39 KB of input + 36 KB of weights per 864 MFMAs -- a third of conv_bf16.hip's bytes and requests per
-//    MFMA, which is what bound that kernel.
+//    and the block moves 39 KB of input + 36 KB of weights per 864 MFMAs -- a third of the bytes and requests per
+//    MFMA of the round-2 bf16 kernel this structure came from, which is what bound that kernel (DESIGN_HISTORY.md 4.2d).
 // Requires Cin % 16 == 0 and W > 16; everything else takes the fp32 Winograd / direct kernels.
 #include <algorithm>
 #include <cstdlib>
@@ -166,7 +166,7 @@ struct SpCfg {
     static constexpr int NB = (NT - 1) + 3;                             // distinct B row-fragments per horizontal tap
 };
 
-// PERSISTENT blocks as in conv_bf16.hip: a block walks over output tiles and the chunk pipeline -- global loads two 16-channel
+// PERSISTENT blocks: a block walks over output tiles and the chunk pipeline -- global loads two 16-channel
 // chunks ahead of the MFMAs, LDS commit one ahead -- runs ACROSS tile boundaries.
 // ST: the forward of a Conv-BatchNorm pair (OV:47-48, 51-52) also emits the BatchNorm statistics of its output, one (n, mean,
 // M2) record per tile and channel from the final accumulators (pivot-shifted sums per wave, the eight waves merged through LDS).
@@ -1491,7 +1491,7 @@ int split_fwd(const float* x, int64_t x_bs, const void* wq, float* z, int64_t z_
 // ------------------------------------------------------------------ weight gradient, split operands
 //   dW[co][ci][ky][kx] = sum_{b,y,x} dz[b][co][y][x] * X[b][ci][y+ky-1][x+kx-1]:  M = co, N = ci, K = pixels, one accumulator per
 //   tap, v_mfma_f32_32x32x16_bf16 with the 8 K-values of a lane = 8 consecutive pixels of one channel row.  The row-streaming
-//   structure of conv3x3_wgrad_bf16_row_kernel (conv_bf16.hip): a unit is ONE image row of a 64-pixel strip -- dz [64 co][64 px],
+//   structure (first used by round 2's bf16 weight gradient, DESIGN_HISTORY.md 4.2d): a unit is ONE image row of a 64-pixel strip -- dz [64 co][64 px],
 //   x rows y-1, y, y+1 [64 ci][66 px] in a 4-slot ring, a block walks down its strip and loads one new row of each operand per
 //   unit as whole 128-byte lines -- with both operands split on the way into LDS (hi | mid parts of dz and of x) and three MFMAs
 //   per (16-pixel segment, tap): dz_mid x_hi + dz_hi x_mid + dz_hi x_hi.  110 KB of LDS: one block per CU, of EIGHT waves -- two
@@ -2526,6 +2526,9 @@ int onet_conv3x3_split_dgrad_pre_bnreduce(const void* dzs, int64_t dzs_bs, const
     if (onet_conv3x3_split_pre_nparts(B, H, W) <= 0 || (W != 16 && (W % 32)) || (Cout % 16)) return 1;
     if (W == 16 && ((group_images % 2) || wq_f16 != 2)) return 1;    // a tile's image pair must lie in one statistics group; (hi | mid)
                                                                      // parts on 16-pixel maps: not built (register budget of that instance)
+    // a tile of fewer than four chunks is too short to cover the epilogue's z loads (plain bf16 operands, 64 channels of dz: two chunks --
+    // measured at BASELINE configs[2]: the fused launches cost more than the reduce pass they replace)
+    if (Cin / (wq_f16 == 2 ? 32 : 16) < 4) return 1;
     ONET_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && (Cin % (wq_f16 == 2 ? 32 : 16)) == 0, "conv3x3_split_dgrad_pre_bnreduce: bad shape");
     ONET_REQUIRE(group_images >= 0 && (group_images == 0 || B % group_images == 0), "conv3x3_split_dgrad_pre_bnreduce: bad statistics groups");
     ONET_REQUIRE((dzs_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(dzs) & 15) == 0 && (z_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(z_prev) & (z_bf16 ? 7 : 15)) == 0 &&

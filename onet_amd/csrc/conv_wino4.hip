@@ -5,7 +5,7 @@
 //   {0, +-1, +-2}.  fp32 error per layer ~2.7e-6 rms of the output scale (F(2x2): 4e-7, direct: 2e-7; measured
 //   against fp64 at Cin = 512), two orders below the 1e-3 parity bar.
 //
-// Same call sites as conv_wino.hip (F.conv2d + input-grad, OV:47,51).  The 36 Winograd positions are 36
+// Call sites: F.conv2d + input-grad, OV:47,51.  The 36 Winograd positions are 36
 // GEMMs  M_pos[co][tile] = sum_ci U_pos[co][ci] * V_pos[ci][tile]; the accumulators of a 64-channel x 32-tile
 // block (36 x 2 MFMA tiles of 32x32 = 288 KB) fill over half of the CU's register file, so the block is
 // 8 waves = 4 position groups (3x3 positions each: rows {0,1,2}|{3,4,5} x columns {0,1,2}|{3,4,5}) x 2 TILE halves,
@@ -38,7 +38,8 @@ static __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* bas
 static __device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
-// LDS-DMA, inline asm for the reason given in conv_wino.hip (the compiler must not see it)
+// LDS-DMA as inline asm: the compiler has no builtin that models a buffer load writing LDS at M0 + lane offset, and must not
+// reorder LDS accesses around one it cannot see; the callers fence with explicit s_waitcnt vmcnt + barriers
 static __device__ __forceinline__ void dma16(i32x4 rsrc, unsigned lds_byte_addr, unsigned voff) {
     unsigned keep;
     asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"

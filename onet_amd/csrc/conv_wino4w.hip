@@ -2,7 +2,7 @@
 //   dW = A'^T [ sum_tiles (G' dY G'^T) (.) (B^T d B) ] A'
 // 6x6 input tiles d, 4x4 tiles of the output gradient dY in the role of the filter, interpolation points 0, +-1, +-2, inf
 // (the B^T of conv_wino4.hip): 36 multiplies per 144 direct ones = 4x fewer MFMAs than the direct algorithm, 1.78x fewer
-// than the F(2x2,3x3) kernel of conv_wino.hip.  The 36 positions are 36 GEMMs M_p[co][ci] = sum_tile DY_p[co][tile] *
+// than an F(2x2,3x3) kernel (round 1's, since removed).  The 36 positions are 36 GEMMs M_p[co][ci] = sum_tile DY_p[co][tile] *
 // X_p[ci][tile] (M = co, N = ci, K = tiles); both operands are transformed in registers from channel-major LDS strips
 // (lane = channel; channel strides 4 x odd floats keep the 16-lane groups of a ds_read_b128 on distinct banks).
 // Block = 8 waves = 4 position groups (3x3 positions each, as in conv_wino4.hip) x 2 co halves: 64 co x 32 ci x 36

@@ -14,8 +14,7 @@ static inline unsigned grid_for(int64_t n, int per_block = 256) {
 
 // ---------------------------------------------------------------- maxpool
 __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, int64_t x_bs, float* __restrict__ y,
-                                    int64_t y_bs, int B, int C, int H, int W, int Ho, int Wo, __bf16* __restrict__ y16 = nullptr,
-                                    int64_t y16_bs = 0) {
+                                    int64_t y_bs, int B, int C, int H, int W, int Ho, int Wo) {
     const int64_t n = (int64_t)B * C * Ho * Wo;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int ox = (int)(i % Wo);
@@ -27,8 +26,7 @@ __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, int64_t x_bs, f
         const float2 t = *reinterpret_cast<const float2*>(p);          // 2*ox even, W even or odd: see note
         const float2 u = *reinterpret_cast<const float2*>(p + W);
         const float m = fmaxf(fmaxf(t.x, t.y), fmaxf(u.x, u.y));
-        if (y) y[(int64_t)b * y_bs + (int64_t)c * Ho * Wo + (int64_t)oy * Wo + ox] = m;
-        if (y16) y16[(int64_t)b * y16_bs + (int64_t)c * Ho * Wo + (int64_t)oy * Wo + ox] = (__bf16)m;   // operand copy for the bf16 conv
+        y[(int64_t)b * y_bs + (int64_t)c * Ho * Wo + (int64_t)oy * Wo + ox] = m;
     }
 }
 
@@ -479,35 +477,11 @@ int onet_maxpool2_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs, int 
     return check_launch("maxpool2_fwd_kernel");
 }
 
-// + a bf16 copy of the pooled tensor for the bf16 conv kernels (y may be NULL: bf16 only); returns 1 (y written, no copy) for
-// odd / unaligned maps
-int onet_maxpool2_fwd_b(const float* x, int64_t x_bs, float* y, int64_t y_bs, void* y_bf16, int64_t y16_bs, int B, int C, int H, int W,
-                        void* stream) {
-    ONET_REQUIRE(x && y_bf16 && B > 0 && C > 0 && H >= 2 && W >= 2, "maxpool2_fwd_b: bad args (H=%d W=%d)", H, W);
-    const int Ho = H / 2, Wo = W / 2;
-    const int64_t n = (int64_t)B * C * Ho * Wo;
-    const bool aligned = ((W & 1) == 0) && ((x_bs & 1) == 0) && ((reinterpret_cast<uintptr_t>(x) & 7) == 0);
-    ONET_REQUIRE(y || aligned, "maxpool2_fwd_b: the bf16-only form (y == NULL) needs an even, 8-byte aligned map");
-    if (!aligned) {
-        const int rc = onet_maxpool2_fwd(x, x_bs, y, y_bs, B, C, H, W, stream);
-        return rc ? rc : 1;
-    }
-    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), x, x_bs, y, y_bs, B, C, H, W, Ho, Wo,
-                       (__bf16*)y_bf16, y16_bs);
-    return check_launch("maxpool2_fwd_kernel");
-}
-
-int onet_maxpool2_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, float* dx, int64_t dx_bs,
-                      int B, int C, int H, int W, int accumulate, void* stream) {
-    ONET_REQUIRE(x && dy && dx && B > 0 && C > 0 && H >= 2 && W >= 2, "maxpool2_bwd: bad args");
-    return maxpool2_bwd_impl(x, x_bs, dy, dy_bs, dx, dx_bs, B, C, H, W, accumulate, nullptr, 0, nullptr, 0, stream);
-}
-
-int onet_maxpool2_bwd_add(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, const float* add, int64_t add_bs,
-                          const float* add2, int64_t add2_bs, float* dx, int64_t dx_bs, int B, int C, int H, int W,
-                          void* stream) {
-    ONET_REQUIRE(x && dy && add && dx && B > 0 && C > 0 && H >= 2 && W >= 2, "maxpool2_bwd_add: bad args");
-    return maxpool2_bwd_impl(x, x_bs, dy, dy_bs, dx, dx_bs, B, C, H, W, 0, add, add_bs, add2, add2_bs, stream);
+int onet_maxpool2_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, const float* add, int64_t add_bs,
+                      const float* add2, int64_t add2_bs, float* dx, int64_t dx_bs, int B, int C, int H, int W, int accumulate,
+                      void* stream) {
+    ONET_REQUIRE(x && dy && dx && (add || !add2) && !(add && accumulate) && B > 0 && C > 0 && H >= 2 && W >= 2, "maxpool2_bwd: bad args");
+    return maxpool2_bwd_impl(x, x_bs, dy, dy_bs, dx, dx_bs, B, C, H, W, accumulate, add, add_bs, add2, add2_bs, stream);
 }
 
 int onet_maxpool2_bwd_bn_bands(int H, int W) {
@@ -523,14 +497,6 @@ static int maxpool2_bwd_add_bnreduce_impl(const float* x, int64_t x_bs, const fl
                                           void* stream);
 
 int onet_maxpool2_bwd_add_bnreduce(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, const float* add, int64_t add_bs,
-                                   const float* add2, int64_t add2_bs, float* dx, int64_t dx_bs, const float* z, int64_t z_bs,
-                                   const float* save, int group_images, float* part2, int B, int C, int H, int W, void* stream) {
-    ONET_REQUIRE(x, "maxpool2_bwd_add_bnreduce: bad args");
-    return maxpool2_bwd_add_bnreduce_impl(x, x_bs, dy, dy_bs, add, add_bs, add2, add2_bs, dx, dx_bs, z, 0, z_bs, save, group_images, part2,
-                                          nullptr, B, C, H, W, stream);
-}
-
-int onet_maxpool2_bwd_add_bnreduce_amax(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, const float* add, int64_t add_bs,
                                         const float* add2, int64_t add2_bs, float* dx, int64_t dx_bs, const void* z, int z_bf16, int64_t z_bs,
                                         const float* save, int group_images, float* part2, void* dx_amax, int B, int C, int H, int W,
                                         void* stream) {

@@ -42,74 +42,57 @@ class ConvBNReLUFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, running_mean, running_var, training, momentum, eps, packed, out, groups=1,
-                link_out=None, link_in=None, b16=None, aux=None, p16=None):
-        """b16 (bf16 storage, BASELINE config 3 only): dict with "x16" = the bf16 copy of x written by its producer (or None),
-        "out16" = a plane-contiguous bf16 destination for the copy of the output (or None: allocated); forward leaves the
-        output's copy in b16["a16"] for the caller to attach to the returned tensor."""
+                link_out=None, link_in=None, aux=None, p16=None):
         ops.require_gpu(x, weight, gamma, beta)
         if p16 is not None and (p16.get("x") is not None or p16.get("want")):
             return ConvBNReLUFn._forward_pre(ctx, x, weight, gamma, beta, running_mean, running_var, training, momentum, eps, packed,
                                              groups, link_out, link_in, p16)
         ctx.pre = False
-        # an encoder output that is max-pooled next: {"bf16_only": bool} left in the link dict by UNet.forward (read before the dict
-        # is refilled below); the pooled tensor goes back through the same dict for SkipPoolFn
+        # an encoder output that is max-pooled next: a request left in the link dict by UNet.forward (read before the dict is refilled
+        # below); the pooled tensor goes back through the same dict for SkipPoolFn
         want_pool = link_out.pop("want_pool", None) if link_out is not None else None
         # normalise on load (ops.norm_on_load_ok, decided by DoubleConv for the pair): as the FIRST unit, this launch computes
         # z and the BatchNorm coefficients and stops there -- the second unit's convolution applies BatchNorm + ReLU in its own
         # operand staging, forward and weight gradient, and a placeholder stands in for the activation in the graph; as the
         # SECOND unit, x is that placeholder and the operand comes from (z, save) of the first
         defer = bool(link_out.pop("defer", False)) if link_out is not None else False
-        defer = defer and training and b16 is None and out is None and want_pool is None
+        defer = defer and training and out is None and want_pool is None
         norm = None
         if link_in is not None and link_in.get("deferred"):
             norm = (link_in["z"], link_in["save"])
-        x16 = None if b16 is None else b16.get("x16")
         # the magnitude slots x's producer left on it (ops.tag_amax): the fp16-split kernel's overflow guard
         # (aux: {"x_amax": slots of x or None} in, {"a_amax": slots of the output} out -- DoubleConv._unit tags the tensors)
-        x_amax = aux.get("x_amax") if (aux is not None and b16 is None and norm is None) else None
+        x_amax = aux.get("x_amax") if (aux is not None and norm is None) else None
         # training: the F(4x4) kernel emits the BatchNorm statistics records from its epilogue (cm), where it can
         if norm is not None:
             z, cm = ops.conv3x3_fwd_bn_partials(None, packed, norm=norm)
         else:
-            z, cm = ops.conv3x3_fwd_bn_partials(x, packed, x16=x16, amax=x_amax) if training else \
-                (ops.conv3x3_auto(x, packed, 0, x16=x16, amax=x_amax), None)
+            z, cm = ops.conv3x3_fwd_bn_partials(x, packed, amax=x_amax) if training else (ops.conv3x3_auto(x, packed, 0, amax=x_amax), None)
         # `out` is None or a 1-tuple holding a plane-contiguous destination view (kept out of autograd's sight)
         dst = None if out is None else out[0]
         G = groups if (training and groups > 1) else 1
         C = z.shape[1]
-        a16 = None
-        if b16 is not None:
-            a16 = b16.get("out16")
-            if a16 is None:
-                a16 = torch.empty(z.shape, dtype=torch.bfloat16, device=z.device)
-        # bf16 storage: every consumer of this activation reads the bf16 copy -> no fp32 tensor is written, a placeholder
-        # goes through autograd
-        drop = a16 is not None and bool(b16.get("drop_fp32")) and dst is None
         save_all = torch.empty((G, 4, C), dtype=torch.float32, device=z.device)
         Bz, _, Hz, Wz = z.shape
         pooled = None
         # magnitude slots of the activation written here (all statistics groups share them), for the convolution that consumes it
-        a_amax = ops.new_amax(z.device) if (b16 is None and not defer and z.is_cuda and ops.split_f16() and ops.split_enabled()
-                                            and ops.conv_algo() in ("auto", "split")) else None
-        if want_pool is not None and ops.FUSE_POOL and not drop and Hz % 2 == 0 and Wz % 4 == 0:
-            only16 = bool(want_pool.get("bf16_only")) and a16 is not None
-            py = None if only16 else torch.empty((Bz, C, Hz // 2, Wz // 2), dtype=torch.float32, device=z.device)
-            py16 = torch.empty((Bz, C, Hz // 2, Wz // 2), dtype=torch.bfloat16, device=z.device) if a16 is not None else None
-            pooled = (py, py16)
+        a_amax = ops.new_amax(z.device) if (not defer and z.is_cuda and ops.split_f16() and ops.split_enabled()
+                                            and ops.conv_algo() in ("auto", "split", "bf16")) else None
+        if want_pool is not None and ops.FUSE_POOL and Hz % 2 == 0 and Wz % 4 == 0:
+            pooled = (torch.empty((Bz, C, Hz // 2, Wz // 2), dtype=torch.float32, device=z.device), None)
 
-        def apply(zg, sv, o, o16, sl):
+        def apply(zg, sv, o, sl):
             """BatchNorm + ReLU of one statistics group (batch slice sl), with the pooled output where it was asked for"""
             nonlocal pooled
             if defer:
                 return None
             if pooled is not None:
-                if o is None and not drop:
+                if o is None:
                     o = torch.empty_like(zg)
-                if ops.bn_relu_apply_pool(zg, sv, o, o16, None if pooled[0] is None else pooled[0][sl],
-                                          None if pooled[1] is None else pooled[1][sl], amax=a_amax):
+                if ops.bn_relu_apply_pool(zg, sv, o, pooled[0][sl], amax=a_amax):
                     return o
                 pooled = None                       # shape not taken: the separate pooling pass runs as before
-            return ops.bn_relu_apply(zg, sv, out=o, out16=o16, no_fp32=drop, amax=a_amax)
+            return ops.bn_relu_apply(zg, sv, out=o, amax=a_amax)
 
         if G == 1:
             if training:
@@ -117,30 +100,25 @@ class ConvBNReLUFn(torch.autograd.Function):
                                     cm=None if cm is None else (cm, 0, cm.shape[1]), save=save_all[0])
             else:
                 ops.bn_eval_coeffs(gamma, beta, running_mean, running_var, eps, save=save_all[0])
-            a = apply(z, save_all[0], dst, a16, slice(0, Bz))
-            if drop or defer:
+            a = apply(z, save_all[0], dst, slice(0, Bz))
+            if defer:
                 a = ops.fp32_placeholder(z.shape, z.device)
         else:
             # twin batch: the G batch slices are separate BatchNorm batches (own statistics, running stats updated
             # slice after slice, exactly as G consecutive forward passes would)
             B = z.shape[0]
             Bg = B // G
-            a = dst if dst is not None else (ops.fp32_placeholder(z.shape, z.device) if (drop or defer) else torch.empty_like(z))
+            a = dst if dst is not None else (ops.fp32_placeholder(z.shape, z.device) if defer else torch.empty_like(z))
             for g in range(G):
                 zg = z[g * Bg:(g + 1) * Bg]
                 npg = 0 if cm is None else cm.shape[1] // G
                 ops.bn_train_coeffs(zg, gamma, beta, running_mean, running_var, momentum, eps,
                                     cm=None if cm is None else (cm, g * npg, npg), save=save_all[g])
-                apply(zg, save_all[g], None if (drop or defer) else a[g * Bg:(g + 1) * Bg],
-                      None if a16 is None else a16[g * Bg:(g + 1) * Bg], slice(g * Bg, (g + 1) * Bg))
-        if b16 is not None:
-            b16["a16"] = a16
+                apply(zg, save_all[g], None if defer else a[g * Bg:(g + 1) * Bg], slice(g * Bg, (g + 1) * Bg))
         if aux is not None:
             aux["a_amax"] = a_amax
-        # (the weight gradient reads the bf16 copy too; saved WITH the tensors so that backward releases it -- a ctx attribute
-        # would live as long as the caller holds the loss)
         ctx.twin = ops.twin_src_of(x)       # a virtual twin batch (placeholder + (X, bias)): backward re-attaches the tag
-        ctx.save_for_backward(x, z, save_all, x16, None if norm is None else norm[0], None if norm is None else norm[1])
+        ctx.save_for_backward(x, z, save_all, None if norm is None else norm[0], None if norm is None else norm[1])
         ctx.training = training
         ctx.packed = packed
         ctx.wshape = tuple(weight.shape)
@@ -264,7 +242,7 @@ class ConvBNReLUFn(torch.autograd.Function):
         z_below = save_below = None
         if ctx.link_in is not None:                 # the unit below's (z, save) must not outlive this backward
             z_below, save_below = ctx.link_in.pop("z", None), ctx.link_in.pop("save", None)
-        nones = (None,) * 13
+        nones = (None,) * 12
         if xP is None:
             # fp32 input (the stem): dz in fp32 for the fp32-input kernels; no input gradient path on pre-split operands
             if need_w and not need_x and x.shape[1] <= 4 and ops.STEM_WGRAD_BN and (not ops.is_placeholder(x) or ops.twin_src_of(x) is not None):
@@ -301,7 +279,7 @@ class ConvBNReLUFn(torch.autograd.Function):
     def backward(ctx, da):
         if ctx.pre:
             return ConvBNReLUFn._backward_pre(ctx, da)
-        x, z, save_all, x16, nz, nsave = ctx.saved_tensors
+        x, z, save_all, nz, nsave = ctx.saved_tensors
         x = ConvBNReLUFn._retag_twin(ctx, x)
         need_x, need_w, need_g, need_b = ctx.needs_input_grad[:4]
         pw, pg, pb = ctx.params
@@ -314,44 +292,34 @@ class ConvBNReLUFn(torch.autograd.Function):
             rda, rec, rec4 = lk.pop("da"), lk.pop("rec", None), lk.pop("rec4", None)
             if rda.data_ptr() != da.data_ptr() or rda.shape != da.shape or rda.stride() != da.stride():
                 rec = rec4 = None                   # autograd handed over something else (another consumer, a hook)
-        # bf16 storage: when both consumers of dz (weight gradient, input gradient) are the bf16 kernels, the BatchNorm
-        # backward writes dz in bf16 ONLY
         Bz, Cz, Hz, Wz = z.shape
-        dz16 = None
-        if (ops.bf16_storage() and ops.wgrad_takes_bf16(ctx.wshape[1], Hz, Wz) and Wz % 8 == 0 and
-                (not need_x or ops.conv3x3_algo(Bz, Cz, ctx.wshape[1], Hz, Wz) == "bf16")):
-            dz16 = torch.empty(z.shape, dtype=torch.bfloat16, device=z.device)
         # fp16-split gradient kernels (Settings.grad_f16): the BatchNorm backward records max |dz| on its way out, and the input- and
         # weight-gradient kernels that consume dz scale it by a power of two chosen from that before splitting it into fp16 parts
-        dz_amax = ops.new_amax(z.device) if (dz16 is None and ops.grad_f16() and ops.conv_algo() in ("auto", "split")
+        dz_amax = ops.new_amax(z.device) if (ops.grad_f16() and ops.conv_algo() in ("auto", "split", "bf16")
                                              and ops.split_enabled() and Wz >= 16) else None
         if G == 1:
             dz, dgamma, dbeta = ops.bn_relu_bwd(da, z, save_all[0], ctx.training, need_affine_grads=(need_g or need_b),
                                                 affine_out=aff, red=None if rec is None else (rec, 0, rec.shape[1]),
-                                                red4=None if rec4 is None else (rec4, 0, rec4.shape[0]), out16=dz16, amax=dz_amax)
+                                                red4=None if rec4 is None else (rec4, 0, rec4.shape[0]), amax=dz_amax)
         else:
             Bg = z.shape[0] // G
-            dz = torch.empty_like(z) if dz16 is None else None
+            dz = torch.empty_like(z)
             dgamma = dbeta = None
             for g in range(G):
                 sl = slice(g * Bg, (g + 1) * Bg)
                 npg = 0 if rec is None else rec.shape[1] // G
                 np4 = 0 if rec4 is None else rec4.shape[0] // G
                 _, dgamma, dbeta = ops.bn_relu_bwd(da[sl], z[sl], save_all[g], ctx.training, need_affine_grads=True,
-                                                   out=None if dz is None else dz[sl], acc=None if g == 0 else (dgamma, dbeta),
+                                                   out=dz[sl], acc=None if g == 0 else (dgamma, dbeta),
                                                    affine_out=aff if g == 0 else None,
                                                    red=None if rec is None else (rec, g * npg, npg),
-                                                   red4=None if rec4 is None else (rec4, g * np4, np4),
-                                                   out16=None if dz16 is None else dz16[sl], amax=dz_amax)
+                                                   red4=None if rec4 is None else (rec4, g * np4, np4), amax=dz_amax)
         if need_w and nz is not None:      # normalise on load: the operand is relu(bn(nz)) of the unit below, applied in the staging
             dw = ops.conv3x3_split_wgrad(nz, dz, ctx.wshape, out=ops.grad_slot_if_free(pw), norm=nsave, dz_amax=dz_amax)
         else:
-            dw = ops.conv3x3_wgrad_auto(x, dz, ctx.wshape, out=ops.grad_slot_if_free(pw), x16=x16, dz16=dz16,
-                                        dz_amax=dz_amax) if need_w else None
+            dw = ops.conv3x3_wgrad_auto(x, dz, ctx.wshape, out=ops.grad_slot_if_free(pw), dz_amax=dz_amax) if need_w else None
         dx = None
-        if need_x and dz16 is not None:
-            dx = ops.conv3x3_auto(None, ctx.packed, 1, x16=dz16)
-        elif need_x:
+        if need_x:
             lk = ctx.link_in
             fused = None
             if lk is not None and "z" in lk:
@@ -366,8 +334,7 @@ class ConvBNReLUFn(torch.autograd.Function):
         if ctx.link_in is not None:                 # whatever path ran: the unit below's (z, save) must not outlive this backward
             ctx.link_in.pop("z", None)
             ctx.link_in.pop("save", None)
-        return (dx, dw, (dgamma if need_g else None), (dbeta if need_b else None), None, None, None, None, None, None,
-                None, None, None, None, None, None, None)
+        return (dx, dw, (dgamma if need_g else None), (dbeta if need_b else None)) + (None,) * 12
 
 
 @_carries_settings
@@ -441,26 +408,21 @@ class SkipPoolFn(torch.autograd.Function):
     dict for the unit's backward."""
 
     @staticmethod
-    def forward(ctx, x, returned=False, link=None, b16=None):
+    def forward(ctx, x, returned=False, link=None, carry=None):
+        """carry: a dict that takes the pooled tensor's pre-split form back to the caller ("yP"), where its producer wrote one."""
         ops.require_gpu(x)
         pooled = link.pop("pooled", None) if link is not None else None
         if pooled is not None and len(pooled) == 3:
             # pre-split storage: the producing pass wrote the pooled tensor pre-split (pooled[2]) or in fp32 (pooled[0])
             shp = (x.shape[0], x.shape[1], x.shape[2] // 2, x.shape[3] // 2)
             y = pooled[0] if pooled[0] is not None else ops.fp32_placeholder(shp, x.device)
-            if b16 is not None:
-                b16["yP"] = pooled[2]
+            if carry is not None:
+                carry["yP"] = pooled[2]
             ctx.pre = True
-        elif pooled is not None and tuple((pooled[0] if pooled[0] is not None else pooled[1]).shape) == \
-                (x.shape[0], x.shape[1], x.shape[2] // 2, x.shape[3] // 2):
-            # the producing BatchNorm + ReLU pass already wrote the pooled tensor (onet_bn_relu_apply_pool)
-            y = pooled[0] if pooled[0] is not None else ops.fp32_placeholder(pooled[1].shape, x.device)
-            if b16 is not None:
-                b16["y16"] = pooled[1]
+        elif pooled is not None and pooled[0] is not None and tuple(pooled[0].shape) == (x.shape[0], x.shape[1], x.shape[2] // 2, x.shape[3] // 2):
+            y = pooled[0]                   # the producing BatchNorm + ReLU pass already wrote the pooled tensor (onet_bn_relu_apply_pool)
         else:
-            y = ops.maxpool2_fwd(x, bf16_only=bool(b16 and b16.get("bf16_only")))
-            if b16 is not None:                               # bf16 storage: the pooled tensor's bf16 copy, for the caller to re-attach
-                b16["y16"] = ops.b16_of(y)
+            y = ops.maxpool2_fwd(x)
         ctx.save_for_backward(x)
         ctx.link = link if (link is not None and "z" in link) else None
         return (x.view_as(x), y, x.view_as(x)) if returned else (x.view_as(x), y)
@@ -500,10 +462,8 @@ class UpConvTCatFn(torch.autograd.Function):
     pixel-shuffle that writes straight into the second half of the concat buffer."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, packed, cat_holder=None, b16=None, p16=None):
-        """b16 (bf16 storage): dict with "cat16" = the bf16 twin of the concat buffer whose skip half the encoder already
-        wrote; the up-sampled half is written here and b16["ok"] tells the caller whether the twin is complete.
-        p16 (pre-split storage): {"catP": the pre-split concat buffer, skip groups written by the encoder}: the up-sampled groups
+    def forward(ctx, x1, x2, weight, bias, packed, cat_holder=None, p16=None):
+        """p16 (pre-split storage): {"catP": the pre-split concat buffer, skip groups written by the encoder}: the up-sampled groups
         are written here and NO fp32 concat exists (a placeholder goes through the graph)."""
         ops.require_gpu(x1, x2, weight, bias)
         wp_fused, wp_dgrad = packed
@@ -526,17 +486,6 @@ class UpConvTCatFn(torch.autograd.Function):
             ctx.params = (weight, bias)
             return ops.fp32_placeholder((B, C2 + Ct, Ho, Wo), x1.device)
         cat = None if cat_holder is None else cat_holder[0]
-        if b16 is not None and b16.get("bf16_only") and b16.get("cat16") is not None:
-            # bf16 storage, the consuming convolution reads only the bf16 twin of the concat buffer: the skip half is there
-            # already (the encoder's BatchNorm wrote it), the up-sampled half goes there in bf16, and NO fp32 concat exists
-            cat16 = b16["cat16"]
-            if tuple(cat16.shape) == (B, C2 + Ct, Ho, Wo) and (Ho, Wo) == (2 * h, 2 * w) and \
-                    ops.convT2x2_fwd(x1, wp_fused, bias, None, Ct, pt, pl, out16=cat16[:, C2:]):
-                b16["ok"] = True
-                ctx.save_for_backward(x1, wp_dgrad)
-                ctx.meta = (C2, Ct, h, w, pt, pl, tuple(weight.shape), bias is not None)
-                ctx.params = (weight, bias)
-                return ops.fp32_placeholder((B, C2 + Ct, Ho, Wo), x1.device)
         in_place = (cat is not None and tuple(cat.shape) == (B, C2 + Ct, Ho, Wo) and C2 > 0
                     and x2.data_ptr() == cat.data_ptr() and x2.stride() == cat[:, :C2].stride())
         if not in_place:       # x2 is an ordinary tensor: torch.cat's copy of the skip half
@@ -546,10 +495,7 @@ class UpConvTCatFn(torch.autograd.Function):
         if (Ho, Wo) != (2 * h, 2 * w):
             for bi in range(B):                      # F.pad border (only when H or W is not a multiple of 16); raw
                 ops.fill(cat[bi, C2:], 0.0)          # fills: a torch in-place op on the base of the skip view is forbidden
-        cat16 = None if (b16 is None or not in_place) else b16.get("cat16")
-        wrote = ops.convT2x2_fwd(x1, wp_fused, bias, cat[:, C2:], Ct, pt, pl, out16=None if cat16 is None else cat16[:, C2:])
-        if b16 is not None:
-            b16["ok"] = bool(wrote)
+        ops.convT2x2_fwd(x1, wp_fused, bias, cat[:, C2:], Ct, pt, pl)
         ctx.save_for_backward(x1, wp_dgrad)
         ctx.meta = (C2, Ct, h, w, pt, pl, tuple(weight.shape), bias is not None)
         ctx.params = (weight, bias)
@@ -581,7 +527,7 @@ class UpConvTCatFn(torch.autograd.Function):
                 dw = ops.conv_wgrad(x1, dsub, wshape, 1, out_layout=1)
             if need_x1:
                 dx1 = ops.conv_fwd(dsub, wp_dgrad, wshape[0], 1)
-        return dx1, dx2, dw, db, None, None, None, None
+        return dx1, dx2, dw, db, None, None, None
 
 
 @_carries_settings

@@ -113,7 +113,7 @@ class DoubleConv(nn.Module):
         return bool(ops.presplit() and s[1].training and s[4].training and s[1].running_mean is not None)
 
     @staticmethod
-    def _unit(x, conv, bn, out=None, groups=1, link_out=None, link_in=None, out16=None, drop_fp32=False, p16=None):
+    def _unit(x, conv, bn, out=None, groups=1, link_out=None, link_in=None, p16=None):
         training = bn.training or (bn.running_mean is None)
         if x.dim() != 4:
             raise ValueError(f"expected 4D input (got {x.dim()}D input)")
@@ -125,25 +125,20 @@ class DoubleConv(nn.Module):
                              f"{[x.shape[0] // groups, conv.out_channels, x.shape[2], x.shape[3]]}")
         if training and bn.track_running_stats:
             ops.count_batches(bn.num_batches_tracked, groups)
-        # bf16 storage (BASELINE config 3): the bf16 copy of x its producer left, a destination for the copy of the output
-        b16 = {"x16": ops.b16_of(x), "out16": out16, "drop_fp32": drop_fp32} if ops.bf16_storage() else None
         # magnitude slots (ops.tag_amax): what x's producer recorded of it goes in, what this unit records of its output comes out
         aux = {"x_amax": ops.amax_of(x)}
         a = Fn.ConvBNReLUFn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                  training, bn.momentum, bn.eps, conv.packed(), out, groups, link_out, link_in, b16, aux, p16)
-        if b16 is not None:
-            ops.tag_b16(a, b16.get("a16"))
+                                  training, bn.momentum, bn.eps, conv.packed(), out, groups, link_out, link_in, aux, p16)
         if p16 is not None:
             ops.tag_p16(a, p16.get("a"), p16.get("a_slots"))      # pre-split storage: the output's pre-split form (+ its scale slots) rides on it
             if p16.get("a_amax") is not None:
                 return ops.tag_amax(a, p16["a_amax"])
         return ops.tag_amax(a, aux.get("a_amax"))
 
-    def forward(self, x, out=None, groups=1, pool_link=None, out16=None, p16_out=None):
+    def forward(self, x, out=None, groups=1, pool_link=None, p16_out=None):
         """`out`: optional plane-contiguous [B, Cout, H, W] destination view (the skip half of a concat buffer);
         `groups`: the batch holds that many independent BatchNorm batches (twin pass); `pool_link`: dict the second
-        unit publishes its (z, save) in for the SkipPoolFn that consumes the block's output; `out16`: the matching view
-        of the concat buffer's bf16 twin (bf16 storage); `p16_out` (pre-split storage): {"out": pre-split destination of the
+        unit publishes its (z, save) in for the SkipPoolFn that consumes the block's output; `p16_out` (pre-split storage): {"out": pre-split destination of the
         block's output (the skip groups of a pre-split concat buffer), "keep_fp32": the fp32 tensor is needed too}."""
         s = self.double_conv
         link = {}       # unit 1 -> unit 2: lets unit 2's dgrad launch take unit 1's BatchNorm-backward reduce pass with it
@@ -162,17 +157,13 @@ class DoubleConv(nn.Module):
                       "out": None if p16_out is None else p16_out.get("out"),
                       "keep_fp32": True if p16_out is None else bool(p16_out.get("keep_fp32"))}
                 return self._unit(a1, s[3], s[4], None, groups, link_out=pool_link, link_in=link, p16=p2)
-        # bf16 storage: unit 1's output feeds unit 2's convolution only -- where that reads the bf16 copy (forward and weight
-        # gradient), unit 1 writes no fp32 activation at all
-        drop1 = x.dim() == 4 and ops.consumer_reads_bf16(x.shape[0], s[3].in_channels, s[3].out_channels, x.shape[2], x.shape[3])
         # fp32 model, split-bf16 kernels: unit 2's convolution (forward and weight gradient) applies unit 1's BatchNorm + ReLU
         # on load -- unit 1 writes no activation (functional.ConvBNReLUFn; bit-identical to the materialised form)
-        if (x.dim() == 4 and x.is_cuda and not drop1 and s[1].training and s[4].training and s[1].running_mean is not None
+        if (x.dim() == 4 and x.is_cuda and s[1].training and s[4].training and s[1].running_mean is not None
                 and ops.norm_on_load_ok(x.shape[0], s[3].in_channels, s[3].out_channels, x.shape[2], x.shape[3], groups)):
             link["defer"] = True
-        a1 = self._unit(x, s[0], s[1], None, groups, link_out=link, drop_fp32=drop1)
-        return self._unit(a1, s[3], s[4], None if out is None else (out,), groups, link_out=pool_link, link_in=link,
-                          out16=out16)
+        a1 = self._unit(x, s[0], s[1], None, groups, link_out=link)
+        return self._unit(a1, s[3], s[4], None if out is None else (out,), groups, link_out=pool_link, link_in=link)
 
 
 _SKIPPOOL = ops._flag("SKIPPOOL", True)
@@ -195,11 +186,11 @@ class Down(nn.Module):
         super().__init__()
         self.maxpool_conv = nn.Sequential(MaxPool2(), DoubleConv(in_channels, out_channels))
 
-    def forward(self, x, out=None, groups=1, pooled=None, pool_link=None, out16=None, p16_out=None):
+    def forward(self, x, out=None, groups=1, pooled=None, pool_link=None, p16_out=None):
         """`pooled`: maxpool2(x) when the caller already has it (UNet.forward pools skip tensors with SkipPoolFn);
-        `pool_link`, `out16`, `p16_out`: see DoubleConv.forward."""
+        `pool_link`, `p16_out`: see DoubleConv.forward."""
         p = self.maxpool_conv[0](x) if pooled is None else pooled
-        return self.maxpool_conv[1](p, out=out, groups=groups, pool_link=pool_link, out16=out16, p16_out=p16_out)
+        return self.maxpool_conv[1](p, out=out, groups=groups, pool_link=pool_link, p16_out=p16_out)
 
 
 class ConvT2x2(nn.ConvTranspose2d, _Packable):
@@ -242,29 +233,20 @@ class Up(nn.Module):
             self.up = ConvT2x2(in_channels, in_channels // 2)
             self.conv = DoubleConv(in_channels, out_channels)
 
-    def forward(self, x1, x2, cat=None, groups=1, cat16=None, catP=None):
+    def forward(self, x1, x2, cat=None, groups=1, catP=None):
         """`cat`: optional concat buffer whose first channels already ARE x2 (UNet.forward lets the encoder write its
-        skip outputs there, so torch.cat's copy of the skip tensor, OV:100, never happens); `cat16`: its bf16 twin (bf16
-        storage), skip half already written; `catP` (pre-split storage): the pre-split concat buffer, skip groups already written."""
+        skip outputs there, so torch.cat's copy of the skip tensor, OV:100, never happens); `catP` (pre-split storage): the pre-split concat buffer, skip groups already written."""
         if isinstance(self.up, ConvT2x2) and catP is not None:
             # scales of the two producers of the concat buffer: the skip groups' (the encoder's BatchNorm bound), the up-sampled groups'
             # (a bound from this layer's weights and the exact maximum of x1, where its producer recorded one)
             s_skip, x1_amax = ops.p16_slots(x2), ops.amax_of(x1)
             s_up = ops.convT2x2_out_bound(self.up.weight, self.up.bias, x1_amax) if (x1_amax is not None and catP.shape[3] == 2) else None
             p16 = {"catP": catP, "up_slots": s_up}
-            x = Fn.UpConvTCatFn.apply(x1, x2, self.up.weight, self.up.bias, self.up.packed(), None, None, p16)
+            x = Fn.UpConvTCatFn.apply(x1, x2, self.up.weight, self.up.bias, self.up.packed(), None, p16)
             ops.tag_p16(x, catP, (s_skip, s_up, x2.shape[1]) if (s_skip is not None or s_up is not None) else None)
             return self.conv(x, groups=groups)
         if isinstance(self.up, ConvT2x2):
-            dc = self.conv.double_conv[0]
-            b16 = None
-            if cat16 is not None and ops.bf16_storage():
-                b16 = {"cat16": cat16, "bf16_only": cat is None and ops.consumer_reads_bf16(
-                    x2.shape[0], dc.in_channels, dc.out_channels, x2.shape[2], x2.shape[3])}
-            x = Fn.UpConvTCatFn.apply(x1, x2, self.up.weight, self.up.bias, self.up.packed(),
-                                      None if cat is None else (cat,), b16)
-            if b16 is not None and b16.get("ok"):
-                ops.tag_b16(x, cat16)
+            x = Fn.UpConvTCatFn.apply(x1, x2, self.up.weight, self.up.bias, self.up.packed(), None if cat is None else (cat,))
         else:
             x = Fn.UpBilinearCatFn.apply(x1, x2)
         return self.conv(x, groups=groups)
@@ -316,20 +298,13 @@ class UNet(nn.Module):
         # ConvTranspose path: the four skip tensors are produced directly inside the first half of their concat
         # buffers (allocated here, before the encoder runs), the decoder fills the second half
         cats = [None] * 4
-        cats16 = [None] * 4                              # bf16 storage: the concat buffers' bf16 twins
         if not self.bilinear and x.dim() == 4 and x.is_cuda:
             B, h, w = x.shape[0], x.shape[2], x.shape[3]
             for k, enc in enumerate((self.inc, self.down1.maxpool_conv[1], self.down2.maxpool_conv[1],
                                      self.down3.maxpool_conv[1])):
                 C = enc.double_conv[3].out_channels
                 if h > 0 and w > 0:
-                    dec = (self.up4, self.up3, self.up2, self.up1)[k].conv.double_conv[0]
-                    if ops.bf16_storage():
-                        cats16[k] = torch.empty((B, 2 * C, h, w), dtype=torch.bfloat16, device=x.device)
-                    # bf16 storage: where the decoder's first convolution reads only the bf16 twin, no fp32 concat buffer is
-                    # made (the skip tensor is an ordinary fp32 tensor, the up-sampled half exists in bf16 only)
-                    if not (ops.consumer_reads_bf16(B, dec.in_channels, dec.out_channels, h, w) and h % 2 == 0 and w % 2 == 0):
-                        cats[k] = torch.empty((B, 2 * C, h, w), dtype=torch.float32, device=x.device)
+                    cats[k] = torch.empty((B, 2 * C, h, w), dtype=torch.float32, device=x.device)
                 h, w = h // 2, w // 2
 
         # pre-split storage: where the decoder's first convolution runs on pre-split operands (ops.pre_layer_ok), the concat buffer
@@ -360,27 +335,17 @@ class UNet(nn.Module):
         def skipP(k, C, keep_fp32=False):
             return None if catsP[k] is None else {"out": catsP[k][:, :C // 8], "keep_fp32": keep_fp32}
 
-        def skip16(k, C):
-            return None if cats16[k] is None else cats16[k][:, :C]
-
         g = groups
 
         def fork(t, returned=False, link=None, nxt=None):
             # skip tensors feed the next Down's pooling AND an Up's concat (x1 also leaves as the first output): one
             # node, so that their gradients are summed inside the pooling-backward kernel
             if t.is_cuda and _SKIPPOOL:
-                b16 = None
-                if ops.bf16_storage():       # the pooled tensor feeds `nxt`'s first convolution only: bf16 copy alone where it reads that
-                    c = nxt.maxpool_conv[1].double_conv[0]
-                    b16 = {"bf16_only": ops.consumer_reads_bf16(t.shape[0], c.in_channels, c.out_channels, t.shape[2] // 2,
-                                                                t.shape[3] // 2)}
                 am = ops.amax_of(t)
-                if b16 is None and ops.presplit():
-                    b16 = {}                                  # (carries the pooled tensor's pre-split form back: "yP")
-                outs = Fn.SkipPoolFn.apply(t, returned, link, b16)
-                if b16 is not None:
-                    ops.tag_b16(outs[1], b16.get("y16"))     # the pooled tensor's bf16 copy, for the next block's first conv
-                    ops.tag_p16(outs[1], b16.get("yP"), ops.p16_slots(t))    # ... or its pre-split form (max-pooling keeps the bound)
+                carry = {} if ops.presplit() else None        # (carries the pooled tensor's pre-split form back: "yP")
+                outs = Fn.SkipPoolFn.apply(t, returned, link, carry)
+                if carry is not None:
+                    ops.tag_p16(outs[1], carry.get("yP"), ops.p16_slots(t))  # the pooled tensor's pre-split form (max-pooling keeps the bound)
                     ops.tag_p16(outs[0], ops.p16_of(t), ops.p16_slots(t))     # the skip view keeps the tensor's pre-split form
                 ops.tag_amax(outs[1], am)                    # max-pooling keeps the maximum: the same slots bound the pooled tensor
                 return outs
@@ -394,26 +359,22 @@ class UNet(nn.Module):
         c3 = self.down3.maxpool_conv[1].double_conv[3].out_channels
         if x.dim() == 4 and x.is_cuda and _SKIPPOOL and ops.FUSE_POOL:
             # the four encoder outputs are max-pooled next: their BatchNorm + ReLU pass writes the pooled tensor too
-            hh, ww = x.shape[2], x.shape[3]
-            for i, nxt in enumerate((self.down1, self.down2, self.down3, self.down4)):
-                cv = nxt.maxpool_conv[1].double_conv[0]
-                pl[i]["want_pool"] = {"bf16_only": ops.consumer_reads_bf16(x.shape[0], cv.in_channels, cv.out_channels, hh // 2, ww // 2),
-                                      "p16": pool_p[i]}
-                hh, ww = hh // 2, ww // 2
+            for i in range(4):
+                pl[i]["want_pool"] = {"p16": pool_p[i]}
         # (pre-split storage: x1 leaves the U-Net and feeds the head, so it keeps its fp32 tensor beside the pre-split skip groups)
-        x1 = self.inc(x, out=skip(0, c0), groups=g, pool_link=pl[0], out16=skip16(0, c0), p16_out=skipP(0, c0, True))
+        x1 = self.inc(x, out=skip(0, c0), groups=g, pool_link=pl[0], p16_out=skipP(0, c0, True))
         x1, p1, x1_out = fork(x1, True, pl[0], self.down1)
-        x2 = self.down1(x1, out=skip(1, c1), groups=g, pooled=p1, pool_link=pl[1], out16=skip16(1, c1), p16_out=skipP(1, c1))
+        x2 = self.down1(x1, out=skip(1, c1), groups=g, pooled=p1, pool_link=pl[1], p16_out=skipP(1, c1))
         x2, p2 = fork(x2, False, pl[1], self.down2)
-        x3 = self.down2(x2, out=skip(2, c2), groups=g, pooled=p2, pool_link=pl[2], out16=skip16(2, c2), p16_out=skipP(2, c2))
+        x3 = self.down2(x2, out=skip(2, c2), groups=g, pooled=p2, pool_link=pl[2], p16_out=skipP(2, c2))
         x3, p3 = fork(x3, False, pl[2], self.down3)
-        x4 = self.down3(x3, out=skip(3, c3), groups=g, pooled=p3, pool_link=pl[3], out16=skip16(3, c3), p16_out=skipP(3, c3))
+        x4 = self.down3(x3, out=skip(3, c3), groups=g, pooled=p3, pool_link=pl[3], p16_out=skipP(3, c3))
         x4, p4 = fork(x4, False, pl[3], self.down4)
         x5 = self.down4(x4, groups=g, pooled=p4)
-        y4 = self.up1(x5, x4, cat=cats[3], groups=g, cat16=cats16[3], catP=catsP[3])
-        y3 = self.up2(y4, x3, cat=cats[2], groups=g, cat16=cats16[2], catP=catsP[2])
-        y2 = self.up3(y3, x2, cat=cats[1], groups=g, cat16=cats16[1], catP=catsP[1])
-        y1 = self.up4(y2, x1, cat=cats[0], groups=g, cat16=cats16[0], catP=catsP[0])
+        y4 = self.up1(x5, x4, cat=cats[3], groups=g, catP=catsP[3])
+        y3 = self.up2(y4, x3, cat=cats[2], groups=g, catP=catsP[2])
+        y2 = self.up3(y3, x2, cat=cats[1], groups=g, catP=catsP[1])
+        y1 = self.up4(y2, x1, cat=cats[0], groups=g, catP=catsP[0])
         return x1_out, y1
 
 

@@ -55,7 +55,6 @@ class Settings:
       conv          3x3 convolution algorithm: "auto" | "split" | "winograd4" | "direct" | "bf16"         (default CONV_ALGO)
       twin          weight-shared Onet: X and 1-X as ONE batch of 2B                                        (default TWIN)
       convt_bf16    under conv == "bf16": the ConvTranspose2d GEMMs take bf16 operands too                  (default CONVT_BF16)
-      bf16_storage  under conv == "bf16": producers write bf16 copies of the conv operands                  (default BF16_STORAGE)
       lazy_nan      OV:234's NaN assertion deferred to FlatAdam.step()                                      (default LAZY_NAN_CHECK)
       split         under conv == "auto": fp32 3x3 convolutions on the bf16 matrix pipe by operand splitting   (default SPLIT_AUTO)
       bn_on_load    the second convolution of a DoubleConv applies the first unit's BatchNorm + ReLU on load     (default BN_ON_LOAD)
@@ -66,14 +65,14 @@ class Settings:
       sync_bn       BatchNorm statistics all-gathered over the process group                                       (default SYNC_BN)
       presplit      the split kernels' operands are written pre-split (fp16 hi | mid slots) by their producers     (default PRESPLIT)
       z_bf16        under conv == "bf16" with pre-split operands: the convolution outputs z are STORED as bf16          (default Z_BF16)"""
-    __slots__ = ("conv", "twin", "convt_bf16", "bf16_storage", "lazy_nan", "split", "bn_on_load", "split_f16", "grad_f16", "split_dgrad",
+    __slots__ = ("conv", "twin", "convt_bf16", "lazy_nan", "split", "bn_on_load", "split_f16", "grad_f16", "split_dgrad",
                  "stem_fused", "sync_bn", "presplit", "z_bf16")
 
-    def __init__(self, conv=None, twin=None, convt_bf16=None, bf16_storage=None, lazy_nan=None, split=None, bn_on_load=None,
+    def __init__(self, conv=None, twin=None, convt_bf16=None, lazy_nan=None, split=None, bn_on_load=None,
                  split_f16=None, grad_f16=None, split_dgrad=None, stem_fused=None, sync_bn=None, presplit=None, z_bf16=None):
         self.presplit = presplit
         self.z_bf16 = z_bf16
-        self.conv, self.twin, self.convt_bf16, self.bf16_storage, self.lazy_nan = conv, twin, convt_bf16, bf16_storage, lazy_nan
+        self.conv, self.twin, self.convt_bf16, self.lazy_nan = conv, twin, convt_bf16, lazy_nan
         self.split, self.bn_on_load = split, bn_on_load
         self.split_f16, self.grad_f16, self.split_dgrad, self.stem_fused, self.sync_bn = split_f16, grad_f16, split_dgrad, stem_fused, sync_bn
 
@@ -156,7 +155,7 @@ def presplit():
     if not bool(_setting("presplit", PRESPLIT)) or sync_bn() or not (FUSE_BN_STATS and FUSE_BN_REDUCE and FUSE_POOL):
         return False
     if conv_algo() == "bf16":           # BASELINE configs[2]: the same machinery with ONE part of plain bf16 operands (p16_parts() == 1)
-        return PRESPLIT_BF16
+        return True
     return split_enabled() and conv_algo() in ("auto", "split") and split_f16() and split_dgrad()
 
 
@@ -391,38 +390,22 @@ def packT2x2_fused(w):
 
 
 # BASELINE configs[2]: under the bf16 conv path the ConvTranspose2d GEMMs take bf16 MFMA operands too (what torch.autocast does to
-# nn.ConvTranspose2d); ONET_CONVT_BF16=0 keeps them fp32.  Passed to the library per call (`operand_bf16`).
+# nn.ConvTranspose2d); CONVT_BF16=0 (ONET_FLAGS) keeps them fp32.  Passed to the library per call (`operand_bf16`).
 CONVT_BF16 = _flag("CONVT_BF16", True)
 
 
-def convT2x2_fwd(x, wq, bias, out, Ct, pt, pl, out16=None):
+def convT2x2_fwd(x, wq, bias, out, Ct, pt, pl):
     """out[:, c, pt + 2i + di, pl + 2j + dj] = sum_ci x[:, ci, i, j] * W[ci, c, di, dj] + bias[c]: ConvTranspose2d(k=2, s=2)
-    written straight into `out`, a plane-contiguous [B, Ct, Ho, Wo] view (e.g. the second half of a concat buffer).
-    out16: the matching bf16 view (bf16 storage) -> returns True if the copy was written (128 x 128 GEMM path only)."""
+    written straight into `out`, a plane-contiguous [B, Ct, Ho, Wo] view (e.g. the second half of a concat buffer)."""
     require_gpu(x, wq, out)
     x, xbs = plane(x)
     B, Cin, h, w = x.shape
-    ref = out if out is not None else out16          # out None (with out16): bf16 output only -- returns False if not possible
-    Ho, Wo = ref.shape[2], ref.shape[3]
-    obs = 0 if out is None else (out.stride(0) if B > 1 else Ct * Ho * Wo)
-    flops, nb = 2.0 * B * h * w * Cin * 4 * Ct, 4.0 * (B * h * w * (Cin + 4 * Ct) + 4 * Cin * Ct)
-    if out16 is not None:
-        o16bs = out16.stride(0) if B > 1 else Ct * Ho * Wo
-        e0 = _prof_begin("convt_gemm_kernel")
-        rc = _lib.load().onet_convT2x2_fwd_b(_p(x), xbs, _p(wq), _p(bias), _p(out), obs, _p(out16), o16bs, B, Cin, Ct, h, w, Ho, Wo,
-                                             pt, pl, convt_operand_bf16(B, h, w, Ct), _stream())
-        _prof_end("convt_gemm_kernel", flops if rc == 0 else 0.0, e0, nb if rc == 0 else 0.0)
-        if rc == 0:
-            return True
-        if rc < 0:
-            raise _lib.OnetHipError(f"onet_convT2x2_fwd_b failed ({rc}): {_lib.last_error()}")
-    if out is None:
-        return False
+    Ho, Wo = out.shape[2], out.shape[3]
+    obs = out.stride(0) if B > 1 else Ct * Ho * Wo
     e0 = _prof_begin("convt_gemm_kernel")
     _lib.call("onet_convT2x2_fwd", _p(x), xbs, _p(wq), _p(bias), _p(out), obs, B, Cin, Ct, h, w, Ho, Wo, pt, pl,
               convt_operand_bf16(B, h, w, Ct), _stream())
-    _prof_end("convt_gemm_kernel", flops, e0, nb)
-    return False
+    _prof_end("convt_gemm_kernel", 2.0 * B * h * w * Cin * 4 * Ct, e0, 4.0 * (B * h * w * (Cin + 4 * Ct) + 4 * Cin * Ct))
 
 
 def convT2x2_out_bound(weight, bias, x_amax):
@@ -452,56 +435,26 @@ def convT2x2_fwd_p(x, wq, bias, outP, Ct, pt, pl, slots=None):
 
 
 # 3x3 convolution algorithm for fwd/dgrad, chosen per call from the layer shape (ONET_CONV_ALGO overrides):
-#   "auto" (default)  the split-bf16 kernel (fp32 accuracy on the bf16 matrix cores, conv_split.hip) on maps at least 32 pixels wide
-#                     with Cin % 16 == 0 and enough tiles to fill the chip; else Winograd F(4x4,3x3) where its 64-channel x
-#                     32-tile blocks fill the chip, else F(2x2,3x3), else the direct implicit-GEMM kernel
-#   "split"           the split-bf16 kernel on every legal layer (parity tests)
+#   "auto" (default)  the split kernels (fp32-level results on the 16-bit matrix cores, conv_split.hip) on maps at least 32 pixels wide
+#                     with Cin % 16 == 0 and enough tiles to fill the chip (pre-split operands: also the 16-pixel level at batches that
+#                     fill it, pre_layer_ok); else Winograd F(4x4,3x3) where its 64-channel x 32-tile blocks fill the chip, else the
+#                     direct implicit-GEMM kernel
+#   "split"           the split kernels on every legal layer (parity tests)
 #   "winograd4"       F(4x4,3x3) on every legal layer with maps >= 8x8 (parity tests; the fp32-MFMA reference dispatch of bench.py)
 #   "direct"          implicit GEMM only
-#   "bf16"            BASELINE config 3: bf16-operand MFMA kernel (conv_bf16.hip) for forward / input gradient on every
-#                     layer with Cin % 16 == 0 and the weight gradient of every layer with Cin >= 16, on maps >= 16 px wide; "auto" (fp32) elsewhere
+#   "bf16"            BASELINE configs[2]: ONE part of plain bf16 operands through the pre-split kernels (forward, input gradient,
+#                     weight gradient) on every layer pre_layer_ok takes -- 32-channel chunks, maps made of full 16 x 32 tiles; "auto"
+#                     (fp32 results) elsewhere (round 5 dropped the round-2 bf16 kernels that served the other shapes)
 # Layers no Winograd kernel takes (stem Cin < 16, channel counts not multiples of 4) always run direct.
 import os as _os
 CONV_ALGO = _os.environ.get("ONET_CONV_ALGO", "auto")
 # Weight-shared Onet (dwnu is topu): run the X and the 1-X pass as ONE batch of 2B through every convolution
-# (BatchNorm keeps the two halves as separate statistics groups).  ONET_TWIN=0 runs the two passes one after the
+# (BatchNorm keeps the two halves as separate statistics groups).  TWIN=0 (ONET_FLAGS) runs the two passes one after the
 # other, as the reference does.
 TWIN = _flag("TWIN", True)
 
 
-# bf16 STORAGE of the conv operands (only with CONV_ALGO == "bf16", BASELINE config 3): the kernels that produce an
-# activation or a pre-activation gradient also write a bf16 copy, and the bf16 conv kernels read that copy instead of rounding
-# the fp32 tensor on the way into LDS -- same rounding (nearest even), so bit-identical results at half the operand bytes.
-# A tensor carries its copy as `t._onet_b16 = (bf16 tensor, t._version)`.  ONET_BF16_STORAGE=0 keeps fp32 operands.
-BF16_STORAGE = _flag("BF16_STORAGE", True)
 BF = torch.bfloat16
-
-
-def bf16_storage():
-    return bool(_setting("bf16_storage", BF16_STORAGE)) and conv_algo() == "bf16" and not presplit()
-
-
-def b16_of(t):
-    """The valid bf16 copy riding on fp32 tensor `t`, or None."""
-    tag = getattr(t, "_onet_b16", None)
-    if tag is None or not bf16_storage():
-        return None
-    t16, ver = tag
-    if ver != t._version or tuple(t16.shape) != tuple(t.shape) or t16.dtype != BF:
-        return None
-    return t16
-
-
-def tag_b16(t, t16):
-    if t16 is not None:
-        t._onet_b16 = (t16, t._version)
-    return t
-
-
-def consumer_reads_bf16(B, Cin, Cout, H, W):
-    """Will a 3x3 convolution (Cin -> Cout on B maps of H x W) read ONLY the bf16 copy of its input -- forward and weight
-    gradient both on the bf16 kernels?  Then the producer need not write the fp32 tensor at all."""
-    return bf16_storage() and conv3x3_algo(B, Cin, Cout, H, W) == "bf16" and wgrad_takes_bf16(Cin, H, W) and W % 8 == 0
 
 
 _SENTINEL = {}
@@ -524,7 +477,7 @@ def is_placeholder(t):
 
 def fp32_placeholder(shape, device):
     """A zero-stride fp32 tensor of the given shape over the device's sentinel storage (4 bytes): what autograd passes around
-    in place of an activation whose only consumers read its bf16 copy (`_onet_b16`).  Never read by a kernel (`plane` raises).
+    in place of an activation that exists only in its consumers' operand form (pre-split slots).  Never read by a kernel (`plane` raises).
     Not a view: it has its own version counter, which is what validates the bf16 copy riding on it."""
     t = torch.empty(0, dtype=F32, device=device)
     t.set_(_sentinel(t.device).untyped_storage(), 0, tuple(shape), (0,) * len(shape))
@@ -569,17 +522,6 @@ def _z16(z):
     """1 if the convolution output z is stored as bf16 (BASELINE configs[2] with Settings.z_bf16), else 0 (fp32): what the entry points
     that read z take as `z_bf16`; batch strides stay in elements."""
     return int(z.dtype == torch.bfloat16)
-
-
-def plane16(t):
-    """-> (bf16 tensor, batch stride in elements) if its (C,H,W) block is contiguous per image, else (None, 0)."""
-    if t is None:
-        return None, 0
-    B, C, H, W = t.shape
-    ok = (W == 1 or t.stride(3) == 1) and (H == 1 or t.stride(2) == W) and (C == 1 or t.stride(1) == H * W)
-    if not ok or (B > 1 and t.stride(0) < C * H * W):
-        return None, 0
-    return t, (t.stride(0) if B > 1 else C * H * W)
 
 
 def _wino_legal(Cin, Cout):
@@ -646,8 +588,7 @@ class Packed3x3(dict):
 
     def get_pack(self, algo):
         if algo not in self:
-            self[algo] = {"direct": pack3x3, "winograd4": pack3x3_winograd4,
-                          "bf16": pack3x3_bf16, "split": pack3x3_split, "plain16": pack3x3_plain16}[algo](self.w)
+            self[algo] = {"direct": pack3x3, "winograd4": pack3x3_winograd4, "split": pack3x3_split, "plain16": pack3x3_plain16}[algo](self.w)
         return self[algo]
 
 
@@ -657,23 +598,32 @@ def pack3x3_auto(w):
     return Packed3x3(w)
 
 
-def conv3x3_auto(x, pk, direction, out=None, x16=None, amax=None):
+def _fp32_algo(B, Cin, Cout, H, W):
+    """conv3x3_algo for a layer that runs on fp32 tensors whatever the model's setting: under conv == "bf16" the layers outside the
+    pre-split plain-bf16 kernels' reach (the stem, the smallest maps, odd shapes) take the fp32 dispatch -- round 5 dropped the
+    round-2 bf16 kernels that used to serve them."""
+    algo = conv3x3_algo(B, Cin, Cout, H, W)
+    if algo != "bf16":
+        return algo
+    cur = active_settings()
+    with using(cur.replace(conv="auto") if cur is not None else Settings(conv="auto")):
+        return conv3x3_algo(B, Cin, Cout, H, W)
+
+
+def conv3x3_auto(x, pk, direction, out=None, amax=None):
     """direction 0: forward (Cin -> Cout); 1: dgrad (Cout -> Cin) with the flipped/transposed pack.
-    x16: a bf16 copy of x (bf16 storage); x itself may then be None (shape taken from x16).
     amax: the 64 magnitude slots of x (int32 [64], written by its producer): what the fp16 split kernels scale x by."""
     Ci, Co = (pk["Cin"], pk["Cout"]) if direction == 0 else (pk["Cout"], pk["Cin"])
-    shp = (x if x is not None else x16).shape
-    algo = conv3x3_algo(shp[0], Ci, Co, shp[2], shp[3])
+    shp = x.shape
+    algo = _fp32_algo(shp[0], Ci, Co, shp[2], shp[3])
     if algo == "split" and direction == 1 and not split_dgrad():     # diagnostic: input gradients on the fp32-MFMA kernels
         with using(active_settings().replace(split=False) if active_settings() is not None else Settings(split=False)):
-            algo = conv3x3_algo(shp[0], Ci, Co, shp[2], shp[3])
+            algo = _fp32_algo(shp[0], Ci, Co, shp[2], shp[3])
     wq = pk.get_pack(algo)[direction]
     if algo == "winograd4":
         return conv3x3_winograd4(x, wq, Co, out=out)
     if algo == "split":
         return conv3x3_split(x, wq, Co, out=out, amax=amax, always=direction == 1)
-    if algo == "bf16":
-        return conv3x3_bf16(x, wq, Co, out=out, x16=x16)
     return conv_fwd(x, wq, Co, 3, out=out)
 
 
@@ -685,7 +635,6 @@ CONVT_SPLIT = _flag("CONVT_SPLIT", True)     # 0: the ConvTranspose2d GEMMs stay
 SPLIT_F16 = _flag("SPLIT_F16", True)         # 0: the forward split kernel takes bf16 parts like the gradients
 SPLIT_DGRAD = _flag("SPLIT_DGRAD", True)     # 0 (diagnostic): input gradients stay on the fp32-MFMA kernels
 PRESPLIT = _flag("PRESPLIT", True)           # 1: pre-split operand storage (Settings.presplit)
-PRESPLIT_BF16 = _flag("PRESPLIT_BF16", True)  # ... also under conv == "bf16" (0: round 3's bf16 kernels + bf16 storage)
 PRESPLIT_W16 = _flag("PRESPLIT_W16", True)    # ... also the 16-pixel level (0: fp32 Winograd F(4x4) there, as in round 3)
 # diagnostic / tests: every activation written pre-split ALSO leaves its fp32 tensor (same values: the parts are split from them), so
 # that a harness can read each unit's output; the kernels that consume the pre-split forms are unchanged
@@ -699,7 +648,7 @@ SPLIT_AUTO = _flag("SPLIT", True)          # 0: "auto" never selects the split-b
 STEM_FUSED = _flag("STEM_FUSED", True)      # 0: the stem takes the direct MFMA kernel + a statistics pass
 
 
-def conv3x3_fwd_bn_partials(x, pk, x16=None, norm=None, amax=None):
+def conv3x3_fwd_bn_partials(x, pk, norm=None, amax=None):
     """Forward 3x3 convolution of a Conv-BatchNorm pair (OV:47-48, 51-52): -> (z, cm).  cm = the channel-major
     BatchNorm records [Cout, nparts, 3] the F(4x4) kernel's epilogue emits (image-major: nparts / B per image), or None
     where the selected kernel does not emit them (then `bn_train_coeffs` runs its own statistics pass).
@@ -720,8 +669,8 @@ def conv3x3_fwd_bn_partials(x, pk, x16=None, norm=None, amax=None):
                   Co * H * W, _p(cm), B, Ci, Co, H, W, _stream())
         _prof_end("conv3x3_split_kernel", 2.0 * B * H * W * Ci * Co * 9, e0, 4.0 * (B * H * W * (Ci + Co) + 9 * Ci * Co))
         return out, cm
-    B, _, H, W = (x if x is not None else x16).shape
-    if Ci <= 4 and x is not None and stem_fused() and FUSE_BN_STATS and not sync_bn() and hasattr(pk, "w"):
+    B, _, H, W = x.shape
+    if Ci <= 4 and stem_fused() and FUSE_BN_STATS and not sync_bn() and hasattr(pk, "w"):
         # the stem (Cin = n_channels): one streaming pass writes z and its statistics records (stem.hip)
         nparts = int(_lib.load().onet_conv3x3_stem_nparts(B, Ci, Co, H, W))
         if nparts > 0:
@@ -736,29 +685,11 @@ def conv3x3_fwd_bn_partials(x, pk, x16=None, norm=None, amax=None):
                       B // 2 if tw is not None else 0, tw[1] if tw is not None else 0.0, _stream())
             _prof_end("stem_conv_stats_kernel", 2.0 * B * H * W * Ci * Co * 9, e0, 4.0 * (B * H * W * (Ci + Co) + 9 * Ci * Co))
             return out, cm
-    algo = conv3x3_algo(B, Ci, Co, H, W)
+    algo = _fp32_algo(B, Ci, Co, H, W)
     nparts = 0
     if algo == "winograd4" and FUSE_BN_STATS and not sync_bn():
         nparts = int(_lib.load().onet_conv3x3_winograd4_nparts(B, H, W))
-    if algo == "bf16" and FUSE_BN_STATS and not sync_bn():
-        nparts = int(_lib.load().onet_conv3x3_bf16_nparts(B, H, W))
-        x16p, x16bs = plane16(x16)
-        if nparts > 0 and (x16p is not None or x is not None):
-            wq = pk.get_pack(algo)[0]
-            if x16p is None:
-                require_gpu(x)
-                xs, xbs = plane(x)
-            dev = (x16p if x16p is not None else x).device
-            out = torch.empty((B, Co, H, W), dtype=F32, device=dev)
-            cm = torch.empty((Co, nparts, 3), dtype=F32, device=dev)
-            e0 = _prof_begin("conv3x3_bf16_kernel")
-            _lib.call("onet_conv3x3_bf16_fwd_stats", _p(x16p if x16p is not None else xs), int(x16p is not None),
-                      x16bs if x16p is not None else xbs, _p(wq), _p(out), Co * H * W, _p(cm), B, Ci, Co, H, W, _stream())
-            _prof_end("conv3x3_bf16_kernel", 2.0 * B * H * W * Ci * Co * 9, e0,
-                      B * H * W * ((2.0 if x16p is not None else 4.0) * Ci + 4.0 * Co) + 18.0 * Ci * Co)
-            return out, cm
-        nparts = 0
-    if algo == "split" and FUSE_BN_STATS and not sync_bn() and x is not None:
+    if algo == "split" and FUSE_BN_STATS and not sync_bn():
         nparts = int(_lib.load().onet_conv3x3_split_nparts(B, H, W))
         if nparts > 0:
             wq = pk.get_pack(algo)[0]
@@ -778,7 +709,7 @@ def conv3x3_fwd_bn_partials(x, pk, x16=None, norm=None, amax=None):
             _prof_end("conv3x3_split_kernel", 2.0 * B * H * W * Ci * Co * 9, e0, 4.0 * (B * H * W * (Ci + Co) + 9 * Ci * Co))
             return out, cm
     if nparts <= 0:
-        return conv3x3_auto(x, pk, 0, x16=x16, amax=amax), None
+        return conv3x3_auto(x, pk, 0, amax=amax), None
     wq = pk.get_pack(algo)[0]
     require_gpu(x, wq)
     x, xbs = plane(x)
@@ -851,48 +782,6 @@ def conv3x3_winograd4(x, wq, Cout, out=None):
     e0 = _prof_begin("conv_wino4_kernel")
     _lib.call("onet_conv3x3_winograd4_fwd", _p(x), xbs, _p(wq), _p(out), zbs, B, Cin, Cout, H, W, _stream())
     _prof_end("conv_wino4_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout))
-    return out
-
-
-def pack3x3_bf16(w):
-    """bf16 packs of a 3x3 weight for conv_bf16.hip: (fwd [Cin/16][9][Cout][16], dgrad [Cout/16][9][Cin][16]); a pack
-    whose K dimension is not a multiple of 16 is None (that orientation takes the fp32 kernels)."""
-    require_gpu(w)
-    w = w.detach().contiguous()
-    Cout, Cin = w.shape[0], w.shape[1]
-    BF = torch.bfloat16
-    wf = torch.empty(Cin * 9 * Cout, dtype=BF, device=w.device) if Cin % 16 == 0 else None
-    wd = torch.empty(-(-Cout // 16) * 16 * 9 * Cin, dtype=BF, device=w.device) if Cout % 16 == 0 else None
-    if wf is not None or wd is not None:
-        _lib.call("onet_conv3x3_pack_weights_bf16", _p(w), _p(wf), _p(wd), Cout, Cin, _stream())
-    return wf, wd
-
-
-def conv3x3_bf16(x, wq, Cout, out=None, x16=None):
-    """z = conv3x3(x) with bf16 operands (x rounded on load, wq packed bf16), fp32 accumulation and output.
-    x16: a bf16 copy of x written by its producer (bf16 storage): read instead of x -- same rounding, half the bytes."""
-    if wq is None or not wq.is_cuda or wq.dtype != torch.bfloat16:
-        raise TypeError("conv3x3_bf16: wq must be a bf16 pack on the GPU (pack3x3_bf16)")
-    x16, x16bs = plane16(x16)
-    if x16 is not None:
-        B, Cin, H, W = x16.shape
-        dev = x16.device
-    else:
-        require_gpu(x)
-        x, xbs = plane(x)
-        B, Cin, H, W = x.shape
-        dev = x.device
-    if out is None:
-        out = torch.empty((B, Cout, H, W), dtype=F32, device=dev)
-    zbs = out.stride(0) if B > 1 else Cout * H * W
-    e0 = _prof_begin("conv3x3_bf16_kernel")
-    if x16 is not None:
-        _lib.call("onet_conv3x3_bf16_fwd_b", _p(x16), x16bs, _p(wq), _p(out), zbs, B, Cin, Cout, H, W, _stream())
-        nb = B * H * W * (2.0 * Cin + 4.0 * Cout) + 18.0 * Cin * Cout
-    else:
-        _lib.call("onet_conv3x3_bf16_fwd", _p(x), xbs, _p(wq), _p(out), zbs, B, Cin, Cout, H, W, _stream())
-        nb = 4.0 * (B * H * W * (Cin + Cout) + 9 * Cin * Cout)
-    _prof_end("conv3x3_bf16_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, nb)
     return out
 
 
@@ -1251,7 +1140,7 @@ def _bn_bwd_groups(da, dabs, z, zbs, save_all, training, affine_out, rec4, da_am
     if rec4 is None:
         nparts = _bn_nparts(Bg, HW)
         rec4 = torch.empty((G * nparts, C, 4), dtype=F32, device=dev)
-        _lib.call("onet_bn_relu_bwd_reduce_amax", _p(da), dabs, _p(z), _z16(z), zbs, _p(save_all), _p(rec4), G * nparts, _p(da_amax), Bg if G > 1 else 0,
+        _lib.call("onet_bn_relu_bwd_reduce", _p(da), dabs, _p(z), _z16(z), zbs, _p(save_all), _p(rec4), G * nparts, _p(da_amax), Bg if G > 1 else 0,
                   B, C, HW, _stream(), nbytes=(4 + z.element_size()) * z.numel())
     else:
         assert rec4.shape[0] % G == 0 and rec4.shape[1] == C and rec4.shape[2] == 4 and rec4.is_contiguous()
@@ -1259,7 +1148,7 @@ def _bn_bwd_groups(da, dabs, z, zbs, save_all, training, affine_out, rec4, da_am
     dgamma = torch.empty(C, dtype=F32, device=dev) if og is None else og
     dbeta = torch.empty(C, dtype=F32, device=dev) if ob is None else ob
     coef = torch.empty((G, 4, C), dtype=F32, device=dev) if training else None
-    _lib.call("onet_bn_bwd_finalize_bound", _p(rec4), rec4.shape[0] // G, Bg * HW, _p(dgamma), _p(dbeta), _p(coef), 0, G, C, _p(save_all),
+    _lib.call("onet_bn_bwd_finalize", _p(rec4), rec4.shape[0] // G, Bg * HW, _p(dgamma), _p(dbeta), _p(coef), 0, G, C, _p(save_all),
               _p(da_amax), _p(dz_slots), _stream())
     return coef, dgamma, dbeta
 
@@ -1323,7 +1212,7 @@ def bn_relu_bwd_groups(da, z, save_all, training, affine_out=None, rec4=None):
     G = save_all.shape[0]
     coef, dgamma, dbeta = _bn_bwd_groups(da, dabs, z, zbs, save_all, training, affine_out, rec4, None, None)
     dz = torch.empty((B, C, H, W), dtype=F32, device=z.device)
-    _lib.call("onet_bn_relu_bwd_apply_amax", _p(da), dabs, _p(z), zbs, _p(save_all), _p(coef), _p(dz), C * H * W, None, B // G if G > 1 else 0,
+    _lib.call("onet_bn_relu_bwd_apply", _p(da), dabs, _p(z), zbs, _p(save_all), _p(coef), _p(dz), C * H * W, None, B // G if G > 1 else 0,
               B, C, H * W, _stream(), nbytes=12 * z.numel())
     return dz, dgamma, dbeta
 
@@ -1358,7 +1247,7 @@ def norm_on_load_ok(B, Cmid, Cout, H, W, groups):
 def conv3x3_split_wgrad(x, dz, dw_shape, out=None, norm=None, dz_amax=None, x_amax=None):
     """dW of a 3x3 convolution in fp32 accuracy on the 16-bit matrix cores (conv_split.hip: both operands split, three MFMAs per term).
     norm = save [G, 4, Cin]: x is the pre-activation of the unit below, normalised (BatchNorm + ReLU) on load.
-    dz_amax (magnitude slots of dz, from onet_bn_relu_bwd_apply_amax): fp16 parts of the scaled operands (22-bit operands; x_amax:
+    dz_amax (magnitude slots of dz, from onet_bn_relu_bwd_apply): fp16 parts of the scaled operands (22-bit operands; x_amax:
     the overflow guard for x); None: bf16 parts (16-bit operands), the round-3 arithmetic."""
     if dz_amax is not None:
         require_gpu(x, dz)
@@ -1434,7 +1323,7 @@ def conv3x3_winograd4_wgrad(x, dz, dw_shape, out=None):
     return dw
 
 
-# ONET_WGRAD4: "auto" (default) = the F(3x3,4x4) weight gradient where it is the faster one today: layers with at least
+# WGRAD4 (ONET_FLAGS): "auto" (default) = the F(3x3,4x4) weight gradient where it is the faster one today: layers with at least
 # 256 input channels (or 128 -> >= 256), whose strips are re-read from L2 by many tiles (d2.*, d3.*, d4.*, up1.*, up2.*,
 # up3.c1 of the 256x256 U-Net: 224-298 TF against 205-238); below that its one-unit prefetch does not cover HBM latency
 # (64-channel layers: 130 TF against 200) or it only ties (128 -> 128).
@@ -1448,55 +1337,10 @@ def winograd4_wgrad_ok(x, dz):
         x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and dz.is_contiguous()
 
 
-def conv3x3_wgrad_bf16(x, dz, dw_shape, out=None, x16=None, dz16=None):
-    """dW of a 3x3 convolution with bf16 operands (x, dz rounded on the way into LDS), fp32 accumulation.
-    x16 / dz16: bf16 copies written by the producers (bf16 storage), read instead of the fp32 tensors where given (the
-    fp32 argument may then be None)."""
-    x16, x16bs = plane16(x16)
-    dz16, dz16bs = plane16(dz16)
-    ref_x, ref_dz = (x16 if x16 is not None else x), (dz16 if dz16 is not None else dz)
-    B, Cin, H, W = ref_x.shape
-    Cout = ref_dz.shape[1]
-    if (x16 is not None or dz16 is not None) and (W % 8 or (x16 is not None and (x16bs % 8 or x16.data_ptr() % 16)) or
-                                                  (dz16 is not None and (dz16bs % 8 or dz16.data_ptr() % 16))):
-        if x is None or dz is None:
-            raise ValueError("conv3x3_wgrad_bf16: bf16 operands need W % 8 == 0 and 16-byte aligned rows")
-        x16 = dz16 = None
-    if x16 is None:
-        require_gpu(x)
-        x, xbs = plane(x)
-    if dz16 is None:
-        require_gpu(dz)
-        dz, dzbs = plane(dz)
-    dev = ref_x.device
-    dw = torch.empty(dw_shape, dtype=F32, device=dev) if out is None else out
-    need = _lib.load().onet_conv3x3_wgrad_bf16_ws_bytes(B, Cin, Cout, H, W)
-    ws = workspace(need, dev)
-    e0 = _prof_begin("conv3x3_wgrad_bf16_kernel")
-    if x16 is None and dz16 is None:
-        _lib.call("onet_conv3x3_wgrad_bf16", _p(x), xbs, _p(dz), dzbs, _p(dw), _p(ws), ws.numel() * 4, B, Cin, Cout, H, W, 0,
-                  _stream())
-    else:
-        _lib.call("onet_conv3x3_wgrad_bf16_b", _p(x16 if x16 is not None else x), int(x16 is not None),
-                  x16bs if x16 is not None else xbs, _p(dz16 if dz16 is not None else dz), int(dz16 is not None),
-                  dz16bs if dz16 is not None else dzbs, _p(dw), _p(ws), ws.numel() * 4, B, Cin, Cout, H, W, 0, _stream())
-    nb = B * H * W * ((2.0 if x16 is not None else 4.0) * Cin + (2.0 if dz16 is not None else 4.0) * Cout) + 36.0 * Cin * Cout
-    _prof_end("conv3x3_wgrad_bf16_kernel", 2.0 * B * H * W * Cin * Cout * 9, e0, nb)
-    return dw
-
-
-def wgrad_takes_bf16(Cin, H, W):
-    """Does conv3x3_wgrad_auto route this layer to the bf16 weight-gradient kernel (given contiguous dz)?"""
-    return conv_algo() == "bf16" and Cin >= 16 and W >= 16 and W % 4 == 0 and H >= 8
-
-
-def conv3x3_wgrad_auto(x, dz, dw_shape, out=None, x16=None, dz16=None, dz_amax=None, x_amax=None):
+def conv3x3_wgrad_auto(x, dz, dw_shape, out=None, dz_amax=None, x_amax=None):
     Cout, Cin = dw_shape[0], dw_shape[1]
-    shp = (x if x is not None else x16).shape
-    if wgrad_takes_bf16(Cin, shp[2], shp[3]) and (dz16 is not None or dz.is_contiguous()):
-        return conv3x3_wgrad_bf16(x, dz, dw_shape, out=out, x16=x16, dz16=dz16)
     # fp32 tensors, maps 16 / 32 / >= 64 pixels wide: the split-bf16 row kernel (the stem, Cin < 16, keeps its own VALU kernel)
-    if conv_algo() in ("auto", "split") and (split_enabled() or conv_algo() == "split") and x is not None and Cin >= 16 and \
+    if conv_algo() in ("auto", "split", "bf16") and (split_enabled() or conv_algo() == "split") and Cin >= 16 and \
             x.shape[3] >= SPLIT_WGRAD_MINW and split_wgrad_ok(x, dz):
         return conv3x3_split_wgrad(x, dz, dw_shape, out=out, dz_amax=dz_amax if grad_f16() else None, x_amax=x_amax)
     if use_winograd(Cin, Cout, x.shape[2], x.shape[3]):
@@ -1583,12 +1427,9 @@ def bn_train_coeffs(z, gamma, beta, running_mean, running_var, momentum, eps, cm
         if save is None:
             save = torch.empty((4, C), dtype=F32, device=z.device)
         assert groups == 1 or (first + groups * count <= rec.shape[1] and save.shape[0] == groups and save.is_contiguous())
-        if act_slots is not None or groups > 1:   # ... also the bound of relu(bn(z)) into the activation's magnitude slots (pre-split storage)
-            _lib.call("onet_bn_finalize_cm_act", rec.data_ptr() + first * 12, count, rec.shape[1] * 3, _p(gamma), _p(beta),
-                      _p(running_mean), _p(running_var), float(momentum), float(eps), _p(save), _p(act_slots), groups, C, _stream())
-            return save
+        # (act_slots: also the bound of relu(bn(z)) into the activation's magnitude slots -- pre-split storage)
         _lib.call("onet_bn_finalize_cm", rec.data_ptr() + first * 12, count, rec.shape[1] * 3, _p(gamma), _p(beta),
-                  _p(running_mean), _p(running_var), float(momentum), float(eps), _p(save), C, _stream())
+                  _p(running_mean), _p(running_var), float(momentum), float(eps), _p(save), _p(act_slots), groups, C, _stream())
         return save
     assert groups == 1
     nparts = _bn_nparts(B, H * W)
@@ -1598,12 +1439,8 @@ def bn_train_coeffs(z, gamma, beta, running_mean, running_var, momentum, eps, cm
     nparts *= world
     if save is None:
         save = torch.empty((4, C), dtype=F32, device=z.device)
-    if act_slots is not None:
-        _lib.call("onet_bn_finalize_act", _p(part), nparts, B * H * W * world, _p(gamma), _p(beta), _p(running_mean),
-                  _p(running_var), float(momentum), float(eps), _p(save), _p(act_slots), C, _stream())
-        return save
     _lib.call("onet_bn_finalize", _p(part), nparts, B * H * W * world, _p(gamma), _p(beta), _p(running_mean),
-              _p(running_var), float(momentum), float(eps), _p(save), C, _stream())
+              _p(running_var), float(momentum), float(eps), _p(save), _p(act_slots), C, _stream())
     return save
 
 
@@ -1631,43 +1468,27 @@ def tag_amax(t, slots):
     return t
 
 
-def bn_relu_apply(z, save, out=None, out16=None, no_fp32=False, amax=None, group_images=0):
-    """a = relu(bn(z)); out16: plane-contiguous bf16 destination for a copy of a (bf16 storage of the conv operands);
-    no_fp32 (with out16): write the bf16 copy ONLY and return None.  amax: magnitude slots that receive max a (fp32 output only).
-    group_images > 0 (fp32 output only): save is [G][4][C], one set per group of that many consecutive images."""
+def bn_relu_apply(z, save, out=None, amax=None, group_images=0):
+    """a = relu(bn(z)) in fp32.  amax: magnitude slots that receive max a.  group_images > 0: save is [G][4][C], one set per group of
+    that many consecutive images.  (z may be stored as bf16: ops.z16_storage.)"""
     z, zbs = plane(z)
     B, C, H, W = z.shape
-    assert group_images == 0 or (out16 is None and B % group_images == 0 and save.numel() == (B // group_images) * 4 * C and save.is_contiguous())
-    if (amax is not None or group_images or _z16(z)) and out16 is None:
-        if out is None:
-            out = torch.empty((B, C, H, W), dtype=F32, device=z.device)
-        _lib.call("onet_bn_relu_apply_amax", _p(z), _z16(z), zbs, _p(out), out.stride(0) if B > 1 else C * H * W, _p(save), _p(amax), group_images,
-                  B, C, H * W, _stream(), nbytes=(4 + z.element_size()) * z.numel())
-        return out
-    if out16 is not None and no_fp32:
-        o16bs = out16.stride(0) if B > 1 else C * H * W
-        _lib.call("onet_bn_relu_apply_b", _p(z), zbs, None, 0, _p(out16), o16bs, _p(save), B, C, H * W, _stream(),
-                  nbytes=6 * z.numel())
-        return None
+    assert group_images == 0 or (B % group_images == 0 and save.numel() == (B // group_images) * 4 * C and save.is_contiguous())
     if out is None:
         out = torch.empty((B, C, H, W), dtype=F32, device=z.device)
     abs_ = out.stride(0) if B > 1 else C * H * W
-    if out16 is not None:
-        o16bs = out16.stride(0) if B > 1 else C * H * W
-        _lib.call("onet_bn_relu_apply_b", _p(z), zbs, _p(out), abs_, _p(out16), o16bs, _p(save), B, C, H * W, _stream(),
-                  nbytes=10 * z.numel())
-        return out
-    _lib.call("onet_bn_relu_apply", _p(z), zbs, _p(out), abs_, _p(save), B, C, H * W, _stream(), nbytes=8 * z.numel())
+    _lib.call("onet_bn_relu_apply", _p(z), _z16(z), zbs, _p(out), abs_, _p(save), _p(amax), group_images,
+              B, C, H * W, _stream(), nbytes=(4 + z.element_size()) * z.numel())
     return out
 
 
 FUSE_POOL = _flag("FUSE_POOL", True)       # 0: separate max-pool pass after BatchNorm + ReLU
 
 
-def bn_relu_apply_pool(z, save, out, out16, y, y16, amax=None):
-    """a = relu(bn(z)) and y = maxpool2(a) in one pass (an encoder block's output that is pooled next); out / out16 and y / y16:
-    fp32 destination and / or its bf16 copy (plane-contiguous; at least one of each pair).  -> False (nothing done) where the
-    fused kernel does not take the shape.  amax: magnitude slots that receive max a = max y (fp32 outputs only)."""
+def bn_relu_apply_pool(z, save, out, y, amax=None):
+    """a = relu(bn(z)) and y = maxpool2(a) in one pass (an encoder block's output that is pooled next); out, y: plane-contiguous fp32
+    destinations.  -> False (nothing done) where the fused kernel does not take the shape.  amax: magnitude slots that receive
+    max a = max y."""
     z, zbs = plane(z)
     B, C, H, W = z.shape
     if H % 2 or W % 4:
@@ -1676,14 +1497,7 @@ def bn_relu_apply_pool(z, save, out, out16, y, y16, amax=None):
     def bs(t, n):
         return 0 if t is None else (t.stride(0) if B > 1 else n)
     n, m = C * H * W, C * (H // 2) * (W // 2)
-    if amax is not None and out16 is None and y16 is None and out is not None and y is not None:
-        rc = _lib.load().onet_bn_relu_apply_pool_amax(_p(z), zbs, _p(out), bs(out, n), _p(y), bs(y, m), _p(save), _p(amax), B, C, H, W,
-                                                      _stream())
-        if rc < 0:
-            raise _lib.OnetHipError(f"onet_bn_relu_apply_pool_amax failed ({rc}): {_lib.last_error()}")
-        return rc == 0
-    rc = _lib.load().onet_bn_relu_apply_pool(_p(z), zbs, _p(out), bs(out, n), _p(out16), bs(out16, n), _p(y), bs(y, m), _p(y16),
-                                            bs(y16, m), _p(save), B, C, H, W, _stream())
+    rc = _lib.load().onet_bn_relu_apply_pool(_p(z), zbs, _p(out), bs(out, n), _p(y), bs(y, m), _p(save), _p(amax), B, C, H, W, _stream())
     if rc < 0:
         raise _lib.OnetHipError(f"onet_bn_relu_apply_pool failed ({rc}): {_lib.last_error()}")
     return rc == 0
@@ -1718,12 +1532,8 @@ def bn_bwd_coefs(da, z, save, training, need_affine_grads=True, acc=None, affine
             part2, nparts = rec4[first:first + count], count
         else:
             part2 = torch.empty((nparts, C, 4), dtype=F32, device=dev)
-            if da_amax is not None:
-                _lib.call("onet_bn_relu_bwd_reduce_amax", _p(da), dabs, _p(z), _z16(z), zbs, _p(save), _p(part2), nparts, _p(da_amax), 0, B, C, HW,
-                          _stream(), nbytes=8 * z.numel())
-            else:
-                _lib.call("onet_bn_relu_bwd_reduce", _p(da), dabs, _p(z), zbs, _p(save), _p(part2), nparts, B, C, HW, _stream(),
-                          nbytes=8 * z.numel())
+            _lib.call("onet_bn_relu_bwd_reduce", _p(da), dabs, _p(z), _z16(z), zbs, _p(save), _p(part2), nparts, _p(da_amax), 0, B, C, HW,
+                      _stream(), nbytes=(4 + z.element_size()) * z.numel())
         if acc is None:
             og, ob = affine_out if affine_out is not None else (None, None)
             dgamma = torch.empty(C, dtype=F32, device=dev) if og is None else og
@@ -1734,26 +1544,24 @@ def bn_bwd_coefs(da, z, save, training, need_affine_grads=True, acc=None, affine
         coef = torch.empty((4, C), dtype=F32, device=dev) if training else None
         gathered, world = _gather_partials(part2) if training else (part2, 1)
         if world == 1:
-            _lib.call("onet_bn_bwd_finalize", _p(part2), nparts, B * HW, _p(dgamma), _p(dbeta), _p(coef), accf, C, _stream())
+            _lib.call("onet_bn_bwd_finalize", _p(part2), nparts, B * HW, _p(dgamma), _p(dbeta), _p(coef), accf, 1, C, None, None, None, _stream())
         else:
             # SyncBN: dgamma/dbeta are the LOCAL sums (the gradient all-reduce adds the ranks, as in
             # torch.nn.SyncBatchNorm); c1/c2 in `coef` are means over the GLOBAL batch.
-            _lib.call("onet_bn_bwd_finalize", _p(part2), nparts, B * HW, _p(dgamma), _p(dbeta), None, accf, C, _stream())
-            _lib.call("onet_bn_bwd_finalize", _p(gathered), nparts * world, B * HW * world, None, None, _p(coef), 0, C,
+            _lib.call("onet_bn_bwd_finalize", _p(part2), nparts, B * HW, _p(dgamma), _p(dbeta), None, accf, 1, C, None, None, None, _stream())
+            _lib.call("onet_bn_bwd_finalize", _p(gathered), nparts * world, B * HW * world, None, None, _p(coef), 0, 1, C, None, None, None,
                       _stream())
     return coef, dgamma, dbeta
 
 
-def bn_relu_bwd(da, z, save, training, need_affine_grads=True, out=None, acc=None, affine_out=None, red=None, red4=None,
-                out16=None, amax=None):
+def bn_relu_bwd(da, z, save, training, need_affine_grads=True, out=None, acc=None, affine_out=None, red=None, red4=None, amax=None):
     """-> dz, dgamma, dbeta.  `out`: plane-contiguous destination for dz (a batch slice of a larger buffer);
     `acc` = (dgamma, dbeta) of another statistics group of the same layer to accumulate into; `affine_out` =
     (dgamma, dbeta) destinations to overwrite (None entries are allocated); `red` = (records [C, NP, 2], first, count):
     the (sum dy, sum dy*xhat) records of this batch slice were already written by the dgrad launch that produced
     `da` (`conv3x3_dgrad_bnreduce`), so the reduce pass over (da, z) is skipped; `red4` = (records [NP, C, 4], first,
     count): the same in the reduce kernel's own record format (written by the pooling-backward kernel).
-    `out16`: plane-contiguous bf16 destination -- dz is then written in bf16 ONLY (its consumers are the bf16 dgrad and
-    weight-gradient kernels) and the returned dz is None.  `amax`: 64 zeroed magnitude slots (new_amax) in which the apply pass
+    `amax`: 64 zeroed magnitude slots (new_amax) in which the apply pass
     records max |dz| for the fp16-split gradient kernels (several statistics groups of one tensor share them)."""
     coef, dgamma, dbeta = bn_bwd_coefs(da, z, save, training, need_affine_grads, acc, affine_out, red, red4)
     da, dabs = plane(da)
@@ -1761,39 +1569,18 @@ def bn_relu_bwd(da, z, save, training, need_affine_grads=True, out=None, acc=Non
     B, C, H, W = z.shape
     HW = H * W
     dev = z.device
-    if out16 is not None:
-        o16bs = out16.stride(0) if B > 1 else C * HW
-        _lib.call("onet_bn_relu_bwd_apply_b", _p(da), dabs, _p(z), zbs, _p(save), _p(coef), None, 0, _p(out16), o16bs, B, C, HW,
-                  _stream(), nbytes=10 * z.numel())
-        return None, dgamma, dbeta
     dz = torch.empty((B, C, H, W), dtype=F32, device=dev) if out is None else out
     dzbs = dz.stride(0) if B > 1 else C * HW
-    if amax is not None:
-        _lib.call("onet_bn_relu_bwd_apply_amax", _p(da), dabs, _p(z), zbs, _p(save), _p(coef), _p(dz), dzbs, _p(amax), 0, B, C, HW,
-                  _stream(), nbytes=12 * z.numel())
-        return dz, dgamma, dbeta
-    _lib.call("onet_bn_relu_bwd_apply", _p(da), dabs, _p(z), zbs, _p(save), _p(coef), _p(dz), dzbs, B, C, HW,
+    _lib.call("onet_bn_relu_bwd_apply", _p(da), dabs, _p(z), zbs, _p(save), _p(coef), _p(dz), dzbs, _p(amax), 0, B, C, HW,
               _stream(), nbytes=12 * z.numel())
     return dz, dgamma, dbeta
 
 
 # ----------------------------------------------------------------------------- pool / up / cat
-def maxpool2_fwd(x, bf16_only=False):
-    """y = MaxPool2d(2)(x); under bf16 storage y carries a bf16 copy for the convolution that consumes it.  bf16_only: the
-    consumer reads nothing else -- y is a placeholder (even, 8-byte aligned maps; otherwise the flag is ignored)."""
+def maxpool2_fwd(x):
+    """y = MaxPool2d(2)(x)"""
     x, xbs = plane(x)
     B, C, H, W = x.shape
-    if bf16_storage() and B * C * (H // 2) * (W // 2) > 0:
-        bf16_only = bf16_only and W % 2 == 0 and xbs % 2 == 0 and x.data_ptr() % 8 == 0
-        y = fp32_placeholder((B, C, H // 2, W // 2), x.device) if bf16_only else \
-            torch.empty((B, C, H // 2, W // 2), dtype=F32, device=x.device)
-        y16 = torch.empty((B, C, H // 2, W // 2), dtype=BF, device=x.device)
-        lib = _lib.load()
-        rc = lib.onet_maxpool2_fwd_b(_p(x), xbs, None if bf16_only else _p(y), C * (H // 2) * (W // 2), _p(y16),
-                                     C * (H // 2) * (W // 2), B, C, H, W, _stream())
-        if rc < 0:
-            raise _lib.OnetHipError(f"onet_maxpool2_fwd_b failed ({rc}): {_lib.last_error()}")
-        return tag_b16(y, y16 if rc == 0 else None)
     y = torch.empty((B, C, H // 2, W // 2), dtype=F32, device=x.device)
     _lib.call("onet_maxpool2_fwd", _p(x), xbs, _p(y), C * (H // 2) * (W // 2), B, C, H, W, _stream(), nbytes=5 * x.numel())
     return y
@@ -1828,23 +1615,14 @@ def maxpool2_bwd(x, dy, add=None, add2=None, bn=None, dx_amax=None):
             (dy.data_ptr() & 7) == 0 and all((v & 3) == 0 for v in (xbs, zbs, a1bs, a2bs)) and (dybs & 1) == 0
         if bands > 0 and aligned and B % G == 0 and tuple(z.shape) == (B, C, H, W) and save_all.is_contiguous():
             part2 = torch.empty((B * bands, C, 4), dtype=F32, device=dy.device)
-            if x is None or dx_amax is not None or _z16(z):
-                _lib.call("onet_maxpool2_bwd_add_bnreduce_amax", _p(x), xbs, _p(dy), dybs, _p(a1), a1bs, _p(a2), a2bs, _p(dx),
-                          C * H * W, _p(z), _z16(z), zbs, _p(save_all), B // G, _p(part2), _p(dx_amax), B, C, H, W, _stream(),
-                          nbytes=(5 + z.element_size() + 4 * (x is not None) + 4 * (a1 is not None) + 4 * (a2 is not None)) * dx.numel())
-            else:
-                _lib.call("onet_maxpool2_bwd_add_bnreduce", _p(x), xbs, _p(dy), dybs, _p(a1), a1bs, _p(a2), a2bs, _p(dx),
-                          C * H * W, _p(z), zbs, _p(save_all), B // G, _p(part2), B, C, H, W, _stream(),
-                          nbytes=(13 + 4 * (a1 is not None) + 4 * (a2 is not None)) * x.numel())
+            _lib.call("onet_maxpool2_bwd_add_bnreduce", _p(x), xbs, _p(dy), dybs, _p(a1), a1bs, _p(a2), a2bs, _p(dx),
+                      C * H * W, _p(z), _z16(z), zbs, _p(save_all), B // G, _p(part2), _p(dx_amax), B, C, H, W, _stream(),
+                      nbytes=(5 + z.element_size() + 4 * (x is not None) + 4 * (a1 is not None) + 4 * (a2 is not None)) * dx.numel())
             return dx, part2
         if x is None:
             raise RuntimeError("onet_amd: max-pooling backward of an activation kept only pre-split: the fused kernel does not take this shape")
-    if add is None:
-        _lib.call("onet_maxpool2_bwd", _p(x), xbs, _p(dy), dybs, _p(dx), C * H * W, B, C, H, W, 0, _stream(),
-                  nbytes=9 * x.numel())
-    else:
-        _lib.call("onet_maxpool2_bwd_add", _p(x), xbs, _p(dy), dybs, _p(a1), a1bs, _p(a2), a2bs, _p(dx), C * H * W,
-                  B, C, H, W, _stream(), nbytes=(9 + 4 * (a1 is not None) + 4 * (a2 is not None)) * x.numel())
+    _lib.call("onet_maxpool2_bwd", _p(x), xbs, _p(dy), dybs, _p(a1), a1bs, _p(a2), a2bs, _p(dx), C * H * W,
+              B, C, H, W, 0, _stream(), nbytes=(9 + 4 * (a1 is not None) + 4 * (a2 is not None)) * x.numel())
     return dx if bn is None else (dx, None)
 
 

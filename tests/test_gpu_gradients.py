@@ -129,10 +129,13 @@ def _model(C, gain, dev, seed=1981, bshare=True):
 
 CASES = {
     # tag: (B, C, H, W, head_gain, algorithms)
-    # ("split_f16grad": the split kernels with Settings.grad_f16 -- input / weight gradients on fp16 parts of scaled operands)
-    "b8_c1_128": (8, 1, 128, 128, 0.3, ("auto", "split", "split_f16grad", "winograd4", "direct")),
-    "b4_c1_256": (4, 1, 256, 256, 0.3, ("auto", "split", "winograd4")),
-    "b2_c3_64_saturated": (2, 3, 64, 64, 1.0, ("auto", "winograd4")),
+    # (round 5: the default dispatch at every size; one forced run per fp32-MFMA family -- F(4x4) at 128 and 64 pixels, the direct kernels
+    # at 64; the default dispatch at 256 pixels with the benchmark's batch is the benchmark-dispatch test below, the non-default
+    # Settings.grad_f16 of the in-staging kernels is held at op level (test_gpu_ops.py).  The suite's wall time is bounded by the fp64
+    # CPU oracle of these cases: 20-35 s each at 128 / 256 pixels)
+    "b8_c1_128": (8, 1, 128, 128, 0.3, ("auto", "winograd4")),
+    "b4_c1_256": (4, 1, 256, 256, 0.3, ("auto",)),
+    "b2_c3_64_saturated": (2, 3, 64, 64, 1.0, ("auto", "winograd4", "direct")),
     "b3_c1_40_padpath": (3, 1, 40, 40, 1.0, ("auto",)),
     "b1_c3_512": (1, 3, 512, 512, 0.3, ("auto",)),        # BASELINE configs[4]'s tile shape (3-channel 512 x 512), batch statistics over ONE image
 }
@@ -142,9 +145,7 @@ CASES = {
 def test_every_gradient_element_vs_routed_fp64_oracle(dev, tag, algo, monkeypatch):
     from onet_amd import ops
     B, C, H, W, gain, algos = CASES[tag]
-    monkeypatch.setattr(ops, "CONV_ALGO", "split" if algo == "split_f16grad" else algo)
-    if algo == "split_f16grad":
-        monkeypatch.setattr(ops, "SPLIT_GRAD_F16", True)
+    monkeypatch.setattr(ops, "CONV_ALGO", algo)
     X = orc.det_input(B, C, H, W)
     m = _model(C, gain, dev)
     (Lt, Vt, Ld, Vd, S), loss, acts = _hip_step_recording(m, X.to(dev), monkeypatch, range(B))
@@ -281,14 +282,17 @@ def test_every_gradient_element_two_pass_and_unshared(dev, mode, monkeypatch):
 
 
 def _bf16_rule(kind, xs, ws):
-    """Which matrix products of the model the bf16 conv path (ops.conv3x3_algo / wgrad_takes_bf16 under "bf16", the 128 x 128
-    ConvTranspose2d GEMMs) evaluates with bf16-rounded operands."""
-    if kind == "bn_z":       # which units STORE their conv output as bf16 (ops.z16_storage: the pre-split plain-bf16 layers, full 16 x 32 tiles)
+    """Which matrix products of the model the bf16 conv path evaluates with bf16-rounded operands: the 3x3 layers that run the
+    pre-split kernels on one part of plain bf16 (ops.pre_layer_ok under conv == "bf16": 32-channel chunks, maps made of full
+    16 x 32-pixel tiles; the 16-pixel level joins them only at batches that fill the chip -- not at this file's sizes; the stem, the
+    smaller maps and odd shapes run the fp32 dispatch, round 5) and the 128 x 128 ConvTranspose2d GEMMs.  The test checks the rule
+    against the run's dispatch (the units whose weight gradient took pre-split operands)."""
+    if kind == "bn_z":       # which units STORE their conv output as bf16 (ops.z16_storage): the same layers
         _, Cout, H, W = xs
-        return ws[1] % 32 == 0 and Cout % 32 == 0 and H % 16 == 0 and (W % 32 == 0 or W == 16)
+        return ws[1] % 32 == 0 and Cout % 32 == 0 and H % 16 == 0 and W % 32 == 0
     if kind == "conv3x3":
         _, Cin, H, W = xs
-        return Cin % 16 == 0 and ws[0] % 4 == 0 and W >= 16 and W % 4 == 0 and H >= 8
+        return Cin % 32 == 0 and ws[0] % 32 == 0 and H % 16 == 0 and W % 32 == 0
     # ConvTranspose2d: the forward and input-gradient GEMMs tile 128 pixels, the weight-gradient GEMM 32 (convt_gemm.hip) --
     # on an 8 x 8 map only the weight gradient takes the bf16-operand fast path
     _, Cin, h, w = xs
@@ -308,7 +312,7 @@ def _record_bf16_operands(monkeypatch, B):
     ORACLE's call order (18 units / 4 Up blocks of the X pass, then of the 1-X pass; the twin batch holds both passes)."""
     from onet_amd import ops
     rb = lambda t: t.detach().to(torch.bfloat16).cpu()          # RNE, == v_cvt_pk_bf16_f32 (tests/test_gpu_ops.py)
-    conv, convt, zs = [], [], []
+    conv, convt, zs, pre = [], [], [], []
     real_w, real_t, real_p = ops.conv3x3_wgrad_auto, ops.convT2x2_wgrad, ops.conv3x3_split_wgrad_pre
     real_zp, real_zf = ops.conv3x3_pre_bn_partials, ops.conv3x3_fwd_bn_partials
 
@@ -331,6 +335,7 @@ def _record_bf16_operands(monkeypatch, B):
     def wgrad(x, dz, *a, **k):
         assert x is not None and dz is not None and x.shape[0] == 2 * B
         conv.append((rb(x), rb(dz)))
+        pre.append(False)
         return real_w(x, dz, *a, **k)
 
     def wgrad_pre(xP, dzP, *a, **k):
@@ -338,6 +343,7 @@ def _record_bf16_operands(monkeypatch, B):
         assert xP.shape[0] == 2 * B and xP.shape[3] == 1 and xP.dtype == torch.bfloat16
         nchw = lambda P: P.detach()[:, :, :, 0].permute(0, 1, 4, 2, 3).reshape(P.shape[0], P.shape[1] * 8, P.shape[2], P.shape[4]).cpu()
         conv.append((nchw(xP), nchw(dzP)))
+        pre.append(True)
         return real_p(xP, dzP, *a, **k)
 
     def wgrad_t(x, dy, *a, **k):
@@ -359,7 +365,7 @@ def _record_bf16_operands(monkeypatch, B):
         monkeypatch.setattr(ops, "conv3x3_pre_bn_partials", real_zp)
         monkeypatch.setattr(ops, "conv3x3_fwd_bn_partials", real_zf)
         assert len(conv) == 18 and len(convt) == 4 and len(zs) == 18, (len(conv), len(convt), len(zs))
-        out = {"conv3x3": [], "convT2x2": [], "bn_z": []}
+        out = {"conv3x3": [], "convT2x2": [], "bn_z": [], "pre": list(reversed(pre)) * 2}
         for p in range(2):                                       # backward visits the units last to first
             out["conv3x3"] += [(x[p * B:(p + 1) * B], g[p * B:(p + 1) * B]) for x, g in reversed(conv)]
             out["convT2x2"] += [(x[p * B:(p + 1) * B], g[p * B:(p + 1) * B]) for x, g in reversed(convt)]
@@ -369,8 +375,8 @@ def _record_bf16_operands(monkeypatch, B):
     return finish
 
 
-@pytest.mark.parametrize("tag,kernels", [("b8_c1_128", "presplit"), ("b4_c1_256", "presplit"), ("b8_c1_128", "round3")])
-def test_bf16_path_every_gradient_element_vs_routed_rounded_oracle(dev, tag, kernels, monkeypatch):
+@pytest.mark.parametrize("tag", ["b8_c1_128", "b4_c1_256"])
+def test_bf16_path_every_gradient_element_vs_routed_rounded_oracle(dev, tag, monkeypatch):
     """BASELINE configs[2]'s arithmetic held to the fp32 path's element-wise statement instead of "gradient norms within 10 %": the
     fp64 oracle evaluates the function the bf16 conv path computes -- every bf16 matrix product (forward, input gradient, weight
     gradient of the 3x3 layers and of the ConvTranspose2d GEMMs the path takes) on bf16-rounded operands, everything else
@@ -381,12 +387,8 @@ def test_bf16_path_every_gradient_element_vs_routed_rounded_oracle(dev, tag, ker
     from onet_amd import ops
     B, C, H, W, gain, _ = CASES[tag]
     monkeypatch.setattr(ops, "CONV_ALGO", "bf16")
-    # kernels = "presplit" (round 4, the default): the layers >= 32 pixels wide run the LDS-DMA staged kernels on ONE part of plain
-    # bf16 operands written by their producers (same roundings, nearest even); "round3": conv_bf16.hip's kernels everywhere
-    monkeypatch.setattr(ops, "PRESPLIT_BF16", kernels == "presplit")
-    # fp32 operand storage, rounded on load: bit-identical to bf16 storage (test_bf16_storage_is_bit_identical_to_rounding_on_load),
-    # and every fp32 activation / gradient exists to be recorded (with bf16 storage half of them are placeholders)
-    monkeypatch.setattr(ops, "BF16_STORAGE", False)
+    # the layers >= 32 pixels wide run the LDS-DMA staged kernels on ONE part of plain bf16 operands written by their producers (nearest
+    # even); the others take the fp32 dispatch
     X = orc.det_input(B, C, H, W)
     m = _model(C, gain, dev)
     finish_ops = _record_bf16_operands(monkeypatch, B)
@@ -396,30 +398,29 @@ def test_bf16_path_every_gradient_element_vs_routed_rounded_oracle(dev, tag, ker
     finally:
         prof, _ = ops.profile_stop()
     replay = finish_ops()
-    if kernels == "presplit":
-        # (round 5: the pre-split layers store their conv output as bf16 -- 11 of 18 units per pass at 128 x 128 with B = 8: the levels
-        # 32 pixels wide and wider except the stem)
-        assert sum(z is not None for z in replay["bn_z"]) >= 20, [None if z is None else tuple(z.shape) for z in replay["bn_z"]]
-        assert len(prof.get("conv3x3_split_pre_kernel", [])) >= 10 and len(prof.get("conv3x3_split_wgrad_pre_kernel", [])) >= 5, {k: len(v) for k, v in prof.items()}
-    else:
-        assert len(prof.get("conv3x3_bf16_kernel", [])) >= 24 and len(prof.get("conv3x3_wgrad_bf16_kernel", [])) >= 12, {k: len(v) for k, v in prof.items()}
+    # (round 5: the pre-split layers store their conv output as bf16 -- 11 of 18 units per pass at 128 x 128 with B = 8: the levels
+    # 32 pixels wide and wider except the stem)
+    assert sum(z is not None for z in replay["bn_z"]) >= 20, [None if z is None else tuple(z.shape) for z in replay["bn_z"]]
+    assert len(prof.get("conv3x3_split_pre_kernel", [])) >= 10 and len(prof.get("conv3x3_split_wgrad_pre_kernel", [])) >= 5, {k: len(v) for k, v in prof.items()}
+    # the rule the oracle rounds by == the run's dispatch, unit by unit (and the stored-z units are the same ones)
+    ran_pre = replay.pop("pre")
+    for (x_r, g_r), was_pre, z_r in zip(replay["conv3x3"], ran_pre, replay["bn_z"]):
+        want = _bf16_rule("conv3x3", tuple(x_r.shape), (g_r.shape[1], x_r.shape[1], 3, 3))
+        assert want == was_pre == (z_r is not None), (tuple(x_r.shape), tuple(g_r.shape), want, was_pre, z_r is not None)
     with orc.operand_rounding(_bf16_rule, replay):
         (oLt, oVt, oLd, oVd, oS), oloss, g64, r = _routed_oracle(X, C, 1981, gain, acts)
     assert abs(loss.item() - float(oloss)) <= 1e-5 * abs(float(oloss))
     assert float((Vt.detach().cpu().double() - oVt.detach()).abs().max()) <= 1e-4 * float(oVt.detach().abs().max())
-    _check(m, g64, r, f"bf16 path {tag} [{kernels}], roundings replayed", tol=BF16_GRAD_TOL)
-    if tag != "b8_c1_128" or kernels != "presplit":
+    _check(m, g64, r, f"bf16 path {tag}, roundings replayed", tol=BF16_GRAD_TOL)
+    if tag != "b8_c1_128":
         return                                       # (the two extra fp64 evaluations below cost a minute at 256 x 256)
     # for the record (and so that the replay is not vacuous): the same evaluation with FREE rounding, and without any rounding
     with orc.operand_rounding(_bf16_rule):
         (_, fVt, _, _, _), _, gfree, _ = _routed_oracle(X, C, 1981, gain, acts)
-    _, _, gexact, _ = _routed_oracle(X, C, 1981, gain, acts)
     free_v = float((fVt.detach() - oVt.detach()).abs().max() / oVt.detach().abs().max())
     free_g = max(float((gfree[k] - g64[k]).norm() / g64[k].norm()) for k in g64)
-    moved = max(float((gexact[k] - g64[k]).norm() / g64[k].norm()) for k in g64)
-    print(f"bf16 path {tag}: free rounding moves the head logits by {free_v:.1e} and the gradients by up to {free_g:.1e}; "
-          f"bf16 operands move the exact gradients by up to {moved:.1e}")
-    assert free_g > 10 * BF16_GRAD_TOL and moved > 10 * BF16_GRAD_TOL, "rounding does not matter here: the check would be vacuous"
+    print(f"bf16 path {tag}: free rounding moves the head logits by {free_v:.1e} and the gradients by up to {free_g:.1e}")
+    assert free_g > 10 * BF16_GRAD_TOL, "rounding does not matter here: the check would be vacuous"
 
 
 @pytest.mark.parametrize("algo", ["auto", "direct"])

@@ -399,34 +399,26 @@ def test_winograd4_fused_bn_statistics(dev, B, Cin, Cout, H, W):
 
 @pytest.mark.parametrize("B,C,H,W", [(2, 8, 16, 32), (3, 5, 6, 12), (2, 64, 64, 64), (1, 3, 2, 4)])
 def test_bn_relu_apply_pool_fused(dev, B, C, H, W):
-    """onet_bn_relu_apply_pool: BatchNorm + ReLU and the 2x2 max-pooling of its output in one pass -- every output (activation,
-    its bf16 copy, pooled tensor, its bf16 copy, each optional) bit-identical to the two separate kernels; shapes it does not
-    take (odd H, W % 4) return False."""
+    """onet_bn_relu_apply_pool: BatchNorm + ReLU and the 2x2 max-pooling of its output in one pass -- activation and pooled tensor
+    bit-identical to the two separate kernels, with and without the magnitude slots (which then hold max a); shapes it does not take
+    (odd H, W % 4) return False."""
     from onet_amd import ops
     z = (rnd(B, C, H, W, seed=81) * 2 + 0.3).to(dev)
     gamma, beta = (1 + 0.2 * rnd(C, seed=82)).to(dev), (0.2 * rnd(C, seed=83)).to(dev)
     save = ops.bn_train_coeffs(z, gamma, beta, torch.zeros(C, device=dev), torch.ones(C, device=dev), 0.1, 1e-5)
     a_ref = ops.bn_relu_apply(z, save)
     y_ref = ops.maxpool2_fwd(a_ref)
-    BF = torch.bfloat16
-    for want_a, want_a16, want_y, want_y16 in [(1, 0, 1, 0), (1, 1, 1, 1), (0, 1, 0, 1), (1, 1, 0, 1), (0, 1, 1, 0)]:
-        a = torch.full_like(z, float("nan")) if want_a else None
-        a16 = torch.zeros((B, C, H, W), dtype=BF, device=dev) if want_a16 else None
-        y = torch.full((B, C, H // 2, W // 2), float("nan"), device=dev) if want_y else None
-        y16 = torch.zeros((B, C, H // 2, W // 2), dtype=BF, device=dev) if want_y16 else None
-        assert ops.bn_relu_apply_pool(z, save, a, a16, y, y16)
-        if want_a:
-            assert torch.equal(a, a_ref)
-        if want_a16:
-            assert torch.equal(a16, a_ref.to(BF))
-        if want_y:
-            assert torch.equal(y, y_ref)
-        if want_y16:
-            assert torch.equal(y16, y_ref.to(BF))
+    for slots in (None, ops.new_amax(dev)):
+        a = torch.full_like(z, float("nan"))
+        y = torch.full((B, C, H // 2, W // 2), float("nan"), device=dev)
+        assert ops.bn_relu_apply_pool(z, save, a, y, amax=slots)
+        assert torch.equal(a, a_ref) and torch.equal(y, y_ref)
+        if slots is not None:
+            assert float(torch.tensor(slots.cpu().numpy().view("float32")).max()) == float(a_ref.max())
     zz = z[:, :, : H - 1 if H > 2 else H, :].contiguous() if H > 2 else z[..., : W - 2].contiguous()
     o = torch.empty_like(zz)
     yy = torch.empty((B, C, zz.shape[2] // 2, zz.shape[3] // 2), device=dev)
-    assert not ops.bn_relu_apply_pool(zz, save, o, None, yy, None)
+    assert not ops.bn_relu_apply_pool(zz, save, o, yy)
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 1, 64, 32, 64), (3, 3, 64, 48, 128), (2, 1, 64, 256, 256), (4, 2, 40, 16, 64),
@@ -488,85 +480,87 @@ def test_stem_conv_fused_bn_statistics(dev, B, Cin, Cout, H, W):
         assert float(((s1[1].cpu().double() - ir) / ir).abs().max()) <= 1e-5
 
 
-@pytest.mark.parametrize("B,Cin,Cout,H,W,x_bf16", [(2, 16, 64, 32, 32, True), (3, 32, 72, 16, 64, False), (4, 64, 128, 64, 64, True),
-                                                    (2, 16, 40, 32, 16, True), (5, 48, 64, 16, 16, False), (2, 32, 64, 200, 96, True)])
-def test_bf16_fused_bn_statistics(dev, B, Cin, Cout, H, W, x_bf16):
-    """bf16 forward with the BatchNorm statistics records written by its epilogue (maps made of full tiles: 8 x 32 pixels, or
-    16 x 16 on maps up to 16 wide; channel tails; several tiles per persistent block): z bit-identical to the plain kernel, and
-    finalize(records) == finalize(separate statistics pass) for the whole batch and for a batch slice (the twin batch's
-    statistics groups).  Ragged maps report nparts == 0 and keep the separate statistics pass."""
-    from onet_amd import _lib, ops
-    for h, w in [(40, 40), (20, 64), (8, 16), (17, 32)]:
-        assert int(_lib.load().onet_conv3x3_bf16_nparts(B, h, w)) == 0
-    x = rnd(B, Cin, H, W, seed=31) + 0.7
-    w = rnd(Cout, Cin, 3, 3, seed=32) / (3.0 * Cin ** 0.5)
-    xd = x.to(dev)
-    x16 = xd.to(torch.bfloat16)
-    qf, _ = ops.pack3x3_bf16(w.to(dev))
-    z0 = ops.conv3x3_bf16(xd, qf, Cout)
-    nparts = int(_lib.load().onet_conv3x3_bf16_nparts(B, H, W))
-    assert nparts == (B * (W // 32) * (H // 8) if W > 16 else B * (W // 16) * (H // 16))
-    z1 = torch.empty_like(z0)
-    cm = torch.full((Cout, nparts, 3), float("nan"), device=dev)
-    src = x16 if x_bf16 else xd
-    _lib.call("onet_conv3x3_bf16_fwd_stats", src.data_ptr(), int(x_bf16), Cin * H * W, qf.data_ptr(), z1.data_ptr(),
-              Cout * H * W, cm.data_ptr(), B, Cin, Cout, H, W, torch.cuda.current_stream().cuda_stream)
-    assert torch.equal(z0, z1)
-    assert torch.isfinite(cm).all()
-    assert float(cm[:, :, 0].sum(1).min()) == float(cm[:, :, 0].sum(1).max()) == B * H * W
-    gamma = (1 + 0.1 * rnd(Cout, seed=33)).to(dev)
-    beta = (0.1 * rnd(Cout, seed=34)).to(dev)
-    for lo, hi in [(0, B), (B // 2, B)]:
-        zs = z0[lo:hi]
-        rm0, rv0 = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
-        rm1, rv1 = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
-        s0 = ops.bn_train_coeffs(zs, gamma, beta, rm0, rv0, 0.1, 1e-5)
-        npi = nparts // B
-        s1 = ops.bn_train_coeffs(zs, gamma, beta, rm1, rv1, 0.1, 1e-5, cm=(cm, lo * npi, (hi - lo) * npi))
-        sd = float(zs.std())
-        assert float((s0[0] - s1[0]).abs().max()) <= 2e-6 * sd, "mean"
-        assert float(((s0[1] - s1[1]) / s0[1]).abs().max()) <= 1e-5, "invstd"
-        assert float((rm0 - rm1).abs().max()) <= 1e-6 * sd and float(((rv0 - rv1) / rv0).abs().max()) <= 1e-5
-        zr = zs.double().cpu()
-        assert float((s1[0].cpu().double() - zr.mean((0, 2, 3))).abs().max()) <= 2e-6 * sd
-        ir = 1.0 / torch.sqrt(zr.var((0, 2, 3), unbiased=False) + 1e-5)
-        assert float(((s1[1].cpu().double() - ir) / ir).abs().max()) <= 1e-5
-
-
-@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 16, 64, 32, 32), (1, 32, 48, 20, 44), (2, 64, 128, 64, 64),
-                                             (3, 48, 32, 17, 33), (2, 128, 64, 16, 96), (3, 64, 128, 16, 16),
-                                             (2, 32, 80, 21, 13), (2, 16, 96, 200, 288), (1, 48, 64, 512, 320)])
-def test_conv3x3_bf16_operands(dev, B, Cin, Cout, H, W):
-    """(The last two shapes give the persistent blocks several tiles each: 900 and 640 tiles on 512 resident blocks, one and three
-    16-channel chunks per tile.)
-    BASELINE config 3's bf16 MFMA conv path (conv_bf16.hip), forward and input-gradient orientation: the kernel
-    rounds activations and weights to bf16 (nearest-even) and accumulates in fp32, so it must equal an fp64 convolution
-    of the bf16-ROUNDED operands to fp32 summation accuracy (1e-5 of the output scale) -- and the full-precision
-    convolution to bf16 accuracy (2^-8 relative per operand: 2e-2 of the output scale at these depths)."""
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 64, 64, 64, 64), (2, 64, 128, 32, 64), (4, 128, 64, 32, 32), (2, 96, 64, 16, 96),
+                                             (4, 64, 128, 16, 16), (8, 128, 64, 32, 16), (2, 256, 64, 48, 32), (1, 64, 64, 8, 128)])
+def test_conv3x3_plain_bf16_presplit_kernels(dev, B, Cin, Cout, H, W):
+    """BASELINE configs[2]'s bf16 MFMA conv path (conv == "bf16"): the pre-split kernels on ONE part of plain bf16 operands
+    (conv3x3_pre16_kernel on v_mfma_f32_16x16x32_bf16 with 32-channel chunks; the 16x16x32 weight-gradient kernel).  Each launch
+    must equal the fp64 convolution of the bf16-ROUNDED operands to fp32 summation accuracy (2e-6 of scale) -- forward with its
+    BatchNorm statistics epilogue, input-gradient orientation, weight gradient -- the statistics records must finalize to the
+    separate statistics pass, and with bf16 STORAGE of z (z16) the stored tensor is the fp32 result rounded once, bit for bit."""
     from onet_amd import ops
-    x = rnd(B, Cin, H, W, seed=51)
-    w = rnd(Cout, Cin, 3, 3, seed=52, scale=(2.0 / (Cin * 9)) ** 0.5)
-    g = rnd(B, Cout, H, W, seed=53)
-    rb = lambda t: t.to(torch.bfloat16).to(torch.float64)
-    qf, qd = ops.pack3x3_bf16(w.to(dev))
-    z = ops.conv3x3_bf16(x.to(dev), qf, Cout).cpu().double()
-    z_ref = F.conv2d(rb(x), rb(w), None, 1, 1)
-    z_full = F.conv2d(x.double(), w.double(), None, 1, 1)
-    sc = float(z_full.abs().max())
-    assert float((z - z_ref).abs().max()) <= 1e-5 * sc, "fwd vs bf16-rounded operands"
-    assert float((z - z_full).abs().max()) <= 2e-2 * sc, "fwd vs full precision"
-    # bf16 STORAGE of the operand: the producer's bf16 copy (rounded to nearest even, as torch does) read instead of x
-    z16 = ops.conv3x3_bf16(None, qf, Cout, x16=x.to(dev).to(torch.bfloat16))
-    assert torch.equal(z16.cpu().double(), z), "bf16-storage forward must be bit-identical to rounding on load"
-    if Cout % 16 == 0:
-        dx = ops.conv3x3_bf16(g.to(dev), qd, Cin).cpu().double()
-        dx_ref = F.conv_transpose2d(rb(g), rb(w), None, 1, 1)
-        sc = float(dx_ref.abs().max())
-        assert float((dx - dx_ref).abs().max()) <= 1e-5 * sc, "dgrad vs bf16-rounded operands"
-        dx16 = ops.conv3x3_bf16(None, qd, Cin, x16=g.to(dev).to(torch.bfloat16))
-        assert torch.equal(dx16.cpu().double(), dx)
+    rb = lambda t: t.to(torch.bfloat16).double()
+    x, g = rnd(B, Cin, H, W, seed=61), rnd(B, Cout, H, W, seed=62)
+    w = rnd(Cout, Cin, 3, 3, seed=63, scale=(2.0 / (Cin * 9)) ** 0.5)
+    xr, wr = rb(x).requires_grad_(True), rb(w).requires_grad_(True)
+    zr = F.conv2d(xr, wr, None, 1, 1)
+    zr.backward(rb(g))
+    wf, wd = ops.pack3x3_plain16(w.to(dev))
+    xP, gP = ops.split_pack_act(x.to(dev), parts=1), ops.split_pack_act(g.to(dev), parts=1)
+    assert xP.dtype == torch.bfloat16 and xP.shape == (B, Cin // 8, H, 1, W, 8)
+    nparts = int(_lib_load().onet_conv3x3_split_pre_nparts(B, H, W))
+    cm = torch.full((Cout, nparts, 3), float("nan"), device=dev) if nparts > 0 else None
+    z = ops.conv3x3_split_pre(xP, wf, Cout, stats=cm)
+    close(z, zr.detach(), tol=2e-6, what="plain-bf16 forward")
+    if cm is not None:
+        assert torch.isfinite(cm).all() and float(cm[:, :, 0].sum(1).min()) == float(cm[:, :, 0].sum(1).max()) == B * H * W
+        gamma, beta = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
+        s0 = ops.bn_train_coeffs(z, gamma, beta, None, None, 0.1, 1e-5)
+        s1 = ops.bn_train_coeffs(z, gamma, beta, None, None, 0.1, 1e-5, cm=(cm, 0, nparts))
+        assert float((s0[0] - s1[0]).abs().max()) <= 2e-6 * float(z.std()) and float(((s0[1] - s1[1]) / s0[1]).abs().max()) <= 1e-5
+        cm2 = torch.full_like(cm, float("nan"))
+        z16 = ops.conv3x3_split_pre(xP, wf, Cout, stats=cm2, z16=True)
+        assert z16.dtype == torch.bfloat16 and torch.equal(z16, z.to(torch.bfloat16)), "bf16 storage of z: one rounding of the fp32 result"
+        assert torch.equal(cm, cm2), "the statistics come from the fp32 accumulators, whatever z is stored as"
+    dx = ops.conv3x3_split_pre(gP, wd, Cin)
+    close(dx, xr.grad, tol=2e-6, what="plain-bf16 input gradient")
+    dw = ops.conv3x3_split_wgrad_pre(xP, gP, (Cout, Cin, 3, 3))
+    close(dw, wr.grad, tol=4e-6, what="plain-bf16 weight gradient")
+
+
+@pytest.mark.parametrize("B,Cd,Ca,H,W,G,mode", [(4, 64, 64, 32, 64, 2, "f16"), (2, 128, 64, 64, 32, 1, "f16"), (6, 64, 64, 16, 64, 3, "f16"),
+                                                 (4, 128, 128, 48, 96, 2, "plain"), (8, 128, 128, 16, 16, 2, "plain")])
+def test_dgrad_with_bn_backward_reduce_epilogue(dev, B, Cd, Ca, H, W, G, mode):
+    """onet_conv3x3_split_dgrad_pre_bnreduce (round 5): the input gradient of a DoubleConv's second convolution with the first unit's
+    BatchNorm-backward REDUCE in the epilogue (the accumulators are that unit's da).  da must equal the unfused launch to summation
+    order, the records -- (hi, lo) pairs in bn_relu_bwd_reduce's format, per statistics group -- must sum to the fp64 sums of
+    dy = da * (relu mask) and dy * xhat formed from the SAME da and z (2e-6 of sum |dy|), and the magnitude slots hold max |da|."""
+    import math
+    from onet_amd import ops
+    dz = (rnd(B, Cd, H, W, seed=71) * 1e-3).to(dev)
+    w = rnd(Cd, Ca, 3, 3, seed=72, scale=(2.0 / (9 * Ca)) ** 0.5).to(dev)
+    zp = (rnd(B, Ca, H, W, seed=73) * 1.5 + 0.2).to(dev)
+    gamma, beta = (1 + 0.1 * rnd(Ca, seed=74)).to(dev), (0.1 * rnd(Ca, seed=75)).to(dev)
+    save = torch.empty(G, 4, Ca, device=dev)
+    Bg = B // G
+    for gi in range(G):
+        ops.bn_train_coeffs(zp[gi * Bg:(gi + 1) * Bg], gamma, beta, None, None, 0.1, 1e-5, save=save[gi])
+    if mode == "f16":
+        _, qd = ops.pack3x3_split(w)
+        sl = ops.absmax_slots(dz)
+        k = 13 - math.floor(math.log2(float(dz.abs().max())))          # the producers' rule: 2^k dz with max |.| in [2^13, 2^14)
+        dzP = ops.split_pack_act(dz, f16=True, scale=2.0 ** k)
+        kw = dict(slots=sl, always=True)
     else:
-        assert qd is None
+        _, qd = ops.pack3x3_plain16(w)
+        dzP = ops.split_pack_act(dz, parts=1)
+        kw = {}
+    ref = ops.conv3x3_split_pre(dzP, qd, Ca, **kw)
+    got = ops.conv3x3_split_dgrad_pre_bnreduce(dzP, qd, Ca, zp, save, want_amax=True, **kw)
+    assert got is not None, "shape not taken by the fused kernel"
+    da, rec4, am = got
+    close(da, ref.double().cpu(), tol=2e-6, what="da vs the unfused launch")
+    r = rec4.double().view(G, -1, Ca, 4).sum(1).cpu()
+    for gi in range(G):
+        s_ = slice(gi * Bg, (gi + 1) * Bg)
+        mean, inv, scl, sh = (save[gi, i].view(1, -1, 1, 1) for i in range(4))
+        mask = torch.addcmul(sh, zp[s_] - mean, scl) > 0                    # the kernel's fp32 expression fma(z - mean, scale, shift) > 0
+        dy = (da[s_].double() * mask).cpu()
+        xhat = ((zp[s_].double() - mean.double()) * inv.double()).cpu()
+        s1, s2, n1 = dy.sum((0, 2, 3)), (dy * xhat).sum((0, 2, 3)), dy.abs().sum((0, 2, 3))
+        assert float(((r[gi, :, 0] + r[gi, :, 1] - s1).abs() / n1).max()) <= 2e-6, "sum dy"
+        assert float(((r[gi, :, 2] + r[gi, :, 3] - s2).abs() / n1).max()) <= 2e-6, "sum dy * xhat"
+    assert float(torch.tensor(am.cpu().numpy().view("float32")).max()) == float(da.abs().max())
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(1, 32, 64, 4, 32), (2, 64, 64, 32, 32), (3, 32, 72, 20, 64), (2, 128, 256, 64, 64),
@@ -583,49 +577,6 @@ def test_conv3x3_winograd4_wgrad(dev, B, Cin, Cout, H, W):
     sc = float(ref.abs().max())
     err = float((dw - ref).abs().max())
     assert err <= 2e-4 * sc, (err, sc)
-
-
-@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 16, 64, 32, 32), (3, 48, 32, 17, 33), (2, 64, 128, 16, 16), (2, 16, 96, 200, 288)])
-def test_conv3x3_bf16_channel_blocked_input(dev, B, Cin, Cout, H, W):
-    """Experimental entry point onet_conv3x3_bf16_fwd_blk: the bf16 forward reading its operand from a channel-blocked copy
-    [C/8][H][W][8] (one 16-byte load per staging slot) must be bit-identical to the NCHW bf16 copy path."""
-    from onet_amd import _lib, ops
-    x16 = rnd(B, Cin, H, W, seed=51).to(dev).to(torch.bfloat16)
-    w = rnd(Cout, Cin, 3, 3, seed=52, scale=(2.0 / (Cin * 9)) ** 0.5)
-    qf, _ = ops.pack3x3_bf16(w.to(dev))
-    z0 = ops.conv3x3_bf16(None, qf, Cout, x16=x16)
-    xb = x16.view(B, Cin // 8, 8, H, W).permute(0, 1, 3, 4, 2).contiguous()
-    z1 = torch.full_like(z0, float("nan"))
-    _lib.call("onet_conv3x3_bf16_fwd_blk", xb.data_ptr(), Cin * H * W, qf.data_ptr(), z1.data_ptr(), Cout * H * W, B, Cin, Cout, H, W,
-              torch.cuda.current_stream().cuda_stream)
-    assert torch.equal(z0, z1)
-
-
-@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 64, 64, 32, 32), (3, 16, 48, 20, 44), (2, 128, 64, 16, 16),
-                                             (1, 72, 40, 9, 28), (4, 64, 128, 64, 64), (2, 64, 64, 40, 72), (3, 32, 96, 24, 128),
-                                             (1, 80, 64, 256, 256), (2, 16, 16, 3, 68), (5, 48, 40, 7, 200)])
-def test_conv3x3_wgrad_bf16_operands(dev, B, Cin, Cout, H, W):
-    """bf16-operand weight gradient (conv_bf16.hip): equal to the fp64 weight gradient of the bf16-ROUNDED x and dz to
-    fp32 summation accuracy; ragged patches (H % 4, W % 16), channel tails, several split-K plans.  Maps from 64 pixels of
-    width take the row-streaming kernel: whole and partial 64-pixel strips (W = 72, 68, 200), runs of rows that cross strips and
-    images inside one block's split-K range, maps of three rows."""
-    from onet_amd import ops
-    x = rnd(B, Cin, H, W, seed=61)
-    g = rnd(B, Cout, H, W, seed=62)
-    rb = lambda t: t.to(torch.bfloat16).to(torch.float64)
-    dw = ops.conv3x3_wgrad_bf16(x.to(dev), g.to(dev), (Cout, Cin, 3, 3)).cpu().double()
-    ref = torch.nn.grad.conv2d_weight(rb(x), (Cout, Cin, 3, 3), rb(g), stride=1, padding=1)
-    full = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), g.double(), stride=1, padding=1)
-    sc = float(full.abs().max())
-    assert float((dw - ref).abs().max()) <= 2e-5 * sc, "vs bf16-rounded operands"
-    if W % 8 == 0:          # bf16 STORAGE of either or both operands: bit-identical to rounding on load
-        x16, g16 = x.to(dev).to(torch.bfloat16), g.to(dev).to(torch.bfloat16)
-        for kw in ({"x16": x16}, {"dz16": g16}, {"x16": x16, "dz16": g16}):
-            d2 = ops.conv3x3_wgrad_bf16(x.to(dev), g.to(dev), (Cout, Cin, 3, 3), **kw)
-            assert torch.equal(d2.cpu().double(), dw), sorted(kw)
-        d3 = ops.conv3x3_wgrad_bf16(None, None, (Cout, Cin, 3, 3), x16=x16, dz16=g16)
-        assert torch.equal(d3.cpu().double(), dw)
-    assert float((dw - full).abs().max()) <= 2e-2 * sc, "vs full precision"
 
 
 @pytest.mark.parametrize("B,Cin,Cmid,Cout,H,W,G", [(4, 8, 64, 32, 32, 32, 1), (4, 16, 72, 64, 32, 64, 2),

@@ -10,6 +10,6 @@ for (B, ci, co, H) in ((4, 64, 64, 64), (4, 256, 256, 32), (4, 1024, 1024, 16)):
     zc = F.conv2d(x, w, None, 1, 1)
     xd, wd = x.cuda(), w.cuda()
     zd = ops.conv_fwd(xd, ops.pack3x3(wd)[0], co, 3).cpu()
-    zw = ops.conv3x3_winograd(xd, ops.pack3x3_winograd(wd)[0], co).cpu()
+    zw = ops.conv3x3_winograd4(xd, ops.pack3x3_winograd4(wd)[0], co).cpu()
     rel = lambda a: float((a.double() - z64).norm() / z64.norm())
-    print(f"Cin {ci:4d} @{H:3d}: cpu32 {rel(zc):.2e}  direct(two-level) {rel(zd):.2e}  winograd {rel(zw):.2e}")
+    print(f"Cin {ci:4d} @{H:3d}: cpu32 {rel(zc):.2e}  direct(two-level) {rel(zd):.2e}  winograd F(4x4) {rel(zw):.2e}")

@@ -7,7 +7,7 @@ from onet_amd import ops
 
 B = int(os.environ.get("B", "64"))
 N = int(os.environ.get("N", "4"))
-which = os.environ.get("WHICH", "wino4,wino4w,winow,convT").split(",")
+which = os.environ.get("WHICH", "wino4,wino4w,presplit,convT").split(",")
 shapes = [(64, 64, 256), (128, 128, 128), (512, 512, 32)]
 
 
@@ -26,8 +26,6 @@ for ci, co, H in shapes:
         rep(lambda: ops.conv3x3_winograd4(x, qf, co))
     if "wino4w" in which and ops.winograd4_wgrad_ok(x, dz):
         rep(lambda: ops.conv3x3_winograd4_wgrad(x, dz, (co, ci, 3, 3)))
-    if "winow" in which:
-        rep(lambda: ops.conv3x3_winograd_wgrad(x, dz, (co, ci, 3, 3)))
     if "split" in which:                    # the round-3 default kernels: forward (fp16 parts), input gradient, weight gradient
         sf, sd = ops.pack3x3_split(w)
         rep(lambda: ops.conv3x3_split(x, sf, co))
@@ -43,11 +41,6 @@ for ci, co, H in shapes:
         rep(lambda: ops.conv3x3_split_pre(xP, pf, co))
         rep(lambda: ops.conv3x3_split_pre(dzP, pd, ci))
         rep(lambda: ops.conv3x3_split_wgrad_pre(xP, dzP, (co, ci, 3, 3)))
-    if "bf16" in which:                     # bf16 STORAGE variants (operands read as bf16 copies)
-        x16, dz16 = x.to(torch.bfloat16), dz.to(torch.bfloat16)
-        bf, bd = ops.pack3x3_bf16(w)
-        rep(lambda: ops.conv3x3_bf16(None, bf, co, x16=x16))
-        rep(lambda: ops.conv3x3_wgrad_bf16(None, None, (co, ci, 3, 3), x16=x16, dz16=dz16))
 if "convT" in which:
     for cin, h in ((128, 128), (512, 32)):
         ct = cin // 2

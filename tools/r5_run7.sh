@@ -1,0 +1,7 @@
+#!/bin/bash
+# full GPU suite with durations
+mkdir -p gpurun_out
+timeout -k 10 1100 python -m pytest tests -m gpu -q --durations=30 > gpurun_out/gputest_f.log 2>&1
+rc=$?
+tail -60 gpurun_out/gputest_f.log
+exit $rc

@@ -18,7 +18,7 @@ for ci, co, H in [(64, 64, 256), (128, 64, 256), (64, 128, 128), (128, 128, 128)
         continue
     x = torch.randn(B, ci, H, H, device="cuda"); g = torch.randn(B, co, H, H, device="cuda")
     shp = (co, ci, 3, 3)
-    tw = timeit(lambda: ops.conv3x3_winograd4_wgrad(x, g, shp) if (ci >= 256 or (ci >= 128 and co >= 256)) and ops.winograd4_wgrad_ok(x, g) else ops.conv3x3_winograd_wgrad(x, g, shp))
+    tw = timeit(lambda: ops.conv3x3_winograd4_wgrad(x, g, shp) if ops.winograd4_wgrad_ok(x, g) else ops.conv_wgrad(x, g, shp, 3))
     ts = timeit(lambda: ops.conv3x3_split_wgrad(x, g, shp))
     fl = 2.0 * B * H * H * ci * co * 9 / 1e9
     tot[0] += tw; tot[1] += ts
