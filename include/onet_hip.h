@@ -132,6 +132,15 @@ int onet_conv3x3_winograd4_dgrad_bnreduce(const float* dz, int64_t dz_bs, const 
  * into the up-sampled channel groups of a pre-split concat buffer; no fp32 output.  Returns 1 (nothing done) outside the GEMM fast path. */
 int onet_convT2x2_fwd_p(const float* x, int64_t x_bs, const float* wq, const float* bias, void* yP, int64_t yP_bs, const void* y_amax,
                         int nparts, int B, int Cin, int Ct, int h, int w, int Ho, int Wo, int pt, int pl, int operand_bf16, void* stream);
+/* Round 5 -- the same forward with BOTH operands in slot form: x pre-split by its producer ([B][Cin/8][h][nparts][w][8], batch stride in
+ * 4-byte units; x_amax: the magnitude slots it was scaled by, guard rule, NULL = unscaled) and the weights packed once per optimizer step
+ * by onet_convT2x2_pack_weights_slots into wP [Cin/8][nparts][4 Ct][8] (nparts = 2: fp16 hi | mid parts of 2^k w, (2^k, 2^-k) as two
+ * floats behind the pack -- allocate Cin * 4 Ct * 2 * nparts + 8 bytes; amax_ws: 8 KB of scratch; nparts = 1: bf16(w)).  Every MFMA
+ * fragment is one 16-byte LDS read of a DMA-copied slot: no conversion or split arithmetic in the kernel.  Output and y_amax as
+ * onet_convT2x2_fwd_p.  Returns 1 (nothing done) unless Cin % 32 == 0, Ct % 32 == 0, h w % 128 == 0 and w is even. */
+int onet_convT2x2_pack_weights_slots(const float* w, void* wP, void* amax_ws, int Cin, int Ct, int nparts, void* stream);
+int onet_convT2x2_fwd_slots(const void* xP, int64_t xP_bs, const void* x_amax, const void* wP, const float* bias, void* yP, int64_t yP_bs,
+                            const void* y_amax, int nparts, int B, int Cin, int Ct, int h, int w, void* stream);
 /* y_amax (may be NULL: unscaled): magnitude slots holding a bound of the up-sampled tensor, written by onet_convT2x2_out_bound from the
  * weights (nn.ConvTranspose2d layout [Cin][Ct][2][2]), the bias and the exact max |x| (x_amax, recorded by the pass that wrote x): the
  * fp16 parts are those of 2^k y with the guard exponent the slots select. */

@@ -560,6 +560,245 @@ __global__ __launch_bounds__(256) void convt_dbias_reduce_kernel(const float* __
     if (threadIdx.x == 0) db[c] = (float)v[0];
 }
 
+
+// ================================================================================================ slot operands (round 5)
+// The forward GEMM with BOTH operands in the 16-byte slot form of conv_split.hip -- 8 consecutive K-values (input channels) of one
+// row / pixel per slot, fp16 (hi | mid) parts of a power-of-two-scaled value (NP = 2: fp32-level results, three MFMAs per term) or
+// one part of plain bf16 (NP = 1: BASELINE configs[2]):
+//   x  [B][Cin/8][h][NP][w][8]    written by the BatchNorm + ReLU pass of the block below (bn.hip: the pre-split producers)
+//   wP [Cin/8][NP][4 Ct][8]       packed once per optimizer step (convt_pack_slots_kernel), column m = 4 c + sub-pixel
+// A slot IS an MFMA fragment (lane (row, kh) of v_mfma_f32_32x32x16 holds k = 8 kh .. 8 kh + 7): both tiles are LDS-DMA copies and
+// every fragment is ONE ds_read_b128 -- per 32-channel chunk a wave issues 8 NP ds_read_b128 for 8 (NP = 1) / 24 (NP = 2) MFMAs and
+// no VALU; the fp32-operand kernel above gathers each fragment with 8 ds_read_b32 and splits it in registers (14.8 VALU per MFMA,
+// 0.23-0.26 of the 16-bit peak issued).  Same 128 x 128 block tile, 2 x 2 waves, double-buffered chunks, one barrier per chunk.
+typedef _Float16 f16x8g __attribute__((ext_vector_type(8)));
+
+struct SArgs {
+    const void* wP;
+    const void* xP;
+    int64_t x_bs;                  // batch stride of x in 4-byte units
+    const float* bias;
+    void* yP;                      // pre-split output [B][Ct/8][Ho][NP][Wo][8]
+    int64_t y_bs;                  // ... its batch stride in 4-byte units
+    const unsigned* x_slots;       // NP = 2: the magnitude slots x's producer scaled it by (guard rule; NULL: unscaled)
+    const unsigned* y_slots;       // NP = 2: ... and those the output is scaled by (guard rule; NULL: unscaled)
+    int B, Cin, Ct, h, w, mTiles, nTiles;
+};
+
+template <int NP>
+__device__ __forceinline__ f32x16 s_mfma(u32x4g a, u32x4g b, f32x16 c) {
+    if constexpr (NP == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8g, a), __builtin_bit_cast(f16x8g, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8g, a), __builtin_bit_cast(bf16x8g, b), c, 0, 0, 0);
+}
+
+#ifndef SLOT_NST
+#define SLOT_NST 2       // measured (B = 64, the four decoder levels, forward): 2 stages / 4 blocks per CU 1.17 ms, 3 / 3 1.20, 4 / 2 1.24
+#endif
+#ifndef SLOT_OCC
+#define SLOT_OCC 4
+#endif
+template <int N>
+__device__ __forceinline__ void slot_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int NP>
+__global__ __launch_bounds__(256, SLOT_OCC) void convt_slot_fwd_kernel(SArgs g) {
+    constexpr int KS = 4 / NP;                     // slots (8 channels each) per chunk: 16 channels (NP = 2) / 32 (NP = 1)
+    constexpr int TILE = KS * NP * 128;            // slots of one operand tile: [slot of the chunk][part][row / pixel] = 8 KB
+    constexpr int NPC = TILE / 256;                // DMA pieces (64 slots) per wave, operand and chunk
+    constexpr int NST = SLOT_NST;                  // ring of chunk buffers, the DMA NST - 1 chunks ahead.  A block lives for 8 .. 64 chunks of
+                                                   // 0.15 us of MFMAs each and is a chain of memory latencies (first chunk, every later
+                                                   // chunk, the stores): what hides them is MORE BLOCKS per CU (32 KB of LDS each), not a
+                                                   // deeper ring -- timing builds without MFMAs / without stores: 0.27 / 0.37 of 0.53 ms on
+                                                   // the 128-channel level, unchanged by the ring depth
+    __shared__ __attribute__((aligned(16))) u32x4g lds[NST * 2 * TILE];     // [stage][A | B]
+    const int bid = xcd_order(gridDim.x);
+    const int mt = bid % g.mTiles;                 // m tile fastest: the blocks of one pixel tile share its x slots in L2
+    const int nt = bid / g.mTiles;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1, l31 = lane & 31, kh = lane >> 5;
+    const int hw = g.h * g.w, M = 4 * g.Ct;
+    const int m0 = mt * 128, n0 = nt * 128;        // global pixel index b * hw + p; hw % 128 == 0: one image per tile
+    const int b = n0 / hw, p0 = n0 % hw;
+
+    const i32x4g ra = g_rsrc(g.wP, (int64_t)(g.Cin / 8) * NP * M * 16);
+    const i32x4g rb = g_rsrc(reinterpret_cast<const unsigned*>(g.xP) + (int64_t)b * g.x_bs, (int64_t)(g.Cin / 8) * hw * NP * 16);
+    unsigned a_off[NPC], b_off[NPC];
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+        const int s = (wid * NPC + j) * 64 + lane;                  // slot of the tile this lane copies
+        const int c8 = s / (NP * 128), part = (s >> 7) % NP, r = s & 127;
+        a_off[j] = (unsigned)((((int64_t)c8 * NP + part) * M + m0 + r) * 16);
+        const int p = p0 + r, i = p / g.w, jx = p % g.w;
+        b_off[j] = (unsigned)(((((int64_t)c8 * g.h + i) * NP + part) * g.w + jx) * 16);
+    }
+    const unsigned a_step = (unsigned)((int64_t)KS * NP * M * 16), b_step = (unsigned)((int64_t)KS * hw * NP * 16);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) u32x4g*)lds;
+    auto issue = [&](int chunk, int buf) __attribute__((always_inline)) {
+        const unsigned la = lds0 + (unsigned)(buf * 2 * TILE * 16), lb = la + TILE * 16;
+#pragma unroll
+        for (int j = 0; j < NPC; ++j) g_dma16(ra, la + (wid * NPC + j) * 1024, a_off[j] + chunk * a_step);
+#pragma unroll
+        for (int j = 0; j < NPC; ++j) g_dma16(rb, lb + (wid * NPC + j) * 1024, b_off[j] + chunk * b_step);
+    };
+    static_assert(NST >= 2 && NST <= 4, "the tail waits below cover rings of two to four stages");
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+    const int nch = g.Cin / (8 * KS);              // >= NST - 1 (host-checked)
+#pragma unroll
+    for (int c = 0; c < NST - 1; ++c) issue(c, c);
+    // what the epilogue needs from memory, asked for now (a block lives for a few microseconds: a dependent load at its end is a stall)
+    float undo = 1.f;
+    if constexpr (NP == 2) {
+        const float* meta = reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(g.wP) + (int64_t)NP * g.Cin * M);
+        float x_inv;
+        (void)amax_scale(amax_read(g.x_slots), false, x_inv);
+        undo = meta[1] * x_inv;
+    }
+    float s_inv;
+    const float s_up = NP == 1 ? 1.f : amax_scale(amax_read(g.y_slots), false, s_inv);
+    float bsv[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) bsv[t][gq] = g.bias ? g.bias[(m0 + wr * 64 + t * 32 + 8 * gq + 4 * kh) >> 2] : 0.f;
+    slot_wait<(NST - 2) * 2 * NPC>();              // chunk 0 landed
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+        const int buf = c % NST;
+        if (c + NST - 1 < nch) issue(c + NST - 1, (c + NST - 1) % NST);
+        const u32x4g* A = lds + buf * 2 * TILE + wr * 64 + l31;
+        const u32x4g* Bt = lds + buf * 2 * TILE + TILE + wc * 64 + l31;
+#pragma unroll
+        for (int s = 0; s < KS / 2; ++s) {                           // one K = 16 step: slots 2 s (kh = 0) and 2 s + 1 (kh = 1)
+            u32x4g af[2][NP], bf[2][NP];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) af[t][q] = A[((2 * s + kh) * NP + q) * 128 + t * 32];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) bf[u][q] = Bt[((2 * s + kh) * NP + q) * 128 + u * 32];
+            if constexpr (NP == 2) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) acc[t][u] = s_mfma<NP>(af[t][1], bf[u][0], acc[t][u]);      // w_mid . x_hi
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) acc[t][u] = s_mfma<NP>(af[t][0], bf[u][1], acc[t][u]);      // w_hi . x_mid
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[t][u] = s_mfma<NP>(af[t][0], bf[u][0], acc[t][u]);          // w_hi . x_hi
+        }
+        // chunk c + 1 landed: all but the pieces of the chunks behind it (in flight: min(NST - 2, nch - 2 - c) chunks of 2 NPC pieces)
+        const int behind = min(NST - 2, nch - 2 - c);
+        constexpr int PPC = 2 * NPC;                             // DMA pieces per wave and chunk
+        if (behind >= 2) slot_wait<2 * PPC>();
+        else if (behind == 1) slot_wait<1 * PPC>();
+        else slot_wait<0>();
+        __syncthreads();                                        // ... and every wave is done with this buffer
+    }
+
+    // ---- epilogue: undo the operand scales, add the bias, write whole pre-split slots (as convt_gemm_kernel's out16_split form)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int p = p0 + wc * 64 + u * 32 + l31, y = p / g.w, x = p % g.w;
+            // A lane holds, of the 8 channels c8 * 8 + {0 .. 7} of this 32-row group, those of its parity (kh = 0: even, kh = 1: odd;
+            // channel 2 gq + kh in acc[4 gq ..]) with all four sub-pixels (di, dj) of input pixel p.  v_permlane32_swap trades the half
+            // it does not keep with the partner lane: afterwards a kh = 0 lane owns the two output pixels of row di = 0 and a kh = 1
+            // lane those of row di = 1, all 8 channels each = whole slots.
+            const int c8 = (m0 + wr * 64 + t * 32) >> 5;
+            float px[2][8];                         // [dj][channel of the group]
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const float bs = bsv[t][gq];
+#pragma unroll
+                for (int dj = 0; dj < 2; ++dj) {
+                    const unsigned d0 = __builtin_bit_cast(unsigned, fmaf(acc[t][u][4 * gq + dj], undo, bs));
+                    const unsigned d1 = __builtin_bit_cast(unsigned, fmaf(acc[t][u][4 * gq + 2 + dj], undo, bs));
+                    const auto sw = __builtin_amdgcn_permlane32_swap(d0, d1, false, false);
+                    const unsigned even = sw[0], odd = sw[1];
+                    px[dj][2 * gq] = __builtin_bit_cast(float, even);
+                    px[dj][2 * gq + 1] = __builtin_bit_cast(float, odd);
+                }
+            }
+            u32x4g* dst = reinterpret_cast<u32x4g*>(reinterpret_cast<unsigned*>(g.yP) + (int64_t)b * g.y_bs) +
+                          ((int64_t)(c8 * (2 * g.h) + 2 * y + kh) * NP) * (2 * g.w) + 2 * x;
+#pragma unroll
+            for (int dj = 0; dj < 2; ++dj) {
+                u32x4g hi, mid;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if constexpr (NP == 2) {
+                        unsigned hh, mm;
+                        split2h_s(px[dj][2 * k], px[dj][2 * k + 1], s_up, hh, mm);
+                        hi[k] = hh;
+                        mid[k] = mm;
+                    } else {
+                        hi[k] = g_pack(px[dj][2 * k], px[dj][2 * k + 1]);
+                    }
+                }
+                dst[dj] = hi;
+                if constexpr (NP == 2) dst[2 * g.w + dj] = mid;
+            }
+        }
+}
+
+// w [Cin][Ct][2][2] fp32 (nn.ConvTranspose2d) -> wP [Cin/8][NP][4 Ct][8]: column m = 4 c + (2 di + dj) (== the weight's own memory
+// order), K-slot = 8 consecutive input channels; NP = 2: fp16 (hi | mid) parts of 2^k w with max |w| in [2^13, 2^14) (k from the
+// magnitude slots wamax; (2^k, 2^-k) stored behind the pack as two floats); NP = 1: bf16(w)
+__global__ void convt_pack_slots_kernel(const float* __restrict__ w, void* __restrict__ wP, int Cin, int Ct, int np,
+                                        const unsigned* __restrict__ wamax) {
+    const int M = 4 * Ct;
+    const int64_t n = (int64_t)Cin * M;
+    float winv = 1.f;
+    const float wscale = np == 2 ? amax_scale(amax_read(wamax), true, winv) : 1.f;
+    if (np == 2 && blockIdx.x == 0 && threadIdx.x == 0) {
+        float* meta = reinterpret_cast<float*>(reinterpret_cast<_Float16*>(wP) + 2 * n);
+        meta[0] = wscale;
+        meta[1] = winv;
+    }
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int kc = (int)(i & 7);
+        const int64_t r = i >> 3;
+        const int m = (int)(r % M), c8 = (int)(r / M);
+        const float v = w[(int64_t)(c8 * 8 + kc) * M + m];
+        if (np == 2) {
+            _Float16* o = reinterpret_cast<_Float16*>(wP);
+            const float vs = v * wscale;
+            const _Float16 hi = (_Float16)vs;
+            o[(((int64_t)c8 * 2 + 0) * M + m) * 8 + kc] = hi;
+            o[(((int64_t)c8 * 2 + 1) * M + m) * 8 + kc] = (_Float16)(vs - (float)hi);
+        } else {
+            reinterpret_cast<__bf16*>(wP)[((int64_t)c8 * M + m) * 8 + kc] = (__bf16)v;
+        }
+    }
+}
+
+__global__ void convt_absmax_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ slots) {
+    float m = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m == m)
+        atomicMax(slots + ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (AMAX_SLOTS - 1)) * AMAX_STRIDE, __builtin_bit_cast(unsigned, m));
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 void wgrad_plan(int B, int Cin, int Ct, int h, int w, int& splitK, int& per) {
@@ -689,3 +928,40 @@ int convt_gemm_wgrad(const float* x, int64_t x_bs, const float* dy, int64_t dy_b
 }
 
 }  // namespace onet
+
+extern "C" {
+
+// ---- ConvTranspose2d GEMMs on slot operands (round 5; include/onet_hip.h)
+int onet_convT2x2_pack_weights_slots(const float* w, void* wP, void* amax_ws, int Cin, int Ct, int nparts, void* stream) {
+    ONET_REQUIRE(w && wP && Cin > 0 && Ct > 0 && (Cin % 8) == 0 && (nparts == 1 || nparts == 2), "convT2x2_pack_weights_slots: bad args");
+    ONET_REQUIRE(nparts == 1 || amax_ws, "convT2x2_pack_weights_slots: the fp16 pack needs the 8 KB magnitude workspace");
+    hipStream_t st = as_stream(stream);
+    const int64_t n = (int64_t)Cin * 4 * Ct;
+    if (nparts == 2) {
+        (void)hipMemsetAsync(amax_ws, 0, AMAX_SLOTS * AMAX_STRIDE * sizeof(unsigned), st);
+        hipLaunchKernelGGL(convt_absmax_kernel, dim3((unsigned)std::min<int64_t>((n + 1023) / 1024, 1024)), dim3(256), 0, st, w, n, (unsigned*)amax_ws);
+        int rc = check_launch("convt_absmax_kernel");
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(convt_pack_slots_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, st, w, wP, Cin, Ct, nparts,
+                       (const unsigned*)amax_ws);
+    return check_launch("convt_pack_slots_kernel");
+}
+
+int onet_convT2x2_fwd_slots(const void* xP, int64_t xP_bs, const void* x_amax, const void* wP, const float* bias, void* yP, int64_t yP_bs,
+                            const void* y_amax, int nparts, int B, int Cin, int Ct, int h, int w, void* stream) {
+    ONET_REQUIRE(xP && wP && yP && B > 0 && Cin > 0 && Ct > 0 && h > 0 && w > 0 && (nparts == 1 || nparts == 2), "convT2x2_fwd_slots: bad args");
+    const int64_t hw = (int64_t)h * w;
+    if ((Cin % 32) || Cin < 128 || (Ct % 32) || (hw % 128) || (w & 1) || !aligned16(xP) || !aligned16(wP) || !aligned16(yP) || (xP_bs & 3) || (yP_bs & 3) ||
+        (int64_t)Cin * hw * 2 * nparts >= (1ll << 31) || (int64_t)Cin * 4 * Ct * 2 * nparts >= (1ll << 31))
+        return 1;                                              // shape outside the fast path: nothing done
+    ONET_REQUIRE(xP_bs >= (int64_t)Cin * hw * nparts / 2 && yP_bs >= (int64_t)Ct * 4 * hw * nparts / 2, "convT2x2_fwd_slots: batch stride too small");
+    SArgs g{wP, xP, xP_bs, bias, yP, yP_bs, (const unsigned*)x_amax, (const unsigned*)y_amax, B, Cin, Ct, h, w, (4 * Ct) / 128, (int)(B * hw / 128)};
+    const int64_t blocks = (int64_t)g.mTiles * g.nTiles;
+    ONET_REQUIRE(blocks > 0 && blocks < (1ll << 31), "convT2x2_fwd_slots: grid too large");
+    if (nparts == 2) hipLaunchKernelGGL(convt_slot_fwd_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), g);
+    else hipLaunchKernelGGL(convt_slot_fwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), g);
+    return check_launch("convt_slot_fwd_kernel");
+}
+
+}  // extern "C"

@@ -474,8 +474,16 @@ class UpConvTCatFn(torch.autograd.Function):
         if p16 is not None:
             catP = p16["catP"]
             assert (Ho, Wo) == (2 * h, 2 * w) and catP.shape[1] * 8 == C2 + Ct and C2 % 8 == 0
+            # round 5: x1 pre-split by its producer and the weights in slot form -- both GEMM operands are LDS-DMA copies
+            x1P = p16.get("x1P")
+            done = False
+            if x1P is not None and hasattr(packed, "slots") and (pt, pl) == (0, 0):
+                done = ops.convT2x2_fwd_slots(x1P, packed.slots(x1P.shape[3]), bias, catP[:, C2 // 8:], Ct, x_slots=p16.get("x1_slots"),
+                                              slots=p16.get("up_slots"))
+            if not done and ops.is_placeholder(x1):
+                raise RuntimeError("onet_amd: ConvTranspose2d input kept only pre-split reached a shape the slot-operand GEMM does not take")
             # the GEMM's epilogue writes whole pre-split slots; shapes outside its fast path: fp32 + one conversion pass
-            if not ops.convT2x2_fwd_p(x1, wp_fused, bias, catP[:, C2 // 8:], Ct, pt, pl, slots=p16.get("up_slots")):
+            if not done and not ops.convT2x2_fwd_p(x1, wp_fused, bias, catP[:, C2 // 8:], Ct, pt, pl, slots=p16.get("up_slots")):
                 # (e.g. an 8 x 8 input map: h w % 128 != 0.)  The conversion pass applies the guard scale of the same slots the
                 # fused epilogue would have used, so the consumer's rescale stays right
                 up = torch.empty((B, Ct, Ho, Wo), dtype=torch.float32, device=x1.device)

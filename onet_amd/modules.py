@@ -200,7 +200,7 @@ class ConvT2x2(nn.ConvTranspose2d, _Packable):
         super().__init__(in_channels, out_channels, kernel_size=2, stride=2)
 
     def _pack_fn(self, w):
-        return ops.packT2x2_fused(w), ops.packT2x2(w)[1]
+        return ops.PackedT(w)
 
     def forward(self, x, output_size=None):
         # standalone use: up-sample only (no skip): concat with an empty skip
@@ -233,23 +233,27 @@ class Up(nn.Module):
             self.up = ConvT2x2(in_channels, in_channels // 2)
             self.conv = DoubleConv(in_channels, out_channels)
 
-    def forward(self, x1, x2, cat=None, groups=1, catP=None):
+    def forward(self, x1, x2, cat=None, groups=1, catP=None, p16_out=None):
         """`cat`: optional concat buffer whose first channels already ARE x2 (UNet.forward lets the encoder write its
-        skip outputs there, so torch.cat's copy of the skip tensor, OV:100, never happens); `catP` (pre-split storage): the pre-split concat buffer, skip groups already written."""
+        skip outputs there, so torch.cat's copy of the skip tensor, OV:100, never happens); `catP` (pre-split storage): the pre-split concat
+        buffer, skip groups already written; `p16_out`: see DoubleConv.forward (the block's output feeds the next Up's slot-operand GEMM)."""
         if isinstance(self.up, ConvT2x2) and catP is not None:
             # scales of the two producers of the concat buffer: the skip groups' (the encoder's BatchNorm bound), the up-sampled groups'
-            # (a bound from this layer's weights and the exact maximum of x1, where its producer recorded one)
-            s_skip, x1_amax = ops.p16_slots(x2), ops.amax_of(x1)
+            # (a bound from this layer's weights and a bound of x1: the exact maximum its producer recorded, or -- x1 written pre-split
+            # for the slot-operand GEMM -- the BatchNorm bound it was scaled by)
+            x1P = ops.p16_of(x1)
+            x1_slots = ops.p16_slots(x1) if x1P is not None else None
+            s_skip, x1_amax = ops.p16_slots(x2), (x1_slots if x1P is not None else ops.amax_of(x1))
             s_up = ops.convT2x2_out_bound(self.up.weight, self.up.bias, x1_amax) if (x1_amax is not None and catP.shape[3] == 2) else None
-            p16 = {"catP": catP, "up_slots": s_up}
+            p16 = {"catP": catP, "up_slots": s_up, "x1P": x1P, "x1_slots": x1_slots}
             x = Fn.UpConvTCatFn.apply(x1, x2, self.up.weight, self.up.bias, self.up.packed(), None, p16)
             ops.tag_p16(x, catP, (s_skip, s_up, x2.shape[1]) if (s_skip is not None or s_up is not None) else None)
-            return self.conv(x, groups=groups)
+            return self.conv(x, groups=groups, p16_out=p16_out)
         if isinstance(self.up, ConvT2x2):
             x = Fn.UpConvTCatFn.apply(x1, x2, self.up.weight, self.up.bias, self.up.packed(), None if cat is None else (cat,))
         else:
             x = Fn.UpBilinearCatFn.apply(x1, x2)
-        return self.conv(x, groups=groups)
+        return self.conv(x, groups=groups, p16_out=p16_out)
 
 
 class UNet(nn.Module):
@@ -328,6 +332,18 @@ class UNet(nn.Module):
                 pool_p[k] = h % 2 == 0 and w % 2 == 0 and ops.pre_layer_ok(B, nxt.in_channels, nxt.out_channels, h // 2, w // 2) \
                     and nxt_blk.pre_capable()
                 h, w = h // 2, w // 2
+        # round 5: the input of a ConvTranspose2d whose output goes into a pre-split concat buffer is written pre-split by the block below
+        # (down4, up1 .. up3) where the slot-operand GEMM takes the shape; its fp32 tensor stays for the weight gradient
+        upP = [None] * 4                                    # [k]: p16_out of the block that feeds level k's Up
+        if any(c is not None for c in catsP):
+            B, h, w = x.shape[0], x.shape[2], x.shape[3]
+            for k in range(4):
+                up = (self.up4, self.up3, self.up2, self.up1)[k]
+                src = (self.up3.conv, self.up2.conv, self.up1.conv, self.down4.maxpool_conv[1])[k]
+                hk, wk = h >> (k + 1), w >> (k + 1)         # the map that level k's ConvTranspose2d reads
+                if catsP[k] is not None and isinstance(up.up, ConvT2x2) and src.pre_capable() and \
+                        ops.convt_slots_ok(B, up.up.in_channels, up.up.out_channels, hk, wk):
+                    upP[k] = {"keep_fp32": True}
 
         def skip(k, C):
             return None if cats[k] is None else cats[k][:, :C]
@@ -370,10 +386,10 @@ class UNet(nn.Module):
         x3, p3 = fork(x3, False, pl[2], self.down3)
         x4 = self.down3(x3, out=skip(3, c3), groups=g, pooled=p3, pool_link=pl[3], p16_out=skipP(3, c3))
         x4, p4 = fork(x4, False, pl[3], self.down4)
-        x5 = self.down4(x4, groups=g, pooled=p4)
-        y4 = self.up1(x5, x4, cat=cats[3], groups=g, catP=catsP[3])
-        y3 = self.up2(y4, x3, cat=cats[2], groups=g, catP=catsP[2])
-        y2 = self.up3(y3, x2, cat=cats[1], groups=g, catP=catsP[1])
+        x5 = self.down4(x4, groups=g, pooled=p4, p16_out=upP[3])
+        y4 = self.up1(x5, x4, cat=cats[3], groups=g, catP=catsP[3], p16_out=upP[2])
+        y3 = self.up2(y4, x3, cat=cats[2], groups=g, catP=catsP[2], p16_out=upP[1])
+        y2 = self.up3(y3, x2, cat=cats[1], groups=g, catP=catsP[1], p16_out=upP[0])
         y1 = self.up4(y2, x1, cat=cats[0], groups=g, catP=catsP[0])
         return x1_out, y1
 

@@ -417,6 +417,70 @@ def convT2x2_out_bound(weight, bias, x_amax):
     return slots
 
 
+def packT2x2_slots(w, parts=2):
+    """nn.ConvTranspose2d weight [Cin, Ct, 2, 2] -> the slot pack of the slot-operand forward GEMM: [Cin/8, parts, 4 Ct, 8] fp16 (hi | mid)
+    parts of 2^k w (+ (2^k, 2^-k) behind the pack), or one part of bf16(w)."""
+    require_gpu(w)
+    w = w.detach().contiguous()
+    Cin, Ct = w.shape[0], w.shape[1]
+    wP = torch.empty(Cin * 4 * Ct * parts + 4, dtype=torch.float16 if parts == 2 else BF, device=w.device)
+    ws = torch.empty(2048, dtype=torch.int32, device=w.device) if parts == 2 else None
+    _lib.call("onet_convT2x2_pack_weights_slots", _p(w), _p(wP), _p(ws), Cin, Ct, parts, _stream())
+    return wP
+
+
+CONVT_SLOTS = _flag("CONVT_SLOTS", True)     # 0: the ConvTranspose2d forward reads the fp32 activation (round 4's kernels)
+
+
+def convt_slots_ok(B, Cin, Ct, h, w):
+    """Does the slot-operand ConvTranspose2d forward take this layer (onet_convT2x2_fwd_slots' predicate)?  The block below then writes
+    its output pre-split for it (UNet._forward)."""
+    return bool(CONVT_SLOTS and presplit() and (p16_parts() == 2 or CONVT_BF16) and Cin % 32 == 0 and Cin >= 128 and Ct % 32 == 0 and (h * w) % 128 == 0 and w % 2 == 0
+                and Cin * h * w * 2 * p16_parts() < 2 ** 31)
+
+
+class PackedT:
+    """Packed forms of one ConvTranspose2d weight: (fused forward pack, input-gradient pack) -- unpacks like that tuple -- plus the slot
+    packs of the slot-operand forward, built on first use per number of parts."""
+
+    def __init__(self, w):
+        self.w = w.detach()
+        self._t = (packT2x2_fused(w), packT2x2(w)[1])
+        self._s = {}
+
+    def __iter__(self):
+        return iter(self._t)
+
+    def __getitem__(self, i):
+        return self._t[i]
+
+    def __len__(self):
+        return 2
+
+    def slots(self, parts):
+        if parts not in self._s:
+            self._s[parts] = packT2x2_slots(self.w, parts)
+        return self._s[parts]
+
+
+def convT2x2_fwd_slots(xP, wP, bias, outP, Ct, x_slots=None, slots=None):
+    """ConvTranspose2d(k=2, s=2) + bias from the PRE-SPLIT input xP [B, Cin/8, h, parts, w, 8] and the slot pack wP (packT2x2_slots),
+    written pre-split into outP [B, Ct/8, 2h, parts, 2w, 8]: both GEMM operands are LDS-DMA copies.  x_slots / slots: the magnitude slots
+    of the input / output.  -> False where the kernel does not take the shape (nothing written)."""
+    B, C8, h, parts, w, _ = xP.shape
+    assert outP.shape[3] == parts and outP.shape[2] == 2 * h and outP.shape[4] == 2 * w and xP.dtype == wP.dtype == outP.dtype
+    Cin = C8 * 8
+    e0 = _prof_begin("convt_gemm_kernel")
+    rc = _lib.load().onet_convT2x2_fwd_slots(_p(xP), _pbs(xP), _p(x_slots), _p(wP), _p(bias), _p(outP), _pbs(outP), _p(slots), parts, B, Cin, Ct,
+                                             h, w, _stream())
+    eb = 2.0 * parts
+    flops, nb = 2.0 * B * h * w * Cin * 4 * Ct, eb * (B * h * w * (Cin + 4 * Ct) + 4 * Cin * Ct)
+    _prof_end("convt_gemm_kernel", flops if rc == 0 else 0.0, e0, nb if rc == 0 else 0.0)
+    if rc < 0:
+        raise _lib.OnetHipError(f"onet_convT2x2_fwd_slots failed ({rc}): {_lib.last_error()}")
+    return rc == 0
+
+
 def convT2x2_fwd_p(x, wq, bias, outP, Ct, pt, pl, slots=None):
     """ConvTranspose2d(k=2, s=2) + bias written PRE-SPLIT into outP [B, Ct/8, Ho, 2, Wo, 8] (the up-sampled channel groups of a pre-split
     concat buffer): no fp32 tensor.  -> False where the GEMM fast path does not take the shape (nothing written)."""

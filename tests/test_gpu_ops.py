@@ -1036,6 +1036,54 @@ def test_convT_presplit_epilogue(dev, B, Cin, h, w):
     assert float(cat[:, :Ct // 8].float().abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,Cin,h,w,parts", [(2, 128, 16, 32, 2), (4, 256, 16, 16, 2), (2, 1024, 16, 16, 2), (1, 128, 64, 64, 2),
+                                             (2, 128, 16, 32, 1), (3, 512, 32, 8, 1)])
+def test_convT_slot_operands(dev, B, Cin, h, w, parts):
+    """Round 5: the ConvTranspose2d forward with BOTH operands in slot form (x pre-split by its producer, the weights packed by
+    onet_convT2x2_pack_weights_slots; every MFMA fragment one 16-byte LDS read of a DMA-copied slot).  fp16 (hi | mid) parts: the
+    pre-split output must equal the fp64 ConvTranspose2d of the fp32 operands to 2e-6 of scale (22-bit operands, fp32 accumulation --
+    the fp32-operand GEMM with bf16 parts holds 1e-5), also with an input written under a guard scale and an output that needs one;
+    plain bf16: the fp64 result of the bf16-rounded operands, rounded once to bf16.  The skip groups of the concat buffer stay untouched."""
+    from onet_amd import ops
+    Ct = Cin // 2
+    x = torch.relu(rnd(B, Cin, h, w, seed=81))
+    wt, bias = rnd(Cin, Ct, 2, 2, seed=82, scale=0.05), rnd(Ct, seed=83)
+    rb = (lambda t: t.to(torch.bfloat16).double()) if parts == 1 else (lambda t: t.double())
+
+    def nchw(P):
+        v = P.float().sum(3) if P.shape[3] == 2 else P[:, :, :, 0].float()
+        return v.permute(0, 1, 4, 2, 3).reshape(P.shape[0], P.shape[1] * 8, P.shape[2], P.shape[4])
+
+    for gain in ((1.0, 3.0e4) if parts == 2 else (1.0,)):            # 3e4: max |x| and max |y| beyond fp16's range -> guard scales
+        xg = x * gain
+        ref = F.conv_transpose2d(rb(xg), rb(wt), bias.double(), stride=2)
+        xd = xg.to(dev)
+        x_slots = ops.absmax_slots(xd) if parts == 2 else None
+        xP = ops.split_pack_act(xd, f16=True, parts=parts, slots=x_slots)
+        wP = ops.packT2x2_slots(wt.to(dev), parts)
+        y_slots = ops.convT2x2_out_bound(wt.to(dev), bias.to(dev), x_slots) if parts == 2 else None
+        cat = torch.zeros((B, 2 * Ct // 8, 2 * h, parts, 2 * w, 8), dtype=xP.dtype, device=dev)
+        assert ops.convT2x2_fwd_slots(xP, wP, bias.to(dev), cat[:, Ct // 8:], Ct, x_slots=x_slots, slots=y_slots)
+        got = nchw(cat[:, Ct // 8:]).double().cpu()
+        if parts == 2 and gain > 1:
+            k = 13 - int(np.floor(np.log2(float(torch.tensor(y_slots.cpu().numpy().view("float32")).max()))))
+            assert k < 0, "this case is meant to need the output guard scale"
+            got = got * 2.0 ** -k
+        if parts == 2:
+            close(got, ref, tol=2e-6, what=f"slot-operand ConvTranspose2d, gain {gain}")
+        else:
+            assert torch.equal(got.float(), ref.float().to(torch.bfloat16).float()) or \
+                float((got - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max()), "plain bf16: one output rounding"
+            close(got, ref, tol=2.0 ** -8, what="slot-operand ConvTranspose2d, plain bf16")
+        assert float(cat[:, :Ct // 8].float().abs().max()) == 0.0
+    # shapes outside the fast path are refused, nothing written
+    if parts == 2:
+        xs = ops.split_pack_act(torch.relu(rnd(1, 64, 8, 8, seed=84)).to(dev), f16=True)
+        out = torch.zeros((1, 4, 16, 2, 16, 8), dtype=torch.float16, device=dev)
+        assert not ops.convT2x2_fwd_slots(xs, ops.packT2x2_slots(rnd(64, 32, 2, 2, seed=85).to(dev)), None, out, 32)
+        assert float(out.float().abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("Cout,Cin", [(64, 64), (128, 64), (72, 48), (512, 256), (40, 16)])
 def test_split_weight_packs_bit_for_bit(dev, Cout, Cin, monkeypatch):
     """The weight packs of conv_split.hip ([K/16][part][tap][half][N][8], written by pack3x3_split_kernel) against their definition in
