@@ -466,7 +466,8 @@ class UpConvTCatFn(torch.autograd.Function):
         """p16 (pre-split storage): {"catP": the pre-split concat buffer, skip groups written by the encoder}: the up-sampled groups
         are written here and NO fp32 concat exists (a placeholder goes through the graph)."""
         ops.require_gpu(x1, x2, weight, bias)
-        wp_fused, wp_dgrad = packed
+        wp_fused, wp_dgrad = packed               # (ops.PackedT hands out lazy handles: the fused fp32 pack is made only if it is used)
+        wp_dgrad = ops.pack_of(wp_dgrad)
         B, Cin, h, w = x1.shape
         Ct = weight.shape[1]
         C2, Ho, Wo = x2.shape[1], x2.shape[2], x2.shape[3]
@@ -483,11 +484,11 @@ class UpConvTCatFn(torch.autograd.Function):
             if not done and ops.is_placeholder(x1):
                 raise RuntimeError("onet_amd: ConvTranspose2d input kept only pre-split reached a shape the slot-operand GEMM does not take")
             # the GEMM's epilogue writes whole pre-split slots; shapes outside its fast path: fp32 + one conversion pass
-            if not done and not ops.convT2x2_fwd_p(x1, wp_fused, bias, catP[:, C2 // 8:], Ct, pt, pl, slots=p16.get("up_slots")):
+            if not done and not ops.convT2x2_fwd_p(x1, ops.pack_of(wp_fused), bias, catP[:, C2 // 8:], Ct, pt, pl, slots=p16.get("up_slots")):
                 # (e.g. an 8 x 8 input map: h w % 128 != 0.)  The conversion pass applies the guard scale of the same slots the
                 # fused epilogue would have used, so the consumer's rescale stays right
                 up = torch.empty((B, Ct, Ho, Wo), dtype=torch.float32, device=x1.device)
-                ops.convT2x2_fwd(x1, wp_fused, bias, up, Ct, pt, pl)
+                ops.convT2x2_fwd(x1, ops.pack_of(wp_fused), bias, up, Ct, pt, pl)
                 ops.split_pack_act(up, out=catP[:, C2 // 8:], slots=p16.get("up_slots"))
             ctx.save_for_backward(x1, wp_dgrad)
             ctx.meta = (C2, Ct, h, w, pt, pl, tuple(weight.shape), bias is not None)
@@ -503,7 +504,7 @@ class UpConvTCatFn(torch.autograd.Function):
         if (Ho, Wo) != (2 * h, 2 * w):
             for bi in range(B):                      # F.pad border (only when H or W is not a multiple of 16); raw
                 ops.fill(cat[bi, C2:], 0.0)          # fills: a torch in-place op on the base of the skip view is forbidden
-        ops.convT2x2_fwd(x1, wp_fused, bias, cat[:, C2:], Ct, pt, pl)
+        ops.convT2x2_fwd(x1, ops.pack_of(wp_fused), bias, cat[:, C2:], Ct, pt, pl)
         ctx.save_for_backward(x1, wp_dgrad)
         ctx.meta = (C2, Ct, h, w, pt, pl, tuple(weight.shape), bias is not None)
         ctx.params = (weight, bias)

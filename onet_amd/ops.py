@@ -439,20 +439,37 @@ def convt_slots_ok(B, Cin, Ct, h, w):
                 and Cin * h * w * 2 * p16_parts() < 2 ** 31)
 
 
+class _LazyPack:
+    """One of PackedT's two classic packs, packed when something actually touches the tensor (get())."""
+
+    def __init__(self, owner, i):
+        self.owner, self.i = owner, i
+
+    def get(self):
+        return self.owner[self.i]
+
+
+def pack_of(p):
+    """The tensor behind a pack handed through autograd as a non-tensor argument: a tensor, or a lazy handle of PackedT."""
+    return p.get() if isinstance(p, _LazyPack) else p
+
+
 class PackedT:
     """Packed forms of one ConvTranspose2d weight: (fused forward pack, input-gradient pack) -- unpacks like that tuple -- plus the slot
     packs of the slot-operand forward, built on first use per number of parts."""
 
     def __init__(self, w):
         self.w = w.detach()
-        self._t = (packT2x2_fused(w), packT2x2(w)[1])
+        self._t = [None, None]          # built on first use: a step on the slot-operand forward never asks for the fused fp32 pack
         self._s = {}
 
-    def __iter__(self):
-        return iter(self._t)
-
     def __getitem__(self, i):
+        if self._t[i] is None:
+            self._t[i] = packT2x2_fused(self.w) if i == 0 else packT2x2(self.w)[1]
         return self._t[i]
+
+    def __iter__(self):
+        return iter((_LazyPack(self, 0), _LazyPack(self, 1)))
 
     def __len__(self):
         return 2
