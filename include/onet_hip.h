@@ -141,6 +141,19 @@ int onet_convT2x2_fwd_p(const float* x, int64_t x_bs, const float* wq, const flo
 int onet_convT2x2_pack_weights_slots(const float* w, void* wP, void* amax_ws, int Cin, int Ct, int nparts, void* stream);
 int onet_convT2x2_fwd_slots(const void* xP, int64_t xP_bs, const void* x_amax, const void* wP, const float* bias, void* yP, int64_t yP_bs,
                             const void* y_amax, int nparts, int B, int Cin, int Ct, int h, int w, void* stream);
+/* ... and the backward GEMMs on slot operands.  dyP [B][Ct/8][2h][nparts][2w][8]: the up-sampled half of the concat gradient, written
+ * pre-split by onet_conv3x3_split_dgrad_pre_slots as parts of 2^k dy (k by the `always` rule from the bound in dy_amax,
+ * onet_conv3x3_dgrad_bound).  Input gradient: wdP = onet_convT2x2_pack_weights_dgrad_slots' pack [(Ct/8) 4][nparts][Cin][8] (K-slot =
+ * 8 channels at one sub-pixel; same size and scale pair as the forward pack), dx fp32 [B][Cin][h][w].  Weight gradient: x pre-split as
+ * for the forward; dw [Cin][Ct][2][2]; dbias (may be NULL) [Ct] = sum of dy over all pixels, taken in the same launch; ws: at least
+ * onet_convT2x2_wgrad_slots_ws_bytes(...) (0: shape not taken).  Both return 1 (nothing done) outside Cin % 128 == 0, Ct % 32 == 0,
+ * h w % 128 == 0 (weight gradient: w a power of two). */
+int onet_convT2x2_pack_weights_dgrad_slots(const float* w, void* wdP, void* amax_ws, int Cin, int Ct, int nparts, void* stream);
+int onet_convT2x2_dgrad_slots(const void* dyP, int64_t dyP_bs, const void* dy_amax, const void* wdP, float* dx, int64_t dx_bs, int nparts, int B,
+                              int Cin, int Ct, int h, int w, void* stream);
+int64_t onet_convT2x2_wgrad_slots_ws_bytes(int B, int Cin, int Ct, int h, int w);
+int onet_convT2x2_wgrad_slots(const void* xP, int64_t xP_bs, const void* x_amax, const void* dyP, int64_t dyP_bs, const void* dy_amax, float* dw,
+                              float* dbias, void* ws, int64_t ws_bytes, int nparts, int B, int Cin, int Ct, int h, int w, void* stream);
 /* y_amax (may be NULL: unscaled): magnitude slots holding a bound of the up-sampled tensor, written by onet_convT2x2_out_bound from the
  * weights (nn.ConvTranspose2d layout [Cin][Ct][2][2]), the bias and the exact max |x| (x_amax, recorded by the pass that wrote x): the
  * fp16 parts are those of 2^k y with the guard exponent the slots select. */
@@ -207,6 +220,15 @@ int onet_conv3x3_split_fwd_pre(const void* xs, int64_t xs_bs, const void* x_amax
                                const void* wq, int wq_f16, void* z, int z_bf16 /* 1: z stored as bf16 (plain-bf16 operands only) */, int64_t z_bs,
                                float* part, int B, int Cin, int Cout, int H, int W,
                                void* stream);
+/* Round 5 -- the input gradient of a decoder block's FIRST convolution (fp16 hi | mid parts, maps made of full 16 x 32 tiles): channels
+ * < ch0 of da (the skip half of the concat gradient) as fp32, channels >= ch0 (the up-sampled half, read only by the ConvTranspose2d
+ * backward GEMMs) pre-split into daP [B][(Cout - ch0)/8][H][2][W][8] as parts of 2^k da, k by the `always` rule from daP_amax -- which
+ * onet_conv3x3_dgrad_bound fills first: max |dz| (dz_amax) x the largest sum over (co, tap) of |w[co][ci][tap]| over ci >= ci0 (w: the
+ * nn.Conv2d weight [Cout][Cin][3][3]; out_slots zeroed by the caller).  Cin / Cout here name the channels of dzs / da. */
+int onet_conv3x3_split_dgrad_pre_slots(const void* dzs, int64_t dzs_bs, const void* dz_amax, int scale_always, const void* wq, float* da,
+                                       int64_t da_bs, void* daP, int64_t daP_bs, int ch0, const void* daP_amax, int B, int Cin, int Cout, int H,
+                                       int W, void* stream);
+int onet_conv3x3_dgrad_bound(const float* w, int Cout, int Cin, int ci0, const void* dz_amax, void* out_slots, void* stream);
 /* Weight gradient (OV:47,51 backward) from pre-split x and dz (both in the slot layout, same 16-bit type): fragments by the gfx950
  * transposing LDS read, staging by LDS-DMA; the producers' power-of-two scales (x_amax: guard rule, dz_amax: always; NULL:
  * unscaled) are undone on the slabs; deterministic split-K through ws

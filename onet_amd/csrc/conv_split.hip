@@ -646,6 +646,14 @@ struct SpPreArgs {
     // conv3x3_pre16_kernel, plain bf16 operands (BASELINE configs[2]): z16 -- the output z is STORED as bf16 (rounded once, to nearest
     // even; the statistics epilogue still reads the fp32 accumulators), z_bs in elements; rd_z16 -- rd_z is such a bf16 tensor
     int z16 = 0, rd_z16 = 0;
+    // conv3x3_split_pre_kernel, fp16 (hi | mid) parts (round 5): output channels >= zP_ch0 (a multiple of 64) are NOT written to z but,
+    // pre-split, to zP [B][(Cout - zP_ch0) / 8][H][2][W][8] (batch stride zP_bs in 4-byte units) as parts of 2^k z, k by the `always`
+    // rule from the bound in zP_slots: the input gradient of a decoder block's first convolution hands the up-sampled half of the
+    // concat gradient to the ConvTranspose2d backward GEMMs in their operand form
+    void* zP = nullptr;
+    int64_t zP_bs = 0;
+    int zP_ch0 = 0;
+    const unsigned* zP_slots = nullptr;
 };
 
 #ifndef SP_PRE_LAST_TAP
@@ -781,6 +789,11 @@ __global__ __launch_bounds__(SP_PRE_NW * 64, SP_PRE_NW / 4) void conv3x3_split_p
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int buf = 0;
+    float zP_scale = 1.f;
+    if constexpr (PM == 1 && !ST && !W16) {
+        float zinv;
+        if (a.zP) zP_scale = amax_scale(amax_read(a.zP_slots), true, zinv);
+    }
     for (int tile = t_first; tile < t_end; tile += t_stride) {
         f32x16 acc[2][NT];
 #pragma unroll
@@ -970,6 +983,51 @@ __global__ __launch_bounds__(SP_PRE_NW * 64, SP_PRE_NW / 4) void conv3x3_split_p
         }
         float* zb = a.z + (int64_t)(W16 ? 2 * b + (l31 >> 4) : b) * a.z_bs;      // (W16: b is the image pair, lanes 16-31 hold the second image)
         const int xo = W16 ? (l31 & 15) : x0 + l31;
+        if constexpr (PM == 1 && !ST && !W16) {
+            if (a.zP && co0 >= a.zP_ch0) {
+                // Pre-split output (SpPreArgs::zP).  A lane holds channels 8 g + 4 kh + {0 .. 3} of its pixel for the four groups g of a
+                // 32-row accumulator; v_permlane32_swap trades halves with the partner lane (kh ^ 1): afterwards a kh = 0 lane owns all
+                // 8 channels of groups 0 and 2, a kh = 1 lane those of groups 1 and 3 -- whole slots, 512 contiguous bytes per half-wave
+                const float zs = zP_scale;
+                u32x4s* zp = reinterpret_cast<u32x4s*>(reinterpret_cast<unsigned*>(a.zP) + (int64_t)b * a.zP_bs);
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const int yo = y0 + wn * NT + n;
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            float v[8];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                // (scalars first: __builtin_bit_cast applied to a vector ELEMENT yields element 0 with hipcc 7.2)
+                                const float f0 = acc[m][n][8 * e + j], f1 = acc[m][n][8 * e + 4 + j];             // groups 2 e, 2 e + 1
+                                const unsigned d0 = __builtin_bit_cast(unsigned, f0);
+                                const unsigned d1 = __builtin_bit_cast(unsigned, f1);
+                                const auto sw = __builtin_amdgcn_permlane32_swap(d0, d1, false, false);
+                                const unsigned lo = sw[0], hi4 = sw[1];
+                                v[j] = __builtin_bit_cast(float, lo);
+                                v[4 + j] = __builtin_bit_cast(float, hi4);
+                            }
+                            u32x4s hi, mid;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                unsigned hh, mm;
+                                split2h_s(v[2 * k], v[2 * k + 1], zs, hh, mm);
+                                hi[k] = hh;
+                                mid[k] = mm;
+                            }
+                            if (yo < a.H && xo < a.W) {
+                                const int c8 = ((co0 - a.zP_ch0 + m * 32) >> 3) + 2 * e + kh;
+                                u32x4s* d = zp + ((int64_t)(c8 * a.H + yo) * 2) * a.W + xo;
+                                d[0] = hi;
+                                d[a.W] = mid;
+                            }
+                        }
+                    }
+                continue;
+            }
+        }
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -2552,6 +2610,55 @@ int onet_conv3x3_split_dgrad_pre_bnreduce(const void* dzs, int64_t dzs_bs, const
     }
     if (wq_f16 == 2) return launch_split_pre<false, 2, false, true>(a, st);
     return wq_f16 ? launch_split_pre<false, 1, false, true>(a, st) : launch_split_pre<false, 0, false, true>(a, st);
+}
+
+// Input gradient of a decoder block's FIRST convolution (fp16 hi | mid parts): channels < ch0 of da as fp32, channels >= ch0 -- the
+// up-sampled half of the concat gradient, read only by the ConvTranspose2d backward GEMMs -- pre-split into daP (SpPreArgs::zP).
+int onet_conv3x3_split_dgrad_pre_slots(const void* dzs, int64_t dzs_bs, const void* dz_amax, int scale_always, const void* wq, float* da,
+                                       int64_t da_bs, void* daP, int64_t daP_bs, int ch0, const void* daP_amax, int B, int Cin, int Cout, int H,
+                                       int W, void* stream) {
+    ONET_REQUIRE(dzs && wq && da && daP && daP_amax, "conv3x3_split_dgrad_pre_slots: null pointer");
+    ONET_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W >= 32 && (W % 32) == 0 && (H % 16) == 0 && (Cin % 16) == 0,
+                 "conv3x3_split_dgrad_pre_slots: maps made of full 16 x 32 tiles, Cin %% 16 == 0");
+    ONET_REQUIRE(ch0 > 0 && ch0 < Cout && (ch0 % 64) == 0 && (Cout % 64) == 0, "conv3x3_split_dgrad_pre_slots: ch0 and Cout must be multiples of 64");
+    ONET_REQUIRE((dzs_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(dzs) & 15) == 0 && (daP_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(daP) & 15) == 0,
+                 "conv3x3_split_dgrad_pre_slots: 16-byte aligned slots required");
+    ONET_REQUIRE(dzs_bs >= (int64_t)Cin * H * W && da_bs >= (int64_t)ch0 * H * W && daP_bs >= (int64_t)(Cout - ch0) * H * W,
+                 "conv3x3_split_dgrad_pre_slots: batch stride too small");
+    ONET_REQUIRE((int64_t)(Cin + 32) * H * W * 4 < (1ll << 31) && (int64_t)(Cin + 32) * 2 * 9 * Cout * 2 < (1ll << 31),
+                 "conv3x3_split_dgrad_pre_slots: operand exceeds the 2 GiB buffer-resource range");
+    SpPreArgs a{dzs, dzs_bs, (const __bf16*)wq, da, da_bs, B, Cin, Cout, H, W, 0, 0, 0, nullptr, (const unsigned*)dz_amax, scale_always, nullptr, 0};
+    a.zP = daP;
+    a.zP_bs = daP_bs;
+    a.zP_ch0 = ch0;
+    a.zP_slots = (const unsigned*)daP_amax;
+    return launch_split_pre<false, 1, false>(a, as_stream(stream));
+}
+
+// |da[ci]| <= max |dz| * sum over (co, tap) of |w[co][ci][tap]|: the bound of the input gradient's channels >= ci0 from the bound of dz
+// (dz_amax) and the weights, into out_slots (zeroed by the caller) -- what onet_conv3x3_split_dgrad_pre_slots scales its slots by
+__global__ __launch_bounds__(256) void conv3x3_dgrad_bound_kernel(const float* __restrict__ w, int Cout, int Cin, int ci0,
+                                                                  const unsigned* __restrict__ dz_slots, unsigned* __restrict__ out_slots) {
+    __shared__ float red[4];
+    const float dzmax = amax_read(dz_slots);
+    const int ci = ci0 + blockIdx.x;
+    float sm = 0.f;
+    for (int i = threadIdx.x; i < Cout * 9; i += 256) sm += fabsf(w[((int64_t)(i / 9) * Cin + ci) * 9 + i % 9]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float bound = ((red[0] + red[1]) + (red[2] + red[3])) * dzmax * 1.00001f;
+        if (bound == bound) atomicMax(out_slots + (blockIdx.x & (AMAX_SLOTS - 1)) * AMAX_STRIDE, __builtin_bit_cast(unsigned, bound));
+    }
+}
+
+int onet_conv3x3_dgrad_bound(const float* w, int Cout, int Cin, int ci0, const void* dz_amax, void* out_slots, void* stream) {
+    ONET_REQUIRE(w && dz_amax && out_slots && Cout > 0 && ci0 >= 0 && ci0 < Cin, "conv3x3_dgrad_bound: bad args");
+    hipLaunchKernelGGL(conv3x3_dgrad_bound_kernel, dim3((unsigned)(Cin - ci0)), dim3(256), 0, as_stream(stream), w, Cout, Cin, ci0,
+                       (const unsigned*)dz_amax, (unsigned*)out_slots);
+    return check_launch("conv3x3_dgrad_bound_kernel");
 }
 
 int onet_conv3x3_split_nparts(int B, int H, int W) { return split_nparts(B, H, W); }

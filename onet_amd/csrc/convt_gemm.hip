@@ -759,6 +759,355 @@ __global__ __launch_bounds__(256, SLOT_OCC) void convt_slot_fwd_kernel(SArgs g) 
         }
 }
 
+// ---- input gradient on slot operands:  dx[b][ci][i][j] = sum_{c,di,dj} dy[b][c][2i+di][2j+dj] W[ci][c][di][dj]   (M = Cin, N = pixels, K = 4 Ct)
+//   dyP [B][Ct/8][Ho][NP][Wo][8]   the up-sampled half of the concat gradient, written pre-split by the input gradient of the decoder
+//                                  block's first convolution (conv_split.hip: SpPreArgs::zP), parts of 2^k dy (rule `always`, dy_slots)
+//   wdP [(Ct/8) 4][NP][Cin][8]     K-slot (c8, q = 2 di + dj) = channels 8 c8 .. 8 c8 + 7 at sub-pixel q: the dy slot of output pixel
+//                                  (2i + di, 2j + dj) IS the B fragment of input pixel (i, j) -- the inverse pixel shuffle is an address
+// Same skeleton as convt_slot_fwd_kernel; the epilogue writes fp32 dx (the gradient of the block below's activation).
+struct SDArgs {
+    const void* wdP;
+    const void* dyP;
+    int64_t dy_bs;                 // 4-byte units
+    float* dx;
+    int64_t dx_bs;                 // elements
+    const unsigned* dy_slots;
+    int B, Cin, Ct, h, w, mTiles, nTiles;
+};
+
+template <int NP>
+__global__ __launch_bounds__(256, SLOT_OCC) void convt_slot_dgrad_kernel(SDArgs g) {
+    constexpr int KS = 4 / NP;
+    constexpr int TILE = KS * NP * 128;
+    constexpr int NPC = TILE / 256;
+    constexpr int NST = SLOT_NST;
+    __shared__ __attribute__((aligned(16))) u32x4g lds[NST * 2 * TILE];
+    const int bid = xcd_order(gridDim.x);
+    const int mt = bid % g.mTiles, nt = bid / g.mTiles;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1, l31 = lane & 31, kh = lane >> 5;
+    const int hw = g.h * g.w, M = g.Cin, Ho = 2 * g.h, Wo = 2 * g.w;
+    const int m0 = mt * 128, n0 = nt * 128;
+    const int b = n0 / hw, p0 = n0 % hw;
+
+    const i32x4g ra = g_rsrc(g.wdP, (int64_t)(g.Ct / 2) * NP * M * 16);
+    const i32x4g rb = g_rsrc(reinterpret_cast<const unsigned*>(g.dyP) + (int64_t)b * g.dy_bs, (int64_t)(g.Ct / 8) * Ho * NP * Wo * 16);
+    unsigned a_off[NPC], b_px[NPC];
+    int b_ks[NPC];
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+        const int s = (wid * NPC + j) * 64 + lane;
+        const int ks = s / (NP * 128), part = (s >> 7) % NP, r = s & 127;
+        a_off[j] = (unsigned)((((int64_t)ks * NP + part) * M + m0 + r) * 16);
+        const int p = p0 + r, i = p / g.w, jx = p % g.w;
+        b_px[j] = (unsigned)(((((int64_t)2 * i) * NP + part) * Wo + 2 * jx) * 16);
+        b_ks[j] = ks;
+    }
+    const unsigned a_step = (unsigned)((int64_t)KS * NP * M * 16);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) u32x4g*)lds;
+    auto issue = [&](int chunk, int buf) __attribute__((always_inline)) {
+        const unsigned la = lds0 + (unsigned)(buf * 2 * TILE * 16), lb = la + TILE * 16;
+#pragma unroll
+        for (int j = 0; j < NPC; ++j) g_dma16(ra, la + (wid * NPC + j) * 1024, a_off[j] + chunk * a_step);
+#pragma unroll
+        for (int j = 0; j < NPC; ++j) {
+            const int kq = chunk * KS + b_ks[j], c8 = kq >> 2, di = (kq >> 1) & 1, dj = kq & 1;
+            g_dma16(rb, lb + (wid * NPC + j) * 1024, b_px[j] + (unsigned)((((int64_t)c8 * Ho + di) * NP * Wo + dj) * 16));
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+    const int nch = (g.Ct / 2) / KS;               // K-slots: 4 Ct / 8
+#pragma unroll
+    for (int c = 0; c < NST - 1; ++c) issue(c, c);
+    float undo = 1.f;
+    if constexpr (NP == 2) {
+        const float* meta = reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(g.wdP) + (int64_t)NP * 4 * g.Ct * M);
+        float dy_inv;
+        (void)amax_scale(amax_read(g.dy_slots), true, dy_inv);
+        undo = meta[1] * dy_inv;
+    }
+    slot_wait<(NST - 2) * 2 * NPC>();
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+        const int buf = c % NST;
+        if (c + NST - 1 < nch) issue(c + NST - 1, (c + NST - 1) % NST);
+        const u32x4g* A = lds + buf * 2 * TILE + wr * 64 + l31;
+        const u32x4g* Bt = lds + buf * 2 * TILE + TILE + wc * 64 + l31;
+#pragma unroll
+        for (int s = 0; s < KS / 2; ++s) {
+            u32x4g af[2][NP], bf[2][NP];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) af[t][q] = A[((2 * s + kh) * NP + q) * 128 + t * 32];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) bf[u][q] = Bt[((2 * s + kh) * NP + q) * 128 + u * 32];
+            if constexpr (NP == 2) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) acc[t][u] = s_mfma<NP>(af[t][1], bf[u][0], acc[t][u]);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) acc[t][u] = s_mfma<NP>(af[t][0], bf[u][1], acc[t][u]);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[t][u] = s_mfma<NP>(af[t][0], bf[u][0], acc[t][u]);
+        }
+        const int behind = min(NST - 2, nch - 2 - c);
+        constexpr int PPC = 2 * NPC;
+        if (behind >= 2) slot_wait<2 * PPC>();
+        else if (behind == 1) slot_wait<1 * PPC>();
+        else slot_wait<0>();
+        __syncthreads();
+    }
+    float* xb = g.dx + (int64_t)b * g.dx_bs;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int p = p0 + wc * 64 + u * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = m0 + wr * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                xb[(int64_t)ci * hw + p] = acc[t][u][r] * undo;
+            }
+        }
+}
+
+// ---- weight gradient on slot operands:  dW[ci][c][di][dj] = sum_{b,i,j} x[b][ci][i][j] dy[b][c][2i+di][2j+dj]   (M = Cin, N = 4 Ct, K = pixels)
+// Both operands are pre-split tensors, channels contiguous inside a slot and the reduction index (pixels) running ACROSS slots: the
+// fragments are read with the transposing LDS read ds_read_b64_tr_b16, exactly as conv3x3_split_wgrad_pre_kernel does (conv_split.hip:
+// a 16-lane group fetches 4 pixel slots x 16 channels and every lane receives ITS channel's four pixels).  Block tile: 128 input
+// channels (16 slot groups) x 32 output channels (4 groups) x 4 sub-pixels; a K-chunk = 32 input pixels; LDS image of a chunk =
+// planes of PXP = 36 slots (32 + 4 pad: 144 dwords = 16 banks mod 64, the conflict-free plane pitch of the 3x3 kernel):
+//   A planes [part][16 groups], B planes [part][sub-pixel q][4 groups]: 64 planes = 36 KB per stage, two stages.
+// Waves 2 x 2: wr = which 64 input channels, wc = which output row parity (di): a wave's two 32-column tiles are dj = 0, 1.
+// The ConvTranspose2d bias gradient (sum of dy over all pixels) rides along as a row of ones: the waves wr == 0 of the blocks mt == 0
+// multiply their dy fragments by a constant-one A fragment (row 0 of the result = the column sums).
+struct SWArgs {
+    const void* xP;
+    int64_t x_bs;                  // 4-byte units
+    const void* dyP;
+    int64_t dy_bs;
+    float* slab;                   // [splitK][Cin][4 Ct]
+    float* db_part;                // [splitK * 4][Ct] partial bias gradients (NULL: not wanted)
+    const unsigned* x_slots;       // guard rule
+    const unsigned* dy_slots;      // rule `always`
+    int B, Cin, Ct, h, w, lw;      // lw = log2(w)
+    int mTiles, nTiles, splitK, chunksPerSplit;
+};
+
+constexpr int SW_PXP = 36, SW_PLANES = 32;                  // planes per part
+
+__device__ __forceinline__ u32x4g sw_frag(unsigned addr) {   // 8 consecutive pixels (K) of this lane's channel: two transposed reads
+    typedef short s16x4g __attribute__((ext_vector_type(4)));
+    const s16x4g lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4g*)(uintptr_t)addr);
+    const s16x4g hv = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4g*)(uintptr_t)(addr + 64));
+    const unsigned long long a = __builtin_bit_cast(unsigned long long, lo), b = __builtin_bit_cast(unsigned long long, hv);
+    return u32x4g{(unsigned)a, (unsigned)(a >> 32), (unsigned)b, (unsigned)(b >> 32)};
+}
+
+template <int NP>
+__global__ __launch_bounds__(256, 2) void convt_slot_wgrad_kernel(SWArgs g) {
+    constexpr int PXP = SW_PXP;
+    constexpr int STAGE = NP * 2 * SW_PLANES / 2 * PXP;      // slots per stage: NP parts x (16 A + 16 B planes) x PXP
+    constexpr int NPIECE = (STAGE + 63) / 64;                // DMA pieces of 64 slots
+    constexpr int NPW = (NPIECE + 3) / 4;                    // ... per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char sw_smem[];
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)sw_smem;
+    const int bid = xcd_order(gridDim.x);
+    const int tiles = g.mTiles * g.nTiles;
+    const int ks = bid / tiles, tile = bid % tiles;
+    const int mt = tile % g.mTiles, nt = tile / g.mTiles;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1, l31 = lane & 31, kh = lane >> 5;
+    const int hw = g.h * g.w, Ho = 2 * g.h, Wo = 2 * g.w;
+    const int ch0 = ks * g.chunksPerSplit;
+    const int ch1 = min(ch0 + g.chunksPerSplit, (int)(((int64_t)g.B * hw) >> 5));
+
+    // ---- staging: slot s = (wid * NPW + k) * 64 + lane of the stage image [part][plane 0 .. 31][PXP]; planes 0 .. 15: x groups
+    // 16 mt + plane; planes 16 .. 31: dy, q = (plane - 16) >> 2, group 4 nt + (plane & 3)
+    int st_kind[NPW];              // 0: x, 1: dy, -1: nothing (padding slot or beyond the image)
+    unsigned st_base[NPW];         // byte offset of (group, part, row 0 / sub-row di, column 0 / dj)
+    int st_px[NPW];
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) {
+        const int s = (wid * NPW + k) * 64 + lane;
+        const int plane_all = s / PXP, px = s % PXP;
+        const int part = plane_all / SW_PLANES, plane = plane_all % SW_PLANES;
+        st_px[k] = px;
+        if (s >= STAGE || px >= 32) {
+            st_kind[k] = -1;
+            st_base[k] = 0;
+        } else if (plane < 16) {
+            st_kind[k] = 0;
+            st_base[k] = (unsigned)(((((int64_t)(16 * mt + plane)) * g.h * NP + part) * g.w) * 16);
+        } else {
+            const int q = (plane - 16) >> 2, c8 = 4 * nt + (plane & 3);
+            st_kind[k] = 1;
+            st_base[k] = (unsigned)((((((int64_t)c8 * Ho + (q >> 1)) * NP + part) * Wo) + (q & 1)) * 16);
+        }
+    }
+    auto issue = [&](int chunk, int buf) __attribute__((always_inline)) {
+        const int64_t pix = (int64_t)chunk << 5;
+        const int b = (int)(pix / hw), p0 = (int)(pix % hw);
+        const i32x4g rx = g_rsrc(reinterpret_cast<const unsigned*>(g.xP) + (int64_t)b * g.x_bs, (int64_t)(g.Cin / 8) * hw * NP * 16);
+        const i32x4g rd = g_rsrc(reinterpret_cast<const unsigned*>(g.dyP) + (int64_t)b * g.dy_bs, (int64_t)(g.Ct / 8) * Ho * NP * Wo * 16);
+        const unsigned lb = lds0 + (unsigned)(buf * STAGE * 16);
+#pragma unroll
+        for (int k = 0; k < NPW; ++k) {
+            if ((wid * NPW + k) * 64 >= STAGE) continue;                       // (wave-uniform: a piece wholly beyond the image)
+            const int p = p0 + st_px[k], i = p >> g.lw, j = p & (g.w - 1);
+            // (16 planes of 36 slots = 9 whole pieces: a piece is all x or all dy, wave-uniformly -- the resource must be scalar)
+            const bool is_x = (((wid * NPW + k) / 9) & 1) == 0;
+            unsigned off;
+            if (st_kind[k] == 0) off = st_base[k] + (unsigned)((i * NP * g.w + j) * 16);
+            else if (st_kind[k] == 1) off = st_base[k] + (unsigned)((2 * i * NP * Wo + 2 * j) * 16);
+            else off = 0x80000000u;                                             // out of the resource's range: the slot reads as zero
+            if (is_x) g_dma16(rx, lb + (unsigned)((wid * NPW + k) * 1024), off);
+            else g_dma16(rd, lb + (unsigned)((wid * NPW + k) * 1024), off);
+        }
+    };
+
+    f32x16 acc[2][2], accb[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[u][r] = 0.f;
+    const bool bias_wave = g.db_part != nullptr && mt == 0 && wr == 0;       // (wave-uniform)
+    u32x4g ones;
+    {
+        const unsigned one2 = NP == 2 ? 0x3c003c00u : 0x3f803f80u;             // (1.0, 1.0) as fp16 / bf16 pairs
+        ones = u32x4g{one2, one2, one2, one2};
+    }
+
+    // transposed-read lane bases (bytes): lane = 16 g + 4 q + p supplies pixel slot q, channels 4 p .. 4 p + 3 of the channel half g & 1
+    const int tq = (lane >> 2) & 3, tp = lane & 3, tg = (lane >> 4) & 1;
+    const unsigned lane_off = (unsigned)((((2 * tg + (tp >> 1)) * PXP + 8 * kh + tq) * 16) + (tp & 1) * 8);
+    const unsigned a_lane = lane_off + (unsigned)((wr * 8) * PXP * 16);                        // + t * 4 planes
+    const unsigned b_lane = lane_off + (unsigned)((16 + (2 * wc) * 4) * PXP * 16);             // + u * 4 planes (q = 2 wc + u)
+    constexpr unsigned PART = SW_PLANES * PXP * 16;                                            // bytes between the parts
+
+    if (ch0 < ch1) {
+        issue(ch0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    for (int c = ch0; c < ch1; ++c) {
+        const int buf = (c - ch0) & 1;
+        if (c + 1 < ch1) issue(c + 1, buf ^ 1);
+        const unsigned base = lds0 + (unsigned)(buf * STAGE * 16);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {                                           // K = 16 pixels per step
+            u32x4g af[2][NP], bf[2][NP];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) af[t][q] = sw_frag(base + a_lane + (unsigned)(t * 4 * PXP * 16 + s * 256) + q * PART);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) bf[u][q] = sw_frag(base + b_lane + (unsigned)(u * 4 * PXP * 16 + s * 256) + q * PART);
+            if constexpr (NP == 2) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) acc[t][u] = s_mfma<NP>(af[t][1], bf[u][0], acc[t][u]);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) acc[t][u] = s_mfma<NP>(af[t][0], bf[u][1], acc[t][u]);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[t][u] = s_mfma<NP>(af[t][0], bf[u][0], acc[t][u]);
+            if (bias_wave) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    accb[u] = s_mfma<NP>(ones, bf[u][0], accb[u]);
+                    if constexpr (NP == 2) accb[u] = s_mfma<NP>(ones, bf[u][1], accb[u]);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    float undo = 1.f, dy_inv = 1.f;
+    if constexpr (NP == 2) {
+        float x_inv;
+        (void)amax_scale(amax_read(g.x_slots), false, x_inv);
+        (void)amax_scale(amax_read(g.dy_slots), true, dy_inv);
+        undo = x_inv * dy_inv;
+    }
+    float* slab = g.slab + (int64_t)ks * g.Cin * 4 * g.Ct;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int col = (32 * nt + l31) * 4 + 2 * wc + u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = 128 * mt + wr * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                slab[(int64_t)ci * 4 * g.Ct + col] = acc[t][u][r] * undo;
+            }
+        }
+    if (bias_wave && kh == 0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) g.db_part[((int64_t)ks * 4 + 2 * wc + u) * g.Ct + 32 * nt + l31] = accb[u][0] * dy_inv;
+    }
+}
+
+// w [Cin][Ct][2][2] -> wdP [(Ct/8) 4][NP][Cin][8] (see convt_slot_dgrad_kernel); scale as convt_pack_slots_kernel (shared magnitude slots)
+__global__ void convt_pack_dgrad_slots_kernel(const float* __restrict__ w, void* __restrict__ wdP, int Cin, int Ct, int np,
+                                              const unsigned* __restrict__ wamax) {
+    const int64_t n = (int64_t)Cin * 4 * Ct;
+    float winv = 1.f;
+    const float wscale = np == 2 ? amax_scale(amax_read(wamax), true, winv) : 1.f;
+    if (np == 2 && blockIdx.x == 0 && threadIdx.x == 0) {
+        float* meta = reinterpret_cast<float*>(reinterpret_cast<_Float16*>(wdP) + 2 * n);
+        meta[0] = wscale;
+        meta[1] = winv;
+    }
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int kc = (int)(i & 7);
+        const int64_t r = i >> 3;
+        const int ci = (int)(r % Cin), ks = (int)(r / Cin);        // K-slot = c8 * 4 + q
+        const int c = (ks >> 2) * 8 + kc, q = ks & 3;
+        const float v = w[((int64_t)ci * Ct + c) * 4 + q];
+        if (np == 2) {
+            _Float16* o = reinterpret_cast<_Float16*>(wdP);
+            const float vs = v * wscale;
+            const _Float16 hi = (_Float16)vs;
+            o[(((int64_t)ks * 2 + 0) * Cin + ci) * 8 + kc] = hi;
+            o[(((int64_t)ks * 2 + 1) * Cin + ci) * 8 + kc] = (_Float16)(vs - (float)hi);
+        } else {
+            reinterpret_cast<__bf16*>(wdP)[((int64_t)ks * Cin + ci) * 8 + kc] = (__bf16)v;
+        }
+    }
+}
+
 // w [Cin][Ct][2][2] fp32 (nn.ConvTranspose2d) -> wP [Cin/8][NP][4 Ct][8]: column m = 4 c + (2 di + dj) (== the weight's own memory
 // order), K-slot = 8 consecutive input channels; NP = 2: fp16 (hi | mid) parts of 2^k w with max |w| in [2^13, 2^14) (k from the
 // magnitude slots wamax; (2^k, 2^-k) stored behind the pack as two floats); NP = 1: bf16(w)
@@ -946,6 +1295,80 @@ int onet_convT2x2_pack_weights_slots(const float* w, void* wP, void* amax_ws, in
     hipLaunchKernelGGL(convt_pack_slots_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, st, w, wP, Cin, Ct, nparts,
                        (const unsigned*)amax_ws);
     return check_launch("convt_pack_slots_kernel");
+}
+
+int onet_convT2x2_pack_weights_dgrad_slots(const float* w, void* wdP, void* amax_ws, int Cin, int Ct, int nparts, void* stream) {
+    ONET_REQUIRE(w && wdP && Cin > 0 && Ct > 0 && (Ct % 8) == 0 && (nparts == 1 || nparts == 2), "convT2x2_pack_weights_dgrad_slots: bad args");
+    ONET_REQUIRE(nparts == 1 || amax_ws, "convT2x2_pack_weights_dgrad_slots: the fp16 pack needs the 8 KB magnitude workspace");
+    hipStream_t st = as_stream(stream);
+    const int64_t n = (int64_t)Cin * 4 * Ct;
+    if (nparts == 2) {
+        (void)hipMemsetAsync(amax_ws, 0, AMAX_SLOTS * AMAX_STRIDE * sizeof(unsigned), st);
+        hipLaunchKernelGGL(convt_absmax_kernel, dim3((unsigned)std::min<int64_t>((n + 1023) / 1024, 1024)), dim3(256), 0, st, w, n, (unsigned*)amax_ws);
+        int rc = check_launch("convt_absmax_kernel");
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(convt_pack_dgrad_slots_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, st, w, wdP, Cin, Ct,
+                       nparts, (const unsigned*)amax_ws);
+    return check_launch("convt_pack_dgrad_slots_kernel");
+}
+
+int onet_convT2x2_dgrad_slots(const void* dyP, int64_t dyP_bs, const void* dy_amax, const void* wdP, float* dx, int64_t dx_bs, int nparts, int B,
+                              int Cin, int Ct, int h, int w, void* stream) {
+    ONET_REQUIRE(dyP && wdP && dx && B > 0 && Cin > 0 && Ct > 0 && h > 0 && w > 0 && (nparts == 1 || nparts == 2), "convT2x2_dgrad_slots: bad args");
+    const int64_t hw = (int64_t)h * w;
+    if ((Cin % 128) || (Ct % 32) || (hw % 128) || (w & 1) || !aligned16(dyP) || !aligned16(wdP) || (dyP_bs & 3) ||
+        (int64_t)Ct * 4 * hw * 2 * nparts >= (1ll << 31) || (int64_t)Cin * 4 * Ct * 2 * nparts >= (1ll << 31))
+        return 1;
+    ONET_REQUIRE(dyP_bs >= (int64_t)Ct * 4 * hw * nparts / 2 && dx_bs >= (int64_t)Cin * hw, "convT2x2_dgrad_slots: batch stride too small");
+    SDArgs g{wdP, dyP, dyP_bs, dx, dx_bs, (const unsigned*)dy_amax, B, Cin, Ct, h, w, Cin / 128, (int)(B * hw / 128)};
+    const int64_t blocks = (int64_t)g.mTiles * g.nTiles;
+    ONET_REQUIRE(blocks > 0 && blocks < (1ll << 31), "convT2x2_dgrad_slots: grid too large");
+    if (nparts == 2) hipLaunchKernelGGL(convt_slot_dgrad_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), g);
+    else hipLaunchKernelGGL(convt_slot_dgrad_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), g);
+    return check_launch("convt_slot_dgrad_kernel");
+}
+
+int64_t onet_convT2x2_wgrad_slots_ws_bytes(int B, int Cin, int Ct, int h, int w) {
+    if ((Cin % 128) || (Ct % 32) || (((int64_t)h * w) % 128) || (w & (w - 1))) return 0;
+    int k, per;
+    wgrad_plan(B, Cin, Ct, h, w, k, per);
+    return (int64_t)k * ((int64_t)Cin * 4 * Ct + 4 * Ct) * 4;
+}
+
+int onet_convT2x2_wgrad_slots(const void* xP, int64_t xP_bs, const void* x_amax, const void* dyP, int64_t dyP_bs, const void* dy_amax, float* dw,
+                              float* dbias, void* ws, int64_t ws_bytes, int nparts, int B, int Cin, int Ct, int h, int w, void* stream) {
+    ONET_REQUIRE(xP && dyP && dw && ws && B > 0 && Cin > 0 && Ct > 0 && h > 0 && w > 0 && (nparts == 1 || nparts == 2), "convT2x2_wgrad_slots: bad args");
+    const int64_t hw = (int64_t)h * w;
+    if ((Cin % 128) || (Ct % 32) || (hw % 128) || (w & (w - 1)) || w < 2 || !aligned16(xP) || !aligned16(dyP) || !aligned16(dw) || (xP_bs & 3) ||
+        (dyP_bs & 3) || (int64_t)Cin * hw * 2 * nparts >= (1ll << 31) || (int64_t)Ct * 4 * hw * 2 * nparts >= (1ll << 31))
+        return 1;
+    ONET_REQUIRE(xP_bs >= (int64_t)Cin * hw * nparts / 2 && dyP_bs >= (int64_t)Ct * 4 * hw * nparts / 2, "convT2x2_wgrad_slots: batch stride too small");
+    int lw = 0;
+    while ((1 << lw) < w) ++lw;
+    SWArgs g{xP, xP_bs, dyP, dyP_bs, (float*)ws, nullptr, (const unsigned*)x_amax, (const unsigned*)dy_amax, B, Cin, Ct, h, w, lw, Cin / 128, Ct / 32, 1, 0};
+    wgrad_plan(B, Cin, Ct, h, w, g.splitK, g.chunksPerSplit);
+    const int64_t n = (int64_t)Cin * 4 * Ct;
+    ONET_REQUIRE(ws_bytes >= (int64_t)g.splitK * (n + 4 * Ct) * 4, "convT2x2_wgrad_slots: workspace too small (onet_convT2x2_wgrad_slots_ws_bytes)");
+    if (dbias) g.db_part = (float*)ws + (int64_t)g.splitK * n;
+    const int64_t blocks = (int64_t)g.splitK * g.mTiles * g.nTiles;
+    ONET_REQUIRE(blocks > 0 && blocks < (1ll << 31), "convT2x2_wgrad_slots: grid too large");
+    hipStream_t st = as_stream(stream);
+    const int lds = nparts * SW_PLANES * SW_PXP * 16 * 2;
+    if (nparts == 2) {
+        static PerDeviceOnce once;
+        if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convt_slot_wgrad_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(convt_slot_wgrad_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, st, g);
+    } else {
+        hipLaunchKernelGGL(convt_slot_wgrad_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, st, g);
+    }
+    int rc = check_launch("convt_slot_wgrad_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(convt_wgrad_reduce_kernel, dim3((unsigned)cdiv(n / 4, 256)), dim3(256), 0, st, (const float*)ws, dw, g.splitK, n / 4, 0);
+    rc = check_launch("convt_wgrad_reduce_kernel");
+    if (rc || !dbias) return rc;
+    hipLaunchKernelGGL(convt_dbias_reduce_kernel, dim3((unsigned)Ct), dim3(256), 0, st, (const float*)g.db_part, dbias, g.splitK * 4, Ct);
+    return check_launch("convt_dbias_reduce_kernel");
 }
 
 int onet_convT2x2_fwd_slots(const void* xP, int64_t xP_bs, const void* x_amax, const void* wP, const float* bias, void* yP, int64_t yP_bs,

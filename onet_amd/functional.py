@@ -199,6 +199,7 @@ class ConvBNReLUFn(torch.autograd.Function):
             ops.bn_relu_apply(z, save_all, out=a, amax=a_amax, group_images=gi)
         p16["a"], p16["a_slots"], p16["a_amax"] = aP, act_slots, a_amax
         ctx.x_slots = x_slots
+        ctx.up_link = p16.get("up_link")    # (first convolution of a decoder block: see UpConvTCatFn -- the up-sampled half of dx leaves pre-split)
         ctx.twin = ops.twin_src_of(x)       # a virtual twin batch (placeholder + (X, bias)): backward re-attaches the tag
         ctx.save_for_backward(x, z, save_all, xP)
         ctx.pre = True
@@ -271,6 +272,15 @@ class ConvBNReLUFn(torch.autograd.Function):
                 ctx.link_in["da"], ctx.link_in["rec4"] = dx, rec_below
                 if am_below is not None:
                     ctx.link_in["da_amax"] = am_below
+        up = getattr(ctx, "up_link", None)
+        if need_x and dx is None and up is not None and up.get("want") and dz_slots is not None and dzP.shape[3] == 2:
+            # the input of this convolution is a concat buffer whose up-sampled half came out of a ConvTranspose2d: that half of dx is
+            # read only by the ConvTranspose2d backward GEMMs, and leaves this launch in THEIR operand form (fp16 hi | mid slots scaled by
+            # a bound from dz's bound and the weights); the fp32 tensor keeps its shape, its upper channels are never written
+            C2, Ct = up["want"]
+            bound = ops.conv3x3_dgrad_bound(pw, dz_slots, C2)
+            dx, dyP = ops.conv3x3_split_dgrad_pre_slots(dzP, dpack, ctx.wshape[1], C2, bound, slots=dz_slots, always=True)
+            up["dyP"], up["dy_slots"], up["da"] = dyP, bound, dx
         if need_x and dx is None:
             dx = ops.conv3x3_split_pre(dzP, dpack, ctx.wshape[1], slots=dz_slots, always=dz_slots is not None)
         return (dx, dw, (dgamma if need_g else None), (dbeta if need_b else None)) + nones
@@ -493,6 +503,15 @@ class UpConvTCatFn(torch.autograd.Function):
             ctx.save_for_backward(x1, wp_dgrad)
             ctx.meta = (C2, Ct, h, w, pt, pl, tuple(weight.shape), bias is not None)
             ctx.params = (weight, bias)
+            # round 5: the backward GEMMs on slot operands too -- the consumer of the concat buffer (the decoder block's first convolution)
+            # is told, through the shared dict, to hand the up-sampled half of its input gradient over pre-split
+            lk = p16.get("up_link")
+            ctx.up_link = None
+            if lk is not None and done:
+                lk["want"] = (C2, Ct)
+                ctx.up_link, ctx.slot_ops = lk, (x1P, p16.get("x1_slots"), packed)
+            elif ops.is_placeholder(x1):
+                raise RuntimeError("onet_amd: ConvTranspose2d input kept only pre-split, but the slot-operand backward is not set up")
             return ops.fp32_placeholder((B, C2 + Ct, Ho, Wo), x1.device)
         cat = None if cat_holder is None else cat_holder[0]
         in_place = (cat is not None and tuple(cat.shape) == (B, C2 + Ct, Ho, Wo) and C2 > 0
@@ -517,6 +536,24 @@ class UpConvTCatFn(torch.autograd.Function):
         need_x1, need_x2, need_w, need_b = ctx.needs_input_grad[:4]
         dx2 = dcat[:, :C2] if need_x2 else None
         dx1 = dw = db = None
+        lk = getattr(ctx, "up_link", None)
+        if lk is not None:
+            dyP, dy_slots, rda = lk.pop("dyP", None), lk.pop("dy_slots", None), lk.pop("da", None)
+            lk.pop("want", None)
+            if dyP is not None and rda is not None and rda.data_ptr() == dcat.data_ptr() and rda.shape == dcat.shape:
+                # the up-sampled half of dcat exists only pre-split (written by the 3x3 input gradient that produced dcat)
+                x1P, x1_slots, packed = ctx.slot_ops
+                want_db = need_b and has_bias
+                if need_x1:
+                    dx1 = ops.convT2x2_dgrad_slots(dyP, packed.dgrad_slots(2), wshape[0], dy_slots=dy_slots)
+                got = ops.convT2x2_wgrad_slots(x1P, dyP, wshape, x_slots=x1_slots, dy_slots=dy_slots, want_dbias=want_db,
+                                               out=ops.grad_slot_if_free(ctx.params[0]),
+                                               db_out=ops.grad_slot_if_free(ctx.params[1]) if want_db else None) if (need_w or want_db) else (None, None)
+                if (need_x1 and dx1 is None) or got is None:
+                    raise RuntimeError("onet_amd: the slot-operand ConvTranspose2d backward refused a shape ops.convt_bwd_slots_ok accepted")
+                return dx1, dx2, (got[0] if need_w else None), (got[1] if want_db else None), None, None, None
+            if ops.is_placeholder(x1):
+                raise RuntimeError("onet_amd: ConvTranspose2d backward: the input exists only pre-split and the pre-split gradient did not arrive")
         if (need_x1 or need_w or need_b) and ops.convT2x2_bwd_fusable(Ct):
             # the GEMM kernels gather dy from the concat gradient themselves: no space-to-depth tensor
             dup = dcat[:, C2:]

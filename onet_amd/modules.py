@@ -135,7 +135,7 @@ class DoubleConv(nn.Module):
                 return ops.tag_amax(a, p16["a_amax"])
         return ops.tag_amax(a, aux.get("a_amax"))
 
-    def forward(self, x, out=None, groups=1, pool_link=None, p16_out=None):
+    def forward(self, x, out=None, groups=1, pool_link=None, p16_out=None, up_link=None):
         """`out`: optional plane-contiguous [B, Cout, H, W] destination view (the skip half of a concat buffer);
         `groups`: the batch holds that many independent BatchNorm batches (twin pass); `pool_link`: dict the second
         unit publishes its (z, save) in for the SkipPoolFn that consumes the block's output; `p16_out` (pre-split storage): {"out": pre-split destination of the
@@ -151,7 +151,7 @@ class DoubleConv(nn.Module):
             if xP is not None or pre2 or p16_out is not None:
                 if xP is None and ops.is_placeholder(x) and ops.twin_src_of(x) is None:
                     raise RuntimeError("onet_amd: a tensor kept only pre-split reached a DoubleConv without its pre-split form")
-                p1 = {"x": xP, "x_slots": ops.p16_slots(x), "want": pre2}
+                p1 = {"x": xP, "x_slots": ops.p16_slots(x), "want": pre2, "up_link": up_link}
                 a1 = self._unit(x, s[0], s[1], None, groups, link_out=link, p16=p1)
                 p2 = {"x": p1.get("a"), "x_slots": p1.get("a_slots"), "want": p16_out is not None,
                       "out": None if p16_out is None else p16_out.get("out"),
@@ -246,9 +246,15 @@ class Up(nn.Module):
             s_skip, x1_amax = ops.p16_slots(x2), (x1_slots if x1P is not None else ops.amax_of(x1))
             s_up = ops.convT2x2_out_bound(self.up.weight, self.up.bias, x1_amax) if (x1_amax is not None and catP.shape[3] == 2) else None
             p16 = {"catP": catP, "up_slots": s_up, "x1P": x1P, "x1_slots": x1_slots}
+            # the backward GEMMs on slot operands (round 5): this Up's ConvTranspose2d and the first convolution of its DoubleConv share a
+            # dict through which the up-sampled half of the concat gradient travels pre-split
+            B, Cin, h, w = x1.shape
+            up_link = {} if (x1P is not None and self.training and self.conv.pre_capable() and
+                             ops.convt_bwd_slots_ok(B, Cin, self.up.out_channels, x2.shape[1], h, w)) else None
+            p16["up_link"] = up_link
             x = Fn.UpConvTCatFn.apply(x1, x2, self.up.weight, self.up.bias, self.up.packed(), None, p16)
             ops.tag_p16(x, catP, (s_skip, s_up, x2.shape[1]) if (s_skip is not None or s_up is not None) else None)
-            return self.conv(x, groups=groups, p16_out=p16_out)
+            return self.conv(x, groups=groups, p16_out=p16_out, up_link=up_link)
         if isinstance(self.up, ConvT2x2):
             x = Fn.UpConvTCatFn.apply(x1, x2, self.up.weight, self.up.bias, self.up.packed(), None if cat is None else (cat,))
         else:
@@ -343,7 +349,10 @@ class UNet(nn.Module):
                 hk, wk = h >> (k + 1), w >> (k + 1)         # the map that level k's ConvTranspose2d reads
                 if catsP[k] is not None and isinstance(up.up, ConvT2x2) and src.pre_capable() and \
                         ops.convt_slots_ok(B, up.up.in_channels, up.up.out_channels, hk, wk):
-                    upP[k] = {"keep_fp32": True}
+                    # (the fp32 tensor stays only where the weight gradient still reads it: Up.forward decides with the same function)
+                    bwd = up.training and up.conv.pre_capable() and \
+                        ops.convt_bwd_slots_ok(B, up.up.in_channels, up.up.out_channels, up.up.out_channels, hk, wk)
+                    upP[k] = {"keep_fp32": not bwd}
 
         def skip(k, C):
             return None if cats[k] is None else cats[k][:, :C]

@@ -429,6 +429,78 @@ def packT2x2_slots(w, parts=2):
     return wP
 
 
+def packT2x2_dgrad_slots(w, parts=2):
+    """-> the K-slot pack of the slot-operand input gradient: [(Ct/8) 4, parts, Cin, 8] (+ the scale pair behind the fp16 pack)."""
+    require_gpu(w)
+    w = w.detach().contiguous()
+    Cin, Ct = w.shape[0], w.shape[1]
+    wP = torch.empty(Cin * 4 * Ct * parts + 4, dtype=torch.float16 if parts == 2 else BF, device=w.device)
+    ws = torch.empty(2048, dtype=torch.int32, device=w.device) if parts == 2 else None
+    _lib.call("onet_convT2x2_pack_weights_dgrad_slots", _p(w), _p(wP), _p(ws), Cin, Ct, parts, _stream())
+    return wP
+
+
+def convT2x2_dgrad_slots(dyP, wdP, Cin, dy_slots=None):
+    """dx1 [B, Cin, h, w] fp32 = input gradient of ConvTranspose2d(k=2, s=2) from the pre-split up-sampled gradient dyP [B, Ct/8, 2h, parts,
+    2w, 8] and the K-slot pack wdP; None where the kernel does not take the shape."""
+    B, C8, Ho, parts, Wo, _ = dyP.shape
+    Ct, h, w = C8 * 8, Ho // 2, Wo // 2
+    dx = torch.empty((B, Cin, h, w), dtype=F32, device=dyP.device)
+    e0 = _prof_begin("convt_gemm_kernel")
+    rc = _lib.load().onet_convT2x2_dgrad_slots(_p(dyP), _pbs(dyP), _p(dy_slots), _p(wdP), _p(dx), Cin * h * w, parts, B, Cin, Ct, h, w, _stream())
+    flops, nb = 2.0 * B * h * w * Cin * 4 * Ct, B * h * w * (4.0 * Cin + 2.0 * parts * 4 * Ct)
+    _prof_end("convt_gemm_kernel", flops if rc == 0 else 0.0, e0, nb if rc == 0 else 0.0)
+    if rc < 0:
+        raise _lib.OnetHipError(f"onet_convT2x2_dgrad_slots failed ({rc}): {_lib.last_error()}")
+    return dx if rc == 0 else None
+
+
+def convT2x2_wgrad_slots(xP, dyP, dw_shape, x_slots=None, dy_slots=None, want_dbias=False, out=None, db_out=None):
+    """(dw [Cin, Ct, 2, 2], dbias | None) from the pre-split input xP and the pre-split up-sampled gradient dyP; None where the kernel does
+    not take the shape."""
+    B, C8, h, parts, w, _ = xP.shape
+    Cin, Ct = C8 * 8, dyP.shape[1] * 8
+    assert tuple(dw_shape) == (Cin, Ct, 2, 2) and dyP.shape[3] == parts and dyP.shape[2] == 2 * h and xP.dtype == dyP.dtype
+    need = int(_lib.load().onet_convT2x2_wgrad_slots_ws_bytes(B, Cin, Ct, h, w))
+    if need <= 0:
+        return None
+    ws = workspace(need, xP.device)
+    dw = out if out is not None else torch.empty(dw_shape, dtype=F32, device=xP.device)
+    db = (db_out if db_out is not None else torch.empty(Ct, dtype=F32, device=xP.device)) if want_dbias else None
+    e0 = _prof_begin("convt_wgrad_gemm_kernel")
+    rc = _lib.load().onet_convT2x2_wgrad_slots(_p(xP), _pbs(xP), _p(x_slots), _p(dyP), _pbs(dyP), _p(dy_slots), _p(dw), _p(db), _p(ws),
+                                               ws.numel() * 4, parts, B, Cin, Ct, h, w, _stream())
+    flops, nb = 2.0 * B * h * w * Cin * 4 * Ct, 2.0 * parts * B * h * w * (Cin + 4 * Ct)
+    _prof_end("convt_wgrad_gemm_kernel", flops if rc == 0 else 0.0, e0, nb if rc == 0 else 0.0)
+    if rc < 0:
+        raise _lib.OnetHipError(f"onet_convT2x2_wgrad_slots failed ({rc}): {_lib.last_error()}")
+    return (dw, db) if rc == 0 else None
+
+
+def conv3x3_dgrad_bound(weight, dz_slots, ci0):
+    """Magnitude slots bounding the channels >= ci0 of a 3x3 convolution's input gradient: max |dz| (dz_slots) x the largest L1 norm of
+    the weights feeding one input channel."""
+    w = weight.detach()
+    w = w if w.is_contiguous() else w.contiguous()
+    slots = new_amax(w.device)
+    _lib.call("onet_conv3x3_dgrad_bound", _p(w), w.shape[0], w.shape[1], int(ci0), _p(dz_slots), _p(slots), _stream())
+    return slots
+
+
+def conv3x3_split_dgrad_pre_slots(dzP, wq, Cout, ch0, daP_slots, slots=None, always=False):
+    """Input gradient of a decoder block's first convolution from pre-split dz: -> (da [B, Cout, H, W] fp32 whose channels >= ch0 are NOT
+    written, daP [B, (Cout - ch0)/8, H, 2, W, 8] = those channels pre-split, scaled by daP_slots' `always` rule)."""
+    B, C8, H, two, W, _ = dzP.shape
+    assert two == 2 and wq.dtype == dzP.dtype == torch.float16
+    da = torch.empty((B, Cout, H, W), dtype=F32, device=dzP.device)
+    daP = torch.empty((B, (Cout - ch0) // 8, H, 2, W, 8), dtype=torch.float16, device=dzP.device)
+    e0 = _prof_begin("conv3x3_split_pre_kernel")
+    _lib.call("onet_conv3x3_split_dgrad_pre_slots", _p(dzP), _pbs(dzP), _p(slots), int(always), _p(wq), _p(da), Cout * H * W, _p(daP), _pbs(daP),
+              int(ch0), _p(daP_slots), B, C8 * 8, Cout, H, W, _stream())
+    _prof_end("conv3x3_split_pre_kernel", 2.0 * B * H * W * C8 * 8 * Cout * 9, e0, 4.0 * B * H * W * (C8 * 8 + Cout) + 4.0 * 9 * C8 * 8 * Cout)
+    return da, daP
+
+
 CONVT_SLOTS = _flag("CONVT_SLOTS", True)     # 0: the ConvTranspose2d forward reads the fp32 activation (round 4's kernels)
 
 
@@ -437,6 +509,16 @@ def convt_slots_ok(B, Cin, Ct, h, w):
     its output pre-split for it (UNet._forward)."""
     return bool(CONVT_SLOTS and presplit() and (p16_parts() == 2 or CONVT_BF16) and Cin % 32 == 0 and Cin >= 128 and Ct % 32 == 0 and (h * w) % 128 == 0 and w % 2 == 0
                 and Cin * h * w * 2 * p16_parts() < 2 ** 31)
+
+
+CONVT_BWD_SLOTS = _flag("CONVT_BWD_SLOTS", True)     # 0: the ConvTranspose2d backward GEMMs read fp32 operands (round 4's kernels)
+
+
+def convt_bwd_slots_ok(B, Cin, Ct, C2, h, w):
+    """Do the slot-operand ConvTranspose2d BACKWARD GEMMs take this layer -- and the input gradient of the decoder block's first
+    convolution (C2 skip + Ct up-sampled channels on a 2h x 2w map) the slot-writing form that feeds them?  fp16 (hi | mid) parts only."""
+    return bool(CONVT_BWD_SLOTS and convt_slots_ok(B, Cin, Ct, h, w) and p16_parts() == 2 and Cin % 128 == 0 and (w & (w - 1)) == 0
+                and C2 % 64 == 0 and (C2 + Ct) % 64 == 0 and (2 * h) % 16 == 0 and (2 * w) % 32 == 0 and Ct * 4 * h * w * 4 < 2 ** 31)
 
 
 class _LazyPack:
@@ -478,6 +560,11 @@ class PackedT:
         if parts not in self._s:
             self._s[parts] = packT2x2_slots(self.w, parts)
         return self._s[parts]
+
+    def dgrad_slots(self, parts):
+        if ("d", parts) not in self._s:
+            self._s[("d", parts)] = packT2x2_dgrad_slots(self.w, parts)
+        return self._s[("d", parts)]
 
 
 def convT2x2_fwd_slots(xP, wP, bias, outP, Ct, x_slots=None, slots=None):

@@ -202,7 +202,8 @@ def test_benchmark_dispatch_b32_256_every_gradient_element(dev, monkeypatch):
     used = {}
     for name in ("conv3x3_fwd_bn_partials", "conv3x3_dgrad_bnreduce", "conv3x3_split", "conv3x3_split_wgrad", "conv3x3_winograd4",
                  "conv3x3_winograd4_wgrad", "convT2x2_wgrad", "convT2x2_dgrad", "conv3x3_pre_bn_partials",
-                 "conv3x3_split_pre", "conv3x3_split_wgrad_pre", "bn_relu_bwd_split", "convT2x2_fwd_p", "convT2x2_fwd_slots", "conv3x3_split_dgrad_pre_bnreduce"):
+                 "conv3x3_split_pre", "conv3x3_split_wgrad_pre", "bn_relu_bwd_split", "convT2x2_fwd_p", "convT2x2_fwd_slots", "conv3x3_split_dgrad_pre_bnreduce",
+                 "conv3x3_split_dgrad_pre_slots", "convT2x2_dgrad_slots", "convT2x2_wgrad_slots"):
         real = getattr(ops, name)
 
         def spy(*a, _real=real, _name=name, **k):
@@ -241,9 +242,15 @@ def test_benchmark_dispatch_b32_256_every_gradient_element(dev, monkeypatch):
         # conv3x3_split_pre)
         fused = used.get("conv3x3_split_dgrad_pre_bnreduce", 0)
         assert fused == (8 if ops.FUSE_DGRAD_REDUCE else 0), used
-        assert used.get("conv3x3_split_pre", 0) + fused == n + n and used.get("bn_relu_bwd_split", 0) == n, used
-        # (round 5: the four ConvTranspose2d forwards read their input pre-split too -- slot-operand GEMMs)
+        # (... and the first convolution of each decoder block hands the up-sampled half of its input gradient to the ConvTranspose2d
+        # backward GEMMs pre-split: 4 launches of conv3x3_split_dgrad_pre_slots)
+        slotted = used.get("conv3x3_split_dgrad_pre_slots", 0)
+        assert slotted == (4 if (ops.CONVT_SLOTS and ops.CONVT_BWD_SLOTS) else 0), used
+        assert used.get("conv3x3_split_pre", 0) + fused + slotted == n + n and used.get("bn_relu_bwd_split", 0) == n, used
+        # (round 5: the four ConvTranspose2d layers run all three GEMMs on slot operands)
         assert used.get("convT2x2_fwd_slots" if ops.CONVT_SLOTS else "convT2x2_fwd_p", 0) == 4, used
+        assert used.get("convT2x2_dgrad_slots", 0) == used.get("convT2x2_wgrad_slots", 0) == slotted and \
+            used.get("convT2x2_dgrad", 0) == used.get("convT2x2_wgrad", 0) == 4 - slotted, used
         assert used.get("conv3x3_split_wgrad", 0) == 17 - n and used.get("conv3x3_winograd4_wgrad", 0) == 0, used
         assert used.get("conv3x3_winograd4", 0) == (0 if ops.PRESPLIT_W16 else 4), used
     else:
