@@ -911,7 +911,27 @@ struct SWArgs {
     int mTiles, nTiles, splitK, chunksPerSplit;
 };
 
-constexpr int SW_PXP = 36, SW_PLANES = 32;                  // planes per part
+// Tile configurations.  BIG = 0: 128 x 128 block tile, 4 waves, 32-pixel chunks, two stages (2 blocks per CU).  BIG = 1 (Cin % 256 == 0,
+// Ct % 64 == 0): 256 input channels x (64 output channels x 4 sub-pixels), EIGHT waves of 128 x 64, one block per CU: twice the MFMAs
+// per staged byte and per barrier (MFMA busy 0.35 -> 0.40 on the 1024-channel level; a per-chunk 64-bit division in the staging code
+// had cost 6 scalar instructions per MFMA).
+#ifndef SLOT_WGRAD_BIG
+#define SLOT_WGRAD_BIG 1
+#endif
+#ifndef SLOT_WGRAD_BIG_CP
+#define SLOT_WGRAD_BIG_CP 32     // (measured, B = 64, four levels: 32-pixel chunks / 2 stages 1.28 ms, 16-pixel chunks / ring of 3 1.35; the 128 x 128 tile 1.47)
+#endif
+template <int BIG> struct SwCfg {
+    static constexpr int NWAVE = BIG ? 8 : 4;
+    static constexpr int TM = BIG ? 4 : 2;                    // 32-row accumulator tiles per wave along M (waves: 2 along M)
+    static constexpr int GB = BIG ? 8 : 4;                    // output-channel groups per block (GB * 8 channels)
+    static constexpr int APL = 2 * TM * 4;                    // A planes per part (input-channel groups)
+    static constexpr int BPL = 4 * GB;                        // B planes per part: [sub-pixel q][group]
+    static constexpr int CP = BIG ? SLOT_WGRAD_BIG_CP : 32;   // pixels per chunk
+    static constexpr int PXP = CP + 4;                        // plane pitch in slots: 36 / 20 -> 144 / 80 dwords = 16 banks mod 64
+    static constexpr int NST = BIG ? (SLOT_WGRAD_BIG_CP == 16 ? 3 : 2) : 2;
+    static constexpr int MT = 64 * TM;                        // block tile rows (input channels)
+};
 
 __device__ __forceinline__ u32x4g sw_frag(unsigned addr) {   // 8 consecutive pixels (K) of this lane's channel: two transposed reads
     typedef short s16x4g __attribute__((ext_vector_type(4)));
@@ -921,12 +941,16 @@ __device__ __forceinline__ u32x4g sw_frag(unsigned addr) {   // 8 consecutive pi
     return u32x4g{(unsigned)a, (unsigned)(a >> 32), (unsigned)b, (unsigned)(b >> 32)};
 }
 
-template <int NP>
-__global__ __launch_bounds__(256, 2) void convt_slot_wgrad_kernel(SWArgs g) {
-    constexpr int PXP = SW_PXP;
-    constexpr int STAGE = NP * 2 * SW_PLANES / 2 * PXP;      // slots per stage: NP parts x (16 A + 16 B planes) x PXP
-    constexpr int NPIECE = (STAGE + 63) / 64;                // DMA pieces of 64 slots
-    constexpr int NPW = (NPIECE + 3) / 4;                    // ... per wave
+template <int NP, int BIG>
+__global__ __launch_bounds__(SwCfg<BIG>::NWAVE * 64, BIG ? 1 : 2) void convt_slot_wgrad_kernel(SWArgs g) {
+    using C = SwCfg<BIG>;
+    constexpr int PXP = C::PXP, TM = C::TM, GB = C::GB, APL = C::APL, BPL = C::BPL, CP = C::CP, NST = C::NST, NWAVE = C::NWAVE;
+    constexpr int A_SLOTS = APL * PXP, B_SLOTS = BPL * PXP;                 // per part; both whole numbers of 64-slot DMA pieces
+    static_assert(A_SLOTS % 64 == 0 && B_SLOTS % 64 == 0 && A_SLOTS == B_SLOTS, "a DMA piece must be all x or all dy");
+    constexpr int STAGE = NP * (A_SLOTS + B_SLOTS);
+    constexpr int NPIECE = STAGE / 64;
+    constexpr int NPW = (NPIECE + NWAVE - 1) / NWAVE;                       // pieces per wave and chunk
+    constexpr int LOG_CP = CP == 16 ? 4 : 5;
     extern __shared__ __attribute__((aligned(16))) unsigned char sw_smem[];
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)sw_smem;
     const int bid = xcd_order(gridDim.x);
@@ -934,58 +958,79 @@ __global__ __launch_bounds__(256, 2) void convt_slot_wgrad_kernel(SWArgs g) {
     const int ks = bid / tiles, tile = bid % tiles;
     const int mt = tile % g.mTiles, nt = tile / g.mTiles;
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wid >> 1, wc = wid & 1, l31 = lane & 31, kh = lane >> 5;
+    // waves: 2 along M (wr); along N the row parity di (and, BIG, the channel half ch)
+    const int wr = BIG ? wid >> 2 : wid >> 1, di = wid & 1, chf = BIG ? (wid >> 1) & 1 : 0;
+    const int l31 = lane & 31, kh = lane >> 5;
     const int hw = g.h * g.w, Ho = 2 * g.h, Wo = 2 * g.w;
     const int ch0 = ks * g.chunksPerSplit;
-    const int ch1 = min(ch0 + g.chunksPerSplit, (int)(((int64_t)g.B * hw) >> 5));
+    const int ch1 = min(ch0 + g.chunksPerSplit, (int)(((int64_t)g.B * hw) >> LOG_CP));
 
-    // ---- staging: slot s = (wid * NPW + k) * 64 + lane of the stage image [part][plane 0 .. 31][PXP]; planes 0 .. 15: x groups
-    // 16 mt + plane; planes 16 .. 31: dy, q = (plane - 16) >> 2, group 4 nt + (plane & 3)
+    // ---- staging: slot s = (wid * NPW + k) * 64 + lane of the stage image [part][A planes | B planes][PXP]; A plane = x group
+    // (MT / 8) mt + plane; B plane = (q, group): q = plane / GB, dy group GB nt + plane % GB
     int st_kind[NPW];              // 0: x, 1: dy, -1: nothing (padding slot or beyond the image)
-    unsigned st_base[NPW];         // byte offset of (group, part, row 0 / sub-row di, column 0 / dj)
+    unsigned st_base[NPW];
     int st_px[NPW];
 #pragma unroll
     for (int k = 0; k < NPW; ++k) {
         const int s = (wid * NPW + k) * 64 + lane;
-        const int plane_all = s / PXP, px = s % PXP;
-        const int part = plane_all / SW_PLANES, plane = plane_all % SW_PLANES;
+        const int part = s / (A_SLOTS + B_SLOTS), r = s % (A_SLOTS + B_SLOTS);
+        const int px = r % PXP;
         st_px[k] = px;
-        if (s >= STAGE || px >= 32) {
+        if (s >= STAGE || px >= CP) {
             st_kind[k] = -1;
             st_base[k] = 0;
-        } else if (plane < 16) {
+        } else if (r < A_SLOTS) {
+            const int plane = r / PXP;
             st_kind[k] = 0;
-            st_base[k] = (unsigned)(((((int64_t)(16 * mt + plane)) * g.h * NP + part) * g.w) * 16);
+            st_base[k] = (unsigned)(((((int64_t)((C::MT / 8) * mt + plane)) * g.h * NP + part) * g.w) * 16);
         } else {
-            const int q = (plane - 16) >> 2, c8 = 4 * nt + (plane & 3);
+            const int plane = (r - A_SLOTS) / PXP, q = plane / GB, c8 = GB * nt + plane % GB;
             st_kind[k] = 1;
             st_base[k] = (unsigned)((((((int64_t)c8 * Ho + (q >> 1)) * NP + part) * Wo) + (q & 1)) * 16);
         }
     }
+    // the chunks of a block are consecutive: image and first pixel of the next chunk to stage are carried along (a 64-bit division per
+    // chunk was 6 scalar instructions per MFMA)
+    int is_b, is_p0;
+    {
+        const int64_t pix = (int64_t)ch0 << LOG_CP;
+        is_b = (int)(pix / hw);
+        is_p0 = (int)(pix - (int64_t)is_b * hw);
+    }
+    i32x4g rx = g_rsrc(reinterpret_cast<const unsigned*>(g.xP) + (int64_t)is_b * g.x_bs, (int64_t)(g.Cin / 8) * hw * NP * 16);
+    i32x4g rd = g_rsrc(reinterpret_cast<const unsigned*>(g.dyP) + (int64_t)is_b * g.dy_bs, (int64_t)(g.Ct / 8) * Ho * NP * Wo * 16);
     auto issue = [&](int chunk, int buf) __attribute__((always_inline)) {
-        const int64_t pix = (int64_t)chunk << 5;
-        const int b = (int)(pix / hw), p0 = (int)(pix % hw);
-        const i32x4g rx = g_rsrc(reinterpret_cast<const unsigned*>(g.xP) + (int64_t)b * g.x_bs, (int64_t)(g.Cin / 8) * hw * NP * 16);
-        const i32x4g rd = g_rsrc(reinterpret_cast<const unsigned*>(g.dyP) + (int64_t)b * g.dy_bs, (int64_t)(g.Ct / 8) * Ho * NP * Wo * 16);
+        (void)chunk;                                       // (called for ch0, ch0 + 1, ... in order)
+        const int p0 = is_p0;
         const unsigned lb = lds0 + (unsigned)(buf * STAGE * 16);
 #pragma unroll
         for (int k = 0; k < NPW; ++k) {
-            if ((wid * NPW + k) * 64 >= STAGE) continue;                       // (wave-uniform: a piece wholly beyond the image)
+            const int pc = wid * NPW + k;
+            if (pc >= NPIECE) continue;                                        // (wave-uniform)
+            // (a part's A and B regions are whole pieces: a piece is all x or all dy, wave-uniformly -- the resource must be scalar)
+            const bool is_x = ((pc / (A_SLOTS / 64)) & 1) == 0;
             const int p = p0 + st_px[k], i = p >> g.lw, j = p & (g.w - 1);
-            // (16 planes of 36 slots = 9 whole pieces: a piece is all x or all dy, wave-uniformly -- the resource must be scalar)
-            const bool is_x = (((wid * NPW + k) / 9) & 1) == 0;
             unsigned off;
             if (st_kind[k] == 0) off = st_base[k] + (unsigned)((i * NP * g.w + j) * 16);
             else if (st_kind[k] == 1) off = st_base[k] + (unsigned)((2 * i * NP * Wo + 2 * j) * 16);
             else off = 0x80000000u;                                             // out of the resource's range: the slot reads as zero
-            if (is_x) g_dma16(rx, lb + (unsigned)((wid * NPW + k) * 1024), off);
-            else g_dma16(rd, lb + (unsigned)((wid * NPW + k) * 1024), off);
+            if (is_x) g_dma16(rx, lb + (unsigned)(pc * 1024), off);
+            else g_dma16(rd, lb + (unsigned)(pc * 1024), off);
+        }
+        is_p0 += CP;
+        if (is_p0 >= hw) {                                 // (hw % CP == 0: a chunk never straddles two images)
+            is_p0 = 0;
+            ++is_b;
+            rx = g_rsrc(reinterpret_cast<const unsigned*>(g.xP) + (int64_t)is_b * g.x_bs, (int64_t)(g.Cin / 8) * hw * NP * 16);
+            rd = g_rsrc(reinterpret_cast<const unsigned*>(g.dyP) + (int64_t)is_b * g.dy_bs, (int64_t)(g.Ct / 8) * Ho * NP * Wo * 16);
         }
     };
+    // DMA pieces this wave issues per chunk (the last waves may own one fewer)
+    const int my_pieces = min(NPW, max(0, NPIECE - wid * NPW));
 
-    f32x16 acc[2][2], accb[2];
+    f32x16 acc[TM][2], accb[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TM; ++t)
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -1004,42 +1049,55 @@ __global__ __launch_bounds__(256, 2) void convt_slot_wgrad_kernel(SWArgs g) {
     // transposed-read lane bases (bytes): lane = 16 g + 4 q + p supplies pixel slot q, channels 4 p .. 4 p + 3 of the channel half g & 1
     const int tq = (lane >> 2) & 3, tp = lane & 3, tg = (lane >> 4) & 1;
     const unsigned lane_off = (unsigned)((((2 * tg + (tp >> 1)) * PXP + 8 * kh + tq) * 16) + (tp & 1) * 8);
-    const unsigned a_lane = lane_off + (unsigned)((wr * 8) * PXP * 16);                        // + t * 4 planes
-    const unsigned b_lane = lane_off + (unsigned)((16 + (2 * wc) * 4) * PXP * 16);             // + u * 4 planes (q = 2 wc + u)
-    constexpr unsigned PART = SW_PLANES * PXP * 16;                                            // bytes between the parts
+    const unsigned a_lane = lane_off + (unsigned)((wr * TM * 4) * PXP * 16);                                   // + t * 4 planes
+    const unsigned b_lane = lane_off + (unsigned)((A_SLOTS + ((2 * di) * GB + chf * 4) * PXP) * 16);          // + u * GB planes (q = 2 di + u)
+    constexpr unsigned PART = (A_SLOTS + B_SLOTS) * 16;                                                        // bytes between the parts
 
-    if (ch0 < ch1) {
-        issue(ch0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ring: chunks c + 1 .. c + NST - 1 in flight while chunk c is consumed
+    const int n_my = ch1 - ch0;
+#pragma unroll
+    for (int c = 0; c < NST - 1; ++c)
+        if (c < n_my) issue(ch0 + c, c);
+    auto wait_behind = [&](int behind) __attribute__((always_inline)) {       // all but `behind` chunks of this wave's pieces have landed
+        // (vmcnt counts this wave's own pieces; my_pieces is NPW or NPW - 1: wait for the stricter of the two -- exact for NPW waves)
+        if (behind >= 1 && NST > 2) {
+            if (my_pieces == NPW) slot_wait<NPW>();
+            else slot_wait<(NPW > 1 ? NPW - 1 : 0)>();
+        } else {
+            slot_wait<0>();
+        }
+    };
+    if (n_my > 0) {
+        wait_behind(min(NST - 2, n_my - 1));
         __syncthreads();
     }
     for (int c = ch0; c < ch1; ++c) {
-        const int buf = (c - ch0) & 1;
-        if (c + 1 < ch1) issue(c + 1, buf ^ 1);
+        const int buf = (c - ch0) % NST;
+        if (c + NST - 1 < ch1) issue(c + NST - 1, (c - ch0 + NST - 1) % NST);
         const unsigned base = lds0 + (unsigned)(buf * STAGE * 16);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {                                           // K = 16 pixels per step
-            u32x4g af[2][NP], bf[2][NP];
+        for (int s = 0; s < CP / 16; ++s) {                                     // K = 16 pixels per step
+            u32x4g af[TM][NP], bf[2][NP];
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < TM; ++t)
 #pragma unroll
                 for (int q = 0; q < NP; ++q) af[t][q] = sw_frag(base + a_lane + (unsigned)(t * 4 * PXP * 16 + s * 256) + q * PART);
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int q = 0; q < NP; ++q) bf[u][q] = sw_frag(base + b_lane + (unsigned)(u * 4 * PXP * 16 + s * 256) + q * PART);
+                for (int q = 0; q < NP; ++q) bf[u][q] = sw_frag(base + b_lane + (unsigned)(u * GB * PXP * 16 + s * 256) + q * PART);
             if constexpr (NP == 2) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < TM; ++t)
 #pragma unroll
                     for (int u = 0; u < 2; ++u) acc[t][u] = s_mfma<NP>(af[t][1], bf[u][0], acc[t][u]);
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < TM; ++t)
 #pragma unroll
                     for (int u = 0; u < 2; ++u) acc[t][u] = s_mfma<NP>(af[t][0], bf[u][1], acc[t][u]);
             }
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < TM; ++t)
 #pragma unroll
                 for (int u = 0; u < 2; ++u) acc[t][u] = s_mfma<NP>(af[t][0], bf[u][0], acc[t][u]);
             if (bias_wave) {
@@ -1050,7 +1108,8 @@ __global__ __launch_bounds__(256, 2) void convt_slot_wgrad_kernel(SWArgs g) {
                 }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // chunk c + 1 has landed: everything but the chunks behind it (min(NST - 2, ch1 - 2 - c))
+        wait_behind(min(NST - 2, ch1 - 2 - c));
         __syncthreads();
     }
 
@@ -1063,19 +1122,19 @@ __global__ __launch_bounds__(256, 2) void convt_slot_wgrad_kernel(SWArgs g) {
     }
     float* slab = g.slab + (int64_t)ks * g.Cin * 4 * g.Ct;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TM; ++t)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int col = (32 * nt + l31) * 4 + 2 * wc + u;
+            const int col = (GB * 8 * nt + chf * 32 + l31) * 4 + 2 * di + u;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ci = 128 * mt + wr * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int ci = C::MT * mt + wr * (TM * 32) + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 slab[(int64_t)ci * 4 * g.Ct + col] = acc[t][u][r] * undo;
             }
         }
     if (bias_wave && kh == 0) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) g.db_part[((int64_t)ks * 4 + 2 * wc + u) * g.Ct + 32 * nt + l31] = accb[u][0] * dy_inv;
+        for (int u = 0; u < 2; ++u) g.db_part[((int64_t)ks * 4 + 2 * di + u) * g.Ct + GB * 8 * nt + chf * 32 + l31] = accb[u][0] * dy_inv;
     }
 }
 
@@ -1278,6 +1337,32 @@ int convt_gemm_wgrad(const float* x, int64_t x_bs, const float* dy, int64_t dy_b
 
 }  // namespace onet
 
+// split-K plan of the slot-operand weight gradient: -> big (256 x 256 tiles, 16-pixel chunks) or not (128 x 128, 32-pixel chunks)
+static bool wgrad_slots_plan(int B, int Cin, int Ct, int h, int w, int& splitK, int& per) {
+    const bool big = (Cin % 256) == 0 && (Ct % 64) == 0;
+    const int64_t chunks = (int64_t)B * h * w / (big ? SLOT_WGRAD_BIG_CP : 32);
+    const int64_t tiles = big ? (int64_t)(Cin / 256) * (Ct / 64) : (int64_t)(Cin / 128) * (Ct / 32);
+    int64_t k = std::max<int64_t>(1, ((big ? 256 : 512) + tiles - 1) / tiles);   // one (two) blocks per CU
+    k = std::min<int64_t>(k, std::max<int64_t>(1, chunks / (big ? 512 / SLOT_WGRAD_BIG_CP : 16)));     // at least 512 pixels per block
+    k = std::min<int64_t>(k, std::max<int64_t>(1, (256ll << 20) / ((int64_t)Cin * 4 * Ct * 4)));
+    per = (int)((chunks + k - 1) / k);
+    splitK = (int)((chunks + per - 1) / per);
+    return big;
+}
+
+template <int NP, int BIG>
+static int launch_wgrad_slots(SWArgs g, hipStream_t st) {
+    using C = SwCfg<BIG>;
+    const int lds = NP * (C::APL + C::BPL) * C::PXP * 16 * C::NST;
+    auto kern = convt_slot_wgrad_kernel<NP, BIG>;
+    static PerDeviceOnce once;
+    if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int64_t blocks = (int64_t)g.splitK * g.mTiles * g.nTiles;
+    ONET_REQUIRE(blocks > 0 && blocks < (1ll << 31), "convT2x2_wgrad_slots: grid too large");
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::NWAVE * 64), lds, st, g);
+    return check_launch("convt_slot_wgrad_kernel");
+}
+
 extern "C" {
 
 // ---- ConvTranspose2d GEMMs on slot operands (round 5; include/onet_hip.h)
@@ -1332,7 +1417,7 @@ int onet_convT2x2_dgrad_slots(const void* dyP, int64_t dyP_bs, const void* dy_am
 int64_t onet_convT2x2_wgrad_slots_ws_bytes(int B, int Cin, int Ct, int h, int w) {
     if ((Cin % 128) || (Ct % 32) || (((int64_t)h * w) % 128) || (w & (w - 1))) return 0;
     int k, per;
-    wgrad_plan(B, Cin, Ct, h, w, k, per);
+    (void)wgrad_slots_plan(B, Cin, Ct, h, w, k, per);
     return (int64_t)k * ((int64_t)Cin * 4 * Ct + 4 * Ct) * 4;
 }
 
@@ -1346,23 +1431,28 @@ int onet_convT2x2_wgrad_slots(const void* xP, int64_t xP_bs, const void* x_amax,
     ONET_REQUIRE(xP_bs >= (int64_t)Cin * hw * nparts / 2 && dyP_bs >= (int64_t)Ct * 4 * hw * nparts / 2, "convT2x2_wgrad_slots: batch stride too small");
     int lw = 0;
     while ((1 << lw) < w) ++lw;
-    SWArgs g{xP, xP_bs, dyP, dyP_bs, (float*)ws, nullptr, (const unsigned*)x_amax, (const unsigned*)dy_amax, B, Cin, Ct, h, w, lw, Cin / 128, Ct / 32, 1, 0};
-    wgrad_plan(B, Cin, Ct, h, w, g.splitK, g.chunksPerSplit);
+    SWArgs g{xP, xP_bs, dyP, dyP_bs, (float*)ws, nullptr, (const unsigned*)x_amax, (const unsigned*)dy_amax, B, Cin, Ct, h, w, lw, 0, 0, 1, 0};
+    const bool big = wgrad_slots_plan(B, Cin, Ct, h, w, g.splitK, g.chunksPerSplit) && SLOT_WGRAD_BIG;
+    if (!big) {          // (SLOT_WGRAD_BIG = 0, A/B builds: the small tile's plan)
+        int k, per;
+        const int64_t chunks = (int64_t)B * hw / 32, tiles = (int64_t)(Cin / 128) * (Ct / 32);
+        int64_t kk = std::max<int64_t>(1, (512 + tiles - 1) / tiles);
+        kk = std::min<int64_t>(kk, std::max<int64_t>(1, chunks / 16));
+        kk = std::min<int64_t>(kk, std::max<int64_t>(1, (256ll << 20) / ((int64_t)Cin * 4 * Ct * 4)));
+        per = (int)((chunks + kk - 1) / kk);
+        k = (int)((chunks + per - 1) / per);
+        g.splitK = k;
+        g.chunksPerSplit = per;
+    }
+    g.mTiles = big ? Cin / 256 : Cin / 128;
+    g.nTiles = big ? Ct / 64 : Ct / 32;
     const int64_t n = (int64_t)Cin * 4 * Ct;
     ONET_REQUIRE(ws_bytes >= (int64_t)g.splitK * (n + 4 * Ct) * 4, "convT2x2_wgrad_slots: workspace too small (onet_convT2x2_wgrad_slots_ws_bytes)");
     if (dbias) g.db_part = (float*)ws + (int64_t)g.splitK * n;
-    const int64_t blocks = (int64_t)g.splitK * g.mTiles * g.nTiles;
-    ONET_REQUIRE(blocks > 0 && blocks < (1ll << 31), "convT2x2_wgrad_slots: grid too large");
     hipStream_t st = as_stream(stream);
-    const int lds = nparts * SW_PLANES * SW_PXP * 16 * 2;
-    if (nparts == 2) {
-        static PerDeviceOnce once;
-        if (once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convt_slot_wgrad_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL(convt_slot_wgrad_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, st, g);
-    } else {
-        hipLaunchKernelGGL(convt_slot_wgrad_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, st, g);
-    }
-    int rc = check_launch("convt_slot_wgrad_kernel");
+    int rc;
+    if (nparts == 2) rc = big ? launch_wgrad_slots<2, 1>(g, st) : launch_wgrad_slots<2, 0>(g, st);
+    else rc = big ? launch_wgrad_slots<1, 1>(g, st) : launch_wgrad_slots<1, 0>(g, st);
     if (rc) return rc;
     hipLaunchKernelGGL(convt_wgrad_reduce_kernel, dim3((unsigned)cdiv(n / 4, 256)), dim3(256), 0, st, (const float*)ws, dw, g.splitK, n / 4, 0);
     rc = check_launch("convt_wgrad_reduce_kernel");
