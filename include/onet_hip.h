@@ -135,20 +135,20 @@ int onet_convT2x2_fwd_p(const float* x, int64_t x_bs, const float* wq, const flo
 /* Round 5 -- the same forward with BOTH operands in slot form: x pre-split by its producer ([B][Cin/8][h][nparts][w][8], batch stride in
  * 4-byte units; x_amax: the magnitude slots it was scaled by, guard rule, NULL = unscaled) and the weights packed once per optimizer step
  * by onet_convT2x2_pack_weights_slots into wP [Cin/8][nparts][4 Ct][8] (nparts = 2: fp16 hi | mid parts of 2^k w, (2^k, 2^-k) as two
- * floats behind the pack -- allocate Cin * 4 Ct * 2 * nparts + 8 bytes; amax_ws: 8 KB of scratch; nparts = 1: bf16(w)).  Every MFMA
+ * floats behind the pack -- allocate Cin * 4 Ct * 2 * nparts + 8 bytes; amax_ws: 8 KB of scratch; nparts = 1: bf16(w); wdP (may be
+ * NULL): the same launch also writes the input gradient's K-slot pack, below).  Every MFMA
  * fragment is one 16-byte LDS read of a DMA-copied slot: no conversion or split arithmetic in the kernel.  Output and y_amax as
  * onet_convT2x2_fwd_p.  Returns 1 (nothing done) unless Cin % 32 == 0, Ct % 32 == 0, h w % 128 == 0 and w is even. */
-int onet_convT2x2_pack_weights_slots(const float* w, void* wP, void* amax_ws, int Cin, int Ct, int nparts, void* stream);
+int onet_convT2x2_pack_weights_slots(const float* w, void* wP, void* wdP, void* amax_ws, int Cin, int Ct, int nparts, void* stream);
 int onet_convT2x2_fwd_slots(const void* xP, int64_t xP_bs, const void* x_amax, const void* wP, const float* bias, void* yP, int64_t yP_bs,
                             const void* y_amax, int nparts, int B, int Cin, int Ct, int h, int w, void* stream);
 /* ... and the backward GEMMs on slot operands.  dyP [B][Ct/8][2h][nparts][2w][8]: the up-sampled half of the concat gradient, written
  * pre-split by onet_conv3x3_split_dgrad_pre_slots as parts of 2^k dy (k by the `always` rule from the bound in dy_amax,
- * onet_conv3x3_dgrad_bound).  Input gradient: wdP = onet_convT2x2_pack_weights_dgrad_slots' pack [(Ct/8) 4][nparts][Cin][8] (K-slot =
+ * onet_conv3x3_dgrad_bound).  Input gradient: wdP = onet_convT2x2_pack_weights_slots' second pack [(Ct/8) 4][nparts][Cin][8] (K-slot =
  * 8 channels at one sub-pixel; same size and scale pair as the forward pack), dx fp32 [B][Cin][h][w].  Weight gradient: x pre-split as
  * for the forward; dw [Cin][Ct][2][2]; dbias (may be NULL) [Ct] = sum of dy over all pixels, taken in the same launch; ws: at least
  * onet_convT2x2_wgrad_slots_ws_bytes(...) (0: shape not taken).  Both return 1 (nothing done) outside Cin % 128 == 0, Ct % 32 == 0,
  * h w % 128 == 0 (weight gradient: w a power of two). */
-int onet_convT2x2_pack_weights_dgrad_slots(const float* w, void* wdP, void* amax_ws, int Cin, int Ct, int nparts, void* stream);
 int onet_convT2x2_dgrad_slots(const void* dyP, int64_t dyP_bs, const void* dy_amax, const void* wdP, float* dx, int64_t dx_bs, int nparts, int B,
                               int Cin, int Ct, int h, int w, void* stream);
 int64_t onet_convT2x2_wgrad_slots_ws_bytes(int B, int Cin, int Ct, int h, int w);

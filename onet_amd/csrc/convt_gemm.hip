@@ -1138,39 +1138,10 @@ __global__ __launch_bounds__(SwCfg<BIG>::NWAVE * 64, BIG ? 1 : 2) void convt_slo
     }
 }
 
-// w [Cin][Ct][2][2] -> wdP [(Ct/8) 4][NP][Cin][8] (see convt_slot_dgrad_kernel); scale as convt_pack_slots_kernel (shared magnitude slots)
-__global__ void convt_pack_dgrad_slots_kernel(const float* __restrict__ w, void* __restrict__ wdP, int Cin, int Ct, int np,
-                                              const unsigned* __restrict__ wamax) {
-    const int64_t n = (int64_t)Cin * 4 * Ct;
-    float winv = 1.f;
-    const float wscale = np == 2 ? amax_scale(amax_read(wamax), true, winv) : 1.f;
-    if (np == 2 && blockIdx.x == 0 && threadIdx.x == 0) {
-        float* meta = reinterpret_cast<float*>(reinterpret_cast<_Float16*>(wdP) + 2 * n);
-        meta[0] = wscale;
-        meta[1] = winv;
-    }
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int kc = (int)(i & 7);
-        const int64_t r = i >> 3;
-        const int ci = (int)(r % Cin), ks = (int)(r / Cin);        // K-slot = c8 * 4 + q
-        const int c = (ks >> 2) * 8 + kc, q = ks & 3;
-        const float v = w[((int64_t)ci * Ct + c) * 4 + q];
-        if (np == 2) {
-            _Float16* o = reinterpret_cast<_Float16*>(wdP);
-            const float vs = v * wscale;
-            const _Float16 hi = (_Float16)vs;
-            o[(((int64_t)ks * 2 + 0) * Cin + ci) * 8 + kc] = hi;
-            o[(((int64_t)ks * 2 + 1) * Cin + ci) * 8 + kc] = (_Float16)(vs - (float)hi);
-        } else {
-            reinterpret_cast<__bf16*>(wdP)[((int64_t)ks * Cin + ci) * 8 + kc] = (__bf16)v;
-        }
-    }
-}
-
 // w [Cin][Ct][2][2] fp32 (nn.ConvTranspose2d) -> wP [Cin/8][NP][4 Ct][8]: column m = 4 c + (2 di + dj) (== the weight's own memory
 // order), K-slot = 8 consecutive input channels; NP = 2: fp16 (hi | mid) parts of 2^k w with max |w| in [2^13, 2^14) (k from the
 // magnitude slots wamax; (2^k, 2^-k) stored behind the pack as two floats); NP = 1: bf16(w)
-__global__ void convt_pack_slots_kernel(const float* __restrict__ w, void* __restrict__ wP, int Cin, int Ct, int np,
+__global__ void convt_pack_slots_kernel(const float* __restrict__ w, void* __restrict__ wP, void* __restrict__ wdP, int Cin, int Ct, int np,
                                         const unsigned* __restrict__ wamax) {
     const int M = 4 * Ct;
     const int64_t n = (int64_t)Cin * M;
@@ -1180,8 +1151,33 @@ __global__ void convt_pack_slots_kernel(const float* __restrict__ w, void* __res
         float* meta = reinterpret_cast<float*>(reinterpret_cast<_Float16*>(wP) + 2 * n);
         meta[0] = wscale;
         meta[1] = winv;
+        if (wdP) {
+            float* md = reinterpret_cast<float*>(reinterpret_cast<_Float16*>(wdP) + 2 * n);
+            md[0] = wscale;
+            md[1] = winv;
+        }
     }
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    // (the second half of the index range, if asked for: the K-slot pack of the input gradient -- convt_slot_dgrad_kernel)
+    for (int64_t i2 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i2 < (wdP ? 2 * n : n); i2 += (int64_t)gridDim.x * blockDim.x) {
+        if (i2 >= n) {
+            const int64_t i = i2 - n;
+            const int kc = (int)(i & 7);
+            const int64_t r = i >> 3;
+            const int ci = (int)(r % Cin), ks = (int)(r / Cin);        // K-slot = c8 * 4 + q
+            const int c = (ks >> 2) * 8 + kc, q = ks & 3;
+            const float v = w[((int64_t)ci * Ct + c) * 4 + q];
+            if (np == 2) {
+                _Float16* o = reinterpret_cast<_Float16*>(wdP);
+                const float vs = v * wscale;
+                const _Float16 hi = (_Float16)vs;
+                o[(((int64_t)ks * 2 + 0) * Cin + ci) * 8 + kc] = hi;
+                o[(((int64_t)ks * 2 + 1) * Cin + ci) * 8 + kc] = (_Float16)(vs - (float)hi);
+            } else {
+                reinterpret_cast<__bf16*>(wdP)[((int64_t)ks * Cin + ci) * 8 + kc] = (__bf16)v;
+            }
+            continue;
+        }
+        const int64_t i = i2;
         const int kc = (int)(i & 7);
         const int64_t r = i >> 3;
         const int m = (int)(r % M), c8 = (int)(r / M);
@@ -1366,8 +1362,9 @@ static int launch_wgrad_slots(SWArgs g, hipStream_t st) {
 extern "C" {
 
 // ---- ConvTranspose2d GEMMs on slot operands (round 5; include/onet_hip.h)
-int onet_convT2x2_pack_weights_slots(const float* w, void* wP, void* amax_ws, int Cin, int Ct, int nparts, void* stream) {
-    ONET_REQUIRE(w && wP && Cin > 0 && Ct > 0 && (Cin % 8) == 0 && (nparts == 1 || nparts == 2), "convT2x2_pack_weights_slots: bad args");
+int onet_convT2x2_pack_weights_slots(const float* w, void* wP, void* wdP, void* amax_ws, int Cin, int Ct, int nparts, void* stream) {
+    ONET_REQUIRE(w && wP && Cin > 0 && Ct > 0 && (Cin % 8) == 0 && (!wdP || (Ct % 8) == 0) && (nparts == 1 || nparts == 2),
+                 "convT2x2_pack_weights_slots: bad args");
     ONET_REQUIRE(nparts == 1 || amax_ws, "convT2x2_pack_weights_slots: the fp16 pack needs the 8 KB magnitude workspace");
     hipStream_t st = as_stream(stream);
     const int64_t n = (int64_t)Cin * 4 * Ct;
@@ -1377,25 +1374,9 @@ int onet_convT2x2_pack_weights_slots(const float* w, void* wP, void* amax_ws, in
         int rc = check_launch("convt_absmax_kernel");
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(convt_pack_slots_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, st, w, wP, Cin, Ct, nparts,
-                       (const unsigned*)amax_ws);
+    hipLaunchKernelGGL(convt_pack_slots_kernel, dim3((unsigned)std::min<int64_t>(((wdP ? 2 : 1) * n + 255) / 256, 8192)), dim3(256), 0, st, w, wP,
+                       wdP, Cin, Ct, nparts, (const unsigned*)amax_ws);
     return check_launch("convt_pack_slots_kernel");
-}
-
-int onet_convT2x2_pack_weights_dgrad_slots(const float* w, void* wdP, void* amax_ws, int Cin, int Ct, int nparts, void* stream) {
-    ONET_REQUIRE(w && wdP && Cin > 0 && Ct > 0 && (Ct % 8) == 0 && (nparts == 1 || nparts == 2), "convT2x2_pack_weights_dgrad_slots: bad args");
-    ONET_REQUIRE(nparts == 1 || amax_ws, "convT2x2_pack_weights_dgrad_slots: the fp16 pack needs the 8 KB magnitude workspace");
-    hipStream_t st = as_stream(stream);
-    const int64_t n = (int64_t)Cin * 4 * Ct;
-    if (nparts == 2) {
-        (void)hipMemsetAsync(amax_ws, 0, AMAX_SLOTS * AMAX_STRIDE * sizeof(unsigned), st);
-        hipLaunchKernelGGL(convt_absmax_kernel, dim3((unsigned)std::min<int64_t>((n + 1023) / 1024, 1024)), dim3(256), 0, st, w, n, (unsigned*)amax_ws);
-        int rc = check_launch("convt_absmax_kernel");
-        if (rc) return rc;
-    }
-    hipLaunchKernelGGL(convt_pack_dgrad_slots_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, st, w, wdP, Cin, Ct,
-                       nparts, (const unsigned*)amax_ws);
-    return check_launch("convt_pack_dgrad_slots_kernel");
 }
 
 int onet_convT2x2_dgrad_slots(const void* dyP, int64_t dyP_bs, const void* dy_amax, const void* wdP, float* dx, int64_t dx_bs, int nparts, int B,

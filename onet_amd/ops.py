@@ -417,27 +417,19 @@ def convT2x2_out_bound(weight, bias, x_amax):
     return slots
 
 
-def packT2x2_slots(w, parts=2):
+def packT2x2_slots(w, parts=2, dgrad=False):
     """nn.ConvTranspose2d weight [Cin, Ct, 2, 2] -> the slot pack of the slot-operand forward GEMM: [Cin/8, parts, 4 Ct, 8] fp16 (hi | mid)
-    parts of 2^k w (+ (2^k, 2^-k) behind the pack), or one part of bf16(w)."""
+    parts of 2^k w (+ (2^k, 2^-k) behind the pack), or one part of bf16(w).  dgrad: -> (that, the K-slot pack of the input gradient
+    [(Ct/8) 4, parts, Cin, 8]) from the same launch."""
     require_gpu(w)
     w = w.detach().contiguous()
     Cin, Ct = w.shape[0], w.shape[1]
-    wP = torch.empty(Cin * 4 * Ct * parts + 4, dtype=torch.float16 if parts == 2 else BF, device=w.device)
+    dt = torch.float16 if parts == 2 else BF
+    wP = torch.empty(Cin * 4 * Ct * parts + 4, dtype=dt, device=w.device)
+    wdP = torch.empty(Cin * 4 * Ct * parts + 4, dtype=dt, device=w.device) if dgrad else None
     ws = torch.empty(2048, dtype=torch.int32, device=w.device) if parts == 2 else None
-    _lib.call("onet_convT2x2_pack_weights_slots", _p(w), _p(wP), _p(ws), Cin, Ct, parts, _stream())
-    return wP
-
-
-def packT2x2_dgrad_slots(w, parts=2):
-    """-> the K-slot pack of the slot-operand input gradient: [(Ct/8) 4, parts, Cin, 8] (+ the scale pair behind the fp16 pack)."""
-    require_gpu(w)
-    w = w.detach().contiguous()
-    Cin, Ct = w.shape[0], w.shape[1]
-    wP = torch.empty(Cin * 4 * Ct * parts + 4, dtype=torch.float16 if parts == 2 else BF, device=w.device)
-    ws = torch.empty(2048, dtype=torch.int32, device=w.device) if parts == 2 else None
-    _lib.call("onet_convT2x2_pack_weights_dgrad_slots", _p(w), _p(wP), _p(ws), Cin, Ct, parts, _stream())
-    return wP
+    _lib.call("onet_convT2x2_pack_weights_slots", _p(w), _p(wP), _p(wdP), _p(ws), Cin, Ct, parts, _stream())
+    return (wP, wdP) if dgrad else wP
 
 
 def convT2x2_dgrad_slots(dyP, wdP, Cin, dy_slots=None):
@@ -557,14 +549,16 @@ class PackedT:
         return 2
 
     def slots(self, parts):
-        if parts not in self._s:
-            self._s[parts] = packT2x2_slots(self.w, parts)
-        return self._s[parts]
+        if parts not in self._s:       # (fp16 parts: the backward GEMMs' pack comes out of the same launch -- a training step wants both)
+            self._s[parts] = packT2x2_slots(self.w, parts, dgrad=(parts == 2 and CONVT_BWD_SLOTS))
+        v = self._s[parts]
+        return v[0] if isinstance(v, tuple) else v
 
     def dgrad_slots(self, parts):
-        if ("d", parts) not in self._s:
-            self._s[("d", parts)] = packT2x2_dgrad_slots(self.w, parts)
-        return self._s[("d", parts)]
+        v = self._s.get(parts)
+        if not isinstance(v, tuple):
+            self._s[parts] = v = packT2x2_slots(self.w, parts, dgrad=True)
+        return v[1]
 
 
 def convT2x2_fwd_slots(xP, wP, bias, outP, Ct, x_slots=None, slots=None):

@@ -1105,7 +1105,7 @@ def test_convT_backward_slot_operands(dev, B, Cin, h, w):
     k = 13 - int(np.floor(np.log2(20.0 * float(dy.abs().max()))))
     dyP = ops.split_pack_act(dyd, f16=True, scale=2.0 ** k)
     xP = ops.split_pack_act(x.to(dev), f16=True)
-    dx = ops.convT2x2_dgrad_slots(dyP, ops.packT2x2_dgrad_slots(wt.to(dev)), Cin, dy_slots=bound)
+    dx = ops.convT2x2_dgrad_slots(dyP, ops.packT2x2_slots(wt.to(dev), dgrad=True)[1], Cin, dy_slots=bound)
     assert dx is not None
     close(dx, xr.grad, tol=4e-6, what="slot-operand ConvTranspose2d input gradient")
     got = ops.convT2x2_wgrad_slots(xP, dyP, (Cin, Ct, 2, 2), dy_slots=bound, want_dbias=True)

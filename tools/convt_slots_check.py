@@ -73,7 +73,7 @@ if parts == 2:
         k = 13 - math.floor(math.log2(float(dy.abs().max())))
         dyP = ops.split_pack_act(dy, f16=True, scale=2.0 ** k)
         xP = ops.split_pack_act(x, f16=True)
-        wdP = ops.packT2x2_dgrad_slots(w)
+        wdP = ops.packT2x2_slots(w, dgrad=True)[1]
         dx = ops.convT2x2_dgrad_slots(dyP, wdP, Cin, dy_slots=dy_slots)
         e1 = float((dx[:nb].double().cpu() - xr.grad).abs().max() / xr.grad.abs().max())
         wd = ops.packT2x2(w)[1]

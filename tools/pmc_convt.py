@@ -20,7 +20,7 @@ for li, (Cin, h) in enumerate(((1024, 16), (512, 32), (256, 64), (128, 128))):
     k = 13 - math.floor(math.log2(float(dy.abs().max())))
     dyP = ops.split_pack_act(dy, f16=True, scale=2.0 ** k)
     xP = ops.split_pack_act(x, f16=True)
-    wP, wdP = ops.packT2x2_slots(w), ops.packT2x2_dgrad_slots(w)
+    wP, wdP = ops.packT2x2_slots(w), ops.packT2x2_slots(w, dgrad=True)[1]
     outP = ops.p16_empty(B, Ct, 2 * h, 2 * h, dev, parts=2)
     for _ in range(N + 2):
         if "fwd" in which:
