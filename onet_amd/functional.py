@@ -476,8 +476,7 @@ class UpConvTCatFn(torch.autograd.Function):
         """p16 (pre-split storage): {"catP": the pre-split concat buffer, skip groups written by the encoder}: the up-sampled groups
         are written here and NO fp32 concat exists (a placeholder goes through the graph)."""
         ops.require_gpu(x1, x2, weight, bias)
-        wp_fused, wp_dgrad = packed               # (ops.PackedT hands out lazy handles: the fused fp32 pack is made only if it is used)
-        wp_dgrad = ops.pack_of(wp_dgrad)
+        wp_fused, wp_dgrad = packed               # (ops.PackedT hands out lazy handles: a classic fp32 pack is made only if it is used)
         B, Cin, h, w = x1.shape
         Ct = weight.shape[1]
         C2, Ho, Wo = x2.shape[1], x2.shape[2], x2.shape[3]
@@ -500,7 +499,8 @@ class UpConvTCatFn(torch.autograd.Function):
                 up = torch.empty((B, Ct, Ho, Wo), dtype=torch.float32, device=x1.device)
                 ops.convT2x2_fwd(x1, ops.pack_of(wp_fused), bias, up, Ct, pt, pl)
                 ops.split_pack_act(up, out=catP[:, C2 // 8:], slots=p16.get("up_slots"))
-            ctx.save_for_backward(x1, wp_dgrad)
+            ctx.save_for_backward(x1)
+            ctx.wp_dgrad = wp_dgrad
             ctx.meta = (C2, Ct, h, w, pt, pl, tuple(weight.shape), bias is not None)
             ctx.params = (weight, bias)
             # round 5: the backward GEMMs on slot operands too -- the consumer of the concat buffer (the decoder block's first convolution)
@@ -524,14 +524,15 @@ class UpConvTCatFn(torch.autograd.Function):
             for bi in range(B):                      # F.pad border (only when H or W is not a multiple of 16); raw
                 ops.fill(cat[bi, C2:], 0.0)          # fills: a torch in-place op on the base of the skip view is forbidden
         ops.convT2x2_fwd(x1, ops.pack_of(wp_fused), bias, cat[:, C2:], Ct, pt, pl)
-        ctx.save_for_backward(x1, wp_dgrad)
+        ctx.save_for_backward(x1)
+        ctx.wp_dgrad = wp_dgrad
         ctx.meta = (C2, Ct, h, w, pt, pl, tuple(weight.shape), bias is not None)
         ctx.params = (weight, bias)
         return cat
 
     @staticmethod
     def backward(ctx, dcat):
-        x1, wp_dgrad = ctx.saved_tensors
+        (x1,) = ctx.saved_tensors
         C2, Ct, h, w, pt, pl, wshape, has_bias = ctx.meta
         need_x1, need_x2, need_w, need_b = ctx.needs_input_grad[:4]
         dx2 = dcat[:, :C2] if need_x2 else None
@@ -554,6 +555,7 @@ class UpConvTCatFn(torch.autograd.Function):
                 return dx1, dx2, (got[0] if need_w else None), (got[1] if want_db else None), None, None, None
             if ops.is_placeholder(x1):
                 raise RuntimeError("onet_amd: ConvTranspose2d backward: the input exists only pre-split and the pre-split gradient did not arrive")
+        wp_dgrad = ops.pack_of(ctx.wp_dgrad) if need_x1 else None     # (the weight is what it was in forward: no optimizer step in between)
         if (need_x1 or need_w or need_b) and ops.convT2x2_bwd_fusable(Ct):
             # the GEMM kernels gather dy from the concat gradient themselves: no space-to-depth tensor
             dup = dcat[:, C2:]

@@ -54,8 +54,10 @@ for t in reversed(dec):
 for n in reversed(enc):
     names += [n + " wgrad", n + " dgrad"]
 names += ["inc.c1 (stem) wgrad + BN bwd"]
-if len(names) != per:
-    names = [""] * per
+rows = [r for r in rows if r[2] > 0]          # (an entry point that declined a shape leaves a zero-FLOP record: the caller launched another)
+rows = [(i,) + r[1:] for i, r in enumerate(rows)]
+if len(names) != len(rows):
+    names = [""] * len(rows)
 SPLIT = {"conv3x3_split_pre_kernel", "conv3x3_split_wgrad_pre_kernel", "convt_gemm_kernel", "convt_wgrad_gemm_kernel"}
 print(f"| # | launch | kernel | direct GFLOP | ms | direct TF | issued fraction of 2.5 PF |\n|---:|---|---|---:|---:|---:|---:|")
 tot = {}
