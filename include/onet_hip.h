@@ -224,10 +224,11 @@ int onet_conv3x3_split_fwd_pre(const void* xs, int64_t xs_bs, const void* x_amax
  * < ch0 of da (the skip half of the concat gradient) as fp32, channels >= ch0 (the up-sampled half, read only by the ConvTranspose2d
  * backward GEMMs) pre-split into daP [B][(Cout - ch0)/8][H][2][W][8] as parts of 2^k da, k by the `always` rule from daP_amax -- which
  * onet_conv3x3_dgrad_bound fills first: max |dz| (dz_amax) x the largest sum over (co, tap) of |w[co][ci][tap]| over ci >= ci0 (w: the
- * nn.Conv2d weight [Cout][Cin][3][3]; out_slots zeroed by the caller).  Cin / Cout here name the channels of dzs / da. */
-int onet_conv3x3_split_dgrad_pre_slots(const void* dzs, int64_t dzs_bs, const void* dz_amax, int scale_always, const void* wq, float* da,
-                                       int64_t da_bs, void* daP, int64_t daP_bs, int ch0, const void* daP_amax, int B, int Cin, int Cout, int H,
-                                       int W, void* stream);
+ * nn.Conv2d weight [Cout][Cin][3][3]; out_slots zeroed by the caller).  Cin / Cout here name the channels of dzs / da.  wq_f16 = 2:
+ * plain bf16 operands -- daP [B][(Cout - ch0)/8][H][W][8] is one part of bf16(da), unscaled (daP_amax may be NULL). */
+int onet_conv3x3_split_dgrad_pre_slots(const void* dzs, int64_t dzs_bs, const void* dz_amax, int scale_always, const void* wq, int wq_f16,
+                                       float* da, int64_t da_bs, void* daP, int64_t daP_bs, int ch0, const void* daP_amax, int B, int Cin,
+                                       int Cout, int H, int W, void* stream);
 int onet_conv3x3_dgrad_bound(const float* w, int Cout, int Cin, int ci0, const void* dz_amax, void* out_slots, void* stream);
 /* Weight gradient (OV:47,51 backward) from pre-split x and dz (both in the slot layout, same 16-bit type): fragments by the gfx950
  * transposing LDS read, staging by LDS-DMA; the producers' power-of-two scales (x_amax: guard rule, dz_amax: always; NULL:

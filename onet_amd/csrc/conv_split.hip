@@ -56,6 +56,10 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
 // numbers (undone on the accumulators, exactly); gradients -- whose magnitude is anyone's guess -- keep the bf16 split.
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {       // two bf16 (round to nearest even) in one dword, `lo` first
+    const bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
 __device__ __forceinline__ void split2h(float a, float b, unsigned& hi, unsigned& mid) {
     const f16x2 h = {(_Float16)a, (_Float16)b};
     const f16x2 m = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
@@ -1382,6 +1386,37 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pre16_kernel(SpPreArgs a) {
                     const i32x4s e2 = {__builtin_amdgcn_update_dpp(vb.x, va.x, 0x128, 0xf, 0x3, false), __builtin_amdgcn_update_dpp(vb.y, va.y, 0x128, 0xf, 0x3, false),
                                        __builtin_amdgcn_update_dpp(vb.z, va.z, 0x128, 0xf, 0x3, false), __builtin_amdgcn_update_dpp(vb.w, va.w, 0x128, 0xf, 0x3, false)};
                     const f32x4s d1 = __builtin_bit_cast(f32x4s, e1), d2 = __builtin_bit_cast(f32x4s, e2);
+                    if constexpr (PM == 2 && !ST && !W16 && !RD) {
+                        if (a.zP && co0 >= a.zP_ch0) {
+                            // Pre-split output, plain bf16 (SpPreArgs::zP, one part): the eight lanes c8 = 0 .. 7 of a (pixel quad, tile half)
+                            // hold 8 channels x 4 pixels of channel group A (d1: channels 16 ct + c8) and of group B (d2: + 8).  Three
+                            // butterfly exchanges (lane ^ 1, ^ 2, ^ 4) transpose them: afterwards lane c8 owns one whole slot -- the 8
+                            // channels of group (c8 >> 2 ? B : A) at pixel c8 & 3 of the quad.
+                            const unsigned a0 = pack2bf(d1[0], d1[1]), a1 = pack2bf(d1[2], d1[3]);
+                            const unsigned b0 = pack2bf(d2[0], d2[1]), b1 = pack2bf(d2[2], d2[3]);
+                            const bool o1 = (c8 & 1) != 0, o2 = (c8 & 2) != 0, o4 = (c8 & 4) != 0;
+                            // stage 1: (pixel pair of one channel) x 2 lanes -> (channel pair) of pixel (c8 & 1) [and + 2]
+                            auto st1 = [&](unsigned x) {
+                                const unsigned y = (unsigned)__shfl_xor((int)x, 1, 64);
+                                return o1 ? ((y >> 16) | (x & 0xffff0000u)) : ((x & 0xffffu) | (y << 16));
+                            };
+                            const unsigned A0 = st1(a0), A1 = st1(a1), B0 = st1(b0), B1 = st1(b1);
+                            // stage 2: -> the channel quad (c8 >> 2) of pixel c8 & 3: lanes with bit 1 clear keep pixel (c8 & 1), the others + 2
+                            const unsigned ra = (unsigned)__shfl_xor((int)(o2 ? A0 : A1), 2, 64), rb = (unsigned)__shfl_xor((int)(o2 ? B0 : B1), 2, 64);
+                            const unsigned ka = o2 ? A1 : A0, kb = o2 ? B1 : B0;
+                            const unsigned Alo = o2 ? ra : ka, Ahi = o2 ? ka : ra, Blo = o2 ? rb : kb, Bhi = o2 ? kb : rb;
+                            // stage 3: lanes with bit 2 clear collect group A (their quad = channels 0 .. 3, the partner's 4 .. 7), the others B
+                            const unsigned r0 = (unsigned)__shfl_xor((int)(o4 ? Alo : Blo), 4, 64), r1 = (unsigned)__shfl_xor((int)(o4 ? Ahi : Bhi), 4, 64);
+                            const u32x4s slot = o4 ? u32x4s{r0, r1, Blo, Bhi} : u32x4s{Alo, Ahi, r0, r1};
+                            const int xs = x0 + 16 * half + 4 * lq + (c8 & 3);
+                            if (yo < a.H && xs < a.W) {
+                                const int g8 = ((co0 - a.zP_ch0) >> 3) + 2 * ct + (o4 ? 1 : 0);
+                                u32x4s* zp = reinterpret_cast<u32x4s*>(reinterpret_cast<unsigned*>(a.zP) + (int64_t)b * a.zP_bs);
+                                zp[((int64_t)g8 * a.H + yo) * a.W + xs] = slot;
+                            }
+                            continue;
+                        }
+                    }
                     if (yo < a.H && xo < a.W) {
                         const int co = co0 + ct * 16 + c8;
                         const int64_t off = (int64_t)co * HW + (int64_t)yo * a.W + xo;
@@ -2614,16 +2649,17 @@ int onet_conv3x3_split_dgrad_pre_bnreduce(const void* dzs, int64_t dzs_bs, const
 
 // Input gradient of a decoder block's FIRST convolution (fp16 hi | mid parts): channels < ch0 of da as fp32, channels >= ch0 -- the
 // up-sampled half of the concat gradient, read only by the ConvTranspose2d backward GEMMs -- pre-split into daP (SpPreArgs::zP).
-int onet_conv3x3_split_dgrad_pre_slots(const void* dzs, int64_t dzs_bs, const void* dz_amax, int scale_always, const void* wq, float* da,
-                                       int64_t da_bs, void* daP, int64_t daP_bs, int ch0, const void* daP_amax, int B, int Cin, int Cout, int H,
-                                       int W, void* stream) {
-    ONET_REQUIRE(dzs && wq && da && daP && daP_amax, "conv3x3_split_dgrad_pre_slots: null pointer");
-    ONET_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W >= 32 && (W % 32) == 0 && (H % 16) == 0 && (Cin % 16) == 0,
-                 "conv3x3_split_dgrad_pre_slots: maps made of full 16 x 32 tiles, Cin %% 16 == 0");
+int onet_conv3x3_split_dgrad_pre_slots(const void* dzs, int64_t dzs_bs, const void* dz_amax, int scale_always, const void* wq, int wq_f16,
+                                       float* da, int64_t da_bs, void* daP, int64_t daP_bs, int ch0, const void* daP_amax, int B, int Cin,
+                                       int Cout, int H, int W, void* stream) {
+    ONET_REQUIRE(dzs && wq && da && daP && (daP_amax || wq_f16 == 2) && (wq_f16 == 1 || wq_f16 == 2), "conv3x3_split_dgrad_pre_slots: bad args");
+    ONET_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W >= 32 && (W % 32) == 0 && (H % 16) == 0 && (Cin % (wq_f16 == 2 ? 32 : 16)) == 0,
+                 "conv3x3_split_dgrad_pre_slots: maps made of full 16 x 32 tiles, Cin %% 16 == 0 (32: plain bf16)");
     ONET_REQUIRE(ch0 > 0 && ch0 < Cout && (ch0 % 64) == 0 && (Cout % 64) == 0, "conv3x3_split_dgrad_pre_slots: ch0 and Cout must be multiples of 64");
     ONET_REQUIRE((dzs_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(dzs) & 15) == 0 && (daP_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(daP) & 15) == 0,
                  "conv3x3_split_dgrad_pre_slots: 16-byte aligned slots required");
-    ONET_REQUIRE(dzs_bs >= (int64_t)Cin * H * W && da_bs >= (int64_t)ch0 * H * W && daP_bs >= (int64_t)(Cout - ch0) * H * W,
+    ONET_REQUIRE(dzs_bs >= (int64_t)Cin * H * W / (wq_f16 == 2 ? 2 : 1) && da_bs >= (int64_t)ch0 * H * W &&
+                     daP_bs >= (int64_t)(Cout - ch0) * H * W / (wq_f16 == 2 ? 2 : 1),
                  "conv3x3_split_dgrad_pre_slots: batch stride too small");
     ONET_REQUIRE((int64_t)(Cin + 32) * H * W * 4 < (1ll << 31) && (int64_t)(Cin + 32) * 2 * 9 * Cout * 2 < (1ll << 31),
                  "conv3x3_split_dgrad_pre_slots: operand exceeds the 2 GiB buffer-resource range");
@@ -2632,6 +2668,7 @@ int onet_conv3x3_split_dgrad_pre_slots(const void* dzs, int64_t dzs_bs, const vo
     a.zP_bs = daP_bs;
     a.zP_ch0 = ch0;
     a.zP_slots = (const unsigned*)daP_amax;
+    if (wq_f16 == 2) return launch_split_pre<false, 2, false>(a, as_stream(stream));      // plain bf16: one part, unscaled (conv3x3_pre16_kernel)
     return launch_split_pre<false, 1, false>(a, as_stream(stream));
 }
 

@@ -273,13 +273,13 @@ class ConvBNReLUFn(torch.autograd.Function):
                 if am_below is not None:
                     ctx.link_in["da_amax"] = am_below
         up = getattr(ctx, "up_link", None)
-        if need_x and dx is None and up is not None and up.get("want") and dz_slots is not None and dzP.shape[3] == 2:
+        if need_x and dx is None and up is not None and up.get("want") and (dz_slots is not None or dzP.shape[3] == 1):
             # the input of this convolution is a concat buffer whose up-sampled half came out of a ConvTranspose2d: that half of dx is
             # read only by the ConvTranspose2d backward GEMMs, and leaves this launch in THEIR operand form (fp16 hi | mid slots scaled by
             # a bound from dz's bound and the weights); the fp32 tensor keeps its shape, its upper channels are never written
             C2, Ct = up["want"]
-            bound = ops.conv3x3_dgrad_bound(pw, dz_slots, C2)
-            dx, dyP = ops.conv3x3_split_dgrad_pre_slots(dzP, dpack, ctx.wshape[1], C2, bound, slots=dz_slots, always=True)
+            bound = ops.conv3x3_dgrad_bound(pw, dz_slots, C2) if dzP.shape[3] == 2 else None      # (plain bf16 parts are not scaled)
+            dx, dyP = ops.conv3x3_split_dgrad_pre_slots(dzP, dpack, ctx.wshape[1], C2, bound, slots=dz_slots, always=dz_slots is not None)
             up["dyP"], up["dy_slots"], up["da"] = dyP, bound, dx
         if need_x and dx is None:
             dx = ops.conv3x3_split_pre(dzP, dpack, ctx.wshape[1], slots=dz_slots, always=dz_slots is not None)
@@ -546,7 +546,7 @@ class UpConvTCatFn(torch.autograd.Function):
                 x1P, x1_slots, packed = ctx.slot_ops
                 want_db = need_b and has_bias
                 if need_x1:
-                    dx1 = ops.convT2x2_dgrad_slots(dyP, packed.dgrad_slots(2), wshape[0], dy_slots=dy_slots)
+                    dx1 = ops.convT2x2_dgrad_slots(dyP, packed.dgrad_slots(dyP.shape[3]), wshape[0], dy_slots=dy_slots)
                 got = ops.convT2x2_wgrad_slots(x1P, dyP, wshape, x_slots=x1_slots, dy_slots=dy_slots, want_dbias=want_db,
                                                out=ops.grad_slot_if_free(ctx.params[0]),
                                                db_out=ops.grad_slot_if_free(ctx.params[1]) if want_db else None) if (need_w or want_db) else (None, None)

@@ -481,15 +481,18 @@ def conv3x3_dgrad_bound(weight, dz_slots, ci0):
 
 def conv3x3_split_dgrad_pre_slots(dzP, wq, Cout, ch0, daP_slots, slots=None, always=False):
     """Input gradient of a decoder block's first convolution from pre-split dz: -> (da [B, Cout, H, W] fp32 whose channels >= ch0 are NOT
-    written, daP [B, (Cout - ch0)/8, H, 2, W, 8] = those channels pre-split, scaled by daP_slots' `always` rule)."""
-    B, C8, H, two, W, _ = dzP.shape
-    assert two == 2 and wq.dtype == dzP.dtype == torch.float16
+    written, daP [B, (Cout - ch0)/8, H, parts, W, 8] = those channels pre-split: fp16 (hi | mid) parts scaled by daP_slots' `always` rule,
+    or -- plain bf16 operands -- one part of bf16(da))."""
+    B, C8, H, parts, W, _ = dzP.shape
+    assert wq.dtype == dzP.dtype == (torch.float16 if parts == 2 else BF)
     da = torch.empty((B, Cout, H, W), dtype=F32, device=dzP.device)
-    daP = torch.empty((B, (Cout - ch0) // 8, H, 2, W, 8), dtype=torch.float16, device=dzP.device)
+    daP = torch.empty((B, (Cout - ch0) // 8, H, parts, W, 8), dtype=dzP.dtype, device=dzP.device)
     e0 = _prof_begin("conv3x3_split_pre_kernel")
-    _lib.call("onet_conv3x3_split_dgrad_pre_slots", _p(dzP), _pbs(dzP), _p(slots), int(always), _p(wq), _p(da), Cout * H * W, _p(daP), _pbs(daP),
-              int(ch0), _p(daP_slots), B, C8 * 8, Cout, H, W, _stream())
-    _prof_end("conv3x3_split_pre_kernel", 2.0 * B * H * W * C8 * 8 * Cout * 9, e0, 4.0 * B * H * W * (C8 * 8 + Cout) + 4.0 * 9 * C8 * 8 * Cout)
+    _lib.call("onet_conv3x3_split_dgrad_pre_slots", _p(dzP), _pbs(dzP), _p(slots), int(always), _p(wq), 2 if parts == 1 else 1, _p(da), Cout * H * W,
+              _p(daP), _pbs(daP), int(ch0), _p(daP_slots), B, C8 * 8, Cout, H, W, _stream())
+    eb = 2.0 * parts
+    _prof_end("conv3x3_split_pre_kernel", 2.0 * B * H * W * C8 * 8 * Cout * 9, e0,
+              B * H * W * (eb * C8 * 8 + 4.0 * ch0 + eb * (Cout - ch0)) + eb * 9 * C8 * 8 * Cout)
     return da, daP
 
 
@@ -508,8 +511,8 @@ CONVT_BWD_SLOTS = _flag("CONVT_BWD_SLOTS", True)     # 0: the ConvTranspose2d ba
 
 def convt_bwd_slots_ok(B, Cin, Ct, C2, h, w):
     """Do the slot-operand ConvTranspose2d BACKWARD GEMMs take this layer -- and the input gradient of the decoder block's first
-    convolution (C2 skip + Ct up-sampled channels on a 2h x 2w map) the slot-writing form that feeds them?  fp16 (hi | mid) parts only."""
-    return bool(CONVT_BWD_SLOTS and convt_slots_ok(B, Cin, Ct, h, w) and p16_parts() == 2 and Cin % 128 == 0 and (w & (w - 1)) == 0
+    convolution (C2 skip + Ct up-sampled channels on a 2h x 2w map) the slot-writing form that feeds them?"""
+    return bool(CONVT_BWD_SLOTS and convt_slots_ok(B, Cin, Ct, h, w) and Cin % 128 == 0 and (w & (w - 1)) == 0
                 and C2 % 64 == 0 and (C2 + Ct) % 64 == 0 and (2 * h) % 16 == 0 and (2 * w) % 32 == 0 and Ct * 4 * h * w * 4 < 2 ** 31)
 
 
@@ -549,8 +552,8 @@ class PackedT:
         return 2
 
     def slots(self, parts):
-        if parts not in self._s:       # (fp16 parts: the backward GEMMs' pack comes out of the same launch -- a training step wants both)
-            self._s[parts] = packT2x2_slots(self.w, parts, dgrad=(parts == 2 and CONVT_BWD_SLOTS))
+        if parts not in self._s:       # (the backward GEMMs' pack comes out of the same launch -- a training step wants both)
+            self._s[parts] = packT2x2_slots(self.w, parts, dgrad=bool(CONVT_BWD_SLOTS))
         v = self._s[parts]
         return v[0] if isinstance(v, tuple) else v
 

@@ -337,7 +337,9 @@ class _RoundedConvT2x2(torch.autograd.Function):
         dx = F.conv2d(gr, wr, None, 2) if "dgrad" in ctx.prods else F.conv2d(g, w, None, 2)
         dw = torch.nn.grad.conv2d_weight(gr, w.shape, xr, stride=2) if "wgrad" in ctx.prods else \
             torch.nn.grad.conv2d_weight(g, w.shape, x, stride=2)
-        return dx, dw, g.sum((0, 2, 3)), None, None, None
+        # ("dbias": the gradient itself is STORED rounded -- a path that hands the up-sampled half of the concat gradient to the
+        # ConvTranspose2d backward as bf16 sums the bias gradient from those values too, as torch.autocast's bf16 grad_output does)
+        return dx, dw, (gr if "dbias" in ctx.prods else g).sum((0, 2, 3)), None, None, None
 
 
 def _conv3x3(x, w):

@@ -307,7 +307,13 @@ def _bf16_rule(kind, xs, ws):
     _, Cin, h, w = xs
     if Cin % 128 or ws[1] % 32:
         return False
+    if (Cin, h, w) in CONVT_SLOT_SHAPES:      # round 5, slot-operand backward: dy itself is stored as bf16 -- the bias gradient sums those values
+        return {"fwd", "dgrad", "wgrad", "dbias"}
     return {"fwd", "dgrad", "wgrad"} if (h * w) % 128 == 0 else ({"wgrad"} if (h * w) % 32 == 0 else False)
+
+
+CONVT_SLOT_SHAPES = set()   # (Cin, h, w) of the ConvTranspose2d layers whose backward GEMMs read slot operands in the recorded run (filled by
+                            # _record_bf16_operands' spy on ops.convT2x2_wgrad_slots: the dispatch is the run's, the rule follows it)
 
 
 BF16_GRAD_TOL = 1e-4     # per parameter tensor, relative L2, with the HIP run's rounded operands replayed (measured 7.1e-6 at
@@ -322,7 +328,8 @@ def _record_bf16_operands(monkeypatch, B):
     from onet_amd import ops
     rb = lambda t: t.detach().to(torch.bfloat16).cpu()          # RNE, == v_cvt_pk_bf16_f32 (tests/test_gpu_ops.py)
     conv, convt, zs, pre = [], [], [], []
-    real_w, real_t, real_p = ops.conv3x3_wgrad_auto, ops.convT2x2_wgrad, ops.conv3x3_split_wgrad_pre
+    CONVT_SLOT_SHAPES.clear()
+    real_w, real_t, real_p, real_ts = ops.conv3x3_wgrad_auto, ops.convT2x2_wgrad, ops.conv3x3_split_wgrad_pre, ops.convT2x2_wgrad_slots
     real_zp, real_zf = ops.conv3x3_pre_bn_partials, ops.conv3x3_fwd_bn_partials
 
     # the conv output z of every unit AS STORED (round 5: bf16 where ops.z16_storage() says so; None for a unit that keeps fp32): the
@@ -360,8 +367,17 @@ def _record_bf16_operands(monkeypatch, B):
         convt.append((rb(x), rb(dy)))
         return real_t(x, dy, *a, **k)
 
+    def wgrad_ts(xP, dyP, *a, **k):
+        # round 5: the ConvTranspose2d backward GEMMs on slot operands -- one part of plain bf16 here: what the kernels consumed
+        assert xP.shape[0] == 2 * B and xP.shape[3] == 1 and dyP.shape[3] == 1
+        nchw = lambda P: P.detach()[:, :, :, 0].permute(0, 1, 4, 2, 3).reshape(P.shape[0], P.shape[1] * 8, P.shape[2], P.shape[4]).cpu()
+        convt.append((nchw(xP), nchw(dyP)))
+        CONVT_SLOT_SHAPES.add((xP.shape[1] * 8, xP.shape[2], xP.shape[4]))
+        return real_ts(xP, dyP, *a, **k)
+
     monkeypatch.setattr(ops, "conv3x3_wgrad_auto", wgrad)
     monkeypatch.setattr(ops, "convT2x2_wgrad", wgrad_t)
+    monkeypatch.setattr(ops, "convT2x2_wgrad_slots", wgrad_ts)
     monkeypatch.setattr(ops, "conv3x3_split_wgrad_pre", wgrad_pre)
     # the stem's dz is recorded too: materialise it (by default its weight gradient forms it on load -- the same bits,
     # tests/test_gpu_ops.py::test_stem_wgrad_with_bn_backward_on_load)
@@ -370,6 +386,7 @@ def _record_bf16_operands(monkeypatch, B):
     def finish():
         monkeypatch.setattr(ops, "conv3x3_wgrad_auto", real_w)
         monkeypatch.setattr(ops, "convT2x2_wgrad", real_t)
+        monkeypatch.setattr(ops, "convT2x2_wgrad_slots", real_ts)
         monkeypatch.setattr(ops, "conv3x3_split_wgrad_pre", real_p)
         monkeypatch.setattr(ops, "conv3x3_pre_bn_partials", real_zp)
         monkeypatch.setattr(ops, "conv3x3_fwd_bn_partials", real_zf)

@@ -1084,46 +1084,62 @@ def test_convT_slot_operands(dev, B, Cin, h, w, parts):
         assert float(out.float().abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("B,Cin,h,w", [(2, 128, 16, 32), (4, 256, 16, 16), (2, 1024, 16, 16), (1, 128, 64, 64), (3, 512, 8, 16)])
-def test_convT_backward_slot_operands(dev, B, Cin, h, w):
+@pytest.mark.parametrize("B,Cin,h,w,parts", [(2, 128, 16, 32, 2), (4, 256, 16, 16, 2), (2, 1024, 16, 16, 2), (1, 128, 64, 64, 2), (3, 512, 8, 16, 2),
+                                             (2, 128, 16, 32, 1), (4, 256, 16, 16, 1), (2, 512, 32, 32, 1)])
+def test_convT_backward_slot_operands(dev, B, Cin, h, w, parts):
     """Round 5: the ConvTranspose2d input-gradient and weight-gradient GEMMs on slot operands (fp16 hi | mid parts): dy pre-split under
     the `always` rule of a BOUND (here 20 x its maximum, as the bound of the 3x3 input gradient that writes it is that loose), x
     pre-split by its producer, the weights in K-slot form; transposed LDS reads for the weight gradient, the bias gradient as a row of
     ones in the same launch.  Each result against fp64 on the fp32 operands: 4e-6 of scale (the fp32-operand GEMMs with bf16 parts hold
-    1e-5); both block-tile configurations of the weight gradient occur (Cin % 256 == 0 or not)."""
+    1e-5); both block-tile configurations of the weight gradient occur (Cin % 256 == 0 or not).  parts = 1 (BASELINE configs[2]): one
+    part of plain bf16, unscaled -- against fp64 on the bf16-ROUNDED operands, to fp32 summation accuracy."""
     from onet_amd import ops
     Ct = Cin // 2
+    rb = (lambda t: t.to(torch.bfloat16).double()) if parts == 1 else (lambda t: t.double())
     x = torch.relu(rnd(B, Cin, h, w, seed=91))
     wt = rnd(Cin, Ct, 2, 2, seed=92, scale=0.05)
     dy = rnd(B, Ct, 2 * h, 2 * w, seed=93, scale=3e-5)
-    xr, wr = x.double().requires_grad_(True), wt.double().requires_grad_(True)
-    (F.conv_transpose2d(xr, wr, None, stride=2) * dy.double()).sum().backward()
-    db_ref = dy.double().sum((0, 2, 3))
+    xr, wr = rb(x).requires_grad_(True), rb(wt).requires_grad_(True)
+    (F.conv_transpose2d(xr, wr, None, stride=2) * rb(dy)).sum().backward()
+    db_ref = rb(dy).sum((0, 2, 3))
     dyd = dy.to(dev)
-    bound = ops.new_amax(dev)
-    bound.view(torch.float32)[::32] = 20.0 * float(dy.abs().max())
-    k = 13 - int(np.floor(np.log2(20.0 * float(dy.abs().max()))))
-    dyP = ops.split_pack_act(dyd, f16=True, scale=2.0 ** k)
-    xP = ops.split_pack_act(x.to(dev), f16=True)
-    dx = ops.convT2x2_dgrad_slots(dyP, ops.packT2x2_slots(wt.to(dev), dgrad=True)[1], Cin, dy_slots=bound)
+    if parts == 2:
+        bound = ops.new_amax(dev)
+        bound.view(torch.float32)[::32] = 20.0 * float(dy.abs().max())
+        k = 13 - int(np.floor(np.log2(20.0 * float(dy.abs().max()))))
+        dyP = ops.split_pack_act(dyd, f16=True, scale=2.0 ** k)
+    else:
+        bound, dyP = None, ops.split_pack_act(dyd, parts=1)
+    xP = ops.split_pack_act(x.to(dev), f16=True, parts=parts)
+    dx = ops.convT2x2_dgrad_slots(dyP, ops.packT2x2_slots(wt.to(dev), parts, dgrad=True)[1], Cin, dy_slots=bound)
     assert dx is not None
     close(dx, xr.grad, tol=4e-6, what="slot-operand ConvTranspose2d input gradient")
     got = ops.convT2x2_wgrad_slots(xP, dyP, (Cin, Ct, 2, 2), dy_slots=bound, want_dbias=True)
     assert got is not None
     close(got[0], wr.grad, tol=4e-6, what="slot-operand ConvTranspose2d weight gradient")
-    assert float((got[1].double().cpu() - db_ref).abs().max()) <= 4e-6 * float(dy.double().abs().sum((0, 2, 3)).max()), "bias gradient"
+    assert float((got[1].double().cpu() - db_ref).abs().max()) <= 4e-6 * float(rb(dy).abs().sum((0, 2, 3)).max()), "bias gradient"
 
 
-@pytest.mark.parametrize("B,Cd,Ca,H,W", [(4, 64, 128, 32, 64), (2, 128, 256, 16, 32), (2, 64, 128, 48, 96)])
-def test_conv3x3_dgrad_with_presplit_upper_half(dev, B, Cd, Ca, H, W):
+@pytest.mark.parametrize("B,Cd,Ca,H,W,parts", [(4, 64, 128, 32, 64, 2), (2, 128, 256, 16, 32, 2), (2, 64, 128, 48, 96, 2),
+                                               (4, 64, 128, 32, 64, 1), (2, 128, 256, 16, 32, 1), (2, 64, 128, 48, 96, 1)])
+def test_conv3x3_dgrad_with_presplit_upper_half(dev, B, Cd, Ca, H, W, parts):
     """onet_conv3x3_split_dgrad_pre_slots (round 5): the input gradient of a decoder block's first convolution writes the channels of
     the up-sampled half pre-split for the ConvTranspose2d backward GEMMs -- the skip half must equal the plain launch bit for bit, the
     slots must equal the split of the plain launch's fp32 values under the scale of the bound (onet_conv3x3_dgrad_bound), and the bound
-    must really bound."""
+    must really bound.  parts = 1: plain bf16 operands (conv3x3_pre16_kernel; an 8 x 8 transposition over eight lanes in its epilogue):
+    the slots are the bf16 roundings of the plain launch's fp32 values."""
     import math
     from onet_amd import ops
     dz = (rnd(B, Cd, H, W, seed=95) * 1e-3).to(dev)
     w3 = rnd(Cd, Ca, 3, 3, seed=96, scale=(2.0 / (9 * Ca)) ** 0.5).to(dev)
+    if parts == 1:
+        _, qd = ops.pack3x3_plain16(w3)
+        dzP = ops.split_pack_act(dz, parts=1)
+        ref = ops.conv3x3_split_pre(dzP, qd, Ca)
+        da, daP = ops.conv3x3_split_dgrad_pre_slots(dzP, qd, Ca, Ca // 2, None)
+        assert torch.equal(da[:, :Ca // 2], ref[:, :Ca // 2])
+        assert torch.equal(daP, ops.split_pack_act(ref[:, Ca // 2:].contiguous(), parts=1))
+        return
     _, qd = ops.pack3x3_split(w3)
     sl = ops.absmax_slots(dz)
     k = 13 - math.floor(math.log2(float(dz.abs().max())))
