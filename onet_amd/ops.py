@@ -1021,14 +1021,13 @@ AMAX_ARENA_ROWS = 192
 
 def amax_arena_reset(device):
     """One fill zeroes a step's worth of magnitude slots (Onet.forward calls this; ~70 sets per training step): new_amax then hands
-    out rows instead of launching a fill each.  Everything is ordered on the one stream the model runs on; a set handed out before a
-    reset is only ever read by kernels launched before it."""
+    out rows instead of launching a fill each."""
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
-    ar = _AMAX_ARENA.get(key)
-    if ar is None:
-        ar = _AMAX_ARENA[key] = [torch.empty((AMAX_ARENA_ROWS, AMAX_SLOTS), dtype=torch.int32, device=device), 0]
+    # a FRESH block per forward (1.5 MB from the caching allocator: no device malloc in steady state): the rows a forward handed out are
+    # read again by its backward (ctx.x_slots: the weight gradient undoes the activation's scale), so a second forward before that backward
+    # -- gradient accumulation, another model on the device, an eval pass -- must not zero or re-issue them; the rows keep their block alive
+    ar = _AMAX_ARENA[key] = [torch.empty((AMAX_ARENA_ROWS, AMAX_SLOTS), dtype=torch.int32, device=device), 0]
     fill(ar[0].view(torch.float32), 0.0)
-    ar[1] = 0
 
 
 def new_amax(device):

@@ -394,6 +394,37 @@ def test_flat_adam_skipped_parameters_follow_torch_adam(dev):
     assert oa._steps is not None and sorted(set(oa._steps)) == [3, 5]
 
 
+def test_second_forward_before_backward_keeps_the_first_one_intact(dev):
+    """Two forwards, then the FIRST one's backward (gradient accumulation, an eval pass in between, another model on the device): the
+    magnitude slots a forward hands out are read again by its backward (the weight gradients undo the activations' guard scales), so a
+    later forward must neither zero nor re-issue them (round 4 re-used one block per device).  BatchNorm gains of 4e3 put the
+    activation bounds beyond fp16's range, so the guard scales are really in use; the gradients of forward 1 must be bit-identical
+    with and without the forward in between (same running-statistics updates in both runs)."""
+    import torch.nn as nn
+    X1, X2 = orc.det_input(2, 1, 64, 64, seed=31).to(dev), 3.0 * orc.det_input(2, 1, 64, 64, seed=32).to(dev)
+
+    def run(second):
+        m = _model(1, True, dev)
+        with torch.no_grad():
+            for mod in m.modules():
+                if isinstance(mod, nn.BatchNorm2d):
+                    mod.weight.mul_(4e3)
+        m.zero_grad()
+        Lt, Vt, Ld, Vd, S = m(X1)
+        loss = m.compute_loss(Lt, S[:, 0].unsqueeze(1), Ld, S[:, 1].unsqueeze(1))
+        if second:
+            m(X2)                                   # its own graph, dropped; its slots must be other rows
+        else:
+            torch.cuda.synchronize()
+        loss.backward()
+        return [p.grad.detach().clone() for p in m.parameters()]
+
+    a, b = run(False), run(True)
+    assert all(torch.isfinite(g).all() for g in a)
+    for ga, gb in zip(a, b):
+        assert torch.equal(ga, gb)
+
+
 def _step_nozero(m, X):
     Lt, Vt, Ld, Vd, S = m(X)
     loss = m.compute_loss(Lt, S[:, 0].unsqueeze(1), Ld, S[:, 1].unsqueeze(1))
