@@ -2,6 +2,7 @@
 // Replaces nn.BatchNorm2d + nn.ReLU(inplace=True) at OV:48-49,52-53 and their autograd.
 // All kernels are HBM-bound streaming passes: float4 loads, wave-shuffle reductions,
 // deterministic two-stage per-channel reductions (partials -> fp64 finalize), no atomics.
+#include <type_traits>
 #include "common.hpp"
 
 using namespace onet;
@@ -362,7 +363,14 @@ __device__ __forceinline__ void bn_store_slots(unsigned* __restrict__ xs, int64_
 // write transactions: measured 0.108 against 0.085 ms per launch for the forward pass).  So a 256-thread block trades its 1024
 // pixels x 2 parts through LDS (one padding slot per four: the 64-byte lane stride of the writes becomes 80 bytes, conflict-free
 // per 16 lanes) and stores lane-linear: every store instruction writes 1 KB of consecutive slots.
-constexpr int BN_TR_SLOTS = 2 * (1024 + 256);       // 40 KB of LDS per block
+constexpr int BN_TR_SLOTS = 2 * (1024 + 256);       // 40 KB of LDS per block -- HALF of it with one part (plain bf16): the launches ask
+                                                    // for what they use, so that twice the blocks fit a CU where the pass moves half the
+                                                    // bytes per thread (a streaming pass runs at bytes in flight / latency)
+__device__ __forceinline__ bn_u32x4* bn_tr_lds() {
+    extern __shared__ __attribute__((aligned(16))) unsigned char bn_dyn_lds[];
+    return reinterpret_cast<bn_u32x4*>(bn_dyn_lds);
+}
+static inline unsigned bn_tr_bytes(int nparts) { return (unsigned)(nparts == 1 ? BN_TR_SLOTS / 2 : BN_TR_SLOTS) * 16u; }
 #ifndef BN_APPLY_SPLIT_TR
 #define BN_APPLY_SPLIT_TR 1
 #endif
@@ -459,7 +467,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_split_kernel(const ZT* __re
     if (gimg) save += (int64_t)(b / gimg) * 4 * C;        // statistics groups = consecutive batch slices of gimg images, save [G][4][C]
 #if BN_APPLY_SPLIT_TR
     {   // variant: four CONSECUTIVE pixels per thread (float4 loads) and the block's slots traded through LDS for coalesced stores
-        __shared__ bn_u32x4 tr[BN_TR_SLOTS];
+        bn_u32x4* const tr = bn_tr_lds();            // 40 KB (np = 2) / 20 KB (np = 1: one part) of dynamic LDS
         const int HW = H * W, p = (blk * 256 + threadIdx.x) * 4;
         const bool live = p < HW;
         const ZT* src = z + (int64_t)b * z_bs + (int64_t)c8 * 8 * HW + p;
@@ -562,7 +570,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_pool_split_kernel(const ZT*
     if (xs) {
         // the patch rows' slots leave through the block transpose (coalesced stores), one round per patch row: block pixel px =
         // (thread px / 4, column px % 4) of that row
-        __shared__ bn_u32x4 tr[BN_TR_SLOTS];
+        bn_u32x4* const tr = bn_tr_lds();            // 40 KB (np = 2) / 20 KB (np = 1: one part) of dynamic LDS
         unsigned* o = xs + (int64_t)b * xs_bs;
         const int npatch = Hp * W4, patch0 = blk * 256;
 #pragma unroll
@@ -598,8 +606,11 @@ __global__ __launch_bounds__(256) void bn_relu_apply_pool_split_kernel(const ZT*
 // dz of the BatchNorm + ReLU backward (bn_relu_bwd_apply_kernel's arithmetic: fp64 per element, rounded once) pre-split: fp16 parts
 // of 2^k dz with k = amax_scale(bound) from the magnitude slots (`slots`: an upper bound of |dz| written by bn_bwd_bound_kernel
 // BEFORE this pass; the consumers read the same slots and undo 2^k on their accumulators).  8 channels x 4 pixels per thread.
+#ifndef BN_BWD_OCC16
+#define BN_BWD_OCC16 4
+#endif
 template <typename ZT = float>
-__global__ __launch_bounds__(256) void bn_relu_bwd_apply_split_kernel(const float* __restrict__ da, int64_t da_bs, const ZT* __restrict__ z,
+__global__ __launch_bounds__(256, sizeof(ZT) == 2 ? BN_BWD_OCC16 : 3) void bn_relu_bwd_apply_split_kernel(const float* __restrict__ da, int64_t da_bs, const ZT* __restrict__ z,
                                                                       int64_t z_bs, const float* __restrict__ save, const float* __restrict__ coef,
                                                                       unsigned* __restrict__ dzs, int64_t dzs_bs, const unsigned* __restrict__ slots,
                                                                       int C, int H, int W, int bpp, int np, int gimg) {
@@ -611,15 +622,20 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_split_kernel(const floa
         save += (int64_t)(b / gimg) * 4 * C;
         if (coef) coef += (int64_t)(b / gimg) * 4 * C;
     }
-    __shared__ bn_u32x4 tr[BN_TR_SLOTS];
+    bn_u32x4* const tr = bn_tr_lds();            // 40 KB (np = 2) / 20 KB (np = 1: one part) of dynamic LDS
     const int HW = H * W, p = (blk * 256 + threadIdx.x) * 4;
     const bool live = p < HW;                     // (HW % 4 == 0: a thread's four pixels are all inside or all outside)
     const ZT* zs = z + (int64_t)b * z_bs + (int64_t)c8 * 8 * HW + p;
     const float* ds = da + (int64_t)b * da_bs + (int64_t)c8 * 8 * HW + p;
-    float4 zq[8], gq[8];
+    // (a bf16 z stays PACKED in registers until it is used: 16 VGPRs instead of 32 -- the kernel fits 128 registers and a fourth
+    // block per CU, which is what a pass with a third fewer bytes per thread in flight needs to reach the same rate)
+    constexpr bool Z16 = sizeof(ZT) == 2;
+    typename std::conditional<Z16, uint2, float4>::type zq[8];
+    float4 gq[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {                 // all sixteen 16-byte loads in flight before the first use
-        zq[k] = live ? bn_ldz4<ZT>(zs + (int64_t)k * HW) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < 8; ++k) {                 // all sixteen loads in flight before the first use
+        if constexpr (Z16) zq[k] = live ? *reinterpret_cast<const uint2*>(zs + (int64_t)k * HW) : make_uint2(0u, 0u);
+        else zq[k] = live ? *reinterpret_cast<const float4*>(zs + (int64_t)k * HW) : make_float4(0.f, 0.f, 0.f, 0.f);
         gq[k] = live ? *reinterpret_cast<const float4*>(ds + (int64_t)k * HW) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float v[4][8];
@@ -629,7 +645,14 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_split_kernel(const floa
         const float mean = save[c], invstd = save[C + c], sc = save[2 * C + c], sh = save[3 * C + c];
         const double c1 = coef ? (double)coef[c] + (double)coef[C + c] : 0.0;
         const double c2 = coef ? (double)coef[2 * C + c] + (double)coef[3 * C + c] : 0.0;
-        const float zz[4] = {zq[k].x, zq[k].y, zq[k].z, zq[k].w}, gg[4] = {gq[k].x, gq[k].y, gq[k].z, gq[k].w};
+        float zz[4];
+        if constexpr (Z16) {
+            zz[0] = __builtin_bit_cast(float, zq[k].x << 16); zz[1] = __builtin_bit_cast(float, zq[k].x & 0xffff0000u);
+            zz[2] = __builtin_bit_cast(float, zq[k].y << 16); zz[3] = __builtin_bit_cast(float, zq[k].y & 0xffff0000u);
+        } else {
+            zz[0] = zq[k].x; zz[1] = zq[k].y; zz[2] = zq[k].z; zz[3] = zq[k].w;
+        }
+        const float gg[4] = {gq[k].x, gq[k].y, gq[k].z, gq[k].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const double dy = fmaf(zz[e] - mean, sc, sh) > 0.f ? (double)gg[e] : 0.0;
@@ -1002,10 +1025,10 @@ int onet_bn_relu_apply_split(const void* z, int z_bf16, int64_t z_bs, void* xs, 
     const int64_t blocks = (int64_t)B * (C / 8) * bpp;
     ONET_REQUIRE(blocks < (1ll << 31) && (int64_t)H * W < (1 << 24), "bn_relu_apply_split: grid too large");
     if (z_bf16)
-        hipLaunchKernelGGL(bn_relu_apply_split_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const __bf16*)z, z_bs,
+        hipLaunchKernelGGL(bn_relu_apply_split_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), bn_tr_bytes(nparts), as_stream(stream), (const __bf16*)z, z_bs,
                            (unsigned*)xs, xs_bs, a, a_bs, save, C, H, W, bpp, nparts, (const unsigned*)act_amax, group_images);
     else
-        hipLaunchKernelGGL(bn_relu_apply_split_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)z, z_bs,
+        hipLaunchKernelGGL(bn_relu_apply_split_kernel<float>, dim3((unsigned)blocks), dim3(256), bn_tr_bytes(nparts), as_stream(stream), (const float*)z, z_bs,
                            (unsigned*)xs, xs_bs, a, a_bs, save, C, H, W, bpp, nparts, (const unsigned*)act_amax, group_images);
     return check_launch("bn_relu_apply_split_kernel");
 }
@@ -1023,11 +1046,11 @@ int onet_bn_relu_apply_pool_split(const void* z, int z_bf16, int64_t z_bs, void*
     const int64_t blocks = (int64_t)B * (C / 8) * bpp;
     ONET_REQUIRE(blocks < (1ll << 31) && (int64_t)H * W < (1 << 24), "bn_relu_apply_pool_split: grid too large");
     if (z_bf16)
-        hipLaunchKernelGGL(bn_relu_apply_pool_split_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const __bf16*)z, z_bs,
+        hipLaunchKernelGGL(bn_relu_apply_pool_split_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), bn_tr_bytes(nparts), as_stream(stream), (const __bf16*)z, z_bs,
                            (unsigned*)xs, xs_bs, a, a_bs, (unsigned*)ys, ys_bs, y, y_bs, save, C, H, W, bpp, nparts, (const unsigned*)act_amax,
                            group_images);
     else
-        hipLaunchKernelGGL(bn_relu_apply_pool_split_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const float*)z, z_bs,
+        hipLaunchKernelGGL(bn_relu_apply_pool_split_kernel<float>, dim3((unsigned)blocks), dim3(256), bn_tr_bytes(nparts), as_stream(stream), (const float*)z, z_bs,
                            (unsigned*)xs, xs_bs, a, a_bs, (unsigned*)ys, ys_bs, y, y_bs, save, C, H, W, bpp, nparts, (const unsigned*)act_amax,
                            group_images);
     return check_launch("bn_relu_apply_pool_split_kernel");
@@ -1045,10 +1068,10 @@ int onet_bn_relu_bwd_apply_split(const float* da, int64_t da_bs, const void* z, 
     const int64_t blocks = (int64_t)B * (C / 8) * bpp;
     ONET_REQUIRE(blocks < (1ll << 31) && (int64_t)H * W < (1 << 24), "bn_relu_bwd_apply_split: grid too large");
     if (z_bf16)
-        hipLaunchKernelGGL(bn_relu_bwd_apply_split_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), da, da_bs,
+        hipLaunchKernelGGL(bn_relu_bwd_apply_split_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), bn_tr_bytes(nparts), as_stream(stream), da, da_bs,
                            (const __bf16*)z, z_bs, save, coef, (unsigned*)dzs, dzs_bs, (const unsigned*)dz_amax, C, H, W, bpp, nparts, group_images);
     else
-        hipLaunchKernelGGL(bn_relu_bwd_apply_split_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), da, da_bs,
+        hipLaunchKernelGGL(bn_relu_bwd_apply_split_kernel<float>, dim3((unsigned)blocks), dim3(256), bn_tr_bytes(nparts), as_stream(stream), da, da_bs,
                            (const float*)z, z_bs, save, coef, (unsigned*)dzs, dzs_bs, (const unsigned*)dz_amax, C, H, W, bpp, nparts, group_images);
     return check_launch("bn_relu_bwd_apply_split_kernel");
 }
