@@ -31,4 +31,10 @@ for (B, C, H) in [(256, 64, 256), (256, 128, 128), (256, 256, 64)]:
         t = timeit(lambda: lib.onet_bn_relu_apply_split(z.data_ptr(), int(zs == 2), C * H * H, aP.data_ptr(), ops._pbs(aP), None, 0, save.data_ptr(), None, 1, 0,
                                                         B, C, H, H, st))
         line += f"  apply[{name}] {t:.3f} ms {n * (zs + 2) / t / 1e9:.0f} GB/s"
+    # the default path's form: fp32 z, fp16 (hi | mid) slots scaled by a bound
+    dzP2 = ops.p16_empty(B, C, H, H, dev, 2)
+    bound = ops.new_amax(dev); bound.view(torch.float32)[::32] = 1e-2
+    t = timeit(lambda: lib.onet_bn_relu_bwd_apply_split(da.data_ptr(), C * H * H, zf.data_ptr(), 0, C * H * H, save.data_ptr(), coef.data_ptr(),
+                                                        dzP2.data_ptr(), ops._pbs(dzP2), bound.data_ptr(), 2, 0, B, C, H, H, st))
+    line += f"  bwd_apply[fp32 z, hi|mid] {t:.3f} ms {n * 12 / t / 1e6:.0f} GB/s"
     print(os.path.basename(os.environ.get("ONET_HIP_LIB", "default")), line, flush=True)
