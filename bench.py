@@ -491,6 +491,8 @@ def main(args):
             BF16 += ("convt_gemm_kernel", "convt_wgrad_gemm_kernel")
         with ops.using(onet.settings):
             convt_split = ops.convt_operand_bf16(2 * args.batch, args.size // 2, args.size // 2, 64) == 2     # the last Up block's GEMM
+            # (round 5: on slot operands -- fp16 hi | mid parts, three MFMAs per term -- wherever the input was written pre-split)
+            convt_split = convt_split or (not bf16 and ops.presplit() and bool(ops.CONVT_SLOTS))
         if bf16:                        # conv == "bf16" through the pre-split kernels with ONE part: one MFMA per product term
             REDUCTION.update({"conv3x3_split_pre_kernel": 1.0, "conv3x3_split_wgrad_pre_kernel": 1.0})
         if convt_split:                 # ... or split bf16 operands (three bf16 MFMAs per term, fp32-level results)
@@ -515,10 +517,14 @@ def main(args):
                 "conv_wgrad_kernel": "direct split-K weight gradient on fp32 MFMA (stem, tiny maps)",
                 "stem_conv_stats_kernel": "stem convolution (Cin = n_channels) + BatchNorm statistics, one streaming VALU pass "
                                           "(bound by writing z: see hbm_frac)",
-                "convt_gemm_kernel": "ConvTranspose2d forward / input-gradient GEMMs, 128x128 DMA-fed tiles (split bf16 "
-                                     "operands, fp32-level results, by default; fp32 MFMA with Settings.split off; bf16 operands under --conv bf16)",
-                "convt_wgrad_gemm_kernel": "ConvTranspose2d weight-gradient GEMM, split-K (split bf16 operands by default; fp32 MFMA "
-                                           "with Settings.split off; bf16 operands under --conv bf16)"}
+                "convt_gemm_kernel": "ConvTranspose2d forward / input-gradient GEMMs on SLOT operands (round 5: x pre-split by the block below, "
+                                     "the up-sampled half of the concat gradient pre-split by the 3x3 input gradient that produces it, weights in "
+                                     "K-slot packs; fp16 hi | mid parts, 3 x v_mfma_f32_32x32x16_f16 per term, every fragment one ds_read_b128 of a "
+                                     "DMA-copied slot; one part of plain bf16 under --conv bf16); 128x128 tiles, 4 blocks per CU; fp32 operands "
+                                     "(split or rounded in registers) where the slot path does not apply",
+                "convt_wgrad_gemm_kernel": "ConvTranspose2d weight-gradient GEMM on slot operands (transposing LDS reads ds_read_b64_tr_b16, "
+                                           "256x256 tiles of 8 waves where Cin % 256 == 0, split-K, bias gradient as a row of ones in the same "
+                                           "launch); fp32 operands where the slot path does not apply"}
         def kernel_table(records, where):
             tab = {}
             for kind, recs in records.items():
@@ -613,7 +619,8 @@ def main(args):
                              "fp16 parts of a power-of-two-scaled value: 22-bit operands, 3 MFMAs per term, f32 accumulate; error vs fp64 5e-8..1.5e-7 "
                              "rms of the output scale forward, 3e-7 max on the weight gradient), their operands stored PRE-SPLIT by the producing "
                              "BatchNorm / pooling / ConvTranspose2d kernels (same values as the fp32 passes: forward bit-identical to fp32 storage); "
-                             "ConvTranspose2d GEMMs on bf16 parts split in registers (16-bit operands); every gradient element within 2e-4 of the "
+                             "ConvTranspose2d GEMMs on the same kind of slots in all three directions (22-bit operands; round 4: bf16 parts split in "
+                             "registers); every gradient element within 2e-4 of the "
                              "fp64 oracle under the run's own decisions incl. this B=32 dispatch (tests/test_gpu_gradients.py: 9.5e-5; the "
                              "fp32-MFMA-only dispatch: 4.6e-5 on the comparable case); Settings(split=False) keeps the fp32-MFMA Winograd kernels "
                              "(timed in f32_mfma_only)") if (conv in ("auto", "split") and ops.split_enabled()) else "f32 throughout (fp32 MFMA)",
