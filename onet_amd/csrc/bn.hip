@@ -757,7 +757,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const float* __
     }
 }
 
-__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ part2, int nparts,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part2, int nparts,
                                                              double count, float* dgamma, float* dbeta,
                                                              float* coef, int accumulate, int C, const float* __restrict__ save = nullptr,
                                                              const unsigned* __restrict__ da_slots = nullptr,
@@ -766,6 +766,10 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __rest
     // saving that launch; da_slots must be complete (every reduce launch of the tensor precedes the first finalize).
     // groups > 1: the statistics groups of a twin batch in one launch: records [g][nparts][C][4], coef / save [g][4][C]; dgamma / dbeta
     // take the groups' sums one after the other in fp32, as one accumulating launch per group did
+    // (256 threads per channel: a layer's 4096 .. 8192 records per group were a 64 .. 128-iteration chain of dependent fp64 adds per
+    // thread with 64 -- 16 us per launch, 18 launches per step on the critical path; fixed summation order: waves, then the four
+    // wave sums in index order)
+    __shared__ double wsum[2][4];
     const float da_max = dz_slots ? amax_read(da_slots) : 0.f;
     const int c = blockIdx.x;
     float acc_b = 0.f, acc_g = 0.f;
@@ -776,14 +780,22 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __rest
     for (int g = 0; g < groups; ++g) {
         const float* rec = part2 + (int64_t)g * nparts * C * 4;
         double s = 0.0, sx = 0.0;
-        for (int p = threadIdx.x; p < nparts; p += 64) {
-            const float* o = rec + ((int64_t)p * C + c) * 4;
-            s += (double)o[0] + (double)o[1];
-            sx += (double)o[2] + (double)o[3];
+        for (int p = threadIdx.x; p < nparts; p += 256) {
+            const float4 o = *reinterpret_cast<const float4*>(rec + ((int64_t)p * C + c) * 4);
+            s += (double)o.x + (double)o.y;
+            sx += (double)o.z + (double)o.w;
         }
         s = wave_sum(s);
         sx = wave_sum(sx);
+        __syncthreads();                                   // (the previous group's sums have been read)
+        if ((threadIdx.x & 63) == 0) {
+            wsum[0][threadIdx.x >> 6] = s;
+            wsum[1][threadIdx.x >> 6] = sx;
+        }
+        __syncthreads();
         if (threadIdx.x == 0) {
+            s = ((wsum[0][0] + wsum[0][1]) + wsum[0][2]) + wsum[0][3];
+            sx = ((wsum[1][0] + wsum[1][1]) + wsum[1][2]) + wsum[1][3];
             const bool first = g == 0 && !accumulate;
             acc_b = first ? (float)s : acc_b + (float)s;
             acc_g = first ? (float)sx : acc_g + (float)sx;
@@ -1087,7 +1099,7 @@ int onet_bn_bwd_finalize_cm(const float* part2, int nparts, int64_t c_stride, in
 int onet_bn_bwd_finalize(const float* part2, int nparts, int64_t count, float* dgamma, float* dbeta, float* coef, int accumulate,
                                int groups, int C, const float* save, const void* da_amax, void* dz_amax, void* stream) {
     ONET_REQUIRE(part2 && nparts > 0 && count > 0 && C > 0 && groups >= 1 && (!dz_amax || (save && da_amax)), "bn_bwd_finalize: bad args");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, as_stream(stream), part2, nparts, (double)count, dgamma, dbeta, coef,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, as_stream(stream), part2, nparts, (double)count, dgamma, dbeta, coef,
                        accumulate, C, save, (const unsigned*)da_amax, (unsigned*)dz_amax, sqrtf((float)(count > 1 ? count - 1 : 1)), groups);
     return check_launch("bn_bwd_finalize_kernel");
 }
