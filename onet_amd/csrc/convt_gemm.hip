@@ -134,7 +134,7 @@ struct GArgs {
     float* out;           // forward: y window;       dgrad: dx;                              wgrad: slab [splitK][Cin][4Ct]
     const float* bias;
     float* dbias_part;    // dgrad: [nTiles][Ct] partial sums of dy over the tile's pixels (blocks with mt == 0), or NULL
-    __bf16* out16;        // forward: optional bf16 copy of y (operand storage for the bf16 conv kernels), batch stride out16_bs
+    __bf16* out16;        // forward: the pre-split destination (out16_split != 0), batch stride out16_bs
     int64_t out16_bs;
     int64_t a_bs, b_bs, out_bs;
     int B, Cin, Ct, h, w, Wo, HoWo;   // y / dy plane: Ho x Wo with Ho = 2h, Wo = 2w (fast path: no F.pad offsets)
@@ -316,12 +316,6 @@ __global__ __launch_bounds__(256, 2) void convt_gemm_kernel(GArgs g) {
                     if (g.out) {
                         *reinterpret_cast<float2*>(o) = make_float2(v0, v1);
                         *reinterpret_cast<float2*>(o + g.Wo) = make_float2(v2, v3);
-                    }
-                    if (g.out16 && !g.out16_split) {
-                        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-                        __bf16* o16 = g.out16 + (int64_t)b * g.out16_bs + oo;
-                        *reinterpret_cast<bf2*>(o16) = bf2{(__bf16)v0, (__bf16)v1};
-                        *reinterpret_cast<bf2*>(o16 + g.Wo) = bf2{(__bf16)v2, (__bf16)v3};
                     }
                 }
                 if (g.out16 && g.out16_split) {
@@ -1232,7 +1226,7 @@ int convt_gemm_fwd(const float* x, int64_t x_bs, const float* wq, const float* b
         (x_bs & 3) || (reinterpret_cast<uintptr_t>(y) & 7) || (y_bs & 1) || (int64_t)Cin * hw * 4 >= (1ll << 31) ||
         (int64_t)Cin * 4 * Ct * 4 >= (1ll << 31))
         return 1;
-    if (y16 && !y16_split && ((reinterpret_cast<uintptr_t>(y16) & 3) || (y16_bs & 1))) return 1;
+    if (y16 && !y16_split) return 1;                   // (round 2's plain bf16 copy of y is gone with the kernels that read it)
     if (y16 && y16_split && ((reinterpret_cast<uintptr_t>(y16) & 15) || (y16_bs & 3) || (Ct % 32))) return 1;
     if (!y && !y16) return 1;
     GArgs g{wq, x, y, bias, nullptr, (__bf16*)y16, y16_bs, 0, x_bs, y_bs, B, Cin, Ct, h, w, Wo, Ho * Wo, (4 * Ct) / 128, (int)(B * hw / 128), 1, 0, y16_split, (const unsigned*)out_slots};
