@@ -443,26 +443,22 @@ int onet_bilinear2x_bwd(const float* dy, int64_t dy_bs, float* dx, int64_t dx_bs
 int onet_complement_clip(const float* x, float* y, float bias, int64_t n, void* stream);
 
 /* ---- K8/K9: head einsum + 2-way softmax (OV:176-189) ----------------------- */
-/* Vt = sum_c Lt*Ht, Vd = sum_c Ld*Hd, S = softmax([Vt,Vd]) -> S [B][2][HW] */
-int onet_head_softmax_fwd(const float* Lt, int64_t Lt_bs, const float* Ht, int64_t Ht_bs,
-                          const float* Ld, int64_t Ld_bs, const float* Hd, int64_t Hd_bs,
-                          float* Vt, float* Vd, float* S, int B, int C, int HW, void* stream);
-/* given dVt,dVd,dS (each nullable) and S: total dV, then dL = dV*H, dH = dV*L per branch */
-int onet_head_softmax_bwd(const float* dVt, const float* dVd, const float* dS, const float* S,
-                          const float* Lt, int64_t Lt_bs, const float* Ht, int64_t Ht_bs,
-                          const float* Ld, int64_t Ld_bs, const float* Hd, int64_t Hd_bs,
-                          float* dLt, float* dHt, float* dLd, float* dHd,
+/* Vt = sum_c Lt*Ht, Vd = sum_c Ld*Hd, S = softmax([Vt,Vd]) -> S [B][2][HW].
+ * sLt, sLd (both or neither; [B][HW]): the per-pixel channel sums sL = sum_c L[c] as a by-product -- the only thing
+ * jensen_shannon_divergence (OV:221-235) needs of L.
+ * h_save_t, h_save_d (both or neither, round 5): Ht / Hd then hold the PRE-ACTIVATION z of the network's last Conv-BatchNorm-ReLU unit
+ * and these are its coefficients [4][C] (onet_bn_finalize's `save`) for the two statistics groups: H = relu(bn(z)) is formed on load,
+ * bit for bit what onet_bn_relu_apply writes -- the last activation tensor (OV:53 of up4) is never materialised. */
+int onet_head_softmax_fwd(const float* Lt, int64_t Lt_bs, const float* Ht, int64_t Ht_bs, const float* Ld, int64_t Ld_bs, const float* Hd,
+                          int64_t Hd_bs, float* Vt, float* Vd, float* S, float* sLt, float* sLd, const float* h_save_t, const float* h_save_d,
                           int B, int C, int HW, void* stream);
-/* The same head with the per-pixel channel sums sL = sum_c L[c] as a by-product (sLt, sLd: [B][HW]) -- the only thing
- * jensen_shannon_divergence (OV:221-235) needs of L -- and, in backward, with their gradients gsLt / gsLd (NULL = 0)
- * folded into dLt / dLd, so that the loss neither re-reads L nor costs a full-tensor gradient add. */
-int onet_head_softmax_sums_fwd(const float* Lt, int64_t Lt_bs, const float* Ht, int64_t Ht_bs, const float* Ld,
-                               int64_t Ld_bs, const float* Hd, int64_t Hd_bs, float* Vt, float* Vd, float* S,
-                               float* sLt, float* sLd, int B, int C, int HW, void* stream);
-int onet_head_softmax_sums_bwd(const float* dVt, const float* dVd, const float* dS, const float* gsLt, const float* gsLd,
-                               const float* S, const float* Lt, int64_t Lt_bs, const float* Ht, int64_t Ht_bs,
-                               const float* Ld, int64_t Ld_bs, const float* Hd, int64_t Hd_bs, float* dLt, float* dHt,
-                               float* dLd, float* dHd, int B, int C, int HW, void* stream);
+/* given dVt, dVd, dS (each nullable) and S: total dV, then dL = dV*H, dH = dV*L per branch; gsLt / gsLd (NULL = 0): the gradients of
+ * the channel sums, folded into dLt / dLd, so that the loss neither re-reads L nor costs a full-tensor gradient add; h_save_*: as above
+ * (dH is then the gradient of the unit's OUTPUT, which its BatchNorm backward takes as usual). */
+int onet_head_softmax_bwd(const float* dVt, const float* dVd, const float* dS, const float* gsLt, const float* gsLd, const float* S,
+                          const float* Lt, int64_t Lt_bs, const float* Ht, int64_t Ht_bs, const float* Ld, int64_t Ld_bs, const float* Hd,
+                          int64_t Hd_bs, float* dLt, float* dHt, float* dLd, float* dHd, const float* h_save_t, const float* h_save_d, int B,
+                          int C, int HW, void* stream);
 
 /* ---- K10: JSD loss with the reference's log1pexp quirk (OV:221-267) ---------- */
 /* One jsd term, Onet.jensen_shannon_divergence(Li, Si, Sprime) (OV:221-235):
@@ -471,7 +467,7 @@ int onet_head_softmax_sums_bwd(const float* dVt, const float* dVd, const float* 
  * Si/Sp: [B][HW] with batch stride (slices of S).  sums [B*HW] saves sL for backward;
  * part: >= onet_jsd_nparts() doubles of scratch; jsd: 1 float.
  * compute_loss (OV:253-267) = -(jsd(Lt,St,Sd) + jsd(Ld,Sd,St)) / 2 is composed by the caller. */
-/* (L may be NULL: `sums` is then an INPUT, the channel sums from onet_head_softmax_sums_fwd) */
+/* (L may be NULL: `sums` is then an INPUT, the channel sums from onet_head_softmax_fwd) */
 int onet_jsd_fwd(const float* L, int64_t L_bs, const float* Si, int64_t Si_bs,
                  const float* Sp, int64_t Sp_bs, float* sums, double* part, float* jsd,
                  int B, int C, int HW, void* stream);

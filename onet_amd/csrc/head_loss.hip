@@ -43,7 +43,11 @@ __global__ __launch_bounds__(256) void head_softmax_fwd_kernel(const float* __re
                                                                const float* __restrict__ Hd, int64_t Hd_bs,
                                                                float* __restrict__ Vt, float* __restrict__ Vd,
                                                                float* __restrict__ S, float* __restrict__ sLt,
-                                                               float* __restrict__ sLd, int B, int C, int HW) {
+                                                               float* __restrict__ sLd, const float* __restrict__ nt,
+                                                               const float* __restrict__ nd, int B, int C, int HW) {
+    // nt / nd (round 5, may be NULL): Ht / Hd hold the PRE-ACTIVATION z of the last Conv-BatchNorm-ReLU unit and these are its
+    // coefficients [4][C] (mean, invstd, scale, shift) for the top / down statistics group: H = max(fma(z - mean, scale, shift), 0) is
+    // formed here -- bit for bit what bn_relu_apply_kernel would have written -- and the activation tensor is never materialised
     const int64_t n = (int64_t)B * HW;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int b = (int)(i / HW);
@@ -55,8 +59,13 @@ __global__ __launch_bounds__(256) void head_softmax_fwd_kernel(const float* __re
         float vt = 0.f, vd = 0.f, st_ = 0.f, sd_ = 0.f;   // st_/sd_: sum_c L[c] in jsd_fwd_kernel's order (bit-identical)
         for (int c = 0; c < C; ++c) {
             const float a = lt[(int64_t)c * HW], d = ld[(int64_t)c * HW];
-            vt = fmaf(a, ht[(int64_t)c * HW], vt);
-            vd = fmaf(d, hd[(int64_t)c * HW], vd);
+            float h1 = ht[(int64_t)c * HW], h2 = hd[(int64_t)c * HW];
+            if (nt) {
+                h1 = fmaxf(fmaf(h1 - nt[c], nt[2 * C + c], nt[3 * C + c]), 0.f);
+                h2 = fmaxf(fmaf(h2 - nd[c], nd[2 * C + c], nd[3 * C + c]), 0.f);
+            }
+            vt = fmaf(a, h1, vt);
+            vd = fmaf(d, h2, vd);
             st_ += a;
             sd_ += d;
         }
@@ -77,7 +86,8 @@ __global__ __launch_bounds__(256) void head_softmax_bwd_kernel(
     const float* __restrict__ S, const float* __restrict__ Lt, int64_t Lt_bs, const float* __restrict__ Ht,
     int64_t Ht_bs, const float* __restrict__ Ld, int64_t Ld_bs, const float* __restrict__ Hd, int64_t Hd_bs,
     float* __restrict__ dLt, float* __restrict__ dHt, float* __restrict__ dLd, float* __restrict__ dHd,
-    const float* __restrict__ gsLt, const float* __restrict__ gsLd, int B, int C, int HW) {
+    const float* __restrict__ gsLt, const float* __restrict__ gsLd, const float* __restrict__ nt, const float* __restrict__ nd, int B,
+    int C, int HW) {
     const int64_t n = (int64_t)B * HW;
     const int64_t CHW = (int64_t)C * HW;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -105,9 +115,14 @@ __global__ __launch_bounds__(256) void head_softmax_bwd_kernel(
         const float at = gsLt ? gsLt[i] : 0.f, ad = gsLd ? gsLd[i] : 0.f;   // d loss / d (sum_c L[c]): same for every channel
         for (int c = 0; c < C; ++c) {
             const int64_t o = (int64_t)c * HW;
-            olt[o] = fmaf(gt, ht[o], at);
+            float h1 = ht[o], h2 = hd[o];
+            if (nt) {                                   // (Ht / Hd are pre-activations: see head_softmax_fwd_kernel)
+                h1 = fmaxf(fmaf(h1 - nt[c], nt[2 * C + c], nt[3 * C + c]), 0.f);
+                h2 = fmaxf(fmaf(h2 - nd[c], nd[2 * C + c], nd[3 * C + c]), 0.f);
+            }
+            olt[o] = fmaf(gt, h1, at);
             oht[o] = gt * lt[o];
-            old_[o] = fmaf(gd, hd[o], ad);
+            old_[o] = fmaf(gd, h2, ad);
             ohd[o] = gd * ld[o];
         }
     }
@@ -134,7 +149,7 @@ __global__ __launch_bounds__(256) void jsd_fwd_kernel(const float* __restrict__ 
             for (int c = 0; c < C; ++c) sl += l[(int64_t)c * HW];
             sums[i] = sl;
         } else {
-            sl = sums[i];                  // channel sums handed over by onet_head_softmax_sums_fwd
+            sl = sums[i];                  // channel sums handed over by onet_head_softmax_fwd
         }
         const float si = Si[b * Si_bs + p], sp = Sp[b * Sp_bs + p];
         acc[0] += (double)(f_quirk(-(sl * si)) + f_quirk(sl * sp));
@@ -197,44 +212,24 @@ static inline unsigned grid_px(int64_t n) {
 
 extern "C" {
 
-int onet_head_softmax_fwd(const float* Lt, int64_t Lt_bs, const float* Ht, int64_t Ht_bs, const float* Ld,
-                          int64_t Ld_bs, const float* Hd, int64_t Hd_bs, float* Vt, float* Vd, float* S, int B,
-                          int C, int HW, void* stream) {
-    ONET_REQUIRE(Lt && Ht && Ld && Hd && Vt && Vd && S && B > 0 && C > 0 && HW > 0, "head_softmax_fwd: bad args");
+int onet_head_softmax_fwd(const float* Lt, int64_t Lt_bs, const float* Ht, int64_t Ht_bs, const float* Ld, int64_t Ld_bs, const float* Hd,
+                          int64_t Hd_bs, float* Vt, float* Vd, float* S, float* sLt, float* sLd, const float* h_save_t, const float* h_save_d,
+                          int B, int C, int HW, void* stream) {
+    ONET_REQUIRE(Lt && Ht && Ld && Hd && Vt && Vd && S && (!sLt == !sLd) && (!h_save_t == !h_save_d) && B > 0 && C > 0 && HW > 0,
+                 "head_softmax_fwd: bad args");
     hipLaunchKernelGGL(head_softmax_fwd_kernel, dim3(grid_px((int64_t)B * HW)), dim3(256), 0, as_stream(stream), Lt,
-                       Lt_bs, Ht, Ht_bs, Ld, Ld_bs, Hd, Hd_bs, Vt, Vd, S, (float*)nullptr, (float*)nullptr, B, C, HW);
+                       Lt_bs, Ht, Ht_bs, Ld, Ld_bs, Hd, Hd_bs, Vt, Vd, S, sLt, sLd, h_save_t, h_save_d, B, C, HW);
     return check_launch("head_softmax_fwd_kernel");
 }
 
-int onet_head_softmax_sums_fwd(const float* Lt, int64_t Lt_bs, const float* Ht, int64_t Ht_bs, const float* Ld,
-                               int64_t Ld_bs, const float* Hd, int64_t Hd_bs, float* Vt, float* Vd, float* S,
-                               float* sLt, float* sLd, int B, int C, int HW, void* stream) {
-    ONET_REQUIRE(Lt && Ht && Ld && Hd && Vt && Vd && S && sLt && sLd && B > 0 && C > 0 && HW > 0, "head_softmax_sums_fwd: bad args");
-    hipLaunchKernelGGL(head_softmax_fwd_kernel, dim3(grid_px((int64_t)B * HW)), dim3(256), 0, as_stream(stream), Lt,
-                       Lt_bs, Ht, Ht_bs, Ld, Ld_bs, Hd, Hd_bs, Vt, Vd, S, sLt, sLd, B, C, HW);
-    return check_launch("head_softmax_fwd_kernel");
-}
-
-int onet_head_softmax_bwd(const float* dVt, const float* dVd, const float* dS, const float* S, const float* Lt,
-                          int64_t Lt_bs, const float* Ht, int64_t Ht_bs, const float* Ld, int64_t Ld_bs,
-                          const float* Hd, int64_t Hd_bs, float* dLt, float* dHt, float* dLd, float* dHd, int B,
+int onet_head_softmax_bwd(const float* dVt, const float* dVd, const float* dS, const float* gsLt, const float* gsLd, const float* S,
+                          const float* Lt, int64_t Lt_bs, const float* Ht, int64_t Ht_bs, const float* Ld, int64_t Ld_bs, const float* Hd,
+                          int64_t Hd_bs, float* dLt, float* dHt, float* dLd, float* dHd, const float* h_save_t, const float* h_save_d, int B,
                           int C, int HW, void* stream) {
-    ONET_REQUIRE(S && Lt && Ht && Ld && Hd && dLt && dHt && dLd && dHd && B > 0 && C > 0 && HW > 0,
+    ONET_REQUIRE(S && Lt && Ht && Ld && Hd && dLt && dHt && dLd && dHd && (!h_save_t == !h_save_d) && B > 0 && C > 0 && HW > 0,
                  "head_softmax_bwd: bad args");
     hipLaunchKernelGGL(head_softmax_bwd_kernel, dim3(grid_px((int64_t)B * HW)), dim3(256), 0, as_stream(stream), dVt,
-                       dVd, dS, S, Lt, Lt_bs, Ht, Ht_bs, Ld, Ld_bs, Hd, Hd_bs, dLt, dHt, dLd, dHd, (const float*)nullptr,
-                       (const float*)nullptr, B, C, HW);
-    return check_launch("head_softmax_bwd_kernel");
-}
-
-int onet_head_softmax_sums_bwd(const float* dVt, const float* dVd, const float* dS, const float* gsLt, const float* gsLd,
-                               const float* S, const float* Lt, int64_t Lt_bs, const float* Ht, int64_t Ht_bs,
-                               const float* Ld, int64_t Ld_bs, const float* Hd, int64_t Hd_bs, float* dLt, float* dHt,
-                               float* dLd, float* dHd, int B, int C, int HW, void* stream) {
-    ONET_REQUIRE(S && Lt && Ht && Ld && Hd && dLt && dHt && dLd && dHd && B > 0 && C > 0 && HW > 0,
-                 "head_softmax_sums_bwd: bad args");
-    hipLaunchKernelGGL(head_softmax_bwd_kernel, dim3(grid_px((int64_t)B * HW)), dim3(256), 0, as_stream(stream), dVt,
-                       dVd, dS, S, Lt, Lt_bs, Ht, Ht_bs, Ld, Ld_bs, Hd, Hd_bs, dLt, dHt, dLd, dHd, gsLt, gsLd, B, C, HW);
+                       dVd, dS, S, Lt, Lt_bs, Ht, Ht_bs, Ld, Ld_bs, Hd, Hd_bs, dLt, dHt, dLd, dHd, gsLt, gsLd, h_save_t, h_save_d, B, C, HW);
     return check_launch("head_softmax_bwd_kernel");
 }
 

@@ -164,7 +164,12 @@ class ConvBNReLUFn(torch.autograd.Function):
             aP = p16.get("out")
             if aP is None:
                 aP = ops.p16_empty(Bz, C, Hz, Wz, z.device)
-        a = torch.empty(z.shape, dtype=torch.float32, device=z.device) if keep else ops.fp32_placeholder(z.shape, z.device)      # (z may be stored as bf16)
+        # the network's last unit (round 5): its activation has ONE reader, the head, which forms relu(bn(z)) on load from z and the
+        # coefficients -- no activation tensor, no BatchNorm + ReLU pass (a placeholder goes through the graph)
+        head = p16.get("head_link")
+        defer_head = bool(head is not None and training and G == 2 and not want and want_pool is None and z.dtype == torch.float32
+                          and ops.HEAD_NORM and not ops.PRESPLIT_KEEP_FP32)
+        a = torch.empty(z.shape, dtype=torch.float32, device=z.device) if (keep and not defer_head) else ops.fp32_placeholder(z.shape, z.device)      # (z may be stored as bf16)
         # magnitude slots: of a pre-split output the BOUND |gamma| sqrt(N - 1) + |beta| (written by the statistics finalize, before
         # the pass that needs it as the guard scale); of an fp32-only output the exact maximum (recorded by the pass that writes
         # it: what bounds a ConvTranspose2d's pre-split output downstream)
@@ -190,7 +195,10 @@ class ConvBNReLUFn(torch.autograd.Function):
                 else:
                     ops.bn_eval_coeffs(gamma, beta, running_mean, running_var, eps, save=save_all[g])
         gi = Bg if G > 1 else 0
-        if pooled is not None:
+        if defer_head:
+            head["z"], head["save"] = z, save_all
+            a_amax = None
+        elif pooled is not None:
             if not ops.bn_relu_apply_pool_split(z, save_all, aP, a if keep else None, pooled[2], pooled[0], slots=act_slots, group_images=gi):
                 raise RuntimeError("onet_amd: pre-split BatchNorm + pooling pass refused a shape ops.pre_layer_ok accepted")
         elif aP is not None:
@@ -676,9 +684,20 @@ class HeadSoftmaxTwinFn(torch.autograd.Function):
     so that compute_loss works on [B,1,H,W] tensors and its gradient re-enters here as two small maps."""
 
     @staticmethod
-    def forward(ctx, L, H):
+    def forward(ctx, L, H, head_link=None):
+        """head_link (round 5): {"z", "save"} published by the network's last Conv-BatchNorm-ReLU unit, which then wrote NO activation
+        (H is a placeholder): the head normalises and rectifies z on load -- the same bits -- in forward and backward."""
         B = L.shape[0] // 2
-        Vt, Vd, S, sLt, sLd = ops.head_softmax_fwd(L[:B], H[:B], L[B:], H[B:], want_sums=True)
+        ctx.h_save = None
+        if head_link is not None and "z" in head_link:
+            z, save = head_link.pop("z"), head_link.pop("save")
+            assert z.shape == H.shape and z.dtype == torch.float32 and save.shape[0] == 2
+            ctx.h_save = save
+            H = z
+        elif ops.is_placeholder(H):
+            raise RuntimeError("onet_amd: the head received a placeholder for the last activation without its pre-activation")
+        nrm = None if ctx.h_save is None else (ctx.h_save[0], ctx.h_save[1])
+        Vt, Vd, S, sLt, sLd = ops.head_softmax_fwd(L[:B], H[:B], L[B:], H[B:], want_sums=True, h_norm=nrm)
         ctx.save_for_backward(L, H, S)
         return Vt, Vd, S, sLt, sLd
 
@@ -686,8 +705,9 @@ class HeadSoftmaxTwinFn(torch.autograd.Function):
     def backward(ctx, dVt, dVd, dS, gsLt, gsLd):
         L, H, S = ctx.saved_tensors
         B = L.shape[0] // 2
-        dL, dH = ops.head_softmax_bwd(dVt, dVd, dS, S, L[:B], H[:B], L[B:], H[B:], twin=True, gsums=(gsLt, gsLd))
-        return dL, dH
+        nrm = None if ctx.h_save is None else (ctx.h_save[0], ctx.h_save[1])
+        dL, dH = ops.head_softmax_bwd(dVt, dVd, dS, S, L[:B], H[:B], L[B:], H[B:], twin=True, gsums=(gsLt, gsLd), h_norm=nrm)
+        return dL, dH, None
 
 
 @_carries_settings

@@ -135,7 +135,7 @@ class DoubleConv(nn.Module):
                 return ops.tag_amax(a, p16["a_amax"])
         return ops.tag_amax(a, aux.get("a_amax"))
 
-    def forward(self, x, out=None, groups=1, pool_link=None, p16_out=None, up_link=None):
+    def forward(self, x, out=None, groups=1, pool_link=None, p16_out=None, up_link=None, head_link=None):
         """`out`: optional plane-contiguous [B, Cout, H, W] destination view (the skip half of a concat buffer);
         `groups`: the batch holds that many independent BatchNorm batches (twin pass); `pool_link`: dict the second
         unit publishes its (z, save) in for the SkipPoolFn that consumes the block's output; `p16_out` (pre-split storage): {"out": pre-split destination of the
@@ -153,7 +153,7 @@ class DoubleConv(nn.Module):
                     raise RuntimeError("onet_amd: a tensor kept only pre-split reached a DoubleConv without its pre-split form")
                 p1 = {"x": xP, "x_slots": ops.p16_slots(x), "want": pre2, "up_link": up_link}
                 a1 = self._unit(x, s[0], s[1], None, groups, link_out=link, p16=p1)
-                p2 = {"x": p1.get("a"), "x_slots": p1.get("a_slots"), "want": p16_out is not None,
+                p2 = {"x": p1.get("a"), "x_slots": p1.get("a_slots"), "want": p16_out is not None, "head_link": head_link,
                       "out": None if p16_out is None else p16_out.get("out"),
                       "keep_fp32": True if p16_out is None else bool(p16_out.get("keep_fp32"))}
                 return self._unit(a1, s[3], s[4], None, groups, link_out=pool_link, link_in=link, p16=p2)
@@ -233,7 +233,7 @@ class Up(nn.Module):
             self.up = ConvT2x2(in_channels, in_channels // 2)
             self.conv = DoubleConv(in_channels, out_channels)
 
-    def forward(self, x1, x2, cat=None, groups=1, catP=None, p16_out=None):
+    def forward(self, x1, x2, cat=None, groups=1, catP=None, p16_out=None, head_link=None):
         """`cat`: optional concat buffer whose first channels already ARE x2 (UNet.forward lets the encoder write its
         skip outputs there, so torch.cat's copy of the skip tensor, OV:100, never happens); `catP` (pre-split storage): the pre-split concat
         buffer, skip groups already written; `p16_out`: see DoubleConv.forward (the block's output feeds the next Up's slot-operand GEMM)."""
@@ -254,7 +254,7 @@ class Up(nn.Module):
             p16["up_link"] = up_link
             x = Fn.UpConvTCatFn.apply(x1, x2, self.up.weight, self.up.bias, self.up.packed(), None, p16)
             ops.tag_p16(x, catP, (s_skip, s_up, x2.shape[1]) if (s_skip is not None or s_up is not None) else None)
-            return self.conv(x, groups=groups, p16_out=p16_out, up_link=up_link)
+            return self.conv(x, groups=groups, p16_out=p16_out, up_link=up_link, head_link=head_link)
         if isinstance(self.up, ConvT2x2):
             x = Fn.UpConvTCatFn.apply(x1, x2, self.up.weight, self.up.bias, self.up.packed(), None if cat is None else (cat,))
         else:
@@ -299,12 +299,14 @@ class UNet(nn.Module):
                 m.weight.data.normal_(0, 0.01)
                 m.bias.data.zero_()
 
-    def forward(self, x, groups=1):
+    def forward(self, x, groups=1, head_link=None):
+        """head_link (Onet.forward, twin batch): a dict through which the LAST unit hands its pre-activation and coefficients to the head
+        instead of writing its activation (the second returned tensor is then a placeholder: Onet's head is its only reader)."""
         # the 18 num_batches_tracked counters of a pass take their increments in one multi-tensor launch when the pass is through
         with ops.counting_batches():
-            return self._forward(x, groups)
+            return self._forward(x, groups, head_link)
 
-    def _forward(self, x, groups=1):
+    def _forward(self, x, groups=1, head_link=None):
         # ConvTranspose path: the four skip tensors are produced directly inside the first half of their concat
         # buffers (allocated here, before the encoder runs), the decoder fills the second half
         cats = [None] * 4
@@ -399,7 +401,7 @@ class UNet(nn.Module):
         y4 = self.up1(x5, x4, cat=cats[3], groups=g, catP=catsP[3], p16_out=upP[2])
         y3 = self.up2(y4, x3, cat=cats[2], groups=g, catP=catsP[2], p16_out=upP[1])
         y2 = self.up3(y3, x2, cat=cats[1], groups=g, catP=catsP[1], p16_out=upP[0])
-        y1 = self.up4(y2, x1, cat=cats[0], groups=g, catP=catsP[0])
+        y1 = self.up4(y2, x1, cat=cats[0], groups=g, catP=catsP[0], head_link=head_link)
         return x1_out, y1
 
 
@@ -446,8 +448,9 @@ class Onet(nn.Module):
             # reference's order (X first).  Results: identical activations, weight gradients summed in one
             # split-K reduction instead of two plus autograd's add.
             XX = Fn.TwinInputFn.apply(X, float(self.bias))
-            L, H = self.topu(XX, groups=2)
-            Vt, Vd, S, sLt, sLd = Fn.HeadSoftmaxTwinFn.apply(L, H)
+            hl = {} if (ops.HEAD_NORM and self.training) else None     # (the last activation is formed by the head from z: no tensor)
+            L, H = self.topu(XX, groups=2, head_link=hl)
+            Vt, Vd, S, sLt, sLd = Fn.HeadSoftmaxTwinFn.apply(L, H, hl)
             Lt, Ld = Fn.TwinSplitFn.apply(L)
             # compute_loss may work on the channel sums of L -- if it is handed exactly these halves, in this order and
             # unmodified (role and tensor version are checked there)

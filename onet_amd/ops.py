@@ -1910,8 +1910,12 @@ def fill(t, value):
 
 
 # ----------------------------------------------------------------------------- head / loss
-def head_softmax_fwd(Lt, Ht, Ld, Hd, want_sums=False):
-    """-> Vt, Vd, S  (+ sLt, sLd = per-pixel channel sums of Lt / Ld, [B,1,H,W], when want_sums)."""
+HEAD_NORM = _flag("HEAD_NORM", True)      # 0: the last unit's BatchNorm + ReLU pass writes its activation for the head to read
+
+
+def head_softmax_fwd(Lt, Ht, Ld, Hd, want_sums=False, h_norm=None):
+    """-> Vt, Vd, S  (+ sLt, sLd = per-pixel channel sums of Lt / Ld, [B,1,H,W], when want_sums).
+    h_norm = (save_t, save_d): Ht / Hd are the pre-activations of the last unit, normalised + rectified on load."""
     require_gpu(Lt, Ht, Ld, Hd)
     Lt, a = plane(Lt)
     Ht, b = plane(Ht)
@@ -1922,18 +1926,15 @@ def head_softmax_fwd(Lt, Ht, Ld, Hd, want_sums=False):
     Vt = torch.empty((B, 1, H, W), dtype=F32, device=dev)
     Vd = torch.empty((B, 1, H, W), dtype=F32, device=dev)
     S = torch.empty((B, 2, H, W), dtype=F32, device=dev)
-    if want_sums:
-        sLt = torch.empty((B, 1, H, W), dtype=F32, device=dev)
-        sLd = torch.empty((B, 1, H, W), dtype=F32, device=dev)
-        _lib.call("onet_head_softmax_sums_fwd", _p(Lt), a, _p(Ht), b, _p(Ld), c, _p(Hd), d, _p(Vt), _p(Vd), _p(S),
-                  _p(sLt), _p(sLd), B, C, H * W, _stream(), nbytes=16 * Lt.numel())
-        return Vt, Vd, S, sLt, sLd
-    _lib.call("onet_head_softmax_fwd", _p(Lt), a, _p(Ht), b, _p(Ld), c, _p(Hd), d, _p(Vt), _p(Vd), _p(S), B, C,
-              H * W, _stream())
-    return Vt, Vd, S
+    sLt = torch.empty((B, 1, H, W), dtype=F32, device=dev) if want_sums else None
+    sLd = torch.empty((B, 1, H, W), dtype=F32, device=dev) if want_sums else None
+    nt, nd = h_norm if h_norm is not None else (None, None)
+    _lib.call("onet_head_softmax_fwd", _p(Lt), a, _p(Ht), b, _p(Ld), c, _p(Hd), d, _p(Vt), _p(Vd), _p(S), _p(sLt), _p(sLd), _p(nt), _p(nd),
+              B, C, H * W, _stream(), nbytes=16 * Lt.numel())
+    return (Vt, Vd, S, sLt, sLd) if want_sums else (Vt, Vd, S)
 
 
-def head_softmax_bwd(dVt, dVd, dS, S, Lt, Ht, Ld, Hd, twin=False, gsums=(None, None)):
+def head_softmax_bwd(dVt, dVd, dS, S, Lt, Ht, Ld, Hd, twin=False, gsums=(None, None), h_norm=None):
     """-> dLt, dHt, dLd, dHd; twin=True: -> (dL, dH) of shape [2B, C, H, W], the top and down halves adjacent.
     gsums = (d loss / d sLt, d loss / d sLd), [B,1,H,W] each or None: added to every channel of dLt / dLd."""
     Lt, a = plane(Lt)
@@ -1953,8 +1954,9 @@ def head_softmax_bwd(dVt, dVd, dS, S, Lt, Ht, Ld, Hd, twin=False, gsums=(None, N
         outs = [torch.empty((B, C, H, W), dtype=F32, device=dev) for _ in range(4)]
     gst = None if gsums[0] is None else gsums[0].contiguous()
     gsd = None if gsums[1] is None else gsums[1].contiguous()
-    _lib.call("onet_head_softmax_sums_bwd", _p(dVt), _p(dVd), _p(dS), _p(gst), _p(gsd), _p(S), _p(Lt), a, _p(Ht), b,
-              _p(Ld), c, _p(Hd), d, _p(outs[0]), _p(outs[1]), _p(outs[2]), _p(outs[3]), B, C, H * W, _stream(),
+    nt, nd = h_norm if h_norm is not None else (None, None)
+    _lib.call("onet_head_softmax_bwd", _p(dVt), _p(dVd), _p(dS), _p(gst), _p(gsd), _p(S), _p(Lt), a, _p(Ht), b,
+              _p(Ld), c, _p(Hd), d, _p(outs[0]), _p(outs[1]), _p(outs[2]), _p(outs[3]), _p(nt), _p(nd), B, C, H * W, _stream(),
               nbytes=32 * Lt.numel())
     return (dL, dH) if twin else outs
 

@@ -394,6 +394,41 @@ def test_flat_adam_skipped_parameters_follow_torch_adam(dev):
     assert oa._steps is not None and sorted(set(oa._steps)) == [3, 5]
 
 
+@pytest.mark.parametrize("shape", [(8, 1, 128, 128), (4, 1, 256, 256)])
+def test_head_normalises_the_last_unit_on_load_bit_identically(dev, shape, monkeypatch):
+    """Round 5 (ops.HEAD_NORM): the network's last Conv-BatchNorm-ReLU unit writes no activation -- the head kernels form relu(bn(z))
+    from its pre-activation and coefficients while they load, in forward and in backward.  Same arithmetic as the BatchNorm + ReLU
+    pass: loss, every output and every gradient bit-identical to the step that materialises the activation, and that pass is gone.
+    (Shapes whose last block runs the pre-split kernels: the only path that defers.)"""
+    from onet_amd import ops
+    B, C, H, W = shape
+    X = orc.det_input(B, C, H, W, seed=41).to(dev)
+    res, applies = {}, {}
+    for on in (False, True):
+        monkeypatch.setattr(ops, "HEAD_NORM", on)
+        n = {"apply": 0}
+        real = ops.bn_relu_apply
+
+        def spy(*a, _r=real, **k):
+            n["apply"] += 1
+            return _r(*a, **k)
+
+        monkeypatch.setattr(ops, "bn_relu_apply", spy)
+        m = _model(C, True, dev)
+        (Lt, Vt, Ld, Vd, S), loss = _step(m, X)
+        monkeypatch.setattr(ops, "bn_relu_apply", real)
+        res[on] = (loss.detach().clone(), Vt.detach().clone(), S.detach().clone(), [p.grad.detach().clone() for p in m.parameters()],
+                   [b.detach().clone() for b in m.buffers()])
+        applies[on] = n["apply"]
+    assert applies[True] == applies[False] - 1, applies
+    a, b = res[False], res[True]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for ga, gb in zip(a[3], b[3]):
+        assert torch.equal(ga, gb)
+    for ba, bb in zip(a[4], b[4]):
+        assert torch.equal(ba, bb)
+
+
 def test_second_forward_before_backward_keeps_the_first_one_intact(dev):
     """Two forwards, then the FIRST one's backward (gradient accumulation, an eval pass in between, another model on the device): the
     magnitude slots a forward hands out are read again by its backward (the weight gradients undo the activations' guard scales), so a
