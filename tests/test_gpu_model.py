@@ -971,16 +971,17 @@ def test_training_behaviour_vs_reference_fixture(dev, mode):
     assert diff_px <= (0.03 if mode == "bf16" else 0.01) * Y.numel()
 
 
-@pytest.mark.parametrize("B,H,algo", [(4, 128, "auto"), (4, 256, "split"), (2, 64, "split")])
-def test_presplit_storage_step_vs_fp32_storage(dev, B, H, algo, monkeypatch):
+@pytest.mark.parametrize("B,H,W,algo", [(4, 128, 128, "auto"), (4, 256, 256, "split"), (2, 64, 64, "split"), (4, 192, 320, "auto")])
+def test_presplit_storage_step_vs_fp32_storage(dev, B, H, W, algo, monkeypatch):
     """Round 4: pre-split storage (Settings.presplit, the default) against the same step with every operand kept in fp32 and split by
     the consuming kernels: the FORWARD (every output, the loss, the BatchNorm buffers) agrees to fp32 summation rounding -- the
     producers split exactly the values the fp32 passes write, the products are the same exact fp16 x fp16 products -- and every parameter
     gradient agrees to rounding (fp16 parts of power-of-two-scaled gradients against bf16 parts; another summation order in the
-    weight gradient)."""
+    weight gradient).  (192 x 320: levels 320 / 160 / 80 / 40 / 20 pixels wide -- pre-split and fp32 levels side by side, a
+    ConvTranspose2d whose forward reads slots while its backward, the map not being a power of two wide, reads the fp32 tensor kept for it.)"""
     from onet_amd import ops
     monkeypatch.setattr(ops, "CONV_ALGO", algo)
-    X = orc.det_input(B, 1, H, H, seed=23).to(dev)
+    X = orc.det_input(B, 1, H, W, seed=23).to(dev)
     res = {}
     for name, st in (("fp32", ops.Settings(presplit=False, bn_on_load=False)), ("presplit", ops.Settings(presplit=True))):
         import Onet_vanilla_20240606 as ov
@@ -1001,7 +1002,7 @@ def test_presplit_storage_step_vs_fp32_storage(dev, B, H, algo, monkeypatch):
     for p, q in zip(a[5], b[5]):
         assert float((p.double() - q.double()).abs().max()) <= 1e-6 * max(1.0, float(p.double().abs().max()))
     worst = max((float((a[4][k] - b[4][k]).norm() / a[4][k].norm()), k) for k in a[4])
-    print(f"pre-split vs fp32 storage [{B}x{H}x{H}, {algo}]: forward to summation rounding; worst relative gradient difference {worst[0]:.2e} ({worst[1]})")
+    print(f"pre-split vs fp32 storage [{B}x{H}x{W}, {algo}]: forward to summation rounding; worst relative gradient difference {worst[0]:.2e} ({worst[1]})")
     # (with a bit-identical forward the two runs took the same ReLU / pooling decisions and the gradients agreed to 1e-4; a forward that
     # differs in the last bits flips a handful of them, and two correct evaluations then differ by 6e-3 .. 9e-3 on every parameter of
     # this network -- test_presplit_range_guard_large_gamma's note.  The element-wise statement under fixed decisions is
